@@ -1,0 +1,86 @@
+"""ctypes binding of libcotnet_hip.so (the C ABI in include/cotnet_amd.h).
+
+This is the only place the shared library is opened.  There is NO fallback: if the library is missing
+or a call fails, a RuntimeError is raised (the product path must fail loudly, never silently compute
+on the CPU).  The reference's equivalent is cupy_layers/utils.py:14-18 (`load_kernel`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcotnet_hip.so")
+
+COT_F32, COT_F64, COT_BF16, COT_F16 = 0, 1, 2, 3
+COT_NCHW, COT_NHWC = 0, 1
+
+_lib = None
+
+
+class AggGeom(ctypes.Structure):
+    """mirror of `cot_agg_geom`"""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "N", "C", "H", "W", "heads", "wC", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw")]
+
+
+# every symbol include/cotnet_amd.h declares: (restype, argtypes)
+_P, _I = ctypes.c_void_p, ctypes.c_int
+_G = ctypes.POINTER(AggGeom)
+SYMBOLS = {
+    "cot_abi_version": (_I, []),
+    "cot_last_error": (ctypes.c_char_p, []),
+    "cot_last_kernel": (ctypes.c_char_p, []),
+    "cot_status_string": (ctypes.c_char_p, [_I]),
+    "cot_agg_out_size": (_I, [_I] * 5),
+    "cot_agg_forward": (_I, [_P, _P, _P, _G, _I, _I, _P]),
+    "cot_agg_backward_input": (_I, [_P, _P, _P, _G, _I, _I, _P]),
+    "cot_agg_backward_weight": (_I, [_P, _P, _P, _G, _I, _I, _P]),
+    "cot_agg_backward": (_I, [_P, _P, _P, _P, _P, _G, _I, _I, _P]),
+    "cot_aggmix_forward": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),
+    "cot_aggmix_backward_input": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _I, _P]),
+    "cot_aggmix_backward_weight": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),
+}
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 (used by __graft_entry__.build and by developers)."""
+    import subprocess
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). cotnet_amd has no CPU or eager fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if L.cot_abi_version() != 1:
+            raise RuntimeError(f"libcotnet_hip.so ABI version {L.cot_abi_version()} != 1")
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        L = lib()
+        raise RuntimeError(f"{what} failed: {L.cot_status_string(status).decode()} -- "
+                           f"{L.cot_last_error().decode()}")
+
+
+def last_kernel():
+    return lib().cot_last_kernel().decode()
+
+
+def dtype_code(torch_dtype):
+    import torch
+    try:
+        return {torch.float32: COT_F32, torch.float64: COT_F64, torch.bfloat16: COT_BF16,
+                torch.float16: COT_F16}[torch_dtype]
+    except KeyError:
+        raise TypeError(f"cotnet_amd: unsupported dtype {torch_dtype} (float32/float64/bfloat16/float16)")

@@ -1,0 +1,165 @@
+"""LocalConvolution / aggregation_zeropad on MI355X -- drop-in for cupy_layers/aggregation_zeropad.py.
+
+Same public surface as the reference:
+    aggregation_zeropad(input, weight, kernel_size=3, stride=1, padding=0, dilation=1)   (ref :188-197)
+    AggregationZeropad (autograd.Function)                                              (ref :112-186)
+    LocalConvolution(in_channels, out_channels, kernel_size, stride=1, padding=0,
+                     dilation=1, pad_mode=0).forward(input, weight)                      (ref :199-236)
+
+Differences, all deliberate (DESIGN.md "boundary"):
+  * device code is the ahead-of-time compiled HIP library behind include/cotnet_amd.h, called with raw
+    device pointers + the current HIP stream exactly like the reference calls its CuPy function
+    (ref :140-143); dimensions are run-time arguments, so there is no per-shape JIT;
+  * bf16/fp16 storage (fp32 accumulate) is accepted besides the reference's float/double (utils.py:8-12);
+  * channels_last (NHWC) tensors are consumed in place instead of being copied;
+  * non-contiguous inputs are made contiguous with .contiguous() (the reference's detach().clone()
+    at :125-128 keeps strides in current torch and would mis-index);
+  * the backward pass produces both gradients in one fused kernel launch when both are needed.
+CPU tensors take the reference's route (:192-196): copy to the GPU, run, copy back -- there is no CPU
+implementation in the product; without a GPU this raises.
+"""
+import ctypes
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+from torch.nn.modules.utils import _pair
+
+from . import _lib
+
+
+def _out_hw(H, W, k, s, p, d):
+    # ref :120-121
+    Ho = int((H + 2 * p[0] - (d[0] * (k[0] - 1) + 1)) / s[0] + 1)
+    Wo = int((W + 2 * p[1] - (d[1] * (k[1] - 1) + 1)) / s[1] + 1)
+    return Ho, Wo
+
+
+def _nhwc_weight_strides(shape):
+    """strides of w[N,heads,wC,taps,Ho,Wo] when memory order is [N,Ho,Wo,heads,wC,taps]"""
+    N, heads, wC, taps, Ho, Wo = shape
+    return (Ho * Wo * heads * wC * taps, wC * taps, taps, 1, Wo * heads * wC * taps, heads * wC * taps)
+
+
+def _is_nhwc_weight(w):
+    shape = tuple(w.shape)
+    want = _nhwc_weight_strides(shape)
+    return all(sz == 1 or st == ws for sz, st, ws in zip(shape, w.stride(), want))
+
+
+def _empty_nhwc_weight(shape, like):
+    N, heads, wC, taps, Ho, Wo = shape
+    return torch.empty((N, Ho, Wo, heads, wC, taps), dtype=like.dtype, device=like.device).permute(0, 3, 4, 5, 1, 2)
+
+
+def _pick_layout(input, weight):
+    """-> (layout, input, weight) with both tensors dense in that layout."""
+    if input.is_contiguous() and weight.is_contiguous():
+        return _lib.COT_NCHW, input, weight
+    if input.dim() == 4 and input.is_contiguous(memory_format=torch.channels_last) and _is_nhwc_weight(weight):
+        return _lib.COT_NHWC, input, weight
+    return _lib.COT_NCHW, input.contiguous(), weight.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _aligned(t):
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.preserve_format)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class AggregationZeropad(Function):
+    @staticmethod
+    def forward(ctx, input, weight, kernel_size, stride, padding, dilation):
+        kernel_size, stride, padding, dilation = _pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation)
+        ctx.kernel_size, ctx.stride, ctx.padding, ctx.dilation = kernel_size, stride, padding, dilation
+        assert input.dim() == 4 and input.is_cuda and weight.is_cuda  # ref :117
+        assert weight.dim() == 6 and input.dtype == weight.dtype
+        batch_size, input_channels, input_height, input_width = input.size()
+        _, weight_heads, weight_channels, weight_kernels, weight_height, weight_width = weight.size()
+        output_height, output_width = _out_hw(input_height, input_width, kernel_size, stride, padding, dilation)
+        assert output_height * output_width == weight_height * weight_width  # ref :122
+        assert weight_kernels == kernel_size[0] * kernel_size[1]
+        layout, input, weight = _pick_layout(input.detach(), weight.detach())
+        input, weight = _aligned(input), _aligned(weight)
+        out_shape = (batch_size, weight_heads * input_channels, output_height, output_width)
+        if layout == _lib.COT_NHWC:
+            output = torch.empty(out_shape, dtype=input.dtype, device=input.device,
+                                 memory_format=torch.channels_last)
+        else:
+            output = torch.empty(out_shape, dtype=input.dtype, device=input.device)
+        geom = _lib.AggGeom(batch_size, input_channels, input_height, input_width, weight_heads, weight_channels,
+                            kernel_size[0], kernel_size[1], stride[0], stride[1], padding[0], padding[1],
+                            dilation[0], dilation[1])
+        with torch.cuda.device_of(input):
+            rc = _lib.lib().cot_agg_forward(_ptr(input), _ptr(weight), _ptr(output), ctypes.byref(geom),
+                                            _lib.dtype_code(input.dtype), layout, _stream())
+        _lib.check(rc, "cot_agg_forward")
+        ctx.geom, ctx.layout = geom, layout
+        ctx.save_for_backward(input, weight)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        assert grad_output.is_cuda
+        layout = ctx.layout
+        if layout == _lib.COT_NHWC:
+            grad_output = grad_output.contiguous(memory_format=torch.channels_last)
+        else:
+            grad_output = grad_output.contiguous()
+        grad_output = _aligned(grad_output)
+        grad_input = grad_weight = None
+        if ctx.needs_input_grad[0]:
+            grad_input = torch.empty_like(input)
+        if ctx.needs_input_grad[1]:
+            grad_weight = (_empty_nhwc_weight(weight.shape, weight) if layout == _lib.COT_NHWC
+                           else torch.empty_like(weight))
+        if grad_input is not None or grad_weight is not None:
+            with torch.cuda.device_of(input):
+                rc = _lib.lib().cot_agg_backward(_ptr(grad_output), _ptr(input), _ptr(weight), _ptr(grad_input),
+                                                 _ptr(grad_weight), ctypes.byref(ctx.geom),
+                                                 _lib.dtype_code(input.dtype), layout, _stream())
+            _lib.check(rc, "cot_agg_backward")
+        return grad_input, grad_weight, None, None, None, None
+
+
+def aggregation_zeropad(input, weight, kernel_size=3, stride=1, padding=0, dilation=1):
+    assert input.shape[0] == weight.shape[0] and (input.shape[1] % weight.shape[2] == 0)  # ref :189
+    if input.is_cuda:
+        out = AggregationZeropad.apply(input, weight, kernel_size, stride, padding, dilation)
+    else:
+        # the reference's CPU route (:192-196): bounce through the GPU.  No CPU compute in the product.
+        out = AggregationZeropad.apply(input.cuda(), weight.cuda(), kernel_size, stride, padding, dilation)
+        torch.cuda.synchronize()
+        out = out.cpu()
+    return out
+
+
+class LocalConvolution(torch.nn.Module):
+    """Parameter-free module; attribute names are read by the reference's FLOP counter
+    (utils/flops_counter.py:500-501) and are kept identical."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, stride: int = 1, padding: int = 0,
+                 dilation: int = 1, pad_mode: int = 0):
+        super(LocalConvolution, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.pad_mode = pad_mode  # stored, ignored -- as in the reference (:220, :228)
+
+    def forward(self, input: Tensor, weight: Tensor):
+        return aggregation_zeropad(input, weight, kernel_size=self.kernel_size, stride=self.stride,
+                                   padding=self.padding, dilation=self.dilation)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, dilation={self.dilation}")

@@ -1,0 +1,217 @@
+// cot_abi.hip -- extern "C" entry points of libcotnet_hip.so (declared in include/cotnet_amd.h):
+// argument validation, dtype/layout dispatch, error strings.  No torch types anywhere.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "cot_common.h"
+
+namespace cot {
+
+static thread_local char g_err[512] = "";
+static thread_local const char* g_kernel = "";
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(COT_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return COT_OK;
+}
+
+// implemented in agg_nchw.hip / agg_nhwc.hip / agg_mix.hip
+template <typename T>
+int agg_forward_nchw(const T*, const T*, T*, const cot_agg_geom&, int, int, hipStream_t, const char*);
+template <typename T>
+int agg_backward_nchw(const T*, const T*, const T*, T*, T*, const cot_agg_geom&, int, int, hipStream_t);
+template <typename T> int agg_forward_nhwc(const T*, const T*, T*, const cot_agg_geom&, int, int, int, hipStream_t);
+template <typename T>
+int agg_backward_nhwc(const T*, const T*, const T*, T*, T*, const cot_agg_geom&, int, int, int, hipStream_t);
+template <typename T>
+int aggmix_forward(const T*, const T*, const T*, T*, const cot_agg_geom&, int, int, int, int, hipStream_t);
+template <typename T>
+int aggmix_backward_input(const T*, const T*, const T*, T*, const cot_agg_geom&, int, int, int, int, int,
+                          hipStream_t);
+template <typename T>
+int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int, int, int, int, hipStream_t);
+const char* last_kernel_nchw();
+const char* last_kernel_nhwc();
+
+static int out_size(int in, int k, int s, int p, int d) {
+    // python: int((in + 2p - (d(k-1)+1)) / s + 1) -- float division, truncation toward zero
+    double v = (double)(in + 2 * p - (d * (k - 1) + 1)) / (double)s + 1.0;
+    return (int)v;
+}
+
+static int validate(const cot_agg_geom* g, int* Ho, int* Wo) {
+    if (!g) return set_error(COT_ERR_INVALID_ARG, "geometry pointer is NULL");
+    if (g->N <= 0 || g->C <= 0 || g->H <= 0 || g->W <= 0 || g->heads <= 0 || g->wC <= 0)
+        return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d C=%d H=%d W=%d heads=%d wC=%d", g->N, g->C,
+                         g->H, g->W, g->heads, g->wC);
+    if (g->C % g->wC != 0)  // aggregation_zeropad.py:189
+        return set_error(COT_ERR_INVALID_ARG, "input channels %d not divisible by weight channels %d", g->C, g->wC);
+    if (g->kh <= 0 || g->kw <= 0 || g->sh <= 0 || g->sw <= 0 || g->dh <= 0 || g->dw <= 0 || g->ph < 0 || g->pw < 0)
+        return set_error(COT_ERR_INVALID_ARG, "bad kernel/stride/dilation/padding");
+    *Ho = out_size(g->H, g->kh, g->sh, g->ph, g->dh);
+    *Wo = out_size(g->W, g->kw, g->sw, g->pw, g->dw);
+    if (*Ho <= 0 || *Wo <= 0) return set_error(COT_ERR_INVALID_ARG, "empty output %dx%d", *Ho, *Wo);
+    return COT_OK;
+}
+
+// largest power-of-two element count (<= 8) such that every pointer is aligned to that many elements
+static int align_elems(size_t esize, std::initializer_list<const void*> ptrs) {
+    int best = 8;
+    for (const void* p : ptrs) {
+        if (!p) continue;
+        uintptr_t a = (uintptr_t)p;
+        int v = 8;
+        while (v > 1 && (a % (v * esize)) != 0) v >>= 1;
+        if (v < best) best = v;
+    }
+    return best;
+}
+
+template <typename T>
+static int fwd_t(const void* x, const void* w, void* out, const cot_agg_geom& g, int Ho, int Wo, int layout,
+                 hipStream_t s) {
+    const int av = align_elems(sizeof(T), {x, w, out});
+    if (layout == COT_NCHW) {
+        // entry points require 16-byte aligned base pointers, so every P-wide row vector is aligned
+        int rc = agg_forward_nchw<T>((const T*)x, (const T*)w, (T*)out, g, Ho, Wo, s, "");
+        g_kernel = last_kernel_nchw();
+        return rc;
+    }
+    int rc = agg_forward_nhwc<T>((const T*)x, (const T*)w, (T*)out, g, Ho, Wo, av, s);
+    g_kernel = last_kernel_nhwc();
+    return rc;
+}
+
+template <typename T>
+static int bwd_t(const void* gout, const void* x, const void* w, void* gx, void* gw, const cot_agg_geom& g, int Ho,
+                 int Wo, int layout, hipStream_t s) {
+    const int av = align_elems(sizeof(T), {gout, x, w, gx, gw});
+    int rc;
+    if (layout == COT_NCHW) {
+        rc = agg_backward_nchw<T>((const T*)gout, (const T*)x, (const T*)w, (T*)gx, (T*)gw, g, Ho, Wo, s);
+        g_kernel = last_kernel_nchw();
+    } else {
+        rc = agg_backward_nhwc<T>((const T*)gout, (const T*)x, (const T*)w, (T*)gx, (T*)gw, g, Ho, Wo, av, s);
+        g_kernel = last_kernel_nhwc();
+    }
+    return rc;
+}
+
+}  // namespace cot
+
+using namespace cot;
+
+#define DISPATCH_DTYPE(dtype, CALL)                                                   \
+    switch (dtype) {                                                                  \
+        case COT_F32: { typedef float T; return CALL; }                               \
+        case COT_F64: { typedef double T; return CALL; }                              \
+        case COT_BF16: { typedef bf16_t T; return CALL; }                             \
+        case COT_F16: { typedef f16_t T; return CALL; }                               \
+        default: return set_error(COT_ERR_UNSUPPORTED, "unknown dtype %d", dtype);    \
+    }
+
+static int check_align16(std::initializer_list<const void*> ptrs) {
+    for (const void* p : ptrs)
+        if (p && ((uintptr_t)p % 16) != 0)
+            return set_error(COT_ERR_INVALID_ARG, "device pointer %p is not 16-byte aligned", p);
+    return COT_OK;
+}
+
+extern "C" {
+
+int cot_abi_version(void) { return COTNET_AMD_ABI_VERSION; }
+const char* cot_last_error(void) { return g_err; }
+const char* cot_last_kernel(void) { return g_kernel; }
+const char* cot_status_string(int status) {
+    switch (status) {
+        case COT_OK: return "ok";
+        case COT_ERR_INVALID_ARG: return "invalid argument";
+        case COT_ERR_UNSUPPORTED: return "unsupported dtype/layout";
+        case COT_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown status";
+    }
+}
+
+int cot_agg_out_size(int in, int k, int s, int p, int d) { return out_size(in, k, s, p, d); }
+
+int cot_agg_forward(const void* x, const void* w, void* out, const cot_agg_geom* g, int dtype, int layout,
+                    void* stream) {
+    int Ho, Wo, rc = validate(g, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !w || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (layout != COT_NCHW && layout != COT_NHWC) return set_error(COT_ERR_UNSUPPORTED, "unknown layout %d", layout);
+    if ((rc = check_align16({x, w, out}))) return rc;
+    DISPATCH_DTYPE(dtype, (fwd_t<T>(x, w, out, *g, Ho, Wo, layout, (hipStream_t)stream)));
+}
+
+int cot_agg_backward(const void* gout, const void* x, const void* w, void* gx, void* gw, const cot_agg_geom* g,
+                     int dtype, int layout, void* stream) {
+    int Ho, Wo, rc = validate(g, &Ho, &Wo);
+    if (rc) return rc;
+    if (!gout) return set_error(COT_ERR_INVALID_ARG, "gout is NULL");
+    if (!gx && !gw) return set_error(COT_ERR_INVALID_ARG, "both gx and gw are NULL: nothing to compute");
+    if (gx && !w) return set_error(COT_ERR_INVALID_ARG, "gx requested but w is NULL");
+    if (gw && !x) return set_error(COT_ERR_INVALID_ARG, "gw requested but x is NULL");
+    if (layout != COT_NCHW && layout != COT_NHWC) return set_error(COT_ERR_UNSUPPORTED, "unknown layout %d", layout);
+    if ((rc = check_align16({gout, x, w, gx, gw}))) return rc;
+    DISPATCH_DTYPE(dtype, (bwd_t<T>(gout, x, w, gx, gw, *g, Ho, Wo, layout, (hipStream_t)stream)));
+}
+
+int cot_agg_backward_input(const void* gout, const void* w, void* gx, const cot_agg_geom* g, int dtype, int layout,
+                           void* stream) {
+    if (!gx) return set_error(COT_ERR_INVALID_ARG, "gx is NULL");
+    return cot_agg_backward(gout, NULL, w, gx, NULL, g, dtype, layout, stream);
+}
+
+int cot_agg_backward_weight(const void* gout, const void* x, void* gw, const cot_agg_geom* g, int dtype, int layout,
+                            void* stream) {
+    if (!gw) return set_error(COT_ERR_INVALID_ARG, "gw is NULL");
+    return cot_agg_backward(gout, x, NULL, NULL, gw, g, dtype, layout, stream);
+}
+
+static int validate_mix(const cot_agg_geom* g, int p2h, int p2w, int* Ho, int* Wo) {
+    int rc = validate(g, Ho, Wo);
+    if (rc) return rc;
+    if (g->kh != 3 || g->kw != 3)  // LocalConvolutionMix asserts kernel sizes 3 and 5 (mix.py:328-329)
+        return set_error(COT_ERR_INVALID_ARG, "mix: first kernel must be 3x3, got %dx%d", g->kh, g->kw);
+    if (p2h < 0 || p2w < 0) return set_error(COT_ERR_INVALID_ARG, "mix: negative padding2");
+    return COT_OK;
+}
+
+int cot_aggmix_forward(const void* x, const void* w1, const void* w2, void* out, const cot_agg_geom* g, int p2h,
+                       int p2w, int dtype, void* stream) {
+    int Ho, Wo, rc = validate_mix(g, p2h, p2w, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !w1 || !w2 || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    DISPATCH_DTYPE(dtype, (aggmix_forward<T>((const T*)x, (const T*)w1, (const T*)w2, (T*)out, *g, p2h, p2w, Ho, Wo,
+                                             (hipStream_t)stream)));
+}
+
+int cot_aggmix_backward_input(const void* gout, const void* w1, const void* w2, void* gx, const cot_agg_geom* g,
+                              int p2h, int p2w, int all_heads, int dtype, void* stream) {
+    int Ho, Wo, rc = validate_mix(g, p2h, p2w, &Ho, &Wo);
+    if (rc) return rc;
+    if (!gout || !w1 || !w2 || !gx) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    DISPATCH_DTYPE(dtype, (aggmix_backward_input<T>((const T*)gout, (const T*)w1, (const T*)w2, (T*)gx, *g, p2h, p2w,
+                                                    all_heads, Ho, Wo, (hipStream_t)stream)));
+}
+
+int cot_aggmix_backward_weight(const void* gout, const void* x, void* gw1, void* gw2, const cot_agg_geom* g, int p2h,
+                               int p2w, int dtype, void* stream) {
+    int Ho, Wo, rc = validate_mix(g, p2h, p2w, &Ho, &Wo);
+    if (rc) return rc;
+    if (!gout || !x || !gw1 || !gw2) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    DISPATCH_DTYPE(dtype, (aggmix_backward_weight<T>((const T*)gout, (const T*)x, (T*)gw1, (T*)gw2, *g, p2h, p2w, Ho,
+                                                     Wo, (hipStream_t)stream)));
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// cot_common.h -- shared device helpers for the cotnet_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cotnet_amd.h"
+
+namespace cot {
+
+typedef __bf16 bf16_t;   // native bf16: conversions lower to v_cvt_pk_bf16_f32 on gfx950 (RNE)
+typedef _Float16 f16_t;
+
+// accumulate type: fp32 for fp32/bf16/fp16 storage, fp64 for fp64 (the reference accumulates in the
+// storage type, cupy_layers/aggregation_zeropad.py:31; fp32 accumulation of bf16 data is the documented
+// extension)
+template <typename T> struct AccOf { typedef float type; };
+template <> struct AccOf<double> { typedef double type; };
+
+template <typename T> __device__ __forceinline__ typename AccOf<T>::type ld(const T* p) {
+    return (typename AccOf<T>::type)(*p);
+}
+template <typename T, typename A> __device__ __forceinline__ void st(T* p, A v) { *p = (T)v; }
+
+// POD vector of V elements with natural (V*sizeof(T)) alignment so the compiler emits one wide access
+template <typename T, int V> struct alignas(sizeof(T) * V) Vec { T v[V]; };
+
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> ldv(const T* p) {
+    return *reinterpret_cast<const Vec<T, V>*>(p);
+}
+template <typename T, int V> __device__ __forceinline__ void stv(T* p, const Vec<T, V>& v) {
+    *reinterpret_cast<Vec<T, V>*>(p) = v;
+}
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace cot
+
+// host-side error plumbing (thread-local message, int status codes from cotnet_amd.h)
+namespace cot {
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+}  // namespace cot

@@ -1,0 +1,111 @@
+/*
+ * cotnet_amd.h -- C ABI of libcotnet_hip.so, the MI355X (gfx950) drop-in for the CoT-block hot path
+ * of JDAI-CV/CoTNet.
+ *
+ * What it replaces.  The reference reaches its device code through CuPy:
+ *     kernel = cupy.cuda.compile_with_cache(src).get_function(name)      cupy_layers/utils.py:14-18
+ *     kernel(block=(1024,1,1), grid=(G,1,1), args=[raw device ptrs],
+ *            stream=Stream(ptr=torch.cuda.current_stream().cuda_stream)) cupy_layers/aggregation_zeropad.py:140-143
+ * i.e. "raw device pointers + a stream handle", with every dimension baked into the JIT-compiled source.
+ * This header is that same boundary, ahead-of-time compiled, with the dimensions as run-time arguments:
+ * plain pointers, ints and an opaque hipStream_t -- no torch types.  A reference maintainer binds it
+ * with ctypes (INTEGRATION.md shows the stub that replaces load_kernel/f(...) in AggregationZeropad).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) owned by the caller; kernels write EVERY element of their
+ *     outputs (the reference allocates outputs uninitialised, aggregation_zeropad.py:123,:169,:178);
+ *   - calls are asynchronous on `stream` (a hipStream_t cast to void*; NULL = the null stream),
+ *     re-entrant, and keep no global mutable state besides a thread-local last-error string;
+ *   - return value: COT_OK (0) or a negative cot_status; cot_last_error() describes the failure.
+ *     The reference reports errors through Python asserts (aggregation_zeropad.py:117,:122,:189).
+ */
+#ifndef COTNET_AMD_H
+#define COTNET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COTNET_AMD_ABI_VERSION 1
+
+typedef enum {
+    COT_OK = 0,
+    COT_ERR_INVALID_ARG = -1,   /* bad geometry / null pointer / unsupported combination */
+    COT_ERR_UNSUPPORTED = -2,   /* dtype or layout not implemented for this entry point */
+    COT_ERR_LAUNCH = -3         /* hipGetLastError() != hipSuccess after launch */
+} cot_status;
+
+typedef enum {
+    COT_F32 = 0,   /* 'float'  in the reference (cupy_layers/utils.py:9-10) */
+    COT_F64 = 1,   /* 'double' in the reference (cupy_layers/utils.py:11-12) */
+    COT_BF16 = 2,  /* extension: bf16 storage, fp32 accumulation */
+    COT_F16 = 3    /* extension: fp16 storage, fp32 accumulation */
+} cot_dtype;
+
+typedef enum {
+    COT_NCHW = 0,  /* reference layout: x[N,C,H,W], w[N,heads,wC,kh*kw,Ho,Wo], out[N,heads*C,Ho,Wo] */
+    COT_NHWC = 1   /* channels-last:    x[N,H,W,C], w[N,Ho,Wo,heads,wC,kh*kw], out[N,Ho,Wo,heads*C]
+                      (what torch's channels_last gives for the same logical shapes / the 6-D view) */
+} cot_layout;
+
+/* Geometry of one aggregation_zeropad call; mirrors the ${...} substitutions of
+ * cupy_layers/aggregation_zeropad.py:131-139.  Ho/Wo are derived with cot_agg_out_size. */
+typedef struct {
+    int32_t N, C, H, W;          /* input  [N, C, H, W]                                        */
+    int32_t heads, wC;           /* weight [N, heads, wC, kh*kw, Ho, Wo];  C % wC == 0          */
+    int32_t kh, kw;              /* kernel_size                                                */
+    int32_t sh, sw;              /* stride                                                     */
+    int32_t ph, pw;              /* zero padding                                               */
+    int32_t dh, dw;              /* dilation                                                   */
+} cot_agg_geom;
+
+/* int((in + 2p - (d(k-1)+1)) / s + 1), aggregation_zeropad.py:120-121 */
+int cot_agg_out_size(int in, int k, int s, int p, int d);
+
+/* out[n,head,c,ho,wo] = sum_{kh,kw} w[n,head,c%wC,kh*KW+kw,ho,wo] * x[n,c,ho*s-p+kh*d, wo*s-p+kw*d]
+ * replaces aggregation_zeropad_forward_kernel (aggregation_zeropad.py:20-46). */
+int cot_agg_forward(const void* x, const void* w, void* out,
+                    const cot_agg_geom* g, int dtype, int layout, void* stream);
+
+/* gx[n,c,h,w] = sum_head sum_taps w[...]*gout[...] -- replaces
+ * aggregation_zeropad_input_backward_kernel (aggregation_zeropad.py:48-79). */
+int cot_agg_backward_input(const void* gout, const void* w, void* gx,
+                           const cot_agg_geom* g, int dtype, int layout, void* stream);
+
+/* gw[n,head,wc,tap,ho,wo] = sum_{cc = wc (mod wC)} x[n,cc,h_in,w_in]*gout[n,head,cc,ho,wo], 0 on padded taps
+ * -- replaces aggregation_zeropad_weight_backward_kernel (aggregation_zeropad.py:81-110). */
+int cot_agg_backward_weight(const void* gout, const void* x, void* gw,
+                            const cot_agg_geom* g, int dtype, int layout, void* stream);
+
+/* Both gradients from ONE pass over gout/x/w (21 B/elem instead of 25 B/elem in fp32).
+ * Either of gx / gw may be NULL (then only the other is produced).  Same results as the two calls above. */
+int cot_agg_backward(const void* gout, const void* x, const void* w, void* gx, void* gw,
+                     const cot_agg_geom* g, int dtype, int layout, void* stream);
+
+/* ---- aggregation_zeropad_mix: 3x3 (w1) and 5x5 (w2) aggregation of the same x; NCHW only.
+ * out[N, 2*heads*C, Ho, Wo] ordered [kernel_idx][head][c] (aggregation_zeropad_mix.py:20-74).
+ * geometry: kh/kw/ph/pw of `g` describe the 3x3 set (kh=kw=3, pad1); p2h/p2w pad the 5x5 set.
+ * backward_input reproduces the reference (only head 0 contributes, mix.py:87-88) unless
+ * all_heads != 0. */
+int cot_aggmix_forward(const void* x, const void* w1, const void* w2, void* out,
+                       const cot_agg_geom* g, int p2h, int p2w, int dtype, void* stream);
+int cot_aggmix_backward_input(const void* gout, const void* w1, const void* w2, void* gx,
+                              const cot_agg_geom* g, int p2h, int p2w, int all_heads, int dtype, void* stream);
+int cot_aggmix_backward_weight(const void* gout, const void* x, void* gw1, void* gw2,
+                               const cot_agg_geom* g, int p2h, int p2w, int dtype, void* stream);
+
+/* ---- library info / errors ---- */
+int cot_abi_version(void);
+const char* cot_last_error(void);          /* thread-local, valid until the next failing call */
+const char* cot_status_string(int status);
+/* name of the kernel variant the last successful aggregation call on this thread dispatched to
+ * (e.g. "agg_fwd_nchw_k3<bf16,P8>"); used by tests to prove the fast path ran. */
+const char* cot_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COTNET_AMD_H */
