@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py -- CoTNet-50 224x224 forward+backward(+SGD) throughput on N MI355X, one JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic input: CoTNet-50 (random init, 1000 classes)
+forward + backward + SGD-nesterov update on B images per GPU, inputs resident in HBM before the timed region.
+Data parallel: weak scaling (B per GPU fixed, reference recipe B=80: cot_experiments/CoTNet-50-350epoch/config.yaml:6),
+gradients averaged with cotnet_amd.data_parallel.GradBucketReducer (RCCL all-reduce on a side stream).
+K steps are timed between barrier + torch.cuda.synchronize() pairs; the slowest rank's time is reported.
+
+Extra objects on the line:
+  roofline      the dominant aggregation kernel of the timed region: algorithmic bytes per launch / mean launch
+                duration, measured with HIP events on the launch stream (cotnet_amd.aggregation_zeropad.profile_*),
+                against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md).  `kernels` lists every aggregation geometry.
+  cpu_baseline  rank 0, N=1 only: the reference's own aggregation kernels compiled for the host CPU
+                (oracle/_ref, kind "reference"; falls back to oracle/agg_oracle.c, kind "port"), OpenMP over all
+                host cores, timed on 4 images per CoT-layer geometry and scaled to images/s of AGGREGATION WORK ONLY
+                (the reference has no CPU path for anything else -- SURVEY.md 0.3).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md "Chip-level parameters": 8.0 TB/s spec (6.29 TB/s measured copy)
+COT50_LAYERS = {(64, 56): 3, (128, 28): 4, (256, 14): 6, (512, 7): 3}  # (C, H=W) -> CoT layers, SURVEY 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=80, help="images per GPU (reference recipe: 80)")
+    ap.add_argument("--model", default="cotnet50")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc"])
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=48.0)
+    return ap.parse_args()
+
+
+def make_optimizer(model, lr, wd):
+    # reference: SGD nesterov, no weight decay on 1-D params (optim/optim_factory.py:19-31,:54-56)
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        (no_decay if p.ndim <= 1 or n.endswith(".bias") else decay).append(p)
+    groups = [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": wd}]
+    return torch.optim.SGD(groups, lr=lr, momentum=0.9, nesterov=True, foreach=True)
+
+
+def cpu_baseline():
+    """reference aggregation kernels on the host cores; -> dict for the JSON line"""
+    from oracle import build_ref, cref
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    per_image_s = 0.0
+    kind = "reference"
+    n_img = 4
+    detail = {}
+    for (C, HW), layers in COT50_LAYERS.items():
+        geom = dict(dtype="float", N=n_img, C=C, H=HW, W=HW, heads=1, wC=C // 8, kernel_size=3, stride=1, padding=1,
+                    dilation=1)
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn(n_img, C, HW, HW, generator=g)
+        w = torch.randn(n_img, 1, C // 8, 9, HW, HW, generator=g)
+        go = torch.randn(n_img, C, HW, HW, generator=g)
+        try:
+            ref = build_ref.RefAggregation(**geom)
+            fns = (lambda: ref.forward(x, w), lambda: ref.backward_input(go, w), lambda: ref.backward_weight(go, x))
+        except FileNotFoundError:
+            kind = "port"
+            fns = (lambda: cref.forward(x, w, 3, 1, 1, 1), lambda: cref.backward_input(go, w, x.shape, 3, 1, 1, 1),
+                   lambda: cref.backward_weight(go, x, w.shape, 3, 1, 1, 1))
+        for f in fns:
+            f()  # warm-up
+        best = float("inf")
+        reps, t_budget, t_start = 0, 3.0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t_start < t_budget and reps < 50):
+            t0 = time.perf_counter()
+            for f in fns:
+                f()
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+        detail[f"C{C}_H{HW}"] = round(best / n_img * 1e3, 3)
+        per_image_s += layers * best / n_img
+    return {"value": round(1.0 / per_image_s, 2), "unit": "images/s (aggregation fwd+bwd work of CoTNet-50 only)",
+            "cores": cores, "kind": kind,
+            "sample": f"{n_img} images per CoT-layer geometry (4 geometries x fwd/input-bwd/weight-bwd, fp32, best of "
+                      f">=3), scaled by layer counts 3/4/6/3; ms per image per layer: {detail}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+
+    import cotnet_amd
+    from cotnet_amd import _lib
+    from cotnet_amd import aggregation_zeropad as agg_mod
+    from cotnet_amd.data_parallel import GradBucketReducer
+    _lib.lib()  # fail loudly here if the HIP library is missing
+
+    torch.manual_seed(1234 + rank)
+    torch.backends.cudnn.benchmark = True
+    model = cotnet_amd.create_model(args.model, num_classes=1000).to(dev)
+    mf = torch.channels_last if args.layout == "nhwc" else torch.contiguous_format
+    if args.layout == "nhwc":
+        model = model.to(memory_format=torch.channels_last)
+    amp = args.dtype == "bf16"
+    B = args.batch
+    x = torch.randn(B, 3, args.img, args.img, device=dev).contiguous(memory_format=mf)
+    t = torch.randint(0, 1000, (B,), device=dev)
+
+    if args.mode == "train":
+        model.train()
+        opt = make_optimizer(model, lr=0.25 * B * world / 640.0, wd=4e-5)
+        red = GradBucketReducer(model, bucket_mb=args.bucket_mb)
+
+        def step():
+            red.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                out = model(x)
+                loss = torch.nn.functional.cross_entropy(out.float(), t)
+            loss.backward()
+            red.finish()
+            opt.step()
+            return loss
+    else:
+        model.eval()
+
+        def step():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                return model(x).float().sum()
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    if not args.no_kernel_timing:
+        agg_mod.profile_begin()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    recs = agg_mod.profile_end() if not args.no_kernel_timing else []
+    final_loss = float(loss)
+
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        # ---- roofline of the aggregation kernels, from the HIP events of the timed region
+        groups = {}
+        for kind, g, dtype, layout, ms, nbytes in recs:
+            key = (kind, g[1], g[2], str(dtype).replace("torch.", ""), "nhwc" if layout else "nchw")
+            e = groups.setdefault(key, {"ms": 0.0, "n": 0, "bytes": nbytes, "N": g[0]})
+            e["ms"] += ms
+            e["n"] += 1
+        kernels = []
+        for (kind, C, H, dt, lay), e in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
+            avg_ms = e["ms"] / e["n"]
+            gbs = e["bytes"] / (avg_ms * 1e-3) / 1e9
+            kernels.append({"kernel": f"agg_{kind}_{lay}", "shape": f"N{e['N']}xC{C}x{H}x{H}", "dtype": dt,
+                            "launches": e["n"], "avg_us": round(avg_ms * 1e3, 2), "GBs": round(gbs, 1),
+                            "frac": round(gbs / HBM_PEAK_GBS, 4), "total_ms": round(e["ms"], 3)})
+        roofline = None
+        if kernels:
+            k0 = kernels[0]
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "agg_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(f"{k0['kernel']}|{k0['shape']}|{k0['dtype']}")
+            agg_total = sum(k["total_ms"] for k in kernels)
+            roofline = {"bound": "hbm", "kernel": k0["kernel"], "shape": k0["shape"], "dtype": k0["dtype"],
+                        "achieved": k0["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k0["frac"],
+                        "traffic": traffic, "avg_us": k0["avg_us"],
+                        "agg_share_of_step": round(agg_total / (elapsed * 1e3), 4), "kernels": kernels}
+        line = {
+            "metric": "images/sec CoTNet-50 224^2 fwd+bwd" if args.mode == "train" else "images/sec CoTNet-50 224^2 fwd",
+            "value": round(B * world * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if amp else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.img}x{args.img} {'fwd+bwd+SGD-nesterov' if args.mode == 'train' else 'forward-only'}, "
+                                   f"random init, 1000 classes, NCHW synthetic ImageNet-shaped input resident in HBM",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "layout": args.layout, "precision": "bf16 autocast, fp32 master weights" if amp else "fp32",
+                       "grad_sync": "RCCL all-reduce (AVG), flat buckets, side stream" if world > 1 else "none (1 GPU)"},
+            "final_loss": round(final_loss, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

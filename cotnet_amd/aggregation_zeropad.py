@@ -73,6 +73,45 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- optional in-situ kernel timing (bench.py): HIP events recorded on the launch stream around each launch ----
+_PROFILE = None
+
+
+def profile_begin():
+    """start collecting (kind, geometry, dtype, layout, start_event, end_event) for every aggregation launch"""
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_end():
+    """stop collecting; returns [(kind, (N,C,H,W,heads,wC,k), dtype, layout, milliseconds, algorithmic_bytes)]"""
+    global _PROFILE
+    recs, _PROFILE = _PROFILE or [], None
+    torch.cuda.synchronize()
+    out = []
+    for kind, g, dtype, layout, e0, e1, nbytes in recs:
+        out.append((kind, g, dtype, layout, e0.elapsed_time(e1), nbytes))
+    return out
+
+
+def _prof_open():
+    if _PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_close(e0, kind, geom, tensors, dtype, layout):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    nbytes = sum(t.numel() * t.element_size() for t in tensors if t is not None)  # algorithmic: each tensor once
+    _PROFILE.append((kind, (geom.N, geom.C, geom.H, geom.W, geom.heads, geom.wC, geom.kh), dtype, layout, e0, e1,
+                     nbytes))
+
+
 class AggregationZeropad(Function):
     @staticmethod
     def forward(ctx, input, weight, kernel_size, stride, padding, dilation):
@@ -97,8 +136,10 @@ class AggregationZeropad(Function):
                             kernel_size[0], kernel_size[1], stride[0], stride[1], padding[0], padding[1],
                             dilation[0], dilation[1])
         with torch.cuda.device_of(input):
+            ev = _prof_open()
             rc = _lib.lib().cot_agg_forward(_ptr(input), _ptr(weight), _ptr(output), ctypes.byref(geom),
                                             _lib.dtype_code(input.dtype), layout, _stream())
+            _prof_close(ev, "fwd", geom, (input, weight, output), input.dtype, layout)
         _lib.check(rc, "cot_agg_forward")
         ctx.geom, ctx.layout = geom, layout
         ctx.save_for_backward(input, weight)
@@ -122,15 +163,24 @@ class AggregationZeropad(Function):
                            else torch.empty_like(weight))
         if grad_input is not None or grad_weight is not None:
             with torch.cuda.device_of(input):
+                ev = _prof_open()
                 rc = _lib.lib().cot_agg_backward(_ptr(grad_output), _ptr(input), _ptr(weight), _ptr(grad_input),
                                                  _ptr(grad_weight), ctypes.byref(ctx.geom),
                                                  _lib.dtype_code(input.dtype), layout, _stream())
+                _prof_close(ev, "bwd", ctx.geom,
+                            (grad_output, input if grad_weight is not None else None,
+                             weight if grad_input is not None else None, grad_input, grad_weight),
+                            input.dtype, layout)
             _lib.check(rc, "cot_agg_backward")
         return grad_input, grad_weight, None, None, None, None
 
 
 def aggregation_zeropad(input, weight, kernel_size=3, stride=1, padding=0, dilation=1):
     assert input.shape[0] == weight.shape[0] and (input.shape[1] % weight.shape[2] == 0)  # ref :189
+    if weight.dtype != input.dtype:
+        # mixed-precision callers (autocast runs GroupNorm in fp32 while the values are bf16): compute in the
+        # values' dtype; the cast is differentiable, so the weight gradient comes back in the weight's dtype
+        weight = weight.to(input.dtype)
     if input.is_cuda:
         out = AggregationZeropad.apply(input, weight, kernel_size, stride, padding, dilation)
     else:

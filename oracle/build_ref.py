@@ -331,8 +331,11 @@ PREBUILT_AGG = [
     dict(dtype="double", N=1, C=8, H=11, W=10, heads=1, wC=4, kernel_size=3, stride=1, padding=2, dilation=2),
     dict(dtype="double", N=1, C=6, H=9, W=12, heads=1, wC=3, kernel_size=(3, 5), stride=(2, 1), padding=(1, 2),
          dilation=(1, 1)),
-    # bench.py cpu_baseline sample: CoTNet-50 stage-1 CoT layer geometry, 8 images, fp32
-    dict(dtype="float", N=8, C=64, H=56, W=56, heads=1, wC=8, kernel_size=3, stride=1, padding=1, dilation=1),
+    # bench.py cpu_baseline sample: the four CoTNet-50 CoT-layer geometries, 4 images, fp32
+    dict(dtype="float", N=4, C=64, H=56, W=56, heads=1, wC=8, kernel_size=3, stride=1, padding=1, dilation=1),
+    dict(dtype="float", N=4, C=128, H=28, W=28, heads=1, wC=16, kernel_size=3, stride=1, padding=1, dilation=1),
+    dict(dtype="float", N=4, C=256, H=14, W=14, heads=1, wC=32, kernel_size=3, stride=1, padding=1, dilation=1),
+    dict(dtype="float", N=4, C=512, H=7, W=7, heads=1, wC=64, kernel_size=3, stride=1, padding=1, dilation=1),
 ]
 PREBUILT_MIX = [
     # reference self-test (aggregation_zeropad_mix.py:344-383)

@@ -1,0 +1,105 @@
+"""world_size-2 gloo tests (CPU) of the bucketed gradient all-reduce and the flattened BN-statistics sync."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from cotnet_amd.data_parallel import GradBucketReducer, distribute_bn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _net():
+    return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 8, 1),
+                         nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 4))
+
+
+def _worker(rank, world, port, bucket_mb, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)  # different initial weights per rank: broadcast must fix that
+        model = _net()
+        red = GradBucketReducer(model, bucket_mb=bucket_mb)
+        # (1) parameters identical to rank 0's after construction
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(g, gathered[0]) for g in gathered)
+        # (2) averaged gradients == mean over ranks of the local gradients, for two consecutive steps
+        for step in range(2):
+            torch.manual_seed(1000 * step + rank)
+            x, t = torch.randn(4, 3, 6, 6), torch.randint(0, 4, (4,))
+            ref = _net()
+            ref.load_state_dict(model.state_dict())
+            nn.functional.cross_entropy(ref(x), t).backward()
+            local = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+            allg = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(allg, local)
+            want = torch.stack(allg).mean(0)
+            red.zero_grad()
+            nn.functional.cross_entropy(model(x), t).backward()
+            red.finish()
+            got = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+            assert torch.allclose(got, want, atol=1e-6), (got - want).abs().max()
+            for p in model.parameters():  # grads are views into the flat buckets
+                assert any(p.grad.data_ptr() >= b.flat.data_ptr() and
+                           p.grad.data_ptr() < b.flat.data_ptr() + b.flat.numel() * 4 for b in red.buckets)
+        # (3) flattened BN running-stat averaging
+        bn = model[1]
+        with torch.no_grad():
+            bn.running_mean.fill_(float(rank))
+            bn.running_var.fill_(1.0 + rank)
+        distribute_bn(model, reduce=True)
+        assert torch.allclose(bn.running_mean, torch.full((8,), (world - 1) / 2.0))
+        assert torch.allclose(bn.running_var, torch.full((8,), 1.0 + (world - 1) / 2.0))
+        with torch.no_grad():
+            bn.running_mean.fill_(float(rank + 5))
+        distribute_bn(model, reduce=False)
+        assert torch.allclose(bn.running_mean, torch.full((8,), 5.0))
+        q.put((rank, len(red.buckets), "ok"))
+    except Exception as e:  # surface the failure in the parent
+        q.put((rank, -1, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_mb", [48.0, 0.0005])  # one bucket / many tiny buckets
+def test_bucketed_allreduce_world2_gloo(bucket_mb):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_mb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, nb, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+    nbs = {nb for _, nb, _ in results}
+    assert len(nbs) == 1
+    assert (nbs.pop() == 1) == (bucket_mb > 1)
+
+
+def test_single_process_is_a_noop_with_flat_buckets():
+    model = _net()
+    red = GradBucketReducer(model)
+    assert not red.enabled and len(red.buckets) == 1
+    nn.functional.cross_entropy(model(torch.randn(2, 3, 6, 6)), torch.tensor([0, 1])).backward()
+    red.finish()
+    total = sum(p.numel() for p in model.parameters())
+    assert red.buckets[0].flat.numel() == total and red.buckets[0].flat.abs().sum() > 0
+    red.zero_grad()
+    assert red.buckets[0].flat.abs().sum() == 0 and all(p.grad is not None for p in model.parameters())

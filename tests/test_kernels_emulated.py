@@ -1,0 +1,159 @@
+"""Pre-GPU check of the HIP kernels' index arithmetic: the SAME .hip sources compiled for the host with a
+launch-loop shim (tests/emul/), driven through the C ABI with CPU pointers and compared with the oracle.
+This is not the parity gate (tests/test_agg_gpu.py on a real MI355X is); it exists so that indexing bugs are
+caught in the GPU-less build container."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from cotnet_amd import _lib
+from oracle import cref, unfold_oracle
+from tests.emul import build_emul
+
+try:
+    _EMUL = ctypes.CDLL(build_emul.build())
+    for _name, (_res, _args) in _lib.SYMBOLS.items():
+        getattr(_EMUL, _name).restype = _res
+        getattr(_EMUL, _name).argtypes = _args
+except (FileNotFoundError, OSError, Exception) as e:  # no host clang: skip, the GPU tests still gate parity
+    _EMUL = None
+    _WHY = repr(e)
+
+pytestmark = pytest.mark.skipif(_EMUL is None, reason="host emulation build unavailable")
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def to_layout(t, layout):
+    """NCHW-shaped CPU tensor -> dense buffer in `layout` order"""
+    if layout == 0:
+        return t.contiguous()
+    if t.dim() == 4:
+        return t.permute(0, 2, 3, 1).contiguous()
+    return t.permute(0, 4, 5, 1, 2, 3).contiguous()
+
+
+def from_layout(buf, shape, layout):
+    if layout == 0:
+        return buf.view(shape)
+    if len(shape) == 4:
+        N, C, H, W = shape
+        return buf.view(N, H, W, C).permute(0, 3, 1, 2).contiguous()
+    N, heads, wC, taps, Ho, Wo = shape
+    return buf.view(N, Ho, Wo, heads, wC, taps).permute(0, 3, 4, 5, 1, 2).contiguous()
+
+
+def run(x, w, gout, k, s, p, d, layout, fused=True):
+    kk = (k, k) if isinstance(k, int) else k
+    ss, pp, dd = [(v, v) if isinstance(v, int) else v for v in (s, p, d)]
+    N, C, H, W = x.shape
+    heads, wC = w.shape[1], w.shape[2]
+    g = _lib.AggGeom(N, C, H, W, heads, wC, kk[0], kk[1], ss[0], ss[1], pp[0], pp[1], dd[0], dd[1])
+    dt = _lib.dtype_code(x.dtype)
+    xb, wb, gb = to_layout(x, layout), to_layout(w, layout), to_layout(gout, layout)
+    out, gx, gw = torch.empty_like(gb), torch.empty_like(xb), torch.empty_like(wb)
+    assert _EMUL.cot_agg_forward(P(xb), P(wb), P(out), ctypes.byref(g), dt, layout, None) == 0, _EMUL.cot_last_error()
+    fk = _EMUL.cot_last_kernel().decode()
+    if fused:
+        assert _EMUL.cot_agg_backward(P(gb), P(xb), P(wb), P(gx), P(gw), ctypes.byref(g), dt, layout, None) == 0
+    else:
+        assert _EMUL.cot_agg_backward_input(P(gb), P(wb), P(gx), ctypes.byref(g), dt, layout, None) == 0
+        assert _EMUL.cot_agg_backward_weight(P(gb), P(xb), P(gw), ctypes.byref(g), dt, layout, None) == 0
+    bk = _EMUL.cot_last_kernel().decode()
+    return (from_layout(out, gout.shape, layout), from_layout(gx, x.shape, layout), from_layout(gw, w.shape, layout),
+            fk, bk)
+
+
+def oracle_all(x, w, gout, k, s, p, d):
+    return (cref.forward(x, w, k, s, p, d), cref.backward_input(gout, w, x.shape, k, s, p, d),
+            cref.backward_weight(gout, x, w.shape, k, s, p, d))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("C,H,W", [(16, 6, 56), (16, 5, 28), (32, 14, 14), (64, 7, 7), (8, 3, 10), (8, 4, 3)])
+def test_k3_fast_path(C, H, W, dtype, layout, fused):
+    g = torch.Generator().manual_seed(C + W)
+    N, wC = 2, C // 8
+    x = torch.randn(N, C, H, W, dtype=dtype, generator=g)
+    w = torch.randn(N, 1, wC, 9, H, W, dtype=dtype, generator=g)
+    gout = torch.randn(N, C, H, W, dtype=dtype, generator=g)
+    y, gx, gw, fk, bk = run(x, w, gout, 3, 1, 1, 1, layout, fused)
+    oy, ogx, ogw = oracle_all(x, w, gout, 3, 1, 1, 1)
+    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    assert (y - oy).abs().max() < tol, fk
+    assert (gx - ogx).abs().max() < tol, bk
+    assert (gw - ogw).abs().max() < tol, bk
+    if layout == 0:
+        assert "k3" in fk and "k3" in bk
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("k,s,p,d,heads,N,C,wC,H,W", [
+    (3, 1, 1, 1, 2, 2, 16, 4, 9, 12), (5, 1, 2, 1, 2, 2, 8, 4, 9, 9), (1, 1, 0, 1, 2, 2, 8, 4, 9, 9),
+    (3, 2, 1, 1, 1, 2, 8, 2, 11, 10), (3, 1, 2, 2, 1, 1, 8, 4, 11, 10),
+    ((3, 5), (2, 1), (1, 2), (1, 1), 1, 1, 6, 3, 9, 12), (3, 1, 0, 1, 1, 2, 8, 8, 7, 9),
+    (3, 3, 1, 2, 1, 1, 4, 1, 13, 13), (3, 1, 1, 1, 1, 2, 24, 3, 5, 5), (3, 1, 1, 1, 1, 1, 8, 8, 1, 1),
+])
+def test_generic_geometries(k, s, p, d, heads, N, C, wC, H, W, layout):
+    g = torch.Generator().manual_seed(5)
+    Ho, Wo = unfold_oracle.out_hw(H, W, k, s, p, d)
+    kk = (k, k) if isinstance(k, int) else k
+    x = torch.randn(N, C, H, W, dtype=torch.float64, generator=g)
+    w = torch.randn(N, heads, wC, kk[0] * kk[1], Ho, Wo, dtype=torch.float64, generator=g)
+    gout = torch.randn(N, heads * C, Ho, Wo, dtype=torch.float64, generator=g)
+    y, gx, gw, _, _ = run(x, w, gout, k, s, p, d, layout)
+    oy, ogx, ogw = oracle_all(x, w, gout, k, s, p, d)
+    assert (y - oy).abs().max() < 1e-12 and (gx - ogx).abs().max() < 1e-12 and (gw - ogw).abs().max() < 1e-12
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_half_storage(dtype, layout):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 16, 6, 56, generator=g).to(dtype)
+    w = torch.randn(2, 1, 2, 9, 6, 56, generator=g).to(dtype)
+    gout = torch.randn(2, 16, 6, 56, generator=g).to(dtype)
+    y, gx, gw, fk, bk = run(x, w, gout, 3, 1, 1, 1, layout)
+    oy, ogx, ogw = oracle_all(x.float(), w.float(), gout.float(), 3, 1, 1, 1)
+    tol = 6e-2 if dtype == torch.bfloat16 else 8e-3
+    for got, want in ((y, oy), (gx, ogx), (gw, ogw)):
+        assert ((got.float() - want).abs() <= tol * (1 + want.abs())).all()
+
+
+def test_integer_exact_and_padded_zero():
+    g = torch.Generator().manual_seed(3)
+    for W in (56, 28, 14, 7, 10):
+        x = torch.randint(-4, 5, (2, 16, 6, W), generator=g).float()
+        w = torch.randint(-3, 4, (2, 1, 2, 9, 6, W), generator=g).float()
+        gout = torch.randint(-2, 3, (2, 16, 6, W), generator=g).float()
+        for layout in (0, 1):
+            y, gx, gw, _, _ = run(x, w, gout, 3, 1, 1, 1, layout)
+            oy, ogx, ogw = oracle_all(x, w, gout, 3, 1, 1, 1)
+            assert torch.equal(y, oy) and torch.equal(gx, ogx) and torch.equal(gw, ogw)
+            assert torch.all(gw[:, :, :, 0, 0, :] == 0) and torch.all(gw[:, :, :, 8, :, -1] == 0)
+
+
+def test_mix_kernels():
+    g = torch.Generator().manual_seed(8)
+    N, C, wC, H, W, heads = 2, 8, 4, 6, 7, 2
+    x = torch.randn(N, C, H, W, dtype=torch.float64, generator=g)
+    w1 = torch.randn(N, heads, wC, 9, H, W, dtype=torch.float64, generator=g)
+    w2 = torch.randn(N, heads, wC, 25, H, W, dtype=torch.float64, generator=g)
+    gout = torch.randn(N, 2 * heads * C, H, W, dtype=torch.float64, generator=g)
+    geo = _lib.AggGeom(N, C, H, W, heads, wC, 3, 3, 1, 1, 1, 1, 1, 1)
+    out, gx, gw1, gw2 = torch.empty_like(gout), torch.empty_like(x), torch.empty_like(w1), torch.empty_like(w2)
+    assert _EMUL.cot_aggmix_forward(P(x), P(w1), P(w2), P(out), ctypes.byref(geo), 2, 2, 1, None) == 0
+    assert torch.equal(out, cref.mix_forward(x, w1, w2, 1, 1, 2, 1))
+    for all_heads in (0, 1):
+        assert _EMUL.cot_aggmix_backward_input(P(gout), P(w1), P(w2), P(gx), ctypes.byref(geo), 2, 2, all_heads, 1,
+                                               None) == 0
+        assert (gx - cref.mix_backward_input(gout, w1, w2, x.shape, 1, 1, 2, 1, bool(all_heads))).abs().max() < 1e-12
+    assert _EMUL.cot_aggmix_backward_weight(P(gout), P(x), P(gw1), P(gw2), ctypes.byref(geo), 2, 2, 1, None) == 0
+    o1, o2 = cref.mix_backward_weight(gout, x, w1.shape, w2.shape, 1, 1, 2, 1)
+    assert (gw1 - o1).abs().max() < 1e-12 and (gw2 - o2).abs().max() < 1e-12

@@ -1,0 +1,86 @@
+"""GPU parity of CotLayer / CoXtLayer / whole models with the REAL HIP kernels, against fixtures produced by the
+reference's own module code (tests/golden/make_golden.py).  fp32 bar: 1e-3 (BASELINE.json)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import cotnet_amd
+from cotnet_amd import _lib, cotnet
+from tests.conftest import LAYER_FIXTURES, MODEL_FIXTURES, layer_case, load_golden, rng_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("memory_format", ["nchw", "nhwc"])
+@pytest.mark.parametrize("name", LAYER_FIXTURES)
+def test_layer_matches_reference_fixture(name, memory_format):
+    gold = load_golden(name)
+    meta, sd, x, gout = layer_case(gold)
+    layer = getattr(cotnet, meta["cls"])(meta["dim"], 3).to(DEV)
+    mf = torch.channels_last if memory_format == "nhwc" else torch.contiguous_format
+    if memory_format == "nhwc":
+        if meta["cls"] == "CoXtLayer":
+            pytest.skip("CoXtLayer folds groups into the batch with NCHW views (ref :157-162)")
+        layer = layer.to(memory_format=torch.channels_last)
+    for mode in ("eval", "train"):
+        layer.load_state_dict(sd, strict=True)
+        layer.train(mode == "train")
+        layer.zero_grad()
+        xin = x.to(DEV).contiguous(memory_format=mf).requires_grad_(True)
+        y = layer(xin)
+        y.backward(gout.to(DEV))
+        tol = 1e-3
+        assert (y.detach().cpu() - torch.from_numpy(gold[f"{mode}_y"])).abs().max() < tol
+        assert (xin.grad.cpu() - torch.from_numpy(gold[f"{mode}_gx"])).abs().max() < tol
+        for key, p in (("g_embed3_w", layer.embed[3].weight), ("g_key0_w", layer.key_embed[0].weight),
+                       ("g_conv1x1_w", layer.conv1x1[0].weight)):
+            ref = torch.from_numpy(gold[f"{mode}_{key}"])
+            assert (p.grad.cpu() - ref).abs().max() <= tol * max(1.0, ref.abs().max().item())
+    assert "agg" in _lib.last_kernel()  # the HIP library did the aggregation
+    assert (layer.bn.running_mean.cpu() - torch.from_numpy(gold["train_bn_running_mean"])).abs().max() < 1e-4
+    assert (layer.bn.running_var.cpu() - torch.from_numpy(gold["train_bn_running_var"])).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_model_matches_reference_fixture(name):
+    """same seed + same construction order => the reference's initial weights; fixture logits are the reference
+    model's (fp64).  fp64 on the GPU pins wiring + kernels to 1e-7; fp32 is checked at the conditioning-limited
+    5e-2 (tests/golden/make_golden.py explains why the 64x64 toy network is ill-conditioned in fp32)."""
+    gold = load_golden(name)
+    meta = json.loads(str(gold["meta"]))
+    seed = int(gold["seed"])
+    x = rng_tensor(np.random.Generator(np.random.PCG64(seed)), (2, 3, meta["size"], meta["size"]), torch.float64)
+    for dtype, tol in ((torch.float64, 1e-7), (torch.float32, 5e-2)):
+        torch.manual_seed(seed)
+        m = cotnet_amd.create_model(name[len("model_"):], num_classes=meta["num_classes"], zero_init_last_bn=False)
+        m = m.to(dtype).to(DEV)
+        with torch.no_grad():
+            try:
+                y = m.eval()(x.to(dtype).to(DEV))
+                yt = m.train()(x.to(dtype).to(DEV))
+            except RuntimeError as e:
+                if dtype == torch.float64 and "agg" not in str(e):
+                    pytest.xfail(f"fp64 convolution unavailable on this ROCm build: {e}")
+                raise
+        for got, key in ((y, "logits"), (yt, "logits_train")):
+            ref = torch.from_numpy(gold[key])
+            assert ((got.double().cpu() - ref).abs().max() / ref.abs().max()).item() < tol
+
+
+def test_cotnet50_train_step_smoke():
+    torch.manual_seed(0)
+    m = cotnet_amd.create_model("cotnet50", num_classes=10).to(DEV).train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, nesterov=True)
+    x = torch.randn(4, 3, 224, 224, device=DEV)
+    t = torch.randint(0, 10, (4,), device=DEV)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(m(x), t)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
