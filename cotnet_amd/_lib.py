@@ -38,6 +38,8 @@ SYMBOLS = {
     "cot_aggmix_forward": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),
     "cot_aggmix_backward_input": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _I, _P]),
     "cot_aggmix_backward_weight": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),
+    "cot_set_tuning": (_I, [_I, _I]),
+    "cot_xchg_mode": (_I, []),
 }
 
 

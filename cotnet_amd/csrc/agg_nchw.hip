@@ -304,10 +304,265 @@ __global__ __launch_bounds__(256) void agg_bwd_nchw_k3(const T* __restrict__ gou
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 fast path, version 2: wave-aligned rows + cross-lane halos + prefetched channel loop
+// ------------------------------------------------------------------------------------------------
+// v1 above is latency-bound on MI355X (bf16 stage-1 forward: 21 % of the HBM roofline, the same time as
+// fp32): 9 dependent load rounds per lane, 6 of the 9 loads per channel being 2-byte halo scalars.  v2:
+//   * a wave owns L = floor(64/segs)*segs consecutive work items (segs = W/P row segments), i.e. WHOLE rows, so the
+//     left/right halo of a lane is always the edge element of lane-1 / lane+1 (or zero at a row end).  Halos move
+//     with one DPP wave-shift (or ds_bpermute) per row instead of two scalar loads: 3 loads per channel, all 16 B.
+//   * the channel loop prefetches channel j+1's raw row vectors before it computes channel j, doubling the
+//     bytes each lane keeps in flight; storage-type rows stay packed until use to keep VGPRs (occupancy) low.
+// XCHG selects the lane-exchange primitive: 0 = v_mov_b32_dpp wave_shr/wave_shl, 1 = ds_bpermute (__shfl);
+// the library probes the DPP direction once on the device and falls back to 1 if it is not what we expect.
+
+template <int XCHG> __device__ __forceinline__ float lane_prev(float v) {
+    if (XCHG == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+    return __shfl_up(v, 1);
+}
+template <int XCHG> __device__ __forceinline__ float lane_next(float v) {
+    if (XCHG == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+    return __shfl_down(v, 1);
+}
+template <int XCHG> __device__ __forceinline__ double lane_prev(double v) { return __shfl_up(v, 1); }
+template <int XCHG> __device__ __forceinline__ double lane_next(double v) { return __shfl_down(v, 1); }
+
+__global__ void dpp_probe_kernel(int* out) {
+    const int l = threadIdx.x;
+    out[l] = __builtin_amdgcn_update_dpp(-1, l, 0x138, 0xf, 0xf, false);       // expect l-1 (lane 0: -1)
+    out[64 + l] = __builtin_amdgcn_update_dpp(-1, l, 0x130, 0xf, 0xf, false);  // expect l+1 (lane 63: -1)
+}
+
+// raw (storage-type) row vector of plane row hr, zero when the row is outside the image
+template <typename T, int P>
+__device__ __forceinline__ Vec<T, P> load_row_raw(const T* __restrict__ plane, int hr, int H, int W, int w0) {
+    Vec<T, P> v;
+    if (hr >= 0 && hr < H) {
+        v = ldv<T, P>(plane + (int64_t)hr * W + w0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i) v.v[i] = (T)0;
+    }
+    return v;
+}
+
+// dst[0..P+1] = columns w0-1 .. w0+P of the row: converted vector + halos taken from the neighbouring lanes
+template <typename T, int P, int XCHG, typename A>
+__device__ __forceinline__ void expand_row(const Vec<T, P>& raw, bool has_left, bool has_right, A (&dst)[P + 2]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) dst[i + 1] = (A)raw.v[i];
+    const A l = lane_prev<XCHG>(dst[P]);
+    const A r = lane_next<XCHG>(dst[1]);
+    dst[0] = has_left ? l : (A)0;
+    dst[P + 1] = has_right ? r : (A)0;
+}
+
+struct ItemV2 {
+    bool valid;
+    int seg, h, wc;
+    int64_t plane, nh;
+};
+// item = wave*L + lane for lane < L; lanes >= L and items >= total are clamped to a valid item and do not store
+__device__ __forceinline__ ItemV2 decode_item_v2(int segs, int L, int H, int wC, int64_t items) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int64_t item = wave * L + lane;
+    ItemV2 it;
+    it.valid = lane < L && item < items;
+    if (!it.valid) item = items - 1;
+    it.seg = (int)(item % segs);
+    it.h = (int)((item / segs) % H);
+    it.plane = item / ((int64_t)segs * H);
+    it.wc = (int)(it.plane % wC);
+    it.nh = it.plane / wC;
+    return it;
+}
+
+template <typename T, int P, int XCHG>
+__global__ __launch_bounds__(256) void agg_fwd_nchw_k3_v2(const T* __restrict__ x, const T* __restrict__ w,
+                                                         T* __restrict__ out, int heads, int C, int wC, int H, int W,
+                                                         int L, int64_t items) {
+    typedef typename AccOf<T>::type A;
+    const int segs = W / P;
+    const ItemV2 it = decode_item_v2(segs, L, H, wC, items);
+    const int n = (int)(it.nh / heads);
+    const int w0 = it.seg * P, h = it.h;
+    const int64_t HW = (int64_t)H * W;
+    const bool has_left = it.seg > 0, has_right = it.seg < segs - 1;
+
+    // the item's 9*P weights stay packed in the storage type (bf16: 36 VGPRs at P=8) and are converted at use
+    Vec<T, P> wr[9];
+    {
+        const T* wp = w + it.plane * 9 * HW + (int64_t)h * W + w0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[t] = ldv<T, P>(wp + t * HW);
+    }
+    const int J = C / wC;
+    const int64_t cstride = (int64_t)wC * HW;
+    const T* xp = x + ((int64_t)n * C + it.wc) * HW;
+    T* op = out + (it.nh * C + it.wc) * HW + (int64_t)h * W + w0;
+    Vec<T, P> cur[3], nxt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cur[r] = load_row_raw<T, P>(xp, h - 1 + r, H, W, w0);
+    for (int j = 0; j < J; ++j) {
+        if (j + 1 < J) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) nxt[r] = load_row_raw<T, P>(xp + (j + 1) * cstride, h - 1 + r, H, W, w0);
+        }
+        A xr[3][P + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) expand_row<T, P, XCHG, A>(cur[r], has_left, has_right, xr[r]);
+        Vec<T, P> o;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            A acc = 0;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc += (A)wr[kh * 3 + kw].v[i] * xr[kh][i + kw];
+            o.v[i] = (T)acc;
+        }
+        if (it.valid) stv<T, P>(op + j * cstride, o);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cur[r] = nxt[r];
+    }
+}
+
+// fused backward v2 (heads == 1): same mapping; shifted weights via lane exchange; gO / x rows prefetched.
+template <typename T, int P, int XCHG, bool DO_GX, bool DO_GW>
+__global__ __launch_bounds__(256) void agg_bwd_nchw_k3_v2(const T* __restrict__ gout, const T* __restrict__ x,
+                                                         const T* __restrict__ w, T* __restrict__ gx,
+                                                         T* __restrict__ gw, int C, int wC, int H, int W, int L,
+                                                         int64_t items) {
+    typedef typename AccOf<T>::type A;
+    const int segs = W / P;
+    const ItemV2 it = decode_item_v2(segs, L, H, wC, items);
+    const int n = (int)it.nh;  // heads == 1
+    const int w0 = it.seg * P, h = it.h;
+    const int64_t HW = (int64_t)H * W;
+    const bool has_left = it.seg > 0, has_right = it.seg < segs - 1;
+
+    // ws[t][i] = w_t[h+1-kh, w0+i+1-kw]  (0 outside): the weight each gathered neighbour was multiplied with
+    A ws[9][P];
+    if (DO_GX) {
+        const T* wp = w + it.plane * 9 * HW;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int t = kh * 3 + kw;
+                A row[P + 2];
+                expand_row<T, P, XCHG, A>(load_row_raw<T, P>(wp + t * HW, h + 1 - kh, H, W, w0), has_left, has_right,
+                                          row);
+#pragma unroll
+                for (int i = 0; i < P; ++i) ws[t][i] = row[i + 2 - kw];
+            }
+        }
+    }
+    A gwacc[9][P];
+    if (DO_GW) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < P; ++i) gwacc[t][i] = (A)0;
+    }
+    const int J = C / wC;
+    const int64_t cstride = (int64_t)wC * HW;
+    const int64_t pl0 = ((int64_t)n * C + it.wc) * HW;
+    Vec<T, P> gcur[3], gnxt[3], xcur[3], xnxt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (DO_GX || r == 1) gcur[r] = load_row_raw<T, P>(gout + pl0, h - 1 + r, H, W, w0);
+        if (DO_GW) xcur[r] = load_row_raw<T, P>(x + pl0, h - 1 + r, H, W, w0);
+    }
+    for (int j = 0; j < J; ++j) {
+        const int64_t pl = pl0 + j * cstride;
+        if (j + 1 < J) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (DO_GX || r == 1) gnxt[r] = load_row_raw<T, P>(gout + pl + cstride, h - 1 + r, H, W, w0);
+                if (DO_GW) xnxt[r] = load_row_raw<T, P>(x + pl + cstride, h - 1 + r, H, W, w0);
+            }
+        }
+        A gr[3][P + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (DO_GX || r == 1) expand_row<T, P, XCHG, A>(gcur[r], has_left, has_right, gr[r]);
+        if (DO_GX) {
+            Vec<T, P> o;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                A acc = 0;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) acc += ws[kh * 3 + kw][i] * gr[2 - kh][i + 2 - kw];
+                o.v[i] = (T)acc;
+            }
+            if (it.valid) stv<T, P>(gx + pl + (int64_t)h * W + w0, o);
+        }
+        if (DO_GW) {
+            A xr[3][P + 2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) expand_row<T, P, XCHG, A>(xcur[r], has_left, has_right, xr[r]);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) gwacc[kh * 3 + kw][i] += xr[kh][i + kw] * gr[1][i + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            gcur[r] = gnxt[r];
+            xcur[r] = xnxt[r];
+        }
+    }
+    if (DO_GW && it.valid) {
+        T* gp = gw + it.plane * 9 * HW + (int64_t)h * W + w0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            Vec<T, P> o;
+#pragma unroll
+            for (int i = 0; i < P; ++i) o.v[i] = (T)gwacc[t][i];
+            stv<T, P>(gp + t * HW, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
-static thread_local const char* g_last_kernel = "";
+static const char* g_last_kernel = "";  // diagnostic only (written by whichever thread launched last)
 const char* last_kernel_nchw() { return g_last_kernel; }
+
+// run-time tuning knobs (cot_set_tuning): 0 = kernel version (0 auto, 1 force v1, 2 force v2),
+// 1 = max P forward, 2 = max P backward, 3 = lane-exchange primitive (-1 auto/probe, 0 DPP, 1 ds_bpermute)
+static int g_tune[4] = {0, 8, 4, -1};
+int set_tuning_nchw(int key, int value) {
+    if (key < 0 || key > 3) return -1;
+    g_tune[key] = value;
+    return 0;
+}
+
+// One-time device probe: does v_mov_b32_dpp wave_shr:1 / wave_shl:1 move data the way the v2 kernels assume?
+int xchg_mode() {
+    if (g_tune[3] >= 0) return g_tune[3];
+    static const int probed = []() {
+        int* d = nullptr;
+        if (hipMalloc((void**)&d, 128 * sizeof(int)) != hipSuccess) return 1;
+        hipLaunchKernelGGL(dpp_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, d);
+        int h[128];
+        bool ok = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+        hipFree(d);
+        for (int l = 0; ok && l < 64; ++l) {
+            if (h[l] != (l == 0 ? -1 : l - 1)) ok = false;
+            if (h[64 + l] != (l == 63 ? -1 : l + 1)) ok = false;
+        }
+        return ok ? 0 : 1;
+    }();
+    return probed;
+}
 
 static inline int grid_for(int64_t total, int block, int64_t cap = (int64_t)1 << 20) {
     int64_t b = ceil_div64(total, block);
@@ -329,13 +584,31 @@ template <typename T> static inline int pick_P(int W, int maxP) {
     return 1;
 }
 
+static inline bool use_v2(int W, int P) { return g_tune[0] != 1 && (W / P) <= 64; }
+
 template <typename T, int P>
-static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, hipStream_t s, const char* name) {
+static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, hipStream_t s) {
+    static_assert(P * sizeof(T) <= 16, "row vector wider than 16 bytes");
+    if (use_v2(g.W, P)) {
+        const int segs = g.W / P, L = (64 / segs) * segs;
+        const int64_t items = (int64_t)g.N * g.heads * g.wC * g.H * segs;
+        const int64_t waves = ceil_div64(items, L);
+        const dim3 grid((unsigned)ceil_div64(waves, 4)), block(256);
+        if (xchg_mode() == 0)
+            hipLaunchKernelGGL((agg_fwd_nchw_k3_v2<T, P, 0>), grid, block, 0, s, x, w, out, g.heads, g.C, g.wC, g.H,
+                               g.W, L, items);
+        else
+            hipLaunchKernelGGL((agg_fwd_nchw_k3_v2<T, P, 1>), grid, block, 0, s, x, w, out, g.heads, g.C, g.wC, g.H,
+                               g.W, L, items);
+        g_last_kernel = P == 8 ? "agg_fwd_nchw_k3_v2<P8>" : P == 4 ? "agg_fwd_nchw_k3_v2<P4>"
+                        : P == 2 ? "agg_fwd_nchw_k3_v2<P2>" : "agg_fwd_nchw_k3_v2<P1>";
+        return check_launch(g_last_kernel);
+    }
     const int64_t items = (int64_t)g.N * g.heads * g.wC * g.H * (g.W / P);
     hipLaunchKernelGGL((agg_fwd_nchw_k3<T, P>), dim3(grid_for(items, 256, INT32_MAX)), dim3(256), 0, s, x, w, out,
                        g.heads, g.C, g.wC, g.H, g.W, items);
-    g_last_kernel = name;
-    return check_launch(name);
+    g_last_kernel = "agg_fwd_nchw_k3<v1>";
+    return check_launch(g_last_kernel);
 }
 
 template <typename T>
@@ -343,11 +616,12 @@ int agg_forward_nchw(const T* x, const T* w, T* out, const cot_agg_geom& g, int 
                      const char* tname) {
     (void)tname;
     if (is_k3_fast(g)) {
-        switch (pick_P<T>(g.W, 8)) {
-            case 8: return launch_fwd_k3<T, (sizeof(T) <= 2 ? 8 : 1)>(x, w, out, g, s, "agg_fwd_nchw_k3<P8>");
-            case 4: return launch_fwd_k3<T, (sizeof(T) <= 4 ? 4 : 1)>(x, w, out, g, s, "agg_fwd_nchw_k3<P4>");
-            case 2: return launch_fwd_k3<T, 2>(x, w, out, g, s, "agg_fwd_nchw_k3<P2>");
-            default: return launch_fwd_k3<T, 1>(x, w, out, g, s, "agg_fwd_nchw_k3<P1>");
+        constexpr int LIM = (int)(16 / sizeof(T));
+        switch (pick_P<T>(g.W, g_tune[1])) {
+            case 8: return launch_fwd_k3<T, (LIM >= 8 ? 8 : 1)>(x, w, out, g, s);
+            case 4: return launch_fwd_k3<T, (LIM >= 4 ? 4 : 1)>(x, w, out, g, s);
+            case 2: return launch_fwd_k3<T, 2>(x, w, out, g, s);
+            default: return launch_fwd_k3<T, 1>(x, w, out, g, s);
         }
     }
     const int64_t total = (int64_t)g.N * g.heads * g.C * Ho * Wo;
@@ -357,33 +631,45 @@ int agg_forward_nchw(const T* x, const T* w, T* out, const cot_agg_geom& g, int 
     return check_launch("agg_fwd_nchw_generic");
 }
 
+template <typename T, int P, bool GX, bool GW>
+static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw, const cot_agg_geom& g,
+                             hipStream_t s) {
+    if (use_v2(g.W, P)) {
+        const int segs = g.W / P, L = (64 / segs) * segs;
+        const int64_t items = (int64_t)g.N * g.wC * g.H * segs;
+        const int64_t waves = ceil_div64(items, L);
+        const dim3 grid((unsigned)ceil_div64(waves, 4)), block(256);
+        if (xchg_mode() == 0)
+            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 0, GX, GW>), grid, block, 0, s, gout, x, w, gx, gw, g.C, g.wC,
+                               g.H, g.W, L, items);
+        else
+            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 1, GX, GW>), grid, block, 0, s, gout, x, w, gx, gw, g.C, g.wC,
+                               g.H, g.W, L, items);
+        g_last_kernel = GX && GW ? "agg_bwd_nchw_k3_v2<gx,gw>" : GX ? "agg_bwd_nchw_k3_v2<gx>" : "agg_bwd_nchw_k3_v2<gw>";
+        return check_launch(g_last_kernel);
+    }
+    const int64_t items = (int64_t)g.N * g.wC * g.H * (g.W / P);
+    hipLaunchKernelGGL((agg_bwd_nchw_k3<T, P, GX, GW>), dim3(grid_for(items, 256, INT32_MAX)), dim3(256), 0, s, gout, x,
+                       w, gx, gw, g.C, g.wC, g.H, g.W, items);
+    g_last_kernel = GX && GW ? "agg_bwd_nchw_k3<gx,gw>" : GX ? "agg_bwd_nchw_k3<gx>" : "agg_bwd_nchw_k3<gw>";
+    return check_launch(g_last_kernel);
+}
+
 template <typename T, int P>
 static int launch_bwd_k3(const T* gout, const T* x, const T* w, T* gx, T* gw, const cot_agg_geom& g, hipStream_t s) {
-    const int64_t items = (int64_t)g.N * g.wC * g.H * (g.W / P);
-    const dim3 grid(grid_for(items, 256, INT32_MAX)), block(256);
-    if (gx && gw) {
-        hipLaunchKernelGGL((agg_bwd_nchw_k3<T, P, true, true>), grid, block, 0, s, gout, x, w, gx, gw, g.C, g.wC, g.H,
-                           g.W, items);
-        g_last_kernel = "agg_bwd_nchw_k3<gx,gw>";
-    } else if (gx) {
-        hipLaunchKernelGGL((agg_bwd_nchw_k3<T, P, true, false>), grid, block, 0, s, gout, x, w, gx, gw, g.C, g.wC, g.H,
-                           g.W, items);
-        g_last_kernel = "agg_bwd_nchw_k3<gx>";
-    } else {
-        hipLaunchKernelGGL((agg_bwd_nchw_k3<T, P, false, true>), grid, block, 0, s, gout, x, w, gx, gw, g.C, g.wC, g.H,
-                           g.W, items);
-        g_last_kernel = "agg_bwd_nchw_k3<gw>";
-    }
-    return check_launch("agg_bwd_nchw_k3");
+    if (gx && gw) return launch_bwd_k3_sel<T, P, true, true>(gout, x, w, gx, gw, g, s);
+    if (gx) return launch_bwd_k3_sel<T, P, true, false>(gout, x, w, gx, gw, g, s);
+    return launch_bwd_k3_sel<T, P, false, true>(gout, x, w, gx, gw, g, s);
 }
 
 template <typename T>
 int agg_backward_nchw(const T* gout, const T* x, const T* w, T* gx, T* gw, const cot_agg_geom& g, int Ho, int Wo,
                       hipStream_t s) {
     if (is_k3_fast(g) && g.heads == 1) {
-        // P capped at 4: the fused kernel keeps 18*P fp32 of weights / weight-gradients in registers
-        switch (pick_P<T>(g.W, 4)) {
-            case 4: return launch_bwd_k3<T, (sizeof(T) <= 4 ? 4 : 1)>(gout, x, w, gx, gw, g, s);
+        // P capped (default 4): the fused kernel keeps 18*P accumulate-type values of weights / weight-gradients live
+        constexpr int LIM = (int)(16 / sizeof(T));
+        switch (pick_P<T>(g.W, g_tune[2] > 4 ? 4 : g_tune[2])) {
+            case 4: return launch_bwd_k3<T, (LIM >= 4 ? 4 : 1)>(gout, x, w, gx, gw, g, s);
             case 2: return launch_bwd_k3<T, 2>(gout, x, w, gx, gw, g, s);
             default: return launch_bwd_k3<T, 1>(gout, x, w, gx, gw, g, s);
         }

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void agg_bwd_weight_nhwc(const T* __restrict__
     }
 }
 
-static thread_local const char* g_last_kernel_nhwc = "";
+static const char* g_last_kernel_nhwc = "";
 const char* last_kernel_nhwc() { return g_last_kernel_nhwc; }
 
 static inline int grid1d(int64_t total, int block, int64_t cap) {

@@ -8,7 +8,7 @@
 namespace cot {
 
 static thread_local char g_err[512] = "";
-static thread_local const char* g_kernel = "";
+static const char* g_kernel = "";  // diagnostic; backward runs on autograd worker threads, so not thread_local
 
 int set_error(int code, const char* fmt, ...) {
     va_list ap;
@@ -41,6 +41,8 @@ template <typename T>
 int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int, int, int, int, hipStream_t);
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
+int set_tuning_nchw(int key, int value);
+int xchg_mode();
 
 static int out_size(int in, int k, int s, int p, int d) {
     // python: int((in + 2p - (d(k-1)+1)) / s + 1) -- float division, truncation toward zero
@@ -142,6 +144,12 @@ const char* cot_status_string(int status) {
 }
 
 int cot_agg_out_size(int in, int k, int s, int p, int d) { return out_size(in, k, s, p, d); }
+
+int cot_set_tuning(int key, int value) {
+    if (set_tuning_nchw(key, value) != 0) return set_error(COT_ERR_INVALID_ARG, "unknown tuning key %d", key);
+    return COT_OK;
+}
+int cot_xchg_mode(void) { return xchg_mode(); }
 
 int cot_agg_forward(const void* x, const void* w, void* out, const cot_agg_geom* g, int dtype, int layout,
                     void* stream) {

@@ -105,6 +105,15 @@ const char* cot_status_string(int status);
  * (e.g. "agg_fwd_nchw_k3<bf16,P8>"); used by tests to prove the fast path ran. */
 const char* cot_last_kernel(void);
 
+/* Developer knobs for A/B benchmarking (process-global, not part of the drop-in contract):
+ *   key 0: 3x3 fast-path kernel version (0 auto, 1 = v1 scalar-halo kernels, 2 = v2 wave-aligned kernels)
+ *   key 1: max pixels per lane, forward   key 2: max pixels per lane, fused backward
+ *   key 3: lane-exchange primitive (-1 probe on first use, 0 = DPP wave shift, 1 = ds_bpermute) */
+int cot_set_tuning(int key, int value);
+/* 0 if the device probe confirmed the DPP wave_shr/wave_shl semantics the v2 kernels rely on, 1 if the
+ * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */
+int cot_xchg_mode(void);
+
 #ifdef __cplusplus
 }
 #endif

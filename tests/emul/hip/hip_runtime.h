@@ -2,11 +2,18 @@
 //
 // Lets the product's .hip sources be compiled as plain host C++ (amdclang++ -x c++) so that the kernels'
 // index arithmetic can be exercised against the oracle in the GPU-less build container before spending
-// MI355X time.  A launch becomes a loop nest over (block, thread).  Never shipped, never loaded by cotnet_amd/.
+// MI355X time.  A launch runs on 64 host threads = the 64 lanes of a wavefront; the threads walk the grid's
+// waves in the same order, so cross-lane primitives (DPP wave shifts, __shfl_up/down) can be emulated with a
+// shared slot array + two barriers.  Never shipped, never loaded by cotnet_amd/.
 #pragma once
+#include <pthread.h>
+
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <initializer_list>
+#include <thread>
+#include <vector>
 
 #define __global__
 #define __device__
@@ -27,17 +34,66 @@ typedef int hipError_t;
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)        \
-    do {                                                                   \
-        const dim3 g_ = (grid), b_ = (block);                              \
-        gridDim = g_;                                                      \
-        blockDim = b_;                                                     \
-        _Pragma("omp parallel for schedule(static)")                       \
-        for (long bx_ = 0; bx_ < (long)g_.x; ++bx_) {                      \
-            blockIdx = dim3((unsigned)bx_, 0, 0);                          \
-            for (unsigned tx_ = 0; tx_ < b_.x; ++tx_) {                    \
-                threadIdx = dim3(tx_, 0, 0);                               \
-                kernel(__VA_ARGS__);                                       \
-            }                                                              \
-        }                                                                  \
-    } while (0)
+namespace emul {
+struct WaveCtx {
+    pthread_barrier_t bar;
+    uint64_t slot[64];
+};
+inline WaveCtx* g_ctx = nullptr;
+inline thread_local int t_lane = 0;
+
+template <typename V> inline V exchange(V v, int delta, V oob) {  // returns lane (l + delta)'s v, oob outside 0..63
+    uint64_t bits = 0;
+    std::memcpy(&bits, &v, sizeof(V));
+    g_ctx->slot[t_lane] = bits;
+    pthread_barrier_wait(&g_ctx->bar);
+    const int src = t_lane + delta;
+    V r = oob;
+    if (src >= 0 && src < 64) std::memcpy(&r, &g_ctx->slot[src], sizeof(V));
+    pthread_barrier_wait(&g_ctx->bar);
+    return r;
+}
+
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    gridDim = grid;
+    blockDim = block;
+    WaveCtx ctx;
+    pthread_barrier_init(&ctx.bar, nullptr, 64);
+    g_ctx = &ctx;
+    const unsigned waves = (block.x + 63) / 64;
+    std::vector<std::thread> lanes;
+    for (int l = 0; l < 64; ++l) {
+        lanes.emplace_back([=, &body]() {
+            t_lane = l;
+            for (unsigned b = 0; b < grid.x; ++b)
+                for (unsigned wv = 0; wv < waves; ++wv) {
+                    blockIdx = dim3(b, 0, 0);
+                    threadIdx = dim3(wv * 64 + l, 0, 0);
+                    if (threadIdx.x < block.x) body();
+                }
+        });
+    }
+    for (auto& t : lanes) t.join();
+    pthread_barrier_destroy(&ctx.bar);
+    g_ctx = nullptr;
+}
+}  // namespace emul
+
+inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+// only the two DPP controls the kernels use: 0x138 = wave_shr:1 (lane l <- l-1), 0x130 = wave_shl:1 (l <- l+1)
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    return emul::exchange<int>(src, ctrl == 0x138 ? -1 : +1, old);
+}
+template <typename V> inline V __shfl_up(V v, int d) { return emul::exchange<V>(v, -d, v); }
+template <typename V> inline V __shfl_down(V v, int d) { return emul::exchange<V>(v, +d, v); }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emul::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
+// host stand-ins for the few runtime calls the library makes outside launches
+inline hipError_t hipMalloc(void** p, size_t n) { *p = ::operator new(n); return 0; }
+inline hipError_t hipFree(void* p) { ::operator delete(p); return 0; }
+#define hipMemcpyDeviceToHost 2
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }

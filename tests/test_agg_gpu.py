@@ -161,8 +161,9 @@ def test_module_surface_noncontiguous_and_cpu_route():
     # needs_input_grad honoured: only w requires grad
     wg = w.to(DEV).requires_grad_(True)
     conv(x.to(DEV), wg).sum().backward()
+    torch.cuda.synchronize()
     assert wg.grad is not None
-    assert "gw" in _lib.last_kernel() and "gx" not in _lib.last_kernel()
+    assert "gw" in _lib.last_kernel() and "gx" not in _lib.last_kernel(), _lib.last_kernel()
     with pytest.raises(AssertionError):
         conv(x.to(DEV), torch.randn(2, 1, 3, 9, 9, 8, device=DEV))  # 16 % 3 != 0
 
