@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256) void agg_fwd_nchw_k3_v2(const T* __restrict__ 
 }
 
 // fused backward v2 (heads == 1): same mapping; shifted weights via lane exchange; gO / x rows prefetched.
-template <typename T, int P, int XCHG, bool DO_GX, bool DO_GW>
-__global__ __launch_bounds__(256) void agg_bwd_nchw_k3_v2(const T* __restrict__ gout, const T* __restrict__ x,
+template <typename T, int P, int XCHG, bool DO_GX, bool DO_GW, int MINW>
+__global__ __launch_bounds__(256, MINW) void agg_bwd_nchw_k3_v2(const T* __restrict__ gout, const T* __restrict__ x,
                                                          const T* __restrict__ w, T* __restrict__ gx,
                                                          T* __restrict__ gw, int C, int wC, int H, int W, int L,
                                                          int64_t items) {
@@ -537,10 +537,11 @@ static const char* g_last_kernel = "";  // diagnostic only (written by whichever
 const char* last_kernel_nchw() { return g_last_kernel; }
 
 // run-time tuning knobs (cot_set_tuning): 0 = kernel version (0 auto, 1 force v1, 2 force v2),
-// 1 = max P forward, 2 = max P backward, 3 = lane-exchange primitive (-1 auto/probe, 0 DPP, 1 ds_bpermute)
-static int g_tune[4] = {0, 8, 4, -1};
+// 1 = max P forward, 2 = max P backward, 3 = lane-exchange primitive (-1 auto/probe, 0 DPP, 1 ds_bpermute),
+// 4 = fused-backward register cap (0 none, 4 = compile for >= 4 waves/SIMD)
+static int g_tune[5] = {0, 4, 4, -1, 0};  // fwd P=4 beats P=8 for bf16 (26.6 vs 38.4 us on N80xC64x56x56)
 int set_tuning_nchw(int key, int value) {
-    if (key < 0 || key > 3) return -1;
+    if (key < 0 || key > 4) return -1;
     g_tune[key] = value;
     return 0;
 }
@@ -639,12 +640,15 @@ static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw
         const int64_t items = (int64_t)g.N * g.wC * g.H * segs;
         const int64_t waves = ceil_div64(items, L);
         const dim3 grid((unsigned)ceil_div64(waves, 4)), block(256);
-        if (xchg_mode() == 0)
-            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 0, GX, GW>), grid, block, 0, s, gout, x, w, gx, gw, g.C, g.wC,
-                               g.H, g.W, L, items);
+        if (xchg_mode() != 0)
+            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 1, GX, GW, 1>), grid, block, 0, s, gout, x, w, gx, gw, g.C,
+                               g.wC, g.H, g.W, L, items);
+        else if (g_tune[4] >= 4)  // register cap: >= 4 waves per SIMD (<= 128 VGPRs)
+            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 0, GX, GW, 4>), grid, block, 0, s, gout, x, w, gx, gw, g.C,
+                               g.wC, g.H, g.W, L, items);
         else
-            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 1, GX, GW>), grid, block, 0, s, gout, x, w, gx, gw, g.C, g.wC,
-                               g.H, g.W, L, items);
+            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 0, GX, GW, 1>), grid, block, 0, s, gout, x, w, gx, gw, g.C,
+                               g.wC, g.H, g.W, L, items);
         g_last_kernel = GX && GW ? "agg_bwd_nchw_k3_v2<gx,gw>" : GX ? "agg_bwd_nchw_k3_v2<gx>" : "agg_bwd_nchw_k3_v2<gw>";
         return check_launch(g_last_kernel);
     }

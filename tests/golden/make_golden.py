@@ -194,6 +194,17 @@ def make_layer_fixtures(ref_cotnet):
             if mode == "train":
                 out["train_bn_running_mean"] = layer.bn.running_mean.numpy().copy()
                 out["train_bn_running_var"] = layer.bn.running_var.numpy().copy()
+        # the same layer, weights and inputs in fp64 (conditioning-free pin for the GPU fp64 run)
+        layer64 = getattr(ref_cotnet, cls)(dim, 3).double()
+        state64 = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
+        for mode in ("eval", "train"):
+            layer64.load_state_dict(state64)
+            layer64.train(mode == "train")
+            xin = x.double().clone().requires_grad_(True)
+            y = layer64(xin)
+            y.backward(gout.double())
+            out[f"{mode}_y_f64"] = y.detach().numpy()
+            out[f"{mode}_gx_f64"] = xin.grad.numpy()
         np.savez_compressed(os.path.join(HERE, f"layer_{name}.npz"), seed=np.int64(seed),
                             meta=json.dumps(dict(cls=cls, dim=dim, B=B, H=H, W=W)),
                             **{"sd__" + k: v.numpy() for k, v in state.items()}, **out)
