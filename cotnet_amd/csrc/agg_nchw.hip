@@ -531,6 +531,233 @@ __global__ __launch_bounds__(256, MINW) void agg_bwd_nchw_k3_v2(const T* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 fast path, version 3: LDS-staged channel slabs (asynchronous global->LDS DMA)
+// ------------------------------------------------------------------------------------------------
+// v2 still reads every x row three times through L1/L2 (rows h-1, h, h+1 are fetched by three lanes) and keeps only
+// two channels' rows in flight per lane.  v3 stages, per 256-lane workgroup, the x rows of ALL channels that share
+// the workgroup's weights in LDS:
+//   * per image-head the (wc, h) rows are flattened to rho = wc*H + h; a workgroup owns TR = 4*R consecutive rho
+//     (R = floor(64/segs) whole rows per wave, as in v2).  For channel group j (c = wc + j*wC) those rows plus one
+//     halo row above and below are ONE contiguous range of x, because channel wc+1 follows channel wc in memory;
+//   * the J ranges ("slabs") are copied with global_load_lds_dwordx4: 16 B per lane, no VGPR round trip, every
+//     byte of the tile in flight at once (34 KB per workgroup for bf16 stage 1, x4-5 workgroups per CU);
+//   * after one barrier each lane reads its three P-wide row vectors per channel with aligned ds_read_b128 (lanes
+//     read consecutive 16 B -> conflict-free), takes the two halo columns from its neighbour lanes (DPP) and
+//     streams the P-wide results to HBM.  x is read from HBM once (+ (TR+2)/TR halo rows), the weights once.
+// Rows outside the image are never dereferenced as data: a lane substitutes zeros when h-1 < 0 or h+1 >= H, so the
+// slab may contain the neighbouring plane's rows (or clamped garbage at the tensor ends) harmlessly.
+
+template <typename T, int P>
+__device__ __forceinline__ Vec<T, P> lds_row(const T* __restrict__ slab, int64_t idx, bool row_ok) {
+    Vec<T, P> v;
+    if (row_ok) {
+        v = *reinterpret_cast<const Vec<T, P>*>(slab + idx);
+    } else {
+#pragma unroll
+        for (int i = 0; i < P; ++i) v.v[i] = (T)0;
+    }
+    return v;
+}
+
+// cooperative async copy of `nslab` slabs of `sle` elements: slab s starts at element src0 + s*sstride of `base`
+template <typename T>
+__device__ __forceinline__ void stage_slabs(const T* __restrict__ base, int64_t src0, int64_t sstride, int nslab,
+                                            int sle, int64_t total_elems, T* __restrict__ lds) {
+    constexpr int VE = 16 / sizeof(T);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int chunks = sle / VE, total = nslab * chunks;
+    for (int q0 = 0; q0 < total; q0 += 256) {
+        const int q = q0 + tid;
+        if (q < total) {  // lanes past the end are masked off (EXEC): they transfer nothing
+            const int sidx = q / chunks, ch = q - sidx * chunks;
+            int64_t e = src0 + (int64_t)sidx * sstride + (int64_t)ch * VE;
+            if (e + VE > total_elems) e = total_elems - VE;  // beyond the tensor: in-bounds bytes, never used as data
+            COT_ASYNC_COPY16(base + e, lds + (int64_t)(q0 + wave * 64) * VE);
+        }
+    }
+}
+
+template <typename T, int P, int XCHG>
+__global__ __launch_bounds__(256) void agg_fwd_nchw_k3_lds(const T* __restrict__ x, const T* __restrict__ w,
+                                                          T* __restrict__ out, int heads, int C, int wC, int H, int W,
+                                                          int R, int tiles_per_nh, int sle, int64_t x_elems) {
+    typedef typename AccOf<T>::type A;
+    constexpr int VE = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    T* slab = reinterpret_cast<T*>(cot_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int segs = W / P, J = C / wC, TR = 4 * R, rows_nh = wC * H;
+    const int64_t HW = (int64_t)H * W;
+    const int tile = blockIdx.x % tiles_per_nh;
+    const int64_t nh = blockIdx.x / tiles_per_nh;
+    const int n = (int)(nh / heads);
+    const int rho0 = tile * TR;
+    int64_t gs = (int64_t)(rho0 - 1) * W;  // first slab element (row rho0-1), rounded down to a 16-byte chunk
+    if (gs < 0) gs = 0;
+    gs &= ~(int64_t)(VE - 1);
+    stage_slabs<T>(x, (int64_t)n * C * HW + gs, (int64_t)wC * HW, J, sle, x_elems, slab);
+
+    // this lane's item: row r of the wave, segment seg of the row
+    int r = lane / segs, seg = lane - r * segs;
+    int rho = rho0 + wave * R + r;
+    const bool valid = r < R && rho < rows_nh;
+    if (!valid) {  // park on the last valid row's last segment: keeps neighbours' halo logic intact, never stores
+        rho = rows_nh - 1;
+        seg = segs - 1;
+    }
+    const int wc = rho / H, h = rho - wc * H, w0 = seg * P;
+    const bool has_left = seg > 0, has_right = seg < segs - 1;
+
+    Vec<T, P> wr[9];
+    {
+        const T* wp = w + (nh * wC + wc) * 9 * HW + (int64_t)h * W + w0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[t] = ldv<T, P>(wp + t * HW);
+    }
+    __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes every wave's slab chunks visible
+
+    const int64_t lidx = (int64_t)rho * W + w0 - gs;  // centre-row vector of this item inside a slab
+    T* op = out + nh * C * HW + (int64_t)rho * W + w0;
+    const int64_t cstride = (int64_t)wC * HW;
+    for (int j = 0; j < J; ++j) {
+        const T* sj = slab + (int64_t)j * sle;
+        A xr[3][P + 2];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const int hr = h - 1 + rr;
+            expand_row<T, P, XCHG, A>(lds_row<T, P>(sj, lidx + (int64_t)(rr - 1) * W, hr >= 0 && hr < H), has_left,
+                                      has_right, xr[rr]);
+        }
+        Vec<T, P> o;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            A acc = 0;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc += (A)wr[kh * 3 + kw].v[i] * xr[kh][i + kw];
+            o.v[i] = (T)acc;
+        }
+        if (valid) stv<T, P>(op + j * cstride, o);
+    }
+}
+
+// fused backward v3 (heads == 1): gO and x slabs staged JP channels at a time (JP*2 slabs resident)
+template <typename T, int P, int XCHG, bool DO_GX, bool DO_GW>
+__global__ __launch_bounds__(256) void agg_bwd_nchw_k3_lds(const T* __restrict__ gout, const T* __restrict__ x,
+                                                          const T* __restrict__ w, T* __restrict__ gx,
+                                                          T* __restrict__ gw, int C, int wC, int H, int W, int R,
+                                                          int tiles_per_n, int sle, int JP, int64_t elems) {
+    typedef typename AccOf<T>::type A;
+    constexpr int VE = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    T* gslab = reinterpret_cast<T*>(cot_smem);
+    T* xslab = gslab + (int64_t)JP * sle;  // (only used when DO_GW)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int segs = W / P, J = C / wC, TR = 4 * R, rows_n = wC * H;
+    const int64_t HW = (int64_t)H * W;
+    const int tile = blockIdx.x % tiles_per_n;
+    const int n = blockIdx.x / tiles_per_n;
+    const int rho0 = tile * TR;
+    int64_t gs = (int64_t)(rho0 - 1) * W;
+    if (gs < 0) gs = 0;
+    gs &= ~(int64_t)(VE - 1);
+
+    int r = lane / segs, seg = lane - r * segs;
+    int rho = rho0 + wave * R + r;
+    const bool valid = r < R && rho < rows_n;
+    if (!valid) {
+        rho = rows_n - 1;
+        seg = segs - 1;
+    }
+    const int wc = rho / H, h = rho - wc * H, w0 = seg * P;
+    const bool has_left = seg > 0, has_right = seg < segs - 1;
+    const int64_t plane = (int64_t)n * wC + wc;
+
+    A ws[9][P];
+    if (DO_GX) {
+        const T* wp = w + plane * 9 * HW;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int t = kh * 3 + kw;
+                A row[P + 2];
+                expand_row<T, P, XCHG, A>(load_row_raw<T, P>(wp + t * HW, h + 1 - kh, H, W, w0), has_left, has_right,
+                                          row);
+#pragma unroll
+                for (int i = 0; i < P; ++i) ws[t][i] = row[i + 2 - kw];
+            }
+        }
+    }
+    A gwacc[9][P];
+    if (DO_GW) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < P; ++i) gwacc[t][i] = (A)0;
+    }
+    const int64_t cstride = (int64_t)wC * HW;
+    const int64_t img = (int64_t)n * C * HW;
+    const int64_t lidx = (int64_t)rho * W + w0 - gs;
+    for (int j0 = 0; j0 < J; j0 += JP) {
+        const int jn = (J - j0 < JP) ? (J - j0) : JP;
+        if (j0 > 0) __syncthreads();  // everyone finished reading the previous phase's slabs
+        stage_slabs<T>(gout, img + (int64_t)j0 * cstride + gs, cstride, jn, sle, elems, gslab);
+        if (DO_GW) stage_slabs<T>(x, img + (int64_t)j0 * cstride + gs, cstride, jn, sle, elems, xslab);
+        __syncthreads();
+        for (int jj = 0; jj < jn; ++jj) {
+            const T* gj = gslab + (int64_t)jj * sle;
+            A gr[3][P + 2];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const int hr = h - 1 + rr;
+                if (DO_GX || rr == 1)
+                    expand_row<T, P, XCHG, A>(lds_row<T, P>(gj, lidx + (int64_t)(rr - 1) * W, hr >= 0 && hr < H),
+                                              has_left, has_right, gr[rr]);
+            }
+            if (DO_GX) {
+                Vec<T, P> o;
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    A acc = 0;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc += ws[kh * 3 + kw][i] * gr[2 - kh][i + 2 - kw];
+                    o.v[i] = (T)acc;
+                }
+                if (valid) stv<T, P>(gx + img + (int64_t)(j0 + jj) * cstride + (int64_t)rho * W + w0, o);
+            }
+            if (DO_GW) {
+                const T* xj = xslab + (int64_t)jj * sle;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int hr = h - 1 + kh;
+                    A xr[P + 2];
+                    expand_row<T, P, XCHG, A>(lds_row<T, P>(xj, lidx + (int64_t)(kh - 1) * W, hr >= 0 && hr < H),
+                                              has_left, has_right, xr);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int i = 0; i < P; ++i) gwacc[kh * 3 + kw][i] += xr[i + kw] * gr[1][i + 1];
+                }
+            }
+        }
+    }
+    if (DO_GW && valid) {
+        T* gp = gw + plane * 9 * HW + (int64_t)h * W + w0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            Vec<T, P> o;
+#pragma unroll
+            for (int i = 0; i < P; ++i) o.v[i] = (T)gwacc[t][i];
+            stv<T, P>(gp + t * HW, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
 static const char* g_last_kernel = "";  // diagnostic only (written by whichever thread launched last)
@@ -538,7 +765,7 @@ const char* last_kernel_nchw() { return g_last_kernel; }
 
 // run-time tuning knobs (cot_set_tuning): 0 = kernel version (0 auto, 1 force v1, 2 force v2),
 // 1 = max P forward, 2 = max P backward, 3 = lane-exchange primitive (-1 auto/probe, 0 DPP, 1 ds_bpermute),
-// 4 = fused-backward register cap (0 none, 4 = compile for >= 4 waves/SIMD)
+// 4 = v3 fused backward: channel groups staged in LDS per phase (0 = default 4)
 static int g_tune[5] = {0, 4, 4, -1, 0};  // fwd P=4 beats P=8 for bf16 (26.6 vs 38.4 us on N80xC64x56x56)
 int set_tuning_nchw(int key, int value) {
     if (key < 0 || key > 4) return -1;
@@ -587,9 +814,47 @@ template <typename T> static inline int pick_P(int W, int maxP) {
 
 static inline bool use_v2(int W, int P) { return g_tune[0] != 1 && (W / P) <= 64; }
 
+// v3 (LDS slabs) needs 16-byte aligned channel-group / image strides and a tile that fits LDS comfortably
+struct LdsPlan {
+    bool ok;
+    int R, TR, tiles, sle;
+    size_t lds_bytes;
+};
+template <typename T> static inline LdsPlan plan_lds(const cot_agg_geom& g, int P, int nslab) {
+    LdsPlan p{};
+    constexpr int VE = (int)(16 / sizeof(T));
+    const int segs = g.W / P;
+    const int64_t HW = (int64_t)g.H * g.W;
+    if (segs > 64 || ((int64_t)g.wC * HW) % VE != 0 || ((int64_t)g.C * HW) % VE != 0) return p;
+    if ((int64_t)g.N * g.C * HW < VE) return p;
+    p.R = 64 / segs;
+    p.TR = 4 * p.R;
+    p.tiles = (g.wC * g.H + p.TR - 1) / p.TR;
+    p.sle = (((p.TR + 2) * g.W + VE) + VE - 1) / VE * VE;  // rows + alignment slack, multiple of a 16-byte chunk
+    const int64_t chunks = (int64_t)nslab * (p.sle / VE);
+    p.lds_bytes = (size_t)((chunks + 255) / 256 * 256) * 16;  // every lane of the last copy round lands in-bounds
+    p.ok = p.lds_bytes <= 64 * 1024;
+    return p;
+}
+
 template <typename T, int P>
 static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, hipStream_t s) {
     static_assert(P * sizeof(T) <= 16, "row vector wider than 16 bytes");
+    if (g_tune[0] == 3 && sizeof(T) <= 4) {
+        const LdsPlan p = plan_lds<T>(g, P, g.C / g.wC);
+        if (p.ok) {
+            const dim3 grid((unsigned)((int64_t)p.tiles * g.N * g.heads)), block(256);
+            const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
+            if (xchg_mode() == 0)
+                hipLaunchKernelGGL((agg_fwd_nchw_k3_lds<T, P, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe);
+            else
+                hipLaunchKernelGGL((agg_fwd_nchw_k3_lds<T, P, 1>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe);
+            g_last_kernel = "agg_fwd_nchw_k3_lds";
+            return check_launch(g_last_kernel);
+        }
+    }
     if (use_v2(g.W, P)) {
         const int segs = g.W / P, L = (64 / segs) * segs;
         const int64_t items = (int64_t)g.N * g.heads * g.wC * g.H * segs;
@@ -635,6 +900,23 @@ int agg_forward_nchw(const T* x, const T* w, T* out, const cot_agg_geom& g, int 
 template <typename T, int P, bool GX, bool GW>
 static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw, const cot_agg_geom& g,
                              hipStream_t s) {
+    if (g_tune[0] == 3 && sizeof(T) <= 4) {
+        const int J = g.C / g.wC;
+        int JP = g_tune[4] > 0 && g_tune[4] <= J ? g_tune[4] : (J >= 4 ? 4 : J);
+        const LdsPlan p = plan_lds<T>(g, P, (GW ? 2 : 1) * JP);
+        if (p.ok) {
+            const dim3 grid((unsigned)((int64_t)p.tiles * g.N)), block(256);
+            const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
+            if (xchg_mode() == 0)
+                hipLaunchKernelGGL((agg_bwd_nchw_k3_lds<T, P, 0, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
+                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
+            else
+                hipLaunchKernelGGL((agg_bwd_nchw_k3_lds<T, P, 1, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
+                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
+            g_last_kernel = GX && GW ? "agg_bwd_nchw_k3_lds<gx,gw>" : GX ? "agg_bwd_nchw_k3_lds<gx>" : "agg_bwd_nchw_k3_lds<gw>";
+            return check_launch(g_last_kernel);
+        }
+    }
     if (use_v2(g.W, P)) {
         const int segs = g.W / P, L = (64 / segs) * segs;
         const int64_t items = (int64_t)g.N * g.wC * g.H * segs;
@@ -642,9 +924,6 @@ static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw
         const dim3 grid((unsigned)ceil_div64(waves, 4)), block(256);
         if (xchg_mode() != 0)
             hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 1, GX, GW, 1>), grid, block, 0, s, gout, x, w, gx, gw, g.C,
-                               g.wC, g.H, g.W, L, items);
-        else if (g_tune[4] >= 4)  // register cap: >= 4 waves per SIMD (<= 128 VGPRs)
-            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 0, GX, GW, 4>), grid, block, 0, s, gout, x, w, gx, gw, g.C,
                                g.wC, g.H, g.W, L, items);
         else
             hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 0, GX, GW, 1>), grid, block, 0, s, gout, x, w, gx, gw, g.C,

@@ -31,6 +31,15 @@ template <typename T, int V> __device__ __forceinline__ void stv(T* p, const Vec
     *reinterpret_cast<Vec<T, V>*>(p) = v;
 }
 
+// 16-byte asynchronous global -> LDS copy (global_load_lds_dwordx4): per-lane source address, destination is the
+// WAVE-UNIFORM LDS address `lds_wave_base` + lane*16.  No VGPR round trip; completion is tracked by vmcnt and
+// drained by the s_waitcnt the compiler places before the next __syncthreads().
+#ifndef COT_ASYNC_COPY16  // (tests/emul pre-defines this one primitive for its host build)
+#define COT_ASYNC_COPY16(gptr, lds_wave_base)                                                                  \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+#endif
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -42,10 +42,13 @@ def main():
         "v1": [(0, 1)], "v2dpp": [(0, 2), (3, 0)], "v2shfl": [(0, 2), (3, 1)],
         "v2dpp_fP4": [(0, 2), (3, 0), (1, 4)], "v2dpp_bP2": [(0, 2), (3, 0), (2, 2)],
         "v2dpp_fP2": [(0, 2), (3, 0), (1, 2)],
+        "v2": [(0, 2), (1, 4)], "v2_fP8": [(0, 2), (1, 8)],
+        "v3": [(0, 3), (1, 4), (4, 4)], "v3_fP8": [(0, 3), (1, 8), (4, 4)], "v3_jp2": [(0, 3), (1, 4), (4, 2)],
+        "v3_jp8": [(0, 3), (1, 8), (4, 8)], "v3_bP2": [(0, 3), (1, 4), (2, 2), (4, 4)],
     }
 
     def set_variant(name):
-        for k, v in ((0, 0), (1, 8), (2, 4), (3, -1)):
+        for k, v in ((0, 0), (1, 4), (2, 4), (3, -1), (4, 0)):
             L.cot_set_tuning(k, v)
         for k, v in VAR[name]:
             L.cot_set_tuning(k, v)
@@ -123,7 +126,7 @@ def main():
                 print(msg, flush=True)
             del sets
             torch.cuda.empty_cache()
-    for k, v in ((0, 0), (1, 8), (2, 4), (3, -1)):
+    for k, v in ((0, 0), (1, 4), (2, 4), (3, -1), (4, 0)):
         L.cot_set_tuning(k, v)
     if args.out:
         json.dump(rows, open(args.out, "w"), indent=1)

@@ -35,49 +35,68 @@ inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 
 namespace emul {
+// One host thread per lane of a WORKGROUP (<= 1024).  All threads walk the grid's blocks in the same order, so
+// __syncthreads() is a barrier over the block's threads and the wave-level exchanges are barriers over 64 of them.
 struct WaveCtx {
     pthread_barrier_t bar;
     uint64_t slot[64];
 };
-inline WaveCtx* g_ctx = nullptr;
-inline thread_local int t_lane = 0;
+struct BlockCtx {
+    pthread_barrier_t bar;
+    WaveCtx wave[16];
+};
+inline BlockCtx* g_blk = nullptr;
+inline thread_local int t_lane = 0, t_wave = 0;
+alignas(16) inline char g_lds[160 * 1024];
 
 template <typename V> inline V exchange(V v, int delta, V oob) {  // returns lane (l + delta)'s v, oob outside 0..63
+    WaveCtx& c = g_blk->wave[t_wave];
     uint64_t bits = 0;
     std::memcpy(&bits, &v, sizeof(V));
-    g_ctx->slot[t_lane] = bits;
-    pthread_barrier_wait(&g_ctx->bar);
+    c.slot[t_lane] = bits;
+    pthread_barrier_wait(&c.bar);
     const int src = t_lane + delta;
     V r = oob;
-    if (src >= 0 && src < 64) std::memcpy(&r, &g_ctx->slot[src], sizeof(V));
-    pthread_barrier_wait(&g_ctx->bar);
+    if (src >= 0 && src < 64) std::memcpy(&r, &c.slot[src], sizeof(V));
+    pthread_barrier_wait(&c.bar);
     return r;
 }
 
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     gridDim = grid;
     blockDim = block;
-    WaveCtx ctx;
-    pthread_barrier_init(&ctx.bar, nullptr, 64);
-    g_ctx = &ctx;
-    const unsigned waves = (block.x + 63) / 64;
-    std::vector<std::thread> lanes;
-    for (int l = 0; l < 64; ++l) {
-        lanes.emplace_back([=, &body]() {
-            t_lane = l;
-            for (unsigned b = 0; b < grid.x; ++b)
-                for (unsigned wv = 0; wv < waves; ++wv) {
-                    blockIdx = dim3(b, 0, 0);
-                    threadIdx = dim3(wv * 64 + l, 0, 0);
-                    if (threadIdx.x < block.x) body();
-                }
+    const unsigned nthreads = (block.x + 63) / 64 * 64, waves = nthreads / 64;
+    BlockCtx ctx;
+    pthread_barrier_init(&ctx.bar, nullptr, nthreads);
+    for (unsigned w = 0; w < waves; ++w) pthread_barrier_init(&ctx.wave[w].bar, nullptr, 64);
+    g_blk = &ctx;
+    std::vector<std::thread> threads;
+    for (unsigned t = 0; t < nthreads; ++t) {
+        threads.emplace_back([=, &body]() {
+            t_lane = t & 63;
+            t_wave = t >> 6;
+            for (unsigned b = 0; b < grid.x; ++b) {
+                blockIdx = dim3(b, 0, 0);
+                threadIdx = dim3(t, 0, 0);
+                if (t < block.x) body();
+                pthread_barrier_wait(&g_blk->bar);  // block boundary: LDS is reused by the next block
+            }
         });
     }
-    for (auto& t : lanes) t.join();
+    for (auto& th : threads) th.join();
     pthread_barrier_destroy(&ctx.bar);
-    g_ctx = nullptr;
+    for (unsigned w = 0; w < waves; ++w) pthread_barrier_destroy(&ctx.wave[w].bar);
+    g_blk = nullptr;
 }
 }  // namespace emul
+
+inline void __syncthreads() { pthread_barrier_wait(&emul::g_blk->bar); }
+// dynamic LDS: `extern __shared__ ... char cot_smem[]` in a kernel refers to this array
+#define __shared__
+namespace cot { alignas(16) inline char cot_smem[160 * 1024]; }  // the kernels live in namespace cot
+// async 16-byte global->LDS copy: destination = wave-uniform base + lane*16
+#define COT_ASYNC_COPY16(gptr, lds_wave_base) \
+    std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)
 
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
