@@ -12,9 +12,11 @@ gradients averaged with cotnet_amd.data_parallel.GradBucketReducer (RCCL all-red
 K steps are timed between barrier + torch.cuda.synchronize() pairs; the slowest rank's time is reported.
 
 Extra objects on the line:
-  roofline      the dominant aggregation kernel of the timed region: algorithmic bytes per launch / mean launch
-                duration, measured with HIP events on the launch stream (cotnet_amd.aggregation_zeropad.profile_*),
-                against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md).  `kernels` lists every aggregation geometry.
+  roofline      the dominant aggregation kernel of the timed region (largest total device time): algorithmic bytes
+                per launch / mean launch duration.  Durations come from HIP start/stop events attached to each kernel
+                dispatch on its launch stream (hipExtLaunchKernelGGL inside libcotnet_hip.so, cot_profile_begin/_end),
+                i.e. device execution time as rocprofv3 --kernel-trace reports it, over the K timed steps.
+                Peak = 8 TB/s HBM3E (MI355X_MICROARCH.md).  `kernels` lists every aggregation geometry.
   cpu_baseline  rank 0, N=1 only: the reference's own aggregation kernels compiled for the host CPU
                 (oracle/_ref, kind "reference"; falls back to oracle/agg_oracle.c, kind "port"), OpenMP over all
                 host cores, timed on 4 images per CoT-layer geometry and scaled to images/s of AGGREGATION WORK ONLY
@@ -104,6 +106,19 @@ def cpu_baseline():
                       f">=3), scaled by layer counts 3/4/6/3; ms per image per layer: {detail}"}
 
 
+def roctx_window(resume):
+    """When run under `rocprofv3 --marker-trace`, COT_ROCTX=1 limits collection to the timed region (MIOpen's
+    one-off convolution search during warm-up otherwise dominates the kernel statistics)."""
+    if os.environ.get("COT_ROCTX") != "1":
+        return
+    try:
+        import ctypes
+        lib = ctypes.CDLL("librocprofiler-sdk-roctx.so")
+        (lib.roctxProfilerResume if resume else lib.roctxProfilerPause)(ctypes.c_uint64(0))
+    except OSError:
+        pass
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,9 +175,11 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    roctx_window(resume=False)
     for _ in range(args.warmup):
         loss = step()
     barrier()
+    roctx_window(resume=True)
     if not args.no_kernel_timing:
         agg_mod.profile_begin()
     barrier()
@@ -172,6 +189,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    roctx_window(resume=False)
     recs = agg_mod.profile_end() if not args.no_kernel_timing else []
     final_loss = float(loss)
 
@@ -183,16 +201,16 @@ def main():
     if rank == 0:
         # ---- roofline of the aggregation kernels, from the HIP events of the timed region
         groups = {}
-        for kind, g, dtype, layout, ms, nbytes in recs:
+        for kind, g, dtype, layout, ms, nbytes, kname in recs:
             key = (kind, g[1], g[2], str(dtype).replace("torch.", ""), "nhwc" if layout else "nchw")
-            e = groups.setdefault(key, {"ms": 0.0, "n": 0, "bytes": nbytes, "N": g[0]})
+            e = groups.setdefault(key, {"ms": 0.0, "n": 0, "bytes": nbytes, "N": g[0], "kernel": kname})
             e["ms"] += ms
             e["n"] += 1
         kernels = []
         for (kind, C, H, dt, lay), e in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
             avg_ms = e["ms"] / e["n"]
             gbs = e["bytes"] / (avg_ms * 1e-3) / 1e9
-            kernels.append({"kernel": f"agg_{kind}_{lay}", "shape": f"N{e['N']}xC{C}x{H}x{H}", "dtype": dt,
+            kernels.append({"kernel": e["kernel"], "op": f"agg_{kind}_{lay}", "shape": f"N{e['N']}xC{C}x{H}x{H}", "dtype": dt,
                             "launches": e["n"], "avg_us": round(avg_ms * 1e3, 2), "GBs": round(gbs, 1),
                             "frac": round(gbs / HBM_PEAK_GBS, 4), "total_ms": round(e["ms"], 3)})
         roofline = None

@@ -22,6 +22,12 @@ class AggGeom(ctypes.Structure):
         "N", "C", "H", "W", "heads", "wC", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw")]
 
 
+class ProfileRec(ctypes.Structure):
+    """mirror of `cot_profile_rec`"""
+    _fields_ = [("kernel", ctypes.c_char * 48), ("kind", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("dtype", ctypes.c_int32), ("layout", ctypes.c_int32), ("geom", AggGeom), ("ms", ctypes.c_float)]
+
+
 # every symbol include/cotnet_amd.h declares: (restype, argtypes)
 _P, _I = ctypes.c_void_p, ctypes.c_int
 _G = ctypes.POINTER(AggGeom)
@@ -40,6 +46,8 @@ SYMBOLS = {
     "cot_aggmix_backward_weight": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),
     "cot_set_tuning": (_I, [_I, _I]),
     "cot_xchg_mode": (_I, []),
+    "cot_profile_begin": (_I, []),
+    "cot_profile_end": (_I, [ctypes.POINTER(ProfileRec), _I]),
 }
 
 

@@ -73,43 +73,40 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# ---- optional in-situ kernel timing (bench.py): HIP events recorded on the launch stream around each launch ----
-_PROFILE = None
-
-
+# ---- optional in-situ kernel timing (bench.py) ---------------------------------------------------------------
+# The library attaches start/stop events to each kernel dispatch (cot_profile_begin/_end in include/cotnet_amd.h),
+# so durations are device execution times -- the same quantity rocprofv3 --kernel-trace reports.
 def profile_begin():
-    """start collecting (kind, geometry, dtype, layout, start_event, end_event) for every aggregation launch"""
-    global _PROFILE
-    _PROFILE = []
+    _lib.check(_lib.lib().cot_profile_begin(), "cot_profile_begin")
 
 
-def profile_end():
-    """stop collecting; returns [(kind, (N,C,H,W,heads,wC,k), dtype, layout, milliseconds, algorithmic_bytes)]"""
-    global _PROFILE
-    recs, _PROFILE = _PROFILE or [], None
-    torch.cuda.synchronize()
+def profile_end(max_records=65536):
+    """-> [(kind 'fwd'|'bwd', (N,C,H,W,heads,wC,k), torch dtype, layout, milliseconds, algorithmic_bytes, kernel)]"""
+    buf = (_lib.ProfileRec * max_records)()
+    n = min(_lib.lib().cot_profile_end(buf, max_records), max_records)
+    dts = {_lib.COT_F32: torch.float32, _lib.COT_F64: torch.float64, _lib.COT_BF16: torch.bfloat16,
+           _lib.COT_F16: torch.float16}
     out = []
-    for kind, g, dtype, layout, e0, e1, nbytes in recs:
-        out.append((kind, g, dtype, layout, e0.elapsed_time(e1), nbytes))
+    for r in buf[:n]:
+        g = r.geom
+        dt = dts[r.dtype]
+        e = torch.empty((), dtype=dt).element_size()
+        Ho = _lib.lib().cot_agg_out_size(g.H, g.kh, g.sh, g.ph, g.dh)
+        Wo = _lib.lib().cot_agg_out_size(g.W, g.kw, g.sw, g.pw, g.dw)
+        x_el = g.N * g.C * g.H * g.W
+        w_el = g.N * g.heads * g.wC * g.kh * g.kw * Ho * Wo
+        o_el = g.N * g.heads * g.C * Ho * Wo
+        if r.kind == 0:
+            nbytes = e * (x_el + w_el + o_el)                      # x + w + out, each once
+        else:
+            nbytes = e * o_el                                       # gO
+            if r.flags & 1:
+                nbytes += e * (w_el + x_el)                         # w read, gX written
+            if r.flags & 2:
+                nbytes += e * (x_el + w_el)                         # x read, gW written
+        out.append(("fwd" if r.kind == 0 else "bwd", (g.N, g.C, g.H, g.W, g.heads, g.wC, g.kh), dt, r.layout,
+                    float(r.ms), nbytes, r.kernel.decode()))
     return out
-
-
-def _prof_open():
-    if _PROFILE is None:
-        return None
-    e0 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    return e0
-
-
-def _prof_close(e0, kind, geom, tensors, dtype, layout):
-    if e0 is None:
-        return
-    e1 = torch.cuda.Event(enable_timing=True)
-    e1.record()
-    nbytes = sum(t.numel() * t.element_size() for t in tensors if t is not None)  # algorithmic: each tensor once
-    _PROFILE.append((kind, (geom.N, geom.C, geom.H, geom.W, geom.heads, geom.wC, geom.kh), dtype, layout, e0, e1,
-                     nbytes))
 
 
 class AggregationZeropad(Function):
@@ -136,10 +133,8 @@ class AggregationZeropad(Function):
                             kernel_size[0], kernel_size[1], stride[0], stride[1], padding[0], padding[1],
                             dilation[0], dilation[1])
         with torch.cuda.device_of(input):
-            ev = _prof_open()
             rc = _lib.lib().cot_agg_forward(_ptr(input), _ptr(weight), _ptr(output), ctypes.byref(geom),
                                             _lib.dtype_code(input.dtype), layout, _stream())
-            _prof_close(ev, "fwd", geom, (input, weight, output), input.dtype, layout)
         _lib.check(rc, "cot_agg_forward")
         ctx.geom, ctx.layout = geom, layout
         ctx.save_for_backward(input, weight)
@@ -163,14 +158,9 @@ class AggregationZeropad(Function):
                            else torch.empty_like(weight))
         if grad_input is not None or grad_weight is not None:
             with torch.cuda.device_of(input):
-                ev = _prof_open()
                 rc = _lib.lib().cot_agg_backward(_ptr(grad_output), _ptr(input), _ptr(weight), _ptr(grad_input),
                                                  _ptr(grad_weight), ctypes.byref(ctx.geom),
                                                  _lib.dtype_code(input.dtype), layout, _stream())
-                _prof_close(ev, "bwd", ctx.geom,
-                            (grad_output, input if grad_weight is not None else None,
-                             weight if grad_input is not None else None, grad_input, grad_weight),
-                            input.dtype, layout)
             _lib.check(rc, "cot_agg_backward")
         return grad_input, grad_weight, None, None, None, None
 

@@ -153,7 +153,7 @@ template <typename T>
 int aggmix_forward(const T* x, const T* w1, const T* w2, T* out, const cot_agg_geom& g, int p2h, int p2w, int Ho,
                    int Wo, hipStream_t s) {
     const int64_t total = (int64_t)g.N * 2 * g.heads * g.C * Ho * Wo;
-    hipLaunchKernelGGL((aggmix_fwd<T>), dim3(grid1d(total)), dim3(256), 0, s, x, w1, w2, out, g, p2h, p2w, Ho, Wo,
+    COT_LAUNCH((aggmix_fwd<T>), dim3(grid1d(total)), dim3(256), 0, s, x, w1, w2, out, g, p2h, p2w, Ho, Wo,
                        total);
     return check_launch("aggmix_fwd");
 }
@@ -161,7 +161,7 @@ template <typename T>
 int aggmix_backward_input(const T* gout, const T* w1, const T* w2, T* gx, const cot_agg_geom& g, int p2h, int p2w,
                           int all_heads, int Ho, int Wo, hipStream_t s) {
     const int64_t total = (int64_t)g.N * g.C * g.H * g.W;
-    hipLaunchKernelGGL((aggmix_bwd_input<T>), dim3(grid1d(total)), dim3(256), 0, s, gout, w1, w2, gx, g, p2h, p2w,
+    COT_LAUNCH((aggmix_bwd_input<T>), dim3(grid1d(total)), dim3(256), 0, s, gout, w1, w2, gx, g, p2h, p2w,
                        all_heads ? g.heads : 1, Ho, Wo, total);
     return check_launch("aggmix_bwd_input");
 }
@@ -169,7 +169,7 @@ template <typename T>
 int aggmix_backward_weight(const T* gout, const T* x, T* gw1, T* gw2, const cot_agg_geom& g, int p2h, int p2w,
                            int Ho, int Wo, hipStream_t s) {
     const int64_t total = (int64_t)g.N * g.heads * g.wC * 34 * Ho * Wo;
-    hipLaunchKernelGGL((aggmix_bwd_weight<T>), dim3(grid1d(total)), dim3(256), 0, s, gout, x, gw1, gw2, g, p2h, p2w,
+    COT_LAUNCH((aggmix_bwd_weight<T>), dim3(grid1d(total)), dim3(256), 0, s, gout, x, gw1, gw2, g, p2h, p2w,
                        Ho, Wo, total);
     return check_launch("aggmix_bwd_weight");
 }

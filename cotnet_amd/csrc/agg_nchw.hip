@@ -766,7 +766,9 @@ const char* last_kernel_nchw() { return g_last_kernel; }
 // run-time tuning knobs (cot_set_tuning): 0 = kernel version (0 auto, 1 force v1, 2 force v2),
 // 1 = max P forward, 2 = max P backward, 3 = lane-exchange primitive (-1 auto/probe, 0 DPP, 1 ds_bpermute),
 // 4 = v3 fused backward: channel groups staged in LDS per phase (0 = default 4)
-static int g_tune[5] = {0, 4, 4, -1, 0};  // fwd P=4 beats P=8 for bf16 (26.6 vs 38.4 us on N80xC64x56x56)
+// defaults from the on-device A/B (profiles/r01_agg_variants.log, N80xC64x56x56 bf16): forward P=4 (v3 22.0 us vs 26.0 at P=8),
+// fused backward P=2 with 4 channel groups per LDS phase (v3 45.4 us; 27.3 vs 31.8 us at 28x28)
+static int g_tune[5] = {0, 4, 2, -1, 0};
 int set_tuning_nchw(int key, int value) {
     if (key < 0 || key > 4) return -1;
     g_tune[key] = value;
@@ -812,7 +814,7 @@ template <typename T> static inline int pick_P(int W, int maxP) {
     return 1;
 }
 
-static inline bool use_v2(int W, int P) { return g_tune[0] != 1 && (W / P) <= 64; }
+static inline bool use_v2(int W, int P) { return g_tune[0] != 1 && (W / P) <= 64; }  // also the fallback of v3
 
 // v3 (LDS slabs) needs 16-byte aligned channel-group / image strides and a tile that fits LDS comfortably
 struct LdsPlan {
@@ -840,16 +842,16 @@ template <typename T> static inline LdsPlan plan_lds(const cot_agg_geom& g, int 
 template <typename T, int P>
 static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, hipStream_t s) {
     static_assert(P * sizeof(T) <= 16, "row vector wider than 16 bytes");
-    if (g_tune[0] == 3 && sizeof(T) <= 4) {
+    if ((g_tune[0] == 0 || g_tune[0] == 3) && sizeof(T) <= 4) {
         const LdsPlan p = plan_lds<T>(g, P, g.C / g.wC);
         if (p.ok) {
             const dim3 grid((unsigned)((int64_t)p.tiles * g.N * g.heads)), block(256);
             const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
-                hipLaunchKernelGGL((agg_fwd_nchw_k3_lds<T, P, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
+                COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
                                    g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe);
             else
-                hipLaunchKernelGGL((agg_fwd_nchw_k3_lds<T, P, 1>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
+                COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
                                    g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe);
             g_last_kernel = "agg_fwd_nchw_k3_lds";
             return check_launch(g_last_kernel);
@@ -861,17 +863,17 @@ static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, 
         const int64_t waves = ceil_div64(items, L);
         const dim3 grid((unsigned)ceil_div64(waves, 4)), block(256);
         if (xchg_mode() == 0)
-            hipLaunchKernelGGL((agg_fwd_nchw_k3_v2<T, P, 0>), grid, block, 0, s, x, w, out, g.heads, g.C, g.wC, g.H,
+            COT_LAUNCH((agg_fwd_nchw_k3_v2<T, P, 0>), grid, block, 0, s, x, w, out, g.heads, g.C, g.wC, g.H,
                                g.W, L, items);
         else
-            hipLaunchKernelGGL((agg_fwd_nchw_k3_v2<T, P, 1>), grid, block, 0, s, x, w, out, g.heads, g.C, g.wC, g.H,
+            COT_LAUNCH((agg_fwd_nchw_k3_v2<T, P, 1>), grid, block, 0, s, x, w, out, g.heads, g.C, g.wC, g.H,
                                g.W, L, items);
         g_last_kernel = P == 8 ? "agg_fwd_nchw_k3_v2<P8>" : P == 4 ? "agg_fwd_nchw_k3_v2<P4>"
                         : P == 2 ? "agg_fwd_nchw_k3_v2<P2>" : "agg_fwd_nchw_k3_v2<P1>";
         return check_launch(g_last_kernel);
     }
     const int64_t items = (int64_t)g.N * g.heads * g.wC * g.H * (g.W / P);
-    hipLaunchKernelGGL((agg_fwd_nchw_k3<T, P>), dim3(grid_for(items, 256, INT32_MAX)), dim3(256), 0, s, x, w, out,
+    COT_LAUNCH((agg_fwd_nchw_k3<T, P>), dim3(grid_for(items, 256, INT32_MAX)), dim3(256), 0, s, x, w, out,
                        g.heads, g.C, g.wC, g.H, g.W, items);
     g_last_kernel = "agg_fwd_nchw_k3<v1>";
     return check_launch(g_last_kernel);
@@ -891,7 +893,7 @@ int agg_forward_nchw(const T* x, const T* w, T* out, const cot_agg_geom& g, int 
         }
     }
     const int64_t total = (int64_t)g.N * g.heads * g.C * Ho * Wo;
-    hipLaunchKernelGGL((agg_fwd_nchw_generic<T>), dim3(grid_for(total, 256)), dim3(256), 0, s, x, w, out, g, Ho, Wo,
+    COT_LAUNCH((agg_fwd_nchw_generic<T>), dim3(grid_for(total, 256)), dim3(256), 0, s, x, w, out, g, Ho, Wo,
                        total);
     g_last_kernel = "agg_fwd_nchw_generic";
     return check_launch("agg_fwd_nchw_generic");
@@ -900,7 +902,7 @@ int agg_forward_nchw(const T* x, const T* w, T* out, const cot_agg_geom& g, int 
 template <typename T, int P, bool GX, bool GW>
 static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw, const cot_agg_geom& g,
                              hipStream_t s) {
-    if (g_tune[0] == 3 && sizeof(T) <= 4) {
+    if ((g_tune[0] == 0 || g_tune[0] == 3) && sizeof(T) <= 4) {
         const int J = g.C / g.wC;
         int JP = g_tune[4] > 0 && g_tune[4] <= J ? g_tune[4] : (J >= 4 ? 4 : J);
         const LdsPlan p = plan_lds<T>(g, P, (GW ? 2 : 1) * JP);
@@ -908,10 +910,10 @@ static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw
             const dim3 grid((unsigned)((int64_t)p.tiles * g.N)), block(256);
             const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
-                hipLaunchKernelGGL((agg_bwd_nchw_k3_lds<T, P, 0, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
+                COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 0, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
                                    g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
             else
-                hipLaunchKernelGGL((agg_bwd_nchw_k3_lds<T, P, 1, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
+                COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 1, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
                                    g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
             g_last_kernel = GX && GW ? "agg_bwd_nchw_k3_lds<gx,gw>" : GX ? "agg_bwd_nchw_k3_lds<gx>" : "agg_bwd_nchw_k3_lds<gw>";
             return check_launch(g_last_kernel);
@@ -923,16 +925,16 @@ static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw
         const int64_t waves = ceil_div64(items, L);
         const dim3 grid((unsigned)ceil_div64(waves, 4)), block(256);
         if (xchg_mode() != 0)
-            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 1, GX, GW, 1>), grid, block, 0, s, gout, x, w, gx, gw, g.C,
+            COT_LAUNCH((agg_bwd_nchw_k3_v2<T, P, 1, GX, GW, 1>), grid, block, 0, s, gout, x, w, gx, gw, g.C,
                                g.wC, g.H, g.W, L, items);
         else
-            hipLaunchKernelGGL((agg_bwd_nchw_k3_v2<T, P, 0, GX, GW, 1>), grid, block, 0, s, gout, x, w, gx, gw, g.C,
+            COT_LAUNCH((agg_bwd_nchw_k3_v2<T, P, 0, GX, GW, 1>), grid, block, 0, s, gout, x, w, gx, gw, g.C,
                                g.wC, g.H, g.W, L, items);
         g_last_kernel = GX && GW ? "agg_bwd_nchw_k3_v2<gx,gw>" : GX ? "agg_bwd_nchw_k3_v2<gx>" : "agg_bwd_nchw_k3_v2<gw>";
         return check_launch(g_last_kernel);
     }
     const int64_t items = (int64_t)g.N * g.wC * g.H * (g.W / P);
-    hipLaunchKernelGGL((agg_bwd_nchw_k3<T, P, GX, GW>), dim3(grid_for(items, 256, INT32_MAX)), dim3(256), 0, s, gout, x,
+    COT_LAUNCH((agg_bwd_nchw_k3<T, P, GX, GW>), dim3(grid_for(items, 256, INT32_MAX)), dim3(256), 0, s, gout, x,
                        w, gx, gw, g.C, g.wC, g.H, g.W, items);
     g_last_kernel = GX && GW ? "agg_bwd_nchw_k3<gx,gw>" : GX ? "agg_bwd_nchw_k3<gx>" : "agg_bwd_nchw_k3<gw>";
     return check_launch(g_last_kernel);
@@ -960,7 +962,7 @@ int agg_backward_nchw(const T* gout, const T* x, const T* w, T* gx, T* gw, const
     int rc = COT_OK;
     if (gx) {
         const int64_t total = (int64_t)g.N * g.C * g.H * g.W;
-        hipLaunchKernelGGL((agg_bwd_input_nchw_generic<T>), dim3(grid_for(total, 256)), dim3(256), 0, s, gout, w, gx, g,
+        COT_LAUNCH((agg_bwd_input_nchw_generic<T>), dim3(grid_for(total, 256)), dim3(256), 0, s, gout, w, gx, g,
                            Ho, Wo, total);
         g_last_kernel = "agg_bwd_input_nchw_generic";
         rc = check_launch("agg_bwd_input_nchw_generic");
@@ -968,7 +970,7 @@ int agg_backward_nchw(const T* gout, const T* x, const T* w, T* gx, T* gw, const
     }
     if (gw) {
         const int64_t total = (int64_t)g.N * g.heads * g.wC * g.kh * g.kw * Ho * Wo;
-        hipLaunchKernelGGL((agg_bwd_weight_nchw_generic<T>), dim3(grid_for(total, 256)), dim3(256), 0, s, gout, x, gw,
+        COT_LAUNCH((agg_bwd_weight_nchw_generic<T>), dim3(grid_for(total, 256)), dim3(256), 0, s, gout, x, gw,
                            g, Ho, Wo, total);
         g_last_kernel = "agg_bwd_weight_nchw_generic";
         rc = check_launch("agg_bwd_weight_nchw_generic");

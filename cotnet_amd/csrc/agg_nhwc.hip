@@ -204,11 +204,11 @@ static int launch_fwd(const T* x, const T* w, T* out, const cot_agg_geom& g, int
     const bool k3 = g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.dh == 1 &&
                     g.dw == 1 && V * sizeof(T) == 16;
     if (k3) {
-        hipLaunchKernelGGL((agg_fwd_nhwc_k3<T, V>), dim3(grid1d(items, 256, INT32_MAX)), dim3(256), 0, s, x, w, out,
+        COT_LAUNCH((agg_fwd_nhwc_k3<T, V>), dim3(grid1d(items, 256, INT32_MAX)), dim3(256), 0, s, x, w, out,
                            g.heads, g.C, g.wC, g.H, g.W, items);
         g_last_kernel_nhwc = "agg_fwd_nhwc_k3";
     } else {
-        hipLaunchKernelGGL((agg_fwd_nhwc<T, V>), dim3(grid1d(items, 256, INT32_MAX)), dim3(256), 0, s, x, w, out, g,
+        COT_LAUNCH((agg_fwd_nhwc<T, V>), dim3(grid1d(items, 256, INT32_MAX)), dim3(256), 0, s, x, w, out, g,
                            Ho, Wo, items);
         g_last_kernel_nhwc = "agg_fwd_nhwc";
     }
@@ -229,7 +229,7 @@ int agg_forward_nhwc(const T* x, const T* w, T* out, const cot_agg_geom& g, int 
 template <typename T, int V>
 static int launch_bwd_in(const T* gout, const T* w, T* gx, const cot_agg_geom& g, int Ho, int Wo, hipStream_t s) {
     const int64_t items = (int64_t)g.N * g.H * g.W * (g.C / V);
-    hipLaunchKernelGGL((agg_bwd_input_nhwc<T, V>), dim3(grid1d(items, 256, INT32_MAX)), dim3(256), 0, s, gout, w, gx, g,
+    COT_LAUNCH((agg_bwd_input_nhwc<T, V>), dim3(grid1d(items, 256, INT32_MAX)), dim3(256), 0, s, gout, w, gx, g,
                        Ho, Wo, items);
     g_last_kernel_nhwc = "agg_bwd_input_nhwc";
     return check_launch("agg_bwd_input_nhwc");
@@ -250,7 +250,7 @@ int agg_backward_nhwc(const T* gout, const T* x, const T* w, T* gx, T* gw, const
     }
     if (gw) {
         const int64_t total = (int64_t)g.N * Ho * Wo * g.heads * g.wC * g.kh * g.kw;
-        hipLaunchKernelGGL((agg_bwd_weight_nhwc<T>), dim3(grid1d(total, 256, (int64_t)1 << 20)), dim3(256), 0, s, gout,
+        COT_LAUNCH((agg_bwd_weight_nhwc<T>), dim3(grid1d(total, 256, (int64_t)1 << 20)), dim3(256), 0, s, gout,
                            x, gw, g, Ho, Wo, total);
         g_last_kernel_nhwc = "agg_bwd_weight_nhwc";
         rc = check_launch("agg_bwd_weight_nhwc");

@@ -2,6 +2,11 @@
 // argument validation, dtype/layout dispatch, error strings.  No torch types anywhere.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+#include <vector>
 
 #include "cot_common.h"
 
@@ -23,6 +28,51 @@ int check_launch(const char* what) {
     if (e != hipSuccess) return set_error(COT_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return COT_OK;
 }
+
+namespace prof {
+struct Rec {
+    cot_profile_rec pub;
+    hipEvent_t e0, e1;
+};
+static std::atomic<bool> g_on{false};
+static std::mutex g_mu;
+static std::vector<Rec> g_recs;
+static thread_local size_t t_mark = 0;  // records [t_mark, size) were created by the current ABI call on this thread
+
+bool enabled() { return g_on.load(std::memory_order_relaxed); }
+void begin_launch(hipEvent_t* e0, hipEvent_t* e1) {
+    (void)hipEventCreate(e0);
+    (void)hipEventCreate(e1);
+}
+void end_launch(const char* name, hipEvent_t e0, hipEvent_t e1) {
+    Rec r;
+    memset(&r.pub, 0, sizeof(r.pub));
+    // "(agg_fwd_nchw_k3_lds<T, P, 0>)" -> "agg_fwd_nchw_k3_lds"
+    const char* b = name;
+    while (*b == '(' || *b == ' ') ++b;
+    size_t n = strcspn(b, "<)");
+    if (n >= sizeof(r.pub.kernel)) n = sizeof(r.pub.kernel) - 1;
+    memcpy(r.pub.kernel, b, n);
+    r.e0 = e0;
+    r.e1 = e1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_recs.push_back(r);
+}
+static void mark() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    t_mark = g_recs.size();
+}
+static void annotate(const cot_agg_geom& g, int dtype, int layout, int kind, int flags) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = t_mark; i < g_recs.size(); ++i) {
+        g_recs[i].pub.geom = g;
+        g_recs[i].pub.dtype = dtype;
+        g_recs[i].pub.layout = layout;
+        g_recs[i].pub.kind = kind;
+        g_recs[i].pub.flags = flags;
+    }
+}
+}  // namespace prof
 
 // implemented in agg_nchw.hip / agg_nhwc.hip / agg_mix.hip
 template <typename T>
@@ -151,6 +201,35 @@ int cot_set_tuning(int key, int value) {
 }
 int cot_xchg_mode(void) { return xchg_mode(); }
 
+int cot_profile_begin(void) {
+    std::lock_guard<std::mutex> lk(prof::g_mu);
+    for (auto& r : prof::g_recs) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    prof::g_recs.clear();
+    prof::g_on.store(true);
+    return COT_OK;
+}
+
+int cot_profile_end(cot_profile_rec* out, int max_records) {
+    prof::g_on.store(false);
+    std::lock_guard<std::mutex> lk(prof::g_mu);
+    int n = 0;
+    for (auto& r : prof::g_recs) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+        r.pub.ms = ms;
+        if (out && n < max_records) out[n] = r.pub;
+        ++n;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    prof::g_recs.clear();
+    return n;  // total number of launches recorded (may exceed max_records)
+}
+
 int cot_agg_forward(const void* x, const void* w, void* out, const cot_agg_geom* g, int dtype, int layout,
                     void* stream) {
     int Ho, Wo, rc = validate(g, &Ho, &Wo);
@@ -158,7 +237,17 @@ int cot_agg_forward(const void* x, const void* w, void* out, const cot_agg_geom*
     if (!x || !w || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if (layout != COT_NCHW && layout != COT_NHWC) return set_error(COT_ERR_UNSUPPORTED, "unknown layout %d", layout);
     if ((rc = check_align16({x, w, out}))) return rc;
-    DISPATCH_DTYPE(dtype, (fwd_t<T>(x, w, out, *g, Ho, Wo, layout, (hipStream_t)stream)));
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    switch (dtype) {
+        case COT_F32: rc = fwd_t<float>(x, w, out, *g, Ho, Wo, layout, (hipStream_t)stream); break;
+        case COT_F64: rc = fwd_t<double>(x, w, out, *g, Ho, Wo, layout, (hipStream_t)stream); break;
+        case COT_BF16: rc = fwd_t<bf16_t>(x, w, out, *g, Ho, Wo, layout, (hipStream_t)stream); break;
+        case COT_F16: rc = fwd_t<f16_t>(x, w, out, *g, Ho, Wo, layout, (hipStream_t)stream); break;
+        default: return set_error(COT_ERR_UNSUPPORTED, "unknown dtype %d", dtype);
+    }
+    if (p) prof::annotate(*g, dtype, layout, 0, 0);
+    return rc;
 }
 
 int cot_agg_backward(const void* gout, const void* x, const void* w, void* gx, void* gw, const cot_agg_geom* g,
@@ -171,7 +260,17 @@ int cot_agg_backward(const void* gout, const void* x, const void* w, void* gx, v
     if (gw && !x) return set_error(COT_ERR_INVALID_ARG, "gw requested but x is NULL");
     if (layout != COT_NCHW && layout != COT_NHWC) return set_error(COT_ERR_UNSUPPORTED, "unknown layout %d", layout);
     if ((rc = check_align16({gout, x, w, gx, gw}))) return rc;
-    DISPATCH_DTYPE(dtype, (bwd_t<T>(gout, x, w, gx, gw, *g, Ho, Wo, layout, (hipStream_t)stream)));
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    switch (dtype) {
+        case COT_F32: rc = bwd_t<float>(gout, x, w, gx, gw, *g, Ho, Wo, layout, (hipStream_t)stream); break;
+        case COT_F64: rc = bwd_t<double>(gout, x, w, gx, gw, *g, Ho, Wo, layout, (hipStream_t)stream); break;
+        case COT_BF16: rc = bwd_t<bf16_t>(gout, x, w, gx, gw, *g, Ho, Wo, layout, (hipStream_t)stream); break;
+        case COT_F16: rc = bwd_t<f16_t>(gout, x, w, gx, gw, *g, Ho, Wo, layout, (hipStream_t)stream); break;
+        default: return set_error(COT_ERR_UNSUPPORTED, "unknown dtype %d", dtype);
+    }
+    if (p) prof::annotate(*g, dtype, layout, 1, (gx ? 1 : 0) | (gw ? 2 : 0));
+    return rc;
 }
 
 int cot_agg_backward_input(const void* gout, const void* w, void* gx, const cot_agg_geom* g, int dtype, int layout,

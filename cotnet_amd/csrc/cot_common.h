@@ -1,6 +1,7 @@
 // cot_common.h -- shared device helpers for the cotnet_amd HIP kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/cotnet_amd.h"
@@ -49,4 +50,24 @@ __host__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / 
 namespace cot {
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
+
+// optional per-launch device timing (cot_profile_begin/_end): the start/stop events are attached to the kernel
+// dispatch itself (hipExtLaunchKernelGGL), so the interval is the kernel's execution, not host launch gaps.
+namespace prof {
+bool enabled();
+void begin_launch(hipEvent_t* e0, hipEvent_t* e1);
+void end_launch(const char* name, hipEvent_t e0, hipEvent_t e1);
+}  // namespace prof
 }  // namespace cot
+
+#define COT_LAUNCH(KERNEL, GRID, BLOCK, SHMEM, STREAM, ...)                                             \
+    do {                                                                                                \
+        if (cot::prof::enabled()) {                                                                     \
+            hipEvent_t e0_, e1_;                                                                        \
+            cot::prof::begin_launch(&e0_, &e1_);                                                        \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, e0_, e1_, 0, __VA_ARGS__);        \
+            cot::prof::end_launch(#KERNEL, e0_, e1_);                                                   \
+        } else {                                                                                        \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, __VA_ARGS__);                        \
+        }                                                                                               \
+    } while (0)

@@ -114,6 +114,22 @@ int cot_set_tuning(int key, int value);
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */
 int cot_xchg_mode(void);
 
+/* Per-launch device timing for bench.py's roofline object.  Between cot_profile_begin() and cot_profile_end()
+ * every aggregation kernel is launched with start/stop events attached to its dispatch (hipExtLaunchKernelGGL),
+ * so `ms` is the kernel's execution time on the device -- what rocprofv3 --kernel-trace reports -- free of host
+ * launch gaps.  cot_profile_end() synchronises, fills at most max_records records in launch order and returns the
+ * number of launches recorded.  Process-global; not meant to be left on in production. */
+typedef struct {
+    char kernel[48];       /* kernel function name without template arguments */
+    int32_t kind;          /* 0 = forward, 1 = backward */
+    int32_t flags;         /* backward: bit 0 = gx produced, bit 1 = gw produced */
+    int32_t dtype, layout; /* cot_dtype, cot_layout */
+    cot_agg_geom geom;
+    float ms;
+} cot_profile_rec;
+int cot_profile_begin(void);
+int cot_profile_end(cot_profile_rec* out, int max_records);
+
 #ifdef __cplusplus
 }
 #endif

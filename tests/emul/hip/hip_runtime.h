@@ -110,6 +110,14 @@ template <typename V> inline V __shfl_down(V v, int d) { return emul::exchange<V
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emul::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
 
+typedef void* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0, e1, flags, ...) \
+    emul::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
 // host stand-ins for the few runtime calls the library makes outside launches
 inline hipError_t hipMalloc(void** p, size_t n) { *p = ::operator new(n); return 0; }
 inline hipError_t hipFree(void* p) { ::operator delete(p); return 0; }
