@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--model", default="cotnet50")
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "autocast"],
+                    help="bf16 only. mixed: bf16 conv/linear weights + fp32 masters, fused flat SGD (cotnet_amd.flat_sgd); "
+                         "autocast: fp32 weights under torch.autocast + torch.optim.SGD")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc"])
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,7 +152,23 @@ def main():
     x = torch.randn(B, 3, args.img, args.img, device=dev).contiguous(memory_format=mf)
     t = torch.randint(0, 1000, (B,), device=dev)
 
-    if args.mode == "train":
+    mixed = amp and args.precision == "mixed"
+    if mixed:
+        from cotnet_amd.flat_sgd import FlatSGD, to_mixed_bf16
+        to_mixed_bf16(model)
+        x = x.bfloat16()
+    if args.mode == "train" and mixed:
+        model.train()
+        opt = FlatSGD(model, lr=0.25 * B * world / 640.0, momentum=0.9, weight_decay=4e-5, nesterov=True,
+                      bucket_mb=args.bucket_mb)
+
+        def step():
+            opt.zero_grad()
+            loss = torch.nn.functional.cross_entropy(model(x).float(), t)
+            loss.backward()
+            opt.step()
+            return loss
+    elif args.mode == "train":
         model.train()
         opt = make_optimizer(model, lr=0.25 * B * world / 640.0, wd=4e-5)
         red = GradBucketReducer(model, bucket_mb=args.bucket_mb)
@@ -167,7 +186,7 @@ def main():
         model.eval()
 
         def step():
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp and not mixed):
                 return model(x).float().sum()
 
     def barrier():
@@ -234,7 +253,8 @@ def main():
             "config": {"workload": f"{args.model} {args.img}x{args.img} {'fwd+bwd+SGD-nesterov' if args.mode == 'train' else 'forward-only'}, "
                                    f"random init, 1000 classes, NCHW synthetic ImageNet-shaped input resident in HBM",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "layout": args.layout, "precision": "bf16 autocast, fp32 master weights" if amp else "fp32",
+                       "layout": args.layout, "precision": ("bf16 weights+activations, fp32 master weights / norm params, fused flat SGD" if mixed
+                                     else "bf16 autocast, fp32 weights" if amp else "fp32"),
                        "grad_sync": "RCCL all-reduce (AVG), flat buckets, side stream" if world > 1 else "none (1 GPU)"},
             "final_loss": round(final_loss, 4),
             "roofline": roofline,

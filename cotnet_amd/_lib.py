@@ -46,6 +46,8 @@ SYMBOLS = {
     "cot_aggmix_backward_weight": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),
     "cot_set_tuning": (_I, [_I, _I]),
     "cot_xchg_mode": (_I, []),
+    "cot_sgd_step": (_I, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                          _I, _I, _I, _P]),
     "cot_profile_begin": (_I, []),
     "cot_profile_end": (_I, [ctypes.POINTER(ProfileRec), _I]),
 }

@@ -89,6 +89,7 @@ int aggmix_backward_input(const T*, const T*, const T*, T*, const cot_agg_geom&,
                           hipStream_t);
 template <typename T>
 int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int, int, int, int, hipStream_t);
+int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
 int set_tuning_nchw(int key, int value);
@@ -200,6 +201,16 @@ int cot_set_tuning(int key, int value) {
     return COT_OK;
 }
 int cot_xchg_mode(void) { return xchg_mode(); }
+
+int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad, int64_t n, float lr, float momentum,
+                 float weight_decay, float grad_scale, int nesterov, int param_dtype, int grad_dtype, void* stream) {
+    if (!param || !momentum_buf || !grad) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (n <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive element count %lld", (long long)n);
+    int rc = check_align16({param, master, momentum_buf, grad});
+    if (rc) return rc;
+    return sgd_flat(param, master, momentum_buf, grad, n, lr, momentum, weight_decay, grad_scale, nesterov, param_dtype,
+                    grad_dtype, (hipStream_t)stream);
+}
 
 int cot_profile_begin(void) {
     std::lock_guard<std::mutex> lk(prof::g_mu);

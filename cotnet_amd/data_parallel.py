@@ -25,24 +25,38 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "pending", "work", "ready_event")
+    __slots__ = ("flat", "params", "pending", "work", "ready_event", "key", "views", "pflat", "fired")
 
-    def __init__(self, flat, params):
+    def __init__(self, flat, params, key=None):
         self.flat = flat
         self.params = params
         self.pending = len(params)
         self.work = None
         self.ready_event = None
+        self.key = key
+        self.views = []      # per-parameter views into `flat`
+        self.pflat = None    # flat PARAMETER storage (flatten_params=True)
+        self.fired = set()
 
 
 class GradBucketReducer:
-    def __init__(self, module, process_group=None, bucket_mb=48.0, broadcast_params=True, grad_dtype=None):
+    def __init__(self, module, process_group=None, bucket_mb=48.0, broadcast_params=True, grad_dtype=None,
+                 group_fn=None, grad_mode="view", flatten_params=False):
+        """group_fn(name, param) -> hashable key: parameters with different keys never share a bucket (used by
+        FlatSGD to keep weight-decay groups / dtypes apart).  grad_mode "view": p.grad is a view into the bucket and
+        autograd accumulates in place (one small add per parameter); "copy": autograd hands over its gradient tensor
+        and the bucket is filled with ONE multi-tensor copy when its last gradient arrives (p.grad is then dropped).
+        flatten_params=True additionally moves the parameters themselves into one flat buffer per bucket."""
+        assert grad_mode in ("view", "copy")
+        self.grad_mode = grad_mode
         self.module = module
         self.group = process_group
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.world = dist.get_world_size(process_group) if self.enabled else 1
-        params = [p for p in module.parameters() if p.requires_grad]
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        params = [p for _, p in named]
         assert params, "module has no trainable parameters"
+        keys = {p: (group_fn(n, p) if group_fn else None) for n, p in named}
         self.device = params[0].device
         self.on_gpu = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.on_gpu and self.enabled) else None
@@ -55,33 +69,53 @@ class GradBucketReducer:
         cap = int(bucket_mb * 1024 * 1024)
         self.buckets = []
         self._bucket_of = {}
-        cur, cur_bytes, cur_dtype = [], 0, None
+        open_buckets = {}  # (key, dtype) -> [params, bytes]; keeps reverse registration order inside each group
+        order = []
         for p in reversed(params):
             dt = grad_dtype or p.dtype
+            k = (keys[p], dt)
             nbytes = p.numel() * torch.empty((), dtype=dt).element_size()
-            if cur and (cur_bytes + nbytes > cap or dt != cur_dtype):
-                self._make_bucket(cur, cur_dtype)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nbytes
-            cur_dtype = dt
-        if cur:
-            self._make_bucket(cur, cur_dtype)
+            cur = open_buckets.get(k)
+            if cur is not None and cur[1] + nbytes > cap:
+                order.append((k, cur[0]))
+                cur = None
+            if cur is None:
+                cur = [[], 0]
+                open_buckets[k] = cur
+            cur[0].append(p)
+            cur[1] += nbytes
+        for k, cur in open_buckets.items():
+            if cur[0]:
+                order.append((k, cur[0]))
+        for (key, dt), plist in order:
+            self._make_bucket(plist, dt, key, flatten_params)
 
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in params]
         self._launched = 0
 
     # ------------------------------------------------------------------------------------------
-    def _make_bucket(self, params, dtype):
-        total = sum(p.numel() for p in params)
+    def _make_bucket(self, params, dtype, key=None, flatten_params=False):
+        # every parameter starts on a 16-byte boundary so flat-buffer kernels can use 16-byte accesses per tensor
+        esz = torch.empty((), dtype=dtype).element_size()
+        align = max(1, 16 // esz)
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + align - 1) // align * align
         flat = torch.zeros(total, dtype=dtype, device=self.device)
-        off = 0
-        for p in params:
+        b = _Bucket(flat, params, key)
+        if flatten_params:
+            b.pflat = torch.zeros(total, dtype=params[0].dtype, device=self.device)
+        for p, off in zip(params, offs):
             n = p.numel()
-            p.grad = flat[off:off + n].view_as(p)  # autograd accumulates in place into the bucket
-            off += n
-        b = _Bucket(flat, params)
-        for p in params:
+            b.views.append(flat[off:off + n].view_as(p))
+            if self.grad_mode == "view":
+                p.grad = b.views[-1]  # autograd accumulates in place into the bucket
+            if flatten_params:
+                assert p.dtype == params[0].dtype
+                pv = b.pflat[off:off + n].view_as(p)
+                pv.copy_(p.data)
+                p.data = pv
             self._bucket_of[p] = b
         self.buckets.append(b)
 
@@ -102,6 +136,13 @@ class GradBucketReducer:
     # ------------------------------------------------------------------------------------------
     def _on_grad_ready(self, param):
         b = self._bucket_of[param]
+        if self.grad_mode == "copy":
+            b.fired.add(param)
+            b.pending -= 1
+            if b.pending == 0:
+                self._fill(b)
+                self._launch(b)
+            return
         if param.grad is not None and param.grad.data_ptr() != self._expected_ptr(b, param):
             # someone replaced .grad (e.g. zero_grad(set_to_none=True)); fold it back into the bucket
             view = self._view(b, param)
@@ -111,21 +152,29 @@ class GradBucketReducer:
         if b.pending == 0:
             self._launch(b)
 
-    def _view(self, b, param):
-        off = 0
+    def _fill(self, b):
+        """copy mode: one multi-tensor copy of the gradients autograd produced into the bucket; zero the rest"""
+        dst, src = [], []
+        for p, v in zip(b.params, b.views):
+            if p in b.fired and p.grad is not None:
+                dst.append(v)
+                src.append(p.grad)
+            else:
+                v.zero_()  # parameter unused this step
+        if dst:
+            torch._foreach_copy_(dst, src)
         for p in b.params:
+            p.grad = None
+        b.fired.clear()
+
+    def _view(self, b, param):
+        for p, v in zip(b.params, b.views):
             if p is param:
-                return b.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+                return v
         raise KeyError("parameter not in bucket")
 
     def _expected_ptr(self, b, param):
-        off = 0
-        for p in b.params:
-            if p is param:
-                return b.flat.data_ptr() + off * b.flat.element_size()
-            off += p.numel()
-        raise KeyError("parameter not in bucket")
+        return self._view(b, param).data_ptr()
 
     def _launch(self, b):
         self._launched += 1
@@ -151,9 +200,11 @@ class GradBucketReducer:
         """call after backward, before optimizer.step(): the compute stream waits for every bucket's all-reduce.
         Buckets whose gradients never fired (unused parameters) are reduced here so ranks stay in lock-step."""
         for b in self.buckets:
-            if b.pending != 0 and b.pending != len(b.params):
-                pass  # partially-filled bucket: some params unused this step; reduce what we have
-            if b.work is None and self.enabled:
+            if self.grad_mode == "copy" and b.pending != 0:
+                self._fill(b)  # some parameters were unused this step: their slots are zeroed
+                b.pending = 0
+                self._launch(b)
+            elif b.work is None and self.enabled:
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:
@@ -168,7 +219,13 @@ class GradBucketReducer:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
 
     def zero_grad(self):
-        """zero the flat buckets (keeps the .grad views alive; use instead of optimizer.zero_grad(set_to_none=True))"""
+        """zero the flat buckets (keeps the .grad views alive; use instead of optimizer.zero_grad(set_to_none=True)).
+        In copy mode nothing accumulates, so this only drops stale .grad tensors."""
+        if self.grad_mode == "copy":
+            for b in self.buckets:
+                for p in b.params:
+                    p.grad = None
+            return
         for b in self.buckets:
             b.flat.zero_()
             for p in b.params:

@@ -1,0 +1,87 @@
+"""Mixed-precision parameters + fused flat SGD-nesterov ("training-loop glue on device").
+
+The reference trains fp32 with `torch.optim.SGD(nesterov=True)` (optim/optim_factory.py:54-56), weight decay only on
+>1-D parameters (:19-31), gradients synchronised by DDP (train.py:115), plus one elementwise op per tensor for EMA.
+On MI355X the step is bound by HBM passes and launch count, so this module
+
+  * keeps Conv2d / Linear weights and biases in bf16 (what the convolutions read) with fp32 MASTER copies, and the
+    normalisation parameters in fp32 -- no per-step autocast casts (measured: ~530 cast launches per CoTNet-50 step);
+  * lays parameters, gradients, masters and momentum out in a few flat buckets per (dtype, weight-decay) group
+    (cotnet_amd.data_parallel.GradBucketReducer with flatten_params=True, grad_mode="copy": autograd's gradients are
+    moved into the bucket with one multi-tensor copy, then all-reduced over RCCL on the side stream);
+  * updates each bucket with ONE hand-written HIP kernel (`cot_sgd_step`, csrc/optim.hip).
+
+Arithmetic = torch.optim.SGD (dampening 0) evaluated in fp32 on the master weights; checked against it in
+tests/test_flat_sgd_gpu.py.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from .data_parallel import GradBucketReducer
+
+
+def to_mixed_bf16(model):
+    """Conv2d / Linear parameters -> bf16 (in place); norm layers and buffers stay fp32.  Returns the model."""
+    for m in model.modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            for p in m.parameters(recurse=False):
+                p.data = p.data.to(torch.bfloat16)
+    return model
+
+
+def _decay_group(name, p):
+    # reference rule: no weight decay on 1-D parameters and biases (optim/optim_factory.py:19-31)
+    return "no_decay" if (p.ndim <= 1 or name.endswith(".bias")) else "decay"
+
+
+class FlatSGD:
+    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0, nesterov=True, bucket_mb=48.0, process_group=None,
+                 broadcast_params=True):
+        self.lr, self.momentum, self.weight_decay, self.nesterov = float(lr), float(momentum), float(weight_decay), nesterov
+        # masters must be taken from the fp32 values BEFORE rounding when the caller converts later; here parameters
+        # are already in their storage dtype, so the master starts as the (exact) up-cast of the working copy.
+        self.reducer = GradBucketReducer(model, process_group=process_group, bucket_mb=bucket_mb,
+                                         broadcast_params=broadcast_params, group_fn=_decay_group, grad_mode="copy",
+                                         flatten_params=True)
+        self.state = []
+        for b in self.reducer.buckets:
+            master = b.pflat.float().clone() if b.pflat.dtype != torch.float32 else None
+            self.state.append({"master": master, "mom": torch.zeros(b.pflat.numel(), dtype=torch.float32,
+                                                                    device=b.pflat.device)})
+        _lib.lib()
+
+    def zero_grad(self):
+        self.reducer.zero_grad()
+
+    def step(self):
+        """finish the gradient all-reduce (stream wait only) and update every bucket with one kernel each"""
+        self.reducer.finish()
+        L = _lib.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for b, st in zip(self.reducer.buckets, self.state):
+            key = b.key
+            wd = self.weight_decay if key == "decay" else 0.0
+            rc = L.cot_sgd_step(ctypes.c_void_p(b.pflat.data_ptr()),
+                                ctypes.c_void_p(st["master"].data_ptr()) if st["master"] is not None else None,
+                                ctypes.c_void_p(st["mom"].data_ptr()), ctypes.c_void_p(b.flat.data_ptr()),
+                                b.pflat.numel(), self.lr, self.momentum, wd, 1.0, 1 if self.nesterov else 0,
+                                _lib.dtype_code(b.pflat.dtype), _lib.dtype_code(b.flat.dtype), stream)
+            _lib.check(rc, "cot_sgd_step")
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+
+    def master_parameters(self):
+        """fp32 view of every parameter (master copy for bf16 parameters), in module.parameters() order of the buckets"""
+        out = {}
+        for b, st in zip(self.reducer.buckets, self.state):
+            src = st["master"] if st["master"] is not None else b.pflat
+            off = 0
+            esz_align = max(1, 16 // b.flat.element_size())
+            for p in b.params:
+                out[p] = src[off:off + p.numel()].view_as(p)
+                off += (p.numel() + esz_align - 1) // esz_align * esz_align
+        return out

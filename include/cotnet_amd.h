@@ -114,6 +114,15 @@ int cot_set_tuning(int key, int value);
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */
 int cot_xchg_mode(void);
 
+/* ---- fused SGD over a flat parameter bucket (replaces torch.optim.SGD(nesterov=True),
+ * optim/optim_factory.py:54-56, which launches per parameter tensor):
+ *     g = grad*grad_scale + weight_decay*p;  buf = momentum*buf + g;  p -= lr*(nesterov ? g + momentum*buf : buf)
+ * param_dtype COT_BF16 needs `master` (fp32 copy, updated in place; `param` receives the rounded working copy);
+ * param_dtype COT_F32 takes master == NULL.  grad_dtype COT_BF16 or COT_F32.  momentum_buf is fp32, n elements. */
+int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad, int64_t n, float lr,
+                 float momentum, float weight_decay, float grad_scale, int nesterov, int param_dtype, int grad_dtype,
+                 void* stream);
+
 /* Per-launch device timing for bench.py's roofline object.  Between cot_profile_begin() and cot_profile_end()
  * every aggregation kernel is launched with start/stop events attached to its dispatch (hipExtLaunchKernelGGL),
  * so `ms` is the kernel's execution time on the device -- what rocprofv3 --kernel-trace reports -- free of host

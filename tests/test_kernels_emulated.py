@@ -199,3 +199,33 @@ def test_mix_kernels():
     assert _EMUL.cot_aggmix_backward_weight(P(gout), P(x), P(gw1), P(gw2), ctypes.byref(geo), 2, 2, 1, None) == 0
     o1, o2 = cref.mix_backward_weight(gout, x, w1.shape, w2.shape, 1, 1, 2, 1)
     assert (gw1 - o1).abs().max() < 1e-12 and (gw2 - o2).abs().max() < 1e-12
+
+
+@pytest.mark.parametrize("pdt,gdt", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32),
+                                     (torch.float32, torch.float32), (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("nesterov", [0, 1])
+def test_fused_sgd_kernel_matches_torch_formula(pdt, gdt, nesterov):
+    g = torch.Generator().manual_seed(4)
+    n = 4 * 1000 + 3  # exercises the vector body and the scalar tail
+    master = torch.randn(n, generator=g)
+    mom = torch.randn(n, generator=g) * 0.1
+    grad = torch.randn(n, generator=g).to(gdt)
+    param = master.to(pdt)
+    if pdt == torch.float32:
+        master_arg, ref_p = None, param.clone()
+    else:
+        master_arg, ref_p = master.clone(), master.clone()
+    lr, mu, wd, gs = 0.1, 0.9, 1e-2, 0.5
+    gg = grad.float() * gs + wd * ref_p
+    buf = mu * mom + gg
+    ref_p = ref_p - lr * (gg + mu * buf if nesterov else buf)
+    mom_k = mom.clone()
+    rc = _EMUL.cot_sgd_step(P(param), P(master_arg) if master_arg is not None else None, P(mom_k), P(grad), n, lr, mu,
+                            wd, gs, nesterov, _lib.dtype_code(pdt), _lib.dtype_code(gdt), None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(mom_k, buf, rtol=1e-6, atol=1e-7)
+    if master_arg is not None:
+        assert torch.allclose(master_arg, ref_p, rtol=1e-6, atol=1e-7)
+        assert torch.equal(param, master_arg.to(pdt))
+    else:
+        assert torch.allclose(param, ref_p, rtol=1e-6, atol=1e-7)
