@@ -565,8 +565,8 @@ __device__ __forceinline__ void stage_slabs(const T* __restrict__ base, int64_t 
                                             int sle, int64_t total_elems, T* __restrict__ lds) {
     constexpr int VE = 16 / sizeof(T);
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int chunks = sle / VE, total = nslab * chunks;
-    for (int q0 = 0; q0 < total; q0 += 256) {
+    const int chunks = sle / VE, total = nslab * chunks, nthr = blockDim.x;
+    for (int q0 = 0; q0 < total; q0 += nthr) {
         const int q = q0 + tid;
         if (q < total) {  // lanes past the end are masked off (EXEC): they transfer nothing
             const int sidx = q / chunks, ch = q - sidx * chunks;
@@ -578,7 +578,7 @@ __device__ __forceinline__ void stage_slabs(const T* __restrict__ base, int64_t 
 }
 
 template <typename T, int P, int XCHG>
-__global__ __launch_bounds__(256) void agg_fwd_nchw_k3_lds(const T* __restrict__ x, const T* __restrict__ w,
+__global__ __launch_bounds__(512) void agg_fwd_nchw_k3_lds(const T* __restrict__ x, const T* __restrict__ w,
                                                           T* __restrict__ out, int heads, int C, int wC, int H, int W,
                                                           int R, int tiles_per_nh, int sle, int64_t x_elems) {
     typedef typename AccOf<T>::type A;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void agg_fwd_nchw_k3_lds(const T* __restrict__
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     T* slab = reinterpret_cast<T*>(cot_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int segs = W / P, J = C / wC, TR = 4 * R, rows_nh = wC * H;
+    const int segs = W / P, J = C / wC, TR = (blockDim.x >> 6) * R, rows_nh = wC * H;
     const int64_t HW = (int64_t)H * W;
     const int tile = blockIdx.x % tiles_per_nh;
     const int64_t nh = blockIdx.x / tiles_per_nh;
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void agg_fwd_nchw_k3_lds(const T* __restrict__
 
 // fused backward v3 (heads == 1): gO and x slabs staged JP channels at a time (JP*2 slabs resident)
 template <typename T, int P, int XCHG, bool DO_GX, bool DO_GW>
-__global__ __launch_bounds__(256) void agg_bwd_nchw_k3_lds(const T* __restrict__ gout, const T* __restrict__ x,
+__global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__ gout, const T* __restrict__ x,
                                                           const T* __restrict__ w, T* __restrict__ gx,
                                                           T* __restrict__ gw, int C, int wC, int H, int W, int R,
                                                           int tiles_per_n, int sle, int JP, int64_t elems) {
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void agg_bwd_nchw_k3_lds(const T* __restrict__
     T* gslab = reinterpret_cast<T*>(cot_smem);
     T* xslab = gslab + (int64_t)JP * sle;  // (only used when DO_GW)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int segs = W / P, J = C / wC, TR = 4 * R, rows_n = wC * H;
+    const int segs = W / P, J = C / wC, TR = (blockDim.x >> 6) * R, rows_n = wC * H;
     const int64_t HW = (int64_t)H * W;
     const int tile = blockIdx.x % tiles_per_n;
     const int n = blockIdx.x / tiles_per_n;
@@ -765,12 +765,14 @@ const char* last_kernel_nchw() { return g_last_kernel; }
 
 // run-time tuning knobs (cot_set_tuning): 0 = kernel version (0 auto, 1 force v1, 2 force v2),
 // 1 = max P forward, 2 = max P backward, 3 = lane-exchange primitive (-1 auto/probe, 0 DPP, 1 ds_bpermute),
-// 4 = v3 fused backward: channel groups staged in LDS per phase (0 = default 4)
+// 4 = v3 fused backward: channel groups staged in LDS per phase (0 = default 4),
+// 5 = v3 waves per workgroup (4 or 8), 6 = v3 extra dynamic LDS per workgroup in KiB (occupancy shaping: fewer
+//     co-resident workgroups => their load / compute / store phases interleave instead of running in lock-step)
 // defaults from the on-device A/B (profiles/r01_agg_variants.log, N80xC64x56x56 bf16): forward P=4 (v3 22.0 us vs 26.0 at P=8),
 // fused backward P=2 with 4 channel groups per LDS phase (v3 45.4 us; 27.3 vs 31.8 us at 28x28)
-static int g_tune[5] = {0, 4, 2, -1, 0};
+static int g_tune[7] = {0, 4, 2, -1, 0, 4, 0};
 int set_tuning_nchw(int key, int value) {
-    if (key < 0 || key > 4) return -1;
+    if (key < 0 || key > 6) return -1;
     g_tune[key] = value;
     return 0;
 }
@@ -819,7 +821,7 @@ static inline bool use_v2(int W, int P) { return g_tune[0] != 1 && (W / P) <= 64
 // v3 (LDS slabs) needs 16-byte aligned channel-group / image strides and a tile that fits LDS comfortably
 struct LdsPlan {
     bool ok;
-    int R, TR, tiles, sle;
+    int R, TR, tiles, sle, nthreads;
     size_t lds_bytes;
 };
 template <typename T> static inline LdsPlan plan_lds(const cot_agg_geom& g, int P, int nslab) {
@@ -829,13 +831,17 @@ template <typename T> static inline LdsPlan plan_lds(const cot_agg_geom& g, int 
     const int64_t HW = (int64_t)g.H * g.W;
     if (segs > 64 || ((int64_t)g.wC * HW) % VE != 0 || ((int64_t)g.C * HW) % VE != 0) return p;
     if ((int64_t)g.N * g.C * HW < VE) return p;
+    const int nw = g_tune[5] == 8 ? 8 : 4;
+    p.nthreads = nw * 64;
     p.R = 64 / segs;
-    p.TR = 4 * p.R;
+    p.TR = nw * p.R;
     p.tiles = (g.wC * g.H + p.TR - 1) / p.TR;
     p.sle = (((p.TR + 2) * g.W + VE) + VE - 1) / VE * VE;  // rows + alignment slack, multiple of a 16-byte chunk
     const int64_t chunks = (int64_t)nslab * (p.sle / VE);
-    p.lds_bytes = (size_t)((chunks + 255) / 256 * 256) * 16;  // every lane of the last copy round lands in-bounds
+    p.lds_bytes = (size_t)chunks * 16;
     p.ok = p.lds_bytes <= 64 * 1024;
+    if (g_tune[6] > 0) p.lds_bytes += (size_t)g_tune[6] * 1024;
+    if (p.lds_bytes > 160 * 1024) p.lds_bytes = 160 * 1024;
     return p;
 }
 
@@ -845,7 +851,7 @@ static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, 
     if ((g_tune[0] == 0 || g_tune[0] == 3) && sizeof(T) <= 4) {
         const LdsPlan p = plan_lds<T>(g, P, g.C / g.wC);
         if (p.ok) {
-            const dim3 grid((unsigned)((int64_t)p.tiles * g.N * g.heads)), block(256);
+            const dim3 grid((unsigned)((int64_t)p.tiles * g.N * g.heads)), block(p.nthreads);
             const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
                 COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
@@ -907,7 +913,7 @@ static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw
         int JP = g_tune[4] > 0 && g_tune[4] <= J ? g_tune[4] : (J >= 4 ? 4 : J);
         const LdsPlan p = plan_lds<T>(g, P, (GW ? 2 : 1) * JP);
         if (p.ok) {
-            const dim3 grid((unsigned)((int64_t)p.tiles * g.N)), block(256);
+            const dim3 grid((unsigned)((int64_t)p.tiles * g.N)), block(p.nthreads);
             const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
                 COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 0, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,

@@ -45,10 +45,13 @@ def main():
         "v2": [(0, 2), (1, 4)], "v2_fP8": [(0, 2), (1, 8)],
         "v3": [(0, 3), (1, 4), (4, 4)], "v3_fP8": [(0, 3), (1, 8), (4, 4)], "v3_jp2": [(0, 3), (1, 4), (4, 2)],
         "v3_jp8": [(0, 3), (1, 8), (4, 8)], "v3_bP2": [(0, 3), (1, 4), (2, 2), (4, 4)],
+        "v3d": [(0, 3)], "v3d_nw8": [(0, 3), (5, 8)], "v3d_pad16": [(0, 3), (6, 16)], "v3d_pad32": [(0, 3), (6, 32)],
+        "v3d_pad56": [(0, 3), (6, 56)], "v3d_nw8_pad32": [(0, 3), (5, 8), (6, 32)], "v3d_bP4": [(0, 3), (2, 4)],
+        "v3d_bP4_pad32": [(0, 3), (2, 4), (6, 32)],
     }
 
     def set_variant(name):
-        for k, v in ((0, 0), (1, 4), (2, 4), (3, -1), (4, 0)):
+        for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0)):
             L.cot_set_tuning(k, v)
         for k, v in VAR[name]:
             L.cot_set_tuning(k, v)
@@ -126,7 +129,7 @@ def main():
                 print(msg, flush=True)
             del sets
             torch.cuda.empty_cache()
-    for k, v in ((0, 0), (1, 4), (2, 4), (3, -1), (4, 0)):
+    for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0)):
         L.cot_set_tuning(k, v)
     if args.out:
         json.dump(rows, open(args.out, "w"), indent=1)

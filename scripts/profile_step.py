@@ -20,24 +20,36 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--model", default="cotnet50")
 ap.add_argument("--out", default="gpurun_out/torch_prof.txt")
 ap.add_argument("--rows", type=int, default=70)
+ap.add_argument("--mixed", action="store_true", help="bf16 weights + FlatSGD instead of autocast + torch SGD")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.backends.cudnn.benchmark = True
 torch.manual_seed(0)
 model = cotnet_amd.create_model(args.model, num_classes=1000).to(dev).train()
-opt = make_optimizer(model, 0.03, 4e-5)
-red = GradBucketReducer(model)
 x = torch.randn(args.batch, 3, 224, 224, device=dev)
 t = torch.randint(0, 1000, (args.batch,), device=dev)
+if args.mixed:
+    from cotnet_amd.flat_sgd import FlatSGD, to_mixed_bf16
+    to_mixed_bf16(model)
+    x = x.bfloat16()
+    opt = FlatSGD(model, lr=0.03, weight_decay=4e-5)
 
-
-def step():
-    red.zero_grad()
-    with torch.autocast("cuda", dtype=torch.bfloat16):
+    def step():
+        opt.zero_grad()
         loss = torch.nn.functional.cross_entropy(model(x).float(), t)
-    loss.backward()
-    red.finish()
-    opt.step()
+        loss.backward()
+        opt.step()
+else:
+    opt = make_optimizer(model, 0.03, 4e-5)
+    red = GradBucketReducer(model)
+
+    def step():
+        red.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(model(x).float(), t)
+        loss.backward()
+        red.finish()
+        opt.step()
 
 
 for _ in range(4):
