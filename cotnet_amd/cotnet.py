@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .aggregation_zeropad import LocalConvolution
+from .fused_bn import fused_bn_act
 from .layers import get_act_layer
 from .registry import build_model_with_cfg, register_model
 from .resnet import ResNet
@@ -34,6 +35,17 @@ def _cfg(url="", **kwargs):
 
 
 default_cfgs = {"cot_basic": _cfg(url="")}
+
+
+def act_name(m):
+    """'relu' / 'silu' / None for the activation modules the fused BN kernels implement, else False"""
+    if m is None or isinstance(m, nn.Identity):
+        return None
+    if isinstance(m, nn.ReLU):
+        return "relu"
+    if isinstance(m, nn.SiLU):
+        return "silu"
+    return False
 
 
 def radix2_fuse(x, k, se):
@@ -89,16 +101,19 @@ class CotLayer(nn.Module):
             nn.Conv2d(attn_chs, self.radix * dim, 1))
 
     def forward(self, x):
-        k = self.key_embed(x)
+        # Sequential members are called one by one so that each BatchNorm runs fused with its activation
+        # (cotnet_amd.fused_bn); module structure and state_dict keys are the reference's.
+        k = fused_bn_act(self.key_embed[0](x), self.key_embed[1], "relu")
         qk = torch.cat([x, k], dim=1)
         b, c, qk_hh, qk_ww = qk.size()
 
-        w = self.embed(qk)
+        w = fused_bn_act(self.embed[0](qk), self.embed[1], "relu")
+        w = self.embed[4](self.embed[3](w))
         w = w.view(b, 1, -1, self.kernel_size * self.kernel_size, qk_hh, qk_ww)
 
         x = self.conv1x1(x)
         x = self.local_conv(x, w)
-        x = self.act(self.bn(x))
+        x = fused_bn_act(x, self.bn, act_name(self.act) or None) if act_name(self.act) is not False else self.act(self.bn(x))
         return radix2_fuse(x, k, self.se)
 
 
@@ -143,18 +158,19 @@ class CoXtLayer(nn.Module):
 
     def forward(self, x):
         batch_size, channels, height, width = x.size()
-        k = self.key_embed(x)
+        k = fused_bn_act(self.key_embed[0](x), self.key_embed[1], "relu")
         # channel-interleave [x0,k0,x1,k1,...] so each of the 2 conv groups sees matching x/k halves (ref :153-154)
         qk = torch.stack([x, k], dim=2).view(batch_size, -1, height, width)
 
-        w = self.embed(qk)
+        w = fused_bn_act(self.embed[0](qk), self.embed[1], "relu")
+        w = self.embed[4](self.embed[3](w))
         w = w.reshape(batch_size * self.dw_group, 1, -1, self.kernel_size * self.kernel_size, height, width)
 
         x = self.conv1x1(x)
         x = x.reshape(batch_size * self.dw_group, -1, height, width)
         x = self.local_conv(x, w)
         x = x.view(batch_size, -1, height, width)
-        x = self.act(self.bn(x))
+        x = fused_bn_act(x, self.bn, act_name(self.act) or None) if act_name(self.act) is not False else self.act(self.bn(x))
         return radix2_fuse(x, k, self.se)
 
 
@@ -193,14 +209,24 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         residual = x
-        x = self.bn1(self.conv1(x))
-        if self.drop_block is not None:
-            x = self.drop_block(x)
-        x = self.act1(x)
+        a1, a3 = act_name(self.act1), act_name(self.act3)
+        fusable = self.drop_block is None and a1 is not False and a3 is not False
+        if fusable:
+            x = fused_bn_act(self.conv1(x), self.bn1, a1)
+        else:
+            x = self.bn1(self.conv1(x))
+            if self.drop_block is not None:
+                x = self.drop_block(x)
+            x = self.act1(x)
         if self.avd is not None:
             x = self.avd(x)
         x = self.conv2(x)
-        x = self.bn3(self.conv3(x))
+        x = self.conv3(x)
+        if fusable and self.drop_path is None:
+            if self.downsample is not None:
+                residual = self.downsample(residual)
+            return fused_bn_act(x, self.bn3, a3, residual)  # bn3 + residual add + act3 in one pass
+        x = self.bn3(x)
         if self.drop_block is not None:
             x = self.drop_block(x)
         if self.drop_path is not None:

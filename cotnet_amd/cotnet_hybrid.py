@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .cotnet import CotLayer, _cfg
+from .fused_bn import fused_bn_act
 from .layers import BlurPool2d, SplitAttnConv2d, create_classifier, get_act_layer
 from .registry import build_model_with_cfg, register_model
 from .resnet import init_weights, make_blocks, make_stem
@@ -83,16 +84,21 @@ class CoTBottleneck(nn.Module):
 
     def forward(self, x):
         residual = x
-        x = self.bn1(self.conv1(x))
-        if self.drop_block is not None:
-            x = self.drop_block(x)
-        x = self.act1(x)
+        if self.drop_block is None:
+            x = fused_bn_act(self.conv1(x), self.bn1, "relu")  # act1 is hard-wired ReLU (ref :124)
+        else:
+            x = self.act1(self.drop_block(self.bn1(self.conv1(x))))
         if self.avd is not None and self.avd_first:
             x = self.avd(x)
         x = self.conv2(x)
         if self.avd is not None and not self.avd_first:
             x = self.avd(x)
-        x = self.bn3(self.conv3(x))
+        x = self.conv3(x)
+        if self.drop_block is None and self.drop_path is None:
+            if self.downsample is not None:
+                residual = self.downsample(residual)
+            return fused_bn_act(x, self.bn3, "relu", residual)  # act3 is hard-wired ReLU (ref :167)
+        x = self.bn3(x)
         if self.drop_block is not None:
             x = self.drop_block(x)
         if self.drop_path is not None:

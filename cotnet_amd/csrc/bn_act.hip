@@ -1,0 +1,319 @@
+// bn_act.hip -- training-mode BatchNorm2d fused with its activation and residual add, NCHW, gfx950.
+//
+// SURVEY.md 8f rank 1 ("the steps either side of the CoT layer"): in the reference every BatchNorm is followed by a
+// separate in-place ReLU / SiLU pass and, at the end of a Bottleneck, a separate residual add
+// (models/cotnet.py:231-235,:248-262,:89-90).  On MI355X these are all HBM-bound passes over the same tensor, so they
+// are folded into the normalisation:
+//   forward   y = act(gamma * (x - mean_c) * rstd_c + beta [+ residual])           act in {identity, ReLU, SiLU}
+//   backward  g = dL/dy * act'(.)  ;  dbeta_c = sum g ; dgamma_c = sum g * xhat
+//             dx = gamma * rstd * (g - dbeta/M - xhat * dgamma/M) ;  dresidual = g
+// Batch statistics use per-block shifted sums merged with Chan's parallel-variance formula (no E[x^2]-E[x]^2
+// cancellation), biased variance for normalisation, unbiased for the running estimate -- torch.nn.BatchNorm2d's
+// convention (the reference relies on it through nn.BatchNorm2d).
+//
+// All kernels are HBM-bound.  Algorithmic traffic per element (e = storage bytes): forward 3e (+e with residual)
+// [stats read, apply read, write], backward 5e (+e) [reduce reads dy,x(,y); apply reads dy,x(,y), writes dx(,dres)].
+#include "cot_common.h"
+
+namespace cot {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+// block-wide sum of up to 3 values; result valid in thread 0
+template <int NV> __device__ __forceinline__ void block_sum(float (&v)[NV], float* smem /* >= NV*4 floats */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) smem[k * 16 + wave] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += smem[k * 16 + w];
+            v[k] = s;
+        }
+    }
+}
+
+// ---- forward statistics: grid (C, SPLIT); block handles images [s*nper, (s+1)*nper) of channel c -----------------
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x, float* __restrict__ part, int N, int C,
+                                                       int HW, int nper) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    float* smem = reinterpret_cast<float*>(cot_smem);
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    const int n0 = s * nper, n1 = min(N, n0 + nper);
+    const int vpp = HW / V;  // vectors per plane
+    float shift = 0.f;
+    if (n0 < n1) shift = (float)x[((int64_t)n0 * C + c) * HW];
+    float acc[2] = {0.f, 0.f};
+    const int64_t nvec = (int64_t)(n1 - n0) * vpp;
+    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
+        const int n = n0 + (int)(i / vpp), v = (int)(i % vpp);
+        const Vec<T, V> xv = ldv<T, V>(x + ((int64_t)n * C + c) * HW + (int64_t)v * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float d = (float)xv.v[k] - shift;
+            acc[0] += d;
+            acc[1] += d * d;
+        }
+    }
+    block_sum<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        float* p = part + ((int64_t)c * split + s) * 4;
+        const float cnt = (float)((int64_t)(n1 - n0) * HW);
+        p[0] = cnt;
+        p[1] = cnt > 0 ? shift + acc[0] / cnt : 0.f;                // mean of the chunk
+        p[2] = cnt > 0 ? acc[1] - acc[0] * acc[0] / cnt : 0.f;       // M2 of the chunk
+        p[3] = 0.f;
+    }
+}
+
+// one thread per channel: merge the SPLIT chunks (Chan), produce mean / rstd, update running statistics
+__global__ void bn_stats_finalize(const float* __restrict__ part, int C, int split, float eps, float momentum,
+                                  float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                  float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float n = 0.f, m = 0.f, M2 = 0.f;
+    for (int s = 0; s < split; ++s) {
+        const float* p = part + ((int64_t)c * split + s) * 4;
+        const float nb = p[0];
+        if (nb <= 0.f) continue;
+        const float delta = p[1] - m, nn = n + nb;
+        m += delta * nb / nn;
+        M2 += p[2] + delta * delta * n * nb / nn;
+        n = nn;
+    }
+    const float var = n > 0 ? M2 / n : 0.f;
+    mean[c] = m;
+    rstd[c] = 1.0f / sqrtf(var + eps);
+    if (running_mean) {
+        const float unbiased = n > 1 ? M2 / (n - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == ACT_SILU) return z / (1.f + __expf(-z));
+    return z;
+}
+
+// ---- forward apply: flat over (plane, vector) -------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, const T* __restrict__ res,
+                                                   T* __restrict__ y, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, int C, int HW, int64_t nvec,
+                                                   int act) {
+    const int vpp = HW / V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t plane = i / vpp;
+        const int c = (int)(plane % C);
+        const float a = gamma[c] * rstd[c], b = beta[c] - mean[c] * a;
+        const Vec<T, V> xv = ldv<T, V>(x + i * V);
+        Vec<T, V> rv, o;
+        if (res) rv = ldv<T, V>(res + i * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float z = (float)xv.v[k] * a + b;
+            if (res) z += (float)rv.v[k];
+            o.v[k] = (T)act_fwd(z, act);
+        }
+        stv<T, V>(y + i * V, o);
+    }
+}
+
+// g = dy * act'(z): ReLU uses the saved output (y > 0), SiLU recomputes z from x
+__device__ __forceinline__ float act_bwd(float dy, float z_or_y, int act) {
+    if (act == ACT_RELU) return z_or_y > 0.f ? dy : 0.f;
+    if (act == ACT_SILU) {
+        const float sg = 1.f / (1.f + __expf(-z_or_y));
+        return dy * sg * (1.f + z_or_y * (1.f - sg));
+    }
+    return dy;
+}
+
+// ---- backward reductions: grid (C, SPLIT): sum g and sum g*xhat per channel chunk -------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_reduce(const T* __restrict__ dy, const T* __restrict__ x,
+                                                    const T* __restrict__ y, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ part, int N,
+                                                    int C, int HW, int nper, int act) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    float* smem = reinterpret_cast<float*>(cot_smem);
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    const int n0 = s * nper, n1 = min(N, n0 + nper);
+    const int vpp = HW / V;
+    const float m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
+    float acc[2] = {0.f, 0.f};
+    const int64_t nvec = (int64_t)(n1 - n0) * vpp;
+    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
+        const int n = n0 + (int)(i / vpp), v = (int)(i % vpp);
+        const int64_t off = ((int64_t)n * C + c) * HW + (int64_t)v * V;
+        const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
+        Vec<T, V> yv;
+        if (act == ACT_RELU) yv = ldv<T, V>(y + off);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = ((float)xv.v[k] - m) * r;
+            const float g = act_bwd((float)dv.v[k], act == ACT_RELU ? (float)yv.v[k] : xh * ga + be, act);
+            acc[0] += g;
+            acc[1] += g * xh;
+        }
+    }
+    block_sum<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        float* p = part + ((int64_t)c * split + s) * 2;
+        p[0] = acc[0];
+        p[1] = acc[1];
+    }
+}
+
+__global__ void bn_bwd_finalize(const float* __restrict__ part, int C, int split, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sb = 0.f, sg = 0.f;
+    for (int s = 0; s < split; ++s) {
+        sb += part[((int64_t)c * split + s) * 2];
+        sg += part[((int64_t)c * split + s) * 2 + 1];
+    }
+    dbeta[c] = sb;
+    dgamma[c] = sg;
+}
+
+// ---- backward apply: dx (and dresidual = g) ---------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_apply_bwd(const T* __restrict__ dy, const T* __restrict__ x,
+                                                   const T* __restrict__ y, T* __restrict__ dx, T* __restrict__ dres,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                   int C, int HW, int64_t nvec, float inv_m, int act) {
+    const int vpp = HW / V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t plane = i / vpp;
+        const int c = (int)(plane % C);
+        const float m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
+        const float k1 = dbeta[c] * inv_m, k2 = dgamma[c] * inv_m, gr = ga * r;
+        const Vec<T, V> dv = ldv<T, V>(dy + i * V), xv = ldv<T, V>(x + i * V);
+        Vec<T, V> yv, o, og;
+        if (act == ACT_RELU) yv = ldv<T, V>(y + i * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = ((float)xv.v[k] - m) * r;
+            const float g = act_bwd((float)dv.v[k], act == ACT_RELU ? (float)yv.v[k] : xh * ga + be, act);
+            o.v[k] = (T)(gr * (g - k1 - xh * k2));
+            og.v[k] = (T)g;
+        }
+        stv<T, V>(dx + i * V, o);
+        if (dres) stv<T, V>(dres + i * V, og);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+static inline int pick_vec(size_t esize, int HW) {
+    int lim = (int)(16 / esize);
+    for (int V = 8; V >= 1; V >>= 1)
+        if (V <= lim && HW % V == 0) return V;
+    return 1;
+}
+static inline void pick_split(int N, int C, int* split, int* nper) {
+    int s = 1;
+    while (C * s < 2048 && s * 2 <= N) s *= 2;   // >= 8 blocks per CU of reduction work when the batch allows
+    *nper = (N + s - 1) / s;
+    *split = (N + *nper - 1) / *nper;
+}
+static inline unsigned flat_grid(int64_t nvec) {
+    int64_t b = ceil_div64(nvec, 256);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+int bn_workspace_floats(int N, int C) {
+    int split, nper;
+    pick_split(N, C, &split, &nper);
+    return C * split * 4;
+}
+
+template <typename T, int V>
+static int bn_fwd_launch(const T* x, const T* res, T* y, const float* gamma, const float* beta, float* mean,
+                         float* rstd, float* rmean, float* rvar, float* ws, int N, int C, int HW, float eps, float mom,
+                         int act, hipStream_t s) {
+    int split, nper;
+    pick_split(N, C, &split, &nper);
+    COT_LAUNCH((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
+    COT_LAUNCH(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
+               rstd, rmean, rvar);
+    const int64_t nvec = (int64_t)N * C * HW / V;
+    COT_LAUNCH((bn_apply_fwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, x, res, y, (const float*)mean,
+               (const float*)rstd, gamma, beta, C, HW, nvec, act);
+    return check_launch("bn_act_forward");
+}
+
+template <typename T, int V>
+static int bn_bwd_launch(const T* dy, const T* x, const T* y, T* dx, T* dres, const float* gamma, const float* beta,
+                         const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ws, int N, int C,
+                         int HW, int act, hipStream_t s) {
+    int split, nper;
+    pick_split(N, C, &split, &nper);
+    COT_LAUNCH((bn_bwd_reduce<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma, beta, ws, N, C, HW,
+               nper, act);
+    COT_LAUNCH(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
+    const int64_t nvec = (int64_t)N * C * HW / V;
+    COT_LAUNCH((bn_apply_bwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma, beta,
+               (const float*)dgamma, (const float*)dbeta, C, HW, nvec, 1.0f / (float)((int64_t)N * HW), act);
+    return check_launch("bn_act_backward");
+}
+
+template <typename T>
+int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* mean,
+                   float* rstd, float* rmean, float* rvar, float* ws, int N, int C, int HW, float eps, float mom, int act,
+                   hipStream_t s) {
+#define BN_F(VV) return bn_fwd_launch<T, VV>((const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, ws, N, C, HW, eps, mom, act, s)
+    const int v = pick_vec(sizeof(T), HW);
+    if (v == 8) BN_F((sizeof(T) <= 2 ? 8 : 1));
+    if (v == 4) BN_F((sizeof(T) <= 4 ? 4 : 1));
+    if (v == 2) BN_F(2);
+    BN_F(1);
+#undef BN_F
+}
+
+template <typename T>
+int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dres, const float* gamma,
+                    const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ws,
+                    int N, int C, int HW, int act, hipStream_t s) {
+#define BN_B(VV) return bn_bwd_launch<T, VV>((const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, ws, N, C, HW, act, s)
+    const int v = pick_vec(sizeof(T), HW);
+    if (v == 8) BN_B((sizeof(T) <= 2 ? 8 : 1));
+    if (v == 4) BN_B((sizeof(T) <= 4 ? 4 : 1));
+    if (v == 2) BN_B(2);
+    BN_B(1);
+#undef BN_B
+}
+
+template int bn_act_forward<float>(const void*, const void*, void*, const float*, const float*, float*, float*, float*,
+                                   float*, float*, int, int, int, float, float, int, hipStream_t);
+template int bn_act_forward<bf16_t>(const void*, const void*, void*, const float*, const float*, float*, float*, float*,
+                                    float*, float*, int, int, int, float, float, int, hipStream_t);
+template int bn_act_backward<float>(const void*, const void*, const void*, void*, void*, const float*, const float*,
+                                    const float*, const float*, float*, float*, float*, int, int, int, int, hipStream_t);
+template int bn_act_backward<bf16_t>(const void*, const void*, const void*, void*, void*, const float*, const float*,
+                                     const float*, const float*, float*, float*, float*, int, int, int, int,
+                                     hipStream_t);
+
+}  // namespace cot

@@ -90,6 +90,13 @@ int aggmix_backward_input(const T*, const T*, const T*, T*, const cot_agg_geom&,
 template <typename T>
 int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int, int, int, int, hipStream_t);
 int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
+int bn_workspace_floats(int N, int C);
+template <typename T>
+int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, float*,
+                   int, int, int, float, float, int, hipStream_t);
+template <typename T>
+int bn_act_backward(const void*, const void*, const void*, void*, void*, const float*, const float*, const float*,
+                    const float*, float*, float*, float*, int, int, int, int, hipStream_t);
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
 int set_tuning_nchw(int key, int value);
@@ -210,6 +217,47 @@ int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad
     if (rc) return rc;
     return sgd_flat(param, master, momentum_buf, grad, n, lr, momentum, weight_decay, grad_scale, nesterov, param_dtype,
                     grad_dtype, (hipStream_t)stream);
+}
+
+int cot_bn_act_workspace(int N, int C) { return (N > 0 && C > 0) ? bn_workspace_floats(N, C) : 0; }
+
+int cot_bn_act_forward(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                       float* save_mean, float* save_rstd, float* running_mean, float* running_var, float* workspace,
+                       int N, int C, int HW, float eps, float momentum, int act, int dtype, void* stream) {
+    if (!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace)
+        return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act");
+    if ((running_mean == NULL) != (running_var == NULL))
+        return set_error(COT_ERR_INVALID_ARG, "running_mean and running_var must be given together");
+    int rc = check_align16({x, residual, y});
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == COT_F32)
+        return bn_act_forward<float>(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var,
+                                     workspace, N, C, HW, eps, momentum, act, s);
+    if (dtype == COT_BF16)
+        return bn_act_forward<bf16_t>(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var,
+                                      workspace, N, C, HW, eps, momentum, act, s);
+    return set_error(COT_ERR_UNSUPPORTED, "bn_act: dtype %d (float32 / bfloat16 only)", dtype);
+}
+
+int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
+                        const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                        float* workspace, int N, int C, int HW, int act, int dtype, void* stream) {
+    if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace)
+        return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (act == 1 && !y) return set_error(COT_ERR_INVALID_ARG, "ReLU backward needs the saved output y");
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act");
+    int rc = check_align16({dy, x, y, dx, dresidual});
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == COT_F32)
+        return bn_act_backward<float>(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
+                                      workspace, N, C, HW, act, s);
+    if (dtype == COT_BF16)
+        return bn_act_backward<bf16_t>(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
+                                       workspace, N, C, HW, act, s);
+    return set_error(COT_ERR_UNSUPPORTED, "bn_act: dtype %d (float32 / bfloat16 only)", dtype);
 }
 
 int cot_profile_begin(void) {

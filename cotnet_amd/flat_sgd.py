@@ -24,9 +24,10 @@ from .data_parallel import GradBucketReducer
 
 
 def to_mixed_bf16(model):
-    """Conv2d / Linear parameters -> bf16 (in place); norm layers and buffers stay fp32.  Returns the model."""
+    """Conv2d / Linear / GroupNorm parameters -> bf16 (in place); BatchNorm parameters and all buffers stay fp32
+    (torch's group_norm wants its affine parameters in the input dtype; batch_norm takes fp32 ones).  Returns the model."""
     for m in model.modules():
-        if isinstance(m, (nn.Conv2d, nn.Linear)):
+        if isinstance(m, (nn.Conv2d, nn.Linear, nn.GroupNorm)):
             for p in m.parameters(recurse=False):
                 p.data = p.data.to(torch.bfloat16)
     return model

@@ -1,0 +1,92 @@
+"""BatchNorm2d + activation (+ residual add) as ONE fused HIP op for training.
+
+`fused_bn_act(x, bn, act, residual)` computes exactly what the reference's module sequences compute --
+`act(bn(x) [+ residual])` with `bn` an ordinary `nn.BatchNorm2d` (same parameters, buffers and state_dict keys,
+running statistics updated with torch's momentum / unbiased-variance convention) -- but in two HBM passes forward and
+two backward instead of one pass per module (models/cotnet.py:231-235 bn1+act1, :248-262 bn3 + residual + act3,
+:43-47 key_embed BN+ReLU, :89-90 bn + SiLU).  Device code: csrc/bn_act.hip behind cot_bn_act_forward/_backward.
+
+The fused path is taken for training-mode NCHW-contiguous fp32 / bf16 CUDA tensors; anything else (eval mode,
+channels_last, fp64, momentum=None, CPU) takes the plain torch modules, so results and state are identical either way.
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+
+ENABLED = os.environ.get("COT_FUSED_BN", "1") != "0"  # A/B switch: 0 = always take the plain torch modules
+_ACTS = {None: 0, "none": 0, "relu": 1, "silu": 2}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _BNAct(Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, act):
+        N, C, H, W = x.shape
+        L = _lib.lib()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.cot_bn_act_workspace(N, C), dtype=torch.float32, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = L.cot_bn_act_forward(_p(x), _p(residual), _p(y), _p(weight), _p(bias), _p(mean), _p(rstd),
+                                      _p(running_mean), _p(running_var), _p(ws), N, C, H * W, eps, momentum, act,
+                                      _lib.dtype_code(x.dtype), _stream())
+        _lib.check(rc, "cot_bn_act_forward")
+        ctx.act, ctx.has_res = act, residual is not None
+        ctx.save_for_backward(x, y if act == 1 else None, weight, bias, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, bias, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.cot_bn_act_workspace(N, C), dtype=torch.float32, device=x.device)
+        with torch.cuda.device_of(x):
+            rc = L.cot_bn_act_backward(_p(dy), _p(x), _p(y), _p(dx), _p(dres), _p(weight), _p(bias), _p(mean), _p(rstd),
+                                       _p(dgamma), _p(dbeta), _p(ws), N, C, H * W, ctx.act, _lib.dtype_code(x.dtype),
+                                       _stream())
+        _lib.check(rc, "cot_bn_act_backward")
+        return dx, dres, dgamma, dbeta, None, None, None, None, None
+
+
+def _torch_path(x, bn, act, residual):
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    if act == "relu":
+        return F.relu(y, inplace=True)
+    if act == "silu":
+        return F.silu(y, inplace=True)
+    return y
+
+
+def fused_bn_act(x, bn, act=None, residual=None):
+    """act(bn(x) [+ residual]) with `bn` an nn.BatchNorm2d.  Fused HIP kernels when eligible, torch otherwise."""
+    ok = (ENABLED and bn.training and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
+          and x.is_contiguous() and bn.affine and bn.track_running_stats and bn.momentum is not None
+          and bn.weight.dtype == torch.float32 and x.data_ptr() % 16 == 0
+          and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype
+                                    and residual.is_contiguous() and residual.data_ptr() % 16 == 0)))
+    if not ok:
+        return _torch_path(x, bn, act, residual)
+    bn.num_batches_tracked.add_(1)  # same bookkeeping as nn.BatchNorm2d.forward
+    return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                        float(bn.momentum), _ACTS[act])

@@ -9,6 +9,7 @@ every CoT recipe leaves it at 0).
 import torch.nn.functional as F
 from torch import nn
 
+from .fused_bn import fused_bn_act
 from .layers import AvgPool2dSame, DropPath, create_classifier
 
 
@@ -157,7 +158,11 @@ class ResNet(nn.Module):
         self.global_pool, self.fc = create_classifier(self.num_features, self.num_classes, pool_type=global_pool)
 
     def forward_features(self, x):
-        x = self.maxpool(self.act1(self.bn1(self.conv1(x))))
+        if isinstance(self.act1, nn.ReLU):
+            x = fused_bn_act(self.conv1(x), self.bn1, "relu")  # stem BN + ReLU in one pass over the 112x112 map
+        else:
+            x = self.act1(self.bn1(self.conv1(x)))
+        x = self.maxpool(x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
     def forward(self, x):

@@ -123,6 +123,22 @@ int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad
                  float momentum, float weight_decay, float grad_scale, int nesterov, int param_dtype, int grad_dtype,
                  void* stream);
 
+/* ---- training-mode BatchNorm2d fused with activation and residual add, NCHW.
+ * Replaces nn.BatchNorm2d + in-place ReLU/SiLU (+ `x += residual`) sequences of the reference's blocks
+ * (models/cotnet.py:231-235, :248-262, :89-90):
+ *     y = act(gamma*(x-mean_c)*rstd_c + beta [+ residual]),   act: 0 identity, 1 ReLU, 2 SiLU
+ * Batch statistics over (N, H*W) per channel (biased variance), saved in save_mean / save_rstd [C] for backward;
+ * running_mean/var (may both be NULL) are updated with `momentum` and the unbiased variance, as torch does.
+ * gamma/beta/statistics are fp32; x/residual/y are `dtype` (COT_F32 or COT_BF16).  workspace: cot_bn_act_workspace
+ * floats.  backward: dx, dgamma, dbeta (and dresidual = dy*act' when non-NULL); ReLU needs the saved output y. */
+int cot_bn_act_workspace(int N, int C);
+int cot_bn_act_forward(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                       float* save_mean, float* save_rstd, float* running_mean, float* running_var, float* workspace,
+                       int N, int C, int HW, float eps, float momentum, int act, int dtype, void* stream);
+int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
+                        const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                        float* workspace, int N, int C, int HW, int act, int dtype, void* stream);
+
 /* Per-launch device timing for bench.py's roofline object.  Between cot_profile_begin() and cot_profile_end()
  * every aggregation kernel is launched with start/stop events attached to its dispatch (hipExtLaunchKernelGGL),
  * so `ms` is the kernel's execution time on the device -- what rocprofv3 --kernel-trace reports -- free of host

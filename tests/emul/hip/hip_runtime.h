@@ -8,6 +8,7 @@
 #pragma once
 #include <pthread.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -75,12 +76,13 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         threads.emplace_back([=, &body]() {
             t_lane = t & 63;
             t_wave = t >> 6;
-            for (unsigned b = 0; b < grid.x; ++b) {
-                blockIdx = dim3(b, 0, 0);
-                threadIdx = dim3(t, 0, 0);
-                if (t < block.x) body();
-                pthread_barrier_wait(&g_blk->bar);  // block boundary: LDS is reused by the next block
-            }
+            for (unsigned by = 0; by < grid.y; ++by)
+                for (unsigned b = 0; b < grid.x; ++b) {
+                    blockIdx = dim3(b, by, 0);
+                    threadIdx = dim3(t, 0, 0);
+                    if (t < block.x) body();
+                    pthread_barrier_wait(&g_blk->bar);  // block boundary: LDS is reused by the next block
+                }
         });
     }
     for (auto& th : threads) th.join();
@@ -98,6 +100,9 @@ namespace cot { alignas(16) inline char cot_smem[160 * 1024]; }  // the kernels 
 #define COT_ASYNC_COPY16(gptr, lds_wave_base) \
     std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)
 
+inline float __expf(float x) { return std::exp(x); }
+using std::min;
+using std::max;
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 // only the two DPP controls the kernels use: 0x138 = wave_shr:1 (lane l <- l-1), 0x130 = wave_shl:1 (l <- l+1)

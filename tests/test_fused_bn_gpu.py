@@ -1,0 +1,66 @@
+"""fused_bn_act (csrc/bn_act.hip) on the GPU against the plain torch module sequence it replaces."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+from cotnet_amd import fused_bn
+from cotnet_amd.fused_bn import fused_bn_act
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act,use_res", [(None, False), ("relu", False), ("relu", True), ("silu", False)])
+@pytest.mark.parametrize("N,C,H", [(8, 64, 56), (8, 128, 28), (8, 256, 14), (8, 2048, 7), (3, 24, 5)])
+def test_matches_torch_modules(N, C, H, act, use_res, dtype):
+    torch.manual_seed(C + H)
+    bn_a = nn.BatchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5)
+        bn_a.bias.normal_(0, 0.2)
+    bn_b = copy.deepcopy(bn_a)
+    x = (torch.randn(N, C, H, H, device=DEV) * 1.3 + 0.4).to(dtype)
+    res = torch.randn(N, C, H, H, device=DEV).to(dtype) if use_res else None
+    dy = torch.randn(N, C, H, H, device=DEV).to(dtype)
+
+    def run(bn, enabled):
+        fused_bn.ENABLED = enabled
+        try:
+            xa = x.clone().requires_grad_(True)
+            ra = res.clone().requires_grad_(True) if use_res else None
+            y = fused_bn_act(xa, bn, act, ra)
+            y.backward(dy)
+            return y.detach().float(), xa.grad.float(), (ra.grad.float() if use_res else None)
+        finally:
+            fused_bn.ENABLED = True
+
+    ya, gxa, gra = run(bn_a, True)
+    yb, gxb, grb = run(bn_b, False)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert ((ya - yb).abs() <= tol * (1 + yb.abs())).all()
+    assert torch.allclose(bn_a.running_mean, bn_b.running_mean, atol=1e-5)
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
+    if dtype == torch.float32:  # bf16: the torch path rounds between its modules, gradients differ by that rounding
+        gtol = 2e-4
+        assert ((gxa - gxb).abs() <= gtol * (1 + gxb.abs())).all()
+        assert torch.allclose(bn_a.weight.grad, bn_b.weight.grad, rtol=1e-3, atol=1e-3)
+        assert torch.allclose(bn_a.bias.grad, bn_b.bias.grad, rtol=1e-3, atol=1e-3)
+        if use_res:
+            assert ((gra - grb).abs() <= gtol * (1 + grb.abs())).all()
+    else:
+        scale = gxb.abs().mean() + 1e-6
+        assert (gxa - gxb).abs().mean() < 0.02 * scale + 1e-3
+
+
+def test_eval_mode_and_channels_last_take_the_torch_path():
+    bn = nn.BatchNorm2d(16).to(DEV).eval()
+    x = torch.randn(2, 16, 8, 8, device=DEV)
+    assert torch.equal(fused_bn_act(x, bn, "relu"), torch.relu(bn(x)))
+    bn.train()
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    y = fused_bn_act(xcl, bn, "relu")
+    assert y.shape == x.shape and int(bn.num_batches_tracked) == 1

@@ -231,3 +231,52 @@ def test_fused_sgd_kernel_matches_torch_formula(pdt, gdt, nesterov):
         assert torch.equal(param, master_arg.to(pdt))
     else:
         assert torch.allclose(param, ref_p, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act,use_res", [(0, False), (1, False), (1, True), (2, False), (0, True)])
+@pytest.mark.parametrize("N,C,H,W", [(6, 8, 7, 7), (5, 16, 14, 14), (3, 4, 8, 8)])
+def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype):
+    """csrc/bn_act.hip (host-emulated) against torch's batch_norm + activation + residual, forward and backward"""
+    g = torch.Generator().manual_seed(N * C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.7).to(dtype)
+    res = torch.randn(N, C, H, W, generator=g).to(dtype) if use_res else None
+    dy = torch.randn(N, C, H, W, generator=g).to(dtype)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    # reference in fp32 on the same (rounded) inputs
+    xr = x.float().requires_grad_(True)
+    rr = res.float().requires_grad_(True) if use_res else None
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = torch.nn.functional.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    if use_res:
+        z = z + rr
+    yr = {0: lambda t: t, 1: torch.relu, 2: torch.nn.functional.silu}[act](z)
+    yr.backward(dy.float())
+    # kernels
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(C), torch.empty(C)
+    ws = torch.empty(_EMUL.cot_bn_act_workspace(N, C))
+    dt = _lib.dtype_code(dtype)
+    rc = _EMUL.cot_bn_act_forward(P(x), P(res) if use_res else None, P(y), P(gamma), P(beta), P(mean), P(rstd), P(rm),
+                                  P(rv), P(ws), N, C, H * W, 1e-5, 0.1, act, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert ((y.float() - yr.detach()).abs() <= tol * (1 + yr.detach().abs())).all()
+    assert torch.allclose(rm, rm_ref, atol=1e-5) and torch.allclose(rv, rv_ref, atol=1e-5)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if use_res else None
+    dgamma, dbeta = torch.empty(C), torch.empty(C)
+    rc = _EMUL.cot_bn_act_backward(P(dy), P(x), P(y), P(dx), P(dres) if use_res else None, P(gamma), P(beta), P(mean),
+                                   P(rstd), P(dgamma), P(dbeta), P(ws), N, C, H * W, act, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    if act == 1 and dtype == torch.bfloat16:
+        return  # ReLU mask taken from the ROUNDED output may differ from the fp32 reference at |z| ~ 1e-3: checked in fp32
+    gtol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert ((dx.float() - xr.grad).abs() <= gtol * (1 + xr.grad.abs())).all()
+    assert torch.allclose(dgamma, gr.grad, rtol=gtol * 10, atol=gtol * 10)
+    assert torch.allclose(dbeta, br.grad, rtol=gtol * 10, atol=gtol * 10)
+    if use_res:
+        assert ((dres.float() - rr.grad).abs() <= gtol * (1 + rr.grad.abs())).all()
