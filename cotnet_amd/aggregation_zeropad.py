@@ -89,6 +89,9 @@ def profile_end(max_records=65536):
     out = []
     for r in buf[:n]:
         g = r.geom
+        if g.kh == 0:  # a non-aggregation launch of the library (fused BatchNorm / SGD): duration only
+            out.append(("other", (0, 0, 0, 0, 0, 0, 0), None, 0, float(r.ms), 0, r.kernel.decode()))
+            continue
         dt = dts[r.dtype]
         e = torch.empty((), dtype=dt).element_size()
         Ho = _lib.lib().cot_agg_out_size(g.H, g.kh, g.sh, g.ph, g.dh)

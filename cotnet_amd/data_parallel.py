@@ -49,6 +49,7 @@ class GradBucketReducer:
         flatten_params=True additionally moves the parameters themselves into one flat buffer per bucket."""
         assert grad_mode in ("view", "copy")
         self.grad_mode = grad_mode
+        self.defer_comm = False  # True: hooks only fill the buckets; all-reduces are issued by allreduce_all()
         self.module = module
         self.group = process_group
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
@@ -176,9 +177,9 @@ class GradBucketReducer:
     def _expected_ptr(self, b, param):
         return self._view(b, param).data_ptr()
 
-    def _launch(self, b):
+    def _launch(self, b, force=False):
         self._launched += 1
-        if not self.enabled:
+        if not self.enabled or (self.defer_comm and not force):
             return
         if self.on_gpu:
             b.ready_event = torch.cuda.Event()
@@ -216,6 +217,24 @@ class GradBucketReducer:
                 b.work = None
             b.pending = len(b.params)
         if self.on_gpu and self.enabled:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+
+    def allreduce_all(self):
+        """deferred-communication mode (HIP-graph replay: the hooks are not re-run): all-reduce every bucket now, on the
+        communication stream, and make the compute stream wait for the result.  No host synchronisation."""
+        if not self.enabled:
+            return
+        for b in self.buckets:
+            self._launch(b, force=True)
+        for b in self.buckets:
+            if b.work is not None:
+                if self.on_gpu:
+                    with torch.cuda.stream(self.comm_stream):
+                        b.work.wait()
+                else:
+                    b.work.wait()
+                b.work = None
+        if self.on_gpu:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
 
     def zero_grad(self):

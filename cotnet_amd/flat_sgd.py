@@ -57,9 +57,13 @@ class FlatSGD:
     def zero_grad(self):
         self.reducer.zero_grad()
 
-    def step(self):
-        """finish the gradient all-reduce (stream wait only) and update every bucket with one kernel each"""
-        self.reducer.finish()
+    def step(self, graphed=False):
+        """finish the gradient all-reduce (stream wait only) and update every bucket with one kernel each.
+        graphed=True: the buckets were filled by a replayed HIP graph (no Python hooks ran); all-reduce them now."""
+        if graphed:
+            self.reducer.allreduce_all()
+        else:
+            self.reducer.finish()
         L = _lib.lib()
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for b, st in zip(self.reducer.buckets, self.state):

@@ -34,8 +34,9 @@ def test_layer_matches_reference_fixture(name, memory_format):
         y.backward(gout.to(DEV))
         # BASELINE bar 1e-3; the 7x7 train-mode case normalises over 98 samples per channel and its input gradient
         # moves by 1.6e-3 between MIOpen's and the CPU's fp32 convolutions (operator-level parity is 2e-5), so it
-        # gets 4e-3 -- the fp64 run below pins the same layer to 1e-9.
-        tol = 4e-3 if (mode == "train" and meta["H"] == 7) else 1e-3
+        # gets 1e-2 (measured 1.6e-3 with MIOpen's BatchNorm, 4.6e-3 with the fused BN kernels, whose own parity with
+        # torch is 2e-5 in tests/test_fused_bn_gpu.py) -- the fp64 run below pins the same layer to 1e-9.
+        tol = 1e-2 if (mode == "train" and meta["H"] == 7) else 1e-3
         assert (y.detach().cpu() - torch.from_numpy(gold[f"{mode}_y"])).abs().max() < tol
         assert (xin.grad.cpu() - torch.from_numpy(gold[f"{mode}_gx"])).abs().max() < tol
         for key, p in (("g_embed3_w", layer.embed[3].weight), ("g_key0_w", layer.key_embed[0].weight),
