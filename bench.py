@@ -53,7 +53,11 @@ def parse():
                          "autocast: fp32 weights under torch.autocast + torch.optim.SGD")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc"])
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
-    ap.add_argument("--no-graph", action="store_true", help="mixed precision only: do not capture the step in a HIP graph")
+    ap.add_argument("--graph", action="store_true",
+                    help="mixed precision only: capture forward+backward in a HIP graph (cotnet_amd.graph_step). OFF by "
+                         "default: MIOpen's split-K weight-gradient solvers accumulate into buffers that are zeroed outside "
+                         "the captured stream, so replays after the first double-count (measured, DESIGN.md 5.3)")
+    ap.add_argument("--deterministic", action="store_true", help="torch.backends.cudnn.deterministic = True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=48.0)
@@ -144,6 +148,7 @@ def main():
 
     torch.manual_seed(1234 + rank)
     torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.deterministic = args.deterministic
     model = cotnet_amd.create_model(args.model, num_classes=1000).to(dev)
     mf = torch.channels_last if args.layout == "nhwc" else torch.contiguous_format
     if args.layout == "nhwc":
@@ -171,7 +176,7 @@ def main():
             opt.step()
             return loss
 
-        if not args.no_graph:
+        if args.graph:
             from cotnet_amd.graph_step import GraphedTrainStep
             try:
                 gstep = GraphedTrainStep(model, opt, lambda o, tt: torch.nn.functional.cross_entropy(o.float(), tt), x, t)
