@@ -92,10 +92,15 @@ def last_kernel():
     return lib().cot_last_kernel().decode()
 
 
+_DTYPES = None
+
+
 def dtype_code(torch_dtype):
-    import torch
+    global _DTYPES
+    if _DTYPES is None:
+        import torch
+        _DTYPES = {torch.float32: COT_F32, torch.float64: COT_F64, torch.bfloat16: COT_BF16, torch.float16: COT_F16}
     try:
-        return {torch.float32: COT_F32, torch.float64: COT_F64, torch.bfloat16: COT_BF16,
-                torch.float16: COT_F16}[torch_dtype]
+        return _DTYPES[torch_dtype]
     except KeyError:
         raise TypeError(f"cotnet_amd: unsupported dtype {torch_dtype} (float32/float64/bfloat16/float16)")

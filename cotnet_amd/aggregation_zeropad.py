@@ -135,10 +135,11 @@ class AggregationZeropad(Function):
         geom = _lib.AggGeom(batch_size, input_channels, input_height, input_width, weight_heads, weight_channels,
                             kernel_size[0], kernel_size[1], stride[0], stride[1], padding[0], padding[1],
                             dilation[0], dilation[1])
-        with torch.cuda.device_of(input):
-            rc = _lib.lib().cot_agg_forward(_ptr(input), _ptr(weight), _ptr(output), ctypes.byref(geom),
-                                            _lib.dtype_code(input.dtype), layout, _stream())
-        _lib.check(rc, "cot_agg_forward")
+        # one process per GPU: tensors live on the current device, launches go to its current stream (ref :130,:143)
+        rc = _lib.lib().cot_agg_forward(_ptr(input), _ptr(weight), _ptr(output), ctypes.byref(geom),
+                                        _lib.dtype_code(input.dtype), layout, _stream())
+        if rc:
+            _lib.check(rc, "cot_agg_forward")
         ctx.geom, ctx.layout = geom, layout
         ctx.save_for_backward(input, weight)
         return output
@@ -160,11 +161,11 @@ class AggregationZeropad(Function):
             grad_weight = (_empty_nhwc_weight(weight.shape, weight) if layout == _lib.COT_NHWC
                            else torch.empty_like(weight))
         if grad_input is not None or grad_weight is not None:
-            with torch.cuda.device_of(input):
-                rc = _lib.lib().cot_agg_backward(_ptr(grad_output), _ptr(input), _ptr(weight), _ptr(grad_input),
-                                                 _ptr(grad_weight), ctypes.byref(ctx.geom),
-                                                 _lib.dtype_code(input.dtype), layout, _stream())
-            _lib.check(rc, "cot_agg_backward")
+            rc = _lib.lib().cot_agg_backward(_ptr(grad_output), _ptr(input), _ptr(weight), _ptr(grad_input),
+                                             _ptr(grad_weight), ctypes.byref(ctx.geom),
+                                             _lib.dtype_code(input.dtype), layout, _stream())
+            if rc:
+                _lib.check(rc, "cot_agg_backward")
         return grad_input, grad_weight, None, None, None, None
 
 

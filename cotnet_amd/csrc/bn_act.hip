@@ -256,11 +256,11 @@ static int bn_fwd_launch(const T* x, const T* res, T* y, const float* gamma, con
                          int act, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
-    COT_LAUNCH((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
-    COT_LAUNCH(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
+    hipLaunchKernelGGL((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
+    hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
                rstd, rmean, rvar);
     const int64_t nvec = (int64_t)N * C * HW / V;
-    COT_LAUNCH((bn_apply_fwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, x, res, y, (const float*)mean,
+    hipLaunchKernelGGL((bn_apply_fwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, x, res, y, (const float*)mean,
                (const float*)rstd, gamma, beta, C, HW, nvec, act);
     return check_launch("bn_act_forward");
 }
@@ -271,11 +271,11 @@ static int bn_bwd_launch(const T* dy, const T* x, const T* y, T* dx, T* dres, co
                          int HW, int act, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
-    COT_LAUNCH((bn_bwd_reduce<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma, beta, ws, N, C, HW,
+    hipLaunchKernelGGL((bn_bwd_reduce<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma, beta, ws, N, C, HW,
                nper, act);
-    COT_LAUNCH(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
     const int64_t nvec = (int64_t)N * C * HW / V;
-    COT_LAUNCH((bn_apply_bwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma, beta,
+    hipLaunchKernelGGL((bn_apply_bwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma, beta,
                (const float*)dgamma, (const float*)dbeta, C, HW, nvec, 1.0f / (float)((int64_t)N * HW), act);
     return check_launch("bn_act_backward");
 }

@@ -30,20 +30,33 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_WS = {}  # (N, C) -> workspace floats (pure function of the shape; avoids a library call per launch)
+_DT = {torch.float32: _lib.COT_F32, torch.bfloat16: _lib.COT_BF16}
+
+
+def _ws_floats(N, C):
+    k = (N, C)
+    v = _WS.get(k)
+    if v is None:
+        v = _WS[k] = _lib.lib().cot_bn_act_workspace(N, C)
+    return v
+
+
 class _BNAct(Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, act):
         N, C, H, W = x.shape
         L = _lib.lib()
         y = torch.empty_like(x)
-        mean = torch.empty(C, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = torch.empty(L.cot_bn_act_workspace(N, C), dtype=torch.float32, device=x.device)
-        with torch.cuda.device_of(x):
-            rc = L.cot_bn_act_forward(_p(x), _p(residual), _p(y), _p(weight), _p(bias), _p(mean), _p(rstd),
-                                      _p(running_mean), _p(running_var), _p(ws), N, C, H * W, eps, momentum, act,
-                                      _lib.dtype_code(x.dtype), _stream())
-        _lib.check(rc, "cot_bn_act_forward")
+        # one allocation for [mean | rstd | workspace]; host overhead matters: the step issues ~160 of these launches
+        nws = _ws_floats(N, C)
+        scratch = torch.empty(2 * C + nws, dtype=torch.float32, device=x.device)
+        mean, rstd, ws = scratch[:C], scratch[C:2 * C], scratch[2 * C:]
+        rc = L.cot_bn_act_forward(_p(x), _p(residual), _p(y), _p(weight), _p(bias), _p(mean), _p(rstd),
+                                  _p(running_mean), _p(running_var), _p(ws), N, C, H * W, eps, momentum, act,
+                                  _DT[x.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_bn_act_forward")
         ctx.act, ctx.has_res = act, residual is not None
         ctx.save_for_backward(x, y if act == 1 else None, weight, bias, mean, rstd)
         return y
@@ -56,14 +69,12 @@ class _BNAct(Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[1]) else None
-        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = torch.empty(L.cot_bn_act_workspace(N, C), dtype=torch.float32, device=x.device)
-        with torch.cuda.device_of(x):
-            rc = L.cot_bn_act_backward(_p(dy), _p(x), _p(y), _p(dx), _p(dres), _p(weight), _p(bias), _p(mean), _p(rstd),
-                                       _p(dgamma), _p(dbeta), _p(ws), N, C, H * W, ctx.act, _lib.dtype_code(x.dtype),
-                                       _stream())
-        _lib.check(rc, "cot_bn_act_backward")
+        scratch = torch.empty(2 * C + _ws_floats(N, C), dtype=torch.float32, device=x.device)
+        dgamma, dbeta, ws = scratch[:C], scratch[C:2 * C], scratch[2 * C:]
+        rc = L.cot_bn_act_backward(_p(dy), _p(x), _p(y), _p(dx), _p(dres), _p(weight), _p(bias), _p(mean), _p(rstd),
+                                   _p(dgamma), _p(dbeta), _p(ws), N, C, H * W, ctx.act, _DT[x.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_bn_act_backward")
         return dx, dres, dgamma, dbeta, None, None, None, None, None
 
 
@@ -80,6 +91,7 @@ def _torch_path(x, bn, act, residual):
 
 def fused_bn_act(x, bn, act=None, residual=None):
     """act(bn(x) [+ residual]) with `bn` an nn.BatchNorm2d.  Fused HIP kernels when eligible, torch otherwise."""
+    # (tensors are assumed to live on the current device, as everywhere in a one-process-per-GPU job)
     ok = (ENABLED and bn.training and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
           and x.is_contiguous() and bn.affine and bn.track_running_stats and bn.momentum is not None
           and bn.weight.dtype == torch.float32 and x.data_ptr() % 16 == 0

@@ -75,6 +75,66 @@ def _worker(rank, world, port, bucket_mb, q):
         dist.destroy_process_group()
 
 
+def _worker_copy_mode(rank, world, port, q):
+    """grad_mode='copy' + flatten_params + weight-decay groups + deferred communication (what FlatSGD / the graphed
+    step use), checked against the mean of the per-rank gradients"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cotnet_amd.flat_sgd import _decay_group
+        torch.manual_seed(7 + rank)
+        model = _net()
+        red = GradBucketReducer(model, bucket_mb=48.0, group_fn=_decay_group, grad_mode="copy", flatten_params=True)
+        assert {b.key for b in red.buckets} == {"decay", "no_decay"}
+        for b in red.buckets:  # parameters now live inside the flat parameter buffers
+            for p in b.params:
+                assert b.pflat.data_ptr() <= p.data_ptr() < b.pflat.data_ptr() + b.pflat.numel() * 4
+        for defer in (False, True):
+            red.defer_comm = defer
+            torch.manual_seed(50 + rank)
+            x, t = torch.randn(4, 3, 6, 6), torch.randint(0, 4, (4,))
+            ref = _net()
+            ref.load_state_dict(model.state_dict())
+            nn.functional.cross_entropy(ref(x), t).backward()
+            want = {}
+            for (n, p) in ref.named_parameters():
+                g = [torch.empty_like(p.grad) for _ in range(world)]
+                dist.all_gather(g, p.grad.contiguous())
+                want[n] = torch.stack(g).mean(0)
+            red.zero_grad()
+            nn.functional.cross_entropy(model(x), t).backward()
+            assert all(p.grad is None for p in model.parameters())  # handed over to the buckets
+            if defer:
+                red.finish()
+                red.allreduce_all()
+            else:
+                red.finish()
+            names = {p: n for n, p in model.named_parameters()}
+            for b in red.buckets:
+                for p, v in zip(b.params, b.views):
+                    assert torch.allclose(v, want[names[p]], atol=1e-6), (defer, names[p])
+        q.put((rank, 0, "ok"))
+    except Exception as e:
+        q.put((rank, -1, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_copy_mode_flat_params_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_copy_mode, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, _, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
 @pytest.mark.parametrize("bucket_mb", [48.0, 0.0005])  # one bucket / many tiny buckets
 def test_bucketed_allreduce_world2_gloo(bucket_mb):
     world, port = 2, _free_port()
