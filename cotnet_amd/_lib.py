@@ -41,6 +41,8 @@ SYMBOLS = {
     "cot_agg_backward_input": (_I, [_P, _P, _P, _G, _I, _I, _P]),
     "cot_agg_backward_weight": (_I, [_P, _P, _P, _G, _I, _I, _P]),
     "cot_agg_backward": (_I, [_P, _P, _P, _P, _P, _G, _I, _I, _P]),
+    "cot_agg_softmax_forward": (_I, [_P, _P, _P, _P, _G, _I, _P]),
+    "cot_agg_softmax_backward": (_I, [_P, _P, _P, _P, _P, _G, _I, _P]),
     "cot_aggmix_forward": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),
     "cot_aggmix_backward_input": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _I, _P]),
     "cot_aggmix_backward_weight": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),

@@ -207,3 +207,55 @@ class LocalConvolution(torch.nn.Module):
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
                 f"padding={self.padding}, dilation={self.dilation}")
+
+
+# ---- window softmax + aggregation in one kernel --------------------------------------------------
+class AggregationZeropadSoftmax(Function):
+    """out = aggregation_zeropad(input, softmax(logits, dim=3)) -- LR-Net's attention application
+    (models/lr_net.py:94-96) -- with the softmax fused into the aggregation kernels (3x3/s1/p1/d1, NCHW)."""
+
+    @staticmethod
+    def forward(ctx, input, logits, geom):
+        input, logits = _aligned(input.detach().contiguous()), _aligned(logits.detach().contiguous())
+        N, heads, C = geom.N, geom.heads, geom.C
+        out = torch.empty((N, heads * C, geom.H, geom.W), dtype=input.dtype, device=input.device)
+        probs = torch.empty_like(logits)
+        rc = _lib.lib().cot_agg_softmax_forward(_ptr(input), _ptr(logits), _ptr(out), _ptr(probs), ctypes.byref(geom),
+                                                _lib.dtype_code(input.dtype), _stream())
+        if rc:
+            _lib.check(rc, "cot_agg_softmax_forward")
+        ctx.geom = geom
+        ctx.save_for_backward(input, probs)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, probs = ctx.saved_tensors
+        grad_output = _aligned(grad_output.contiguous())
+        gx, gl = torch.empty_like(input), torch.empty_like(probs)
+        rc = _lib.lib().cot_agg_softmax_backward(_ptr(grad_output), _ptr(input), _ptr(probs), _ptr(gx), _ptr(gl),
+                                                 ctypes.byref(ctx.geom), _lib.dtype_code(input.dtype), _stream())
+        if rc:
+            _lib.check(rc, "cot_agg_softmax_backward")
+        return gx, gl, None
+
+
+def softmax_fusable(input, logits, kernel_size, stride, padding, dilation):
+    k, s, p, d = _pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation)
+    return (input.is_cuda and k == (3, 3) and s == (1, 1) and p == (1, 1) and d == (1, 1) and logits.shape[1] == 1
+            and input.dtype == logits.dtype and input.dtype in (torch.float32, torch.bfloat16, torch.float16))
+
+
+def aggregation_zeropad_softmax(input, logits, kernel_size=3, stride=1, padding=0, dilation=1):
+    """softmax over the kh*kw window of `logits` [N,heads,wC,kh*kw,Ho,Wo], then aggregation_zeropad.  Uses the fused
+    kernels when the geometry is the 3x3 / stride-1 / pad-1 single-head one, else softmax + aggregation_zeropad."""
+    assert input.shape[0] == logits.shape[0] and (input.shape[1] % logits.shape[2] == 0)
+    if softmax_fusable(input, logits, kernel_size, stride, padding, dilation):
+        N, C, H, W = input.shape
+        geom = _lib.AggGeom(N, C, H, W, 1, logits.shape[2], 3, 3, 1, 1, 1, 1, 1, 1)
+        try:
+            return AggregationZeropadSoftmax.apply(input, logits, geom)
+        except RuntimeError as e:
+            if "not covered" not in str(e):  # COT_ERR_UNSUPPORTED (tile does not fit LDS, odd alignment): compose
+                raise
+    return aggregation_zeropad(input, torch.softmax(logits, dim=3), kernel_size, stride, padding, dilation)

@@ -577,10 +577,15 @@ __device__ __forceinline__ void stage_slabs(const T* __restrict__ base, int64_t 
     }
 }
 
-template <typename T, int P, int XCHG>
+// SM = 1: window-softmax producer fused in front of the aggregation (LR-Net's
+// F.softmax(w, dim=3) + LocalConvolution, models/lr_net.py:94-96): `w` holds LOGITS, the lane normalises its own
+// 9 taps per pixel in registers (the taps of a pixel all live in one lane, so no cross-lane reduction is needed),
+// writes the probabilities to `probs` (what backward needs) and aggregates with them.
+template <typename T, int P, int XCHG, int SM>
 __global__ __launch_bounds__(512) void agg_fwd_nchw_k3_lds(const T* __restrict__ x, const T* __restrict__ w,
                                                           T* __restrict__ out, int heads, int C, int wC, int H, int W,
-                                                          int R, int tiles_per_nh, int sle, int64_t x_elems) {
+                                                          int R, int tiles_per_nh, int sle, int64_t x_elems,
+                                                          T* __restrict__ probs) {
     typedef typename AccOf<T>::type A;
     constexpr int VE = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
@@ -613,6 +618,28 @@ __global__ __launch_bounds__(512) void agg_fwd_nchw_k3_lds(const T* __restrict__
         const T* wp = w + (nh * wC + wc) * 9 * HW + (int64_t)h * W + w0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[t] = ldv<T, P>(wp + t * HW);
+        if (SM) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                A m = (A)wr[0].v[i];
+#pragma unroll
+                for (int t = 1; t < 9; ++t) m = (A)wr[t].v[i] > m ? (A)wr[t].v[i] : m;
+                A e[9], sum = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    e[t] = (A)expf((float)((A)wr[t].v[i] - m));
+                    sum += e[t];
+                }
+                const A inv = (A)1 / sum;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wr[t].v[i] = (T)(e[t] * inv);  // rounded once: forward and backward agree
+            }
+            if (valid && probs) {
+                T* pp = probs + (nh * wC + wc) * 9 * HW + (int64_t)h * W + w0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) stv<T, P>(pp + t * HW, wr[t]);
+            }
+        }
     }
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes every wave's slab chunks visible
 
@@ -643,7 +670,9 @@ __global__ __launch_bounds__(512) void agg_fwd_nchw_k3_lds(const T* __restrict__
 }
 
 // fused backward v3 (heads == 1): gO and x slabs staged JP channels at a time (JP*2 slabs resident)
-template <typename T, int P, int XCHG, bool DO_GX, bool DO_GW>
+// SM = 1: `w` holds the saved probabilities and `gw` receives the gradient w.r.t. the LOGITS:
+// d_logit_t = p_t * (g_t - sum_u p_u g_u) per pixel, again entirely in-lane.
+template <typename T, int P, int XCHG, bool DO_GX, bool DO_GW, int SM = 0>
 __global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__ gout, const T* __restrict__ x,
                                                           const T* __restrict__ w, T* __restrict__ gx,
                                                           T* __restrict__ gw, int C, int wC, int H, int W, int R,
@@ -743,6 +772,20 @@ __global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__
                         for (int i = 0; i < P; ++i) gwacc[kh * 3 + kw][i] += xr[i + kw] * gr[1][i + 1];
                 }
             }
+        }
+    }
+    if (DO_GW && SM) {
+        const T* pp = w + plane * 9 * HW + (int64_t)h * W + w0;
+        Vec<T, P> pr[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) pr[t] = ldv<T, P>(pp + t * HW);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            A dot = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dot += (A)pr[t].v[i] * gwacc[t][i];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) gwacc[t][i] = (A)pr[t].v[i] * (gwacc[t][i] - dot);
         }
     }
     if (DO_GW && valid) {
@@ -854,11 +897,11 @@ static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, 
             const dim3 grid((unsigned)((int64_t)p.tiles * g.N * g.heads)), block(p.nthreads);
             const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
-                COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
-                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe);
+                COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr);
             else
-                COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
-                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe);
+                COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr);
             g_last_kernel = "agg_fwd_nchw_k3_lds";
             return check_launch(g_last_kernel);
         }
@@ -984,7 +1027,65 @@ int agg_backward_nchw(const T* gout, const T* x, const T* w, T* gx, T* gw, const
     return rc;
 }
 
+// window-softmax mode: only the LDS-staged 3x3 kernels implement it; anything else reports "unsupported" and the
+// Python layer composes softmax + aggregation instead.
+template <typename T, int P>
+static int launch_softmax_fwd(const T* x, const T* logits, T* out, T* probs, const cot_agg_geom& g, hipStream_t s) {
+    const LdsPlan p = plan_lds<T>(g, P, g.C / g.wC);
+    if (!p.ok) return COT_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((int64_t)p.tiles * g.N * g.heads)), block(p.nthreads);
+    const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
+    if (xchg_mode() == 0)
+        COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0, 1>), grid, block, p.lds_bytes, s, x, logits, out, g.heads, g.C, g.wC,
+                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs);
+    else
+        COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1, 1>), grid, block, p.lds_bytes, s, x, logits, out, g.heads, g.C, g.wC,
+                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs);
+    g_last_kernel = "agg_fwd_nchw_k3_lds<softmax>";
+    return check_launch(g_last_kernel);
+}
+template <typename T, int P>
+static int launch_softmax_bwd(const T* gout, const T* x, const T* probs, T* gx, T* glogits, const cot_agg_geom& g,
+                              hipStream_t s) {
+    const int J = g.C / g.wC;
+    const int JP = J >= 4 ? 4 : J;
+    const LdsPlan p = plan_lds<T>(g, P, 2 * JP);
+    if (!p.ok) return COT_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((int64_t)p.tiles * g.N)), block(p.nthreads);
+    const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
+    if (xchg_mode() == 0)
+        COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 0, true, true, 1>), grid, block, p.lds_bytes, s, gout, x, probs, gx,
+                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
+    else
+        COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 1, true, true, 1>), grid, block, p.lds_bytes, s, gout, x, probs, gx,
+                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
+    g_last_kernel = "agg_bwd_nchw_k3_lds<softmax>";
+    return check_launch(g_last_kernel);
+}
+
+template <typename T>
+int agg_softmax_forward_nchw(const T* x, const T* logits, T* out, T* probs, const cot_agg_geom& g, hipStream_t s) {
+    if (!is_k3_fast(g) || sizeof(T) > 4) return COT_ERR_UNSUPPORTED;
+    switch (pick_P<T>(g.W, 4)) {
+        case 4: return launch_softmax_fwd<T, (sizeof(T) <= 4 ? 4 : 1)>(x, logits, out, probs, g, s);
+        case 2: return launch_softmax_fwd<T, 2>(x, logits, out, probs, g, s);
+        default: return launch_softmax_fwd<T, 1>(x, logits, out, probs, g, s);
+    }
+}
+template <typename T>
+int agg_softmax_backward_nchw(const T* gout, const T* x, const T* probs, T* gx, T* glogits, const cot_agg_geom& g,
+                              hipStream_t s) {
+    if (!is_k3_fast(g) || g.heads != 1 || sizeof(T) > 4) return COT_ERR_UNSUPPORTED;
+    switch (pick_P<T>(g.W, 2)) {
+        case 2: return launch_softmax_bwd<T, 2>(gout, x, probs, gx, glogits, g, s);
+        default: return launch_softmax_bwd<T, 1>(gout, x, probs, gx, glogits, g, s);
+    }
+}
+
 #define INSTANTIATE(T)                                                                                          \
+    template int agg_softmax_forward_nchw<T>(const T*, const T*, T*, T*, const cot_agg_geom&, hipStream_t);     \
+    template int agg_softmax_backward_nchw<T>(const T*, const T*, const T*, T*, T*, const cot_agg_geom&,        \
+                                              hipStream_t);                                                     \
     template int agg_forward_nchw<T>(const T*, const T*, T*, const cot_agg_geom&, int, int, hipStream_t,        \
                                      const char*);                                                              \
     template int agg_backward_nchw<T>(const T*, const T*, const T*, T*, T*, const cot_agg_geom&, int, int,      \

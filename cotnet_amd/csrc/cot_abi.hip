@@ -97,6 +97,10 @@ int bn_act_forward(const void*, const void*, void*, const float*, const float*, 
 template <typename T>
 int bn_act_backward(const void*, const void*, const void*, void*, void*, const float*, const float*, const float*,
                     const float*, float*, float*, float*, int, int, int, int, hipStream_t);
+template <typename T>
+int agg_softmax_forward_nchw(const T*, const T*, T*, T*, const cot_agg_geom&, hipStream_t);
+template <typename T>
+int agg_softmax_backward_nchw(const T*, const T*, const T*, T*, T*, const cot_agg_geom&, hipStream_t);
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
 int set_tuning_nchw(int key, int value);
@@ -217,6 +221,42 @@ int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad
     if (rc) return rc;
     return sgd_flat(param, master, momentum_buf, grad, n, lr, momentum, weight_decay, grad_scale, nesterov, param_dtype,
                     grad_dtype, (hipStream_t)stream);
+}
+
+int cot_agg_softmax_forward(const void* x, const void* logits, void* out, void* probs, const cot_agg_geom* g, int dtype,
+                            void* stream) {
+    int Ho, Wo, rc = validate(g, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !logits || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x, logits, out, probs}))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case COT_F32: rc = agg_softmax_forward_nchw<float>((const float*)x, (const float*)logits, (float*)out, (float*)probs, *g, s); break;
+        case COT_BF16: rc = agg_softmax_forward_nchw<bf16_t>((const bf16_t*)x, (const bf16_t*)logits, (bf16_t*)out, (bf16_t*)probs, *g, s); break;
+        case COT_F16: rc = agg_softmax_forward_nchw<f16_t>((const f16_t*)x, (const f16_t*)logits, (f16_t*)out, (f16_t*)probs, *g, s); break;
+        default: rc = COT_ERR_UNSUPPORTED;
+    }
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "fused window-softmax aggregation: geometry/dtype not covered (compose softmax + cot_agg_forward)");
+    else g_kernel = last_kernel_nchw();
+    return rc;
+}
+
+int cot_agg_softmax_backward(const void* gout, const void* x, const void* probs, void* gx, void* glogits,
+                             const cot_agg_geom* g, int dtype, void* stream) {
+    int Ho, Wo, rc = validate(g, &Ho, &Wo);
+    if (rc) return rc;
+    if (!gout || !x || !probs || !gx || !glogits) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gout, x, probs, gx, glogits}))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case COT_F32: rc = agg_softmax_backward_nchw<float>((const float*)gout, (const float*)x, (const float*)probs, (float*)gx, (float*)glogits, *g, s); break;
+        case COT_BF16: rc = agg_softmax_backward_nchw<bf16_t>((const bf16_t*)gout, (const bf16_t*)x, (const bf16_t*)probs, (bf16_t*)gx, (bf16_t*)glogits, *g, s); break;
+        case COT_F16: rc = agg_softmax_backward_nchw<f16_t>((const f16_t*)gout, (const f16_t*)x, (const f16_t*)probs, (f16_t*)gx, (f16_t*)glogits, *g, s); break;
+        default: rc = COT_ERR_UNSUPPORTED;
+    }
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "fused window-softmax aggregation backward: geometry/dtype not covered");
+    else g_kernel = last_kernel_nchw();
+    return rc;
 }
 
 int cot_bn_act_workspace(int N, int C) { return (N > 0 && C > 0) ? bn_workspace_floats(N, C) : 0; }

@@ -85,6 +85,18 @@ int cot_agg_backward_weight(const void* gout, const void* x, void* gw,
 int cot_agg_backward(const void* gout, const void* x, const void* w, void* gx, void* gw,
                      const cot_agg_geom* g, int dtype, int layout, void* stream);
 
+/* ---- window softmax fused in front of the aggregation: what LR-Net's SelfAttLayer does with
+ * F.softmax(w, dim=3) followed by LocalConvolution (models/lr_net.py:94-96), in one kernel each way.
+ *   forward : probs = softmax over the kh*kw taps of `logits` (same shape as a weight tensor), written to `probs`
+ *             (may be NULL for inference); out = aggregation(x, probs)
+ *   backward: gx as cot_agg_backward_input with w = probs; glogits_t = p_t*(g_t - sum_u p_u g_u), g = d(out)/d(probs)
+ * NCHW, 3x3 / stride 1 / pad 1 / dilation 1 (backward: heads == 1) only: other geometries return
+ * COT_ERR_UNSUPPORTED and the caller composes softmax + cot_agg_forward. */
+int cot_agg_softmax_forward(const void* x, const void* logits, void* out, void* probs, const cot_agg_geom* g,
+                            int dtype, void* stream);
+int cot_agg_softmax_backward(const void* gout, const void* x, const void* probs, void* gx, void* glogits,
+                             const cot_agg_geom* g, int dtype, void* stream);
+
 /* ---- aggregation_zeropad_mix: 3x3 (w1) and 5x5 (w2) aggregation of the same x; NCHW only.
  * out[N, 2*heads*C, Ho, Wo] ordered [kernel_idx][head][c] (aggregation_zeropad_mix.py:20-74).
  * geometry: kh/kw/ph/pw of `g` describe the 3x3 set (kh=kw=3, pad1); p2h/p2w pad the 5x5 set.

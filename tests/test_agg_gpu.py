@@ -247,3 +247,37 @@ def test_mix_config5_shape_fp32():
     w2 = torch.randn(4, 1, 32, 25, 20, 20, generator=g)
     y = aggregation_zeropad_mix(x.to(DEV), w1.to(DEV), w2.to(DEV), 3, 5, 1, 1, 2, 1)
     assert (y.cpu() - cref.mix_forward(x, w1, w2, 1, 1, 2, 1)).abs().max() < 5e-5
+
+
+# ---- window softmax fused into the aggregation ------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,HW", STAGE_SHAPES)
+def test_fused_window_softmax(C, HW, dtype):
+    from cotnet_amd.aggregation_zeropad import aggregation_zeropad_softmax
+    g = torch.Generator().manual_seed(C)
+    N, wC = 3, C // 8
+    x = torch.randn(N, C, HW, HW, generator=g).to(dtype)
+    logits = (torch.randn(N, 1, wC, 9, HW, HW, generator=g) * 2).to(dtype)
+    gout = torch.randn(N, C, HW, HW, generator=g).to(dtype)
+    xa, la = x.to(DEV).requires_grad_(True), logits.to(DEV).requires_grad_(True)
+    y = aggregation_zeropad_softmax(xa, la, 3, 1, 1, 1)
+    assert "softmax" in _lib.last_kernel()
+    y.backward(gout.to(DEV))
+    # checker: torch softmax + the ORACLE aggregation, differentiated by autograd, in fp32 on the same inputs
+    xr, lr = x.float().requires_grad_(True), logits.float().requires_grad_(True)
+    yr = unfold_oracle.aggregation_unfold(xr, torch.softmax(lr, dim=3), 3, 1, 1, 1)
+    yr.backward(gout.float())
+    tol = 2e-5 if dtype == torch.float32 else 4e-2
+    assert ((y.detach().float().cpu() - yr.detach()).abs() <= tol * (1 + yr.detach().abs())).all()
+    assert ((xa.grad.float().cpu() - xr.grad).abs() <= tol * (1 + xr.grad.abs())).all()
+    assert ((la.grad.float().cpu() - lr.grad).abs() <= 4 * tol * (1 + lr.grad.abs())).all()
+
+
+def test_window_softmax_composes_when_not_fusable():
+    from cotnet_amd.aggregation_zeropad import aggregation_zeropad_softmax
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 9, 9, generator=g, dtype=torch.float64)
+    logits = torch.randn(2, 2, 4, 25, 9, 9, generator=g, dtype=torch.float64)
+    y = aggregation_zeropad_softmax(x.to(DEV), logits.to(DEV), 5, 1, 2, 1)   # 5x5, heads=2, fp64: composed path
+    want = cref.forward(x, torch.softmax(logits, dim=3), 5, 1, 2, 1)
+    assert (y.cpu() - want).abs().max() < 1e-9

@@ -280,3 +280,33 @@ def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype):
     assert torch.allclose(dbeta, br.grad, rtol=gtol * 10, atol=gtol * 10)
     if use_res:
         assert ((dres.float() - rr.grad).abs() <= gtol * (1 + rr.grad.abs())).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,H,W", [(64, 9, 56), (64, 11, 28), (64, 14, 14), (128, 7, 7)])
+def test_fused_window_softmax_aggregation(C, H, W, dtype):
+    """cot_agg_softmax_forward/_backward (host-emulated) against torch.softmax + the oracle aggregation via autograd"""
+    g = torch.Generator().manual_seed(C + H)
+    N, wC = 2, C // 8
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    logits = (torch.randn(N, 1, wC, 9, H, W, generator=g) * 2).to(dtype)
+    gout = torch.randn(N, C, H, W, generator=g).to(dtype)
+    geo = _lib.AggGeom(N, C, H, W, 1, wC, 3, 3, 1, 1, 1, 1, 1, 1)
+    dt = _lib.dtype_code(dtype)
+    out, probs = torch.empty_like(gout), torch.empty_like(logits)
+    assert _EMUL.cot_agg_softmax_forward(P(x), P(logits), P(out), P(probs), ctypes.byref(geo), dt, None) == 0, \
+        _EMUL.cot_last_error()
+    xr, lr = x.float().requires_grad_(True), logits.float().requires_grad_(True)
+    pr = torch.softmax(lr, dim=3)
+    yr = unfold_oracle.aggregation_unfold(xr, pr, 3, 1, 1, 1)
+    yr.backward(gout.float())
+    tol = 2e-5 if dtype == torch.float32 else 4e-2
+    assert ((probs.float() - pr.detach()).abs() <= tol).all()
+    assert ((out.float() - yr.detach()).abs() <= tol * (1 + yr.detach().abs())).all()
+    gx, gl = torch.empty_like(x), torch.empty_like(logits)
+    assert _EMUL.cot_agg_softmax_backward(P(gout), P(x), P(probs), P(gx), P(gl), ctypes.byref(geo), dt, None) == 0
+    assert ((gx.float() - xr.grad).abs() <= tol * (1 + xr.grad.abs())).all()
+    assert ((gl.float() - lr.grad).abs() <= (tol * 4) * (1 + lr.grad.abs())).all()
+    # unsupported geometry reports COT_ERR_UNSUPPORTED (-2) so that the Python layer composes the two ops
+    geo5 = _lib.AggGeom(N, C, H, W, 1, wC, 5, 5, 1, 1, 2, 2, 1, 1)
+    assert _EMUL.cot_agg_softmax_forward(P(x), P(logits), P(out), P(probs), ctypes.byref(geo5), dt, None) == -2
