@@ -82,10 +82,14 @@ def tuning():
     set_()
 
 
-@pytest.mark.parametrize("variant", ["v1", "v2_dpp", "v2_shfl", "v2_P8", "v3_lds", "v3_lds_P8_jp2", "v3_lds_jp8",
-                                     "v3_lds_nw8_bP4"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("C,H,W", [(64, 9, 56), (64, 11, 28), (64, 14, 14), (128, 7, 7), (64, 5, 8)])
+_ALL_VARIANTS = ["v1", "v2_dpp", "v2_shfl", "v2_P8", "v3_lds", "v3_lds_P8_jp2", "v3_lds_jp8", "v3_lds_nw8_bP4"]
+_SHAPES = [(16, 9, 56), (16, 11, 28), (32, 14, 14), (64, 7, 7), (16, 5, 8)]
+# fp32: every kernel generation x every shape; bf16 (same index arithmetic, packed rows): the default kernels only
+_VERSION_CASES = ([(c, h, w, torch.float32, v) for (c, h, w) in _SHAPES for v in _ALL_VARIANTS] +
+                  [(c, h, w, torch.bfloat16, v) for (c, h, w) in _SHAPES[:4] for v in ("v2_dpp", "v3_lds")])
+
+
+@pytest.mark.parametrize("C,H,W,dtype,variant", _VERSION_CASES)
 def test_k3_kernel_versions(C, H, W, dtype, variant, tuning):
     """every 3x3 kernel generation and lane-exchange primitive against the oracle (NCHW)"""
     kw = {"v1": dict(version=1), "v2_dpp": dict(version=2), "v2_shfl": dict(version=2, xchg=1),
@@ -93,7 +97,7 @@ def test_k3_kernel_versions(C, H, W, dtype, variant, tuning):
           "v3_lds_jp8": dict(version=3, jp=8), "v3_lds_nw8_bP4": dict(version=3, nw=8, bwd_p=4, pad=8)}[variant]
     tuning(**kw)
     g = torch.Generator().manual_seed(C + W)
-    N, wC = 2, C // 8
+    N, wC = 2, C // 8  # small channel counts keep the 256-host-thread emulation fast; indexing is size-agnostic
     x = torch.randn(N, C, H, W, generator=g).to(dtype)
     w = torch.randn(N, 1, wC, 9, H, W, generator=g).to(dtype)
     gout = torch.randn(N, C, H, W, generator=g).to(dtype)
@@ -283,7 +287,7 @@ def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("C,H,W", [(64, 9, 56), (64, 11, 28), (64, 14, 14), (128, 7, 7)])
+@pytest.mark.parametrize("C,H,W", [(16, 9, 56), (16, 11, 28), (32, 14, 14), (64, 7, 7)])
 def test_fused_window_softmax_aggregation(C, H, W, dtype):
     """cot_agg_softmax_forward/_backward (host-emulated) against torch.softmax + the oracle aggregation via autograd"""
     g = torch.Generator().manual_seed(C + H)
