@@ -48,10 +48,13 @@ SYMBOLS = {
     "cot_aggmix_backward_weight": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),
     "cot_set_tuning": (_I, [_I, _I]),
     "cot_xchg_mode": (_I, []),
+    "cot_radix_gap": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _P]),
+    "cot_radix_mix": (_I, [_P, _P, _P, _P, ctypes.c_int64, _I, _I, _P]),
+    "cot_radix_mix_backward": (_I, [_P] * 7 + [ctypes.c_int64, _I, _I, _P]),
     "cot_sgd_step": (_I, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                           _I, _I, _I, _P]),
     "cot_bn_act_workspace": (_I, [_I, _I]),
-    "cot_bn_act_forward": (_I, [_P] * 10 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
+    "cot_bn_act_forward": (_I, [_P] * 11 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "cot_bn_act_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _P]),
     "cot_profile_begin": (_I, []),
     "cot_profile_end": (_I, [ctypes.POINTER(ProfileRec), _I]),

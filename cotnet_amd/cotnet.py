@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .aggregation_zeropad import LocalConvolution
+from . import radix_tail
 from .fused_bn import fused_bn_act
 from .layers import get_act_layer
 from .registry import build_model_with_cfg, register_model
@@ -48,12 +49,30 @@ def act_name(m):
     return False
 
 
+def se_mlp(gap, se):
+    """The `se` branch (ref :71-77: 1x1 conv + BN + ReLU + 1x1 conv) applied to the pooled [B,C,1,1] descriptor.
+    A 1x1 convolution on a 1x1 map IS a matrix product with the same weights, so it is issued as one GEMM (F.linear on
+    the conv's own weight/bias) instead of a convolution call (which on ROCm costs layout transposes + cast kernels
+    around a tiny GEMM, forward and twice backward).  Same parameters, same state_dict, same function."""
+    c0, bn, act, c3 = se[0], se[1], se[2], se[3]
+    plain = all(isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.groups == 1 and c.stride == (1, 1)
+                and c.padding == (0, 0) for c in (c0, c3))
+    if not plain:
+        return se(gap)
+    h = F.linear(gap.flatten(1), c0.weight.flatten(1), c0.bias)
+    h = act(bn(h[:, :, None, None]))
+    return F.linear(h.flatten(1), c3.weight.flatten(1), c3.bias)
+
+
 def radix2_fuse(x, k, se):
     """ref :92-104 without the [B,C,2,H,W] temporaries.
     attn = softmax over the radix pair of se(GAP(x + k)), channel index of se's output = c*2 + r (:100)."""
     B, C = x.shape[:2]
+    if radix_tail.eligible(x, k):  # two fused HIP ops around the tiny se MLP (csrc/radix_tail.hip)
+        attn = F.softmax(se_mlp(radix_tail.radix_gap(x, k), se).view(B, C, 2), dim=2)
+        return radix_tail.radix_mix(x, k, attn)
     gap = (x + k).mean((2, 3), keepdim=True)
-    attn = F.softmax(se(gap).view(B, C, 2), dim=2)
+    attn = F.softmax(se_mlp(gap, se).view(B, C, 2), dim=2)
     a0 = attn[:, :, 0].reshape(B, C, 1, 1)
     a1 = attn[:, :, 1].reshape(B, C, 1, 1)
     return (x * a0 + k * a1).contiguous()

@@ -81,8 +81,9 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
 // one thread per channel: merge the SPLIT chunks (Chan), produce mean / rstd, update running statistics
 __global__ void bn_stats_finalize(const float* __restrict__ part, int C, int split, float eps, float momentum,
                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                                  float* __restrict__ running_var) {
+                                  float* __restrict__ running_var, long long* __restrict__ num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;  // nn.BatchNorm2d's bookkeeping, without a launch
     if (c >= C) return;
     float n = 0.f, m = 0.f, M2 = 0.f;
     for (int s = 0; s < split; ++s) {
@@ -252,13 +253,13 @@ int bn_workspace_floats(int N, int C) {
 
 template <typename T, int V>
 static int bn_fwd_launch(const T* x, const T* res, T* y, const float* gamma, const float* beta, float* mean,
-                         float* rstd, float* rmean, float* rvar, float* ws, int N, int C, int HW, float eps, float mom,
-                         int act, hipStream_t s) {
+                         float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW,
+                         float eps, float mom, int act, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
     hipLaunchKernelGGL((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
     hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
-               rstd, rmean, rvar);
+               rstd, rmean, rvar, nbt);
     const int64_t nvec = (int64_t)N * C * HW / V;
     hipLaunchKernelGGL((bn_apply_fwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, x, res, y, (const float*)mean,
                (const float*)rstd, gamma, beta, C, HW, nvec, act);
@@ -282,9 +283,9 @@ static int bn_bwd_launch(const T* dy, const T* x, const T* y, T* dx, T* dres, co
 
 template <typename T>
 int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* mean,
-                   float* rstd, float* rmean, float* rvar, float* ws, int N, int C, int HW, float eps, float mom, int act,
-                   hipStream_t s) {
-#define BN_F(VV) return bn_fwd_launch<T, VV>((const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, ws, N, C, HW, eps, mom, act, s)
+                   float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW, float eps,
+                   float mom, int act, hipStream_t s) {
+#define BN_F(VV) return bn_fwd_launch<T, VV>((const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, ws, N, C, HW, eps, mom, act, s)
     const int v = pick_vec(sizeof(T), HW);
     if (v == 8) BN_F((sizeof(T) <= 2 ? 8 : 1));
     if (v == 4) BN_F((sizeof(T) <= 4 ? 4 : 1));
@@ -307,9 +308,9 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
 }
 
 template int bn_act_forward<float>(const void*, const void*, void*, const float*, const float*, float*, float*, float*,
-                                   float*, float*, int, int, int, float, float, int, hipStream_t);
+                                   float*, long long*, float*, int, int, int, float, float, int, hipStream_t);
 template int bn_act_forward<bf16_t>(const void*, const void*, void*, const float*, const float*, float*, float*, float*,
-                                    float*, float*, int, int, int, float, float, int, hipStream_t);
+                                    float*, long long*, float*, int, int, int, float, float, int, hipStream_t);
 template int bn_act_backward<float>(const void*, const void*, const void*, void*, void*, const float*, const float*,
                                     const float*, const float*, float*, float*, float*, int, int, int, int, hipStream_t);
 template int bn_act_backward<bf16_t>(const void*, const void*, const void*, void*, void*, const float*, const float*,

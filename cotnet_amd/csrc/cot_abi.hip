@@ -92,8 +92,8 @@ int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int,
 int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
 int bn_workspace_floats(int N, int C);
 template <typename T>
-int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, float*,
-                   int, int, int, float, float, int, hipStream_t);
+int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, long long*,
+                   float*, int, int, int, float, float, int, hipStream_t);
 template <typename T>
 int bn_act_backward(const void*, const void*, const void*, void*, void*, const float*, const float*, const float*,
                     const float*, float*, float*, float*, int, int, int, int, hipStream_t);
@@ -101,6 +101,10 @@ template <typename T>
 int agg_softmax_forward_nchw(const T*, const T*, T*, T*, const cot_agg_geom&, hipStream_t);
 template <typename T>
 int agg_softmax_backward_nchw(const T*, const T*, const T*, T*, T*, const cot_agg_geom&, hipStream_t);
+template <typename T> int radix_gap(const void*, const void*, void*, int64_t, int, hipStream_t);
+template <typename T> int radix_mix(const void*, const void*, const void*, void*, int64_t, int, hipStream_t);
+template <typename T>
+int radix_mix_bwd(const void*, const void*, const void*, const void*, void*, void*, void*, int64_t, int, hipStream_t);
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
 int set_tuning_nchw(int key, int value);
@@ -259,11 +263,48 @@ int cot_agg_softmax_backward(const void* gout, const void* x, const void* probs,
     return rc;
 }
 
+static int tail_check(int64_t planes, int HW, int dtype) {
+    if (planes <= 0 || HW <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive planes/HW");
+    if (dtype != COT_F32 && dtype != COT_BF16)
+        return set_error(COT_ERR_UNSUPPORTED, "radix tail: dtype %d (float32 / bfloat16 only)", dtype);
+    return COT_OK;
+}
+
+int cot_radix_gap(const void* y, const void* k, void* gap, int64_t planes, int HW, int dtype, void* stream) {
+    int rc = tail_check(planes, HW, dtype);
+    if (rc) return rc;
+    if (!y || !k || !gap) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({y, k}))) return rc;
+    return dtype == COT_F32 ? radix_gap<float>(y, k, gap, planes, HW, (hipStream_t)stream)
+                            : radix_gap<bf16_t>(y, k, gap, planes, HW, (hipStream_t)stream);
+}
+
+int cot_radix_mix(const void* y, const void* k, const void* attn, void* out, int64_t planes, int HW, int dtype,
+                  void* stream) {
+    int rc = tail_check(planes, HW, dtype);
+    if (rc) return rc;
+    if (!y || !k || !attn || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({y, k, out}))) return rc;
+    return dtype == COT_F32 ? radix_mix<float>(y, k, attn, out, planes, HW, (hipStream_t)stream)
+                            : radix_mix<bf16_t>(y, k, attn, out, planes, HW, (hipStream_t)stream);
+}
+
+int cot_radix_mix_backward(const void* gout, const void* y, const void* k, const void* attn, void* gy, void* gk,
+                           void* gattn, int64_t planes, int HW, int dtype, void* stream) {
+    int rc = tail_check(planes, HW, dtype);
+    if (rc) return rc;
+    if (!gout || !y || !k || !attn || !gy || !gk || !gattn) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gout, y, k, gy, gk}))) return rc;
+    return dtype == COT_F32 ? radix_mix_bwd<float>(gout, y, k, attn, gy, gk, gattn, planes, HW, (hipStream_t)stream)
+                            : radix_mix_bwd<bf16_t>(gout, y, k, attn, gy, gk, gattn, planes, HW, (hipStream_t)stream);
+}
+
 int cot_bn_act_workspace(int N, int C) { return (N > 0 && C > 0) ? bn_workspace_floats(N, C) : 0; }
 
 int cot_bn_act_forward(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
-                       float* save_mean, float* save_rstd, float* running_mean, float* running_var, float* workspace,
-                       int N, int C, int HW, float eps, float momentum, int act, int dtype, void* stream) {
+                       float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, float* workspace, int N, int C, int HW, float eps, float momentum,
+                       int act, int dtype, void* stream) {
     if (!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace)
         return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act");
@@ -274,10 +315,10 @@ int cot_bn_act_forward(const void* x, const void* residual, void* y, const float
     hipStream_t s = (hipStream_t)stream;
     if (dtype == COT_F32)
         return bn_act_forward<float>(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var,
-                                     workspace, N, C, HW, eps, momentum, act, s);
+                                     (long long*)num_batches_tracked, workspace, N, C, HW, eps, momentum, act, s);
     if (dtype == COT_BF16)
         return bn_act_forward<bf16_t>(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var,
-                                      workspace, N, C, HW, eps, momentum, act, s);
+                                      (long long*)num_batches_tracked, workspace, N, C, HW, eps, momentum, act, s);
     return set_error(COT_ERR_UNSUPPORTED, "bn_act: dtype %d (float32 / bfloat16 only)", dtype);
 }
 

@@ -1,0 +1,133 @@
+// radix_tail.hip -- the radix-2 split-attention tail of the CoT layer, NCHW, gfx950.
+//
+// Reference (models/cotnet.py:92-104): x,k -> view/cat to [B,C,2,H,W] -> sum(dim=2) -> mean(H,W) -> se -> softmax over the
+// radix pair -> (x * attn).sum(dim=2): ~12 C*H*W-sized tensor passes for ~4 flop per element.  Here:
+//   radix_gap      gap[b,c]  = mean_hw(y + k)                                   reads y,k once
+//   radix_mix      out       = y*a0[b,c] + k*a1[b,c]                            reads y,k once, writes out
+//   radix_mix_bwd  gy = g*a0, gk = g*a1, ga0[b,c] = sum_hw g*y, ga1 = sum_hw g*k one pass over g,y,k
+// (the tiny se MLP + softmax between gap and mix stay in torch).  One wavefront per (b,c) plane: the per-plane scalars
+// are wave-uniform, plane rows are contiguous, loads are V-wide vectors when H*W allows.
+#include "cot_common.h"
+
+namespace cot {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_gap_kernel(const T* __restrict__ y, const T* __restrict__ k,
+                                                       T* __restrict__ gap, int64_t planes, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= planes) return;  // whole wave exits together (plane is wave-uniform)
+    const T* yp = y + plane * HW;
+    const T* kp = k + plane * HW;
+    float acc = 0.f;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc += (float)a.v[j] + (float)b.v[j];
+    }
+    acc = wave_sum_f(acc);
+    if (lane == 0) gap[plane] = (T)(acc / (float)HW);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_mix_kernel(const T* __restrict__ y, const T* __restrict__ k,
+                                                       const T* __restrict__ attn, T* __restrict__ out,
+                                                       int64_t planes, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= planes) return;
+    const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
+    const T* yp = y + plane * HW;
+    const T* kp = k + plane * HW;
+    T* op = out + plane * HW;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
+        Vec<T, V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.v[j] = (T)((float)a.v[j] * a0 + (float)b.v[j] * a1);
+        stv<T, V>(op + i, o);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_mix_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                           const T* __restrict__ k, const T* __restrict__ attn,
+                                                           T* __restrict__ gy, T* __restrict__ gk,
+                                                           T* __restrict__ gattn, int64_t planes, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= planes) return;
+    const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
+    const int64_t base = plane * HW;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> gv = ldv<T, V>(g + base + i), a = ldv<T, V>(y + base + i), b = ldv<T, V>(k + base + i);
+        Vec<T, V> oy, ok;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gg = (float)gv.v[j];
+            oy.v[j] = (T)(gg * a0);
+            ok.v[j] = (T)(gg * a1);
+            s0 += gg * (float)a.v[j];
+            s1 += gg * (float)b.v[j];
+        }
+        stv<T, V>(gy + base + i, oy);
+        stv<T, V>(gk + base + i, ok);
+    }
+    s0 = wave_sum_f(s0);
+    s1 = wave_sum_f(s1);
+    if (lane == 0) {
+        gattn[plane * 2] = (T)s0;
+        gattn[plane * 2 + 1] = (T)s1;
+    }
+}
+
+static inline int tail_vec(size_t esize, int HW) {
+    int lim = (int)(16 / esize);
+    for (int V = 8; V >= 1; V >>= 1)
+        if (V <= lim && HW % V == 0) return V;
+    return 1;
+}
+
+#define TAIL_DISPATCH(KERNEL, ...)                                                                                 \
+    do {                                                                                                           \
+        const dim3 grid((unsigned)ceil_div64(planes, 4)), block(256);                                              \
+        const int v = tail_vec(sizeof(T), HW);                                                                     \
+        if (v == 8) hipLaunchKernelGGL((KERNEL<T, (sizeof(T) <= 2 ? 8 : 1)>), grid, block, 0, s, __VA_ARGS__);     \
+        else if (v == 4) hipLaunchKernelGGL((KERNEL<T, (sizeof(T) <= 4 ? 4 : 1)>), grid, block, 0, s, __VA_ARGS__);\
+        else if (v == 2) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, s, __VA_ARGS__);                       \
+        else hipLaunchKernelGGL((KERNEL<T, 1>), grid, block, 0, s, __VA_ARGS__);                                   \
+    } while (0)
+
+template <typename T> int radix_gap(const void* y, const void* k, void* gap, int64_t planes, int HW, hipStream_t s) {
+    TAIL_DISPATCH(radix_gap_kernel, (const T*)y, (const T*)k, (T*)gap, planes, HW);
+    return check_launch("radix_gap");
+}
+template <typename T>
+int radix_mix(const void* y, const void* k, const void* attn, void* out, int64_t planes, int HW, hipStream_t s) {
+    TAIL_DISPATCH(radix_mix_kernel, (const T*)y, (const T*)k, (const T*)attn, (T*)out, planes, HW);
+    return check_launch("radix_mix");
+}
+template <typename T>
+int radix_mix_bwd(const void* g, const void* y, const void* k, const void* attn, void* gy, void* gk, void* gattn,
+                  int64_t planes, int HW, hipStream_t s) {
+    TAIL_DISPATCH(radix_mix_bwd_kernel, (const T*)g, (const T*)y, (const T*)k, (const T*)attn, (T*)gy, (T*)gk,
+                  (T*)gattn, planes, HW);
+    return check_launch("radix_mix_bwd");
+}
+
+#define INST(T)                                                                                                    \
+    template int radix_gap<T>(const void*, const void*, void*, int64_t, int, hipStream_t);                         \
+    template int radix_mix<T>(const void*, const void*, const void*, void*, int64_t, int, hipStream_t);            \
+    template int radix_mix_bwd<T>(const void*, const void*, const void*, const void*, void*, void*, void*, int64_t, \
+                                  int, hipStream_t);
+INST(float)
+INST(bf16_t)
+
+}  // namespace cot

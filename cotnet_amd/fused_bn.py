@@ -44,7 +44,7 @@ def _ws_floats(N, C):
 
 class _BNAct(Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, eps, momentum, act):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, eps, momentum, act):
         N, C, H, W = x.shape
         L = _lib.lib()
         y = torch.empty_like(x)
@@ -53,7 +53,7 @@ class _BNAct(Function):
         scratch = torch.empty(2 * C + nws, dtype=torch.float32, device=x.device)
         mean, rstd, ws = scratch[:C], scratch[C:2 * C], scratch[2 * C:]
         rc = L.cot_bn_act_forward(_p(x), _p(residual), _p(y), _p(weight), _p(bias), _p(mean), _p(rstd),
-                                  _p(running_mean), _p(running_var), _p(ws), N, C, H * W, eps, momentum, act,
+                                  _p(running_mean), _p(running_var), _p(nbt), _p(ws), N, C, H * W, eps, momentum, act,
                                   _DT[x.dtype], _stream())
         if rc:
             _lib.check(rc, "cot_bn_act_forward")
@@ -75,7 +75,7 @@ class _BNAct(Function):
                                    _p(dgamma), _p(dbeta), _p(ws), N, C, H * W, ctx.act, _DT[x.dtype], _stream())
         if rc:
             _lib.check(rc, "cot_bn_act_backward")
-        return dx, dres, dgamma, dbeta, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
 def _torch_path(x, bn, act, residual):
@@ -95,10 +95,11 @@ def fused_bn_act(x, bn, act=None, residual=None):
     ok = (ENABLED and bn.training and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
           and x.is_contiguous() and bn.affine and bn.track_running_stats and bn.momentum is not None
           and bn.weight.dtype == torch.float32 and x.data_ptr() % 16 == 0
+          and bn.num_batches_tracked is not None and bn.num_batches_tracked.dtype == torch.int64
           and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype
                                     and residual.is_contiguous() and residual.data_ptr() % 16 == 0)))
     if not ok:
         return _torch_path(x, bn, act, residual)
-    bn.num_batches_tracked.add_(1)  # same bookkeeping as nn.BatchNorm2d.forward
-    return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
-                        float(bn.momentum), _ACTS[act])
+    # num_batches_tracked += 1 (nn.BatchNorm2d.forward's bookkeeping) is done by the statistics kernel itself
+    return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                        float(bn.eps), float(bn.momentum), _ACTS[act])

@@ -126,6 +126,17 @@ int cot_set_tuning(int key, int value);
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */
 int cot_xchg_mode(void);
 
+/* ---- radix-2 split-attention tail of the CoT layer (models/cotnet.py:92-104), NCHW, `planes` = N*C, HW = H*W:
+ *   cot_radix_gap           gap[plane] = mean_hw(y + k)                    (replaces cat / sum(dim=2) / mean, :95-98)
+ *   cot_radix_mix           out = y*attn[plane][0] + k*attn[plane][1]      (replaces (x*attn).sum(dim=2), :102)
+ *   cot_radix_mix_backward  gy = g*a0, gk = g*a1, gattn[plane] = (sum g*y, sum g*k)
+ * attn / gattn are [planes][2] in the storage dtype (the softmax over the radix pair, :100-101, stays in torch). */
+int cot_radix_gap(const void* y, const void* k, void* gap, int64_t planes, int HW, int dtype, void* stream);
+int cot_radix_mix(const void* y, const void* k, const void* attn, void* out, int64_t planes, int HW, int dtype,
+                  void* stream);
+int cot_radix_mix_backward(const void* gout, const void* y, const void* k, const void* attn, void* gy, void* gk,
+                           void* gattn, int64_t planes, int HW, int dtype, void* stream);
+
 /* ---- fused SGD over a flat parameter bucket (replaces torch.optim.SGD(nesterov=True),
  * optim/optim_factory.py:54-56, which launches per parameter tensor):
  *     g = grad*grad_scale + weight_decay*p;  buf = momentum*buf + g;  p -= lr*(nesterov ? g + momentum*buf : buf)
@@ -140,13 +151,15 @@ int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad
  * (models/cotnet.py:231-235, :248-262, :89-90):
  *     y = act(gamma*(x-mean_c)*rstd_c + beta [+ residual]),   act: 0 identity, 1 ReLU, 2 SiLU
  * Batch statistics over (N, H*W) per channel (biased variance), saved in save_mean / save_rstd [C] for backward;
- * running_mean/var (may both be NULL) are updated with `momentum` and the unbiased variance, as torch does.
+ * running_mean/var (may both be NULL) are updated with `momentum` and the unbiased variance, as torch does;
+ * num_batches_tracked (int64 scalar on the device, may be NULL) is incremented by one, as nn.BatchNorm2d does.
  * gamma/beta/statistics are fp32; x/residual/y are `dtype` (COT_F32 or COT_BF16).  workspace: cot_bn_act_workspace
  * floats.  backward: dx, dgamma, dbeta (and dresidual = dy*act' when non-NULL); ReLU needs the saved output y. */
 int cot_bn_act_workspace(int N, int C);
 int cot_bn_act_forward(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
-                       float* save_mean, float* save_rstd, float* running_mean, float* running_var, float* workspace,
-                       int N, int C, int HW, float eps, float momentum, int act, int dtype, void* stream);
+                       float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, float* workspace, int N, int C, int HW, float eps, float momentum,
+                       int act, int dtype, void* stream);
 int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
                         const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                         float* workspace, int N, int C, int HW, int act, int dtype, void* stream);

@@ -264,9 +264,11 @@ def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype):
     mean, rstd = torch.empty(C), torch.empty(C)
     ws = torch.empty(_EMUL.cot_bn_act_workspace(N, C))
     dt = _lib.dtype_code(dtype)
+    nbt = torch.tensor(41, dtype=torch.int64)
     rc = _EMUL.cot_bn_act_forward(P(x), P(res) if use_res else None, P(y), P(gamma), P(beta), P(mean), P(rstd), P(rm),
-                                  P(rv), P(ws), N, C, H * W, 1e-5, 0.1, act, dt, None)
+                                  P(rv), P(nbt), P(ws), N, C, H * W, 1e-5, 0.1, act, dt, None)
     assert rc == 0, _EMUL.cot_last_error()
+    assert int(nbt) == 42
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert ((y.float() - yr.detach()).abs() <= tol * (1 + yr.detach().abs())).all()
     assert torch.allclose(rm, rm_ref, atol=1e-5) and torch.allclose(rv, rv_ref, atol=1e-5)
@@ -314,3 +316,33 @@ def test_fused_window_softmax_aggregation(C, H, W, dtype):
     # unsupported geometry reports COT_ERR_UNSUPPORTED (-2) so that the Python layer composes the two ops
     geo5 = _lib.AggGeom(N, C, H, W, 1, wC, 5, 5, 1, 1, 2, 2, 1, 1)
     assert _EMUL.cot_agg_softmax_forward(P(x), P(logits), P(out), P(probs), ctypes.byref(geo5), dt, None) == -2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,W", [(3, 8, 56, 56), (2, 16, 14, 14), (5, 12, 7, 7), (1, 3, 5, 3)])
+def test_radix_tail_kernels(B, C, H, W, dtype):
+    """csrc/radix_tail.hip (host-emulated) against the reference formula (models/cotnet.py:92-104) via autograd"""
+    g = torch.Generator().manual_seed(B * C + H)
+    y = torch.randn(B, C, H, W, generator=g).to(dtype)
+    k = torch.randn(B, C, H, W, generator=g).to(dtype)
+    attn = torch.softmax(torch.randn(B, C, 2, generator=g), dim=2).to(dtype)
+    gout = torch.randn(B, C, H, W, generator=g).to(dtype)
+    dt, planes, HW = _lib.dtype_code(dtype), B * C, H * W
+    gap = torch.empty(B, C, 1, 1, dtype=dtype)
+    assert _EMUL.cot_radix_gap(P(y), P(k), P(gap), planes, HW, dt, None) == 0, _EMUL.cot_last_error()
+    # reference: the 5-D formulation of the reference, fp32 on the rounded inputs
+    yr, kr, ar = y.float().requires_grad_(True), k.float().requires_grad_(True), attn.float().requires_grad_(True)
+    x5 = torch.cat([yr.view(B, C, 1, H, W), kr.view(B, C, 1, H, W)], dim=2)
+    gap_ref = x5.sum(dim=2).mean((2, 3), keepdim=True)
+    out_ref = (x5 * ar.reshape(B, C, 2, 1, 1)).sum(dim=2)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert ((gap.float() - gap_ref.detach()).abs() <= tol * (1 + gap_ref.detach().abs())).all()
+    out = torch.empty_like(y)
+    assert _EMUL.cot_radix_mix(P(y), P(k), P(attn), P(out), planes, HW, dt, None) == 0
+    assert ((out.float() - out_ref.detach()).abs() <= tol * (1 + out_ref.detach().abs())).all()
+    out_ref.backward(gout.float())
+    gy, gk, ga = torch.empty_like(y), torch.empty_like(k), torch.empty_like(attn)
+    assert _EMUL.cot_radix_mix_backward(P(gout), P(y), P(k), P(attn), P(gy), P(gk), P(ga), planes, HW, dt, None) == 0
+    assert ((gy.float() - yr.grad).abs() <= tol * (1 + yr.grad.abs())).all()
+    assert ((gk.float() - kr.grad).abs() <= tol * (1 + kr.grad.abs())).all()
+    assert ((ga.float() - ar.grad).abs() <= tol * 4 * (1 + ar.grad.abs())).all()
