@@ -20,6 +20,7 @@ from torch import nn
 
 from .aggregation_zeropad import LocalConvolution
 from . import radix_tail
+from .conv1x1 import conv1x1
 from .fused_bn import fused_bn_act
 from .layers import get_act_layer
 from .registry import build_model_with_cfg, register_model
@@ -126,11 +127,11 @@ class CotLayer(nn.Module):
         qk = torch.cat([x, k], dim=1)
         b, c, qk_hh, qk_ww = qk.size()
 
-        w = fused_bn_act(self.embed[0](qk), self.embed[1], "relu")
-        w = self.embed[4](self.embed[3](w))
+        w = fused_bn_act(conv1x1(self.embed[0], qk), self.embed[1], "relu")
+        w = self.embed[4](conv1x1(self.embed[3], w))
         w = w.view(b, 1, -1, self.kernel_size * self.kernel_size, qk_hh, qk_ww)
 
-        x = self.conv1x1(x)
+        x = self.conv1x1[1](conv1x1(self.conv1x1[0], x))
         x = self.local_conv(x, w)
         x = fused_bn_act(x, self.bn, act_name(self.act) or None) if act_name(self.act) is not False else self.act(self.bn(x))
         return radix2_fuse(x, k, self.se)
@@ -231,7 +232,7 @@ class Bottleneck(nn.Module):
         a1, a3 = act_name(self.act1), act_name(self.act3)
         fusable = self.drop_block is None and a1 is not False and a3 is not False
         if fusable:
-            x = fused_bn_act(self.conv1(x), self.bn1, a1)
+            x = fused_bn_act(conv1x1(self.conv1, x), self.bn1, a1)
         else:
             x = self.bn1(self.conv1(x))
             if self.drop_block is not None:
@@ -240,7 +241,7 @@ class Bottleneck(nn.Module):
         if self.avd is not None:
             x = self.avd(x)
         x = self.conv2(x)
-        x = self.conv3(x)
+        x = conv1x1(self.conv3, x)
         if fusable and self.drop_path is None:
             if self.downsample is not None:
                 residual = self.downsample(residual)
