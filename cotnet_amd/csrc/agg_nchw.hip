@@ -547,6 +547,16 @@ __global__ __launch_bounds__(256, MINW) void agg_bwd_nchw_k3_v2(const T* __restr
 // Rows outside the image are never dereferenced as data: a lane substitutes zeros when h-1 < 0 or h+1 >= H, so the
 // slab may contain the neighbouring plane's rows (or clamped garbage at the tensor ends) harmlessly.
 
+// XCD-aware work-item order (guide T1): the dispatcher places block b on XCD b % 8, each XCD has its own L2.  Tiles that
+// are adjacent in memory share halo rows, so when `xcd_remap` is set a block takes the tile whose index keeps
+// consecutive tiles on the SAME XCD: logical = (b % 8) * (nblk / 8) + b / 8 (bijective when nblk % 8 == 0).
+// Placement only affects speed (which L2 serves the halo re-reads), never results.
+__device__ __forceinline__ unsigned logical_block(int xcd_remap) {
+    const unsigned b = blockIdx.x, nblk = gridDim.x;
+    if (!xcd_remap || (nblk & 7u) != 0) return b;
+    return (b & 7u) * (nblk >> 3) + (b >> 3);
+}
+
 template <typename T, int P>
 __device__ __forceinline__ Vec<T, P> lds_row(const T* __restrict__ slab, int64_t idx, bool row_ok) {
     Vec<T, P> v;
@@ -585,7 +595,7 @@ template <typename T, int P, int XCHG, int SM>
 __global__ __launch_bounds__(512) void agg_fwd_nchw_k3_lds(const T* __restrict__ x, const T* __restrict__ w,
                                                           T* __restrict__ out, int heads, int C, int wC, int H, int W,
                                                           int R, int tiles_per_nh, int sle, int64_t x_elems,
-                                                          T* __restrict__ probs) {
+                                                          T* __restrict__ probs, int xcd_remap) {
     typedef typename AccOf<T>::type A;
     constexpr int VE = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
@@ -593,8 +603,9 @@ __global__ __launch_bounds__(512) void agg_fwd_nchw_k3_lds(const T* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int segs = W / P, J = C / wC, TR = (blockDim.x >> 6) * R, rows_nh = wC * H;
     const int64_t HW = (int64_t)H * W;
-    const int tile = blockIdx.x % tiles_per_nh;
-    const int64_t nh = blockIdx.x / tiles_per_nh;
+    const unsigned lb = logical_block(xcd_remap);
+    const int tile = lb % tiles_per_nh;
+    const int64_t nh = lb / tiles_per_nh;
     const int n = (int)(nh / heads);
     const int rho0 = tile * TR;
     int64_t gs = (int64_t)(rho0 - 1) * W;  // first slab element (row rho0-1), rounded down to a 16-byte chunk
@@ -676,7 +687,8 @@ template <typename T, int P, int XCHG, bool DO_GX, bool DO_GW, int SM = 0>
 __global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__ gout, const T* __restrict__ x,
                                                           const T* __restrict__ w, T* __restrict__ gx,
                                                           T* __restrict__ gw, int C, int wC, int H, int W, int R,
-                                                          int tiles_per_n, int sle, int JP, int64_t elems) {
+                                                          int tiles_per_n, int sle, int JP, int64_t elems,
+                                                          int xcd_remap) {
     typedef typename AccOf<T>::type A;
     constexpr int VE = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
@@ -685,8 +697,9 @@ __global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int segs = W / P, J = C / wC, TR = (blockDim.x >> 6) * R, rows_n = wC * H;
     const int64_t HW = (int64_t)H * W;
-    const int tile = blockIdx.x % tiles_per_n;
-    const int n = blockIdx.x / tiles_per_n;
+    const unsigned lb = logical_block(xcd_remap);
+    const int tile = lb % tiles_per_n;
+    const int n = lb / tiles_per_n;
     const int rho0 = tile * TR;
     int64_t gs = (int64_t)(rho0 - 1) * W;
     if (gs < 0) gs = 0;
@@ -810,12 +823,14 @@ const char* last_kernel_nchw() { return g_last_kernel; }
 // 1 = max P forward, 2 = max P backward, 3 = lane-exchange primitive (-1 auto/probe, 0 DPP, 1 ds_bpermute),
 // 4 = v3 fused backward: channel groups staged in LDS per phase (0 = default 4),
 // 5 = v3 waves per workgroup (4 or 8), 6 = v3 extra dynamic LDS per workgroup in KiB (occupancy shaping: fewer
-//     co-resident workgroups => their load / compute / store phases interleave instead of running in lock-step)
+//     co-resident workgroups => their load / compute / store phases interleave instead of running in lock-step),
+// 7 = v3 XCD-aware tile order (0 off, 1 on; unmeasured, off by default), 8 = split the fused backward into a gX launch
+//     and a gW launch (0 fused, 1 split; unmeasured A/B knob)
 // defaults from the on-device A/B (profiles/r01_agg_variants.log, N80xC64x56x56 bf16): forward P=4 (v3 22.0 us vs 26.0 at P=8),
 // fused backward P=2 with 4 channel groups per LDS phase (v3 45.4 us; 27.3 vs 31.8 us at 28x28)
-static int g_tune[7] = {0, 4, 2, -1, 0, 4, 0};
+static int g_tune[9] = {0, 4, 2, -1, 0, 4, 0, 0, 0};
 int set_tuning_nchw(int key, int value) {
-    if (key < 0 || key > 6) return -1;
+    if (key < 0 || key > 8) return -1;
     g_tune[key] = value;
     return 0;
 }
@@ -898,10 +913,10 @@ static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, 
             const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
                 COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
-                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr);
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, g_tune[7]);
             else
                 COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
-                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr);
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, g_tune[7]);
             g_last_kernel = "agg_fwd_nchw_k3_lds";
             return check_launch(g_last_kernel);
         }
@@ -960,10 +975,10 @@ static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw
             const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
                 COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 0, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
-                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
+                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, g_tune[7]);
             else
                 COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 1, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
-                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
+                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, g_tune[7]);
             g_last_kernel = GX && GW ? "agg_bwd_nchw_k3_lds<gx,gw>" : GX ? "agg_bwd_nchw_k3_lds<gx>" : "agg_bwd_nchw_k3_lds<gw>";
             return check_launch(g_last_kernel);
         }
@@ -991,6 +1006,10 @@ static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw
 
 template <typename T, int P>
 static int launch_bwd_k3(const T* gout, const T* x, const T* w, T* gx, T* gw, const cot_agg_geom& g, hipStream_t s) {
+    if (gx && gw && g_tune[8] == 1) {
+        const int rc = launch_bwd_k3_sel<T, P, true, false>(gout, x, w, gx, (T*)nullptr, g, s);
+        return rc ? rc : launch_bwd_k3_sel<T, P, false, true>(gout, x, w, (T*)nullptr, gw, g, s);
+    }
     if (gx && gw) return launch_bwd_k3_sel<T, P, true, true>(gout, x, w, gx, gw, g, s);
     if (gx) return launch_bwd_k3_sel<T, P, true, false>(gout, x, w, gx, gw, g, s);
     return launch_bwd_k3_sel<T, P, false, true>(gout, x, w, gx, gw, g, s);
@@ -1037,10 +1056,10 @@ static int launch_softmax_fwd(const T* x, const T* logits, T* out, T* probs, con
     const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
     if (xchg_mode() == 0)
         COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0, 1>), grid, block, p.lds_bytes, s, x, logits, out, g.heads, g.C, g.wC,
-                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs);
+                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, g_tune[7]);
     else
         COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1, 1>), grid, block, p.lds_bytes, s, x, logits, out, g.heads, g.C, g.wC,
-                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs);
+                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, g_tune[7]);
     g_last_kernel = "agg_fwd_nchw_k3_lds<softmax>";
     return check_launch(g_last_kernel);
 }
@@ -1055,10 +1074,10 @@ static int launch_softmax_bwd(const T* gout, const T* x, const T* probs, T* gx, 
     const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
     if (xchg_mode() == 0)
         COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 0, true, true, 1>), grid, block, p.lds_bytes, s, gout, x, probs, gx,
-                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
+                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, g_tune[7]);
     else
         COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 1, true, true, 1>), grid, block, p.lds_bytes, s, gout, x, probs, gx,
-                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne);
+                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, g_tune[7]);
     g_last_kernel = "agg_bwd_nchw_k3_lds<softmax>";
     return check_launch(g_last_kernel);
 }

@@ -118,9 +118,12 @@ const char* cot_status_string(int status);
 const char* cot_last_kernel(void);
 
 /* Developer knobs for A/B benchmarking (process-global, not part of the drop-in contract):
- *   key 0: 3x3 fast-path kernel version (0 auto, 1 = v1 scalar-halo kernels, 2 = v2 wave-aligned kernels)
+ *   key 0: 3x3 fast-path kernel version (0 auto, 1 = v1 scalar-halo, 2 = v2 wave-aligned, 3 = v3 LDS-staged kernels)
  *   key 1: max pixels per lane, forward   key 2: max pixels per lane, fused backward
- *   key 3: lane-exchange primitive (-1 probe on first use, 0 = DPP wave shift, 1 = ds_bpermute) */
+ *   key 3: lane-exchange primitive (-1 probe on first use, 0 = DPP wave shift, 1 = ds_bpermute)
+ *   key 4: v3 backward channel groups per LDS phase   key 5: v3 waves per workgroup (4|8)
+ *   key 6: v3 extra LDS KiB per workgroup             key 7: v3 XCD-aware tile order (0|1)
+ *   key 8: issue the fused backward as separate gX and gW launches (0|1) */
 int cot_set_tuning(int key, int value);
 /* 0 if the device probe confirmed the DPP wave_shr/wave_shl semantics the v2 kernels rely on, 1 if the
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */

@@ -48,10 +48,12 @@ def main():
         "v3d": [(0, 3)], "v3d_nw8": [(0, 3), (5, 8)], "v3d_pad16": [(0, 3), (6, 16)], "v3d_pad32": [(0, 3), (6, 32)],
         "v3d_pad56": [(0, 3), (6, 56)], "v3d_nw8_pad32": [(0, 3), (5, 8), (6, 32)], "v3d_bP4": [(0, 3), (2, 4)],
         "v3d_bP4_pad32": [(0, 3), (2, 4), (6, 32)],
+        "v3d_xcd": [(0, 3), (7, 1)], "v3d_split": [(0, 3), (8, 1)], "v3d_xcd_split": [(0, 3), (7, 1), (8, 1)],
+        "v3d_jp8": [(0, 3), (4, 8)], "v3d_jp2": [(0, 3), (4, 2)],
     }
 
     def set_variant(name):
-        for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0)):
+        for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, 0), (8, 0)):
             L.cot_set_tuning(k, v)
         for k, v in VAR[name]:
             L.cot_set_tuning(k, v)
@@ -129,7 +131,7 @@ def main():
                 print(msg, flush=True)
             del sets
             torch.cuda.empty_cache()
-    for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0)):
+    for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, 0), (8, 0)):
         L.cot_set_tuning(k, v)
     if args.out:
         json.dump(rows, open(args.out, "w"), indent=1)

@@ -75,14 +75,15 @@ def oracle_all(x, w, gout, k, s, p, d):
 
 @pytest.fixture
 def tuning():
-    def set_(version=0, fwd_p=4, bwd_p=2, xchg=0, jp=0, nw=4, pad=0):
-        for k, v in ((0, version), (1, fwd_p), (2, bwd_p), (3, xchg), (4, jp), (5, nw), (6, pad)):
+    def set_(version=0, fwd_p=4, bwd_p=2, xchg=0, jp=0, nw=4, pad=0, xcd=0, split=0):
+        for k, v in ((0, version), (1, fwd_p), (2, bwd_p), (3, xchg), (4, jp), (5, nw), (6, pad), (7, xcd), (8, split)):
             assert _EMUL.cot_set_tuning(k, v) == 0
     yield set_
     set_()
 
 
-_ALL_VARIANTS = ["v1", "v2_dpp", "v2_shfl", "v2_P8", "v3_lds", "v3_lds_P8_jp2", "v3_lds_jp8", "v3_lds_nw8_bP4"]
+_ALL_VARIANTS = ["v1", "v2_dpp", "v2_shfl", "v2_P8", "v3_lds", "v3_lds_P8_jp2", "v3_lds_jp8", "v3_lds_nw8_bP4",
+                 "v3_lds_xcd_split"]
 _SHAPES = [(16, 9, 56), (16, 11, 28), (32, 14, 14), (64, 7, 7), (16, 5, 8)]
 # fp32: every kernel generation x every shape; bf16 (same index arithmetic, packed rows): the default kernels only
 _VERSION_CASES = ([(c, h, w, torch.float32, v) for (c, h, w) in _SHAPES for v in _ALL_VARIANTS] +
@@ -94,7 +95,8 @@ def test_k3_kernel_versions(C, H, W, dtype, variant, tuning):
     """every 3x3 kernel generation and lane-exchange primitive against the oracle (NCHW)"""
     kw = {"v1": dict(version=1), "v2_dpp": dict(version=2), "v2_shfl": dict(version=2, xchg=1),
           "v2_P8": dict(version=2, fwd_p=8), "v3_lds": dict(version=3), "v3_lds_P8_jp2": dict(version=3, fwd_p=8, jp=2),
-          "v3_lds_jp8": dict(version=3, jp=8), "v3_lds_nw8_bP4": dict(version=3, nw=8, bwd_p=4, pad=8)}[variant]
+          "v3_lds_jp8": dict(version=3, jp=8), "v3_lds_nw8_bP4": dict(version=3, nw=8, bwd_p=4, pad=8),
+          "v3_lds_xcd_split": dict(version=3, xcd=1, split=1)}[variant]
     tuning(**kw)
     g = torch.Generator().manual_seed(C + W)
     N, wC = 2, C // 8  # small channel counts keep the 256-host-thread emulation fast; indexing is size-agnostic
@@ -111,6 +113,8 @@ def test_k3_kernel_versions(C, H, W, dtype, variant, tuning):
     may_fall_back = variant in ("v3_lds_jp8", "v3_lds_nw8_bP4")
     assert want_tag in fk or (may_fall_back and "k3_v2" in fk), (fk, bk)
     assert want_tag in bk or (may_fall_back and "k3_v2" in bk), (fk, bk)
+    if variant == "v3_lds_xcd_split":
+        assert bk.endswith("<gw>"), bk  # the split knob issues a gX launch then a gW launch
     # gx-only and gw-only launches of the same generation
     N_, C_ = x.shape[:2]
     geo = _lib.AggGeom(N_, C_, H, W, 1, wC, 3, 3, 1, 1, 1, 1, 1, 1)
