@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=48.0)
+    ap.add_argument("--conv1x1", default=None, choices=["module", "hip", "matmul"],
+                    help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
     return ap.parse_args()
 
 
@@ -129,6 +131,9 @@ def roctx_window(resume):
 
 def main():
     args = parse()
+    if args.conv1x1 is not None:
+        from cotnet_amd import conv1x1 as _c1
+        _c1.MODE = "" if args.conv1x1 == "module" else args.conv1x1
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -290,6 +295,7 @@ def main():
                        "layout": args.layout, "precision": ("bf16 weights+activations, fp32 master weights / norm params, fused flat SGD" if mixed
                                      else "bf16 autocast, fp32 weights" if amp else "fp32"),
                        "hip_graph": graphed,
+                       "conv1x1": __import__("cotnet_amd.conv1x1", fromlist=["MODE"]).MODE or "module",
                        "grad_sync": "RCCL all-reduce (AVG), flat buckets, side stream" if world > 1 else "none (1 GPU)"},
             "final_loss": round(final_loss, 4),
             "roofline": roofline,

@@ -53,6 +53,10 @@ SYMBOLS = {
     "cot_radix_mix_backward": (_I, [_P] * 7 + [ctypes.c_int64, _I, _I, _P]),
     "cot_sgd_step": (_I, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                           _I, _I, _I, _P]),
+    "cot_conv1x1_workspace": (ctypes.c_int64, [_I, _I, _I, _I, _I]),
+    "cot_conv1x1_forward": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cot_conv1x1_backward_data": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "cot_conv1x1_backward_weight": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cot_bn_act_workspace": (_I, [_I, _I]),
     "cot_bn_act_forward": (_I, [_P] * 11 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "cot_bn_act_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _P]),

@@ -1,19 +1,32 @@
-"""1x1 convolution in NCHW as batched GEMMs, without layout changes (experimental, opt-in: COT_CONV1X1=matmul).
+"""1x1 convolution on NCHW tensors without layout changes.
 
 Round-1 profile: MIOpen runs every convolution through NHWC kernels and brackets each call with
 NCHW<->NHWC transposes and cast/zero kernels -- 6.7 + 2.3 ms of a 36 ms step, more than the GEMMs themselves for the
-1x1 convolutions.  In NCHW a 1x1 convolution is, per image, Y[n] = W[Co,Ci] @ X[n][Ci,HW]: a strided-batched GEMM
-whose B operand is already row-major, so forward and the data gradient (gX[n] = W^T @ gY[n]) need no transposes at
-all; only the weight gradient (a reduction over n and pixels) needs one.  Same parameters / state_dict as the
-nn.Conv2d it is applied to.  Not enabled by default: hipBLASLt's behaviour on these small-K shapes has not been
-measured yet (next round's first A/B).
+1x1 convolutions.  In NCHW a 1x1 convolution is, per image, Y[n] = W[Co,Ci] @ X[n][Ci,HW]; forward and the data
+gradient (gX[n] = W^T @ gY[n]) need no transposes at all, the weight gradient reduces over the contiguous pixel index.
+
+`conv1x1(conv, x, x2=None)` evaluates an ordinary `nn.Conv2d` (same parameters / state_dict as the reference's
+modules: CotLayer.embed[0], embed[3], conv1x1[0] -- models/cotnet.py:51-62 -- Bottleneck.conv1 / conv3 / downsample)
+on `x`, or on the channel concatenation `[x, x2]` WITHOUT materialising it (the reference's `torch.cat([x, k], dim=1)`,
+models/cotnet.py:81).  Implementation is chosen by COT_CONV1X1:
+
+    (unset)  the module itself (MIOpen)                                   -- current default
+    hip      hand-written MFMA kernels, csrc/conv1x1.hip behind cot_conv1x1_*  (bf16, Ci % 8 == 0, Co % 8 == 0)
+    matmul   torch.matmul / einsum batched GEMMs (rocBLAS / hipBLASLt)
+
+`hip` is verified against torch through the host emulation of the kernels (tests/test_kernels_emulated.py) and by
+tests/test_conv1x1_gpu.py; it becomes the default once measured on an MI355X (ROUND2_PLAN.md).
 """
+import ctypes
 import os
 
 import torch
 from torch.autograd import Function
 
-ENABLED = os.environ.get("COT_CONV1X1", "") == "matmul"
+from . import _lib
+
+MODE = os.environ.get("COT_CONV1X1", "")
+_DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
 
 
 class _Conv1x1(Function):
@@ -45,15 +58,107 @@ class _Conv1x1(Function):
         return gx, gw, gb
 
 
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if _DEVICE_ONLY else None
+
+
+_WS = {}  # (N, Ci, Co, HW, has_bias) -> backward workspace bytes (pure function of the shape)
+
+
+def _ws_bytes(N, Ci, Co, HW, has_bias):
+    k = (N, Ci, Co, HW, has_bias)
+    v = _WS.get(k)
+    if v is None:
+        v = _WS[k] = int(_lib.lib().cot_conv1x1_workspace(N, Ci, Co, HW, has_bias))
+    return v
+
+
+class _Conv1x1Hip(Function):
+    """y = conv1x1([x1 | x2], weight, bias) through libcotnet_hip.so; x2 may be None"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias):
+        N, c1, H, W = x1.shape
+        Co, Ci = weight.shape[0], weight.shape[1]
+        y = torch.empty((N, Co, H, W), dtype=x1.dtype, device=x1.device)
+        rc = _lib.lib().cot_conv1x1_forward(_p(x1), _p(x2), c1, _p(weight), _p(bias), _p(y), N, Ci, Co, H * W,
+                                            _lib.COT_BF16, _stream())
+        if rc:
+            _lib.check(rc, "cot_conv1x1_forward")
+        ctx.save_for_backward(x1, x2, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, weight = ctx.saved_tensors
+        N, c1, H, W = x1.shape
+        Co, Ci = weight.shape[0], weight.shape[1]
+        HW = H * W
+        gy = gy.contiguous()
+        L = _lib.lib()
+        has_bias = 1 if ctx.has_bias else 0
+        ws = torch.empty(_ws_bytes(N, Ci, Co, HW, has_bias), dtype=torch.uint8, device=gy.device)
+        gx1 = gx2 = gw = gb = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            gx1 = torch.empty_like(x1)
+            gx2 = torch.empty_like(x2) if x2 is not None else None
+            rc = L.cot_conv1x1_backward_data(_p(gy), _p(weight), _p(gx1), _p(gx2), c1, _p(ws), N, Ci, Co, HW,
+                                             _lib.COT_BF16, _stream())
+            if rc:
+                _lib.check(rc, "cot_conv1x1_backward_data")
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            gw = torch.empty_like(weight)
+            gb = torch.empty(Co, dtype=weight.dtype, device=gy.device) if ctx.has_bias else None
+            rc = L.cot_conv1x1_backward_weight(_p(gy), _p(x1), _p(x2), c1, _p(gw), _p(gb), _p(ws), N, Ci, Co, HW,
+                                               _lib.COT_BF16, _stream())
+            if rc:
+                _lib.check(rc, "cot_conv1x1_backward_weight")
+        return gx1, gx2, gw, gb
+
+
+def _plain_1x1(conv):
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1))
+
+
 def eligible(conv, x):
-    return (ENABLED and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
-            and conv.padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1) and x.dim() == 4
-            and x.is_contiguous() and x.dtype == conv.weight.dtype)
+    """matmul path"""
+    return (MODE == "matmul" and _plain_1x1(conv) and x.dim() == 4 and x.is_contiguous()
+            and x.dtype == conv.weight.dtype)
 
 
-def conv1x1(conv, x):
-    """`conv(x)` for an nn.Conv2d; 1x1 / stride-1 / ungrouped convolutions on NCHW tensors go through batched GEMMs when
-    COT_CONV1X1=matmul, everything else through the module itself."""
-    if eligible(conv, x):
+def eligible_hip(conv, x, x2=None):
+    if not (MODE == "hip" and _plain_1x1(conv) and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4 and x.dtype == torch.bfloat16
+            and conv.weight.dtype == torch.bfloat16 and x.is_contiguous() and conv.weight.is_contiguous()):
+        return False
+    if x2 is not None and not (x2.dtype == x.dtype and x2.is_contiguous() and x2.shape[0] == x.shape[0]
+                               and x2.shape[2:] == x.shape[2:]):
+        return False
+    ci = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    return ci == conv.in_channels and ci % 8 == 0 and conv.out_channels % 8 == 0
+
+
+def conv1x1(conv, x, x2=None):
+    """`conv(x)`, or `conv(torch.cat([x, x2], 1))` when x2 is given, for an nn.Conv2d (see the module docstring)."""
+    if MODE == "hip" and eligible_hip(conv, x, x2):
+        return _Conv1x1Hip.apply(x, x2, conv.weight, conv.bias)
+    if x2 is not None:
+        x = torch.cat([x, x2], dim=1)
+    if MODE == "matmul" and eligible(conv, x):
         return _Conv1x1.apply(x, conv.weight, conv.bias)
     return conv(x)
+
+
+def run_downsample(ds, x):
+    """`ds(x)` for the residual branch's nn.Sequential (pool, 1x1 conv, norm -- models/resnet.py:364-394) with the
+    convolution routed through `conv1x1`"""
+    if MODE and isinstance(ds, torch.nn.Sequential):
+        for m in ds:
+            x = conv1x1(m, x) if isinstance(m, torch.nn.Conv2d) else m(x)
+        return x
+    return ds(x)

@@ -20,7 +20,7 @@ from torch import nn
 
 from .aggregation_zeropad import LocalConvolution
 from . import radix_tail
-from .conv1x1 import conv1x1
+from .conv1x1 import conv1x1, run_downsample
 from .fused_bn import fused_bn_act
 from .layers import get_act_layer
 from .registry import build_model_with_cfg, register_model
@@ -124,10 +124,10 @@ class CotLayer(nn.Module):
         # Sequential members are called one by one so that each BatchNorm runs fused with its activation
         # (cotnet_amd.fused_bn); module structure and state_dict keys are the reference's.
         k = fused_bn_act(self.key_embed[0](x), self.key_embed[1], "relu")
-        qk = torch.cat([x, k], dim=1)
-        b, c, qk_hh, qk_ww = qk.size()
+        b, _, qk_hh, qk_ww = x.size()
 
-        w = fused_bn_act(conv1x1(self.embed[0], qk), self.embed[1], "relu")
+        # embed[0] consumes the concatenation [x, k] (ref :81); conv1x1 reads the two slabs in place when it can
+        w = fused_bn_act(conv1x1(self.embed[0], x, k), self.embed[1], "relu")
         w = self.embed[4](conv1x1(self.embed[3], w))
         w = w.view(b, 1, -1, self.kernel_size * self.kernel_size, qk_hh, qk_ww)
 
@@ -244,7 +244,7 @@ class Bottleneck(nn.Module):
         x = conv1x1(self.conv3, x)
         if fusable and self.drop_path is None:
             if self.downsample is not None:
-                residual = self.downsample(residual)
+                residual = run_downsample(self.downsample, residual)
             return fused_bn_act(x, self.bn3, a3, residual)  # bn3 + residual add + act3 in one pass
         x = self.bn3(x)
         if self.drop_block is not None:
@@ -252,7 +252,7 @@ class Bottleneck(nn.Module):
         if self.drop_path is not None:
             x = self.drop_path(x)
         if self.downsample is not None:
-            residual = self.downsample(residual)
+            residual = run_downsample(self.downsample, residual)
         x += residual
         return self.act3(x)
 

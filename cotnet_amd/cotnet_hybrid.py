@@ -11,6 +11,7 @@ import math
 import torch.nn.functional as F
 from torch import nn
 
+from .conv1x1 import conv1x1, run_downsample
 from .cotnet import CotLayer, _cfg
 from .fused_bn import fused_bn_act
 from .layers import BlurPool2d, SplitAttnConv2d, create_classifier, get_act_layer
@@ -85,7 +86,7 @@ class CoTBottleneck(nn.Module):
     def forward(self, x):
         residual = x
         if self.drop_block is None:
-            x = fused_bn_act(self.conv1(x), self.bn1, "relu")  # act1 is hard-wired ReLU (ref :124)
+            x = fused_bn_act(conv1x1(self.conv1, x), self.bn1, "relu")  # act1 is hard-wired ReLU (ref :124)
         else:
             x = self.act1(self.drop_block(self.bn1(self.conv1(x))))
         if self.avd is not None and self.avd_first:
@@ -93,10 +94,10 @@ class CoTBottleneck(nn.Module):
         x = self.conv2(x)
         if self.avd is not None and not self.avd_first:
             x = self.avd(x)
-        x = self.conv3(x)
+        x = conv1x1(self.conv3, x)
         if self.drop_block is None and self.drop_path is None:
             if self.downsample is not None:
-                residual = self.downsample(residual)
+                residual = run_downsample(self.downsample, residual)
             return fused_bn_act(x, self.bn3, "relu", residual)  # act3 is hard-wired ReLU (ref :167)
         x = self.bn3(x)
         if self.drop_block is not None:
@@ -104,7 +105,7 @@ class CoTBottleneck(nn.Module):
         if self.drop_path is not None:
             x = self.drop_path(x)
         if self.downsample is not None:
-            residual = self.downsample(residual)
+            residual = run_downsample(self.downsample, residual)
         x += residual
         return self.act3(x)
 

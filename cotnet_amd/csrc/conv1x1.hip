@@ -1,0 +1,355 @@
+// conv1x1.hip -- 1x1 convolutions of the CoT block on NCHW bf16 tensors, as MFMA GEMMs WITHOUT layout changes.
+//
+// Replaces nn.Conv2d(kernel_size=1) forward / data-gradient / weight-gradient for the reference's
+//   CotLayer.embed[0], embed[3] (models/cotnet.py:51-57), CotLayer.conv1x1[0] (:59-62),
+//   Bottleneck.conv1 / conv3 / downsample conv (models/cotnet.py:206-224, models/resnet.py:383-401).
+// Round-1 profile: MIOpen serves these through NHWC implicit-GEMM kernels bracketed by NCHW<->NHWC transposes and
+// cast/zero kernels (batched_transpose_* + SubTensorOp* = 8 ms of a 36 ms step).  In NCHW the op is, per image n,
+//       Y[n] (M x HW) = A (M x K) * X[n] (K x HW)            A = weight [Co][Ci]  (forward)
+//                                                            A = weight^T         (data gradient, X = dY)
+//       dW (M x J)   = sum_n dY[n] (M x HW) * X[n]^T (HW x J)                     (weight gradient)
+// All three are HBM-bound on MI355X (arithmetic intensity <= Ci/2 flop/byte, far left of the MFMA ridge), so the
+// kernels are organised around streaming X / Y exactly once with 16-byte accesses; MFMA does the arithmetic because
+// it is free at this intensity, not because the op is compute-bound.
+//
+// MFMA operand maps used (v_mfma_f32_16x16x32_bf16, D = A*B + C, one wave):
+//       A: lane l holds A[i = l&15][k = 8*(l>>4) .. +7]          (8 bf16, K-contiguous)
+//       B: lane l holds B[k = 8*(l>>4) .. +7][j = l&15]
+//     C/D: lane l holds D[i = 4*(l>>4) + r][j = l&15], r = 0..3
+// Forward / data gradient: the K index of B = X is the STRIDED one in NCHW (channels are HW apart).  Each lane loads,
+// for its 8 channels, PXV consecutive pixels (one 16- or 8-byte access per channel), and transposes that 8 x PXV block
+// inside its own registers: MFMA number c takes pixel c of every lane's piece as column j.  Column j of MFMA c is
+// therefore pixel 16*PXV*tile + PXV*j + c, so in the C/D map a lane ends up with PXV CONSECUTIVE pixels of 4 output
+// channels -> one wide store per channel row.  No LDS, no cross-lane traffic, no barriers.
+// Weight gradient: the reduction index is the pixel index, contiguous for both operands -> fragments are plain
+// 16-byte loads.  Split over the (n, pixel) range into S deterministic partial sums (fp32 workspace) + one reduce
+// kernel (no atomics: bit-reproducible, and capturable in a HIP graph without a zero-fill node).
+#include "cot_common.h"
+
+namespace cot {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#ifndef COT_MFMA_16X16X32_BF16  // (tests/emul pre-defines this primitive for its host build)
+#define COT_MFMA_16X16X32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
+
+template <int V> struct BFVec {
+    typedef __attribute__((ext_vector_type(V))) __bf16 type;
+};
+
+// dst[0..V) = p[0..V) for the first `cnt` elements, zero beyond (cnt may be <= 0 or > V).  `full` is a WAVE-UNIFORM
+// promise that cnt >= V for every lane (scalar branch: the wide access is not entangled with the element-wise tail path)
+template <int V, int AL>
+__device__ __forceinline__ void load_piece(bf16_t (&dst)[V], const bf16_t* p, int cnt, bool full) {
+    if (full) {
+        typename BFVec<V>::type t;  // one wide access; AL = what is known about p's alignment
+        __builtin_memcpy(&t, __builtin_assume_aligned(p, AL), sizeof(t));
+#pragma unroll
+        for (int i = 0; i < V; ++i) dst[i] = t[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) dst[i] = (i < cnt) ? p[i] : (bf16_t)0.0f;
+    }
+}
+template <int V, int AL>
+__device__ __forceinline__ void store_piece(bf16_t* p, const bf16_t (&src)[V], int cnt, bool full) {
+    if (full) {
+        typename BFVec<V>::type t;
+#pragma unroll
+        for (int i = 0; i < V; ++i) t[i] = src[i];
+        __builtin_memcpy(__builtin_assume_aligned(p, AL), &t, sizeof(t));
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            if (i < cnt) p[i] = src[i];
+    }
+}
+// wave-uniform value -> SGPR (so that conditions on it become scalar branches)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ int64_t wave_work_id(int xcd_remap) {
+    unsigned b = blockIdx.x;
+    const unsigned nblk = gridDim.x;
+    if (xcd_remap && (nblk & 7u) == 0) b = (b & 7u) * (nblk >> 3) + (b >> 3);  // consecutive ids -> same XCD
+    return (int64_t)b * (blockDim.x >> 6) + (threadIdx.x >> 6);
+}
+
+// channel row `r` of image n in a tensor given as two channel slabs (concatenation along C): rows [0,c1) live in
+// t1 (c1 channels per image), rows [c1,C) in t2 (C-c1 channels per image)
+template <typename P> __device__ __forceinline__ P* row_ptr(P* t1, P* t2, int c1, int C, int n, int r, int HW) {
+    return r < c1 ? t1 + ((int64_t)n * c1 + r) * HW : t2 + ((int64_t)n * (C - c1) + (r - c1)) * HW;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Y[n][m][p] = sum_k A[m][k] * X[n][k][p] (+ bias[m]);  A row-major [M][K], K % 8 == 0.
+// One wave = (image n, tile of 16*PXV pixels, block of 16*MT output channels); 4 waves per workgroup.
+template <int PXV, int MT, int AL>
+__global__ void __launch_bounds__(256, 2)
+conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, int k1, const bf16_t* __restrict__ A,
+                 const bf16_t* __restrict__ bias, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2, int m1, int K,
+                 int M, int HW, int mblocks, int ptiles, int64_t total_waves, int xcd_remap) {
+    const int64_t wid = wave_work_id(xcd_remap);
+    if (wid >= total_waves) return;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int mb = uniform((int)(wid % mblocks));
+    const int64_t t = wid / mblocks;
+    const int pt = uniform((int)(t % ptiles)), n = uniform((int)(t / ptiles));
+    const int p0 = pt * (16 * PXV) + j * PXV;  // this lane's first pixel
+    const int cnt = HW - p0;                   // valid pixels from p0 on (<= 0: lane idles through the loads)
+    const bool full_px = (pt + 1) * (16 * PXV) <= HW;  // wave-uniform: every lane has all PXV pixels
+    const int mbase = mb * (16 * MT);
+
+    f32x4_t acc[MT][PXV];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int c = 0; c < PXV; ++c) acc[mt][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t* arow[MT];  // A rows of this lane (clamped: rows >= M are computed on a copy of row M-1, never stored)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (int64_t)min(mbase + mt * 16 + j, M - 1) * K;
+
+    // Single-buffered on purpose: latency is hidden by occupancy (the wave's whole state is acc + one 8 x PXV block),
+    // several waves per SIMD each keep 8 wide loads in flight.
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int kb = k0 + 8 * g;
+        const bool kok = kb < K;          // K % 8 == 0: a lane group's 8 channels are all inside or all outside
+        const bool full_k = k0 + 32 <= K;  // wave-uniform: all four lane groups inside
+        bf16_t raw[8][PXV];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            load_piece<PXV, AL>(raw[r], kok ? row_ptr(x1, x2, k1, K, n, kb + r, HW) + p0 : x1, kok ? cnt : 0,
+                                full_px && full_k);
+        bf16x8_t af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16_t a_[8];
+            load_piece<8, 16>(a_, arow[mt] + (kok ? kb : 0), kok ? 8 : 0, full_k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[mt][e] = a_[e];
+        }
+#pragma unroll
+        for (int c = 0; c < PXV; ++c) {
+            bf16x8_t bfrag;  // in-register transposition: pixel c of each of this lane's 8 channels
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bfrag[r] = raw[r][c];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][c] = COT_MFMA_16X16X32_BF16(af[mt], bfrag, acc[mt][c]);
+        }
+    }
+
+    if (cnt <= 0) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mbase + mt * 16 + g * 4 + i;
+            if (m < M) {
+                const float b = bias ? (float)bias[m] : 0.f;
+                bf16_t o[PXV];
+#pragma unroll
+                for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b);
+                store_piece<PXV, AL>(row_ptr(y1, y2, m1, M, n, m, HW) + p0, o, cnt, full_px);
+            }
+        }
+}
+
+// WT[k][m] = W[m][k]  (weights are tiny: <= 2 MB)
+__global__ void conv1x1_transpose_w(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt, int M, int K) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)M * K) return;
+    const int m = (int)(e % M), k = (int)(e / M);
+    wt[e] = w[(int64_t)m * K + k];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// part[s][m][jj] = sum over the s-th slice of (n, pixel) of dY[n][m][p] * X[n][jj][p];  column jj == J (when has_bias)
+// multiplies by 1 -> the bias gradient.  One wave = (64 x 64 output tile, slice s); 4 waves per workgroup.
+template <int AL>
+__global__ void __launch_bounds__(256, 2)
+conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, int k1,
+                   float* __restrict__ part, int N, int M, int J, int HW, int has_bias, int mblocks, int jblocks, int S,
+                   int spi, int64_t total_waves, int xcd_remap) {
+    const int64_t wid = wave_work_id(xcd_remap);
+    if (wid >= total_waves) return;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    const int jb = uniform((int)(wid % jblocks));
+    const int64_t u = wid / jblocks;
+    const int mb = uniform((int)(u % mblocks)), s = uniform((int)(u / mblocks));
+    const int Jp = J + (has_bias ? 1 : 0);
+    const int64_t T = (int64_t)N * spi;
+    const int64_t t0 = T * s / S, t1 = T * (s + 1) / S;
+
+    int mrow[4], jrow[4];
+    bool ones[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mrow[q] = min(mb * 64 + q * 16 + i16, M - 1);
+        const int jj = jb * 64 + q * 16 + i16;
+        ones[q] = has_bias && jj == J;
+        jrow[q] = min(jj, J - 1);
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8_t af[2][4], bfr[2][4];
+#define COT_WG_LOAD(BUF, NN, ST)                                                                                   \
+    {                                                                                                              \
+        const int p_ = (ST) * 32 + g * 8;                                                                          \
+        const int cnt_ = HW - p_;                                                                                  \
+        const bool full_ = ((ST) + 1) * 32 <= HW;                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
+            bf16_t a_[8], b_[8];                                                                                   \
+            load_piece<8, AL>(a_, gy + ((int64_t)(NN) * M + mrow[q]) * HW + p_, cnt_, full_);                      \
+            load_piece<8, AL>(b_, row_ptr(x1, x2, k1, J, (NN), jrow[q], HW) + p_, cnt_, full_);                     \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                        \
+                af[BUF][q][e] = a_[e];                                                                             \
+                bfr[BUF][q][e] = ones[q] ? (bf16_t)1.0f : b_[e];                                                   \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+#define COT_WG_COMPUTE(BUF)                                                                   \
+    {                                                                                         \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b) \
+            acc[a][b] = COT_MFMA_16X16X32_BF16(af[BUF][a], bfr[BUF][b], acc[a][b]);           \
+    }
+
+    if (t0 < t1) {
+        int n = (int)(t0 / spi), st = (int)(t0 % spi);
+        COT_WG_LOAD(0, n, st)
+        for (int64_t t = t0; t < t1; t += 2) {
+            int n1 = n, st1 = st + 1;
+            if (st1 == spi) { st1 = 0; ++n1; }
+            if (t + 1 < t1) COT_WG_LOAD(1, n1, st1)
+            COT_WG_COMPUTE(0)
+            if (t + 1 < t1) {
+                n = n1; st = st1 + 1;
+                if (st == spi) { st = 0; ++n; }
+                if (t + 2 < t1) COT_WG_LOAD(0, n, st)
+                COT_WG_COMPUTE(1)
+            }
+        }
+    }
+#undef COT_WG_LOAD
+#undef COT_WG_COMPUTE
+
+    float* ps = part + (int64_t)s * M * Jp;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mb * 64 + a * 16 + g * 4 + i;
+            if (m >= M) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int jj = jb * 64 + b * 16 + i16;
+                if (jj < Jp) ps[(int64_t)m * Jp + jj] = acc[a][b][i];
+            }
+        }
+}
+
+// gw[m][j] = bf16(sum_s part[s][m][j]);  gb[m] = bf16(sum_s part[s][m][J])
+__global__ void conv1x1_wgrad_reduce(const float* __restrict__ part, int S, int M, int J, int has_bias,
+                                     bf16_t* __restrict__ gw, bf16_t* __restrict__ gb) {
+    const int Jp = J + (has_bias ? 1 : 0);
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, tot = (int64_t)M * Jp;
+    if (e >= tot) return;
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) sum += part[(int64_t)s * tot + e];
+    const int m = (int)(e / Jp), jj = (int)(e % Jp);
+    if (jj < J) {
+        if (gw) gw[(int64_t)m * J + jj] = (bf16_t)sum;
+    } else if (gb) {
+        gb[m] = (bf16_t)sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+extern int g_conv1x1_tune[4];  // [0] xcd remap (default 1), [1] MT override (0 = auto), [2] wgrad target waves, [3] spare
+int g_conv1x1_tune[4] = {1, 0, 2048, 0};
+
+static int grid_blocks(int64_t waves) {
+    int64_t b = (waves + 3) / 4;
+    return (int)((b + 7) / 8 * 8);
+}
+
+template <int PXV, int AL>
+static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_t* A, const bf16_t* bias, bf16_t* y1,
+                         bf16_t* y2, int m1, int N, int K, int M, int HW, hipStream_t stream) {
+    int MT = g_conv1x1_tune[1] ? g_conv1x1_tune[1] : (M <= 32 ? 2 : 4);
+    if (MT != 2) MT = 4;
+    const int mblocks = ceil_div(M, 16 * MT), ptiles = ceil_div(HW, 16 * PXV);
+    const int64_t waves = (int64_t)N * ptiles * mblocks;
+    const dim3 grid(grid_blocks(waves)), block(256);
+    const int xcd = g_conv1x1_tune[0];
+    if (MT == 2)
+        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, K, M, HW,
+                   mblocks, ptiles, waves, xcd);
+    else
+        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 4, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, K, M, HW,
+                   mblocks, ptiles, waves, xcd);
+    return check_launch("conv1x1_fwd_mfma");
+}
+
+// x = [x1 | x2] along channels (x2 may be NULL, then k1 == K); y = [y1 | y2] likewise (m1 == M when y2 == NULL)
+int conv1x1_gemm(const void* x1, const void* x2, int k1, const void* A, const void* bias, void* y1, void* y2, int m1,
+                 int N, int K, int M, int HW, hipStream_t stream) {
+    const bf16_t *X1 = (const bf16_t*)x1, *X2 = (const bf16_t*)x2, *a = (const bf16_t*)A, *b = (const bf16_t*)bias;
+    bf16_t *Y1 = (bf16_t*)y1, *Y2 = (bf16_t*)y2;
+    if (HW % 8 == 0) return launch_fwd_mt<8, 16>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, stream);
+    if (HW % 4 == 0) return launch_fwd_mt<4, 8>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, stream);
+    return launch_fwd_mt<4, 2>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, stream);
+}
+
+int conv1x1_transpose(const void* w, void* wt, int M, int K, hipStream_t stream) {
+    const int64_t tot = (int64_t)M * K;
+    COT_LAUNCH(conv1x1_transpose_w, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, stream, (const bf16_t*)w,
+               (bf16_t*)wt, M, K);
+    return check_launch("conv1x1_transpose_w");
+}
+
+// number of deterministic partial sums the weight gradient is split into (also sizes the workspace)
+int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias) {
+    const int Jp = J + (has_bias ? 1 : 0);
+    const int64_t units = (int64_t)ceil_div(M, 64) * ceil_div(Jp, 64);
+    const int64_t T = (int64_t)N * ceil_div(HW, 32);
+    if (g_conv1x1_tune[2] < 0) return (int)(-g_conv1x1_tune[2] < T ? -g_conv1x1_tune[2] : T);  // forced split (tests)
+    int64_t S = ceil_div64(g_conv1x1_tune[2] > 0 ? g_conv1x1_tune[2] : 2048, units);
+    const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
+    const int64_t cap = in_bytes / 8 / out_bytes;  // partial sums may cost at most 1/8 of the input traffic
+    if (S > cap) S = cap;
+    if (S > T) S = T;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+int conv1x1_wgrad(const void* gy, const void* x1, const void* x2, int k1, void* gw, void* gb, float* workspace, int N,
+                  int J, int M, int HW, hipStream_t stream) {
+    const int has_bias = gb ? 1 : 0, Jp = J + has_bias;
+    const int S = conv1x1_wgrad_splits(N, M, J, HW, has_bias);
+    const int mblocks = ceil_div(M, 64), jblocks = ceil_div(Jp, 64), spi = ceil_div(HW, 32);
+    const int64_t waves = (int64_t)S * mblocks * jblocks;
+    const dim3 grid(grid_blocks(waves)), block(256);
+    const int xcd = g_conv1x1_tune[0];
+    const bf16_t *GY = (const bf16_t*)gy, *X1 = (const bf16_t*)x1, *X2 = (const bf16_t*)x2;
+    if (HW % 8 == 0)
+        COT_LAUNCH((conv1x1_wgrad_mfma<16>), grid, block, 0, stream, GY, X1, X2, k1, workspace, N, M, J, HW, has_bias,
+                   mblocks, jblocks, S, spi, waves, xcd);
+    else
+        COT_LAUNCH((conv1x1_wgrad_mfma<2>), grid, block, 0, stream, GY, X1, X2, k1, workspace, N, M, J, HW, has_bias,
+                   mblocks, jblocks, S, spi, waves, xcd);
+    int rc = check_launch("conv1x1_wgrad_mfma");
+    if (rc) return rc;
+    const int64_t tot = (int64_t)M * Jp;
+    COT_LAUNCH(conv1x1_wgrad_reduce, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, stream,
+               (const float*)workspace, S, M, J, has_bias, (bf16_t*)gw, (bf16_t*)gb);
+    return check_launch("conv1x1_wgrad_reduce");
+}
+
+}  // namespace cot

@@ -105,6 +105,13 @@ template <typename T> int radix_gap(const void*, const void*, void*, int64_t, in
 template <typename T> int radix_mix(const void*, const void*, const void*, void*, int64_t, int, hipStream_t);
 template <typename T>
 int radix_mix_bwd(const void*, const void*, const void*, const void*, void*, void*, void*, int64_t, int, hipStream_t);
+// implemented in conv1x1.hip
+int conv1x1_gemm(const void*, const void*, int, const void*, const void*, void*, void*, int, int, int, int, int,
+                 hipStream_t);
+int conv1x1_transpose(const void*, void*, int, int, hipStream_t);
+int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
+int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
+extern int g_conv1x1_tune[4];
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
 int set_tuning_nchw(int key, int value);
@@ -212,6 +219,10 @@ const char* cot_status_string(int status) {
 int cot_agg_out_size(int in, int k, int s, int p, int d) { return out_size(in, k, s, p, d); }
 
 int cot_set_tuning(int key, int value) {
+    if (key >= 9 && key <= 11) {
+        g_conv1x1_tune[key - 9] = value;
+        return COT_OK;
+    }
     if (set_tuning_nchw(key, value) != 0) return set_error(COT_ERR_INVALID_ARG, "unknown tuning key %d", key);
     return COT_OK;
 }
@@ -225,6 +236,55 @@ int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad
     if (rc) return rc;
     return sgd_flat(param, master, momentum_buf, grad, n, lr, momentum, weight_decay, grad_scale, nesterov, param_dtype,
                     grad_dtype, (hipStream_t)stream);
+}
+
+static int conv1x1_validate(int N, int Ci, int Co, int HW, int c1, bool split, int dtype, int kdim) {
+    if (N <= 0 || Ci <= 0 || Co <= 0 || HW <= 0)
+        return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d Ci=%d Co=%d HW=%d", N, Ci, Co, HW);
+    if (split ? (c1 <= 0 || c1 >= Ci) : (c1 != Ci))
+        return set_error(COT_ERR_INVALID_ARG, "channel split c1=%d does not fit Ci=%d (second slab %s)", c1, Ci,
+                         split ? "given" : "NULL");
+    if (dtype != COT_BF16)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_*: only COT_BF16 tensors (dtype %d given)", dtype);
+    if (kdim % 8 != 0)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_*: reduction channel count %d is not a multiple of 8", kdim);
+    return COT_OK;
+}
+
+int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias) {
+    if (N <= 0 || Ci <= 0 || Co <= 0 || HW <= 0) return 0;
+    const int64_t wt = (int64_t)Ci * Co * 2;
+    const int64_t part = (int64_t)conv1x1_wgrad_splits(N, Co, Ci, HW, has_bias) * Co * (Ci + (has_bias ? 1 : 0)) * 4;
+    return ((wt > part ? wt : part) + 255) / 256 * 256;
+}
+
+int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, int N,
+                        int Ci, int Co, int HW, int dtype, void* stream) {
+    int rc = conv1x1_validate(N, Ci, Co, HW, c1, x2 != nullptr, dtype, Ci);
+    if (rc) return rc;
+    if (!x1 || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x1, x2, weight, y}))) return rc;
+    return conv1x1_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, (hipStream_t)stream);
+}
+
+int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, void* workspace, int N,
+                              int Ci, int Co, int HW, int dtype, void* stream) {
+    int rc = conv1x1_validate(N, Ci, Co, HW, c1, gx2 != nullptr, dtype, Co);
+    if (rc) return rc;
+    if (!gy || !weight || !gx1 || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gy, weight, gx1, gx2, workspace}))) return rc;
+    // A = weight^T [Ci][Co] (row-major, K = Co contiguous): one tiny transpose, then the forward kernel on dY
+    if ((rc = conv1x1_transpose(weight, workspace, Co, Ci, (hipStream_t)stream))) return rc;
+    return conv1x1_gemm(gy, nullptr, Co, workspace, nullptr, gx1, gx2, c1, N, Co, Ci, HW, (hipStream_t)stream);
+}
+
+int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, int c1, void* gweight, void* gbias,
+                                void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream) {
+    int rc = conv1x1_validate(N, Ci, Co, HW, c1, x2 != nullptr, dtype, 8);
+    if (rc) return rc;
+    if (!gy || !x1 || !gweight || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gy, x1, x2, gweight, workspace}))) return rc;
+    return conv1x1_wgrad(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
 }
 
 int cot_agg_softmax_forward(const void* x, const void* logits, void* out, void* probs, const cot_agg_geom* g, int dtype,

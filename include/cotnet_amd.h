@@ -123,7 +123,9 @@ const char* cot_last_kernel(void);
  *   key 3: lane-exchange primitive (-1 probe on first use, 0 = DPP wave shift, 1 = ds_bpermute)
  *   key 4: v3 backward channel groups per LDS phase   key 5: v3 waves per workgroup (4|8)
  *   key 6: v3 extra LDS KiB per workgroup             key 7: v3 XCD-aware tile order (0|1)
- *   key 8: issue the fused backward as separate gX and gW launches (0|1) */
+ *   key 8: issue the fused backward as separate gX and gW launches (0|1)
+ *   key 9: 1x1-convolution kernels XCD-aware wave order (0|1)   key 10: 16-row tiles per wave, forward (0 auto|2|4)
+ *   key 11: 1x1 weight-gradient target wave count (sizes the split of the reduction); negative = force -value splits */
 int cot_set_tuning(int key, int value);
 /* 0 if the device probe confirmed the DPP wave_shr/wave_shl semantics the v2 kernels rely on, 1 if the
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */
@@ -139,6 +141,25 @@ int cot_radix_mix(const void* y, const void* k, const void* attn, void* out, int
                   void* stream);
 int cot_radix_mix_backward(const void* gout, const void* y, const void* k, const void* attn, void* gy, void* gk,
                            void* gattn, int64_t planes, int HW, int dtype, void* stream);
+
+/* ---- 1x1 convolution on NCHW tensors WITHOUT layout changes (CotLayer.embed[0], embed[3],
+ * conv1x1[0] -- models/cotnet.py:51-62 -- and Bottleneck.conv1/conv3/downsample, models/cotnet.py:206-224).  Replaces
+ * nn.Conv2d(kernel_size=1, stride=1, groups=1) forward and both gradients; COT_BF16 only (fp32 accumulation), other
+ * dtypes and channel counts that are not multiples of 8 return COT_ERR_UNSUPPORTED (caller keeps nn.Conv2d).
+ *     y[n][co][p] = sum_ci weight[co][ci] * x[n][ci][p] + bias[co]         weight [Co][Ci] row-major, bias NULL or [Co]
+ * x may be given as TWO channel slabs that the reference concatenates first (`torch.cat([x, k], dim=1)`,
+ * models/cotnet.py:81): x1 = [N][c1][HW], x2 = [N][Ci-c1][HW]; x2 == NULL means one tensor and c1 must equal Ci.
+ * backward_data writes the gradient of that concatenation to gx1 / gx2 the same way.
+ * backward_weight: gweight [Co][Ci], gbias [Co] or NULL; deterministic (partial sums in `workspace`, no atomics).
+ * workspace: cot_conv1x1_workspace(...) BYTES (256-byte multiple), needed by the two backward calls only; they may
+ * share one buffer when issued on one stream. */
+int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias);
+int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, int N,
+                        int Ci, int Co, int HW, int dtype, void* stream);
+int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, void* workspace, int N,
+                              int Ci, int Co, int HW, int dtype, void* stream);
+int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, int c1, void* gweight, void* gbias,
+                                void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream);
 
 /* ---- fused SGD over a flat parameter bucket (replaces torch.optim.SGD(nesterov=True),
  * optim/optim_factory.py:54-56, which launches per parameter tensor):

@@ -41,6 +41,7 @@ namespace emul {
 struct WaveCtx {
     pthread_barrier_t bar;
     uint64_t slot[64];
+    uint64_t wide[64][4];  // MFMA operands: [lane][0..1] = A fragment (8 bf16), [lane][2..3] = B fragment
 };
 struct BlockCtx {
     pthread_barrier_t bar;
@@ -61,6 +62,38 @@ template <typename V> inline V exchange(V v, int delta, V oob) {  // returns lan
     if (src >= 0 && src < 64) std::memcpy(&r, &c.slot[src], sizeof(V));
     pthread_barrier_wait(&c.bar);
     return r;
+}
+
+inline float bf16_bits_to_float(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// v_mfma_f32_16x16x32_bf16, D = A*B + C over the 64 lanes of the calling wave.  Operand maps (gfx950):
+//   A: lane l holds A[i = l&15][k = 8*(l>>4) .. +7];  B: lane l holds B[k = 8*(l>>4) .. +7][j = l&15];
+//   C/D: lane l holds D[i = 4*(l>>4) + r][j = l&15], r = 0..3.   Every lane of the wave must make the call.
+template <typename AB, typename C> inline C mfma_16x16x32_bf16(const AB& a, const AB& b, const C& c) {
+    static_assert(sizeof(AB) == 16, "8 x bf16 operand fragments");
+    WaveCtx& w = g_blk->wave[t_wave];
+    std::memcpy(&w.wide[t_lane][0], &a, 16);
+    std::memcpy(&w.wide[t_lane][2], &b, 16);
+    pthread_barrier_wait(&w.bar);
+    C d = c;
+    const int col = t_lane & 15, rg = t_lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rg + r;
+        float sum = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            uint16_t av, bv;
+            std::memcpy(&av, (const char*)&w.wide[row + 16 * (k >> 3)][0] + 2 * (k & 7), 2);
+            std::memcpy(&bv, (const char*)&w.wide[col + 16 * (k >> 3)][2] + 2 * (k & 7), 2);
+            sum += bf16_bits_to_float(av) * bf16_bits_to_float(bv);
+        }
+        d[r] = c[r] + sum;
+    }
+    pthread_barrier_wait(&w.bar);
+    return d;
 }
 
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
@@ -100,6 +133,8 @@ namespace cot { alignas(16) inline char cot_smem[160 * 1024]; }  // the kernels 
 #define COT_ASYNC_COPY16(gptr, lds_wave_base) \
     std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)
 
+#define COT_MFMA_16X16X32_BF16(a, b, c) emul::mfma_16x16x32_bf16((a), (b), (c))
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only ever applied to wave-uniform values
 inline float __expf(float x) { return std::exp(x); }
 using std::min;
 using std::max;

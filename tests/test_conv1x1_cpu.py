@@ -8,7 +8,7 @@ from cotnet_amd import conv1x1 as c1
 
 @pytest.mark.parametrize("bias", [False, True])
 def test_matches_conv2d(bias, monkeypatch):
-    monkeypatch.setattr(c1, "ENABLED", True)
+    monkeypatch.setattr(c1, "MODE", "matmul")
     torch.manual_seed(0)
     conv = nn.Conv2d(12, 20, 1, bias=bias).double()
     x = torch.randn(3, 12, 5, 7, dtype=torch.float64, requires_grad=True)
@@ -28,10 +28,10 @@ def test_matches_conv2d(bias, monkeypatch):
 
 
 def test_other_convolutions_fall_through(monkeypatch):
-    monkeypatch.setattr(c1, "ENABLED", True)
+    monkeypatch.setattr(c1, "MODE", "matmul")
     x = torch.randn(2, 8, 6, 6)
     for conv in (nn.Conv2d(8, 8, 3, padding=1), nn.Conv2d(8, 8, 1, groups=2), nn.Conv2d(8, 8, 1, stride=2)):
         assert not c1.eligible(conv, x)
         assert torch.equal(c1.conv1x1(conv, x), conv(x))
-    monkeypatch.setattr(c1, "ENABLED", False)
+    monkeypatch.setattr(c1, "MODE", "")
     assert not c1.eligible(nn.Conv2d(8, 8, 1), x)

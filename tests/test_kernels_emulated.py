@@ -350,3 +350,110 @@ def test_radix_tail_kernels(B, C, H, W, dtype):
     assert ((gy.float() - yr.grad).abs() <= tol * (1 + yr.grad.abs())).all()
     assert ((gk.float() - kr.grad).abs() <= tol * (1 + kr.grad.abs())).all()
     assert ((ga.float() - ar.grad).abs() <= tol * 4 * (1 + ar.grad.abs())).all()
+
+
+def _conv1x1_ref(x, w, b):
+    """fp32 reference on the bf16-rounded operands (the kernels accumulate in fp32)"""
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    bf = b.float().requires_grad_(True) if b is not None else None
+    y = torch.nn.functional.conv2d(xf, wf[:, :, None, None], bf)
+    return xf, wf, bf, y
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,c1,bias", [
+    (2, 64, 32, 8, 16, 0, False),     # HW % 8 == 0 : 16-byte pieces, one full + no partial tile, MT=2
+    (1, 40, 72, 12, 12, 0, True),     # HW = 144: partial pixel tile, K = 40 (partial K step), M = 72 (two m-blocks), bias
+    (2, 32, 24, 14, 14, 0, False),    # HW = 196: 8-byte pieces
+    (3, 16, 80, 7, 7, 0, True),       # HW = 49 : unaligned rows
+    (2, 48, 40, 8, 8, 16, True),      # two input slabs (the torch.cat the kernel absorbs)
+    (1, 24, 16, 7, 7, 8, False),
+    (2, 64, 144, 16, 24, 0, True),    # three pixel tiles, three m-blocks of 64 (MT=4), two K steps
+])
+@pytest.mark.parametrize("splits", [0, 3])
+def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
+    assert _EMUL.cot_set_tuning(11, -splits if splits else 2048) == 0
+    torch.manual_seed(5)
+    HW = H * W
+    x = torch.randn(N, Ci, H, W).bfloat16()
+    w = (torch.randn(Co, Ci) / Ci ** 0.5).bfloat16()
+    b = torch.randn(Co).bfloat16() if bias else None
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    xf, wf, bf, yref = _conv1x1_ref(x, w, b)
+    yref.backward(gy.float())
+    split = c1 > 0
+    x1 = x[:, :c1].contiguous() if split else x
+    x2 = x[:, c1:].contiguous() if split else None
+    cc1 = c1 if split else Ci
+    dt = _lib.dtype_code(torch.bfloat16)
+    PN = lambda t: P(t) if t is not None else None
+
+    y = torch.full((N, Co, H, W), float("nan")).bfloat16()
+    rc = _EMUL.cot_conv1x1_forward(P(x1), PN(x2), cc1, P(w), PN(b), P(y), N, Ci, Co, HW, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(y.float(), yref.detach(), atol=2e-2, rtol=2e-2), (y.float() - yref).abs().max()
+
+    ws_bytes = _EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 1 if bias else 0)
+    assert ws_bytes > 0 and ws_bytes % 256 == 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8)
+    if Co % 8 == 0:
+        gx1 = torch.full_like(x1, float("nan"))
+        gx2 = torch.full_like(x2, float("nan")) if split else None
+        rc = _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx1), PN(gx2), cc1, P(ws), N, Ci, Co, HW, dt, None)
+        assert rc == 0, _EMUL.cot_last_error()
+        gx = torch.cat([gx1, gx2], 1) if split else gx1
+        assert torch.allclose(gx.float(), xf.grad, atol=3e-2, rtol=2e-2), (gx.float() - xf.grad).abs().max()
+    gw = torch.full_like(w, float("nan"))
+    gb = torch.full_like(b, float("nan")) if bias else None
+    rc = _EMUL.cot_conv1x1_backward_weight(P(gy), P(x1), PN(x2), cc1, P(gw), PN(gb), P(ws), N, Ci, Co, HW, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    scale = wf.grad.abs().max().item()
+    assert (gw.float() - wf.grad).abs().max().item() <= 1e-2 * scale + 1e-2
+    if bias:
+        assert (gb.float() - bf.grad).abs().max().item() <= 1e-2 * bf.grad.abs().max().item() + 1e-2
+    assert _EMUL.cot_set_tuning(11, 2048) == 0
+
+
+def test_conv1x1_rejects_what_it_does_not_cover():
+    x = torch.zeros(1, 12, 4, 4).bfloat16()
+    w = torch.zeros(8, 12).bfloat16()
+    y = torch.zeros(1, 8, 4, 4).bfloat16()
+    dt = _lib.dtype_code(torch.bfloat16)
+    assert _EMUL.cot_conv1x1_forward(P(x), None, 12, P(w), None, P(y), 1, 12, 8, 16, dt, None) == -2  # Ci % 8 != 0
+    assert _EMUL.cot_conv1x1_forward(P(x), None, 16, P(w), None, P(y), 1, 16, 8, 16, 0, None) == -2   # fp32
+    assert _EMUL.cot_conv1x1_forward(P(x), None, 8, P(w), None, P(y), 1, 16, 8, 16, dt, None) == -1   # c1 != Ci, no x2
+
+
+@pytest.mark.parametrize("split,bias", [(False, False), (True, True)])
+def test_conv1x1_autograd_wiring_on_emulated_kernels(split, bias, monkeypatch):
+    """cotnet_amd.conv1x1's Function (argument order, needs_input_grad handling, the cat-free two-slab form) driven on CPU
+    tensors with the host-emulated library standing in for libcotnet_hip.so"""
+    from torch import nn
+    from cotnet_amd import conv1x1 as c1
+    monkeypatch.setattr(c1, "MODE", "hip")
+    monkeypatch.setattr(c1, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    c1._WS.clear()
+    torch.manual_seed(2)
+    conv = nn.Conv2d(32, 24, 1, bias=bias).bfloat16()
+    xa = torch.randn(2, 16 if split else 32, 7, 7).bfloat16().requires_grad_(True)
+    xb = torch.randn(2, 16, 7, 7).bfloat16().requires_grad_(True) if split else None
+    g = torch.randn(2, 24, 7, 7).bfloat16()
+    assert c1.eligible_hip(conv, xa, xb)
+    y = c1.conv1x1(conv, xa, xb)
+    y.backward(g)
+    got = [y.detach().float(), xa.grad.float(), xb.grad.float() if split else None, conv.weight.grad.float(),
+           conv.bias.grad.float() if bias else None]
+    # reference: the module itself in fp32 on the same (bf16-rounded) values
+    ref = nn.Conv2d(32, 24, 1, bias=bias)
+    ref.weight.data = conv.weight.data.float()
+    if bias:
+        ref.bias.data = conv.bias.data.float()
+    ra = xa.detach().float().requires_grad_(True)
+    rb = xb.detach().float().requires_grad_(True) if split else None
+    yr = ref(torch.cat([ra, rb], 1) if split else ra)
+    yr.backward(g.float())
+    want = [yr.detach(), ra.grad, rb.grad if split else None, ref.weight.grad, ref.bias.grad if bias else None]
+    for a, b in zip(got, want):
+        if b is not None:
+            assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 2e-2
+    c1._WS.clear()

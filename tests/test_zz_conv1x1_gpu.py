@@ -1,0 +1,123 @@
+"""The NCHW-native MFMA 1x1-convolution kernels (csrc/conv1x1.hip behind cot_conv1x1_*, opt-in COT_CONV1X1=hip) on the
+GPU against torch's own convolution evaluated in fp32 on the same bf16-rounded operands.  (File name sorts last: these
+kernels are the newest code in the library.)"""
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from cotnet_amd import conv1x1 as c1
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref(xs, w, b, gy):
+    """fp32 autograd reference on the bf16-rounded values; xs = list of channel slabs"""
+    rs = [x.detach().float().requires_grad_(True) for x in xs]
+    wf = w.detach().float().requires_grad_(True)
+    bf = b.detach().float().requires_grad_(True) if b is not None else None
+    y = F.conv2d(torch.cat(rs, 1) if len(rs) > 1 else rs[0], wf, bf)
+    y.backward(gy.float())
+    return y.detach(), [r.grad for r in rs], wf.grad, (bf.grad if bf is not None else None)
+
+
+def _close(a, b, rel):
+    # bf16 outputs of fp32-accumulated sums: error <= half an ulp of the result (2^-9 relative) + accumulation-order noise
+    return ((a.float() - b).abs() <= rel * (b.abs() + b.abs().mean())).all()
+
+
+# (N, Ci, Co, H, split, bias): the CoTNet-50 layer shapes (models/cotnet.py:51-62,:206-224) at a small batch + odd ones
+CASES = [
+    (4, 256, 64, 56, 0, False),    # Bottleneck.conv1, stage 1
+    (4, 128, 32, 56, 64, False),   # CotLayer.embed[0] on [x | k]
+    (4, 32, 72, 56, 0, True),      # CotLayer.embed[3] (bias; Co = 72)
+    (4, 64, 64, 56, 0, False),     # CotLayer.conv1x1[0]
+    (4, 64, 256, 56, 0, False),    # Bottleneck.conv3, stage 1
+    (4, 128, 512, 28, 0, False),
+    (4, 512, 128, 28, 256, False),
+    (3, 256, 1024, 14, 0, False),  # 14x14: 8-byte pieces
+    (3, 128, 288, 14, 0, True),
+    (3, 512, 2048, 7, 0, False),   # 7x7: unaligned rows
+    (3, 1024, 256, 7, 512, False),
+    (2, 24, 40, 5, 8, True),       # nothing aligned, partial K step
+    (1, 8, 8, 1, 0, False),        # a single pixel
+]
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,split,bias", CASES)
+def test_matches_torch_convolution(N, Ci, Co, H, split, bias, monkeypatch):
+    monkeypatch.setattr(c1, "MODE", "hip")
+    torch.manual_seed(Ci + Co + H)
+    conv = nn.Conv2d(Ci, Co, 1, bias=bias).to(DEV).bfloat16()
+    x = torch.randn(N, Ci, H, H, device=DEV).bfloat16()
+    xs = [x[:, :split].contiguous(), x[:, split:].contiguous()] if split else [x]
+    xs = [t.requires_grad_(True) for t in xs]
+    gy = torch.randn(N, Co, H, H, device=DEV).bfloat16()
+    assert c1.eligible_hip(conv, *xs)
+    y = c1.conv1x1(conv, *xs)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    yr, gxr, gwr, gbr = _ref(xs, conv.weight, conv.bias, gy)
+    assert _close(y, yr, 1e-2)
+    for t, r in zip(xs, gxr):
+        assert _close(t.grad, r, 1e-2)
+    assert _close(conv.weight.grad, gwr, 1e-2)
+    if bias:
+        assert _close(conv.bias.grad, gbr, 1e-2)
+
+
+def test_weight_gradient_is_deterministic(monkeypatch):
+    monkeypatch.setattr(c1, "MODE", "hip")
+    torch.manual_seed(0)
+    conv = nn.Conv2d(64, 256, 1, bias=False).to(DEV).bfloat16()
+    x = torch.randn(16, 64, 56, 56, device=DEV).bfloat16()
+    gy = torch.randn(16, 256, 56, 56, device=DEV).bfloat16()
+    grads = []
+    for _ in range(3):
+        conv.weight.grad = None
+        c1.conv1x1(conv, x).backward(gy)
+        grads.append(conv.weight.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+def test_cot_layer_and_bottleneck_with_hip_convolutions(monkeypatch):
+    """whole CotLayer / Bottleneck forward+backward: COT_CONV1X1=hip against the default (MIOpen) path, same weights"""
+    import copy
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    torch.manual_seed(1)
+    ds = nn.Sequential(nn.Identity(), nn.Conv2d(128, 256, 1, bias=False), nn.BatchNorm2d(256))
+    blk_a = to_mixed_bf16(Bottleneck(128, 64, downsample=ds).to(DEV)).train()
+    with torch.no_grad():
+        blk_a.bn3.weight.fill_(1.0)  # zero-init would hide conv3
+    blk_b = copy.deepcopy(blk_a)
+    x = torch.randn(4, 128, 28, 28, device=DEV).bfloat16()
+    gy = torch.randn(4, 256, 28, 28, device=DEV).bfloat16()
+
+    def run(blk, mode):
+        monkeypatch.setattr(c1, "MODE", mode)
+        xa = x.clone().requires_grad_(True)
+        y = blk(xa)
+        y.backward(gy)
+        return y.detach().float(), xa.grad.float(), {n: p.grad.float() for n, p in blk.named_parameters()}
+
+    ya, gxa, ga = run(blk_a, "hip")
+    yb, gxb, gb = run(blk_b, "")
+    assert (ya - yb).abs().mean() <= 0.02 * yb.abs().mean() + 1e-3
+    assert (gxa - gxb).abs().mean() <= 0.03 * gxb.abs().mean() + 1e-3
+    scale = max(g.abs().mean().item() for g in gb.values())  # (a bias in front of a BatchNorm has a pure-noise gradient)
+    for n in ga:
+        assert (ga[n] - gb[n]).abs().mean() <= 0.05 * gb[n].abs().mean() + 2e-3 * scale, n
+
+
+def test_other_inputs_keep_the_module_path(monkeypatch):
+    monkeypatch.setattr(c1, "MODE", "hip")
+    conv = nn.Conv2d(16, 16, 1).to(DEV)
+    x = torch.randn(2, 16, 8, 8, device=DEV)
+    assert not c1.eligible_hip(conv, x)                      # fp32
+    assert torch.equal(c1.conv1x1(conv, x), conv(x))
+    convb = nn.Conv2d(12, 16, 1).to(DEV).bfloat16()
+    assert not c1.eligible_hip(convb, torch.zeros(2, 12, 8, 8, device=DEV).bfloat16())   # Ci % 8 != 0
+    convs = nn.Conv2d(16, 16, 1, stride=2).to(DEV).bfloat16()
+    assert not c1.eligible_hip(convs, x.bfloat16())
