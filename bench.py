@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--conv1x1", default=None, choices=["module", "hip", "matmul"],
                     help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
+    ap.add_argument("--conv3x3", default=None, choices=["module", "hip"],
+                    help="grouped 3x3 key-embed convolution (cotnet_amd/conv3x3g.py); default: COT_CONV3X3 or the module")
     return ap.parse_args()
 
 
@@ -134,6 +136,9 @@ def main():
     if args.conv1x1 is not None:
         from cotnet_amd import conv1x1 as _c1
         _c1.MODE = "" if args.conv1x1 == "module" else args.conv1x1
+    if args.conv3x3 is not None:
+        from cotnet_amd import conv3x3g as _c3
+        _c3.MODE = "" if args.conv3x3 == "module" else args.conv3x3
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -296,6 +301,7 @@ def main():
                                      else "bf16 autocast, fp32 weights" if amp else "fp32"),
                        "hip_graph": graphed,
                        "conv1x1": __import__("cotnet_amd.conv1x1", fromlist=["MODE"]).MODE or "module",
+                       "conv3x3": __import__("cotnet_amd.conv3x3g", fromlist=["MODE"]).MODE or "module",
                        "grad_sync": "RCCL all-reduce (AVG), flat buckets, side stream" if world > 1 else "none (1 GPU)"},
             "final_loss": round(final_loss, 4),
             "roofline": roofline,

@@ -1,0 +1,107 @@
+"""Grouped 3x3 convolution (stride 1, padding 1) on NCHW bf16 tensors without layout changes.
+
+`conv3x3(conv, x)` evaluates an ordinary `nn.Conv2d(kernel_size=3, stride=1, padding=1, bias=False)` -- the reference's
+`CotLayer.key_embed[0]` (groups 4, models/cotnet.py:43-47) and `CoXtLayer.key_embed[0]` (groups 8, :112-116); same
+parameter, same state_dict -- through the hand-written MFMA kernels of csrc/conv3x3g.hip (cot_conv3x3g_*) when
+COT_CONV3X3=hip and the tensor qualifies (bf16, NCHW-contiguous, channels per group a multiple of 8); otherwise through
+the module itself (MIOpen).  Opt-in until measured on an MI355X (ROUND2_PLAN.md); verified against torch through the host
+emulation of the kernels (tests/test_kernels_emulated.py) and by tests/test_zz_conv3x3g_gpu.py.
+"""
+import ctypes
+import os
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+MODE = os.environ.get("COT_CONV3X3", "")
+_DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
+
+_MASKS = {}  # (H, W, device) -> uint8 tensor holding the per-pixel tap-validity table (read-only after creation)
+_WS = {}     # (N, Cin, Cout, G, H, W) -> workspace bytes
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if _DEVICE_ONLY else None
+
+
+def _masks(H, W, device):
+    k = (H, W, str(device))
+    m = _MASKS.get(k)
+    if m is None:
+        L = _lib.lib()
+        m = torch.empty(int(L.cot_conv3x3g_masks_bytes(H, W)), dtype=torch.uint8, device=device)
+        rc = L.cot_conv3x3g_masks(_p(m), H, W, _stream())
+        if rc:
+            _lib.check(rc, "cot_conv3x3g_masks")
+        _MASKS[k] = m
+    return m
+
+
+def _ws_bytes(*key):
+    v = _WS.get(key)
+    if v is None:
+        v = _WS[key] = int(_lib.lib().cot_conv3x3g_workspace(*key))
+    return v
+
+
+class _Conv3x3G(Function):
+    @staticmethod
+    def forward(ctx, x, weight, groups):
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        masks = _masks(H, W, x.device)
+        ws = torch.empty(_ws_bytes(N, Cin, Cout, groups, H, W), dtype=torch.uint8, device=x.device)
+        y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device)
+        rc = _lib.lib().cot_conv3x3g_forward(_p(x), _p(weight), _p(y), _p(masks), _p(ws), N, Cin, Cout, groups, H, W,
+                                             _lib.COT_BF16, _stream())
+        if rc:
+            _lib.check(rc, "cot_conv3x3g_forward")
+        ctx.save_for_backward(x, weight)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        Cout, G = weight.shape[0], ctx.groups
+        gy = gy.contiguous()
+        L = _lib.lib()
+        masks = _masks(H, W, x.device)
+        ws = torch.empty(_ws_bytes(N, Cin, Cout, G, H, W), dtype=torch.uint8, device=x.device)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            rc = L.cot_conv3x3g_backward_data(_p(gy), _p(weight), _p(gx), _p(masks), _p(ws), N, Cin, Cout, G, H, W,
+                                              _lib.COT_BF16, _stream())
+            if rc:
+                _lib.check(rc, "cot_conv3x3g_backward_data")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            rc = L.cot_conv3x3g_backward_weight(_p(gy), _p(x), _p(gw), _p(masks), _p(ws), N, Cin, Cout, G, H, W,
+                                                _lib.COT_BF16, _stream())
+            if rc:
+                _lib.check(rc, "cot_conv3x3g_backward_weight")
+        return gx, gw, None
+
+
+def eligible(conv, x):
+    return (MODE == "hip" and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3)
+            and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.bias is None
+            and conv.padding_mode == "zeros" and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4
+            and x.dtype == torch.bfloat16 and conv.weight.dtype == torch.bfloat16 and x.is_contiguous()
+            and conv.weight.is_contiguous() and x.shape[1] == conv.in_channels
+            and (conv.in_channels // conv.groups) % 8 == 0 and (conv.out_channels // conv.groups) % 8 == 0)
+
+
+def conv3x3(conv, x):
+    """`conv(x)` for an nn.Conv2d; see the module docstring for when the HIP kernels serve it"""
+    if MODE == "hip" and eligible(conv, x):
+        return _Conv3x3G.apply(x, conv.weight, conv.groups)
+    return conv(x)

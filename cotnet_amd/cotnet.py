@@ -21,6 +21,7 @@ from torch import nn
 from .aggregation_zeropad import LocalConvolution
 from . import radix_tail
 from .conv1x1 import conv1x1, run_downsample
+from .conv3x3g import conv3x3
 from .fused_bn import fused_bn_act
 from .layers import get_act_layer
 from .registry import build_model_with_cfg, register_model
@@ -123,7 +124,7 @@ class CotLayer(nn.Module):
     def forward(self, x):
         # Sequential members are called one by one so that each BatchNorm runs fused with its activation
         # (cotnet_amd.fused_bn); module structure and state_dict keys are the reference's.
-        k = fused_bn_act(self.key_embed[0](x), self.key_embed[1], "relu")
+        k = fused_bn_act(conv3x3(self.key_embed[0], x), self.key_embed[1], "relu")
         b, _, qk_hh, qk_ww = x.size()
 
         # embed[0] consumes the concatenation [x, k] (ref :81); conv1x1 reads the two slabs in place when it can
@@ -178,7 +179,7 @@ class CoXtLayer(nn.Module):
 
     def forward(self, x):
         batch_size, channels, height, width = x.size()
-        k = fused_bn_act(self.key_embed[0](x), self.key_embed[1], "relu")
+        k = fused_bn_act(conv3x3(self.key_embed[0], x), self.key_embed[1], "relu")
         # channel-interleave [x0,k0,x1,k1,...] so each of the 2 conv groups sees matching x/k halves (ref :153-154)
         qk = torch.stack([x, k], dim=2).view(batch_size, -1, height, width)
 

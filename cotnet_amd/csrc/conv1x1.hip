@@ -25,56 +25,9 @@
 // 16-byte loads.  Split over the (n, pixel) range into S deterministic partial sums (fp32 workspace) + one reduce
 // kernel (no atomics: bit-reproducible, and capturable in a HIP graph without a zero-fill node).
 #include "cot_common.h"
+#include "mfma_common.h"
 
 namespace cot {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-#ifndef COT_MFMA_16X16X32_BF16  // (tests/emul pre-defines this primitive for its host build)
-#define COT_MFMA_16X16X32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-#endif
-
-template <int V> struct BFVec {
-    typedef __attribute__((ext_vector_type(V))) __bf16 type;
-};
-
-// dst[0..V) = p[0..V) for the first `cnt` elements, zero beyond (cnt may be <= 0 or > V).  `full` is a WAVE-UNIFORM
-// promise that cnt >= V for every lane (scalar branch: the wide access is not entangled with the element-wise tail path)
-template <int V, int AL>
-__device__ __forceinline__ void load_piece(bf16_t (&dst)[V], const bf16_t* p, int cnt, bool full) {
-    if (full) {
-        typename BFVec<V>::type t;  // one wide access; AL = what is known about p's alignment
-        __builtin_memcpy(&t, __builtin_assume_aligned(p, AL), sizeof(t));
-#pragma unroll
-        for (int i = 0; i < V; ++i) dst[i] = t[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < V; ++i) dst[i] = (i < cnt) ? p[i] : (bf16_t)0.0f;
-    }
-}
-template <int V, int AL>
-__device__ __forceinline__ void store_piece(bf16_t* p, const bf16_t (&src)[V], int cnt, bool full) {
-    if (full) {
-        typename BFVec<V>::type t;
-#pragma unroll
-        for (int i = 0; i < V; ++i) t[i] = src[i];
-        __builtin_memcpy(__builtin_assume_aligned(p, AL), &t, sizeof(t));
-    } else {
-#pragma unroll
-        for (int i = 0; i < V; ++i)
-            if (i < cnt) p[i] = src[i];
-    }
-}
-// wave-uniform value -> SGPR (so that conditions on it become scalar branches)
-__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ int64_t wave_work_id(int xcd_remap) {
-    unsigned b = blockIdx.x;
-    const unsigned nblk = gridDim.x;
-    if (xcd_remap && (nblk & 7u) == 0) b = (b & 7u) * (nblk >> 3) + (b >> 3);  // consecutive ids -> same XCD
-    return (int64_t)b * (blockDim.x >> 6) + (threadIdx.x >> 6);
-}
 
 // channel row `r` of image n in a tensor given as two channel slabs (concatenation along C): rows [0,c1) live in
 // t1 (c1 channels per image), rows [c1,C) in t2 (C-c1 channels per image)
@@ -269,15 +222,18 @@ __global__ void conv1x1_wgrad_reduce(const float* __restrict__ part, int S, int 
     }
 }
 
+int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_bias, void* gw, void* gb,
+                                hipStream_t stream) {
+    const int64_t tot = (int64_t)M * (J + (has_bias ? 1 : 0));
+    COT_LAUNCH(conv1x1_wgrad_reduce, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, stream, part, S, M, J, has_bias,
+               (bf16_t*)gw, (bf16_t*)gb);
+    return check_launch("conv1x1_wgrad_reduce");
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 extern int g_conv1x1_tune[4];  // [0] xcd remap (default 1), [1] MT override (0 = auto), [2] wgrad target waves, [3] spare
 int g_conv1x1_tune[4] = {1, 0, 2048, 0};
-
-static int grid_blocks(int64_t waves) {
-    int64_t b = (waves + 3) / 4;
-    return (int)((b + 7) / 8 * 8);
-}
 
 template <int PXV, int AL>
 static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_t* A, const bf16_t* bias, bf16_t* y1,
@@ -286,7 +242,7 @@ static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_
     if (MT != 2) MT = 4;
     const int mblocks = ceil_div(M, 16 * MT), ptiles = ceil_div(HW, 16 * PXV);
     const int64_t waves = (int64_t)N * ptiles * mblocks;
-    const dim3 grid(grid_blocks(waves)), block(256);
+    const dim3 grid(wave_grid_blocks(waves)), block(256);
     const int xcd = g_conv1x1_tune[0];
     if (MT == 2)
         COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, K, M, HW,
@@ -335,7 +291,7 @@ int conv1x1_wgrad(const void* gy, const void* x1, const void* x2, int k1, void* 
     const int S = conv1x1_wgrad_splits(N, M, J, HW, has_bias);
     const int mblocks = ceil_div(M, 64), jblocks = ceil_div(Jp, 64), spi = ceil_div(HW, 32);
     const int64_t waves = (int64_t)S * mblocks * jblocks;
-    const dim3 grid(grid_blocks(waves)), block(256);
+    const dim3 grid(wave_grid_blocks(waves)), block(256);
     const int xcd = g_conv1x1_tune[0];
     const bf16_t *GY = (const bf16_t*)gy, *X1 = (const bf16_t*)x1, *X2 = (const bf16_t*)x2;
     if (HW % 8 == 0)
@@ -346,10 +302,7 @@ int conv1x1_wgrad(const void* gy, const void* x1, const void* x2, int k1, void* 
                    mblocks, jblocks, S, spi, waves, xcd);
     int rc = check_launch("conv1x1_wgrad_mfma");
     if (rc) return rc;
-    const int64_t tot = (int64_t)M * Jp;
-    COT_LAUNCH(conv1x1_wgrad_reduce, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, stream,
-               (const float*)workspace, S, M, J, has_bias, (bf16_t*)gw, (bf16_t*)gb);
-    return check_launch("conv1x1_wgrad_reduce");
+    return conv1x1_wgrad_reduce_launch(workspace, S, M, J, has_bias, gw, gb, stream);
 }
 
 }  // namespace cot

@@ -1,0 +1,351 @@
+// conv3x3g.hip -- grouped 3x3 convolution (stride 1, padding 1) on NCHW bf16 tensors as MFMA implicit GEMMs.
+//
+// Replaces the reference's CotLayer.key_embed[0] = nn.Conv2d(dim, dim, 3, padding=1, groups=4, bias=False)
+// (models/cotnet.py:43-47; groups=8 in CoXtLayer, :112-116): forward, data gradient and weight gradient.
+// Per group (Kc input channels -> Mg output channels), per image:
+//       Y (Mg x HW) = A (Mg x 9*Kc) * B (9*Kc x HW),     B[(tap, ci)][p] = X[ci][p + dy*W + dx] or 0 outside the image
+// B is never materialised.  Same in-register transposition as conv1x1.hip (mfma_common.h has the operand maps): a lane
+// loads, for its 8 channels, PXV consecutive pixels STARTING AT THE SHIFTED ADDRESS p0 + dy*W + dx -- one wide, in
+// general unaligned, load per channel; pixels whose shifted neighbour falls outside the image come in as the neighbouring
+// row's / channel's data and are zeroed afterwards by select (never by multiplication: the garbage may be Inf/NaN) with
+// a 9-bit per-pixel tap-validity mask (`masks`, one uint16 per pixel, built once per H x W by conv3x3g_masks).
+// The K order is (tap, ci): every lane group's 8 channels share one tap, so the mask is applied per MFMA column.  The
+// weights are re-ordered to that K order by a small kernel per call (<= 1.2 MB); for the data gradient the same
+// re-ordering transposes (co, ci) and flips the taps, and the forward kernel is reused on dY.
+// Weight gradient: reduction over pixels, both operands pixel-contiguous; the B fragment of column (ci, tap) is X at the
+// shifted address with the tap's mask bits ANDed in; deterministic split-K partial sums + the reduce kernel of
+// conv1x1.hip.  Output columns are in the weight tensor's own [ci][3][3] order, so no re-ordering on the way out.
+#include "cot_common.h"
+#include "mfma_common.h"
+
+namespace cot {
+
+int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_bias, void* gw, void* gb,
+                                hipStream_t stream);  // conv1x1.hip
+extern int g_conv1x1_tune[4];
+
+__host__ __device__ inline int masks_padded(int HW) { return (HW + 127) / 128 * 128 + 128; }
+
+// masks[p] bit t (t = 3*(dy+1) + (dx+1)) = 1 iff pixel p = h*W + w has an in-image neighbour (h+dy, w+dx); 0 for p >= HW
+__global__ void conv3x3g_masks_kernel(uint16_t* __restrict__ masks, int H, int W, int padded) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= padded) return;
+    unsigned bits = 0;
+    if (p < H * W) {
+        const int h = p / W, w = p - h * W;
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) bits |= 1u << t;
+        }
+    }
+    masks[p] = (uint16_t)bits;
+}
+
+// mode 0: A[co][tap][ci]               = w[co][ci][tap]                  (rows: Cout, K = 9*Kc)
+// mode 1: A[g*Kc + ci][tap][co_local]  = w[g*Mg + co_local][ci][8 - tap] (rows: Cin,  K = 9*Mg)   -- data gradient
+__global__ void conv3x3g_repack(const bf16_t* __restrict__ w, bf16_t* __restrict__ A, int Cout, int Kc, int Mg,
+                                int mode) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)Cout * Kc * 9) return;
+    if (mode == 0) {
+        const int co = (int)(e / (9 * Kc)), rem = (int)(e % (9 * Kc)), tap = rem / Kc, ci = rem % Kc;
+        A[e] = w[((int64_t)co * Kc + ci) * 9 + tap];
+    } else {
+        const int row = (int)(e / (9 * Mg)), rem = (int)(e % (9 * Mg)), tap = rem / Mg, col = rem % Mg;
+        const int g = row / Kc, ci = row % Kc;
+        A[e] = w[(((int64_t)g * Mg + col) * Kc + ci) * 9 + (8 - tap)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Y[n][grp*Mg + m][p] = sum_{tap, ci} A[grp*Mg + m][tap*Kc + ci] * X[n][grp*Kc + ci][p + off(tap)]   (zero outside)
+// One wave = (image, pixel tile of 16*PXV, group, block of 16*MT output channels of the group).
+template <int PXV, int MT, int AL>
+__global__ void __launch_bounds__(256, 2)
+conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf16_t* __restrict__ y,
+                  const uint16_t* __restrict__ masks, int Cin, int Cout, int G, int H, int W, int mblocks, int ptiles,
+                  int64_t total_waves, int64_t x_elems, int xcd_remap) {
+    const int64_t wid = wave_work_id(xcd_remap);
+    if (wid >= total_waves) return;
+    const int lane = threadIdx.x & 63, j = lane & 15, lg = lane >> 4;
+    const int mb = uniform((int)(wid % mblocks));
+    int64_t t = wid / mblocks;
+    const int grp = uniform((int)(t % G));
+    t /= G;
+    const int pt = uniform((int)(t % ptiles)), n = uniform((int)(t / ptiles));
+    const int HW = H * W, Kc = Cin / G, Mg = Cout / G, Kg = 9 * Kc;
+    const int P0 = pt * (16 * PXV), p0 = P0 + j * PXV;
+    const int cnt = HW - p0;
+    const bool full_px = P0 + 16 * PXV <= HW;
+    const int mbase = mb * (16 * MT);
+    const int64_t base = ((int64_t)n * Cin + (int64_t)grp * Kc) * HW;  // element offset of the group's first channel
+    // every wide load of this wave stays inside the tensor (false only for the first / last waves of the launch)
+    const bool wave_safe = base + P0 - W - 1 >= 0 && base + (int64_t)(Kc - 1) * HW + P0 + 16 * PXV + W + 1 <= x_elems;
+
+    unsigned vm[PXV];  // tap-validity bits of this lane's pixels (masks is zero beyond HW and padded past every tile)
+#pragma unroll
+    for (int c = 0; c < PXV; ++c) vm[c] = masks[p0 + c];
+
+    f32x4_t acc[MT][PXV];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int c = 0; c < PXV; ++c) acc[mt][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = A + ((int64_t)grp * Mg + min(mbase + mt * 16 + j, Mg - 1)) * Kg;
+
+    for (int k0 = 0; k0 < Kg; k0 += 32) {
+        const int kb = k0 + 8 * lg;
+        const bool kok = kb < Kg;  // Kc % 8 == 0: the 8 channels of a lane group share one tap and are all in or all out
+        const int kbc = kok ? kb : 0;
+        const int tap = kbc / Kc, ci0 = kbc - tap * Kc;
+        const int shift = (tap / 3 - 1) * W + (tap % 3 - 1);
+        bf16_t raw[8][PXV];
+        if (wave_safe) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                load_piece<PXV, 2>(raw[r], x + (base + (int64_t)(ci0 + r) * HW + p0 + shift), PXV, true);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int64_t off = base + (int64_t)(ci0 + r) * HW + p0 + shift;
+#pragma unroll
+                for (int c = 0; c < PXV; ++c)
+                    raw[r][c] = (off + c >= 0 && off + c < x_elems) ? x[off + c] : (bf16_t)0.0f;
+            }
+        }
+        bf16x8_t af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16_t a_[8];
+            load_piece<8, 16>(a_, arow[mt] + kbc, 8, true);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[mt][e] = kok ? a_[e] : (bf16_t)0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < PXV; ++c) {
+            const bool valid = kok && ((vm[c] >> tap) & 1u);
+            bf16x8_t bfrag;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bfrag[r] = valid ? raw[r][c] : (bf16_t)0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][c] = COT_MFMA_16X16X32_BF16(af[mt], bfrag, acc[mt][c]);
+        }
+    }
+
+    if (cnt <= 0) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mbase + mt * 16 + lg * 4 + i;
+            if (m < Mg) {
+                bf16_t o[PXV];
+#pragma unroll
+                for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)acc[mt][c][i];
+                store_piece<PXV, AL>(y + ((int64_t)n * Cout + (int64_t)grp * Mg + m) * HW + p0, o, cnt, full_px);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// part[s][grp*Mg + m][ci*9 + tap] = sum over slice s of (n, p) of dY[n][grp*Mg + m][p] * X[n][grp*Kc + ci][p + off(tap)]
+// One wave = (group, 16*MTW output channels, 64 of the group's 9*Kc weight columns, slice s).
+template <int MTW, int AL>
+__global__ void __launch_bounds__(256, 2)
+conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, float* __restrict__ part,
+                    const uint16_t* __restrict__ masks, int N, int Cin, int Cout, int G, int H, int W, int mblocks,
+                    int jblocks, int S, int spi, int64_t total_waves, int64_t x_elems, int xcd_remap) {
+    const int64_t wid = wave_work_id(xcd_remap);
+    if (wid >= total_waves) return;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, lg = lane >> 4;
+    const int jb = uniform((int)(wid % jblocks));
+    int64_t u = wid / jblocks;
+    const int mb = uniform((int)(u % mblocks));
+    u /= mblocks;
+    const int grp = uniform((int)(u % G)), s = uniform((int)(u / G));
+    const int HW = H * W, Kc = Cin / G, Mg = Cout / G, Jg = 9 * Kc;
+    const int64_t T = (int64_t)N * spi;
+    const int64_t t0 = T * s / S, t1 = T * (s + 1) / S;
+
+    int mrow[MTW], jch[4], jtap[4], jshift[4];
+#pragma unroll
+    for (int q = 0; q < MTW; ++q) mrow[q] = grp * Mg + min(mb * (16 * MTW) + q * 16 + i16, Mg - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int jj = min(jb * 64 + q * 16 + i16, Jg - 1);  // columns >= Jg are computed on a copy, never stored
+        jch[q] = grp * Kc + jj / 9;
+        jtap[q] = jj % 9;
+        jshift[q] = (jtap[q] / 3 - 1) * W + (jtap[q] % 3 - 1);
+    }
+    f32x4_t acc[MTW][4];
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    int n = (int)(t0 / spi), st = (int)(t0 % spi);
+    for (int64_t t = t0; t < t1; ++t) {
+        const int P = st * 32, p = P + lg * 8;
+        const int cnt = HW - p;
+        const bool full = P + 32 <= HW;
+        const int64_t base = ((int64_t)n * Cin + (int64_t)grp * Kc) * HW;
+        const bool safe = base + P - W - 1 >= 0 && base + (int64_t)(Kc - 1) * HW + P + 32 + W + 1 <= x_elems;
+        // tap-validity bits of this lane's 8 pixels, two pixels per dword
+        unsigned vmd[4];
+        {
+            uint16_t v_[8];
+            __builtin_memcpy(v_, __builtin_assume_aligned(masks + p, 16), 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vmd[i] = (unsigned)v_[2 * i] | ((unsigned)v_[2 * i + 1] << 16);
+        }
+        bf16x8_t af[MTW], bfr[4];
+#pragma unroll
+        for (int q = 0; q < MTW; ++q) {
+            bf16_t a_[8];
+            load_piece<8, AL>(a_, gy + ((int64_t)n * Cout + mrow[q]) * HW + p, cnt, full);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[q][e] = a_[e];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t off = ((int64_t)n * Cin + jch[q]) * HW + p + jshift[q];
+            bf16_t b_[8];
+            if (safe) {
+                load_piece<8, 2>(b_, x + off, 8, true);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b_[e] = (off + e >= 0 && off + e < x_elems) ? x[off + e] : (bf16_t)0.0f;
+            }
+            unsigned bd[4];
+            __builtin_memcpy(bd, b_, 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bd[i] &= ((vmd[i] >> jtap[q]) & 0x00010001u) * 0xffffu;
+            __builtin_memcpy(&bfr[q], bd, 16);
+        }
+#pragma unroll
+        for (int a = 0; a < MTW; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af[a], bfr[b], acc[a][b]);
+        if (++st == spi) {
+            st = 0;
+            ++n;
+        }
+    }
+
+    float* ps = part + (int64_t)s * Cout * Jg;
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mb * (16 * MTW) + a * 16 + lg * 4 + i;
+            if (m >= Mg) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int jj = jb * 64 + b * 16 + i16;
+                if (jj < Jg) ps[((int64_t)grp * Mg + m) * Jg + jj] = acc[a][b][i];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+int64_t conv3x3g_masks_bytes(int H, int W) { return ((int64_t)masks_padded(H * W) * 2 + 255) / 256 * 256; }
+
+int conv3x3g_masks(void* masks, int H, int W, hipStream_t stream) {
+    const int padded = masks_padded(H * W);
+    COT_LAUNCH(conv3x3g_masks_kernel, dim3(ceil_div(padded, 256)), dim3(256), 0, stream, (uint16_t*)masks, H, W,
+               padded);
+    return check_launch("conv3x3g_masks_kernel");
+}
+
+template <int PXV, int AL>
+static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_t* masks, int N, int Cin, int Cout,
+                      int G, int H, int W, hipStream_t stream) {
+    const int Mg = Cout / G, HW = H * W;
+    const int MT = Mg <= 16 ? 1 : (Mg <= 32 ? 2 : 4);
+    const int mblocks = ceil_div(Mg, 16 * MT), ptiles = ceil_div(HW, 16 * PXV);
+    const int64_t waves = (int64_t)N * ptiles * G * mblocks, x_elems = (int64_t)N * Cin * HW;
+    const dim3 grid(wave_grid_blocks(waves)), block(256);
+    const int xcd = g_conv1x1_tune[0];
+#define COT_C3_LAUNCH(MT_)                                                                                            \
+    COT_LAUNCH((conv3x3g_fwd_mfma<PXV, MT_, AL>), grid, block, 0, stream, x, A, y, masks, Cin, Cout, G, H, W, mblocks, \
+               ptiles, waves, x_elems, xcd)
+    if (MT == 1) COT_C3_LAUNCH(1);
+    else if (MT == 2) COT_C3_LAUNCH(2);
+    else COT_C3_LAUNCH(4);
+#undef COT_C3_LAUNCH
+    return check_launch("conv3x3g_fwd_mfma");
+}
+
+// mode 0: y = conv(x, w);  mode 1: x-gradient (x := dY with Cout channels, y := dX with Cin channels)
+// `ws` receives the re-ordered weights (Cout*Cin/G*9 bf16)
+int conv3x3g_gemm(const void* x, const void* w, void* y, const void* masks, void* ws, int N, int Cin, int Cout, int G,
+                  int H, int W, int mode, hipStream_t stream) {
+    const int Kc = Cin / G, Mg = Cout / G, HW = H * W;
+    const int64_t wel = (int64_t)Cout * Kc * 9;
+    COT_LAUNCH(conv3x3g_repack, dim3((unsigned)ceil_div64(wel, 256)), dim3(256), 0, stream, (const bf16_t*)w,
+               (bf16_t*)ws, Cout, Kc, Mg, mode);
+    int rc = check_launch("conv3x3g_repack");
+    if (rc) return rc;
+    const bf16_t* X = (const bf16_t*)x;
+    const bf16_t* A = (const bf16_t*)ws;
+    bf16_t* Y = (bf16_t*)y;
+    const uint16_t* mk = (const uint16_t*)masks;
+    // K side / M side channel counts of the GEMM that is actually run
+    const int ck = mode == 0 ? Cin : Cout, cm = mode == 0 ? Cout : Cin;
+    if (HW % 8 == 0) return launch_fwd<8, 16>(X, A, Y, mk, N, ck, cm, G, H, W, stream);
+    if (HW % 4 == 0) return launch_fwd<4, 8>(X, A, Y, mk, N, ck, cm, G, H, W, stream);
+    return launch_fwd<4, 2>(X, A, Y, mk, N, ck, cm, G, H, W, stream);
+}
+
+int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW) {
+    const int Kc = Cin / G, Mg = Cout / G, Jg = 9 * Kc;
+    const int MTW = Mg <= 16 ? 1 : (Mg <= 32 ? 2 : 4);
+    const int64_t units = (int64_t)G * ceil_div(Mg, 16 * MTW) * ceil_div(Jg, 64);
+    const int64_t T = (int64_t)N * ceil_div(HW, 32);
+    if (g_conv1x1_tune[2] < 0) return (int)(-g_conv1x1_tune[2] < T ? -g_conv1x1_tune[2] : T);  // forced split (tests)
+    int64_t S = ceil_div64(g_conv1x1_tune[2] > 0 ? g_conv1x1_tune[2] : 2048, units);
+    const int64_t in_bytes = (int64_t)N * HW * (Cin + Cout) * 2, out_bytes = (int64_t)Cout * Jg * 4;
+    const int64_t cap = in_bytes / 8 / out_bytes;
+    if (S > cap) S = cap;
+    if (S > T) S = T;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+template <int AL>
+static int launch_wgrad(const bf16_t* gy, const bf16_t* x, float* part, const uint16_t* masks, int N, int Cin,
+                        int Cout, int G, int H, int W, int S, hipStream_t stream) {
+    const int Kc = Cin / G, Mg = Cout / G, Jg = 9 * Kc, HW = H * W;
+    const int MTW = Mg <= 16 ? 1 : (Mg <= 32 ? 2 : 4);
+    const int mblocks = ceil_div(Mg, 16 * MTW), jblocks = ceil_div(Jg, 64), spi = ceil_div(HW, 32);
+    const int64_t waves = (int64_t)S * G * mblocks * jblocks, x_elems = (int64_t)N * Cin * HW;
+    const dim3 grid(wave_grid_blocks(waves)), block(256);
+    const int xcd = g_conv1x1_tune[0];
+#define COT_C3_LAUNCH(MTW_)                                                                                        \
+    COT_LAUNCH((conv3x3g_wgrad_mfma<MTW_, AL>), grid, block, 0, stream, gy, x, part, masks, N, Cin, Cout, G, H, W, \
+               mblocks, jblocks, S, spi, waves, x_elems, xcd)
+    if (MTW == 1) COT_C3_LAUNCH(1);
+    else if (MTW == 2) COT_C3_LAUNCH(2);
+    else COT_C3_LAUNCH(4);
+#undef COT_C3_LAUNCH
+    return check_launch("conv3x3g_wgrad_mfma");
+}
+
+int conv3x3g_wgrad(const void* gy, const void* x, void* gw, const void* masks, float* ws, int N, int Cin, int Cout, int G,
+                   int H, int W, hipStream_t stream) {
+    const int HW = H * W, S = conv3x3g_wgrad_splits(N, Cin, Cout, G, HW);
+    int rc;
+    if (HW % 8 == 0)
+        rc = launch_wgrad<16>((const bf16_t*)gy, (const bf16_t*)x, ws, (const uint16_t*)masks, N, Cin, Cout, G, H, W, S,
+                              stream);
+    else
+        rc = launch_wgrad<2>((const bf16_t*)gy, (const bf16_t*)x, ws, (const uint16_t*)masks, N, Cin, Cout, G, H, W, S,
+                             stream);
+    if (rc) return rc;
+    return conv1x1_wgrad_reduce_launch(ws, S, Cout, 9 * (Cin / G), 0, gw, nullptr, stream);
+}
+
+}  // namespace cot

@@ -112,6 +112,12 @@ int conv1x1_transpose(const void*, void*, int, int, hipStream_t);
 int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_conv1x1_tune[4];
+// implemented in conv3x3g.hip
+int64_t conv3x3g_masks_bytes(int H, int W);
+int conv3x3g_masks(void*, int, int, hipStream_t);
+int conv3x3g_gemm(const void*, const void*, void*, const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW);
+int conv3x3g_wgrad(const void*, const void*, void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
 int set_tuning_nchw(int key, int value);
@@ -285,6 +291,64 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
     if (!gy || !x1 || !gweight || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, x1, x2, gweight, workspace}))) return rc;
     return conv1x1_wgrad(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
+}
+
+static int conv3x3g_validate(int N, int Cin, int Cout, int G, int H, int W, int dtype, int kdim_per_group) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || G <= 0 || H <= 0 || W <= 0)
+        return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d Cin=%d Cout=%d groups=%d H=%d W=%d", N, Cin,
+                         Cout, G, H, W);
+    if (Cin % G != 0 || Cout % G != 0)
+        return set_error(COT_ERR_INVALID_ARG, "channels %d -> %d not divisible by groups %d", Cin, Cout, G);
+    if (dtype != COT_BF16)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_*: only COT_BF16 tensors (dtype %d given)", dtype);
+    if (kdim_per_group % 8 != 0)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_*: %d reduction channels per group, not a multiple of 8",
+                         kdim_per_group);
+    return COT_OK;
+}
+
+int64_t cot_conv3x3g_masks_bytes(int H, int W) { return (H > 0 && W > 0) ? conv3x3g_masks_bytes(H, W) : 0; }
+
+int cot_conv3x3g_masks(void* masks, int H, int W, void* stream) {
+    if (H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive image size %dx%d", H, W);
+    if (!masks) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    int rc = check_align16({masks});
+    if (rc) return rc;
+    return conv3x3g_masks(masks, H, W, (hipStream_t)stream);
+}
+
+int64_t cot_conv3x3g_workspace(int N, int Cin, int Cout, int groups, int H, int W) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || H <= 0 || W <= 0 || Cin % groups || Cout % groups) return 0;
+    const int64_t wb = (int64_t)Cout * (Cin / groups) * 9 * 2;
+    const int64_t part = (int64_t)conv3x3g_wgrad_splits(N, Cin, Cout, groups, H * W) * Cout * (Cin / groups) * 9 * 4;
+    return ((wb > part ? wb : part) + 255) / 256 * 256;
+}
+
+int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void* masks, void* workspace, int N, int Cin,
+                         int Cout, int groups, int H, int W, int dtype, void* stream) {
+    int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, Cin / (groups > 0 ? groups : 1));
+    if (rc) return rc;
+    if (!x || !weight || !y || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x, weight, y, masks, workspace}))) return rc;
+    return conv3x3g_gemm(x, weight, y, masks, workspace, N, Cin, Cout, groups, H, W, 0, (hipStream_t)stream);
+}
+
+int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, const void* masks, void* workspace, int N,
+                               int Cin, int Cout, int groups, int H, int W, int dtype, void* stream) {
+    int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, Cout / (groups > 0 ? groups : 1));
+    if (rc) return rc;
+    if (!gy || !weight || !gx || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gy, weight, gx, masks, workspace}))) return rc;
+    return conv3x3g_gemm(gy, weight, gx, masks, workspace, N, Cin, Cout, groups, H, W, 1, (hipStream_t)stream);
+}
+
+int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
+                                 int Cin, int Cout, int groups, int H, int W, int dtype, void* stream) {
+    int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, 8);
+    if (rc) return rc;
+    if (!gy || !x || !gweight || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gy, x, gweight, masks, workspace}))) return rc;
+    return conv3x3g_wgrad(gy, x, gweight, masks, (float*)workspace, N, Cin, Cout, groups, H, W, (hipStream_t)stream);
 }
 
 int cot_agg_softmax_forward(const void* x, const void* logits, void* out, void* probs, const cot_agg_geom* g, int dtype,

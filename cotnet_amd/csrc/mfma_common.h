@@ -1,0 +1,67 @@
+// mfma_common.h -- pieces shared by the MFMA convolution kernels (conv1x1.hip, conv3x3g.hip): operand types, the one
+// MFMA primitive, wide (possibly unaligned) accesses with a wave-uniform fast path, wave -> work-item mapping.
+//
+// MFMA operand maps used (v_mfma_f32_16x16x32_bf16, D = A*B + C, one wave):
+//       A: lane l holds A[i = l&15][k = 8*(l>>4) .. +7]          (8 bf16, K-contiguous)
+//       B: lane l holds B[k = 8*(l>>4) .. +7][j = l&15]
+//     C/D: lane l holds D[i = 4*(l>>4) + r][j = l&15], r = 0..3
+#pragma once
+#include "cot_common.h"
+
+namespace cot {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#ifndef COT_MFMA_16X16X32_BF16  // (tests/emul pre-defines this primitive for its host build)
+#define COT_MFMA_16X16X32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
+
+template <int V> struct BFVec {
+    typedef __attribute__((ext_vector_type(V))) __bf16 type;
+};
+
+// dst[0..V) = p[0..V) for the first `cnt` elements, zero beyond (cnt may be <= 0 or > V).  `full` is a WAVE-UNIFORM
+// promise that cnt >= V for every lane (scalar branch: the wide access is not entangled with the element-wise tail path)
+template <int V, int AL>
+__device__ __forceinline__ void load_piece(bf16_t (&dst)[V], const bf16_t* p, int cnt, bool full) {
+    if (full) {
+        typename BFVec<V>::type t;  // one wide access; AL = what is known about p's alignment
+        __builtin_memcpy(&t, __builtin_assume_aligned(p, AL), sizeof(t));
+#pragma unroll
+        for (int i = 0; i < V; ++i) dst[i] = t[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) dst[i] = (i < cnt) ? p[i] : (bf16_t)0.0f;
+    }
+}
+template <int V, int AL>
+__device__ __forceinline__ void store_piece(bf16_t* p, const bf16_t (&src)[V], int cnt, bool full) {
+    if (full) {
+        typename BFVec<V>::type t;
+#pragma unroll
+        for (int i = 0; i < V; ++i) t[i] = src[i];
+        __builtin_memcpy(__builtin_assume_aligned(p, AL), &t, sizeof(t));
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            if (i < cnt) p[i] = src[i];
+    }
+}
+// wave-uniform value -> SGPR (so that conditions on it become scalar branches)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ int64_t wave_work_id(int xcd_remap) {
+    unsigned b = blockIdx.x;
+    const unsigned nblk = gridDim.x;
+    if (xcd_remap && (nblk & 7u) == 0) b = (b & 7u) * (nblk >> 3) + (b >> 3);  // consecutive ids -> same XCD
+    return (int64_t)b * (blockDim.x >> 6) + (threadIdx.x >> 6);
+}
+
+// grid size (4 waves per workgroup) rounded up to a multiple of 8 so that the XCD-aware order applies
+__host__ inline int wave_grid_blocks(int64_t waves) {
+    const int64_t b = (waves + 3) / 4;
+    return (int)((b + 7) / 8 * 8);
+}
+
+}  // namespace cot

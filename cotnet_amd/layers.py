@@ -15,6 +15,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .conv3x3g import conv3x3
+
 
 def get_act_layer(name="relu"):
     table = {"relu": nn.ReLU, "swish": nn.SiLU, "silu": nn.SiLU, "sigmoid": nn.Sigmoid, "gelu": nn.GELU}
@@ -183,7 +185,7 @@ class SplitAttnConv2d(nn.Module):
         return self.fc1.out_channels
 
     def forward(self, x):
-        x = self.conv(x)
+        x = conv3x3(self.conv, x)  # the module itself unless COT_CONV3X3=hip and the tensor qualifies
         if self.bn0 is not None:
             x = self.bn0(x)
         if self.drop_block is not None:

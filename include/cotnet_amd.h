@@ -161,6 +161,24 @@ int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, voi
 int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, int c1, void* gweight, void* gbias,
                                 void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream);
 
+/* ---- grouped 3x3 convolution, stride 1, padding 1, NCHW, no layout changes (CotLayer.key_embed[0] =
+ * nn.Conv2d(dim, dim, 3, padding=1, groups=4, bias=False), models/cotnet.py:43-47; groups=8 in CoXtLayer, :112-116).
+ * weight [Cout][Cin/groups][3][3] as torch stores it.  COT_BF16 only (fp32 accumulation); Cin/groups (forward) and
+ * Cout/groups (backward_data) must be multiples of 8, otherwise COT_ERR_UNSUPPORTED (caller keeps nn.Conv2d).
+ *   masks:     per-pixel tap-validity table for an H x W image: cot_conv3x3g_masks_bytes(H, W) bytes, filled once by
+ *              cot_conv3x3g_masks and reusable by every call with the same H, W (read-only afterwards)
+ *   workspace: cot_conv3x3g_workspace(...) bytes (re-ordered weights / partial sums of the weight gradient); the three
+ *              calls may share one buffer when issued on one stream.  backward_weight is deterministic (no atomics). */
+int64_t cot_conv3x3g_masks_bytes(int H, int W);
+int cot_conv3x3g_masks(void* masks, int H, int W, void* stream);
+int64_t cot_conv3x3g_workspace(int N, int Cin, int Cout, int groups, int H, int W);
+int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void* masks, void* workspace, int N, int Cin,
+                         int Cout, int groups, int H, int W, int dtype, void* stream);
+int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, const void* masks, void* workspace, int N,
+                               int Cin, int Cout, int groups, int H, int W, int dtype, void* stream);
+int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
+                                 int Cin, int Cout, int groups, int H, int W, int dtype, void* stream);
+
 /* ---- fused SGD over a flat parameter bucket (replaces torch.optim.SGD(nesterov=True),
  * optim/optim_factory.py:54-56, which launches per parameter tensor):
  *     g = grad*grad_scale + weight_decay*p;  buf = momentum*buf + g;  p -= lr*(nesterov ? g + momentum*buf : buf)

@@ -457,3 +457,91 @@ def test_conv1x1_autograd_wiring_on_emulated_kernels(split, bias, monkeypatch):
         if b is not None:
             assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 2e-2
     c1._WS.clear()
+
+
+@pytest.mark.parametrize("N,C,G,H,W", [
+    (2, 64, 4, 8, 16),     # HW % 8 == 0, Kc = 16 (4.5 K steps), Mg = 16 (MT = 1)
+    (1, 128, 4, 6, 12),    # Kc = Mg = 32 (MT = 2), partial pixel tile
+    (2, 32, 4, 14, 14),    # Kc = 8, HW = 196 (8-byte pieces), rows straddle pieces
+    (3, 64, 8, 7, 7),      # groups = 8 (CoXtLayer), HW = 49
+    (1, 256, 4, 5, 4),     # Kc = Mg = 64 (MT = 4), tiny image: every tap masked somewhere
+    (1, 16, 2, 1, 3),      # one-row image
+])
+@pytest.mark.parametrize("splits", [0, 2])
+def test_conv3x3_grouped_mfma_kernels(N, C, G, H, W, splits):
+    assert _EMUL.cot_set_tuning(11, -splits if splits else 2048) == 0
+    torch.manual_seed(7)
+    x = torch.randn(N, C, H, W).bfloat16()
+    w = (torch.randn(C, C // G, 3, 3) / (9 * C // G) ** 0.5).bfloat16()
+    gy = torch.randn(N, C, H, W).bfloat16()
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    yref = torch.nn.functional.conv2d(xf, wf, None, 1, 1, 1, G)
+    yref.backward(gy.float())
+    dt = _lib.dtype_code(torch.bfloat16)
+    masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert _EMUL.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    ws = torch.empty(_EMUL.cot_conv3x3g_workspace(N, C, C, G, H, W), dtype=torch.uint8)
+    assert ws.numel() > 0 and ws.numel() % 256 == 0
+
+    y = torch.full_like(x, float("nan"))
+    rc = _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(y.float(), yref.detach(), atol=2e-2, rtol=2e-2), (y.float() - yref).abs().max()
+    gx = torch.full_like(x, float("nan"))
+    rc = _EMUL.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), P(masks), P(ws), N, C, C, G, H, W, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(gx.float(), xf.grad, atol=3e-2, rtol=2e-2), (gx.float() - xf.grad).abs().max()
+    gw = torch.full_like(w, float("nan"))
+    rc = _EMUL.cot_conv3x3g_backward_weight(P(gy), P(x), P(gw), P(masks), P(ws), N, C, C, G, H, W, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    scale = wf.grad.abs().max().item()
+    assert (gw.float() - wf.grad).abs().max().item() <= 1e-2 * scale + 1e-2
+    assert _EMUL.cot_set_tuning(11, 2048) == 0
+
+
+def test_conv3x3_grouped_unequal_channels_and_nan_neighbours():
+    """Cin != Cout; and the last channel of group 0 is all NaN.  Group 1 never depends on it, but its shifted wide loads
+    for the taps above / left of the image run across that channel's rows in memory: the masked taps must be removed by
+    selection, not by multiplying with zero."""
+    torch.manual_seed(8)
+    N, Cin, Cout, G, H, W = 2, 32, 64, 2, 4, 8
+    Kc, Mg = Cin // G, Cout // G
+    x = torch.randn(N, Cin, H, W).bfloat16()
+    x[:, Kc - 1] = float("nan")
+    w = (torch.randn(Cout, Kc, 3, 3) / 12).bfloat16()
+    yref = torch.nn.functional.conv2d(x[:, Kc:].float(), w[Mg:].float(), None, 1, 1)   # group 1 alone
+    dt = _lib.dtype_code(torch.bfloat16)
+    masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert _EMUL.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    ws = torch.empty(_EMUL.cot_conv3x3g_workspace(N, Cin, Cout, G, H, W), dtype=torch.uint8)
+    y = torch.empty(N, Cout, H, W).bfloat16()
+    assert _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, Cin, Cout, G, H, W, dt, None) == 0
+    assert torch.isnan(y[:, :Mg].float()).all()          # group 0 really reads the NaN channel
+    assert torch.allclose(y[:, Mg:].float(), yref, atol=2e-2, rtol=2e-2)
+
+
+def test_conv3x3_autograd_wiring_on_emulated_kernels(monkeypatch):
+    from torch import nn
+    from cotnet_amd import conv3x3g as c3
+    monkeypatch.setattr(c3, "MODE", "hip")
+    monkeypatch.setattr(c3, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    c3._WS.clear()
+    c3._MASKS.clear()
+    torch.manual_seed(3)
+    conv = nn.Conv2d(32, 32, 3, padding=1, groups=4, bias=False).bfloat16()
+    x = torch.randn(2, 32, 6, 5).bfloat16().requires_grad_(True)
+    g = torch.randn(2, 32, 6, 5).bfloat16()
+    assert c3.eligible(conv, x)
+    assert not c3.eligible(nn.Conv2d(32, 32, 3, padding=1, groups=8, bias=False).bfloat16(), x)   # 4 channels per group
+    assert not c3.eligible(nn.Conv2d(32, 32, 3, stride=2, padding=1, bias=False).bfloat16(), x)
+    y = c3.conv3x3(conv, x)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    wr = conv.weight.detach().float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, 1, 1, 1, 4)
+    yr.backward(g.float())
+    for a, b in ((y, yr), (x.grad, xr.grad), (conv.weight.grad, wr.grad)):
+        assert (a.float() - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 2e-2
+    c3._WS.clear()
+    c3._MASKS.clear()

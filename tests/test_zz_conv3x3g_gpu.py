@@ -1,0 +1,100 @@
+"""The grouped 3x3 MFMA convolution kernels (csrc/conv3x3g.hip behind cot_conv3x3g_*, opt-in COT_CONV3X3=hip) on the GPU
+against torch's convolution evaluated in fp32 on the same bf16-rounded operands.  (Sorts last: newest code.)"""
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from cotnet_amd import conv3x3g as c3
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(a, b, rel):
+    return ((a.float() - b).abs() <= rel * (b.abs() + b.abs().mean())).all()
+
+
+# (N, C, groups, H): CotLayer.key_embed at the four CoTNet-50 stages (models/cotnet.py:43-47), CoXtLayer's groups=8
+# (:112-116), the ungrouped SplitAttn 3x3 of SE-CoTNetD, and shapes where nothing is aligned
+CASES = [(4, 64, 4, 56), (4, 128, 4, 28), (3, 256, 4, 14), (3, 512, 4, 7), (2, 192, 8, 28), (2, 64, 1, 40),
+         (2, 32, 4, 9), (1, 16, 2, 3), (1, 8, 1, 1)]
+
+
+@pytest.mark.parametrize("N,C,G,H", CASES)
+def test_matches_torch_convolution(N, C, G, H, monkeypatch):
+    monkeypatch.setattr(c3, "MODE", "hip")
+    torch.manual_seed(C + H)
+    conv = nn.Conv2d(C, C, 3, padding=1, groups=G, bias=False).to(DEV).bfloat16()
+    x = torch.randn(N, C, H, H, device=DEV).bfloat16().requires_grad_(True)
+    gy = torch.randn(N, C, H, H, device=DEV).bfloat16()
+    assert c3.eligible(conv, x)
+    y = c3.conv3x3(conv, x)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    xr = x.detach().float().requires_grad_(True)
+    wr = conv.weight.detach().float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1, 1, G)
+    yr.backward(gy.float())
+    assert _close(y, yr.detach(), 1e-2)
+    assert _close(x.grad, xr.grad, 1e-2)
+    assert _close(conv.weight.grad, wr.grad, 1e-2)
+
+
+def test_first_and_last_waves_do_not_read_outside_the_tensor(monkeypatch):
+    """x is a view placed at the very start / end of its allocation neighbours: NaN-filled guard tensors allocated right
+    before and after must not leak into the result (the first / last waves take the bounds-checked path)"""
+    monkeypatch.setattr(c3, "MODE", "hip")
+    torch.manual_seed(0)
+    N, C, G, H = 2, 32, 4, 12
+    buf = torch.full((3, N, C, H, H), float("nan"), device=DEV).bfloat16()
+    buf[1] = torch.randn(N, C, H, H, device=DEV).bfloat16()
+    x = buf[1]
+    conv = nn.Conv2d(C, C, 3, padding=1, groups=G, bias=False).to(DEV).bfloat16()
+    y = c3.conv3x3(conv, x)
+    yr = F.conv2d(x.float(), conv.weight.float(), None, 1, 1, 1, G)
+    assert not torch.isnan(y.float()).any()
+    assert _close(y, yr, 1e-2)
+
+
+def test_weight_gradient_is_deterministic(monkeypatch):
+    monkeypatch.setattr(c3, "MODE", "hip")
+    torch.manual_seed(0)
+    conv = nn.Conv2d(64, 64, 3, padding=1, groups=4, bias=False).to(DEV).bfloat16()
+    x = torch.randn(16, 64, 56, 56, device=DEV).bfloat16()
+    gy = torch.randn(16, 64, 56, 56, device=DEV).bfloat16()
+    grads = []
+    for _ in range(3):
+        conv.weight.grad = None
+        c3.conv3x3(conv, x).backward(gy)
+        grads.append(conv.weight.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+def test_cot_layer_with_all_hip_convolutions(monkeypatch):
+    """CotLayer forward+backward with every convolution on the hand-written kernels against the default path"""
+    import copy
+    from cotnet_amd import conv1x1 as c1
+    from cotnet_amd.cotnet import CotLayer
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    torch.manual_seed(1)
+    la = to_mixed_bf16(CotLayer(64, 3).to(DEV)).train()
+    lb = copy.deepcopy(la)
+    x = torch.randn(4, 64, 28, 28, device=DEV).bfloat16()
+    gy = torch.randn(4, 64, 28, 28, device=DEV).bfloat16()
+
+    def run(layer, mode):
+        monkeypatch.setattr(c1, "MODE", mode)
+        monkeypatch.setattr(c3, "MODE", mode)
+        xa = x.clone().requires_grad_(True)
+        y = layer(xa)
+        y.backward(gy)
+        return y.detach().float(), xa.grad.float(), {n: p.grad.float() for n, p in layer.named_parameters()}
+
+    ya, gxa, ga = run(la, "hip")
+    yb, gxb, gb = run(lb, "")
+    assert (ya - yb).abs().mean() <= 0.02 * yb.abs().mean() + 1e-3
+    assert (gxa - gxb).abs().mean() <= 0.04 * gxb.abs().mean() + 1e-3
+    scale = max(g.abs().mean().item() for g in gb.values())
+    for n in ga:
+        assert (ga[n] - gb[n]).abs().mean() <= 0.06 * gb[n].abs().mean() + 3e-3 * scale, n
