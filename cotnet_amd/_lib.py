@@ -55,13 +55,13 @@ SYMBOLS = {
                           _I, _I, _I, _P]),
     "cot_conv1x1_workspace": (ctypes.c_int64, [_I, _I, _I, _I, _I]),
     "cot_conv1x1_forward": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "cot_conv1x1_backward_data": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "cot_conv1x1_backward_data": (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "cot_conv1x1_backward_weight": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cot_conv3x3g_masks_bytes": (ctypes.c_int64, [_I, _I]),
     "cot_conv3x3g_masks": (_I, [_P, _I, _I, _P]),
     "cot_conv3x3g_workspace": (ctypes.c_int64, [_I] * 6),
     "cot_conv3x3g_forward": (_I, [_P] * 5 + [_I] * 7 + [_P]),
-    "cot_conv3x3g_backward_data": (_I, [_P] * 5 + [_I] * 7 + [_P]),
+    "cot_conv3x3g_backward_data": (_I, [_P] * 3 + [_I] + [_P] * 2 + [_I] * 7 + [_P]),
     "cot_conv3x3g_backward_weight": (_I, [_P] * 5 + [_I] * 7 + [_P]),
     "cot_bn_act_workspace": (_I, [_I, _I]),
     "cot_bn_act_forward": (_I, [_P] * 11 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),

@@ -107,7 +107,7 @@ class _Conv1x1Hip(Function):
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             gx1 = torch.empty_like(x1)
             gx2 = torch.empty_like(x2) if x2 is not None else None
-            rc = L.cot_conv1x1_backward_data(_p(gy), _p(weight), _p(gx1), _p(gx2), c1, _p(ws), N, Ci, Co, HW,
+            rc = L.cot_conv1x1_backward_data(_p(gy), _p(weight), _p(gx1), _p(gx2), c1, 0, _p(ws), N, Ci, Co, HW,
                                              _lib.COT_BF16, _stream())
             if rc:
                 _lib.check(rc, "cot_conv1x1_backward_data")

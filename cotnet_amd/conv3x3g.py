@@ -78,7 +78,7 @@ class _Conv3x3G(Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            rc = L.cot_conv3x3g_backward_data(_p(gy), _p(weight), _p(gx), _p(masks), _p(ws), N, Cin, Cout, G, H, W,
+            rc = L.cot_conv3x3g_backward_data(_p(gy), _p(weight), _p(gx), 0, _p(masks), _p(ws), N, Cin, Cout, G, H, W,
                                               _lib.COT_BF16, _stream())
             if rc:
                 _lib.check(rc, "cot_conv3x3g_backward_data")

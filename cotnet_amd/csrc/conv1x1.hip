@@ -42,7 +42,7 @@ template <int PXV, int MT, int AL>
 __global__ void __launch_bounds__(256, 2)
 conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, int k1, const bf16_t* __restrict__ A,
                  const bf16_t* __restrict__ bias, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2, int m1, int K,
-                 int M, int HW, int mblocks, int ptiles, int64_t total_waves, int xcd_remap) {
+                 int M, int HW, int mblocks, int ptiles, int64_t total_waves, int xcd_remap, int accumulate) {
     const int64_t wid = wave_work_id(xcd_remap);
     if (wid >= total_waves) return;
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -101,10 +101,17 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
             const int m = mbase + mt * 16 + g * 4 + i;
             if (m < M) {
                 const float b = bias ? (float)bias[m] : 0.f;
+                bf16_t* dst = row_ptr(y1, y2, m1, M, n, m, HW) + p0;
                 bf16_t o[PXV];
+                if ((accumulate >> (m < m1 ? 0 : 1)) & 1) {  // y += result (bit 0: first slab, bit 1: second slab)
+                    load_piece<PXV, AL>(o, dst, cnt, full_px);
 #pragma unroll
-                for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b);
-                store_piece<PXV, AL>(row_ptr(y1, y2, m1, M, n, m, HW) + p0, o, cnt, full_px);
+                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b + (float)o[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b);
+                }
+                store_piece<PXV, AL>(dst, o, cnt, full_px);
             }
         }
 }
@@ -237,7 +244,7 @@ int g_conv1x1_tune[4] = {1, 0, 2048, 0};
 
 template <int PXV, int AL>
 static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_t* A, const bf16_t* bias, bf16_t* y1,
-                         bf16_t* y2, int m1, int N, int K, int M, int HW, hipStream_t stream) {
+                         bf16_t* y2, int m1, int N, int K, int M, int HW, int accumulate, hipStream_t stream) {
     int MT = g_conv1x1_tune[1] ? g_conv1x1_tune[1] : (M <= 32 ? 2 : 4);
     if (MT != 2) MT = 4;
     const int mblocks = ceil_div(M, 16 * MT), ptiles = ceil_div(HW, 16 * PXV);
@@ -246,21 +253,21 @@ static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_
     const int xcd = g_conv1x1_tune[0];
     if (MT == 2)
         COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, K, M, HW,
-                   mblocks, ptiles, waves, xcd);
+                   mblocks, ptiles, waves, xcd, accumulate);
     else
         COT_LAUNCH((conv1x1_fwd_mfma<PXV, 4, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, K, M, HW,
-                   mblocks, ptiles, waves, xcd);
+                   mblocks, ptiles, waves, xcd, accumulate);
     return check_launch("conv1x1_fwd_mfma");
 }
 
 // x = [x1 | x2] along channels (x2 may be NULL, then k1 == K); y = [y1 | y2] likewise (m1 == M when y2 == NULL)
 int conv1x1_gemm(const void* x1, const void* x2, int k1, const void* A, const void* bias, void* y1, void* y2, int m1,
-                 int N, int K, int M, int HW, hipStream_t stream) {
+                 int N, int K, int M, int HW, int accumulate, hipStream_t stream) {
     const bf16_t *X1 = (const bf16_t*)x1, *X2 = (const bf16_t*)x2, *a = (const bf16_t*)A, *b = (const bf16_t*)bias;
     bf16_t *Y1 = (bf16_t*)y1, *Y2 = (bf16_t*)y2;
-    if (HW % 8 == 0) return launch_fwd_mt<8, 16>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, stream);
-    if (HW % 4 == 0) return launch_fwd_mt<4, 8>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, stream);
-    return launch_fwd_mt<4, 2>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, stream);
+    if (HW % 8 == 0) return launch_fwd_mt<8, 16>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, accumulate, stream);
+    if (HW % 4 == 0) return launch_fwd_mt<4, 8>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, accumulate, stream);
+    return launch_fwd_mt<4, 2>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, accumulate, stream);
 }
 
 int conv1x1_transpose(const void* w, void* wt, int M, int K, hipStream_t stream) {

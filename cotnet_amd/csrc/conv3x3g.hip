@@ -64,7 +64,7 @@ template <int PXV, int MT, int AL>
 __global__ void __launch_bounds__(256, 2)
 conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf16_t* __restrict__ y,
                   const uint16_t* __restrict__ masks, int Cin, int Cout, int G, int H, int W, int mblocks, int ptiles,
-                  int64_t total_waves, int64_t x_elems, int xcd_remap) {
+                  int64_t total_waves, int64_t x_elems, int xcd_remap, int accumulate) {
     const int64_t wid = wave_work_id(xcd_remap);
     if (wid >= total_waves) return;
     const int lane = threadIdx.x & 63, j = lane & 15, lg = lane >> 4;
@@ -141,10 +141,17 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf
         for (int i = 0; i < 4; ++i) {
             const int m = mbase + mt * 16 + lg * 4 + i;
             if (m < Mg) {
+                bf16_t* dst = y + ((int64_t)n * Cout + (int64_t)grp * Mg + m) * HW + p0;
                 bf16_t o[PXV];
+                if (accumulate) {  // y += result
+                    load_piece<PXV, AL>(o, dst, cnt, full_px);
 #pragma unroll
-                for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)acc[mt][c][i];
-                store_piece<PXV, AL>(y + ((int64_t)n * Cout + (int64_t)grp * Mg + m) * HW + p0, o, cnt, full_px);
+                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + (float)o[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)acc[mt][c][i];
+                }
+                store_piece<PXV, AL>(dst, o, cnt, full_px);
             }
         }
 }
@@ -262,7 +269,7 @@ int conv3x3g_masks(void* masks, int H, int W, hipStream_t stream) {
 
 template <int PXV, int AL>
 static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_t* masks, int N, int Cin, int Cout,
-                      int G, int H, int W, hipStream_t stream) {
+                      int G, int H, int W, int accumulate, hipStream_t stream) {
     const int Mg = Cout / G, HW = H * W;
     const int MT = Mg <= 16 ? 1 : (Mg <= 32 ? 2 : 4);
     const int mblocks = ceil_div(Mg, 16 * MT), ptiles = ceil_div(HW, 16 * PXV);
@@ -271,7 +278,7 @@ static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_
     const int xcd = g_conv1x1_tune[0];
 #define COT_C3_LAUNCH(MT_)                                                                                            \
     COT_LAUNCH((conv3x3g_fwd_mfma<PXV, MT_, AL>), grid, block, 0, stream, x, A, y, masks, Cin, Cout, G, H, W, mblocks, \
-               ptiles, waves, x_elems, xcd)
+               ptiles, waves, x_elems, xcd, accumulate)
     if (MT == 1) COT_C3_LAUNCH(1);
     else if (MT == 2) COT_C3_LAUNCH(2);
     else COT_C3_LAUNCH(4);
@@ -282,7 +289,7 @@ static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_
 // mode 0: y = conv(x, w);  mode 1: x-gradient (x := dY with Cout channels, y := dX with Cin channels)
 // `ws` receives the re-ordered weights (Cout*Cin/G*9 bf16)
 int conv3x3g_gemm(const void* x, const void* w, void* y, const void* masks, void* ws, int N, int Cin, int Cout, int G,
-                  int H, int W, int mode, hipStream_t stream) {
+                  int H, int W, int mode, int accumulate, hipStream_t stream) {
     const int Kc = Cin / G, Mg = Cout / G, HW = H * W;
     const int64_t wel = (int64_t)Cout * Kc * 9;
     COT_LAUNCH(conv3x3g_repack, dim3((unsigned)ceil_div64(wel, 256)), dim3(256), 0, stream, (const bf16_t*)w,
@@ -295,9 +302,9 @@ int conv3x3g_gemm(const void* x, const void* w, void* y, const void* masks, void
     const uint16_t* mk = (const uint16_t*)masks;
     // K side / M side channel counts of the GEMM that is actually run
     const int ck = mode == 0 ? Cin : Cout, cm = mode == 0 ? Cout : Cin;
-    if (HW % 8 == 0) return launch_fwd<8, 16>(X, A, Y, mk, N, ck, cm, G, H, W, stream);
-    if (HW % 4 == 0) return launch_fwd<4, 8>(X, A, Y, mk, N, ck, cm, G, H, W, stream);
-    return launch_fwd<4, 2>(X, A, Y, mk, N, ck, cm, G, H, W, stream);
+    if (HW % 8 == 0) return launch_fwd<8, 16>(X, A, Y, mk, N, ck, cm, G, H, W, accumulate, stream);
+    if (HW % 4 == 0) return launch_fwd<4, 8>(X, A, Y, mk, N, ck, cm, G, H, W, accumulate, stream);
+    return launch_fwd<4, 2>(X, A, Y, mk, N, ck, cm, G, H, W, accumulate, stream);
 }
 
 int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW) {

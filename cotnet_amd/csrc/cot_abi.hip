@@ -106,7 +106,7 @@ template <typename T> int radix_mix(const void*, const void*, const void*, void*
 template <typename T>
 int radix_mix_bwd(const void*, const void*, const void*, const void*, void*, void*, void*, int64_t, int, hipStream_t);
 // implemented in conv1x1.hip
-int conv1x1_gemm(const void*, const void*, int, const void*, const void*, void*, void*, int, int, int, int, int,
+int conv1x1_gemm(const void*, const void*, int, const void*, const void*, void*, void*, int, int, int, int, int, int,
                  hipStream_t);
 int conv1x1_transpose(const void*, void*, int, int, hipStream_t);
 int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
@@ -115,7 +115,8 @@ extern int g_conv1x1_tune[4];
 // implemented in conv3x3g.hip
 int64_t conv3x3g_masks_bytes(int H, int W);
 int conv3x3g_masks(void*, int, int, hipStream_t);
-int conv3x3g_gemm(const void*, const void*, void*, const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int conv3x3g_gemm(const void*, const void*, void*, const void*, void*, int, int, int, int, int, int, int, int,
+                  hipStream_t);
 int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW);
 int conv3x3g_wgrad(const void*, const void*, void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 const char* last_kernel_nchw();
@@ -270,18 +271,19 @@ int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weig
     if (rc) return rc;
     if (!x1 || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x1, x2, weight, y}))) return rc;
-    return conv1x1_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, (hipStream_t)stream);
+    return conv1x1_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, 0, (hipStream_t)stream);
 }
 
-int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, void* workspace, int N,
-                              int Ci, int Co, int HW, int dtype, void* stream) {
+int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, int accumulate,
+                              void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream) {
     int rc = conv1x1_validate(N, Ci, Co, HW, c1, gx2 != nullptr, dtype, Co);
     if (rc) return rc;
     if (!gy || !weight || !gx1 || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx1, gx2, workspace}))) return rc;
     // A = weight^T [Ci][Co] (row-major, K = Co contiguous): one tiny transpose, then the forward kernel on dY
     if ((rc = conv1x1_transpose(weight, workspace, Co, Ci, (hipStream_t)stream))) return rc;
-    return conv1x1_gemm(gy, nullptr, Co, workspace, nullptr, gx1, gx2, c1, N, Co, Ci, HW, (hipStream_t)stream);
+    return conv1x1_gemm(gy, nullptr, Co, workspace, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3,
+                        (hipStream_t)stream);
 }
 
 int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, int c1, void* gweight, void* gbias,
@@ -330,16 +332,18 @@ int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void*
     if (rc) return rc;
     if (!x || !weight || !y || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x, weight, y, masks, workspace}))) return rc;
-    return conv3x3g_gemm(x, weight, y, masks, workspace, N, Cin, Cout, groups, H, W, 0, (hipStream_t)stream);
+    return conv3x3g_gemm(x, weight, y, masks, workspace, N, Cin, Cout, groups, H, W, 0, 0, (hipStream_t)stream);
 }
 
-int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, const void* masks, void* workspace, int N,
-                               int Cin, int Cout, int groups, int H, int W, int dtype, void* stream) {
+int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int accumulate, const void* masks,
+                               void* workspace, int N, int Cin, int Cout, int groups, int H, int W, int dtype,
+                               void* stream) {
     int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, Cout / (groups > 0 ? groups : 1));
     if (rc) return rc;
     if (!gy || !weight || !gx || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx, masks, workspace}))) return rc;
-    return conv3x3g_gemm(gy, weight, gx, masks, workspace, N, Cin, Cout, groups, H, W, 1, (hipStream_t)stream);
+    return conv3x3g_gemm(gy, weight, gx, masks, workspace, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0,
+                         (hipStream_t)stream);
 }
 
 int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,

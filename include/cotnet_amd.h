@@ -149,15 +149,17 @@ int cot_radix_mix_backward(const void* gout, const void* y, const void* k, const
  *     y[n][co][p] = sum_ci weight[co][ci] * x[n][ci][p] + bias[co]         weight [Co][Ci] row-major, bias NULL or [Co]
  * x may be given as TWO channel slabs that the reference concatenates first (`torch.cat([x, k], dim=1)`,
  * models/cotnet.py:81): x1 = [N][c1][HW], x2 = [N][Ci-c1][HW]; x2 == NULL means one tensor and c1 must equal Ci.
- * backward_data writes the gradient of that concatenation to gx1 / gx2 the same way.
+ * backward_data writes the gradient of that concatenation to gx1 / gx2 the same way; `accumulate` bit 0 / bit 1 make it
+ * ADD to the existing contents of gx1 / gx2 instead (a tensor with several consumers collects its gradient without
+ * separate add kernels; the sum is formed in fp32 and rounded once).
  * backward_weight: gweight [Co][Ci], gbias [Co] or NULL; deterministic (partial sums in `workspace`, no atomics).
  * workspace: cot_conv1x1_workspace(...) BYTES (256-byte multiple), needed by the two backward calls only; they may
  * share one buffer when issued on one stream. */
 int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias);
 int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, int N,
                         int Ci, int Co, int HW, int dtype, void* stream);
-int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, void* workspace, int N,
-                              int Ci, int Co, int HW, int dtype, void* stream);
+int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, int accumulate,
+                              void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream);
 int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, int c1, void* gweight, void* gbias,
                                 void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream);
 
@@ -168,14 +170,16 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
  *   masks:     per-pixel tap-validity table for an H x W image: cot_conv3x3g_masks_bytes(H, W) bytes, filled once by
  *              cot_conv3x3g_masks and reusable by every call with the same H, W (read-only afterwards)
  *   workspace: cot_conv3x3g_workspace(...) bytes (re-ordered weights / partial sums of the weight gradient); the three
- *              calls may share one buffer when issued on one stream.  backward_weight is deterministic (no atomics). */
+ *              calls may share one buffer when issued on one stream.  backward_weight is deterministic (no atomics).
+ *   accumulate (backward_data): nonzero = gx += result instead of gx = result. */
 int64_t cot_conv3x3g_masks_bytes(int H, int W);
 int cot_conv3x3g_masks(void* masks, int H, int W, void* stream);
 int64_t cot_conv3x3g_workspace(int N, int Cin, int Cout, int groups, int H, int W);
 int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void* masks, void* workspace, int N, int Cin,
                          int Cout, int groups, int H, int W, int dtype, void* stream);
-int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, const void* masks, void* workspace, int N,
-                               int Cin, int Cout, int groups, int H, int W, int dtype, void* stream);
+int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int accumulate, const void* masks,
+                               void* workspace, int N, int Cin, int Cout, int groups, int H, int W, int dtype,
+                               void* stream);
 int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
                                  int Cin, int Cout, int groups, int H, int W, int dtype, void* stream);
 

@@ -398,7 +398,7 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
     if Co % 8 == 0:
         gx1 = torch.full_like(x1, float("nan"))
         gx2 = torch.full_like(x2, float("nan")) if split else None
-        rc = _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx1), PN(gx2), cc1, P(ws), N, Ci, Co, HW, dt, None)
+        rc = _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx1), PN(gx2), cc1, 0, P(ws), N, Ci, Co, HW, dt, None)
         assert rc == 0, _EMUL.cot_last_error()
         gx = torch.cat([gx1, gx2], 1) if split else gx1
         assert torch.allclose(gx.float(), xf.grad, atol=3e-2, rtol=2e-2), (gx.float() - xf.grad).abs().max()
@@ -488,7 +488,7 @@ def test_conv3x3_grouped_mfma_kernels(N, C, G, H, W, splits):
     assert rc == 0, _EMUL.cot_last_error()
     assert torch.allclose(y.float(), yref.detach(), atol=2e-2, rtol=2e-2), (y.float() - yref).abs().max()
     gx = torch.full_like(x, float("nan"))
-    rc = _EMUL.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), P(masks), P(ws), N, C, C, G, H, W, dt, None)
+    rc = _EMUL.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), 0, P(masks), P(ws), N, C, C, G, H, W, dt, None)
     assert rc == 0, _EMUL.cot_last_error()
     assert torch.allclose(gx.float(), xf.grad, atol=3e-2, rtol=2e-2), (gx.float() - xf.grad).abs().max()
     gw = torch.full_like(w, float("nan"))
@@ -545,3 +545,34 @@ def test_conv3x3_autograd_wiring_on_emulated_kernels(monkeypatch):
         assert (a.float() - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 2e-2
     c3._WS.clear()
     c3._MASKS.clear()
+
+
+def test_data_gradients_can_accumulate_into_their_outputs():
+    """`accumulate` of cot_conv1x1_backward_data / cot_conv3x3g_backward_data: gx += result, per slab"""
+    torch.manual_seed(11)
+    dt = _lib.dtype_code(torch.bfloat16)
+    N, Ci, Co, H, W, c1 = 2, 32, 24, 6, 6, 16
+    w = (torch.randn(Co, Ci) / 6).bfloat16()
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    ws = torch.empty(_EMUL.cot_conv1x1_workspace(N, Ci, Co, H * W, 0), dtype=torch.uint8)
+    fresh1, fresh2 = torch.empty(N, c1, H, W).bfloat16(), torch.empty(N, Ci - c1, H, W).bfloat16()
+    assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(fresh1), P(fresh2), c1, 0, P(ws), N, Ci, Co, H * W, dt, None) == 0
+    for acc in (1, 2, 3):
+        base1, base2 = torch.randn_like(fresh1), torch.randn_like(fresh2)
+        g1, g2 = base1.clone(), base2.clone()
+        assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(g1), P(g2), c1, acc, P(ws), N, Ci, Co, H * W, dt, None) == 0
+        want1 = fresh1.float() + base1.float() if acc & 1 else fresh1.float()
+        want2 = fresh2.float() + base2.float() if acc & 2 else fresh2.float()
+        assert torch.allclose(g1.float(), want1, atol=3e-2, rtol=2e-2) and torch.allclose(g2.float(), want2, atol=3e-2, rtol=2e-2)
+    C, G = 32, 4
+    w3 = (torch.randn(C, C // G, 3, 3) / 8).bfloat16()
+    gy3 = torch.randn(N, C, H, W).bfloat16()
+    masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert _EMUL.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    ws3 = torch.empty(_EMUL.cot_conv3x3g_workspace(N, C, C, G, H, W), dtype=torch.uint8)
+    fresh = torch.empty(N, C, H, W).bfloat16()
+    assert _EMUL.cot_conv3x3g_backward_data(P(gy3), P(w3), P(fresh), 0, P(masks), P(ws3), N, C, C, G, H, W, dt, None) == 0
+    base = torch.randn_like(fresh)
+    g = base.clone()
+    assert _EMUL.cot_conv3x3g_backward_data(P(gy3), P(w3), P(g), 1, P(masks), P(ws3), N, C, C, G, H, W, dt, None) == 0
+    assert torch.allclose(g.float(), fresh.float() + base.float(), atol=3e-2, rtol=2e-2)
