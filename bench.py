@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--conv1x1", default=None, choices=["module", "hip", "matmul"],
                     help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
+    ap.add_argument("--fused-layer", action="store_true",
+                    help="CotLayer as one autograd node (cotnet_amd/cot_layer_fused.py); implies --conv1x1 hip --conv3x3 hip")
     ap.add_argument("--conv3x3", default=None, choices=["module", "hip"],
                     help="grouped 3x3 key-embed convolution (cotnet_amd/conv3x3g.py); default: COT_CONV3X3 or the module")
     return ap.parse_args()
@@ -133,6 +135,11 @@ def roctx_window(resume):
 
 def main():
     args = parse()
+    if args.fused_layer:
+        from cotnet_amd import cot_layer_fused as _clf
+        _clf.ENABLED = True
+        args.conv1x1 = args.conv1x1 or "hip"
+        args.conv3x3 = args.conv3x3 or "hip"
     if args.conv1x1 is not None:
         from cotnet_amd import conv1x1 as _c1
         _c1.MODE = "" if args.conv1x1 == "module" else args.conv1x1
@@ -302,6 +309,7 @@ def main():
                        "hip_graph": graphed,
                        "conv1x1": __import__("cotnet_amd.conv1x1", fromlist=["MODE"]).MODE or "module",
                        "conv3x3": __import__("cotnet_amd.conv3x3g", fromlist=["MODE"]).MODE or "module",
+                       "cot_layer_single_node": __import__("cotnet_amd.cot_layer_fused", fromlist=["ENABLED"]).ENABLED,
                        "grad_sync": "RCCL all-reduce (AVG), flat buckets, side stream" if world > 1 else "none (1 GPU)"},
             "final_loss": round(final_loss, 4),
             "roofline": roofline,

@@ -51,6 +51,10 @@ SYMBOLS = {
     "cot_radix_gap": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _P]),
     "cot_radix_mix": (_I, [_P, _P, _P, _P, ctypes.c_int64, _I, _I, _P]),
     "cot_radix_mix_backward": (_I, [_P] * 7 + [ctypes.c_int64, _I, _I, _P]),
+    "cot_radix_gap_t": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "cot_radix_mix_logits": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
+    "cot_radix_mix_backward_reduce": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
+    "cot_radix_mix_backward_apply": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
     "cot_sgd_step": (_I, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                           _I, _I, _I, _P]),
     "cot_conv1x1_workspace": (ctypes.c_int64, [_I, _I, _I, _I, _I]),

@@ -1,0 +1,302 @@
+"""CotLayer.forward as ONE autograd node (opt-in: COT_FUSED_LAYER=1).
+
+Why: at the reference's batch (80 / GPU) the CoTNet-50 step on MI355X is bound by the host, not the device (round-1
+profile: ~3100 launches, ~38 ms of Python/dispatch per step against 36 ms of kernels).  One CotLayer is ~14 autograd
+nodes forward and as many backward, plus the engine's gradient-accumulation adds wherever a tensor has several consumers
+(x feeds key_embed, embed and conv1x1: two adds of C*H*W; k feeds embed and the radix tail: one more).  This module
+evaluates the same function (models/cotnet.py:79-104) by calling the library's kernels back to back through the C ABI:
+
+    forward   conv3x3g -> bn+relu -> conv1x1 on [x | k] (no cat) -> bn+relu -> conv1x1(+bias) -> GroupNorm (aten)
+              -> conv1x1 -> bn -> aggregation -> bn+silu -> radix gap (channel-major) -> se branch as two 1x1
+              convolutions over the batch axis with its BatchNorm+ReLU between them -> pair softmax + radix mix
+    backward  the mirror image; the three contributions to dx and the two to dk are summed inside the data-gradient
+              kernels (`accumulate`), not by separate add kernels.
+
+Same parameters, buffers (running statistics, num_batches_tracked) and state_dict as the module it is applied to;
+eligible in training mode for bf16 NCHW tensors with dim % 64 == 0 (every CoTNet stage); anything else takes the
+module's ordinary forward.  Verified against the unfused reference formula through the host-emulated kernels
+(tests/test_kernels_emulated.py) and on the GPU by tests/test_zz_fused_layer_gpu.py; not yet timed on hardware.
+"""
+import ctypes
+import os
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import _lib
+
+ENABLED = os.environ.get("COT_FUSED_LAYER", "") == "1"
+_DEVICE_ONLY = True  # tests drive the node on CPU tensors through the host-emulated kernels
+BF16 = _lib.COT_BF16
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if _DEVICE_ONLY else None
+
+
+def _ck(rc, what):
+    if rc:
+        _lib.check(rc, what)
+
+
+_SIZES = {}  # (N, C, H, W, A) -> (workspace bytes, bn workspace floats for C, C/2 and the se branch's A channels)
+_MASKS = {}
+
+
+def _sizes(L, N, C, H, W, A, G):
+    k = (N, C, H, W, A, G)
+    v = _SIZES.get(k)
+    if v is None:
+        HW = H * W
+        ws = max(int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_conv1x1_workspace(N, 2 * C, C // 2, HW, 0)),
+                 int(L.cot_conv1x1_workspace(N, C // 2, 9 * C // 8, HW, 1)), int(L.cot_conv1x1_workspace(N, C, C, HW, 0)),
+                 int(L.cot_conv1x1_workspace(1, C, A, N, 1)), int(L.cot_conv1x1_workspace(1, A, 2 * C, N, 1)))
+        v = _SIZES[k] = (ws, int(L.cot_bn_act_workspace(N, C)), int(L.cot_bn_act_workspace(N, C // 2)),
+                         int(L.cot_bn_act_workspace(1, A)))
+    return v
+
+
+def _masks(L, H, W, device):
+    k = (H, W, str(device))
+    m = _MASKS.get(k)
+    if m is None:
+        m = torch.empty(int(L.cot_conv3x3g_masks_bytes(H, W)), dtype=torch.uint8, device=device)
+        _ck(L.cot_conv3x3g_masks(_p(m), H, W, _stream()), "cot_conv3x3g_masks")
+        _MASKS[k] = m
+    return m
+
+
+class _Plan:
+    """per-layer handles resolved once (nn.Sequential indexing and parameter walks cost more than a kernel launch)"""
+    __slots__ = ("ke0", "ke1", "em0", "em1", "em3", "gn", "cv0", "cv1", "bn", "se0", "sebn", "se3", "params",
+                 "static_ok")
+
+    def __init__(self, layer):
+        ke, em, cv = layer.key_embed, layer.embed, layer.conv1x1
+        self.ke0, self.ke1, self.em0, self.em1, self.em3, self.gn = ke[0], ke[1], em[0], em[1], em[3], em[4]
+        se = layer.se
+        self.cv0, self.cv1, self.bn, self.se0, self.sebn, self.se3 = cv[0], cv[1], layer.bn, se[0], se[1], se[3]
+        self.params = [ke[0].weight, ke[1].weight, ke[1].bias, em[0].weight, em[1].weight, em[1].bias, em[3].weight,
+                       em[3].bias, em[4].weight, em[4].bias, cv[0].weight, cv[1].weight, cv[1].bias, layer.bn.weight,
+                       layer.bn.bias, se[0].weight, se[0].bias, se[1].weight, se[1].bias, se[3].weight, se[3].bias]
+        C = layer.dim
+        self.static_ok = (
+            C % 64 == 0 and layer.kernel_size == 3 and isinstance(layer.act, nn.SiLU) and layer.radix == 2
+            and _conv_ok(ke[0], 3) and ke[0].bias is None and (C // ke[0].groups) % 8 == 0
+            and isinstance(ke[2], nn.ReLU) and _conv_ok(em[0], 1, 1) and em[0].bias is None
+            and isinstance(em[2], nn.ReLU) and _conv_ok(em[3], 1, 1) and em[3].bias is not None
+            and isinstance(em[4], nn.GroupNorm) and _conv_ok(cv[0], 1, 1) and cv[0].bias is None
+            and len(se) == 4 and _conv_ok(se[0], 1, 1) and se[0].bias is not None and isinstance(se[2], nn.ReLU)
+            and _conv_ok(se[3], 1, 1) and se[3].bias is not None and se[0].out_channels % 8 == 0
+            and se[3].out_channels == 2 * C
+            and all(_bn_static_ok(b) for b in (ke[1], em[1], cv[1], layer.bn, se[1])))
+
+
+def _plan(layer):
+    p = layer.__dict__.get("_cot_plan")
+    if p is None:
+        p = layer.__dict__["_cot_plan"] = _Plan(layer)
+    return p
+
+
+def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act):
+    """stats: fp32 [2*C + workspace] -> mean = stats[:C], rstd = stats[C:2C]"""
+    _ck(L.cot_bn_act_forward(_p(x), None, _p(y), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
+                             _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _p(stats[nws_off:]),
+                             N, C, HW, float(bn.eps), float(bn.momentum), act, BF16, _stream()), "cot_bn_act_forward")
+
+
+def _bn_bwd(L, dy, x, y, dx, bn, stats, N, C, HW, act, nws):
+    """-> (dgamma, dbeta) views of one fp32 scratch"""
+    scratch = torch.empty(2 * C + nws, dtype=torch.float32, device=dy.device)
+    _ck(L.cot_bn_act_backward(_p(dy), _p(x), _p(y), _p(dx), None, _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
+                              _p(scratch), _p(scratch[C:]), _p(scratch[2 * C:]), N, C, HW, act, BF16, _stream()),
+        "cot_bn_act_backward")
+    return scratch[:C], scratch[C:2 * C]
+
+
+class _CotLayerNode(Function):
+    @staticmethod
+    def forward(ctx, layer, x, *params):
+        # params (in this order) are only here so that autograd routes their gradients; values are read off `layer`
+        L = _lib.lib()
+        N, C, H, W = x.shape
+        HW, Ch, Ce = H * W, C // 2, 9 * C // 8
+        dev = x.device
+        pl = _plan(layer)
+        A = pl.se0.out_channels
+        ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        masks = _masks(L, H, W, dev)
+        st = _stream()
+        new = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
+        stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
+
+        # static context k = relu(bn(conv3x3_grouped(x)))                                             (ref :80)
+        k_pre, k = new(C), new(C)
+        _ck(L.cot_conv3x3g_forward(_p(x), _p(pl.ke0.weight), _p(k_pre), _p(masks), _p(ws), N, C, C, pl.ke0.groups, H, W,
+                                   BF16, st), "cot_conv3x3g_forward")
+        s_k = stat(C, nws_c)
+        _bn_fwd(L, k_pre, k, pl.ke1, s_k, 2 * C, N, C, HW, 1)
+        # attention logits from [x | k]                                                             (ref :81-85)
+        e0, e1 = new(Ch), new(Ch)
+        _ck(L.cot_conv1x1_forward(_p(x), _p(k), C, _p(pl.em0.weight), None, _p(e0), N, 2 * C, Ch, HW, BF16, st),
+            "cot_conv1x1_forward")
+        s_e = stat(Ch, nws_h)
+        _bn_fwd(L, e0, e1, pl.em1, s_e, 2 * Ch, N, Ch, HW, 1)
+        e3 = new(Ce)
+        _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, HW, BF16, st),
+            "cot_conv1x1_forward")
+        gn = pl.gn
+        w, gn_mean, gn_rstd = torch.native_group_norm(e3, gn.weight, gn.bias, N, Ce, HW, gn.num_groups, gn.eps)
+        # values                                                                                     (ref :87)
+        v_pre, v = new(C), new(C)
+        _ck(L.cot_conv1x1_forward(_p(x), None, C, _p(pl.cv0.weight), None, _p(v_pre), N, C, C, HW, BF16, st),
+            "cot_conv1x1_forward")
+        s_v = stat(C, nws_c)
+        _bn_fwd(L, v_pre, v, pl.cv1, s_v, 2 * C, N, C, HW, 0)
+        # local aggregation, bn + swish                                                              (ref :88-90)
+        geom = _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
+        a, y = new(C), new(C)
+        _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
+        s_y = stat(C, nws_c)
+        _bn_fwd(L, a, y, pl.bn, s_y, 2 * C, N, C, HW, 2)
+        # radix-2 split attention                                                                    (ref :92-104)
+        # descriptors are kept channel-major ([C][N]) so that the se branch runs on the 1x1-convolution / BatchNorm
+        # kernels with the batch as the pixel axis
+        row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
+        gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
+        _ck(L.cot_radix_gap_t(_p(y), _p(k), _p(gapT), N, C, HW, BF16, st), "cot_radix_gap_t")
+        _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st),
+            "cot_conv1x1_forward")
+        s_a = stat(A, nws_a)
+        _bn_fwd(L, hpre, h, pl.sebn, s_a, 2 * A, 1, A, N, 1)
+        _ck(L.cot_conv1x1_forward(_p(h), None, A, _p(pl.se3.weight), _p(pl.se3.bias), _p(logitsT), 1, A, 2 * C, N, BF16,
+                                  st), "cot_conv1x1_forward")
+        attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
+        out = new(C)
+        _ck(L.cot_radix_mix_logits(_p(y), _p(k), _p(logitsT), _p(out), _p(attn), N, C, HW, BF16, st),
+            "cot_radix_mix_logits")
+
+        ctx.layer, ctx.geom = layer, geom
+        ctx.save_for_backward(x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y,
+                              gapT, hpre, h, s_a)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y, gapT, hpre, h,
+         s_a) = ctx.saved_tensors
+        layer, geom = ctx.layer, ctx.geom
+        L = _lib.lib()
+        N, C, H, W = x.shape
+        HW, Ch, Ce = H * W, C // 2, 9 * C // 8
+        dev = x.device
+        pl = _plan(layer)
+        A = pl.se0.out_channels
+        ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        masks = _masks(L, H, W, dev)
+        st = _stream()
+        ke0, ke1, em0, em1, em3, cv0, cv1 = pl.ke0, pl.ke1, pl.em0, pl.em1, pl.em3, pl.cv0, pl.cv1
+        se0, sebn, se3 = pl.se0, pl.sebn, pl.se3
+        gout = gout.contiguous()
+
+        # radix mix -> pair-softmax backward -> se branch (two 1x1 convolutions over the batch axis) -> gap
+        row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
+        glogT, gh, ggapT = row(2 * C), row(A), row(C)
+        _ck(L.cot_radix_mix_backward_reduce(_p(gout), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, BF16, st),
+            "cot_radix_mix_backward_reduce")
+        _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st),
+            "cot_conv1x1_backward_data")
+        g_w3, g_b3 = torch.empty_like(se3.weight), torch.empty_like(se3.bias)
+        _ck(L.cot_conv1x1_backward_weight(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(ws), 1, A, 2 * C, N, BF16,
+                                          st), "cot_conv1x1_backward_weight")
+        ghpre = row(A)
+        d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, h, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
+        _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st),
+            "cot_conv1x1_backward_data")
+        g_w0, g_b0 = torch.empty_like(se0.weight), torch.empty_like(se0.bias)
+        _ck(L.cot_conv1x1_backward_weight(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(ws), 1, C, A, N, BF16, st),
+            "cot_conv1x1_backward_weight")
+        gy, gk = torch.empty_like(y), torch.empty_like(k)
+        _ck(L.cot_radix_mix_backward_apply(_p(gout), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, BF16, st),
+            "cot_radix_mix_backward_apply")
+        # bn + swish, aggregation
+        ga = torch.empty_like(a)
+        d_bn_w, d_bn_b = _bn_bwd(L, gy, a, None, ga, pl.bn, s_y, N, C, HW, 2, nws_c)
+        gv, gw = torch.empty_like(v), torch.empty_like(w)
+        _ck(L.cot_agg_backward(_p(ga), _p(v), _p(w), _p(gv), _p(gw), ctypes.byref(geom), BF16, _lib.COT_NCHW, st),
+            "cot_agg_backward")
+        # values branch: bn, conv1x1 -> first contribution to dx
+        gv_pre = ga  # (reuse: ga is dead)
+        d_cv_w, d_cv_b = _bn_bwd(L, gv, v_pre, None, gv_pre, cv1, s_v, N, C, HW, 0, nws_c)
+        gx = torch.empty_like(x)
+        _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gx), None, C, 0, _p(ws), N, C, C, HW, BF16, st),
+            "cot_conv1x1_backward_data")
+        g_wv = torch.empty_like(cv0.weight)
+        _ck(L.cot_conv1x1_backward_weight(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(ws), N, C, C, HW, BF16, st),
+            "cot_conv1x1_backward_weight")
+        # logits branch: GroupNorm, conv1x1(+bias), bn+relu, conv1x1 on [x | k] -> dx +=, dk +=
+        gn = pl.gn
+        ge3, g_gn_w, g_gn_b = torch.ops.aten.native_group_norm_backward(gw, e3, gn_mean, gn_rstd, gn.weight, N, Ce, HW,
+                                                                        gn.num_groups, [True, True, True])
+        ge3 = ge3.contiguous()
+        ge1 = torch.empty_like(e1)
+        _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), N, Ch, Ce, HW, BF16,
+                                        st), "cot_conv1x1_backward_data")
+        g_we3, g_be3 = torch.empty_like(em3.weight), torch.empty_like(em3.bias)
+        _ck(L.cot_conv1x1_backward_weight(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(ws), N, Ch, Ce, HW, BF16,
+                                          st), "cot_conv1x1_backward_weight")
+        ge0 = torch.empty_like(e0)
+        d_em_w, d_em_b = _bn_bwd(L, ge1, e0, e1, ge0, em1, s_e, N, Ch, HW, 1, nws_h)
+        _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gx), _p(gk), C, 3, _p(ws), N, 2 * C, Ch, HW, BF16,
+                                        st), "cot_conv1x1_backward_data")
+        g_we0 = torch.empty_like(em0.weight)
+        _ck(L.cot_conv1x1_backward_weight(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(ws), N, 2 * C, Ch, HW, BF16, st),
+            "cot_conv1x1_backward_weight")
+        # key branch: bn+relu, grouped 3x3 -> dx +=
+        gk_pre = gv  # (reuse: gv is dead)
+        d_ke_w, d_ke_b = _bn_bwd(L, gk, k_pre, k, gk_pre, ke1, s_k, N, C, HW, 1, nws_c)
+        G = ke0.groups
+        _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx), 1, _p(masks), _p(ws), N, C, C, G, H, W,
+                                         BF16, st), "cot_conv3x3g_backward_data")
+        g_wk = torch.empty_like(ke0.weight)
+        _ck(L.cot_conv3x3g_backward_weight(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(ws), N, C, C, G, H, W, BF16, st),
+            "cot_conv3x3g_backward_weight")
+        # order = _Plan.params
+        return (None, gx, g_wk, d_ke_w, d_ke_b, g_we0, d_em_w, d_em_b, g_we3, g_be3, g_gn_w, g_gn_b, g_wv, d_cv_w, d_cv_b,
+                d_bn_w, d_bn_b, g_w0, g_b0, d_sa_w, d_sa_b, g_w3, g_b3)
+
+
+def _bn_static_ok(bn):
+    return (isinstance(bn, nn.BatchNorm2d) and bn.affine and bn.track_running_stats and bn.momentum is not None
+            and bn.num_batches_tracked is not None)
+
+
+def _conv_ok(conv, k, groups=None):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (k, k) and conv.stride == (1, 1)
+            and conv.padding == (k // 2, k // 2) and conv.dilation == (1, 1) and (groups is None or conv.groups == groups))
+
+
+def eligible(layer, x):
+    """training-mode CotLayer on a bf16 NCHW tensor whose every piece the kernels cover (mixed precision as
+    cotnet_amd.flat_sgd.to_mixed_bf16 sets it up: bf16 convolution / GroupNorm parameters, fp32 BatchNorm parameters)"""
+    if not (ENABLED and layer.training and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4
+            and x.dtype == torch.bfloat16 and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and x.shape[1] == layer.dim):
+        return False
+    pl = _plan(layer)
+    return (pl.static_ok and pl.ke0.weight.dtype == torch.bfloat16 and pl.em3.weight.dtype == torch.bfloat16
+            and pl.gn.weight.dtype == torch.bfloat16 and pl.bn.weight.dtype == torch.float32 and pl.bn.training
+            and pl.ke1.training)
+
+
+def cot_layer_forward(layer, x):
+    """layer(x) through the single-node path; caller checks `eligible` first"""
+    return _CotLayerNode.apply(layer, x, *_plan(layer).params)

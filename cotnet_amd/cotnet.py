@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .aggregation_zeropad import LocalConvolution
-from . import radix_tail
+from . import cot_layer_fused, radix_tail
 from .conv1x1 import conv1x1, run_downsample
 from .conv3x3g import conv3x3
 from .fused_bn import fused_bn_act
@@ -122,6 +122,8 @@ class CotLayer(nn.Module):
             nn.Conv2d(attn_chs, self.radix * dim, 1))
 
     def forward(self, x):
+        if cot_layer_fused.ENABLED and cot_layer_fused.eligible(self, x):
+            return cot_layer_fused.cot_layer_forward(self, x)  # the whole layer as one autograd node (opt-in)
         # Sequential members are called one by one so that each BatchNorm runs fused with its activation
         # (cotnet_amd.fused_bn); module structure and state_dict keys are the reference's.
         k = fused_bn_act(conv3x3(self.key_embed[0], x), self.key_embed[1], "relu")

@@ -119,6 +119,13 @@ int conv3x3g_gemm(const void*, const void*, void*, const void*, void*, int, int,
                   hipStream_t);
 int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW);
 int conv3x3g_wgrad(const void*, const void*, void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
+template <typename T> int radix_gap_t(const void*, const void*, void*, int, int, int, hipStream_t);
+template <typename T>
+int radix_mix_logits(const void*, const void*, const void*, void*, void*, int, int, int, hipStream_t);
+template <typename T>
+int radix_mix_bwd_reduce(const void*, const void*, const void*, const void*, void*, int, int, int, hipStream_t);
+template <typename T>
+int radix_mix_bwd_apply(const void*, const void*, const void*, void*, void*, int, int, int, hipStream_t);
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
 int set_tuning_nchw(int key, int value);
@@ -425,6 +432,49 @@ int cot_radix_mix_backward(const void* gout, const void* y, const void* k, const
     if ((rc = check_align16({gout, y, k, gy, gk}))) return rc;
     return dtype == COT_F32 ? radix_mix_bwd<float>(gout, y, k, attn, gy, gk, gattn, planes, HW, (hipStream_t)stream)
                             : radix_mix_bwd<bf16_t>(gout, y, k, attn, gy, gk, gattn, planes, HW, (hipStream_t)stream);
+}
+
+int cot_radix_gap_t(const void* y, const void* k, void* gapT, int N, int C, int HW, int dtype, void* stream) {
+    int rc = tail_check((int64_t)N * C, HW, dtype);
+    if (rc) return rc;
+    if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive N=%d C=%d", N, C);
+    if (!y || !k || !gapT) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({y, k}))) return rc;
+    return dtype == COT_F32 ? radix_gap_t<float>(y, k, gapT, N, C, HW, (hipStream_t)stream)
+                            : radix_gap_t<bf16_t>(y, k, gapT, N, C, HW, (hipStream_t)stream);
+}
+
+int cot_radix_mix_logits(const void* y, const void* k, const void* logitsT, void* out, void* attn, int N, int C, int HW,
+                         int dtype, void* stream) {
+    int rc = tail_check((int64_t)N * C, HW, dtype);
+    if (rc) return rc;
+    if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive N=%d C=%d", N, C);
+    if (!y || !k || !logitsT || !out || !attn) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({y, k, out}))) return rc;
+    return dtype == COT_F32 ? radix_mix_logits<float>(y, k, logitsT, out, attn, N, C, HW, (hipStream_t)stream)
+                            : radix_mix_logits<bf16_t>(y, k, logitsT, out, attn, N, C, HW, (hipStream_t)stream);
+}
+
+int cot_radix_mix_backward_reduce(const void* gout, const void* y, const void* k, const void* attn, void* glogitsT, int N,
+                                  int C, int HW, int dtype, void* stream) {
+    int rc = tail_check((int64_t)N * C, HW, dtype);
+    if (rc) return rc;
+    if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive N=%d C=%d", N, C);
+    if (!gout || !y || !k || !attn || !glogitsT) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gout, y, k}))) return rc;
+    return dtype == COT_F32 ? radix_mix_bwd_reduce<float>(gout, y, k, attn, glogitsT, N, C, HW, (hipStream_t)stream)
+                            : radix_mix_bwd_reduce<bf16_t>(gout, y, k, attn, glogitsT, N, C, HW, (hipStream_t)stream);
+}
+
+int cot_radix_mix_backward_apply(const void* gout, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C,
+                                 int HW, int dtype, void* stream) {
+    int rc = tail_check((int64_t)N * C, HW, dtype);
+    if (rc) return rc;
+    if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive N=%d C=%d", N, C);
+    if (!gout || !attn || !ggapT || !gy || !gk) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gout, gy, gk}))) return rc;
+    return dtype == COT_F32 ? radix_mix_bwd_apply<float>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream)
+                            : radix_mix_bwd_apply<bf16_t>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream);
 }
 
 int cot_bn_act_workspace(int N, int C) { return (N > 0 && C > 0) ? bn_workspace_floats(N, C) : 0; }

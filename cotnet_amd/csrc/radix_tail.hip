@@ -88,6 +88,113 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_kernel(const T* __restrict_
     }
 }
 
+
+// ---- channel-major ("T") variants: the se branch between gap and mix is a two-layer MLP on [N, C]; with the
+// descriptors stored [C][N] it is two 1x1 convolutions over ONE image of N "pixels" (cot_conv1x1_*) with a BatchNorm
+// between them (cot_bn_act_*, statistics over the N pixels = over the batch, as nn.BatchNorm2d on [N, A, 1, 1] does).
+//   radix_gap_t          gapT[c][n] = mean_hw(y + k)
+//   radix_mix_logits     a0 = softmax over the pair (logitsT[2c][n], logitsT[2c+1][n]); out = y*a0 + k*a1; attn saved
+//   radix_mix_bwd_reduce s0 = sum g*y, s1 = sum g*k;  glogitsT[2c][n] = a0*a1*(s0 - s1) = -glogitsT[2c+1][n]
+//   radix_mix_bwd_apply  gy = g*a0 + ggapT[c][n]/HW,  gk = g*a1 + ggapT[c][n]/HW
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_gap_t_kernel(const T* __restrict__ y, const T* __restrict__ k,
+                                                         T* __restrict__ gapT, int N, int C, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= (int64_t)N * C) return;
+    const T* yp = y + plane * HW;
+    const T* kp = k + plane * HW;
+    float acc = 0.f;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc += (float)a.v[j] + (float)b.v[j];
+    }
+    acc = wave_sum_f(acc);
+    const int n = (int)(plane / C), c = (int)(plane % C);
+    if (lane == 0) gapT[(int64_t)c * N + n] = (T)(acc / (float)HW);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_mix_logits_kernel(const T* __restrict__ y, const T* __restrict__ k,
+                                                              const T* __restrict__ logitsT, T* __restrict__ out,
+                                                              T* __restrict__ attn, int N, int C, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= (int64_t)N * C) return;
+    const int n = (int)(plane / C), c = (int)(plane % C);
+    const float l0 = (float)logitsT[(int64_t)(2 * c) * N + n], l1 = (float)logitsT[(int64_t)(2 * c + 1) * N + n];
+    const float a0 = 1.f / (1.f + __expf(l1 - l0)), a1 = 1.f - a0;  // softmax over the radix pair
+    if (lane == 0) {
+        attn[plane * 2] = (T)a0;
+        attn[plane * 2 + 1] = (T)a1;
+    }
+    const T* yp = y + plane * HW;
+    const T* kp = k + plane * HW;
+    T* op = out + plane * HW;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
+        Vec<T, V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.v[j] = (T)((float)a.v[j] * a0 + (float)b.v[j] * a1);
+        stv<T, V>(op + i, o);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_mix_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                                  const T* __restrict__ k, const T* __restrict__ attn,
+                                                                  T* __restrict__ glogitsT, int N, int C, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= (int64_t)N * C) return;
+    const int64_t base = plane * HW;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> gv = ldv<T, V>(g + base + i), a = ldv<T, V>(y + base + i), b = ldv<T, V>(k + base + i);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gg = (float)gv.v[j];
+            s0 += gg * (float)a.v[j];
+            s1 += gg * (float)b.v[j];
+        }
+    }
+    s0 = wave_sum_f(s0);
+    s1 = wave_sum_f(s1);
+    if (lane == 0) {
+        const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
+        const float gl = a0 * a1 * (s0 - s1);  // softmax backward for a pair: gl0 = a0*(s0 - (a0*s0 + a1*s1))
+        const int n = (int)(plane / C), c = (int)(plane % C);
+        glogitsT[(int64_t)(2 * c) * N + n] = (T)gl;
+        glogitsT[(int64_t)(2 * c + 1) * N + n] = (T)(-gl);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_mix_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ attn,
+                                                                 const T* __restrict__ ggapT, T* __restrict__ gy,
+                                                                 T* __restrict__ gk, int N, int C, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= (int64_t)N * C) return;
+    const int n = (int)(plane / C), c = (int)(plane % C);
+    const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
+    const float add = (float)ggapT[(int64_t)c * N + n] / (float)HW;  // d mean_hw(y + k)
+    const int64_t base = plane * HW;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> gv = ldv<T, V>(g + base + i);
+        Vec<T, V> oy, ok;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gg = (float)gv.v[j];
+            oy.v[j] = (T)(gg * a0 + add);
+            ok.v[j] = (T)(gg * a1 + add);
+        }
+        stv<T, V>(gy + base + i, oy);
+        stv<T, V>(gk + base + i, ok);
+    }
+}
+
 static inline int tail_vec(size_t esize, int HW) {
     int lim = (int)(16 / esize);
     for (int V = 8; V >= 1; V >>= 1)
@@ -122,11 +229,46 @@ int radix_mix_bwd(const void* g, const void* y, const void* k, const void* attn,
     return check_launch("radix_mix_bwd");
 }
 
+template <typename T> int radix_gap_t(const void* y, const void* k, void* gapT, int N, int C, int HW, hipStream_t s) {
+    const int64_t planes = (int64_t)N * C;
+    TAIL_DISPATCH(radix_gap_t_kernel, (const T*)y, (const T*)k, (T*)gapT, N, C, HW);
+    return check_launch("radix_gap_t");
+}
+template <typename T>
+int radix_mix_logits(const void* y, const void* k, const void* logitsT, void* out, void* attn, int N, int C, int HW,
+                     hipStream_t s) {
+    const int64_t planes = (int64_t)N * C;
+    TAIL_DISPATCH(radix_mix_logits_kernel, (const T*)y, (const T*)k, (const T*)logitsT, (T*)out, (T*)attn, N, C, HW);
+    return check_launch("radix_mix_logits");
+}
+template <typename T>
+int radix_mix_bwd_reduce(const void* g, const void* y, const void* k, const void* attn, void* glogitsT, int N, int C,
+                         int HW, hipStream_t s) {
+    const int64_t planes = (int64_t)N * C;
+    TAIL_DISPATCH(radix_mix_bwd_reduce_kernel, (const T*)g, (const T*)y, (const T*)k, (const T*)attn, (T*)glogitsT, N,
+                  C, HW);
+    return check_launch("radix_mix_bwd_reduce");
+}
+template <typename T>
+int radix_mix_bwd_apply(const void* g, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C, int HW,
+                        hipStream_t s) {
+    const int64_t planes = (int64_t)N * C;
+    TAIL_DISPATCH(radix_mix_bwd_apply_kernel, (const T*)g, (const T*)attn, (const T*)ggapT, (T*)gy, (T*)gk, N, C, HW);
+    return check_launch("radix_mix_bwd_apply");
+}
+
 #define INST(T)                                                                                                    \
     template int radix_gap<T>(const void*, const void*, void*, int64_t, int, hipStream_t);                         \
     template int radix_mix<T>(const void*, const void*, const void*, void*, int64_t, int, hipStream_t);            \
     template int radix_mix_bwd<T>(const void*, const void*, const void*, const void*, void*, void*, void*, int64_t, \
-                                  int, hipStream_t);
+                                  int, hipStream_t);                                                               \
+    template int radix_gap_t<T>(const void*, const void*, void*, int, int, int, hipStream_t);                      \
+    template int radix_mix_logits<T>(const void*, const void*, const void*, void*, void*, int, int, int,           \
+                                     hipStream_t);                                                                 \
+    template int radix_mix_bwd_reduce<T>(const void*, const void*, const void*, const void*, void*, int, int, int, \
+                                         hipStream_t);                                                             \
+    template int radix_mix_bwd_apply<T>(const void*, const void*, const void*, void*, void*, int, int, int,        \
+                                        hipStream_t);
 INST(float)
 INST(bf16_t)
 

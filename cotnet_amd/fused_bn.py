@@ -26,8 +26,11 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if _DEVICE_ONLY else None
 
 
 _WS = {}  # (N, C) -> workspace floats (pure function of the shape; avoids a library call per launch)
@@ -92,7 +95,7 @@ def _torch_path(x, bn, act, residual):
 def fused_bn_act(x, bn, act=None, residual=None):
     """act(bn(x) [+ residual]) with `bn` an nn.BatchNorm2d.  Fused HIP kernels when eligible, torch otherwise."""
     # (tensors are assumed to live on the current device, as everywhere in a one-process-per-GPU job)
-    ok = (ENABLED and bn.training and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
+    ok = (ENABLED and bn.training and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
           and x.is_contiguous() and bn.affine and bn.track_running_stats and bn.momentum is not None
           and bn.weight.dtype == torch.float32 and x.data_ptr() % 16 == 0
           and bn.num_batches_tracked is not None and bn.num_batches_tracked.dtype == torch.int64

@@ -183,6 +183,22 @@ int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int
 int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
                                  int Cin, int Cout, int groups, int H, int W, int dtype, void* stream);
 
+/* Channel-major variants for running the `se` branch (models/cotnet.py:71-77,:98-101) on the library's own kernels: with
+ * the pooled descriptor stored [C][N] the two 1x1 convolutions of `se` are cot_conv1x1_* calls on ONE image of N
+ * "pixels" and its BatchNorm is cot_bn_act_* over those N pixels (= over the batch, as nn.BatchNorm2d on [N,A,1,1]).
+ *   cot_radix_gap_t               gapT[c][n] = mean_hw(y + k)
+ *   cot_radix_mix_logits          attn[n][c][0..1] = softmax over the pair (logitsT[2c][n], logitsT[2c+1][n])  (saved for
+ *                                 backward), out = y*attn0 + k*attn1
+ *   cot_radix_mix_backward_reduce glogitsT[2c][n] = a0*a1*(sum g*y - sum g*k) = -glogitsT[2c+1][n]  (pair-softmax backward)
+ *   cot_radix_mix_backward_apply  gy = g*a0 + ggapT[c][n]/HW,  gk = g*a1 + ggapT[c][n]/HW */
+int cot_radix_gap_t(const void* y, const void* k, void* gapT, int N, int C, int HW, int dtype, void* stream);
+int cot_radix_mix_logits(const void* y, const void* k, const void* logitsT, void* out, void* attn, int N, int C, int HW,
+                         int dtype, void* stream);
+int cot_radix_mix_backward_reduce(const void* gout, const void* y, const void* k, const void* attn, void* glogitsT, int N,
+                                  int C, int HW, int dtype, void* stream);
+int cot_radix_mix_backward_apply(const void* gout, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C,
+                                 int HW, int dtype, void* stream);
+
 /* ---- fused SGD over a flat parameter bucket (replaces torch.optim.SGD(nesterov=True),
  * optim/optim_factory.py:54-56, which launches per parameter tensor):
  *     g = grad*grad_scale + weight_decay*p;  buf = momentum*buf + g;  p -= lr*(nesterov ? g + momentum*buf : buf)

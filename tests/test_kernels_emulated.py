@@ -576,3 +576,125 @@ def test_data_gradients_can_accumulate_into_their_outputs():
     g = base.clone()
     assert _EMUL.cot_conv3x3g_backward_data(P(gy3), P(w3), P(g), 1, P(masks), P(ws3), N, C, C, G, H, W, dt, None) == 0
     assert torch.allclose(g.float(), fresh.float() + base.float(), atol=3e-2, rtol=2e-2)
+
+
+class _EmulAggregation(torch.autograd.Function):
+    """test-local stand-in for cotnet_amd.aggregation_zeropad.AggregationZeropad on CPU tensors (3x3/s1/p1, NCHW)"""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        N, C, H, W = x.shape
+        geom = _lib.AggGeom(N, C, H, W, 1, w.shape[2], 3, 3, 1, 1, 1, 1, 1, 1)
+        out = torch.empty_like(x)
+        assert _EMUL.cot_agg_forward(P(x), P(w), P(out), ctypes.byref(geom), _lib.dtype_code(x.dtype), 0, None) == 0
+        ctx.geom = geom
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx, gw = torch.empty_like(x), torch.empty_like(w)
+        assert _EMUL.cot_agg_backward(P(g), P(x), P(w), P(gx), P(gw), ctypes.byref(ctx.geom),
+                                      _lib.dtype_code(x.dtype), 0, None) == 0
+        return gx, gw
+
+
+def test_fused_cot_layer_node_on_emulated_kernels(monkeypatch):
+    """cotnet_amd.cot_layer_fused: the whole CotLayer as one autograd node (hand-written backward chain) against the
+    module's ordinary node-per-op forward, both on the host-emulated kernels: same arithmetic and rounding points, so the
+    two must agree to a few bf16 ulps (the only difference: dx / dk are summed in fp32 inside the kernels)."""
+    import copy
+    import cotnet_amd.aggregation_zeropad as az
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, radix_tail
+    from cotnet_amd.cotnet import CotLayer
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    torch.manual_seed(4)
+    N, C, H, W = 3, 64, 6, 6
+    node = CotLayer(C, 3).train()
+    with torch.no_grad():
+        for p in node.parameters():
+            if p.ndim == 1:
+                p.add_(0.3 * torch.randn_like(p))   # non-trivial BN / GN affine parameters and biases
+    node = to_mixed_bf16(node)
+    perop = copy.deepcopy(node)
+    x = torch.randn(N, C, H, W).bfloat16()
+    g = torch.randn(N, C, H, W).bfloat16()
+
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(c1, "MODE", "hip")
+    monkeypatch.setattr(c3, "MODE", "hip")
+    monkeypatch.setattr(az, "aggregation_zeropad",
+                        lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
+    for cache in (clf._SIZES, clf._MASKS, c1._WS, c3._WS, c3._MASKS, fused_bn._WS):
+        cache.clear()
+
+    monkeypatch.setattr(clf, "ENABLED", False)
+    xr = x.clone().requires_grad_(True)
+    yr = perop(xr)
+    assert "CotLayerNode" not in yr.grad_fn.name()
+    yr.backward(g)
+
+    monkeypatch.setattr(clf, "ENABLED", True)
+    xf = x.clone().requires_grad_(True)
+    assert clf.eligible(node, xf)
+    yf = node(xf)
+    assert yf.grad_fn.name().startswith("_CotLayerNode")
+    yf.backward(g)
+
+    def rel(a, b):
+        return ((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-6)).item()
+
+    assert rel(yf, yr.detach()) < 1e-2
+    assert rel(xf.grad, xr.grad) < 2e-2
+    pr = dict(perop.named_parameters())
+    top = max(q.grad.float().abs().max() for q in pr.values())
+    for n_, p in node.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == p.dtype, n_
+        if pr[n_].grad.float().abs().max() > 1e-3 * top:   # (a bias in front of a BatchNorm has a pure-noise gradient)
+            assert rel(p.grad, pr[n_].grad) < 3e-2, (n_, rel(p.grad, pr[n_].grad))
+    br, bf = dict(perop.named_buffers()), dict(node.named_buffers())
+    for n_ in br:
+        assert torch.allclose(bf[n_].float(), br[n_].float(), atol=1e-3, rtol=1e-3), n_
+    for cache in (clf._SIZES, clf._MASKS, c1._WS, c3._WS, c3._MASKS, fused_bn._WS):
+        cache.clear()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(3, 8, 8, 8), (2, 16, 14, 14), (5, 12, 7, 7), (1, 4, 3, 5)])
+def test_radix_tail_channel_major_kernels(N, C, H, W, dtype):
+    """cot_radix_gap_t / _mix_logits / _mix_backward_reduce / _mix_backward_apply against the torch formulas"""
+    torch.manual_seed(9)
+    HW = H * W
+    dt = _lib.dtype_code(dtype)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    y, k, g = (torch.randn(N, C, H, W).to(dtype) for _ in range(3))
+    gapT = torch.empty(C, N, dtype=dtype)
+    assert _EMUL.cot_radix_gap_t(P(y), P(k), P(gapT), N, C, HW, dt, None) == 0
+    want = (y.float() + k.float()).mean((2, 3)).t()
+    assert torch.allclose(gapT.float(), want, atol=tol, rtol=tol)
+
+    logitsT = torch.randn(2 * C, N).to(dtype)
+    out, attn = torch.empty_like(y), torch.empty(N, C, 2, dtype=dtype)
+    assert _EMUL.cot_radix_mix_logits(P(y), P(k), P(logitsT), P(out), P(attn), N, C, HW, dt, None) == 0
+    lg = logitsT.float().t().reshape(N, C, 2).requires_grad_(True)      # [n][2c + r] -> [n][c][r]
+    yf, kf = y.float().requires_grad_(True), k.float().requires_grad_(True)
+    a = torch.softmax(lg, dim=2)
+    ref = yf * a[:, :, 0, None, None] + kf * a[:, :, 1, None, None]
+    assert torch.allclose(attn.float(), a.detach(), atol=tol, rtol=tol)
+    assert torch.allclose(out.float(), ref.detach(), atol=2 * tol, rtol=2 * tol)
+
+    ref.backward(g.float())
+    glogT = torch.empty(2 * C, N, dtype=dtype)
+    assert _EMUL.cot_radix_mix_backward_reduce(P(g), P(y), P(k), P(attn), P(glogT), N, C, HW, dt, None) == 0
+    want_gl = lg.grad.reshape(N, 2 * C).t()
+    assert (glogT.float() - want_gl).abs().max() <= 3 * tol * (1 + want_gl.abs().max())
+    ggapT = torch.randn(C, N).to(dtype)
+    gy, gk = torch.empty_like(y), torch.empty_like(k)
+    assert _EMUL.cot_radix_mix_backward_apply(P(g), P(attn), P(ggapT), P(gy), P(gk), N, C, HW, dt, None) == 0
+    add = (ggapT.float().t() / HW)[:, :, None, None]
+    assert torch.allclose(gy.float(), yf.grad + add, atol=3 * tol, rtol=3 * tol)
+    assert torch.allclose(gk.float(), kf.grad + add, atol=3 * tol, rtol=3 * tol)
