@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--conv1x1", default=None, choices=["module", "hip", "matmul"],
                     help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
+    ap.add_argument("--gn9", action="store_true", help="GroupNorm of the attention logits on csrc/group_norm9.hip")
     ap.add_argument("--fused-layer", action="store_true",
                     help="CotLayer as one autograd node (cotnet_amd/cot_layer_fused.py); implies --conv1x1 hip --conv3x3 hip")
     ap.add_argument("--conv3x3", default=None, choices=["module", "hip"],
@@ -135,6 +136,9 @@ def roctx_window(resume):
 
 def main():
     args = parse()
+    if args.gn9:
+        from cotnet_amd import group_norm9 as _gn9
+        _gn9.MODE = "hip"
     if args.fused_layer:
         from cotnet_amd import cot_layer_fused as _clf
         _clf.ENABLED = True
@@ -309,6 +313,7 @@ def main():
                        "hip_graph": graphed,
                        "conv1x1": __import__("cotnet_amd.conv1x1", fromlist=["MODE"]).MODE or "module",
                        "conv3x3": __import__("cotnet_amd.conv3x3g", fromlist=["MODE"]).MODE or "module",
+                       "group_norm9": __import__("cotnet_amd.group_norm9", fromlist=["MODE"]).MODE or "module",
                        "cot_layer_single_node": __import__("cotnet_amd.cot_layer_fused", fromlist=["ENABLED"]).ENABLED,
                        "grad_sync": "RCCL all-reduce (AVG), flat buckets, side stream" if world > 1 else "none (1 GPU)"},
             "final_loss": round(final_loss, 4),

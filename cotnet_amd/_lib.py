@@ -55,6 +55,8 @@ SYMBOLS = {
     "cot_radix_mix_logits": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_reduce": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_apply": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
+    "cot_group_norm9_forward": (_I, [_P] * 6 + [_I, _I, _I, ctypes.c_float, _I, _P]),
+    "cot_group_norm9_backward": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
     "cot_sgd_step": (_I, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                           _I, _I, _I, _P]),
     "cot_conv1x1_workspace": (ctypes.c_int64, [_I, _I, _I, _I, _I]),

@@ -6,7 +6,7 @@ nodes forward and as many backward, plus the engine's gradient-accumulation adds
 (x feeds key_embed, embed and conv1x1: two adds of C*H*W; k feeds embed and the radix tail: one more).  This module
 evaluates the same function (models/cotnet.py:79-104) by calling the library's kernels back to back through the C ABI:
 
-    forward   conv3x3g -> bn+relu -> conv1x1 on [x | k] (no cat) -> bn+relu -> conv1x1(+bias) -> GroupNorm (aten)
+    forward   conv3x3g -> bn+relu -> conv1x1 on [x | k] (no cat) -> bn+relu -> conv1x1(+bias) -> GroupNorm
               -> conv1x1 -> bn -> aggregation -> bn+silu -> radix gap (channel-major) -> se branch as two 1x1
               convolutions over the batch axis with its BatchNorm+ReLU between them -> pair softmax + radix mix
     backward  the mirror image; the three contributions to dx and the two to dk are summed inside the data-gradient
@@ -90,7 +90,8 @@ class _Plan:
             and _conv_ok(ke[0], 3) and ke[0].bias is None and (C // ke[0].groups) % 8 == 0
             and isinstance(ke[2], nn.ReLU) and _conv_ok(em[0], 1, 1) and em[0].bias is None
             and isinstance(em[2], nn.ReLU) and _conv_ok(em[3], 1, 1) and em[3].bias is not None
-            and isinstance(em[4], nn.GroupNorm) and _conv_ok(cv[0], 1, 1) and cv[0].bias is None
+            and isinstance(em[4], nn.GroupNorm) and em[4].num_groups * 9 == em[4].num_channels and em[4].affine
+            and _conv_ok(cv[0], 1, 1) and cv[0].bias is None
             and len(se) == 4 and _conv_ok(se[0], 1, 1) and se[0].bias is not None and isinstance(se[2], nn.ReLU)
             and _conv_ok(se[3], 1, 1) and se[3].bias is not None and se[0].out_channels % 8 == 0
             and se[3].out_channels == 2 * C
@@ -153,7 +154,14 @@ class _CotLayerNode(Function):
         _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, HW, BF16, st),
             "cot_conv1x1_forward")
         gn = pl.gn
-        w, gn_mean, gn_rstd = torch.native_group_norm(e3, gn.weight, gn.bias, N, Ce, HW, gn.num_groups, gn.eps)
+        if HW <= 8192:  # one (image, group) fits a workgroup's registers: 1 read + 1 write (csrc/group_norm9.hip)
+            w = new(Ce)
+            gn_mean = torch.empty(2 * N * gn.num_groups, dtype=torch.float32, device=dev)
+            gn_rstd = gn_mean[N * gn.num_groups:]
+            _ck(L.cot_group_norm9_forward(_p(e3), _p(gn.weight), _p(gn.bias), _p(w), _p(gn_mean), _p(gn_rstd), N, Ce, HW,
+                                          float(gn.eps), BF16, st), "cot_group_norm9_forward")
+        else:
+            w, gn_mean, gn_rstd = torch.native_group_norm(e3, gn.weight, gn.bias, N, Ce, HW, gn.num_groups, gn.eps)
         # values                                                                                     (ref :87)
         v_pre, v = new(C), new(C)
         _ck(L.cot_conv1x1_forward(_p(x), None, C, _p(pl.cv0.weight), None, _p(v_pre), N, C, C, HW, BF16, st),
@@ -244,9 +252,15 @@ class _CotLayerNode(Function):
             "cot_conv1x1_backward_weight")
         # logits branch: GroupNorm, conv1x1(+bias), bn+relu, conv1x1 on [x | k] -> dx +=, dk +=
         gn = pl.gn
-        ge3, g_gn_w, g_gn_b = torch.ops.aten.native_group_norm_backward(gw, e3, gn_mean, gn_rstd, gn.weight, N, Ce, HW,
-                                                                        gn.num_groups, [True, True, True])
-        ge3 = ge3.contiguous()
+        if HW <= 8192:
+            ge3, g_gn_w, g_gn_b = torch.empty_like(e3), torch.empty_like(gn.weight), torch.empty_like(gn.bias)
+            gn_ws = torch.empty(2 * N * Ce, dtype=torch.float32, device=dev)
+            _ck(L.cot_group_norm9_backward(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), _p(g_gn_w),
+                                           _p(g_gn_b), _p(gn_ws), N, Ce, HW, BF16, st), "cot_group_norm9_backward")
+        else:
+            ge3, g_gn_w, g_gn_b = torch.ops.aten.native_group_norm_backward(
+                gw, e3, gn_mean, gn_rstd, gn.weight, N, Ce, HW, gn.num_groups, [True, True, True])
+            ge3 = ge3.contiguous()
         ge1 = torch.empty_like(e1)
         _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), N, Ch, Ce, HW, BF16,
                                         st), "cot_conv1x1_backward_data")

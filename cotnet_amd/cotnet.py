@@ -22,6 +22,7 @@ from .aggregation_zeropad import LocalConvolution
 from . import cot_layer_fused, radix_tail
 from .conv1x1 import conv1x1, run_downsample
 from .conv3x3g import conv3x3
+from .group_norm9 import group_norm9
 from .fused_bn import fused_bn_act
 from .layers import get_act_layer
 from .registry import build_model_with_cfg, register_model
@@ -131,7 +132,7 @@ class CotLayer(nn.Module):
 
         # embed[0] consumes the concatenation [x, k] (ref :81); conv1x1 reads the two slabs in place when it can
         w = fused_bn_act(conv1x1(self.embed[0], x, k), self.embed[1], "relu")
-        w = self.embed[4](conv1x1(self.embed[3], w))
+        w = group_norm9(self.embed[4], conv1x1(self.embed[3], w))
         w = w.view(b, 1, -1, self.kernel_size * self.kernel_size, qk_hh, qk_ww)
 
         x = self.conv1x1[1](conv1x1(self.conv1x1[0], x))

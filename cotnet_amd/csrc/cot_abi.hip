@@ -112,6 +112,10 @@ int conv1x1_transpose(const void*, void*, int, int, hipStream_t);
 int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_conv1x1_tune[4];
+// implemented in group_norm9.hip
+int gn9_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, hipStream_t);
+int gn9_backward(const void*, const void*, const float*, const float*, const void*, void*, void*, void*, float*, int, int,
+                 int, hipStream_t);
 // implemented in conv3x3g.hip
 int64_t conv3x3g_masks_bytes(int H, int W);
 int conv3x3g_masks(void*, int, int, hipStream_t);
@@ -475,6 +479,37 @@ int cot_radix_mix_backward_apply(const void* gout, const void* attn, const void*
     if ((rc = check_align16({gout, gy, gk}))) return rc;
     return dtype == COT_F32 ? radix_mix_bwd_apply<float>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream)
                             : radix_mix_bwd_apply<bf16_t>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream);
+}
+
+static int gn9_validate(int N, int C, int HW, int dtype) {
+    if (N <= 0 || C <= 0 || HW <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d C=%d HW=%d", N, C, HW);
+    if (C % 9 != 0) return set_error(COT_ERR_INVALID_ARG, "channel count %d is not a multiple of 9", C);
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_group_norm9_*: only COT_BF16 (dtype %d given)", dtype);
+    return COT_OK;
+}
+
+int cot_group_norm9_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N,
+                            int C, int HW, float eps, int dtype, void* stream) {
+    int rc = gn9_validate(N, C, HW, dtype);
+    if (rc) return rc;
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x, y}))) return rc;
+    rc = gn9_forward(x, gamma, beta, y, mean, rstd, N, C, HW, eps, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_group_norm9_forward: %d pixels per plane exceed one workgroup", HW);
+    return rc;
+}
+
+int cot_group_norm9_backward(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma,
+                             void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int dtype,
+                             void* stream) {
+    int rc = gn9_validate(N, C, HW, dtype);
+    if (rc) return rc;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace)
+        return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({dy, x, dx}))) return rc;
+    rc = gn9_backward(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, N, C, HW, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_group_norm9_backward: %d pixels per plane exceed one workgroup", HW);
+    return rc;
 }
 
 int cot_bn_act_workspace(int N, int C) { return (N > 0 && C > 0) ? bn_workspace_floats(N, C) : 0; }

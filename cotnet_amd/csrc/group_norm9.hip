@@ -1,0 +1,243 @@
+// group_norm9.hip -- GroupNorm with 9 channels per group on NCHW bf16 tensors: the normalisation of the k*k = 9 attention
+// logits that share a weight channel (reference: CotLayer.embed[4] = nn.GroupNorm(dim/8, 9*dim/8), models/cotnet.py:56;
+// its output, viewed [B,1,dim/8,9,H,W] (:85), is the aggregation's weight tensor).
+//
+// One (image, group) = 9 consecutive channels = ONE contiguous run of 9*H*W elements (56 KB at 56x56), small enough to
+// sit in the registers of one workgroup.  So:
+//   forward   1 read + 1 write:  load the group, mean / variance in two in-register passes (no E[x^2]-E[x]^2
+//             cancellation), normalise from registers.              (torch: moments pass + apply pass = 2R + 1W)
+//   backward  2 reads + 1 write: load dy and x once, per-channel sums (sum dy, sum dy*xhat) by a block reduction,
+//             dx from registers; the per-(image, channel) sums go to a small workspace and a second, tiny kernel
+//             reduces them over the batch into dgamma / dbeta (deterministic).       (torch: 6R + 1W, 4-5 launches)
+// Thread t of a workgroup owns, for each of the 9 channels and each round r < R, the 8 consecutive pixels starting at
+// 8*(r*NT + t): all channel indices are compile-time, so per-channel accumulators stay in registers.
+#include "cot_common.h"
+#include "mfma_common.h"
+
+namespace cot {
+
+__device__ __forceinline__ float gn_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+// block-wide sums of NV values, result broadcast to every thread; smem >= NV * 16 floats, blockDim <= 1024
+template <int NV> __device__ __forceinline__ void gn_block_sum_all(float (&v)[NV], float* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = gn_wave_sum(v[k]);
+    __syncthreads();  // previous use of smem is over
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) smem[k * 16 + wave] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += smem[k * 16 + w];
+        v[k] = s;
+    }
+}
+
+template <int NT, int R, int AL>
+__global__ void __launch_bounds__(NT)
+gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+               bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int G, int HW,
+               float eps) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];  // 16 floats per reduced value
+    float* smem = reinterpret_cast<float*>(cot_smem);
+    const int t = threadIdx.x, g = blockIdx.x % G;
+    const int wend = 64 * (uniform(t >> 6) + 1);        // one past this wave's last thread index
+    const int64_t base = (int64_t)blockIdx.x * 9 * HW;  // (n*G + g) * 9 channels
+    bf16_t v[9][R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = 8 * (r * NT + t);
+        const bool full = 8 * (r * NT + wend) <= HW;  // wave-uniform: every lane's piece of this round is complete
+#pragma unroll
+        for (int cl = 0; cl < 9; ++cl) load_piece<8, AL>(v[cl][r], x + base + (int64_t)cl * HW + p, HW - p, full);
+    }
+    const float inv = 1.f / (9.f * (float)HW);
+    float s[1] = {0.f};
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[0] += (float)v[cl][r][e];  // (pieces past the end were loaded as zeros)
+    gn_block_sum_all<1>(s, smem);
+    const float mean = s[0] * inv;
+    float q[1] = {0.f};
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = 8 * (r * NT + t);
+#pragma unroll
+        for (int cl = 0; cl < 9; ++cl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)v[cl][r][e] - mean;
+                if (p + e < HW) q[0] += d * d;
+            }
+    }
+    gn_block_sum_all<1>(q, smem);
+    const float rstd = 1.f / sqrtf(q[0] * inv + eps);
+    if (t == 0) {
+        mean_out[blockIdx.x] = mean;
+        rstd_out[blockIdx.x] = rstd;
+    }
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl) {
+        const float ga = (float)gamma[g * 9 + cl] * rstd, be = (float)beta[g * 9 + cl] - mean * ga;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = 8 * (r * NT + t);
+            const bool full = 8 * (r * NT + wend) <= HW;
+            bf16_t o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)v[cl][r][e] * ga + be);
+            if (p < HW) store_piece<8, AL>(y + base + (int64_t)cl * HW + p, o, HW - p, full);
+        }
+    }
+}
+
+template <int NT, int R, int AL>
+__global__ void __launch_bounds__(NT)
+gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean_in,
+               const float* __restrict__ rstd_in, const bf16_t* __restrict__ gamma, bf16_t* __restrict__ dx,
+               float* __restrict__ part, int G, int HW) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    float* smem = reinterpret_cast<float*>(cot_smem);
+    const int t = threadIdx.x, g = blockIdx.x % G;
+    const int wend = 64 * (uniform(t >> 6) + 1);
+    const int64_t base = (int64_t)blockIdx.x * 9 * HW;
+    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    bf16_t xv[9][R][8], gv[9][R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = 8 * (r * NT + t);
+        const bool full = 8 * (r * NT + wend) <= HW;
+#pragma unroll
+        for (int cl = 0; cl < 9; ++cl) {
+            load_piece<8, AL>(xv[cl][r], x + base + (int64_t)cl * HW + p, HW - p, full);
+            load_piece<8, AL>(gv[cl][r], dy + base + (int64_t)cl * HW + p, HW - p, full);
+        }
+    }
+    float s[18];  // per channel: sum dy, sum dy * xhat   (dy past the end was loaded as zero)
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)gv[cl][r][e];
+                a += d;
+                b += d * (((float)xv[cl][r][e] - mean) * rstd);
+            }
+        s[2 * cl] = a;
+        s[2 * cl + 1] = b;
+    }
+    gn_block_sum_all<18>(s, smem);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl) {
+        const float ga = (float)gamma[g * 9 + cl];
+        c1 += ga * s[2 * cl];
+        c2 += ga * s[2 * cl + 1];
+    }
+    const float inv = 1.f / (9.f * (float)HW);
+    c1 *= inv;
+    c2 *= inv;
+    if (t < 18) part[(int64_t)blockIdx.x * 18 + t] = s[t];
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl) {
+        const float ga = (float)gamma[g * 9 + cl];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = 8 * (r * NT + t);
+            const bool full = 8 * (r * NT + wend) <= HW;
+            bf16_t o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = ((float)xv[cl][r][e] - mean) * rstd;
+                o[e] = (bf16_t)(rstd * (ga * (float)gv[cl][r][e] - c1 - xh * c2));
+            }
+            if (p < HW) store_piece<8, AL>(dx + base + (int64_t)cl * HW + p, o, HW - p, full);
+        }
+    }
+}
+
+// dgamma[c] = sum_n part[n][c].dy_xhat, dbeta[c] = sum_n part[n][c].dy      part is [N][G*9][2]
+__global__ void gn9_bwd_params_kernel(const float* __restrict__ part, bf16_t* __restrict__ dgamma,
+                                      bf16_t* __restrict__ dbeta, int N, int Ctot) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Ctot) return;
+    float a = 0.f, b = 0.f;
+    for (int n = 0; n < N; ++n) {
+        a += part[((int64_t)n * Ctot + c) * 2];
+        b += part[((int64_t)n * Ctot + c) * 2 + 1];
+    }
+    dbeta[c] = (bf16_t)a;
+    dgamma[c] = (bf16_t)b;
+}
+
+// smallest (threads, rounds) configuration whose 8*NT*R pixels cover one channel plane; 0 = not covered
+static int gn9_config(int HW) {
+    const int need = (HW + 7) / 8;  // pieces per channel
+    if (need <= 64) return 1;
+    if (need <= 128) return 2;
+    if (need <= 256) return 3;
+    if (need <= 512) return 4;
+    if (need <= 1024) return 5;
+    return 0;  // (> 8192 pixels per plane: caller keeps torch's GroupNorm)
+}
+
+#define GN9_SWITCH(CFG, CALL)                 \
+    switch (CFG) {                            \
+        case 1: { CALL(64, 1); } break;       \
+        case 2: { CALL(64, 2); } break;       \
+        case 3: { CALL(256, 1); } break;      \
+        case 4: { CALL(256, 2); } break;      \
+        default: { CALL(1024, 1); } break;    \
+    }
+
+int gn9_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N, int C,
+                int HW, float eps, hipStream_t stream) {
+    const int cfg = gn9_config(HW), G = C / 9;
+    if (!cfg) return COT_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((int64_t)N * G));
+#define GN9_FWD(NT_, R_)                                                                                             \
+    if (HW % 8 == 0)                                                                                                 \
+        COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 16>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma, \
+                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps);                                         \
+    else                                                                                                             \
+        COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 2>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma,  \
+                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps)
+    GN9_SWITCH(cfg, GN9_FWD)
+#undef GN9_FWD
+    return check_launch("gn9_fwd_kernel");
+}
+
+int gn9_backward(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, void* dx,
+                 void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, hipStream_t stream) {
+    const int cfg = gn9_config(HW), G = C / 9;
+    if (!cfg) return COT_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((int64_t)N * G));
+#define GN9_BWD(NT_, R_)                                                                                             \
+    if (HW % 8 == 0)                                                                                                 \
+        COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 16>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,    \
+                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW);                                 \
+    else                                                                                                             \
+        COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 2>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,     \
+                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW)
+    GN9_SWITCH(cfg, GN9_BWD)
+#undef GN9_BWD
+    int rc = check_launch("gn9_bwd_kernel");
+    if (rc) return rc;
+    COT_LAUNCH(gn9_bwd_params_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, (const float*)workspace,
+               (bf16_t*)dgamma, (bf16_t*)dbeta, N, C);
+    return check_launch("gn9_bwd_params_kernel");
+}
+
+}  // namespace cot

@@ -199,6 +199,19 @@ int cot_radix_mix_backward_reduce(const void* gout, const void* y, const void* k
 int cot_radix_mix_backward_apply(const void* gout, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C,
                                  int HW, int dtype, void* stream);
 
+/* ---- GroupNorm with 9 channels per group, NCHW, COT_BF16 (CotLayer.embed[4] =
+ * nn.GroupNorm(dim/8, 9*dim/8), models/cotnet.py:56 -- the normalisation of the 3x3 attention logits; its output is the
+ * aggregation's weight tensor).  One (image, group) is a contiguous run of 9*HW elements that one workgroup keeps in
+ * registers: forward = 1 read + 1 write, backward = 2 reads + 1 write + a tiny batch reduction.
+ *   y = (x - mean_g) * rstd_g * gamma[c] + beta[c];  mean / rstd: fp32 [N * C/9], written by forward, read by backward
+ *   gamma / beta / dgamma / dbeta: [C] in the storage dtype;  workspace (backward): N*C*2 floats
+ * HW > 8192 returns COT_ERR_UNSUPPORTED (caller keeps torch's GroupNorm). */
+int cot_group_norm9_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N,
+                            int C, int HW, float eps, int dtype, void* stream);
+int cot_group_norm9_backward(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma,
+                             void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int dtype,
+                             void* stream);
+
 /* ---- fused SGD over a flat parameter bucket (replaces torch.optim.SGD(nesterov=True),
  * optim/optim_factory.py:54-56, which launches per parameter tensor):
  *     g = grad*grad_scale + weight_decay*p;  buf = momentum*buf + g;  p -= lr*(nesterov ? g + momentum*buf : buf)

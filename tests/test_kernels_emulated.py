@@ -698,3 +698,46 @@ def test_radix_tail_channel_major_kernels(N, C, H, W, dtype):
     add = (ggapT.float().t() / HW)[:, :, None, None]
     assert torch.allclose(gy.float(), yf.grad + add, atol=3 * tol, rtol=3 * tol)
     assert torch.allclose(gk.float(), kf.grad + add, atol=3 * tol, rtol=3 * tol)
+
+
+@pytest.mark.parametrize("N,G,H,W", [(2, 2, 8, 8), (1, 3, 24, 24), (2, 1, 14, 14), (3, 2, 7, 7), (1, 1, 40, 40),
+                                     (1, 1, 56, 56), (1, 2, 3, 5)])
+def test_group_norm9_kernels(N, G, H, W):
+    """cot_group_norm9_forward / _backward against torch's GroupNorm in fp32 on the same bf16-rounded operands"""
+    torch.manual_seed(13)
+    C, HW = 9 * G, H * W
+    dt = _lib.dtype_code(torch.bfloat16)
+    x = (torch.randn(N, C, H, W) * 1.7 + 0.6).bfloat16()
+    gamma, beta = (1 + 0.3 * torch.randn(C)).bfloat16(), (0.2 * torch.randn(C)).bfloat16()
+    dy = torch.randn(N, C, H, W).bfloat16()
+    xf, gf, bf = x.float().requires_grad_(True), gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
+    yr = torch.nn.functional.group_norm(xf, G, gf, bf, 1e-5)
+    yr.backward(dy.float())
+
+    y = torch.full_like(x, float("nan"))
+    mean, rstd = torch.empty(N * G), torch.empty(N * G)
+    rc = _EMUL.cot_group_norm9_forward(P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, C, HW, 1e-5, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(y.float(), yr.detach(), atol=2e-2, rtol=2e-2)
+    xg = x.float().view(N, G, -1)
+    assert torch.allclose(mean, xg.mean(2).flatten(), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(rstd, (xg.var(2, unbiased=False) + 1e-5).rsqrt().flatten(), atol=1e-4, rtol=1e-4)
+
+    dx, dg, db = torch.full_like(x, float("nan")), torch.empty(C).bfloat16(), torch.empty(C).bfloat16()
+    ws = torch.empty(N * C * 2)
+    rc = _EMUL.cot_group_norm9_backward(P(dy), P(x), P(mean), P(rstd), P(gamma), P(dx), P(dg), P(db), P(ws), N, C, HW, dt,
+                                        None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(dx.float(), xf.grad, atol=3e-2, rtol=3e-2), (dx.float() - xf.grad).abs().max()
+    assert (dg.float() - gf.grad).abs().max() <= 1e-2 * gf.grad.abs().max() + 1e-2
+    assert (db.float() - bf.grad).abs().max() <= 1e-2 * bf.grad.abs().max() + 1e-2
+
+
+def test_group_norm9_rejects_what_it_does_not_cover():
+    x = torch.zeros(1, 9, 4, 4).bfloat16()
+    m = torch.zeros(1)
+    g = torch.zeros(9).bfloat16()
+    dt = _lib.dtype_code(torch.bfloat16)
+    assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 8, 16, 1e-5, dt, None) == -1      # C % 9
+    assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 9, 16, 1e-5, 0, None) == -2       # fp32
+    assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 9, 9000, 1e-5, dt, None) == -2    # too large
