@@ -105,187 +105,199 @@ def _plan(layer):
     return p
 
 
-def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act):
+def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act, residual=None):
     """stats: fp32 [2*C + workspace] -> mean = stats[:C], rstd = stats[C:2C]"""
-    _ck(L.cot_bn_act_forward(_p(x), None, _p(y), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
+    _ck(L.cot_bn_act_forward(_p(x), _p(residual), _p(y), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
                              _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _p(stats[nws_off:]),
                              N, C, HW, float(bn.eps), float(bn.momentum), act, BF16, _stream()), "cot_bn_act_forward")
 
 
-def _bn_bwd(L, dy, x, y, dx, bn, stats, N, C, HW, act, nws):
+def _bn_bwd(L, dy, x, y, dx, bn, stats, N, C, HW, act, nws, dres=None):
     """-> (dgamma, dbeta) views of one fp32 scratch"""
     scratch = torch.empty(2 * C + nws, dtype=torch.float32, device=dy.device)
-    _ck(L.cot_bn_act_backward(_p(dy), _p(x), _p(y), _p(dx), None, _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
+    _ck(L.cot_bn_act_backward(_p(dy), _p(x), _p(y), _p(dx), _p(dres), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
                               _p(scratch), _p(scratch[C:]), _p(scratch[2 * C:]), N, C, HW, act, BF16, _stream()),
         "cot_bn_act_backward")
     return scratch[:C], scratch[C:2 * C]
 
 
+def _cot_forward(L, layer, x):
+    """the layer's forward on the library kernels -> (out, tensors to keep for backward, aggregation geometry)"""
+    N, C, H, W = x.shape
+    HW, Ch, Ce = H * W, C // 2, 9 * C // 8
+    dev = x.device
+    pl = _plan(layer)
+    A = pl.se0.out_channels
+    ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    masks = _masks(L, H, W, dev)
+    st = _stream()
+    new = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
+    stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
+
+    # static context k = relu(bn(conv3x3_grouped(x)))                                             (ref :80)
+    k_pre, k = new(C), new(C)
+    _ck(L.cot_conv3x3g_forward(_p(x), _p(pl.ke0.weight), _p(k_pre), _p(masks), _p(ws), N, C, C, pl.ke0.groups, H, W,
+                               BF16, st), "cot_conv3x3g_forward")
+    s_k = stat(C, nws_c)
+    _bn_fwd(L, k_pre, k, pl.ke1, s_k, 2 * C, N, C, HW, 1)
+    # attention logits from [x | k]                                                             (ref :81-85)
+    e0, e1 = new(Ch), new(Ch)
+    _ck(L.cot_conv1x1_forward(_p(x), _p(k), C, _p(pl.em0.weight), None, _p(e0), N, 2 * C, Ch, HW, BF16, st),
+        "cot_conv1x1_forward")
+    s_e = stat(Ch, nws_h)
+    _bn_fwd(L, e0, e1, pl.em1, s_e, 2 * Ch, N, Ch, HW, 1)
+    e3 = new(Ce)
+    _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, HW, BF16, st),
+        "cot_conv1x1_forward")
+    gn = pl.gn
+    if HW <= 8192:  # one (image, group) fits a workgroup's registers: 1 read + 1 write (csrc/group_norm9.hip)
+        w = new(Ce)
+        gn_mean = torch.empty(2 * N * gn.num_groups, dtype=torch.float32, device=dev)
+        gn_rstd = gn_mean[N * gn.num_groups:]
+        _ck(L.cot_group_norm9_forward(_p(e3), _p(gn.weight), _p(gn.bias), _p(w), _p(gn_mean), _p(gn_rstd), N, Ce, HW,
+                                      float(gn.eps), BF16, st), "cot_group_norm9_forward")
+    else:
+        w, gn_mean, gn_rstd = torch.native_group_norm(e3, gn.weight, gn.bias, N, Ce, HW, gn.num_groups, gn.eps)
+    # values                                                                                     (ref :87)
+    v_pre, v = new(C), new(C)
+    _ck(L.cot_conv1x1_forward(_p(x), None, C, _p(pl.cv0.weight), None, _p(v_pre), N, C, C, HW, BF16, st),
+        "cot_conv1x1_forward")
+    s_v = stat(C, nws_c)
+    _bn_fwd(L, v_pre, v, pl.cv1, s_v, 2 * C, N, C, HW, 0)
+    # local aggregation, bn + swish                                                              (ref :88-90)
+    geom = _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
+    a, y = new(C), new(C)
+    _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
+    s_y = stat(C, nws_c)
+    _bn_fwd(L, a, y, pl.bn, s_y, 2 * C, N, C, HW, 2)
+    # radix-2 split attention                                                                    (ref :92-104)
+    # descriptors are kept channel-major ([C][N]) so that the se branch runs on the 1x1-convolution / BatchNorm
+    # kernels with the batch as the pixel axis
+    row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
+    gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
+    _ck(L.cot_radix_gap_t(_p(y), _p(k), _p(gapT), N, C, HW, BF16, st), "cot_radix_gap_t")
+    _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st),
+        "cot_conv1x1_forward")
+    s_a = stat(A, nws_a)
+    _bn_fwd(L, hpre, h, pl.sebn, s_a, 2 * A, 1, A, N, 1)
+    _ck(L.cot_conv1x1_forward(_p(h), None, A, _p(pl.se3.weight), _p(pl.se3.bias), _p(logitsT), 1, A, 2 * C, N, BF16,
+                              st), "cot_conv1x1_forward")
+    attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
+    out = new(C)
+    _ck(L.cot_radix_mix_logits(_p(y), _p(k), _p(logitsT), _p(out), _p(attn), N, C, HW, BF16, st),
+        "cot_radix_mix_logits")
+
+    return out, (x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y, gapT, hpre, h,
+                 s_a), geom
+
+
+_N_SAVED = 22  # tensors _cot_forward hands back for the backward pass
+
+
+def _cot_backward(L, layer, saved, geom, gout):
+    """-> (dx, gradients of _Plan.params in that order)"""
+    (x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y, gapT, hpre, h,
+     s_a) = saved
+    N, C, H, W = x.shape
+    HW, Ch, Ce = H * W, C // 2, 9 * C // 8
+    dev = x.device
+    pl = _plan(layer)
+    A = pl.se0.out_channels
+    ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    masks = _masks(L, H, W, dev)
+    st = _stream()
+    ke0, ke1, em0, em1, em3, cv0, cv1 = pl.ke0, pl.ke1, pl.em0, pl.em1, pl.em3, pl.cv0, pl.cv1
+    se0, sebn, se3 = pl.se0, pl.sebn, pl.se3
+    gout = gout.contiguous()
+
+    # radix mix -> pair-softmax backward -> se branch (two 1x1 convolutions over the batch axis) -> gap
+    row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
+    glogT, gh, ggapT = row(2 * C), row(A), row(C)
+    _ck(L.cot_radix_mix_backward_reduce(_p(gout), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, BF16, st),
+        "cot_radix_mix_backward_reduce")
+    _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st),
+        "cot_conv1x1_backward_data")
+    g_w3, g_b3 = torch.empty_like(se3.weight), torch.empty_like(se3.bias)
+    _ck(L.cot_conv1x1_backward_weight(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(ws), 1, A, 2 * C, N, BF16,
+                                      st), "cot_conv1x1_backward_weight")
+    ghpre = row(A)
+    d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, h, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
+    _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st),
+        "cot_conv1x1_backward_data")
+    g_w0, g_b0 = torch.empty_like(se0.weight), torch.empty_like(se0.bias)
+    _ck(L.cot_conv1x1_backward_weight(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(ws), 1, C, A, N, BF16, st),
+        "cot_conv1x1_backward_weight")
+    gy, gk = torch.empty_like(y), torch.empty_like(k)
+    _ck(L.cot_radix_mix_backward_apply(_p(gout), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, BF16, st),
+        "cot_radix_mix_backward_apply")
+    # bn + swish, aggregation
+    ga = torch.empty_like(a)
+    d_bn_w, d_bn_b = _bn_bwd(L, gy, a, None, ga, pl.bn, s_y, N, C, HW, 2, nws_c)
+    gv, gw = torch.empty_like(v), torch.empty_like(w)
+    _ck(L.cot_agg_backward(_p(ga), _p(v), _p(w), _p(gv), _p(gw), ctypes.byref(geom), BF16, _lib.COT_NCHW, st),
+        "cot_agg_backward")
+    # values branch: bn, conv1x1 -> first contribution to dx
+    gv_pre = ga  # (reuse: ga is dead)
+    d_cv_w, d_cv_b = _bn_bwd(L, gv, v_pre, None, gv_pre, cv1, s_v, N, C, HW, 0, nws_c)
+    gx = torch.empty_like(x)
+    _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gx), None, C, 0, _p(ws), N, C, C, HW, BF16, st),
+        "cot_conv1x1_backward_data")
+    g_wv = torch.empty_like(cv0.weight)
+    _ck(L.cot_conv1x1_backward_weight(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(ws), N, C, C, HW, BF16, st),
+        "cot_conv1x1_backward_weight")
+    # logits branch: GroupNorm, conv1x1(+bias), bn+relu, conv1x1 on [x | k] -> dx +=, dk +=
+    gn = pl.gn
+    if HW <= 8192:
+        ge3, g_gn_w, g_gn_b = torch.empty_like(e3), torch.empty_like(gn.weight), torch.empty_like(gn.bias)
+        gn_ws = torch.empty(2 * N * Ce, dtype=torch.float32, device=dev)
+        _ck(L.cot_group_norm9_backward(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), _p(g_gn_w),
+                                       _p(g_gn_b), _p(gn_ws), N, Ce, HW, BF16, st), "cot_group_norm9_backward")
+    else:
+        ge3, g_gn_w, g_gn_b = torch.ops.aten.native_group_norm_backward(
+            gw, e3, gn_mean, gn_rstd, gn.weight, N, Ce, HW, gn.num_groups, [True, True, True])
+        ge3 = ge3.contiguous()
+    ge1 = torch.empty_like(e1)
+    _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), N, Ch, Ce, HW, BF16,
+                                    st), "cot_conv1x1_backward_data")
+    g_we3, g_be3 = torch.empty_like(em3.weight), torch.empty_like(em3.bias)
+    _ck(L.cot_conv1x1_backward_weight(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(ws), N, Ch, Ce, HW, BF16,
+                                      st), "cot_conv1x1_backward_weight")
+    ge0 = torch.empty_like(e0)
+    d_em_w, d_em_b = _bn_bwd(L, ge1, e0, e1, ge0, em1, s_e, N, Ch, HW, 1, nws_h)
+    _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gx), _p(gk), C, 3, _p(ws), N, 2 * C, Ch, HW, BF16,
+                                    st), "cot_conv1x1_backward_data")
+    g_we0 = torch.empty_like(em0.weight)
+    _ck(L.cot_conv1x1_backward_weight(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(ws), N, 2 * C, Ch, HW, BF16, st),
+        "cot_conv1x1_backward_weight")
+    # key branch: bn+relu, grouped 3x3 -> dx +=
+    gk_pre = gv  # (reuse: gv is dead)
+    d_ke_w, d_ke_b = _bn_bwd(L, gk, k_pre, k, gk_pre, ke1, s_k, N, C, HW, 1, nws_c)
+    G = ke0.groups
+    _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx), 1, _p(masks), _p(ws), N, C, C, G, H, W,
+                                     BF16, st), "cot_conv3x3g_backward_data")
+    g_wk = torch.empty_like(ke0.weight)
+    _ck(L.cot_conv3x3g_backward_weight(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(ws), N, C, C, G, H, W, BF16, st),
+        "cot_conv3x3g_backward_weight")
+    # order = _Plan.params
+    return gx, (g_wk, d_ke_w, d_ke_b, g_we0, d_em_w, d_em_b, g_we3, g_be3, g_gn_w, g_gn_b, g_wv, d_cv_w, d_cv_b,
+                d_bn_w, d_bn_b, g_w0, g_b0, d_sa_w, d_sa_b, g_w3, g_b3)
+
+
 class _CotLayerNode(Function):
     @staticmethod
     def forward(ctx, layer, x, *params):
-        # params (in this order) are only here so that autograd routes their gradients; values are read off `layer`
-        L = _lib.lib()
-        N, C, H, W = x.shape
-        HW, Ch, Ce = H * W, C // 2, 9 * C // 8
-        dev = x.device
-        pl = _plan(layer)
-        A = pl.se0.out_channels
-        ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        masks = _masks(L, H, W, dev)
-        st = _stream()
-        new = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
-        stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
-
-        # static context k = relu(bn(conv3x3_grouped(x)))                                             (ref :80)
-        k_pre, k = new(C), new(C)
-        _ck(L.cot_conv3x3g_forward(_p(x), _p(pl.ke0.weight), _p(k_pre), _p(masks), _p(ws), N, C, C, pl.ke0.groups, H, W,
-                                   BF16, st), "cot_conv3x3g_forward")
-        s_k = stat(C, nws_c)
-        _bn_fwd(L, k_pre, k, pl.ke1, s_k, 2 * C, N, C, HW, 1)
-        # attention logits from [x | k]                                                             (ref :81-85)
-        e0, e1 = new(Ch), new(Ch)
-        _ck(L.cot_conv1x1_forward(_p(x), _p(k), C, _p(pl.em0.weight), None, _p(e0), N, 2 * C, Ch, HW, BF16, st),
-            "cot_conv1x1_forward")
-        s_e = stat(Ch, nws_h)
-        _bn_fwd(L, e0, e1, pl.em1, s_e, 2 * Ch, N, Ch, HW, 1)
-        e3 = new(Ce)
-        _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, HW, BF16, st),
-            "cot_conv1x1_forward")
-        gn = pl.gn
-        if HW <= 8192:  # one (image, group) fits a workgroup's registers: 1 read + 1 write (csrc/group_norm9.hip)
-            w = new(Ce)
-            gn_mean = torch.empty(2 * N * gn.num_groups, dtype=torch.float32, device=dev)
-            gn_rstd = gn_mean[N * gn.num_groups:]
-            _ck(L.cot_group_norm9_forward(_p(e3), _p(gn.weight), _p(gn.bias), _p(w), _p(gn_mean), _p(gn_rstd), N, Ce, HW,
-                                          float(gn.eps), BF16, st), "cot_group_norm9_forward")
-        else:
-            w, gn_mean, gn_rstd = torch.native_group_norm(e3, gn.weight, gn.bias, N, Ce, HW, gn.num_groups, gn.eps)
-        # values                                                                                     (ref :87)
-        v_pre, v = new(C), new(C)
-        _ck(L.cot_conv1x1_forward(_p(x), None, C, _p(pl.cv0.weight), None, _p(v_pre), N, C, C, HW, BF16, st),
-            "cot_conv1x1_forward")
-        s_v = stat(C, nws_c)
-        _bn_fwd(L, v_pre, v, pl.cv1, s_v, 2 * C, N, C, HW, 0)
-        # local aggregation, bn + swish                                                              (ref :88-90)
-        geom = _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
-        a, y = new(C), new(C)
-        _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
-        s_y = stat(C, nws_c)
-        _bn_fwd(L, a, y, pl.bn, s_y, 2 * C, N, C, HW, 2)
-        # radix-2 split attention                                                                    (ref :92-104)
-        # descriptors are kept channel-major ([C][N]) so that the se branch runs on the 1x1-convolution / BatchNorm
-        # kernels with the batch as the pixel axis
-        row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
-        gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
-        _ck(L.cot_radix_gap_t(_p(y), _p(k), _p(gapT), N, C, HW, BF16, st), "cot_radix_gap_t")
-        _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st),
-            "cot_conv1x1_forward")
-        s_a = stat(A, nws_a)
-        _bn_fwd(L, hpre, h, pl.sebn, s_a, 2 * A, 1, A, N, 1)
-        _ck(L.cot_conv1x1_forward(_p(h), None, A, _p(pl.se3.weight), _p(pl.se3.bias), _p(logitsT), 1, A, 2 * C, N, BF16,
-                                  st), "cot_conv1x1_forward")
-        attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
-        out = new(C)
-        _ck(L.cot_radix_mix_logits(_p(y), _p(k), _p(logitsT), _p(out), _p(attn), N, C, HW, BF16, st),
-            "cot_radix_mix_logits")
-
+        # params (_Plan.params) are only here so that autograd routes their gradients; values are read off `layer`
+        out, saved, geom = _cot_forward(_lib.lib(), layer, x)
         ctx.layer, ctx.geom = layer, geom
-        ctx.save_for_backward(x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y,
-                              gapT, hpre, h, s_a)
+        ctx.save_for_backward(*saved)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        (x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y, gapT, hpre, h,
-         s_a) = ctx.saved_tensors
-        layer, geom = ctx.layer, ctx.geom
-        L = _lib.lib()
-        N, C, H, W = x.shape
-        HW, Ch, Ce = H * W, C // 2, 9 * C // 8
-        dev = x.device
-        pl = _plan(layer)
-        A = pl.se0.out_channels
-        ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        masks = _masks(L, H, W, dev)
-        st = _stream()
-        ke0, ke1, em0, em1, em3, cv0, cv1 = pl.ke0, pl.ke1, pl.em0, pl.em1, pl.em3, pl.cv0, pl.cv1
-        se0, sebn, se3 = pl.se0, pl.sebn, pl.se3
-        gout = gout.contiguous()
-
-        # radix mix -> pair-softmax backward -> se branch (two 1x1 convolutions over the batch axis) -> gap
-        row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
-        glogT, gh, ggapT = row(2 * C), row(A), row(C)
-        _ck(L.cot_radix_mix_backward_reduce(_p(gout), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, BF16, st),
-            "cot_radix_mix_backward_reduce")
-        _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st),
-            "cot_conv1x1_backward_data")
-        g_w3, g_b3 = torch.empty_like(se3.weight), torch.empty_like(se3.bias)
-        _ck(L.cot_conv1x1_backward_weight(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(ws), 1, A, 2 * C, N, BF16,
-                                          st), "cot_conv1x1_backward_weight")
-        ghpre = row(A)
-        d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, h, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
-        _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st),
-            "cot_conv1x1_backward_data")
-        g_w0, g_b0 = torch.empty_like(se0.weight), torch.empty_like(se0.bias)
-        _ck(L.cot_conv1x1_backward_weight(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(ws), 1, C, A, N, BF16, st),
-            "cot_conv1x1_backward_weight")
-        gy, gk = torch.empty_like(y), torch.empty_like(k)
-        _ck(L.cot_radix_mix_backward_apply(_p(gout), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, BF16, st),
-            "cot_radix_mix_backward_apply")
-        # bn + swish, aggregation
-        ga = torch.empty_like(a)
-        d_bn_w, d_bn_b = _bn_bwd(L, gy, a, None, ga, pl.bn, s_y, N, C, HW, 2, nws_c)
-        gv, gw = torch.empty_like(v), torch.empty_like(w)
-        _ck(L.cot_agg_backward(_p(ga), _p(v), _p(w), _p(gv), _p(gw), ctypes.byref(geom), BF16, _lib.COT_NCHW, st),
-            "cot_agg_backward")
-        # values branch: bn, conv1x1 -> first contribution to dx
-        gv_pre = ga  # (reuse: ga is dead)
-        d_cv_w, d_cv_b = _bn_bwd(L, gv, v_pre, None, gv_pre, cv1, s_v, N, C, HW, 0, nws_c)
-        gx = torch.empty_like(x)
-        _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gx), None, C, 0, _p(ws), N, C, C, HW, BF16, st),
-            "cot_conv1x1_backward_data")
-        g_wv = torch.empty_like(cv0.weight)
-        _ck(L.cot_conv1x1_backward_weight(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(ws), N, C, C, HW, BF16, st),
-            "cot_conv1x1_backward_weight")
-        # logits branch: GroupNorm, conv1x1(+bias), bn+relu, conv1x1 on [x | k] -> dx +=, dk +=
-        gn = pl.gn
-        if HW <= 8192:
-            ge3, g_gn_w, g_gn_b = torch.empty_like(e3), torch.empty_like(gn.weight), torch.empty_like(gn.bias)
-            gn_ws = torch.empty(2 * N * Ce, dtype=torch.float32, device=dev)
-            _ck(L.cot_group_norm9_backward(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), _p(g_gn_w),
-                                           _p(g_gn_b), _p(gn_ws), N, Ce, HW, BF16, st), "cot_group_norm9_backward")
-        else:
-            ge3, g_gn_w, g_gn_b = torch.ops.aten.native_group_norm_backward(
-                gw, e3, gn_mean, gn_rstd, gn.weight, N, Ce, HW, gn.num_groups, [True, True, True])
-            ge3 = ge3.contiguous()
-        ge1 = torch.empty_like(e1)
-        _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), N, Ch, Ce, HW, BF16,
-                                        st), "cot_conv1x1_backward_data")
-        g_we3, g_be3 = torch.empty_like(em3.weight), torch.empty_like(em3.bias)
-        _ck(L.cot_conv1x1_backward_weight(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(ws), N, Ch, Ce, HW, BF16,
-                                          st), "cot_conv1x1_backward_weight")
-        ge0 = torch.empty_like(e0)
-        d_em_w, d_em_b = _bn_bwd(L, ge1, e0, e1, ge0, em1, s_e, N, Ch, HW, 1, nws_h)
-        _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gx), _p(gk), C, 3, _p(ws), N, 2 * C, Ch, HW, BF16,
-                                        st), "cot_conv1x1_backward_data")
-        g_we0 = torch.empty_like(em0.weight)
-        _ck(L.cot_conv1x1_backward_weight(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(ws), N, 2 * C, Ch, HW, BF16, st),
-            "cot_conv1x1_backward_weight")
-        # key branch: bn+relu, grouped 3x3 -> dx +=
-        gk_pre = gv  # (reuse: gv is dead)
-        d_ke_w, d_ke_b = _bn_bwd(L, gk, k_pre, k, gk_pre, ke1, s_k, N, C, HW, 1, nws_c)
-        G = ke0.groups
-        _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx), 1, _p(masks), _p(ws), N, C, C, G, H, W,
-                                         BF16, st), "cot_conv3x3g_backward_data")
-        g_wk = torch.empty_like(ke0.weight)
-        _ck(L.cot_conv3x3g_backward_weight(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(ws), N, C, C, G, H, W, BF16, st),
-            "cot_conv3x3g_backward_weight")
-        # order = _Plan.params
-        return (None, gx, g_wk, d_ke_w, d_ke_b, g_we0, d_em_w, d_em_b, g_we3, g_be3, g_gn_w, g_gn_b, g_wv, d_cv_w, d_cv_b,
-                d_bn_w, d_bn_b, g_w0, g_b0, d_sa_w, d_sa_b, g_w3, g_b3)
+        gx, gparams = _cot_backward(_lib.lib(), ctx.layer, ctx.saved_tensors, ctx.geom, gout)
+        return (None, gx) + gparams
 
 
 def _bn_static_ok(bn):
@@ -314,3 +326,153 @@ def eligible(layer, x):
 def cot_layer_forward(layer, x):
     """layer(x) through the single-node path; caller checks `eligible` first"""
     return _CotLayerNode.apply(layer, x, *_plan(layer).params)
+
+
+# ---- the whole Bottleneck (models/cotnet.py:228-264) as one node: conv1 -> bn1+relu -> CotLayer -> conv3 -> bn3 + residual
+# + relu, for the blocks without the avd pooling (13 of CoTNet-50's 16: every block but the three stride-2 ones); the
+# residual branch may carry the stage's 1x1 projection (`downsample` = [Identity,] conv1x1, BatchNorm).  dx collects the
+# residual gradient, the projection's and conv1's data gradients inside the kernels (`accumulate`).
+class _BlockPlan:
+    __slots__ = ("conv1", "bn1", "cot", "conv3", "bn3", "ds_conv", "ds_bn", "params", "static_ok")
+
+    def __init__(self, blk):
+        from .cotnet import CotLayer
+        self.conv1, self.bn1, self.cot, self.conv3, self.bn3 = blk.conv1, blk.bn1, blk.conv2, blk.conv3, blk.bn3
+        ds = blk.downsample
+        self.ds_conv = self.ds_bn = None
+        ds_ok = ds is None
+        if isinstance(ds, nn.Sequential) and (len(ds) == 2 or (len(ds) == 3 and isinstance(ds[0], nn.Identity))):
+            self.ds_conv, self.ds_bn = ds[-2], ds[-1]  # models/resnet.py:364-394: [pool,] conv, norm
+            ds_ok = _conv_ok(ds[-2], 1, 1) and ds[-2].bias is None and _bn_static_ok(ds[-1])
+        self.static_ok = (
+            ds_ok and isinstance(blk.conv2, CotLayer) and blk.avd is None and blk.drop_block is None
+            and blk.drop_path is None and blk.se is None and isinstance(blk.act1, nn.ReLU)
+            and isinstance(blk.act3, nn.ReLU) and _conv_ok(blk.conv1, 1, 1) and blk.conv1.bias is None
+            and _conv_ok(blk.conv3, 1, 1) and blk.conv3.bias is None and _bn_static_ok(blk.bn1)
+            and _bn_static_ok(blk.bn3) and blk.conv1.in_channels % 8 == 0 and blk.conv3.out_channels % 8 == 0
+            and _plan(blk.conv2).static_ok)
+        self.params = [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias] + _plan(blk.conv2).params + \
+            [blk.conv3.weight, blk.bn3.weight, blk.bn3.bias] + \
+            ([self.ds_conv.weight, self.ds_bn.weight, self.ds_bn.bias] if self.ds_conv is not None else [])
+
+
+def _block_plan(blk):
+    p = blk.__dict__.get("_cot_block_plan")
+    if p is None:
+        p = blk.__dict__["_cot_block_plan"] = _BlockPlan(blk)
+    return p
+
+
+_BSIZES = {}
+
+
+def _block_sizes(L, N, Cin, Cw, Cout, HW):
+    k = (N, Cin, Cw, Cout, HW)
+    v = _BSIZES.get(k)
+    if v is None:
+        ws = max(int(L.cot_conv1x1_workspace(N, Cin, Cw, HW, 0)), int(L.cot_conv1x1_workspace(N, Cw, Cout, HW, 0)),
+                 int(L.cot_conv1x1_workspace(N, Cin, Cout, HW, 0)))
+        v = _BSIZES[k] = (ws, int(L.cot_bn_act_workspace(N, Cw)), int(L.cot_bn_act_workspace(N, Cout)))
+    return v
+
+
+class _BottleneckNode(Function):
+    @staticmethod
+    def forward(ctx, blk, x, *params):
+        L = _lib.lib()
+        bp = _block_plan(blk)
+        N, Cin, H, W = x.shape
+        HW, Cw, Cout = H * W, bp.conv1.out_channels, bp.conv3.out_channels
+        dev, st = x.device, _stream()
+        ws_bytes, nws_w, nws_o = _block_sizes(L, N, Cin, Cw, Cout, HW)
+        new = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
+        stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
+        c1, a1 = new(Cw), new(Cw)
+        _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(bp.conv1.weight), None, _p(c1), N, Cin, Cw, HW, BF16, st),
+            "cot_conv1x1_forward")
+        s_1 = stat(Cw, nws_w)
+        _bn_fwd(L, c1, a1, bp.bn1, s_1, 2 * Cw, N, Cw, HW, 1)
+        cot_out, saved, geom = _cot_forward(L, bp.cot, a1)
+        c3, y = new(Cout), new(Cout)
+        _ck(L.cot_conv1x1_forward(_p(cot_out), None, Cw, _p(bp.conv3.weight), None, _p(c3), N, Cw, Cout, HW, BF16, st),
+            "cot_conv1x1_forward")
+        if bp.ds_conv is not None:  # projection shortcut: bn(conv1x1(x))
+            d0, res = new(Cout), new(Cout)
+            _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(bp.ds_conv.weight), None, _p(d0), N, Cin, Cout, HW, BF16, st),
+                "cot_conv1x1_forward")
+            s_d = stat(Cout, nws_o)
+            _bn_fwd(L, d0, res, bp.ds_bn, s_d, 2 * Cout, N, Cout, HW, 0)
+        else:
+            d0, res, s_d = None, x, None
+        s_3 = stat(Cout, nws_o)
+        _bn_fwd(L, c3, y, bp.bn3, s_3, 2 * Cout, N, Cout, HW, 1, residual=res)
+        ctx.blk, ctx.geom, ctx.has_ds = blk, geom, bp.ds_conv is not None
+        extra = (x, c1, a1, s_1, cot_out, c3, y, s_3) + ((d0, s_d) if bp.ds_conv is not None else ())
+        ctx.save_for_backward(*(saved + extra))
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        blk = ctx.blk
+        bp = _block_plan(blk)
+        t = ctx.saved_tensors
+        saved, extra = t[:_N_SAVED], t[_N_SAVED:]
+        x, c1, a1, s_1, cot_out, c3, y, s_3 = extra[:8]
+        N, Cin, H, W = x.shape
+        HW, Cw, Cout = H * W, bp.conv1.out_channels, bp.conv3.out_channels
+        dev, st = x.device, _stream()
+        ws_bytes, nws_w, nws_o = _block_sizes(L, N, Cin, Cw, Cout, HW)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        gout = gout.contiguous()
+        # bn3 + residual + relu: dx of the normalisation and the residual's gradient in one pass
+        g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
+        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, bp.bn3, s_3, N, Cout, HW, 1, nws_o, dres=g_res)
+        g_cot_out = torch.empty_like(cot_out)
+        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_cot_out), None, Cw, 0, _p(ws), N, Cw, Cout, HW,
+                                        BF16, st), "cot_conv1x1_backward_data")
+        g_w3 = torch.empty_like(bp.conv3.weight)
+        _ck(L.cot_conv1x1_backward_weight(_p(g_c3), _p(cot_out), None, Cw, _p(g_w3), None, _p(ws), N, Cw, Cout, HW, BF16,
+                                          st), "cot_conv1x1_backward_weight")
+        g_a1, g_cot = _cot_backward(L, bp.cot, saved, ctx.geom, g_cot_out)
+        g_c1 = g_cot_out  # (reuse: consumed by the layer's backward)
+        d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1, c1, a1, g_c1, bp.bn1, s_1, N, Cw, HW, 1, nws_w)
+        g_ds = ()
+        if ctx.has_ds:
+            d0, s_d = extra[8], extra[9]
+            g_d0 = g_c3  # (reuse: consumed by conv3's backward)
+            d_ds_w, d_ds_b = _bn_bwd(L, g_res, d0, None, g_d0, bp.ds_bn, s_d, N, Cout, HW, 0, nws_o)
+            gx = torch.empty_like(x)
+            _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(gx), None, Cin, 0, _p(ws), N, Cin, Cout,
+                                            HW, BF16, st), "cot_conv1x1_backward_data")
+            g_wd = torch.empty_like(bp.ds_conv.weight)
+            _ck(L.cot_conv1x1_backward_weight(_p(g_d0), _p(x), None, Cin, _p(g_wd), None, _p(ws), N, Cin, Cout, HW, BF16,
+                                              st), "cot_conv1x1_backward_weight")
+            g_ds = (g_wd, d_ds_w, d_ds_b)
+        else:
+            gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
+        _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16,
+                                        st), "cot_conv1x1_backward_data")
+        g_w1 = torch.empty_like(bp.conv1.weight)
+        _ck(L.cot_conv1x1_backward_weight(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(ws), N, Cin, Cw, HW, BF16, st),
+            "cot_conv1x1_backward_weight")
+        return (None, gx, g_w1, d_bn1_w, d_bn1_b) + g_cot + (g_w3, d_bn3_w, d_bn3_b) + g_ds
+
+
+def block_eligible(blk, x):
+    """training-mode cotnet.Bottleneck (no avd pooling, no drop-block/path) whose CotLayer is eligible"""
+    if not (ENABLED and blk.training and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4
+            and x.dtype == torch.bfloat16 and x.is_contiguous() and x.data_ptr() % 16 == 0):
+        return False
+    bp = _block_plan(blk)
+    if not (bp.static_ok and x.shape[1] == bp.conv1.in_channels and bp.conv1.weight.dtype == torch.bfloat16
+            and bp.conv3.weight.dtype == torch.bfloat16 and bp.bn1.weight.dtype == torch.float32 and bp.bn1.training
+            and (bp.ds_conv is not None or bp.conv1.in_channels == bp.conv3.out_channels)):
+        return False
+    pl = _plan(bp.cot)
+    return (pl.ke0.weight.dtype == torch.bfloat16 and pl.em3.weight.dtype == torch.bfloat16
+            and pl.gn.weight.dtype == torch.bfloat16 and pl.bn.weight.dtype == torch.float32 and pl.bn.training)
+
+
+def block_forward(blk, x):
+    return _BottleneckNode.apply(blk, x, *_block_plan(blk).params)

@@ -232,6 +232,8 @@ class Bottleneck(nn.Module):
         nn.init.zeros_(self.bn3.weight)
 
     def forward(self, x):
+        if cot_layer_fused.ENABLED and cot_layer_fused.block_eligible(self, x):
+            return cot_layer_fused.block_forward(self, x)  # the whole block as one autograd node (opt-in)
         residual = x
         a1, a3 = act_name(self.act1), act_name(self.act3)
         fusable = self.drop_block is None and a1 is not False and a3 is not False

@@ -2,11 +2,12 @@
 //
 // Lets the product's .hip sources be compiled as plain host C++ (amdclang++ -x c++) so that the kernels'
 // index arithmetic can be exercised against the oracle in the GPU-less build container before spending
-// MI355X time.  A launch runs on 64 host threads = the 64 lanes of a wavefront; the threads walk the grid's
-// waves in the same order, so cross-lane primitives (DPP wave shifts, __shfl_up/down) can be emulated with a
-// shared slot array + two barriers.  Never shipped, never loaded by cotnet_amd/.
+// MI355X time.  Every lane of a workgroup runs as a user-space coroutine (see namespace emul), so cross-lane
+// primitives (DPP wave shifts, __shfl_up/down, MFMA, __syncthreads) keep their lock-step meaning.
+// Never shipped, never loaded by cotnet_amd/.
 #pragma once
-#include <pthread.h>
+#include <atomic>
+#include <algorithm>
 
 #include <cmath>
 #include <cstdint>
@@ -36,31 +37,98 @@ inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 
 namespace emul {
-// One host thread per lane of a WORKGROUP (<= 1024).  All threads walk the grid's blocks in the same order, so
-// __syncthreads() is a barrier over the block's threads and the wave-level exchanges are barriers over 64 of them.
-struct WaveCtx {
-    pthread_barrier_t bar;
-    uint64_t slot[64];
-    uint64_t wide[64][4];  // MFMA operands: [lane][0..1] = A fragment (8 bf16), [lane][2..3] = B fragment
+// Execution model: every lane of a workgroup is a COROUTINE (own stack, switched in user space by a 10-instruction
+// x86-64 routine -- no syscalls); the lanes of one workgroup are scheduled round-robin by one OS thread, and a pool of OS
+// threads works through the grid's blocks.  A lane runs until it reaches a cross-lane operation (wave exchange, MFMA,
+// __syncthreads), parks there, and continues once all live lanes of its wave / block have arrived -- the same
+// lock-step guarantee the hardware gives, at ~100 ns per switch instead of a futex barrier per operation.
+extern "C" void emul_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .weak emul_switch
+    .type emul_switch,@function
+emul_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size emul_switch, .-emul_switch
+)");
+
+constexpr int kStack = 64 * 1024;
+struct Sched {
+    void* main_sp = nullptr;
+    std::vector<void*> lane_sp;
+    std::vector<char> stacks;
+    std::vector<char> done;
+    int nthreads = 0, cur = 0, live_block = 0;
+    int live_wave[16] = {0};
+    int wave_arrived[16] = {0}, block_arrived = 0;
+    uint64_t wave_gen[16] = {0}, block_gen = 0;
+    uint64_t slot[16][64];
+    uint64_t wide[16][64][4];  // MFMA operands: [lane][0..1] = A fragment (8 bf16), [lane][2..3] = B fragment
+    const std::function<void()>* body = nullptr;
 };
-struct BlockCtx {
-    pthread_barrier_t bar;
-    WaveCtx wave[16];
-};
-inline BlockCtx* g_blk = nullptr;
+inline thread_local Sched* t_sched = nullptr;
 inline thread_local int t_lane = 0, t_wave = 0;
-alignas(16) inline char g_lds[160 * 1024];
+
+inline void yield_lane() {
+    Sched& S = *t_sched;
+    emul_switch(&S.lane_sp[S.cur], S.main_sp);
+}
+inline void wave_barrier() {
+    Sched& S = *t_sched;
+    const int w = t_wave;
+    const uint64_t gen = S.wave_gen[w];
+    if (++S.wave_arrived[w] >= S.live_wave[w]) {
+        S.wave_arrived[w] = 0;
+        ++S.wave_gen[w];
+    } else {
+        while (S.wave_gen[w] == gen) yield_lane();
+    }
+}
+inline void block_barrier() {
+    Sched& S = *t_sched;
+    const uint64_t gen = S.block_gen;
+    if (++S.block_arrived >= S.live_block) {
+        S.block_arrived = 0;
+        ++S.block_gen;
+    } else {
+        while (S.block_gen == gen) yield_lane();
+    }
+}
+inline void lane_entry() {  // first frame of every coroutine
+    Sched& S = *t_sched;
+    (*S.body)();
+    const int me = S.cur, w = me >> 6;
+    S.done[me] = 1;
+    // a finished lane no longer takes part in barriers; release anybody who was only waiting for it
+    if (--S.live_wave[w] > 0 && S.wave_arrived[w] >= S.live_wave[w]) { S.wave_arrived[w] = 0; ++S.wave_gen[w]; }
+    if (--S.live_block > 0 && S.block_arrived >= S.live_block) { S.block_arrived = 0; ++S.block_gen; }
+    for (;;) yield_lane();  // never resumed again
+}
 
 template <typename V> inline V exchange(V v, int delta, V oob) {  // returns lane (l + delta)'s v, oob outside 0..63
-    WaveCtx& c = g_blk->wave[t_wave];
+    Sched& S = *t_sched;
     uint64_t bits = 0;
     std::memcpy(&bits, &v, sizeof(V));
-    c.slot[t_lane] = bits;
-    pthread_barrier_wait(&c.bar);
+    S.slot[t_wave][t_lane] = bits;
+    wave_barrier();
     const int src = t_lane + delta;
     V r = oob;
-    if (src >= 0 && src < 64) std::memcpy(&r, &c.slot[src], sizeof(V));
-    pthread_barrier_wait(&c.bar);
+    if (src >= 0 && src < 64) std::memcpy(&r, &S.slot[t_wave][src], sizeof(V));
+    wave_barrier();
     return r;
 }
 
@@ -75,10 +143,11 @@ inline float bf16_bits_to_float(uint16_t b) {
 //   C/D: lane l holds D[i = 4*(l>>4) + r][j = l&15], r = 0..3.   Every lane of the wave must make the call.
 template <typename AB, typename C> inline C mfma_16x16x32_bf16(const AB& a, const AB& b, const C& c) {
     static_assert(sizeof(AB) == 16, "8 x bf16 operand fragments");
-    WaveCtx& w = g_blk->wave[t_wave];
-    std::memcpy(&w.wide[t_lane][0], &a, 16);
-    std::memcpy(&w.wide[t_lane][2], &b, 16);
-    pthread_barrier_wait(&w.bar);
+    Sched& S = *t_sched;
+    auto& w = S.wide[t_wave];
+    std::memcpy(&w[t_lane][0], &a, 16);
+    std::memcpy(&w[t_lane][2], &b, 16);
+    wave_barrier();
     C d = c;
     const int col = t_lane & 15, rg = t_lane >> 4;
     for (int r = 0; r < 4; ++r) {
@@ -86,49 +155,83 @@ template <typename AB, typename C> inline C mfma_16x16x32_bf16(const AB& a, cons
         float sum = 0.f;
         for (int k = 0; k < 32; ++k) {
             uint16_t av, bv;
-            std::memcpy(&av, (const char*)&w.wide[row + 16 * (k >> 3)][0] + 2 * (k & 7), 2);
-            std::memcpy(&bv, (const char*)&w.wide[col + 16 * (k >> 3)][2] + 2 * (k & 7), 2);
+            std::memcpy(&av, (const char*)&w[row + 16 * (k >> 3)][0] + 2 * (k & 7), 2);
+            std::memcpy(&bv, (const char*)&w[col + 16 * (k >> 3)][2] + 2 * (k & 7), 2);
             sum += bf16_bits_to_float(av) * bf16_bits_to_float(bv);
         }
         d[r] = c[r] + sum;
     }
-    pthread_barrier_wait(&w.bar);
+    wave_barrier();
     return d;
+}
+
+inline void run_block(Sched& S, unsigned bx, unsigned by, unsigned block_threads) {
+    const int n = (int)block_threads;
+    S.nthreads = n;
+    S.lane_sp.assign(n, nullptr);
+    S.done.assign(n, 0);
+    if (S.stacks.size() < (size_t)n * kStack) S.stacks.resize((size_t)n * kStack);
+    S.live_block = n;
+    S.block_arrived = 0;
+    for (int w = 0; w < 16; ++w) {
+        S.live_wave[w] = std::max(0, std::min(64, n - 64 * w));
+        S.wave_arrived[w] = 0;
+    }
+    for (int t = 0; t < n; ++t) {  // initial frame: six callee-saved registers + return address = lane_entry
+        uintptr_t top = ((uintptr_t)(S.stacks.data() + (size_t)(t + 1) * kStack)) & ~(uintptr_t)15;
+        void** sp = (void**)top;
+        *--sp = nullptr;               // keeps (rsp + 8) % 16 == 0 at lane_entry's first instruction
+        *--sp = (void*)&lane_entry;    // `ret` target
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;
+        S.lane_sp[t] = sp;
+    }
+    blockIdx = dim3(bx, by, 0);
+    int remaining = n;
+    while (remaining > 0) {
+        remaining = 0;
+        for (int t = 0; t < n; ++t) {
+            if (S.done[t]) continue;
+            S.cur = t;
+            t_lane = t & 63;
+            t_wave = t >> 6;
+            threadIdx = dim3(t, 0, 0);
+            emul_switch(&S.main_sp, S.lane_sp[t]);
+            if (!S.done[t]) ++remaining;
+        }
+    }
 }
 
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     gridDim = grid;
     blockDim = block;
-    const unsigned nthreads = (block.x + 63) / 64 * 64, waves = nthreads / 64;
-    BlockCtx ctx;
-    pthread_barrier_init(&ctx.bar, nullptr, nthreads);
-    for (unsigned w = 0; w < waves; ++w) pthread_barrier_init(&ctx.wave[w].bar, nullptr, 64);
-    g_blk = &ctx;
-    std::vector<std::thread> threads;
-    for (unsigned t = 0; t < nthreads; ++t) {
-        threads.emplace_back([=, &body]() {
-            t_lane = t & 63;
-            t_wave = t >> 6;
-            for (unsigned by = 0; by < grid.y; ++by)
-                for (unsigned b = 0; b < grid.x; ++b) {
-                    blockIdx = dim3(b, by, 0);
-                    threadIdx = dim3(t, 0, 0);
-                    if (t < block.x) body();
-                    pthread_barrier_wait(&g_blk->bar);  // block boundary: LDS is reused by the next block
-                }
-        });
+    const unsigned nblocks = grid.x * grid.y;
+    const unsigned nworkers = std::max(1u, std::min(std::min(nblocks, std::thread::hardware_concurrency()), 16u));
+    std::atomic<unsigned> next{0};
+    auto worker = [&]() {
+        Sched S;
+        S.body = &body;
+        t_sched = &S;
+        for (;;) {
+            const unsigned b = next.fetch_add(1);
+            if (b >= nblocks) break;
+            run_block(S, b % grid.x, b / grid.x, block.x);
+        }
+        t_sched = nullptr;
+    };
+    if (nworkers == 1) {
+        worker();
+    } else {
+        std::vector<std::thread> threads;
+        for (unsigned i = 0; i < nworkers; ++i) threads.emplace_back(worker);
+        for (auto& th : threads) th.join();
     }
-    for (auto& th : threads) th.join();
-    pthread_barrier_destroy(&ctx.bar);
-    for (unsigned w = 0; w < waves; ++w) pthread_barrier_destroy(&ctx.wave[w].bar);
-    g_blk = nullptr;
 }
 }  // namespace emul
 
-inline void __syncthreads() { pthread_barrier_wait(&emul::g_blk->bar); }
+inline void __syncthreads() { emul::block_barrier(); }
 // dynamic LDS: `extern __shared__ ... char cot_smem[]` in a kernel refers to this array
-#define __shared__
-namespace cot { alignas(16) inline char cot_smem[160 * 1024]; }  // the kernels live in namespace cot
+#define __shared__ thread_local  // one workgroup at a time per OS thread
+namespace cot { alignas(16) inline thread_local char cot_smem[160 * 1024]; }  // the kernels live in namespace cot
 // async 16-byte global->LDS copy: destination = wave-uniform base + lane*16
 #define COT_ASYNC_COPY16(gptr, lds_wave_base) \
     std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)

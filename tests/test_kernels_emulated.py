@@ -741,3 +741,72 @@ def test_group_norm9_rejects_what_it_does_not_cover():
     assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 8, 16, 1e-5, dt, None) == -1      # C % 9
     assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 9, 16, 1e-5, 0, None) == -2       # fp32
     assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 9, 9000, 1e-5, dt, None) == -2    # too large
+
+
+@pytest.mark.parametrize("project", [False, True])
+def test_fused_bottleneck_node_on_emulated_kernels(project, monkeypatch):
+    """the whole cotnet.Bottleneck as one autograd node against the node-per-op path on the same emulated kernels.
+    The two forwards differ by bf16 ulps (the se branch is evaluated by different kernels), which flips a few ReLU masks
+    at bn3: gradients are therefore compared in the mean, not element by element."""
+    import copy
+    import cotnet_amd.aggregation_zeropad as az
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, radix_tail
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    from cotnet_amd.resnet import downsample_conv
+    torch.manual_seed(6)
+    N, H, W = 2, 4, 4
+    inpl = 128 if project else 256
+    ds = downsample_conv(inpl, 256, 1) if project else None
+    node = Bottleneck(inpl, 64, downsample=ds).train()
+    with torch.no_grad():
+        for p in node.parameters():
+            if p.ndim == 1:
+                p.add_(0.3 * torch.randn_like(p))
+        node.bn3.weight.fill_(0.8)
+    node = to_mixed_bf16(node)
+    perop = copy.deepcopy(node)
+    x = torch.randn(N, inpl, H, W).bfloat16()
+    g = torch.randn(N, 256, H, W).bfloat16()
+
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(c1, "MODE", "hip")
+    monkeypatch.setattr(c3, "MODE", "hip")
+    monkeypatch.setattr(az, "aggregation_zeropad",
+                        lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
+    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
+    for cache in caches:
+        cache.clear()
+
+    monkeypatch.setattr(clf, "ENABLED", False)
+    xr = x.clone().requires_grad_(True)
+    yr = perop(xr)
+    yr.backward(g)
+    monkeypatch.setattr(clf, "ENABLED", True)
+    xf = x.clone().requires_grad_(True)
+    assert clf.block_eligible(node, xf)
+    yf = node(xf)
+    assert yf.grad_fn.name().startswith("_BottleneckNode")
+    yf.backward(g)
+
+    def relmax(a, b):
+        return ((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-6)).item()
+
+    def rel(a, b):
+        return ((a.float() - b.float()).abs().mean() / (b.float().abs().mean() + 1e-6)).item()
+
+    assert relmax(yf, yr.detach()) < 1e-2
+    assert rel(xf.grad, xr.grad) < 6e-2
+    pr = dict(perop.named_parameters())
+    top = max(q.grad.float().abs().max() for q in pr.values())
+    for n_, p in node.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == p.dtype, n_
+        if pr[n_].grad.float().abs().max() > 1e-3 * top and not n_.endswith("se.0.bias"):  # (bias before a BatchNorm)
+            assert rel(p.grad, pr[n_].grad) < 0.12, (n_, rel(p.grad, pr[n_].grad))   # (a wrong term shows as > 0.3)
+    br, bf = dict(perop.named_buffers()), dict(node.named_buffers())
+    for n_ in br:
+        assert torch.allclose(bf[n_].float(), br[n_].float(), atol=1e-3, rtol=1e-3), n_
+    for cache in caches:
+        cache.clear()
