@@ -810,3 +810,63 @@ def test_fused_bottleneck_node_on_emulated_kernels(project, monkeypatch):
         assert torch.allclose(bf[n_].float(), br[n_].float(), atol=1e-3, rtol=1e-3), n_
     for cache in caches:
         cache.clear()
+
+
+def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(monkeypatch):
+    """cotnet50 (tiny input) trained one step's worth -- forward, loss, backward into the flat gradient buckets -- twice on
+    the host-emulated kernels: node-per-op with the default switches, and with every opt-in on (hand-written 1x1 / 3x3
+    convolutions, GroupNorm9, single-node CotLayer / Bottleneck).  Same function, so loss and gradients must agree up to
+    bf16 rounding noise (ReLU masks may flip: gradients are compared in the mean)."""
+    import copy
+    import cotnet_amd
+    import cotnet_amd.aggregation_zeropad as az
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, group_norm9 as g9, radix_tail
+    from cotnet_amd.data_parallel import GradBucketReducer
+    from cotnet_amd.flat_sgd import _decay_group, to_mixed_bf16
+    torch.manual_seed(21)
+    base = to_mixed_bf16(cotnet_amd.create_model("cotnet50", num_classes=10)).train()
+    x = torch.randn(4, 3, 64, 64).bfloat16()
+    target = torch.tensor([1, 7, 3, 3])
+
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail, g9):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(az, "aggregation_zeropad",
+                        lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
+    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
+
+    def run(opt_in):
+        for cache in caches:
+            cache.clear()
+        monkeypatch.setattr(clf, "ENABLED", opt_in)
+        for mod in (c1, c3, g9):
+            monkeypatch.setattr(mod, "MODE", "hip" if opt_in else "")
+        model = copy.deepcopy(base)
+        red = GradBucketReducer(model, group_fn=_decay_group, grad_mode="copy", flatten_params=True, broadcast_params=False)
+        red.zero_grad()
+        logits = model(x)
+        loss = torch.nn.functional.cross_entropy(logits.float(), target)
+        loss.backward()
+        red.finish()
+        nodes = set()
+        stack, seen = [loss.grad_fn], set()
+        while stack:
+            f = stack.pop()
+            if f is None or f in seen:
+                continue
+            seen.add(f)
+            nodes.add(f.name())
+            stack.extend(n for n, _ in f.next_functions)
+        return loss.item(), [b.flat.float().clone() for b in red.buckets], nodes, len(seen)
+
+    loss_a, grads_a, nodes_a, count_a = run(False)
+    loss_b, grads_b, nodes_b, count_b = run(True)
+    assert any(n.startswith("_BottleneckNode") for n in nodes_b) and any(n.startswith("_CotLayerNode") for n in nodes_b)
+    assert not any(n.startswith("_CotLayerNode") or n.startswith("_BottleneckNode") for n in nodes_a)
+    assert count_b < 0.6 * count_a   # the autograd graph really is that much smaller (161 of the nodes are leaves)
+    assert abs(loss_a - loss_b) < 2e-2 * abs(loss_a)
+    for ga, gb in zip(grads_a, grads_b):
+        assert torch.isfinite(gb).all()
+        assert (ga - gb).abs().mean() < 0.2 * ga.abs().mean()
+    for cache in caches:
+        cache.clear()
