@@ -98,6 +98,11 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.cot_abi_version() != 1:
             raise RuntimeError(f"libcotnet_hip.so ABI version {L.cot_abi_version()} != 1")
+        # developer knobs: COT_TUNING="12=1,9=0" -> cot_set_tuning(12, 1), cot_set_tuning(9, 0)  (include/cotnet_amd.h)
+        for item in filter(None, os.environ.get("COT_TUNING", "").split(",")):
+            k, v = item.split("=")
+            if L.cot_set_tuning(int(k), int(v)) != 0:
+                raise RuntimeError(f"COT_TUNING: {L.cot_last_error().decode()}")
         _lib = L
     return _lib
 

@@ -225,7 +225,105 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const T* __restrict__ dy, co
     }
 }
 
+
+// ---- "folded" variants (cot_set_tuning key 12): the per-channel finalize step lives in the apply kernel's prologue.
+// Grid (C, SPLIT) like the partial kernels, so the channel is block-uniform: every thread merges the SPLIT chunk
+// statistics of its channel (a few dozen flops), block (c, 0) writes mean / rstd / running statistics.  One launch less
+// per BatchNorm forward and backward (~230 launches of a CoTNet-50 step).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_apply_fwd_fold(const T* __restrict__ x, const T* __restrict__ res,
+                                                        T* __restrict__ y, const float* __restrict__ part,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        long long* __restrict__ num_batches_tracked, int N, int C, int HW,
+                                                        int nper, float eps, float momentum, int act) {
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    float n = 0.f, m = 0.f, M2 = 0.f;
+    for (int q = 0; q < split; ++q) {
+        const float* p = part + ((int64_t)c * split + q) * 4;
+        const float nb = p[0];
+        if (nb <= 0.f) continue;
+        const float delta = p[1] - m, nn = n + nb;
+        m += delta * nb / nn;
+        M2 += p[2] + delta * delta * n * nb / nn;
+        n = nn;
+    }
+    const float var = n > 0 ? M2 / n : 0.f;
+    const float r = 1.0f / sqrtf(var + eps);
+    if (s == 0 && threadIdx.x == 0) {
+        mean[c] = m;
+        rstd[c] = r;
+        if (running_mean) {
+            const float unbiased = n > 1 ? M2 / (n - 1.f) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    }
+    const float a = gamma[c] * r, b = beta[c] - m * a;
+    const int n0 = s * nper, n1 = min(N, n0 + nper);
+    const int vpp = HW / V;
+    const int64_t nvec = (int64_t)(n1 - n0) * vpp;
+    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
+        const int ni = n0 + (int)(i / vpp), v = (int)(i % vpp);
+        const int64_t off = ((int64_t)ni * C + c) * HW + (int64_t)v * V;
+        const Vec<T, V> xv = ldv<T, V>(x + off);
+        Vec<T, V> rv, o;
+        if (res) rv = ldv<T, V>(res + off);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float z = (float)xv.v[k] * a + b;
+            if (res) z += (float)rv.v[k];
+            o.v[k] = (T)act_fwd(z, act);
+        }
+        stv<T, V>(y + off, o);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ dy, const T* __restrict__ x,
+                                                        const T* __restrict__ y, T* __restrict__ dx, T* __restrict__ dres,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ part, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int N, int C, int HW, int nper,
+                                                        float inv_m, int act) {
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    float sb = 0.f, sg = 0.f;
+    for (int q = 0; q < split; ++q) {
+        sb += part[((int64_t)c * split + q) * 2];
+        sg += part[((int64_t)c * split + q) * 2 + 1];
+    }
+    if (s == 0 && threadIdx.x == 0) {
+        dbeta[c] = sb;
+        dgamma[c] = sg;
+    }
+    const float m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
+    const float k1 = sb * inv_m, k2 = sg * inv_m, gr = ga * r;
+    const int n0 = s * nper, n1 = min(N, n0 + nper);
+    const int vpp = HW / V;
+    const int64_t nvec = (int64_t)(n1 - n0) * vpp;
+    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
+        const int ni = n0 + (int)(i / vpp), v = (int)(i % vpp);
+        const int64_t off = ((int64_t)ni * C + c) * HW + (int64_t)v * V;
+        const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
+        Vec<T, V> yv, o, og;
+        if (act == ACT_RELU) yv = ldv<T, V>(y + off);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = ((float)xv.v[k] - m) * r;
+            const float g = act_bwd((float)dv.v[k], act == ACT_RELU ? (float)yv.v[k] : xh * ga + be, act);
+            o.v[k] = (T)(gr * (g - k1 - xh * k2));
+            og.v[k] = (T)g;
+        }
+        stv<T, V>(dx + off, o);
+        if (dres) stv<T, V>(dres + off, og);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
+int g_bn_fold = 0;  // cot_set_tuning key 12
 static inline int pick_vec(size_t esize, int HW) {
     int lim = (int)(16 / esize);
     for (int V = 8; V >= 1; V >>= 1)
@@ -258,6 +356,11 @@ static int bn_fwd_launch(const T* x, const T* res, T* y, const float* gamma, con
     int split, nper;
     pick_split(N, C, &split, &nper);
     hipLaunchKernelGGL((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
+    if (g_bn_fold) {
+        hipLaunchKernelGGL((bn_apply_fwd_fold<T, V>), dim3(C, split), dim3(256), 0, s, x, res, y, (const float*)ws, gamma,
+                           beta, mean, rstd, rmean, rvar, nbt, N, C, HW, nper, eps, mom, act);
+        return check_launch("bn_act_forward");
+    }
     hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
                rstd, rmean, rvar, nbt);
     const int64_t nvec = (int64_t)N * C * HW / V;
@@ -274,6 +377,11 @@ static int bn_bwd_launch(const T* dy, const T* x, const T* y, T* dx, T* dres, co
     pick_split(N, C, &split, &nper);
     hipLaunchKernelGGL((bn_bwd_reduce<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma, beta, ws, N, C, HW,
                nper, act);
+    if (g_bn_fold) {
+        hipLaunchKernelGGL((bn_apply_bwd_fold<T, V>), dim3(C, split), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma,
+                           beta, (const float*)ws, dgamma, dbeta, N, C, HW, nper, 1.0f / (float)((int64_t)N * HW), act);
+        return check_launch("bn_act_backward");
+    }
     hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
     const int64_t nvec = (int64_t)N * C * HW / V;
     hipLaunchKernelGGL((bn_apply_bwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma, beta,

@@ -91,6 +91,7 @@ template <typename T>
 int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int, int, int, int, hipStream_t);
 int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
 int bn_workspace_floats(int N, int C);
+extern int g_bn_fold;
 template <typename T>
 int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, long long*,
                    float*, int, int, int, float, float, int, hipStream_t);
@@ -239,6 +240,10 @@ int cot_agg_out_size(int in, int k, int s, int p, int d) { return out_size(in, k
 int cot_set_tuning(int key, int value) {
     if (key >= 9 && key <= 11) {
         g_conv1x1_tune[key - 9] = value;
+        return COT_OK;
+    }
+    if (key == 12) {
+        g_bn_fold = value ? 1 : 0;
         return COT_OK;
     }
     if (set_tuning_nchw(key, value) != 0) return set_error(COT_ERR_INVALID_ARG, "unknown tuning key %d", key);

@@ -28,6 +28,14 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+@pytest.fixture(autouse=True)
+def _default_knobs():
+    yield
+    if _EMUL is not None:  # process-global developer knobs back to their defaults after every test
+        _EMUL.cot_set_tuning(11, 2048)
+        _EMUL.cot_set_tuning(12, 0)
+
+
 def to_layout(t, layout):
     """NCHW-shaped CPU tensor -> dense buffer in `layout` order"""
     if layout == 0:
@@ -244,7 +252,9 @@ def test_fused_sgd_kernel_matches_torch_formula(pdt, gdt, nesterov):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act,use_res", [(0, False), (1, False), (1, True), (2, False), (0, True)])
 @pytest.mark.parametrize("N,C,H,W", [(6, 8, 7, 7), (5, 16, 14, 14), (3, 4, 8, 8)])
-def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype):
+@pytest.mark.parametrize("fold", [0, 1])
+def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold):
+    assert _EMUL.cot_set_tuning(12, fold) == 0
     """csrc/bn_act.hip (host-emulated) against torch's batch_norm + activation + residual, forward and backward"""
     g = torch.Generator().manual_seed(N * C + H)
     x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.7).to(dtype)
@@ -870,3 +880,36 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
         assert (ga - gb).abs().mean() < 0.2 * ga.abs().mean()
     for cache in caches:
         cache.clear()
+
+
+def test_whole_model_with_folded_batchnorm_finalize(monkeypatch):
+    """cot_set_tuning(12, 1) (BatchNorm finalize folded into the apply kernels) inside the single-node Bottleneck: same
+    numbers as with the separate finalize launches"""
+    import copy
+    import cotnet_amd.aggregation_zeropad as az
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, radix_tail
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    torch.manual_seed(3)
+    blk = to_mixed_bf16(Bottleneck(256, 64)).train()
+    x = torch.randn(2, 256, 6, 6).bfloat16()
+    g = torch.randn(2, 256, 6, 6).bfloat16()
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(clf, "ENABLED", True)
+    outs = []
+    for fold in (0, 1):
+        for cache in (clf._SIZES, clf._MASKS, clf._BSIZES):
+            cache.clear()
+        assert _EMUL.cot_set_tuning(12, fold) == 0
+        b = copy.deepcopy(blk)
+        xi = x.clone().requires_grad_(True)
+        y = b(xi)
+        assert y.grad_fn.name().startswith("_BottleneckNode")
+        y.backward(g)
+        outs.append((y.detach().float(), xi.grad.float(), [p.grad.float() for p in b.parameters()],
+                     [bf.float() for bf in b.buffers()]))
+    (ya, gxa, pa, ba), (yb, gxb, pb, bb) = outs
+    assert torch.equal(ya, yb) and torch.equal(gxa, gxb)     # same arithmetic, same order
+    assert all(torch.equal(u, v) for u, v in zip(pa, pb)) and all(torch.equal(u, v) for u, v in zip(ba, bb))
