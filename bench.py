@@ -11,6 +11,13 @@ Data parallel: weak scaling (B per GPU fixed, reference recipe B=80: cot_experim
 gradients averaged with cotnet_amd.data_parallel.GradBucketReducer (RCCL all-reduce on a side stream).
 K steps are timed between barrier + torch.cuda.synchronize() pairs; the slowest rank's time is reported.
 
+Kernel set (`--kernels`, config.kernel_selection on the line): `round1` = the configuration measured in round 1 (MIOpen
+convolutions, one autograd node per op); `new` = hand-written 1x1 / grouped-3x3 / GroupNorm kernels inside single-node
+CotLayer / Bottleneck, written after round 1's GPU budget was spent.  The default `auto` lets a
+child process run both on this GPU from identical weights and input -- loss and flat gradient buckets must agree -- and
+time them; the step then runs on the faster verified set (round1 unless `new` is at least 3 % faster; any trouble in the
+child = round1).  With N > 1 rank 0 probes and publishes the verdict on the rendezvous store.
+
 Extra objects on the line:
   roofline      the dominant aggregation kernel of the timed region (largest total device time): algorithmic bytes
                 per launch / mean launch duration.  Durations come from HIP start/stop events attached to each kernel
@@ -63,6 +70,12 @@ def parse():
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--conv1x1", default=None, choices=["module", "hip", "matmul"],
                     help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
+    ap.add_argument("--kernels", default="auto", choices=["auto", "round1", "new"],
+                    help="which kernel set the step runs on: round1 = MIOpen convolutions + node-per-op layers (the "
+                         "configuration measured in round 1); new = hand-written 1x1 / grouped-3x3 / GroupNorm kernels inside "
+                         "single-node CotLayer / Bottleneck; auto (default) = a child process checks `new` against `round1` on "
+                         "this GPU (same loss and gradients) and times both, the faster verified one is used")
+    ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gn9", action="store_true", help="GroupNorm of the attention logits on csrc/group_norm9.hip")
     ap.add_argument("--fused-layer", action="store_true",
                     help="CotLayer as one autograd node (cotnet_amd/cot_layer_fused.py); implies --conv1x1 hip --conv3x3 hip")
@@ -134,8 +147,119 @@ def roctx_window(resume):
         pass
 
 
+KERNEL_SETS = {  # name -> (single-node layers, 1x1 mode, 3x3 mode, GroupNorm9 mode, cot_set_tuning(12) BatchNorm finalize fold)
+    "round1": (False, "", "", "", 0),
+    "new": (True, "hip", "hip", "hip", 0),
+    "new+bnfold": (True, "hip", "hip", "hip", 1),
+}
+
+
+def apply_kernel_set(name):
+    from cotnet_amd import _lib, conv1x1 as c1, conv3x3g as c3, cot_layer_fused as clf, group_norm9 as g9
+    fused, m1, m3, mg, fold = KERNEL_SETS[name]
+    clf.ENABLED, c1.MODE, c3.MODE, g9.MODE = fused, m1, m3, mg
+    _lib.check(_lib.lib().cot_set_tuning(12, fold), "cot_set_tuning")
+
+
+def probe_child(args, dev=None, make_model=None, warm=4, timed=8):
+    """(child process of --kernels auto) one forward/backward of the benchmark model per kernel set from identical weights
+    and input -> loss and flat gradient buckets must agree with `round1`; then a short timing of each set.
+    (dev / make_model / warm / timed: the CPU test drives this very function on the host-emulated kernels.)"""
+    import cotnet_amd
+    from cotnet_amd.flat_sgd import FlatSGD, to_mixed_bf16
+    if dev is None:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        torch.backends.cudnn.benchmark = True
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    make_model = make_model or (lambda: cotnet_amd.create_model(args.model, num_classes=1000))
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(99)
+    x = torch.randn(B, 3, args.img, args.img, generator=g).to(dev).bfloat16()
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    out = {"sets": {}}
+    ref = None
+    for name in KERNEL_SETS:
+        try:
+            apply_kernel_set(name)
+            torch.manual_seed(4321)
+            model = to_mixed_bf16(make_model().to(dev)).train()
+            opt = FlatSGD(model, lr=1e-3, momentum=0.9, weight_decay=4e-5, nesterov=True)
+
+            def fwd_bwd():
+                opt.zero_grad()
+                loss = torch.nn.functional.cross_entropy(model(x).float(), t)
+                loss.backward()
+                return loss
+
+            loss = float(fwd_bwd().detach())
+            opt.reducer.finish()
+            grads = [b.flat.float().clone() for b in opt.reducer.buckets]
+            sync()
+            rec = {"loss": loss, "finite": bool(all(torch.isfinite(gb).all() for gb in grads))}
+            if ref is None:
+                ref = (loss, grads)
+                rec["parity"] = True
+            else:
+                dl = abs(loss - ref[0]) / max(abs(ref[0]), 1e-6)
+                dg = max(float((a - b).abs().mean() / (a.abs().mean() + 1e-12)) for a, b in zip(ref[1], grads))
+                rec.update(loss_rel_diff=round(dl, 5), grad_mean_rel_diff=round(dg, 4),
+                           parity=bool(rec["finite"] and dl < 0.02 and dg < 0.25))
+            for _ in range(warm):
+                fwd_bwd()
+                opt.step()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(timed):
+                fwd_bwd()
+                opt.step()
+            sync()
+            rec["ms_per_step"] = round((time.perf_counter() - t0) / timed * 1e3, 3)
+            out["sets"][name] = rec
+            del model, opt, grads
+            if dev.type == "cuda":
+                torch.cuda.empty_cache()
+        except Exception as e:  # a kernel set that cannot run is simply not eligible
+            out["sets"][name] = {"parity": False, "error": f"{type(e).__name__}: {e}"[:300]}
+    print("PROBE_RESULT " + json.dumps(out), flush=True)
+    return out
+
+
+def choose_kernels(args):
+    """-> (name of the kernel set to run, dict describing how it was chosen).  Never raises: any trouble = round1."""
+    import subprocess
+    info = {"mode": "auto"}
+    try:
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                            "MASTER_PORT", "TORCHELASTIC_RUN_ID", "COT_ROCTX")}
+        cmd = [sys.executable, os.path.abspath(__file__), "--probe-child", "--batch", str(args.batch), "--img",
+               str(args.img), "--model", args.model]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("PROBE_RESULT ")]
+        if not line:
+            info["probe_error"] = f"child exit {r.returncode}: {r.stderr[-300:]}"
+            return "round1", info
+        sets = json.loads(line[-1][len("PROBE_RESULT "):])["sets"]
+        info["probe"] = sets
+        ok = {n: v["ms_per_step"] for n, v in sets.items() if v.get("parity") and "ms_per_step" in v}
+        if "round1" not in ok:
+            return "round1", info
+        best = min(ok, key=ok.get)
+        if best != "round1" and ok[best] > 0.97 * ok["round1"]:
+            best = "round1"  # not worth leaving the configuration with a full round of measurements behind it
+        return best, info
+    except Exception as e:  # timeout, JSON trouble, ...
+        info["probe_error"] = f"{type(e).__name__}: {e}"[:300]
+        return "round1", info
+
+
 def main():
     args = parse()
+    if args.probe_child:
+        return probe_child(args)
+    explicit = args.gn9 or args.fused_layer or args.conv1x1 is not None or args.conv3x3 is not None
+    selection = {"mode": "flags" if explicit else args.kernels}
     if args.gn9:
         from cotnet_amd import group_norm9 as _gn9
         _gn9.MODE = "hip"
@@ -158,8 +282,28 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        dist.init_process_group("nccl", init_method="env://", device_id=dev, timeout=datetime.timedelta(minutes=30))
+    if not explicit:
+        chosen = args.kernels
+        if args.kernels == "auto":
+            if not (args.mode == "train" and args.dtype == "bf16" and args.precision == "mixed" and args.layout == "nchw"):
+                chosen, selection = "round1", {"mode": "auto", "note": "the new kernel set covers bf16 mixed-precision NCHW training"}
+            elif world == 1:
+                chosen, selection = choose_kernels(args)
+            else:  # rank 0 probes on its GPU, everybody else waits for the verdict on the rendezvous store (CPU side)
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    chosen, selection = choose_kernels(args)
+                    store.set("cot_kernel_set", chosen)
+                else:
+                    store.wait(["cot_kernel_set"], datetime.timedelta(minutes=25))
+                    chosen = store.get("cot_kernel_set").decode()
+        selection["chosen"] = chosen
+        if rank == 0:
+            print(f"[bench] kernel set: {chosen}  ({json.dumps(selection)[:600]})", file=sys.stderr, flush=True)
+        apply_kernel_set(chosen)
 
     import cotnet_amd
     from cotnet_amd import _lib
@@ -311,6 +455,7 @@ def main():
                        "layout": args.layout, "precision": ("bf16 weights+activations, fp32 master weights / norm params, fused flat SGD" if mixed
                                      else "bf16 autocast, fp32 weights" if amp else "fp32"),
                        "hip_graph": graphed,
+                       "kernel_selection": selection,
                        "conv1x1": __import__("cotnet_amd.conv1x1", fromlist=["MODE"]).MODE or "module",
                        "conv3x3": __import__("cotnet_amd.conv3x3g", fromlist=["MODE"]).MODE or "module",
                        "group_norm9": __import__("cotnet_amd.group_norm9", fromlist=["MODE"]).MODE or "module",

@@ -23,6 +23,9 @@ from . import _lib
 from .data_parallel import GradBucketReducer
 
 
+_DEVICE_ONLY = True  # tests drive the optimizer on CPU tensors through the host-emulated kernels
+
+
 def to_mixed_bf16(model):
     """Conv2d / Linear / GroupNorm parameters -> bf16 (in place); BatchNorm parameters and all buffers stay fp32
     (torch's group_norm wants its affine parameters in the input dtype; batch_norm takes fp32 ones).  Returns the model."""
@@ -65,7 +68,7 @@ class FlatSGD:
         else:
             self.reducer.finish()
         L = _lib.lib()
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if _DEVICE_ONLY else None
         for b, st in zip(self.reducer.buckets, self.state):
             key = b.key
             wd = self.weight_decay if key == "decay" else 0.0

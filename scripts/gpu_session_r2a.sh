@@ -14,7 +14,7 @@ tail -6 $O/r2a_pytest_gpu.log | cut -c1-300
 timeout 300 python scripts/bench_conv1x1.py --iters 20 > $O/r2a_bench_conv1x1.log 2>&1; tail -45 $O/r2a_bench_conv1x1.log | cut -c1-200
 timeout 200 python scripts/bench_conv3x3g.py --iters 20 > $O/r2a_bench_conv3x3g.log 2>&1; tail -12 $O/r2a_bench_conv3x3g.log | cut -c1-200
 # 3. the step: default (MIOpen convolutions) / hip 1x1 / hip 1x1 + 3x3 / + single-node CotLayer / + HIP graph
-B="timeout 420 python bench.py --steps 20 --warmup 8 --no-cpu-baseline"
+B="timeout 420 python bench.py --steps 20 --warmup 8 --no-cpu-baseline --kernels round1"
 $B                                              > $O/r2a_step_default.json   2> $O/r2a_step_default.err;   cut -c1-700 $O/r2a_step_default.json
 $B --conv1x1 hip                                > $O/r2a_step_c1.json        2> $O/r2a_step_c1.err;        cut -c1-700 $O/r2a_step_c1.json
 $B --conv1x1 hip --conv3x3 hip --gn9            > $O/r2a_step_c1c3.json      2> $O/r2a_step_c1c3.err;      cut -c1-700 $O/r2a_step_c1c3.json
@@ -22,6 +22,7 @@ $B --fused-layer                                > $O/r2a_step_fused.json     2> 
 COT_TUNING=12=1 $B --fused-layer                > $O/r2a_step_fused_bnfold.json 2> $O/r2a_step_fused_bnfold.err; cut -c1-700 $O/r2a_step_fused_bnfold.json
 $B --fused-layer --graph                        > $O/r2a_step_fused_graph.json 2> $O/r2a_step_fused_graph.err; cut -c1-700 $O/r2a_step_fused_graph.json
 tail -3 $O/r2a_step_fused.err | cut -c1-300
+timeout 900 python bench.py --steps 20 --warmup 8 --no-cpu-baseline > $O/r2a_step_auto.json 2> $O/r2a_step_auto.err; cut -c1-900 $O/r2a_step_auto.json; grep "kernel set" $O/r2a_step_auto.err | cut -c1-700
 # 4. which op breaks graph replay
 timeout 200 python scripts/graph_bisect.py > $O/r2a_graph_bisect.log 2>&1; cut -c1-200 $O/r2a_graph_bisect.log | tail -22
 # 5. kernel trace of the fused configuration, timed region only

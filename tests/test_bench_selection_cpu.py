@@ -1,0 +1,113 @@
+"""bench.py --kernels auto: the decision logic around the probe child (the child itself needs a GPU)."""
+import json
+import subprocess
+import types
+
+import bench
+
+
+def _args():
+    return types.SimpleNamespace(batch=80, img=224, model="cotnet50")
+
+
+def _fake_run(stdout="", returncode=0, raises=None):
+    def run(cmd, **kw):
+        assert "--probe-child" in cmd and kw.get("timeout")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR"):
+            assert k not in kw["env"]   # the child must run as a plain single-GPU process
+        if raises:
+            raise raises
+        return types.SimpleNamespace(stdout=stdout, stderr="boom", returncode=returncode)
+    return run
+
+
+def _result(**sets):
+    return "noise from a library\nPROBE_RESULT " + json.dumps({"sets": sets}) + "\n"
+
+
+def test_faster_verified_set_wins(monkeypatch):
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": True, "ms_per_step": 25.0},
+                  **{"new+bnfold": {"parity": True, "ms_per_step": 24.0}})
+    monkeypatch.setattr(subprocess, "run", _fake_run(out))
+    name, info = bench.choose_kernels(_args())
+    assert name == "new+bnfold" and info["probe"]["new"]["ms_per_step"] == 25.0
+
+
+def test_parity_failure_or_small_gain_keeps_round1(monkeypatch):
+    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": False, "ms_per_step": 20.0},
+                  **{"new+bnfold": {"parity": True, "ms_per_step": 37.5}})
+    monkeypatch.setattr(subprocess, "run", _fake_run(out))
+    assert bench.choose_kernels(_args())[0] == "round1"
+    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": False, "error": "RuntimeError: x"})
+    monkeypatch.setattr(subprocess, "run", _fake_run(out))
+    assert bench.choose_kernels(_args())[0] == "round1"
+
+
+def test_any_trouble_with_the_child_keeps_round1(monkeypatch):
+    monkeypatch.setattr(subprocess, "run", _fake_run("segfault\n", returncode=-11))
+    name, info = bench.choose_kernels(_args())
+    assert name == "round1" and "child exit -11" in info["probe_error"]
+    monkeypatch.setattr(subprocess, "run", _fake_run(raises=subprocess.TimeoutExpired("x", 900)))
+    name, info = bench.choose_kernels(_args())
+    assert name == "round1" and "TimeoutExpired" in info["probe_error"]
+    monkeypatch.setattr(subprocess, "run", _fake_run("PROBE_RESULT {not json"))
+    assert bench.choose_kernels(_args())[0] == "round1"
+    out = _result(round1={"parity": False, "error": "x"}, new={"parity": True, "ms_per_step": 20.0})
+    monkeypatch.setattr(subprocess, "run", _fake_run(out))
+    assert bench.choose_kernels(_args())[0] == "round1"
+
+
+def test_kernel_sets_apply_the_documented_switches(monkeypatch):
+    from cotnet_amd import _lib, conv1x1 as c1, conv3x3g as c3, cot_layer_fused as clf, group_norm9 as g9
+    calls = []
+
+    class Fake:
+        def cot_set_tuning(self, k, v):
+            calls.append((k, v))
+            return 0
+    monkeypatch.setattr(_lib, "lib", lambda: Fake())
+    for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE")):
+        monkeypatch.setattr(mod, attr, getattr(mod, attr))  # restored after the test
+    bench.apply_kernel_set("new+bnfold")
+    assert clf.ENABLED and c1.MODE == c3.MODE == g9.MODE == "hip" and calls[-1] == (12, 1)
+    bench.apply_kernel_set("round1")
+    assert not clf.ENABLED and c1.MODE == c3.MODE == g9.MODE == "" and calls[-1] == (12, 0)
+
+
+def test_probe_child_body_on_emulated_kernels(monkeypatch, capsys):
+    """bench.probe_child itself (what the --kernels auto child process runs on the GPU), driven on CPU tensors through the
+    host-emulated library with a two-block CoTNet: every kernel set must reproduce round1's loss and gradients"""
+    import ctypes
+    import torch
+    import cotnet_amd.aggregation_zeropad as az
+    from cotnet_amd import (_lib, conv1x1 as c1, conv3x3g as c3, cot_layer_fused as clf, flat_sgd, fused_bn,
+                            group_norm9 as g9, radix_tail)
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.resnet import ResNet
+    from tests import test_kernels_emulated as tke
+    if tke._EMUL is None:
+        import pytest
+        pytest.skip("host emulation build unavailable")
+    monkeypatch.setattr(_lib, "lib", lambda: tke._EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, flat_sgd):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE")):
+        monkeypatch.setattr(mod, attr, getattr(mod, attr))
+    monkeypatch.setattr(az, "aggregation_zeropad",
+                        lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: tke._EmulAggregation.apply(i, w))
+    for cache in (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS):
+        cache.clear()
+    args = types.SimpleNamespace(batch=4, img=32, model="unused")
+    out = bench.probe_child(args, dev=torch.device("cpu"), warm=1, timed=1,
+                            make_model=lambda: ResNet(Bottleneck, [2, 1, 1, 1], num_classes=1000))
+    assert "PROBE_RESULT " in capsys.readouterr().out
+    assert set(out["sets"]) == {"round1", "new", "new+bnfold"}
+    for name, rec in out["sets"].items():
+        assert "error" not in rec, (name, rec)
+        assert rec["parity"] and rec["finite"] and rec["ms_per_step"] > 0, (name, rec)
+    assert out["sets"]["new"]["loss_rel_diff"] < 0.02
+    tke._EMUL.cot_set_tuning(12, 0)
+    for cache in (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS):
+        cache.clear()
