@@ -41,7 +41,7 @@ template <typename P> __device__ __forceinline__ P* row_ptr(P* t1, P* t2, int c1
 template <int PXV, int MT, int AL>
 __global__ void __launch_bounds__(256, 2)
 conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, int k1, const bf16_t* __restrict__ A,
-                 const bf16_t* __restrict__ bias, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2, int m1, int K,
+                 const bf16_t* __restrict__ bias, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2, int m1, int N, int K,
                  int M, int HW, int mblocks, int ptiles, int64_t total_waves, int xcd_remap, int accumulate) {
     const int64_t wid = wave_work_id(xcd_remap);
     if (wid >= total_waves) return;
@@ -49,9 +49,8 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
     const int mb = uniform((int)(wid % mblocks));
     const int64_t t = wid / mblocks;
     const int pt = uniform((int)(t % ptiles)), n = uniform((int)(t / ptiles));
-    const int p0 = pt * (16 * PXV) + j * PXV;  // this lane's first pixel
-    const int cnt = HW - p0;                   // valid pixels from p0 on (<= 0: lane idles through the loads)
-    const bool full_px = (pt + 1) * (16 * PXV) <= HW;  // wave-uniform: every lane has all PXV pixels
+    const int P0 = pt * (16 * PXV), p0 = P0 + j * PXV;  // this lane's first pixel
+    const int cnt = HW - p0;                            // valid pixels from p0 on (<= 0: nothing to store)
     const int mbase = mb * (16 * MT);
 
     f32x4_t acc[MT][PXV];
@@ -68,20 +67,38 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
     // several waves per SIMD each keep 8 wide loads in flight.
     for (int k0 = 0; k0 < K; k0 += 32) {
         const int kb = k0 + 8 * g;
-        const bool kok = kb < K;          // K % 8 == 0: a lane group's 8 channels are all inside or all outside
+        const bool kok = kb < K;           // K % 8 == 0: a lane group's 8 channels are all inside or all outside
         const bool full_k = k0 + 32 <= K;  // wave-uniform: all four lane groups inside
+        // Pixels past the row's end are loaded like any others (they are the next channel's data and only ever reach
+        // output columns that are not stored); what must hold is that the wide loads stay inside their slab -- false
+        // only for the last image's last channels in a partial pixel tile (wave-uniform test).
+        const int rend = min(k0 + 32, K);
+        bool wide = true;
+        if (k0 < k1) wide = ((int64_t)n * k1 + min(rend, k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * k1 * HW;
+        if (rend > k1)
+            wide = wide && ((int64_t)n * (K - k1) + (rend - k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * (K - k1) * HW;
         bf16_t raw[8][PXV];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
-            load_piece<PXV, AL>(raw[r], kok ? row_ptr(x1, x2, k1, K, n, kb + r, HW) + p0 : x1, kok ? cnt : 0,
-                                full_px && full_k);
+            load_piece<PXV, AL>(raw[r], kok ? row_ptr(x1, x2, k1, K, n, kb + r, HW) + p0 : x1, kok ? cnt : 0, wide,
+                                /*zero_tail=*/false);
         bf16x8_t af[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             bf16_t a_[8];
-            load_piece<8, 16>(a_, arow[mt] + (kok ? kb : 0), kok ? 8 : 0, full_k);
+            load_piece<8, 16>(a_, arow[mt] + (kok ? kb : 0), 8, true, false);
 #pragma unroll
             for (int e = 0; e < 8; ++e) af[mt][e] = a_[e];
+        }
+        if (!full_k && !kok) {  // partial last K step (scalar branch): lane groups past K contribute exact zeros
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int c = 0; c < PXV; ++c) raw[r][c] = (bf16_t)0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[mt][e] = (bf16_t)0.0f;
         }
 #pragma unroll
         for (int c = 0; c < PXV; ++c) {
@@ -104,14 +121,14 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
                 bf16_t* dst = row_ptr(y1, y2, m1, M, n, m, HW) + p0;
                 bf16_t o[PXV];
                 if ((accumulate >> (m < m1 ? 0 : 1)) & 1) {  // y += result (bit 0: first slab, bit 1: second slab)
-                    load_piece<PXV, AL>(o, dst, cnt, full_px);
+                    load_piece<PXV, AL>(o, dst, cnt, false);
 #pragma unroll
                     for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b + (float)o[c]);
                 } else {
 #pragma unroll
                     for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b);
                 }
-                store_piece<PXV, AL>(dst, o, cnt, full_px);
+                store_piece<PXV, AL>(dst, o, cnt);
             }
         }
 }
@@ -162,11 +179,15 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
     {                                                                                                              \
         const int p_ = (ST) * 32 + g * 8;                                                                          \
         const int cnt_ = HW - p_;                                                                                  \
-        const bool full_ = ((ST) + 1) * 32 <= HW;                                                                  \
+        const bool tail_ = ((ST) + 1) * 32 > HW;  /* wave-uniform: this step runs over the row's end */          \
+        /* every lane reads 8 elements at (row, ST*32 + 8g): inside the tensor for ALL rows of image NN? (the rows   \
+           of later images follow in memory; only the last image(s) can run out) -- per tensor, by channel count */  \
+        const int64_t over_ = (int64_t)(ST) * 32 + 32 - HW, left_ = (int64_t)(N - 1 - (NN)) * HW;                  \
+        const bool wide_ = over_ <= left_ * M && over_ <= left_ * (x2 ? min(k1, J - k1) : J);                       \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
             bf16_t a_[8], b_[8];                                                                                   \
-            load_piece<8, AL>(a_, gy + ((int64_t)(NN) * M + mrow[q]) * HW + p_, cnt_, full_);                      \
-            load_piece<8, AL>(b_, row_ptr(x1, x2, k1, J, (NN), jrow[q], HW) + p_, cnt_, full_);                     \
+            load_piece<8, AL>(a_, gy + ((int64_t)(NN) * M + mrow[q]) * HW + p_, cnt_, wide_, tail_);               \
+            load_piece<8, AL>(b_, row_ptr(x1, x2, k1, J, (NN), jrow[q], HW) + p_, cnt_, wide_, tail_);              \
             _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                        \
                 af[BUF][q][e] = a_[e];                                                                             \
                 bfr[BUF][q][e] = ones[q] ? (bf16_t)1.0f : b_[e];                                                   \
@@ -252,10 +273,10 @@ static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_
     const dim3 grid(wave_grid_blocks(waves)), block(256);
     const int xcd = g_conv1x1_tune[0];
     if (MT == 2)
-        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, K, M, HW,
+        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M, HW,
                    mblocks, ptiles, waves, xcd, accumulate);
     else
-        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 4, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, K, M, HW,
+        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 4, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M, HW,
                    mblocks, ptiles, waves, xcd, accumulate);
     return check_launch("conv1x1_fwd_mfma");
 }

@@ -76,7 +76,6 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf
     const int HW = H * W, Kc = Cin / G, Mg = Cout / G, Kg = 9 * Kc;
     const int P0 = pt * (16 * PXV), p0 = P0 + j * PXV;
     const int cnt = HW - p0;
-    const bool full_px = P0 + 16 * PXV <= HW;
     const int mbase = mb * (16 * MT);
     const int64_t base = ((int64_t)n * Cin + (int64_t)grp * Kc) * HW;  // element offset of the group's first channel
     // every wide load of this wave stays inside the tensor (false only for the first / last waves of the launch)
@@ -105,7 +104,7 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf
         if (wave_safe) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
-                load_piece<PXV, 2>(raw[r], x + (base + (int64_t)(ci0 + r) * HW + p0 + shift), PXV, true);
+                load_piece<PXV, 2>(raw[r], x + (base + (int64_t)(ci0 + r) * HW + p0 + shift), PXV, true, false);
         } else {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -119,7 +118,7 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             bf16_t a_[8];
-            load_piece<8, 16>(a_, arow[mt] + kbc, 8, true);
+            load_piece<8, 16>(a_, arow[mt] + kbc, 8, true, false);
 #pragma unroll
             for (int e = 0; e < 8; ++e) af[mt][e] = kok ? a_[e] : (bf16_t)0.0f;
         }
@@ -144,14 +143,14 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf
                 bf16_t* dst = y + ((int64_t)n * Cout + (int64_t)grp * Mg + m) * HW + p0;
                 bf16_t o[PXV];
                 if (accumulate) {  // y += result
-                    load_piece<PXV, AL>(o, dst, cnt, full_px);
+                    load_piece<PXV, AL>(o, dst, cnt, false);
 #pragma unroll
                     for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + (float)o[c]);
                 } else {
 #pragma unroll
                     for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)acc[mt][c][i];
                 }
-                store_piece<PXV, AL>(dst, o, cnt, full_px);
+                store_piece<PXV, AL>(dst, o, cnt);
             }
         }
 }
@@ -196,7 +195,9 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
     for (int64_t t = t0; t < t1; ++t) {
         const int P = st * 32, p = P + lg * 8;
         const int cnt = HW - p;
-        const bool full = P + 32 <= HW;
+        const bool tail = P + 32 > HW;                  // wave-uniform: this step runs over the row's end
+        // every lane reads 8 elements of dY at (row, P + 8*lg): inside the tensor for all rows of image n?
+        const bool wide_a = (int64_t)P + 32 - HW <= (int64_t)(N - 1 - n) * Cout * HW;
         const int64_t base = ((int64_t)n * Cin + (int64_t)grp * Kc) * HW;
         const bool safe = base + P - W - 1 >= 0 && base + (int64_t)(Kc - 1) * HW + P + 32 + W + 1 <= x_elems;
         // tap-validity bits of this lane's 8 pixels, two pixels per dword
@@ -211,7 +212,7 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
 #pragma unroll
         for (int q = 0; q < MTW; ++q) {
             bf16_t a_[8];
-            load_piece<8, AL>(a_, gy + ((int64_t)n * Cout + mrow[q]) * HW + p, cnt, full);
+            load_piece<8, AL>(a_, gy + ((int64_t)n * Cout + mrow[q]) * HW + p, cnt, wide_a, tail);
 #pragma unroll
             for (int e = 0; e < 8; ++e) af[q][e] = a_[e];
         }
@@ -220,7 +221,7 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
             const int64_t off = ((int64_t)n * Cin + jch[q]) * HW + p + jshift[q];
             bf16_t b_[8];
             if (safe) {
-                load_piece<8, 2>(b_, x + off, 8, true);
+                load_piece<8, 2>(b_, x + off, 8, true, false);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) b_[e] = (off + e >= 0 && off + e < x_elems) ? x[off + e] : (bf16_t)0.0f;

@@ -54,9 +54,15 @@ gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, c
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int p = 8 * (r * NT + t);
-        const bool full = 8 * (r * NT + wend) <= HW;  // wave-uniform: every lane's piece of this round is complete
+        // wave-uniform: does any lane's piece of this round run over the channel's end?  It is still loaded wide (what
+        // follows is the next channel; lanes wholly past the end all read the 16 bytes at the end) unless that could
+        // leave the tensor (the end of the last (image, group))
+        const bool tail = 8 * (r * NT + wend) > HW;
+        const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
 #pragma unroll
-        for (int cl = 0; cl < 9; ++cl) load_piece<8, AL>(v[cl][r], x + base + (int64_t)cl * HW + p, HW - p, full);
+        for (int cl = 0; cl < 9; ++cl)
+            load_piece<8, AL>(v[cl][r], x + base + (int64_t)cl * HW + min(p, HW), HW - p,
+                              !tail || base + (int64_t)(cl + 1) * HW + 8 <= total, tail);
     }
     const float inv = 1.f / (9.f * (float)HW);
     float s[1] = {0.f};
@@ -92,11 +98,10 @@ gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, c
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int p = 8 * (r * NT + t);
-            const bool full = 8 * (r * NT + wend) <= HW;
             bf16_t o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)v[cl][r][e] * ga + be);
-            if (p < HW) store_piece<8, AL>(y + base + (int64_t)cl * HW + p, o, HW - p, full);
+            if (p < HW) store_piece<8, AL>(y + base + (int64_t)cl * HW + p, o, HW - p);
         }
     }
 }
@@ -116,11 +121,13 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int p = 8 * (r * NT + t);
-        const bool full = 8 * (r * NT + wend) <= HW;
+        const bool tail = 8 * (r * NT + wend) > HW;
+        const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
 #pragma unroll
         for (int cl = 0; cl < 9; ++cl) {
-            load_piece<8, AL>(xv[cl][r], x + base + (int64_t)cl * HW + p, HW - p, full);
-            load_piece<8, AL>(gv[cl][r], dy + base + (int64_t)cl * HW + p, HW - p, full);
+            const bool wide = !tail || base + (int64_t)(cl + 1) * HW + 8 <= total;
+            load_piece<8, AL>(xv[cl][r], x + base + (int64_t)cl * HW + min(p, HW), HW - p, wide, tail);
+            load_piece<8, AL>(gv[cl][r], dy + base + (int64_t)cl * HW + min(p, HW), HW - p, wide, tail);
         }
     }
     float s[18];  // per channel: sum dy, sum dy * xhat   (dy past the end was loaded as zero)
@@ -156,14 +163,13 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int p = 8 * (r * NT + t);
-            const bool full = 8 * (r * NT + wend) <= HW;
             bf16_t o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xh = ((float)xv[cl][r][e] - mean) * rstd;
                 o[e] = (bf16_t)(rstd * (ga * (float)gv[cl][r][e] - c1 - xh * c2));
             }
-            if (p < HW) store_piece<8, AL>(dx + base + (int64_t)cl * HW + p, o, HW - p, full);
+            if (p < HW) store_piece<8, AL>(dx + base + (int64_t)cl * HW + p, o, HW - p);
         }
     }
 }

@@ -21,23 +21,31 @@ template <int V> struct BFVec {
     typedef __attribute__((ext_vector_type(V))) __bf16 type;
 };
 
-// dst[0..V) = p[0..V) for the first `cnt` elements, zero beyond (cnt may be <= 0 or > V).  `full` is a WAVE-UNIFORM
-// promise that cnt >= V for every lane (scalar branch: the wide access is not entangled with the element-wise tail path)
+// dst[0..V) = p[0..V) for the first `cnt` elements, zero beyond (cnt may be <= 0 or > V).
+// `wide` is a WAVE-UNIFORM promise that reading all V elements at p is inside the tensor for every lane (scalar branch:
+// the one wide -- possibly unaligned -- access is not entangled with the element-wise path).  With `wide`, elements past
+// `cnt` hold whatever follows in memory unless `zero_tail` asks for them to be cleared (by selection, never by
+// multiplication: they may be Inf/NaN).  AL = what is known about p's alignment.
 template <int V, int AL>
-__device__ __forceinline__ void load_piece(bf16_t (&dst)[V], const bf16_t* p, int cnt, bool full) {
-    if (full) {
-        typename BFVec<V>::type t;  // one wide access; AL = what is known about p's alignment
+__device__ __forceinline__ void load_piece(bf16_t (&dst)[V], const bf16_t* p, int cnt, bool wide, bool zero_tail = true) {
+    if (wide) {
+        typename BFVec<V>::type t;
         __builtin_memcpy(&t, __builtin_assume_aligned(p, AL), sizeof(t));
 #pragma unroll
         for (int i = 0; i < V; ++i) dst[i] = t[i];
+        if (zero_tail) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) dst[i] = (i < cnt) ? dst[i] : (bf16_t)0.0f;
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < V; ++i) dst[i] = (i < cnt) ? p[i] : (bf16_t)0.0f;
     }
 }
+// p[0..min(cnt,V)) = src: one wide store for lanes that own all V elements, element-wise for the lane at the row's end
 template <int V, int AL>
-__device__ __forceinline__ void store_piece(bf16_t* p, const bf16_t (&src)[V], int cnt, bool full) {
-    if (full) {
+__device__ __forceinline__ void store_piece(bf16_t* p, const bf16_t (&src)[V], int cnt) {
+    if (cnt >= V) {
         typename BFVec<V>::type t;
 #pragma unroll
         for (int i = 0; i < V; ++i) t[i] = src[i];

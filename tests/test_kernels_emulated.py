@@ -913,3 +913,15 @@ def test_whole_model_with_folded_batchnorm_finalize(monkeypatch):
     (ya, gxa, pa, ba), (yb, gxb, pb, bb) = outs
     assert torch.equal(ya, yb) and torch.equal(gxa, gxb)     # same arithmetic, same order
     assert all(torch.equal(u, v) for u, v in zip(pa, pb)) and all(torch.equal(u, v) for u, v in zip(ba, bb))
+
+
+def test_no_kernel_touches_memory_past_its_tensors():
+    """tests/emul/guard_check.py in a child process: every kernel family on tensors that end right in front of an
+    inaccessible page (a read or write past the end of a tensor is a SIGSEGV there; on the GPU it would be a silent
+    over-read or a memory fault).  The MFMA convolution / GroupNorm kernels deliberately read wide, possibly unaligned
+    pieces that run over a row's end -- this is the check that they never run over the TENSOR's end."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(build_emul.__file__)), "guard_check.py")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "GUARD_OK" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-800:])
