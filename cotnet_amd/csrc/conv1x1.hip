@@ -38,7 +38,9 @@ template <typename P> __device__ __forceinline__ P* row_ptr(P* t1, P* t2, int c1
 // ------------------------------------------------------------------------------------------------------------------
 // Y[n][m][p] = sum_k A[m][k] * X[n][k][p] (+ bias[m]);  A row-major [M][K], K % 8 == 0.
 // One wave = (image n, tile of 16*PXV pixels, block of 16*MT output channels); 4 waves per workgroup.
-template <int PXV, int MT, int AL>
+// TA: A is given TRANSPOSED (element (m, k) at A[k*M + m]) -- the data gradient reads the weight tensor as it is stored,
+// with eight 2-byte loads per fragment (weights are L2-resident) instead of a transposed copy made by an extra launch.
+template <int PXV, int MT, int AL, bool TA>
 __global__ void __launch_bounds__(256, 2)
 conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, int k1, const bf16_t* __restrict__ A,
                  const bf16_t* __restrict__ bias, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2, int m1, int N, int K,
@@ -61,7 +63,10 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
 
     const bf16_t* arow[MT];  // A rows of this lane (clamped: rows >= M are computed on a copy of row M-1, never stored)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (int64_t)min(mbase + mt * 16 + j, M - 1) * K;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int mrow = min(mbase + mt * 16 + j, M - 1);
+        arow[mt] = TA ? A + mrow : A + (int64_t)mrow * K;
+    }
 
     // Single-buffered on purpose: latency is hidden by occupancy (the wave's whole state is acc + one 8 x PXV block),
     // several waves per SIMD each keep 8 wide loads in flight.
@@ -86,7 +91,12 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             bf16_t a_[8];
-            load_piece<8, 16>(a_, arow[mt] + (kok ? kb : 0), 8, true, false);
+            if (TA) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a_[e] = arow[mt][(int64_t)((kok ? kb : 0) + e) * M];
+            } else {
+                load_piece<8, 16>(a_, arow[mt] + (kok ? kb : 0), 8, true, false);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) af[mt][e] = a_[e];
         }
@@ -133,22 +143,15 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
         }
 }
 
-// WT[k][m] = W[m][k]  (weights are tiny: <= 2 MB)
-__global__ void conv1x1_transpose_w(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt, int M, int K) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)M * K) return;
-    const int m = (int)(e % M), k = (int)(e / M);
-    wt[e] = w[(int64_t)m * K + k];
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // part[s][m][jj] = sum over the s-th slice of (n, pixel) of dY[n][m][p] * X[n][jj][p];  column jj == J (when has_bias)
 // multiplies by 1 -> the bias gradient.  One wave = (64 x 64 output tile, slice s); 4 waves per workgroup.
+// S == 1 (small problems): there is nothing to reduce -- the single slice is written straight to gw / gb (bf16).
 template <int AL>
 __global__ void __launch_bounds__(256, 2)
 conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, int k1,
-                   float* __restrict__ part, int N, int M, int J, int HW, int has_bias, int mblocks, int jblocks, int S,
-                   int spi, int64_t total_waves, int xcd_remap) {
+                   float* __restrict__ part, bf16_t* __restrict__ gw, bf16_t* __restrict__ gb, int N, int M, int J, int HW,
+                   int has_bias, int mblocks, int jblocks, int S, int spi, int64_t total_waves, int xcd_remap) {
     const int64_t wid = wave_work_id(xcd_remap);
     if (wid >= total_waves) return;
     const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
@@ -229,7 +232,13 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int jj = jb * 64 + b * 16 + i16;
-                if (jj < Jp) ps[(int64_t)m * Jp + jj] = acc[a][b][i];
+                if (S > 1) {
+                    if (jj < Jp) ps[(int64_t)m * Jp + jj] = acc[a][b][i];
+                } else if (jj < J) {
+                    gw[(int64_t)m * J + jj] = (bf16_t)acc[a][b][i];
+                } else if (jj == J && has_bias) {
+                    gb[m] = (bf16_t)acc[a][b][i];
+                }
             }
         }
 }
@@ -263,7 +272,7 @@ int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_
 extern int g_conv1x1_tune[4];  // [0] xcd remap (default 1), [1] MT override (0 = auto), [2] wgrad target waves, [3] spare
 int g_conv1x1_tune[4] = {1, 0, 2048, 0};
 
-template <int PXV, int AL>
+template <int PXV, int AL, bool TA>
 static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_t* A, const bf16_t* bias, bf16_t* y1,
                          bf16_t* y2, int m1, int N, int K, int M, int HW, int accumulate, hipStream_t stream) {
     int MT = g_conv1x1_tune[1] ? g_conv1x1_tune[1] : (M <= 32 ? 2 : 4);
@@ -273,29 +282,29 @@ static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_
     const dim3 grid(wave_grid_blocks(waves)), block(256);
     const int xcd = g_conv1x1_tune[0];
     if (MT == 2)
-        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M, HW,
+        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL, TA>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M, HW,
                    mblocks, ptiles, waves, xcd, accumulate);
     else
-        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 4, AL>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M, HW,
+        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 4, AL, TA>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M, HW,
                    mblocks, ptiles, waves, xcd, accumulate);
     return check_launch("conv1x1_fwd_mfma");
 }
 
-// x = [x1 | x2] along channels (x2 may be NULL, then k1 == K); y = [y1 | y2] likewise (m1 == M when y2 == NULL)
+// x = [x1 | x2] along channels (x2 may be NULL, then k1 == K); y = [y1 | y2] likewise (m1 == M when y2 == NULL);
+// transposed_a: A holds the [K][M] matrix (the weight tensor itself, for the data gradient)
 int conv1x1_gemm(const void* x1, const void* x2, int k1, const void* A, const void* bias, void* y1, void* y2, int m1,
-                 int N, int K, int M, int HW, int accumulate, hipStream_t stream) {
+                 int N, int K, int M, int HW, int accumulate, int transposed_a, hipStream_t stream) {
     const bf16_t *X1 = (const bf16_t*)x1, *X2 = (const bf16_t*)x2, *a = (const bf16_t*)A, *b = (const bf16_t*)bias;
     bf16_t *Y1 = (bf16_t*)y1, *Y2 = (bf16_t*)y2;
-    if (HW % 8 == 0) return launch_fwd_mt<8, 16>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, accumulate, stream);
-    if (HW % 4 == 0) return launch_fwd_mt<4, 8>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, accumulate, stream);
-    return launch_fwd_mt<4, 2>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, accumulate, stream);
-}
-
-int conv1x1_transpose(const void* w, void* wt, int M, int K, hipStream_t stream) {
-    const int64_t tot = (int64_t)M * K;
-    COT_LAUNCH(conv1x1_transpose_w, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, stream, (const bf16_t*)w,
-               (bf16_t*)wt, M, K);
-    return check_launch("conv1x1_transpose_w");
+#define COT_C1_DISPATCH(TA_)                                                                                          \
+    do {                                                                                                              \
+        if (HW % 8 == 0) return launch_fwd_mt<8, 16, TA_>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, accumulate, stream); \
+        if (HW % 4 == 0) return launch_fwd_mt<4, 8, TA_>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, accumulate, stream);  \
+        return launch_fwd_mt<4, 2, TA_>(X1, X2, k1, a, b, Y1, Y2, m1, N, K, M, HW, accumulate, stream);                   \
+    } while (0)
+    if (transposed_a) COT_C1_DISPATCH(true);
+    COT_C1_DISPATCH(false);
+#undef COT_C1_DISPATCH
 }
 
 // number of deterministic partial sums the weight gradient is split into (also sizes the workspace)
@@ -323,13 +332,13 @@ int conv1x1_wgrad(const void* gy, const void* x1, const void* x2, int k1, void* 
     const int xcd = g_conv1x1_tune[0];
     const bf16_t *GY = (const bf16_t*)gy, *X1 = (const bf16_t*)x1, *X2 = (const bf16_t*)x2;
     if (HW % 8 == 0)
-        COT_LAUNCH((conv1x1_wgrad_mfma<16>), grid, block, 0, stream, GY, X1, X2, k1, workspace, N, M, J, HW, has_bias,
-                   mblocks, jblocks, S, spi, waves, xcd);
+        COT_LAUNCH((conv1x1_wgrad_mfma<16>), grid, block, 0, stream, GY, X1, X2, k1, workspace, (bf16_t*)gw, (bf16_t*)gb, N,
+                   M, J, HW, has_bias, mblocks, jblocks, S, spi, waves, xcd);
     else
-        COT_LAUNCH((conv1x1_wgrad_mfma<2>), grid, block, 0, stream, GY, X1, X2, k1, workspace, N, M, J, HW, has_bias,
-                   mblocks, jblocks, S, spi, waves, xcd);
+        COT_LAUNCH((conv1x1_wgrad_mfma<2>), grid, block, 0, stream, GY, X1, X2, k1, workspace, (bf16_t*)gw, (bf16_t*)gb, N,
+                   M, J, HW, has_bias, mblocks, jblocks, S, spi, waves, xcd);
     int rc = check_launch("conv1x1_wgrad_mfma");
-    if (rc) return rc;
+    if (rc || S == 1) return rc;
     return conv1x1_wgrad_reduce_launch(workspace, S, M, J, has_bias, gw, gb, stream);
 }
 

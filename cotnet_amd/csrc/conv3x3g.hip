@@ -10,8 +10,8 @@
 // row's / channel's data and are zeroed afterwards by select (never by multiplication: the garbage may be Inf/NaN) with
 // a 9-bit per-pixel tap-validity mask (`masks`, one uint16 per pixel, built once per H x W by conv3x3g_masks).
 // The K order is (tap, ci): every lane group's 8 channels share one tap, so the mask is applied per MFMA column.  The
-// weights are re-ordered to that K order by a small kernel per call (<= 1.2 MB); for the data gradient the same
-// re-ordering transposes (co, ci) and flips the taps, and the forward kernel is reused on dY.
+// weight fragments are gathered from the tensor as torch stores it (2-byte loads; <= 1.2 MB, L2-resident); for the
+// data gradient the same kernel runs on dY with the gather transposing (co, ci) and flipping the taps.
 // Weight gradient: reduction over pixels, both operands pixel-contiguous; the B fragment of column (ci, tap) is X at the
 // shifted address with the tap's mask bits ANDed in; deterministic split-K partial sums + the reduce kernel of
 // conv1x1.hip.  Output columns are in the weight tensor's own [ci][3][3] order, so no re-ordering on the way out.
@@ -41,30 +41,14 @@ __global__ void conv3x3g_masks_kernel(uint16_t* __restrict__ masks, int H, int W
     masks[p] = (uint16_t)bits;
 }
 
-// mode 0: A[co][tap][ci]               = w[co][ci][tap]                  (rows: Cout, K = 9*Kc)
-// mode 1: A[g*Kc + ci][tap][co_local]  = w[g*Mg + co_local][ci][8 - tap] (rows: Cin,  K = 9*Mg)   -- data gradient
-__global__ void conv3x3g_repack(const bf16_t* __restrict__ w, bf16_t* __restrict__ A, int Cout, int Kc, int Mg,
-                                int mode) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)Cout * Kc * 9) return;
-    if (mode == 0) {
-        const int co = (int)(e / (9 * Kc)), rem = (int)(e % (9 * Kc)), tap = rem / Kc, ci = rem % Kc;
-        A[e] = w[((int64_t)co * Kc + ci) * 9 + tap];
-    } else {
-        const int row = (int)(e / (9 * Mg)), rem = (int)(e % (9 * Mg)), tap = rem / Mg, col = rem % Mg;
-        const int g = row / Kc, ci = row % Kc;
-        A[e] = w[(((int64_t)g * Mg + col) * Kc + ci) * 9 + (8 - tap)];
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// Y[n][grp*Mg + m][p] = sum_{tap, ci} A[grp*Mg + m][tap*Kc + ci] * X[n][grp*Kc + ci][p + off(tap)]   (zero outside)
+// Y[n][grp*Mg + m][p] = sum_{tap, ci} Wt(m, tap, ci) * X[n][grp*Kc + ci][p + off(tap)]   (zero outside the image)
 // One wave = (image, pixel tile of 16*PXV, group, block of 16*MT output channels of the group).
 template <int PXV, int MT, int AL>
 __global__ void __launch_bounds__(256, 2)
-conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf16_t* __restrict__ y,
+conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, bf16_t* __restrict__ y,
                   const uint16_t* __restrict__ masks, int Cin, int Cout, int G, int H, int W, int mblocks, int ptiles,
-                  int64_t total_waves, int64_t x_elems, int xcd_remap, int accumulate) {
+                  int64_t total_waves, int64_t x_elems, int xcd_remap, int accumulate, int dgrad) {
     const int64_t wid = wave_work_id(xcd_remap);
     if (wid >= total_waves) return;
     const int lane = threadIdx.x & 63, j = lane & 15, lg = lane >> 4;
@@ -90,9 +74,13 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int c = 0; c < PXV; ++c) acc[mt][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* arow[MT];
+    // The A operand is read from the weight tensor [co][ci][3][3] AS STORED (eight 2-byte loads per fragment, L2 hits):
+    //   forward        row m = co, K index (tap, ci):   wt[((grp*Mg + m)*Kc + ci)*9 + tap]
+    //   data gradient  row m = ci, K index (tap, co):   wt[((grp*Kc + co)*Mg + m)*9 + (8 - tap)]     (Kc, Mg as THIS
+    //                  launch sees them: K side = the convolution's output channels) -- transposed, taps flipped
+    int mrow[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) arow[mt] = A + ((int64_t)grp * Mg + min(mbase + mt * 16 + j, Mg - 1)) * Kg;
+    for (int mt = 0; mt < MT; ++mt) mrow[mt] = min(mbase + mt * 16 + j, Mg - 1);
 
     for (int k0 = 0; k0 < Kg; k0 += 32) {
         const int kb = k0 + 8 * lg;
@@ -117,10 +105,12 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf
         bf16x8_t af[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            bf16_t a_[8];
-            load_piece<8, 16>(a_, arow[mt] + kbc, 8, true, false);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) af[mt][e] = kok ? a_[e] : (bf16_t)0.0f;
+            for (int e = 0; e < 8; ++e) {
+                const int wi = dgrad ? ((grp * Kc + ci0 + e) * Mg + mrow[mt]) * 9 + (8 - tap)  // (< 2^31 elements)
+                                     : ((grp * Mg + mrow[mt]) * Kc + ci0 + e) * 9 + tap;
+                af[mt][e] = kok ? wt[wi] : (bf16_t)0.0f;
+            }
         }
 #pragma unroll
         for (int c = 0; c < PXV; ++c) {
@@ -161,7 +151,8 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf
 template <int MTW, int AL>
 __global__ void __launch_bounds__(256, 2)
 conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, float* __restrict__ part,
-                    const uint16_t* __restrict__ masks, int N, int Cin, int Cout, int G, int H, int W, int mblocks,
+                    bf16_t* __restrict__ gw, const uint16_t* __restrict__ masks, int N, int Cin, int Cout, int G, int H,
+                    int W, int mblocks,
                     int jblocks, int S, int spi, int64_t total_waves, int64_t x_elems, int xcd_remap) {
     const int64_t wid = wave_work_id(xcd_remap);
     if (wid >= total_waves) return;
@@ -252,7 +243,10 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int jj = jb * 64 + b * 16 + i16;
-                if (jj < Jg) ps[((int64_t)grp * Mg + m) * Jg + jj] = acc[a][b][i];
+                if (jj < Jg) {
+                    if (S > 1) ps[((int64_t)grp * Mg + m) * Jg + jj] = acc[a][b][i];
+                    else gw[((int64_t)grp * Mg + m) * Jg + jj] = (bf16_t)acc[a][b][i];  // single slice: nothing to reduce
+                }
             }
         }
 }
@@ -270,7 +264,7 @@ int conv3x3g_masks(void* masks, int H, int W, hipStream_t stream) {
 
 template <int PXV, int AL>
 static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_t* masks, int N, int Cin, int Cout,
-                      int G, int H, int W, int accumulate, hipStream_t stream) {
+                      int G, int H, int W, int accumulate, int dgrad, hipStream_t stream) {
     const int Mg = Cout / G, HW = H * W;
     const int MT = Mg <= 16 ? 1 : (Mg <= 32 ? 2 : 4);
     const int mblocks = ceil_div(Mg, 16 * MT), ptiles = ceil_div(HW, 16 * PXV);
@@ -279,7 +273,7 @@ static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_
     const int xcd = g_conv1x1_tune[0];
 #define COT_C3_LAUNCH(MT_)                                                                                            \
     COT_LAUNCH((conv3x3g_fwd_mfma<PXV, MT_, AL>), grid, block, 0, stream, x, A, y, masks, Cin, Cout, G, H, W, mblocks, \
-               ptiles, waves, x_elems, xcd, accumulate)
+               ptiles, waves, x_elems, xcd, accumulate, dgrad)
     if (MT == 1) COT_C3_LAUNCH(1);
     else if (MT == 2) COT_C3_LAUNCH(2);
     else COT_C3_LAUNCH(4);
@@ -288,24 +282,18 @@ static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_
 }
 
 // mode 0: y = conv(x, w);  mode 1: x-gradient (x := dY with Cout channels, y := dX with Cin channels)
-// `ws` receives the re-ordered weights (Cout*Cin/G*9 bf16)
-int conv3x3g_gemm(const void* x, const void* w, void* y, const void* masks, void* ws, int N, int Cin, int Cout, int G,
-                  int H, int W, int mode, int accumulate, hipStream_t stream) {
-    const int Kc = Cin / G, Mg = Cout / G, HW = H * W;
-    const int64_t wel = (int64_t)Cout * Kc * 9;
-    COT_LAUNCH(conv3x3g_repack, dim3((unsigned)ceil_div64(wel, 256)), dim3(256), 0, stream, (const bf16_t*)w,
-               (bf16_t*)ws, Cout, Kc, Mg, mode);
-    int rc = check_launch("conv3x3g_repack");
-    if (rc) return rc;
+int conv3x3g_gemm(const void* x, const void* w, void* y, const void* masks, int N, int Cin, int Cout, int G, int H, int W,
+                  int mode, int accumulate, hipStream_t stream) {
+    const int HW = H * W;
     const bf16_t* X = (const bf16_t*)x;
-    const bf16_t* A = (const bf16_t*)ws;
+    const bf16_t* A = (const bf16_t*)w;
     bf16_t* Y = (bf16_t*)y;
     const uint16_t* mk = (const uint16_t*)masks;
     // K side / M side channel counts of the GEMM that is actually run
     const int ck = mode == 0 ? Cin : Cout, cm = mode == 0 ? Cout : Cin;
-    if (HW % 8 == 0) return launch_fwd<8, 16>(X, A, Y, mk, N, ck, cm, G, H, W, accumulate, stream);
-    if (HW % 4 == 0) return launch_fwd<4, 8>(X, A, Y, mk, N, ck, cm, G, H, W, accumulate, stream);
-    return launch_fwd<4, 2>(X, A, Y, mk, N, ck, cm, G, H, W, accumulate, stream);
+    if (HW % 8 == 0) return launch_fwd<8, 16>(X, A, Y, mk, N, ck, cm, G, H, W, accumulate, mode, stream);
+    if (HW % 4 == 0) return launch_fwd<4, 8>(X, A, Y, mk, N, ck, cm, G, H, W, accumulate, mode, stream);
+    return launch_fwd<4, 2>(X, A, Y, mk, N, ck, cm, G, H, W, accumulate, mode, stream);
 }
 
 int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW) {
@@ -324,7 +312,7 @@ int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW) {
 }
 
 template <int AL>
-static int launch_wgrad(const bf16_t* gy, const bf16_t* x, float* part, const uint16_t* masks, int N, int Cin,
+static int launch_wgrad(const bf16_t* gy, const bf16_t* x, float* part, bf16_t* gw, const uint16_t* masks, int N, int Cin,
                         int Cout, int G, int H, int W, int S, hipStream_t stream) {
     const int Kc = Cin / G, Mg = Cout / G, Jg = 9 * Kc, HW = H * W;
     const int MTW = Mg <= 16 ? 1 : (Mg <= 32 ? 2 : 4);
@@ -333,7 +321,7 @@ static int launch_wgrad(const bf16_t* gy, const bf16_t* x, float* part, const ui
     const dim3 grid(wave_grid_blocks(waves)), block(256);
     const int xcd = g_conv1x1_tune[0];
 #define COT_C3_LAUNCH(MTW_)                                                                                        \
-    COT_LAUNCH((conv3x3g_wgrad_mfma<MTW_, AL>), grid, block, 0, stream, gy, x, part, masks, N, Cin, Cout, G, H, W, \
+    COT_LAUNCH((conv3x3g_wgrad_mfma<MTW_, AL>), grid, block, 0, stream, gy, x, part, gw, masks, N, Cin, Cout, G, H, W, \
                mblocks, jblocks, S, spi, waves, x_elems, xcd)
     if (MTW == 1) COT_C3_LAUNCH(1);
     else if (MTW == 2) COT_C3_LAUNCH(2);
@@ -347,12 +335,12 @@ int conv3x3g_wgrad(const void* gy, const void* x, void* gw, const void* masks, f
     const int HW = H * W, S = conv3x3g_wgrad_splits(N, Cin, Cout, G, HW);
     int rc;
     if (HW % 8 == 0)
-        rc = launch_wgrad<16>((const bf16_t*)gy, (const bf16_t*)x, ws, (const uint16_t*)masks, N, Cin, Cout, G, H, W, S,
-                              stream);
+        rc = launch_wgrad<16>((const bf16_t*)gy, (const bf16_t*)x, ws, (bf16_t*)gw, (const uint16_t*)masks, N, Cin, Cout, G,
+                              H, W, S, stream);
     else
-        rc = launch_wgrad<2>((const bf16_t*)gy, (const bf16_t*)x, ws, (const uint16_t*)masks, N, Cin, Cout, G, H, W, S,
-                             stream);
-    if (rc) return rc;
+        rc = launch_wgrad<2>((const bf16_t*)gy, (const bf16_t*)x, ws, (bf16_t*)gw, (const uint16_t*)masks, N, Cin, Cout, G,
+                             H, W, S, stream);
+    if (rc || S == 1) return rc;
     return conv1x1_wgrad_reduce_launch(ws, S, Cout, 9 * (Cin / G), 0, gw, nullptr, stream);
 }
 

@@ -107,9 +107,8 @@ template <typename T> int radix_mix(const void*, const void*, const void*, void*
 template <typename T>
 int radix_mix_bwd(const void*, const void*, const void*, const void*, void*, void*, void*, int64_t, int, hipStream_t);
 // implemented in conv1x1.hip
-int conv1x1_gemm(const void*, const void*, int, const void*, const void*, void*, void*, int, int, int, int, int, int,
+int conv1x1_gemm(const void*, const void*, int, const void*, const void*, void*, void*, int, int, int, int, int, int, int,
                  hipStream_t);
-int conv1x1_transpose(const void*, void*, int, int, hipStream_t);
 int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_conv1x1_tune[4];
@@ -120,8 +119,7 @@ int gn9_backward(const void*, const void*, const float*, const float*, const voi
 // implemented in conv3x3g.hip
 int64_t conv3x3g_masks_bytes(int H, int W);
 int conv3x3g_masks(void*, int, int, hipStream_t);
-int conv3x3g_gemm(const void*, const void*, void*, const void*, void*, int, int, int, int, int, int, int, int,
-                  hipStream_t);
+int conv3x3g_gemm(const void*, const void*, void*, const void*, int, int, int, int, int, int, int, int, hipStream_t);
 int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW);
 int conv3x3g_wgrad(const void*, const void*, void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int radix_gap_t(const void*, const void*, void*, int, int, int, hipStream_t);
@@ -287,7 +285,7 @@ int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weig
     if (rc) return rc;
     if (!x1 || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x1, x2, weight, y}))) return rc;
-    return conv1x1_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, 0, (hipStream_t)stream);
+    return conv1x1_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, 0, 0, (hipStream_t)stream);
 }
 
 int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, int accumulate,
@@ -296,9 +294,8 @@ int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, voi
     if (rc) return rc;
     if (!gy || !weight || !gx1 || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx1, gx2, workspace}))) return rc;
-    // A = weight^T [Ci][Co] (row-major, K = Co contiguous): one tiny transpose, then the forward kernel on dY
-    if ((rc = conv1x1_transpose(weight, workspace, Co, Ci, (hipStream_t)stream))) return rc;
-    return conv1x1_gemm(gy, nullptr, Co, workspace, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3,
+    // the forward kernel on dY with A = weight^T, read in place from the [Co][Ci] weight tensor
+    return conv1x1_gemm(gy, nullptr, Co, weight, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3, 1,
                         (hipStream_t)stream);
 }
 
@@ -348,7 +345,7 @@ int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void*
     if (rc) return rc;
     if (!x || !weight || !y || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x, weight, y, masks, workspace}))) return rc;
-    return conv3x3g_gemm(x, weight, y, masks, workspace, N, Cin, Cout, groups, H, W, 0, 0, (hipStream_t)stream);
+    return conv3x3g_gemm(x, weight, y, masks, N, Cin, Cout, groups, H, W, 0, 0, (hipStream_t)stream);
 }
 
 int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int accumulate, const void* masks,
@@ -358,8 +355,7 @@ int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int
     if (rc) return rc;
     if (!gy || !weight || !gx || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx, masks, workspace}))) return rc;
-    return conv3x3g_gemm(gy, weight, gx, masks, workspace, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0,
-                         (hipStream_t)stream);
+    return conv3x3g_gemm(gy, weight, gx, masks, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
 }
 
 int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,

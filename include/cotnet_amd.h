@@ -154,8 +154,8 @@ int cot_radix_mix_backward(const void* gout, const void* y, const void* k, const
  * ADD to the existing contents of gx1 / gx2 instead (a tensor with several consumers collects its gradient without
  * separate add kernels; the sum is formed in fp32 and rounded once).
  * backward_weight: gweight [Co][Ci], gbias [Co] or NULL; deterministic (partial sums in `workspace`, no atomics).
- * workspace: cot_conv1x1_workspace(...) BYTES (256-byte multiple), needed by the two backward calls only; they may
- * share one buffer when issued on one stream. */
+ * workspace: cot_conv1x1_workspace(...) BYTES (256-byte multiple): partial sums of backward_weight (backward_data reads
+ * the weight tensor in place, transposed, and only checks the pointer). */
 int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias);
 int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, int N,
                         int Ci, int Co, int HW, int dtype, void* stream);
@@ -170,8 +170,8 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
  * Cout/groups (backward_data) must be multiples of 8, otherwise COT_ERR_UNSUPPORTED (caller keeps nn.Conv2d).
  *   masks:     per-pixel tap-validity table for an H x W image: cot_conv3x3g_masks_bytes(H, W) bytes, filled once by
  *              cot_conv3x3g_masks and reusable by every call with the same H, W (read-only afterwards)
- *   workspace: cot_conv3x3g_workspace(...) bytes (re-ordered weights / partial sums of the weight gradient); the three
- *              calls may share one buffer when issued on one stream.  backward_weight is deterministic (no atomics).
+ *   workspace: cot_conv3x3g_workspace(...) bytes (partial sums of the weight gradient; forward and backward_data read
+ *              the weight tensor in place and only check the pointer).  backward_weight is deterministic (no atomics).
  *   accumulate (backward_data): nonzero = gx += result instead of gx = result. */
 int64_t cot_conv3x3g_masks_bytes(int H, int W);
 int cot_conv3x3g_masks(void* masks, int H, int W, void* stream);
