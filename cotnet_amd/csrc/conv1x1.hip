@@ -40,7 +40,7 @@ template <typename P> __device__ __forceinline__ P* row_ptr(P* t1, P* t2, int c1
 // One wave = (image n, tile of 16*PXV pixels, block of 16*MT output channels); 4 waves per workgroup.
 // TA: A is given TRANSPOSED (element (m, k) at A[k*M + m]) -- the data gradient reads the weight tensor as it is stored,
 // with eight 2-byte loads per fragment (weights are L2-resident) instead of a transposed copy made by an extra launch.
-template <int PXV, int MT, int AL, bool TA>
+template <int PXV, int MT, int AL, bool TA, int D>
 __global__ void __launch_bounds__(256, 2)
 conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, int k1, const bf16_t* __restrict__ A,
                  const bf16_t* __restrict__ bias, bf16_t* __restrict__ y1, bf16_t* __restrict__ y2, int m1, int N, int K,
@@ -68,9 +68,12 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
         arow[mt] = TA ? A + mrow : A + (int64_t)mrow * K;
     }
 
-    // Single-buffered on purpose: latency is hidden by occupancy (the wave's whole state is acc + one 8 x PXV block),
-    // several waves per SIMD each keep 8 wide loads in flight.
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    // K loop with a D-stage register ring: the loads of steps k+1 .. k+D-1 are in flight while step k is multiplied.
+    // Deep-K / small-image layers (K up to 2048 at 7x7, one or two waves per CU) are chains of dependent load latencies
+    // otherwise; the big-image layers have enough waves per SIMD and use D = 1 to keep their 128 accumulators resident.
+    bf16_t raw[D][8][PXV];
+    bf16x8_t af[D][MT];
+    auto load_stage = [&](int d, int k0) {
         const int kb = k0 + 8 * g;
         const bool kok = kb < K;           // K % 8 == 0: a lane group's 8 channels are all inside or all outside
         const bool full_k = k0 + 32 <= K;  // wave-uniform: all four lane groups inside
@@ -82,41 +85,54 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
         if (k0 < k1) wide = ((int64_t)n * k1 + min(rend, k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * k1 * HW;
         if (rend > k1)
             wide = wide && ((int64_t)n * (K - k1) + (rend - k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * (K - k1) * HW;
-        bf16_t raw[8][PXV];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
-            load_piece<PXV, AL>(raw[r], kok ? row_ptr(x1, x2, k1, K, n, kb + r, HW) + p0 : x1, kok ? cnt : 0, wide,
+            load_piece<PXV, AL>(raw[d][r], kok ? row_ptr(x1, x2, k1, K, n, kb + r, HW) + p0 : x1, kok ? cnt : 0, wide,
                                 /*zero_tail=*/false);
-        bf16x8_t af[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             bf16_t a_[8];
             if (TA) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a_[e] = arow[mt][(int64_t)((kok ? kb : 0) + e) * M];
+                for (int e = 0; e < 8; ++e) a_[e] = arow[mt][((kok ? kb : 0) + e) * M];  // (weights: < 2^31 elements)
             } else {
                 load_piece<8, 16>(a_, arow[mt] + (kok ? kb : 0), 8, true, false);
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) af[mt][e] = a_[e];
+            for (int e = 0; e < 8; ++e) af[d][mt][e] = a_[e];
         }
         if (!full_k && !kok) {  // partial last K step (scalar branch): lane groups past K contribute exact zeros
 #pragma unroll
             for (int r = 0; r < 8; ++r)
 #pragma unroll
-                for (int c = 0; c < PXV; ++c) raw[r][c] = (bf16_t)0.0f;
+                for (int c = 0; c < PXV; ++c) raw[d][r][c] = (bf16_t)0.0f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) af[mt][e] = (bf16_t)0.0f;
+                for (int e = 0; e < 8; ++e) af[d][mt][e] = (bf16_t)0.0f;
         }
+    };
+    auto multiply_stage = [&](int d) {
 #pragma unroll
         for (int c = 0; c < PXV; ++c) {
             bf16x8_t bfrag;  // in-register transposition: pixel c of each of this lane's 8 channels
 #pragma unroll
-            for (int r = 0; r < 8; ++r) bfrag[r] = raw[r][c];
+            for (int r = 0; r < 8; ++r) bfrag[r] = raw[d][r][c];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][c] = COT_MFMA_16X16X32_BF16(af[mt], bfrag, acc[mt][c]);
+            for (int mt = 0; mt < MT; ++mt) acc[mt][c] = COT_MFMA_16X16X32_BF16(af[d][mt], bfrag, acc[mt][c]);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (32 * d < K) load_stage(d, 32 * d);
+    for (int k0 = 0; k0 < K; k0 += 32 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int kc = k0 + 32 * d;  // the step multiplied now lives in slot d; slot (d + D - 1) % D is free
+            if (kc < K) {
+                if (kc + 32 * (D - 1) < K) load_stage((d + D - 1) % D, kc + 32 * (D - 1));
+                multiply_stage(d);
+            }
         }
     }
 
@@ -177,50 +193,49 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    bf16x8_t af[2][4], bfr[2][4];
-#define COT_WG_LOAD(BUF, NN, ST)                                                                                   \
-    {                                                                                                              \
-        const int p_ = (ST) * 32 + g * 8;                                                                          \
-        const int cnt_ = HW - p_;                                                                                  \
-        const bool tail_ = ((ST) + 1) * 32 > HW;  /* wave-uniform: this step runs over the row's end */          \
-        /* every lane reads 8 elements at (row, ST*32 + 8g): inside the tensor for ALL rows of image NN? (the rows   \
-           of later images follow in memory; only the last image(s) can run out) -- per tensor, by channel count */  \
-        const int64_t over_ = (int64_t)(ST) * 32 + 32 - HW, left_ = (int64_t)(N - 1 - (NN)) * HW;                  \
-        const bool wide_ = over_ <= left_ * M && over_ <= left_ * (x2 ? min(k1, J - k1) : J);                       \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
-            bf16_t a_[8], b_[8];                                                                                   \
-            load_piece<8, AL>(a_, gy + ((int64_t)(NN) * M + mrow[q]) * HW + p_, cnt_, wide_, tail_);               \
-            load_piece<8, AL>(b_, row_ptr(x1, x2, k1, J, (NN), jrow[q], HW) + p_, cnt_, wide_, tail_);              \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                        \
-                af[BUF][q][e] = a_[e];                                                                             \
-                bfr[BUF][q][e] = ones[q] ? (bf16_t)1.0f : b_[e];                                                   \
-            }                                                                                                      \
-        }                                                                                                          \
-    }
-#define COT_WG_COMPUTE(BUF)                                                                   \
-    {                                                                                         \
-        _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b) \
-            acc[a][b] = COT_MFMA_16X16X32_BF16(af[BUF][a], bfr[BUF][b], acc[a][b]);           \
-    }
-
-    if (t0 < t1) {
-        int n = (int)(t0 / spi), st = (int)(t0 % spi);
-        COT_WG_LOAD(0, n, st)
-        for (int64_t t = t0; t < t1; t += 2) {
-            int n1 = n, st1 = st + 1;
-            if (st1 == spi) { st1 = 0; ++n1; }
-            if (t + 1 < t1) COT_WG_LOAD(1, n1, st1)
-            COT_WG_COMPUTE(0)
-            if (t + 1 < t1) {
-                n = n1; st = st1 + 1;
-                if (st == spi) { st = 0; ++n; }
-                if (t + 2 < t1) COT_WG_LOAD(0, n, st)
-                COT_WG_COMPUTE(1)
+    // reduction loop with a 3-stage register ring: two steps' loads are in flight while one is multiplied (a slice is a
+    // chain of up to a few hundred dependent steps; without the ring every step pays a full memory latency)
+    constexpr int DW = 3;
+    bf16x8_t af[DW][4], bfr[DW][4];
+    auto load_stage = [&](int d, int64_t t) {
+        const int nn = (int)(t / spi), st = (int)(t % spi);
+        const int p = st * 32 + g * 8;
+        const int cnt = HW - p;
+        const bool tail = (st + 1) * 32 > HW;  // wave-uniform: this step runs over the row's end
+        // every lane reads 8 elements at (row, st*32 + 8g): inside the tensor for ALL rows of image nn?  (the rows of
+        // later images follow in memory; only the last image(s) can run out) -- per tensor, by its channel count
+        const int64_t over = (int64_t)st * 32 + 32 - HW, left = (int64_t)(N - 1 - nn) * HW;
+        const bool wide = over <= left * M && over <= left * (x2 ? min(k1, J - k1) : J);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16_t a_[8], b_[8];
+            load_piece<8, AL>(a_, gy + ((int64_t)nn * M + mrow[q]) * HW + p, cnt, wide, tail);
+            load_piece<8, AL>(b_, row_ptr(x1, x2, k1, J, nn, jrow[q], HW) + p, cnt, wide, tail);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                af[d][q][e] = a_[e];
+                bfr[d][q][e] = ones[q] ? (bf16_t)1.0f : b_[e];
+            }
+        }
+    };
+    auto multiply_stage = [&](int d) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af[d][a], bfr[d][b], acc[a][b]);
+    };
+#pragma unroll
+    for (int d = 0; d < DW - 1; ++d)
+        if (t0 + d < t1) load_stage(d, t0 + d);
+    for (int64_t t = t0; t < t1; t += DW) {
+#pragma unroll
+        for (int d = 0; d < DW; ++d) {
+            if (t + d < t1) {
+                if (t + d + DW - 1 < t1) load_stage((d + DW - 1) % DW, t + d + DW - 1);
+                multiply_stage(d);
             }
         }
     }
-#undef COT_WG_LOAD
-#undef COT_WG_COMPUTE
 
     float* ps = part + (int64_t)s * M * Jp;
 #pragma unroll
@@ -275,18 +290,27 @@ int g_conv1x1_tune[4] = {1, 0, 2048, 0};
 template <int PXV, int AL, bool TA>
 static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_t* A, const bf16_t* bias, bf16_t* y1,
                          bf16_t* y2, int m1, int N, int K, int M, int HW, int accumulate, hipStream_t stream) {
-    int MT = g_conv1x1_tune[1] ? g_conv1x1_tune[1] : (M <= 32 ? 2 : 4);
-    if (MT != 2) MT = 4;
-    const int mblocks = ceil_div(M, 16 * MT), ptiles = ceil_div(HW, 16 * PXV);
+    const int ptiles = ceil_div(HW, 16 * PXV);
+    // rows per wave: 64 when that still gives the chip several waves per SIMD (the X tile is then re-read by fewer
+    // waves), 32 for small outputs and small problems -- more waves, and room for a deeper prefetch ring
+    int MT = g_conv1x1_tune[1];
+    if (MT != 2 && MT != 4) MT = (M <= 32 || (int64_t)N * ptiles * ceil_div(M, 64) < 2048) ? 2 : 4;
+    if (TA && PXV == 8) MT = 2;  // (the strided weight gather of the data gradient does not fit next to 128 accumulators)
+    const int mblocks = ceil_div(M, 16 * MT);
     const int64_t waves = (int64_t)N * ptiles * mblocks;
     const dim3 grid(wave_grid_blocks(waves)), block(256);
     const int xcd = g_conv1x1_tune[0];
-    if (MT == 2)
-        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL, TA>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M, HW,
-                   mblocks, ptiles, waves, xcd, accumulate);
-    else
-        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 4, AL, TA>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M, HW,
-                   mblocks, ptiles, waves, xcd, accumulate);
+    // ring depth: whatever the register file allows next to the accumulators (PXV*MT*4 registers)
+    constexpr int D2 = PXV == 8 ? 2 : 4, D4 = PXV == 8 ? 1 : 3;
+    if (MT == 2 && waves >= 8192)  // big launch: occupancy hides the latency, registers stay free for more waves
+        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL, TA, 1>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M,
+                   HW, mblocks, ptiles, waves, xcd, accumulate);
+    else if (MT == 2)
+        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL, TA, D2>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M,
+                   HW, mblocks, ptiles, waves, xcd, accumulate);
+    else if constexpr (!(TA && PXV == 8))
+        COT_LAUNCH((conv1x1_fwd_mfma<PXV, 4, AL, TA, D4>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M,
+                   HW, mblocks, ptiles, waves, xcd, accumulate);
     return check_launch("conv1x1_fwd_mfma");
 }
 
@@ -315,7 +339,8 @@ int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias) {
     if (g_conv1x1_tune[2] < 0) return (int)(-g_conv1x1_tune[2] < T ? -g_conv1x1_tune[2] : T);  // forced split (tests)
     int64_t S = ceil_div64(g_conv1x1_tune[2] > 0 ? g_conv1x1_tune[2] : 2048, units);
     const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
-    const int64_t cap = in_bytes / 8 / out_bytes;  // partial sums may cost at most 1/8 of the input traffic
+    int64_t cap = in_bytes / 8 / out_bytes;  // partial sums may cost at most 1/8 of the input traffic ...
+    if (cap < 4 && T >= 64) cap = 4;         // ... except that a slice should not be a chain of hundreds of steps
     if (S > cap) S = cap;
     if (S > T) S = T;
     if (S < 1) S = 1;

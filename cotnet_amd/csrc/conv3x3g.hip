@@ -44,7 +44,7 @@ __global__ void conv3x3g_masks_kernel(uint16_t* __restrict__ masks, int H, int W
 // ------------------------------------------------------------------------------------------------------------------
 // Y[n][grp*Mg + m][p] = sum_{tap, ci} Wt(m, tap, ci) * X[n][grp*Kc + ci][p + off(tap)]   (zero outside the image)
 // One wave = (image, pixel tile of 16*PXV, group, block of 16*MT output channels of the group).
-template <int PXV, int MT, int AL>
+template <int PXV, int MT, int AL, int D>
 __global__ void __launch_bounds__(256, 2)
 conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, bf16_t* __restrict__ y,
                   const uint16_t* __restrict__ masks, int Cin, int Cout, int G, int H, int W, int mblocks, int ptiles,
@@ -82,44 +82,62 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, b
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) mrow[mt] = min(mbase + mt * 16 + j, Mg - 1);
 
-    for (int k0 = 0; k0 < Kg; k0 += 32) {
+    // K loop (9*Kc/32 = 4.5 .. 36 steps) with a D-stage register ring, as in conv1x1.hip
+    bf16_t raw[D][8][PXV];
+    bf16x8_t af[D][MT];
+    int tapd[D];
+    auto load_stage = [&](int d, int k0) {
         const int kb = k0 + 8 * lg;
         const bool kok = kb < Kg;  // Kc % 8 == 0: the 8 channels of a lane group share one tap and are all in or all out
         const int kbc = kok ? kb : 0;
         const int tap = kbc / Kc, ci0 = kbc - tap * Kc;
         const int shift = (tap / 3 - 1) * W + (tap % 3 - 1);
-        bf16_t raw[8][PXV];
+        tapd[d] = kok ? tap : 9;  // bit 9 of a validity mask is never set: lane groups past K contribute zeros
         if (wave_safe) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
-                load_piece<PXV, 2>(raw[r], x + (base + (int64_t)(ci0 + r) * HW + p0 + shift), PXV, true, false);
+                load_piece<PXV, 2>(raw[d][r], x + (base + (int64_t)(ci0 + r) * HW + p0 + shift), PXV, true, false);
         } else {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int64_t off = base + (int64_t)(ci0 + r) * HW + p0 + shift;
 #pragma unroll
                 for (int c = 0; c < PXV; ++c)
-                    raw[r][c] = (off + c >= 0 && off + c < x_elems) ? x[off + c] : (bf16_t)0.0f;
+                    raw[d][r][c] = (off + c >= 0 && off + c < x_elems) ? x[off + c] : (bf16_t)0.0f;
             }
         }
-        bf16x8_t af[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int wi = dgrad ? ((grp * Kc + ci0 + e) * Mg + mrow[mt]) * 9 + (8 - tap)  // (< 2^31 elements)
                                      : ((grp * Mg + mrow[mt]) * Kc + ci0 + e) * 9 + tap;
-                af[mt][e] = kok ? wt[wi] : (bf16_t)0.0f;
+                af[d][mt][e] = kok ? wt[wi] : (bf16_t)0.0f;
             }
         }
+    };
+    auto multiply_stage = [&](int d) {
 #pragma unroll
         for (int c = 0; c < PXV; ++c) {
-            const bool valid = kok && ((vm[c] >> tap) & 1u);
+            const bool valid = (vm[c] >> tapd[d]) & 1u;
             bf16x8_t bfrag;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) bfrag[r] = valid ? raw[r][c] : (bf16_t)0.0f;
+            for (int r = 0; r < 8; ++r) bfrag[r] = valid ? raw[d][r][c] : (bf16_t)0.0f;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][c] = COT_MFMA_16X16X32_BF16(af[mt], bfrag, acc[mt][c]);
+            for (int mt = 0; mt < MT; ++mt) acc[mt][c] = COT_MFMA_16X16X32_BF16(af[d][mt], bfrag, acc[mt][c]);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (32 * d < Kg) load_stage(d, 32 * d);
+    for (int k0 = 0; k0 < Kg; k0 += 32 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int kc = k0 + 32 * d;
+            if (kc < Kg) {
+                if (kc + 32 * (D - 1) < Kg) load_stage((d + D - 1) % D, kc + 32 * (D - 1));
+                multiply_stage(d);
+            }
         }
     }
 
@@ -182,30 +200,31 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    int n = (int)(t0 / spi), st = (int)(t0 % spi);
-    for (int64_t t = t0; t < t1; ++t) {
+    // reduction loop with a 3-stage register ring (see conv1x1_wgrad_mfma); the tap masks are applied at load time
+    constexpr int DW = 3;
+    bf16x8_t af[DW][MTW], bfr[DW][4];
+    auto load_stage = [&](int d, int64_t t) {
+        const int n = (int)(t / spi), st = (int)(t % spi);
         const int P = st * 32, p = P + lg * 8;
         const int cnt = HW - p;
-        const bool tail = P + 32 > HW;                  // wave-uniform: this step runs over the row's end
+        const bool tail = P + 32 > HW;  // wave-uniform: this step runs over the row's end
         // every lane reads 8 elements of dY at (row, P + 8*lg): inside the tensor for all rows of image n?
         const bool wide_a = (int64_t)P + 32 - HW <= (int64_t)(N - 1 - n) * Cout * HW;
         const int64_t base = ((int64_t)n * Cin + (int64_t)grp * Kc) * HW;
         const bool safe = base + P - W - 1 >= 0 && base + (int64_t)(Kc - 1) * HW + P + 32 + W + 1 <= x_elems;
-        // tap-validity bits of this lane's 8 pixels, two pixels per dword
-        unsigned vmd[4];
+        unsigned vmd[4];  // tap-validity bits of this lane's 8 pixels, two pixels per dword
         {
             uint16_t v_[8];
             __builtin_memcpy(v_, __builtin_assume_aligned(masks + p, 16), 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) vmd[i] = (unsigned)v_[2 * i] | ((unsigned)v_[2 * i + 1] << 16);
         }
-        bf16x8_t af[MTW], bfr[4];
 #pragma unroll
         for (int q = 0; q < MTW; ++q) {
             bf16_t a_[8];
             load_piece<8, AL>(a_, gy + ((int64_t)n * Cout + mrow[q]) * HW + p, cnt, wide_a, tail);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) af[q][e] = a_[e];
+            for (int e = 0; e < 8; ++e) af[d][q][e] = a_[e];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -221,15 +240,25 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
             __builtin_memcpy(bd, b_, 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) bd[i] &= ((vmd[i] >> jtap[q]) & 0x00010001u) * 0xffffu;
-            __builtin_memcpy(&bfr[q], bd, 16);
+            __builtin_memcpy(&bfr[d][q], bd, 16);
         }
+    };
+    auto multiply_stage = [&](int d) {
 #pragma unroll
         for (int a = 0; a < MTW; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af[a], bfr[b], acc[a][b]);
-        if (++st == spi) {
-            st = 0;
-            ++n;
+            for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af[d][a], bfr[d][b], acc[a][b]);
+    };
+#pragma unroll
+    for (int d = 0; d < DW - 1; ++d)
+        if (t0 + d < t1) load_stage(d, t0 + d);
+    for (int64_t t = t0; t < t1; t += DW) {
+#pragma unroll
+        for (int d = 0; d < DW; ++d) {
+            if (t + d < t1) {
+                if (t + d + DW - 1 < t1) load_stage((d + DW - 1) % DW, t + d + DW - 1);
+                multiply_stage(d);
+            }
         }
     }
 
@@ -271,12 +300,21 @@ static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_
     const int64_t waves = (int64_t)N * ptiles * G * mblocks, x_elems = (int64_t)N * Cin * HW;
     const dim3 grid(wave_grid_blocks(waves)), block(256);
     const int xcd = g_conv1x1_tune[0];
-#define COT_C3_LAUNCH(MT_)                                                                                            \
-    COT_LAUNCH((conv3x3g_fwd_mfma<PXV, MT_, AL>), grid, block, 0, stream, x, A, y, masks, Cin, Cout, G, H, W, mblocks, \
+#define COT_C3_LAUNCH(MT_, D_)                                                                                         \
+    COT_LAUNCH((conv3x3g_fwd_mfma<PXV, MT_, AL, D_>), grid, block, 0, stream, x, A, y, masks, Cin, Cout, G, H, W, mblocks, \
                ptiles, waves, x_elems, xcd, accumulate, dgrad)
-    if (MT == 1) COT_C3_LAUNCH(1);
-    else if (MT == 2) COT_C3_LAUNCH(2);
-    else COT_C3_LAUNCH(4);
+    // ring depth: big launches (many waves per SIMD resident) hide latency by occupancy and keep their registers for
+    // that; small ones get as deep a ring as fits next to the PXV*MT*4 accumulators
+    const bool big = waves >= 8192;
+    if (MT == 1) {
+        if (big) COT_C3_LAUNCH(1, 1);
+        else COT_C3_LAUNCH(1, (PXV == 8 ? 3 : 4));
+    } else if (MT == 2) {
+        if (big) COT_C3_LAUNCH(2, 1);
+        else COT_C3_LAUNCH(2, (PXV == 8 ? 2 : 3));
+    } else {
+        COT_C3_LAUNCH(4, (PXV == 8 ? 1 : 2));
+    }
 #undef COT_C3_LAUNCH
     return check_launch("conv3x3g_fwd_mfma");
 }
@@ -304,7 +342,8 @@ int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW) {
     if (g_conv1x1_tune[2] < 0) return (int)(-g_conv1x1_tune[2] < T ? -g_conv1x1_tune[2] : T);  // forced split (tests)
     int64_t S = ceil_div64(g_conv1x1_tune[2] > 0 ? g_conv1x1_tune[2] : 2048, units);
     const int64_t in_bytes = (int64_t)N * HW * (Cin + Cout) * 2, out_bytes = (int64_t)Cout * Jg * 4;
-    const int64_t cap = in_bytes / 8 / out_bytes;
+    int64_t cap = in_bytes / 8 / out_bytes;
+    if (cap < 4 && T >= 64) cap = 4;  // (a slice should not be a chain of hundreds of dependent steps)
     if (S > cap) S = cap;
     if (S > T) S = T;
     if (S < 1) S = 1;

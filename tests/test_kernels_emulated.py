@@ -32,6 +32,7 @@ def P(t):
 def _default_knobs():
     yield
     if _EMUL is not None:  # process-global developer knobs back to their defaults after every test
+        _EMUL.cot_set_tuning(10, 0)
         _EMUL.cot_set_tuning(11, 2048)
         _EMUL.cot_set_tuning(12, 0)
 
@@ -378,6 +379,8 @@ def _conv1x1_ref(x, w, b):
     (2, 48, 40, 8, 8, 16, True),      # two input slabs (the torch.cat the kernel absorbs)
     (1, 24, 16, 7, 7, 8, False),
     (2, 64, 144, 16, 24, 0, True),    # three pixel tiles, three m-blocks of 64 (MT=4), two K steps
+    (1, 520, 40, 7, 7, 0, False),     # deep K (16.25 steps): the prefetch ring wraps several times, partial last step
+    (1, 328, 136, 8, 8, 200, True),   # deep K over two slabs, M = 136 (data gradient: K = 136, 4.25 steps)
 ])
 @pytest.mark.parametrize("splits", [0, 3])
 def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
@@ -925,3 +928,24 @@ def test_no_kernel_touches_memory_past_its_tensors():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(build_emul.__file__)), "guard_check.py")],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "GUARD_OK" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-800:])
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W", [(2, 64, 144, 16, 24), (1, 72, 80, 7, 7), (1, 200, 64, 14, 14)])
+def test_conv1x1_with_64_rows_per_wave(N, Ci, Co, H, W):
+    """the 64-output-channels-per-wave variants (picked automatically only for launches with thousands of waves) forced
+    through cot_set_tuning(10, 4)"""
+    assert _EMUL.cot_set_tuning(10, 4) == 0
+    torch.manual_seed(17)
+    HW = H * W
+    x = torch.randn(N, Ci, H, W).bfloat16()
+    w = (torch.randn(Co, Ci) / Ci ** 0.5).bfloat16()
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    xf, wf, _, yref = _conv1x1_ref(x, w, None)
+    yref.backward(gy.float())
+    dt = _lib.dtype_code(torch.bfloat16)
+    y, gx = torch.full_like(gy, float("nan")), torch.full_like(x, float("nan"))
+    assert _EMUL.cot_conv1x1_forward(P(x), None, Ci, P(w), None, P(y), N, Ci, Co, HW, dt, None) == 0
+    assert torch.allclose(y.float(), yref.detach(), atol=2e-2, rtol=2e-2)
+    ws = torch.empty(_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 0), dtype=torch.uint8)
+    assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, HW, dt, None) == 0
+    assert torch.allclose(gx.float(), xf.grad, atol=3e-2, rtol=2e-2)
