@@ -221,8 +221,64 @@ def probe_child(args, dev=None, make_model=None, warm=4, timed=8):
                 torch.cuda.empty_cache()
         except Exception as e:  # a kernel set that cannot run is simply not eligible
             out["sets"][name] = {"parity": False, "error": f"{type(e).__name__}: {e}"[:300]}
+    if dev.type == "cuda":
+        try:  # the same step replayed from a HIP graph, on the fastest verified kernel set
+            ok = {n: v["ms_per_step"] for n, v in out["sets"].items() if v.get("parity") and "ms_per_step" in v}
+            if ok:
+                best = min(ok, key=ok.get)
+                out["sets"][best + "+graph"] = probe_graph(best, make_model, dev, x, t, timed)
+        except Exception as e:
+            out["graph_error"] = f"{type(e).__name__}: {e}"[:300]
     print("PROBE_RESULT " + json.dumps(out), flush=True)
     return out
+
+
+def probe_graph(name, make_model, dev, x, t, timed):
+    """HIP-graph replay of the step against the eager step, in lock-step from identical weights: after EVERY one of six
+    replays the flat gradient buckets must match the eager ones (round 1 found replays that were right once and wrong
+    afterwards, DESIGN.md 5.3 -- this is the test for exactly that), then the replay is timed."""
+    from cotnet_amd.flat_sgd import FlatSGD, to_mixed_bf16
+    from cotnet_amd.graph_step import GraphedTrainStep
+    apply_kernel_set(name)
+
+    def loss_fn(o, tt):
+        return torch.nn.functional.cross_entropy(o.float(), tt)
+
+    pair = []
+    for _ in range(2):
+        torch.manual_seed(4321)
+        m = to_mixed_bf16(make_model().to(dev)).train()
+        pair.append((m, FlatSGD(m, lr=1e-3, momentum=0.9, weight_decay=4e-5, nesterov=True)))
+    (me, oe), (mg, og) = pair
+    for _ in range(3):  # the graph's constructor runs three eager warm-up steps: keep the eager twin in step
+        oe.zero_grad()
+        loss_fn(me(x), t).backward()
+        oe.step()
+    gstep = GraphedTrainStep(mg, og, loss_fn, x, t, warmup=3)
+    worst = 0.0
+    for _ in range(6):
+        oe.zero_grad()
+        loss_fn(me(x), t).backward()
+        oe.reducer.finish()
+        ge = [b.flat.float().clone() for b in oe.reducer.buckets]
+        gstep.graph.replay()
+        gg = [b.flat.float() for b in og.reducer.buckets]
+        torch.cuda.synchronize()
+        for a, b in zip(ge, gg):
+            if not torch.isfinite(b).all():
+                return {"parity": False, "error": "non-finite gradients from a graph replay"}
+            worst = max(worst, float((a - b).abs().mean() / (a.abs().mean() + 1e-12)))
+        oe.step(graphed=True)  # (finish() already ran: a second one would refill the buckets from the dropped .grad's)
+        og.step(graphed=True)
+    rec = {"grad_mean_rel_diff_over_6_replays": round(worst, 4), "parity": bool(worst < 0.1)}
+    if rec["parity"]:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            gstep()
+        torch.cuda.synchronize()
+        rec["ms_per_step"] = round((time.perf_counter() - t0) / timed * 1e3, 3)
+    return rec
 
 
 def choose_kernels(args):
@@ -301,6 +357,9 @@ def main():
                     store.wait(["cot_kernel_set"], datetime.timedelta(minutes=25))
                     chosen = store.get("cot_kernel_set").decode()
         selection["chosen"] = chosen
+        if chosen.endswith("+graph"):
+            chosen = chosen[:-len("+graph")]
+            args.graph = True
         if rank == 0:
             print(f"[bench] kernel set: {chosen}  ({json.dumps(selection)[:600]})", file=sys.stderr, flush=True)
         apply_kernel_set(chosen)

@@ -111,3 +111,14 @@ def test_probe_child_body_on_emulated_kernels(monkeypatch, capsys):
     tke._EMUL.cot_set_tuning(12, 0)
     for cache in (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS):
         cache.clear()
+
+
+def test_graph_variant_is_chosen_only_when_verified(monkeypatch):
+    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": True, "ms_per_step": 30.0},
+                  **{"new+graph": {"parity": True, "ms_per_step": 24.0, "grad_mean_rel_diff_over_6_replays": 0.01}})
+    monkeypatch.setattr(subprocess, "run", _fake_run(out))
+    assert bench.choose_kernels(_args())[0] == "new+graph"
+    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": True, "ms_per_step": 30.0},
+                  **{"new+graph": {"parity": False, "grad_mean_rel_diff_over_6_replays": 0.9}})
+    monkeypatch.setattr(subprocess, "run", _fake_run(out))
+    assert bench.choose_kernels(_args())[0] == "new"
