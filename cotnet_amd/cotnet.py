@@ -23,6 +23,7 @@ from . import cot_layer_fused, radix_tail
 from .conv1x1 import conv1x1, run_downsample
 from .conv3x3g import conv3x3
 from .group_norm9 import group_norm9
+from .pool3x3 import pool
 from .fused_bn import fused_bn_act
 from .layers import get_act_layer
 from .registry import build_model_with_cfg, register_model
@@ -245,7 +246,7 @@ class Bottleneck(nn.Module):
                 x = self.drop_block(x)
             x = self.act1(x)
         if self.avd is not None:
-            x = self.avd(x)
+            x = pool(self.avd, x)
         x = self.conv2(x)
         x = conv1x1(self.conv3, x)
         if fusable and self.drop_path is None:

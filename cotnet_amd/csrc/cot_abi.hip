@@ -112,6 +112,8 @@ int conv1x1_gemm(const void*, const void*, int, const void*, const void*, void*,
 int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_conv1x1_tune[4];
+// implemented in pool3x3.hip
+template <typename T> int pool3x3s2(int, const void*, const void*, void*, int64_t, int, int, hipStream_t);
 // implemented in group_norm9.hip
 int gn9_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, hipStream_t);
 int gn9_backward(const void*, const void*, const float*, const float*, const void*, void*, void*, void*, float*, int, int,
@@ -480,6 +482,27 @@ int cot_radix_mix_backward_apply(const void* gout, const void* attn, const void*
     if ((rc = check_align16({gout, gy, gk}))) return rc;
     return dtype == COT_F32 ? radix_mix_bwd_apply<float>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream)
                             : radix_mix_bwd_apply<bf16_t>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream);
+}
+
+static int pool_call(int op, const void* a, const void* b, void* out, int64_t planes, int H, int W, int dtype, void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive planes/H/W");
+    if (!a || !out || (op == 3 && !b)) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (dtype == COT_F32) return pool3x3s2<float>(op, a, b, out, planes, H, W, (hipStream_t)stream);
+    if (dtype == COT_BF16) return pool3x3s2<bf16_t>(op, a, b, out, planes, H, W, (hipStream_t)stream);
+    return set_error(COT_ERR_UNSUPPORTED, "cot_*pool3x3s2_*: dtype %d (float32 / bfloat16 only)", dtype);
+}
+int cot_avgpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream) {
+    return pool_call(0, x, nullptr, y, planes, H, W, dtype, stream);
+}
+int cot_avgpool3x3s2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream) {
+    return pool_call(1, gy, nullptr, gx, planes, H, W, dtype, stream);
+}
+int cot_maxpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream) {
+    return pool_call(2, x, nullptr, y, planes, H, W, dtype, stream);
+}
+int cot_maxpool3x3s2_backward(const void* gy, const void* x, void* gx, int64_t planes, int H, int W, int dtype,
+                              void* stream) {
+    return pool_call(3, gy, x, gx, planes, H, W, dtype, stream);
 }
 
 static int gn9_validate(int N, int C, int HW, int dtype) {

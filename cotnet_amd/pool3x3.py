@@ -1,0 +1,101 @@
+"""The backbone's two 3x3 / stride-2 / padding-1 poolings on csrc/pool3x3.hip (opt-in COT_POOL=hip).
+
+`pool(module, x)` evaluates `nn.MaxPool2d(3, 2, 1)` (after the stem, models/resnet.py:556-561) or `nn.AvgPool2d(3, 2,
+padding=1)` (the "avd" pooling of stride-2 bottlenecks, models/cotnet.py:216) with kernels whose backward runs at
+memory speed -- torch's max_pool_backward / avg_pool2d_backward were 436 us and 3 x 163 us of the round-1 step for ~30 us of
+traffic each; the max-pool backward recomputes the arg-max (torch's tie rule) instead of reading an int64 index tensor.
+Any other module or tensor (other geometry, ceil_mode, fp64, channels-last, CPU) takes the module itself.
+"""
+import ctypes
+import os
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import _lib
+
+MODE = os.environ.get("COT_POOL", "")
+_DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
+_DT = {torch.float32: _lib.COT_F32, torch.bfloat16: _lib.COT_BF16}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if _DEVICE_ONLY else None
+
+
+def _out(x):
+    N, C, H, W = x.shape
+    return torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device)
+
+
+class _AvgPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        y = _out(x)
+        rc = _lib.lib().cot_avgpool3x3s2_forward(_p(x), _p(y), N * C, H, W, _DT[x.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_avgpool3x3s2_forward")
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty(ctx.shape, dtype=gy.dtype, device=gy.device)
+        rc = _lib.lib().cot_avgpool3x3s2_backward(_p(gy), _p(gx), N * C, H, W, _DT[gy.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_avgpool3x3s2_backward")
+        return gx
+
+
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        y = _out(x)
+        rc = _lib.lib().cot_maxpool3x3s2_forward(_p(x), _p(y), N * C, H, W, _DT[x.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_maxpool3x3s2_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        rc = _lib.lib().cot_maxpool3x3s2_backward(_p(gy), _p(x), _p(gx), N * C, H, W, _DT[x.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_maxpool3x3s2_backward")
+        return gx
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def eligible(module, x):
+    if not (MODE == "hip" and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4 and x.dtype in _DT and x.is_contiguous()):
+        return False
+    if isinstance(module, nn.MaxPool2d):
+        return (_pair(module.kernel_size) == (3, 3) and _pair(module.stride) == (2, 2) and _pair(module.padding) == (1, 1)
+                and _pair(module.dilation) == (1, 1) and not module.ceil_mode and not module.return_indices)
+    if isinstance(module, nn.AvgPool2d):
+        return (_pair(module.kernel_size) == (3, 3) and _pair(module.stride) == (2, 2) and _pair(module.padding) == (1, 1)
+                and not module.ceil_mode and module.count_include_pad and module.divisor_override is None)
+    return False
+
+
+def pool(module, x):
+    """`module(x)`; the two backbone poolings go through the HIP kernels when COT_POOL=hip and the tensor qualifies"""
+    if MODE == "hip" and eligible(module, x):
+        return (_MaxPool if isinstance(module, nn.MaxPool2d) else _AvgPool).apply(x)
+    return module(x)

@@ -11,6 +11,7 @@ from torch import nn
 
 from .fused_bn import fused_bn_act
 from .layers import AvgPool2dSame, DropPath, create_classifier
+from .pool3x3 import pool
 
 
 def get_padding(kernel_size, stride, dilation=1):
@@ -162,7 +163,7 @@ class ResNet(nn.Module):
             x = fused_bn_act(self.conv1(x), self.bn1, "relu")  # stem BN + ReLU in one pass over the 112x112 map
         else:
             x = self.act1(self.bn1(self.conv1(x)))
-        x = self.maxpool(x)
+        x = pool(self.maxpool, x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
     def forward(self, x):

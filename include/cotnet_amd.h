@@ -213,6 +213,18 @@ int cot_group_norm9_backward(const void* dy, const void* x, const float* mean, c
                              void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int dtype,
                              void* stream);
 
+/* ---- the backbone's two 3x3 / stride-2 / padding-1 poolings, NCHW, `planes` = N*C images of H x W -> Ho = (H-1)/2 + 1:
+ *   cot_avgpool3x3s2_*  nn.AvgPool2d(3, 2, padding=1) (count_include_pad: every window / 9) -- the "avd" pooling of
+ *                       stride-2 bottlenecks, models/cotnet.py:216
+ *   cot_maxpool3x3s2_*  nn.MaxPool2d(kernel_size=3, stride=2, padding=1) after the stem, models/resnet.py:556-561; the
+ *                       backward recomputes the arg-max from x with torch's tie rule (first maximum in row-major window
+ *                       order) instead of reading an index tensor.   COT_F32 / COT_BF16. */
+int cot_avgpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);
+int cot_avgpool3x3s2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream);
+int cot_maxpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);
+int cot_maxpool3x3s2_backward(const void* gy, const void* x, void* gx, int64_t planes, int H, int W, int dtype,
+                              void* stream);
+
 /* ---- fused SGD over a flat parameter bucket (replaces torch.optim.SGD(nesterov=True),
  * optim/optim_factory.py:54-56, which launches per parameter tensor):
  *     g = grad*grad_scale + weight_decay*p;  buf = momentum*buf + g;  p -= lr*(nesterov ? g + momentum*buf : buf)

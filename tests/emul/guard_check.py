@@ -129,6 +129,17 @@ def radix(N, C, H, W, dtype):
     assert E.cot_radix_mix_backward(P(g), P(y), P(k), P(attn), P(gy), P(gk), P(ga), N * C, HW, dt, None) == 0
 
 
+def pooling(N, C, H, W, dtype):
+    dt = _lib.dtype_code(dtype)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x, gx = guarded(torch.randn(N, C, H, W).to(dtype)), guarded(torch.empty(N, C, H, W).to(dtype))
+    y, gy = guarded(torch.empty(N, C, Ho, Wo).to(dtype)), guarded(torch.randn(N, C, Ho, Wo).to(dtype))
+    assert E.cot_maxpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
+    assert E.cot_maxpool3x3s2_backward(P(gy), P(x), P(gx), N * C, H, W, dt, None) == 0
+    assert E.cot_avgpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
+    assert E.cot_avgpool3x3s2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     # tensors whose byte size is a multiple of 16 keep the 16-byte base alignment the ABI asks for
@@ -146,4 +157,6 @@ if __name__ == "__main__":
             for fold in (0, 1):
                 bn_act(*shape, dtype, fold)
             radix(*shape, dtype)
+        for shape in [(2, 4, 8, 8), (1, 8, 7, 7), (2, 4, 5, 9), (8, 2, 1, 1)]:
+            pooling(*shape, dtype)
     print("GUARD_OK")

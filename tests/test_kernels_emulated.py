@@ -833,7 +833,8 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
     import copy
     import cotnet_amd
     import cotnet_amd.aggregation_zeropad as az
-    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, group_norm9 as g9, radix_tail
+    from cotnet_amd import (cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, group_norm9 as g9, pool3x3 as p3,
+                            radix_tail)
     from cotnet_amd.data_parallel import GradBucketReducer
     from cotnet_amd.flat_sgd import _decay_group, to_mixed_bf16
     torch.manual_seed(21)
@@ -842,7 +843,7 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
     target = torch.tensor([1, 7, 3, 3])
 
     monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
-    for mod in (clf, c1, c3, fused_bn, radix_tail, g9):
+    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, p3):
         monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
     monkeypatch.setattr(az, "aggregation_zeropad",
                         lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
@@ -852,7 +853,7 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
         for cache in caches:
             cache.clear()
         monkeypatch.setattr(clf, "ENABLED", opt_in)
-        for mod in (c1, c3, g9):
+        for mod in (c1, c3, g9, p3):
             monkeypatch.setattr(mod, "MODE", "hip" if opt_in else "")
         model = copy.deepcopy(base)
         red = GradBucketReducer(model, group_fn=_decay_group, grad_mode="copy", flatten_params=True, broadcast_params=False)
@@ -949,3 +950,30 @@ def test_conv1x1_with_64_rows_per_wave(N, Ci, Co, H, W):
     ws = torch.empty(_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 0), dtype=torch.uint8)
     assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, HW, dt, None) == 0
     assert torch.allclose(gx.float(), xf.grad, atol=3e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 4, 7, 7), (2, 2, 14, 14), (1, 2, 5, 9), (1, 1, 1, 1), (1, 2, 2, 3)])
+def test_pooling_kernels_match_torch(N, C, H, W, dtype):
+    """csrc/pool3x3.hip against nn.MaxPool2d(3, 2, 1) / nn.AvgPool2d(3, 2, padding=1); the max pooling is exercised on a
+    ReLU output (ties at zero everywhere): the recomputed arg-max must follow torch's first-maximum rule exactly"""
+    torch.manual_seed(31)
+    dt = _lib.dtype_code(dtype)
+    x = torch.relu(torch.randn(N, C, H, W)).to(dtype)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = torch.randn(N, C, Ho, Wo).to(dtype)
+    for kind, mod in (("max", torch.nn.MaxPool2d(3, 2, 1)), ("avg", torch.nn.AvgPool2d(3, 2, padding=1))):
+        xr = x.float().clone().requires_grad_(True)
+        yr = mod(xr)
+        yr.backward(gy.float())
+        y, gx = torch.full((N, C, Ho, Wo), float("nan")).to(dtype), torch.full_like(x, float("nan"))
+        if kind == "max":
+            assert _EMUL.cot_maxpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
+            assert _EMUL.cot_maxpool3x3s2_backward(P(gy), P(x), P(gx), N * C, H, W, dt, None) == 0
+            assert torch.equal(y.float(), yr.detach())
+        else:
+            assert _EMUL.cot_avgpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
+            assert _EMUL.cot_avgpool3x3s2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
+            assert torch.allclose(y.float(), yr.detach(), atol=1e-6 if dtype == torch.float32 else 1e-2)
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert torch.allclose(gx.float(), xr.grad, atol=tol, rtol=tol), kind

@@ -1,0 +1,41 @@
+"""csrc/pool3x3.hip (opt-in COT_POOL=hip) on the GPU against nn.MaxPool2d(3, 2, 1) / nn.AvgPool2d(3, 2, padding=1)."""
+import pytest
+import torch
+from torch import nn
+
+from cotnet_amd import pool3x3 as p3
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H", [(8, 64, 112), (8, 128, 56), (8, 256, 28), (8, 512, 14), (3, 5, 9), (2, 3, 1)])
+@pytest.mark.parametrize("kind", ["max", "avg"])
+def test_matches_torch_pooling(kind, N, C, H, dtype, monkeypatch):
+    monkeypatch.setattr(p3, "MODE", "hip")
+    torch.manual_seed(H)
+    mod = nn.MaxPool2d(3, 2, 1) if kind == "max" else nn.AvgPool2d(3, 2, padding=1)
+    x = torch.relu(torch.randn(N, C, H, H, device=DEV)).to(dtype)   # post-ReLU: ties at zero everywhere
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    assert p3.eligible(mod, xa)
+    ya = p3.pool(mod, xa)
+    yb = mod(xb)
+    g = torch.randn_like(yb)
+    ya.backward(g)
+    yb.backward(g)
+    if kind == "max":
+        assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)   # same arg-max rule: bit-identical
+    else:
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert torch.allclose(ya.float(), yb.float(), atol=tol, rtol=tol)
+        assert torch.allclose(xa.grad.float(), xb.grad.float(), atol=tol, rtol=tol)
+
+
+def test_other_poolings_keep_the_module(monkeypatch):
+    monkeypatch.setattr(p3, "MODE", "hip")
+    x = torch.randn(2, 4, 8, 8, device=DEV)
+    for mod in (nn.MaxPool2d(2, 2), nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False), nn.MaxPool2d(3, 1, 1)):
+        assert not p3.eligible(mod, x)
+        assert torch.equal(p3.pool(mod, x), mod(x))
+    assert not p3.eligible(nn.MaxPool2d(3, 2, 1), x.double())
