@@ -155,10 +155,24 @@ def conv1x1(conv, x, x2=None):
 
 
 def run_downsample(ds, x):
-    """`ds(x)` for the residual branch's nn.Sequential (pool, 1x1 conv, norm -- models/resnet.py:364-394) with the
-    convolution routed through `conv1x1`"""
+    """`ds(x)` for the residual branch's nn.Sequential ([pool,] 1x1 conv, norm -- models/resnet.py:364-394) with the
+    convolution routed through `conv1x1`.  A stride-2 1x1 convolution (the stage-entry projection when avg_down is off)
+    is the stride-1 one on every second pixel: subsample, then the same kernels; its BatchNorm goes through the fused
+    BatchNorm kernels instead of MIOpen."""
     if MODE and isinstance(ds, torch.nn.Sequential):
+        from .fused_bn import fused_bn_act
         for m in ds:
-            x = conv1x1(m, x) if isinstance(m, torch.nn.Conv2d) else m(x)
+            if isinstance(m, torch.nn.Conv2d):
+                if (MODE == "hip" and m.kernel_size == (1, 1) and m.stride == (2, 2) and m.padding == (0, 0)
+                        and m.groups == 1 and x.dim() == 4 and x.dtype == torch.bfloat16
+                        and m.weight.dtype == torch.bfloat16 and (x.is_cuda or not _DEVICE_ONLY)
+                        and m.in_channels % 8 == 0 and m.out_channels % 8 == 0):
+                    x = _Conv1x1Hip.apply(x[:, :, ::2, ::2].contiguous(), None, m.weight, m.bias)
+                else:
+                    x = conv1x1(m, x)
+            elif isinstance(m, torch.nn.BatchNorm2d):
+                x = fused_bn_act(x, m, None)  # (falls back to the module itself when not eligible)
+            else:
+                x = m(x)
         return x
     return ds(x)

@@ -977,3 +977,35 @@ def test_pooling_kernels_match_torch(N, C, H, W, dtype):
             assert torch.allclose(y.float(), yr.detach(), atol=1e-6 if dtype == torch.float32 else 1e-2)
         tol = 1e-5 if dtype == torch.float32 else 2e-2
         assert torch.allclose(gx.float(), xr.grad, atol=tol, rtol=tol), kind
+
+
+def test_strided_projection_shortcut_on_emulated_kernels(monkeypatch):
+    """conv1x1.run_downsample: a stride-2 1x1 projection (+ BatchNorm) as subsample + the stride-1 kernels"""
+    from cotnet_amd import conv1x1 as c1, fused_bn
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    from cotnet_amd.resnet import downsample_conv
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    monkeypatch.setattr(c1, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(fused_bn, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(c1, "MODE", "hip")
+    c1._WS.clear()
+    fused_bn._WS.clear()
+    torch.manual_seed(12)
+    ds = to_mixed_bf16(downsample_conv(32, 64, 1, stride=2)).train()
+    assert ds[0].stride == (2, 2) and ds[0].kernel_size == (1, 1)
+    x = torch.randn(3, 32, 9, 8).bfloat16().requires_grad_(True)
+    y = c1.run_downsample(ds, x)
+    assert "BNAct" in y.grad_fn.name()
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(32, 64, 1, stride=2, bias=False), torch.nn.BatchNorm2d(64)).train()
+    ref[0].weight.data = ds[0].weight.data.float()
+    xr = x.detach().float().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g.float())
+    assert y.shape == yr.shape
+    assert torch.allclose(y.float(), yr.detach(), atol=5e-2, rtol=5e-2)
+    assert (x.grad.float() - xr.grad).abs().mean() < 0.05 * xr.grad.abs().mean() + 1e-3
+    assert (ds[0].weight.grad.float() - ref[0].weight.grad).abs().mean() < 0.05 * ref[0].weight.grad.abs().mean() + 1e-3
+    c1._WS.clear()
+    fused_bn._WS.clear()
