@@ -445,7 +445,7 @@ int cot_radix_gap_t(const void* y, const void* k, void* gapT, int N, int C, int 
     int rc = tail_check((int64_t)N * C, HW, dtype);
     if (rc) return rc;
     if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive N=%d C=%d", N, C);
-    if (!y || !k || !gapT) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (!y || !gapT) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");  // k == NULL: pool y alone
     if ((rc = check_align16({y, k}))) return rc;
     return dtype == COT_F32 ? radix_gap_t<float>(y, k, gapT, N, C, HW, (hipStream_t)stream)
                             : radix_gap_t<bf16_t>(y, k, gapT, N, C, HW, (hipStream_t)stream);

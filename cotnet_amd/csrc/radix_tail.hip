@@ -103,12 +103,20 @@ __global__ __launch_bounds__(256) void radix_gap_t_kernel(const T* __restrict__ 
     const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (plane >= (int64_t)N * C) return;
     const T* yp = y + plane * HW;
-    const T* kp = k + plane * HW;
     float acc = 0.f;
-    for (int i = lane * V; i < HW; i += 64 * V) {
-        const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
+    if (k) {
+        const T* kp = k + plane * HW;
+        for (int i = lane * V; i < HW; i += 64 * V) {
+            const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc += (float)a.v[j] + (float)b.v[j];
+            for (int j = 0; j < V; ++j) acc += (float)a.v[j] + (float)b.v[j];
+        }
+    } else {  // plain global average pooling (the classifier head)
+        for (int i = lane * V; i < HW; i += 64 * V) {
+            const Vec<T, V> a = ldv<T, V>(yp + i);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc += (float)a.v[j];
+        }
     }
     acc = wave_sum_f(acc);
     const int n = (int)(plane / C), c = (int)(plane % C);

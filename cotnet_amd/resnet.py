@@ -12,6 +12,7 @@ from torch import nn
 from .fused_bn import fused_bn_act
 from .layers import AvgPool2dSame, DropPath, create_classifier
 from .pool3x3 import pool
+from .head_fused import head
 
 
 def get_padding(kernel_size, stride, dilation=1):
@@ -167,7 +168,8 @@ class ResNet(nn.Module):
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
     def forward(self, x):
-        x = self.global_pool(self.forward_features(x))
-        if self.drop_rate:
-            x = F.dropout(x, p=float(self.drop_rate), training=self.training)
+        x = self.forward_features(x)
+        if not self.drop_rate:
+            return head(self.global_pool, self.fc, x)  # fc(global_pool(x)), on the library's kernels when opted in
+        x = F.dropout(self.global_pool(x), p=float(self.drop_rate), training=self.training)
         return self.fc(x)

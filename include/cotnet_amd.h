@@ -187,7 +187,7 @@ int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, c
 /* Channel-major variants for running the `se` branch (models/cotnet.py:71-77,:98-101) on the library's own kernels: with
  * the pooled descriptor stored [C][N] the two 1x1 convolutions of `se` are cot_conv1x1_* calls on ONE image of N
  * "pixels" and its BatchNorm is cot_bn_act_* over those N pixels (= over the batch, as nn.BatchNorm2d on [N,A,1,1]).
- *   cot_radix_gap_t               gapT[c][n] = mean_hw(y + k)
+ *   cot_radix_gap_t               gapT[c][n] = mean_hw(y + k)   (k == NULL: mean_hw(y), the classifier head's global pooling)
  *   cot_radix_mix_logits          attn[n][c][0..1] = softmax over the pair (logitsT[2c][n], logitsT[2c+1][n])  (saved for
  *                                 backward), out = y*attn0 + k*attn1
  *   cot_radix_mix_backward_reduce glogitsT[2c][n] = a0*a1*(sum g*y - sum g*k) = -glogitsT[2c+1][n]  (pair-softmax backward)

@@ -833,27 +833,27 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
     import copy
     import cotnet_amd
     import cotnet_amd.aggregation_zeropad as az
-    from cotnet_amd import (cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, group_norm9 as g9, pool3x3 as p3,
-                            radix_tail)
+    from cotnet_amd import (cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, group_norm9 as g9, head_fused as hf,
+                            pool3x3 as p3, radix_tail)
     from cotnet_amd.data_parallel import GradBucketReducer
     from cotnet_amd.flat_sgd import _decay_group, to_mixed_bf16
     torch.manual_seed(21)
-    base = to_mixed_bf16(cotnet_amd.create_model("cotnet50", num_classes=10)).train()
+    base = to_mixed_bf16(cotnet_amd.create_model("cotnet50", num_classes=16)).train()
     x = torch.randn(4, 3, 64, 64).bfloat16()
     target = torch.tensor([1, 7, 3, 3])
 
     monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
-    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, p3):
+    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, p3, hf):
         monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
     monkeypatch.setattr(az, "aggregation_zeropad",
                         lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
-    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
+    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS, hf._WS)
 
     def run(opt_in):
         for cache in caches:
             cache.clear()
         monkeypatch.setattr(clf, "ENABLED", opt_in)
-        for mod in (c1, c3, g9, p3):
+        for mod in (c1, c3, g9, p3, hf):
             monkeypatch.setattr(mod, "MODE", "hip" if opt_in else "")
         model = copy.deepcopy(base)
         red = GradBucketReducer(model, group_fn=_decay_group, grad_mode="copy", flatten_params=True, broadcast_params=False)
@@ -876,6 +876,7 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
     loss_a, grads_a, nodes_a, count_a = run(False)
     loss_b, grads_b, nodes_b, count_b = run(True)
     assert any(n.startswith("_BottleneckNode") for n in nodes_b) and any(n.startswith("_CotLayerNode") for n in nodes_b)
+    assert any(n.startswith("_Head") for n in nodes_b) and any(n.startswith("_MaxPool") for n in nodes_b)
     assert not any(n.startswith("_CotLayerNode") or n.startswith("_BottleneckNode") for n in nodes_a)
     assert count_b < 0.6 * count_a   # the autograd graph really is that much smaller (161 of the nodes are leaves)
     assert abs(loss_a - loss_b) < 2e-2 * abs(loss_a)
@@ -1009,3 +1010,31 @@ def test_strided_projection_shortcut_on_emulated_kernels(monkeypatch):
     assert (ds[0].weight.grad.float() - ref[0].weight.grad).abs().mean() < 0.05 * ref[0].weight.grad.abs().mean() + 1e-3
     c1._WS.clear()
     fused_bn._WS.clear()
+
+
+def test_classifier_head_on_emulated_kernels(monkeypatch):
+    """cotnet_amd.head_fused: global average pooling + fc as channel-major pooling + 1x1 convolution over the batch axis"""
+    from cotnet_amd import head_fused as hf
+    from cotnet_amd.layers import create_classifier
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    monkeypatch.setattr(hf, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(hf, "MODE", "hip")
+    hf._WS.clear()
+    torch.manual_seed(14)
+    pool, fc = create_classifier(64, 24, pool_type="avg")
+    fc = fc.bfloat16()
+    x = torch.randn(5, 64, 7, 7).bfloat16().requires_grad_(True)
+    assert hf.eligible(pool, fc, x)
+    y = hf.head(pool, fc, x)
+    assert y.shape == (5, 24) and y.grad_fn.name().startswith("_Head")
+    g = torch.randn(5, 24).bfloat16()
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    wr, br = fc.weight.detach().float().requires_grad_(True), fc.bias.detach().float().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr.mean((2, 3)), wr, br)
+    yr.backward(g.float())
+    assert torch.allclose(y.float(), yr.detach(), atol=2e-2, rtol=2e-2)
+    assert torch.allclose(x.grad.float(), xr.grad, atol=1e-3, rtol=3e-2)
+    assert torch.allclose(fc.weight.grad.float(), wr.grad, atol=3e-2, rtol=3e-2)
+    assert torch.allclose(fc.bias.grad.float(), br.grad, atol=3e-2, rtol=3e-2)
+    hf._WS.clear()
