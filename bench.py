@@ -256,7 +256,7 @@ def probe_graph(name, make_model, dev, x, t, timed):
         loss_fn(me(x), t).backward()
         oe.step()
     gstep = GraphedTrainStep(mg, og, loss_fn, x, t, warmup=3)
-    worst = 0.0
+    worst, per_replay = 0.0, []
     for _ in range(6):
         oe.zero_grad()
         loss_fn(me(x), t).backward()
@@ -265,13 +265,16 @@ def probe_graph(name, make_model, dev, x, t, timed):
         gstep.graph.replay()
         gg = [b.flat.float() for b in og.reducer.buckets]
         torch.cuda.synchronize()
+        diffs = []
         for a, b in zip(ge, gg):
             if not torch.isfinite(b).all():
-                return {"parity": False, "error": "non-finite gradients from a graph replay"}
-            worst = max(worst, float((a - b).abs().mean() / (a.abs().mean() + 1e-12)))
+                return {"parity": False, "error": "non-finite gradients from a graph replay", "per_replay": per_replay}
+            diffs.append(round(float((a - b).abs().mean() / (a.abs().mean() + 1e-12)), 4))
+        per_replay.append(diffs)  # one number per gradient bucket (bucket 0 is filled first: fc, layer4, ...)
+        worst = max(worst, max(diffs))
         oe.step(graphed=True)  # (finish() already ran: a second one would refill the buckets from the dropped .grad's)
         og.step(graphed=True)
-    rec = {"grad_mean_rel_diff_over_6_replays": round(worst, 4), "parity": bool(worst < 0.1)}
+    rec = {"grad_mean_rel_diff_over_6_replays": round(worst, 4), "parity": bool(worst < 0.1), "per_replay": per_replay}
     if rec["parity"]:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
