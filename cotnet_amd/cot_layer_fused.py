@@ -329,24 +329,34 @@ def cot_layer_forward(layer, x):
     return _CotLayerNode.apply(layer, x, *_plan(layer).params)
 
 
-# ---- the whole Bottleneck (models/cotnet.py:228-264) as one node: conv1 -> bn1+relu -> CotLayer -> conv3 -> bn3 + residual
-# + relu, for the blocks without the avd pooling (13 of CoTNet-50's 16: every block but the three stride-2 ones); the
-# residual branch may carry the stage's 1x1 projection (`downsample` = [Identity,] conv1x1, BatchNorm).  dx collects the
-# residual gradient, the projection's and conv1's data gradients inside the kernels (`accumulate`).
+# ---- the whole Bottleneck (models/cotnet.py:228-264) as one node: conv1 -> bn1+relu [-> 3x3/2 average pooling "avd"] ->
+# CotLayer -> conv3 -> bn3 + residual + relu.  The residual branch may carry the stage's 1x1 projection (`downsample` =
+# [Identity,] conv1x1, BatchNorm); in a stride-2 block that projection has stride 2 = the stride-1 convolution on every
+# second pixel.  dx collects the residual gradient, the projection's and conv1's data gradients inside the kernels
+# (`accumulate`).
 class _BlockPlan:
-    __slots__ = ("conv1", "bn1", "cot", "conv3", "bn3", "ds_conv", "ds_bn", "params", "static_ok")
+    __slots__ = ("conv1", "bn1", "cot", "conv3", "bn3", "ds_conv", "ds_bn", "ds_stride", "avd", "params", "static_ok")
 
     def __init__(self, blk):
         from .cotnet import CotLayer
         self.conv1, self.bn1, self.cot, self.conv3, self.bn3 = blk.conv1, blk.bn1, blk.conv2, blk.conv3, blk.bn3
         ds = blk.downsample
         self.ds_conv = self.ds_bn = None
-        ds_ok = ds is None
+        self.ds_stride = 1
+        avd = blk.avd
+        self.avd = avd is not None
+        avd_ok = avd is None or (isinstance(avd, nn.AvgPool2d) and avd.kernel_size == 3 and avd.stride == 2
+                                 and avd.padding == 1 and not avd.ceil_mode and avd.count_include_pad
+                                 and avd.divisor_override is None)
+        ds_ok = ds is None and avd is None
         if isinstance(ds, nn.Sequential) and (len(ds) == 2 or (len(ds) == 3 and isinstance(ds[0], nn.Identity))):
             self.ds_conv, self.ds_bn = ds[-2], ds[-1]  # models/resnet.py:364-394: [pool,] conv, norm
-            ds_ok = _conv_ok(ds[-2], 1, 1) and ds[-2].bias is None and _bn_static_ok(ds[-1])
+            c = ds[-2]
+            self.ds_stride = 2 if avd is not None else 1
+            ds_ok = (isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.padding == (0, 0) and c.groups == 1
+                     and c.stride == (self.ds_stride, self.ds_stride) and c.bias is None and _bn_static_ok(ds[-1]))
         self.static_ok = (
-            ds_ok and isinstance(blk.conv2, CotLayer) and blk.avd is None and blk.drop_block is None
+            ds_ok and avd_ok and isinstance(blk.conv2, CotLayer) and blk.drop_block is None
             and blk.drop_path is None and blk.se is None and isinstance(blk.act1, nn.ReLU)
             and isinstance(blk.act3, nn.ReLU) and _conv_ok(blk.conv1, 1, 1) and blk.conv1.bias is None
             and _conv_ok(blk.conv3, 1, 1) and blk.conv3.bias is None and _bn_static_ok(blk.bn1)
@@ -383,32 +393,41 @@ class _BottleneckNode(Function):
         L = _lib.lib()
         bp = _block_plan(blk)
         N, Cin, H, W = x.shape
-        HW, Cw, Cout = H * W, bp.conv1.out_channels, bp.conv3.out_channels
+        Cw, Cout = bp.conv1.out_channels, bp.conv3.out_channels
+        Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if bp.avd else (H, W)  # 3x3/2 pooling, padding 1
+        HW, HWo = H * W, Ho * Wo
         dev, st = x.device, _stream()
-        ws_bytes, nws_w, nws_o = _block_sizes(L, N, Cin, Cw, Cout, HW)
-        new = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
+        _, nws_w, _ = _block_sizes(L, N, Cin, Cw, Cout, HW)
+        _, _, nws_o = _block_sizes(L, N, Cin, Cw, Cout, HWo)
+        new = lambda c, h, w: torch.empty((N, c, h, w), dtype=x.dtype, device=dev)  # noqa: E731
         stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
-        c1, a1 = new(Cw), new(Cw)
+        c1, a1 = new(Cw, H, W), new(Cw, H, W)
         _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(bp.conv1.weight), None, _p(c1), N, Cin, Cw, HW, BF16, st),
             "cot_conv1x1_forward")
         s_1 = stat(Cw, nws_w)
         _bn_fwd(L, c1, a1, bp.bn1, s_1, 2 * Cw, N, Cw, HW, 1)
-        cot_out, saved, geom = _cot_forward(L, bp.cot, a1)
-        c3, y = new(Cout), new(Cout)
-        _ck(L.cot_conv1x1_forward(_p(cot_out), None, Cw, _p(bp.conv3.weight), None, _p(c3), N, Cw, Cout, HW, BF16, st),
-            "cot_conv1x1_forward")
-        if bp.ds_conv is not None:  # projection shortcut: bn(conv1x1(x))
-            d0, res = new(Cout), new(Cout)
-            _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(bp.ds_conv.weight), None, _p(d0), N, Cin, Cout, HW, BF16, st),
-                "cot_conv1x1_forward")
-            s_d = stat(Cout, nws_o)
-            _bn_fwd(L, d0, res, bp.ds_bn, s_d, 2 * Cout, N, Cout, HW, 0)
+        if bp.avd:
+            p1 = new(Cw, Ho, Wo)
+            _ck(L.cot_avgpool3x3s2_forward(_p(a1), _p(p1), N * Cw, H, W, BF16, st), "cot_avgpool3x3s2_forward")
         else:
-            d0, res, s_d = None, x, None
+            p1 = a1
+        cot_out, saved, geom = _cot_forward(L, bp.cot, p1)
+        c3, y = new(Cout, Ho, Wo), new(Cout, Ho, Wo)
+        _ck(L.cot_conv1x1_forward(_p(cot_out), None, Cw, _p(bp.conv3.weight), None, _p(c3), N, Cw, Cout, HWo, BF16, st),
+            "cot_conv1x1_forward")
+        if bp.ds_conv is not None:  # projection shortcut: bn(conv1x1(x)), on every second pixel in a stride-2 block
+            xs = x[:, :, ::2, ::2].contiguous() if bp.ds_stride == 2 else x
+            d0, res = new(Cout, Ho, Wo), new(Cout, Ho, Wo)
+            _ck(L.cot_conv1x1_forward(_p(xs), None, Cin, _p(bp.ds_conv.weight), None, _p(d0), N, Cin, Cout, HWo, BF16,
+                                      st), "cot_conv1x1_forward")
+            s_d = stat(Cout, nws_o)
+            _bn_fwd(L, d0, res, bp.ds_bn, s_d, 2 * Cout, N, Cout, HWo, 0)
+        else:
+            xs, d0, res, s_d = None, None, x, None
         s_3 = stat(Cout, nws_o)
-        _bn_fwd(L, c3, y, bp.bn3, s_3, 2 * Cout, N, Cout, HW, 1, residual=res)
+        _bn_fwd(L, c3, y, bp.bn3, s_3, 2 * Cout, N, Cout, HWo, 1, residual=res)
         ctx.blk, ctx.geom, ctx.has_ds = blk, geom, bp.ds_conv is not None
-        extra = (x, c1, a1, s_1, cot_out, c3, y, s_3) + ((d0, s_d) if bp.ds_conv is not None else ())
+        extra = (x, c1, a1, s_1, cot_out, c3, y, s_3) + ((d0, s_d, xs) if bp.ds_conv is not None else ())
         ctx.save_for_backward(*(saved + extra))
         return y
 
@@ -421,33 +440,49 @@ class _BottleneckNode(Function):
         saved, extra = t[:_N_SAVED], t[_N_SAVED:]
         x, c1, a1, s_1, cot_out, c3, y, s_3 = extra[:8]
         N, Cin, H, W = x.shape
-        HW, Cw, Cout = H * W, bp.conv1.out_channels, bp.conv3.out_channels
+        Cw, Cout = bp.conv1.out_channels, bp.conv3.out_channels
+        Ho, Wo = y.shape[2], y.shape[3]
+        HW, HWo = H * W, Ho * Wo
         dev, st = x.device, _stream()
-        ws_bytes, nws_w, nws_o = _block_sizes(L, N, Cin, Cw, Cout, HW)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws_a, nws_w, _ = _block_sizes(L, N, Cin, Cw, Cout, HW)
+        ws_b, _, nws_o = _block_sizes(L, N, Cin, Cw, Cout, HWo)
+        ws = torch.empty(max(ws_a, ws_b), dtype=torch.uint8, device=dev)
         gout = gout.contiguous()
         # bn3 + residual + relu: dx of the normalisation and the residual's gradient in one pass
         g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
-        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, bp.bn3, s_3, N, Cout, HW, 1, nws_o, dres=g_res)
+        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, bp.bn3, s_3, N, Cout, HWo, 1, nws_o, dres=g_res)
         g_cot_out = torch.empty_like(cot_out)
-        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_cot_out), None, Cw, 0, _p(ws), N, Cw, Cout, HW,
+        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_cot_out), None, Cw, 0, _p(ws), N, Cw, Cout, HWo,
                                         BF16, st), "cot_conv1x1_backward_data")
         g_w3 = torch.empty_like(bp.conv3.weight)
-        _ck(L.cot_conv1x1_backward_weight(_p(g_c3), _p(cot_out), None, Cw, _p(g_w3), None, _p(ws), N, Cw, Cout, HW, BF16,
+        _ck(L.cot_conv1x1_backward_weight(_p(g_c3), _p(cot_out), None, Cw, _p(g_w3), None, _p(ws), N, Cw, Cout, HWo, BF16,
                                           st), "cot_conv1x1_backward_weight")
-        g_a1, g_cot = _cot_backward(L, bp.cot, saved, ctx.geom, g_cot_out)
-        g_c1 = g_cot_out  # (reuse: consumed by the layer's backward)
+        g_p1, g_cot = _cot_backward(L, bp.cot, saved, ctx.geom, g_cot_out)
+        if bp.avd:
+            g_a1 = torch.empty_like(a1)
+            _ck(L.cot_avgpool3x3s2_backward(_p(g_p1), _p(g_a1), N * Cw, H, W, BF16, st), "cot_avgpool3x3s2_backward")
+            g_c1 = torch.empty_like(c1)
+        else:
+            g_a1 = g_p1
+            g_c1 = g_cot_out  # (reuse: consumed by the layer's backward)
         d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1, c1, a1, g_c1, bp.bn1, s_1, N, Cw, HW, 1, nws_w)
         g_ds = ()
         if ctx.has_ds:
-            d0, s_d = extra[8], extra[9]
+            d0, s_d, xs = extra[8], extra[9], extra[10]
             g_d0 = g_c3  # (reuse: consumed by conv3's backward)
-            d_ds_w, d_ds_b = _bn_bwd(L, g_res, d0, None, g_d0, bp.ds_bn, s_d, N, Cout, HW, 0, nws_o)
-            gx = torch.empty_like(x)
-            _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(gx), None, Cin, 0, _p(ws), N, Cin, Cout,
-                                            HW, BF16, st), "cot_conv1x1_backward_data")
+            d_ds_w, d_ds_b = _bn_bwd(L, g_res, d0, None, g_d0, bp.ds_bn, s_d, N, Cout, HWo, 0, nws_o)
+            if bp.ds_stride == 2:  # the projection saw every second pixel: its data gradient lands there, zeros elsewhere
+                g_xs = torch.empty_like(xs)
+                _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(g_xs), None, Cin, 0, _p(ws), N, Cin,
+                                                Cout, HWo, BF16, st), "cot_conv1x1_backward_data")
+                gx = torch.zeros_like(x)
+                gx[:, :, ::2, ::2] = g_xs
+            else:
+                gx = torch.empty_like(x)
+                _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(gx), None, Cin, 0, _p(ws), N, Cin,
+                                                Cout, HWo, BF16, st), "cot_conv1x1_backward_data")
             g_wd = torch.empty_like(bp.ds_conv.weight)
-            _ck(L.cot_conv1x1_backward_weight(_p(g_d0), _p(x), None, Cin, _p(g_wd), None, _p(ws), N, Cin, Cout, HW, BF16,
+            _ck(L.cot_conv1x1_backward_weight(_p(g_d0), _p(xs), None, Cin, _p(g_wd), None, _p(ws), N, Cin, Cout, HWo, BF16,
                                               st), "cot_conv1x1_backward_weight")
             g_ds = (g_wd, d_ds_w, d_ds_b)
         else:
@@ -468,7 +503,7 @@ def block_eligible(blk, x):
     bp = _block_plan(blk)
     if not (bp.static_ok and x.shape[1] == bp.conv1.in_channels and bp.conv1.weight.dtype == torch.bfloat16
             and bp.conv3.weight.dtype == torch.bfloat16 and bp.bn1.weight.dtype == torch.float32 and bp.bn1.training
-            and (bp.ds_conv is not None or bp.conv1.in_channels == bp.conv3.out_channels)):
+            and (bp.ds_conv is not None or (bp.conv1.in_channels == bp.conv3.out_channels and not bp.avd))):
         return False
     pl = _plan(bp.cot)
     return (pl.ke0.weight.dtype == torch.bfloat16 and pl.em3.weight.dtype == torch.bfloat16

@@ -756,7 +756,7 @@ def test_group_norm9_rejects_what_it_does_not_cover():
     assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 9, 9000, 1e-5, dt, None) == -2    # too large
 
 
-@pytest.mark.parametrize("project", [False, True])
+@pytest.mark.parametrize("project", [False, True, "stride2"])
 def test_fused_bottleneck_node_on_emulated_kernels(project, monkeypatch):
     """the whole cotnet.Bottleneck as one autograd node against the node-per-op path on the same emulated kernels.
     The two forwards differ by bf16 ulps (the se branch is evaluated by different kernels), which flips a few ReLU masks
@@ -768,10 +768,12 @@ def test_fused_bottleneck_node_on_emulated_kernels(project, monkeypatch):
     from cotnet_amd.flat_sgd import to_mixed_bf16
     from cotnet_amd.resnet import downsample_conv
     torch.manual_seed(6)
-    N, H, W = 2, 4, 4
+    stride = 2 if project == "stride2" else 1
+    N, H, W = 2, 4 * stride, 4 * stride
     inpl = 128 if project else 256
-    ds = downsample_conv(inpl, 256, 1) if project else None
-    node = Bottleneck(inpl, 64, downsample=ds).train()
+    ds = downsample_conv(inpl, 256, 1, stride=stride) if project else None
+    node = Bottleneck(inpl, 64, stride=stride, downsample=ds).train()
+    assert (node.avd is not None) == (stride == 2)
     with torch.no_grad():
         for p in node.parameters():
             if p.ndim == 1:
@@ -780,13 +782,15 @@ def test_fused_bottleneck_node_on_emulated_kernels(project, monkeypatch):
     node = to_mixed_bf16(node)
     perop = copy.deepcopy(node)
     x = torch.randn(N, inpl, H, W).bfloat16()
-    g = torch.randn(N, 256, H, W).bfloat16()
+    g = torch.randn(N, 256, H // stride, W // stride).bfloat16()
 
+    from cotnet_amd import pool3x3 as p3
     monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
-    for mod in (clf, c1, c3, fused_bn, radix_tail):
+    for mod in (clf, c1, c3, fused_bn, radix_tail, p3):
         monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
     monkeypatch.setattr(c1, "MODE", "hip")
     monkeypatch.setattr(c3, "MODE", "hip")
+    monkeypatch.setattr(p3, "MODE", "hip")
     monkeypatch.setattr(az, "aggregation_zeropad",
                         lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
     caches = (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
@@ -875,7 +879,8 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
 
     loss_a, grads_a, nodes_a, count_a = run(False)
     loss_b, grads_b, nodes_b, count_b = run(True)
-    assert any(n.startswith("_BottleneckNode") for n in nodes_b) and any(n.startswith("_CotLayerNode") for n in nodes_b)
+    assert any(n.startswith("_BottleneckNode") for n in nodes_b)   # all 16 blocks, the stride-2 ones included
+    assert not any(n.startswith("_CotLayerNode") or "Conv1x1" in n or "AvgPool" in n for n in nodes_b)
     assert any(n.startswith("_Head") for n in nodes_b) and any(n.startswith("_MaxPool") for n in nodes_b)
     assert not any(n.startswith("_CotLayerNode") or n.startswith("_BottleneckNode") for n in nodes_a)
     assert count_b < 0.6 * count_a   # the autograd graph really is that much smaller (161 of the nodes are leaves)
