@@ -92,3 +92,46 @@ def test_bottleneck_trains_with_the_single_node_layer(monkeypatch):
         losses.append(loss.item())
     assert losses[-1] < losses[0]
     assert all(torch.isfinite(p.float()).all() for p in blk.parameters())
+
+
+@pytest.mark.parametrize("kind", ["identity", "project", "stride2"])
+def test_single_node_bottleneck_matches_node_per_op(kind, monkeypatch):
+    """the whole Bottleneck as one node (identity shortcut / 1x1 projection / stride-2 block with avd pooling) against the
+    node-per-op path on the same kernels; ReLU masks may flip on bf16 ulps, so gradients are compared in the mean"""
+    from cotnet_amd import pool3x3 as p3
+    from cotnet_amd.resnet import downsample_conv
+    monkeypatch.setattr(c1, "MODE", "hip")
+    monkeypatch.setattr(c3, "MODE", "hip")
+    monkeypatch.setattr(p3, "MODE", "hip")
+    torch.manual_seed(7)
+    stride = 2 if kind == "stride2" else 1
+    inpl = 256 if kind == "identity" else 128
+    ds = None if kind == "identity" else downsample_conv(inpl, 256, 1, stride=stride)
+    node = Bottleneck(inpl, 64, stride=stride, downsample=ds).to(DEV).train()
+    with torch.no_grad():
+        node.bn3.weight.fill_(0.8)
+    node = to_mixed_bf16(node)
+    perop = copy.deepcopy(node)
+    x = torch.randn(8, inpl, 28, 28, device=DEV).bfloat16()
+    g = torch.randn(8, 256, 28 // stride, 28 // stride, device=DEV).bfloat16()
+
+    def run(blk, enabled):
+        monkeypatch.setattr(clf, "ENABLED", enabled)
+        xi = x.clone().requires_grad_(True)
+        y = blk(xi)
+        y.backward(g)
+        return y, xi.grad, {n: p.grad for n, p in blk.named_parameters()}
+
+    yr, gxr, gr = run(perop, False)
+    yf, gxf, gf = run(node, True)
+    assert yf.grad_fn.name().startswith("_BottleneckNode") and not yr.grad_fn.name().startswith("_BottleneckNode")
+
+    def mrel(a, b):
+        return ((a.float() - b.float()).abs().mean() / (b.float().abs().mean() + 1e-9)).item()
+
+    assert mrel(yf, yr) < 1e-2
+    assert mrel(gxf, gxr) < 6e-2
+    top = max(v.float().abs().max() for v in gr.values())
+    for n_, v in gf.items():
+        if gr[n_].float().abs().max() > 1e-3 * top and not n_.endswith("se.0.bias"):
+            assert mrel(v, gr[n_]) < 0.12, (n_, mrel(v, gr[n_]))
