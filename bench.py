@@ -156,9 +156,10 @@ KERNEL_SETS = {  # name -> (single-node layers, 1x1 mode, 3x3 mode, GroupNorm9 m
 
 def apply_kernel_set(name):
     from cotnet_amd import (_lib, conv1x1 as c1, conv3x3g as c3, cot_layer_fused as clf, group_norm9 as g9, head_fused as hf,
-                            pool3x3 as p3)
+                            pool3x3 as p3, stem7x7 as s7)
     fused, m1, m3, mg, fold = KERNEL_SETS[name]
-    clf.ENABLED, c1.MODE, c3.MODE, g9.MODE, p3.MODE, hf.MODE = fused, m1, m3, mg, mg, mg  # (poolings / head: with the rest)
+    clf.ENABLED, c1.MODE, c3.MODE, g9.MODE = fused, m1, m3, mg
+    p3.MODE = hf.MODE = s7.MODE = mg  # poolings, classifier head and stem convolution go with the rest
     _lib.check(_lib.lib().cot_set_tuning(12, fold), "cot_set_tuning")
 
 
@@ -324,9 +325,9 @@ def main():
         from cotnet_amd import group_norm9 as _gn9
         _gn9.MODE = "hip"
     if args.fused_layer:
-        from cotnet_amd import cot_layer_fused as _clf, head_fused as _hf, pool3x3 as _p3
+        from cotnet_amd import cot_layer_fused as _clf, head_fused as _hf, pool3x3 as _p3, stem7x7 as _s7
         _clf.ENABLED = True
-        _p3.MODE = _hf.MODE = "hip"
+        _p3.MODE = _hf.MODE = _s7.MODE = "hip"
         args.conv1x1 = args.conv1x1 or "hip"
         args.conv3x3 = args.conv3x3 or "hip"
     if args.conv1x1 is not None:

@@ -112,6 +112,10 @@ int conv1x1_gemm(const void*, const void*, int, const void*, const void*, void*,
 int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_conv1x1_tune[4];
+// implemented in stem7x7.hip
+int stem7x7_splits(int N, int H, int W);
+int stem7x7_forward(const void*, const void*, void*, int, int, int, hipStream_t);
+int stem7x7_wgrad(const void*, const void*, void*, float*, int, int, int, hipStream_t);
 // implemented in pool3x3.hip
 template <typename T> int pool3x3s2(int, const void*, const void*, void*, int64_t, int, int, hipStream_t);
 // implemented in group_norm9.hip
@@ -482,6 +486,35 @@ int cot_radix_mix_backward_apply(const void* gout, const void* attn, const void*
     if ((rc = check_align16({gout, gy, gk}))) return rc;
     return dtype == COT_F32 ? radix_mix_bwd_apply<float>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream)
                             : radix_mix_bwd_apply<bf16_t>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream);
+}
+
+int64_t cot_stem7x7s2_workspace(int N, int H, int W) {
+    if (N <= 0) return 0;
+    const int S = stem7x7_splits(N, H, W);
+    return S ? ((int64_t)S * 64 * 147 * 4 + 255) / 256 * 256 : 0;
+}
+
+int cot_stem7x7s2_forward(const void* x, const void* weight, void* y, int N, int H, int W, int dtype, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d H=%d W=%d", N, H, W);
+    if (!x || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_stem7x7s2_*: only COT_BF16 (dtype %d given)", dtype);
+    int rc = check_align16({x, weight, y});
+    if (rc) return rc;
+    rc = stem7x7_forward(x, weight, y, N, H, W, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_stem7x7s2_forward: output width of a %dx%d input is not a multiple of 8", H, W);
+    return rc;
+}
+
+int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, void* workspace, int N, int H, int W,
+                                  int dtype, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d H=%d W=%d", N, H, W);
+    if (!gy || !x || !gweight || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_stem7x7s2_*: only COT_BF16 (dtype %d given)", dtype);
+    int rc = check_align16({gy, x, gweight, workspace});
+    if (rc) return rc;
+    rc = stem7x7_wgrad(gy, x, gweight, (float*)workspace, N, H, W, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_stem7x7s2_backward_weight: %dx%d input not covered", H, W);
+    return rc;
 }
 
 static int pool_call(int op, const void* a, const void* b, void* out, int64_t planes, int H, int W, int dtype, void* stream) {

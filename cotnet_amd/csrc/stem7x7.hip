@@ -1,0 +1,201 @@
+// stem7x7.hip -- the backbone's first convolution: 7x7, stride 2, padding 3, 3 -> 64 channels, NCHW bf16
+// (reference: models/resnet.py:539-555, `self.conv1 = nn.Conv2d(in_chans, inplanes, kernel_size=7, stride=2, padding=3,
+// bias=False)`), forward and weight gradient (the network input needs no data gradient).
+//
+// Why: with the CoT blocks, poolings and the head on this library's kernels it is the last MIOpen call of a CoTNet-50
+// training step (an NHWC implicit GEMM bracketed by layout transposes; its weight gradient accumulates with atomics into a
+// zeroed buffer -- the kind of kernel HIP-graph replay tripped over in round 1).
+//
+// Both kernels are implicit GEMMs on v_mfma_f32_16x16x32_bf16 (operand maps: mfma_common.h) with K = (ci, kh, kw) =
+// 147 taps in the weight tensor's own memory order, padded to 160:
+//   forward   Y (64 x pixels) = Wt (64 x 160) * B (160 x pixels); Wt staged once per workgroup in LDS (20 KB), B gathered
+//             from x (a 300 KB image: L1/L2 hits) with bounds predicates.  MFMA column j of column set cs is output pixel
+//             4j + cs, so a lane ends up with 4 consecutive pixels of 4 channels -> 8-byte stores.
+//   wgrad     dW (64 x 160) = sum over pixels dY (64 x pixels) * B^T; dY fragments are 16-byte loads (pixels are
+//             contiguous), B fragments are 8 strided taps of one (ci, kh, kw) each; deterministic slices + reduce kernel.
+#include "cot_common.h"
+#include "mfma_common.h"
+
+namespace cot {
+
+int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_bias, void* gw, void* gb,
+                                hipStream_t stream);  // conv1x1.hip
+
+constexpr int kStemK = 147, kStemKp = 160, kStemCo = 64;
+
+// tap index k -> (ci, kh, kw)
+__device__ __forceinline__ void stem_tap(int k, int& ci, int& kh, int& kw) {
+    ci = k / 49;
+    const int r = k - 49 * ci;
+    kh = r / 7;
+    kw = r - 7 * kh;
+}
+
+__global__ void __launch_bounds__(256)
+stem7x7_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int H, int W, int Ho,
+                 int Wo, int tiles_per_image, int64_t total_waves) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    bf16_t* As = reinterpret_cast<bf16_t*>(cot_smem);  // [64][160], zero beyond tap 146
+    for (int i = threadIdx.x; i < kStemCo * kStemKp; i += blockDim.x) {
+        const int m = i / kStemKp, k = i - m * kStemKp;
+        As[i] = k < kStemK ? w[m * kStemK + k] : (bf16_t)0.0f;
+    }
+    __syncthreads();
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= total_waves) return;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int n = uniform((int)(wid / tiles_per_image)), tile = uniform((int)(wid % tiles_per_image));
+    const int HWo = Ho * Wo;
+    const int p0 = tile * 64 + 4 * j;  // this lane's 4 consecutive output pixels (one row: Wo % 4 == 0)
+    const int oh = min(p0, HWo - 1) / Wo, ow0 = min(p0, HWo - 1) % Wo;
+    const int ih0 = 2 * oh - 3, iw0 = 2 * ow0 - 3;
+    const bf16_t* xn = x + (int64_t)n * 3 * H * W;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int step = 0; step < kStemKp / 32; ++step) {
+        const int kb = 32 * step + 8 * g;
+        bf16x8_t bfrag[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kb + e;
+            int ci, kh, kw;
+            stem_tap(min(k, kStemK - 1), ci, kh, kw);
+            const int ih = ih0 + kh;
+            const bool rok = k < kStemK && ih >= 0 && ih < H && p0 < HWo;
+            const bf16_t* row = xn + ((int64_t)ci * H + (rok ? ih : 0)) * W;
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) {
+                const int iw = iw0 + 2 * cs + kw;
+                bfrag[cs][e] = (rok && iw >= 0 && iw < W) ? row[iw] : (bf16_t)0.0f;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bf16x8_t af;
+            __builtin_memcpy(&af, __builtin_assume_aligned(As + (16 * a + j) * kStemKp + kb, 16), 16);
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) acc[a][cs] = COT_MFMA_16X16X32_BF16(af, bfrag[cs], acc[a][cs]);
+        }
+    }
+    if (p0 >= HWo) return;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = 16 * a + 4 * g + i;
+            bf16_t o[4];
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) o[cs] = (bf16_t)acc[a][cs][i];
+            store_piece<4, 8>(y + ((int64_t)n * kStemCo + co) * HWo + p0, o, HWo - p0);
+        }
+}
+
+// part[s][co][k] = sum over slice s of (n, pixel) of dY[n][co][p] * x[n][ci][2*oh - 3 + kh][2*ow - 3 + kw]
+// one wave = (80 of the 160 tap columns, slice s); 4 waves per workgroup
+__global__ void __launch_bounds__(256)
+stem7x7_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, float* __restrict__ part, int N, int H,
+                   int W, int Ho, int Wo, int S, int spi, int64_t total_waves) {
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= total_waves) return;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, lg = lane >> 4;
+    const int cb = uniform((int)(wid & 1)), s = uniform((int)(wid >> 1));
+    const int HWo = Ho * Wo;
+    const int64_t T = (int64_t)N * spi, t0 = T * s / S, t1 = T * (s + 1) / S;
+    int tci[5], tkh[5], tkw[5];
+    bool tok[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int k = cb * 80 + q * 16 + i16;
+        tok[q] = k < kStemK;
+        stem_tap(min(k, kStemK - 1), tci[q], tkh[q], tkw[q]);
+    }
+    f32x4_t acc[4][5];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[a][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t t = t0; t < t1; ++t) {
+        const int n = (int)(t / spi), st = (int)(t % spi);
+        const int p = st * 32 + 8 * lg;  // 8 consecutive output pixels of one row (Wo % 8 == 0, HWo % 32 == 0)
+        const int oh = p / Wo, ow = p - oh * Wo;
+        bf16x8_t af[4], bfr[5];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            __builtin_memcpy(&af[a], __builtin_assume_aligned(gy + ((int64_t)n * kStemCo + 16 * a + i16) * HWo + p, 16), 16);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int ih = 2 * oh - 3 + tkh[q];
+            const bool rok = tok[q] && ih >= 0 && ih < H;
+            const bf16_t* row = x + (((int64_t)n * 3 + tci[q]) * H + (rok ? ih : 0)) * W;
+            const int iw0 = 2 * ow - 3 + tkw[q];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int iw = iw0 + 2 * e;
+                bfr[q][e] = (rok && iw >= 0 && iw < W) ? row[iw] : (bf16_t)0.0f;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) acc[a][q] = COT_MFMA_16X16X32_BF16(af[a], bfr[q], acc[a][q]);
+    }
+    float* ps = part + (int64_t)s * kStemCo * kStemK;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = 16 * a + 4 * lg + i;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int k = cb * 80 + q * 16 + i16;
+                if (k < kStemK) ps[co * kStemK + k] = acc[a][q][i];
+            }
+        }
+}
+
+// host side
+static bool stem_geometry(int H, int W, int* Ho, int* Wo) {
+    *Ho = (H + 6 - 7) / 2 + 1;
+    *Wo = (W + 6 - 7) / 2 + 1;
+    return H > 0 && W > 0 && (*Wo % 8) == 0 && ((*Ho * *Wo) % 32) == 0;
+}
+
+int stem7x7_splits(int N, int H, int W) {
+    int Ho, Wo;
+    if (!stem_geometry(H, W, &Ho, &Wo)) return 0;
+    const int64_t T = (int64_t)N * (Ho * Wo / 32);
+    int64_t S = 512;
+    if (S > T / 16) S = T / 16;
+    return (int)(S < 1 ? 1 : S);
+}
+
+int stem7x7_forward(const void* x, const void* w, void* y, int N, int H, int W, hipStream_t stream) {
+    int Ho, Wo;
+    if (!stem_geometry(H, W, &Ho, &Wo)) return COT_ERR_UNSUPPORTED;
+    const int tpi = ceil_div(Ho * Wo, 64);
+    const int64_t waves = (int64_t)N * tpi;
+    COT_LAUNCH(stem7x7_fwd_mfma, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), kStemCo * kStemKp * 2, stream,
+               (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, H, W, Ho, Wo, tpi, waves);
+    return check_launch("stem7x7_fwd_mfma");
+}
+
+int stem7x7_wgrad(const void* gy, const void* x, void* gw, float* workspace, int N, int H, int W, hipStream_t stream) {
+    int Ho, Wo;
+    if (!stem_geometry(H, W, &Ho, &Wo)) return COT_ERR_UNSUPPORTED;
+    const int S = stem7x7_splits(N, H, W), spi = Ho * Wo / 32;
+    const int64_t waves = (int64_t)S * 2;
+    COT_LAUNCH(stem7x7_wgrad_mfma, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, stream, (const bf16_t*)gy,
+               (const bf16_t*)x, workspace, N, H, W, Ho, Wo, S, spi, waves);
+    int rc = check_launch("stem7x7_wgrad_mfma");
+    if (rc) return rc;
+    return conv1x1_wgrad_reduce_launch(workspace, S, kStemCo, kStemK, 0, gw, nullptr, stream);
+}
+
+}  // namespace cot

@@ -13,6 +13,7 @@ from .fused_bn import fused_bn_act
 from .layers import AvgPool2dSame, DropPath, create_classifier
 from .pool3x3 import pool
 from .head_fused import head
+from .stem7x7 import stem_conv
 
 
 def get_padding(kernel_size, stride, dilation=1):
@@ -161,7 +162,7 @@ class ResNet(nn.Module):
 
     def forward_features(self, x):
         if isinstance(self.act1, nn.ReLU):
-            x = fused_bn_act(self.conv1(x), self.bn1, "relu")  # stem BN + ReLU in one pass over the 112x112 map
+            x = fused_bn_act(stem_conv(self.conv1, x), self.bn1, "relu")  # stem BN + ReLU in one pass over 112x112
         else:
             x = self.act1(self.bn1(self.conv1(x)))
         x = pool(self.maxpool, x)

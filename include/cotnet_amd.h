@@ -213,6 +213,16 @@ int cot_group_norm9_backward(const void* dy, const void* x, const float* mean, c
                              void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int dtype,
                              void* stream);
 
+/* ---- the backbone's first convolution: 7x7, stride 2, padding 3, 3 -> 64 channels, NCHW, COT_BF16 (reference:
+ * models/resnet.py:539-555, conv1 of the default stem), forward and weight gradient (the network input takes no gradient).
+ * weight [64][3][7][7] as torch stores it; x [N][3][H][W]; y / gy [N][64][Ho][Wo], Ho = (H - 1)/2 + 1.  Covered when Wo is a
+ * multiple of 8 and Ho*Wo of 32 (224, 256, 288, 320 inputs); otherwise COT_ERR_UNSUPPORTED / workspace 0 (caller keeps
+ * nn.Conv2d).  backward_weight is deterministic; workspace: cot_stem7x7s2_workspace(...) bytes. */
+int64_t cot_stem7x7s2_workspace(int N, int H, int W);
+int cot_stem7x7s2_forward(const void* x, const void* weight, void* y, int N, int H, int W, int dtype, void* stream);
+int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, void* workspace, int N, int H, int W,
+                                  int dtype, void* stream);
+
 /* ---- the backbone's two 3x3 / stride-2 / padding-1 poolings, NCHW, `planes` = N*C images of H x W -> Ho = (H-1)/2 + 1:
  *   cot_avgpool3x3s2_*  nn.AvgPool2d(3, 2, padding=1) (count_include_pad: every window / 9) -- the "avd" pooling of
  *                       stride-2 bottlenecks, models/cotnet.py:216

@@ -140,6 +140,16 @@ def pooling(N, C, H, W, dtype):
     assert E.cot_avgpool3x3s2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
 
 
+def stem(N, H, W):
+    x, w = guarded(torch.randn(N, 3, H, W).bfloat16()), guarded(torch.randn(64, 3, 7, 7).bfloat16())
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y, gy = (guarded(torch.randn(N, 64, Ho, Wo).bfloat16()) for _ in range(2))
+    gw = guarded(torch.empty_like(w))
+    ws = torch.empty(E.cot_stem7x7s2_workspace(N, H, W), dtype=torch.uint8)
+    assert E.cot_stem7x7s2_forward(P(x), P(w), P(y), N, H, W, BF, None) == 0
+    assert E.cot_stem7x7s2_backward_weight(P(gy), P(x), P(gw), P(ws), N, H, W, BF, None) == 0
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     # tensors whose byte size is a multiple of 16 keep the 16-byte base alignment the ABI asks for
@@ -150,6 +160,8 @@ if __name__ == "__main__":
         conv3x3(*shape)
     for shape in [(2, 2, 8, 8), (2, 1, 14, 14), (8, 2, 7, 7), (1, 1, 56, 56), (8, 2, 3, 5)]:
         gn9(*shape)
+    for shape in [(2, 32, 32), (1, 16, 64)]:
+        stem(*shape)
     for dtype in (torch.bfloat16, torch.float32):
         for shape in [(2, 16, 6, 56), (2, 16, 5, 28), (2, 32, 14, 14), (8, 64, 7, 7), (8, 8, 3, 10)]:
             aggregation(*shape, dtype)

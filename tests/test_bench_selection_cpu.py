@@ -68,8 +68,8 @@ def test_kernel_sets_apply_the_documented_switches(monkeypatch):
             calls.append((k, v))
             return 0
     monkeypatch.setattr(_lib, "lib", lambda: Fake())
-    from cotnet_amd import head_fused as hf, pool3x3 as p3
-    for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE"), (p3, "MODE"), (hf, "MODE")):
+    from cotnet_amd import head_fused as hf, pool3x3 as p3, stem7x7 as s7
+    for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE"), (p3, "MODE"), (hf, "MODE"), (s7, "MODE")):
         monkeypatch.setattr(mod, attr, getattr(mod, attr))  # restored after the test
     bench.apply_kernel_set("new+bnfold")
     assert clf.ENABLED and c1.MODE == c3.MODE == g9.MODE == "hip" and calls[-1] == (12, 1)
@@ -92,10 +92,10 @@ def test_probe_child_body_on_emulated_kernels(monkeypatch, capsys):
         import pytest
         pytest.skip("host emulation build unavailable")
     monkeypatch.setattr(_lib, "lib", lambda: tke._EMUL)
-    from cotnet_amd import head_fused as hf, pool3x3 as p3
-    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, flat_sgd, p3, hf):
+    from cotnet_amd import head_fused as hf, pool3x3 as p3, stem7x7 as s7
+    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, flat_sgd, p3, hf, s7):
         monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
-    for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE"), (p3, "MODE"), (hf, "MODE")):
+    for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE"), (p3, "MODE"), (hf, "MODE"), (s7, "MODE")):
         monkeypatch.setattr(mod, attr, getattr(mod, attr))
     monkeypatch.setattr(az, "aggregation_zeropad",
                         lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: tke._EmulAggregation.apply(i, w))

@@ -838,7 +838,7 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
     import cotnet_amd
     import cotnet_amd.aggregation_zeropad as az
     from cotnet_amd import (cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, group_norm9 as g9, head_fused as hf,
-                            pool3x3 as p3, radix_tail)
+                            pool3x3 as p3, radix_tail, stem7x7 as s7)
     from cotnet_amd.data_parallel import GradBucketReducer
     from cotnet_amd.flat_sgd import _decay_group, to_mixed_bf16
     torch.manual_seed(21)
@@ -847,7 +847,7 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
     target = torch.tensor([1, 7, 3, 3])
 
     monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
-    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, p3, hf):
+    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, p3, hf, s7):
         monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
     monkeypatch.setattr(az, "aggregation_zeropad",
                         lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
@@ -857,7 +857,7 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
         for cache in caches:
             cache.clear()
         monkeypatch.setattr(clf, "ENABLED", opt_in)
-        for mod in (c1, c3, g9, p3, hf):
+        for mod in (c1, c3, g9, p3, hf, s7):
             monkeypatch.setattr(mod, "MODE", "hip" if opt_in else "")
         model = copy.deepcopy(base)
         red = GradBucketReducer(model, group_fn=_decay_group, grad_mode="copy", flatten_params=True, broadcast_params=False)
@@ -882,6 +882,7 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
     assert any(n.startswith("_BottleneckNode") for n in nodes_b)   # all 16 blocks, the stride-2 ones included
     assert not any(n.startswith("_CotLayerNode") or "Conv1x1" in n or "AvgPool" in n for n in nodes_b)
     assert any(n.startswith("_Head") for n in nodes_b) and any(n.startswith("_MaxPool") for n in nodes_b)
+    assert any(n.startswith("_Stem") for n in nodes_b) and not any("Convolution" in n or "Addmm" in n for n in nodes_b)
     assert not any(n.startswith("_CotLayerNode") or n.startswith("_BottleneckNode") for n in nodes_a)
     assert count_b < 0.6 * count_a   # the autograd graph really is that much smaller (161 of the nodes are leaves)
     assert abs(loss_a - loss_b) < 2e-2 * abs(loss_a)
@@ -1043,3 +1044,27 @@ def test_classifier_head_on_emulated_kernels(monkeypatch):
     assert torch.allclose(fc.weight.grad.float(), wr.grad, atol=3e-2, rtol=3e-2)
     assert torch.allclose(fc.bias.grad.float(), br.grad, atol=3e-2, rtol=3e-2)
     hf._WS.clear()
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (1, 16, 64), (3, 32, 16)])
+def test_stem_convolution_kernels(N, H, W):
+    """csrc/stem7x7.hip (7x7 / stride 2 / padding 3, 3 -> 64) forward and weight gradient against torch in fp32"""
+    torch.manual_seed(19)
+    dt = _lib.dtype_code(torch.bfloat16)
+    x = torch.randn(N, 3, H, W).bfloat16()
+    w = (torch.randn(64, 3, 7, 7) / 12).bfloat16()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = torch.randn(N, 64, Ho, Wo).bfloat16()
+    wf = w.float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(x.float(), wf, None, 2, 3)
+    yr.backward(gy.float())
+    y = torch.full((N, 64, Ho, Wo), float("nan")).bfloat16()
+    assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(y), N, H, W, dt, None) == 0, _EMUL.cot_last_error()
+    assert torch.allclose(y.float(), yr.detach(), atol=2e-2, rtol=2e-2), (y.float() - yr).abs().max()
+    nb = _EMUL.cot_stem7x7s2_workspace(N, H, W)
+    assert nb > 0
+    ws, gw = torch.empty(nb, dtype=torch.uint8), torch.full_like(w, float("nan"))
+    assert _EMUL.cot_stem7x7s2_backward_weight(P(gy), P(x), P(gw), P(ws), N, H, W, dt, None) == 0
+    assert (gw.float() - wf.grad).abs().max() <= 1e-2 * wf.grad.abs().max() + 1e-2
+    assert _EMUL.cot_stem7x7s2_workspace(N, 30, 30) == 0   # output width 15: not covered
+    assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(y), N, 30, 30, dt, None) == -2
