@@ -124,3 +124,19 @@ def test_graph_variant_is_chosen_only_when_verified(monkeypatch):
                   **{"new+graph": {"parity": False, "grad_mean_rel_diff_over_6_replays": 0.9}})
     monkeypatch.setattr(subprocess, "run", _fake_run(out))
     assert bench.choose_kernels(_args())[0] == "new"
+
+
+def test_verdict_reaches_every_rank_through_the_rendezvous_store():
+    """world size 2 on gloo: the store calls bench.py uses to publish rank 0's choice (tests/dist_store_verdict.py)"""
+    import os
+    import random
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    port = 20000 + random.randrange(20000)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(here, "dist_store_verdict.py")],
+                       capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0, r.stderr[-600:]
+    got = sorted(ln for ln in r.stdout.splitlines() if ln.startswith("VERDICT"))
+    assert got == ["VERDICT rank0 new+bnfold+graph", "VERDICT rank1 new+bnfold+graph"], r.stdout[-300:]
