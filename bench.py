@@ -317,6 +317,8 @@ def choose_kernels(args):
 
 def main():
     args = parse()
+    if os.environ.get("COT_KERNEL_SUMMARY"):
+        os.environ["COT_PROFILE_ALL"] = "1"  # (costs host time per launch: not for headline numbers)
     if args.probe_child:
         return probe_child(args)
     explicit = args.gn9 or args.fused_layer or args.conv1x1 is not None or args.conv3x3 is not None
@@ -476,6 +478,20 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    if rank == 0 and os.environ.get("COT_KERNEL_SUMMARY"):
+        # per-kernel device time of every launch the library made in the instrumented steps (dispatch-attached events):
+        # a rocprofv3-free way to see which of the library's kernels carry the step
+        summ = {}
+        for kind, g, dtype, layout, ms, nbytes, kname in recs:
+            e = summ.setdefault(kname, {"launches": 0, "total_ms": 0.0})
+            e["launches"] += 1
+            e["total_ms"] += ms
+        rows = sorted(({"kernel": k, "launches_per_step": round(v["launches"] / timing_steps, 1),
+                        "ms_per_step": round(v["total_ms"] / timing_steps, 4),
+                        "avg_us": round(v["total_ms"] / v["launches"] * 1e3, 2)} for k, v in summ.items()),
+                      key=lambda r: -r["ms_per_step"])
+        with open(os.environ["COT_KERNEL_SUMMARY"], "w") as f:
+            json.dump({"library_ms_per_step": round(sum(r["ms_per_step"] for r in rows), 3), "kernels": rows}, f, indent=1)
     if rank == 0:
         # ---- roofline of the aggregation kernels, from the HIP events of the timed region
         groups = {}

@@ -355,16 +355,16 @@ static int bn_fwd_launch(const T* x, const T* res, T* y, const float* gamma, con
                          float eps, float mom, int act, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
-    hipLaunchKernelGGL((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
+    COT_LAUNCH((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
     if (g_bn_fold) {
-        hipLaunchKernelGGL((bn_apply_fwd_fold<T, V>), dim3(C, split), dim3(256), 0, s, x, res, y, (const float*)ws, gamma,
+        COT_LAUNCH((bn_apply_fwd_fold<T, V>), dim3(C, split), dim3(256), 0, s, x, res, y, (const float*)ws, gamma,
                            beta, mean, rstd, rmean, rvar, nbt, N, C, HW, nper, eps, mom, act);
         return check_launch("bn_act_forward");
     }
-    hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
+    COT_LAUNCH(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
                rstd, rmean, rvar, nbt);
     const int64_t nvec = (int64_t)N * C * HW / V;
-    hipLaunchKernelGGL((bn_apply_fwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, x, res, y, (const float*)mean,
+    COT_LAUNCH((bn_apply_fwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, x, res, y, (const float*)mean,
                (const float*)rstd, gamma, beta, C, HW, nvec, act);
     return check_launch("bn_act_forward");
 }
@@ -375,16 +375,16 @@ static int bn_bwd_launch(const T* dy, const T* x, const T* y, T* dx, T* dres, co
                          int HW, int act, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
-    hipLaunchKernelGGL((bn_bwd_reduce<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma, beta, ws, N, C, HW,
+    COT_LAUNCH((bn_bwd_reduce<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma, beta, ws, N, C, HW,
                nper, act);
     if (g_bn_fold) {
-        hipLaunchKernelGGL((bn_apply_bwd_fold<T, V>), dim3(C, split), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma,
+        COT_LAUNCH((bn_apply_bwd_fold<T, V>), dim3(C, split), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma,
                            beta, (const float*)ws, dgamma, dbeta, N, C, HW, nper, 1.0f / (float)((int64_t)N * HW), act);
         return check_launch("bn_act_backward");
     }
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
+    COT_LAUNCH(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
     const int64_t nvec = (int64_t)N * C * HW / V;
-    hipLaunchKernelGGL((bn_apply_bwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma, beta,
+    COT_LAUNCH((bn_apply_bwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma, beta,
                (const float*)dgamma, (const float*)dbeta, C, HW, nvec, 1.0f / (float)((int64_t)N * HW), act);
     return check_launch("bn_act_backward");
 }

@@ -2,6 +2,7 @@
 // argument validation, dtype/layout dispatch, error strings.  No torch types anywhere.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -39,7 +40,12 @@ static std::mutex g_mu;
 static std::vector<Rec> g_recs;
 static thread_local size_t t_mark = 0;  // records [t_mark, size) were created by the current ABI call on this thread
 
+static std::atomic<bool> g_all{false};  // COT_PROFILE_ALL=1: time every kernel of the library, not only the aggregation
 bool enabled() { return g_on.load(std::memory_order_relaxed); }
+bool enabled_for(const char* kernel) {
+    if (!g_on.load(std::memory_order_relaxed)) return false;
+    return g_all.load(std::memory_order_relaxed) || strstr(kernel, "agg_") != nullptr;
+}
 void begin_launch(hipEvent_t* e0, hipEvent_t* e1) {
     (void)hipEventCreate(e0);
     (void)hipEventCreate(e1);
@@ -618,6 +624,8 @@ int cot_profile_begin(void) {
         (void)hipEventDestroy(r.e1);
     }
     prof::g_recs.clear();
+    const char* all = getenv("COT_PROFILE_ALL");
+    prof::g_all.store(all && all[0] == '1');
     prof::g_on.store(true);
     return COT_OK;
 }

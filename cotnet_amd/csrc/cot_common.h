@@ -55,6 +55,7 @@ int check_launch(const char* what);
 // dispatch itself (hipExtLaunchKernelGGL), so the interval is the kernel's execution, not host launch gaps.
 namespace prof {
 bool enabled();
+bool enabled_for(const char* kernel);  // enabled() and (all kernels requested or an aggregation kernel)
 void begin_launch(hipEvent_t* e0, hipEvent_t* e1);
 void end_launch(const char* name, hipEvent_t e0, hipEvent_t e1);
 }  // namespace prof
@@ -62,7 +63,7 @@ void end_launch(const char* name, hipEvent_t e0, hipEvent_t e1);
 
 #define COT_LAUNCH(KERNEL, GRID, BLOCK, SHMEM, STREAM, ...)                                             \
     do {                                                                                                \
-        if (cot::prof::enabled()) {                                                                     \
+        if (cot::prof::enabled_for(#KERNEL)) {                                                          \
             hipEvent_t e0_, e1_;                                                                        \
             cot::prof::begin_launch(&e0_, &e1_);                                                        \
             hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, e0_, e1_, 0, __VA_ARGS__);        \

@@ -62,7 +62,7 @@ static int launch_sgd(void* param, void* master, void* mom, const void* grad, in
     constexpr int V = 4;  // 16 B of fp32 state per lane
     int64_t blocks = ceil_div64(n / V > 0 ? n / V : 1, 256);
     if (blocks > 2048) blocks = 2048;  // grid-stride: 8 blocks per CU
-    hipLaunchKernelGGL((sgd_flat_kernel<PT, GT, HAS_MASTER, V>), dim3((unsigned)blocks), dim3(256), 0, s, (PT*)param,
+    COT_LAUNCH((sgd_flat_kernel<PT, GT, HAS_MASTER, V>), dim3((unsigned)blocks), dim3(256), 0, s, (PT*)param,
                (float*)master, (float*)mom, (const GT*)grad, n, lr, momentum, wd, gscale, nesterov);
     return check_launch("sgd_flat_kernel");
 }

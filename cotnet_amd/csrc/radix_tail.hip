@@ -214,10 +214,10 @@ static inline int tail_vec(size_t esize, int HW) {
     do {                                                                                                           \
         const dim3 grid((unsigned)ceil_div64(planes, 4)), block(256);                                              \
         const int v = tail_vec(sizeof(T), HW);                                                                     \
-        if (v == 8) hipLaunchKernelGGL((KERNEL<T, (sizeof(T) <= 2 ? 8 : 1)>), grid, block, 0, s, __VA_ARGS__);     \
-        else if (v == 4) hipLaunchKernelGGL((KERNEL<T, (sizeof(T) <= 4 ? 4 : 1)>), grid, block, 0, s, __VA_ARGS__);\
-        else if (v == 2) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, s, __VA_ARGS__);                       \
-        else hipLaunchKernelGGL((KERNEL<T, 1>), grid, block, 0, s, __VA_ARGS__);                                   \
+        if (v == 8) COT_LAUNCH((KERNEL<T, (sizeof(T) <= 2 ? 8 : 1)>), grid, block, 0, s, __VA_ARGS__);     \
+        else if (v == 4) COT_LAUNCH((KERNEL<T, (sizeof(T) <= 4 ? 4 : 1)>), grid, block, 0, s, __VA_ARGS__);\
+        else if (v == 2) COT_LAUNCH((KERNEL<T, 2>), grid, block, 0, s, __VA_ARGS__);                       \
+        else COT_LAUNCH((KERNEL<T, 1>), grid, block, 0, s, __VA_ARGS__);                                   \
     } while (0)
 
 template <typename T> int radix_gap(const void* y, const void* k, void* gap, int64_t planes, int HW, hipStream_t s) {

@@ -263,7 +263,7 @@ int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, 
                         float* workspace, int N, int C, int HW, int act, int dtype, void* stream);
 
 /* Per-launch device timing for bench.py's roofline object.  Between cot_profile_begin() and cot_profile_end()
- * every aggregation kernel is launched with start/stop events attached to its dispatch (hipExtLaunchKernelGGL),
+ * every aggregation kernel (every kernel of the library when the environment has COT_PROFILE_ALL=1) is launched with start/stop events attached to its dispatch (hipExtLaunchKernelGGL),
  * so `ms` is the kernel's execution time on the device -- what rocprofv3 --kernel-trace reports -- free of host
  * launch gaps.  cot_profile_end() synchronises, fills at most max_records records in launch order and returns the
  * number of launches recorded.  Process-global; not meant to be left on in production. */

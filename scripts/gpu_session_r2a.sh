@@ -18,7 +18,8 @@ B="timeout 420 python bench.py --steps 20 --warmup 8 --no-cpu-baseline --kernels
 $B                                              > $O/r2a_step_default.json   2> $O/r2a_step_default.err;   cut -c1-700 $O/r2a_step_default.json
 $B --conv1x1 hip                                > $O/r2a_step_c1.json        2> $O/r2a_step_c1.err;        cut -c1-700 $O/r2a_step_c1.json
 $B --conv1x1 hip --conv3x3 hip --gn9            > $O/r2a_step_c1c3.json      2> $O/r2a_step_c1c3.err;      cut -c1-700 $O/r2a_step_c1c3.json
-$B --fused-layer                                > $O/r2a_step_fused.json     2> $O/r2a_step_fused.err;     cut -c1-700 $O/r2a_step_fused.json
+COT_KERNEL_SUMMARY=$O/r2a_kernels_fused.json $B --fused-layer > $O/r2a_step_fused.json 2> $O/r2a_step_fused.err; cut -c1-700 $O/r2a_step_fused.json
+head -c 2500 $O/r2a_kernels_fused.json
 COT_TUNING=12=1 $B --fused-layer                > $O/r2a_step_fused_bnfold.json 2> $O/r2a_step_fused_bnfold.err; cut -c1-700 $O/r2a_step_fused_bnfold.json
 $B --fused-layer --graph                        > $O/r2a_step_fused_graph.json 2> $O/r2a_step_fused_graph.err; cut -c1-700 $O/r2a_step_fused_graph.json
 tail -3 $O/r2a_step_fused.err | cut -c1-300
