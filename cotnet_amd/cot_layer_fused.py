@@ -19,6 +19,7 @@ module's ordinary forward.  Verified against the unfused reference formula throu
 """
 import ctypes
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -99,10 +100,14 @@ class _Plan:
             and all(_bn_static_ok(b) for b in (ke[1], em[1], cv[1], layer.bn, se[1])))
 
 
+_PLANS = weakref.WeakKeyDictionary()  # module -> plan (kept out of the module's __dict__: deepcopy / pickling / state_dict
+_BLOCK_PLANS = weakref.WeakKeyDictionary()  # never see it, and a copied module gets a plan of its own)
+
+
 def _plan(layer):
-    p = layer.__dict__.get("_cot_plan")
+    p = _PLANS.get(layer)
     if p is None:
-        p = layer.__dict__["_cot_plan"] = _Plan(layer)
+        p = _PLANS[layer] = _Plan(layer)
     return p
 
 
@@ -368,9 +373,9 @@ class _BlockPlan:
 
 
 def _block_plan(blk):
-    p = blk.__dict__.get("_cot_block_plan")
+    p = _BLOCK_PLANS.get(blk)
     if p is None:
-        p = blk.__dict__["_cot_block_plan"] = _BlockPlan(blk)
+        p = _BLOCK_PLANS[blk] = _BlockPlan(blk)
     return p
 
 

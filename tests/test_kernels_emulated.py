@@ -1068,3 +1068,22 @@ def test_stem_convolution_kernels(N, H, W):
     assert (gw.float() - wf.grad).abs().max() <= 1e-2 * wf.grad.abs().max() + 1e-2
     assert _EMUL.cot_stem7x7s2_workspace(N, 30, 30) == 0   # output width 15: not covered
     assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(y), N, 30, 30, dt, None) == -2
+
+
+def test_plans_of_the_single_node_layers_do_not_travel_with_the_module(monkeypatch):
+    """a deep-copied / pickled block gets a plan of its own (handles to ITS parameters), and the module's state is untouched"""
+    import copy
+    import io
+    from cotnet_amd import cot_layer_fused as clf
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    blk = to_mixed_bf16(Bottleneck(256, 64)).train()
+    plan = clf._block_plan(blk)
+    assert "_cot_block_plan" not in blk.__dict__ and "_cot_plan" not in blk.conv2.__dict__
+    twin = copy.deepcopy(blk)
+    tplan = clf._block_plan(twin)
+    assert tplan is not plan and tplan.conv1 is twin.conv1 and tplan.params[0] is twin.conv1.weight
+    assert clf._plan(twin.conv2).ke0 is twin.conv2.key_embed[0]
+    buf = io.BytesIO()
+    torch.save(blk, buf)   # pickles the module object itself
+    assert list(blk.state_dict().keys()) == list(twin.state_dict().keys())
