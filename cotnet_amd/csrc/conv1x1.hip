@@ -175,8 +175,8 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
     const int64_t u = wid / jblocks;
     const int mb = uniform((int)(u % mblocks)), s = uniform((int)(u / mblocks));
     const int Jp = J + (has_bias ? 1 : 0);
-    const int64_t T = (int64_t)N * spi;
-    const int64_t t0 = T * s / S, t1 = T * (s + 1) / S;
+    const int T = N * spi;  // (reduction steps: far below 2^31)
+    const int t0 = (int)((int64_t)T * s / S), t1 = (int)((int64_t)T * (s + 1) / S);
 
     int mrow[4], jrow[4];
     bool ones[4];
@@ -197,8 +197,8 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
     // chain of up to a few hundred dependent steps; without the ring every step pays a full memory latency)
     constexpr int DW = 3;
     bf16x8_t af[DW][4], bfr[DW][4];
-    auto load_stage = [&](int d, int64_t t) {
-        const int nn = (int)(t / spi), st = (int)(t % spi);
+    auto load_stage = [&](int d, int t) {
+        const int nn = t / spi, st = t - nn * spi;
         const int p = st * 32 + g * 8;
         const int cnt = HW - p;
         const bool tail = (st + 1) * 32 > HW;  // wave-uniform: this step runs over the row's end
@@ -227,7 +227,7 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
 #pragma unroll
     for (int d = 0; d < DW - 1; ++d)
         if (t0 + d < t1) load_stage(d, t0 + d);
-    for (int64_t t = t0; t < t1; t += DW) {
+    for (int t = t0; t < t1; t += DW) {
 #pragma unroll
         for (int d = 0; d < DW; ++d) {
             if (t + d < t1) {

@@ -181,8 +181,8 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
     u /= mblocks;
     const int grp = uniform((int)(u % G)), s = uniform((int)(u / G));
     const int HW = H * W, Kc = Cin / G, Mg = Cout / G, Jg = 9 * Kc;
-    const int64_t T = (int64_t)N * spi;
-    const int64_t t0 = T * s / S, t1 = T * (s + 1) / S;
+    const int T = N * spi;  // (reduction steps: far below 2^31)
+    const int t0 = (int)((int64_t)T * s / S), t1 = (int)((int64_t)T * (s + 1) / S);
 
     int mrow[MTW], jch[4], jtap[4], jshift[4];
 #pragma unroll
@@ -203,8 +203,8 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
     // reduction loop with a 3-stage register ring (see conv1x1_wgrad_mfma); the tap masks are applied at load time
     constexpr int DW = 3;
     bf16x8_t af[DW][MTW], bfr[DW][4];
-    auto load_stage = [&](int d, int64_t t) {
-        const int n = (int)(t / spi), st = (int)(t % spi);
+    auto load_stage = [&](int d, int t) {
+        const int n = t / spi, st = t - n * spi;
         const int P = st * 32, p = P + lg * 8;
         const int cnt = HW - p;
         const bool tail = P + 32 > HW;  // wave-uniform: this step runs over the row's end
@@ -252,7 +252,7 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
 #pragma unroll
     for (int d = 0; d < DW - 1; ++d)
         if (t0 + d < t1) load_stage(d, t0 + d);
-    for (int64_t t = t0; t < t1; t += DW) {
+    for (int t = t0; t < t1; t += DW) {
 #pragma unroll
         for (int d = 0; d < DW; ++d) {
             if (t + d < t1) {

@@ -106,7 +106,7 @@ stem7x7_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, 
     const int lane = threadIdx.x & 63, i16 = lane & 15, lg = lane >> 4;
     const int cb = uniform((int)(wid & 1)), s = uniform((int)(wid >> 1));
     const int HWo = Ho * Wo;
-    const int64_t T = (int64_t)N * spi, t0 = T * s / S, t1 = T * (s + 1) / S;
+    const int T = N * spi, t0 = (int)((int64_t)T * s / S), t1 = (int)((int64_t)T * (s + 1) / S);
     int tci[5], tkh[5], tkw[5];
     bool tok[5];
 #pragma unroll
@@ -121,8 +121,8 @@ stem7x7_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, 
 #pragma unroll
         for (int q = 0; q < 5; ++q) acc[a][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    for (int64_t t = t0; t < t1; ++t) {
-        const int n = (int)(t / spi), st = (int)(t % spi);
+    for (int t = t0; t < t1; ++t) {
+        const int n = t / spi, st = t - n * spi;
         const int p = st * 32 + 8 * lg;  // 8 consecutive output pixels of one row (Wo % 8 == 0, HWo % 32 == 0)
         const int oh = p / Wo, ow = p - oh * Wo;
         bf16x8_t af[4], bfr[5];
