@@ -229,7 +229,7 @@ def _cot_backward(L, layer, saved, geom, gout):
     _ck(L.cot_conv1x1_backward_weight(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(ws), 1, A, 2 * C, N, BF16,
                                       st), "cot_conv1x1_backward_weight")
     ghpre = row(A)
-    d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, h, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
+    d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, None, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
     _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st),
         "cot_conv1x1_backward_data")
     g_w0, g_b0 = torch.empty_like(se0.weight), torch.empty_like(se0.bias)
@@ -271,7 +271,7 @@ def _cot_backward(L, layer, saved, geom, gout):
     _ck(L.cot_conv1x1_backward_weight(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(ws), N, Ch, Ce, HW, BF16,
                                       st), "cot_conv1x1_backward_weight")
     ge0 = torch.empty_like(e0)
-    d_em_w, d_em_b = _bn_bwd(L, ge1, e0, e1, ge0, em1, s_e, N, Ch, HW, 1, nws_h)
+    d_em_w, d_em_b = _bn_bwd(L, ge1, e0, None, ge0, em1, s_e, N, Ch, HW, 1, nws_h)  # (ReLU mask recomputed from e0)
     _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gx), _p(gk), C, 3, _p(ws), N, 2 * C, Ch, HW, BF16,
                                     st), "cot_conv1x1_backward_data")
     g_we0 = torch.empty_like(em0.weight)
@@ -279,7 +279,7 @@ def _cot_backward(L, layer, saved, geom, gout):
         "cot_conv1x1_backward_weight")
     # key branch: bn+relu, grouped 3x3 -> dx +=
     gk_pre = gv  # (reuse: gv is dead)
-    d_ke_w, d_ke_b = _bn_bwd(L, gk, k_pre, k, gk_pre, ke1, s_k, N, C, HW, 1, nws_c)
+    d_ke_w, d_ke_b = _bn_bwd(L, gk, k_pre, None, gk_pre, ke1, s_k, N, C, HW, 1, nws_c)
     G = ke0.groups
     _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx), 1, _p(masks), _p(ws), N, C, C, G, H, W,
                                      BF16, st), "cot_conv3x3g_backward_data")
@@ -470,7 +470,7 @@ class _BottleneckNode(Function):
         else:
             g_a1 = g_p1
             g_c1 = g_cot_out  # (reuse: consumed by the layer's backward)
-        d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1, c1, a1, g_c1, bp.bn1, s_1, N, Cw, HW, 1, nws_w)
+        d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1, c1, None, g_c1, bp.bn1, s_1, N, Cw, HW, 1, nws_w)
         g_ds = ()
         if ctx.has_ds:
             d0, s_d, xs = extra[8], extra[9], extra[10]

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, con
     }
 }
 
-// g = dy * act'(z): ReLU uses the saved output (y > 0), SiLU recomputes z from x
+// g = dy * act'(z): SiLU recomputes z from x; ReLU uses the saved output (y > 0) when it is given -- it must be when
+// there was a residual (z + residual decides the sign) -- and otherwise recomputes z as well (one tensor read less)
 __device__ __forceinline__ float act_bwd(float dy, float z_or_y, int act) {
     if (act == ACT_RELU) return z_or_y > 0.f ? dy : 0.f;
     if (act == ACT_SILU) {
@@ -166,11 +167,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const T* __restrict__ dy, c
         const int64_t off = ((int64_t)n * C + c) * HW + (int64_t)v * V;
         const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
         Vec<T, V> yv;
-        if (act == ACT_RELU) yv = ldv<T, V>(y + off);
+        if (act == ACT_RELU && y) yv = ldv<T, V>(y + off);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = act_bwd((float)dv.v[k], act == ACT_RELU ? (float)yv.v[k] : xh * ga + be, act);
+            const float g = act_bwd((float)dv.v[k], (act == ACT_RELU && y) ? (float)yv.v[k] : xh * ga + be, act);
             acc[0] += g;
             acc[1] += g * xh;
         }
@@ -212,11 +213,11 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const T* __restrict__ dy, co
         const float k1 = dbeta[c] * inv_m, k2 = dgamma[c] * inv_m, gr = ga * r;
         const Vec<T, V> dv = ldv<T, V>(dy + i * V), xv = ldv<T, V>(x + i * V);
         Vec<T, V> yv, o, og;
-        if (act == ACT_RELU) yv = ldv<T, V>(y + i * V);
+        if (act == ACT_RELU && y) yv = ldv<T, V>(y + i * V);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = act_bwd((float)dv.v[k], act == ACT_RELU ? (float)yv.v[k] : xh * ga + be, act);
+            const float g = act_bwd((float)dv.v[k], (act == ACT_RELU && y) ? (float)yv.v[k] : xh * ga + be, act);
             o.v[k] = (T)(gr * (g - k1 - xh * k2));
             og.v[k] = (T)g;
         }
@@ -309,11 +310,11 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ d
         const int64_t off = ((int64_t)ni * C + c) * HW + (int64_t)v * V;
         const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
         Vec<T, V> yv, o, og;
-        if (act == ACT_RELU) yv = ldv<T, V>(y + off);
+        if (act == ACT_RELU && y) yv = ldv<T, V>(y + off);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = act_bwd((float)dv.v[k], act == ACT_RELU ? (float)yv.v[k] : xh * ga + be, act);
+            const float g = act_bwd((float)dv.v[k], (act == ACT_RELU && y) ? (float)yv.v[k] : xh * ga + be, act);
             o.v[k] = (T)(gr * (g - k1 - xh * k2));
             og.v[k] = (T)g;
         }

@@ -603,7 +603,8 @@ int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, 
                         float* workspace, int N, int C, int HW, int act, int dtype, void* stream) {
     if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace)
         return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
-    if (act == 1 && !y) return set_error(COT_ERR_INVALID_ARG, "ReLU backward needs the saved output y");
+    if (act == 1 && !y && dresidual)
+        return set_error(COT_ERR_INVALID_ARG, "ReLU backward after a residual add needs the saved output y");
     if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act");
     int rc = check_align16({dy, x, y, dx, dresidual});
     if (rc) return rc;

@@ -1087,3 +1087,31 @@ def test_plans_of_the_single_node_layers_do_not_travel_with_the_module(monkeypat
     buf = io.BytesIO()
     torch.save(blk, buf)   # pickles the module object itself
     assert list(blk.state_dict().keys()) == list(twin.state_dict().keys())
+
+
+@pytest.mark.parametrize("fold", [0, 1])
+def test_bn_relu_backward_without_the_saved_output(fold):
+    """cot_bn_act_backward with y == NULL for ReLU (no residual): the mask is recomputed from x -- same gradients as with y"""
+    assert _EMUL.cot_set_tuning(12, fold) == 0
+    torch.manual_seed(23)
+    N, C, H, W = 4, 8, 7, 7
+    dt = _lib.dtype_code(torch.bfloat16)
+    x, dy = torch.randn(N, C, H, W).bfloat16(), torch.randn(N, C, H, W).bfloat16()
+    ga, be = 1 + 0.3 * torch.randn(C), 0.2 * torch.randn(C)
+    mean, rstd, rm, rv = torch.empty(C), torch.empty(C), torch.zeros(C), torch.ones(C)
+    nbt = torch.zeros((), dtype=torch.int64)
+    ws = torch.empty(_EMUL.cot_bn_act_workspace(N, C))
+    y = torch.empty_like(x)
+    assert _EMUL.cot_bn_act_forward(P(x), None, P(y), P(ga), P(be), P(mean), P(rstd), P(rm), P(rv), P(nbt), P(ws), N, C, H * W,
+                                    1e-5, 0.1, 1, dt, None) == 0
+    outs = []
+    for yy in (y, None):
+        dx, dg, db = torch.empty_like(x), torch.empty(C), torch.empty(C)
+        assert _EMUL.cot_bn_act_backward(P(dy), P(x), P(yy) if yy is not None else None, P(dx), None, P(ga), P(be), P(mean),
+                                         P(rstd), P(dg), P(db), P(ws), N, C, H * W, 1, dt, None) == 0
+        outs.append((dx.float(), dg.clone(), db.clone()))
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, atol=1e-3, rtol=1e-3)
+    res, dres = torch.randn_like(x), torch.empty_like(x)   # with a residual the saved output is mandatory
+    assert _EMUL.cot_bn_act_backward(P(dy), P(x), None, P(outs[0][0].bfloat16()), P(dres), P(ga), P(be), P(mean), P(rstd),
+                                     P(outs[0][1]), P(outs[0][2]), P(ws), N, C, H * W, 1, dt, None) == -1
