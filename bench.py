@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--bucket-mb", type=float, default=48.0)
     ap.add_argument("--conv1x1", default=None, choices=["module", "hip", "matmul"],
                     help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
+    ap.add_argument("--ema", type=float, default=None, metavar="DECAY",
+                    help="also keep the reference recipe's weight EMA (model_ema_decay 0.9999) in the step, flat kernel")
     ap.add_argument("--kernels", default="auto", choices=["auto", "round1", "new"],
                     help="which kernel set the step runs on: round1 = MIOpen convolutions + node-per-op layers (the "
                          "configuration measured in round 1); new = hand-written 1x1 / grouped-3x3 / GroupNorm kernels inside "
@@ -399,7 +401,7 @@ def main():
     if args.mode == "train" and mixed:
         model.train()
         opt = FlatSGD(model, lr=0.25 * B * world / 640.0, momentum=0.9, weight_decay=4e-5, nesterov=True,
-                      bucket_mb=args.bucket_mb)
+                      bucket_mb=args.bucket_mb, ema_decay=args.ema)
 
         def step():
             opt.zero_grad()

@@ -96,6 +96,7 @@ int aggmix_backward_input(const T*, const T*, const T*, T*, const cot_agg_geom&,
 template <typename T>
 int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int, int, int, int, hipStream_t);
 int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
+int ema_flat(void*, const void*, int64_t, float, int, hipStream_t);
 int bn_workspace_floats(int N, int C);
 extern int g_bn_fold;
 template <typename T>
@@ -269,6 +270,15 @@ int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad
     if (rc) return rc;
     return sgd_flat(param, master, momentum_buf, grad, n, lr, momentum, weight_decay, grad_scale, nesterov, param_dtype,
                     grad_dtype, (hipStream_t)stream);
+}
+
+int cot_ema_step(void* ema, const void* src, int64_t n, float decay, int src_dtype, void* stream) {
+    if (!ema || !src) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (n <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive element count %lld", (long long)n);
+    if (!(decay >= 0.f && decay <= 1.f)) return set_error(COT_ERR_INVALID_ARG, "decay %g outside [0, 1]", (double)decay);
+    int rc = check_align16({ema, src});
+    if (rc) return rc;
+    return ema_flat(ema, src, n, decay, src_dtype, (hipStream_t)stream);
 }
 
 static int conv1x1_validate(int N, int Ci, int Co, int HW, int c1, bool split, int dtype, int kdim) {

@@ -56,6 +56,41 @@ __global__ __launch_bounds__(256) void sgd_flat_kernel(PT* __restrict__ param, f
     }
 }
 
+// ema = decay * ema + (1 - decay) * src over a flat buffer (reference: utils/model_ema.py:45-53, ModelEmaV2._update, one
+// elementwise op per state_dict tensor); src = the fp32 master copy (or the fp32 parameters), ema fp32
+template <typename ST, int V>
+__global__ __launch_bounds__(256) void ema_flat_kernel(float* __restrict__ ema, const ST* __restrict__ src, int64_t n,
+                                                      float decay) {
+    const int64_t nvec = n / V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        Vec<float, V> e = ldv<float, V>(ema + i * V);
+        const Vec<ST, V> sv = ldv<ST, V>(src + i * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) e.v[k] = decay * e.v[k] + (1.f - decay) * (float)sv.v[k];
+        stv<float, V>(ema + i * V, e);
+    }
+    const int64_t tail0 = nvec * V;
+    if (blockIdx.x == 0 && threadIdx.x < n - tail0) {
+        const int64_t i = tail0 + threadIdx.x;
+        ema[i] = decay * ema[i] + (1.f - decay) * (float)src[i];
+    }
+}
+
+int ema_flat(void* ema, const void* src, int64_t n, float decay, int src_dtype, hipStream_t s) {
+    constexpr int V = 4;
+    int64_t blocks = ceil_div64(n / V > 0 ? n / V : 1, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (src_dtype == COT_F32)
+        COT_LAUNCH((ema_flat_kernel<float, V>), dim3((unsigned)blocks), dim3(256), 0, s, (float*)ema, (const float*)src, n,
+                   decay);
+    else if (src_dtype == COT_BF16)
+        COT_LAUNCH((ema_flat_kernel<bf16_t, V>), dim3((unsigned)blocks), dim3(256), 0, s, (float*)ema, (const bf16_t*)src, n,
+                   decay);
+    else
+        return set_error(COT_ERR_UNSUPPORTED, "ema: source dtype %d not supported (float32 / bfloat16)", src_dtype);
+    return check_launch("ema_flat_kernel");
+}
+
 template <typename PT, typename GT, bool HAS_MASTER>
 static int launch_sgd(void* param, void* master, void* mom, const void* grad, int64_t n, float lr, float momentum,
                       float wd, float gscale, int nesterov, hipStream_t s) {

@@ -43,8 +43,14 @@ def _decay_group(name, p):
 
 class FlatSGD:
     def __init__(self, model, lr, momentum=0.9, weight_decay=0.0, nesterov=True, bucket_mb=48.0, process_group=None,
-                 broadcast_params=True):
+                 broadcast_params=True, ema_decay=None):
+        """ema_decay: also keep an exponential moving average of the weights (the reference's ModelEmaV2,
+        utils/model_ema.py, `model_ema: True` / decay 0.9999 in its recipes): one flat kernel per bucket after the SGD
+        kernel instead of one elementwise op per state_dict tensor; floating-point buffers (BatchNorm running statistics)
+        are averaged with one multi-tensor lerp.  `ema_state_dict()` returns it under the model's state_dict keys."""
         self.lr, self.momentum, self.weight_decay, self.nesterov = float(lr), float(momentum), float(weight_decay), nesterov
+        self.ema_decay = None if ema_decay is None else float(ema_decay)
+        self.model = model
         # masters must be taken from the fp32 values BEFORE rounding when the caller converts later; here parameters
         # are already in their storage dtype, so the master starts as the (exact) up-cast of the working copy.
         self.reducer = GradBucketReducer(model, process_group=process_group, bucket_mb=bucket_mb,
@@ -53,8 +59,13 @@ class FlatSGD:
         self.state = []
         for b in self.reducer.buckets:
             master = b.pflat.float().clone() if b.pflat.dtype != torch.float32 else None
-            self.state.append({"master": master, "mom": torch.zeros(b.pflat.numel(), dtype=torch.float32,
-                                                                    device=b.pflat.device)})
+            st = {"master": master, "mom": torch.zeros(b.pflat.numel(), dtype=torch.float32, device=b.pflat.device)}
+            if self.ema_decay is not None:
+                st["ema"] = (master if master is not None else b.pflat).float().clone()
+            self.state.append(st)
+        if self.ema_decay is not None:
+            self._buf_src = [bf for bf in model.buffers() if bf.is_floating_point()]
+            self._buf_ema = [bf.detach().float().clone() for bf in self._buf_src]
         _lib.lib()
 
     def zero_grad(self):
@@ -78,6 +89,38 @@ class FlatSGD:
                                 b.pflat.numel(), self.lr, self.momentum, wd, 1.0, 1 if self.nesterov else 0,
                                 _lib.dtype_code(b.pflat.dtype), _lib.dtype_code(b.flat.dtype), stream)
             _lib.check(rc, "cot_sgd_step")
+            if self.ema_decay is not None:
+                src = st["master"] if st["master"] is not None else b.pflat
+                rc = L.cot_ema_step(ctypes.c_void_p(st["ema"].data_ptr()), ctypes.c_void_p(src.data_ptr()), src.numel(),
+                                    self.ema_decay, _lib.dtype_code(src.dtype), stream)
+                _lib.check(rc, "cot_ema_step")
+        if self.ema_decay is not None and self._buf_src:
+            torch._foreach_lerp_(self._buf_ema, [bf.float() if bf.dtype != torch.float32 else bf for bf in self._buf_src],
+                                 1.0 - self.ema_decay)
+
+    def ema_state_dict(self):
+        """the averaged weights under the model's own state_dict keys (fp32; integer buffers are copied as they are) --
+        what the reference stores as `state_dict_ema` (utils/checkpoint_saver.py:103-120)"""
+        assert self.ema_decay is not None, "FlatSGD was built without ema_decay"
+        by_param = {}
+        esz = {}
+        for b, st in zip(self.reducer.buckets, self.state):
+            off = 0
+            align = max(1, 16 // b.flat.element_size())
+            for p in b.params:
+                by_param[p] = st["ema"][off:off + p.numel()].view_as(p)
+                off += (p.numel() + align - 1) // align * align
+        by_buf = {id(bf): e for bf, e in zip(self._buf_src, self._buf_ema)}
+        out = {}
+        params = dict(self.model.named_parameters())
+        bufs = dict(self.model.named_buffers())
+        for k in self.model.state_dict().keys():
+            if k in params:
+                out[k] = by_param[params[k]].clone()
+            else:
+                bf = bufs[k]
+                out[k] = by_buf[id(bf)].clone() if id(bf) in by_buf else bf.detach().clone()
+        return out
 
     def set_lr(self, lr):
         self.lr = float(lr)

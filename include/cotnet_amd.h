@@ -244,6 +244,11 @@ int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad
                  float momentum, float weight_decay, float grad_scale, int nesterov, int param_dtype, int grad_dtype,
                  void* stream);
 
+/* ---- exponential moving average of the weights over a flat buffer (replaces the per-tensor
+ * `ema = decay*ema + (1-decay)*model` of ModelEmaV2._update, utils/model_ema.py:45-53):  ema fp32 [n], src the fp32
+ * master copy / fp32 parameters (COT_F32) or bf16 parameters (COT_BF16). */
+int cot_ema_step(void* ema, const void* src, int64_t n, float decay, int src_dtype, void* stream);
+
 /* ---- training-mode BatchNorm2d fused with activation and residual add, NCHW.
  * Replaces nn.BatchNorm2d + in-place ReLU/SiLU (+ `x += residual`) sequences of the reference's blocks
  * (models/cotnet.py:231-235, :248-262, :89-90):

@@ -1115,3 +1115,39 @@ def test_bn_relu_backward_without_the_saved_output(fold):
     res, dres = torch.randn_like(x), torch.empty_like(x)   # with a residual the saved output is mandatory
     assert _EMUL.cot_bn_act_backward(P(dy), P(x), None, P(outs[0][0].bfloat16()), P(dres), P(ga), P(be), P(mean), P(rstd),
                                      P(outs[0][1]), P(outs[0][2]), P(ws), N, C, H * W, 1, dt, None) == -1
+
+
+def test_flat_sgd_weight_averaging_matches_the_reference_formula(monkeypatch):
+    """FlatSGD(ema_decay=...): cot_ema_step over the flat buckets + one multi-tensor lerp for the buffers, against
+    ModelEmaV2's per-tensor `decay*e + (1-decay)*m` (utils/model_ema.py:45-53) applied to the same sequence of models"""
+    from cotnet_amd import flat_sgd
+    from torch import nn
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    monkeypatch.setattr(flat_sgd, "_DEVICE_ONLY", False)
+    torch.manual_seed(5)
+    model = flat_sgd.to_mixed_bf16(nn.Sequential(nn.Conv2d(4, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(),
+                                                 nn.Conv2d(8, 6, 1))).train()
+    decay = 0.9
+    opt = flat_sgd.FlatSGD(model, lr=0.05, momentum=0.9, weight_decay=1e-4, ema_decay=decay, broadcast_params=False)
+    masters = opt.master_parameters()
+    ema_ref = {k: (masters[p].clone() if k in dict(model.named_parameters()) else v.detach().float().clone())
+               for k, v in model.state_dict().items()
+               for p in [dict(model.named_parameters()).get(k)]}
+    x = torch.randn(5, 4, 6, 6).bfloat16()
+    for _ in range(3):
+        opt.zero_grad()
+        model(x).float().square().mean().backward()
+        opt.step()
+        masters = opt.master_parameters()
+        named = dict(model.named_parameters())
+        for k, v in model.state_dict().items():
+            cur = masters[named[k]] if k in named else v.detach().float()
+            if v.is_floating_point():
+                ema_ref[k] = decay * ema_ref[k] + (1 - decay) * cur
+            else:
+                ema_ref[k] = v.detach().clone()
+    got = opt.ema_state_dict()
+    assert list(got.keys()) == list(model.state_dict().keys())
+    for k in got:
+        assert got[k].shape == model.state_dict()[k].shape
+        assert torch.allclose(got[k].float(), ema_ref[k].float(), atol=1e-5, rtol=1e-5), k
