@@ -5,6 +5,10 @@
 //       A: lane l holds A[i = l&15][k = 8*(l>>4) .. +7]          (8 bf16, K-contiguous)
 //       B: lane l holds B[k = 8*(l>>4) .. +7][j = l&15]
 //     C/D: lane l holds D[i = 4*(l>>4) + r][j = l&15], r = 0..3
+// (sources: cdna_hip_programming.md "Fragment layout" for C/D; the K split -- four lane blocks of 8 consecutive k -- is
+// what composable_kernel's mfma_type<mfma_f32_16x16x32bf16> encodes: num_input_blks = 4, k_per_blk = 8, is_k_reduction,
+// /opt/rocm/include/ck/tensor_operation/gpu/warp/xdlops_gemm.hpp.  Any K split that is the same for A and B gives the
+// same product, so only the row / column / accumulator maps can be wrong; tests/emul implements exactly these maps.)
 #pragma once
 #include "cot_common.h"
 
