@@ -93,10 +93,10 @@ def tuning():
 
 _ALL_VARIANTS = ["v1", "v2_dpp", "v2_shfl", "v2_P8", "v3_lds", "v3_lds_P8_jp2", "v3_lds_jp8", "v3_lds_nw8_bP4",
                  "v3_lds_xcd_split"]
-_SHAPES = [(16, 9, 56), (16, 11, 28), (32, 14, 14), (64, 7, 7), (16, 5, 8)]
-# fp32: every kernel generation x every shape; bf16 (same index arithmetic, packed rows): the default kernels only
-_VERSION_CASES = ([(c, h, w, torch.float32, v) for (c, h, w) in _SHAPES for v in _ALL_VARIANTS] +
-                  [(c, h, w, torch.bfloat16, v) for (c, h, w) in _SHAPES[:4] for v in ("v2_dpp", "v3_lds")])
+_SHAPES = [(16, 9, 56), (16, 11, 28), (32, 14, 14), (64, 7, 7), (16, 5, 8), (64, 56, 56), (128, 28, 28), (24, 6, 40)]
+# every kernel generation x every shape x fp32 / bf16 (the coroutine emulator makes the full matrix a matter of seconds)
+_VERSION_CASES = [(c, h, w, dt, v) for (c, h, w) in _SHAPES for dt in (torch.float32, torch.bfloat16)
+                  for v in _ALL_VARIANTS]
 
 
 @pytest.mark.parametrize("C,H,W,dtype,variant", _VERSION_CASES)
