@@ -80,6 +80,7 @@ struct Sched {
     uint64_t wide[16][64][4];  // MFMA operands: [lane][0..1] = A fragment (8 bf16), [lane][2..3] = B fragment
     const std::function<void()>* body = nullptr;
 };
+inline int g_sched_order = 0;  // see run_block
 inline thread_local Sched* t_sched = nullptr;
 inline thread_local int t_lane = 0, t_wave = 0;
 
@@ -187,9 +188,16 @@ inline void run_block(Sched& S, unsigned bx, unsigned by, unsigned block_threads
     }
     blockIdx = dim3(bx, by, 0);
     int remaining = n;
+    unsigned pass = 0;
     while (remaining > 0) {
         remaining = 0;
-        for (int t = 0; t < n; ++t) {
+        ++pass;
+        for (int u = 0; u < n; ++u) {
+            // lane scheduling order: 0 = ascending, 1 = descending, 2 = a different rotation + stride every pass.  Results
+            // must not depend on it -- a kernel that needs a barrier it does not have shows up under 1 / 2.
+            int t = u;
+            if (g_sched_order == 1) t = n - 1 - u;
+            else if (g_sched_order == 2) t = (int)(((unsigned)u * 37u + pass * 101u) % (unsigned)n);  // 37 coprime to 64*k
             if (S.done[t]) continue;
             S.cur = t;
             t_lane = t & 63;
@@ -228,6 +236,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 }
 }  // namespace emul
 
+extern "C" __attribute__((weak)) void emul_set_order(int order) { emul::g_sched_order = order; }
 inline void __syncthreads() { emul::block_barrier(); }
 // dynamic LDS: `extern __shared__ ... char cot_smem[]` in a kernel refers to this array
 #define __shared__ thread_local  // one workgroup at a time per OS thread

@@ -1151,3 +1151,60 @@ def test_flat_sgd_weight_averaging_matches_the_reference_formula(monkeypatch):
     for k in got:
         assert got[k].shape == model.state_dict()[k].shape
         assert torch.allclose(got[k].float(), ema_ref[k].float(), atol=1e-5, rtol=1e-5), k
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_results_do_not_depend_on_the_lane_schedule(order):
+    """The emulator runs the lanes of a workgroup in a fixed order between synchronisation points; a kernel that is missing
+    a barrier can pass by luck of that order.  Re-run the kernels that use LDS / cross-lane exchanges with the lanes
+    scheduled in descending and in pass-dependent shuffled order: results must be bit-identical to the ascending order."""
+    def run_all():
+        out = []
+        torch.manual_seed(41)
+        dtb = _lib.dtype_code(torch.bfloat16)
+        # aggregation v3 (async LDS slabs, DPP halos), forward + fused backward
+        x, w, g = torch.randn(2, 16, 9, 56).bfloat16(), torch.randn(2, 1, 2, 9, 9, 56).bfloat16(), torch.randn(2, 16, 9, 56).bfloat16()
+        out.extend(run(x, w, g, 3, 1, 1, 1, 0, True)[:3])
+        # fused BatchNorm (block reductions through LDS), both finalize modes
+        for fold in (0, 1):
+            _EMUL.cot_set_tuning(12, fold)
+            xb, dy = torch.randn(5, 16, 14, 14).bfloat16(), torch.randn(5, 16, 14, 14).bfloat16()
+            ga, be = torch.rand(16) + 0.5, torch.randn(16)
+            mean, rstd, dg, db = (torch.empty(16) for _ in range(4))
+            ws = torch.empty(_EMUL.cot_bn_act_workspace(5, 16))
+            y, dx = torch.empty_like(xb), torch.empty_like(xb)
+            assert _EMUL.cot_bn_act_forward(P(xb), None, P(y), P(ga), P(be), P(mean), P(rstd), None, None, None, P(ws), 5, 16,
+                                            196, 1e-5, 0.1, 2, dtb, None) == 0
+            assert _EMUL.cot_bn_act_backward(P(dy), P(xb), None, P(dx), None, P(ga), P(be), P(mean), P(rstd), P(dg), P(db),
+                                             P(ws), 5, 16, 196, 2, dtb, None) == 0
+            out.extend([y, dx, dg.clone(), db.clone()])
+        _EMUL.cot_set_tuning(12, 0)
+        # GroupNorm9 (LDS block sums), two workgroup sizes
+        for H in (8, 40):
+            xg, dyg = torch.randn(2, 18, H, H).bfloat16(), torch.randn(2, 18, H, H).bfloat16()
+            gam, bet = torch.randn(18).bfloat16(), torch.randn(18).bfloat16()
+            m, r = torch.empty(4), torch.empty(4)
+            yg, dxg, dgam, dbet = torch.empty_like(xg), torch.empty_like(xg), torch.empty(18).bfloat16(), torch.empty(18).bfloat16()
+            wsg = torch.empty(2 * 2 * 18)
+            assert _EMUL.cot_group_norm9_forward(P(xg), P(gam), P(bet), P(yg), P(m), P(r), 2, 18, H * H, 1e-5, dtb, None) == 0
+            assert _EMUL.cot_group_norm9_backward(P(dyg), P(xg), P(m), P(r), P(gam), P(dxg), P(dgam), P(dbet), P(wsg), 2, 18,
+                                                  H * H, dtb, None) == 0
+            out.extend([yg, dxg, dgam, dbet])
+        # stem convolution (weights staged in LDS) and a 1x1 convolution (MFMA exchanges only)
+        xs, wsn = torch.randn(2, 3, 32, 32).bfloat16(), torch.randn(64, 3, 7, 7).bfloat16()
+        ys = torch.empty(2, 64, 16, 16).bfloat16()
+        assert _EMUL.cot_stem7x7s2_forward(P(xs), P(wsn), P(ys), 2, 32, 32, dtb, None) == 0
+        xc, wc, yc = torch.randn(2, 64, 7, 7).bfloat16(), torch.randn(40, 64).bfloat16(), torch.empty(2, 40, 7, 7).bfloat16()
+        assert _EMUL.cot_conv1x1_forward(P(xc), None, 64, P(wc), None, P(yc), 2, 64, 40, 49, dtb, None) == 0
+        out.extend([ys, yc])
+        return [t.clone() for t in out]
+
+    _EMUL.emul_set_order(0)
+    base = run_all()
+    try:
+        _EMUL.emul_set_order(order)
+        other = run_all()
+    finally:
+        _EMUL.emul_set_order(0)
+    for i, (a, b) in enumerate(zip(base, other)):
+        assert torch.equal(a, b), i
