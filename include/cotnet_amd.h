@@ -125,7 +125,8 @@ const char* cot_last_kernel(void);
  *   key 6: v3 extra LDS KiB per workgroup             key 7: v3 XCD-aware tile order (0|1)
  *   key 8: issue the fused backward as separate gX and gW launches (0|1)
  *   key 9: 1x1-convolution kernels XCD-aware wave order (0|1)   key 10: 16-row tiles per wave, forward (0 auto|2|4)
- *   key 11: 1x1 weight-gradient target wave count (sizes the split of the reduction); negative = force -value splits
+ *   key 11: weight-gradient target wave count (sizes the split of the reduction AND therefore cot_*_workspace: query the
+ *           workspace after setting it); negative = force -value splits
  *   key 12: BatchNorm: fold the per-channel finalize step into the apply kernels (0|1; one launch less each way) */
 int cot_set_tuning(int key, int value);
 /* 0 if the device probe confirmed the DPP wave_shr/wave_shl semantics the v2 kernels rely on, 1 if the
