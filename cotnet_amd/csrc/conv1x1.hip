@@ -71,70 +71,64 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
     // K loop with a D-stage register ring: the loads of steps k+1 .. k+D-1 are in flight while step k is multiplied.
     // Deep-K / small-image layers (K up to 2048 at 7x7, one or two waves per CU) are chains of dependent load latencies
     // otherwise; the big-image layers have enough waves per SIMD and use D = 1 to keep their 128 accumulators resident.
-    bf16_t raw[D][8][PXV];
+    // (pieces stay packed from the load to the multiply: mfma_common.h "pieces")
+    uint32_t raw[D][8][PXV / 2];
     bf16x8_t af[D][MT];
-    auto load_stage = [&](int d, int k0) {
-        const int kb = k0 + 8 * g;
+    // Pixels past a row's end are loaded like any others (they are the next channel's data and only ever reach output
+    // columns that are not stored); what must hold is that the wide loads stay inside their slab -- false only for the
+    // last image's last channels in a partial pixel tile.  Waves that can get there (a handful per launch) run a second
+    // copy of the loop that tests every stage; the others run loads only (see ring_loop on why that matters).
+    const bool wave_safe = ((int64_t)n * k1 + k1 - 1) * HW + P0 + 16 * PXV <= (int64_t)N * k1 * HW &&
+                           (K == k1 || ((int64_t)n * (K - k1) + (K - k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * (K - k1) * HW);
+    auto load_stage = [&](auto safe, int d, int step) __attribute__((always_inline)) {
+        const int k0 = 32 * step, kb = k0 + 8 * g;
         const bool kok = kb < K;           // K % 8 == 0: a lane group's 8 channels are all inside or all outside
         const bool full_k = k0 + 32 <= K;  // wave-uniform: all four lane groups inside
-        // Pixels past the row's end are loaded like any others (they are the next channel's data and only ever reach
-        // output columns that are not stored); what must hold is that the wide loads stay inside their slab -- false
-        // only for the last image's last channels in a partial pixel tile (wave-uniform test).
-        const int rend = min(k0 + 32, K);
         bool wide = true;
-        if (k0 < k1) wide = ((int64_t)n * k1 + min(rend, k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * k1 * HW;
-        if (rend > k1)
-            wide = wide && ((int64_t)n * (K - k1) + (rend - k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * (K - k1) * HW;
+        if (!decltype(safe)::value) {  // wave-uniform test of this stage's rows
+            const int rend = min(k0 + 32, K);
+            if (k0 < k1) wide = ((int64_t)n * k1 + min(rend, k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * k1 * HW;
+            if (rend > k1)
+                wide = wide && ((int64_t)n * (K - k1) + (rend - k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * (K - k1) * HW;
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r)
-            load_piece<PXV, AL>(raw[d][r], kok ? row_ptr(x1, x2, k1, K, n, kb + r, HW) + p0 : x1, kok ? cnt : 0, wide,
-                                /*zero_tail=*/false);
+            load_packed<PXV, AL>(raw[d][r], kok ? row_ptr(x1, x2, k1, K, n, kb + r, HW) + p0 : x1, kok ? cnt : 0, wide);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            bf16_t a_[8];
             if (TA) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a_[e] = arow[mt][((kok ? kb : 0) + e) * M];  // (weights: < 2^31 elements)
+                for (int e = 0; e < 8; ++e) af[d][mt][e] = arow[mt][((kok ? kb : 0) + e) * M];  // (weights: < 2^31 elements)
             } else {
-                load_piece<8, 16>(a_, arow[mt] + (kok ? kb : 0), 8, true, false);
+                __builtin_memcpy(&af[d][mt], __builtin_assume_aligned(arow[mt] + (kok ? kb : 0), 16), 16);
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) af[d][mt][e] = a_[e];
         }
         if (!full_k && !kok) {  // partial last K step (scalar branch): lane groups past K contribute exact zeros
 #pragma unroll
             for (int r = 0; r < 8; ++r)
 #pragma unroll
-                for (int c = 0; c < PXV; ++c) raw[d][r][c] = (bf16_t)0.0f;
+                for (int c = 0; c < PXV / 2; ++c) raw[d][r][c] = 0u;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) af[d][mt][e] = (bf16_t)0.0f;
         }
     };
-    auto multiply_stage = [&](int d) {
+    auto multiply_stage = [&](int d) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < PXV; ++c) {
-            bf16x8_t bfrag;  // in-register transposition: pixel c of each of this lane's 8 channels
+            uint32_t bq[4];  // in-register transposition: pixel c of each of this lane's 8 channels
 #pragma unroll
-            for (int r = 0; r < 8; ++r) bfrag[r] = raw[d][r][c];
+            for (int h = 0; h < 4; ++h) bq[h] = packed_pair(raw[d][2 * h], raw[d][2 * h + 1], c);
+            const bf16x8_t bfrag = packed_as_frag(bq);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt][c] = COT_MFMA_16X16X32_BF16(af[d][mt], bfrag, acc[mt][c]);
         }
     };
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d)
-        if (32 * d < K) load_stage(d, 32 * d);
-    for (int k0 = 0; k0 < K; k0 += 32 * D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int kc = k0 + 32 * d;  // the step multiplied now lives in slot d; slot (d + D - 1) % D is free
-            if (kc < K) {
-                if (kc + 32 * (D - 1) < K) load_stage((d + D - 1) % D, kc + 32 * (D - 1));
-                multiply_stage(d);
-            }
-        }
-    }
+    if (wave_safe)
+        ring_loop<D>(ceil_div(K, 32), [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); }, multiply_stage);
+    else
+        ring_loop<D>(ceil_div(K, 32), [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); }, multiply_stage);
 
     if (cnt <= 0) return;
 #pragma unroll
@@ -147,9 +141,10 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
                 bf16_t* dst = row_ptr(y1, y2, m1, M, n, m, HW) + p0;
                 bf16_t o[PXV];
                 if ((accumulate >> (m < m1 ? 0 : 1)) & 1) {  // y += result (bit 0: first slab, bit 1: second slab)
-                    load_piece<PXV, AL>(o, dst, cnt, false);
+                    uint32_t prev[PXV / 2];
+                    load_packed_lane<PXV, AL>(prev, dst, cnt);
 #pragma unroll
-                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b + (float)o[c]);
+                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b + packed_get(prev, c));
                 } else {
 #pragma unroll
                     for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b);
@@ -195,47 +190,66 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
 
     // reduction loop with a 3-stage register ring: two steps' loads are in flight while one is multiplied (a slice is a
     // chain of up to a few hundred dependent steps; without the ring every step pays a full memory latency)
+    // Fragments stay packed and untouched from the load to the multiply (mfma_common.h "pieces"): the tail of a row is
+    // cleared, and the column of ones for the bias gradient put in, at multiply time.
     constexpr int DW = 3;
-    bf16x8_t af[DW][4], bfr[DW][4];
-    auto load_stage = [&](int d, int t) {
-        const int nn = t / spi, st = t - nn * spi;
+    uint32_t aq[DW][4][4], bq[DW][4][4];
+    int pleft[DW];   // valid pixels of this lane's pieces in the stage
+    bool tails[DW];  // wave-uniform: the stage runs over the row's end
+    const bool any_ones = has_bias && jb * 64 <= J && J < jb * 64 + 64;  // wave-uniform: the bias column is in this tile
+    // every lane reads 8 elements at (row, st*32 + 8g): inside the tensor for ALL rows of image nn?  (the rows of later
+    // images follow in memory; only the last image(s) can run out) -- per tensor, by its channel count.  Decided once per
+    // wave for the last image of its slice (the worst case); the few waves that can run out test every step in a second
+    // copy of the loop (see ring_loop).
+    const int jmin = x2 ? min(k1, J - k1) : J;
+    const int64_t over_max = (int64_t)spi * 32 - HW, left_min = (int64_t)(N - 1 - (t1 > t0 ? (t1 - 1) / spi : 0)) * HW;
+    const bool wave_safe = over_max <= left_min * M && over_max <= left_min * jmin;
+    auto load_stage = [&](auto safe, int d, int step) __attribute__((always_inline)) {
+        const int t = t0 + step, nn = t / spi, st = t - nn * spi;
         const int p = st * 32 + g * 8;
         const int cnt = HW - p;
         const bool tail = (st + 1) * 32 > HW;  // wave-uniform: this step runs over the row's end
-        // every lane reads 8 elements at (row, st*32 + 8g): inside the tensor for ALL rows of image nn?  (the rows of
-        // later images follow in memory; only the last image(s) can run out) -- per tensor, by its channel count
-        const int64_t over = (int64_t)st * 32 + 32 - HW, left = (int64_t)(N - 1 - nn) * HW;
-        const bool wide = over <= left * M && over <= left * (x2 ? min(k1, J - k1) : J);
+        bool wide = true;
+        if (!decltype(safe)::value) {
+            const int64_t over = (int64_t)st * 32 + 32 - HW, left = (int64_t)(N - 1 - nn) * HW;
+            wide = over <= left * M && over <= left * jmin;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            bf16_t a_[8], b_[8];
-            load_piece<8, AL>(a_, gy + ((int64_t)nn * M + mrow[q]) * HW + p, cnt, wide, tail);
-            load_piece<8, AL>(b_, row_ptr(x1, x2, k1, J, nn, jrow[q], HW) + p, cnt, wide, tail);
+            load_packed<8, AL>(aq[d][q], gy + ((int64_t)nn * M + mrow[q]) * HW + p, cnt, wide);
+            load_packed<8, AL>(bq[d][q], row_ptr(x1, x2, k1, J, nn, jrow[q], HW) + p, cnt, wide);
+        }
+        pleft[d] = cnt;
+        tails[d] = tail;
+    };
+    auto multiply_stage = [&](int d) __attribute__((always_inline)) {
+        if (any_ones) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                af[d][q][e] = a_[e];
-                bfr[d][q][e] = ones[q] ? (bf16_t)1.0f : b_[e];
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bq[d][q][i] = ones[q] ? 0x3f803f80u : bq[d][q][i];  // bf16 1.0 twice
+        }
+        if (tails[d]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                mask_packed<8>(aq[d][q], pleft[d]);
+                mask_packed<8>(bq[d][q], pleft[d]);
             }
         }
-    };
-    auto multiply_stage = [&](int d) {
+        bf16x8_t bfr[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) bfr[b] = packed_as_frag(bq[d][b]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af[d][a], bfr[d][b], acc[a][b]);
-    };
+        for (int a = 0; a < 4; ++a) {
+            const bf16x8_t af = packed_as_frag(aq[d][a]);
 #pragma unroll
-    for (int d = 0; d < DW - 1; ++d)
-        if (t0 + d < t1) load_stage(d, t0 + d);
-    for (int t = t0; t < t1; t += DW) {
-#pragma unroll
-        for (int d = 0; d < DW; ++d) {
-            if (t + d < t1) {
-                if (t + d + DW - 1 < t1) load_stage((d + DW - 1) % DW, t + d + DW - 1);
-                multiply_stage(d);
-            }
+            for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af, bfr[b], acc[a][b]);
         }
-    }
+    };
+    if (wave_safe)
+        ring_loop<DW>(t1 - t0, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); }, multiply_stage);
+    else
+        ring_loop<DW>(t1 - t0, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); }, multiply_stage);
 
     float* ps = part + (int64_t)s * M * Jp;
 #pragma unroll

@@ -82,29 +82,27 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, b
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) mrow[mt] = min(mbase + mt * 16 + j, Mg - 1);
 
-    // K loop (9*Kc/32 = 4.5 .. 36 steps) with a D-stage register ring, as in conv1x1.hip
-    bf16_t raw[D][8][PXV];
+    // K loop (9*Kc/32 = 4.5 .. 36 steps) with a D-stage register ring, as in conv1x1.hip: pieces stay packed from the load
+    // to the multiply, and the first / last waves of the launch (whose shifted loads could leave the tensor) run their
+    // own copy of the loop with bounds-checked element loads
+    uint32_t raw[D][8][PXV / 2];
     bf16x8_t af[D][MT];
     int tapd[D];
-    auto load_stage = [&](int d, int k0) {
-        const int kb = k0 + 8 * lg;
+    auto load_stage = [&](auto safe, int d, int step) __attribute__((always_inline)) {
+        const int k0 = 32 * step, kb = k0 + 8 * lg;
         const bool kok = kb < Kg;  // Kc % 8 == 0: the 8 channels of a lane group share one tap and are all in or all out
         const int kbc = kok ? kb : 0;
         const int tap = kbc / Kc, ci0 = kbc - tap * Kc;
         const int shift = (tap / 3 - 1) * W + (tap % 3 - 1);
         tapd[d] = kok ? tap : 9;  // bit 9 of a validity mask is never set: lane groups past K contribute zeros
-        if (wave_safe) {
+        if (decltype(safe)::value) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
-                load_piece<PXV, 2>(raw[d][r], x + (base + (int64_t)(ci0 + r) * HW + p0 + shift), PXV, true, false);
+                load_packed<PXV, 2>(raw[d][r], x + (base + (int64_t)(ci0 + r) * HW + p0 + shift), PXV, true);
         } else {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int64_t off = base + (int64_t)(ci0 + r) * HW + p0 + shift;
-#pragma unroll
-                for (int c = 0; c < PXV; ++c)
-                    raw[d][r][c] = (off + c >= 0 && off + c < x_elems) ? x[off + c] : (bf16_t)0.0f;
-            }
+            for (int r = 0; r < 8; ++r)
+                load_packed_checked<PXV>(raw[d][r], x, base + (int64_t)(ci0 + r) * HW + p0 + shift, x_elems);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -116,30 +114,22 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, b
             }
         }
     };
-    auto multiply_stage = [&](int d) {
+    auto multiply_stage = [&](int d) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < PXV; ++c) {
-            const bool valid = (vm[c] >> tapd[d]) & 1u;
-            bf16x8_t bfrag;
+            const uint32_t keep = ((vm[c] >> tapd[d]) & 1u) ? 0xffffffffu : 0u;  // tap outside the image: exact zeros
+            uint32_t bq[4];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) bfrag[r] = valid ? raw[d][r][c] : (bf16_t)0.0f;
+            for (int h = 0; h < 4; ++h) bq[h] = packed_pair(raw[d][2 * h], raw[d][2 * h + 1], c) & keep;
+            const bf16x8_t bfrag = packed_as_frag(bq);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt][c] = COT_MFMA_16X16X32_BF16(af[d][mt], bfrag, acc[mt][c]);
         }
     };
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d)
-        if (32 * d < Kg) load_stage(d, 32 * d);
-    for (int k0 = 0; k0 < Kg; k0 += 32 * D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int kc = k0 + 32 * d;
-            if (kc < Kg) {
-                if (kc + 32 * (D - 1) < Kg) load_stage((d + D - 1) % D, kc + 32 * (D - 1));
-                multiply_stage(d);
-            }
-        }
-    }
+    if (wave_safe)
+        ring_loop<D>(ceil_div(Kg, 32), [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); }, multiply_stage);
+    else
+        ring_loop<D>(ceil_div(Kg, 32), [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); }, multiply_stage);
 
     if (cnt <= 0) return;
 #pragma unroll
@@ -151,9 +141,10 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, b
                 bf16_t* dst = y + ((int64_t)n * Cout + (int64_t)grp * Mg + m) * HW + p0;
                 bf16_t o[PXV];
                 if (accumulate) {  // y += result
-                    load_piece<PXV, AL>(o, dst, cnt, false);
+                    uint32_t prev[PXV / 2];
+                    load_packed_lane<PXV, AL>(prev, dst, cnt);
 #pragma unroll
-                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + (float)o[c]);
+                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + packed_get(prev, c));
                 } else {
 #pragma unroll
                     for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)acc[mt][c][i];
@@ -200,67 +191,66 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // reduction loop with a 3-stage register ring (see conv1x1_wgrad_mfma); the tap masks are applied at load time
-    constexpr int DW = 3;
-    bf16x8_t af[DW][MTW], bfr[DW][4];
-    auto load_stage = [&](int d, int t) {
-        const int n = t / spi, st = t - n * spi;
+    // reduction loop with a 3-stage register ring (see conv1x1_wgrad_mfma).  Fragments stay packed and untouched from the
+    // load to the multiply: the tap-validity masks (which also clear pixels past the row's end: they are zero there) and
+    // the clearing of dY's tail are applied at multiply time.  Waves whose loads could leave a tensor -- the first and
+    // last of the launch -- run their own copy of the loop with checked loads.
+    constexpr int DW = MTW == 4 ? 2 : 3;  // (what fits next to 16*MTW accumulators)
+    uint32_t aq[DW][MTW][4], bq[DW][4][4], vmd[DW][4];  // vmd: validity bits of the lane's 8 pixels, two per register
+    int pleft[DW];    // valid pixels of this lane's pieces in the stage
+    bool tails[DW];   // wave-uniform: the stage runs over the row's end
+    const int n_first = t0 / spi, n_last = t1 > t0 ? (t1 - 1) / spi : n_first;
+    const bool wave_safe =
+        ((int64_t)n_first * Cin + (int64_t)grp * Kc) * HW - W - 1 >= 0 &&
+        ((int64_t)n_last * Cin + (int64_t)grp * Kc + Kc - 1) * HW + (int64_t)spi * 32 + W + 1 <= x_elems &&
+        (int64_t)spi * 32 - HW <= (int64_t)(N - 1 - n_last) * Cout * HW;
+    auto load_stage = [&](auto safe, int d, int step) __attribute__((always_inline)) {
+        const int t = t0 + step, n = t / spi, st = t - n * spi;
         const int P = st * 32, p = P + lg * 8;
         const int cnt = HW - p;
-        const bool tail = P + 32 > HW;  // wave-uniform: this step runs over the row's end
-        // every lane reads 8 elements of dY at (row, P + 8*lg): inside the tensor for all rows of image n?
-        const bool wide_a = (int64_t)P + 32 - HW <= (int64_t)(N - 1 - n) * Cout * HW;
-        const int64_t base = ((int64_t)n * Cin + (int64_t)grp * Kc) * HW;
-        const bool safe = base + P - W - 1 >= 0 && base + (int64_t)(Kc - 1) * HW + P + 32 + W + 1 <= x_elems;
-        unsigned vmd[4];  // tap-validity bits of this lane's 8 pixels, two pixels per dword
-        {
-            uint16_t v_[8];
-            __builtin_memcpy(v_, __builtin_assume_aligned(masks + p, 16), 16);
+        __builtin_memcpy(vmd[d], __builtin_assume_aligned(masks + p, 16), 16);
+        if (decltype(safe)::value) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vmd[i] = (unsigned)v_[2 * i] | ((unsigned)v_[2 * i + 1] << 16);
+            for (int q = 0; q < MTW; ++q) load_packed<8, AL>(aq[d][q], gy + ((int64_t)n * Cout + mrow[q]) * HW + p, cnt, true);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                load_packed<8, 2>(bq[d][q], x + (((int64_t)n * Cin + jch[q]) * HW + p + jshift[q]), 8, true);
+        } else {
+            // every lane reads 8 elements of dY at (row, P + 8*lg): inside the tensor for all rows of image n?
+            const bool wide_a = (int64_t)P + 32 - HW <= (int64_t)(N - 1 - n) * Cout * HW;
+#pragma unroll
+            for (int q = 0; q < MTW; ++q)
+                load_packed<8, AL>(aq[d][q], gy + ((int64_t)n * Cout + mrow[q]) * HW + p, cnt, wide_a);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                load_packed_checked<8>(bq[d][q], x, ((int64_t)n * Cin + jch[q]) * HW + p + jshift[q], x_elems);
+        }
+        pleft[d] = cnt;
+        tails[d] = P + 32 > HW;
+    };
+    auto multiply_stage = [&](int d) __attribute__((always_inline)) {
+        if (tails[d]) {
+#pragma unroll
+            for (int q = 0; q < MTW; ++q) mask_packed<8>(aq[d][q], pleft[d]);
+        }
+        bf16x8_t bfr[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bq[d][b][i] &= ((vmd[d][i] >> jtap[b]) & 0x00010001u) * 0xffffu;
+            bfr[b] = packed_as_frag(bq[d][b]);
         }
 #pragma unroll
-        for (int q = 0; q < MTW; ++q) {
-            bf16_t a_[8];
-            load_piece<8, AL>(a_, gy + ((int64_t)n * Cout + mrow[q]) * HW + p, cnt, wide_a, tail);
+        for (int a = 0; a < MTW; ++a) {
+            const bf16x8_t af = packed_as_frag(aq[d][a]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) af[d][q][e] = a_[e];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t off = ((int64_t)n * Cin + jch[q]) * HW + p + jshift[q];
-            bf16_t b_[8];
-            if (safe) {
-                load_piece<8, 2>(b_, x + off, 8, true, false);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) b_[e] = (off + e >= 0 && off + e < x_elems) ? x[off + e] : (bf16_t)0.0f;
-            }
-            unsigned bd[4];
-            __builtin_memcpy(bd, b_, 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bd[i] &= ((vmd[i] >> jtap[q]) & 0x00010001u) * 0xffffu;
-            __builtin_memcpy(&bfr[d][q], bd, 16);
+            for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af, bfr[b], acc[a][b]);
         }
     };
-    auto multiply_stage = [&](int d) {
-#pragma unroll
-        for (int a = 0; a < MTW; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af[d][a], bfr[d][b], acc[a][b]);
-    };
-#pragma unroll
-    for (int d = 0; d < DW - 1; ++d)
-        if (t0 + d < t1) load_stage(d, t0 + d);
-    for (int t = t0; t < t1; t += DW) {
-#pragma unroll
-        for (int d = 0; d < DW; ++d) {
-            if (t + d < t1) {
-                if (t + d + DW - 1 < t1) load_stage((d + DW - 1) % DW, t + d + DW - 1);
-                multiply_stage(d);
-            }
-        }
-    }
+    if (wave_safe)
+        ring_loop<DW>(t1 - t0, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); }, multiply_stage);
+    else
+        ring_loop<DW>(t1 - t0, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); }, multiply_stage);
 
     float* ps = part + (int64_t)s * Cout * Jg;
 #pragma unroll
@@ -308,7 +298,7 @@ static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_
     const bool big = waves >= 8192;
     if (MT == 1) {
         if (big) COT_C3_LAUNCH(1, 1);
-        else COT_C3_LAUNCH(1, (PXV == 8 ? 3 : 4));
+        else COT_C3_LAUNCH(1, (PXV == 8 ? 2 : 3));
     } else if (MT == 2) {
         if (big) COT_C3_LAUNCH(2, 1);
         else COT_C3_LAUNCH(2, (PXV == 8 ? 2 : 3));

@@ -40,6 +40,11 @@ template <int NV> __device__ __forceinline__ void gn_block_sum_all(float (&v)[NV
     }
 }
 
+// The group sits in registers PACKED (two bf16 per register; mfma_common.h "pieces"): all loads of a thread are issued
+// back to back and nothing touches them until the last one is on its way.  Rounds whose pieces run over a channel's end
+// (wave-uniform `tail`) are loaded wide all the same -- what follows is the next channel; lanes wholly past the end all
+// read the 16 bytes at the end -- unless that could leave the tensor (the end of the last (image, group)), and have
+// their excess elements cleared afterwards.
 template <int NT, int R, int AL>
 __global__ void __launch_bounds__(NT)
 gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
@@ -50,20 +55,33 @@ gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, c
     const int t = threadIdx.x, g = blockIdx.x % G;
     const int wend = 64 * (uniform(t >> 6) + 1);        // one past this wave's last thread index
     const int64_t base = (int64_t)blockIdx.x * 9 * HW;  // (n*G + g) * 9 channels
-    bf16_t v[9][R][8];
+    const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
+    uint32_t v[9][R][4];
+    bool tail[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int p = 8 * (r * NT + t);
-        // wave-uniform: does any lane's piece of this round run over the channel's end?  It is still loaded wide (what
-        // follows is the next channel; lanes wholly past the end all read the 16 bytes at the end) unless that could
-        // leave the tensor (the end of the last (image, group))
-        const bool tail = 8 * (r * NT + wend) > HW;
-        const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
+    for (int r = 0; r < R; ++r) tail[r] = 8 * (r * NT + wend) > HW;
+    if (base + 9 * (int64_t)HW + 8 <= total) {  // every workgroup but the tensor's last: loads only, in a straight line
 #pragma unroll
-        for (int cl = 0; cl < 9; ++cl)
-            load_piece<8, AL>(v[cl][r], x + base + (int64_t)cl * HW + min(p, HW), HW - p,
-                              !tail || base + (int64_t)(cl + 1) * HW + 8 <= total, tail);
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int cl = 0; cl < 9; ++cl)
+                load_packed<8, AL>(v[cl][r], x + base + (int64_t)cl * HW + min(8 * (r * NT + t), HW), 8, true);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = 8 * (r * NT + t);
+#pragma unroll
+            for (int cl = 0; cl < 9; ++cl)
+                load_packed<8, AL>(v[cl][r], x + base + (int64_t)cl * HW + min(p, HW), HW - p,
+                                   !tail[r] || base + (int64_t)(cl + 1) * HW + 8 <= total);
+        }
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (tail[r]) {
+#pragma unroll
+            for (int cl = 0; cl < 9; ++cl) mask_packed<8>(v[cl][r], HW - 8 * (r * NT + t));
+        }
     const float inv = 1.f / (9.f * (float)HW);
     float s[1] = {0.f};
 #pragma unroll
@@ -71,19 +89,19 @@ gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, c
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s[0] += (float)v[cl][r][e];  // (pieces past the end were loaded as zeros)
+            for (int e = 0; e < 8; ++e) s[0] += packed_get(v[cl][r], e);
     gn_block_sum_all<1>(s, smem);
     const float mean = s[0] * inv;
     float q[1] = {0.f};
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int p = 8 * (r * NT + t);
+        const int left = HW - 8 * (r * NT + t);
 #pragma unroll
         for (int cl = 0; cl < 9; ++cl)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float d = (float)v[cl][r][e] - mean;
-                if (p + e < HW) q[0] += d * d;
+                const float d = packed_get(v[cl][r], e) - mean;
+                if (!tail[r] || e < left) q[0] += d * d;
             }
     }
     gn_block_sum_all<1>(q, smem);
@@ -100,7 +118,7 @@ gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, c
             const int p = 8 * (r * NT + t);
             bf16_t o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)v[cl][r][e] * ga + be);
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(packed_get(v[cl][r], e) * ga + be);
             if (p < HW) store_piece<8, AL>(y + base + (int64_t)cl * HW + p, o, HW - p);
         }
     }
@@ -116,21 +134,43 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
     const int t = threadIdx.x, g = blockIdx.x % G;
     const int wend = 64 * (uniform(t >> 6) + 1);
     const int64_t base = (int64_t)blockIdx.x * 9 * HW;
-    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
-    bf16_t xv[9][R][8], gv[9][R][8];
+    const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
+    uint32_t xv[9][R][4], gv[9][R][4];
+    bool tail[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int p = 8 * (r * NT + t);
-        const bool tail = 8 * (r * NT + wend) > HW;
-        const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
+    for (int r = 0; r < R; ++r) tail[r] = 8 * (r * NT + wend) > HW;
+    if (base + 9 * (int64_t)HW + 8 <= total) {  // every workgroup but the tensor's last: loads only, in a straight line
 #pragma unroll
-        for (int cl = 0; cl < 9; ++cl) {
-            const bool wide = !tail || base + (int64_t)(cl + 1) * HW + 8 <= total;
-            load_piece<8, AL>(xv[cl][r], x + base + (int64_t)cl * HW + min(p, HW), HW - p, wide, tail);
-            load_piece<8, AL>(gv[cl][r], dy + base + (int64_t)cl * HW + min(p, HW), HW - p, wide, tail);
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int cl = 0; cl < 9; ++cl) {
+                const int64_t o = base + (int64_t)cl * HW + min(8 * (r * NT + t), HW);
+                load_packed<8, AL>(xv[cl][r], x + o, 8, true);
+                load_packed<8, AL>(gv[cl][r], dy + o, 8, true);
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = 8 * (r * NT + t);
+#pragma unroll
+            for (int cl = 0; cl < 9; ++cl) {
+                const bool wide = !tail[r] || base + (int64_t)(cl + 1) * HW + 8 <= total;
+                load_packed<8, AL>(xv[cl][r], x + base + (int64_t)cl * HW + min(p, HW), HW - p, wide);
+                load_packed<8, AL>(gv[cl][r], dy + base + (int64_t)cl * HW + min(p, HW), HW - p, wide);
+            }
         }
     }
-    float s[18];  // per channel: sum dy, sum dy * xhat   (dy past the end was loaded as zero)
+    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (tail[r]) {  // (dy alone decides: every use of x below is multiplied into a dy term or not stored)
+#pragma unroll
+            for (int cl = 0; cl < 9; ++cl) {
+                mask_packed<8>(xv[cl][r], HW - 8 * (r * NT + t));
+                mask_packed<8>(gv[cl][r], HW - 8 * (r * NT + t));
+            }
+        }
+    float s[18];  // per channel: sum dy, sum dy * xhat
 #pragma unroll
     for (int cl = 0; cl < 9; ++cl) {
         float a = 0.f, b = 0.f;
@@ -138,13 +178,24 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float d = (float)gv[cl][r][e];
+                const float d = packed_get(gv[cl][r], e);
                 a += d;
-                b += d * (((float)xv[cl][r][e] - mean) * rstd);
+                b += d * ((packed_get(xv[cl][r], e) - mean) * rstd);
             }
         s[2 * cl] = a;
         s[2 * cl + 1] = b;
     }
+    // the fp32 forms of this phase must not be kept for the next one (they would triple the registers held across the
+    // reduction): as far as the optimiser can tell, these are new values
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                COT_KEEP_PACKED(xv[cl][r][i]);
+                COT_KEEP_PACKED(gv[cl][r][i]);
+            }
     gn_block_sum_all<18>(s, smem);
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -166,8 +217,8 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
             bf16_t o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float xh = ((float)xv[cl][r][e] - mean) * rstd;
-                o[e] = (bf16_t)(rstd * (ga * (float)gv[cl][r][e] - c1 - xh * c2));
+                const float xh = (packed_get(xv[cl][r], e) - mean) * rstd;
+                o[e] = (bf16_t)(rstd * (ga * packed_get(gv[cl][r], e) - c1 - xh * c2));
             }
             if (p < HW) store_piece<8, AL>(dx + base + (int64_t)cl * HW + p, o, HW - p);
         }
@@ -205,7 +256,7 @@ static int gn9_config(int HW) {
         case 2: { CALL(64, 2); } break;       \
         case 3: { CALL(256, 1); } break;      \
         case 4: { CALL(256, 2); } break;      \
-        default: { CALL(1024, 1); } break;    \
+        default: { CALL(512, 2); } break;     \
     }
 
 int gn9_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N, int C,

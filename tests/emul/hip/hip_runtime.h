@@ -246,6 +246,8 @@ namespace cot { alignas(16) inline thread_local char cot_smem[160 * 1024]; }  //
     std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)
 
 #define COT_MFMA_16X16X32_BF16(a, b, c) emul::mfma_16x16x32_bf16((a), (b), (c))
+#define COT_KEEP_PACKED(u) ((void)(u))
+#define COT_WAIT_LOADS() ((void)0)
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only ever applied to wave-uniform values
 inline float __expf(float x) { return std::exp(x); }
 using std::min;
