@@ -110,8 +110,14 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, b
             for (int e = 0; e < 8; ++e) {
                 const int wi = dgrad ? ((grp * Kc + ci0 + e) * Mg + mrow[mt]) * 9 + (8 - tap)  // (< 2^31 elements)
                                      : ((grp * Mg + mrow[mt]) * Kc + ci0 + e) * 9 + tap;
-                af[d][mt][e] = kok ? wt[wi] : (bf16_t)0.0f;
+                af[d][mt][e] = wt[wi];  // (kbc keeps the index inside the tensor for lane groups past K)
             }
+        }
+        if (k0 + 32 > Kg && !kok) {  // partial last K step (scalar branch first): lane groups past K contribute exact zeros
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[d][mt][e] = (bf16_t)0.0f;
         }
     };
     auto multiply_stage = [&](int d) __attribute__((always_inline)) {
