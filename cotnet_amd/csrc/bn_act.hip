@@ -18,6 +18,53 @@
 namespace cot {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+// kernel-side activation selector (template parameter: the element loops carry no branches on it); ACT_RELU_Y = ReLU
+// whose backward reads the saved OUTPUT's sign instead of recomputing z
+enum { ACT_RELU_Y = 3 };
+
+// Index walkers: the kernels step through a tensor with a fixed stride (blockDim, or gridDim*blockDim); what they need
+// per step is (image, vector-in-plane) or (channel, ...) of the flat index.  Dividing per step costs more instructions than
+// the eight elements of a vector (the first version did: two integer divisions per 16 bytes); stepping the quotient and
+// remainder costs three.
+struct PlaneWalk {  // i = start, start + step, ... -> (n, v) = divmod(i, vpp)
+    int n, v, qn, qv, vpp;
+    __device__ __forceinline__ PlaneWalk(int start, int step, int vpp_) : vpp(vpp_) {
+        n = start / vpp_;
+        v = start - n * vpp_;
+        qn = step / vpp_;
+        qv = step - qn * vpp_;
+    }
+    __device__ __forceinline__ void next() {
+        n += qn;
+        v += qv;
+        if (v >= vpp) {
+            v -= vpp;
+            ++n;
+        }
+    }
+};
+struct ChannelWalk {  // i = start, start + step, ... -> c = (i / vpp) % C  (and i itself)
+    int64_t i, step;
+    int c, v, qc, qv, vpp, C;
+    __device__ __forceinline__ ChannelWalk(int64_t start, int64_t step_, int vpp_, int C_)
+        : i(start), step(step_), vpp(vpp_), C(C_) {
+        const int64_t plane = start / vpp_, qp = step_ / vpp_;
+        c = (int)(plane % C_);
+        v = (int)(start - plane * vpp_);
+        qc = (int)(qp % C_);
+        qv = (int)(step_ - qp * vpp_);
+    }
+    __device__ __forceinline__ void next() {
+        i += step;
+        v += qv;
+        c += qc;
+        if (v >= vpp) {
+            v -= vpp;
+            ++c;
+        }
+        if (c >= C) c -= C;
+    }
+};
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -56,10 +103,9 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
     float shift = 0.f;
     if (n0 < n1) shift = (float)x[((int64_t)n0 * C + c) * HW];
     float acc[2] = {0.f, 0.f};
-    const int64_t nvec = (int64_t)(n1 - n0) * vpp;
-    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
-        const int n = n0 + (int)(i / vpp), v = (int)(i % vpp);
-        const Vec<T, V> xv = ldv<T, V>(x + ((int64_t)n * C + c) * HW + (int64_t)v * V);
+#pragma unroll 2
+    for (PlaneWalk w(threadIdx.x, blockDim.x, vpp); w.n < n1 - n0; w.next()) {
+        const Vec<T, V> xv = ldv<T, V>(x + ((int64_t)(n0 + w.n) * C + c) * HW + (int64_t)w.v * V);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float d = (float)xv.v[k] - shift;
@@ -105,23 +151,23 @@ __global__ void bn_stats_finalize(const float* __restrict__ part, int C, int spl
     }
 }
 
-__device__ __forceinline__ float act_fwd(float z, int act) {
-    if (act == ACT_RELU) return z > 0.f ? z : 0.f;
-    if (act == ACT_SILU) return z / (1.f + __expf(-z));
+template <int ACT> __device__ __forceinline__ float act_fwd(float z) {
+    if (ACT == ACT_RELU || ACT == ACT_RELU_Y) return z > 0.f ? z : 0.f;
+    if (ACT == ACT_SILU) return z / (1.f + __expf(-z));
     return z;
 }
 
 // ---- forward apply: flat over (plane, vector) -------------------------------------------------------------------
-template <typename T, int V>
+template <typename T, int V, int ACT>
 __global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, const T* __restrict__ res,
                                                    T* __restrict__ y, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, int C, int HW, int64_t nvec,
-                                                   int act) {
-    const int vpp = HW / V;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t plane = i / vpp;
-        const int c = (int)(plane % C);
+                                                   const float* __restrict__ beta, int C, int HW, int64_t nvec) {
+#pragma unroll 2
+    for (ChannelWalk w((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, HW / V, C);
+         w.i < nvec; w.next()) {
+        const int c = w.c;
+        const int64_t i = w.i;
         const float a = gamma[c] * rstd[c], b = beta[c] - mean[c] * a;
         const Vec<T, V> xv = ldv<T, V>(x + i * V);
         Vec<T, V> rv, o;
@@ -130,7 +176,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, con
         for (int k = 0; k < V; ++k) {
             float z = (float)xv.v[k] * a + b;
             if (res) z += (float)rv.v[k];
-            o.v[k] = (T)act_fwd(z, act);
+            o.v[k] = (T)act_fwd<ACT>(z);
         }
         stv<T, V>(y + i * V, o);
     }
@@ -138,9 +184,9 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, con
 
 // g = dy * act'(z): SiLU recomputes z from x; ReLU uses the saved output (y > 0) when it is given -- it must be when
 // there was a residual (z + residual decides the sign) -- and otherwise recomputes z as well (one tensor read less)
-__device__ __forceinline__ float act_bwd(float dy, float z_or_y, int act) {
-    if (act == ACT_RELU) return z_or_y > 0.f ? dy : 0.f;
-    if (act == ACT_SILU) {
+template <int ACT> __device__ __forceinline__ float act_bwd(float dy, float z_or_y) {
+    if (ACT == ACT_RELU || ACT == ACT_RELU_Y) return z_or_y > 0.f ? dy : 0.f;
+    if (ACT == ACT_SILU) {
         const float sg = 1.f / (1.f + __expf(-z_or_y));
         return dy * sg * (1.f + z_or_y * (1.f - sg));
     }
@@ -148,12 +194,12 @@ __device__ __forceinline__ float act_bwd(float dy, float z_or_y, int act) {
 }
 
 // ---- backward reductions: grid (C, SPLIT): sum g and sum g*xhat per channel chunk -------------------------------
-template <typename T, int V>
+template <typename T, int V, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce(const T* __restrict__ dy, const T* __restrict__ x,
                                                     const T* __restrict__ y, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float* __restrict__ part, int N,
-                                                    int C, int HW, int nper, int act) {
+                                                    int C, int HW, int nper) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* smem = reinterpret_cast<float*>(cot_smem);
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
@@ -161,17 +207,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const T* __restrict__ dy, c
     const int vpp = HW / V;
     const float m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
     float acc[2] = {0.f, 0.f};
-    const int64_t nvec = (int64_t)(n1 - n0) * vpp;
-    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
-        const int n = n0 + (int)(i / vpp), v = (int)(i % vpp);
-        const int64_t off = ((int64_t)n * C + c) * HW + (int64_t)v * V;
+#pragma unroll 2
+    for (PlaneWalk w(threadIdx.x, blockDim.x, vpp); w.n < n1 - n0; w.next()) {
+        const int64_t off = ((int64_t)(n0 + w.n) * C + c) * HW + (int64_t)w.v * V;
         const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
         Vec<T, V> yv;
-        if (act == ACT_RELU && y) yv = ldv<T, V>(y + off);
+        if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + off);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = act_bwd((float)dv.v[k], (act == ACT_RELU && y) ? (float)yv.v[k] : xh * ga + be, act);
+            const float g = act_bwd<ACT>((float)dv.v[k], ACT == ACT_RELU_Y ? (float)yv.v[k] : xh * ga + be);
             acc[0] += g;
             acc[1] += g * xh;
         }
@@ -198,26 +243,27 @@ __global__ void bn_bwd_finalize(const float* __restrict__ part, int C, int split
 }
 
 // ---- backward apply: dx (and dresidual = g) ---------------------------------------------------------------------
-template <typename T, int V>
+template <typename T, int V, int ACT>
 __global__ __launch_bounds__(256) void bn_apply_bwd(const T* __restrict__ dy, const T* __restrict__ x,
                                                    const T* __restrict__ y, T* __restrict__ dx, T* __restrict__ dres,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                   int C, int HW, int64_t nvec, float inv_m, int act) {
-    const int vpp = HW / V;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t plane = i / vpp;
-        const int c = (int)(plane % C);
+                                                   int C, int HW, int64_t nvec, float inv_m) {
+#pragma unroll 2
+    for (ChannelWalk w((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, HW / V, C);
+         w.i < nvec; w.next()) {
+        const int c = w.c;
+        const int64_t i = w.i;
         const float m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
         const float k1 = dbeta[c] * inv_m, k2 = dgamma[c] * inv_m, gr = ga * r;
         const Vec<T, V> dv = ldv<T, V>(dy + i * V), xv = ldv<T, V>(x + i * V);
         Vec<T, V> yv, o, og;
-        if (act == ACT_RELU && y) yv = ldv<T, V>(y + i * V);
+        if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + i * V);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = act_bwd((float)dv.v[k], (act == ACT_RELU && y) ? (float)yv.v[k] : xh * ga + be, act);
+            const float g = act_bwd<ACT>((float)dv.v[k], ACT == ACT_RELU_Y ? (float)yv.v[k] : xh * ga + be);
             o.v[k] = (T)(gr * (g - k1 - xh * k2));
             og.v[k] = (T)g;
         }
@@ -231,14 +277,14 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const T* __restrict__ dy, co
 // Grid (C, SPLIT) like the partial kernels, so the channel is block-uniform: every thread merges the SPLIT chunk
 // statistics of its channel (a few dozen flops), block (c, 0) writes mean / rstd / running statistics.  One launch less
 // per BatchNorm forward and backward (~230 launches of a CoTNet-50 step).
-template <typename T, int V>
+template <typename T, int V, int ACT>
 __global__ __launch_bounds__(256) void bn_apply_fwd_fold(const T* __restrict__ x, const T* __restrict__ res,
                                                         T* __restrict__ y, const float* __restrict__ part,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
                                                         long long* __restrict__ num_batches_tracked, int N, int C, int HW,
-                                                        int nper, float eps, float momentum, int act) {
+                                                        int nper, float eps, float momentum) {
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     float n = 0.f, m = 0.f, M2 = 0.f;
     for (int q = 0; q < split; ++q) {
@@ -265,10 +311,9 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_fold(const T* __restrict__ x
     const float a = gamma[c] * r, b = beta[c] - m * a;
     const int n0 = s * nper, n1 = min(N, n0 + nper);
     const int vpp = HW / V;
-    const int64_t nvec = (int64_t)(n1 - n0) * vpp;
-    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
-        const int ni = n0 + (int)(i / vpp), v = (int)(i % vpp);
-        const int64_t off = ((int64_t)ni * C + c) * HW + (int64_t)v * V;
+#pragma unroll 2
+    for (PlaneWalk w(threadIdx.x, blockDim.x, vpp); w.n < n1 - n0; w.next()) {
+        const int64_t off = ((int64_t)(n0 + w.n) * C + c) * HW + (int64_t)w.v * V;
         const Vec<T, V> xv = ldv<T, V>(x + off);
         Vec<T, V> rv, o;
         if (res) rv = ldv<T, V>(res + off);
@@ -276,20 +321,20 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_fold(const T* __restrict__ x
         for (int k = 0; k < V; ++k) {
             float z = (float)xv.v[k] * a + b;
             if (res) z += (float)rv.v[k];
-            o.v[k] = (T)act_fwd(z, act);
+            o.v[k] = (T)act_fwd<ACT>(z);
         }
         stv<T, V>(y + off, o);
     }
 }
 
-template <typename T, int V>
+template <typename T, int V, int ACT>
 __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ dy, const T* __restrict__ x,
                                                         const T* __restrict__ y, T* __restrict__ dx, T* __restrict__ dres,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ part, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int N, int C, int HW, int nper,
-                                                        float inv_m, int act) {
+                                                        float inv_m) {
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     float sb = 0.f, sg = 0.f;
     for (int q = 0; q < split; ++q) {
@@ -304,17 +349,16 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ d
     const float k1 = sb * inv_m, k2 = sg * inv_m, gr = ga * r;
     const int n0 = s * nper, n1 = min(N, n0 + nper);
     const int vpp = HW / V;
-    const int64_t nvec = (int64_t)(n1 - n0) * vpp;
-    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
-        const int ni = n0 + (int)(i / vpp), v = (int)(i % vpp);
-        const int64_t off = ((int64_t)ni * C + c) * HW + (int64_t)v * V;
+#pragma unroll 2
+    for (PlaneWalk w(threadIdx.x, blockDim.x, vpp); w.n < n1 - n0; w.next()) {
+        const int64_t off = ((int64_t)(n0 + w.n) * C + c) * HW + (int64_t)w.v * V;
         const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
         Vec<T, V> yv, o, og;
-        if (act == ACT_RELU && y) yv = ldv<T, V>(y + off);
+        if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + off);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = act_bwd((float)dv.v[k], (act == ACT_RELU && y) ? (float)yv.v[k] : xh * ga + be, act);
+            const float g = act_bwd<ACT>((float)dv.v[k], ACT == ACT_RELU_Y ? (float)yv.v[k] : xh * ga + be);
             o.v[k] = (T)(gr * (g - k1 - xh * k2));
             og.v[k] = (T)g;
         }
@@ -324,7 +368,8 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-int g_bn_fold = 0;  // cot_set_tuning key 12
+int g_bn_fold = 0;          // cot_set_tuning key 12
+int g_bn_grid_cap = 4096;  // cot_set_tuning key 13: most workgroups of a flat (grid-stride) BatchNorm apply kernel
 static inline int pick_vec(size_t esize, int HW) {
     int lim = (int)(16 / esize);
     for (int V = 8; V >= 1; V >>= 1)
@@ -339,7 +384,7 @@ static inline void pick_split(int N, int C, int* split, int* nper) {
 }
 static inline unsigned flat_grid(int64_t nvec) {
     int64_t b = ceil_div64(nvec, 256);
-    if (b > 4096) b = 4096;
+    if (b > g_bn_grid_cap) b = g_bn_grid_cap;
     if (b < 1) b = 1;
     return (unsigned)b;
 }
@@ -350,44 +395,67 @@ int bn_workspace_floats(int N, int C) {
     return C * split * 4;
 }
 
-template <typename T, int V>
-static int bn_fwd_launch(const T* x, const T* res, T* y, const float* gamma, const float* beta, float* mean,
-                         float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW,
-                         float eps, float mom, int act, hipStream_t s) {
+template <typename T, int V, int ACT>
+static int bn_fwd_launch_act(const T* x, const T* res, T* y, const float* gamma, const float* beta, float* mean,
+                             float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW,
+                             float eps, float mom, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
     COT_LAUNCH((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
     if (g_bn_fold) {
-        COT_LAUNCH((bn_apply_fwd_fold<T, V>), dim3(C, split), dim3(256), 0, s, x, res, y, (const float*)ws, gamma,
-                           beta, mean, rstd, rmean, rvar, nbt, N, C, HW, nper, eps, mom, act);
+        COT_LAUNCH((bn_apply_fwd_fold<T, V, ACT>), dim3(C, split), dim3(256), 0, s, x, res, y, (const float*)ws, gamma,
+                   beta, mean, rstd, rmean, rvar, nbt, N, C, HW, nper, eps, mom);
         return check_launch("bn_act_forward");
     }
     COT_LAUNCH(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
                rstd, rmean, rvar, nbt);
     const int64_t nvec = (int64_t)N * C * HW / V;
-    COT_LAUNCH((bn_apply_fwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, x, res, y, (const float*)mean,
-               (const float*)rstd, gamma, beta, C, HW, nvec, act);
+    COT_LAUNCH((bn_apply_fwd<T, V, ACT>), dim3(flat_grid(nvec)), dim3(256), 0, s, x, res, y, (const float*)mean,
+               (const float*)rstd, gamma, beta, C, HW, nvec);
     return check_launch("bn_act_forward");
+}
+
+template <typename T, int V>
+static int bn_fwd_launch(const T* x, const T* res, T* y, const float* gamma, const float* beta, float* mean,
+                         float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW,
+                         float eps, float mom, int act, hipStream_t s) {
+#define BN_FA(A_) return bn_fwd_launch_act<T, V, A_>(x, res, y, gamma, beta, mean, rstd, rmean, rvar, nbt, ws, N, C, HW, eps, mom, s)
+    if (act == ACT_RELU) BN_FA(ACT_RELU);
+    if (act == ACT_SILU) BN_FA(ACT_SILU);
+    BN_FA(ACT_NONE);
+#undef BN_FA
+}
+
+template <typename T, int V, int ACT>
+static int bn_bwd_launch_act(const T* dy, const T* x, const T* y, T* dx, T* dres, const float* gamma, const float* beta,
+                             const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ws, int N, int C,
+                             int HW, hipStream_t s) {
+    int split, nper;
+    pick_split(N, C, &split, &nper);
+    COT_LAUNCH((bn_bwd_reduce<T, V, ACT>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma,
+               beta, ws, N, C, HW, nper);
+    if (g_bn_fold) {
+        COT_LAUNCH((bn_apply_bwd_fold<T, V, ACT>), dim3(C, split), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma,
+                   beta, (const float*)ws, dgamma, dbeta, N, C, HW, nper, 1.0f / (float)((int64_t)N * HW));
+        return check_launch("bn_act_backward");
+    }
+    COT_LAUNCH(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
+    const int64_t nvec = (int64_t)N * C * HW / V;
+    COT_LAUNCH((bn_apply_bwd<T, V, ACT>), dim3(flat_grid(nvec)), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma,
+               beta, (const float*)dgamma, (const float*)dbeta, C, HW, nvec, 1.0f / (float)((int64_t)N * HW));
+    return check_launch("bn_act_backward");
 }
 
 template <typename T, int V>
 static int bn_bwd_launch(const T* dy, const T* x, const T* y, T* dx, T* dres, const float* gamma, const float* beta,
                          const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ws, int N, int C,
                          int HW, int act, hipStream_t s) {
-    int split, nper;
-    pick_split(N, C, &split, &nper);
-    COT_LAUNCH((bn_bwd_reduce<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma, beta, ws, N, C, HW,
-               nper, act);
-    if (g_bn_fold) {
-        COT_LAUNCH((bn_apply_bwd_fold<T, V>), dim3(C, split), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma,
-                           beta, (const float*)ws, dgamma, dbeta, N, C, HW, nper, 1.0f / (float)((int64_t)N * HW), act);
-        return check_launch("bn_act_backward");
-    }
-    COT_LAUNCH(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
-    const int64_t nvec = (int64_t)N * C * HW / V;
-    COT_LAUNCH((bn_apply_bwd<T, V>), dim3(flat_grid(nvec)), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma, beta,
-               (const float*)dgamma, (const float*)dbeta, C, HW, nvec, 1.0f / (float)((int64_t)N * HW), act);
-    return check_launch("bn_act_backward");
+#define BN_BA(A_) return bn_bwd_launch_act<T, V, A_>(dy, x, y, dx, dres, gamma, beta, mean, rstd, dgamma, dbeta, ws, N, C, HW, s)
+    if (act == ACT_RELU && y) BN_BA(ACT_RELU_Y);  // sign of the saved output (required when there was a residual)
+    if (act == ACT_RELU) BN_BA(ACT_RELU);
+    if (act == ACT_SILU) BN_BA(ACT_SILU);
+    BN_BA(ACT_NONE);
+#undef BN_BA
 }
 
 template <typename T>

@@ -127,7 +127,8 @@ const char* cot_last_kernel(void);
  *   key 9: 1x1-convolution kernels XCD-aware wave order (0|1)   key 10: 16-row tiles per wave, forward (0 auto|2|4)
  *   key 11: weight-gradient target wave count (sizes the split of the reduction AND therefore cot_*_workspace: query the
  *           workspace after setting it); negative = force -value splits
- *   key 12: BatchNorm: fold the per-channel finalize step into the apply kernels (0|1; one launch less each way) */
+ *   key 12: BatchNorm: fold the per-channel finalize step into the apply kernels (0|1; one launch less each way)
+ *   key 13: BatchNorm: most workgroups of the flat (grid-stride) apply kernels (default 4096; <= 0 restores it) */
 int cot_set_tuning(int key, int value);
 /* 0 if the device probe confirmed the DPP wave_shr/wave_shl semantics the v2 kernels rely on, 1 if the
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */

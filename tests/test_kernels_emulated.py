@@ -303,6 +303,47 @@ def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold):
         assert ((dres.float() - rr.grad).abs() <= gtol * (1 + rr.grad.abs())).all()
 
 
+@pytest.mark.parametrize("cap", [1, 2, 3, 7])
+@pytest.mark.parametrize("N,C,H,W,dtype", [(6, 8, 7, 7, torch.bfloat16), (5, 3, 14, 14, torch.bfloat16),
+                                           (3, 5, 4, 6, torch.float32), (2, 1, 40, 40, torch.bfloat16),
+                                           (7, 2, 1, 1, torch.float32), (2, 13, 5, 8, torch.bfloat16)])
+def test_bn_apply_kernels_do_not_depend_on_the_grid(N, C, H, W, dtype, cap):
+    """The flat BatchNorm apply kernels walk (channel, vector) incrementally instead of dividing per vector
+    (bn_act.hip ChannelWalk): with the grid capped at a few workgroups (tuning key 13) every thread takes many strides --
+    planes shorter / longer than a stride, channel counts that the stride wraps several times -- and the results must be
+    bit-identical to the one-stride launch."""
+    g = torch.Generator().manual_seed(N * C + H + cap)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.7).to(dtype)
+    res = torch.randn(N, C, H, W, generator=g).to(dtype)
+    dy = torch.randn(N, C, H, W, generator=g).to(dtype)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    dt = _lib.dtype_code(dtype)
+    assert _EMUL.cot_set_tuning(12, 0) == 0
+    outs = {}
+    try:
+        for k in (0, cap):
+            assert _EMUL.cot_set_tuning(13, k) == 0
+            for act in (0, 1, 2):
+                y, dx, dres = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+                mean, rstd, dgamma, dbeta = torch.empty(C), torch.empty(C), torch.empty(C), torch.empty(C)
+                ws = torch.empty(_EMUL.cot_bn_act_workspace(N, C))
+                assert _EMUL.cot_bn_act_forward(P(x), P(res), P(y), P(gamma), P(beta), P(mean), P(rstd), None, None, None,
+                                                P(ws), N, C, H * W, 1e-5, 0.1, act, dt, None) == 0
+                assert _EMUL.cot_bn_act_backward(P(dy), P(x), P(y), P(dx), P(dres), P(gamma), P(beta), P(mean), P(rstd),
+                                                 P(dgamma), P(dbeta), P(ws), N, C, H * W, act, dt, None) == 0
+                outs[(k, act)] = (y, dx, dres)
+    finally:
+        _EMUL.cot_set_tuning(13, 0)
+    for act in (0, 1, 2):
+        for a, b in zip(outs[(0, act)], outs[(cap, act)]):
+            assert torch.equal(a, b)
+    # and the one-stride launch itself is right (forward, fp32 reference)
+    z = torch.nn.functional.batch_norm(x.float(), None, None, gamma, beta, True, 0.1, 1e-5) + res.float()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    if N * H * W > 1:
+        assert ((outs[(0, 0)][0].float() - z).abs() <= tol * (1 + z.abs())).all()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,H,W", [(16, 9, 56), (16, 11, 28), (32, 14, 14), (64, 7, 7)])
 def test_fused_window_softmax_aggregation(C, H, W, dtype):
