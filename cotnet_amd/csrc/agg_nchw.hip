@@ -557,12 +557,14 @@ __device__ __forceinline__ unsigned logical_block(int xcd_remap) {
     return (b & 7u) * (nblk >> 3) + (b >> 3);
 }
 
+// The read is unconditional (a predicated LDS read is its own exec-masked region, and the six reads of a channel were
+// issued and waited for one by one); rows outside the image are cleared afterwards by selection.  Every index a lane can
+// form lies inside its slab -- the halo rows are staged too, whatever they hold -- except row -1 of the tensor's first
+// tile, which is clamped to the slab's start (and cleared: that row is outside the image).
 template <typename T, int P>
 __device__ __forceinline__ Vec<T, P> lds_row(const T* __restrict__ slab, int64_t idx, bool row_ok) {
-    Vec<T, P> v;
-    if (row_ok) {
-        v = *reinterpret_cast<const Vec<T, P>*>(slab + idx);
-    } else {
+    Vec<T, P> v = *reinterpret_cast<const Vec<T, P>*>(slab + (idx > 0 ? idx : 0));
+    if (!row_ok) {
 #pragma unroll
         for (int i = 0; i < P; ++i) v.v[i] = (T)0;
     }
