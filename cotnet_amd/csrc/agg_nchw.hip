@@ -357,6 +357,16 @@ __device__ __forceinline__ void expand_row(const Vec<T, P>& raw, bool has_left, 
     dst[P + 1] = has_right ? r : (A)0;
 }
 
+// the same without the row-end test: the halos are whatever the neighbouring lanes hold (the previous / next row's edge
+// pixels at a row's end).  For accumulators that are cleared at row ends afterwards (weight gradient, below).
+template <typename T, int P, int XCHG, typename A>
+__device__ __forceinline__ void expand_row_unmasked(const Vec<T, P>& raw, A (&dst)[P + 2]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) dst[i + 1] = (A)raw.v[i];
+    dst[0] = lane_prev<XCHG>(dst[P]);
+    dst[P + 1] = lane_next<XCHG>(dst[1]);
+}
+
 struct ItemV2 {
     bool valid;
     int seg, h, wc;
@@ -778,15 +788,23 @@ __global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const int hr = h - 1 + kh;
-                    A xr[P + 2];
-                    expand_row<T, P, XCHG, A>(lds_row<T, P>(xj, lidx + (int64_t)(kh - 1) * W, hr >= 0 && hr < H),
-                                              has_left, has_right, xr);
+                    A xr[P + 2];  // (halo columns unmasked: the two accumulators they feed are cleared after the loop)
+                    expand_row_unmasked<T, P, XCHG, A>(lds_row<T, P>(xj, lidx + (int64_t)(kh - 1) * W, hr >= 0 && hr < H),
+                                                       xr);
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                         for (int i = 0; i < P; ++i) gwacc[kh * 3 + kw][i] += xr[i + kw] * gr[1][i + 1];
                 }
             }
+        }
+    }
+    if (DO_GW) {  // taps that reach over the row's end saw the neighbouring row's pixels: their sums are discarded here,
+                  // once per item, instead of masking the halo columns once per channel (selection: also drops Inf/NaN)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            gwacc[kh * 3 + 0][0] = has_left ? gwacc[kh * 3 + 0][0] : (A)0;
+            gwacc[kh * 3 + 2][P - 1] = has_right ? gwacc[kh * 3 + 2][P - 1] : (A)0;
         }
     }
     if (DO_GW && SM) {
