@@ -316,12 +316,14 @@ __global__ __launch_bounds__(256) void agg_bwd_nchw_k3(const T* __restrict__ gou
 // XCHG selects the lane-exchange primitive: 0 = v_mov_b32_dpp wave_shr/wave_shl, 1 = ds_bpermute (__shfl);
 // the library probes the DPP direction once on the device and falls back to 1 if it is not what we expect.
 
+// (bound_ctrl: a lane without a source -- lane 0 of wave_shr, lane 63 of wave_shl -- reads 0; with it and full masks the
+// "old" operand is dead, so no register has to be zeroed per exchange and the move can fold into its consumer)
 template <int XCHG> __device__ __forceinline__ float lane_prev(float v) {
-    if (XCHG == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+    if (XCHG == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
     return __shfl_up(v, 1);
 }
 template <int XCHG> __device__ __forceinline__ float lane_next(float v) {
-    if (XCHG == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+    if (XCHG == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
     return __shfl_down(v, 1);
 }
 template <int XCHG> __device__ __forceinline__ double lane_prev(double v) { return __shfl_up(v, 1); }
@@ -329,8 +331,9 @@ template <int XCHG> __device__ __forceinline__ double lane_next(double v) { retu
 
 __global__ void dpp_probe_kernel(int* out) {
     const int l = threadIdx.x;
-    out[l] = __builtin_amdgcn_update_dpp(-1, l, 0x138, 0xf, 0xf, false);       // expect l-1 (lane 0: -1)
-    out[64 + l] = __builtin_amdgcn_update_dpp(-1, l, 0x130, 0xf, 0xf, false);  // expect l+1 (lane 63: -1)
+    // exactly the exchanges lane_prev / lane_next use (old = -1 here so that a lane that is NOT zero-filled shows)
+    out[l] = __builtin_amdgcn_update_dpp(-1, l + 1, 0x138, 0xf, 0xf, true);       // expect l     (lane 0: 0)
+    out[64 + l] = __builtin_amdgcn_update_dpp(-1, l + 1, 0x130, 0xf, 0xf, true);  // expect l + 2 (lane 63: 0)
 }
 
 // raw (storage-type) row vector of plane row hr, zero when the row is outside the image
@@ -866,8 +869,8 @@ int xchg_mode() {
         bool ok = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
         hipFree(d);
         for (int l = 0; ok && l < 64; ++l) {
-            if (h[l] != (l == 0 ? -1 : l - 1)) ok = false;
-            if (h[64 + l] != (l == 63 ? -1 : l + 1)) ok = false;
+            if (h[l] != (l == 0 ? 0 : l)) ok = false;
+            if (h[64 + l] != (l == 63 ? 0 : l + 2)) ok = false;
         }
         return ok ? 0 : 1;
     }();

@@ -255,8 +255,8 @@ using std::max;
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 // only the two DPP controls the kernels use: 0x138 = wave_shr:1 (lane l <- l-1), 0x130 = wave_shl:1 (l <- l+1)
-inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
-    return emul::exchange<int>(src, ctrl == 0x138 ? -1 : +1, old);
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
+    return emul::exchange<int>(src, ctrl == 0x138 ? -1 : +1, bound_ctrl ? 0 : old);  // bound_ctrl: no source lane -> 0
 }
 template <typename V> inline V __shfl_up(V v, int d) { return emul::exchange<V>(v, -d, v); }
 template <typename V> inline V __shfl_down(V v, int d) { return emul::exchange<V>(v, +d, v); }
