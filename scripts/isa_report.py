@@ -7,6 +7,7 @@ last is the quick check that a register ring really keeps loads in flight: a ste
 stages k+1.. are on their way waits with vmcnt(#loads of the younger stages), not vmcnt(0)  (DESIGN.md 4.7).
 
     python scripts/isa_report.py conv1x1 conv3x3g group_norm9 > profiles/rNN_isa_report.txt
+    python scripts/isa_report.py --only k3_lds agg_nchw        (only kernels whose name contains the substring)
 """
 import collections
 import os
@@ -22,7 +23,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc"]
 
 
 def demangle(names):
-    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    # binutils' c++filt does not know the mangling of __bf16 ("DF16b"): hand it over as a vendor type of the same name
+    text = "\n".join(n.replace("DF16b", "u6__bf16") for n in names)
+    out = subprocess.run(["c++filt"], input=text, capture_output=True, text=True).stdout.splitlines()
     return [re.sub(r"\(.*$", "", re.sub(r"^void ", "", d)) for d in out]
 
 
@@ -57,13 +60,18 @@ def kernels(src, tmp):
 
 
 def main():
-    for stem in sys.argv[1:] or ["conv1x1", "conv3x3g", "group_norm9", "stem7x7"]:
+    args, only = sys.argv[1:], None
+    if args[:1] == ["--only"]:
+        only, args = args[1], args[2:]
+    for stem in args or ["conv1x1", "conv3x3g", "group_norm9", "stem7x7"]:
         src = os.path.join(CSRC, stem + ".hip")
         with tempfile.TemporaryDirectory() as tmp:
             res, body = resources(src, tmp), kernels(src, tmp)
         names = list(body)
         print(f"==== {stem}.hip")
         for name, dem in zip(names, demangle(names)):
+            if only and only not in dem:
+                continue
             lines = body[name]
             mem = collections.Counter(m.group(1) for ln in lines
                                       for m in [re.match(r"\s+((?:global|ds|buffer|scratch)_\w+)", ln)] if m)
