@@ -337,12 +337,13 @@ __global__ void dpp_probe_kernel(int* out) {
 }
 
 // raw (storage-type) row vector of plane row hr, zero when the row is outside the image
+// (the load is unconditional, from the nearest row inside the plane, and cleared by selection afterwards: a predicated
+// load is an exec-masked region of its own, and a lane's nine of them were issued and waited for one at a time)
 template <typename T, int P>
 __device__ __forceinline__ Vec<T, P> load_row_raw(const T* __restrict__ plane, int hr, int H, int W, int w0) {
-    Vec<T, P> v;
-    if (hr >= 0 && hr < H) {
-        v = ldv<T, P>(plane + (int64_t)hr * W + w0);
-    } else {
+    const int hc = hr < 0 ? 0 : (hr >= H ? H - 1 : hr);
+    Vec<T, P> v = ldv<T, P>(plane + (int64_t)hc * W + w0);
+    if (hc != hr) {
 #pragma unroll
         for (int i = 0; i < P; ++i) v.v[i] = (T)0;
     }
@@ -731,6 +732,14 @@ __global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__
     const bool has_left = seg > 0, has_right = seg < segs - 1;
     const int64_t plane = (int64_t)n * wC + wc;
 
+    const int64_t cstride = (int64_t)wC * HW;
+    const int64_t img = (int64_t)n * C * HW;
+    auto stage_phase = [&](int j0, int jn) __attribute__((always_inline)) {
+        stage_slabs<T>(gout, img + (int64_t)j0 * cstride + gs, cstride, jn, sle, elems, gslab);
+        if (DO_GW) stage_slabs<T>(x, img + (int64_t)j0 * cstride + gs, cstride, jn, sle, elems, xslab);
+    };
+    stage_phase(0, J < JP ? J : JP);  // the first phase's slabs are on their way while the weights are fetched
+
     A ws[9][P];
     if (DO_GX) {
         const T* wp = w + plane * 9 * HW;
@@ -754,14 +763,13 @@ __global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__
 #pragma unroll
             for (int i = 0; i < P; ++i) gwacc[t][i] = (A)0;
     }
-    const int64_t cstride = (int64_t)wC * HW;
-    const int64_t img = (int64_t)n * C * HW;
     const int64_t lidx = (int64_t)rho * W + w0 - gs;
     for (int j0 = 0; j0 < J; j0 += JP) {
         const int jn = (J - j0 < JP) ? (J - j0) : JP;
-        if (j0 > 0) __syncthreads();  // everyone finished reading the previous phase's slabs
-        stage_slabs<T>(gout, img + (int64_t)j0 * cstride + gs, cstride, jn, sle, elems, gslab);
-        if (DO_GW) stage_slabs<T>(x, img + (int64_t)j0 * cstride + gs, cstride, jn, sle, elems, xslab);
+        if (j0 > 0) {
+            __syncthreads();  // everyone finished reading the previous phase's slabs
+            stage_phase(j0, jn);
+        }
         __syncthreads();
         for (int jj = 0; jj < jn; ++jj) {
             const T* gj = gslab + (int64_t)jj * sle;
