@@ -799,9 +799,10 @@ __global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const int hr = h - 1 + kh;
-                    A xr[P + 2];  // (halo columns unmasked: the two accumulators they feed are cleared after the loop)
-                    expand_row_unmasked<T, P, XCHG, A>(lds_row<T, P>(xj, lidx + (int64_t)(kh - 1) * W, hr >= 0 && hr < H),
-                                                       xr);
+                    // (rows outside the image and halo columns past a row's end are read as they are -- staged
+                    // neighbours, in-bounds -- because every accumulator they feed is cleared after the loop)
+                    A xr[P + 2];
+                    expand_row_unmasked<T, P, XCHG, A>(lds_row<T, P>(xj, lidx + (int64_t)(kh - 1) * W, true), xr);
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -810,8 +811,18 @@ __global__ __launch_bounds__(512) void agg_bwd_nchw_k3_lds(const T* __restrict__
             }
         }
     }
-    if (DO_GW) {  // taps that reach over the row's end saw the neighbouring row's pixels: their sums are discarded here,
-                  // once per item, instead of masking the halo columns once per channel (selection: also drops Inf/NaN)
+    if (DO_GW) {  // taps that reach outside the image saw neighbouring rows / planes: their sums are discarded here, once
+                  // per item, instead of masking x once per channel.  Selection, so a padded tap's gradient is an exact
+                  // zero whatever gO holds there (Inf/NaN included) -- as in the reference's kernel, which writes 0 for
+                  // padded taps without multiplying (aggregation_zeropad.py:81-110)
+        const bool top = h > 0, bottom = h < H - 1;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                gwacc[0 + kw][i] = top ? gwacc[0 + kw][i] : (A)0;
+                gwacc[6 + kw][i] = bottom ? gwacc[6 + kw][i] : (A)0;
+            }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             gwacc[kh * 3 + 0][0] = has_left ? gwacc[kh * 3 + 0][0] : (A)0;

@@ -82,6 +82,33 @@ def oracle_all(x, w, gout, k, s, p, d):
             cref.backward_weight(gout, x, w.shape, k, s, p, d))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,H,W", [(16, 6, 14), (16, 9, 56), (64, 7, 7)])
+def test_non_finite_values_propagate_as_in_the_reference(C, H, W, dtype):
+    """Inf / NaN in x or gO must turn up in exactly the outputs the reference's kernels put them in: neither staged
+    neighbours (rows of the next plane, the previous row's last pixel) may leak in, nor may a zero-padded tap turn a
+    non-finite gO into a NaN weight gradient (the reference writes an explicit 0 there, aggregation_zeropad.py:81-110)."""
+    g_ = torch.Generator().manual_seed(C + H)
+    N, wC = 2, C // 8
+    x = torch.randn(N, C, H, W, generator=g_).to(dtype)
+    w = torch.randn(N, 1, wC, 9, H, W, generator=g_).to(dtype)
+    gout = torch.randn(N, C, H, W, generator=g_).to(dtype)
+    x[0, 1, 2, W - 1] = float("nan")
+    x[1, 3, H - 1, 0] = float("inf")
+    gout[0, 2, 1, 0] = float("nan")
+    gout[1, 0, 0, W - 1] = float("inf")
+    gout[1, 5, H - 1, 3] = float("nan")
+    y, gx, gw, fk, bk = run(x, w, gout, 3, 1, 1, 1, 0, True)
+    assert "k3_lds" in fk and "k3_lds" in bk
+    tol = 1e-5 if dtype == torch.float32 else 6e-2
+    for got, want in zip((y, gx, gw), oracle_all(x.float(), w.float(), gout.float(), 3, 1, 1, 1)):
+        got = got.float()
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        assert torch.equal(torch.isinf(got), torch.isinf(want))
+        fin = torch.isfinite(want)
+        assert ((got[fin] - want[fin]).abs() <= tol * (1 + want[fin].abs())).all()
+
+
 @pytest.fixture
 def tuning():
     def set_(version=0, fwd_p=4, bwd_p=2, xchg=0, jp=0, nw=4, pad=0, xcd=0, split=0):
