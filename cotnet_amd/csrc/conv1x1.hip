@@ -132,7 +132,18 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
 
     if (cnt <= 0) return;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        // y += result (accumulate bit 0: first slab, bit 1: second slab): the four rows' previous values are fetched
+        // together, not one round trip per row
+        uint32_t prev[4][PXV / 2];
+        if (accumulate) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mbase + mt * 16 + g * 4 + i;
+                if (m < M && ((accumulate >> (m < m1 ? 0 : 1)) & 1))
+                    load_packed_lane<PXV, AL>(prev[i], row_ptr(y1, y2, m1, M, n, m, HW) + p0, cnt);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mbase + mt * 16 + g * 4 + i;
@@ -140,11 +151,9 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
                 const float b = bias ? (float)bias[m] : 0.f;
                 bf16_t* dst = row_ptr(y1, y2, m1, M, n, m, HW) + p0;
                 bf16_t o[PXV];
-                if ((accumulate >> (m < m1 ? 0 : 1)) & 1) {  // y += result (bit 0: first slab, bit 1: second slab)
-                    uint32_t prev[PXV / 2];
-                    load_packed_lane<PXV, AL>(prev, dst, cnt);
+                if ((accumulate >> (m < m1 ? 0 : 1)) & 1) {
 #pragma unroll
-                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b + packed_get(prev, c));
+                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b + packed_get(prev[i], c));
                 } else {
 #pragma unroll
                     for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + b);
@@ -152,6 +161,7 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
                 store_piece<PXV, AL>(dst, o, cnt);
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -139,18 +139,24 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, b
 
     if (cnt <= 0) return;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        uint32_t prev[4][PXV / 2];  // y += result: the four rows' previous values are fetched together
+        if (accumulate) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mbase + mt * 16 + lg * 4 + i;
+                if (m < Mg) load_packed_lane<PXV, AL>(prev[i], y + ((int64_t)n * Cout + (int64_t)grp * Mg + m) * HW + p0, cnt);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mbase + mt * 16 + lg * 4 + i;
             if (m < Mg) {
                 bf16_t* dst = y + ((int64_t)n * Cout + (int64_t)grp * Mg + m) * HW + p0;
                 bf16_t o[PXV];
-                if (accumulate) {  // y += result
-                    uint32_t prev[PXV / 2];
-                    load_packed_lane<PXV, AL>(prev, dst, cnt);
+                if (accumulate) {
 #pragma unroll
-                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + packed_get(prev, c));
+                    for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)(acc[mt][c][i] + packed_get(prev[i], c));
                 } else {
 #pragma unroll
                     for (int c = 0; c < PXV; ++c) o[c] = (bf16_t)acc[mt][c][i];
@@ -158,6 +164,7 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, b
                 store_piece<PXV, AL>(dst, o, cnt);
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
