@@ -10,6 +10,9 @@ O=gpurun_out
 # 1. parity: the whole GPU suite, new files last (pytest -x stops at the first failure)
 timeout 900 python -m pytest tests -m gpu -q -x > $O/r2a_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/r2a_pytest_gpu.log
 tail -6 $O/r2a_pytest_gpu.log | cut -c1-300
+# 1b. the aggregation kernels changed after their last measurement (118 -> 79 VALU per channel in the
+#     bf16 backward loop); round-1 figures at N80xC64x56x56: bf16 fwd 22.0 us / bwd 44.9 us cold
+timeout 200 python scripts/bench_agg_abi.py --shapes 0,1 --variants v3d --dtypes bf16,fp32 > $O/r2a_bench_agg.log 2>&1; tail -14 $O/r2a_bench_agg.log | cut -c1-200
 # 2. microbenchmarks of the two convolution families against MIOpen / rocBLAS
 timeout 300 python scripts/bench_conv1x1.py --iters 20 > $O/r2a_bench_conv1x1.log 2>&1; tail -45 $O/r2a_bench_conv1x1.log | cut -c1-200
 timeout 200 python scripts/bench_conv3x3g.py --iters 20 > $O/r2a_bench_conv3x3g.log 2>&1; tail -12 $O/r2a_bench_conv3x3g.log | cut -c1-200
