@@ -45,10 +45,16 @@ def case_conv1x1(rng):
     y = torch.empty(N, Co, H, W).bfloat16()
     assert E.cot_conv1x1_forward(P(x1), P(x2), c1, P(w), P(b), P(y), N, Ci, Co, H * W, BF, None) == 0
     ws = torch.empty(E.cot_conv1x1_workspace(N, Ci, Co, H * W, 1 if bias else 0), dtype=torch.uint8)
-    gx1 = torch.empty_like(x1)
-    gx2 = torch.empty_like(x2) if split else None
-    assert E.cot_conv1x1_backward_data(P(gy), P(w), P(gx1), P(gx2), c1, 0, P(ws), N, Ci, Co, H * W, BF, None) == 0
+    # accumulate bits: 1 = add into the first slab's buffer, 2 = into the second's (fp32 sum, one rounding)
+    accumulate = rng.choice([0, 0, 1, 2, 3]) & (3 if split else 1)
+    init1, init2 = torch.randn_like(x1.float()).bfloat16(), (torch.randn_like(x2.float()).bfloat16() if split else None)
+    gx1, gx2 = init1.clone(), (init2.clone() if split else None)
+    assert E.cot_conv1x1_backward_data(P(gy), P(w), P(gx1), P(gx2), c1, accumulate, P(ws), N, Ci, Co, H * W, BF, None) == 0
     gx = torch.cat([gx1, gx2], 1) if split else gx1
+    add = [init1.float() if accumulate & 1 else torch.zeros_like(init1.float())]
+    if split:
+        add.append(init2.float() if accumulate & 2 else torch.zeros_like(init2.float()))
+    xf.grad += torch.cat(add, 1)
     gw = torch.empty_like(w)
     gb = torch.empty_like(b) if bias else None
     assert E.cot_conv1x1_backward_weight(P(gy), P(x1), P(x2), c1, P(gw), P(gb), P(ws), N, Ci, Co, H * W, BF, None) == 0
@@ -69,9 +75,14 @@ def case_conv3x3(rng):
     masks = torch.empty(E.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
     assert E.cot_conv3x3g_masks(P(masks), H, W, None) == 0
     ws = torch.empty(E.cot_conv3x3g_workspace(N, C, C, G, H, W), dtype=torch.uint8)
-    y, gx, gw = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
+    y, gw = torch.empty_like(x), torch.empty_like(w)
+    accumulate = rng.choice([0, 1])
+    init = torch.randn_like(x.float()).bfloat16()
+    gx = init.clone()
     assert E.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, BF, None) == 0
-    assert E.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), 0, P(masks), P(ws), N, C, C, G, H, W, BF, None) == 0
+    assert E.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), accumulate, P(masks), P(ws), N, C, C, G, H, W, BF, None) == 0
+    if accumulate:
+        xf.grad += init.float()
     assert E.cot_conv3x3g_backward_weight(P(gy), P(x), P(gw), P(masks), P(ws), N, C, C, G, H, W, BF, None) == 0
     return close(y, yr.detach()) and close(gx, xf.grad, 3e-2) and close(gw, wf.grad), ("conv3x3g", N, C, G, H, W)
 
