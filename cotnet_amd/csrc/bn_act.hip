@@ -103,16 +103,27 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
     float shift = 0.f;
     if (n0 < n1) shift = (float)x[((int64_t)n0 * C + c) * HW];
     float acc[2] = {0.f, 0.f};
-#pragma unroll 2
-    for (PlaneWalk w(threadIdx.x, blockDim.x, vpp); w.n < n1 - n0; w.next()) {
-        const Vec<T, V> xv = ldv<T, V>(x + ((int64_t)(n0 + w.n) * C + c) * HW + (int64_t)w.v * V);
+    // Two interleaved streams per thread (vectors t, t+2B, .. and t+B, t+3B, ..; B = blockDim): both loads are issued
+    // before either is used -- twice the bytes in flight of this one-read kernel -- and the sums still run in the order
+    // t, t+B, t+2B, .. of a one-stream loop.  Stream b is always one stride ahead of a, so "b valid" implies "a valid"
+    // and at most one vector of stream a is left over.
+    const int cnt = n1 - n0;
+    auto accumulate = [&](const Vec<T, V>& xv) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float d = (float)xv.v[k] - shift;
             acc[0] += d;
             acc[1] += d * d;
         }
+    };
+    PlaneWalk a(threadIdx.x, 2 * blockDim.x, vpp), b(threadIdx.x + blockDim.x, 2 * blockDim.x, vpp);
+    for (; b.n < cnt; a.next(), b.next()) {
+        const Vec<T, V> xa = ldv<T, V>(x + ((int64_t)(n0 + a.n) * C + c) * HW + (int64_t)a.v * V);
+        const Vec<T, V> xb = ldv<T, V>(x + ((int64_t)(n0 + b.n) * C + c) * HW + (int64_t)b.v * V);
+        accumulate(xa);
+        accumulate(xb);
     }
+    if (a.n < cnt) accumulate(ldv<T, V>(x + ((int64_t)(n0 + a.n) * C + c) * HW + (int64_t)a.v * V));
     block_sum<2>(acc, smem);
     if (threadIdx.x == 0) {
         float* p = part + ((int64_t)c * split + s) * 4;
@@ -163,15 +174,11 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, con
                                                    T* __restrict__ y, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, int C, int HW, int64_t nvec) {
-#pragma unroll 2
-    for (ChannelWalk w((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, HW / V, C);
-         w.i < nvec; w.next()) {
-        const int c = w.c;
-        const int64_t i = w.i;
+    // two interleaved streams per thread, one grid stride apart: the loads of both are issued before either is used
+    // (see bn_stats_partial); elements are independent, so the order does not matter here
+    auto apply = [&](int c, int64_t i, const Vec<T, V>& xv, const Vec<T, V>& rv) __attribute__((always_inline)) {
         const float a = gamma[c] * rstd[c], b = beta[c] - mean[c] * a;
-        const Vec<T, V> xv = ldv<T, V>(x + i * V);
-        Vec<T, V> rv, o;
-        if (res) rv = ldv<T, V>(res + i * V);
+        Vec<T, V> o;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float z = (float)xv.v[k] * a + b;
@@ -179,6 +186,23 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, con
             o.v[k] = (T)act_fwd<ACT>(z);
         }
         stv<T, V>(y + i * V, o);
+    };
+    const int64_t start = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    ChannelWalk wa(start, 2 * stride, HW / V, C), wb(start + stride, 2 * stride, HW / V, C);
+    for (; wb.i < nvec; wa.next(), wb.next()) {
+        const Vec<T, V> xa = ldv<T, V>(x + wa.i * V), xb = ldv<T, V>(x + wb.i * V);
+        Vec<T, V> ra, rb;
+        if (res) {
+            ra = ldv<T, V>(res + wa.i * V);
+            rb = ldv<T, V>(res + wb.i * V);
+        }
+        apply(wa.c, wa.i, xa, ra);
+        apply(wb.c, wb.i, xb, rb);
+    }
+    if (wa.i < nvec) {
+        Vec<T, V> ra;
+        if (res) ra = ldv<T, V>(res + wa.i * V);
+        apply(wa.c, wa.i, ldv<T, V>(x + wa.i * V), ra);
     }
 }
 
