@@ -234,9 +234,19 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
 #pragma unroll
             for (int q = 0; q < MTW; ++q)
                 load_packed<8, AL>(aq[d][q], gy + ((int64_t)n * Cout + mrow[q]) * HW + p, cnt, wide_a);
+            // x: only the steps at the very start of the first image / end of the last one need checked loads (a slice
+            // of this wave merely CONTAINS such a step; the others must not pay eight element loads per piece)
+            const int64_t base = ((int64_t)n * Cin + (int64_t)grp * Kc) * HW;
+            const bool step_safe = base + P - W - 1 >= 0 && base + (int64_t)(Kc - 1) * HW + P + 32 + W + 1 <= x_elems;
+            if (step_safe) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                load_packed_checked<8>(bq[d][q], x, ((int64_t)n * Cin + jch[q]) * HW + p + jshift[q], x_elems);
+                for (int q = 0; q < 4; ++q)
+                    load_packed<8, 2>(bq[d][q], x + (((int64_t)n * Cin + jch[q]) * HW + p + jshift[q]), 8, true);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    load_packed_checked<8>(bq[d][q], x, ((int64_t)n * Cin + jch[q]) * HW + p + jshift[q], x_elems);
+            }
         }
         pleft[d] = cnt;
         tails[d] = P + 32 > HW;
