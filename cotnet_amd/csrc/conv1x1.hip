@@ -208,14 +208,17 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
     bool tails[DW];  // wave-uniform: the stage runs over the row's end
     const bool any_ones = has_bias && jb * 64 <= J && J < jb * 64 + 64;  // wave-uniform: the bias column is in this tile
     // every lane reads 8 elements at (row, st*32 + 8g): inside the tensor for ALL rows of image nn?  (the rows of later
-    // images follow in memory; only the last image(s) can run out) -- per tensor, by its channel count.  Decided once per
-    // wave for the last image of its slice (the worst case); the few waves that can run out test every step in a second
-    // copy of the loop (see ring_loop).
+    // images follow in memory; only the last image can run out) -- per tensor, by its channel count.  The steps of all
+    // images but the last are covered by one test and run the loads-only loop; the steps of the last image, if the
+    // slice has any, test each step in a second copy of the loop (see ring_loop).
     const int jmin = x2 ? min(k1, J - k1) : J;
-    const int64_t over_max = (int64_t)spi * 32 - HW, left_min = (int64_t)(N - 1 - (t1 > t0 ? (t1 - 1) / spi : 0)) * HW;
-    const bool wave_safe = over_max <= left_min * M && over_max <= left_min * jmin;
+    const int64_t over_max = (int64_t)spi * 32 - HW;  // pixels the last step of a row reads past the row's end
+    int t_split = t1;                                  // steps [t0, t_split) are safe, [t_split, t1) are tested
+    if (over_max > 0) t_split = (over_max <= (int64_t)HW * M && over_max <= (int64_t)HW * jmin) ? (N - 1) * spi : 0;
+    t_split = max(t0, min(t1, t_split));
+    int tbase = t0;
     auto load_stage = [&](auto safe, int d, int step) __attribute__((always_inline)) {
-        const int t = t0 + step, nn = t / spi, st = t - nn * spi;
+        const int t = tbase + step, nn = t / spi, st = t - nn * spi;
         const int p = st * 32 + g * 8;
         const int cnt = HW - p;
         const bool tail = (st + 1) * 32 > HW;  // wave-uniform: this step runs over the row's end
@@ -256,10 +259,11 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
             for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af, bfr[b], acc[a][b]);
         }
     };
-    if (wave_safe)
-        ring_loop<DW>(t1 - t0, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); }, multiply_stage);
-    else
-        ring_loop<DW>(t1 - t0, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); }, multiply_stage);
+    ring_loop<DW>(t_split - t0, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); },
+                  multiply_stage);
+    tbase = t_split;
+    ring_loop<DW>(t1 - t_split, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); },
+                  multiply_stage);
 
     float* ps = part + (int64_t)s * M * Jp;
 #pragma unroll

@@ -212,13 +212,20 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
     uint32_t aq[DW][MTW][4], bq[DW][4][4], vmd[DW][4];  // vmd: validity bits of the lane's 8 pixels, two per register
     int pleft[DW];    // valid pixels of this lane's pieces in the stage
     bool tails[DW];   // wave-uniform: the stage runs over the row's end
-    const int n_first = t0 / spi, n_last = t1 > t0 ? (t1 - 1) / spi : n_first;
-    const bool wave_safe =
-        ((int64_t)n_first * Cin + (int64_t)grp * Kc) * HW - W - 1 >= 0 &&
-        ((int64_t)n_last * Cin + (int64_t)grp * Kc + Kc - 1) * HW + (int64_t)spi * 32 + W + 1 <= x_elems &&
-        (int64_t)spi * 32 - HW <= (int64_t)(N - 1 - n_last) * Cout * HW;
+    // The slice is cut at image boundaries into [t0, t_lo) (first image), [t_lo, t_hi) and [t_hi, t1) (last image): one
+    // test covers the middle part, which runs the loads-only loop; the outer parts, if the slice has any, test each step.
+    int t_lo = max(t0, min(t1, spi)), t_hi = max(t_lo, min(t1, (N - 1) * spi));
+    if (t_hi > t_lo) {
+        const int n_first = t_lo / spi, n_last = (t_hi - 1) / spi;
+        const bool mid_safe =
+            ((int64_t)n_first * Cin + (int64_t)grp * Kc) * HW - W - 1 >= 0 &&
+            ((int64_t)n_last * Cin + (int64_t)grp * Kc + Kc - 1) * HW + (int64_t)spi * 32 + W + 1 <= x_elems &&
+            (int64_t)spi * 32 - HW <= (int64_t)(N - 1 - n_last) * Cout * HW;
+        if (!mid_safe) t_lo = t_hi = t1;  // (tiny tensors: everything is tested)
+    }
+    int tbase = t0;
     auto load_stage = [&](auto safe, int d, int step) __attribute__((always_inline)) {
-        const int t = t0 + step, n = t / spi, st = t - n * spi;
+        const int t = tbase + step, n = t / spi, st = t - n * spi;
         const int P = st * 32, p = P + lg * 8;
         const int cnt = HW - p;
         __builtin_memcpy(vmd[d], __builtin_assume_aligned(masks + p, 16), 16);
@@ -270,10 +277,13 @@ conv3x3g_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
             for (int b = 0; b < 4; ++b) acc[a][b] = COT_MFMA_16X16X32_BF16(af, bfr[b], acc[a][b]);
         }
     };
-    if (wave_safe)
-        ring_loop<DW>(t1 - t0, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); }, multiply_stage);
-    else
-        ring_loop<DW>(t1 - t0, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); }, multiply_stage);
+    auto tested = [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); };
+    ring_loop<DW>(t_lo - t0, tested, multiply_stage);
+    tbase = t_lo;
+    ring_loop<DW>(t_hi - t_lo, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); },
+                  multiply_stage);
+    tbase = t_hi;
+    ring_loop<DW>(t1 - t_hi, tested, multiply_stage);
 
     float* ps = part + (int64_t)s * Cout * Jg;
 #pragma unroll
