@@ -76,12 +76,24 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
     bf16x8_t af[D][MT];
     // Pixels past a row's end are loaded like any others (they are the next channel's data and only ever reach output
     // columns that are not stored); what must hold is that the wide loads stay inside their slab -- false only for the
-    // last image's last channels in a partial pixel tile.  Waves that can get there (a handful per launch) run a second
-    // copy of the loop that tests every stage; the others run loads only (see ring_loop on why that matters).
+    // last image's last channels in a partial pixel tile.  The K steps before the first such channel (all of them, for
+    // every wave but a handful per launch) run the loads-only loop, the rest a second copy of the loop that tests every
+    // stage (see ring_loop on why that matters).
+    const int nsteps = ceil_div(K, 32);
     const bool wave_safe = ((int64_t)n * k1 + k1 - 1) * HW + P0 + 16 * PXV <= (int64_t)N * k1 * HW &&
                            (K == k1 || ((int64_t)n * (K - k1) + (K - k1) - 1) * HW + P0 + 16 * PXV <= (int64_t)N * (K - k1) * HW);
+    int steps_safe = nsteps;
+    if (!wave_safe) {
+        steps_safe = 0;
+        const int64_t over = (int64_t)P0 + 16 * PXV - HW;  // pixels this wave's tile reaches past a row's end
+        if (n == N - 1 && over > 0) {  // the last ceil(over / HW) rows of a slab are the ones that can run out; slab 1 is first in K
+            const int64_t bad = (over + HW - 1) / HW;
+            steps_safe = (int)((k1 > bad ? k1 - bad : 0) / 32);
+        }
+    }
+    int sbase = 0;
     auto load_stage = [&](auto safe, int d, int step) __attribute__((always_inline)) {
-        const int k0 = 32 * step, kb = k0 + 8 * g;
+        const int k0 = 32 * (sbase + step), kb = k0 + 8 * g;
         const bool kok = kb < K;           // K % 8 == 0: a lane group's 8 channels are all inside or all outside
         const bool full_k = k0 + 32 <= K;  // wave-uniform: all four lane groups inside
         bool wide = true;
@@ -125,10 +137,11 @@ conv1x1_fwd_mfma(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, i
             for (int mt = 0; mt < MT; ++mt) acc[mt][c] = COT_MFMA_16X16X32_BF16(af[d][mt], bfrag, acc[mt][c]);
         }
     };
-    if (wave_safe)
-        ring_loop<D>(ceil_div(K, 32), [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); }, multiply_stage);
-    else
-        ring_loop<D>(ceil_div(K, 32), [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); }, multiply_stage);
+    ring_loop<D>(steps_safe, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::true_type{}, d, step); },
+                 multiply_stage);
+    sbase = steps_safe;
+    ring_loop<D>(nsteps - steps_safe, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); },
+                 multiply_stage);
 
     if (cnt <= 0) return;
 #pragma unroll
