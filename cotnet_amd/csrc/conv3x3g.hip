@@ -95,7 +95,20 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, b
         const int tap = kbc / Kc, ci0 = kbc - tap * Kc;
         const int shift = (tap / 3 - 1) * W + (tap % 3 - 1);
         tapd[d] = kok ? tap : 9;  // bit 9 of a validity mask is never set: lane groups past K contribute zeros
-        if (decltype(safe)::value) {
+        bool wide = true;
+        if (!decltype(safe)::value && D == 1) {
+            wide = false;  // big launches (D = 1): a few slow waves among thousands; keep this copy of the loop small
+        } else if (!decltype(safe)::value) {
+            // one of the launch's first / last waves: does THIS step stay inside the tensor?  (wave-uniform bound over the
+            // step's K range: taps are ordered by their shift, channels within a tap by address.)  Small launches are one
+            // round of waves: their duration is that of the slowest wave, so these must not check every element.
+            const int kend = min(k0 + 32, Kg) - 1, tlo = k0 / Kc, thi = kend / Kc;
+            const int cmin = tlo == thi ? k0 - tlo * Kc : 0, cmax = tlo == thi ? kend - tlo * Kc : Kc - 1;
+            const int64_t lo = base + (int64_t)cmin * HW + P0 + ((tlo / 3 - 1) * W + (tlo % 3 - 1));
+            const int64_t hi = base + (int64_t)cmax * HW + P0 + 16 * PXV + ((thi / 3 - 1) * W + (thi % 3 - 1));
+            wide = lo >= 0 && hi <= x_elems;
+        }
+        if (wide) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 load_packed<PXV, 2>(raw[d][r], x + (base + (int64_t)(ci0 + r) * HW + p0 + shift), PXV, true);
