@@ -107,6 +107,8 @@ conv3x3g_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wt, b
             const int64_t lo = base + (int64_t)cmin * HW + P0 + ((tlo / 3 - 1) * W + (tlo % 3 - 1));
             const int64_t hi = base + (int64_t)cmax * HW + P0 + 16 * PXV + ((thi / 3 - 1) * W + (thi % 3 - 1));
             wide = lo >= 0 && hi <= x_elems;
+            // (lane groups past K in a partial last step read at (tap 0, channel 0), the most negative shift)
+            if (k0 + 32 > Kg) wide = wide && base + P0 - W - 1 >= 0;
         }
         if (wide) {
 #pragma unroll
