@@ -325,7 +325,7 @@ int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_
 
 // ------------------------------------------------------------------------------------------------------------------
 // host side
-extern int g_conv1x1_tune[4];  // [0] xcd remap (default 1), [1] MT override (0 = auto), [2] wgrad target waves, [3] spare
+extern int g_conv1x1_tune[4];  // [0] xcd remap (default 1), [1] MT override (0 = auto), [2] wgrad target waves, [3] launches of at least this many waves use ring depth 1 (0 = 8192)
 int g_conv1x1_tune[4] = {1, 0, 2048, 0};
 
 template <int PXV, int AL, bool TA>
@@ -343,7 +343,8 @@ static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_
     const int xcd = g_conv1x1_tune[0];
     // ring depth: whatever the register file allows next to the accumulators (PXV*MT*4 registers)
     constexpr int D2 = PXV == 8 ? 2 : 4, D4 = PXV == 8 ? 1 : 3;
-    if (MT == 2 && waves >= 8192)  // big launch: occupancy hides the latency, registers stay free for more waves
+    const int64_t big = g_conv1x1_tune[3] > 0 ? g_conv1x1_tune[3] : 8192;
+    if (MT == 2 && waves >= big)  // big launch: occupancy hides the latency, registers stay free for more waves
         COT_LAUNCH((conv1x1_fwd_mfma<PXV, 2, AL, TA, 1>), grid, block, 0, stream, x1, x2, k1, A, bias, y1, y2, m1, N, K, M,
                    HW, mblocks, ptiles, waves, xcd, accumulate);
     else if (MT == 2)

@@ -343,7 +343,7 @@ static int launch_fwd(const bf16_t* x, const bf16_t* A, bf16_t* y, const uint16_
                ptiles, waves, x_elems, xcd, accumulate, dgrad)
     // ring depth: big launches (many waves per SIMD resident) hide latency by occupancy and keep their registers for
     // that; small ones get as deep a ring as fits next to the PXV*MT*4 accumulators
-    const bool big = waves >= 8192;
+    const bool big = waves >= (g_conv1x1_tune[3] > 0 ? g_conv1x1_tune[3] : 8192);  // (tuning key 14)
     if (MT == 1) {
         if (big) COT_C3_LAUNCH(1, 1);
         else COT_C3_LAUNCH(1, (PXV == 8 ? 2 : 3));

@@ -257,6 +257,10 @@ int cot_set_tuning(int key, int value) {
         g_bn_fold = value ? 1 : 0;
         return COT_OK;
     }
+    if (key == 14) {
+        g_conv1x1_tune[3] = value;
+        return COT_OK;
+    }
     if (key == 13) {
         g_bn_grid_cap = value > 0 ? value : 4096;
         return COT_OK;

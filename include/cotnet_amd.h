@@ -128,7 +128,9 @@ const char* cot_last_kernel(void);
  *   key 11: weight-gradient target wave count (sizes the split of the reduction AND therefore cot_*_workspace: query the
  *           workspace after setting it); negative = force -value splits
  *   key 12: BatchNorm: fold the per-channel finalize step into the apply kernels (0|1; one launch less each way)
- *   key 13: BatchNorm: most workgroups of the flat (grid-stride) apply kernels (default 4096; <= 0 restores it) */
+ *   key 13: BatchNorm: most workgroups of the flat (grid-stride) apply kernels (default 4096; <= 0 restores it)
+ *   key 14: convolutions: launches of at least this many waves use the shallow register ring (default 8192;
+ *           a huge value = deep rings everywhere, 1 = shallow everywhere; <= 0 restores the default) */
 int cot_set_tuning(int key, int value);
 /* 0 if the device probe confirmed the DPP wave_shr/wave_shl semantics the v2 kernels rely on, 1 if the
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */

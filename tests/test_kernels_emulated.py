@@ -330,6 +330,36 @@ def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold):
         assert ((dres.float() - rr.grad).abs() <= gtol * (1 + rr.grad.abs())).all()
 
 
+@pytest.mark.parametrize("H", [8, 7])
+def test_ring_depth_choice_does_not_change_results(H):
+    """tuning key 14 moves the launch size from which the convolutions use the shallow register ring: shallow everywhere
+    (1) and deep everywhere (huge) must give bit-identical outputs (same products, same summation order)"""
+    torch.manual_seed(H)
+    N, Ci, Co, G = 2, 64, 64, 4
+    x = torch.randn(N, Ci, H, H).bfloat16()
+    w1 = (torch.randn(Co, Ci) / 8).bfloat16()
+    w3 = (torch.randn(Co, Ci // G, 3, 3) / 12).bfloat16()
+    masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, H), dtype=torch.uint8)
+    assert _EMUL.cot_conv3x3g_masks(P(masks), H, H, None) == 0
+    ws = torch.empty(_EMUL.cot_conv3x3g_workspace(N, Ci, Co, G, H, H), dtype=torch.uint8)
+    outs = []
+    try:
+        for thr in (1, 1 << 30):
+            assert _EMUL.cot_set_tuning(14, thr) == 0
+            y1, y3, g1 = torch.empty(N, Co, H, H).bfloat16(), torch.empty(N, Co, H, H).bfloat16(), torch.empty_like(x)
+            assert _EMUL.cot_conv1x1_forward(P(x), None, Ci, P(w1), None, P(y1), N, Ci, Co, H * H, 2, None) == 0
+            ws1 = torch.empty(_EMUL.cot_conv1x1_workspace(N, Ci, Co, H * H, 0), dtype=torch.uint8)
+            assert _EMUL.cot_conv1x1_backward_data(P(y1), P(w1), P(g1), None, Ci, 0, P(ws1), N, Ci, Co, H * H, 2, None) == 0
+            assert _EMUL.cot_conv3x3g_forward(P(x), P(w3), P(y3), P(masks), P(ws), N, Ci, Co, G, H, H, 2, None) == 0
+            outs.append((y1, g1, y3))
+    finally:
+        _EMUL.cot_set_tuning(14, 0)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = torch.nn.functional.conv2d(x.float(), w3.float(), None, 1, 1, 1, G)
+    assert ((outs[0][2].float() - ref).abs() <= 2e-2 * (ref.abs() + ref.abs().mean())).all()
+
+
 @pytest.mark.parametrize("cap", [1, 2, 3, 7])
 @pytest.mark.parametrize("N,C,H,W,dtype", [(6, 8, 7, 7, torch.bfloat16), (5, 3, 14, 14, torch.bfloat16),
                                            (3, 5, 4, 6, torch.float32), (2, 1, 40, 40, torch.bfloat16),
