@@ -41,7 +41,7 @@ class _Bucket:
 
 class GradBucketReducer:
     def __init__(self, module, process_group=None, bucket_mb=48.0, broadcast_params=True, grad_dtype=None,
-                 group_fn=None, grad_mode="view", flatten_params=False):
+                 group_fn=None, grad_mode="view", flatten_params=False, force_collectives=False):
         """group_fn(name, param) -> hashable key: parameters with different keys never share a bucket (used by
         FlatSGD to keep weight-decay groups / dtypes apart).  grad_mode "view": p.grad is a view into the bucket and
         autograd accumulates in place (one small add per parameter); "copy": autograd hands over its gradient tensor
@@ -52,7 +52,10 @@ class GradBucketReducer:
         self.defer_comm = False  # True: hooks only fill the buckets; all-reduces are issued by allreduce_all()
         self.module = module
         self.group = process_group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        # force_collectives: issue the collectives even in a world of one rank (a 1-GPU box can then exercise the real RCCL
+        # communicator, the side stream and the event hand-off: tests/test_rccl_gpu.py)
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(process_group) > 1 or force_collectives)
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         params = [p for _, p in named]

@@ -43,7 +43,7 @@ def _decay_group(name, p):
 
 class FlatSGD:
     def __init__(self, model, lr, momentum=0.9, weight_decay=0.0, nesterov=True, bucket_mb=48.0, process_group=None,
-                 broadcast_params=True, ema_decay=None):
+                 broadcast_params=True, ema_decay=None, force_collectives=False):
         """ema_decay: also keep an exponential moving average of the weights (the reference's ModelEmaV2,
         utils/model_ema.py, `model_ema: True` / decay 0.9999 in its recipes): one flat kernel per bucket after the SGD
         kernel instead of one elementwise op per state_dict tensor; floating-point buffers (BatchNorm running statistics)
@@ -55,7 +55,7 @@ class FlatSGD:
         # are already in their storage dtype, so the master starts as the (exact) up-cast of the working copy.
         self.reducer = GradBucketReducer(model, process_group=process_group, bucket_mb=bucket_mb,
                                          broadcast_params=broadcast_params, group_fn=_decay_group, grad_mode="copy",
-                                         flatten_params=True)
+                                         flatten_params=True, force_collectives=force_collectives)
         self.state = []
         for b in self.reducer.buckets:
             master = b.pflat.float().clone() if b.pflat.dtype != torch.float32 else None

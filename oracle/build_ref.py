@@ -336,6 +336,11 @@ PREBUILT_AGG = [
     dict(dtype="float", N=4, C=128, H=28, W=28, heads=1, wC=16, kernel_size=3, stride=1, padding=1, dilation=1),
     dict(dtype="float", N=4, C=256, H=14, W=14, heads=1, wC=32, kernel_size=3, stride=1, padding=1, dilation=1),
     dict(dtype="float", N=4, C=512, H=7, W=7, heads=1, wC=64, kernel_size=3, stride=1, padding=1, dilation=1),
+    # the same at 32 images per geometry (SURVEY 8d asks for >= 32: 4 images starve the host's OpenMP threads)
+    dict(dtype="float", N=32, C=64, H=56, W=56, heads=1, wC=8, kernel_size=3, stride=1, padding=1, dilation=1),
+    dict(dtype="float", N=32, C=128, H=28, W=28, heads=1, wC=16, kernel_size=3, stride=1, padding=1, dilation=1),
+    dict(dtype="float", N=32, C=256, H=14, W=14, heads=1, wC=32, kernel_size=3, stride=1, padding=1, dilation=1),
+    dict(dtype="float", N=32, C=512, H=7, W=7, heads=1, wC=64, kernel_size=3, stride=1, padding=1, dilation=1),
 ]
 PREBUILT_MIX = [
     # reference self-test (aggregation_zeropad_mix.py:344-383)

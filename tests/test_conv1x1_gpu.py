@@ -1,6 +1,6 @@
 """The NCHW-native MFMA 1x1-convolution kernels (csrc/conv1x1.hip behind cot_conv1x1_*, opt-in COT_CONV1X1=hip) on the
-GPU against torch's own convolution evaluated in fp32 on the same bf16-rounded operands.  (File name sorts last: these
-kernels are the newest code in the library.)"""
+GPU against torch's own convolution evaluated in fp32 on the same bf16-rounded operands; composed blocks against an
+fp32 truth (tests/truth.py)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -81,34 +81,60 @@ def test_weight_gradient_is_deterministic(monkeypatch):
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
 
 
-def test_cot_layer_and_bottleneck_with_hip_convolutions(monkeypatch):
-    """whole CotLayer / Bottleneck forward+backward: COT_CONV1X1=hip against the default (MIOpen) path, same weights"""
-    import copy
+def test_cot_layer_and_bottleneck_with_hip_convolutions():
+    """whole Bottleneck forward+backward with COT_CONV1X1=hip: its distance from an fp32 evaluation of the same block
+    must not exceed the default (MIOpen) path's distance (round 1 compared the two bf16 paths with each other at a 3 %
+    bar -- below the bf16 noise floor of a BatchNorm block, whose input gradient sits ~10 % from the fp32 truth)"""
     from cotnet_amd.cotnet import Bottleneck
     from cotnet_amd.flat_sgd import to_mixed_bf16
+    from tests import truth
     torch.manual_seed(1)
     ds = nn.Sequential(nn.Identity(), nn.Conv2d(128, 256, 1, bias=False), nn.BatchNorm2d(256))
-    blk_a = to_mixed_bf16(Bottleneck(128, 64, downsample=ds).to(DEV)).train()
+    blk = to_mixed_bf16(Bottleneck(128, 64, downsample=ds).to(DEV)).train()
     with torch.no_grad():
-        blk_a.bn3.weight.fill_(1.0)  # zero-init would hide conv3
-    blk_b = copy.deepcopy(blk_a)
+        blk.bn3.weight.fill_(1.0)  # zero-init would hide conv3
     x = torch.randn(4, 128, 28, 28, device=DEV).bfloat16()
     gy = torch.randn(4, 256, 28, 28, device=DEV).bfloat16()
+    rep = truth.check_against_truth(blk, x, gy, cand=dict(truth.ROUND1, conv1x1="hip"))
+    print({k: (round(a, 4), round(b, 4)) for k, (a, b) in rep.items() if k in ("y", "gx")})
 
-    def run(blk, mode):
-        monkeypatch.setattr(c1, "MODE", mode)
-        xa = x.clone().requires_grad_(True)
-        y = blk(xa)
-        y.backward(gy)
-        return y.detach().float(), xa.grad.float(), {n: p.grad.float() for n, p in blk.named_parameters()}
 
-    ya, gxa, ga = run(blk_a, "hip")
-    yb, gxb, gb = run(blk_b, "")
-    assert (ya - yb).abs().mean() <= 0.02 * yb.abs().mean() + 1e-3
-    assert (gxa - gxb).abs().mean() <= 0.03 * gxb.abs().mean() + 1e-3
-    scale = max(g.abs().mean().item() for g in gb.values())  # (a bias in front of a BatchNorm has a pure-noise gradient)
-    for n in ga:
-        assert (ga[n] - gb[n]).abs().mean() <= 0.05 * gb[n].abs().mean() + 2e-3 * scale, n
+# every 1x1 shape of that Bottleneck / CotLayer(64) at 28x28 plus the se convolutions on a 1x1 map (verdict r1: the
+# composed block uses shapes the op-level list did not have), with the workspace poisoned
+BLOCK_CASES = [(4, 128, 64, 28, 0, False), (4, 64, 256, 28, 0, False), (4, 128, 256, 28, 0, False),
+               (4, 128, 32, 28, 64, False), (4, 32, 72, 28, 0, True), (4, 64, 64, 28, 0, False),
+               (1, 64, 32, 2, 0, True), (1, 32, 128, 2, 0, True)]
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,split,bias", BLOCK_CASES)
+def test_block_shapes_with_poisoned_workspace(N, Ci, Co, H, split, bias, monkeypatch):
+    monkeypatch.setattr(c1, "MODE", "hip")
+    torch.manual_seed(Ci * 3 + Co + H)
+    conv = nn.Conv2d(Ci, Co, 1, bias=bias).to(DEV).bfloat16()
+    x = torch.randn(N, Ci, H, H, device=DEV).bfloat16()
+    xs = [x[:, :split].contiguous(), x[:, split:].contiguous()] if split else [x]
+    xs = [t.requires_grad_(True) for t in xs]
+    gy = torch.randn(N, Co, H, H, device=DEV).bfloat16()
+    real_empty = torch.empty
+
+    def poisoned(*a, **k):  # every workspace / output the wrapper allocates starts as NaN (bytes 0xFF)
+        t = real_empty(*a, **k)
+        if t.is_cuda and t.numel():
+            t.view(torch.uint8).fill_(0xFF)
+        return t
+
+    monkeypatch.setattr(torch, "empty", poisoned)
+    y = c1.conv1x1(conv, *xs)
+    y.backward(gy)
+    monkeypatch.setattr(torch, "empty", real_empty)
+    torch.cuda.synchronize()
+    yr, gxr, gwr, gbr = _ref(xs, conv.weight, conv.bias, gy)
+    assert _close(y, yr, 1e-2)
+    for t, r in zip(xs, gxr):
+        assert _close(t.grad, r, 1e-2)
+    assert _close(conv.weight.grad, gwr, 1e-2)
+    if bias:
+        assert _close(conv.bias.grad, gbr, 1e-2)
 
 
 def test_other_inputs_keep_the_module_path(monkeypatch):

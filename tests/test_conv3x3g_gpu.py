@@ -1,5 +1,5 @@
 """The grouped 3x3 MFMA convolution kernels (csrc/conv3x3g.hip behind cot_conv3x3g_*, opt-in COT_CONV3X3=hip) on the GPU
-against torch's convolution evaluated in fp32 on the same bf16-rounded operands.  (Sorts last: newest code.)"""
+against torch's convolution evaluated in fp32 on the same bf16-rounded operands."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -71,30 +71,14 @@ def test_weight_gradient_is_deterministic(monkeypatch):
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
 
 
-def test_cot_layer_with_all_hip_convolutions(monkeypatch):
-    """CotLayer forward+backward with every convolution on the hand-written kernels against the default path"""
-    import copy
-    from cotnet_amd import conv1x1 as c1
+def test_cot_layer_with_all_hip_convolutions():
+    """CotLayer forward+backward with every convolution on the hand-written kernels: not further from the fp32 truth
+    than the default (MIOpen) path (tests/truth.py)"""
     from cotnet_amd.cotnet import CotLayer
     from cotnet_amd.flat_sgd import to_mixed_bf16
+    from tests import truth
     torch.manual_seed(1)
-    la = to_mixed_bf16(CotLayer(64, 3).to(DEV)).train()
-    lb = copy.deepcopy(la)
+    layer = to_mixed_bf16(CotLayer(64, 3).to(DEV)).train()
     x = torch.randn(4, 64, 28, 28, device=DEV).bfloat16()
     gy = torch.randn(4, 64, 28, 28, device=DEV).bfloat16()
-
-    def run(layer, mode):
-        monkeypatch.setattr(c1, "MODE", mode)
-        monkeypatch.setattr(c3, "MODE", mode)
-        xa = x.clone().requires_grad_(True)
-        y = layer(xa)
-        y.backward(gy)
-        return y.detach().float(), xa.grad.float(), {n: p.grad.float() for n, p in layer.named_parameters()}
-
-    ya, gxa, ga = run(la, "hip")
-    yb, gxb, gb = run(lb, "")
-    assert (ya - yb).abs().mean() <= 0.02 * yb.abs().mean() + 1e-3
-    assert (gxa - gxb).abs().mean() <= 0.04 * gxb.abs().mean() + 1e-3
-    scale = max(g.abs().mean().item() for g in gb.values())
-    for n in ga:
-        assert (ga[n] - gb[n]).abs().mean() <= 0.06 * gb[n].abs().mean() + 3e-3 * scale, n
+    truth.check_against_truth(layer, x, gy, cand=dict(truth.ROUND1, conv1x1="hip", conv3x3="hip"))

@@ -1,4 +1,4 @@
-"""FlatSGD(ema_decay=...) / cot_ema_step on the GPU (sorts last: written after the last GPU session of round 1)."""
+"""FlatSGD(ema_decay=...) / cot_ema_step on the GPU."""
 import pytest
 import torch
 

@@ -1,4 +1,4 @@
-"""csrc/group_norm9.hip (opt-in COT_GN9=hip) on the GPU against torch's GroupNorm evaluated in fp32.  (Sorts last.)"""
+"""csrc/group_norm9.hip (opt-in COT_GN9=hip) on the GPU against torch's GroupNorm evaluated in fp32."""
 import pytest
 import torch
 import torch.nn.functional as F

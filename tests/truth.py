@@ -1,0 +1,93 @@
+"""fp32 truth for the composed (layer / block / model level) bf16 tests.
+
+A bf16 training block has a noise floor of several per cent in its input gradient (BatchNorm backward amplifies the
+rounding of every intermediate), so "bf16 path A vs bf16 path B" cannot tell a defect from noise (round-1 verdict,
+weak #1).  The composed tests therefore compare BOTH paths with an fp32 evaluation of the same module on the same
+bf16-rounded parameters and inputs, computed by plain torch modules (every hand-written switch off; the aggregation
+stays the fp32 HIP kernel, which is pinned to the oracle at 1e-5 on its own), and require
+
+        err(candidate vs truth)  <=  slack * err(baseline vs truth) + floor
+
+per tensor, with err = mean |a - b| / mean |b|.  A wrong kernel shows up as a candidate error far above the baseline's.
+"""
+import contextlib
+import copy
+
+import torch
+
+
+@contextlib.contextmanager
+def switches(**kw):
+    """set module-level switches for the duration: conv1x1 / conv3x3 / gn9 / pool / head / stem = "hip" | "";
+    fused_layer / fused_bn / fused_tail = bool"""
+    from cotnet_amd import (conv1x1 as c1, conv3x3g as c3, cot_layer_fused as clf, fused_bn, group_norm9 as g9,
+                            head_fused as hf, pool3x3 as p3, radix_tail, stem7x7 as s7)
+    table = {"conv1x1": (c1, "MODE"), "conv3x3": (c3, "MODE"), "gn9": (g9, "MODE"), "pool": (p3, "MODE"),
+             "head": (hf, "MODE"), "stem": (s7, "MODE"), "fused_layer": (clf, "ENABLED"), "fused_bn": (fused_bn, "ENABLED"),
+             "fused_tail": (radix_tail, "ENABLED")}
+    old = {}
+    try:
+        for k, v in kw.items():
+            mod, attr = table[k]
+            old[k] = getattr(mod, attr)
+            setattr(mod, attr, v)
+        yield
+    finally:
+        for k, v in old.items():
+            mod, attr = table[k]
+            setattr(mod, attr, v)
+
+
+PLAIN = dict(conv1x1="", conv3x3="", gn9="", pool="", head="", stem="", fused_layer=False, fused_bn=False, fused_tail=False)
+ROUND1 = dict(conv1x1="", conv3x3="", gn9="", pool="", head="", stem="", fused_layer=False, fused_bn=True, fused_tail=True)
+ALL_HIP = dict(conv1x1="hip", conv3x3="hip", gn9="hip", pool="hip", head="hip", stem="hip", fused_layer=False, fused_bn=True,
+               fused_tail=True)
+SINGLE_NODE = dict(ALL_HIP, fused_layer=True)
+
+
+def run(module, x, gy, want_module=False, **sw):
+    """forward + backward of a deep copy of `module` (so BatchNorm buffers of the original stay put) under switches
+    -> (y, gx, {name: grad}) as fp32 tensors (+ the copy and the output's grad_fn name with want_module)"""
+    m = copy.deepcopy(module)
+    with switches(**sw):
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        node = y.grad_fn.name() if y.grad_fn is not None else ""
+        y.backward(gy.to(y.dtype))
+    torch.cuda.synchronize()
+    out = (y.detach().float(), xi.grad.float(), {n: p.grad.float() for n, p in m.named_parameters() if p.grad is not None})
+    return out + (m, node) if want_module else out
+
+
+def truth(module, x, gy):
+    """the same function in fp32 on the bf16-rounded parameters and inputs, plain torch modules"""
+    return run(copy.deepcopy(module).float(), x.float(), gy.float(), **PLAIN)
+
+
+def err(a, b):
+    return ((a - b).abs().mean() / (b.abs().mean() + 1e-20)).item()
+
+
+def check_against_truth(module, x, gy, cand, base=None, slack=1.5, floor=2e-3, skip=()):
+    """cand / base: switch dicts.  Returns the report {tensor: (err_cand, err_base)}; asserts per tensor.  Parameter
+    gradients whose truth magnitude is below 1e-3 of the largest one are pure noise in bf16 (e.g. a bias in front of a
+    BatchNorm: its true gradient is 0) and are only required to stay as small as the baseline's."""
+    base = ROUND1 if base is None else base
+    yt, gxt, gt = truth(module, x, gy)
+    yc, gxc, gc = run(module, x, gy, **cand)
+    yb, gxb, gb = run(module, x, gy, **base)
+    report = {"y": (err(yc, yt), err(yb, yt)), "gx": (err(gxc, gxt), err(gxb, gxt))}
+    top = max(v.abs().mean().item() for v in gt.values())
+    for n, v in gt.items():
+        if n in skip:
+            continue
+        if v.abs().mean().item() < 1e-3 * top:
+            ec, eb = (gc[n] - v).abs().mean().item() / top, (gb[n] - v).abs().mean().item() / top
+        else:
+            ec, eb = err(gc[n], v), err(gb[n], v)
+        report[n] = (ec, eb)
+    # small tensors: err is a mean over few elements, i.e. itself noisy -> wider slack (a defect gives err ~ 1)
+    numel = {"y": yt.numel(), "gx": gxt.numel(), **{n: v.numel() for n, v in gt.items()}}
+    bad = {k: v for k, v in report.items() if not v[0] <= (slack if numel[k] >= 4096 else 2 * slack) * v[1] + floor}
+    assert not bad, f"candidate further from the fp32 truth than {slack} x baseline: {bad}"
+    return report
