@@ -206,6 +206,21 @@ def named_bucket_grads(model, reducer):
     return grads, layout
 
 
+def probe_model(make_model, dev, seed):
+    """the benchmark model for the parity probe: same seed -> same init; the last BatchNorm of every residual branch is
+    moved off its zero initialisation (models/cotnet.py:225-226, resnet.py:581-584) -- with bn3.weight == 0 every gradient
+    inside the branches is exactly zero and a parity check would compare zeros with zeros"""
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    torch.manual_seed(seed)
+    model = make_model().to(dev)
+    with torch.no_grad():
+        for m in model.modules():
+            bn3 = getattr(m, "bn3", None)
+            if isinstance(bn3, torch.nn.BatchNorm2d):
+                bn3.weight.fill_(0.5)
+    return to_mixed_bf16(model)
+
+
 def fp32_truth(make_model, dev, x, t, seed):
     """loss and per-parameter gradients of the SAME model (same seed -> same init, rounded to bf16 exactly as
     to_mixed_bf16 does, then widened) evaluated in fp32 by plain torch modules: what both kernel sets approximate"""
@@ -217,8 +232,7 @@ def fp32_truth(make_model, dev, x, t, seed):
     try:
         for m, a, v in saved:
             setattr(m, a, False if isinstance(v, bool) else "")
-        torch.manual_seed(seed)
-        model = to_mixed_bf16(make_model().to(dev)).float().train()
+        model = probe_model(make_model, dev, seed).float().train()
         loss = torch.nn.functional.cross_entropy(model(x.float()), t)
         loss.backward()
         return float(loss.detach()), {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
@@ -284,8 +298,7 @@ def probe_child(args, dev=None, make_model=None, warm=4, timed=8):
     for name in KERNEL_SETS:
         try:
             apply_kernel_set(name)
-            torch.manual_seed(4321)
-            model = to_mixed_bf16(make_model().to(dev)).train()
+            model = probe_model(make_model, dev, 4321).train()
             opt = FlatSGD(model, lr=1e-3, momentum=0.9, weight_decay=4e-5, nesterov=True)
 
             def fwd_bwd():
@@ -348,8 +361,7 @@ def probe_graph(name, make_model, dev, x, t, timed):
 
     pair = []
     for _ in range(2):
-        torch.manual_seed(4321)
-        m = to_mixed_bf16(make_model().to(dev)).train()
+        m = probe_model(make_model, dev, 4321).train()
         pair.append((m, FlatSGD(m, lr=1e-3, momentum=0.9, weight_decay=4e-5, nesterov=True)))
     (me, oe), (mg, og) = pair
     for _ in range(3):  # the graph's constructor runs three eager warm-up steps: keep the eager twin in step

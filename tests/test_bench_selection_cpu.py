@@ -79,40 +79,75 @@ def test_kernel_sets_apply_the_documented_switches(monkeypatch):
 
 def test_probe_child_body_on_emulated_kernels(monkeypatch, capsys):
     """bench.probe_child itself (what the --kernels auto child process runs on the GPU), driven on CPU tensors through the
-    host-emulated library with a two-block CoTNet: every kernel set must reproduce round1's loss and gradients"""
-    import ctypes
-    import torch
-    import cotnet_amd.aggregation_zeropad as az
-    from cotnet_amd import (_lib, conv1x1 as c1, conv3x3g as c3, cot_layer_fused as clf, flat_sgd, fused_bn,
-                            group_norm9 as g9, radix_tail)
-    from cotnet_amd.cotnet import Bottleneck
-    from cotnet_amd.resnet import ResNet
-    from tests import test_kernels_emulated as tke
-    if tke._EMUL is None:
-        import pytest
-        pytest.skip("host emulation build unavailable")
-    monkeypatch.setattr(_lib, "lib", lambda: tke._EMUL)
-    from cotnet_amd import head_fused as hf, pool3x3 as p3, stem7x7 as s7
-    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, flat_sgd, p3, hf, s7):
-        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
-    for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE"), (p3, "MODE"), (hf, "MODE"), (s7, "MODE")):
-        monkeypatch.setattr(mod, attr, getattr(mod, attr))
-    monkeypatch.setattr(az, "aggregation_zeropad",
-                        lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: tke._EmulAggregation.apply(i, w))
-    for cache in (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS):
-        cache.clear()
-    args = types.SimpleNamespace(batch=4, img=32, model="unused")
-    out = bench.probe_child(args, dev=torch.device("cpu"), warm=1, timed=1,
-                            make_model=lambda: ResNet(Bottleneck, [2, 1, 1, 1], num_classes=1000))
+    host-emulated library with a two-block CoTNet: every kernel set must be as close to the fp32 truth as round1 is"""
+    out = _emulated_probe(monkeypatch)
     assert "PROBE_RESULT " in capsys.readouterr().out
     assert set(out["sets"]) == {"round1", "new", "new+bnfold"}
     for name, rec in out["sets"].items():
         assert "error" not in rec, (name, rec)
         assert rec["parity"] and rec["finite"] and rec["ms_per_step"] > 0, (name, rec)
     assert out["sets"]["new"]["loss_rel_diff"] < 0.02
-    tke._EMUL.cot_set_tuning(12, 0)
-    for cache in (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS):
+
+
+def _emulated_probe(monkeypatch, lib_wrapper=None):
+    """bench.probe_child on CPU tensors through the host-emulated library with a two-block CoTNet"""
+    import torch
+    import cotnet_amd.aggregation_zeropad as az
+    from cotnet_amd import (_lib, conv1x1 as c1, conv3x3g as c3, cot_layer_fused as clf, flat_sgd, fused_bn,
+                            group_norm9 as g9, head_fused as hf, pool3x3 as p3, radix_tail, stem7x7 as s7)
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.resnet import ResNet
+    from tests import test_kernels_emulated as tke
+    if tke._EMUL is None:
+        import pytest
+        pytest.skip("host emulation build unavailable")
+    L = lib_wrapper(tke._EMUL) if lib_wrapper else tke._EMUL
+    monkeypatch.setattr(_lib, "lib", lambda: L)
+    for mod in (clf, c1, c3, fused_bn, radix_tail, g9, flat_sgd, p3, hf, s7):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE"), (p3, "MODE"), (hf, "MODE"), (s7, "MODE")):
+        monkeypatch.setattr(mod, attr, getattr(mod, attr))
+    monkeypatch.setattr(az, "aggregation_zeropad",
+                        lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: tke._EmulAggregation.apply(i, w))
+    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
+    for cache in caches:
         cache.clear()
+    args = types.SimpleNamespace(batch=4, img=32, model="unused")
+    try:
+        return bench.probe_child(args, dev=torch.device("cpu"), warm=1, timed=1,
+                                 make_model=lambda: ResNet(Bottleneck, [2, 1, 1, 1], num_classes=1000))
+    finally:
+        tke._EMUL.cot_set_tuning(12, 0)
+        for cache in caches:
+            cache.clear()
+
+
+def test_probe_rejects_a_kernel_set_with_a_broken_convolution(monkeypatch, capsys):
+    """verdict r1 #2: the probe's parity gate must reject a deliberately broken kernel.  Here the 1x1 data gradient of ONE
+    layer shape (Co == 64: CotLayer.conv1x1 / Bottleneck.conv1 of the first stage) returns 1.5x the right answer -- loss
+    unchanged, every downstream... i.e. upstream-in-backward gradient scaled.  Round 1's gate (loss 2 %, gradients 25 % in
+    the mean over a 25M-element bucket) let exactly this kind of defect through."""
+    class Broken:
+        def __init__(self, real):
+            self._real = real
+
+        def __getattr__(self, name):
+            return getattr(self._real, name)
+
+        def cot_conv1x1_backward_data(self, gy, w, gx1, gx2, c1_, accumulate, ws, N, Ci, Co, HW, dtype, stream):
+            rc = self._real.cot_conv1x1_backward_data(gy, w, gx1, gx2, c1_, accumulate, ws, N, Ci, Co, HW, dtype, stream)
+            if rc == 0 and Co == 64 and Ci == 64:  # a second, accumulating pass at half... no: the same again = 2x
+                rc = self._real.cot_conv1x1_backward_data(gy, w, gx1, gx2, c1_, 3, ws, N, Ci, Co, HW, dtype, stream)
+            return rc
+
+    out = _emulated_probe(monkeypatch, Broken)
+    capsys.readouterr()
+    assert out["sets"]["round1"]["parity"]
+    for name in ("new", "new+bnfold"):
+        rec = out["sets"][name]
+        assert "error" not in rec, rec
+        assert not rec["parity"], (name, rec)
+        assert rec["worst_param_ratio_to_round1"] > bench.GATE_PARAM or rec["worst_bucket_ratio_to_round1"] > bench.GATE_BUCKET
 
 
 def test_graph_variant_is_chosen_only_when_verified(monkeypatch):
