@@ -77,6 +77,8 @@ SYMBOLS = {
     "cot_conv3x3g_backward_data": (_I, [_P] * 3 + [_I] + [_P] * 2 + [_I] * 7 + [_P]),
     "cot_conv3x3g_backward_weight": (_I, [_P] * 5 + [_I] * 7 + [_P]),
     "cot_ema_step": (_I, [_P, _P, ctypes.c_int64, ctypes.c_float, _I, _P]),
+    "cot_conv1x1_lds_covers": (_I, [_I, _I, _I, _I]),
+    "cot_input_normalize": (_I, [_P, _P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_bn_act_workspace": (_I, [_I, _I]),
     "cot_bn_act_forward": (_I, [_P] * 11 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "cot_bn_act_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _P]),

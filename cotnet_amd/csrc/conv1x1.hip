@@ -186,15 +186,20 @@ __global__ void __launch_bounds__(256, 2)
 conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2, int k1,
                    float* __restrict__ part, bf16_t* __restrict__ gw, bf16_t* __restrict__ gb, int N, int M, int J, int HW,
                    int has_bias, int mblocks, int jblocks, int S, int spi, int64_t total_waves, int xcd_remap) {
-    const int64_t wid = wave_work_id(xcd_remap);
-    if (wid >= total_waves) return;
-    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    // one WORKGROUP per (64 x 64 tile, slice): its four waves take a quarter of the slice's steps each and are summed through
+    // LDS before the slice's partial sum is written -- four times fewer partial sums in memory than one wave per slice
+    unsigned wgb = blockIdx.x;
+    if (xcd_remap && (gridDim.x & 7u) == 0) wgb = (wgb & 7u) * (gridDim.x >> 3) + (wgb >> 3);
+    const int64_t wid = wgb;
+    if (wid >= total_waves) return;  // (whole workgroups: `total_waves` counts workgroups here)
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int jb = uniform((int)(wid % jblocks));
     const int64_t u = wid / jblocks;
     const int mb = uniform((int)(u % mblocks)), s = uniform((int)(u / mblocks));
     const int Jp = J + (has_bias ? 1 : 0);
     const int T = N * spi;  // (reduction steps: far below 2^31)
-    const int t0 = (int)((int64_t)T * s / S), t1 = (int)((int64_t)T * (s + 1) / S);
+    const int ts0 = (int)((int64_t)T * s / S), ts1 = (int)((int64_t)T * (s + 1) / S);
+    const int t0 = ts0 + (int)((int64_t)(ts1 - ts0) * wave / 4), t1 = ts0 + (int)((int64_t)(ts1 - ts0) * (wave + 1) / 4);
 
     int mrow[4], jrow[4];
     bool ones[4];
@@ -278,6 +283,45 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
     ring_loop<DW>(t1 - t_split, [&](int d, int step) __attribute__((always_inline)) { load_stage(std::false_type{}, d, step); },
                   multiply_stage);
 
+    // sum the four waves' accumulators: waves 2,3 -> LDS -> waves 0,1; wave 1 -> LDS -> wave 0 (lane-linear images: no conflicts)
+    {
+        extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+        float* red = reinterpret_cast<float*>(cot_smem);  // 2 x 4096 floats
+        if (wave >= 2) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) red[(wave - 2) * 4096 + ((a * 4 + b) * 4 + i) * 64 + lane] = acc[a][b][i];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[a][b][i] += red[wave * 4096 + ((a * 4 + b) * 4 + i) * 64 + lane];
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) red[((a * 4 + b) * 4 + i) * 64 + lane] = acc[a][b][i];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[a][b][i] += red[((a * 4 + b) * 4 + i) * 64 + lane];
+    }
     float* ps = part + (int64_t)s * M * Jp;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -299,14 +343,34 @@ conv1x1_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x1,
         }
 }
 
-// gw[m][j] = bf16(sum_s part[s][m][j]);  gb[m] = bf16(sum_s part[s][m][J])
-__global__ void conv1x1_wgrad_reduce(const float* __restrict__ part, int S, int M, int J, int has_bias,
-                                     bf16_t* __restrict__ gw, bf16_t* __restrict__ gb) {
+// gw[m][j] = bf16(sum_s part[s][m][j]);  gb[m] = bf16(sum_s part[s][m][J]).  A workgroup owns 32 consecutive outputs; its 8
+// thread groups of 32 take the slices s = q, q+8, .. (coalesced 128-byte reads, four loads in flight per thread) and are
+// summed through LDS in a fixed order (deterministic).  (The first version walked all S slices in one thread: 128 us for the
+// 64 x 64 layers, whose S is in the hundreds.)
+__global__ __launch_bounds__(256) void conv1x1_wgrad_reduce(const float* __restrict__ part, int S, int M, int J, int has_bias,
+                                                           bf16_t* __restrict__ gw, bf16_t* __restrict__ gb) {
+    __shared__ float red[8][32];
     const int Jp = J + (has_bias ? 1 : 0);
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, tot = (int64_t)M * Jp;
-    if (e >= tot) return;
+    const int64_t tot = (int64_t)M * Jp;
+    const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < tot) {
+        int sl = q;
+        for (; sl + 24 < S; sl += 32) {
+            s0 += part[(int64_t)sl * tot + e];
+            s1 += part[(int64_t)(sl + 8) * tot + e];
+            s2 += part[(int64_t)(sl + 16) * tot + e];
+            s3 += part[(int64_t)(sl + 24) * tot + e];
+        }
+        for (; sl < S; sl += 8) s0 += part[(int64_t)sl * tot + e];
+    }
+    red[q][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q != 0 || e >= tot) return;
     float sum = 0.f;
-    for (int s = 0; s < S; ++s) sum += part[(int64_t)s * tot + e];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += red[k][el];
     const int m = (int)(e / Jp), jj = (int)(e % Jp);
     if (jj < J) {
         if (gw) gw[(int64_t)m * J + jj] = (bf16_t)sum;
@@ -318,7 +382,7 @@ __global__ void conv1x1_wgrad_reduce(const float* __restrict__ part, int S, int 
 int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_bias, void* gw, void* gb,
                                 hipStream_t stream) {
     const int64_t tot = (int64_t)M * (J + (has_bias ? 1 : 0));
-    COT_LAUNCH(conv1x1_wgrad_reduce, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, stream, part, S, M, J, has_bias,
+    COT_LAUNCH(conv1x1_wgrad_reduce, dim3((unsigned)ceil_div64(tot, 32)), dim3(256), 0, stream, part, S, M, J, has_bias,
                (bf16_t*)gw, (bf16_t*)gb);
     return check_launch("conv1x1_wgrad_reduce");
 }
@@ -373,18 +437,21 @@ int conv1x1_gemm(const void* x1, const void* x2, int k1, const void* A, const vo
 #undef COT_C1_DISPATCH
 }
 
-// number of deterministic partial sums the weight gradient is split into (also sizes the workspace)
+// number of deterministic partial sums (slices, one workgroup each per 64 x 64 tile) the weight gradient is split into;
+// also sizes the workspace
 int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias) {
     const int Jp = J + (has_bias ? 1 : 0);
     const int64_t units = (int64_t)ceil_div(M, 64) * ceil_div(Jp, 64);
     const int64_t T = (int64_t)N * ceil_div(HW, 32);
     if (g_conv1x1_tune[2] < 0) return (int)(-g_conv1x1_tune[2] < T ? -g_conv1x1_tune[2] : T);  // forced split (tests)
-    int64_t S = ceil_div64(g_conv1x1_tune[2] > 0 ? g_conv1x1_tune[2] : 2048, units);
+    // ~4 workgroups per CU ...
+    int64_t S = ceil_div64(g_conv1x1_tune[2] > 0 ? g_conv1x1_tune[2] / 2 : 1024, units);
+    // ... as long as the partial sums (written once, read once) stay below a quarter of the input bytes ...
     const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
-    int64_t cap = in_bytes / 8 / out_bytes;  // partial sums may cost at most 1/8 of the input traffic ...
-    if (cap < 4 && T >= 64) cap = 4;         // ... except that a slice should not be a chain of hundreds of steps
+    const int64_t cap = in_bytes / 4 / out_bytes;
     if (S > cap) S = cap;
-    if (S > T) S = T;
+    if (S > T / 8) S = T / 8;  // ... and every wave of a slice has at least two reduction steps
+    if (S > 1024) S = 1024;
     if (S < 1) S = 1;
     return (int)S;
 }
@@ -394,15 +461,16 @@ int conv1x1_wgrad(const void* gy, const void* x1, const void* x2, int k1, void* 
     const int has_bias = gb ? 1 : 0, Jp = J + has_bias;
     const int S = conv1x1_wgrad_splits(N, M, J, HW, has_bias);
     const int mblocks = ceil_div(M, 64), jblocks = ceil_div(Jp, 64), spi = ceil_div(HW, 32);
-    const int64_t waves = (int64_t)S * mblocks * jblocks;
-    const dim3 grid(wave_grid_blocks(waves)), block(256);
+    const int64_t waves = (int64_t)S * mblocks * jblocks;  // workgroups: one per (tile, slice)
+    const dim3 grid((unsigned)((waves + 7) / 8 * 8)), block(256);
     const int xcd = g_conv1x1_tune[0];
     const bf16_t *GY = (const bf16_t*)gy, *X1 = (const bf16_t*)x1, *X2 = (const bf16_t*)x2;
+    constexpr size_t red_lds = 2 * 4096 * sizeof(float);
     if (HW % 8 == 0)
-        COT_LAUNCH((conv1x1_wgrad_mfma<16>), grid, block, 0, stream, GY, X1, X2, k1, workspace, (bf16_t*)gw, (bf16_t*)gb, N,
+        COT_LAUNCH((conv1x1_wgrad_mfma<16>), grid, block, red_lds, stream, GY, X1, X2, k1, workspace, (bf16_t*)gw, (bf16_t*)gb, N,
                    M, J, HW, has_bias, mblocks, jblocks, S, spi, waves, xcd);
     else
-        COT_LAUNCH((conv1x1_wgrad_mfma<2>), grid, block, 0, stream, GY, X1, X2, k1, workspace, (bf16_t*)gw, (bf16_t*)gb, N,
+        COT_LAUNCH((conv1x1_wgrad_mfma<2>), grid, block, red_lds, stream, GY, X1, X2, k1, workspace, (bf16_t*)gw, (bf16_t*)gb, N,
                    M, J, HW, has_bias, mblocks, jblocks, S, spi, waves, xcd);
     int rc = check_launch("conv1x1_wgrad_mfma");
     if (rc || S == 1) return rc;

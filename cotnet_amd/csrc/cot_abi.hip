@@ -119,6 +119,12 @@ int conv1x1_gemm(const void*, const void*, int, const void*, const void*, void*,
 int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_conv1x1_tune[4];
+// implemented in conv_lds.hip
+extern int g_conv_lds_tune[3];
+bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
+int conv1x1_lds_gemm(const void*, const void*, int, const void*, const void*, void*, void*, int, int, int, int, int, int,
+                     hipStream_t);
+int transpose_bf16(const void* src, void* dst, int R, int C, hipStream_t stream);
 // implemented in stem7x7.hip
 int stem7x7_splits(int N, int H, int W);
 int stem7x7_forward(const void*, const void*, void*, int, int, int, hipStream_t);
@@ -142,6 +148,7 @@ template <typename T>
 int radix_mix_bwd_reduce(const void*, const void*, const void*, const void*, void*, int, int, int, hipStream_t);
 template <typename T>
 int radix_mix_bwd_apply(const void*, const void*, const void*, void*, void*, int, int, int, hipStream_t);
+int input_normalize(const void*, void*, const float*, const float*, int64_t, int, int, int, hipStream_t);  // input_norm.hip
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
 int set_tuning_nchw(int key, int value);
@@ -261,6 +268,10 @@ int cot_set_tuning(int key, int value) {
         g_conv1x1_tune[3] = value;
         return COT_OK;
     }
+    if (key >= 15 && key <= 17) {
+        g_conv_lds_tune[key - 15] = value;
+        return COT_OK;
+    }
     if (key == 13) {
         g_bn_grid_cap = value > 0 ? value : 4096;
         return COT_OK;
@@ -315,6 +326,10 @@ int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weig
     if (rc) return rc;
     if (!x1 || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x1, x2, weight, y}))) return rc;
+    if (conv1x1_lds_covers(Ci, c1, x2 != nullptr, HW)) {
+        rc = conv1x1_lds_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, 0, (hipStream_t)stream);
+        if (rc != -1) return rc;
+    }
     return conv1x1_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, 0, 0, (hipStream_t)stream);
 }
 
@@ -324,6 +339,13 @@ int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, voi
     if (rc) return rc;
     if (!gy || !weight || !gx1 || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx1, gx2, workspace}))) return rc;
+    if (conv1x1_lds_covers(Co, Co, false, HW)) {
+        // the LDS forward kernel on dY with W^T [Ci][Co], written into the workspace by a small transposition launch
+        if ((rc = transpose_bf16(weight, workspace, Co, Ci, (hipStream_t)stream))) return rc;
+        rc = conv1x1_lds_gemm(gy, nullptr, Co, workspace, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3,
+                              (hipStream_t)stream);
+        if (rc != -1) return rc;
+    }
     // the forward kernel on dY with A = weight^T, read in place from the [Co][Ci] weight tensor
     return conv1x1_gemm(gy, nullptr, Co, weight, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3, 1,
                         (hipStream_t)stream);
@@ -591,6 +613,18 @@ int cot_group_norm9_backward(const void* dy, const void* x, const float* mean, c
     rc = gn9_backward(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, N, C, HW, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_group_norm9_backward: %d pixels per plane exceed one workgroup", HW);
     return rc;
+}
+
+int cot_conv1x1_lds_covers(int K, int k1, int two_slabs, int HW) { return conv1x1_lds_covers(K, k1, two_slabs != 0, HW) ? 1 : 0; }
+
+int cot_input_normalize(const void* x_u8, void* y, const float* mean, const float* stdv, int64_t planes, int C, int HW,
+                        int dtype, void* stream) {
+    if (!x_u8 || !y || !mean || !stdv) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (planes <= 0 || C <= 0 || HW <= 0 || planes % C != 0)
+        return set_error(COT_ERR_INVALID_ARG, "bad planes=%lld / C=%d / HW=%d", (long long)planes, C, HW);
+    int rc = check_align16({x_u8, y});
+    if (rc) return rc;
+    return input_normalize(x_u8, y, mean, stdv, planes, C, HW, dtype, (hipStream_t)stream);
 }
 
 int cot_bn_act_workspace(int N, int C) { return (N > 0 && C > 0) ? bn_workspace_floats(N, C) : 0; }

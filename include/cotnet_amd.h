@@ -253,6 +253,19 @@ int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad
  * master copy / fp32 parameters (COT_F32) or bf16 parameters (COT_BF16). */
 int cot_ema_step(void* ema, const void* src, int64_t n, float decay, int src_dtype, void* stream);
 
+/* 1 when cot_conv1x1_forward / _backward_data run the LDS-tiled second-generation kernel (csrc/conv_lds.hip) for this
+ * reduction length K (first slab k1, two_slabs 0/1) and plane size HW, 0 when they take the first-generation kernel. */
+int cot_conv1x1_lds_covers(int K, int k1, int two_slabs, int HW);
+
+/* ---- on-device input pipeline (replaces the three elementwise kernels of the reference's
+ * PrefetchLoader, datasets/loader.py:85-90: `next_input.float().sub_(mean).div_(std)` / the `.half()` form):
+ *     y[n,c,h,w] = (x[n,c,h,w] - mean[c]) / std[c],   x uint8 NCHW, mean/std fp32 device arrays of C entries
+ *     (the caller passes 255*mean and 255*std as the reference does, loader.py:66-67)
+ * `planes` = N*C images of HW pixels.  dtype of y: COT_F32 (bit-identical to torch: IEEE subtract then divide),
+ * COT_F16 (the reference's fp16=True: each step rounded to half), COT_BF16 (fp32 arithmetic, one rounding). */
+int cot_input_normalize(const void* x_u8, void* y, const float* mean, const float* std, int64_t planes, int C, int HW,
+                        int dtype, void* stream);
+
 /* ---- training-mode BatchNorm2d fused with activation and residual add, NCHW.
  * Replaces nn.BatchNorm2d + in-place ReLU/SiLU (+ `x += residual`) sequences of the reference's blocks
  * (models/cotnet.py:231-235, :248-262, :89-90):

@@ -245,6 +245,13 @@ namespace cot { alignas(16) inline thread_local char cot_smem[160 * 1024]; }  //
 #define COT_ASYNC_COPY16(gptr, lds_wave_base) \
     std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)
 
+// the hand-counted LDS-DMA pipeline primitives of conv_lds.hip: the copy lands at once, the waits are no-ops, the barrier
+// is the block barrier (so the emulation checks index arithmetic and barrier placement, not the vmcnt arithmetic)
+#define COT_GLDS16(gptr, lds_wave_base) \
+    std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)
+#define COT_WAIT_VM(N) ((void)0)
+#define COT_LDS_BARRIER() emul::block_barrier()
+
 #define COT_MFMA_16X16X32_BF16(a, b, c) emul::mfma_16x16x32_bf16((a), (b), (c))
 #define COT_KEEP_PACKED(u) ((void)(u))
 #define COT_WAIT_LOADS() ((void)0)

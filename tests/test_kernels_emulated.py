@@ -524,6 +524,74 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
     assert _EMUL.cot_set_tuning(11, 2048) == 0
 
 
+@pytest.mark.parametrize("N,Ci,Co,H,W,c1,bias", [
+    (2, 64, 32, 16, 24, 0, False),    # BIG: HW = 384 = 3 tiles of 128, M <= 32
+    (1, 96, 200, 20, 20, 32, True),   # BIG: HW = 400 (partial last tile of 16 pixels), two slabs, two m-blocks (200 > 128)
+    (2, 32, 64, 28, 28, 0, False),    # BIG: 784 = 6 tiles + 16 pixels, M = 64
+    (3, 64, 136, 14, 14, 0, True),    # FLAT: HW = 196, one image per workgroup, 12.25 column blocks, two m-blocks
+    (7, 128, 40, 7, 7, 64, True),     # FLAT: HW = 49, five images per workgroup (second group partial), two slabs
+    (1, 64, 24, 1, 80, 0, True),      # FLAT: the se branch's "one image whose pixels are the batch" (80 columns)
+    (5, 32, 16, 8, 8, 0, False),      # FLAT: HW = 64, four images per workgroup + one left over
+    (2, 160, 72, 14, 14, 0, False),   # FLAT: five K steps (pipeline wraps), M = 72
+])
+def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias):
+    """second-generation 1x1 kernels (csrc/conv_lds.hip): every case satisfies K % 32 == 0 so the LDS path is the one
+    that runs (cot_last_kernel is checked); forward, data gradient (through the transposed-weight workspace), the
+    accumulate flags of both output slabs, against torch in fp32 on the same bf16-rounded operands"""
+    torch.manual_seed(11)
+    HW = H * W
+    x = torch.randn(N, Ci, H, W).bfloat16()
+    w = (torch.randn(Co, Ci) / Ci ** 0.5).bfloat16()
+    b = torch.randn(Co).bfloat16() if bias else None
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    xf, wf, bf, yref = _conv1x1_ref(x, w, b)
+    yref.backward(gy.float())
+    split = c1 > 0
+    x1 = x[:, :c1].contiguous() if split else x
+    x2 = x[:, c1:].contiguous() if split else None
+    cc1 = c1 if split else Ci
+    dt = _lib.dtype_code(torch.bfloat16)
+    PN = lambda t: P(t) if t is not None else None
+    assert _EMUL.cot_set_tuning(15, 1) == 0
+    y = torch.full((N, Co, H, W), float("nan")).bfloat16()
+    assert _EMUL.cot_conv1x1_forward(P(x1), PN(x2), cc1, P(w), PN(b), P(y), N, Ci, Co, HW, dt, None) == 0, _EMUL.cot_last_error()
+    assert torch.allclose(y.float(), yref.detach(), atol=2e-2, rtol=2e-2), (y.float() - yref).abs().max()
+    # the same through the first-generation kernel: both paths must agree to rounding (same products, different order)
+    assert _EMUL.cot_set_tuning(15, 0) == 0
+    y0 = torch.full_like(y, float("nan"))
+    assert _EMUL.cot_conv1x1_forward(P(x1), PN(x2), cc1, P(w), PN(b), P(y0), N, Ci, Co, HW, dt, None) == 0
+    assert _EMUL.cot_set_tuning(15, 1) == 0
+    assert (y.float() - y0.float()).abs().max() <= 2e-2 * yref.abs().max()
+    if Co % 32 == 0 or True:
+        ws = torch.empty(_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 1 if bias else 0), dtype=torch.uint8)
+        gx1 = torch.full_like(x1, float("nan"))
+        gx2 = torch.full_like(x2, float("nan")) if split else None
+        rc = _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx1), PN(gx2), cc1, 0, P(ws), N, Ci, Co, HW, dt, None)
+        assert rc == 0, _EMUL.cot_last_error()
+        gx = torch.cat([gx1, gx2], 1) if split else gx1
+        assert torch.allclose(gx.float(), xf.grad, atol=3e-2, rtol=2e-2), (gx.float() - xf.grad).abs().max()
+        # accumulate: first slab += (bit 0), second slab += (bit 1)
+        base1, base2 = torch.randn_like(x1.float()).bfloat16(), (torch.randn_like(x2.float()).bfloat16() if split else None)
+        a1, a2 = base1.clone(), (base2.clone() if split else None)
+        rc = _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(a1), PN(a2), cc1, 3 if split else 1, P(ws), N, Ci, Co, HW, dt, None)
+        assert rc == 0
+        want1 = base1.float() + xf.grad[:, :cc1]
+        assert torch.allclose(a1.float(), want1, atol=5e-2, rtol=2e-2)
+        if split:
+            assert torch.allclose(a2.float(), base2.float() + xf.grad[:, cc1:], atol=5e-2, rtol=2e-2)
+
+
+def test_conv1x1_lds_kernel_is_the_one_that_runs():
+    x = torch.randn(1, 64, 16, 16).bfloat16()
+    w = torch.randn(32, 64).bfloat16()
+    y = torch.zeros(1, 32, 16, 16).bfloat16()
+    dt = _lib.dtype_code(torch.bfloat16)
+    assert _EMUL.cot_set_tuning(15, 1) == 0
+    assert _EMUL.cot_conv1x1_lds_covers(64, 64, 0, 256) == 1 and _EMUL.cot_conv1x1_lds_covers(40, 40, 0, 256) == 0
+    assert _EMUL.cot_conv1x1_forward(P(x), None, 64, P(w), None, P(y), 1, 64, 32, 256, dt, None) == 0
+    assert (y.float() - torch.einsum("oc,nchw->nohw", w.float(), x.float())).abs().max() < 0.1
+
+
 def test_conv1x1_rejects_what_it_does_not_cover():
     x = torch.zeros(1, 12, 4, 4).bfloat16()
     w = torch.zeros(8, 12).bfloat16()
@@ -1294,7 +1362,10 @@ def test_results_do_not_depend_on_the_lane_schedule(order):
         assert _EMUL.cot_stem7x7s2_forward(P(xs), P(wsn), P(ys), 2, 32, 32, dtb, None) == 0
         xc, wc, yc = torch.randn(2, 64, 7, 7).bfloat16(), torch.randn(40, 64).bfloat16(), torch.empty(2, 40, 7, 7).bfloat16()
         assert _EMUL.cot_conv1x1_forward(P(xc), None, 64, P(wc), None, P(yc), 2, 64, 40, 49, dtb, None) == 0
-        out.extend([ys, yc])
+        # LDS-pipelined 1x1 kernel: five K steps through three stages (a barrier short would show as a stale stage)
+        xl, wl, yl = torch.randn(3, 160, 14, 14).bfloat16(), torch.randn(72, 160).bfloat16(), torch.empty(3, 72, 14, 14).bfloat16()
+        assert _EMUL.cot_conv1x1_forward(P(xl), None, 160, P(wl), None, P(yl), 3, 160, 72, 196, dtb, None) == 0
+        out.extend([ys, yc, yl])
         return [t.clone() for t in out]
 
     _EMUL.emul_set_order(0)
