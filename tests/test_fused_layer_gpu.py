@@ -1,6 +1,8 @@
 """CotLayer / Bottleneck as ONE autograd node (cotnet_amd/cot_layer_fused.py, opt-in COT_FUSED_LAYER=1) on the GPU.
 Each composed result is compared with an fp32 evaluation of the same module (tests/truth.py): the single-node path must
 not sit further from that truth than the round-1 path (MIOpen convolutions, one node per op) does."""
+import copy
+
 import pytest
 import torch
 
@@ -32,8 +34,12 @@ def test_single_node_layer_against_fp32_truth(N, C, H):
     _, _, gr, mr, node_r = truth.run(layer, x, g, want_module=True, **truth.ROUND1)
     assert not node_r.startswith("_CotLayerNode")
     assert set(gf) == set(gr) == {n for n, _ in layer.named_parameters()}
-    for (n_, a), (_, b) in zip(mf.named_buffers(), mr.named_buffers()):
-        assert torch.allclose(a.float(), b.float(), atol=2e-3, rtol=2e-3), n_
+    # running statistics: against the fp32 truth's buffers (bf16 activations move a batch variance by ~0.5 %, i.e. the
+    # running variance by ~5e-4 after one momentum-0.1 update: both paths must stay in that class)
+    *_, mt, _ = truth.run(copy.deepcopy(layer).float(), x.float(), g.float(), want_module=True, **truth.PLAIN)
+    for (n_, a), (_, b), (_, tb) in zip(mf.named_buffers(), mr.named_buffers(), mt.named_buffers()):
+        ea, eb = (a.float() - tb.float()).abs().max().item(), (b.float() - tb.float()).abs().max().item()
+        assert ea <= 2.0 * eb + 2e-3 * (1 + tb.float().abs().max().item()), (n_, ea, eb)
 
 
 def test_ineligible_inputs_take_the_ordinary_forward(monkeypatch):

@@ -581,6 +581,29 @@ def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias):
             assert torch.allclose(a2.float(), base2.float() + xf.grad[:, cc1:], atol=5e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (3, 3, 7, 9), (1, 4, 32, 32)])
+def test_input_normalize_matches_the_reference_loader_arithmetic(shape):
+    """csrc/input_norm.hip against datasets/loader.py:85-90 on CPU torch: fp32 bit-identical, fp16 = the half path,
+    bf16 = one rounding of the fp32 result"""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+    C = shape[1]
+    mean = torch.tensor([123.675, 116.28, 103.53, 99.0][:C])
+    std = torch.tensor([58.395, 57.12, 57.375, 50.0][:C])
+    planes, HW = shape[0] * C, shape[2] * shape[3]
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        m, sd = (mean.half().float(), std.half().float()) if dtype == torch.float16 else (mean, std)
+        y = torch.empty(shape, dtype=dtype)
+        rc = _EMUL.cot_input_normalize(P(x), P(y), P(m), P(sd), planes, C, HW, _lib.dtype_code(dtype), None)
+        assert rc == 0, _EMUL.cot_last_error()
+        if dtype == torch.float16:
+            ref = x.half().sub_(m.half().view(1, C, 1, 1)).div_(sd.half().view(1, C, 1, 1))
+        else:
+            ref = x.float().sub_(m.view(1, C, 1, 1)).div_(sd.view(1, C, 1, 1)).to(dtype)
+        assert torch.equal(y, ref), dtype
+    assert _EMUL.cot_input_normalize(P(x), P(y), P(mean), P(std), planes, C, HW, 1, None) != 0  # fp64 output: unsupported
+
+
 def test_conv1x1_lds_kernel_is_the_one_that_runs():
     x = torch.randn(1, 64, 16, 16).bfloat16()
     w = torch.randn(32, 64).bfloat16()

@@ -25,7 +25,8 @@ def rccl_world_of_one():
     dist.init_process_group("nccl", init_method=f"file://{f.name}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield
     dist.destroy_process_group()
-    os.unlink(f.name)
+    if os.path.exists(f.name):  # (the file store removes its file itself)
+        os.unlink(f.name)
 
 
 def _net():
