@@ -69,12 +69,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 #define COT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
-template <int G> __device__ __forceinline__ void wait_stages_behind(int ahead) {
-    // `ahead` stages (G copies each, per wave) were issued after the one about to be read
-    if (ahead >= 2) COT_WAIT_VM(2 * G);
-    else if (ahead == 1) COT_WAIT_VM(G);
-    else COT_WAIT_VM(0);
-}
+// `ahead` stages (G copies each, per wave) were issued after the one about to be read: leave exactly those in flight
+template <int G, int A> struct WaitBehind {
+    static __device__ __forceinline__ void go(int ahead) {
+        if (ahead >= A) COT_WAIT_VM(A * G);
+        else WaitBehind<G, A - 1>::go(ahead);
+    }
+};
+template <int G> struct WaitBehind<G, 0> {
+    static __device__ __forceinline__ void go(int) { COT_WAIT_VM(0); }
+};
 
 struct C1LdsArgs {
     const bf16_t* x1;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
     constexpr int WPASS = (BM * 4 + 255) / 256;        // W copies per thread and stage
     constexpr int XST = XP * 2048, WST = WPASS * 2048;  // stage sizes in elements (padded to whole passes)
     constexpr int G = XP + WPASS;
-    static_assert(XP >= 1 && 2 * G <= 63, "vmcnt range");
+    static_assert(XP >= 1 && (NS - 2) * G <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     const int HW = a.HW, K = a.K, M = a.M;
     bf16_t* const wsm = reinterpret_cast<bf16_t*>(cot_smem);  // [NS][WST] then [NS][XST]
@@ -130,43 +134,49 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
 
     // ---- staging: every wave issues exactly G copies per stage (lanes past a stage's data copy in-bounds bytes into the
     // stage's padding), so one vmcnt arithmetic holds for all waves
+    // Source addresses are resolved once: a K step moves every X copy BK rows down its slab (BK*HW elements) and every W
+    // copy BK elements along its row; the step's slab (first / second input tensor) is a scalar choice.
     const int cpi = BK * HW / 8, xtotal = FLAT ? a.ni * cpi : BK * BPX / 8;
+    int xn[XP], xin[XP];  // this thread's copies: image, element offset inside the image's block of 32 rows
+#pragma unroll
+    for (int ps = 0; ps < XP; ++ps) {
+        const int q = min(ps * 256 + tid, xtotal - 1);
+        int n, inner;  // image, element offset inside the image's 32-row block
+        if (FLAT) {
+            const int img = q / cpi, c = q - img * cpi;
+            n = min(n0 + img, a.N - 1);  // images past the batch: in-bounds bytes, never stored
+            inner = c * 8;
+        } else {
+            constexpr int cpr = BPX / 8;  // chunks per row
+            const int row = q / cpr, c = q - row * cpr;
+            int pc = p0 + c * 8;
+            if (pc + 8 > HW) pc = 0;  // partial last tile: columns never stored; any in-bounds bytes will do
+            n = n0;
+            inner = row * HW + pc;
+        }
+        xn[ps] = n;
+        xin[ps] = inner;
+    }
+    const bf16_t* wsrc[WPASS];
+#pragma unroll
+    for (int ps = 0; ps < WPASS; ++ps) {
+        const int q = min(ps * 256 + tid, BM * 4 - 1);
+        const int row = q >> 2, pos = q & 3;
+        const int c = pos ^ ((row >> 2) & 3);  // XOR swizzle: position `pos` of a row holds its k-chunk c
+        const int m = min(m0 + row, M - 1);    // rows past M: a copy of row M-1, never stored
+        wsrc[ps] = a.w + (int64_t)m * K + c * 8;
+    }
     auto stage = [&](int ks) __attribute__((always_inline)) {
         const int k0 = ks * BK, buf = ks % NS;
         bf16_t* xd = xsm + buf * XST;
-        const bf16_t* xsrc;  // the K step's rows come from one slab (k1 % 32 == 0 is checked on the host)
-        int krow, kc;
-        if (k0 < a.k1) {
-            xsrc = a.x1; krow = k0; kc = a.k1;
-        } else {
-            xsrc = a.x2; krow = k0 - a.k1; kc = K - a.k1;
-        }
+        const bool first = k0 < a.k1;  // the K step's rows come from one slab (k1 % 32 == 0 is checked on the host)
+        const bf16_t* xbase = first ? a.x1 + (int64_t)k0 * HW : a.x2 + (int64_t)(k0 - a.k1) * HW;
+        const int64_t istride = (int64_t)(first ? a.k1 : K - a.k1) * HW;  // elements per image of that slab
 #pragma unroll
-        for (int ps = 0; ps < XP; ++ps) {
-            const int q = min(ps * 256 + tid, xtotal - 1);
-            const bf16_t* src;
-            if (FLAT) {
-                const int img = q / cpi, c = q - img * cpi;
-                const int n = min(n0 + img, a.N - 1);  // images past the batch: in-bounds bytes, never stored
-                src = xsrc + ((int64_t)n * kc + krow) * HW + (int64_t)c * 8;
-            } else {
-                constexpr int cpr = BPX / 8;  // chunks per row
-                const int row = q / cpr, c = q - row * cpr;
-                int pc = p0 + c * 8;
-                if (pc + 8 > HW) pc = 0;  // partial last tile: columns never stored; any in-bounds bytes will do
-                src = xsrc + ((int64_t)n0 * kc + krow + row) * HW + pc;
-            }
-            COT_GLDS16(src, xd + (ps * 256 + wave * 64) * 8);
-        }
+        for (int ps = 0; ps < XP; ++ps) COT_GLDS16(xbase + xn[ps] * istride + xin[ps], xd + (ps * 256 + wave * 64) * 8);
         bf16_t* wd = wsm + buf * WST;
 #pragma unroll
-        for (int ps = 0; ps < WPASS; ++ps) {
-            const int q = min(ps * 256 + tid, BM * 4 - 1);
-            const int row = q >> 2, pos = q & 3;
-            const int c = pos ^ ((row >> 2) & 3);  // XOR swizzle: position `pos` of a row holds its k-chunk c
-            const int m = min(m0 + row, M - 1);    // rows past M: a copy of row M-1, never stored
-            COT_GLDS16(a.w + (int64_t)m * K + k0 + c * 8, wd + (ps * 256 + wave * 64) * 8);
-        }
+        for (int ps = 0; ps < WPASS; ++ps) COT_GLDS16(wsrc[ps] + k0, wd + (ps * 256 + wave * 64) * 8);
     };
 
     // ---- per-lane LDS offsets of the A (= X^T) gathers: column -> element offset of (k = 0, column) inside a stage
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
     for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nk) stage(s0);
     for (int ks = 0; ks < nk; ++ks) {
-        wait_stages_behind<G>(min(NS - 2, nk - 1 - ks));  // this wave's copies of stage ks have landed
+        WaitBehind<G, NS - 2>::go(min(NS - 2, nk - 1 - ks));  // this wave's copies of stage ks have landed
         COT_LDS_BARRIER();                                // everybody's have; nobody still reads stage ks-1's buffer
         if (ks + NS - 1 < nk) stage(ks + NS - 1);
         const uint16_t* xb = reinterpret_cast<const uint16_t*>(xsm + (ks % NS) * XST);
@@ -228,49 +238,86 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
         }
     }
 
-    // ---- epilogue: lane holds pixels (columns) 4g .. 4g+3 of channel i16 of every (cb, mbk) block
+    // ---- epilogue through LDS.  In the C/D map a lane holds 4 consecutive pixels of ONE channel and the 16 lanes of a group
+    // 16 different channels: stored directly that is 32 contiguous bytes per channel row and instruction.  Instead the tile
+    // goes to LDS in its memory order (rounded to bf16, bias added) and is copied out in full 16-byte pieces, 256
+    // contiguous bytes per 16 lanes: BIG = BM rows of BPX pixels; FLAT = per image one contiguous [channels][H*W] block
+    // (whatever H*W is -- the channel block of an image IS one flat range of y).
+    COT_LDS_BARRIER();  // every wave is done with the last stage: the stage memory is free
+    bf16_t* const ot = reinterpret_cast<bf16_t*>(cot_smem);
+    constexpr int OS = BPX + 8;                      // BIG: padded row stride of the tile image (bank spread)
+    const int mv = min(BM, M - m0);                 // valid channels of this block (a multiple of 8 unless it is the last)
+    const int nimg = FLAT ? min(a.ni, a.N - n0) : 1;
+    const int per = mv * HW, pers = (per + 7) & ~7;  // FLAT: elements of one image's channel block, its (16-byte) LDS stride
 #pragma unroll
     for (int mbk = 0; mbk < MB; ++mbk) {
-        const int m = m0 + mbk * 16 + i16;
-        if (m >= M) continue;
-        const float bs = a.bias ? (float)a.bias[m] : 0.f;
-        const bool second = m >= a.m1;
-        bf16_t* ybase = second ? a.y2 : a.y1;
-        const int mc = second ? M - a.m1 : a.m1, mr = second ? m - a.m1 : m;
-        const bool accu = (a.accumulate >> (second ? 1 : 0)) & 1;
+        const int ml = mbk * 16 + i16;
+        const float bs = (a.bias && m0 + ml < M) ? (float)a.bias[m0 + ml] : 0.f;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             const int col = (wave * CB + cb) * 16 + 4 * g;
-            if (col >= ncols) continue;
-            float v[4];
+            bf16_t o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[cb][mbk][r] + bs;
-            if (FLAT && HW % 4 != 0) {  // 4 consecutive columns may straddle two images / are not 8-byte aligned
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[cb][mbk][r] + bs);
+            if (!FLAT) {
+                __builtin_memcpy(__builtin_assume_aligned(ot + ml * OS + col, 8), o, 8);
+            } else if (HW % 4 == 0) {
+                if (col < ncols && ml < mv) {  // 4 consecutive columns stay inside one image
+                    const int img = col / HW, p = col - img * HW;
+                    __builtin_memcpy(__builtin_assume_aligned(ot + img * pers + ml * HW + p, 8), o, 8);
+                }
+            } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = col + r;
-                    if (c < ncols) {
+                    if (c < ncols && ml < mv) {
                         const int img = c / HW, p = c - img * HW;
-                        bf16_t* dst = ybase + ((int64_t)(n0 + img) * mc + mr) * HW + p;
-                        *dst = (bf16_t)(accu ? v[r] + (float)*dst : v[r]);
+                        ot[img * pers + ml * HW + p] = o[r];
                     }
                 }
-            } else {  // the 4 pixels are valid together, inside one image, 8-byte aligned
-                int img = 0, p = p0 + col;
-                if (FLAT) {
-                    img = col / HW;
-                    p = col - img * HW;
-                }
-                bf16_t* dst = ybase + ((int64_t)(n0 + img) * mc + mr) * HW + p;
-                Vec<bf16_t, 4> o;
+            }
+        }
+    }
+    COT_LDS_BARRIER();
+    // copy out: 16 bytes per lane.  Output slabs (y1 | y2 at channel m1): a block lies in one slab or, when it straddles m1,
+    // rows are routed one by one (m1 % 8 == 0 is checked on the host, so flat 16-byte pieces never straddle the slabs).
+    if (!FLAT) {
+        constexpr int cpr = BPX / 8;
+        for (int q = tid; q < mv * cpr; q += 256) {
+            const int row = q / cpr, c = q - row * cpr;
+            if (c * 8 >= ncols) continue;
+            const int m = m0 + row;
+            const bool second = m >= a.m1;
+            bf16_t* dst = (second ? a.y2 + ((int64_t)n0 * (M - a.m1) + (m - a.m1)) * HW : a.y1 + ((int64_t)n0 * a.m1 + m) * HW) + p0 + c * 8;
+            Vec<bf16_t, 8> v = *reinterpret_cast<const Vec<bf16_t, 8>*>(ot + row * OS + c * 8);
+            if ((a.accumulate >> (second ? 1 : 0)) & 1) {
+                const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(dst);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
+            }
+            stv<bf16_t, 8>(dst, v);
+        }
+    } else {
+        const int cpi_o = pers / 8;  // (one image's channel block is contiguous in y -- inside one slab -- and in LDS)
+        for (int q = tid; q < nimg * cpi_o; q += 256) {
+            const int img = q / cpi_o, c = q - img * cpi_o;
+            const int e0 = c * 8;                 // first element of the piece inside the block
+            const int m = m0 + e0 / HW;           // its channel decides the slab (pieces do not straddle m1)
+            const bool second = m >= a.m1;
+            bf16_t* blk = second ? a.y2 + ((int64_t)(n0 + img) * (M - a.m1) + (m0 - a.m1)) * HW
+                                 : a.y1 + ((int64_t)(n0 + img) * a.m1 + m0) * HW;
+            const bool accu = (a.accumulate >> (second ? 1 : 0)) & 1;
+            const bf16_t* src = ot + img * pers + e0;
+            if (e0 + 8 <= per) {
+                Vec<bf16_t, 8> v = *reinterpret_cast<const Vec<bf16_t, 8>*>(src);
                 if (accu) {
-                    const Vec<bf16_t, 4> pv = ldv<bf16_t, 4>(dst);
+                    const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(blk + e0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)pv.v[r];
+                    for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o.v[r] = (bf16_t)v[r];
-                stv<bf16_t, 4>(dst, o);
+                stv<bf16_t, 8>(blk + e0, v);
+            } else {  // the block's last, partial piece (mv * HW % 8 != 0: only when mv is not a multiple of 8)
+                for (int e = e0; e < per; ++e) blk[e] = (bf16_t)(accu ? (float)src[e - e0] + (float)blk[e] : (float)src[e - e0]);
             }
         }
     }
@@ -280,14 +327,25 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
 // [1] images per workgroup in FLAT mode (0 = auto), [2] reserved
 int g_conv_lds_tune[3] = {1, 0, 0};
 
-template <int CB, int MB, int FLAT>
+template <int CB, int MB, int FLAT, int NS>
 static int launch_c1(const C1LdsArgs& a, int tiles, hipStream_t stream) {
-    constexpr int NS = 3;
-    constexpr int XST = 32 * 64 * CB, WST = ((16 * MB * 4 + 255) / 256) * 2048;
-    const size_t lds = (size_t)NS * (XST + WST) * sizeof(bf16_t);
+    constexpr int BPX = 64 * CB, BM = 16 * MB;
+    constexpr int XST = 32 * BPX, WST = ((BM * 4 + 255) / 256) * 2048;
+    size_t lds = (size_t)NS * (XST + WST) * sizeof(bf16_t);
+    const size_t otile = (FLAT ? (size_t)a.ni * (((size_t)BM * a.HW + 7) & ~(size_t)7) : (size_t)BM * (BPX + 8)) * sizeof(bf16_t);
+    if (otile > lds) lds = otile;
     const int64_t blocks = (int64_t)tiles * a.mblocks;
     C1LdsArgs b = a;
     b.xcd_remap = (blocks % 8 == 0) ? 1 : 0;
+    if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation (160 KB per CU on gfx950)
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_lds_fwd<CB, MB, FLAT, NS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipGetLastError();
+            raised = true;
+        }
+    }
     COT_LAUNCH((conv1x1_lds_fwd<CB, MB, FLAT, NS>), dim3((unsigned)blocks), dim3(256), lds, stream, b);
     return check_launch("conv1x1_lds_fwd");
 }
@@ -302,29 +360,32 @@ bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW) {
 int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, const void* bias, void* y1, void* y2, int m1,
                      int N, int K, int M, int HW, int accumulate, hipStream_t stream) {
     if (!conv1x1_lds_covers(K, k1, x2 != nullptr, HW)) return -1;
+    if (y2 && m1 % 8 != 0) return -1;  // (16-byte pieces of the output must not straddle the two output slabs)
+    if (HW % 8 != 0 && ((y2 ? m1 : M) % 8 != 0 || (y2 && (M - m1) % 8 != 0))) return -1;  // image blocks of y 16-byte aligned
     C1LdsArgs a;
     a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.w = (const bf16_t*)w; a.bias = (const bf16_t*)bias;
     a.y1 = (bf16_t*)y1; a.y2 = (bf16_t*)y2;
     a.k1 = x2 ? k1 : K; a.m1 = y2 ? m1 : M; a.N = N; a.K = K; a.M = M; a.HW = HW; a.accumulate = accumulate;
     a.ni = 1; a.xcd_remap = 0;
-    if (HW > 256) {  // BIG: 128-pixel tiles of one image
+    if (HW > 256) {  // BIG: 128-pixel tiles of one image; three stages, several workgroups per CU
         a.ptiles = ceil_div(HW, 128);
         const int tiles = N * a.ptiles;
-        if (M <= 32) { a.mblocks = 1; return launch_c1<2, 2, 0>(a, tiles, stream); }
-        if (M <= 64) { a.mblocks = 1; return launch_c1<2, 4, 0>(a, tiles, stream); }
+        if (M <= 32) { a.mblocks = 1; return launch_c1<2, 2, 0, 3>(a, tiles, stream); }
+        if (M <= 64) { a.mblocks = 1; return launch_c1<2, 4, 0, 3>(a, tiles, stream); }
         a.mblocks = ceil_div(M, 128);
-        return launch_c1<2, 8, 0>(a, tiles, stream);
+        return launch_c1<2, 8, 0, 3>(a, tiles, stream);
     }
-    // FLAT: whole images, up to 256 columns per workgroup (4 waves x 4 column blocks), up to 128 channels
+    // FLAT: whole images, up to 256 columns per workgroup (4 waves x 4 column blocks), up to 128 channels.  These are the
+    // deep-K layers with few workgroups (one per CU at best): six stages, five of them in flight per workgroup
     int ni = g_conv_lds_tune[1] > 0 ? g_conv_lds_tune[1] : 256 / HW;
     if (ni > N) ni = N;
     if (ni < 1 || ni * HW > 256) return -1;
     a.ni = ni;
     a.ptiles = ceil_div(N, ni);
-    if (M <= 32) { a.mblocks = 1; return launch_c1<4, 2, 1>(a, a.ptiles, stream); }
-    if (M <= 64) { a.mblocks = 1; return launch_c1<4, 4, 1>(a, a.ptiles, stream); }
+    if (M <= 32) { a.mblocks = 1; return launch_c1<4, 2, 1, 6>(a, a.ptiles, stream); }
+    if (M <= 64) { a.mblocks = 1; return launch_c1<4, 4, 1, 6>(a, a.ptiles, stream); }
     a.mblocks = ceil_div(M, 128);
-    return launch_c1<4, 8, 1>(a, a.ptiles, stream);
+    return launch_c1<4, 8, 1, 6>(a, a.ptiles, stream);
 }
 
 }  // namespace cot

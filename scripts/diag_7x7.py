@@ -83,3 +83,32 @@ for n, act in names.items():
         e = [float((a - r).abs().max()) for a, r in zip(res[tag], res["fp64"])]
         s = [float(r.abs().max()) for r in res["fp64"]]
         print(f"{n:12s} M={xi.shape[0] * xi.shape[2] * xi.shape[3]} {tag:8s} max|err| y {e[0]:.2e} dx {e[1]:.2e} dgamma {e[2]:.2e}   (scales {s[0]:.1e} {s[1]:.1e} {s[2]:.1e})")
+
+# ---- (3) every LEAF module of the layer in isolation: fp32 on the GPU and fp32 on the CPU against fp64, same inputs
+print("\nleaf modules, fp32 vs fp64 on the fp64 run's activations (max|err| of output / input gradient, GPU then CPU):")
+fused_bn.ENABLED, radix_tail.ENABLED = False, False
+layer = cotnet.CotLayer(meta["dim"], 3).double().to(DEV).train()
+layer.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, strict=True)
+cap = {}
+leaves = [(n, m) for n, m in layer.named_modules() if not list(m.children()) and list(m.parameters())]
+for n, m in leaves:
+    m.register_forward_hook(hook(n))
+xin = x.double().to(DEV).requires_grad_(True)
+layer(xin).backward(gout.double().to(DEV))
+import copy  # noqa: E402
+for n, m in leaves:
+    if n not in cap or cap[n][1] is None:
+        continue
+    xi, gy = cap[n]
+    res = {}
+    for tag, dt, dv in (("fp64", torch.float64, DEV), ("gpu32", torch.float32, DEV), ("cpu32", torch.float32, "cpu")):
+        mm = copy.deepcopy(m).to(dt).to(dv).train()
+        xa = xi.to(dt).to(dv).clone().requires_grad_(True)
+        yo = mm(xa)
+        yo.backward(gy.to(dt).to(dv))
+        res[tag] = (yo.detach().double().cpu(), xa.grad.double().cpu())
+    line = f"{n:14s} {type(m).__name__:12s} in {tuple(xi.shape)}"
+    for tag in ("gpu32", "cpu32"):
+        e = [float((a - r).abs().max()) for a, r in zip(res[tag], res["fp64"])]
+        line += f" | {tag} y {e[0]:.1e} dx {e[1]:.1e}"
+    print(line + f"  (scales {float(res['fp64'][0].abs().max()):.1e} {float(res['fp64'][1].abs().max()):.1e})")

@@ -285,3 +285,5 @@ inline hipError_t hipFree(void* p) { ::operator delete(p); return 0; }
 #define hipMemcpyDeviceToHost 2
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
