@@ -95,18 +95,22 @@ struct C1LdsArgs {
     int xcd_remap;
 };
 
-// One wave = CB x 16 columns (pixels) x MB x 16 channels; four waves side by side along the pixels (BPX = 64*CB columns per
-// workgroup), every wave computes all BM = 16*MB channels of its columns: the 2-byte gathers of the X fragments are done
+// One wave = CB x 16 columns (pixels) x MB x 16 channels; the WAVES waves side by side along the pixels (BPX = 16*WAVES*CB
+// columns per workgroup), every wave computes all BM = 16*MB channels of its columns: the 2-byte gathers of the X fragments are done
 // once per workgroup, the cheap 16-byte W fragment reads four times.
 // FLAT = 0: a tile is BPX consecutive pixels of one image (H*W % 8 == 0: rows are 16-byte multiples)
 // FLAT = 1: a tile is `ni` whole images (ni * H*W <= BPX columns); the K step's 32 rows of an image are one flat range
 // NS = LDS stages: stages ks+1 .. ks+NS-2 are in flight while stage ks is multiplied, one barrier per K step.
-template <int CB, int MB, int FLAT, int NS>
-__global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
-    constexpr int BPX = 64 * CB, BM = 16 * MB, BK = 32;
-    constexpr int XP = BK * BPX / 8 / 256;             // X copies per thread and stage (full passes of 256 x 16 B)
-    constexpr int WPASS = (BM * 4 + 255) / 256;        // W copies per thread and stage
-    constexpr int XST = XP * 2048, WST = WPASS * 2048;  // stage sizes in elements (padded to whole passes)
+// WAVES = 4 or 8 waves per workgroup.  With 8 (two per SIMD, from the same workgroup) one wave's LDS round trips -- the
+// fragment gathers of a K step, ~10 dependent batches -- hide behind the other's MFMAs; with 4 and one workgroup per CU
+// (the deep-K layers) they are fully exposed: measured 1.2 us per K step for 0.25 us of MFMA work.
+template <int CB, int MB, int FLAT, int NS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
+    constexpr int NT = 64 * WAVES;
+    constexpr int BPX = 16 * WAVES * CB, BM = 16 * MB, BK = 32;
+    constexpr int XP = (BK * BPX / 8 + NT - 1) / NT;     // X copies per thread and stage (full passes of NT x 16 B)
+    constexpr int WPASS = (BM * 4 + NT - 1) / NT;        // W copies per thread and stage
+    constexpr int XST = XP * NT * 8, WST = WPASS * NT * 8;  // stage sizes in elements (padded to whole passes)
     constexpr int G = XP + WPASS;
     static_assert(XP >= 1 && (NS - 2) * G <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
     int xn[XP], xin[XP];  // this thread's copies: image, element offset inside the image's block of 32 rows
 #pragma unroll
     for (int ps = 0; ps < XP; ++ps) {
-        const int q = min(ps * 256 + tid, xtotal - 1);
+        const int q = min(ps * NT + tid, xtotal - 1);
         int n, inner;  // image, element offset inside the image's 32-row block
         if (FLAT) {
             const int img = q / cpi, c = q - img * cpi;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
     const bf16_t* wsrc[WPASS];
 #pragma unroll
     for (int ps = 0; ps < WPASS; ++ps) {
-        const int q = min(ps * 256 + tid, BM * 4 - 1);
+        const int q = min(ps * NT + tid, BM * 4 - 1);
         const int row = q >> 2, pos = q & 3;
         const int c = pos ^ ((row >> 2) & 3);  // XOR swizzle: position `pos` of a row holds its k-chunk c
         const int m = min(m0 + row, M - 1);    // rows past M: a copy of row M-1, never stored
@@ -173,10 +177,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
         const bf16_t* xbase = first ? a.x1 + (int64_t)k0 * HW : a.x2 + (int64_t)(k0 - a.k1) * HW;
         const int64_t istride = (int64_t)(first ? a.k1 : K - a.k1) * HW;  // elements per image of that slab
 #pragma unroll
-        for (int ps = 0; ps < XP; ++ps) COT_GLDS16(xbase + xn[ps] * istride + xin[ps], xd + (ps * 256 + wave * 64) * 8);
+        for (int ps = 0; ps < XP; ++ps) COT_GLDS16(xbase + xn[ps] * istride + xin[ps], xd + (ps * NT + wave * 64) * 8);
         bf16_t* wd = wsm + buf * WST;
 #pragma unroll
-        for (int ps = 0; ps < WPASS; ++ps) COT_GLDS16(wsrc[ps] + k0, wd + (ps * 256 + wave * 64) * 8);
+        for (int ps = 0; ps < WPASS; ++ps) COT_GLDS16(wsrc[ps] + k0, wd + (ps * NT + wave * 64) * 8);
     };
 
     // ---- per-lane LDS offsets of the A (= X^T) gathers: column -> element offset of (k = 0, column) inside a stage
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
     // rows are routed one by one (m1 % 8 == 0 is checked on the host, so flat 16-byte pieces never straddle the slabs).
     if (!FLAT) {
         constexpr int cpr = BPX / 8;
-        for (int q = tid; q < mv * cpr; q += 256) {
+        for (int q = tid; q < mv * cpr; q += NT) {
             const int row = q / cpr, c = q - row * cpr;
             if (c * 8 >= ncols) continue;
             const int m = m0 + row;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
         }
     } else {
         const int cpi_o = pers / 8;  // (one image's channel block is contiguous in y -- inside one slab -- and in LDS)
-        for (int q = tid; q < nimg * cpi_o; q += 256) {
+        for (int q = tid; q < nimg * cpi_o; q += NT) {
             const int img = q / cpi_o, c = q - img * cpi_o;
             const int e0 = c * 8;                 // first element of the piece inside the block
             const int m = m0 + e0 / HW;           // its channel decides the slab (pieces do not straddle m1)
@@ -327,10 +331,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
 // [1] images per workgroup in FLAT mode (0 = auto), [2] reserved
 int g_conv_lds_tune[3] = {1, 0, 0};
 
-template <int CB, int MB, int FLAT, int NS>
+template <int CB, int MB, int FLAT, int NS, int WAVES>
 static int launch_c1(const C1LdsArgs& a, int tiles, hipStream_t stream) {
-    constexpr int BPX = 64 * CB, BM = 16 * MB;
-    constexpr int XST = 32 * BPX, WST = ((BM * 4 + 255) / 256) * 2048;
+    constexpr int NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB;
+    constexpr int XST = ((32 * BPX / 8 + NT - 1) / NT) * NT * 8, WST = ((BM * 4 + NT - 1) / NT) * NT * 8;
     size_t lds = (size_t)NS * (XST + WST) * sizeof(bf16_t);
     const size_t otile = (FLAT ? (size_t)a.ni * (((size_t)BM * a.HW + 7) & ~(size_t)7) : (size_t)BM * (BPX + 8)) * sizeof(bf16_t);
     if (otile > lds) lds = otile;
@@ -340,13 +344,13 @@ static int launch_c1(const C1LdsArgs& a, int tiles, hipStream_t stream) {
     if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation (160 KB per CU on gfx950)
         static bool raised = false;
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_lds_fwd<CB, MB, FLAT, NS>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipGetLastError();
             raised = true;
         }
     }
-    COT_LAUNCH((conv1x1_lds_fwd<CB, MB, FLAT, NS>), dim3((unsigned)blocks), dim3(256), lds, stream, b);
+    COT_LAUNCH((conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
     return check_launch("conv1x1_lds_fwd");
 }
 
@@ -367,25 +371,26 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, cons
     a.y1 = (bf16_t*)y1; a.y2 = (bf16_t*)y2;
     a.k1 = x2 ? k1 : K; a.m1 = y2 ? m1 : M; a.N = N; a.K = K; a.M = M; a.HW = HW; a.accumulate = accumulate;
     a.ni = 1; a.xcd_remap = 0;
+    const int w8 = g_conv_lds_tune[2];  // tuning key 17: 0 = default (8-wave workgroups), 1 = 4-wave workgroups (A/B)
     if (HW > 256) {  // BIG: 128-pixel tiles of one image; three stages, several workgroups per CU
         a.ptiles = ceil_div(HW, 128);
         const int tiles = N * a.ptiles;
-        if (M <= 32) { a.mblocks = 1; return launch_c1<2, 2, 0, 3>(a, tiles, stream); }
-        if (M <= 64) { a.mblocks = 1; return launch_c1<2, 4, 0, 3>(a, tiles, stream); }
+        if (M <= 32) { a.mblocks = 1; return w8 ? launch_c1<2, 2, 0, 3, 4>(a, tiles, stream) : launch_c1<1, 2, 0, 3, 8>(a, tiles, stream); }
+        if (M <= 64) { a.mblocks = 1; return w8 ? launch_c1<2, 4, 0, 3, 4>(a, tiles, stream) : launch_c1<1, 4, 0, 3, 8>(a, tiles, stream); }
         a.mblocks = ceil_div(M, 128);
-        return launch_c1<2, 8, 0, 3>(a, tiles, stream);
+        return w8 ? launch_c1<2, 8, 0, 3, 4>(a, tiles, stream) : launch_c1<1, 8, 0, 3, 8>(a, tiles, stream);
     }
-    // FLAT: whole images, up to 256 columns per workgroup (4 waves x 4 column blocks), up to 128 channels.  These are the
-    // deep-K layers with few workgroups (one per CU at best): six stages, five of them in flight per workgroup
+    // FLAT: whole images, up to 256 columns per workgroup, up to 128 channels.  These are the deep-K layers with few
+    // workgroups (one per CU at best): six stages, five of them in flight per workgroup
     int ni = g_conv_lds_tune[1] > 0 ? g_conv_lds_tune[1] : 256 / HW;
     if (ni > N) ni = N;
     if (ni < 1 || ni * HW > 256) return -1;
     a.ni = ni;
     a.ptiles = ceil_div(N, ni);
-    if (M <= 32) { a.mblocks = 1; return launch_c1<4, 2, 1, 6>(a, a.ptiles, stream); }
-    if (M <= 64) { a.mblocks = 1; return launch_c1<4, 4, 1, 6>(a, a.ptiles, stream); }
+    if (M <= 32) { a.mblocks = 1; return w8 ? launch_c1<4, 2, 1, 6, 4>(a, a.ptiles, stream) : launch_c1<2, 2, 1, 6, 8>(a, a.ptiles, stream); }
+    if (M <= 64) { a.mblocks = 1; return w8 ? launch_c1<4, 4, 1, 6, 4>(a, a.ptiles, stream) : launch_c1<2, 4, 1, 6, 8>(a, a.ptiles, stream); }
     a.mblocks = ceil_div(M, 128);
-    return launch_c1<4, 8, 1, 6>(a, a.ptiles, stream);
+    return w8 ? launch_c1<4, 8, 1, 6, 4>(a, a.ptiles, stream) : launch_c1<2, 8, 1, 6, 8>(a, a.ptiles, stream);
 }
 
 }  // namespace cot

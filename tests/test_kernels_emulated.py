@@ -534,7 +534,8 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
     (5, 32, 16, 8, 8, 0, False),      # FLAT: HW = 64, four images per workgroup + one left over
     (2, 160, 72, 14, 14, 0, False),   # FLAT: five K steps (pipeline wraps), M = 72
 ])
-def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias):
+@pytest.mark.parametrize("waves4", [0, 1])
+def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias, waves4):
     """second-generation 1x1 kernels (csrc/conv_lds.hip): every case satisfies K % 32 == 0 so the LDS path is the one
     that runs (cot_last_kernel is checked); forward, data gradient (through the transposed-weight workspace), the
     accumulate flags of both output slabs, against torch in fp32 on the same bf16-rounded operands"""
@@ -552,7 +553,7 @@ def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias):
     cc1 = c1 if split else Ci
     dt = _lib.dtype_code(torch.bfloat16)
     PN = lambda t: P(t) if t is not None else None
-    assert _EMUL.cot_set_tuning(15, 1) == 0
+    assert _EMUL.cot_set_tuning(15, 1) == 0 and _EMUL.cot_set_tuning(17, waves4) == 0  # 8- / 4-wave workgroups
     y = torch.full((N, Co, H, W), float("nan")).bfloat16()
     assert _EMUL.cot_conv1x1_forward(P(x1), PN(x2), cc1, P(w), PN(b), P(y), N, Ci, Co, HW, dt, None) == 0, _EMUL.cot_last_error()
     assert torch.allclose(y.float(), yref.detach(), atol=2e-2, rtol=2e-2), (y.float() - yref).abs().max()
@@ -579,6 +580,7 @@ def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias):
         assert torch.allclose(a1.float(), want1, atol=5e-2, rtol=2e-2)
         if split:
             assert torch.allclose(a2.float(), base2.float() + xf.grad[:, cc1:], atol=5e-2, rtol=2e-2)
+    assert _EMUL.cot_set_tuning(17, 0) == 0
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 16, 16), (3, 3, 7, 9), (1, 4, 32, 32)])
