@@ -22,9 +22,15 @@
 
 namespace cot {
 
-// dst[c][r] = src[r][c]   (R x C row-major -> C x R row-major), 32x32 tiles through LDS
+extern int g_conv_lds_tune[3];
+
+// dst[c][r] = src[r][c]   (R x C row-major -> C x R row-major), 32x32 tiles through LDS.
+// pack = 1: the K-step-major form the LDS kernels read for the data gradient: dst[((r/32)*C + c)*32 + r%32] = src[r][c],
+// i.e. for every block of 32 reduction rows r (= output channels of the convolution) a contiguous [C][32] image -- a K
+// step's W tile is then ONE contiguous range instead of C segments of 64 bytes that are R*2 bytes apart (with R*2 = 4096
+// all of them sit on one L2 channel: measured 2x slower than the same GEMM with a 1 KB row stride).  R % 32 == 0.
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
-                                                            int R, int C) {
+                                                            int R, int C, int pack) {
     __shared__ bf16_t tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -37,13 +43,13 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (r < R && c < C) dst[(int64_t)c * R + r] = tile[tx][ty + 8 * i];
+        if (r < R && c < C) dst[pack ? ((int64_t)blockIdx.y * C + c) * 32 + tx : (int64_t)c * R + r] = tile[tx][ty + 8 * i];
     }
 }
 
-int transpose_bf16(const void* src, void* dst, int R, int C, hipStream_t stream) {
+int transpose_bf16(const void* src, void* dst, int R, int C, int pack, hipStream_t stream) {
     COT_LAUNCH(transpose_bf16_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, stream, (const bf16_t*)src,
-               (bf16_t*)dst, R, C);
+               (bf16_t*)dst, R, C, pack);
     return check_launch("transpose_bf16_kernel");
 }
 
@@ -80,15 +86,116 @@ template <int G> struct WaitBehind<G, 0> {
     static __device__ __forceinline__ void go(int) { COT_WAIT_VM(0); }
 };
 
+// ---- epilogue through LDS (shared by the 1x1 and the grouped 3x3 kernels).  In the C/D map a lane holds 4 consecutive
+// pixels of ONE channel and the 16 lanes of a group 16 different channels: stored directly that is 32 contiguous bytes per
+// channel row and instruction.  Instead the tile goes to LDS in its memory order (rounded to bf16, bias added) and is
+// copied out in full 16-byte pieces, 256 contiguous bytes per 16 lanes: BIG = rows of BPX pixels; FLAT = per image one
+// contiguous [channels][H*W] block (whatever H*W is -- the channel block of an image IS one flat range of y).
+struct EpiArgs {
+    bf16_t* y1;
+    bf16_t* y2;          // second channel slab of the output (NULL: m1 == M)
+    const bf16_t* bias;  // indexed by the global channel (may be NULL)
+    int m1, M, HW, N, ni;
+    int n0, p0, m0;      // first image, first pixel (BIG), first channel of the tile
+    int mv, ncols;       // valid channels / columns of the tile
+    int accumulate;      // bit 0: y1 += result, bit 1: y2 += result
+};
+
+template <int CB, int MB, int FLAT, int WAVES>
+__device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], const EpiArgs& a) {
+    constexpr int NT = 64 * WAVES, BPX = 16 * WAVES * CB;
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int HW = a.HW, M = a.M, m0 = a.m0, n0 = a.n0, p0 = a.p0, ncols = a.ncols, mv = a.mv;
+    COT_LDS_BARRIER();  // every wave is done with the last stage: the stage memory is free
+    bf16_t* const ot = reinterpret_cast<bf16_t*>(cot_smem);
+    constexpr int OS = BPX + 8;                      // BIG: padded row stride of the tile image (bank spread)
+    const int nimg = FLAT ? min(a.ni, a.N - n0) : 1;
+    const int per = mv * HW, pers = (per + 7) & ~7;  // FLAT: elements of one image's channel block, its (16-byte) LDS stride
+#pragma unroll
+    for (int mbk = 0; mbk < MB; ++mbk) {
+        const int ml = mbk * 16 + i16;
+        const float bs = (a.bias && ml < mv) ? (float)a.bias[m0 + ml] : 0.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int col = (wave * CB + cb) * 16 + 4 * g;
+            bf16_t o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[cb][mbk][r] + bs);
+            if (!FLAT) {
+                __builtin_memcpy(__builtin_assume_aligned(ot + ml * OS + col, 8), o, 8);
+            } else if (HW % 4 == 0) {
+                if (col < ncols && ml < mv) {  // 4 consecutive columns stay inside one image
+                    const int img = col / HW, p = col - img * HW;
+                    __builtin_memcpy(__builtin_assume_aligned(ot + img * pers + ml * HW + p, 8), o, 8);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = col + r;
+                    if (c < ncols && ml < mv) {
+                        const int img = c / HW, p = c - img * HW;
+                        ot[img * pers + ml * HW + p] = o[r];
+                    }
+                }
+            }
+        }
+    }
+    COT_LDS_BARRIER();
+    // copy out: 16 bytes per lane.  Output slabs (y1 | y2 at channel m1): a block lies in one slab or, when it straddles m1,
+    // rows are routed one by one (m1 % 8 == 0 is checked on the host, so flat 16-byte pieces never straddle the slabs).
+    if (!FLAT) {
+        constexpr int cpr = BPX / 8;
+        for (int q = tid; q < mv * cpr; q += NT) {
+            const int row = q / cpr, c = q - row * cpr;
+            if (c * 8 >= ncols) continue;
+            const int m = m0 + row;
+            const bool second = m >= a.m1;
+            bf16_t* dst = (second ? a.y2 + ((int64_t)n0 * (M - a.m1) + (m - a.m1)) * HW : a.y1 + ((int64_t)n0 * a.m1 + m) * HW) + p0 + c * 8;
+            Vec<bf16_t, 8> v = *reinterpret_cast<const Vec<bf16_t, 8>*>(ot + row * OS + c * 8);
+            if ((a.accumulate >> (second ? 1 : 0)) & 1) {
+                const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(dst);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
+            }
+            stv<bf16_t, 8>(dst, v);
+        }
+    } else {
+        const int cpi_o = pers / 8;  // (one image's channel block is contiguous in y -- inside one slab -- and in LDS)
+        for (int q = tid; q < nimg * cpi_o; q += NT) {
+            const int img = q / cpi_o, c = q - img * cpi_o;
+            const int e0 = c * 8;                 // first element of the piece inside the block
+            const int m = m0 + e0 / HW;           // its channel decides the slab (pieces do not straddle m1)
+            const bool second = m >= a.m1;
+            bf16_t* blk = second ? a.y2 + ((int64_t)(n0 + img) * (M - a.m1) + (m0 - a.m1)) * HW
+                                 : a.y1 + ((int64_t)(n0 + img) * a.m1 + m0) * HW;
+            const bool accu = (a.accumulate >> (second ? 1 : 0)) & 1;
+            const bf16_t* src = ot + img * pers + e0;
+            if (e0 + 8 <= per) {
+                Vec<bf16_t, 8> v = *reinterpret_cast<const Vec<bf16_t, 8>*>(src);
+                if (accu) {
+                    const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(blk + e0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
+                }
+                stv<bf16_t, 8>(blk + e0, v);
+            } else {  // the block's last, partial piece (mv * HW % 8 != 0: only when mv is not a multiple of 8)
+                for (int e = e0; e < per; ++e) blk[e] = (bf16_t)(accu ? (float)src[e - e0] + (float)blk[e] : (float)src[e - e0]);
+            }
+        }
+    }
+}
+
 struct C1LdsArgs {
     const bf16_t* x1;
     const bf16_t* x2;  // second channel slab of the input (NULL: k1 == K)
-    const bf16_t* w;   // [M][K] row-major
+    const bf16_t* w;   // [M][K] row-major, or (wpacked) K-step-major [K/32][M][32]
     const bf16_t* bias;
     bf16_t* y1;
     bf16_t* y2;        // second channel slab of the output (NULL: m1 == M)
     int k1, m1, N, K, M, HW;
     int accumulate;    // bit 0: y1 += result, bit 1: y2 += result
+    int wpacked;
     int mblocks;       // output-channel blocks of BM
     int ptiles;        // pixel tiles per image (BIG) / image groups (FLAT)
     int ni;            // FLAT: images per workgroup
@@ -168,10 +275,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
         const int row = q >> 2, pos = q & 3;
         const int c = pos ^ ((row >> 2) & 3);  // XOR swizzle: position `pos` of a row holds its k-chunk c
         const int m = min(m0 + row, M - 1);    // rows past M: a copy of row M-1, never stored
-        wsrc[ps] = a.w + (int64_t)m * K + c * 8;
+        wsrc[ps] = a.wpacked ? a.w + (int64_t)m * 32 + c * 8 : a.w + (int64_t)m * K + c * 8;
     }
-    auto stage = [&](int ks) __attribute__((always_inline)) {
-        const int k0 = ks * BK, buf = ks % NS;
+    const int64_t wstep = a.wpacked ? (int64_t)M * 32 : 32;  // elements from one K step's W tile to the next
+    // Workgroups walk K from different starting steps (cyclically): otherwise all of them read the same 64-byte column
+    // of W -- 128 segments that are K*2 bytes apart, i.e. (K >= 2048) ONE L2 channel -- at about the same time.
+    const int nk = K / BK;
+    const int ks0 = (int)(((unsigned)t * 5u + (unsigned)mb * 3u) % (unsigned)nk);
+    auto stage = [&](int ksl) __attribute__((always_inline)) {
+        int ks = ksl + ks0;
+        if (ks >= nk) ks -= nk;
+        const int k0 = ks * BK, buf = ksl % NS;
         bf16_t* xd = xsm + buf * XST;
         const bool first = k0 < a.k1;  // the K step's rows come from one slab (k1 % 32 == 0 is checked on the host)
         const bf16_t* xbase = first ? a.x1 + (int64_t)k0 * HW : a.x2 + (int64_t)(k0 - a.k1) * HW;
@@ -180,7 +294,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
         for (int ps = 0; ps < XP; ++ps) COT_GLDS16(xbase + xn[ps] * istride + xin[ps], xd + (ps * NT + wave * 64) * 8);
         bf16_t* wd = wsm + buf * WST;
 #pragma unroll
-        for (int ps = 0; ps < WPASS; ++ps) COT_GLDS16(wsrc[ps] + k0, wd + (ps * NT + wave * 64) * 8);
+        for (int ps = 0; ps < WPASS; ++ps) COT_GLDS16(wsrc[ps] + ks * wstep, wd + (ps * NT + wave * 64) * 8);
     };
 
     // ---- per-lane LDS offsets of the A (= X^T) gathers: column -> element offset of (k = 0, column) inside a stage
@@ -210,7 +324,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
 #pragma unroll
         for (int mbk = 0; mbk < MB; ++mbk) acc[cb][mbk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nk) stage(s0);
@@ -242,89 +355,314 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
         }
     }
 
-    // ---- epilogue through LDS.  In the C/D map a lane holds 4 consecutive pixels of ONE channel and the 16 lanes of a group
-    // 16 different channels: stored directly that is 32 contiguous bytes per channel row and instruction.  Instead the tile
-    // goes to LDS in its memory order (rounded to bf16, bias added) and is copied out in full 16-byte pieces, 256
-    // contiguous bytes per 16 lanes: BIG = BM rows of BPX pixels; FLAT = per image one contiguous [channels][H*W] block
-    // (whatever H*W is -- the channel block of an image IS one flat range of y).
-    COT_LDS_BARRIER();  // every wave is done with the last stage: the stage memory is free
-    bf16_t* const ot = reinterpret_cast<bf16_t*>(cot_smem);
-    constexpr int OS = BPX + 8;                      // BIG: padded row stride of the tile image (bank spread)
-    const int mv = min(BM, M - m0);                 // valid channels of this block (a multiple of 8 unless it is the last)
-    const int nimg = FLAT ? min(a.ni, a.N - n0) : 1;
-    const int per = mv * HW, pers = (per + 7) & ~7;  // FLAT: elements of one image's channel block, its (16-byte) LDS stride
+    EpiArgs e;
+    e.y1 = a.y1; e.y2 = a.y2; e.bias = a.bias; e.m1 = a.m1; e.M = M; e.HW = HW; e.N = a.N; e.ni = a.ni;
+    e.n0 = n0; e.p0 = p0; e.m0 = m0; e.mv = min(BM, M - m0); e.ncols = ncols; e.accumulate = a.accumulate;
+    tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
+}
+
+// ====================================================================================================================
+// Grouped 3x3 convolution (stride 1, padding 1) -- CotLayer.key_embed[0] (models/cotnet.py:43-47; groups 4; CoXtLayer 8) --
+// on the same machinery: per group an implicit GEMM  Y (MM x HW) = sum over (tap, ci) Wr[tap][co][ci] * X[ci][p + off(tap)].
+//   * the group's input channels are staged ONCE per 32-channel chunk (all 9 taps read the same staged rows at shifted
+//     positions): BIG = a tile of TR image rows plus one halo row above and below, each channel's rows one contiguous range
+//     (like the aggregation kernels' slabs); FLAT = whole small images, flat;
+//   * a K step = (channel chunk, tap): 32 channels of one tap (KK >= 32), or two taps x 16 channels (KK == 16; the tenth
+//     "tap" of the fifth step is a block of zeros in the repacked weights).  The A fragment (pixels x 8 channels) is the
+//     same 2-byte gather as in the 1x1 kernel at `+ dy*W + dx`; positions whose neighbour lies outside the image read a
+//     neighbouring row / channel / image and are zeroed by SELECTION with a per-lane 9-bit validity mask;
+//   * weights are repacked per call into [group][tap][co][ci] (ci contiguous; data gradient: [tap][ci][co] with the taps
+//     flipped) by a small kernel into the call's workspace (<= 1.2 MB), so W fragments are 16-byte rows as in the 1x1 case.
+// dst[((g*NT + tap)*Mo + mo)*Kk + kk] = forward:  w[((g*Mo + mo)*Kk + kk)*9 + tap]
+//                                        dgrad:    w[((g*Kk + kk)*Mo + mo)*9 + (8 - tap)]     (tap == 9: zeros)
+__global__ void conv3x3g_repack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ dst, int G, int Mo, int Kk, int NTAP,
+                                       int dgrad) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (int64_t)G * NTAP * Mo * Kk;
+    if (o >= total) return;
+    const int kk = (int)(o % Kk);
+    int64_t r = o / Kk;
+    const int mo = (int)(r % Mo);
+    r /= Mo;
+    const int tap = (int)(r % NTAP), g = (int)(r / NTAP);
+    bf16_t v = (bf16_t)0.0f;
+    if (tap < 9) v = dgrad ? w[(((int64_t)g * Kk + kk) * Mo + mo) * 9 + (8 - tap)] : w[(((int64_t)g * Mo + mo) * Kk + kk) * 9 + tap];
+    dst[o] = v;
+}
+
+struct C3LdsArgs {
+    const bf16_t* x;   // [N][G*KK][H*W]
+    const bf16_t* wr;  // repacked weights [G][NTAP][MM][KK]
+    bf16_t* y;         // [N][G*MM][H*W]
+    int N, G, KK, MM, H, W;
+    int accumulate;
+    int tiles;         // BIG: row tiles per image; FLAT: image groups
+    int ni;            // FLAT: images per workgroup
+    int TR;            // BIG: image rows per tile
+    int SL;            // BIG: staged elements per channel ((TR+2)*W + 8, rounded up to 8)
+    int xcd_remap;
+};
+
+// K16: KK == 16 (two taps per K step, 5 steps); else KK % 32 == 0 (9 steps per 32-channel chunk).  XP = X copies per thread
+// and chunk (compile-time so that the vmcnt arithmetic is uniform; the host picks TR / ni to fit).
+template <int CB, int MB, int FLAT, int K16, int XP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArgs a) {
+    constexpr int NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB;
+    constexpr int CH = K16 ? 16 : 32;                 // channels per staged chunk
+    constexpr int WPASS = (BM * 4 + NT - 1) / NT;
+    constexpr int XST = XP * NT * 8, WST = WPASS * NT * 8, NSW = 3;
+    constexpr int GW = WPASS, GX = XP;
+    static_assert(GW + GX <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    bf16_t* const wsm = reinterpret_cast<bf16_t*>(cot_smem);  // [NSW][WST] then [2][XST]
+    bf16_t* const xsm = wsm + NSW * WST;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int H = a.H, W = a.W, HW = H * W, KK = a.KK, MM = a.MM, G = a.G;
+
+    unsigned b = blockIdx.x;
+    if (a.xcd_remap && (gridDim.x & 7u) == 0) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
+    const int grp = b % G;
+    const int t = b / G;
+    int n0, r0 = 0, ncols, gs = 0;
+    if (FLAT) {
+        n0 = t * a.ni;
+        ncols = min(a.ni, a.N - n0) * HW;
+    } else {
+        n0 = t / a.tiles;
+        r0 = (t - n0 * a.tiles) * a.TR;
+        ncols = min(a.TR, H - r0) * W;
+        gs = max(0, (r0 - 1) * W) & ~7;  // first staged element of every channel (16-byte aligned)
+    }
+    const int SLc = FLAT ? HW : a.SL;                          // channel stride inside a staged chunk
+    const int xelems = FLAT ? a.ni * CH * HW : CH * a.SL;      // elements of a staged chunk
+    const int64_t x_total = (int64_t)a.N * G * KK * HW;
+
+    // ---- X copies of this thread (resolved once; a chunk step moves them CH channels = CH*HW elements)
+    int64_t xoff[XP];
+#pragma unroll
+    for (int ps = 0; ps < XP; ++ps) {
+        const int q = min(ps * NT + tid, xelems / 8 - 1);
+        int64_t e;
+        if (FLAT) {
+            const int cpi = CH * HW / 8, img = q / cpi, c = q - img * cpi;
+            e = ((int64_t)min(n0 + img, a.N - 1) * G * KK + (int64_t)grp * KK) * HW + (int64_t)c * 8;
+        } else {
+            const int cpc = a.SL / 8, ch = q / cpc, c = q - ch * cpc;
+            e = ((int64_t)n0 * G * KK + (int64_t)grp * KK + ch) * HW + gs + c * 8;
+        }
+        xoff[ps] = e;
+    }
+    // ---- W copies: row = output channel of the group, 4 chunks of 8 k per row (swizzled position)
+    int64_t woff[WPASS];
+#pragma unroll
+    for (int ps = 0; ps < WPASS; ++ps) {
+        const int q = min(ps * NT + tid, BM * 4 - 1);
+        const int row = q >> 2, pos = q & 3, c = pos ^ ((row >> 2) & 3);
+        const int rr = min(row, MM - 1);
+        if (K16) woff[ps] = ((int64_t)(c >> 1) * MM + rr) * 16 + (c & 1) * 8;  // chunk c: tap 2t + (c>>1), channels 8*(c&1)..
+        else woff[ps] = (int64_t)rr * KK + c * 8;
+    }
+    const int ncc = K16 ? 1 : KK / 32, spc = K16 ? 5 : 9, nsteps = ncc * spc;  // chunks, steps per chunk
+    const bf16_t* wgrp = a.wr + (int64_t)grp * (K16 ? 10 : 9) * MM * KK;
+    auto stage_x = [&](int cc) __attribute__((always_inline)) {
+        bf16_t* xd = xsm + (cc & 1) * XST;
+#pragma unroll
+        for (int ps = 0; ps < XP; ++ps) {
+            int64_t e = xoff[ps] + (int64_t)cc * CH * HW;
+            if (e + 8 > x_total) e = x_total - 8;  // (BIG: the last tile's halo row past the tensor: in-bounds bytes, masked)
+            COT_GLDS16(a.x + e, xd + (ps * NT + wave * 64) * 8);
+        }
+    };
+    auto stage_w = [&](int s) __attribute__((always_inline)) {
+        const int cc = s / spc, tp = s - cc * spc;
+        const bf16_t* src = K16 ? wgrp + (int64_t)(2 * tp) * MM * 16 : wgrp + (int64_t)tp * MM * KK + cc * 32;
+        bf16_t* wd = wsm + (s % NSW) * WST;
+#pragma unroll
+        for (int ps = 0; ps < WPASS; ++ps) COT_GLDS16(src + woff[ps], wd + (ps * NT + wave * 64) * 8);
+    };
+    auto stage = [&](int s) __attribute__((always_inline)) {  // a step's copies: its W tile, and the next chunk's X with a chunk's first step
+        if (s % spc == 0) stage_x(s / spc);
+        stage_w(s);
+    };
+
+    // ---- per-lane gather bases and tap-validity masks of the lane's column in every column block
+    int abase[CB];
+    unsigned amask[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int col = (wave * CB + cb) * 16 + i16;
+        int h, w, base;
+        bool ok;
+        if (FLAT) {
+            const int cc = min(col, a.ni * HW - 1), img = cc / HW, p = cc - img * HW;
+            h = p / W; w = p - h * W;
+            base = img * CH * HW + p;
+            ok = col < ncols;
+        } else {
+            const int cc = min(col, a.TR * W - 1);
+            h = r0 + cc / W; w = cc - (cc / W) * W;
+            base = r0 * W + cc - gs;
+            ok = col < ncols;
+        }
+        unsigned m = 0;
+        if (ok) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int hh = h + tp / 3 - 1, ww = w + tp % 3 - 1;
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W) m |= 1u << tp;
+            }
+        }
+        amask[cb] = m;
+        abase[cb] = base + (K16 ? 8 * (g & 1) : 8 * g) * SLc;  // this lane group's 8 channels
+    }
+    int boff[MB];
 #pragma unroll
     for (int mbk = 0; mbk < MB; ++mbk) {
-        const int ml = mbk * 16 + i16;
-        const float bs = (a.bias && m0 + ml < M) ? (float)a.bias[m0 + ml] : 0.f;
+        const int row = mbk * 16 + i16;
+        boff[mbk] = row * 32 + (g ^ ((row >> 2) & 3)) * 8;
+    }
+    f32x4_t acc[CB][MB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int mbk = 0; mbk < MB; ++mbk) acc[cb][mbk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    stage(0);
+    if (nsteps > 1) stage(1);
+    for (int s = 0; s < nsteps; ++s) {
+        // leave exactly the copies of step s+1 in flight (NSW = 3: one step ahead besides the one being read)
+        if (s + 1 < nsteps) {
+            if ((s + 1) % spc == 0) COT_WAIT_VM(GW + GX);
+            else COT_WAIT_VM(GW);
+        } else {
+            COT_WAIT_VM(0);
+        }
+        COT_LDS_BARRIER();
+        if (s + 2 < nsteps) stage(s + 2);
+        const int cc = s / spc, tp = s - cc * spc;
+        const uint16_t* xb = reinterpret_cast<const uint16_t*>(xsm + (cc & 1) * XST);
+        const bf16_t* wb = wsm + (s % NSW) * WST;
+        const int tapraw = K16 ? 2 * tp + (g >> 1) : tp;  // (K16: lane groups 2,3 take the step's second tap; "tap 9" = zero weights)
+        const int tap = min(tapraw, 8);
+        const int shift = (tap / 3 - 1) * W + (tap % 3 - 1);
+        typedef __attribute__((ext_vector_type(2))) uint16_t u16x2_t;
+        bf16x8_t af[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            const int col = (wave * CB + cb) * 16 + 4 * g;
-            bf16_t o[4];
+            const int idx = min(max(abase[cb] + shift, 0), xelems - 7 * SLc - 1);  // masked positions: any staged element
+            const uint16_t* p = xb + idx;
+            u16x2_t q4[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[cb][mbk][r] + bs);
-            if (!FLAT) {
-                __builtin_memcpy(__builtin_assume_aligned(ot + ml * OS + col, 8), o, 8);
-            } else if (HW % 4 == 0) {
-                if (col < ncols && ml < mv) {  // 4 consecutive columns stay inside one image
-                    const int img = col / HW, p = col - img * HW;
-                    __builtin_memcpy(__builtin_assume_aligned(ot + img * pers + ml * HW + p, 8), o, 8);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = col + r;
-                    if (c < ncols && ml < mv) {
-                        const int img = c / HW, p = c - img * HW;
-                        ot[img * pers + ml * HW + p] = o[r];
-                    }
-                }
+            for (int hh = 0; hh < 4; ++hh) {
+                q4[hh][0] = p[(2 * hh) * SLc];
+                q4[hh][1] = p[(2 * hh + 1) * SLc];
             }
+            const bool valid = tapraw < 9 && ((amask[cb] >> tap) & 1);
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {
+                q4[hh][0] = valid ? q4[hh][0] : (uint16_t)0;
+                q4[hh][1] = valid ? q4[hh][1] : (uint16_t)0;
+            }
+            __builtin_memcpy(&af[cb], q4, 16);
+        }
+#pragma unroll
+        for (int mbk = 0; mbk < MB; ++mbk) {
+            bf16x8_t bf;
+            __builtin_memcpy(&bf, __builtin_assume_aligned(wb + boff[mbk], 16), 16);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[cb][mbk] = COT_MFMA_16X16X32_BF16(af[cb], bf, acc[cb][mbk]);
         }
     }
-    COT_LDS_BARRIER();
-    // copy out: 16 bytes per lane.  Output slabs (y1 | y2 at channel m1): a block lies in one slab or, when it straddles m1,
-    // rows are routed one by one (m1 % 8 == 0 is checked on the host, so flat 16-byte pieces never straddle the slabs).
-    if (!FLAT) {
-        constexpr int cpr = BPX / 8;
-        for (int q = tid; q < mv * cpr; q += NT) {
-            const int row = q / cpr, c = q - row * cpr;
-            if (c * 8 >= ncols) continue;
-            const int m = m0 + row;
-            const bool second = m >= a.m1;
-            bf16_t* dst = (second ? a.y2 + ((int64_t)n0 * (M - a.m1) + (m - a.m1)) * HW : a.y1 + ((int64_t)n0 * a.m1 + m) * HW) + p0 + c * 8;
-            Vec<bf16_t, 8> v = *reinterpret_cast<const Vec<bf16_t, 8>*>(ot + row * OS + c * 8);
-            if ((a.accumulate >> (second ? 1 : 0)) & 1) {
-                const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(dst);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
-            }
-            stv<bf16_t, 8>(dst, v);
+    EpiArgs e;
+    e.y1 = a.y; e.y2 = nullptr; e.bias = nullptr; e.m1 = G * MM; e.M = G * MM; e.HW = HW; e.N = a.N; e.ni = a.ni;
+    e.n0 = n0; e.p0 = r0 * W; e.m0 = grp * MM; e.mv = MM; e.ncols = ncols; e.accumulate = a.accumulate;
+    tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
+}
+
+template <int CB, int MB, int FLAT, int K16, int XP>
+static int launch_c3(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
+    constexpr int WAVES = 8, NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB;
+    constexpr int XST = XP * NT * 8, WST = ((BM * 4 + NT - 1) / NT) * NT * 8;
+    const int ncc = K16 ? 1 : a.KK / 32;
+    size_t lds = (size_t)(3 * WST + (ncc > 1 ? 2 : 1) * XST) * sizeof(bf16_t);
+    const size_t otile = (FLAT ? (size_t)a.ni * (((size_t)BM * a.H * a.W + 7) & ~(size_t)7) : (size_t)BM * (BPX + 8)) * sizeof(bf16_t);
+    if (otile > lds) lds = otile;
+    C3LdsArgs b = a;
+    b.xcd_remap = (blocks % 8 == 0) ? 1 : 0;
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3g_lds_fwd<CB, MB, FLAT, K16, XP, WAVES>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipGetLastError();
+            raised = true;
         }
+    }
+    COT_LAUNCH((conv3x3g_lds_fwd<CB, MB, FLAT, K16, XP, WAVES>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
+    return check_launch("conv3x3g_lds_fwd");
+}
+
+bool conv3x3g_lds_covers(int KK, int MM, int H, int W) {
+    if (!g_conv_lds_tune[0]) return false;
+    if (!(MM == 16 || MM == 32 || MM == 64 || MM == 128)) return false;
+    if (!((KK == 16 && MM == 16) || (KK % 32 == 0 && KK >= 32 && MM >= 32))) return false;
+    const int HW = H * W;
+    if (HW <= 256) return HW % 8 == 0 || MM % 8 == 0;
+    return HW % 8 == 0 && W % 4 == 0 && W <= 128;
+}
+
+// mode 0: y = conv(x, w);  mode 1: data gradient (x := dY, y := dX, weights transposed and flipped).  `ws`: the call's
+// workspace (>= G*10*MM*KK bf16).  Returns COT_OK, an error, or -1 when the geometry is not covered.
+int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, int Cin, int Cout, int G, int H, int W,
+                      int mode, int accumulate, hipStream_t stream) {
+    const int KK = (mode == 0 ? Cin : Cout) / G, MM = (mode == 0 ? Cout : Cin) / G, HW = H * W;
+    if (!conv3x3g_lds_covers(KK, MM, H, W)) return -1;
+    const int K16 = KK == 16, NTAP = K16 ? 10 : 9;
+    C3LdsArgs a;
+    a.x = (const bf16_t*)x; a.wr = (const bf16_t*)ws; a.y = (bf16_t*)y;
+    a.N = N; a.G = G; a.KK = KK; a.MM = MM; a.H = H; a.W = W; a.accumulate = accumulate;
+    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0;
+    int64_t blocks;
+    const bool flat = HW <= 256;
+    if (flat) {
+        int ni = 256 / HW;                      // CB = 2: 256 columns
+        const int want = (N * G + 127) / 128;   // ... but keep >= ~128 workgroups when the batch allows
+        if (ni > want) ni = want;
+        if (ni > N) ni = N;
+        if (ni < 1) ni = 1;
+        a.ni = ni;
+        a.tiles = ceil_div(N, ni);
+        blocks = (int64_t)a.tiles * G;
     } else {
-        const int cpi_o = pers / 8;  // (one image's channel block is contiguous in y -- inside one slab -- and in LDS)
-        for (int q = tid; q < nimg * cpi_o; q += NT) {
-            const int img = q / cpi_o, c = q - img * cpi_o;
-            const int e0 = c * 8;                 // first element of the piece inside the block
-            const int m = m0 + e0 / HW;           // its channel decides the slab (pieces do not straddle m1)
-            const bool second = m >= a.m1;
-            bf16_t* blk = second ? a.y2 + ((int64_t)(n0 + img) * (M - a.m1) + (m0 - a.m1)) * HW
-                                 : a.y1 + ((int64_t)(n0 + img) * a.m1 + m0) * HW;
-            const bool accu = (a.accumulate >> (second ? 1 : 0)) & 1;
-            const bf16_t* src = ot + img * pers + e0;
-            if (e0 + 8 <= per) {
-                Vec<bf16_t, 8> v = *reinterpret_cast<const Vec<bf16_t, 8>*>(src);
-                if (accu) {
-                    const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(blk + e0);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
-                }
-                stv<bf16_t, 8>(blk + e0, v);
-            } else {  // the block's last, partial piece (mv * HW % 8 != 0: only when mv is not a multiple of 8)
-                for (int e = e0; e < per; ++e) blk[e] = (bf16_t)(accu ? (float)src[e - e0] + (float)blk[e] : (float)src[e - e0]);
-            }
-        }
+        // BIG: TR image rows per tile (CB = 4: 512 columns), TR*W a multiple of 8, the staged chunk within XP passes
+        const int CH = K16 ? 16 : 32, XPmax = K16 ? 3 : 5;
+        int TR = 512 / W;
+        if (TR > H) TR = H;
+        const int nt = ceil_div(H, TR);
+        TR = ceil_div(H, nt);  // balanced tiles
+        while (TR > 1 && ((TR * W) % 8 != 0 || (int64_t)CH * (((TR + 2) * W + 8 + 7) / 8) > (int64_t)XPmax * 512)) --TR;
+        if ((TR * W) % 8 != 0 || (int64_t)CH * (((TR + 2) * W + 8 + 7) / 8) > (int64_t)XPmax * 512) return -1;
+        a.TR = TR;
+        a.SL = ((TR + 2) * W + 8 + 7) / 8 * 8;
+        a.tiles = ceil_div(H, TR);
+        blocks = (int64_t)N * a.tiles * G;
     }
+    {   // repack the weights: [G][NTAP][MM][KK]
+        const int64_t total = (int64_t)G * NTAP * MM * KK;
+        COT_LAUNCH(conv3x3g_repack_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, (const bf16_t*)w,
+                   (bf16_t*)ws, G, MM, KK, NTAP, mode);
+        int rc = check_launch("conv3x3g_repack_kernel");
+        if (rc) return rc;
+    }
+    if (flat) {
+        if (K16) return launch_c3<2, 1, 1, 1, 1>(a, blocks, stream);
+        if (MM == 32) return launch_c3<2, 2, 1, 0, 2>(a, blocks, stream);
+        if (MM == 64) return launch_c3<2, 4, 1, 0, 2>(a, blocks, stream);
+        return launch_c3<2, 8, 1, 0, 2>(a, blocks, stream);
+    }
+    if (K16) return launch_c3<4, 1, 0, 1, 3>(a, blocks, stream);
+    if (MM == 32) return launch_c3<4, 2, 0, 0, 5>(a, blocks, stream);
+    if (MM == 64) return launch_c3<4, 4, 0, 0, 5>(a, blocks, stream);
+    return launch_c3<4, 8, 0, 0, 5>(a, blocks, stream);
 }
 
 // tuning (cot_set_tuning keys 15..17): [0] 0 = first-generation kernels, 1 = LDS kernels where eligible (default),
@@ -361,8 +699,8 @@ bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW) {
 }
 
 // returns COT_OK, an error, or -1 when the geometry is not covered (the caller then takes the first-generation kernel)
-int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, const void* bias, void* y1, void* y2, int m1,
-                     int N, int K, int M, int HW, int accumulate, hipStream_t stream) {
+int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int wpacked, const void* bias, void* y1, void* y2,
+                     int m1, int N, int K, int M, int HW, int accumulate, hipStream_t stream) {
     if (!conv1x1_lds_covers(K, k1, x2 != nullptr, HW)) return -1;
     if (y2 && m1 % 8 != 0) return -1;  // (16-byte pieces of the output must not straddle the two output slabs)
     if (HW % 8 != 0 && ((y2 ? m1 : M) % 8 != 0 || (y2 && (M - m1) % 8 != 0))) return -1;  // image blocks of y 16-byte aligned
@@ -370,7 +708,7 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, cons
     a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.w = (const bf16_t*)w; a.bias = (const bf16_t*)bias;
     a.y1 = (bf16_t*)y1; a.y2 = (bf16_t*)y2;
     a.k1 = x2 ? k1 : K; a.m1 = y2 ? m1 : M; a.N = N; a.K = K; a.M = M; a.HW = HW; a.accumulate = accumulate;
-    a.ni = 1; a.xcd_remap = 0;
+    a.ni = 1; a.xcd_remap = 0; a.wpacked = wpacked;
     const int w8 = g_conv_lds_tune[2];  // tuning key 17: 0 = default (8-wave workgroups), 1 = 4-wave workgroups (A/B)
     if (HW > 256) {  // BIG: 128-pixel tiles of one image; three stages, several workgroups per CU
         a.ptiles = ceil_div(HW, 128);

@@ -122,9 +122,10 @@ extern int g_conv1x1_tune[4];
 // implemented in conv_lds.hip
 extern int g_conv_lds_tune[3];
 bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
-int conv1x1_lds_gemm(const void*, const void*, int, const void*, const void*, void*, void*, int, int, int, int, int, int,
+int conv1x1_lds_gemm(const void*, const void*, int, const void*, int, const void*, void*, void*, int, int, int, int, int, int,
                      hipStream_t);
-int transpose_bf16(const void* src, void* dst, int R, int C, hipStream_t stream);
+int transpose_bf16(const void* src, void* dst, int R, int C, int pack, hipStream_t stream);
+int conv3x3g_lds_gemm(const void*, const void*, void*, void*, int, int, int, int, int, int, int, int, hipStream_t);
 // implemented in stem7x7.hip
 int stem7x7_splits(int N, int H, int W);
 int stem7x7_forward(const void*, const void*, void*, int, int, int, hipStream_t);
@@ -327,7 +328,7 @@ int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weig
     if (!x1 || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x1, x2, weight, y}))) return rc;
     if (conv1x1_lds_covers(Ci, c1, x2 != nullptr, HW)) {
-        rc = conv1x1_lds_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, 0, (hipStream_t)stream);
+        rc = conv1x1_lds_gemm(x1, x2, c1, weight, 0, bias, y, nullptr, Co, N, Ci, Co, HW, 0, (hipStream_t)stream);
         if (rc != -1) return rc;
     }
     return conv1x1_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, 0, 0, (hipStream_t)stream);
@@ -340,9 +341,10 @@ int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, voi
     if (!gy || !weight || !gx1 || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx1, gx2, workspace}))) return rc;
     if (conv1x1_lds_covers(Co, Co, false, HW)) {
-        // the LDS forward kernel on dY with W^T [Ci][Co], written into the workspace by a small transposition launch
-        if ((rc = transpose_bf16(weight, workspace, Co, Ci, (hipStream_t)stream))) return rc;
-        rc = conv1x1_lds_gemm(gy, nullptr, Co, workspace, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3,
+        // the LDS forward kernel on dY with W^T in K-step-major form [Co/32][Ci][32], written into the workspace by a small
+        // transposition launch
+        if ((rc = transpose_bf16(weight, workspace, Co, Ci, 1, (hipStream_t)stream))) return rc;
+        rc = conv1x1_lds_gemm(gy, nullptr, Co, workspace, 1, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3,
                               (hipStream_t)stream);
         if (rc != -1) return rc;
     }
@@ -386,7 +388,7 @@ int cot_conv3x3g_masks(void* masks, int H, int W, void* stream) {
 
 int64_t cot_conv3x3g_workspace(int N, int Cin, int Cout, int groups, int H, int W) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || H <= 0 || W <= 0 || Cin % groups || Cout % groups) return 0;
-    const int64_t wb = (int64_t)Cout * (Cin / groups) * 9 * 2;
+    const int64_t wb = (int64_t)Cout * (Cin / groups) * 10 * 2;  // repacked weights of the LDS kernels (10 taps: one of zeros)
     const int64_t part = (int64_t)conv3x3g_wgrad_splits(N, Cin, Cout, groups, H * W) * Cout * (Cin / groups) * 9 * 4;
     return ((wb > part ? wb : part) + 255) / 256 * 256;
 }
@@ -397,6 +399,8 @@ int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void*
     if (rc) return rc;
     if (!x || !weight || !y || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x, weight, y, masks, workspace}))) return rc;
+    rc = conv3x3g_lds_gemm(x, weight, y, workspace, N, Cin, Cout, groups, H, W, 0, 0, (hipStream_t)stream);
+    if (rc != -1) return rc;
     return conv3x3g_gemm(x, weight, y, masks, N, Cin, Cout, groups, H, W, 0, 0, (hipStream_t)stream);
 }
 
@@ -407,6 +411,8 @@ int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int
     if (rc) return rc;
     if (!gy || !weight || !gx || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx, masks, workspace}))) return rc;
+    rc = conv3x3g_lds_gemm(gy, weight, gx, workspace, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
+    if (rc != -1) return rc;
     return conv3x3g_gemm(gy, weight, gx, masks, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
 }
 

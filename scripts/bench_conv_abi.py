@@ -125,6 +125,55 @@ def main():
             if d > 0.05 * outs[0].abs().max().item() + 1e-3:
                 print(f"   !! generations disagree: max|diff| {d:.3e}")
         L.cot_set_tuning(15, 1)
+    # ---- grouped 3x3 key-embed convolutions (CoTNet-50: groups 4)
+    print(f"\n{'grouped 3x3':26s} {'gen':3s} {'fwd us':>8s} {'%HBM':>6s} {'TF/s':>6s} | {'dgrad us':>8s} {'%HBM':>6s} | {'wgrad us':>8s} {'%HBM':>6s}")
+    for C, H in ((64, 56), (128, 28), (256, 14), (512, 7)):
+        N, G = args.batch, 4
+        nset = max(2, min(6, int(300e6 // (2 * C * N * H * H * 2)) + 1))
+        sets = [(torch.randn(N, C, H, H, device=dev).bfloat16(), torch.randn(N, C, H, H, device=dev).bfloat16(),
+                 torch.empty(N, C, H, H, device=dev).bfloat16()) for _ in range(nset)]
+        w3 = (torch.randn(C, C // G, 3, 3, device=dev) / (9 * C // G) ** 0.5).bfloat16()
+        gw3 = torch.empty_like(w3)
+        masks = torch.empty(int(L.cot_conv3x3g_masks_bytes(H, H)), dtype=torch.uint8, device=dev)
+        assert L.cot_conv3x3g_masks(P(masks), H, H, st) == 0
+        ws3 = torch.empty(int(L.cot_conv3x3g_workspace(N, C, C, G, H, H)), dtype=torch.uint8, device=dev)
+        act_bytes = 2 * N * H * H * 2 * C
+        flops = 2.0 * 9 * (C // G) * C * N * H * H
+
+        def timed3(fn):
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(args.iters):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / args.iters * 1e3
+
+        def f3(i):
+            x, gy, y = sets[i % nset]
+            assert L.cot_conv3x3g_forward(P(x), P(w3), P(y), P(masks), P(ws3), N, C, C, G, H, H, BF, st) == 0, L.cot_last_error()
+
+        def d3(i):
+            x, gy, y = sets[i % nset]
+            assert L.cot_conv3x3g_backward_data(P(gy), P(w3), P(y), 0, P(masks), P(ws3), N, C, C, G, H, H, BF, st) == 0
+
+        def w3g(i):
+            x, gy, y = sets[i % nset]
+            assert L.cot_conv3x3g_backward_weight(P(gy), P(x), P(gw3), P(masks), P(ws3), N, C, C, G, H, H, BF, st) == 0
+
+        for gen in [int(m) for m in args.modes.split(",")]:
+            assert L.cot_set_tuning(15, gen) == 0
+            tf, td, tw = timed3(f3), timed3(d3), timed3(w3g)
+            pf, pd, pw = (100 * act_bytes / (t * 1e-6) / 8e12 for t in (tf, td, tw))
+            name = f"C{C} g4 {H}x{H}"
+            print(f"{name:26s} {gen:3d} {tf:8.1f} {pf:6.1f} {flops / (tf * 1e-6) / 1e12:6.0f} | {td:8.1f} {pd:6.1f} | {tw:8.1f} {pw:6.1f}", flush=True)
+            rows.append({"shape": "conv3x3g " + name, "gen": gen, "fwd_us": round(tf, 2), "dgrad_us": round(td, 2),
+                         "wgrad_us": round(tw, 2), "fwd_frac_hbm": round(pf / 100, 4), "dgrad_frac_hbm": round(pd / 100, 4),
+                         "wgrad_frac_hbm": round(pw / 100, 4), "fwd_tflops": round(flops / (tf * 1e-6) / 1e12, 1)})
+        L.cot_set_tuning(15, 1)
     if args.json:
         json.dump(rows, open(args.json, "w"), indent=1)
 

@@ -160,7 +160,9 @@ if __name__ == "__main__":
                   (1, 64, 40, 20, 20, 0), (3, 64, 72, 14, 14, 32), (8, 32, 24, 7, 7, 0), (1, 96, 136, 1, 80, 0),
                   (2, 32, 32, 16, 24, 0)]:
         conv1x1(*shape)
-    for shape in [(2, 64, 4, 8, 16), (2, 32, 4, 14, 14), (8, 64, 8, 7, 7), (1, 256, 4, 5, 4), (8, 16, 2, 1, 3)]:
+    for shape in [(2, 64, 4, 8, 16), (2, 32, 4, 14, 14), (8, 64, 8, 7, 7), (1, 256, 4, 5, 4), (8, 16, 2, 1, 3),
+                  # LDS kernels: BIG with row tiles whose halo runs past both ends of the tensor, FLAT with a partial image group
+                  (1, 128, 4, 30, 20), (1, 64, 4, 24, 24), (3, 256, 4, 7, 7)]:
         conv3x3(*shape)
     for shape in [(2, 2, 8, 8), (2, 1, 14, 14), (8, 2, 7, 7), (1, 1, 56, 56), (8, 2, 3, 5)]:
         gn9(*shape)

@@ -703,6 +703,65 @@ def test_conv3x3_grouped_mfma_kernels(N, C, G, H, W, splits):
     assert _EMUL.cot_set_tuning(11, 2048) == 0
 
 
+@pytest.mark.parametrize("N,C,G,H,W", [
+    (1, 64, 4, 24, 24),    # BIG, Kc = Mg = 16 (two taps per K step), two row tiles of 12 rows
+    (1, 128, 4, 30, 20),   # BIG, Kc = 32, three row tiles (14, 14, 2 rows): halo rows past the image at both ends
+    (2, 256, 4, 14, 14),   # FLAT, Kc = 64: two channel chunks x 9 taps, one image per workgroup
+    (3, 512, 4, 7, 7),     # FLAT, Kc = 128: four chunks (the X double buffer wraps), 7x7
+    (5, 128, 4, 8, 8),     # FLAT, several images per workgroup?  (N*G small: one image each) + HW = 64
+])
+def test_conv3x3_grouped_lds_kernels(N, C, G, H, W):
+    """csrc/conv_lds.hip conv3x3g_lds_fwd (forward and data gradient incl. accumulate) against torch on the same rounded
+    operands, and against the first-generation kernel"""
+    torch.manual_seed(17)
+    x = torch.randn(N, C, H, W).bfloat16()
+    w = (torch.randn(C, C // G, 3, 3) / (9 * C // G) ** 0.5).bfloat16()
+    gy = torch.randn(N, C, H, W).bfloat16()
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    yref = torch.nn.functional.conv2d(xf, wf, None, 1, 1, 1, G)
+    yref.backward(gy.float())
+    dt = _lib.dtype_code(torch.bfloat16)
+    masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert _EMUL.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    ws = torch.empty(_EMUL.cot_conv3x3g_workspace(N, C, C, G, H, W), dtype=torch.uint8)
+    outs = []
+    for gen in (1, 0):
+        assert _EMUL.cot_set_tuning(15, gen) == 0
+        y = torch.full_like(x, float("nan"))
+        assert _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0, _EMUL.cot_last_error()
+        gx = torch.full_like(x, float("nan"))
+        assert _EMUL.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), 0, P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
+        base = torch.randn(N, C, H, W).bfloat16()
+        ga = base.clone()
+        assert _EMUL.cot_conv3x3g_backward_data(P(gy), P(w), P(ga), 1, P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
+        assert torch.allclose(y.float(), yref.detach(), atol=2e-2, rtol=2e-2), (gen, (y.float() - yref).abs().max())
+        assert torch.allclose(gx.float(), xf.grad, atol=3e-2, rtol=2e-2), (gen, (gx.float() - xf.grad).abs().max())
+        assert torch.allclose(ga.float(), base.float() + xf.grad, atol=6e-2, rtol=2e-2), gen
+        outs.append((y, gx))
+    assert _EMUL.cot_set_tuning(15, 1) == 0
+    assert (outs[0][0].float() - outs[1][0].float()).abs().max() <= 2e-2 * yref.abs().max()
+
+
+def test_conv3x3_lds_masks_by_selection():
+    """the LDS kernel's masked taps read neighbouring channels / rows: a NaN channel next door must not leak"""
+    torch.manual_seed(18)
+    N, C, G, H, W = 2, 64, 2, 4, 8
+    Kc = C // G
+    x = torch.randn(N, C, H, W).bfloat16()
+    x[:, Kc - 1] = float("nan")   # last channel of group 0: group 1's shifted reads run across it
+    w = (torch.randn(C, Kc, 3, 3) / 17).bfloat16()
+    yref = torch.nn.functional.conv2d(x[:, Kc:].float(), w[Kc:].float(), None, 1, 1)
+    dt = _lib.dtype_code(torch.bfloat16)
+    masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert _EMUL.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    ws = torch.empty(_EMUL.cot_conv3x3g_workspace(N, C, C, G, H, W), dtype=torch.uint8)
+    y = torch.empty(N, C, H, W).bfloat16()
+    assert _EMUL.cot_set_tuning(15, 1) == 0
+    assert _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
+    assert torch.isnan(y[:, :Kc].float()).all()
+    assert torch.allclose(y[:, Kc:].float(), yref, atol=2e-2, rtol=2e-2)
+
+
 def test_conv3x3_grouped_unequal_channels_and_nan_neighbours():
     """Cin != Cout; and the last channel of group 0 is all NaN.  Group 1 never depends on it, but its shifted wide loads
     for the taps above / left of the image run across that channel's rows in memory: the masked taps must be removed by
