@@ -70,9 +70,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                  : "v"(gsrc), "s"(dst)
                  : "memory");
 }
+// ds_read_b64_tr_b16: every lane passes the address of 4 consecutive bf16 (8-byte aligned); within each group of 16 lanes,
+// lane L (0..15) pointing at row (L>>2), columns 4*(L&3).. of a 4 x 16 block receives rows 0..3 of column L -- a free 4x4
+// transposition (mapping confirmed on the MI355X by scripts/ubench_trprobe.py).  Two of them build the 8-deep K fragment of
+// a K-strided operand that otherwise takes eight 2-byte reads and four permutes.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ s16x4_t lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+}
+#define COT_LDS_READ_TR16(p) cot::lds_read_tr16((p))
 #define COT_GLDS16(gptr, lds_wave_base) cot::glds16((gptr), (lds_wave_base))
 #define COT_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #define COT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #endif
 
 // `ahead` stages (G copies each, per wave) were issued after the one about to be read: leave exactly those in flight
@@ -211,7 +222,9 @@ struct C1LdsArgs {
 // WAVES = 4 or 8 waves per workgroup.  With 8 (two per SIMD, from the same workgroup) one wave's LDS round trips -- the
 // fragment gathers of a K step, ~10 dependent batches -- hide behind the other's MFMAs; with 4 and one workgroup per CU
 // (the deep-K layers) they are fully exposed: measured 1.2 us per K step for 0.25 us of MFMA work.
-template <int CB, int MB, int FLAT, int NS, int WAVES>
+// TRD = 1: the X fragments come from two transposing reads (needs 4-column groups that are 8-byte aligned and inside one
+// image: always true for BIG, H*W % 4 == 0 for FLAT); TRD = 0: eight 2-byte reads (any H*W, e.g. 7 x 7).
+template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
     constexpr int NT = 64 * WAVES;
     constexpr int BPX = 16 * WAVES * CB, BM = 16 * MB, BK = 32;
@@ -301,13 +314,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
     int aoff[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
-        const int col = (wave * CB + cb) * 16 + i16;
+        // TRD: this lane points at row 8g + (i16 >> 2) (+4 for the second read), columns 4*(i16 & 3) .. +3 of the block
+        const int col = (wave * CB + cb) * 16 + (TRD ? 4 * (i16 & 3) : i16);
+        const int row = TRD ? 8 * g + (i16 >> 2) : 8 * g;
         if (FLAT) {
-            const int cc = min(col, a.ni * HW - 1);  // columns past the tile: any staged element
+            const int cc = min(col, a.ni * HW - (TRD ? 4 : 1));  // columns past the tile: any staged element
             const int img = cc / HW;
-            aoff[cb] = img * BK * HW + (cc - img * HW) + 8 * g * HW;
+            aoff[cb] = img * BK * HW + (cc - img * HW) + row * HW;
         } else {
-            aoff[cb] = col + 8 * g * BPX;
+            aoff[cb] = col + row * BPX;
         }
     }
     const int rs = FLAT ? HW : BPX;  // row (= k) stride of the X stage
@@ -338,13 +353,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             const uint16_t* p = xb + aoff[cb];
-            u16x2_t q4[4];
+            if (TRD) {
+                s16x4_t lo = COT_LDS_READ_TR16(p), hi = COT_LDS_READ_TR16(p + 4 * rs);
+                __builtin_memcpy(&af[cb], &lo, 8);
+                __builtin_memcpy(reinterpret_cast<char*>(&af[cb]) + 8, &hi, 8);
+            } else {
+                u16x2_t q4[4];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                q4[h][0] = p[(2 * h) * rs];
-                q4[h][1] = p[(2 * h + 1) * rs];
+                for (int h = 0; h < 4; ++h) {
+                    q4[h][0] = p[(2 * h) * rs];
+                    q4[h][1] = p[(2 * h + 1) * rs];
+                }
+                __builtin_memcpy(&af[cb], q4, 16);
             }
-            __builtin_memcpy(&af[cb], q4, 16);
         }
 #pragma unroll
         for (int mbk = 0; mbk < MB; ++mbk) {
@@ -669,7 +690,7 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
 // [1] images per workgroup in FLAT mode (0 = auto), [2] reserved
 int g_conv_lds_tune[3] = {1, 0, 0};
 
-template <int CB, int MB, int FLAT, int NS, int WAVES>
+template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD>
 static int launch_c1(const C1LdsArgs& a, int tiles, hipStream_t stream) {
     constexpr int NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB;
     constexpr int XST = ((32 * BPX / 8 + NT - 1) / NT) * NT * 8, WST = ((BM * 4 + NT - 1) / NT) * NT * 8;
@@ -682,13 +703,13 @@ static int launch_c1(const C1LdsArgs& a, int tiles, hipStream_t stream) {
     if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation (160 KB per CU on gfx950)
         static bool raised = false;
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES, TRD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipGetLastError();
             raised = true;
         }
     }
-    COT_LAUNCH((conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
+    COT_LAUNCH((conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES, TRD>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
     return check_launch("conv1x1_lds_fwd");
 }
 
@@ -709,14 +730,23 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int 
     a.y1 = (bf16_t*)y1; a.y2 = (bf16_t*)y2;
     a.k1 = x2 ? k1 : K; a.m1 = y2 ? m1 : M; a.N = N; a.K = K; a.M = M; a.HW = HW; a.accumulate = accumulate;
     a.ni = 1; a.xcd_remap = 0; a.wpacked = wpacked;
-    const int w8 = g_conv_lds_tune[2];  // tuning key 17: 0 = default (8-wave workgroups), 1 = 4-wave workgroups (A/B)
+    const int w4 = g_conv_lds_tune[2] & 1;     // tuning key 17 bit 0: 4-wave workgroups (A/B; default 8 waves)
+    const int u16 = (g_conv_lds_tune[2] >> 1) & 1;  // bit 1: 2-byte gathers everywhere (A/B; default: transposing reads)
+#define COT_C1(CB4, CB8, MB_, FLAT_, NS_)                                                                   \
+    do {                                                                                                   \
+        if (w4) return tr ? launch_c1<CB4, MB_, FLAT_, NS_, 4, 1>(a, tiles, stream)                        \
+                          : launch_c1<CB4, MB_, FLAT_, NS_, 4, 0>(a, tiles, stream);                       \
+        return tr ? launch_c1<CB8, MB_, FLAT_, NS_, 8, 1>(a, tiles, stream)                                \
+                  : launch_c1<CB8, MB_, FLAT_, NS_, 8, 0>(a, tiles, stream);                               \
+    } while (0)
     if (HW > 256) {  // BIG: 128-pixel tiles of one image; three stages, several workgroups per CU
         a.ptiles = ceil_div(HW, 128);
         const int tiles = N * a.ptiles;
-        if (M <= 32) { a.mblocks = 1; return w8 ? launch_c1<2, 2, 0, 3, 4>(a, tiles, stream) : launch_c1<1, 2, 0, 3, 8>(a, tiles, stream); }
-        if (M <= 64) { a.mblocks = 1; return w8 ? launch_c1<2, 4, 0, 3, 4>(a, tiles, stream) : launch_c1<1, 4, 0, 3, 8>(a, tiles, stream); }
+        const bool tr = !u16;
+        if (M <= 32) { a.mblocks = 1; COT_C1(2, 1, 2, 0, 3); }
+        if (M <= 64) { a.mblocks = 1; COT_C1(2, 1, 4, 0, 3); }
         a.mblocks = ceil_div(M, 128);
-        return w8 ? launch_c1<2, 8, 0, 3, 4>(a, tiles, stream) : launch_c1<1, 8, 0, 3, 8>(a, tiles, stream);
+        COT_C1(2, 1, 8, 0, 3);
     }
     // FLAT: whole images, up to 256 columns per workgroup, up to 128 channels.  These are the deep-K layers with few
     // workgroups (one per CU at best): six stages, five of them in flight per workgroup
@@ -725,10 +755,13 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int 
     if (ni < 1 || ni * HW > 256) return -1;
     a.ni = ni;
     a.ptiles = ceil_div(N, ni);
-    if (M <= 32) { a.mblocks = 1; return w8 ? launch_c1<4, 2, 1, 6, 4>(a, a.ptiles, stream) : launch_c1<2, 2, 1, 6, 8>(a, a.ptiles, stream); }
-    if (M <= 64) { a.mblocks = 1; return w8 ? launch_c1<4, 4, 1, 6, 4>(a, a.ptiles, stream) : launch_c1<2, 4, 1, 6, 8>(a, a.ptiles, stream); }
+    const int tiles = a.ptiles;
+    const bool tr = !u16 && HW % 4 == 0;
+    if (M <= 32) { a.mblocks = 1; COT_C1(4, 2, 2, 1, 6); }
+    if (M <= 64) { a.mblocks = 1; COT_C1(4, 2, 4, 1, 6); }
     a.mblocks = ceil_div(M, 128);
-    return w8 ? launch_c1<4, 8, 1, 6, 4>(a, a.ptiles, stream) : launch_c1<2, 8, 1, 6, 8>(a, a.ptiles, stream);
+    COT_C1(4, 2, 8, 1, 6);
+#undef COT_C1
 }
 
 }  // namespace cot

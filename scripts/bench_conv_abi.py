@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--json", default="")
     ap.add_argument("--modes", default="0,1")
+    ap.add_argument("--only", default="", help="substring filter on the shape name (e.g. 's4 conv1')")
     args = ap.parse_args()
     L = _lib.lib()
     dev = torch.device("cuda:0")
@@ -63,6 +64,8 @@ def main():
     rows = []
     print(f"{'shape':26s} {'gen':3s} {'fwd us':>8s} {'%HBM':>6s} {'TF/s':>6s} | {'dgrad us':>8s} {'%HBM':>6s} | {'wgrad us':>8s} {'%HBM':>6s}")
     for name, Ci, Co, H, split, bias in SHAPES:
+        if args.only and args.only not in name:
+            continue
         N, HW = (args.batch, H * H) if H else (1, args.batch)
         nset = max(2, min(6, int(300e6 // ((Ci + Co) * N * HW * 2)) + 1))  # rotate through > 256 MiB where it fits
         sets = []
@@ -128,6 +131,8 @@ def main():
     # ---- grouped 3x3 key-embed convolutions (CoTNet-50: groups 4)
     print(f"\n{'grouped 3x3':26s} {'gen':3s} {'fwd us':>8s} {'%HBM':>6s} {'TF/s':>6s} | {'dgrad us':>8s} {'%HBM':>6s} | {'wgrad us':>8s} {'%HBM':>6s}")
     for C, H in ((64, 56), (128, 28), (256, 14), (512, 7)):
+        if args.only and args.only not in f"C{C} g4":
+            continue
         N, G = args.batch, 4
         nset = max(2, min(6, int(300e6 // (2 * C * N * H * H * 2)) + 1))
         sets = [(torch.randn(N, C, H, H, device=dev).bfloat16(), torch.randn(N, C, H, H, device=dev).bfloat16(),

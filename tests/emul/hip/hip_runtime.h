@@ -249,6 +249,25 @@ namespace cot { alignas(16) inline thread_local char cot_smem[160 * 1024]; }  //
 // is the block barrier (so the emulation checks index arithmetic and barrier placement, not the vmcnt arithmetic)
 #define COT_GLDS16(gptr, lds_wave_base) \
     std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)
+// ds_read_b64_tr_b16 (mapping measured on the MI355X, scripts/ubench_trprobe.py): within each group of 16 lanes, lane Li
+// receives element (Li & 3) of the four lanes 4e + (Li >> 2), e = 0..3
+typedef __attribute__((ext_vector_type(4))) short emul_s16x4;
+inline emul_s16x4 emul_read_tr16(const void* p) {
+    emul::Sched& S = *emul::t_sched;
+    uint64_t mine;
+    std::memcpy(&mine, p, 8);
+    S.slot[emul::t_wave][emul::t_lane] = mine;
+    emul::wave_barrier();
+    const int base = emul::t_lane & ~15, Li = emul::t_lane & 15;
+    emul_s16x4 r;
+    for (int e = 0; e < 4; ++e) {
+        const uint64_t v = S.slot[emul::t_wave][base + 4 * e + (Li >> 2)];
+        r[e] = (short)((v >> (16 * (Li & 3))) & 0xffff);
+    }
+    emul::wave_barrier();
+    return r;
+}
+#define COT_LDS_READ_TR16(p) emul_read_tr16((p))
 #define COT_WAIT_VM(N) ((void)0)
 #define COT_LDS_BARRIER() emul::block_barrier()
 

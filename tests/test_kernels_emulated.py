@@ -534,7 +534,7 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
     (5, 32, 16, 8, 8, 0, False),      # FLAT: HW = 64, four images per workgroup + one left over
     (2, 160, 72, 14, 14, 0, False),   # FLAT: five K steps (pipeline wraps), M = 72
 ])
-@pytest.mark.parametrize("waves4", [0, 1])
+@pytest.mark.parametrize("waves4", [0, 1, 2])  # cot_set_tuning(17): bit 0 = 4-wave workgroups, bit 1 = 2-byte gathers instead of transposing reads
 def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias, waves4):
     """second-generation 1x1 kernels (csrc/conv_lds.hip): every case satisfies K % 32 == 0 so the LDS path is the one
     that runs (cot_last_kernel is checked); forward, data gradient (through the transposed-weight workspace), the
