@@ -98,7 +98,7 @@ int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int,
 int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
 int ema_flat(void*, const void*, int64_t, float, int, hipStream_t);
 int bn_workspace_floats(int N, int C);
-extern int g_bn_fold, g_bn_grid_cap;
+extern int g_bn_fold, g_bn_grid_cap, g_bn_small_m;
 template <typename T>
 int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, long long*,
                    float*, int, int, int, float, float, int, hipStream_t);
@@ -271,6 +271,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key >= 15 && key <= 17) {
         g_conv_lds_tune[key - 15] = value;
+        return COT_OK;
+    }
+    if (key == 18) {
+        g_bn_small_m = value > 0 ? value : 0;
         return COT_OK;
     }
     if (key == 13) {

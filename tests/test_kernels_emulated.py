@@ -30,11 +30,16 @@ def P(t):
 
 @pytest.fixture(autouse=True)
 def _default_knobs():
+    # the emulated tests use tensors of a few hundred samples per channel: keep them on the STREAMING BatchNorm kernels
+    # (the fp64 small-batch path, cot_set_tuning(18), has its own test below)
+    if _EMUL is not None:
+        _EMUL.cot_set_tuning(18, 0)
     yield
     if _EMUL is not None:  # process-global developer knobs back to their defaults after every test
         _EMUL.cot_set_tuning(10, 0)
         _EMUL.cot_set_tuning(11, 2048)
         _EMUL.cot_set_tuning(12, 0)
+        _EMUL.cot_set_tuning(18, 4096)
 
 
 def to_layout(t, layout):
@@ -358,6 +363,49 @@ def test_ring_depth_choice_does_not_change_results(H):
         assert torch.equal(a, b)
     ref = torch.nn.functional.conv2d(x.float(), w3.float(), None, 1, 1, 1, G)
     assert ((outs[0][2].float() - ref).abs() <= 2e-2 * (ref.abs() + ref.abs().mean())).all()
+
+
+@pytest.mark.parametrize("N,C,H,W,act,use_res", [(2, 32, 1, 1, 1, False), (2, 5, 1, 1, 0, False), (80, 16, 1, 1, 1, False),
+                                                  (3, 4, 5, 5, 2, False), (4, 3, 2, 3, 1, True)])
+def test_bn_small_batch_fp64_path(N, C, H, W, act, use_res):
+    """csrc/bn_act.hip "small batches": the CoT layer's se branch normalises over the batch alone (2 samples per channel
+    in the 7x7 fixture).  Against an fp64 evaluation; the 2-sample input gradient -- catastrophic cancellation in fp32 --
+    must come out at fp32-rounding accuracy of the fp64 result, not at the 1e-3 relative level MIOpen's kernel shows."""
+    assert _EMUL.cot_set_tuning(18, 4096) == 0
+    g = torch.Generator().manual_seed(N + 7 * C)
+    x = torch.randn(N, C, H, W, generator=g) * (0.05 if N == 2 else 1.0) + 0.3   # small variance: rstd ~ 20 .. 300
+    res = torch.randn(N, C, H, W, generator=g) if use_res else None
+    dy = torch.randn(N, C, H, W, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if use_res else None
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    z = torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    if use_res:
+        z = z + rr
+    yr = (torch.relu(z) if act == 1 else torch.nn.functional.silu(z) if act == 2 else z)
+    yr.backward(dy.double())
+    mean, rstd, dg, db = (torch.empty(C) for _ in range(4))
+    rm, rv, nbt = torch.zeros(C), torch.ones(C), torch.zeros((), dtype=torch.int64)
+    ws = torch.empty(max(1, _EMUL.cot_bn_act_workspace(N, C)))
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    dres = torch.empty_like(x) if use_res else None
+    assert _EMUL.cot_bn_act_forward(P(x), P(res) if use_res else None, P(y), P(gamma), P(beta), P(mean), P(rstd), P(rm), P(rv),
+                                    P(nbt), P(ws), N, C, H * W, 1e-5, 0.1, act, 0, None) == 0, _EMUL.cot_last_error()
+    assert _EMUL.cot_bn_act_backward(P(dy), P(x), P(y), P(dx), P(dres) if use_res else None, P(gamma), P(beta), P(mean),
+                                     P(rstd), P(dg), P(db), P(ws), N, C, H * W, act, 0, None) == 0
+    assert int(nbt) == 1
+    scale = xr.grad.abs().max().item()
+    assert (y.double() - yr.detach()).abs().max() <= 1e-6 * (1 + yr.abs().max().item())
+    assert (dx.double() - xr.grad).abs().max() <= 2e-6 * scale + 1e-6, ((dx.double() - xr.grad).abs().max().item(), scale)
+    assert (dg.double() - gr.grad).abs().max() <= 1e-5 * (1 + gr.grad.abs().max().item())
+    assert (db.double() - br.grad).abs().max() <= 1e-5 * (1 + br.grad.abs().max().item())
+    M = N * H * W
+    xm = x.double().transpose(0, 1).reshape(C, -1)
+    assert torch.allclose(rm.double(), 0.1 * xm.mean(1), atol=1e-6)
+    assert torch.allclose(rv.double(), 0.9 + 0.1 * (xm.var(1, unbiased=True) if M > 1 else xm.var(1, unbiased=False)), atol=1e-6)
+    if use_res:
+        assert (dres.double() - rr.grad).abs().max() <= 1e-6 * (1 + rr.grad.abs().max().item())
 
 
 @pytest.mark.parametrize("cap", [1, 2, 3, 7])

@@ -32,11 +32,11 @@ def test_layer_matches_reference_fixture(name, memory_format):
         xin = x.to(DEV).contiguous(memory_format=mf).requires_grad_(True)
         y = layer(xin)
         y.backward(gout.to(DEV))
-        # BASELINE bar 1e-3; the 7x7 train-mode case normalises over 98 samples per channel and its input gradient
-        # moves by 1.6e-3 between MIOpen's and the CPU's fp32 convolutions (operator-level parity is 2e-5), so it
-        # gets 1e-2 (measured 1.6e-3 with MIOpen's BatchNorm, 4.6e-3 with the fused BN kernels, whose own parity with
-        # torch is 2e-5 in tests/test_fused_bn_gpu.py) -- the fp64 run below pins the same layer to 1e-9.
-        tol = 1e-2 if (mode == "train" and meta["H"] == 7) else 1e-3
+        # BASELINE bar 1e-3, every geometry.  (Round 1 had widened it to 1e-2 for the 7x7 train-mode case and blamed the
+        # fused BatchNorm kernels; the real cause, found with scripts/diag_7x7.py, was the se branch's BatchNorm over a
+        # batch of TWO samples, where MIOpen's fp32 kernel is 300x off an fp64 evaluation -- csrc/bn_act.hip now takes an
+        # fp64 path for such batches.)
+        tol = 1e-3
         assert (y.detach().cpu() - torch.from_numpy(gold[f"{mode}_y"])).abs().max() < tol
         assert (xin.grad.cpu() - torch.from_numpy(gold[f"{mode}_gx"])).abs().max() < tol
         for key, p in (("g_embed3_w", layer.embed[3].weight), ("g_key0_w", layer.key_embed[0].weight),
