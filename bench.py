@@ -60,10 +60,6 @@ def parse():
                          "autocast: fp32 weights under torch.autocast + torch.optim.SGD")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc"])
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
-    ap.add_argument("--graph", action="store_true",
-                    help="mixed precision only: capture forward+backward in a HIP graph (cotnet_amd.graph_step). OFF by "
-                         "default: MIOpen's split-K weight-gradient solvers accumulate into buffers that are zeroed outside "
-                         "the captured stream, so replays after the first double-count (measured, DESIGN.md 5.3)")
     ap.add_argument("--deterministic", action="store_true", help="torch.backends.cudnn.deterministic = True")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -177,9 +173,8 @@ def roctx_window(resume):
 
 
 KERNEL_SETS = {  # name -> (single-node layers, 1x1 mode, 3x3 mode, GroupNorm9 mode, cot_set_tuning(12) BatchNorm finalize fold)
-    "round1": (False, "", "", "", 0),
-    "new": (True, "hip", "hip", "hip", 0),
-    "new+bnfold": (True, "hip", "hip", "hip", 1),
+    "round1": (False, "", "", "", 0),       # MIOpen convolutions, torch GroupNorm, one autograd node per op
+    "new": (True, "hip", "hip", "hip", 0),  # every kernel of the step from cotnet_amd/csrc, one node per Bottleneck
 }
 
 
@@ -336,66 +331,8 @@ def probe_child(args, dev=None, make_model=None, warm=4, timed=8):
                 torch.cuda.empty_cache()
         except Exception as e:  # a kernel set that cannot run is simply not eligible
             out["sets"][name] = {"parity": False, "error": f"{type(e).__name__}: {e}"[:300]}
-    if dev.type == "cuda" and not getattr(args, "no_graph_probe", False):
-        try:  # the same step replayed from a HIP graph, on the fastest verified kernel set
-            ok = {n: v["ms_per_step"] for n, v in out["sets"].items() if v.get("parity") and "ms_per_step" in v}
-            if ok:
-                best = min(ok, key=ok.get)
-                out["sets"][best + "+graph"] = probe_graph(best, make_model, dev, x, t, timed)
-        except Exception as e:
-            out["graph_error"] = f"{type(e).__name__}: {e}"[:300]
     print("PROBE_RESULT " + json.dumps(out), flush=True)
     return out
-
-
-def probe_graph(name, make_model, dev, x, t, timed):
-    """HIP-graph replay of the step against the eager step, in lock-step from identical weights: after EVERY one of six
-    replays the flat gradient buckets must match the eager ones (round 1 found replays that were right once and wrong
-    afterwards, DESIGN.md 5.3 -- this is the test for exactly that), then the replay is timed."""
-    from cotnet_amd.flat_sgd import FlatSGD, to_mixed_bf16
-    from cotnet_amd.graph_step import GraphedTrainStep
-    apply_kernel_set(name)
-
-    def loss_fn(o, tt):
-        return torch.nn.functional.cross_entropy(o.float(), tt)
-
-    pair = []
-    for _ in range(2):
-        m = probe_model(make_model, dev, 4321).train()
-        pair.append((m, FlatSGD(m, lr=1e-3, momentum=0.9, weight_decay=4e-5, nesterov=True)))
-    (me, oe), (mg, og) = pair
-    for _ in range(3):  # the graph's constructor runs three eager warm-up steps: keep the eager twin in step
-        oe.zero_grad()
-        loss_fn(me(x), t).backward()
-        oe.step()
-    gstep = GraphedTrainStep(mg, og, loss_fn, x, t, warmup=3)
-    worst, per_replay = 0.0, []
-    for _ in range(6):
-        oe.zero_grad()
-        loss_fn(me(x), t).backward()
-        oe.reducer.finish()
-        ge = [b.flat.float().clone() for b in oe.reducer.buckets]
-        gstep.graph.replay()
-        gg = [b.flat.float() for b in og.reducer.buckets]
-        torch.cuda.synchronize()
-        diffs = []
-        for a, b in zip(ge, gg):
-            if not torch.isfinite(b).all():
-                return {"parity": False, "error": "non-finite gradients from a graph replay", "per_replay": per_replay}
-            diffs.append(round(float((a - b).abs().mean() / (a.abs().mean() + 1e-12)), 4))
-        per_replay.append(diffs)  # one number per gradient bucket (bucket 0 is filled first: fc, layer4, ...)
-        worst = max(worst, max(diffs))
-        oe.step(graphed=True)  # (finish() already ran: a second one would refill the buckets from the dropped .grad's)
-        og.step(graphed=True)
-    rec = {"grad_mean_rel_diff_over_6_replays": round(worst, 4), "parity": bool(worst < 0.1), "per_replay": per_replay}
-    if rec["parity"]:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(timed):
-            gstep()
-        torch.cuda.synchronize()
-        rec["ms_per_step"] = round((time.perf_counter() - t0) / timed * 1e3, 3)
-    return rec
 
 
 def choose_kernels(args):
@@ -499,9 +436,6 @@ def main():
                     store.wait(["cot_kernel_set"], datetime.timedelta(minutes=25))
                     chosen = store.get("cot_kernel_set").decode()
         selection["chosen"] = chosen
-        if chosen.endswith("+graph"):
-            chosen = chosen[:-len("+graph")]
-            args.graph = True
         if rank == 0:
             print(f"[bench] kernel set: {chosen}  ({json.dumps(selection)[:600]})", file=sys.stderr, flush=True)
         apply_kernel_set(chosen)
@@ -525,7 +459,6 @@ def main():
     t = torch.randint(0, 1000, (B,), device=dev)
 
     mixed = amp and args.precision == "mixed"
-    graphed = False
     if mixed:
         from cotnet_amd.flat_sgd import FlatSGD, to_mixed_bf16
         to_mixed_bf16(model)
@@ -541,17 +474,6 @@ def main():
             loss.backward()
             opt.step()
             return loss
-
-        if args.graph:
-            from cotnet_amd.graph_step import GraphedTrainStep
-            try:
-                gstep = GraphedTrainStep(model, opt, lambda o, tt: torch.nn.functional.cross_entropy(o.float(), tt), x, t)
-                step = gstep
-                graphed = True
-            except Exception as e:  # keep the bench alive: report the eager number and say why
-                print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-                torch.cuda.synchronize()
-                opt.reducer.defer_comm = False
     elif args.mode == "train":
         model.train()
         opt = make_optimizer(model, lr=0.25 * B * world / 640.0, wd=4e-5)
@@ -585,8 +507,7 @@ def main():
     roctx_window(resume=True)
     # The timed region carries NO instrumentation (round 1 attached events to every dispatch inside it and gave away ~10 %
     # of the headline).  Kernel timing for the roofline object: the same step is run `timing_steps` more times right
-    # after the timed region with the library's dispatch-attached events on (identical kernels, shapes and data; a
-    # replayed HIP graph has no host-side launches to attach events to, so there the eager twin of the step is used).
+    # after the timed region with the library's dispatch-attached events on (identical kernels, shapes and data).
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -598,10 +519,9 @@ def main():
     recs, timing_steps = [], 0
     if not args.no_kernel_timing:
         timing_steps = 3
-        inst = gstep._eager if graphed else step
         agg_mod.profile_begin()
         for _ in range(timing_steps):
-            inst()
+            step()
         torch.cuda.synchronize()
         recs = agg_mod.profile_end()
     final_loss = float(loss)
@@ -667,7 +587,6 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "layout": args.layout, "precision": ("bf16 weights+activations, fp32 master weights / norm params, fused flat SGD" if mixed
                                      else "bf16 autocast, fp32 weights" if amp else "fp32"),
-                       "hip_graph": graphed,
                        "kernel_selection": selection,
                        "conv1x1": __import__("cotnet_amd.conv1x1", fromlist=["MODE"]).MODE or "module",
                        "conv3x3": __import__("cotnet_amd.conv3x3g", fromlist=["MODE"]).MODE or "module",

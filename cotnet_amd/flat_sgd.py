@@ -71,10 +71,10 @@ class FlatSGD:
     def zero_grad(self):
         self.reducer.zero_grad()
 
-    def step(self, graphed=False):
+    def step(self, deferred=False):
         """finish the gradient all-reduce (stream wait only) and update every bucket with one kernel each.
-        graphed=True: the buckets were filled by a replayed HIP graph (no Python hooks ran); all-reduce them now."""
-        if graphed:
+        deferred=True: the reducer ran with defer_comm (hooks only filled the buckets); all-reduce them now."""
+        if deferred:
             self.reducer.allreduce_all()
         else:
             self.reducer.finish()

@@ -11,7 +11,7 @@ dist.init_process_group("gloo", init_method="env://", timeout=datetime.timedelta
 store = dist.distributed_c10d._get_default_store()
 if rank == 0:
     time.sleep(1.0)  # "probing"
-    chosen = "new+bnfold+graph"
+    chosen = "new"
     store.set("cot_kernel_set", chosen)
 else:
     store.wait(["cot_kernel_set"], datetime.timedelta(minutes=2))

@@ -28,16 +28,17 @@ def _result(**sets):
 def test_faster_verified_set_wins(monkeypatch):
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("WORLD_SIZE", "8")
-    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": True, "ms_per_step": 25.0},
-                  **{"new+bnfold": {"parity": True, "ms_per_step": 24.0}})
+    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": True, "ms_per_step": 25.0})
     monkeypatch.setattr(subprocess, "run", _fake_run(out))
     name, info = bench.choose_kernels(_args())
-    assert name == "new+bnfold" and info["probe"]["new"]["ms_per_step"] == 25.0
+    assert name == "new" and info["probe"]["new"]["ms_per_step"] == 25.0
 
 
 def test_parity_failure_or_small_gain_keeps_round1(monkeypatch):
-    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": False, "ms_per_step": 20.0},
-                  **{"new+bnfold": {"parity": True, "ms_per_step": 37.5}})
+    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": False, "ms_per_step": 20.0})
+    monkeypatch.setattr(subprocess, "run", _fake_run(out))
+    assert bench.choose_kernels(_args())[0] == "round1"
+    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": True, "ms_per_step": 37.5})  # < 3 % faster
     monkeypatch.setattr(subprocess, "run", _fake_run(out))
     assert bench.choose_kernels(_args())[0] == "round1"
     out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": False, "error": "RuntimeError: x"})
@@ -71,8 +72,8 @@ def test_kernel_sets_apply_the_documented_switches(monkeypatch):
     from cotnet_amd import head_fused as hf, pool3x3 as p3, stem7x7 as s7
     for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE"), (p3, "MODE"), (hf, "MODE"), (s7, "MODE")):
         monkeypatch.setattr(mod, attr, getattr(mod, attr))  # restored after the test
-    bench.apply_kernel_set("new+bnfold")
-    assert clf.ENABLED and c1.MODE == c3.MODE == g9.MODE == "hip" and calls[-1] == (12, 1)
+    bench.apply_kernel_set("new")
+    assert clf.ENABLED and c1.MODE == c3.MODE == g9.MODE == "hip" and calls[-1] == (12, 0)
     bench.apply_kernel_set("round1")
     assert not clf.ENABLED and c1.MODE == c3.MODE == g9.MODE == "" and calls[-1] == (12, 0)
 
@@ -82,7 +83,7 @@ def test_probe_child_body_on_emulated_kernels(monkeypatch, capsys):
     host-emulated library with a two-block CoTNet: every kernel set must be as close to the fp32 truth as round1 is"""
     out = _emulated_probe(monkeypatch)
     assert "PROBE_RESULT " in capsys.readouterr().out
-    assert set(out["sets"]) == {"round1", "new", "new+bnfold"}
+    assert set(out["sets"]) == {"round1", "new"}
     for name, rec in out["sets"].items():
         assert "error" not in rec, (name, rec)
         assert rec["parity"] and rec["finite"] and rec["ms_per_step"] > 0, (name, rec)
@@ -113,9 +114,19 @@ def _emulated_probe(monkeypatch, lib_wrapper=None):
     for cache in caches:
         cache.clear()
     args = types.SimpleNamespace(batch=4, img=32, model="unused")
+
+    def make_model():
+        # 32x32 images and a batch of 4 leave 4 .. 16 samples per channel in the late BatchNorms: with the default eps the
+        # bf16 paths sit ~0.9 (pure noise) from the fp32 truth and no gate can see a defect.  A large eps bounds every rstd
+        # and brings the toy network into the regime of the real probe (thousands of samples per channel, error ~0.1).
+        m = ResNet(Bottleneck, [2, 1, 1, 1], num_classes=1000)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.eps = 0.5
+        return m
+
     try:
-        return bench.probe_child(args, dev=torch.device("cpu"), warm=1, timed=1,
-                                 make_model=lambda: ResNet(Bottleneck, [2, 1, 1, 1], num_classes=1000))
+        return bench.probe_child(args, dev=torch.device("cpu"), warm=1, timed=1, make_model=make_model)
     finally:
         tke._EMUL.cot_set_tuning(12, 0)
         for cache in caches:
@@ -143,22 +154,11 @@ def test_probe_rejects_a_kernel_set_with_a_broken_convolution(monkeypatch, capsy
     out = _emulated_probe(monkeypatch, Broken)
     capsys.readouterr()
     assert out["sets"]["round1"]["parity"]
-    for name in ("new", "new+bnfold"):
+    for name in ("new",):
         rec = out["sets"][name]
         assert "error" not in rec, rec
         assert not rec["parity"], (name, rec)
         assert rec["worst_param_ratio_to_round1"] > bench.GATE_PARAM or rec["worst_bucket_ratio_to_round1"] > bench.GATE_BUCKET
-
-
-def test_graph_variant_is_chosen_only_when_verified(monkeypatch):
-    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": True, "ms_per_step": 30.0},
-                  **{"new+graph": {"parity": True, "ms_per_step": 24.0, "grad_mean_rel_diff_over_6_replays": 0.01}})
-    monkeypatch.setattr(subprocess, "run", _fake_run(out))
-    assert bench.choose_kernels(_args())[0] == "new+graph"
-    out = _result(round1={"parity": True, "ms_per_step": 38.0}, new={"parity": True, "ms_per_step": 30.0},
-                  **{"new+graph": {"parity": False, "grad_mean_rel_diff_over_6_replays": 0.9}})
-    monkeypatch.setattr(subprocess, "run", _fake_run(out))
-    assert bench.choose_kernels(_args())[0] == "new"
 
 
 def test_verdict_reaches_every_rank_through_the_rendezvous_store():
@@ -174,4 +174,4 @@ def test_verdict_reaches_every_rank_through_the_rendezvous_store():
                        capture_output=True, text=True, timeout=180, env=env)
     assert r.returncode == 0, r.stderr[-600:]
     got = sorted(ln for ln in r.stdout.splitlines() if ln.startswith("VERDICT"))
-    assert got == ["VERDICT rank0 new+bnfold+graph", "VERDICT rank1 new+bnfold+graph"], r.stdout[-300:]
+    assert got == ["VERDICT rank0 new", "VERDICT rank1 new"], r.stdout[-300:]
