@@ -25,7 +25,7 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
-from . import _lib
+from . import _lib, grad_sink
 
 ENABLED = os.environ.get("COT_FUSED_LAYER", "") == "1"
 _DEVICE_ONLY = True  # tests drive the node on CPU tensors through the host-emulated kernels
@@ -119,12 +119,13 @@ def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act, residual=None):
 
 
 def _bn_bwd(L, dy, x, y, dx, bn, stats, N, C, HW, act, nws, dres=None):
-    """-> (dgamma, dbeta) views of one fp32 scratch"""
-    scratch = torch.empty(2 * C + nws, dtype=torch.float32, device=dy.device)
+    """-> (dgamma, dbeta): the parameters' slots in the flat gradient buckets when registered (grad_sink), else fresh"""
+    dg, db = grad_sink.out_like(bn.weight), grad_sink.out_like(bn.bias)
+    ws = torch.empty(max(nws, 1), dtype=torch.float32, device=dy.device)
     _ck(L.cot_bn_act_backward(_p(dy), _p(x), _p(y), _p(dx), _p(dres), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
-                              _p(scratch), _p(scratch[C:]), _p(scratch[2 * C:]), N, C, HW, act, BF16, _stream()),
+                              _p(dg), _p(db), _p(ws), N, C, HW, act, BF16, _stream()),
         "cot_bn_act_backward")
-    return scratch[:C], scratch[C:2 * C]
+    return dg, db
 
 
 def _cot_forward(L, layer, x):
@@ -225,14 +226,14 @@ def _cot_backward(L, layer, saved, geom, gout):
         "cot_radix_mix_backward_reduce")
     _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st),
         "cot_conv1x1_backward_data")
-    g_w3, g_b3 = torch.empty_like(se3.weight), torch.empty_like(se3.bias)
+    g_w3, g_b3 = grad_sink.out_like(se3.weight), grad_sink.out_like(se3.bias)
     _ck(L.cot_conv1x1_backward_weight(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(ws), 1, A, 2 * C, N, BF16,
                                       st), "cot_conv1x1_backward_weight")
     ghpre = row(A)
     d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, None, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
     _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st),
         "cot_conv1x1_backward_data")
-    g_w0, g_b0 = torch.empty_like(se0.weight), torch.empty_like(se0.bias)
+    g_w0, g_b0 = grad_sink.out_like(se0.weight), grad_sink.out_like(se0.bias)
     _ck(L.cot_conv1x1_backward_weight(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(ws), 1, C, A, N, BF16, st),
         "cot_conv1x1_backward_weight")
     gy, gk = torch.empty_like(y), torch.empty_like(k)
@@ -250,13 +251,13 @@ def _cot_backward(L, layer, saved, geom, gout):
     gx = torch.empty_like(x)
     _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gx), None, C, 0, _p(ws), N, C, C, HW, BF16, st),
         "cot_conv1x1_backward_data")
-    g_wv = torch.empty_like(cv0.weight)
+    g_wv = grad_sink.out_like(cv0.weight)
     _ck(L.cot_conv1x1_backward_weight(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(ws), N, C, C, HW, BF16, st),
         "cot_conv1x1_backward_weight")
     # logits branch: GroupNorm, conv1x1(+bias), bn+relu, conv1x1 on [x | k] -> dx +=, dk +=
     gn = pl.gn
     if HW <= 8192:
-        ge3, g_gn_w, g_gn_b = torch.empty_like(e3), torch.empty_like(gn.weight), torch.empty_like(gn.bias)
+        ge3, g_gn_w, g_gn_b = torch.empty_like(e3), grad_sink.out_like(gn.weight), grad_sink.out_like(gn.bias)
         gn_ws = torch.empty(2 * N * Ce, dtype=torch.float32, device=dev)
         _ck(L.cot_group_norm9_backward(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), _p(g_gn_w),
                                        _p(g_gn_b), _p(gn_ws), N, Ce, HW, BF16, st), "cot_group_norm9_backward")
@@ -267,14 +268,14 @@ def _cot_backward(L, layer, saved, geom, gout):
     ge1 = torch.empty_like(e1)
     _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), N, Ch, Ce, HW, BF16,
                                     st), "cot_conv1x1_backward_data")
-    g_we3, g_be3 = torch.empty_like(em3.weight), torch.empty_like(em3.bias)
+    g_we3, g_be3 = grad_sink.out_like(em3.weight), grad_sink.out_like(em3.bias)
     _ck(L.cot_conv1x1_backward_weight(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(ws), N, Ch, Ce, HW, BF16,
                                       st), "cot_conv1x1_backward_weight")
     ge0 = torch.empty_like(e0)
     d_em_w, d_em_b = _bn_bwd(L, ge1, e0, None, ge0, em1, s_e, N, Ch, HW, 1, nws_h)  # (ReLU mask recomputed from e0)
     _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gx), _p(gk), C, 3, _p(ws), N, 2 * C, Ch, HW, BF16,
                                     st), "cot_conv1x1_backward_data")
-    g_we0 = torch.empty_like(em0.weight)
+    g_we0 = grad_sink.out_like(em0.weight)
     _ck(L.cot_conv1x1_backward_weight(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(ws), N, 2 * C, Ch, HW, BF16, st),
         "cot_conv1x1_backward_weight")
     # key branch: bn+relu, grouped 3x3 -> dx +=
@@ -283,7 +284,7 @@ def _cot_backward(L, layer, saved, geom, gout):
     G = ke0.groups
     _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx), 1, _p(masks), _p(ws), N, C, C, G, H, W,
                                      BF16, st), "cot_conv3x3g_backward_data")
-    g_wk = torch.empty_like(ke0.weight)
+    g_wk = grad_sink.out_like(ke0.weight)
     _ck(L.cot_conv3x3g_backward_weight(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(ws), N, C, C, G, H, W, BF16, st),
         "cot_conv3x3g_backward_weight")
     # order = _Plan.params
@@ -459,7 +460,7 @@ class _BottleneckNode(Function):
         g_cot_out = torch.empty_like(cot_out)
         _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_cot_out), None, Cw, 0, _p(ws), N, Cw, Cout, HWo,
                                         BF16, st), "cot_conv1x1_backward_data")
-        g_w3 = torch.empty_like(bp.conv3.weight)
+        g_w3 = grad_sink.out_like(bp.conv3.weight)
         _ck(L.cot_conv1x1_backward_weight(_p(g_c3), _p(cot_out), None, Cw, _p(g_w3), None, _p(ws), N, Cw, Cout, HWo, BF16,
                                           st), "cot_conv1x1_backward_weight")
         g_p1, g_cot = _cot_backward(L, bp.cot, saved, ctx.geom, g_cot_out)
@@ -486,7 +487,7 @@ class _BottleneckNode(Function):
                 gx = torch.empty_like(x)
                 _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(gx), None, Cin, 0, _p(ws), N, Cin,
                                                 Cout, HWo, BF16, st), "cot_conv1x1_backward_data")
-            g_wd = torch.empty_like(bp.ds_conv.weight)
+            g_wd = grad_sink.out_like(bp.ds_conv.weight)
             _ck(L.cot_conv1x1_backward_weight(_p(g_d0), _p(xs), None, Cin, _p(g_wd), None, _p(ws), N, Cin, Cout, HWo, BF16,
                                               st), "cot_conv1x1_backward_weight")
             g_ds = (g_wd, d_ds_w, d_ds_b)
@@ -494,7 +495,7 @@ class _BottleneckNode(Function):
             gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
         _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16,
                                         st), "cot_conv1x1_backward_data")
-        g_w1 = torch.empty_like(bp.conv1.weight)
+        g_w1 = grad_sink.out_like(bp.conv1.weight)
         _ck(L.cot_conv1x1_backward_weight(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(ws), N, Cin, Cw, HW, BF16, st),
             "cot_conv1x1_backward_weight")
         return (None, gx, g_w1, d_bn1_w, d_bn1_b) + g_cot + (g_w3, d_bn3_w, d_bn3_b) + g_ds

@@ -686,6 +686,170 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
     return launch_c3<4, 8, 0, 0, 5>(a, blocks, stream);
 }
 
+// ====================================================================================================================
+// 1x1 weight gradient on the same machinery:  dW[m][j] = sum over (n, p) of dY[n][m][p] * X[n][j][p]  (+ db[m] = sum dY).
+// Both operands are contiguous along the reduction index (pixels), so both fragments are 16-byte LDS reads; what the
+// first-generation kernel (conv1x1.hip) lacks is sharing: every wave fetched its own fragment-shaped pieces (16 rows x 64 B
+// per instruction) from global memory, and the counters show it stalled on instruction issue behind the vector-memory
+// pipe for half its cycles.  Here a workgroup (8 waves, 2 x 4) owns a 128 x 128 tile of dW and a slice of the reduction;
+// each K step copies 128 rows x 32 pixels of dY and of X into LDS with full 16-byte pieces (4-stage pipeline), every
+// piece is fetched once per workgroup.  The reduction index runs over the images as one sequence r = n*H*W + p in steps of
+// 32 (H*W % 8 == 0: an 8-pixel piece never straddles two images), slices are summed by the deterministic reduce kernel.
+struct WgLdsArgs {
+    const bf16_t* gy;
+    const bf16_t* x1;
+    const bf16_t* x2;
+    float* part;   // [S][M][Jp] partial sums (S > 1)
+    bf16_t* gw;    // [M][J]   (S == 1: written directly)
+    bf16_t* gb;    // [M] or NULL
+    int k1, N, M, J, HW, has_bias, S, jtiles, T;
+    int xcd_remap;
+};
+
+__global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
+    constexpr int NT = 512, BMw = 128, BJw = 128, NS = 4, STG = 128 * 32;  // elements per operand stage
+    constexpr int G = 2;                                                    // copies per thread and stage
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    bf16_t* const asm_ = reinterpret_cast<bf16_t*>(cot_smem);  // [NS][STG] dY tiles, then [NS][STG] X tiles
+    bf16_t* const bsm = asm_ + NS * STG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 2, wj = wave & 3;
+    const int HW = a.HW, M = a.M, J = a.J, Jp = J + (a.has_bias ? 1 : 0);
+    unsigned b = blockIdx.x;
+    if (a.xcd_remap && (gridDim.x & 7u) == 0) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
+    const int jt = b % a.jtiles;
+    const int rest = b / a.jtiles;
+    const int mtiles = (M + BMw - 1) / BMw;
+    const int mt = rest % mtiles, sl = rest / mtiles;
+    const int m0 = mt * BMw, j0 = jt * BJw;
+    const int t0 = (int)((int64_t)a.T * sl / a.S), t1 = (int)((int64_t)a.T * (sl + 1) / a.S);
+
+    // this thread's piece of each stage: row tid/4, 8-pixel chunk tid%4 (swizzled LDS position as in the forward's W tile)
+    const int row = tid >> 2, pos = tid & 3, chunk = pos ^ ((row >> 2) & 3);
+    const int mrow = min(m0 + row, M - 1), jrow = min(j0 + row, J - 1);  // rows past the matrix: copies, never stored
+    const bool second = a.x2 && jrow >= a.k1;
+    const bf16_t* ybase = a.gy + (int64_t)mrow * HW;                       // + n * M * HW + p
+    const bf16_t* xbase = second ? a.x2 + (int64_t)(jrow - a.k1) * HW : a.x1 + (int64_t)jrow * HW;
+    const int64_t ystr = (int64_t)M * HW, xstr = (int64_t)(second ? J - a.k1 : (a.x2 ? a.k1 : J)) * HW;
+    // position of this thread's chunk in the reduction sequence at step t: r = 32 t + 8 chunk -> (image, pixel)
+    int64_t r = (int64_t)t0 * 32 + chunk * 8;
+    int n_ = (int)(r / HW), p_ = (int)(r - (int64_t)n_ * HW);
+    auto stage = [&](int tl) __attribute__((always_inline)) {  // stages are issued in order: (n_, p_) walks along
+        const int buf = tl % NS;
+        COT_GLDS16(ybase + n_ * ystr + p_, asm_ + buf * STG + (wave * 64) * 8);
+        COT_GLDS16(xbase + n_ * xstr + p_, bsm + buf * STG + (wave * 64) * 8);
+        p_ += 32;
+        if (p_ >= HW) {  // (H*W >= 32)
+            p_ -= HW;
+            ++n_;
+        }
+    };
+    int aoff[4], boff[2];
+    bool ones[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rw = wm * 64 + q * 16 + i16;
+        aoff[q] = rw * 32 + (g ^ ((rw >> 2) & 3)) * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rw = wj * 32 + q * 16 + i16;
+        boff[q] = rw * 32 + (g ^ ((rw >> 2) & 3)) * 8;
+        ones[q] = a.has_bias && j0 + rw == J;  // the bias gradient rides along as a column of ones
+    }
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[q][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nst = t1 - t0;
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nst) stage(s0);
+    for (int tl = 0; tl < nst; ++tl) {
+        WaitBehind<G, NS - 2>::go(min(NS - 2, nst - 1 - tl));
+        COT_LDS_BARRIER();
+        if (tl + NS - 1 < nst) stage(tl + NS - 1);
+        const bf16_t* ab = asm_ + (tl % NS) * STG;
+        const bf16_t* bb = bsm + (tl % NS) * STG;
+        bf16x8_t bf[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            __builtin_memcpy(&bf[u], __builtin_assume_aligned(bb + boff[u], 16), 16);
+            if (ones[u]) {
+                const uint32_t one2[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};  // bf16 1.0 x 8
+                __builtin_memcpy(&bf[u], one2, 16);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16x8_t af;
+            __builtin_memcpy(&af, __builtin_assume_aligned(ab + aoff[q], 16), 16);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[q][u] = COT_MFMA_16X16X32_BF16(af, bf[u], acc[q][u]);
+        }
+    }
+    // D[i = dY row][j = X row]: lane holds rows 4g .. 4g+3 of block q, column i16 of block u
+    float* ps = a.part + (int64_t)sl * M * Jp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + q * 16 + g * 4 + i;
+            if (m >= M) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int jj = j0 + wj * 32 + u * 16 + i16;
+                if (a.S > 1) {
+                    if (jj < Jp) ps[(int64_t)m * Jp + jj] = acc[q][u][i];
+                } else if (jj < J) {
+                    a.gw[(int64_t)m * J + jj] = (bf16_t)acc[q][u][i];
+                } else if (jj == J && a.has_bias) {
+                    a.gb[m] = (bf16_t)acc[q][u][i];
+                }
+            }
+        }
+}
+
+bool conv1x1_wgrad_lds_covers(int N, int HW) {
+    return g_conv_lds_tune[0] && HW % 8 == 0 && HW >= 64 && ((int64_t)N * HW) % 32 == 0;
+}
+
+// number of slices of the LDS weight-gradient kernel (also sizes the workspace)
+int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias) {
+    const int Jp = J + (has_bias ? 1 : 0);
+    const int64_t tiles = (int64_t)ceil_div(M, 128) * ceil_div(Jp, 128), T = (int64_t)N * HW / 32;
+    int64_t S = ceil_div64(1024, tiles);  // ~4 workgroups per CU
+    const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
+    const int64_t cap = in_bytes / 4 / out_bytes;  // partial sums (written + read once) below a quarter of the inputs
+    if (S > cap) S = cap;
+    if (S > T / 8) S = T / 8;
+    if (S > 1024) S = 1024;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_bias, void* gw, void* gb, hipStream_t stream);
+
+int conv1x1_wgrad_lds_run(const void* gy, const void* x1, const void* x2, int k1, void* gw, void* gb, float* workspace, int N,
+                          int J, int M, int HW, hipStream_t stream) {
+    WgLdsArgs a;
+    a.gy = (const bf16_t*)gy; a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.part = workspace;
+    a.gw = (bf16_t*)gw; a.gb = (bf16_t*)gb; a.k1 = x2 ? k1 : J; a.N = N; a.M = M; a.J = J; a.HW = HW;
+    a.has_bias = gb ? 1 : 0;
+    a.S = conv1x1_wgrad_lds_splits(N, M, J, HW, a.has_bias);
+    a.jtiles = ceil_div(J + a.has_bias, 128);
+    a.T = (int)((int64_t)N * HW / 32);
+    const int64_t blocks = (int64_t)a.jtiles * ceil_div(M, 128) * a.S;
+    a.xcd_remap = blocks % 8 == 0;
+    const size_t lds = (size_t)2 * 4 * 128 * 32 * sizeof(bf16_t);  // 64 KB
+    COT_LAUNCH(conv1x1_wgrad_lds, dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    int rc = check_launch("conv1x1_wgrad_lds");
+    if (rc || a.S == 1) return rc;
+    return conv1x1_wgrad_reduce_launch(workspace, a.S, M, J, a.has_bias, gw, gb, stream);
+}
+
 // tuning (cot_set_tuning keys 15..17): [0] 0 = first-generation kernels, 1 = LDS kernels where eligible (default),
 // [1] images per workgroup in FLAT mode (0 = auto), [2] reserved
 int g_conv_lds_tune[3] = {1, 0, 0};

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -121,10 +122,14 @@ int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, floa
 extern int g_conv1x1_tune[4];
 // implemented in conv_lds.hip
 extern int g_conv_lds_tune[3];
+static inline bool g_conv_lds_tune_wgrad_off() { return (g_conv_lds_tune[2] >> 2) & 1; }  // tuning key 17 bit 2 (A/B)
 bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
 int conv1x1_lds_gemm(const void*, const void*, int, const void*, int, const void*, void*, void*, int, int, int, int, int, int,
                      hipStream_t);
 int transpose_bf16(const void* src, void* dst, int R, int C, int pack, hipStream_t stream);
+bool conv1x1_wgrad_lds_covers(int N, int HW);
+int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias);
+int conv1x1_wgrad_lds_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 int conv3x3g_lds_gemm(const void*, const void*, void*, void*, int, int, int, int, int, int, int, int, hipStream_t);
 // implemented in stem7x7.hip
 int stem7x7_splits(int N, int H, int W);
@@ -321,7 +326,9 @@ static int conv1x1_validate(int N, int Ci, int Co, int HW, int c1, bool split, i
 int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias) {
     if (N <= 0 || Ci <= 0 || Co <= 0 || HW <= 0) return 0;
     const int64_t wt = (int64_t)Ci * Co * 2;
-    const int64_t part = (int64_t)conv1x1_wgrad_splits(N, Co, Ci, HW, has_bias) * Co * (Ci + (has_bias ? 1 : 0)) * 4;
+    int splits = conv1x1_wgrad_splits(N, Co, Ci, HW, has_bias);
+    if (conv1x1_wgrad_lds_covers(N, HW)) splits = std::max(splits, conv1x1_wgrad_lds_splits(N, Co, Ci, HW, has_bias));
+    const int64_t part = (int64_t)splits * Co * (Ci + (has_bias ? 1 : 0)) * 4;
     return ((wt > part ? wt : part) + 255) / 256 * 256;
 }
 
@@ -363,6 +370,8 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
     if (rc) return rc;
     if (!gy || !x1 || !gweight || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, x1, x2, gweight, workspace}))) return rc;
+    if (conv1x1_wgrad_lds_covers(N, HW) && !g_conv_lds_tune_wgrad_off())
+        return conv1x1_wgrad_lds_run(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
     return conv1x1_wgrad(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
 }
 

@@ -226,14 +226,36 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
 }
 
 // dgamma[c] = sum_n part[n][c].dy_xhat, dbeta[c] = sum_n part[n][c].dy      part is [N][G*9][2]
-__global__ void gn9_bwd_params_kernel(const float* __restrict__ part, bf16_t* __restrict__ dgamma,
-                                      bf16_t* __restrict__ dbeta, int N, int Ctot) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Ctot) return;
+// A workgroup owns 32 channels; its 8 thread groups take the images n = q, q+8, .. (the one-thread-per-channel loop over the
+// whole batch was a chain of N strided loads: 21 us for 80 images) and are summed through LDS in a fixed order.
+__global__ __launch_bounds__(256) void gn9_bwd_params_kernel(const float* __restrict__ part, bf16_t* __restrict__ dgamma,
+                                                            bf16_t* __restrict__ dbeta, int N, int Ctot) {
+    __shared__ float red[8][32][2];
+    const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+    if (c < Ctot) {
+        int n = q;
+        for (; n + 8 < N; n += 16) {
+            const float* u = part + ((int64_t)n * Ctot + c) * 2;
+            const float* v = part + ((int64_t)(n + 8) * Ctot + c) * 2;
+            const float ux = u[0], uy = u[1], vx = v[0], vy = v[1];
+            a0 += ux; b0 += uy; a1 += vx; b1 += vy;
+        }
+        for (; n < N; n += 8) {
+            const float* u = part + ((int64_t)n * Ctot + c) * 2;
+            a0 += u[0]; b0 += u[1];
+        }
+    }
+    red[q][cl][0] = a0 + a1;
+    red[q][cl][1] = b0 + b1;
+    __syncthreads();
+    if (q != 0 || c >= Ctot) return;
     float a = 0.f, b = 0.f;
-    for (int n = 0; n < N; ++n) {
-        a += part[((int64_t)n * Ctot + c) * 2];
-        b += part[((int64_t)n * Ctot + c) * 2 + 1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a += red[k][cl][0];
+        b += red[k][cl][1];
     }
     dbeta[c] = (bf16_t)a;
     dgamma[c] = (bf16_t)b;
@@ -292,7 +314,7 @@ int gn9_backward(const void* dy, const void* x, const float* mean, const float* 
 #undef GN9_BWD
     int rc = check_launch("gn9_bwd_kernel");
     if (rc) return rc;
-    COT_LAUNCH(gn9_bwd_params_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, (const float*)workspace,
+    COT_LAUNCH(gn9_bwd_params_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, (const float*)workspace,
                (bf16_t*)dgamma, (bf16_t*)dbeta, N, C);
     return check_launch("gn9_bwd_params_kernel");
 }

@@ -23,6 +23,8 @@ tests); with no process group (single GPU) it degrades to a no-op that still pro
 import torch
 import torch.distributed as dist
 
+from . import grad_sink
+
 
 class _Bucket:
     __slots__ = ("flat", "params", "pending", "work", "ready_event", "key", "views", "pflat", "fired")
@@ -94,6 +96,10 @@ class GradBucketReducer:
         for (key, dt), plist in order:
             self._make_bucket(plist, dt, key, flatten_params)
 
+        if grad_mode == "copy":  # kernels that produce parameter gradients may write the bucket slots directly
+            for b in self.buckets:
+                for p, v in zip(b.params, b.views):
+                    grad_sink.register(p, v)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in params]
         self._launched = 0
 
@@ -161,8 +167,9 @@ class GradBucketReducer:
         dst, src = [], []
         for p, v in zip(b.params, b.views):
             if p in b.fired and p.grad is not None:
-                dst.append(v)
-                src.append(p.grad)
+                if not grad_sink.is_in_place(p, v):  # (the producing kernel may have written the slot itself: grad_sink)
+                    dst.append(v)
+                    src.append(p.grad)
             else:
                 v.zero_()  # parameter unused this step
         if dst:

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
-from . import _lib
+from . import _lib, grad_sink
 
 MODE = os.environ.get("COT_HEAD", "")
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
@@ -67,7 +67,7 @@ class _Head(Function):
         ggapT = torch.empty_like(gapT)
         _ck(L.cot_conv1x1_backward_data(_p(gT), _p(weight), _p(ggapT), None, C, 0, _p(ws), 1, C, O, N, BF16, st),
             "cot_conv1x1_backward_data")
-        gw = torch.empty_like(weight)
+        gw = grad_sink.out_like(weight)
         gb = torch.empty(O, dtype=weight.dtype, device=g.device) if ctx.has_bias else None
         _ck(L.cot_conv1x1_backward_weight(_p(gT), _p(gapT), None, C, _p(gw), _p(gb), _p(ws), 1, C, O, N, BF16, st),
             "cot_conv1x1_backward_weight")

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
-from . import _lib
+from . import _lib, grad_sink
 
 MODE = os.environ.get("COT_STEM", "")
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
@@ -51,7 +51,7 @@ class _Stem(Function):
         N, _, H, W = x.shape
         gy = gy.contiguous()
         ws = torch.empty(_ws_bytes(N, H, W), dtype=torch.uint8, device=gy.device)
-        gw = torch.empty_like(weight)
+        gw = grad_sink.out_like(weight)
         rc = _lib.lib().cot_stem7x7s2_backward_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, H, W,
                                                       _lib.COT_BF16, _stream())
         if rc:

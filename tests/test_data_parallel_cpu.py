@@ -163,3 +163,50 @@ def test_single_process_is_a_noop_with_flat_buckets():
     assert red.buckets[0].flat.numel() == total and red.buckets[0].flat.abs().sum() > 0
     red.zero_grad()
     assert red.buckets[0].flat.abs().sum() == 0 and all(p.grad is not None for p in model.parameters())
+
+
+def test_grad_sink_lets_a_producer_write_its_bucket_slot():
+    """cotnet_amd.grad_sink: a custom backward that writes a parameter's gradient straight into the flat bucket (what the
+    single-node layers do on the GPU) -- autograd adopts the alias, the bucket fill skips the copy, values are right; a
+    second backward before zero_grad falls back to an ordinary tensor and accumulates as usual."""
+    import torch
+    from torch import nn
+    from torch.autograd import Function
+    from cotnet_amd import grad_sink
+    from cotnet_amd.data_parallel import GradBucketReducer
+
+    torch.manual_seed(0)
+    lin = nn.Linear(4, 3)
+    red = GradBucketReducer(lin, grad_mode="copy", flatten_params=True)
+    slot = {id(p): v for b in red.buckets for p, v in zip(b.params, b.views)}
+    seen = []
+
+    class Lin(Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w)
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            gw = grad_sink.out_like(lin.weight)
+            seen.append(gw.data_ptr() == slot[id(lin.weight)].data_ptr())
+            gw.copy_(g.t() @ x)
+            return g @ w, gw, g.sum(0)
+
+    x = torch.randn(5, 4)
+    g = torch.randn(5, 3)
+    red.zero_grad()
+    Lin.apply(x, lin.weight, lin.bias).backward(g)
+    red.finish()
+    assert seen == [True]
+    assert torch.allclose(slot[id(lin.weight)], g.t() @ x, atol=1e-6)
+    assert torch.allclose(slot[id(lin.bias)], g.sum(0), atol=1e-6)   # (no sink use for the bias: ordinary copy)
+    assert lin.weight.grad is None and lin.bias.grad is None
+    # a parameter that already has a gradient: no alias, autograd accumulates
+    lin.weight.grad = torch.ones_like(lin.weight)
+    gw2 = grad_sink.out_like(lin.weight)
+    assert gw2.data_ptr() != slot[id(lin.weight)].data_ptr()
+    red.remove()
+    grad_sink.unregister_all()
