@@ -482,53 +482,65 @@ static int bn_bwd_launch(const T* dy, const T* x, const T* y, T* dx, T* dres, co
 #undef BN_BA
 }
 
-// ---- small batches: N*H*W <= g_bn_small_m (4096) samples per channel (the `se` branch of a CoT layer normalises over the batch
+// ---- small batches: N*H*W <= g_bn_small_m (256) samples per channel (the `se` branch of a CoT layer normalises over the batch
 // alone: [B, A, 1, 1], models/cotnet.py:71-77).  With a handful of samples the backward formula
 //     dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))
 // cancels catastrophically (for 2 samples the two terms agree to eps/(var+eps)); measured on the MI355X: MIOpen's fp32
 // kernel is 300x further from an fp64 evaluation than the CPU's (3.8e-1 on a gradient of scale 2.8e2) and is what kept
-// the 7x7 CotLayer off the 1e-3 parity bar.  Here one thread owns a channel and does the WHOLE computation in fp64
+// the 7x7 CotLayer off the 1e-3 parity bar.  Here one wave owns a channel and does the WHOLE computation in fp64
 // (statistics recomputed from x in the backward, not taken from the fp32 saves): one launch each way, a few KB of traffic.
-int g_bn_small_m = 4096;  // cot_set_tuning(18, M): per-channel sample count up to which the fp64 path is taken (0 = never)
+int g_bn_small_m = 256;  // cot_set_tuning(18, M): per-channel sample count up to which the fp64 path is taken (0 = never); one thread walks a whole channel, so this must stay small
 
+// sum over the 64 lanes in fp64, result in every lane (butterfly with a fixed order: deterministic)
+__device__ __forceinline__ double wave_allsum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one WAVE per channel: lane l takes the samples l, l+64, .. of the channel's N*H*W
 template <typename T, int ACT>
 __global__ __launch_bounds__(64) void bn_small_fwd(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   float* __restrict__ mean, float* __restrict__ rstd,
                                                   float* __restrict__ rmean, float* __restrict__ rvar,
                                                   long long* __restrict__ nbt, int N, int C, int HW, float eps, float mom) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c == 0 && lane == 0 && nbt) *nbt += 1;
     const int M = N * HW;
     double sm = 0.0;
-    for (int n = 0; n < N; ++n)
-        for (int p = 0; p < HW; ++p) sm += (double)(float)x[((int64_t)n * C + c) * HW + p];
-    const double mu = sm / M;
+    for (int e = lane; e < M; e += 64) {
+        const int n = e / HW, p = e - n * HW;
+        sm += (double)(float)x[((int64_t)n * C + c) * HW + p];
+    }
+    const double mu = wave_allsum_d(sm) / M;
     double m2 = 0.0;
-    for (int n = 0; n < N; ++n)
-        for (int p = 0; p < HW; ++p) {
-            const double d = (double)(float)x[((int64_t)n * C + c) * HW + p] - mu;
-            m2 += d * d;
-        }
+    for (int e = lane; e < M; e += 64) {
+        const int n = e / HW, p = e - n * HW;
+        const double d = (double)(float)x[((int64_t)n * C + c) * HW + p] - mu;
+        m2 += d * d;
+    }
+    m2 = wave_allsum_d(m2);
     const double var = m2 / M, r = 1.0 / sqrt(var + (double)eps);
-    mean[c] = (float)mu;
-    rstd[c] = (float)r;
-    if (rmean) {
-        const double unbiased = M > 1 ? m2 / (M - 1) : var;
-        rmean[c] = (float)((1.0 - mom) * rmean[c] + mom * mu);
-        rvar[c] = (float)((1.0 - mom) * rvar[c] + mom * unbiased);
+    if (lane == 0) {
+        mean[c] = (float)mu;
+        rstd[c] = (float)r;
+        if (rmean) {
+            const double unbiased = M > 1 ? m2 / (M - 1) : var;
+            rmean[c] = (float)((1.0 - mom) * rmean[c] + mom * mu);
+            rvar[c] = (float)((1.0 - mom) * rvar[c] + mom * unbiased);
+        }
     }
     const double ga = gamma[c], be = beta[c];
-    for (int n = 0; n < N; ++n)
-        for (int p = 0; p < HW; ++p) {
-            const int64_t i = ((int64_t)n * C + c) * HW + p;
-            double z = ((double)(float)x[i] - mu) * r * ga + be;
-            if (res) z += (double)(float)res[i];
-            if (ACT == ACT_RELU) z = z > 0.0 ? z : 0.0;
-            if (ACT == ACT_SILU) z = z / (1.0 + exp(-z));
-            y[i] = (T)(float)z;
-        }
+    for (int e = lane; e < M; e += 64) {
+        const int n = e / HW, p = e - n * HW;
+        const int64_t i = ((int64_t)n * C + c) * HW + p;
+        double z = ((double)(float)x[i] - mu) * r * ga + be;
+        if (res) z += (double)(float)res[i];
+        if (ACT == ACT_RELU) z = z > 0.0 ? z : 0.0;
+        if (ACT == ACT_SILU) z = z / (1.0 + exp(-z));
+        y[i] = (T)(float)z;
+    }
 }
 
 template <typename T, int ACT>
@@ -536,15 +548,16 @@ __global__ __launch_bounds__(64) void bn_small_bwd(const T* __restrict__ dy, con
                                                   T* __restrict__ dx, T* __restrict__ dres, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, const float* __restrict__ rstd,
                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int HW) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
     const int M = N * HW;
     double sm = 0.0;
-    for (int n = 0; n < N; ++n)
-        for (int p = 0; p < HW; ++p) sm += (double)(float)x[((int64_t)n * C + c) * HW + p];
+    for (int e = lane; e < M; e += 64) {
+        const int n = e / HW, p = e - n * HW;
+        sm += (double)(float)x[((int64_t)n * C + c) * HW + p];
+    }
     // mean recomputed in fp64 (so that sum(xhat) == 0 to fp64 accuracy); rstd is the forward's (its own rounding only
     // scales the result by 1 + 6e-8, it does not enter the cancellation)
-    const double mu = sm / M, r = (double)rstd[c], ga = gamma[c], be = beta[c];
+    const double mu = wave_allsum_d(sm) / M, r = (double)rstd[c], ga = gamma[c], be = beta[c];
     auto gof = [&](int64_t i, double xh) {
         const double d = (double)(float)dy[i];
         if (ACT == ACT_RELU_Y) return (float)y[i] > 0.f ? d : 0.0;
@@ -557,23 +570,27 @@ __global__ __launch_bounds__(64) void bn_small_bwd(const T* __restrict__ dy, con
         return d;
     };
     double sg = 0.0, sgx = 0.0;
-    for (int n = 0; n < N; ++n)
-        for (int p = 0; p < HW; ++p) {
-            const int64_t i = ((int64_t)n * C + c) * HW + p;
-            const double xh = ((double)(float)x[i] - mu) * r, g = gof(i, xh);
-            sg += g;
-            sgx += g * xh;
-        }
-    dbeta[c] = (float)sg;
-    dgamma[c] = (float)sgx;
+    for (int e = lane; e < M; e += 64) {
+        const int n = e / HW, p = e - n * HW;
+        const int64_t i = ((int64_t)n * C + c) * HW + p;
+        const double xh = ((double)(float)x[i] - mu) * r, g = gof(i, xh);
+        sg += g;
+        sgx += g * xh;
+    }
+    sg = wave_allsum_d(sg);
+    sgx = wave_allsum_d(sgx);
+    if (lane == 0) {
+        dbeta[c] = (float)sg;
+        dgamma[c] = (float)sgx;
+    }
     const double k1 = sg / M, k2 = sgx / M;
-    for (int n = 0; n < N; ++n)
-        for (int p = 0; p < HW; ++p) {
-            const int64_t i = ((int64_t)n * C + c) * HW + p;
-            const double xh = ((double)(float)x[i] - mu) * r, g = gof(i, xh);
-            dx[i] = (T)(float)(ga * r * (g - k1 - xh * k2));
-            if (dres) dres[i] = (T)(float)g;
-        }
+    for (int e = lane; e < M; e += 64) {
+        const int n = e / HW, p = e - n * HW;
+        const int64_t i = ((int64_t)n * C + c) * HW + p;
+        const double xh = ((double)(float)x[i] - mu) * r, g = gof(i, xh);
+        dx[i] = (T)(float)(ga * r * (g - k1 - xh * k2));
+        if (dres) dres[i] = (T)(float)g;
+    }
 }
 
 template <typename T>
@@ -582,7 +599,7 @@ int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, 
                    float mom, int act, hipStream_t s) {
 #define BN_F(VV) return bn_fwd_launch<T, VV>((const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, ws, N, C, HW, eps, mom, act, s)
     if ((int64_t)N * HW <= g_bn_small_m) {
-        const dim3 grid((C + 63) / 64), block(64);
+        const dim3 grid(C), block(64);  // one wave per channel
 #define BN_SF(A_) COT_LAUNCH((bn_small_fwd<T, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom)
         if (act == ACT_RELU) BN_SF(ACT_RELU);
         else if (act == ACT_SILU) BN_SF(ACT_SILU);
@@ -604,7 +621,7 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
                     int N, int C, int HW, int act, hipStream_t s) {
 #define BN_B(VV) return bn_bwd_launch<T, VV>((const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, ws, N, C, HW, act, s)
     if ((int64_t)N * HW <= g_bn_small_m) {
-        const dim3 grid((C + 63) / 64), block(64);
+        const dim3 grid(C), block(64);  // one wave per channel
 #define BN_SB(A_) COT_LAUNCH((bn_small_bwd<T, A_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, rstd, dgamma, dbeta, N, C, HW)
         if (act == ACT_RELU && y) BN_SB(ACT_RELU_Y);
         else if (act == ACT_RELU) BN_SB(ACT_RELU);

@@ -286,6 +286,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, boo
 }
 template <typename V> inline V __shfl_up(V v, int d) { return emul::exchange<V>(v, -d, v); }
 template <typename V> inline V __shfl_down(V v, int d) { return emul::exchange<V>(v, +d, v); }
+template <typename V> inline V __shfl_xor(V v, int m) { return emul::exchange<V>(v, (emul::t_lane ^ m) - emul::t_lane, v); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emul::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })

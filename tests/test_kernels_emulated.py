@@ -39,7 +39,7 @@ def _default_knobs():
         _EMUL.cot_set_tuning(10, 0)
         _EMUL.cot_set_tuning(11, 2048)
         _EMUL.cot_set_tuning(12, 0)
-        _EMUL.cot_set_tuning(18, 4096)
+        _EMUL.cot_set_tuning(18, 256)
 
 
 def to_layout(t, layout):
@@ -371,7 +371,7 @@ def test_bn_small_batch_fp64_path(N, C, H, W, act, use_res):
     """csrc/bn_act.hip "small batches": the CoT layer's se branch normalises over the batch alone (2 samples per channel
     in the 7x7 fixture).  Against an fp64 evaluation; the 2-sample input gradient -- catastrophic cancellation in fp32 --
     must come out at fp32-rounding accuracy of the fp64 result, not at the 1e-3 relative level MIOpen's kernel shows."""
-    assert _EMUL.cot_set_tuning(18, 4096) == 0
+    assert _EMUL.cot_set_tuning(18, 4096) == 0  # (the test shapes have up to 80 samples; the library default is 256)
     g = torch.Generator().manual_seed(N + 7 * C)
     x = torch.randn(N, C, H, W, generator=g) * (0.05 if N == 2 else 1.0) + 0.3   # small variance: rstd ~ 20 .. 300
     res = torch.randn(N, C, H, W, generator=g) if use_res else None
