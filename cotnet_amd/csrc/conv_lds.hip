@@ -703,12 +703,21 @@ struct WgLdsArgs {
     bf16_t* gw;    // [M][J]   (S == 1: written directly)
     bf16_t* gb;    // [M] or NULL
     int k1, N, M, J, HW, has_bias, S, jtiles, T;
+    int spi;       // GEN: K steps per image = ceil(H*W / 32)
     int xcd_remap;
 };
 
+// GEN = 0: H*W % 8 == 0 -- the reduction index runs over all images as one sequence r = n*H*W + p in steps of 32 (an
+//          8-pixel piece never straddles two images), every piece 16-byte aligned.
+// GEN = 1: any H*W >= 32 (14 x 14, 7 x 7, ..) -- ceil(H*W/32) steps per image; pieces start at 2-byte-aligned addresses (the
+//          LDS-DMA takes them: scripts/ubench_misaligned.py, exact, ~80 % of the aligned rate) and the last step of an
+//          image is partial: a piece past the row's end reads the following row(s) -- finite or not -- and is removed from
+//          BOTH operands by selection at fragment level.  The one piece of a launch that would run past the END of a
+//          tensor is fetched element by element instead.
+template <int GEN>
 __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
-    constexpr int NT = 512, BMw = 128, BJw = 128, NS = 4, STG = 128 * 32;  // elements per operand stage
-    constexpr int G = 2;                                                    // copies per thread and stage
+    constexpr int NS = 4, STG = 128 * 32;  // stages; elements per operand stage
+    constexpr int G = 2;                    // copies per thread and stage
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     bf16_t* const asm_ = reinterpret_cast<bf16_t*>(cot_smem);  // [NS][STG] dY tiles, then [NS][STG] X tiles
     bf16_t* const bsm = asm_ + NS * STG;
@@ -719,28 +728,59 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
     if (a.xcd_remap && (gridDim.x & 7u) == 0) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
     const int jt = b % a.jtiles;
     const int rest = b / a.jtiles;
-    const int mtiles = (M + BMw - 1) / BMw;
+    const int mtiles = (M + 127) / 128;
     const int mt = rest % mtiles, sl = rest / mtiles;
-    const int m0 = mt * BMw, j0 = jt * BJw;
+    const int m0 = mt * 128, j0 = jt * 128;
     const int t0 = (int)((int64_t)a.T * sl / a.S), t1 = (int)((int64_t)a.T * (sl + 1) / a.S);
 
     // this thread's piece of each stage: row tid/4, 8-pixel chunk tid%4 (swizzled LDS position as in the forward's W tile)
     const int row = tid >> 2, pos = tid & 3, chunk = pos ^ ((row >> 2) & 3);
     const int mrow = min(m0 + row, M - 1), jrow = min(j0 + row, J - 1);  // rows past the matrix: copies, never stored
     const bool second = a.x2 && jrow >= a.k1;
+    const int xch = second ? J - a.k1 : (a.x2 ? a.k1 : J);               // channels per image of this row's X slab
     const bf16_t* ybase = a.gy + (int64_t)mrow * HW;                       // + n * M * HW + p
     const bf16_t* xbase = second ? a.x2 + (int64_t)(jrow - a.k1) * HW : a.x1 + (int64_t)jrow * HW;
-    const int64_t ystr = (int64_t)M * HW, xstr = (int64_t)(second ? J - a.k1 : (a.x2 ? a.k1 : J)) * HW;
-    // position of this thread's chunk in the reduction sequence at step t: r = 32 t + 8 chunk -> (image, pixel)
-    int64_t r = (int64_t)t0 * 32 + chunk * 8;
-    int n_ = (int)(r / HW), p_ = (int)(r - (int64_t)n_ * HW);
+    const bf16_t* xten = second ? a.x2 : a.x1;
+    const int64_t ystr = (int64_t)M * HW, xstr = (int64_t)xch * HW;
+    const int64_t yend = (int64_t)a.N * M * HW, xend = (int64_t)a.N * xch * HW;  // elements of the two tensors
+    // position of this thread's chunk at step t: GEN 0: r = 32 t + 8 chunk -> (image, pixel); GEN 1: image t / spi, pixel
+    // 32 (t % spi) + 8 chunk
+    int n_, p_;
+    if (GEN) {
+        n_ = t0 / a.spi;
+        p_ = (t0 - n_ * a.spi) * 32 + chunk * 8;
+    } else {
+        const int64_t r = (int64_t)t0 * 32 + chunk * 8;
+        n_ = (int)(r / HW);
+        p_ = (int)(r - (int64_t)n_ * HW);
+    }
+    const int prow_end = GEN ? a.spi * 32 : HW;  // p_ wraps here
     auto stage = [&](int tl) __attribute__((always_inline)) {  // stages are issued in order: (n_, p_) walks along
         const int buf = tl % NS;
-        COT_GLDS16(ybase + n_ * ystr + p_, asm_ + buf * STG + (wave * 64) * 8);
-        COT_GLDS16(xbase + n_ * xstr + p_, bsm + buf * STG + (wave * 64) * 8);
+        bf16_t* ad = asm_ + buf * STG + (wave * 64) * 8;
+        bf16_t* bd = bsm + buf * STG + (wave * 64) * 8;
+        const int pp = GEN ? min(p_, HW - 1) : p_;  // (GEN: a piece entirely past the row's end: any in-bounds bytes, masked)
+        const bf16_t* ys = ybase + n_ * ystr + pp;
+        const bf16_t* xs = xbase + n_ * xstr + pp;
+        if (GEN) {
+            // the piece that would run past the end of its tensor (the last row of the last image only): element-wise
+            const bool yover = (ys - a.gy) + 8 > yend, xover = (xs - xten) + 8 > xend;
+            COT_GLDS16(yover ? a.gy : ys, ad);
+            COT_GLDS16(xover ? xten : xs, bd);
+            if (yover || xover) {
+                COT_WAIT_VM(0);  // (rare: at most a few lanes of one workgroup per launch) the DMA above must land first
+                if (yover)
+                    for (int e = 0; e < 8; ++e) ad[lane * 8 + e] = (ys - a.gy) + e < yend ? ys[e] : (bf16_t)0.0f;
+                if (xover)
+                    for (int e = 0; e < 8; ++e) bd[lane * 8 + e] = (xs - xten) + e < xend ? xs[e] : (bf16_t)0.0f;
+            }
+        } else {
+            COT_GLDS16(ys, ad);
+            COT_GLDS16(xs, bd);
+        }
         p_ += 32;
-        if (p_ >= HW) {  // (H*W >= 32)
-            p_ -= HW;
+        if (p_ >= prow_end) {  // (H*W >= 32)
+            p_ -= prow_end;
             ++n_;
         }
     };
@@ -764,6 +804,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
         for (int u = 0; u < 2; ++u) acc[q][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nst = t1 - t0;
+    int st_ = GEN ? t0 % a.spi : 0;  // GEN: step inside the image of the stage being multiplied
+    const int tailv = HW - (a.spi - 1) * 32 - 8 * g;  // GEN: valid pixels of this lane group's 8 in an image's last step
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nst) stage(s0);
@@ -773,22 +815,27 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
         if (tl + NS - 1 < nst) stage(tl + NS - 1);
         const bf16_t* ab = asm_ + (tl % NS) * STG;
         const bf16_t* bb = bsm + (tl % NS) * STG;
-        bf16x8_t bf[2];
+        const bool tail = GEN && st_ == a.spi - 1 && (HW & 31) != 0;  // wave-uniform
+        uint32_t bq[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            __builtin_memcpy(&bf[u], __builtin_assume_aligned(bb + boff[u], 16), 16);
+            __builtin_memcpy(bq[u], __builtin_assume_aligned(bb + boff[u], 16), 16);
+            if (tail) mask_packed<8>(bq[u], tailv);
             if (ones[u]) {
-                const uint32_t one2[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};  // bf16 1.0 x 8
-                __builtin_memcpy(&bf[u], one2, 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[u][e] = 0x3f803f80u;  // bf16 1.0 twice (dY's own tail mask keeps the sum right)
             }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            bf16x8_t af;
-            __builtin_memcpy(&af, __builtin_assume_aligned(ab + aoff[q], 16), 16);
+            uint32_t aq[4];
+            __builtin_memcpy(aq, __builtin_assume_aligned(ab + aoff[q], 16), 16);
+            if (tail) mask_packed<8>(aq, tailv);
+            const bf16x8_t af = packed_as_frag(aq);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) acc[q][u] = COT_MFMA_16X16X32_BF16(af, bf[u], acc[q][u]);
+            for (int u = 0; u < 2; ++u) acc[q][u] = COT_MFMA_16X16X32_BF16(af, packed_as_frag(bq[u]), acc[q][u]);
         }
+        if (GEN && ++st_ == a.spi) st_ = 0;
     }
     // D[i = dY row][j = X row]: lane holds rows 4g .. 4g+3 of block q, column i16 of block u
     float* ps = a.part + (int64_t)sl * M * Jp;
@@ -812,14 +859,18 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
         }
 }
 
+static inline bool wgrad_lds_aligned(int N, int HW) { return HW % 8 == 0 && HW >= 64 && ((int64_t)N * HW) % 32 == 0; }
+
 bool conv1x1_wgrad_lds_covers(int N, int HW) {
-    return g_conv_lds_tune[0] && HW % 8 == 0 && HW >= 64 && ((int64_t)N * HW) % 32 == 0;
+    if (!g_conv_lds_tune[0]) return false;
+    return wgrad_lds_aligned(N, HW) || HW >= 32;
 }
 
 // number of slices of the LDS weight-gradient kernel (also sizes the workspace)
 int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias) {
     const int Jp = J + (has_bias ? 1 : 0);
-    const int64_t tiles = (int64_t)ceil_div(M, 128) * ceil_div(Jp, 128), T = (int64_t)N * HW / 32;
+    const int64_t tiles = (int64_t)ceil_div(M, 128) * ceil_div(Jp, 128);
+    const int64_t T = wgrad_lds_aligned(N, HW) ? (int64_t)N * HW / 32 : (int64_t)N * ceil_div(HW, 32);
     int64_t S = ceil_div64(1024, tiles);  // ~4 workgroups per CU
     const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
     const int64_t cap = in_bytes / 4 / out_bytes;  // partial sums (written + read once) below a quarter of the inputs
@@ -840,11 +891,14 @@ int conv1x1_wgrad_lds_run(const void* gy, const void* x1, const void* x2, int k1
     a.has_bias = gb ? 1 : 0;
     a.S = conv1x1_wgrad_lds_splits(N, M, J, HW, a.has_bias);
     a.jtiles = ceil_div(J + a.has_bias, 128);
-    a.T = (int)((int64_t)N * HW / 32);
+    const bool aligned = wgrad_lds_aligned(N, HW);
+    a.spi = ceil_div(HW, 32);
+    a.T = aligned ? (int)((int64_t)N * HW / 32) : N * a.spi;
     const int64_t blocks = (int64_t)a.jtiles * ceil_div(M, 128) * a.S;
     a.xcd_remap = blocks % 8 == 0;
     const size_t lds = (size_t)2 * 4 * 128 * 32 * sizeof(bf16_t);  // 64 KB
-    COT_LAUNCH(conv1x1_wgrad_lds, dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    if (aligned) COT_LAUNCH((conv1x1_wgrad_lds<0>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    else COT_LAUNCH((conv1x1_wgrad_lds<1>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
     int rc = check_launch("conv1x1_wgrad_lds");
     if (rc || a.S == 1) return rc;
     return conv1x1_wgrad_reduce_launch(workspace, a.S, M, J, a.has_bias, gw, gb, stream);

@@ -20,13 +20,14 @@ __global__ __launch_bounds__(256) void ingest(const char* __restrict__ base, int
     const char* reg = base + (int64_t)(blockIdx.x % nregions) * span;
     uint4 acc = {0, 0, 0, 0};
     int64_t off = ((int64_t)blockIdx.x * 16384 * 7) % span;  // different workgroups start at different places of a shared region
-    if (MODE == 0) {
+    if (MODE == 2) reg += 2;  // every 16-byte piece 2-byte aligned only
+    if (MODE == 0 || MODE == 2) {
         for (int it = 0; it < iters; ++it) {
             char* slot = smem + (it & 7) * 16384;
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) glds16(reg + off + (ps * 256 + tid) * 16, slot + (ps * 256 + wave * 64) * 16);
             off += 16384;
-            if (off + 16384 > span) off = 0;
+            if (off + 16384 + 16 > span) off = 0;
             asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // 6 slots (24 copies) stay in flight
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -46,10 +47,25 @@ __global__ __launch_bounds__(256) void ingest(const char* __restrict__ base, int
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = acc.x;
 }
 
+// misaligned LDS-DMA probe: copy 64 x 16 bytes from `src + off` (off = 0, 2, 4, 8 bytes) and write the LDS image out
+__global__ void glds_misaligned(const char* __restrict__ src, int off, unsigned* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char lds[1024];
+    glds16(src + off + threadIdx.x * 16, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 64) out[i] = ((const unsigned*)lds)[i];
+}
+extern "C" int ubench_glds_misaligned(const void* src, int off, void* out, void* stream) {
+    hipLaunchKernelGGL(glds_misaligned, dim3(1), dim3(64), 0, (hipStream_t)stream, (const char*)src, off, (unsigned*)out);
+    return (int)hipGetLastError();
+}
 extern "C" int ubench_ingest(int mode, const void* base, int64_t span, int nregions, int iters, int nwg, void* sink, void* stream) {
     if (mode == 0) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(ingest<0>, dim3(nwg), dim3(256), 8 * 16384, (hipStream_t)stream, (const char*)base, span, nregions, iters, (unsigned*)sink);
+    } else if (mode == 2) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(ingest<2>, dim3(nwg), dim3(256), 8 * 16384, (hipStream_t)stream, (const char*)base, span, nregions, iters, (unsigned*)sink);
     } else {
         hipLaunchKernelGGL(ingest<1>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, (const char*)base, span, nregions, iters, (unsigned*)sink);
     }
