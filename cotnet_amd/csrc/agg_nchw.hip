@@ -866,11 +866,14 @@ const char* last_kernel_nchw() { return g_last_kernel; }
 // 4 = v3 fused backward: channel groups staged in LDS per phase (0 = default 4),
 // 5 = v3 waves per workgroup (4 or 8), 6 = v3 extra dynamic LDS per workgroup in KiB (occupancy shaping: fewer
 //     co-resident workgroups => their load / compute / store phases interleave instead of running in lock-step),
-// 7 = v3 XCD-aware tile order (0 off, 1 on; unmeasured, off by default), 8 = split the fused backward into a gX launch
+// 7 = v3 XCD-aware tile order (-1 automatic, 0 off, 1 on; see xcd_order below), 8 = split the fused backward into a gX launch
 //     and a gW launch (0 fused, 1 split; unmeasured A/B knob)
 // defaults from the on-device A/B (profiles/r01_agg_variants.log, N80xC64x56x56 bf16): forward P=4 (v3 22.0 us vs 26.0 at P=8),
 // fused backward P=2 with 4 channel groups per LDS phase (v3 45.4 us; 27.3 vs 31.8 us at 28x28)
-static int g_tune[9] = {0, 4, 2, -1, 0, 4, 0, 0, 0};
+static int g_tune[9] = {0, 4, 2, -1, 0, 4, 0, -1, 0};
+// XCD-aware tile order (key 7): -1 = automatic -- on for planes up to 28 x 28 (round-2 A/B on the MI355X: 28 x 28 forward
+// 15.7 -> 14.7 us, backward 23.6 -> 22.5 us; 56 x 56 is 2 % slower with it), 0 off, 1 on
+static inline int xcd_order(int H, int W) { return g_tune[7] < 0 ? (H * W <= 28 * 28 ? 1 : 0) : g_tune[7]; }
 int set_tuning_nchw(int key, int value) {
     if (key < 0 || key > 8) return -1;
     g_tune[key] = value;
@@ -955,10 +958,10 @@ static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, 
             const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
                 COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
-                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, g_tune[7]);
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, xcd_order(g.H, g.W));
             else
                 COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
-                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, g_tune[7]);
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, xcd_order(g.H, g.W));
             g_last_kernel = "agg_fwd_nchw_k3_lds";
             return check_launch(g_last_kernel);
         }
@@ -1017,10 +1020,10 @@ static int launch_bwd_k3_sel(const T* gout, const T* x, const T* w, T* gx, T* gw
             const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
                 COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 0, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
-                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, g_tune[7]);
+                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, xcd_order(g.H, g.W));
             else
                 COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 1, GX, GW>), grid, block, p.lds_bytes, s, gout, x, w, gx, gw,
-                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, g_tune[7]);
+                                   g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, xcd_order(g.H, g.W));
             g_last_kernel = GX && GW ? "agg_bwd_nchw_k3_lds<gx,gw>" : GX ? "agg_bwd_nchw_k3_lds<gx>" : "agg_bwd_nchw_k3_lds<gw>";
             return check_launch(g_last_kernel);
         }
@@ -1098,10 +1101,10 @@ static int launch_softmax_fwd(const T* x, const T* logits, T* out, T* probs, con
     const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
     if (xchg_mode() == 0)
         COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0, 1>), grid, block, p.lds_bytes, s, x, logits, out, g.heads, g.C, g.wC,
-                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, g_tune[7]);
+                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, xcd_order(g.H, g.W));
     else
         COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1, 1>), grid, block, p.lds_bytes, s, x, logits, out, g.heads, g.C, g.wC,
-                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, g_tune[7]);
+                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, xcd_order(g.H, g.W));
     g_last_kernel = "agg_fwd_nchw_k3_lds<softmax>";
     return check_launch(g_last_kernel);
 }
@@ -1116,10 +1119,10 @@ static int launch_softmax_bwd(const T* gout, const T* x, const T* probs, T* gx, 
     const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
     if (xchg_mode() == 0)
         COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 0, true, true, 1>), grid, block, p.lds_bytes, s, gout, x, probs, gx,
-                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, g_tune[7]);
+                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, xcd_order(g.H, g.W));
     else
         COT_LAUNCH((agg_bwd_nchw_k3_lds<T, P, 1, true, true, 1>), grid, block, p.lds_bytes, s, gout, x, probs, gx,
-                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, g_tune[7]);
+                   glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, xcd_order(g.H, g.W));
     g_last_kernel = "agg_bwd_nchw_k3_lds<softmax>";
     return check_launch(g_last_kernel);
 }

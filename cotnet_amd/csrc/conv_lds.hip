@@ -861,9 +861,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
 
 static inline bool wgrad_lds_aligned(int N, int HW) { return HW % 8 == 0 && HW >= 64 && ((int64_t)N * HW) % 32 == 0; }
 
+// Default: the aligned form only.  The general form (GEN = 1) is correct everywhere (tests, guard pages) but on the deep
+// layers it serves -- 14 x 14 / 7 x 7: outputs of 1-4 MB fp32 against 20-40 MB of input, so few slices -- its 128 x 128
+// tiles leave most CUs idle: measured 58 us (= first generation) at 14 x 14 and 118 us (vs 60) at 7 x 7.  cot_set_tuning
+// key 17 bit 3 switches it on for experiments.
 bool conv1x1_wgrad_lds_covers(int N, int HW) {
     if (!g_conv_lds_tune[0]) return false;
-    return wgrad_lds_aligned(N, HW) || HW >= 32;
+    return wgrad_lds_aligned(N, HW) || (((g_conv_lds_tune[2] >> 3) & 1) && HW >= 32);
 }
 
 // number of slices of the LDS weight-gradient kernel (also sizes the workspace)

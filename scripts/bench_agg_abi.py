@@ -53,7 +53,7 @@ def main():
     }
 
     def set_variant(name):
-        for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, 0), (8, 0)):
+        for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0)):
             L.cot_set_tuning(k, v)
         for k, v in VAR[name]:
             L.cot_set_tuning(k, v)
@@ -131,7 +131,7 @@ def main():
                 print(msg, flush=True)
             del sets
             torch.cuda.empty_cache()
-    for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, 0), (8, 0)):
+    for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0)):
         L.cot_set_tuning(k, v)
     if args.out:
         json.dump(rows, open(args.out, "w"), indent=1)

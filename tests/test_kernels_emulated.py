@@ -39,6 +39,7 @@ def _default_knobs():
         _EMUL.cot_set_tuning(10, 0)
         _EMUL.cot_set_tuning(11, 2048)
         _EMUL.cot_set_tuning(12, 0)
+        _EMUL.cot_set_tuning(17, 0)
         _EMUL.cot_set_tuning(18, 256)
 
 
@@ -528,8 +529,11 @@ def _conv1x1_ref(x, w, b):
     (1, 520, 40, 7, 7, 0, False),     # deep K (16.25 steps): the prefetch ring wraps several times, partial last step
     (1, 328, 136, 8, 8, 200, True),   # deep K over two slabs, M = 136 (data gradient: K = 136, 4.25 steps)
 ])
-@pytest.mark.parametrize("splits", [0, 3])
+@pytest.mark.parametrize("splits", [0, 3, -1])   # -1: the general (any H*W) LDS weight-gradient kernel, cot_set_tuning(17, 8)
 def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
+    if splits < 0:
+        assert _EMUL.cot_set_tuning(17, 8) == 0
+        splits = 0
     assert _EMUL.cot_set_tuning(11, -splits if splits else 2048) == 0
     torch.manual_seed(5)
     HW = H * W
