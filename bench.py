@@ -187,6 +187,9 @@ def roctx_window(resume):
         pass
 
 
+MODEL_TITLES = {"cotnet50": "CoTNet-50", "cotnet101": "CoTNet-101", "cotnext50_2x48d": "CoTNeXt-50", "cotnext101_2x48d": "CoTNeXt-101",
+                "se_cotnetd_50": "SE-CoTNetD-50", "se_cotnetd_101": "SE-CoTNetD-101", "se_cotnetd_152": "SE-CoTNetD-152",
+                "se_cotnetd_152_L": "SE-CoTNetD-152"}
 KERNEL_SETS = {  # name -> (single-node layers, 1x1 mode, 3x3 mode, GroupNorm9 mode, cot_set_tuning(12) BatchNorm finalize fold)
     "round1": (False, "", "", "", 0),       # MIOpen convolutions, torch GroupNorm, one autograd node per op
     "new": (True, "hip", "hip", "hip", 0),  # every kernel of the step from cotnet_amd/csrc, one node per Bottleneck
@@ -598,7 +601,7 @@ def main():
                                   "step right after the un-instrumented timed region",
                         "agg_share_of_step": round(agg_total / (elapsed / args.steps * 1e3), 4), "kernels": kernels}
         line = {
-            "metric": "images/sec CoTNet-50 224^2 fwd+bwd" if args.mode == "train" else "images/sec CoTNet-50 224^2 fwd",
+            "metric": f"images/sec {MODEL_TITLES.get(args.model, args.model)} {args.img}^2 " + ("fwd+bwd" if args.mode == "train" else "fwd"),
             "value": round(B * world * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -76,6 +76,10 @@ SYMBOLS = {
     "cot_conv3x3g_forward": (_I, [_P] * 5 + [_I] * 7 + [_P]),
     "cot_conv3x3g_backward_data": (_I, [_P] * 3 + [_I] + [_P] * 2 + [_I] * 7 + [_P]),
     "cot_conv3x3g_backward_weight": (_I, [_P] * 5 + [_I] * 7 + [_P]),
+    "cot_conv1x1g_workspace": (ctypes.c_int64, [_I] * 5),
+    "cot_conv1x1g_forward": (_I, [_P] * 4 + [_I] * 6 + [_P]),
+    "cot_conv1x1g_backward_data": (_I, [_P] * 3 + [_I] * 7 + [_P]),
+    "cot_conv1x1g_backward_weight": (_I, [_P] * 5 + [_I] * 6 + [_P]),
     "cot_ema_step": (_I, [_P, _P, ctypes.c_int64, ctypes.c_float, _I, _P]),
     "cot_conv1x1_lds_covers": (_I, [_I, _I, _I, _I]),
     "cot_input_normalize": (_I, [_P, _P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),

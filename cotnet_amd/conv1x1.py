@@ -86,7 +86,7 @@ class _Conv1x1Hip(Function):
         Co, Ci = weight.shape[0], weight.shape[1]
         y = torch.empty((N, Co, H, W), dtype=x1.dtype, device=x1.device)
         rc = _lib.lib().cot_conv1x1_forward(_p(x1), _p(x2), c1, _p(weight), _p(bias), _p(y), N, Ci, Co, H * W,
-                                            _lib.COT_BF16, _stream())
+                                            _lib.dtype_code(x1.dtype), _stream())
         if rc:
             _lib.check(rc, "cot_conv1x1_forward")
         ctx.save_for_backward(x1, x2, weight)
@@ -102,23 +102,71 @@ class _Conv1x1Hip(Function):
         gy = gy.contiguous()
         L = _lib.lib()
         has_bias = 1 if ctx.has_bias else 0
+        dt = _lib.dtype_code(x1.dtype)
         ws = torch.empty(_ws_bytes(N, Ci, Co, HW, has_bias), dtype=torch.uint8, device=gy.device)
         gx1 = gx2 = gw = gb = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             gx1 = torch.empty_like(x1)
             gx2 = torch.empty_like(x2) if x2 is not None else None
             rc = L.cot_conv1x1_backward_data(_p(gy), _p(weight), _p(gx1), _p(gx2), c1, 0, _p(ws), N, Ci, Co, HW,
-                                             _lib.COT_BF16, _stream())
+                                             dt, _stream())
             if rc:
                 _lib.check(rc, "cot_conv1x1_backward_data")
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             gw = torch.empty_like(weight)
             gb = torch.empty(Co, dtype=weight.dtype, device=gy.device) if ctx.has_bias else None
             rc = L.cot_conv1x1_backward_weight(_p(gy), _p(x1), _p(x2), c1, _p(gw), _p(gb), _p(ws), N, Ci, Co, HW,
-                                               _lib.COT_BF16, _stream())
+                                               dt, _stream())
             if rc:
                 _lib.check(rc, "cot_conv1x1_backward_weight")
         return gx1, gx2, gw, gb
+
+
+class _Conv1x1gHip(Function):
+    """y = conv1x1(x, weight, bias, groups) through the general kernels (cot_conv1x1g_*, csrc/conv_gen.hip): grouped 1x1
+    convolutions of CoXtLayer (models/cotnet.py:123-131) and channel counts the tuned bf16 kernels do not tile"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups):
+        N, Ci, H, W = x.shape
+        Co = weight.shape[0]
+        y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
+        rc = _lib.lib().cot_conv1x1g_forward(_p(x), _p(weight), _p(bias), _p(y), N, Ci, Co, groups, H * W,
+                                             _lib.dtype_code(x.dtype), _stream())
+        if rc:
+            _lib.check(rc, "cot_conv1x1g_forward")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        N, Ci, H, W = x.shape
+        Co, G, HW = weight.shape[0], ctx.groups, H * W
+        gy = gy.contiguous()
+        L = _lib.lib()
+        dt = _lib.dtype_code(x.dtype)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            rc = L.cot_conv1x1g_backward_data(_p(gy), _p(weight), _p(gx), 0, N, Ci, Co, G, HW, dt, _stream())
+            if rc:
+                _lib.check(rc, "cot_conv1x1g_backward_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            ws = torch.empty(int(L.cot_conv1x1g_workspace(N, Ci, Co, G, HW)), dtype=torch.uint8, device=gy.device)
+            gw = torch.empty_like(weight)
+            gb = torch.empty(Co, dtype=weight.dtype, device=gy.device) if ctx.has_bias else None
+            rc = L.cot_conv1x1g_backward_weight(_p(gy), _p(x), _p(gw), _p(gb), _p(ws), N, Ci, Co, G, HW, dt, _stream())
+            if rc:
+                _lib.check(rc, "cot_conv1x1g_backward_weight")
+        return gx, gw, gb, None
+
+
+def _is_1x1(conv):
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1))
 
 
 def _plain_1x1(conv):
@@ -130,6 +178,14 @@ def eligible(conv, x):
     """matmul path"""
     return (MODE == "matmul" and _plain_1x1(conv) and x.dim() == 4 and x.is_contiguous()
             and x.dtype == conv.weight.dtype)
+
+
+def eligible_general(conv, x):
+    """the general kernels: any groups and channel counts, bf16 or fp32 (one input tensor)"""
+    return (MODE == "hip" and _is_1x1(conv) and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4
+            and x.dtype in (torch.bfloat16, torch.float32) and conv.weight.dtype == x.dtype and x.is_contiguous()
+            and conv.weight.is_contiguous() and x.shape[1] == conv.in_channels
+            and (conv.bias is None or conv.bias.dtype == x.dtype))
 
 
 def eligible_hip(conv, x, x2=None):
@@ -149,6 +205,10 @@ def conv1x1(conv, x, x2=None):
         return _Conv1x1Hip.apply(x, x2, conv.weight, conv.bias)
     if x2 is not None:
         x = torch.cat([x, x2], dim=1)
+    if MODE == "hip" and eligible_general(conv, x):
+        if conv.groups == 1 and x.dtype == torch.float32:
+            return _Conv1x1Hip.apply(x, None, conv.weight, conv.bias)
+        return _Conv1x1gHip.apply(x, conv.weight, conv.bias, conv.groups)
     if MODE == "matmul" and eligible(conv, x):
         return _Conv1x1.apply(x, conv.weight, conv.bias)
     return conv(x)

@@ -3,9 +3,10 @@
 `conv3x3(conv, x)` evaluates an ordinary `nn.Conv2d(kernel_size=3, stride=1, padding=1, bias=False)` -- the reference's
 `CotLayer.key_embed[0]` (groups 4, models/cotnet.py:43-47) and `CoXtLayer.key_embed[0]` (groups 8, :112-116); same
 parameter, same state_dict -- through the hand-written MFMA kernels of csrc/conv3x3g.hip (cot_conv3x3g_*) when
-COT_CONV3X3=hip and the tensor qualifies (bf16, NCHW-contiguous, channels per group a multiple of 8); otherwise through
-the module itself (MIOpen).  Opt-in until measured on an MI355X (ROUND2_PLAN.md); verified against torch through the host
-emulation of the kernels (tests/test_kernels_emulated.py) and by tests/test_zz_conv3x3g_gpu.py.
+COT_CONV3X3=hip and the tensor qualifies (bf16 or fp32, NCHW-contiguous); otherwise through the module itself (MIOpen).
+bf16 with channels per group a multiple of 8 runs the tuned kernels (csrc/conv_lds.hip, conv3x3g.hip), fp32 and other
+channel counts (CoXtLayer: 12 / 24 per group) the general ones (csrc/conv_gen.hip).  Verified against torch through the
+host emulation of the kernels (tests/test_kernels_emulated.py) and on the device by tests/test_conv3x3g_gpu.py.
 """
 import ctypes
 import os
@@ -59,7 +60,7 @@ class _Conv3x3G(Function):
         ws = torch.empty(_ws_bytes(N, Cin, Cout, groups, H, W), dtype=torch.uint8, device=x.device)
         y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device)
         rc = _lib.lib().cot_conv3x3g_forward(_p(x), _p(weight), _p(y), _p(masks), _p(ws), N, Cin, Cout, groups, H, W,
-                                             _lib.COT_BF16, _stream())
+                                             _lib.dtype_code(x.dtype), _stream())
         if rc:
             _lib.check(rc, "cot_conv3x3g_forward")
         ctx.save_for_backward(x, weight)
@@ -79,13 +80,13 @@ class _Conv3x3G(Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             rc = L.cot_conv3x3g_backward_data(_p(gy), _p(weight), _p(gx), 0, _p(masks), _p(ws), N, Cin, Cout, G, H, W,
-                                              _lib.COT_BF16, _stream())
+                                              _lib.dtype_code(x.dtype), _stream())
             if rc:
                 _lib.check(rc, "cot_conv3x3g_backward_data")
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)
             rc = L.cot_conv3x3g_backward_weight(_p(gy), _p(x), _p(gw), _p(masks), _p(ws), N, Cin, Cout, G, H, W,
-                                                _lib.COT_BF16, _stream())
+                                                _lib.dtype_code(x.dtype), _stream())
             if rc:
                 _lib.check(rc, "cot_conv3x3g_backward_weight")
         return gx, gw, None
@@ -95,9 +96,8 @@ def eligible(conv, x):
     return (MODE == "hip" and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3)
             and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.bias is None
             and conv.padding_mode == "zeros" and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4
-            and x.dtype == torch.bfloat16 and conv.weight.dtype == torch.bfloat16 and x.is_contiguous()
-            and conv.weight.is_contiguous() and x.shape[1] == conv.in_channels
-            and (conv.in_channels // conv.groups) % 8 == 0 and (conv.out_channels // conv.groups) % 8 == 0)
+            and x.dtype in (torch.bfloat16, torch.float32) and conv.weight.dtype == x.dtype and x.is_contiguous()
+            and conv.weight.is_contiguous() and x.shape[1] == conv.in_channels)
 
 
 def conv3x3(conv, x):

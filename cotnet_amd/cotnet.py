@@ -139,7 +139,7 @@ class CotLayer(nn.Module):
         w = group_norm9(self.embed[4], conv1x1(self.embed[3], w))
         w = w.view(b, 1, -1, self.kernel_size * self.kernel_size, qk_hh, qk_ww)
 
-        x = self.conv1x1[1](conv1x1(self.conv1x1[0], x))
+        x = fused_bn_act(conv1x1(self.conv1x1[0], x), self.conv1x1[1], None)
         x = self.local_conv(x, w)
         x = fused_bn_act(x, self.bn, act_name(self.act) or None) if act_name(self.act) is not False else self.act(self.bn(x))
         return radix2_fuse(x, k, self.se)
@@ -190,11 +190,11 @@ class CoXtLayer(nn.Module):
         # channel-interleave [x0,k0,x1,k1,...] so each of the 2 conv groups sees matching x/k halves (ref :153-154)
         qk = torch.stack([x, k], dim=2).view(batch_size, -1, height, width)
 
-        w = fused_bn_act(self.embed[0](qk), self.embed[1], "relu")
-        w = self.embed[4](self.embed[3](w))
+        w = fused_bn_act(conv1x1(self.embed[0], qk), self.embed[1], "relu")
+        w = group_norm9(self.embed[4], conv1x1(self.embed[3], w))
         w = w.reshape(batch_size * self.dw_group, 1, -1, self.kernel_size * self.kernel_size, height, width)
 
-        x = self.conv1x1(x)
+        x = fused_bn_act(conv1x1(self.conv1x1[0], x), self.conv1x1[1], None)
         x = x.reshape(batch_size * self.dw_group, -1, height, width)
         x = self.local_conv(x, w)
         x = x.view(batch_size, -1, height, width)

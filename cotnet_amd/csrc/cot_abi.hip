@@ -141,6 +141,15 @@ template <typename T> int pool3x3s2(int, const void*, const void*, void*, int64_
 int gn9_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, hipStream_t);
 int gn9_backward(const void*, const void*, const float*, const float*, const void*, void*, void*, void*, float*, int, int,
                  int, hipStream_t);
+int gn9f_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, hipStream_t);
+int gn9f_backward(const void*, const void*, const float*, const float*, const void*, void*, void*, void*, float*, int, int,
+                  int, hipStream_t);
+// implemented in conv_gen.hip (general grouped 1x1 / 3x3 convolutions, fp32 or bf16, any channel counts)
+int convg_forward(const void*, const void*, const void*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int convg_backward_data(const void*, const void*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int64_t convg_workspace(int, int, int, int, int, int, int);
+int convg_backward_weight(const void*, const void*, void*, void*, float*, int, int, int, int, int, int, int, int,
+                          hipStream_t);
 // implemented in conv3x3g.hip
 int64_t conv3x3g_masks_bytes(int H, int W);
 int conv3x3g_masks(void*, int, int, hipStream_t);
@@ -316,8 +325,13 @@ static int conv1x1_validate(int N, int Ci, int Co, int HW, int c1, bool split, i
     if (split ? (c1 <= 0 || c1 >= Ci) : (c1 != Ci))
         return set_error(COT_ERR_INVALID_ARG, "channel split c1=%d does not fit Ci=%d (second slab %s)", c1, Ci,
                          split ? "given" : "NULL");
+    if (dtype == COT_F32) {  // general kernels (conv_gen.hip): one tensor, any channel counts
+        if (split)
+            return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_*: COT_F32 takes one input tensor (concatenate the slabs first)");
+        return COT_OK;
+    }
     if (dtype != COT_BF16)
-        return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_*: only COT_BF16 tensors (dtype %d given)", dtype);
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_*: COT_BF16 or COT_F32 tensors (dtype %d given)", dtype);
     if (kdim % 8 != 0)
         return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_*: reduction channel count %d is not a multiple of 8", kdim);
     return COT_OK;
@@ -329,7 +343,8 @@ int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias) {
     int splits = conv1x1_wgrad_splits(N, Co, Ci, HW, has_bias);
     if (conv1x1_wgrad_lds_covers(N, HW)) splits = std::max(splits, conv1x1_wgrad_lds_splits(N, Co, Ci, HW, has_bias));
     const int64_t part = (int64_t)splits * Co * (Ci + (has_bias ? 1 : 0)) * 4;
-    return ((wt > part ? wt : part) + 255) / 256 * 256;
+    const int64_t gen = convg_workspace(N, Ci, Co, 1, HW, 1, 1);  // (the query has no dtype: the fp32 path's need is covered too)
+    return ((std::max(std::max(wt, part), gen)) + 255) / 256 * 256;
 }
 
 int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, int N,
@@ -338,6 +353,7 @@ int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weig
     if (rc) return rc;
     if (!x1 || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x1, x2, weight, y}))) return rc;
+    if (dtype == COT_F32) return convg_forward(x1, weight, bias, y, N, Ci, Co, 1, HW, 1, 1, 0, dtype, (hipStream_t)stream);
     if (conv1x1_lds_covers(Ci, c1, x2 != nullptr, HW)) {
         rc = conv1x1_lds_gemm(x1, x2, c1, weight, 0, bias, y, nullptr, Co, N, Ci, Co, HW, 0, (hipStream_t)stream);
         if (rc != -1) return rc;
@@ -351,6 +367,8 @@ int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, voi
     if (rc) return rc;
     if (!gy || !weight || !gx1 || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx1, gx2, workspace}))) return rc;
+    if (dtype == COT_F32)
+        return convg_backward_data(gy, weight, gx1, N, Ci, Co, 1, HW, 1, 1, accumulate & 1, dtype, (hipStream_t)stream);
     if (conv1x1_lds_covers(Co, Co, false, HW)) {
         // the LDS forward kernel on dY with W^T in K-step-major form [Co/32][Ci][32], written into the workspace by a small
         // transposition launch
@@ -370,6 +388,9 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
     if (rc) return rc;
     if (!gy || !x1 || !gweight || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, x1, x2, gweight, workspace}))) return rc;
+    if (dtype == COT_F32)
+        return convg_backward_weight(gy, x1, gweight, gbias, (float*)workspace, N, Ci, Co, 1, HW, 1, 1, dtype,
+                                     (hipStream_t)stream);
     if (conv1x1_wgrad_lds_covers(N, HW) && !g_conv_lds_tune_wgrad_off())
         return conv1x1_wgrad_lds_run(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
     return conv1x1_wgrad(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
@@ -381,12 +402,14 @@ static int conv3x3g_validate(int N, int Cin, int Cout, int G, int H, int W, int 
                          Cout, G, H, W);
     if (Cin % G != 0 || Cout % G != 0)
         return set_error(COT_ERR_INVALID_ARG, "channels %d -> %d not divisible by groups %d", Cin, Cout, G);
-    if (dtype != COT_BF16)
-        return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_*: only COT_BF16 tensors (dtype %d given)", dtype);
-    if (kdim_per_group % 8 != 0)
-        return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_*: %d reduction channels per group, not a multiple of 8",
-                         kdim_per_group);
+    if (dtype != COT_BF16 && dtype != COT_F32)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_*: COT_BF16 or COT_F32 tensors (dtype %d given)", dtype);
+    (void)kdim_per_group;  // (channel counts the MFMA-32 kernels do not tile go to the general kernels of conv_gen.hip)
     return COT_OK;
+}
+// the specialised bf16 kernels take groups whose channel counts are multiples of 8; everything else (and fp32) is conv_gen's
+static bool conv3x3g_general(int Cin, int Cout, int G, int dtype) {
+    return dtype == COT_F32 || (Cin / G) % 8 != 0 || (Cout / G) % 8 != 0;
 }
 
 int64_t cot_conv3x3g_masks_bytes(int H, int W) { return (H > 0 && W > 0) ? conv3x3g_masks_bytes(H, W) : 0; }
@@ -403,7 +426,8 @@ int64_t cot_conv3x3g_workspace(int N, int Cin, int Cout, int groups, int H, int 
     if (N <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || H <= 0 || W <= 0 || Cin % groups || Cout % groups) return 0;
     const int64_t wb = (int64_t)Cout * (Cin / groups) * 10 * 2;  // repacked weights of the LDS kernels (10 taps: one of zeros)
     const int64_t part = (int64_t)conv3x3g_wgrad_splits(N, Cin, Cout, groups, H * W) * Cout * (Cin / groups) * 9 * 4;
-    return ((wb > part ? wb : part) + 255) / 256 * 256;
+    const int64_t gen = convg_workspace(N, Cin, Cout, groups, H, W, 3);
+    return (std::max(std::max(wb, part), gen) + 255) / 256 * 256;
 }
 
 int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void* masks, void* workspace, int N, int Cin,
@@ -412,6 +436,8 @@ int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void*
     if (rc) return rc;
     if (!x || !weight || !y || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x, weight, y, masks, workspace}))) return rc;
+    if (conv3x3g_general(Cin, Cout, groups, dtype))
+        return convg_forward(x, weight, nullptr, y, N, Cin, Cout, groups, H, W, 3, 0, dtype, (hipStream_t)stream);
     rc = conv3x3g_lds_gemm(x, weight, y, workspace, N, Cin, Cout, groups, H, W, 0, 0, (hipStream_t)stream);
     if (rc != -1) return rc;
     return conv3x3g_gemm(x, weight, y, masks, N, Cin, Cout, groups, H, W, 0, 0, (hipStream_t)stream);
@@ -424,6 +450,9 @@ int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int
     if (rc) return rc;
     if (!gy || !weight || !gx || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx, masks, workspace}))) return rc;
+    if (conv3x3g_general(Cin, Cout, groups, dtype))
+        return convg_backward_data(gy, weight, gx, N, Cin, Cout, groups, H, W, 3, accumulate ? 1 : 0, dtype,
+                                   (hipStream_t)stream);
     rc = conv3x3g_lds_gemm(gy, weight, gx, workspace, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
     if (rc != -1) return rc;
     return conv3x3g_gemm(gy, weight, gx, masks, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
@@ -435,6 +464,9 @@ int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, c
     if (rc) return rc;
     if (!gy || !x || !gweight || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, x, gweight, masks, workspace}))) return rc;
+    if (conv3x3g_general(Cin, Cout, groups, dtype))
+        return convg_backward_weight(gy, x, gweight, nullptr, (float*)workspace, N, Cin, Cout, groups, H, W, 3, dtype,
+                                     (hipStream_t)stream);
     return conv3x3g_wgrad(gy, x, gweight, masks, (float*)workspace, N, Cin, Cout, groups, H, W, (hipStream_t)stream);
 }
 
@@ -603,10 +635,55 @@ int cot_maxpool3x3s2_backward(const void* gy, const void* x, void* gx, int64_t p
     return pool_call(3, gy, x, gx, planes, H, W, dtype, stream);
 }
 
+// ---- grouped 1x1 convolution (CoXtLayer, groups = 2): the general kernels of conv_gen.hip
+static int conv1x1g_validate(int N, int Ci, int Co, int G, int HW, int dtype) {
+    if (N <= 0 || Ci <= 0 || Co <= 0 || G <= 0 || HW <= 0)
+        return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d Ci=%d Co=%d groups=%d HW=%d", N, Ci, Co, G, HW);
+    if (Ci % G != 0 || Co % G != 0)
+        return set_error(COT_ERR_INVALID_ARG, "channels %d -> %d not divisible by groups %d", Ci, Co, G);
+    if (dtype != COT_BF16 && dtype != COT_F32)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1g_*: COT_BF16 or COT_F32 tensors (dtype %d given)", dtype);
+    return COT_OK;
+}
+
+int64_t cot_conv1x1g_workspace(int N, int Ci, int Co, int groups, int HW) {
+    if (N <= 0 || Ci <= 0 || Co <= 0 || groups <= 0 || HW <= 0 || Ci % groups || Co % groups) return 0;
+    return convg_workspace(N, Ci, Co, groups, HW, 1, 1);
+}
+
+int cot_conv1x1g_forward(const void* x, const void* weight, const void* bias, void* y, int N, int Ci, int Co, int groups,
+                         int HW, int dtype, void* stream) {
+    int rc = conv1x1g_validate(N, Ci, Co, groups, HW, dtype);
+    if (rc) return rc;
+    if (!x || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x, weight, y}))) return rc;
+    return convg_forward(x, weight, bias, y, N, Ci, Co, groups, HW, 1, 1, 0, dtype, (hipStream_t)stream);
+}
+
+int cot_conv1x1g_backward_data(const void* gy, const void* weight, void* gx, int accumulate, int N, int Ci, int Co,
+                               int groups, int HW, int dtype, void* stream) {
+    int rc = conv1x1g_validate(N, Ci, Co, groups, HW, dtype);
+    if (rc) return rc;
+    if (!gy || !weight || !gx) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gy, weight, gx}))) return rc;
+    return convg_backward_data(gy, weight, gx, N, Ci, Co, groups, HW, 1, 1, accumulate ? 1 : 0, dtype, (hipStream_t)stream);
+}
+
+int cot_conv1x1g_backward_weight(const void* gy, const void* x, void* gweight, void* gbias, void* workspace, int N, int Ci,
+                                 int Co, int groups, int HW, int dtype, void* stream) {
+    int rc = conv1x1g_validate(N, Ci, Co, groups, HW, dtype);
+    if (rc) return rc;
+    if (!gy || !x || !gweight || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gy, x, gweight, workspace}))) return rc;
+    return convg_backward_weight(gy, x, gweight, gbias, (float*)workspace, N, Ci, Co, groups, HW, 1, 1, dtype,
+                                 (hipStream_t)stream);
+}
+
 static int gn9_validate(int N, int C, int HW, int dtype) {
     if (N <= 0 || C <= 0 || HW <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d C=%d HW=%d", N, C, HW);
     if (C % 9 != 0) return set_error(COT_ERR_INVALID_ARG, "channel count %d is not a multiple of 9", C);
-    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_group_norm9_*: only COT_BF16 (dtype %d given)", dtype);
+    if (dtype != COT_BF16 && dtype != COT_F32)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_group_norm9_*: COT_BF16 or COT_F32 (dtype %d given)", dtype);
     return COT_OK;
 }
 
@@ -616,6 +693,7 @@ int cot_group_norm9_forward(const void* x, const void* gamma, const void* beta, 
     if (rc) return rc;
     if (!x || !gamma || !beta || !y || !mean || !rstd) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x, y}))) return rc;
+    if (dtype == COT_F32) return gn9f_forward(x, gamma, beta, y, mean, rstd, N, C, HW, eps, (hipStream_t)stream);
     rc = gn9_forward(x, gamma, beta, y, mean, rstd, N, C, HW, eps, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_group_norm9_forward: %d pixels per plane exceed one workgroup", HW);
     return rc;
@@ -629,6 +707,8 @@ int cot_group_norm9_backward(const void* dy, const void* x, const float* mean, c
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace)
         return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({dy, x, dx}))) return rc;
+    if (dtype == COT_F32)
+        return gn9f_backward(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, N, C, HW, (hipStream_t)stream);
     rc = gn9_backward(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, N, C, HW, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_group_norm9_backward: %d pixels per plane exceed one workgroup", HW);
     return rc;

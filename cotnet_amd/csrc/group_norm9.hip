@@ -228,8 +228,9 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
 // dgamma[c] = sum_n part[n][c].dy_xhat, dbeta[c] = sum_n part[n][c].dy      part is [N][G*9][2]
 // A workgroup owns 32 channels; its 8 thread groups take the images n = q, q+8, .. (the one-thread-per-channel loop over the
 // whole batch was a chain of N strided loads: 21 us for 80 images) and are summed through LDS in a fixed order.
-__global__ __launch_bounds__(256) void gn9_bwd_params_kernel(const float* __restrict__ part, bf16_t* __restrict__ dgamma,
-                                                            bf16_t* __restrict__ dbeta, int N, int Ctot) {
+template <typename T>
+__global__ __launch_bounds__(256) void gn9_bwd_params_kernel(const float* __restrict__ part, T* __restrict__ dgamma,
+                                                            T* __restrict__ dbeta, int N, int Ctot) {
     __shared__ float red[8][32][2];
     const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -257,8 +258,97 @@ __global__ __launch_bounds__(256) void gn9_bwd_params_kernel(const float* __rest
         a += red[k][cl][0];
         b += red[k][cl][1];
     }
-    dbeta[c] = (bf16_t)a;
-    dgamma[c] = (bf16_t)b;
+    dbeta[c] = (T)a;
+    dgamma[c] = (T)b;
+}
+
+// ---- fp32 tensors (the reference's own precision, config.yaml `amp: False`): one workgroup per (image, group) sweeps the
+// group's 9*HW contiguous floats -- 113 KB at 56x56, more than a workgroup's registers hold comfortably -- three times in
+// forward (mean, centred variance, normalise) and twice in backward (sums, dx); every sweep after the first is served by
+// the L2 of the XCD the workgroup runs on, so HBM sees 1 read + 1 write (forward) and 2 reads + 1 write (backward) as in
+// the bf16 kernels.  Same statistics (two-pass variance), same workspace layout, same batch reduction for the parameters.
+__global__ __launch_bounds__(256) void gn9f_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int G,
+                                                      int HW, float eps) {
+    __shared__ float smem[16];
+    const int t = threadIdx.x, g = blockIdx.x % G, n9 = 9 * HW;
+    const float* xb = x + (int64_t)blockIdx.x * n9;
+    float s[1] = {0.f};
+    for (int i = t; i < n9; i += 256) s[0] += xb[i];
+    gn_block_sum_all<1>(s, smem);
+    const float mean = s[0] / (float)n9;
+    float v[1] = {0.f};
+    for (int i = t; i < n9; i += 256) {
+        const float d = xb[i] - mean;
+        v[0] += d * d;
+    }
+    gn_block_sum_all<1>(v, smem);
+    const float rstd = 1.f / sqrtf(v[0] / (float)n9 + eps);
+    if (t == 0) {
+        mean_out[blockIdx.x] = mean;
+        rstd_out[blockIdx.x] = rstd;
+    }
+    float* yb = y + (int64_t)blockIdx.x * n9;
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl) {
+        const float ga = gamma[g * 9 + cl], be = beta[g * 9 + cl];
+        for (int p = t; p < HW; p += 256) yb[cl * HW + p] = (xb[cl * HW + p] - mean) * rstd * ga + be;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn9f_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                      const float* __restrict__ gamma, float* __restrict__ dx,
+                                                      float* __restrict__ part, int G, int HW) {
+    __shared__ float smem[18 * 16];
+    const int t = threadIdx.x, g = blockIdx.x % G, n9 = 9 * HW;
+    const float* xb = x + (int64_t)blockIdx.x * n9;
+    const float* gb = dy + (int64_t)blockIdx.x * n9;
+    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    float s[18];  // per channel: sum dy, sum dy * xhat
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl) {
+        float a = 0.f, b = 0.f;
+        for (int p = t; p < HW; p += 256) {
+            const float d = gb[cl * HW + p];
+            a += d;
+            b += d * ((xb[cl * HW + p] - mean) * rstd);
+        }
+        s[2 * cl] = a;
+        s[2 * cl + 1] = b;
+    }
+    gn_block_sum_all<18>(s, smem);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl) {
+        const float ga = gamma[g * 9 + cl];
+        c1 += ga * s[2 * cl];
+        c2 += ga * s[2 * cl + 1];
+    }
+    const float inv = 1.f / (float)n9;
+    c1 *= inv;
+    c2 *= inv;
+#pragma unroll
+    for (int k = 0; k < 18; ++k)
+        if (t == k) part[(int64_t)blockIdx.x * 18 + k] = s[k];
+    float* db = dx + (int64_t)blockIdx.x * n9;
+#pragma unroll
+    for (int cl = 0; cl < 9; ++cl) {
+        const float ga = gamma[g * 9 + cl];
+        for (int p = t; p < HW; p += 256) {
+            const float xh = (xb[cl * HW + p] - mean) * rstd;
+            db[cl * HW + p] = rstd * (ga * gb[cl * HW + p] - c1 - xh * c2);
+        }
+    }
+}
+
+int gn9f_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N, int C,
+                 int HW, float eps, hipStream_t stream) {
+    const int G = C / 9;
+    COT_LAUNCH(gn9f_fwd_kernel, dim3((unsigned)((int64_t)N * G)), dim3(256), 0, stream, (const float*)x,
+               (const float*)gamma, (const float*)beta, (float*)y, mean, rstd, G, HW, eps);
+    return check_launch("gn9f_fwd_kernel");
 }
 
 // smallest (threads, rounds) configuration whose 8*NT*R pixels cover one channel plane; 0 = not covered
@@ -314,8 +404,20 @@ int gn9_backward(const void* dy, const void* x, const float* mean, const float* 
 #undef GN9_BWD
     int rc = check_launch("gn9_bwd_kernel");
     if (rc) return rc;
-    COT_LAUNCH(gn9_bwd_params_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, (const float*)workspace,
+    COT_LAUNCH((gn9_bwd_params_kernel<bf16_t>), dim3(ceil_div(C, 32)), dim3(256), 0, stream, (const float*)workspace,
                (bf16_t*)dgamma, (bf16_t*)dbeta, N, C);
+    return check_launch("gn9_bwd_params_kernel");
+}
+
+int gn9f_backward(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, void* dx,
+                  void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, hipStream_t stream) {
+    const int G = C / 9;
+    COT_LAUNCH(gn9f_bwd_kernel, dim3((unsigned)((int64_t)N * G)), dim3(256), 0, stream, (const float*)dy, (const float*)x,
+               mean, rstd, (const float*)gamma, (float*)dx, workspace, G, HW);
+    int rc = check_launch("gn9f_bwd_kernel");
+    if (rc) return rc;
+    COT_LAUNCH((gn9_bwd_params_kernel<float>), dim3(ceil_div(C, 32)), dim3(256), 0, stream, (const float*)workspace,
+               (float*)dgamma, (float*)dbeta, N, C);
     return check_launch("gn9_bwd_params_kernel");
 }
 

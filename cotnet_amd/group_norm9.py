@@ -2,7 +2,8 @@
 
 `group_norm9(gn, x)` evaluates an ordinary `nn.GroupNorm(dim/8, 9*dim/8)` -- CotLayer.embed[4], models/cotnet.py:56 --
 with one read and one write forward, two reads and one write backward (torch: 2R+1W and 6R+1W in 3 + 5 launches).
-Eligible: bf16 NCHW-contiguous tensors, bf16 affine parameters, 9 channels per group, H*W <= 8192; otherwise the module.
+Eligible: bf16 (H*W <= 8192) or fp32 NCHW-contiguous tensors, affine parameters of the same dtype, 9 channels per group;
+otherwise the module.
 """
 import ctypes
 import os
@@ -32,7 +33,7 @@ class _GroupNorm9(Function):
         y = torch.empty_like(x)
         stats = torch.empty(2 * N * G, dtype=torch.float32, device=x.device)
         rc = _lib.lib().cot_group_norm9_forward(_p(x), _p(weight), _p(bias), _p(y), _p(stats), _p(stats[N * G:]), N, C,
-                                                H * W, eps, _lib.COT_BF16, _stream())
+                                                H * W, eps, _lib.dtype_code(x.dtype), _stream())
         if rc:
             _lib.check(rc, "cot_group_norm9_forward")
         ctx.save_for_backward(x, weight, stats)
@@ -47,7 +48,7 @@ class _GroupNorm9(Function):
         dx, dg, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(weight)
         ws = torch.empty(2 * N * C, dtype=torch.float32, device=x.device)
         rc = _lib.lib().cot_group_norm9_backward(_p(dy), _p(x), _p(stats), _p(stats[N * G:]), _p(weight), _p(dx), _p(dg),
-                                                 _p(db), _p(ws), N, C, H * W, _lib.COT_BF16, _stream())
+                                                 _p(db), _p(ws), N, C, H * W, _lib.dtype_code(x.dtype), _stream())
         if rc:
             _lib.check(rc, "cot_group_norm9_backward")
         return dx, dg, db, None
@@ -55,9 +56,9 @@ class _GroupNorm9(Function):
 
 def eligible(gn, x):
     return (MODE == "hip" and isinstance(gn, torch.nn.GroupNorm) and gn.affine and gn.num_groups * 9 == gn.num_channels
-            and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous()
-            and x.shape[1] == gn.num_channels and gn.weight.dtype == torch.bfloat16 and x.shape[2] * x.shape[3] <= 8192
-            and x.data_ptr() % 16 == 0)
+            and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32)
+            and x.is_contiguous() and x.shape[1] == gn.num_channels and gn.weight.dtype == x.dtype
+            and (x.dtype == torch.float32 or x.shape[2] * x.shape[3] <= 8192) and x.data_ptr() % 16 == 0)
 
 
 def group_norm9(gn, x):

@@ -149,8 +149,10 @@ int cot_radix_mix_backward(const void* gout, const void* y, const void* k, const
 
 /* ---- 1x1 convolution on NCHW tensors WITHOUT layout changes (CotLayer.embed[0], embed[3],
  * conv1x1[0] -- models/cotnet.py:51-62 -- and Bottleneck.conv1/conv3/downsample, models/cotnet.py:206-224).  Replaces
- * nn.Conv2d(kernel_size=1, stride=1, groups=1) forward and both gradients; COT_BF16 only (fp32 accumulation), other
- * dtypes and channel counts that are not multiples of 8 return COT_ERR_UNSUPPORTED (caller keeps nn.Conv2d).
+ * nn.Conv2d(kernel_size=1, stride=1, groups=1) forward and both gradients.  COT_BF16 (fp32 accumulation; channel counts
+ * that are not multiples of 8 return COT_ERR_UNSUPPORTED and the caller keeps nn.Conv2d -- or uses cot_conv1x1g_* with
+ * groups = 1) and COT_F32 (the reference's own precision, `amp: False`: fp32 MFMA, any channel counts, one input tensor:
+ * x2 / gx2 must be NULL and the bias is fp32).
  *     y[n][co][p] = sum_ci weight[co][ci] * x[n][ci][p] + bias[co]         weight [Co][Ci] row-major, bias NULL or [Co]
  * x may be given as TWO channel slabs that the reference concatenates first (`torch.cat([x, k], dim=1)`,
  * models/cotnet.py:81): x1 = [N][c1][HW], x2 = [N][Ci-c1][HW]; x2 == NULL means one tensor and c1 must equal Ci.
@@ -170,8 +172,8 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
 
 /* ---- grouped 3x3 convolution, stride 1, padding 1, NCHW, no layout changes (CotLayer.key_embed[0] =
  * nn.Conv2d(dim, dim, 3, padding=1, groups=4, bias=False), models/cotnet.py:43-47; groups=8 in CoXtLayer, :112-116).
- * weight [Cout][Cin/groups][3][3] as torch stores it.  COT_BF16 only (fp32 accumulation); Cin/groups (forward) and
- * Cout/groups (backward_data) must be multiples of 8, otherwise COT_ERR_UNSUPPORTED (caller keeps nn.Conv2d).
+ * weight [Cout][Cin/groups][3][3] as torch stores it.  COT_BF16 (fp32 accumulation) or COT_F32; any channels per group
+ * (multiples of 8 in bf16 take the tuned kernels, everything else the general ones of csrc/conv_gen.hip).
  *   masks:     per-pixel tap-validity table for an H x W image: cot_conv3x3g_masks_bytes(H, W) bytes, filled once by
  *              cot_conv3x3g_masks and reusable by every call with the same H, W (read-only afterwards)
  *   workspace: cot_conv3x3g_workspace(...) bytes (partial sums of the weight gradient; forward and backward_data read
@@ -187,6 +189,19 @@ int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int
                                void* stream);
 int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
                                  int Cin, int Cout, int groups, int H, int W, int dtype, void* stream);
+
+/* ---- grouped 1x1 convolution, NCHW (CoXtLayer.embed[0] = Conv2d(2*dim, dim/2, 1, groups=2),
+ * embed[3] = Conv2d(dim/2, 9*dim/8, 1, groups=2) with bias, conv1x1[0] = Conv2d(dim, dim, 1, groups=2),
+ * models/cotnet.py:123-131).  weight [Co][Ci/groups] as torch stores it, bias NULL or [Co]; COT_BF16 or COT_F32, any channel
+ * counts (12 / 24 / 54 per group occur).  backward_weight is deterministic (partial sums in `workspace`, fixed order);
+ * accumulate (backward_data): nonzero = gx += result. */
+int64_t cot_conv1x1g_workspace(int N, int Ci, int Co, int groups, int HW);
+int cot_conv1x1g_forward(const void* x, const void* weight, const void* bias, void* y, int N, int Ci, int Co, int groups,
+                         int HW, int dtype, void* stream);
+int cot_conv1x1g_backward_data(const void* gy, const void* weight, void* gx, int accumulate, int N, int Ci, int Co,
+                               int groups, int HW, int dtype, void* stream);
+int cot_conv1x1g_backward_weight(const void* gy, const void* x, void* gweight, void* gbias, void* workspace, int N, int Ci,
+                                 int Co, int groups, int HW, int dtype, void* stream);
 
 /* Channel-major variants for running the `se` branch (models/cotnet.py:71-77,:98-101) on the library's own kernels: with
  * the pooled descriptor stored [C][N] the two 1x1 convolutions of `se` are cot_conv1x1_* calls on ONE image of N
@@ -204,13 +219,14 @@ int cot_radix_mix_backward_reduce(const void* gout, const void* y, const void* k
 int cot_radix_mix_backward_apply(const void* gout, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C,
                                  int HW, int dtype, void* stream);
 
-/* ---- GroupNorm with 9 channels per group, NCHW, COT_BF16 (CotLayer.embed[4] =
+/* ---- GroupNorm with 9 channels per group, NCHW, COT_BF16 or COT_F32 (CotLayer.embed[4] =
  * nn.GroupNorm(dim/8, 9*dim/8), models/cotnet.py:56 -- the normalisation of the 3x3 attention logits; its output is the
  * aggregation's weight tensor).  One (image, group) is a contiguous run of 9*HW elements that one workgroup keeps in
  * registers: forward = 1 read + 1 write, backward = 2 reads + 1 write + a tiny batch reduction.
  *   y = (x - mean_g) * rstd_g * gamma[c] + beta[c];  mean / rstd: fp32 [N * C/9], written by forward, read by backward
  *   gamma / beta / dgamma / dbeta: [C] in the storage dtype;  workspace (backward): N*C*2 floats
- * HW > 8192 returns COT_ERR_UNSUPPORTED (caller keeps torch's GroupNorm). */
+ * COT_BF16 with HW > 8192 returns COT_ERR_UNSUPPORTED (caller keeps torch's GroupNorm); COT_F32 sweeps the group through
+ * L2 instead of holding it in registers and takes any HW. */
 int cot_group_norm9_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N,
                             int C, int HW, float eps, int dtype, void* stream);
 int cot_group_norm9_backward(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma,

@@ -71,6 +71,38 @@ def conv3x3(N, C, G, H, W):
     assert E.cot_conv3x3g_backward_weight(P(gy), P(x), P(gw), P(masks), P(ws), N, C, C, G, H, W, BF, None) == 0
 
 
+def conv_general(N, Ci, Co, G, H, W, ksize, dtype):
+    """csrc/conv_gen.hip through cot_conv1x1g_* (ksize 1) / cot_conv3x3g_* (ksize 3, fp32 or channel counts off the grid)"""
+    dt = _lib.dtype_code(dtype)
+    x, gy = guarded(torch.randn(N, Ci, H, W).to(dtype)), guarded(torch.randn(N, Co, H, W).to(dtype))
+    w, b = guarded(torch.randn(Co, Ci // G, ksize, ksize).to(dtype)), guarded(torch.randn(Co).to(dtype))
+    y, gx, gw, gb = (guarded(torch.zeros_like(t)) for t in (gy, x, w, b))
+    if ksize == 1:
+        ws = guarded(torch.empty(E.cot_conv1x1g_workspace(N, Ci, Co, G, H * W), dtype=torch.uint8))
+        assert E.cot_conv1x1g_forward(P(x), P(w), P(b), P(y), N, Ci, Co, G, H * W, dt, None) == 0
+        assert E.cot_conv1x1g_backward_data(P(gy), P(w), P(gx), 1, N, Ci, Co, G, H * W, dt, None) == 0
+        assert E.cot_conv1x1g_backward_weight(P(gy), P(x), P(gw), P(gb), P(ws), N, Ci, Co, G, H * W, dt, None) == 0
+    else:
+        masks = torch.empty(E.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+        assert E.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+        ws = guarded(torch.empty(E.cot_conv3x3g_workspace(N, Ci, Co, G, H, W), dtype=torch.uint8))
+        assert E.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, Ci, Co, G, H, W, dt, None) == 0
+        assert E.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), 1, P(masks), P(ws), N, Ci, Co, G, H, W, dt, None) == 0
+        assert E.cot_conv3x3g_backward_weight(P(gy), P(x), P(gw), P(masks), P(ws), N, Ci, Co, G, H, W, dt, None) == 0
+
+
+def gn9f(N, G, H, W):
+    C = 9 * G
+    x, dy = guarded(torch.randn(N, C, H, W)), guarded(torch.randn(N, C, H, W))
+    ga, be = guarded(torch.randn(C)), guarded(torch.randn(C))
+    y, dx = guarded(torch.empty_like(x)), guarded(torch.empty_like(x))
+    mean, rstd = guarded(torch.empty(N * G)), guarded(torch.empty(N * G))
+    dg, db, ws = guarded(torch.empty_like(ga)), guarded(torch.empty_like(ga)), guarded(torch.empty(2 * N * C))
+    assert E.cot_group_norm9_forward(P(x), P(ga), P(be), P(y), P(mean), P(rstd), N, C, H * W, 1e-5, 0, None) == 0
+    assert E.cot_group_norm9_backward(P(dy), P(x), P(mean), P(rstd), P(ga), P(dx), P(dg), P(db), P(ws), N, C, H * W, 0,
+                                      None) == 0
+
+
 def gn9(N, G, H, W):
     C, HW = 9 * G, H * W
     x, dy = guarded(torch.randn(N, C, H, W).bfloat16()), guarded(torch.randn(N, C, H, W).bfloat16())
@@ -170,6 +202,13 @@ if __name__ == "__main__":
         conv3x3(*shape)
     for shape in [(2, 2, 8, 8), (2, 1, 14, 14), (8, 2, 7, 7), (1, 1, 56, 56), (8, 2, 3, 5)]:
         gn9(*shape)
+    for dtype in (torch.float32, torch.bfloat16):
+        # (element counts are multiples of 8 so that the guarded tensors keep the 16-byte base alignment the ABI asks for)
+        for shape in [(2, 32, 24, 1, 4, 4, 1), (2, 48, 108, 2, 4, 6, 1), (1, 16, 8, 2, 1, 8, 1), (2, 16, 16, 4, 4, 4, 3),
+                      (1, 96, 96, 8, 2, 4, 3), (2, 72, 72, 1, 2, 2, 3)]:
+            conv_general(*shape, dtype)
+    for shape in [(2, 2, 8, 8), (8, 2, 2, 2), (1, 1, 56, 56), (4, 1, 2, 6)]:
+        gn9f(*shape)
     for shape in [(2, 32, 32), (1, 16, 64)]:
         stem(*shape)
     for dtype in (torch.bfloat16, torch.float32):

@@ -166,6 +166,54 @@ template <typename AB, typename C> inline C mfma_16x16x32_bf16(const AB& a, cons
     return d;
 }
 
+// v_mfma_f32_16x16x4_f32 (A: lane l holds A[i = l&15][k = l>>4], B: B[k = l>>4][j = l&15]) and
+// v_mfma_f32_16x16x16_bf16 (A[i = l&15][k = 4*(l>>4) .. +3], B[k = 4*(l>>4) .. +3][j = l&15]); C/D as above.
+template <typename C> inline C mfma_16x16x4_f32(float a, float b, const C& c) {
+    Sched& S = *t_sched;
+    auto& w = S.wide[t_wave];
+    std::memcpy(&w[t_lane][0], &a, 4);
+    std::memcpy(&w[t_lane][2], &b, 4);
+    wave_barrier();
+    C d = c;
+    const int col = t_lane & 15, rg = t_lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rg + r;
+        float sum = 0.f;
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            std::memcpy(&av, &w[row + 16 * k][0], 4);
+            std::memcpy(&bv, &w[col + 16 * k][2], 4);
+            sum += av * bv;
+        }
+        d[r] = c[r] + sum;
+    }
+    wave_barrier();
+    return d;
+}
+template <typename AB, typename C> inline C mfma_16x16x16_bf16(const AB& a, const AB& b, const C& c) {
+    static_assert(sizeof(AB) == 8, "4 x bf16 operand fragments");
+    Sched& S = *t_sched;
+    auto& w = S.wide[t_wave];
+    std::memcpy(&w[t_lane][0], &a, 8);
+    std::memcpy(&w[t_lane][2], &b, 8);
+    wave_barrier();
+    C d = c;
+    const int col = t_lane & 15, rg = t_lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rg + r;
+        float sum = 0.f;
+        for (int k = 0; k < 16; ++k) {
+            uint16_t av, bv;
+            std::memcpy(&av, (const char*)&w[row + 16 * (k >> 2)][0] + 2 * (k & 3), 2);
+            std::memcpy(&bv, (const char*)&w[col + 16 * (k >> 2)][2] + 2 * (k & 3), 2);
+            sum += bf16_bits_to_float(av) * bf16_bits_to_float(bv);
+        }
+        d[r] = c[r] + sum;
+    }
+    wave_barrier();
+    return d;
+}
+
 inline void run_block(Sched& S, unsigned bx, unsigned by, unsigned block_threads) {
     const int n = (int)block_threads;
     S.nthreads = n;
@@ -272,6 +320,8 @@ inline emul_s16x4 emul_read_tr16(const void* p) {
 #define COT_LDS_BARRIER() emul::block_barrier()
 
 #define COT_MFMA_16X16X32_BF16(a, b, c) emul::mfma_16x16x32_bf16((a), (b), (c))
+#define COT_MFMA_16X16X4_F32(a, b, c) emul::mfma_16x16x4_f32((a), (b), (c))
+#define COT_MFMA_16X16X16_BF16(a, b, c) emul::mfma_16x16x16_bf16((a), (b), (c))
 #define COT_KEEP_PACKED(u) ((void)(u))
 #define COT_WAIT_LOADS() ((void)0)
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only ever applied to wave-uniform values

@@ -141,8 +141,12 @@ def test_other_inputs_keep_the_module_path(monkeypatch):
     monkeypatch.setattr(c1, "MODE", "hip")
     conv = nn.Conv2d(16, 16, 1).to(DEV)
     x = torch.randn(2, 16, 8, 8, device=DEV)
-    assert not c1.eligible_hip(conv, x)                      # fp32
-    assert torch.equal(c1.conv1x1(conv, x), conv(x))
+    assert not c1.eligible_hip(conv, x) and c1.eligible_general(conv, x)    # fp32: the general kernels (conv_gen.hip)
+    assert torch.allclose(c1.conv1x1(conv, x), conv(x), atol=1e-5, rtol=1e-5)
+    xh = x.half()
+    assert not c1.eligible_general(conv.half(), xh)          # fp16: the module
+    assert torch.equal(c1.conv1x1(conv, xh), conv(xh))
+    conv = conv.float()
     convb = nn.Conv2d(12, 16, 1).to(DEV).bfloat16()
     assert not c1.eligible_hip(convb, torch.zeros(2, 12, 8, 8, device=DEV).bfloat16())   # Ci % 8 != 0
     convs = nn.Conv2d(16, 16, 1, stride=2).to(DEV).bfloat16()

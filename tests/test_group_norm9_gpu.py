@@ -39,6 +39,9 @@ def test_other_inputs_keep_the_module(monkeypatch):
     monkeypatch.setattr(g9, "MODE", "hip")
     gn = nn.GroupNorm(4, 36).to(DEV)
     x = torch.randn(2, 36, 8, 8, device=DEV)
-    assert not g9.eligible(gn, x)                                   # fp32
-    assert torch.equal(g9.group_norm9(gn, x), gn(x))
+    assert g9.eligible(gn, x)                                       # fp32: the fp32 kernels
+    assert torch.allclose(g9.group_norm9(gn, x), gn(x), atol=1e-5, rtol=1e-5)
+    assert not g9.eligible(gn.half(), x.half())                     # fp16: the module
+    assert torch.equal(g9.group_norm9(gn, x.half()), gn(x.half()))
+    gn = gn.float()
     assert not g9.eligible(nn.GroupNorm(4, 32).to(DEV).bfloat16(), torch.zeros(2, 32, 8, 8, device=DEV).bfloat16())

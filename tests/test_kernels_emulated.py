@@ -675,7 +675,7 @@ def test_conv1x1_rejects_what_it_does_not_cover():
     y = torch.zeros(1, 8, 4, 4).bfloat16()
     dt = _lib.dtype_code(torch.bfloat16)
     assert _EMUL.cot_conv1x1_forward(P(x), None, 12, P(w), None, P(y), 1, 12, 8, 16, dt, None) == -2  # Ci % 8 != 0
-    assert _EMUL.cot_conv1x1_forward(P(x), None, 16, P(w), None, P(y), 1, 16, 8, 16, 0, None) == -2   # fp32
+    assert _EMUL.cot_conv1x1_forward(P(x), P(x), 8, P(w), None, P(y), 1, 16, 8, 16, 0, None) == -2    # fp32 with two slabs
     assert _EMUL.cot_conv1x1_forward(P(x), None, 8, P(w), None, P(y), 1, 16, 8, 16, dt, None) == -1   # c1 != Ci, no x2
 
 
@@ -848,7 +848,8 @@ def test_conv3x3_autograd_wiring_on_emulated_kernels(monkeypatch):
     x = torch.randn(2, 32, 6, 5).bfloat16().requires_grad_(True)
     g = torch.randn(2, 32, 6, 5).bfloat16()
     assert c3.eligible(conv, x)
-    assert not c3.eligible(nn.Conv2d(32, 32, 3, padding=1, groups=8, bias=False).bfloat16(), x)   # 4 channels per group
+    assert c3.eligible(nn.Conv2d(32, 32, 3, padding=1, groups=8, bias=False).bfloat16(), x)   # 4 per group: general kernels
+    assert not c3.eligible(nn.Conv2d(32, 32, 3, padding=1, groups=4, bias=False).half(), x.half())
     assert not c3.eligible(nn.Conv2d(32, 32, 3, stride=2, padding=1, bias=False).bfloat16(), x)
     y = c3.conv3x3(conv, x)
     y.backward(g)
@@ -1054,7 +1055,7 @@ def test_group_norm9_rejects_what_it_does_not_cover():
     g = torch.zeros(9).bfloat16()
     dt = _lib.dtype_code(torch.bfloat16)
     assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 8, 16, 1e-5, dt, None) == -1      # C % 9
-    assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 9, 16, 1e-5, 0, None) == -2       # fp32
+    assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 9, 16, 1e-5, 3, None) == -2       # fp16
     assert _EMUL.cot_group_norm9_forward(P(x), P(g), P(g), P(x), P(m), P(m), 1, 9, 9000, 1e-5, dt, None) == -2    # too large
 
 
@@ -1513,3 +1514,198 @@ def test_results_do_not_depend_on_the_lane_schedule(order):
         _EMUL.emul_set_order(0)
     for i, (a, b) in enumerate(zip(base, other)):
         assert torch.equal(a, b), i
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# general grouped convolutions (csrc/conv_gen.hip): fp32 tensors, grouped 1x1, channel counts off the MFMA-32 grid
+# ---------------------------------------------------------------------------------------------------------------------
+def _tol(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 3e-2)
+
+
+@pytest.mark.parametrize("N,Ci,Co,G,H,W,bias", [
+    (2, 32, 24, 1, 7, 7, True),      # groups = 1, partial output tile, 98 pixels = 1.5 pixel tiles
+    (1, 192, 48, 2, 8, 8, False),    # CoXtLayer.embed[0] at dim = 96: 96 -> 24 per group
+    (2, 48, 108, 2, 5, 6, True),     # embed[3]: 24 -> 54 per group, bias
+    (1, 96, 96, 2, 9, 9, False),     # conv1x1[0]: 48 -> 48 per group
+    (3, 20, 136, 1, 3, 3, False),    # 20 reduction channels (two steps, the second mostly zeros), three output tiles
+    (1, 6, 2, 2, 1, 5, True),        # 3 -> 1 per group, one-row image
+])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_general_grouped_conv1x1_kernels(N, Ci, Co, G, H, W, bias, dtype):
+    torch.manual_seed(31)
+    HW, dt = H * W, _lib.dtype_code(dtype)
+    x = torch.randn(N, Ci, H, W).to(dtype)
+    w = (torch.randn(Co, Ci // G) / (Ci // G) ** 0.5).to(dtype)
+    b = torch.randn(Co).to(dtype) if bias else None
+    gy = torch.randn(N, Co, H, W).to(dtype)
+    xf, wf = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    bf = b.double().requires_grad_(True) if bias else None
+    yr = torch.nn.functional.conv2d(xf, wf.view(Co, Ci // G, 1, 1), bf, 1, 0, 1, G)
+    yr.backward(gy.double())
+    atol, rtol = _tol(dtype)
+
+    y = torch.full_like(x[:, :1].expand(N, Co, H, W).contiguous(), float("nan"))
+    rc = _EMUL.cot_conv1x1g_forward(P(x), P(w), P(b) if bias else None, P(y), N, Ci, Co, G, HW, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(y.double(), yr.detach(), atol=atol * 4, rtol=rtol), (y.double() - yr).abs().max()
+    gx = torch.full_like(x, float("nan"))
+    rc = _EMUL.cot_conv1x1g_backward_data(P(gy), P(w), P(gx), 0, N, Ci, Co, G, HW, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(gx.double(), xf.grad, atol=atol * 4, rtol=rtol), (gx.double() - xf.grad).abs().max()
+    # accumulate: gx += the same product
+    rc = _EMUL.cot_conv1x1g_backward_data(P(gy), P(w), P(gx), 1, N, Ci, Co, G, HW, dt, None)
+    assert rc == 0
+    assert torch.allclose(gx.double(), 2 * xf.grad, atol=atol * 12, rtol=2 * rtol)
+    nbytes = _EMUL.cot_conv1x1g_workspace(N, Ci, Co, G, HW)
+    assert nbytes > 0 and nbytes % 256 == 0
+    ws = torch.full((nbytes // 4,), float("nan"))
+    gw, gb = torch.full_like(w, float("nan")), (torch.full_like(b, float("nan")) if bias else None)
+    rc = _EMUL.cot_conv1x1g_backward_weight(P(gy), P(x), P(gw), P(gb) if bias else None, P(ws), N, Ci, Co, G, HW, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    scale = wf.grad.abs().max().item()
+    assert (gw.double() - wf.grad.view(Co, Ci // G)).abs().max().item() <= rtol * scale + atol
+    if bias:
+        assert (gb.double() - bf.grad).abs().max().item() <= rtol * bf.grad.abs().max().item() + atol
+
+
+@pytest.mark.parametrize("N,C,G,H,W,dtype", [
+    (2, 32, 4, 7, 7, torch.float32),      # CotLayer.key_embed geometry (8 per group) at the reference's precision
+    (1, 96, 8, 6, 10, torch.float32),     # CoXtLayer.key_embed: 12 per group
+    (1, 96, 8, 6, 10, torch.bfloat16),    # the same in bf16: channel counts the tuned kernels do not tile
+    (2, 48, 2, 1, 4, torch.bfloat16),     # 24 per group, one-row image
+    (1, 130, 1, 3, 3, torch.float32),     # 130 channels: three output tiles, nine reduction steps per tap
+])
+def test_general_grouped_conv3x3_kernels(N, C, G, H, W, dtype):
+    torch.manual_seed(37)
+    dt = _lib.dtype_code(dtype)
+    x = torch.randn(N, C, H, W).to(dtype)
+    w = (torch.randn(C, C // G, 3, 3) / (9 * C // G) ** 0.5).to(dtype)
+    gy = torch.randn(N, C, H, W).to(dtype)
+    xf, wf = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xf, wf, None, 1, 1, 1, G)
+    yr.backward(gy.double())
+    atol, rtol = _tol(dtype)
+    masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert _EMUL.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    ws = torch.full((_EMUL.cot_conv3x3g_workspace(N, C, C, G, H, W) // 4,), float("nan"))
+    y = torch.full_like(x, float("nan"))
+    rc = _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(y.double(), yr.detach(), atol=4 * atol, rtol=rtol), (y.double() - yr).abs().max()
+    gx = torch.full_like(x, float("nan"))
+    rc = _EMUL.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), 0, P(masks), P(ws), N, C, C, G, H, W, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(gx.double(), xf.grad, atol=4 * atol, rtol=rtol), (gx.double() - xf.grad).abs().max()
+    gw = torch.full_like(w, float("nan"))
+    rc = _EMUL.cot_conv3x3g_backward_weight(P(gy), P(x), P(gw), P(masks), P(ws), N, C, C, G, H, W, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert (gw.double() - wf.grad).abs().max().item() <= rtol * wf.grad.abs().max().item() + atol
+
+
+def test_conv1x1_fp32_through_the_plain_entry_points():
+    """cot_conv1x1_* with COT_F32 (one tensor): the reference's own precision on the MFMA fp32 path"""
+    torch.manual_seed(41)
+    N, Ci, Co, H, W = 2, 40, 72, 6, 6
+    x, w, b, gy = torch.randn(N, Ci, H, W), torch.randn(Co, Ci) / Ci ** 0.5, torch.randn(Co), torch.randn(N, Co, H, W)
+    xf, wf, bf = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xf, wf.view(Co, Ci, 1, 1), bf)
+    yr.backward(gy.double())
+    y = torch.full((N, Co, H, W), float("nan"))
+    assert _EMUL.cot_conv1x1_forward(P(x), None, Ci, P(w), P(b), P(y), N, Ci, Co, H * W, 0, None) == 0
+    assert torch.allclose(y.double(), yr.detach(), atol=1e-4, rtol=1e-5)
+    ws = torch.full((_EMUL.cot_conv1x1_workspace(N, Ci, Co, H * W, 1) // 4,), float("nan"))
+    gx = torch.full_like(x, float("nan"))
+    assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, H * W, 0, None) == 0
+    assert torch.allclose(gx.double(), xf.grad, atol=1e-4, rtol=1e-5)
+    gw, gb = torch.full_like(w, float("nan")), torch.full_like(b, float("nan"))
+    assert _EMUL.cot_conv1x1_backward_weight(P(gy), P(x), None, Ci, P(gw), P(gb), P(ws), N, Ci, Co, H * W, 0, None) == 0
+    assert torch.allclose(gw.double(), wf.grad.view(Co, Ci), atol=1e-4, rtol=1e-5)
+    assert torch.allclose(gb.double(), bf.grad, atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,G,H,W", [(2, 2, 8, 8), (1, 3, 24, 24), (3, 2, 7, 7), (1, 1, 56, 56), (1, 2, 3, 5), (1, 1, 100, 100)])
+def test_group_norm9_fp32_kernels(N, G, H, W):
+    torch.manual_seed(43)
+    C, HW = 9 * G, H * W
+    x = torch.randn(N, C, H, W) * 1.7 + 0.6
+    gamma, beta, dy = 1 + 0.3 * torch.randn(C), 0.2 * torch.randn(C), torch.randn(N, C, H, W)
+    xf, gf, bf = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.group_norm(xf, G, gf, bf, 1e-5)
+    yr.backward(dy.double())
+    y = torch.full_like(x, float("nan"))
+    mean, rstd = torch.empty(N * G), torch.empty(N * G)
+    rc = _EMUL.cot_group_norm9_forward(P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, C, HW, 1e-5, 0, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(y.double(), yr.detach(), atol=2e-5, rtol=1e-5)
+    dx, dg, db = torch.full_like(x, float("nan")), torch.empty(C), torch.empty(C)
+    ws = torch.full((N * C * 2,), float("nan"))
+    rc = _EMUL.cot_group_norm9_backward(P(dy), P(x), P(mean), P(rstd), P(gamma), P(dx), P(dg), P(db), P(ws), N, C, HW, 0,
+                                        None)
+    assert rc == 0, _EMUL.cot_last_error()
+    assert torch.allclose(dx.double(), xf.grad, atol=5e-5, rtol=1e-4), (dx.double() - xf.grad).abs().max()
+    assert torch.allclose(dg.double(), gf.grad, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(db.double(), bf.grad, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_coxt_layer_on_emulated_kernels(dtype, monkeypatch):
+    """CoXtLayer (models/cotnet.py:106-178) with every convolution and the GroupNorm on the library's kernels -- grouped 1x1
+    (groups 2), grouped 3x3 (groups 8, 12 channels per group), GroupNorm-9 -- against the plain modules in fp64; fp32 as the
+    reference trains, and the mixed-precision form (bf16 convolutions, fp32 BatchNorm parameters) of bench.py"""
+    import copy
+    import cotnet_amd.aggregation_zeropad as az
+    from cotnet_amd import conv1x1 as c1, conv3x3g as c3, group_norm9 as g9, fused_bn, radix_tail
+    from cotnet_amd.cotnet import CoXtLayer
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (c1, c3, g9, fused_bn, radix_tail):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    for mod in (c1, c3, g9):
+        monkeypatch.setattr(mod, "MODE", "hip")
+    monkeypatch.setattr(az, "aggregation_zeropad",
+                        lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
+    caches = (c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
+    for cache in caches:
+        cache.clear()
+    torch.manual_seed(5)
+    layer = CoXtLayer(96, 3).train()
+    for m in layer.modules():   # off the all-ones / all-zeros initial values, so that every gradient is exercised
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.GroupNorm)):
+            torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+            torch.nn.init.uniform_(m.bias, -0.3, 0.3)
+    if dtype == torch.bfloat16:
+        to_mixed_bf16(layer)
+    ref = copy.deepcopy(layer).double()
+    x = torch.randn(2, 96, 6, 6).to(dtype)
+    g = torch.randn(2, 96, 6, 6).to(dtype)
+    calls = []
+    for name in ("cot_conv1x1g_forward", "cot_conv1x1g_backward_data", "cot_conv1x1g_backward_weight", "cot_conv3x3g_forward",
+                 "cot_group_norm9_forward"):
+        real = getattr(_EMUL, name)
+        monkeypatch.setattr(_EMUL, name, (lambda real, name: lambda *a: (calls.append(name), real(*a))[1])(real, name),
+                            raising=False)
+    xi = x.clone().requires_grad_(True)
+    y = layer(xi)
+    y.backward(g)
+    for name, n in (("cot_conv1x1g_forward", 3), ("cot_conv1x1g_backward_data", 3), ("cot_conv1x1g_backward_weight", 3),
+                    ("cot_conv3x3g_forward", 1), ("cot_group_norm9_forward", 1)):
+        assert calls.count(name) == n, (name, calls)
+    for mod in (c1, c3, g9):
+        monkeypatch.setattr(mod, "MODE", "")
+    monkeypatch.setattr(fused_bn, "ENABLED", False)
+    monkeypatch.setattr(radix_tail, "ENABLED", False)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g.double())
+
+    def err(a, b):
+        return ((a.double() - b).abs().mean() / (b.abs().mean() + 1e-30)).item()
+    tol = 1e-4 if dtype == torch.float32 else 0.12   # bf16: every intermediate is rounded; a wrong kernel gives ~1
+    assert err(y, yr.detach()) < tol
+    assert err(xi.grad, xr.grad) < tol
+    for (n, p), (_, q) in zip(layer.named_parameters(), ref.named_parameters()):
+        if q.grad.abs().mean() > 1e-3 * yr.abs().mean():   # (a bias in front of a BatchNorm has a zero gradient)
+            assert err(p.grad, q.grad) < 2 * tol, (n, err(p.grad, q.grad))
+    for cache in caches:
+        cache.clear()
