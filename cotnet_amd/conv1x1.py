@@ -10,12 +10,14 @@ modules: CotLayer.embed[0], embed[3], conv1x1[0] -- models/cotnet.py:51-62 -- Bo
 on `x`, or on the channel concatenation `[x, x2]` WITHOUT materialising it (the reference's `torch.cat([x, k], dim=1)`,
 models/cotnet.py:81).  Implementation is chosen by COT_CONV1X1:
 
-    (unset)  the module itself (MIOpen)                                   -- current default
-    hip      hand-written MFMA kernels, csrc/conv1x1.hip behind cot_conv1x1_*  (bf16, Ci % 8 == 0, Co % 8 == 0)
+    (unset)  the module itself (MIOpen)                                   -- the library default; bench.py's `new` set uses hip
+    hip      hand-written MFMA kernels behind cot_conv1x1_* / cot_conv1x1g_*:
+               bf16, groups 1, Ci % 8 == 0, Co % 8 == 0 -> csrc/conv_lds.hip (LDS-DMA pipeline) / csrc/conv1x1.hip
+               fp32, grouped (CoXtLayer, groups 2), other channel counts -> csrc/conv_gen.hip (general kernels)
     matmul   torch.matmul / einsum batched GEMMs (rocBLAS / hipBLASLt)
 
-`hip` is verified against torch through the host emulation of the kernels (tests/test_kernels_emulated.py) and by
-tests/test_conv1x1_gpu.py; it becomes the default once measured on an MI355X (ROUND2_PLAN.md).
+`hip` is verified against torch through the host emulation of the kernels (tests/test_kernels_emulated.py) and on the MI355X
+by tests/test_conv1x1_gpu.py / tests/test_conv_general_gpu.py.
 """
 import ctypes
 import os
@@ -103,7 +105,9 @@ class _Conv1x1Hip(Function):
         L = _lib.lib()
         has_bias = 1 if ctx.has_bias else 0
         dt = _lib.dtype_code(x1.dtype)
-        ws = torch.empty(_ws_bytes(N, Ci, Co, HW, has_bias), dtype=torch.uint8, device=gy.device)
+        nbytes = (int(L.cot_convg_workspace(N, Ci, Co, 1, HW, 1, 1)) if x1.dtype == torch.float32
+                  else _ws_bytes(N, Ci, Co, HW, has_bias))  # fp32: the general kernels' partial sums
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=gy.device)
         gx1 = gx2 = gw = gb = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             gx1 = torch.empty_like(x1)
@@ -155,7 +159,7 @@ class _Conv1x1gHip(Function):
             if rc:
                 _lib.check(rc, "cot_conv1x1g_backward_data")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            ws = torch.empty(int(L.cot_conv1x1g_workspace(N, Ci, Co, G, HW)), dtype=torch.uint8, device=gy.device)
+            ws = torch.empty(int(L.cot_convg_workspace(N, Ci, Co, G, HW, 1, 1)), dtype=torch.uint8, device=gy.device)
             gw = torch.empty_like(weight)
             gb = torch.empty(Co, dtype=weight.dtype, device=gy.device) if ctx.has_bias else None
             rc = L.cot_conv1x1g_backward_weight(_p(gy), _p(x), _p(gw), _p(gb), _p(ws), N, Ci, Co, G, HW, dt, _stream())

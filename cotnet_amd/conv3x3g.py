@@ -44,10 +44,15 @@ def _masks(H, W, device):
     return m
 
 
-def _ws_bytes(*key):
+def _ws_bytes(N, Cin, Cout, G, H, W, dtype=torch.bfloat16):
+    """workspace bytes; fp32 tensors and channel counts off the tuned kernels' grid are served by the general kernels"""
+    general = dtype == torch.float32 or (Cin // G) % 8 != 0 or (Cout // G) % 8 != 0
+    key = (N, Cin, Cout, G, H, W, general)
     v = _WS.get(key)
     if v is None:
-        v = _WS[key] = int(_lib.lib().cot_conv3x3g_workspace(*key))
+        L = _lib.lib()
+        v = _WS[key] = max(int(L.cot_conv3x3g_workspace(N, Cin, Cout, G, H, W)),
+                           int(L.cot_convg_workspace(N, Cin, Cout, G, H, W, 3)) if general else 0)
     return v
 
 
@@ -57,7 +62,7 @@ class _Conv3x3G(Function):
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
         masks = _masks(H, W, x.device)
-        ws = torch.empty(_ws_bytes(N, Cin, Cout, groups, H, W), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(_ws_bytes(N, Cin, Cout, groups, H, W, x.dtype), dtype=torch.uint8, device=x.device)
         y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=x.device)
         rc = _lib.lib().cot_conv3x3g_forward(_p(x), _p(weight), _p(y), _p(masks), _p(ws), N, Cin, Cout, groups, H, W,
                                              _lib.dtype_code(x.dtype), _stream())
@@ -75,7 +80,7 @@ class _Conv3x3G(Function):
         gy = gy.contiguous()
         L = _lib.lib()
         masks = _masks(H, W, x.device)
-        ws = torch.empty(_ws_bytes(N, Cin, Cout, G, H, W), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(_ws_bytes(N, Cin, Cout, G, H, W, x.dtype), dtype=torch.uint8, device=x.device)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)

@@ -27,6 +27,8 @@
 // order and one small kernel adds them (deterministic, no atomics) and rounds once.
 // These kernels are MFMA-bound in fp32 (157 TFLOP/s dense fp32 matrix peak, 1/16 of bf16) and staging-bound in bf16; they
 // are the general path, not the tuned one -- DESIGN.md 4.16.
+#include <algorithm>
+
 #include "mfma_common.h"
 
 namespace cot {
@@ -192,7 +194,6 @@ template <typename T> __global__ __launch_bounds__(256) void convg_wgrad_kernel(
     id /= a.ktiles;
     const int mt = id % a.mtiles, g = id / a.mtiles;
     const int split = blockIdx.y;
-    const int n0 = (int)((int64_t)split * a.N / a.splits), n1 = (int)((int64_t)(split + 1) * a.N / a.splits);
     int dh = 0, dw = 0;
     if (a.taps == 9) {
         dh = tap / 3 - 1;
@@ -201,13 +202,19 @@ template <typename T> __global__ __launch_bounds__(256) void convg_wgrad_kernel(
     const int row = t >> 2, qq = t & 3;
     const int m = mt * TILE + row, k = kt * TILE + row;
     const bool mok = m < a.Og, kok = k < a.Ig;
-    const int psteps = (HW + BK - 1) / BK, nsteps = (n1 - n0) * psteps;
+    // the reduction runs over (image, 16-pixel block) pairs; a split owns a contiguous range of them, so even a 56 x 56 plane
+    // of a 64-channel layer (4 output tiles) spreads over the whole chip
+    const int psteps = (HW + BK - 1) / BK;
+    const int64_t all_steps = (int64_t)a.N * psteps;
+    const int64_t s0 = all_steps * split / a.splits;
+    const int nsteps = (int)(all_steps * (split + 1) / a.splits - s0);
     const bool do_bias = a.want_bias && kt == 0 && tap == 0;
     float bsum = 0.f;
 
     Quad<T> ar, br;
     auto load_step = [&](int s) __attribute__((always_inline)) {
-        const int ni = s / psteps, n = n0 + ni, pb = (s - ni * psteps) * BK + 4 * qq;
+        const int64_t sg = s0 + s;
+        const int n = (int)(sg / psteps), pb = (int)(sg - (int64_t)n * psteps) * BK + 4 * qq;
         const T* gp = (const T*)a.gy + ((int64_t)n * a.Co + (int64_t)g * a.Og + m) * HW;
         const T* xp = (const T*)a.x + ((int64_t)n * a.Ci + (int64_t)g * a.Ig + k) * HW;
 #pragma unroll
@@ -265,19 +272,29 @@ template <typename T> __global__ __launch_bounds__(256) void convg_wgrad_kernel(
     }
 }
 
+// gw[i] = sum over splits of part[k][i] (bias entries appended after the weight entries).  16 elements x 16 split lanes
+// per workgroup: a lane adds every 16th split, the 16 lane sums are added in a fixed order through LDS -- deterministic, and
+// a 256-split reduction is 16 dependent loads deep instead of 256.
 template <typename T>
 __global__ __launch_bounds__(256) void convg_wgrad_reduce(const float* __restrict__ part, T* __restrict__ gw,
                                                          T* __restrict__ gbias, int64_t PS, int Co, int splits) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < PS) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(int64_t)k * PS + i];
-        gw[i] = (T)s;
-    } else if (gbias && i - PS < Co) {
-        const int c = (int)(i - PS);
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(int64_t)splits * PS + (int64_t)k * Co + c];
-        gbias[c] = (T)s;
+    __shared__ float red[16][17];
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + e, total = PS + (gbias ? Co : 0);
+    float s = 0.f;
+    if (i < total) {
+        const float* src = i < PS ? part + i : part + (int64_t)splits * PS + (i - PS);
+        const int64_t stride = i < PS ? PS : Co;
+        for (int k = sl; k < splits; k += 16) s += src[(int64_t)k * stride];
+    }
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][e];
+        if (i < PS) gw[i] = (T)t;
+        else gbias[i - PS] = (T)t;
     }
 }
 
@@ -326,18 +343,23 @@ int convg_backward_data(const void* gy, const void* w, void* gx, int N, int Cin,
     return convg_launch(a, dtype, stream);
 }
 
-static int convg_splits(int N, int Cin, int Cout, int G, int ksize) {
+// splits of the pixel reduction: enough workgroups for ~4 per CU, at least 8 steps (128 pixels) per workgroup, and at most
+// 32 MB of partial sums
+static int convg_splits(int N, int Cin, int Cout, int G, int HW, int ksize) {
     const int64_t tiles = (int64_t)G * ceil_div(Cout / G, gen::TILE) * ceil_div(Cin / G, gen::TILE) * ksize * ksize;
+    const int64_t steps = (int64_t)N * ceil_div(HW, gen::BK);
+    const int64_t PS = (int64_t)Cout * (Cin / G) * ksize * ksize;
     int64_t s = (1024 + tiles - 1) / tiles;
-    if (s > 32) s = 32;
-    if (s > N) s = N;
+    s = std::min(s, std::max<int64_t>(1, steps / 8));
+    s = std::min(s, std::max<int64_t>(1, ((int64_t)32 << 20) / ((PS + Cout) * 4)));
+    s = std::min<int64_t>(s, 512);
     return s < 1 ? 1 : (int)s;
 }
 
 int64_t convg_workspace(int N, int Cin, int Cout, int G, int H, int W, int ksize) {
     if (!convg_shape_ok(N, Cin, Cout, G, H, W, ksize)) return 0;
     const int64_t PS = (int64_t)Cout * (Cin / G) * ksize * ksize;
-    return ((int64_t)convg_splits(N, Cin, Cout, G, ksize) * (PS + Cout) * 4 + 255) / 256 * 256;
+    return ((int64_t)convg_splits(N, Cin, Cout, G, H * W, ksize) * (PS + Cout) * 4 + 255) / 256 * 256;
 }
 
 int convg_backward_weight(const void* gy, const void* x, void* gw, void* gbias, float* workspace, int N, int Cin, int Cout,
@@ -346,12 +368,12 @@ int convg_backward_weight(const void* gy, const void* x, void* gw, void* gbias, 
     gen::WgArgs a;
     a.gy = gy; a.x = x; a.part = workspace;
     a.N = N; a.Ci = Cin; a.Co = Cout; a.G = G; a.Ig = Cin / G; a.Og = Cout / G; a.H = H; a.W = W;
-    a.taps = ksize * ksize; a.splits = convg_splits(N, Cin, Cout, G, ksize);
+    a.taps = ksize * ksize; a.splits = convg_splits(N, Cin, Cout, G, H * W, ksize);
     a.mtiles = ceil_div(a.Og, gen::TILE); a.ktiles = ceil_div(a.Ig, gen::TILE);
     a.want_bias = gbias != nullptr;
     const dim3 grid((unsigned)(G * a.mtiles * a.ktiles * a.taps), (unsigned)a.splits);
     const int64_t PS = (int64_t)Cout * a.Ig * a.taps;
-    const dim3 rgrid((unsigned)ceil_div64(PS + (gbias ? Cout : 0), 256));
+    const dim3 rgrid((unsigned)ceil_div64(PS + (gbias ? Cout : 0), 16));
     if (dtype == COT_F32) {
         COT_LAUNCH((gen::convg_wgrad_kernel<float>), grid, dim3(256), 0, stream, a);
         COT_LAUNCH((gen::convg_wgrad_reduce<float>), rgrid, dim3(256), 0, stream, (const float*)workspace, (float*)gw,

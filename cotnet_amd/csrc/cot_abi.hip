@@ -343,8 +343,7 @@ int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias) {
     int splits = conv1x1_wgrad_splits(N, Co, Ci, HW, has_bias);
     if (conv1x1_wgrad_lds_covers(N, HW)) splits = std::max(splits, conv1x1_wgrad_lds_splits(N, Co, Ci, HW, has_bias));
     const int64_t part = (int64_t)splits * Co * (Ci + (has_bias ? 1 : 0)) * 4;
-    const int64_t gen = convg_workspace(N, Ci, Co, 1, HW, 1, 1);  // (the query has no dtype: the fp32 path's need is covered too)
-    return ((std::max(std::max(wt, part), gen)) + 255) / 256 * 256;
+    return ((wt > part ? wt : part) + 255) / 256 * 256;
 }
 
 int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, int N,
@@ -426,8 +425,7 @@ int64_t cot_conv3x3g_workspace(int N, int Cin, int Cout, int groups, int H, int 
     if (N <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || H <= 0 || W <= 0 || Cin % groups || Cout % groups) return 0;
     const int64_t wb = (int64_t)Cout * (Cin / groups) * 10 * 2;  // repacked weights of the LDS kernels (10 taps: one of zeros)
     const int64_t part = (int64_t)conv3x3g_wgrad_splits(N, Cin, Cout, groups, H * W) * Cout * (Cin / groups) * 9 * 4;
-    const int64_t gen = convg_workspace(N, Cin, Cout, groups, H, W, 3);
-    return (std::max(std::max(wb, part), gen) + 255) / 256 * 256;
+    return ((wb > part ? wb : part) + 255) / 256 * 256;
 }
 
 int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void* masks, void* workspace, int N, int Cin,
@@ -646,9 +644,9 @@ static int conv1x1g_validate(int N, int Ci, int Co, int G, int HW, int dtype) {
     return COT_OK;
 }
 
-int64_t cot_conv1x1g_workspace(int N, int Ci, int Co, int groups, int HW) {
-    if (N <= 0 || Ci <= 0 || Co <= 0 || groups <= 0 || HW <= 0 || Ci % groups || Co % groups) return 0;
-    return convg_workspace(N, Ci, Co, groups, HW, 1, 1);
+int64_t cot_convg_workspace(int N, int Cin, int Cout, int groups, int H, int W, int ksize) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || H <= 0 || W <= 0 || Cin % groups || Cout % groups) return 0;
+    return convg_workspace(N, Cin, Cout, groups, H, W, ksize);
 }
 
 int cot_conv1x1g_forward(const void* x, const void* weight, const void* bias, void* y, int N, int Ci, int Co, int groups,

@@ -194,8 +194,12 @@ int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, c
  * embed[3] = Conv2d(dim/2, 9*dim/8, 1, groups=2) with bias, conv1x1[0] = Conv2d(dim, dim, 1, groups=2),
  * models/cotnet.py:123-131).  weight [Co][Ci/groups] as torch stores it, bias NULL or [Co]; COT_BF16 or COT_F32, any channel
  * counts (12 / 24 / 54 per group occur).  backward_weight is deterministic (partial sums in `workspace`, fixed order);
- * accumulate (backward_data): nonzero = gx += result. */
-int64_t cot_conv1x1g_workspace(int N, int Ci, int Co, int groups, int HW);
+ * accumulate (backward_data): nonzero = gx += result.
+ * Workspace of the general kernels: cot_convg_workspace(N, Cin, Cout, groups, H, W, ksize) bytes, ksize 1 (H*W = the plane,
+ * pass H = HW, W = 1) or 3.  It is what backward_weight needs for every cot_conv1x1g_* call AND for the cot_conv1x1_* /
+ * cot_conv3x3g_* calls that the general kernels serve: COT_F32 tensors, and COT_BF16 3x3 convolutions with channels per
+ * group that are not multiples of 8 (cot_conv1x1_workspace / cot_conv3x3g_workspace size the tuned bf16 kernels only). */
+int64_t cot_convg_workspace(int N, int Cin, int Cout, int groups, int H, int W, int ksize);
 int cot_conv1x1g_forward(const void* x, const void* weight, const void* bias, void* y, int N, int Ci, int Co, int groups,
                          int HW, int dtype, void* stream);
 int cot_conv1x1g_backward_data(const void* gy, const void* weight, void* gx, int accumulate, int N, int Ci, int Co,

@@ -78,14 +78,15 @@ def conv_general(N, Ci, Co, G, H, W, ksize, dtype):
     w, b = guarded(torch.randn(Co, Ci // G, ksize, ksize).to(dtype)), guarded(torch.randn(Co).to(dtype))
     y, gx, gw, gb = (guarded(torch.zeros_like(t)) for t in (gy, x, w, b))
     if ksize == 1:
-        ws = guarded(torch.empty(E.cot_conv1x1g_workspace(N, Ci, Co, G, H * W), dtype=torch.uint8))
+        ws = guarded(torch.empty(E.cot_convg_workspace(N, Ci, Co, G, H * W, 1, 1), dtype=torch.uint8))
         assert E.cot_conv1x1g_forward(P(x), P(w), P(b), P(y), N, Ci, Co, G, H * W, dt, None) == 0
         assert E.cot_conv1x1g_backward_data(P(gy), P(w), P(gx), 1, N, Ci, Co, G, H * W, dt, None) == 0
         assert E.cot_conv1x1g_backward_weight(P(gy), P(x), P(gw), P(gb), P(ws), N, Ci, Co, G, H * W, dt, None) == 0
     else:
         masks = torch.empty(E.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
         assert E.cot_conv3x3g_masks(P(masks), H, W, None) == 0
-        ws = guarded(torch.empty(E.cot_conv3x3g_workspace(N, Ci, Co, G, H, W), dtype=torch.uint8))
+        ws = guarded(torch.empty(max(E.cot_conv3x3g_workspace(N, Ci, Co, G, H, W), E.cot_convg_workspace(N, Ci, Co, G, H, W, 3)),
+                                 dtype=torch.uint8))
         assert E.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, Ci, Co, G, H, W, dt, None) == 0
         assert E.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), 1, P(masks), P(ws), N, Ci, Co, G, H, W, dt, None) == 0
         assert E.cot_conv3x3g_backward_weight(P(gy), P(x), P(gw), P(masks), P(ws), N, Ci, Co, G, H, W, dt, None) == 0

@@ -12,10 +12,20 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(params=[0, 1], ids=["finalize-kernel", "finalize-folded"])
+def fold(request):
+    """cot_set_tuning(12): the per-channel finalize step as its own launch, or folded into the apply kernels' prologue (what
+    bench.py's `new` kernel set runs)"""
+    from cotnet_amd import _lib
+    _lib.check(_lib.lib().cot_set_tuning(12, request.param), "cot_set_tuning")
+    yield request.param
+    _lib.check(_lib.lib().cot_set_tuning(12, 0), "cot_set_tuning")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act,use_res", [(None, False), ("relu", False), ("relu", True), ("silu", False)])
 @pytest.mark.parametrize("N,C,H", [(8, 64, 56), (8, 128, 28), (8, 256, 14), (8, 2048, 7), (3, 24, 5)])
-def test_matches_torch_modules(N, C, H, act, use_res, dtype):
+def test_matches_torch_modules(N, C, H, act, use_res, dtype, fold):
     torch.manual_seed(C + H)
     bn_a = nn.BatchNorm2d(C).to(DEV).train()
     with torch.no_grad():

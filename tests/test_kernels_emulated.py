@@ -1557,7 +1557,7 @@ def test_general_grouped_conv1x1_kernels(N, Ci, Co, G, H, W, bias, dtype):
     rc = _EMUL.cot_conv1x1g_backward_data(P(gy), P(w), P(gx), 1, N, Ci, Co, G, HW, dt, None)
     assert rc == 0
     assert torch.allclose(gx.double(), 2 * xf.grad, atol=atol * 12, rtol=2 * rtol)
-    nbytes = _EMUL.cot_conv1x1g_workspace(N, Ci, Co, G, HW)
+    nbytes = _EMUL.cot_convg_workspace(N, Ci, Co, G, HW, 1, 1)
     assert nbytes > 0 and nbytes % 256 == 0
     ws = torch.full((nbytes // 4,), float("nan"))
     gw, gb = torch.full_like(w, float("nan")), (torch.full_like(b, float("nan")) if bias else None)
@@ -1588,7 +1588,8 @@ def test_general_grouped_conv3x3_kernels(N, C, G, H, W, dtype):
     atol, rtol = _tol(dtype)
     masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
     assert _EMUL.cot_conv3x3g_masks(P(masks), H, W, None) == 0
-    ws = torch.full((_EMUL.cot_conv3x3g_workspace(N, C, C, G, H, W) // 4,), float("nan"))
+    ws = torch.full((max(_EMUL.cot_conv3x3g_workspace(N, C, C, G, H, W), _EMUL.cot_convg_workspace(N, C, C, G, H, W, 3)) // 4,),
+                    float("nan"))
     y = torch.full_like(x, float("nan"))
     rc = _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None)
     assert rc == 0, _EMUL.cot_last_error()
@@ -1614,7 +1615,7 @@ def test_conv1x1_fp32_through_the_plain_entry_points():
     y = torch.full((N, Co, H, W), float("nan"))
     assert _EMUL.cot_conv1x1_forward(P(x), None, Ci, P(w), P(b), P(y), N, Ci, Co, H * W, 0, None) == 0
     assert torch.allclose(y.double(), yr.detach(), atol=1e-4, rtol=1e-5)
-    ws = torch.full((_EMUL.cot_conv1x1_workspace(N, Ci, Co, H * W, 1) // 4,), float("nan"))
+    ws = torch.full((_EMUL.cot_convg_workspace(N, Ci, Co, 1, H * W, 1, 1) // 4,), float("nan"))
     gx = torch.full_like(x, float("nan"))
     assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, H * W, 0, None) == 0
     assert torch.allclose(gx.double(), xf.grad, atol=1e-4, rtol=1e-5)
