@@ -391,6 +391,7 @@ int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_
 // host side
 extern int g_conv1x1_tune[4];  // [0] xcd remap (default 1), [1] MT override (0 = auto), [2] wgrad target waves, [3] launches of at least this many waves use ring depth 1 (0 = 8192)
 int g_conv1x1_tune[4] = {1, 0, 2048, 0};
+int g_wgrad_cap_pct = 0;  // cot_set_tuning key 19: partial-sum bytes of a weight gradient as a percentage of its input bytes (0 = the kernels' defaults)
 
 template <int PXV, int AL, bool TA>
 static int launch_fwd_mt(const bf16_t* x1, const bf16_t* x2, int k1, const bf16_t* A, const bf16_t* bias, bf16_t* y1,
@@ -446,9 +447,10 @@ int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias) {
     if (g_conv1x1_tune[2] < 0) return (int)(-g_conv1x1_tune[2] < T ? -g_conv1x1_tune[2] : T);  // forced split (tests)
     // ~4 workgroups per CU ...
     int64_t S = ceil_div64(g_conv1x1_tune[2] > 0 ? g_conv1x1_tune[2] / 2 : 1024, units);
-    // ... as long as the partial sums (written once, read once) stay below a quarter of the input bytes ...
+    // ... as long as the partial sums (written once, read once) stay below half of the input bytes (A/B on the MI355X,
+    // whole step: 25 % 21.72 ms, 50 % 21.07, 100 % 21.15, 200 % 21.15 -- profiles/r02_wgrad_split_ab.txt) ...
     const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
-    const int64_t cap = in_bytes / 4 / out_bytes;
+    const int64_t cap = in_bytes * (g_wgrad_cap_pct > 0 ? g_wgrad_cap_pct : 50) / 100 / out_bytes;
     if (S > cap) S = cap;
     if (S > T / 8) S = T / 8;  // ... and every wave of a slice has at least two reduction steps
     if (S > 1024) S = 1024;

@@ -23,6 +23,7 @@ namespace cot {
 int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_bias, void* gw, void* gb,
                                 hipStream_t stream);  // conv1x1.hip
 extern int g_conv1x1_tune[4];
+extern int g_wgrad_cap_pct;
 
 __host__ __device__ inline int masks_padded(int HW) { return (HW + 127) / 128 * 128 + 128; }
 
@@ -380,7 +381,7 @@ int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW) {
     if (g_conv1x1_tune[2] < 0) return (int)(-g_conv1x1_tune[2] < T ? -g_conv1x1_tune[2] : T);  // forced split (tests)
     int64_t S = ceil_div64(g_conv1x1_tune[2] > 0 ? g_conv1x1_tune[2] : 2048, units);
     const int64_t in_bytes = (int64_t)N * HW * (Cin + Cout) * 2, out_bytes = (int64_t)Cout * Jg * 4;
-    int64_t cap = in_bytes / 8 / out_bytes;
+    int64_t cap = in_bytes * (g_wgrad_cap_pct > 0 ? g_wgrad_cap_pct : 50) / 100 / out_bytes;  // (see conv1x1_wgrad_splits)
     if (cap < 4 && T >= 64) cap = 4;  // (a slice should not be a chain of hundreds of dependent steps)
     if (S > cap) S = cap;
     if (S > T) S = T;

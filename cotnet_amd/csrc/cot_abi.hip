@@ -120,6 +120,7 @@ int conv1x1_gemm(const void*, const void*, int, const void*, const void*, void*,
 int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_conv1x1_tune[4];
+extern int g_wgrad_cap_pct;
 // implemented in conv_lds.hip
 extern int g_conv_lds_tune[3];
 static inline bool g_conv_lds_tune_wgrad_off() { return (g_conv_lds_tune[2] >> 2) & 1; }  // tuning key 17 bit 2 (A/B)
@@ -293,6 +294,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 13) {
         g_bn_grid_cap = value > 0 ? value : 4096;
+        return COT_OK;
+    }
+    if (key == 19) {
+        g_wgrad_cap_pct = value > 0 ? value : 0;
         return COT_OK;
     }
     if (set_tuning_nchw(key, value) != 0) return set_error(COT_ERR_INVALID_ARG, "unknown tuning key %d", key);
