@@ -61,6 +61,8 @@ SYMBOLS = {
     "cot_avgpool3x3s2_backward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_maxpool3x3s2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_maxpool3x3s2_backward": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
+    "cot_maxpool3x3s2_forward_taps": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
+    "cot_maxpool3x3s2_backward_taps": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_stem7x7s2_workspace": (ctypes.c_int64, [_I, _I, _I]),
     "cot_stem7x7s2_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cot_stem7x7s2_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -593,6 +593,196 @@ __global__ __launch_bounds__(64) void bn_small_bwd(const T* __restrict__ dy, con
     }
 }
 
+// ---- channel-resident kernels: N*H*W small enough for one workgroup to hold a channel in registers -------------------------
+// The 14 x 14 and 7 x 7 stages (and 28 x 28 in bf16) have 4-63 K samples per channel: the streaming path's four launches
+// (statistics, apply, backward reduce, backward apply) each move a few MB and cost 5-10 us of launch ramp apiece --
+// 54 of CoTNet-50's 101 BatchNorms, ~1.7 ms of a 21 ms step.  Here one workgroup of up to 1024 lanes owns a channel: it loads
+// the channel once (the N row segments of H*W elements, vector width V), keeps it packed in registers, reduces through LDS
+// and writes the result: forward = 1 read + 1 write and ONE launch (streaming: 2 reads + 1 write, 2 launches), backward =
+// 2 reads + 1 write and one launch (streaming: 4 reads + 1 write, 2 launches).  Statistics: mean, then the centred sum of
+// squares from the registers (two-pass, no cancellation), per-lane fp32 partials added in fp64 across the workgroup.
+int g_bn_chan = 1;  // cot_set_tuning key 21: 1 = on where eligible (default), 0 = streaming kernels only
+
+template <typename T, int V, bool BWD> struct ChanRounds {  // most rounds (vectors per lane) of a channel-resident kernel:
+    // 64 elements per lane forward; the backward holds two tensors and takes 32 in bf16 (128 registers per lane is all a
+    // 1024-lane workgroup gets)
+    static constexpr int value = sizeof(T) <= 2 ? (V == 8 ? (BWD ? 4 : 8) : (V == 4 ? (BWD ? 8 : 16) : 16)) : (V == 4 ? 8 : 16);
+};
+
+// sums of NV doubles over the workgroup, result in every lane; fixed order (deterministic)
+template <int NV> __device__ __forceinline__ void block_allsum_d(double (&v)[NV], double* smem /* NV * 16 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_allsum_d(v[k]);
+    __syncthreads();  // the previous use of smem is over
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) smem[k * 16 + wave] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += smem[k * 16 + w];
+        v[k] = t;
+    }
+}
+
+template <typename T, int V, int ACT>
+__global__ __launch_bounds__(1024) void bn_chan_fwd(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                                   float* __restrict__ rmean, float* __restrict__ rvar,
+                                                   long long* __restrict__ nbt, int N, int C, int HW, float eps, float mom) {
+    constexpr int R = ChanRounds<T, V, false>::value;
+    __shared__ double red[16];
+    const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
+    const int vpp = HW / V, MV = N * vpp;
+    const double M = (double)N * HW;
+    if (c == 0 && t == 0 && nbt) *nbt += 1;
+    Vec<T, V> xv[R];
+    int off[R];  // element offset of round r's vector (host: N*C*HW < 2^31), -1 = past the channel's end
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = r * NT + t;
+        off[r] = -1;
+        if (e < MV) {
+            const int n = e / vpp, v = e - n * vpp;
+            off[r] = (n * C + c) * HW + v * V;
+            xv[r] = ldv<T, V>(x + off[r]);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s += (float)xv[r].v[k];
+        }
+    }
+    double acc[1] = {(double)s};
+    block_allsum_d<1>(acc, red);
+    const float mu = (float)(acc[0] / M);
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (off[r] >= 0) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float d = (float)xv[r].v[k] - mu;
+                q += d * d;
+            }
+        }
+    acc[0] = (double)q;
+    block_allsum_d<1>(acc, red);
+    const float var = (float)(acc[0] / M), rs = 1.0f / sqrtf(var + eps);
+    if (t == 0) {
+        mean[c] = mu;
+        rstd[c] = rs;
+        if (rmean) {
+            const float unbiased = M > 1.0 ? (float)(acc[0] / (M - 1.0)) : var;
+            rmean[c] = (1.f - mom) * rmean[c] + mom * mu;
+            rvar[c] = (1.f - mom) * rvar[c] + mom * unbiased;
+        }
+    }
+    const float a = gamma[c] * rs, b = beta[c] - mu * a;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (off[r] >= 0) {
+            Vec<T, V> rv, o;
+            if (res) rv = ldv<T, V>(res + off[r]);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float z = (float)xv[r].v[k] * a + b;
+                if (res) z += (float)rv.v[k];
+                o.v[k] = (T)act_fwd<ACT>(z);
+            }
+            stv<T, V>(y + off[r], o);
+        }
+}
+
+template <typename T, int V, int ACT>
+__global__ __launch_bounds__(1024) void bn_chan_bwd(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                   T* __restrict__ dx, T* __restrict__ dres, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, int N, int C, int HW) {
+    constexpr int R = ChanRounds<T, V, true>::value;
+    __shared__ double red[32];
+    const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
+    const int vpp = HW / V, MV = N * vpp;
+    const float inv_m = 1.0f / ((float)N * (float)HW);
+    const float m = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    Vec<T, V> xv[R], dv[R];
+    int off[R];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = r * NT + t;
+        off[r] = -1;
+        if (e < MV) {
+            const int n = e / vpp, v = e - n * vpp;
+            off[r] = (n * C + c) * HW + v * V;
+            xv[r] = ldv<T, V>(x + off[r]);
+            dv[r] = ldv<T, V>(dy + off[r]);
+            if (ACT == ACT_RELU_Y) {  // the saved output's sign decides: fold it into dy now (exact), y is not kept
+                const Vec<T, V> yv = ldv<T, V>(y + off[r]);
+#pragma unroll
+                for (int k = 0; k < V; ++k) dv[r].v[k] = (float)yv.v[k] > 0.f ? dv[r].v[k] : (T)0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float xh = ((float)xv[r].v[k] - m) * rs;
+                const float g = ACT == ACT_RELU_Y ? (float)dv[r].v[k] : act_bwd<ACT>((float)dv[r].v[k], xh * ga + be);
+                sg += g;
+                sgx += g * xh;
+            }
+        }
+    }
+    double acc[2] = {(double)sg, (double)sgx};
+    block_allsum_d<2>(acc, red);
+    const float sb = (float)acc[0], sx = (float)acc[1];
+    if (t == 0) {
+        dbeta[c] = sb;
+        dgamma[c] = sx;
+    }
+    const float k1 = sb * inv_m, k2 = sx * inv_m, gr = ga * rs;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (off[r] >= 0) {
+            Vec<T, V> o, og;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float xh = ((float)xv[r].v[k] - m) * rs;
+                const float g = ACT == ACT_RELU_Y ? (float)dv[r].v[k] : act_bwd<ACT>((float)dv[r].v[k], xh * ga + be);
+                o.v[k] = (T)(gr * (g - k1 - xh * k2));
+                og.v[k] = (T)g;
+            }
+            stv<T, V>(dx + off[r], o);
+            if (dres) stv<T, V>(dres + off[r], og);
+        }
+}
+
+// vector width of the channel-resident kernels for this tensor, 0 = not eligible (streaming kernels)
+template <typename T, bool BWD> static int bn_chan_vec(int N, int C, int HW) {
+    if (!g_bn_chan || (int64_t)N * C * HW >= ((int64_t)1 << 31)) return 0;
+    int V = pick_vec(sizeof(T), HW);
+    if (V == 2) V = 1;  // (V = 2 has no instantiation: H*W = 2 * odd does not occur in the networks)
+    if (sizeof(T) > 2 && V == 8) V = 4;
+    const int64_t MV = (int64_t)N * HW / V;
+    const int rounds = V == 8 ? ChanRounds<T, 8, BWD>::value : (V == 4 ? ChanRounds<T, 4, BWD>::value : ChanRounds<T, 1, BWD>::value);
+    return MV <= (int64_t)1024 * rounds ? V : 0;
+}
+// lanes per workgroup (256 / 512 / 1024): at least what `rounds` vectors per lane need to cover the channel, and beyond
+// that as many as it takes for the C workgroups to fill the chip (~1024 lanes per CU): few channels -> big workgroups (more
+// loads in flight per CU), many channels -> small ones (more workgroups resident per CU, their load / reduce / store phases
+// interleave).  Measured on the MI355X (scripts/ubench_bn.py, profiles/r02_ubench_bn.log), forward us at 256 / 512 / 1024
+// lanes: 128 ch 14x14 11.2 / 7.9 / 7.5, 1024 ch 14x14 17.4 / 21.0 / 27.5, 2048 ch 7x7 23.8 / 24.6 / 44.2.
+static inline int bn_chan_threads(int N, int C, int HW, int V, int rounds) {
+    const int64_t MV = (int64_t)N * HW / V;
+    if (g_bn_chan > 1 && g_bn_chan <= 1024 && MV <= (int64_t)g_bn_chan * rounds) return g_bn_chan;  // (A/B: forced size)
+    const int need = MV <= (int64_t)256 * rounds ? 256 : (MV <= (int64_t)512 * rounds ? 512 : 1024);
+    const int fill = C <= 256 ? 1024 : (C <= 512 ? 512 : 256);
+    return need > fill ? need : fill;
+}
+template <typename T, bool BWD> static int bn_chan_rounds(int V) {
+    return V == 8 ? ChanRounds<T, 8, BWD>::value : (V == 4 ? ChanRounds<T, 4, BWD>::value : ChanRounds<T, 1, BWD>::value);
+}
+
 template <typename T>
 int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* mean,
                    float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW, float eps,
@@ -606,6 +796,22 @@ int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, 
         else BN_SF(ACT_NONE);
 #undef BN_SF
         return check_launch("bn_small_fwd");
+    }
+    if (const int cv = bn_chan_vec<T, false>(N, C, HW)) {
+        const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, false>(cv)));
+#define BN_CF(V_, A_) COT_LAUNCH((bn_chan_fwd<T, V_, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom)
+#define BN_CFV(V_)                                \
+    do {                                          \
+        if (act == ACT_RELU) BN_CF(V_, ACT_RELU); \
+        else if (act == ACT_SILU) BN_CF(V_, ACT_SILU); \
+        else BN_CF(V_, ACT_NONE);                 \
+    } while (0)
+        if (cv == 8) BN_CFV((sizeof(T) <= 2 ? 8 : 4));
+        else if (cv == 4) BN_CFV(4);
+        else BN_CFV(1);
+#undef BN_CFV
+#undef BN_CF
+        return check_launch("bn_chan_fwd");
     }
     const int v = pick_vec(sizeof(T), HW);
     if (v == 8) BN_F((sizeof(T) <= 2 ? 8 : 1));
@@ -629,6 +835,23 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
         else BN_SB(ACT_NONE);
 #undef BN_SB
         return check_launch("bn_small_bwd");
+    }
+    if (const int cv = bn_chan_vec<T, true>(N, C, HW)) {
+        const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, true>(cv)));
+#define BN_CB(V_, A_) COT_LAUNCH((bn_chan_bwd<T, V_, A_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW)
+#define BN_CBV(V_)                                         \
+    do {                                                   \
+        if (act == ACT_RELU && y) BN_CB(V_, ACT_RELU_Y);   \
+        else if (act == ACT_RELU) BN_CB(V_, ACT_RELU);     \
+        else if (act == ACT_SILU) BN_CB(V_, ACT_SILU);     \
+        else BN_CB(V_, ACT_NONE);                          \
+    } while (0)
+        if (cv == 8) BN_CBV((sizeof(T) <= 2 ? 8 : 4));
+        else if (cv == 4) BN_CBV(4);
+        else BN_CBV(1);
+#undef BN_CBV
+#undef BN_CB
+        return check_launch("bn_chan_bwd");
     }
     const int v = pick_vec(sizeof(T), HW);
     if (v == 8) BN_B((sizeof(T) <= 2 ? 8 : 1));

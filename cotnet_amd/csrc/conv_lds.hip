@@ -859,15 +859,21 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
         }
 }
 
+int g_wgrad_lds_cap_pct = 0;  // cot_set_tuning key 20 (0 = default 25 %)
 static inline bool wgrad_lds_aligned(int N, int HW) { return HW % 8 == 0 && HW >= 64 && ((int64_t)N * HW) % 32 == 0; }
 
-// Default: the aligned form only.  The general form (GEN = 1) is correct everywhere (tests, guard pages) but on the deep
-// layers it serves -- 14 x 14 / 7 x 7: outputs of 1-4 MB fp32 against 20-40 MB of input, so few slices -- its 128 x 128
-// tiles leave most CUs idle: measured 58 us (= first generation) at 14 x 14 and 118 us (vs 60) at 7 x 7.  cot_set_tuning
-// key 17 bit 3 switches it on for experiments.
-bool conv1x1_wgrad_lds_covers(int N, int HW) {
+// The aligned form wherever it applies; the general form (GEN = 1, any plane) for the big weight matrices of the deep layers
+// (14 x 14 / 7 x 7, Co*Ci >= 256 K: Bottleneck.conv1 / conv3 of stages 3-4, embed[0] / conv1x1 of stage 4), where its deeper
+// pipeline beats the register kernel once it is given enough slices -- measured cold on the MI355X (scripts/
+// ubench_wgrad_deep.py, profiles/r02_wgrad_deep.log): 2048->512 @7x7 50 us vs 71, 1024->256 @14x14 50 vs 59, the 512->512 /
+// 1024->256 @7x7 pair 28 vs 30.  Smaller matrices stay on the register kernel (22 vs 25 us).  cot_set_tuning key 17 bit 3
+// forces the general form everywhere (tests), bit 4 switches this rule off (A/B).
+static inline bool wgrad_lds_general(int HW, int M, int J) {
+    return HW >= 32 && (int64_t)M * J >= 262144 && !((g_conv_lds_tune[2] >> 4) & 1);
+}
+bool conv1x1_wgrad_lds_covers(int N, int HW, int M, int J) {
     if (!g_conv_lds_tune[0]) return false;
-    return wgrad_lds_aligned(N, HW) || (((g_conv_lds_tune[2] >> 3) & 1) && HW >= 32);
+    return wgrad_lds_aligned(N, HW) || (((g_conv_lds_tune[2] >> 3) & 1) && HW >= 32) || wgrad_lds_general(HW, M, J);
 }
 
 // number of slices of the LDS weight-gradient kernel (also sizes the workspace)
@@ -877,7 +883,10 @@ int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias) {
     const int64_t T = wgrad_lds_aligned(N, HW) ? (int64_t)N * HW / 32 : (int64_t)N * ceil_div(HW, 32);
     int64_t S = ceil_div64(1024, tiles);  // ~4 workgroups per CU
     const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
-    const int64_t cap = in_bytes / 4 / out_bytes;  // partial sums (written + read once) below a quarter of the inputs
+    // partial sums (written + read once) below a quarter of the inputs -- the same amount as the inputs for the general form
+    // (few, large tiles: 25 % would leave most CUs idle)
+    const int dflt = wgrad_lds_aligned(N, HW) ? 25 : 100;
+    const int64_t cap = in_bytes * (g_wgrad_lds_cap_pct > 0 ? g_wgrad_lds_cap_pct : dflt) / 100 / out_bytes;
     if (S > cap) S = cap;
     if (S > T / 8) S = T / 8;
     if (S > 1024) S = 1024;

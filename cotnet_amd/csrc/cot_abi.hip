@@ -121,6 +121,8 @@ int conv1x1_wgrad_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_conv1x1_tune[4];
 extern int g_wgrad_cap_pct;
+extern int g_wgrad_lds_cap_pct;
+extern int g_bn_chan;
 // implemented in conv_lds.hip
 extern int g_conv_lds_tune[3];
 static inline bool g_conv_lds_tune_wgrad_off() { return (g_conv_lds_tune[2] >> 2) & 1; }  // tuning key 17 bit 2 (A/B)
@@ -128,7 +130,7 @@ bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
 int conv1x1_lds_gemm(const void*, const void*, int, const void*, int, const void*, void*, void*, int, int, int, int, int, int,
                      hipStream_t);
 int transpose_bf16(const void* src, void* dst, int R, int C, int pack, hipStream_t stream);
-bool conv1x1_wgrad_lds_covers(int N, int HW);
+bool conv1x1_wgrad_lds_covers(int N, int HW, int M, int J);
 int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad_lds_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 int conv3x3g_lds_gemm(const void*, const void*, void*, void*, int, int, int, int, int, int, int, int, hipStream_t);
@@ -296,6 +298,14 @@ int cot_set_tuning(int key, int value) {
         g_bn_grid_cap = value > 0 ? value : 4096;
         return COT_OK;
     }
+    if (key == 21) {
+        g_bn_chan = value > 0 ? value : 0;  // 0 off, 1 on, 256 / 512 / 1024: on with that workgroup size (A/B)
+        return COT_OK;
+    }
+    if (key == 20) {
+        g_wgrad_lds_cap_pct = value > 0 ? value : 0;
+        return COT_OK;
+    }
     if (key == 19) {
         g_wgrad_cap_pct = value > 0 ? value : 0;
         return COT_OK;
@@ -346,7 +356,7 @@ int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias) {
     if (N <= 0 || Ci <= 0 || Co <= 0 || HW <= 0) return 0;
     const int64_t wt = (int64_t)Ci * Co * 2;
     int splits = conv1x1_wgrad_splits(N, Co, Ci, HW, has_bias);
-    if (conv1x1_wgrad_lds_covers(N, HW)) splits = std::max(splits, conv1x1_wgrad_lds_splits(N, Co, Ci, HW, has_bias));
+    if (conv1x1_wgrad_lds_covers(N, HW, Co, Ci)) splits = std::max(splits, conv1x1_wgrad_lds_splits(N, Co, Ci, HW, has_bias));
     const int64_t part = (int64_t)splits * Co * (Ci + (has_bias ? 1 : 0)) * 4;
     return ((wt > part ? wt : part) + 255) / 256 * 256;
 }
@@ -395,7 +405,7 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
     if (dtype == COT_F32)
         return convg_backward_weight(gy, x1, gweight, gbias, (float*)workspace, N, Ci, Co, 1, HW, 1, 1, dtype,
                                      (hipStream_t)stream);
-    if (conv1x1_wgrad_lds_covers(N, HW) && !g_conv_lds_tune_wgrad_off())
+    if (conv1x1_wgrad_lds_covers(N, HW, Co, Ci) && !g_conv_lds_tune_wgrad_off())
         return conv1x1_wgrad_lds_run(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
     return conv1x1_wgrad(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
 }
@@ -619,7 +629,7 @@ int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, 
 
 static int pool_call(int op, const void* a, const void* b, void* out, int64_t planes, int H, int W, int dtype, void* stream) {
     if (planes <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive planes/H/W");
-    if (!a || !out || (op == 3 && !b)) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (!a || !out || (op >= 3 && !b)) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if (dtype == COT_F32) return pool3x3s2<float>(op, a, b, out, planes, H, W, (hipStream_t)stream);
     if (dtype == COT_BF16) return pool3x3s2<bf16_t>(op, a, b, out, planes, H, W, (hipStream_t)stream);
     return set_error(COT_ERR_UNSUPPORTED, "cot_*pool3x3s2_*: dtype %d (float32 / bfloat16 only)", dtype);
@@ -636,6 +646,14 @@ int cot_maxpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int 
 int cot_maxpool3x3s2_backward(const void* gy, const void* x, void* gx, int64_t planes, int H, int W, int dtype,
                               void* stream) {
     return pool_call(3, gy, x, gx, planes, H, W, dtype, stream);
+}
+
+int cot_maxpool3x3s2_forward_taps(const void* x, void* y, void* taps, int64_t planes, int H, int W, int dtype, void* stream) {
+    return pool_call(4, x, taps, y, planes, H, W, dtype, stream);
+}
+int cot_maxpool3x3s2_backward_taps(const void* gy, const void* taps, void* gx, int64_t planes, int H, int W, int dtype,
+                                   void* stream) {
+    return pool_call(5, gy, taps, gx, planes, H, W, dtype, stream);
 }
 
 // ---- grouped 1x1 convolution (CoXtLayer, groups = 2): the general kernels of conv_gen.hip

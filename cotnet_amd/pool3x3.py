@@ -3,7 +3,8 @@
 `pool(module, x)` evaluates `nn.MaxPool2d(3, 2, 1)` (after the stem, models/resnet.py:556-561) or `nn.AvgPool2d(3, 2,
 padding=1)` (the "avd" pooling of stride-2 bottlenecks, models/cotnet.py:216) with kernels whose backward runs at
 memory speed -- torch's max_pool_backward / avg_pool2d_backward were 436 us and 3 x 163 us of the round-1 step for ~30 us of
-traffic each; the max-pool backward recomputes the arg-max (torch's tie rule) instead of reading an int64 index tensor.
+traffic each; the max-pool forward keeps the arg-max as one byte per window (torch's tie rule) and the backward reads that instead
+of an int64 index tensor (or x).
 Any other module or tensor (other geometry, ceil_mode, fp64, channels-last, CPU) takes the module itself.
 """
 import ctypes
@@ -60,21 +61,23 @@ class _MaxPool(Function):
     def forward(ctx, x):
         N, C, H, W = x.shape
         y = _out(x)
-        rc = _lib.lib().cot_maxpool3x3s2_forward(_p(x), _p(y), N * C, H, W, _DT[x.dtype], _stream())
+        taps = torch.empty(y.shape, dtype=torch.uint8, device=x.device)  # winning element of every window, one byte
+        rc = _lib.lib().cot_maxpool3x3s2_forward_taps(_p(x), _p(y), _p(taps), N * C, H, W, _DT[x.dtype], _stream())
         if rc:
-            _lib.check(rc, "cot_maxpool3x3s2_forward")
-        ctx.save_for_backward(x)
+            _lib.check(rc, "cot_maxpool3x3s2_forward_taps")
+        ctx.save_for_backward(taps)
+        ctx.shape = x.shape
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        (x,) = ctx.saved_tensors
-        N, C, H, W = x.shape
+        (taps,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
         gy = gy.contiguous()
-        gx = torch.empty_like(x)
-        rc = _lib.lib().cot_maxpool3x3s2_backward(_p(gy), _p(x), _p(gx), N * C, H, W, _DT[x.dtype], _stream())
+        gx = torch.empty(ctx.shape, dtype=gy.dtype, device=gy.device)
+        rc = _lib.lib().cot_maxpool3x3s2_backward_taps(_p(gy), _p(taps), _p(gx), N * C, H, W, _DT[gy.dtype], _stream())
         if rc:
-            _lib.check(rc, "cot_maxpool3x3s2_backward")
+            _lib.check(rc, "cot_maxpool3x3s2_backward_taps")
         return gx
 
 

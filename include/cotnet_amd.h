@@ -252,12 +252,18 @@ int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, 
  *                       stride-2 bottlenecks, models/cotnet.py:216
  *   cot_maxpool3x3s2_*  nn.MaxPool2d(kernel_size=3, stride=2, padding=1) after the stem, models/resnet.py:556-561; the
  *                       backward recomputes the arg-max from x with torch's tie rule (first maximum in row-major window
- *                       order) instead of reading an index tensor.   COT_F32 / COT_BF16. */
+ *                       order) instead of reading an index tensor.   COT_F32 / COT_BF16.
+ *   cot_maxpool3x3s2_forward_taps / _backward_taps: the same pooling with the arg-max kept as ONE BYTE per output window
+ *                       (taps [planes][Ho][Wo], value kh*3 + kw of the winning element): the backward reads dY and the taps
+ *                       and never touches x (torch keeps an int64 index per window). */
 int cot_avgpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);
 int cot_avgpool3x3s2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream);
 int cot_maxpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);
 int cot_maxpool3x3s2_backward(const void* gy, const void* x, void* gx, int64_t planes, int H, int W, int dtype,
                               void* stream);
+int cot_maxpool3x3s2_forward_taps(const void* x, void* y, void* taps, int64_t planes, int H, int W, int dtype, void* stream);
+int cot_maxpool3x3s2_backward_taps(const void* gy, const void* taps, void* gx, int64_t planes, int H, int W, int dtype,
+                                   void* stream);
 
 /* ---- fused SGD over a flat parameter bucket (replaces torch.optim.SGD(nesterov=True),
  * optim/optim_factory.py:54-56, which launches per parameter tensor):

@@ -169,6 +169,9 @@ def pooling(N, C, H, W, dtype):
     y, gy = guarded(torch.empty(N, C, Ho, Wo).to(dtype)), guarded(torch.randn(N, C, Ho, Wo).to(dtype))
     assert E.cot_maxpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
     assert E.cot_maxpool3x3s2_backward(P(gy), P(x), P(gx), N * C, H, W, dt, None) == 0
+    taps = guarded(torch.empty(y.shape, dtype=torch.uint8))
+    assert E.cot_maxpool3x3s2_forward_taps(P(x), P(y), P(taps), N * C, H, W, dt, None) == 0
+    assert E.cot_maxpool3x3s2_backward_taps(P(gy), P(taps), P(gx), N * C, H, W, dt, None) == 0
     assert E.cot_avgpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
     assert E.cot_avgpool3x3s2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
 
@@ -217,7 +220,9 @@ if __name__ == "__main__":
             aggregation(*shape, dtype)
         for shape in [(8, 8, 7, 7), (4, 16, 14, 14), (2, 8, 8, 8), (8, 8, 1, 1)]:
             for fold in (0, 1):
-                bn_act(*shape, dtype, fold)
+                for chan in (0, 1):  # streaming kernels, then the channel-resident ones
+                    E.cot_set_tuning(21, chan)
+                    bn_act(*shape, dtype, fold)
             radix(*shape, dtype)
         for shape in [(2, 4, 8, 8), (1, 8, 7, 7), (2, 4, 5, 9), (8, 2, 1, 1)]:
             pooling(*shape, dtype)

@@ -73,7 +73,7 @@ def test_kernel_sets_apply_the_documented_switches(monkeypatch):
     for mod, attr in ((clf, "ENABLED"), (c1, "MODE"), (c3, "MODE"), (g9, "MODE"), (p3, "MODE"), (hf, "MODE"), (s7, "MODE")):
         monkeypatch.setattr(mod, attr, getattr(mod, attr))  # restored after the test
     bench.apply_kernel_set("new")
-    assert clf.ENABLED and c1.MODE == c3.MODE == g9.MODE == "hip" and calls[-1] == (12, 0)
+    assert clf.ENABLED and c1.MODE == c3.MODE == g9.MODE == "hip" and calls[-1] == (12, 1)
     bench.apply_kernel_set("round1")
     assert not clf.ENABLED and c1.MODE == c3.MODE == g9.MODE == "" and calls[-1] == (12, 0)
 

@@ -12,19 +12,24 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(params=[0, 1], ids=["finalize-kernel", "finalize-folded"])
+@pytest.fixture(params=[0, 1, 2], ids=["finalize-kernel", "finalize-folded", "channel-resident"])
 def fold(request):
-    """cot_set_tuning(12): the per-channel finalize step as its own launch, or folded into the apply kernels' prologue (what
-    bench.py's `new` kernel set runs)"""
+    """streaming kernels with the per-channel finalize step as its own launch (cot_set_tuning(12, 0)) or folded into the apply
+    kernels' prologue (12 = 1, what bench.py's `new` kernel set runs), both with the channel-resident kernels off
+    (cot_set_tuning(21, 0)); and the library default: channel-resident kernels wherever a channel fits a workgroup's registers"""
     from cotnet_amd import _lib
-    _lib.check(_lib.lib().cot_set_tuning(12, request.param), "cot_set_tuning")
+    L = _lib.lib()
+    _lib.check(L.cot_set_tuning(12, 1 if request.param == 1 else 0), "cot_set_tuning")
+    _lib.check(L.cot_set_tuning(21, 1 if request.param == 2 else 0), "cot_set_tuning")
     yield request.param
-    _lib.check(_lib.lib().cot_set_tuning(12, 0), "cot_set_tuning")
+    _lib.check(L.cot_set_tuning(12, 0), "cot_set_tuning")
+    _lib.check(L.cot_set_tuning(21, 1), "cot_set_tuning")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act,use_res", [(None, False), ("relu", False), ("relu", True), ("silu", False)])
-@pytest.mark.parametrize("N,C,H", [(8, 64, 56), (8, 128, 28), (8, 256, 14), (8, 2048, 7), (3, 24, 5)])
+@pytest.mark.parametrize("N,C,H", [(8, 64, 56), (8, 128, 28), (8, 256, 14), (8, 2048, 7), (3, 24, 5), (80, 128, 28), (80, 256, 14),
+                                   (80, 512, 7)])
 def test_matches_torch_modules(N, C, H, act, use_res, dtype, fold):
     torch.manual_seed(C + H)
     bn_a = nn.BatchNorm2d(C).to(DEV).train()

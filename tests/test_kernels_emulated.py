@@ -34,6 +34,7 @@ def _default_knobs():
     # (the fp64 small-batch path, cot_set_tuning(18), has its own test below)
     if _EMUL is not None:
         _EMUL.cot_set_tuning(18, 0)
+        _EMUL.cot_set_tuning(21, 0)  # ... and off the channel-resident ones (own test: `chan` below)
     yield
     if _EMUL is not None:  # process-global developer knobs back to their defaults after every test
         _EMUL.cot_set_tuning(10, 0)
@@ -41,6 +42,7 @@ def _default_knobs():
         _EMUL.cot_set_tuning(12, 0)
         _EMUL.cot_set_tuning(17, 0)
         _EMUL.cot_set_tuning(18, 256)
+        _EMUL.cot_set_tuning(21, 1)
 
 
 def to_layout(t, layout):
@@ -285,10 +287,16 @@ def test_fused_sgd_kernel_matches_torch_formula(pdt, gdt, nesterov):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act,use_res", [(0, False), (1, False), (1, True), (2, False), (0, True)])
-@pytest.mark.parametrize("N,C,H,W", [(6, 8, 7, 7), (5, 16, 14, 14), (3, 4, 8, 8)])
-@pytest.mark.parametrize("fold", [0, 1])
+@pytest.mark.parametrize("N,C,H,W", [(6, 8, 7, 7), (5, 16, 14, 14), (3, 4, 8, 8),
+                                     (40, 3, 14, 14), (12, 2, 28, 28), (30, 2, 7, 7)])  # (1024-lane workgroups, 2-3 rounds)
+@pytest.mark.parametrize("fold", [0, 1, "chan"])
 def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold):
-    assert _EMUL.cot_set_tuning(12, fold) == 0
+    # fold 0 / 1: streaming kernels with the finalize step as a launch / folded; "chan": the channel-resident kernels
+    # (one workgroup keeps a channel in registers: 1 launch each way)
+    if fold == "chan":
+        assert _EMUL.cot_set_tuning(21, 1) == 0
+    else:
+        assert _EMUL.cot_set_tuning(12, fold) == 0
     """csrc/bn_act.hip (host-emulated) against torch's batch_norm + activation + residual, forward and backward"""
     g = torch.Generator().manual_seed(N * C + H)
     x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.7).to(dtype)
@@ -1281,6 +1289,13 @@ def test_pooling_kernels_match_torch(N, C, H, W, dtype):
             assert _EMUL.cot_maxpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
             assert _EMUL.cot_maxpool3x3s2_backward(P(gy), P(x), P(gx), N * C, H, W, dt, None) == 0
             assert torch.equal(y.float(), yr.detach())
+            # the byte-tap form (what cotnet_amd.pool3x3 calls): same outputs, and the same gradient without reading x
+            y2, gx2 = torch.full_like(y, float("nan")), torch.full_like(x, float("nan"))
+            taps = torch.full((N, C, Ho, Wo), 255, dtype=torch.uint8)
+            assert _EMUL.cot_maxpool3x3s2_forward_taps(P(x), P(y2), P(taps), N * C, H, W, dt, None) == 0
+            assert _EMUL.cot_maxpool3x3s2_backward_taps(P(gy), P(taps), P(gx2), N * C, H, W, dt, None) == 0
+            assert torch.equal(y2, y) and int(taps.max()) <= 8
+            assert torch.equal(gx2, gx)
         else:
             assert _EMUL.cot_avgpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
             assert _EMUL.cot_avgpool3x3s2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
