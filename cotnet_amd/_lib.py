@@ -61,6 +61,11 @@ SYMBOLS = {
     "cot_avgpool3x3s2_backward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_maxpool3x3s2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_maxpool3x3s2_backward": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
+    "cot_blurpool3x3s2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
+    "cot_blurpool3x3s2_backward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
+    "cot_se_gap": (_I, [_P, _P, ctypes.c_int64, _I, _I, _P]),
+    "cot_se_gate": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _P]),
+    "cot_se_gate_backward": (_I, [_P, _P, _P, _P, _P, ctypes.c_int64, _I, _I, _P]),
     "cot_maxpool3x3s2_forward_taps": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_maxpool3x3s2_backward_taps": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_stem7x7s2_workspace": (ctypes.c_int64, [_I, _I, _I]),

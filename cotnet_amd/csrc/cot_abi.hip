@@ -160,6 +160,9 @@ int conv3x3g_gemm(const void*, const void*, void*, const void*, int, int, int, i
 int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW);
 int conv3x3g_wgrad(const void*, const void*, void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
 template <typename T> int radix_gap_t(const void*, const void*, void*, int, int, int, hipStream_t);
+template <typename T> int se_gap(const void*, void*, int64_t, int, hipStream_t);
+template <typename T> int se_gate(const void*, const void*, void*, int64_t, int, hipStream_t);
+template <typename T> int se_gate_bwd(const void*, const void*, const void*, void*, void*, int64_t, int, hipStream_t);
 template <typename T>
 int radix_mix_logits(const void*, const void*, const void*, void*, void*, int, int, int, hipStream_t);
 template <typename T>
@@ -535,6 +538,32 @@ int cot_radix_gap(const void* y, const void* k, void* gap, int64_t planes, int H
                             : radix_gap<bf16_t>(y, k, gap, planes, HW, (hipStream_t)stream);
 }
 
+int cot_se_gap(const void* x, void* gap, int64_t planes, int HW, int dtype, void* stream) {
+    int rc = tail_check(planes, HW, dtype);
+    if (rc) return rc;
+    if (!x || !gap) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x}))) return rc;
+    return dtype == COT_F32 ? se_gap<float>(x, gap, planes, HW, (hipStream_t)stream)
+                            : se_gap<bf16_t>(x, gap, planes, HW, (hipStream_t)stream);
+}
+int cot_se_gate(const void* x, const void* logit, void* out, int64_t planes, int HW, int dtype, void* stream) {
+    int rc = tail_check(planes, HW, dtype);
+    if (rc) return rc;
+    if (!x || !logit || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x, out}))) return rc;
+    return dtype == COT_F32 ? se_gate<float>(x, logit, out, planes, HW, (hipStream_t)stream)
+                            : se_gate<bf16_t>(x, logit, out, planes, HW, (hipStream_t)stream);
+}
+int cot_se_gate_backward(const void* g, const void* x, const void* logit, void* gx, void* glogit, int64_t planes, int HW,
+                         int dtype, void* stream) {
+    int rc = tail_check(planes, HW, dtype);
+    if (rc) return rc;
+    if (!g || !x || !logit || !gx || !glogit) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({g, x, gx}))) return rc;
+    return dtype == COT_F32 ? se_gate_bwd<float>(g, x, logit, gx, glogit, planes, HW, (hipStream_t)stream)
+                            : se_gate_bwd<bf16_t>(g, x, logit, gx, glogit, planes, HW, (hipStream_t)stream);
+}
+
 int cot_radix_mix(const void* y, const void* k, const void* attn, void* out, int64_t planes, int HW, int dtype,
                   void* stream) {
     int rc = tail_check(planes, HW, dtype);
@@ -629,7 +658,8 @@ int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, 
 
 static int pool_call(int op, const void* a, const void* b, void* out, int64_t planes, int H, int W, int dtype, void* stream) {
     if (planes <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive planes/H/W");
-    if (!a || !out || (op >= 3 && !b)) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (!a || !out || (op >= 3 && op <= 5 && !b)) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (op >= 6 && (H < 2 || W < 2)) return set_error(COT_ERR_UNSUPPORTED, "blur pooling reflects by one pixel: H, W >= 2");
     if (dtype == COT_F32) return pool3x3s2<float>(op, a, b, out, planes, H, W, (hipStream_t)stream);
     if (dtype == COT_BF16) return pool3x3s2<bf16_t>(op, a, b, out, planes, H, W, (hipStream_t)stream);
     return set_error(COT_ERR_UNSUPPORTED, "cot_*pool3x3s2_*: dtype %d (float32 / bfloat16 only)", dtype);
@@ -648,6 +678,12 @@ int cot_maxpool3x3s2_backward(const void* gy, const void* x, void* gx, int64_t p
     return pool_call(3, gy, x, gx, planes, H, W, dtype, stream);
 }
 
+int cot_blurpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream) {
+    return pool_call(6, x, nullptr, y, planes, H, W, dtype, stream);
+}
+int cot_blurpool3x3s2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream) {
+    return pool_call(7, gy, nullptr, gx, planes, H, W, dtype, stream);
+}
 int cot_maxpool3x3s2_forward_taps(const void* x, void* y, void* taps, int64_t planes, int H, int W, int dtype, void* stream) {
     return pool_call(4, x, taps, y, planes, H, W, dtype, stream);
 }

@@ -211,6 +211,69 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_tap(const T* __restrict_
     }
 }
 
+// ---- BlurPool2d(filt_size = 3, stride = 2): reflection padding by one pixel, depthwise binomial filter [1 2 1] x [1 2 1] / 16,
+// stride 2 (the anti-aliased down-sampling of SE-CoTNetD, reference models/layers/blur_pool.py:53-58 -- there a
+// ReflectionPad2d + a grouped F.conv2d whose weight is the filter repeated per channel: MIOpen runs a depthwise convolution
+// with layout changes for what is a 9-tap stencil).  Output Ho = (H - 1)/2 + 1.  H, W >= 2 (reflection needs a neighbour).
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+__device__ __forceinline__ float binom3(int k) { return k == 1 ? 0.5f : ((k == 0 || k == 2) ? 0.25f : 0.f); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void blurpool3x3s2_fwd(const T* __restrict__ x, T* __restrict__ y, int64_t planes, int H,
+                                                        int W, int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ho * Wo) return;
+    const int ow = (int)(i % Wo), oh = (int)((i / Wo) % Ho);
+    const int64_t pl = i / ((int64_t)Wo * Ho);
+    const T* xp = x + pl * H * W;
+    float s = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = reflect1(2 * oh - 1 + kh, H);
+        float r = 0.f;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) r += binom3(kw) * (float)xp[h * W + reflect1(2 * ow - 1 + kw, W)];
+        s += binom3(kh) * r;
+    }
+    y[i] = (T)s;
+}
+
+// weight with which output row `o` (of `no`) reads input row `h` (of `n`): the padded positions that reflect onto h are h
+// itself, -1 when h == 1 and n when h == n - 2; position q is tap q - (2*o - 1) of window o
+__device__ __forceinline__ float blur_w(int h, int o, int n) {
+    float w = binom3(h - (2 * o - 1));
+    if (h == 1) w += binom3(-1 - (2 * o - 1));
+    if (h == n - 2) w += binom3(n - (2 * o - 1));
+    return w;
+}
+
+// gather form (no atomics): one thread per input pixel sums the windows that read it
+template <typename T>
+__global__ __launch_bounds__(256) void blurpool3x3s2_bwd(const T* __restrict__ gy, T* __restrict__ gx, int64_t planes,
+                                                        int H, int W, int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int w = (int)(i % W), h = (int)((i / W) % H);
+    const int64_t pl = i / ((int64_t)W * H);
+    const T* gp = gy + pl * Ho * Wo;
+    // windows that can touch row h directly are (h-1)/2 .. (h+1)/2; the reflected positions add window 0 (h == 1) and the
+    // last window (h == H-2): scan the (at most) four candidates per axis
+    float s = 0.f;
+    const int o0 = max(0, (h - 1) / 2 - 1), o1 = min(Ho - 1, (h + 1) / 2 + 1);
+    const int p0 = max(0, (w - 1) / 2 - 1), p1 = min(Wo - 1, (w + 1) / 2 + 1);
+    for (int oh = o0; oh <= o1; ++oh) {
+        const float wh = blur_w(h, oh, H);
+        if (wh == 0.f) continue;
+        float r = 0.f;
+        for (int ow = p0; ow <= p1; ++ow) {
+            const float ww = blur_w(w, ow, W);
+            if (ww != 0.f) r += ww * (float)gp[oh * Wo + ow];
+        }
+        s += wh * r;
+    }
+    gx[i] = (T)s;
+}
+
 template <typename T>
 int pool3x3s2(int op, const void* a, const void* b, void* out, int64_t planes, int H, int W, hipStream_t stream) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;  // floor((H + 2 - 3) / 2) + 1
@@ -220,6 +283,8 @@ int pool3x3s2(int op, const void* a, const void* b, void* out, int64_t planes, i
         case 0: COT_LAUNCH((avgpool3x3s2_fwd<T>), dim3((unsigned)ceil_div64(n_out, 256)), block, 0, stream, (const T*)a, (T*)out, planes, H, W, Ho, Wo); break;
         case 1: COT_LAUNCH((avgpool3x3s2_bwd<T>), dim3((unsigned)ceil_div64(n_in, 256)), block, 0, stream, (const T*)a, (T*)out, planes, H, W, Ho, Wo); break;
         case 2: COT_LAUNCH((maxpool3x3s2_fwd<T>), dim3((unsigned)ceil_div64(n_out, 256)), block, 0, stream, (const T*)a, (T*)out, planes, H, W, Ho, Wo); break;
+        case 6: COT_LAUNCH((blurpool3x3s2_fwd<T>), dim3((unsigned)ceil_div64(n_out, 256)), block, 0, stream, (const T*)a, (T*)out, planes, H, W, Ho, Wo); break;
+        case 7: COT_LAUNCH((blurpool3x3s2_bwd<T>), dim3((unsigned)ceil_div64(n_in, 256)), block, 0, stream, (const T*)a, (T*)out, planes, H, W, Ho, Wo); break;
         case 4: COT_LAUNCH((maxpool3x3s2_fwd_tap<T>), dim3((unsigned)ceil_div64(n_out, 256)), block, 0, stream, (const T*)a, (T*)out, (uint8_t*)const_cast<void*>(b), planes, H, W, Ho, Wo); break;
         case 5: COT_LAUNCH((maxpool3x3s2_bwd_tap<T>), dim3((unsigned)ceil_div64(planes * ((H + 1) / 2) * ((W + 1) / 2), 256)), block, 0, stream, (const T*)a, (const uint8_t*)b, (T*)out, planes, H, W, Ho, Wo); break;
         default: COT_LAUNCH((maxpool3x3s2_bwd<T>), dim3((unsigned)ceil_div64(planes * ((H + 1) / 2) * ((W + 1) / 2), 256)), block, 0, stream, (const T*)a, (const T*)b, (T*)out, planes, H, W, Ho, Wo); break;

@@ -203,6 +203,72 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_apply_kernel(const T* __res
     }
 }
 
+// ---- SE-style sigmoid gate of SplitAttnConv2d(radix = 1) (reference models/layers/split_attn.py:62-88 as
+// SE-CoTNetD uses it, models/cotnet_hybrid.py:143-146): out = x * sigmoid(logit[n][c]) with logit = fc2(relu(bn1(fc1(
+// mean_hw(x))))).  Three HBM-bound kernels around the tiny MLP, one wave per (image, channel) plane:
+//   se_gap        gap[plane] = mean_hw(x)
+//   se_gate       out = x * sigmoid(logit[plane])
+//   se_gate_bwd   gx = g * sigmoid(logit);  glogit[plane] = sigmoid' * sum_hw g * x     (one pass over g and x)
+// (the reference runs adaptive_avg_pool2d, sigmoid, a broadcast multiply and their three backward kernels)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void se_gap_kernel(const T* __restrict__ x, T* __restrict__ gap, int64_t planes, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= planes) return;
+    const T* xp = x + plane * HW;
+    float acc = 0.f;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> a = ldv<T, V>(xp + i);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc += (float)a.v[j];
+    }
+    acc = wave_sum_f(acc);
+    if (lane == 0) gap[plane] = (T)(acc / (float)HW);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void se_gate_kernel(const T* __restrict__ x, const T* __restrict__ logit,
+                                                     T* __restrict__ out, int64_t planes, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= planes) return;
+    const float a = 1.f / (1.f + __expf(-(float)logit[plane]));
+    const T* xp = x + plane * HW;
+    T* op = out + plane * HW;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> v = ldv<T, V>(xp + i);
+        Vec<T, V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.v[j] = (T)((float)v.v[j] * a);
+        stv<T, V>(op + i, o);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                         const T* __restrict__ logit, T* __restrict__ gx,
+                                                         T* __restrict__ glogit, int64_t planes, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (plane >= planes) return;
+    const float a = 1.f / (1.f + __expf(-(float)logit[plane]));
+    const int64_t base = plane * HW;
+    float s = 0.f;
+    for (int i = lane * V; i < HW; i += 64 * V) {
+        const Vec<T, V> gv = ldv<T, V>(g + base + i), xv = ldv<T, V>(x + base + i);
+        Vec<T, V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gg = (float)gv.v[j];
+            o.v[j] = (T)(gg * a);
+            s += gg * (float)xv.v[j];
+        }
+        stv<T, V>(gx + base + i, o);
+    }
+    s = wave_sum_f(s);
+    if (lane == 0) glogit[plane] = (T)(s * a * (1.f - a));
+}
+
 static inline int tail_vec(size_t esize, int HW) {
     int lim = (int)(16 / esize);
     for (int V = 8; V >= 1; V >>= 1)
@@ -235,6 +301,20 @@ int radix_mix_bwd(const void* g, const void* y, const void* k, const void* attn,
     TAIL_DISPATCH(radix_mix_bwd_kernel, (const T*)g, (const T*)y, (const T*)k, (const T*)attn, (T*)gy, (T*)gk,
                   (T*)gattn, planes, HW);
     return check_launch("radix_mix_bwd");
+}
+
+template <typename T> int se_gap(const void* x, void* gap, int64_t planes, int HW, hipStream_t s) {
+    TAIL_DISPATCH(se_gap_kernel, (const T*)x, (T*)gap, planes, HW);
+    return check_launch("se_gap");
+}
+template <typename T> int se_gate(const void* x, const void* logit, void* out, int64_t planes, int HW, hipStream_t s) {
+    TAIL_DISPATCH(se_gate_kernel, (const T*)x, (const T*)logit, (T*)out, planes, HW);
+    return check_launch("se_gate");
+}
+template <typename T>
+int se_gate_bwd(const void* g, const void* x, const void* logit, void* gx, void* glogit, int64_t planes, int HW, hipStream_t s) {
+    TAIL_DISPATCH(se_gate_bwd_kernel, (const T*)g, (const T*)x, (const T*)logit, (T*)gx, (T*)glogit, planes, HW);
+    return check_launch("se_gate_bwd");
 }
 
 template <typename T> int radix_gap_t(const void* y, const void* k, void* gapT, int N, int C, int HW, hipStream_t s) {
@@ -271,6 +351,9 @@ int radix_mix_bwd_apply(const void* g, const void* attn, const void* ggapT, void
     template int radix_mix_bwd<T>(const void*, const void*, const void*, const void*, void*, void*, void*, int64_t, \
                                   int, hipStream_t);                                                               \
     template int radix_gap_t<T>(const void*, const void*, void*, int, int, int, hipStream_t);                      \
+    template int se_gap<T>(const void*, void*, int64_t, int, hipStream_t);                                         \
+    template int se_gate<T>(const void*, const void*, void*, int64_t, int, hipStream_t);                           \
+    template int se_gate_bwd<T>(const void*, const void*, const void*, void*, void*, int64_t, int, hipStream_t);   \
     template int radix_mix_logits<T>(const void*, const void*, const void*, void*, void*, int, int, int,           \
                                      hipStream_t);                                                                 \
     template int radix_mix_bwd_reduce<T>(const void*, const void*, const void*, const void*, void*, int, int, int, \

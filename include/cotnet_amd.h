@@ -223,6 +223,19 @@ int cot_radix_mix_backward_reduce(const void* gout, const void* y, const void* k
 int cot_radix_mix_backward_apply(const void* gout, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C,
                                  int HW, int dtype, void* stream);
 
+/* ---- SE-style sigmoid gate of SplitAttnConv2d(radix = 1) as SE-CoTNetD uses it (reference
+ * models/layers/split_attn.py:62-88, models/cotnet_hybrid.py:143-146):  out = x * sigmoid(fc2(relu(bn1(fc1(mean_hw(x))))));
+ * the two fc layers and bn1 act on [N, C] descriptors (cot_conv1x1_* / cot_bn_act_* or any GEMM), these three kernels are the
+ * passes over x: `planes` = N*C planes of HW elements, gap / logit / glogit [planes] in the storage dtype, COT_F32 / COT_BF16.
+ *   cot_se_gap            gap[i] = mean_hw(x[i])
+ *   cot_se_gate           out[i] = x[i] * sigmoid(logit[i])
+ *   cot_se_gate_backward  gx[i] = g[i] * sigmoid(logit[i]);  glogit[i] = sigmoid'(logit[i]) * sum_hw g[i] * x[i]
+ *                         (the gradient that arrives through the pooled descriptor is added by the caller: d gap / HW) */
+int cot_se_gap(const void* x, void* gap, int64_t planes, int HW, int dtype, void* stream);
+int cot_se_gate(const void* x, const void* logit, void* out, int64_t planes, int HW, int dtype, void* stream);
+int cot_se_gate_backward(const void* g, const void* x, const void* logit, void* gx, void* glogit, int64_t planes, int HW,
+                         int dtype, void* stream);
+
 /* ---- GroupNorm with 9 channels per group, NCHW, COT_BF16 or COT_F32 (CotLayer.embed[4] =
  * nn.GroupNorm(dim/8, 9*dim/8), models/cotnet.py:56 -- the normalisation of the 3x3 attention logits; its output is the
  * aggregation's weight tensor).  One (image, group) is a contiguous run of 9*HW elements that one workgroup keeps in
@@ -262,6 +275,11 @@ int cot_maxpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int 
 int cot_maxpool3x3s2_backward(const void* gy, const void* x, void* gx, int64_t planes, int H, int W, int dtype,
                               void* stream);
 int cot_maxpool3x3s2_forward_taps(const void* x, void* y, void* taps, int64_t planes, int H, int W, int dtype, void* stream);
+/*   cot_blurpool3x3s2_* BlurPool2d(channels, filt_size=3, stride=2) of SE-CoTNetD (reference
+ *                       models/layers/blur_pool.py:53-58: ReflectionPad2d(1) + depthwise binomial [1 2 1]x[1 2 1]/16, stride 2)
+ *                       as a 9-tap stencil, forward and gather-form backward; H, W >= 2. */
+int cot_blurpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);
+int cot_blurpool3x3s2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream);
 int cot_maxpool3x3s2_backward_taps(const void* gy, const void* taps, void* gx, int64_t planes, int H, int W, int dtype,
                                    void* stream);
 
