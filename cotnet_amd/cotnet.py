@@ -25,6 +25,7 @@ from .conv3x3g import conv3x3
 from .group_norm9 import group_norm9
 from .pool3x3 import pool
 from .fused_bn import fused_bn_act
+from .se_gate import se_mlp  # noqa: F401  (re-exported: the se branch of the CoT layers and SplitAttnConv2d's gate share it)
 from .layers import get_act_layer
 from .registry import build_model_with_cfg, register_model
 from .resnet import ResNet
@@ -51,24 +52,6 @@ def act_name(m):
     if isinstance(m, nn.SiLU):
         return "silu"
     return False
-
-
-def se_mlp(gap, se):
-    """The `se` branch (ref :71-77: 1x1 conv + BN + ReLU + 1x1 conv) applied to the pooled [B,C,1,1] descriptor.
-    A 1x1 convolution on a 1x1 map IS a matrix product with the same weights, so it is issued as one GEMM (F.linear on
-    the conv's own weight/bias) instead of a convolution call (which on ROCm costs layout transposes + cast kernels
-    around a tiny GEMM, forward and twice backward).  Same parameters, same state_dict, same function."""
-    c0, bn, act, c3 = se[0], se[1], se[2], se[3]
-    plain = all(isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.groups == 1 and c.stride == (1, 1)
-                and c.padding == (0, 0) for c in (c0, c3))
-    if not plain:
-        return se(gap)
-    h = F.linear(gap.flatten(1), c0.weight.flatten(1), c0.bias)
-    # BatchNorm over the batch alone ([B, A, 1, 1]): the library's small-batch fp64 path when eligible (csrc/bn_act.hip
-    # "small batches": MIOpen's fp32 kernel is 300x off an fp64 evaluation here -- what kept the 7x7 layer above 1e-3)
-    h4 = h[:, :, None, None]
-    h = fused_bn_act(h4.contiguous(), bn, "relu") if isinstance(act, nn.ReLU) else act(bn(h4))
-    return F.linear(h.flatten(1), c3.weight.flatten(1), c3.bias)
 
 
 def radix2_fuse(x, k, se):

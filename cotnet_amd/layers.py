@@ -15,7 +15,10 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import se_gate
 from .conv3x3g import conv3x3
+from .fused_bn import fused_bn_act
+from .se_gate import se_mlp
 
 
 def get_act_layer(name="relu"):
@@ -138,6 +141,9 @@ class BlurPool2d(nn.Module):
         return f
 
     def forward(self, x):
+        from . import pool3x3  # (late: pool3x3 imports nothing from here, but keep module import order flat)
+        if pool3x3.MODE == "hip" and self.filt_size == 3 and self.stride == 2 and pool3x3.blur_eligible(x):
+            return pool3x3.blur_pool(x)  # the same 9-tap stencil on csrc/pool3x3.hip (reflection folded into the indices)
         return F.conv2d(self.padding(x), self._filter(x), stride=self.stride, groups=x.shape[1])
 
 
@@ -186,12 +192,19 @@ class SplitAttnConv2d(nn.Module):
 
     def forward(self, x):
         x = conv3x3(self.conv, x)  # the module itself unless COT_CONV3X3=hip and the tensor qualifies
-        if self.bn0 is not None:
-            x = self.bn0(x)
-        if self.drop_block is not None:
-            x = self.drop_block(x)
-        x = self.act0(x)
+        if (isinstance(self.bn0, nn.BatchNorm2d) and self.drop_block is None and isinstance(self.act0, nn.ReLU)):
+            x = fused_bn_act(x, self.bn0, "relu")  # one fused op when eligible, the same modules otherwise
+        else:
+            if self.bn0 is not None:
+                x = self.bn0(x)
+            if self.drop_block is not None:
+                x = self.drop_block(x)
+            x = self.act0(x)
         B, RC, H, W = x.shape
+        if self.radix == 1 and se_gate.eligible(x) and isinstance(self.bn1, nn.BatchNorm2d) and self.fc1.groups == 1:
+            # SE-CoTNetD's form: pooled descriptor -> fc1 / bn1 / act1 / fc2 on [B, C] -> sigmoid gate, three passes over x
+            logits = se_mlp(se_gate.se_gap(x), (self.fc1, self.bn1, self.act1, self.fc2))
+            return se_gate.se_gate(x, logits)
         if self.radix > 1:
             x = x.reshape(B, self.radix, RC // self.radix, H, W)
             gap = x.sum(dim=1)

@@ -81,6 +81,39 @@ class _MaxPool(Function):
         return gx
 
 
+class _BlurPool(Function):
+    """BlurPool2d(filt_size=3, stride=2): reflection pad 1 + depthwise [1 2 1] x [1 2 1] / 16, stride 2 (blur_pool.py:53-58)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        y = _out(x)
+        rc = _lib.lib().cot_blurpool3x3s2_forward(_p(x), _p(y), N * C, H, W, _DT[x.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_blurpool3x3s2_forward")
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty(ctx.shape, dtype=gy.dtype, device=gy.device)
+        rc = _lib.lib().cot_blurpool3x3s2_backward(_p(gy), _p(gx), N * C, H, W, _DT[gy.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_blurpool3x3s2_backward")
+        return gx
+
+
+def blur_eligible(x):
+    return ((x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4 and x.dtype in _DT and x.is_contiguous() and x.shape[2] >= 2
+            and x.shape[3] >= 2)
+
+
+def blur_pool(x):
+    return _BlurPool.apply(x)
+
+
 def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 

@@ -157,6 +157,10 @@ def radix(N, C, H, W, dtype):
     assert E.cot_radix_mix_backward_reduce(P(g), P(y), P(k), P(attn), P(glogT), N, C, HW, dt, None) == 0
     assert E.cot_radix_mix_backward_apply(P(g), P(attn), P(ggapT), P(gy), P(gk), N, C, HW, dt, None) == 0
     gap, ga = guarded(torch.empty(N, C).to(dtype)), guarded(torch.empty(N, C, 2).to(dtype))
+    lg, glg = guarded(torch.randn(N, C).to(dtype)), guarded(torch.empty(N, C).to(dtype))
+    assert E.cot_se_gap(P(y), P(gap), N * C, HW, dt, None) == 0
+    assert E.cot_se_gate(P(y), P(lg), P(out), N * C, HW, dt, None) == 0
+    assert E.cot_se_gate_backward(P(g), P(y), P(lg), P(gy), P(glg), N * C, HW, dt, None) == 0
     assert E.cot_radix_gap(P(y), P(k), P(gap), N * C, HW, dt, None) == 0
     assert E.cot_radix_mix(P(y), P(k), P(attn), P(out), N * C, HW, dt, None) == 0
     assert E.cot_radix_mix_backward(P(g), P(y), P(k), P(attn), P(gy), P(gk), P(ga), N * C, HW, dt, None) == 0
@@ -172,6 +176,9 @@ def pooling(N, C, H, W, dtype):
     taps = guarded(torch.empty(y.shape, dtype=torch.uint8))
     assert E.cot_maxpool3x3s2_forward_taps(P(x), P(y), P(taps), N * C, H, W, dt, None) == 0
     assert E.cot_maxpool3x3s2_backward_taps(P(gy), P(taps), P(gx), N * C, H, W, dt, None) == 0
+    if H >= 2 and W >= 2:
+        assert E.cot_blurpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
+        assert E.cot_blurpool3x3s2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
     assert E.cot_avgpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
     assert E.cot_avgpool3x3s2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
 

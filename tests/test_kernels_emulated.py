@@ -1725,3 +1725,100 @@ def test_coxt_layer_on_emulated_kernels(dtype, monkeypatch):
             assert err(p.grad, q.grad) < 2 * tol, (n, err(p.grad, q.grad))
     for cache in caches:
         cache.clear()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SE-CoTNetD's extra layers: BlurPool2d and the sigmoid gate of SplitAttnConv2d(radix=1)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 4, 7, 7), (2, 2, 14, 10), (1, 2, 5, 9), (1, 1, 2, 2), (1, 2, 3, 2), (1, 1, 2, 5)])
+def test_blurpool_kernels_match_the_reference_formula(N, C, H, W, dtype):
+    """cot_blurpool3x3s2_* against ReflectionPad2d(1) + depthwise conv2d with the binomial filter, stride 2
+    (models/layers/blur_pool.py:53-58 as restated in cotnet_amd.layers.BlurPool2d)"""
+    from cotnet_amd.layers import BlurPool2d
+    torch.manual_seed(47)
+    dt = _lib.dtype_code(dtype)
+    x = torch.randn(N, C, H, W).to(dtype)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = torch.randn(N, C, Ho, Wo).to(dtype)
+    xr = x.double().requires_grad_(True)
+    yr = BlurPool2d(C)(xr)
+    assert yr.shape == (N, C, Ho, Wo)
+    yr.backward(gy.double())
+    y, gx = torch.full((N, C, Ho, Wo), float("nan")).to(dtype), torch.full_like(x, float("nan"))
+    assert _EMUL.cot_blurpool3x3s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
+    assert _EMUL.cot_blurpool3x3s2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
+    tol = 1e-6 if dtype == torch.float32 else 1.5e-2
+    assert torch.allclose(y.double(), yr.detach(), atol=tol, rtol=tol)
+    assert torch.allclose(gx.double(), xr.grad, atol=tol, rtol=tol)
+    assert _EMUL.cot_blurpool3x3s2_forward(P(x), P(y), N * C, 1, W, dt, None) == -2   # reflection needs two rows
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 8, 8), (3, 4, 7, 7), (1, 6, 5, 3), (2, 2, 20, 20)])
+def test_se_gate_kernels(B, C, H, W, dtype):
+    torch.manual_seed(53)
+    dt = _lib.dtype_code(dtype)
+    x, g = torch.randn(B, C, H, W).to(dtype), torch.randn(B, C, H, W).to(dtype)
+    logit = (2 * torch.randn(B, C)).to(dtype)
+    xr, lr = x.double().requires_grad_(True), logit.double().requires_grad_(True)
+    outr = xr * torch.sigmoid(lr)[:, :, None, None]
+    outr.backward(g.double())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    gap = torch.full((B, C), float("nan")).to(dtype)
+    assert _EMUL.cot_se_gap(P(x), P(gap), B * C, H * W, dt, None) == 0
+    assert torch.allclose(gap.double(), x.double().mean((2, 3)), atol=tol, rtol=tol)
+    out = torch.full_like(x, float("nan"))
+    assert _EMUL.cot_se_gate(P(x), P(logit), P(out), B * C, H * W, dt, None) == 0
+    assert torch.allclose(out.double(), outr.detach(), atol=tol, rtol=tol)
+    gx, gl = torch.full_like(x, float("nan")), torch.full_like(logit, float("nan"))
+    assert _EMUL.cot_se_gate_backward(P(g), P(x), P(logit), P(gx), P(gl), B * C, H * W, dt, None) == 0
+    assert torch.allclose(gx.double(), xr.grad, atol=tol, rtol=tol)
+    assert torch.allclose(gl.double(), lr.grad, atol=10 * tol, rtol=2 * tol)
+
+
+def test_split_attn_radix1_and_blurpool_modules_on_emulated_kernels(monkeypatch):
+    """SplitAttnConv2d(radix=1) as SE-CoTNetD builds it and BlurPool2d, every pass over the activation on the library's
+    kernels (3x3 convolution, fused BN+ReLU, pooled descriptor, fc / bn1 on [B, C], sigmoid gate; 9-tap blur stencil),
+    against the plain module formulas in fp64"""
+    import copy
+    from cotnet_amd import conv3x3g as c3, fused_bn, pool3x3 as p3, radix_tail, se_gate
+    from cotnet_amd.layers import BlurPool2d, SplitAttnConv2d
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (c3, fused_bn, p3, se_gate):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(c3, "MODE", "hip")
+    monkeypatch.setattr(p3, "MODE", "hip")
+    for cache in (c3._WS, c3._MASKS, fused_bn._WS):
+        cache.clear()
+    torch.manual_seed(9)
+    mod = torch.nn.Sequential(SplitAttnConv2d(16, 16, 3, padding=1, radix=1, norm_layer=torch.nn.BatchNorm2d), BlurPool2d(16)).train()
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+            torch.nn.init.uniform_(m.bias, -0.3, 0.3)
+    ref = copy.deepcopy(mod).double()
+    x, g = torch.randn(4, 16, 10, 10), torch.randn(4, 16, 5, 5)
+    calls = []
+    for name in ("cot_se_gap", "cot_se_gate", "cot_se_gate_backward", "cot_blurpool3x3s2_forward", "cot_blurpool3x3s2_backward",
+                 "cot_conv3x3g_forward"):
+        real = getattr(_EMUL, name)
+        monkeypatch.setattr(_EMUL, name, (lambda real, name: lambda *a: (calls.append(name), real(*a))[1])(real, name), raising=False)
+    xi = x.clone().requires_grad_(True)
+    y = mod(xi)
+    y.backward(g)
+    assert sorted(set(calls)) == sorted(["cot_se_gap", "cot_se_gate", "cot_se_gate_backward", "cot_blurpool3x3s2_forward",
+                                         "cot_blurpool3x3s2_backward", "cot_conv3x3g_forward"]), calls
+    monkeypatch.setattr(c3, "MODE", "")
+    monkeypatch.setattr(p3, "MODE", "")
+    monkeypatch.setattr(fused_bn, "ENABLED", False)
+    monkeypatch.setattr(radix_tail, "ENABLED", False)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g.double())
+    assert torch.allclose(y.double(), yr.detach(), atol=2e-4, rtol=1e-4), (y.double() - yr).abs().max()
+    assert torch.allclose(xi.grad.double(), xr.grad, atol=5e-4, rtol=1e-3), (xi.grad.double() - xr.grad).abs().max()
+    for (n, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p.grad.double(), q.grad, atol=5e-4 * max(1.0, q.grad.abs().max().item()), rtol=2e-3), n
+    for cache in (c3._WS, c3._MASKS, fused_bn._WS):
+        cache.clear()
