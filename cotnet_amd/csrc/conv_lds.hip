@@ -200,7 +200,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], cons
 struct C1LdsArgs {
     const bf16_t* x1;
     const bf16_t* x2;  // second channel slab of the input (NULL: k1 == K)
-    const bf16_t* w;   // [M][K] row-major, or (wpacked) K-step-major [K/32][M][32]
+    const bf16_t* w;   // wpacked 0: [M][K] row-major; 1: K-step-major [K/32][M][32]; 2: the TRANSPOSE [K][M] row-major (WT kernels)
     const bf16_t* bias;
     bf16_t* y1;
     bf16_t* y2;        // second channel slab of the output (NULL: m1 == M)
@@ -224,7 +224,13 @@ struct C1LdsArgs {
 // (the deep-K layers) they are fully exposed: measured 1.2 us per K step for 0.25 us of MFMA work.
 // TRD = 1: the X fragments come from two transposing reads (needs 4-column groups that are 8-byte aligned and inside one
 // image: always true for BIG, H*W % 4 == 0 for FLAT); TRD = 0: eight 2-byte reads (any H*W, e.g. 7 x 7).
-template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD>
+// WT = 1: the weight operand is given TRANSPOSED, [K][M] row-major -- the data gradient reads the forward's [Co][Ci] weight
+// tensor in place (K = Co, M = Ci) instead of a transposed copy made by a launch of its own (50 launches / 0.5 ms per
+// CoTNet-50 step).  A K step's tile is then 32 rows of BM consecutive channels, staged as it lies in memory, and the W
+// fragments (8 consecutive k of one channel) come from the same transposing reads as the X fragments.  The 16 rows one such
+// read touches are BM*2 bytes apart -- the same banks -- so the 16-byte chunks of a row are stored XOR-permuted by
+// s(row) = 4*((row >> 3) & 3) + (row & 3), which sends those 16 rows to 16 different chunk positions (BM = 128).
+template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD, int WT>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs a) {
     constexpr int NT = 64 * WAVES;
     constexpr int BPX = 16 * WAVES * CB, BM = 16 * MB, BK = 32;
@@ -285,12 +291,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
 #pragma unroll
     for (int ps = 0; ps < WPASS; ++ps) {
         const int q = min(ps * NT + tid, BM * 4 - 1);
-        const int row = q >> 2, pos = q & 3;
-        const int c = pos ^ ((row >> 2) & 3);  // XOR swizzle: position `pos` of a row holds its k-chunk c
-        const int m = min(m0 + row, M - 1);    // rows past M: a copy of row M-1, never stored
-        wsrc[ps] = a.wpacked ? a.w + (int64_t)m * 32 + c * 8 : a.w + (int64_t)m * K + c * 8;
+        if (WT) {
+            constexpr int CPR = BM / 8;  // 16-byte chunks per k row
+            const int row = q / CPR, pos = q - row * CPR;
+            const int c = pos ^ (((((row >> 3) & 3) << 2) | (row & 3)) & (CPR - 1));  // position `pos` holds channel chunk c
+            int mcol = m0 + c * 8;
+            if (mcol + 8 > M) mcol = M - 8;  // channels past M (M % 8 == 0): in-bounds bytes, never stored
+            wsrc[ps] = a.w + (int64_t)row * M + mcol;
+        } else {
+            const int row = q >> 2, pos = q & 3;
+            const int c = pos ^ ((row >> 2) & 3);  // XOR swizzle: position `pos` of a row holds its k-chunk c
+            const int m = min(m0 + row, M - 1);    // rows past M: a copy of row M-1, never stored
+            wsrc[ps] = a.wpacked ? a.w + (int64_t)m * 32 + c * 8 : a.w + (int64_t)m * K + c * 8;
+        }
     }
-    const int64_t wstep = a.wpacked ? (int64_t)M * 32 : 32;  // elements from one K step's W tile to the next
+    const int64_t wstep = WT ? (int64_t)M * 32 : (a.wpacked ? (int64_t)M * 32 : 32);  // elements from one K step's W tile to the next
     // Workgroups walk K from different starting steps (cyclically): otherwise all of them read the same 64-byte column
     // of W -- 128 segments that are K*2 bytes apart, i.e. (K >= 2048) ONE L2 channel -- at about the same time.
     const int nk = K / BK;
@@ -329,8 +344,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
     int boff[MB];                    // B (= W) fragments: row i16 of channel block mbk, k-chunk g (swizzled position)
 #pragma unroll
     for (int mbk = 0; mbk < MB; ++mbk) {
-        const int row = mbk * 16 + i16;
-        boff[mbk] = row * BK + (g ^ ((row >> 2) & 3)) * 8;
+        if (WT) {  // k row 8g + (i16 >> 2) (+4 for the second read), channels mbk*16 + 4*(i16 & 3) .. +3
+            constexpr int CPR = BM / 8;
+            const int row = 8 * g + (i16 >> 2), c = 2 * mbk + ((i16 & 3) >> 1);
+            const int pos = c ^ ((((g & 3) << 2) | (i16 >> 2)) & (CPR - 1));
+            boff[mbk] = row * BM + pos * 8 + (i16 & 1) * 4;
+        } else {
+            const int row = mbk * 16 + i16;
+            boff[mbk] = row * BK + (g ^ ((row >> 2) & 3)) * 8;
+        }
     }
 
     f32x4_t acc[CB][MB];
@@ -370,7 +392,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
 #pragma unroll
         for (int mbk = 0; mbk < MB; ++mbk) {
             bf16x8_t bf;
-            __builtin_memcpy(&bf, __builtin_assume_aligned(wb + boff[mbk], 16), 16);
+            if (WT) {
+                const uint16_t* p = reinterpret_cast<const uint16_t*>(wb) + boff[mbk];
+                s16x4_t lo = COT_LDS_READ_TR16(p), hi = COT_LDS_READ_TR16(p + 4 * BM);
+                __builtin_memcpy(&bf, &lo, 8);
+                __builtin_memcpy(reinterpret_cast<char*>(&bf) + 8, &hi, 8);
+            } else {
+                __builtin_memcpy(&bf, __builtin_assume_aligned(wb + boff[mbk], 16), 16);
+            }
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) acc[cb][mbk] = COT_MFMA_16X16X32_BF16(af[cb], bf, acc[cb][mbk]);
         }
@@ -921,7 +950,7 @@ int conv1x1_wgrad_lds_run(const void* gy, const void* x1, const void* x2, int k1
 // [1] images per workgroup in FLAT mode (0 = auto), [2] reserved
 int g_conv_lds_tune[3] = {1, 0, 0};
 
-template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD>
+template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD, int WT>
 static int launch_c1(const C1LdsArgs& a, int tiles, hipStream_t stream) {
     constexpr int NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB;
     constexpr int XST = ((32 * BPX / 8 + NT - 1) / NT) * NT * 8, WST = ((BM * 4 + NT - 1) / NT) * NT * 8;
@@ -934,13 +963,13 @@ static int launch_c1(const C1LdsArgs& a, int tiles, hipStream_t stream) {
     if (lds > 64 * 1024) {  // more than the default dynamic-LDS window: opt in once per instantiation (160 KB per CU on gfx950)
         static bool raised = false;
         if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES, TRD>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES, TRD, WT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipGetLastError();
             raised = true;
         }
     }
-    COT_LAUNCH((conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES, TRD>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
+    COT_LAUNCH((conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES, TRD, WT>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
     return check_launch("conv1x1_lds_fwd");
 }
 
@@ -963,12 +992,19 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int 
     a.ni = 1; a.xcd_remap = 0; a.wpacked = wpacked;
     const int w4 = g_conv_lds_tune[2] & 1;     // tuning key 17 bit 0: 4-wave workgroups (A/B; default 8 waves)
     const int u16 = (g_conv_lds_tune[2] >> 1) & 1;  // bit 1: 2-byte gathers everywhere (A/B; default: transposing reads)
+    const bool wt = wpacked == 2;
+    if (wt && (M % 8 != 0 || M < 8)) return -1;
+#define COT_C1W(CB_, MB_, FLAT_, NS_, WV_, TR_)                                                             \
+    return wt ? launch_c1<CB_, MB_, FLAT_, NS_, WV_, TR_, 1>(a, tiles, stream)                             \
+              : launch_c1<CB_, MB_, FLAT_, NS_, WV_, TR_, 0>(a, tiles, stream)
 #define COT_C1(CB4, CB8, MB_, FLAT_, NS_)                                                                   \
     do {                                                                                                   \
-        if (w4) return tr ? launch_c1<CB4, MB_, FLAT_, NS_, 4, 1>(a, tiles, stream)                        \
-                          : launch_c1<CB4, MB_, FLAT_, NS_, 4, 0>(a, tiles, stream);                       \
-        return tr ? launch_c1<CB8, MB_, FLAT_, NS_, 8, 1>(a, tiles, stream)                                \
-                  : launch_c1<CB8, MB_, FLAT_, NS_, 8, 0>(a, tiles, stream);                               \
+        if (w4) {                                                                                          \
+            if (tr) COT_C1W(CB4, MB_, FLAT_, NS_, 4, 1);                                                   \
+            COT_C1W(CB4, MB_, FLAT_, NS_, 4, 0);                                                           \
+        }                                                                                                  \
+        if (tr) COT_C1W(CB8, MB_, FLAT_, NS_, 8, 1);                                                       \
+        COT_C1W(CB8, MB_, FLAT_, NS_, 8, 0);                                                               \
     } while (0)
     if (HW > 256) {  // BIG: 128-pixel tiles of one image; three stages, several workgroups per CU
         a.ptiles = ceil_div(HW, 128);
@@ -993,6 +1029,7 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int 
     a.mblocks = ceil_div(M, 128);
     COT_C1(4, 2, 8, 1, 6);
 #undef COT_C1
+#undef COT_C1W
 }
 
 }  // namespace cot

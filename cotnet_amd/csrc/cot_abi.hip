@@ -387,11 +387,17 @@ int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, voi
     if (dtype == COT_F32)
         return convg_backward_data(gy, weight, gx1, N, Ci, Co, 1, HW, 1, 1, accumulate & 1, dtype, (hipStream_t)stream);
     if (conv1x1_lds_covers(Co, Co, false, HW)) {
-        // the LDS forward kernel on dY with W^T in K-step-major form [Co/32][Ci][32], written into the workspace by a small
-        // transposition launch
-        if ((rc = transpose_bf16(weight, workspace, Co, Ci, 1, (hipStream_t)stream))) return rc;
-        rc = conv1x1_lds_gemm(gy, nullptr, Co, workspace, 1, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3,
-                              (hipStream_t)stream);
+        // the LDS forward kernel on dY; its weight operand is W^T, which IS the [Co][Ci] weight tensor read as [K][M] (WT
+        // kernels: transposing LDS reads) -- tuning key 17 bit 5 brings back the round-2-mid form (a transposed, K-step-major
+        // copy [Co/32][Ci][32] written into the workspace by a launch of its own) for A/B
+        if ((g_conv_lds_tune[2] >> 5) & 1) {
+            if ((rc = transpose_bf16(weight, workspace, Co, Ci, 1, (hipStream_t)stream))) return rc;
+            rc = conv1x1_lds_gemm(gy, nullptr, Co, workspace, 1, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3,
+                                  (hipStream_t)stream);
+        } else {
+            rc = conv1x1_lds_gemm(gy, nullptr, Co, weight, 2, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3,
+                                  (hipStream_t)stream);
+        }
         if (rc != -1) return rc;
     }
     // the forward kernel on dY with A = weight^T, read in place from the [Co][Ci] weight tensor

@@ -1822,3 +1822,42 @@ def test_split_attn_radix1_and_blurpool_modules_on_emulated_kernels(monkeypatch)
         assert torch.allclose(p.grad.double(), q.grad, atol=5e-4 * max(1.0, q.grad.abs().max().item()), rtol=2e-3), n
     for cache in (c3._WS, c3._MASKS, fused_bn._WS):
         cache.clear()
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,c1", [
+    (1, 200, 64, 20, 20, 0),     # BIG: M = Ci = 200 -> two channel blocks, the second partial (72 of 128)
+    (2, 136, 96, 14, 14, 64),    # FLAT, M = 136, three K steps, gradient written to two slabs
+    (7, 40, 32, 7, 7, 0),        # FLAT 7 x 7 (2-byte gathers for dY), M = 40 of a 64-channel block
+    (2, 24, 64, 8, 8, 8),        # M = 24 of a 32-channel block, two slabs
+    (1, 512, 160, 1, 80, 0),     # the se branch's shape (one "image" of 80 pixels), four channel blocks, five K steps
+    (3, 128, 256, 16, 16, 0),    # BIG / FLAT border (H*W = 256), eight K steps: the six-stage ring wraps
+])
+@pytest.mark.parametrize("waves4", [0, 1])
+def test_conv1x1_lds_data_gradient_reads_the_weight_in_place(N, Ci, Co, H, W, c1, waves4):
+    """cot_conv1x1_backward_data on the LDS kernels with the [Co][Ci] weight tensor read in place as the transposed operand
+    (WT kernels: transposing LDS reads, chunk-permuted rows) must equal -- bit for bit: same products, same order -- the
+    form that multiplies a transposed copy (cot_set_tuning(17) bit 5), and both the fp32 reference"""
+    torch.manual_seed(17)
+    HW, dt = H * W, _lib.dtype_code(torch.bfloat16)
+    w = (torch.randn(Co, Ci) / Co ** 0.5).bfloat16()
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    ref = torch.einsum("oc,nohw->nchw", w.float(), gy.float())
+    ws = torch.full((_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 0),), 0x7f, dtype=torch.uint8)
+    outs = []
+    for copy_form in (0, 1):
+        assert _EMUL.cot_set_tuning(17, waves4 | (32 if copy_form else 0)) == 0
+        k1 = c1 if c1 else Ci
+        g1 = torch.full((N, k1, H, W), float("nan")).bfloat16()
+        g2 = torch.full((N, Ci - k1, H, W), float("nan")).bfloat16() if c1 else None
+        rc = _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(g1), P(g2) if c1 else None, k1, 0, P(ws), N, Ci, Co, HW, dt, None)
+        assert rc == 0, _EMUL.cot_last_error()
+        g = torch.cat([g1, g2], 1) if c1 else g1
+        assert torch.allclose(g.float(), ref, atol=3e-2, rtol=2e-2), (g.float() - ref).abs().max()
+        # accumulate into both slabs
+        rc = _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(g1), P(g2) if c1 else None, k1, 3, P(ws), N, Ci, Co, HW, dt, None)
+        assert rc == 0
+        g = torch.cat([g1, g2], 1) if c1 else g1
+        assert torch.allclose(g.float(), 2 * ref, atol=8e-2, rtol=3e-2)
+        outs.append(g.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert _EMUL.cot_set_tuning(17, 0) == 0
