@@ -1026,6 +1026,16 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int 
     const bool tr = !u16 && HW % 4 == 0;
     if (M <= 32) { a.mblocks = 1; COT_C1(4, 2, 2, 1, 6); }
     if (M <= 64) { a.mblocks = 1; COT_C1(4, 2, 4, 1, 6); }
+    // few tiles (the 7 x 7 stage at B = 80: 16 image groups x M/128 channel blocks = 64 workgroups for 512 channels, each a
+    // chain of K/32 = 64 steps): 64-channel blocks double the workgroups and halve a step's MFMA and W traffic.  Measured
+    // cold, forward | data gradient us (profiles/r02_conv_fewtiles_ab.log): 2048->512 68 -> 54 | =, 1024->256 39 -> 32 | 21 ->
+    // 15, 512->512 27 -> 20 | 27 -> 19, 512->2048 = | 67 -> 52.  Not for 14 x 14 (80 image groups: 31 -> 45 us).
+    // cot_set_tuning key 17 bits 8..: 0 = this rule, 1 = off, n > 1 = threshold on the workgroup count instead of 200.
+    const int fw = g_conv_lds_tune[2] >> 8;
+    if (fw != 1 && tiles <= 32 && (int64_t)tiles * ceil_div(M, 128) < (fw > 1 ? fw : 200)) {
+        a.mblocks = ceil_div(M, 64);
+        COT_C1(4, 2, 4, 1, 6);
+    }
     a.mblocks = ceil_div(M, 128);
     COT_C1(4, 2, 8, 1, 6);
 #undef COT_C1

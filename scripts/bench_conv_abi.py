@@ -56,8 +56,12 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--modes", default="0,1")
     ap.add_argument("--only", default="", help="substring filter on the shape name (e.g. 's4 conv1')")
+    ap.add_argument("--tune", default="", help="KEY=VALUE[,KEY=VALUE...] for cot_set_tuning (A/B)")
     args = ap.parse_args()
     L = _lib.lib()
+    for kv in filter(None, args.tune.split(",")):
+        key, value = kv.split("=")
+        assert L.cot_set_tuning(int(key), int(value)) == 0
     dev = torch.device("cuda:0")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     BF = _lib.COT_BF16

@@ -151,3 +151,31 @@ def test_other_inputs_keep_the_module_path(monkeypatch):
     assert not c1.eligible_hip(convb, torch.zeros(2, 12, 8, 8, device=DEV).bfloat16())   # Ci % 8 != 0
     convs = nn.Conv2d(16, 16, 1, stride=2).to(DEV).bfloat16()
     assert not c1.eligible_hip(convs, x.bfloat16())
+
+
+@pytest.mark.parametrize("N,Ci,Co,H", [(6, 512, 2048, 7), (6, 2048, 512, 7), (5, 256, 1024, 14)])
+def test_deep_layers_with_both_channel_block_sizes(N, Ci, Co, H, monkeypatch):
+    """the 7 x 7 / 14 x 14 layers run 64-channel blocks when a launch has few workgroups (the small batches of these tests
+    always do) and 128-channel blocks otherwise (B = 80): both forms (cot_set_tuning(17) bits 8..) against the fp32
+    reference (the two walk K from different staggered starting steps, so they agree to rounding, not bit for bit)"""
+    from cotnet_amd import _lib
+    monkeypatch.setattr(c1, "MODE", "hip")
+    torch.manual_seed(Ci + H)
+    conv = nn.Conv2d(Ci, Co, 1, bias=False).to(DEV).bfloat16()
+    x = torch.randn(N, Ci, H, H, device=DEV).bfloat16()
+    gy = torch.randn(N, Co, H, H, device=DEV).bfloat16()
+    outs = []
+    try:
+        for key in (0, 256):
+            _lib.check(_lib.lib().cot_set_tuning(17, key), "cot_set_tuning")
+            xi = x.clone().requires_grad_(True)
+            conv.zero_grad()
+            y = c1.conv1x1(conv, xi)
+            y.backward(gy)
+            outs.append((y.detach().clone(), xi.grad.clone(), conv.weight.grad.clone()))
+    finally:
+        _lib.check(_lib.lib().cot_set_tuning(17, 0), "cot_set_tuning")
+    yr, gxr, gwr, _ = _ref([x], conv.weight, None, gy)
+    for y, gx, gw in outs:
+        assert _close(y, yr, 1e-2) and _close(gx, gxr[0], 1e-2) and _close(gw, gwr, 1e-2)
+    assert _close(outs[0][0], outs[1][0].float(), 1e-2) and _close(outs[0][1], outs[1][1].float(), 1e-2)

@@ -594,7 +594,7 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
     (5, 32, 16, 8, 8, 0, False),      # FLAT: HW = 64, four images per workgroup + one left over
     (2, 160, 72, 14, 14, 0, False),   # FLAT: five K steps (pipeline wraps), M = 72
 ])
-@pytest.mark.parametrize("waves4", [0, 1, 2])  # cot_set_tuning(17): bit 0 = 4-wave workgroups, bit 1 = 2-byte gathers instead of transposing reads
+@pytest.mark.parametrize("waves4", [0, 1, 2, 256])  # cot_set_tuning(17): bit 0 = 4-wave workgroups, bit 1 = 2-byte gathers instead of transposing reads; 256 = 128-channel blocks even for few tiles
 def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias, waves4):
     """second-generation 1x1 kernels (csrc/conv_lds.hip): every case satisfies K % 32 == 0 so the LDS path is the one
     that runs (cot_last_kernel is checked); forward, data gradient (through the transposed-weight workspace), the
@@ -1832,7 +1832,7 @@ def test_split_attn_radix1_and_blurpool_modules_on_emulated_kernels(monkeypatch)
     (1, 512, 160, 1, 80, 0),     # the se branch's shape (one "image" of 80 pixels), four channel blocks, five K steps
     (3, 128, 256, 16, 16, 0),    # BIG / FLAT border (H*W = 256), eight K steps: the six-stage ring wraps
 ])
-@pytest.mark.parametrize("waves4", [0, 1])
+@pytest.mark.parametrize("waves4", [0, 1, 256])
 def test_conv1x1_lds_data_gradient_reads_the_weight_in_place(N, Ci, Co, H, W, c1, waves4):
     """cot_conv1x1_backward_data on the LDS kernels with the [Co][Ci] weight tensor read in place as the transposed operand
     (WT kernels: transposing LDS reads, chunk-permuted rows) must equal -- bit for bit: same products, same order -- the
