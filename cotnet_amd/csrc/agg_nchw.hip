@@ -867,7 +867,7 @@ const char* last_kernel_nchw() { return g_last_kernel; }
 // 5 = v3 waves per workgroup (4 or 8), 6 = v3 extra dynamic LDS per workgroup in KiB (occupancy shaping: fewer
 //     co-resident workgroups => their load / compute / store phases interleave instead of running in lock-step),
 // 7 = v3 XCD-aware tile order (-1 automatic, 0 off, 1 on; see xcd_order below), 8 = split the fused backward into a gX launch
-//     and a gW launch (0 fused, 1 split; unmeasured A/B knob)
+//     and a gW launch (0 fused, 1 split; A/B on the MI355X: the split form is slower, fused stays the default)
 // defaults from the on-device A/B (profiles/r01_agg_variants.log, N80xC64x56x56 bf16): forward P=4 (v3 22.0 us vs 26.0 at P=8),
 // fused backward P=2 with 4 channel groups per LDS phase (v3 45.4 us; 27.3 vs 31.8 us at 28x28)
 static int g_tune[9] = {0, 4, 2, -1, 0, 4, 0, -1, 0};
