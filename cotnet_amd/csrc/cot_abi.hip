@@ -147,6 +147,12 @@ int gn9_backward(const void*, const void*, const float*, const float*, const voi
 int gn9f_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, hipStream_t);
 int gn9f_backward(const void*, const void*, const float*, const float*, const void*, void*, void*, void*, float*, int, int,
                   int, hipStream_t);
+// implemented in conv_tiny.hip (one image of <= 256 pixels: the se branch's convolutions over the batch axis)
+extern int g_conv_tiny;
+bool conv_tiny_covers(int N, int Ci, int Co, int HW);
+int conv_tiny_forward(const void*, const void*, const void*, void*, int, int, int, hipStream_t);
+int conv_tiny_backward_data(const void*, const void*, void*, int, int, int, int, hipStream_t);
+int conv_tiny_backward_weight(const void*, const void*, void*, void*, int, int, int, hipStream_t);
 // implemented in conv_gen.hip (general grouped 1x1 / 3x3 convolutions, fp32 or bf16, any channel counts)
 int convg_forward(const void*, const void*, const void*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int convg_backward_data(const void*, const void*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -301,6 +307,10 @@ int cot_set_tuning(int key, int value) {
         g_bn_grid_cap = value > 0 ? value : 4096;
         return COT_OK;
     }
+    if (key == 22) {
+        g_conv_tiny = value ? 1 : 0;
+        return COT_OK;
+    }
     if (key == 21) {
         g_bn_chan = value > 0 ? value : 0;  // 0 off, 1 on, 256 / 512 / 1024: on with that workgroup size (A/B)
         return COT_OK;
@@ -371,6 +381,7 @@ int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weig
     if (!x1 || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x1, x2, weight, y}))) return rc;
     if (dtype == COT_F32) return convg_forward(x1, weight, bias, y, N, Ci, Co, 1, HW, 1, 1, 0, dtype, (hipStream_t)stream);
+    if (!x2 && conv_tiny_covers(N, Ci, Co, HW)) return conv_tiny_forward(x1, weight, bias, y, Ci, Co, HW, (hipStream_t)stream);
     if (conv1x1_lds_covers(Ci, c1, x2 != nullptr, HW)) {
         rc = conv1x1_lds_gemm(x1, x2, c1, weight, 0, bias, y, nullptr, Co, N, Ci, Co, HW, 0, (hipStream_t)stream);
         if (rc != -1) return rc;
@@ -386,6 +397,8 @@ int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, voi
     if ((rc = check_align16({gy, weight, gx1, gx2, workspace}))) return rc;
     if (dtype == COT_F32)
         return convg_backward_data(gy, weight, gx1, N, Ci, Co, 1, HW, 1, 1, accumulate & 1, dtype, (hipStream_t)stream);
+    if (!gx2 && conv_tiny_covers(N, Ci, Co, HW))
+        return conv_tiny_backward_data(gy, weight, gx1, Ci, Co, HW, accumulate & 1, (hipStream_t)stream);
     if (conv1x1_lds_covers(Co, Co, false, HW)) {
         // the LDS forward kernel on dY; its weight operand is W^T, which IS the [Co][Ci] weight tensor read as [K][M] (WT
         // kernels: transposing LDS reads) -- tuning key 17 bit 5 brings back the round-2-mid form (a transposed, K-step-major
@@ -414,6 +427,8 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
     if (dtype == COT_F32)
         return convg_backward_weight(gy, x1, gweight, gbias, (float*)workspace, N, Ci, Co, 1, HW, 1, 1, dtype,
                                      (hipStream_t)stream);
+    if (!x2 && HW % 8 == 0 && conv_tiny_covers(N, Ci, Co, HW))
+        return conv_tiny_backward_weight(gy, x1, gweight, gbias, Ci, Co, HW, (hipStream_t)stream);
     if (conv1x1_wgrad_lds_covers(N, HW, Co, Ci) && !g_conv_lds_tune_wgrad_off())
         return conv1x1_wgrad_lds_run(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
     return conv1x1_wgrad(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);

@@ -204,7 +204,8 @@ if __name__ == "__main__":
                   (2, 48, 40, 8, 8, 16), (8, 24, 16, 7, 7, 8), (8, 8, 8, 1, 1, 0),
                   # K % 32 == 0: the LDS-pipelined kernels (csrc/conv_lds.hip): partial pixel tile, flat images, partial
                   # image group, two slabs, channel counts that are not multiples of the tile
-                  (1, 64, 40, 20, 20, 0), (3, 64, 72, 14, 14, 32), (8, 32, 24, 7, 7, 0), (1, 96, 136, 1, 80, 0),
+                  (1, 64, 40, 20, 20, 0), (3, 64, 72, 14, 14, 32), (8, 32, 24, 7, 7, 0), (1, 96, 136, 1, 80, 0), (1, 40, 24, 1, 24, 0),
+                  (1, 16, 8, 3, 8, 0),
                   (2, 32, 32, 16, 24, 0)]:
         conv1x1(*shape)
     for shape in [(2, 64, 4, 8, 16), (2, 32, 4, 14, 14), (8, 64, 8, 7, 7), (1, 256, 4, 5, 4), (8, 16, 2, 1, 3),

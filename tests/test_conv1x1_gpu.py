@@ -179,3 +179,29 @@ def test_deep_layers_with_both_channel_block_sizes(N, Ci, Co, H, monkeypatch):
     for y, gx, gw in outs:
         assert _close(y, yr, 1e-2) and _close(gx, gxr[0], 1e-2) and _close(gw, gwr, 1e-2)
     assert _close(outs[0][0], outs[1][0].float(), 1e-2) and _close(outs[0][1], outs[1][1].float(), 1e-2)
+
+
+@pytest.mark.parametrize("Ci,Co,NB", [(64, 32, 80), (32, 128, 80), (512, 256, 80), (256, 1024, 80), (128, 64, 24), (72, 40, 250)])
+def test_one_image_convolutions_of_the_se_branch(Ci, Co, NB, monkeypatch):
+    """the `se` branch's two 1x1 convolutions as the single-node layers issue them: ONE image whose pixels are the batch
+    (csrc/conv_tiny.hip: a wave per 16 x 16 output tile, no LDS), against the fp32 reference, and the tiled kernels next to
+    them (cot_set_tuning(22, 0))"""
+    from cotnet_amd import _lib
+    monkeypatch.setattr(c1, "MODE", "hip")
+    torch.manual_seed(Ci + Co)
+    conv = nn.Conv2d(Ci, Co, 1, bias=True).to(DEV).bfloat16()
+    x = torch.randn(1, Ci, 1, NB, device=DEV).bfloat16()
+    gy = torch.randn(1, Co, 1, NB, device=DEV).bfloat16()
+    yr, gxr, gwr, gbr = _ref([x], conv.weight, conv.bias, gy)
+    try:
+        for key in (1, 0):
+            _lib.check(_lib.lib().cot_set_tuning(22, key), "cot_set_tuning")
+            xi = x.clone().requires_grad_(True)
+            conv.zero_grad()
+            y = c1.conv1x1(conv, xi)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            assert _close(y, yr, 1e-2) and _close(xi.grad, gxr[0], 1e-2)
+            assert _close(conv.weight.grad, gwr, 1e-2) and _close(conv.bias.grad, gbr, 1e-2)
+    finally:
+        _lib.check(_lib.lib().cot_set_tuning(22, 1), "cot_set_tuning")

@@ -1861,3 +1861,51 @@ def test_conv1x1_lds_data_gradient_reads_the_weight_in_place(N, Ci, Co, H, W, c1
         outs.append(g.clone())
     assert torch.equal(outs[0], outs[1])
     assert _EMUL.cot_set_tuning(17, 0) == 0
+
+
+@pytest.mark.parametrize("Ci,Co,NB,bias", [
+    (512, 256, 80, True),     # CotLayer.se[0] of stage 4 at B = 80 (pooled descriptors stored [C][B])
+    (256, 1024, 80, True),    # se[3]
+    (64, 40, 24, False),      # 40 output channels (partial 16-row tile), 24 pixels (partial column tile)
+    (8, 3, 8, True),          # one reduction chunk, three channels
+    (72, 136, 256, True),     # K = 72: the last 32-step has one chunk; the most pixels the path takes
+    (32, 16, 5, False),       # 5 pixels: not a multiple of 8 -> the weight gradient stays on the tiled kernels
+])
+def test_one_image_convolutions_of_the_se_branch(Ci, Co, NB, bias):
+    """csrc/conv_tiny.hip behind cot_conv1x1_* for ONE image of <= 256 pixels (one wave per 16 x 16 output tile, no LDS):
+    forward, data gradient (+ accumulate), weight / bias gradient against fp32 on the same bf16-rounded operands, and against
+    the tiled kernels (cot_set_tuning(22, 0))"""
+    torch.manual_seed(Ci + NB)
+    dt = _lib.dtype_code(torch.bfloat16)
+    x = torch.randn(1, Ci, NB).bfloat16()
+    w = (torch.randn(Co, Ci) / Ci ** 0.5).bfloat16()
+    b = torch.randn(Co).bfloat16() if bias else None
+    gy = torch.randn(1, Co, NB).bfloat16()
+    yr = torch.einsum("oc,ncp->nop", w.float(), x.float()) + (b.float()[None, :, None] if bias else 0)
+    gxr = torch.einsum("oc,nop->ncp", w.float(), gy.float())
+    gwr = torch.einsum("nop,ncp->oc", gy.float(), x.float())
+    gbr = gy.float().sum((0, 2))
+    ws = torch.full((_EMUL.cot_conv1x1_workspace(1, Ci, Co, NB, 1 if bias else 0),), 0x7f, dtype=torch.uint8)
+    res = []
+    for tiny in (1, 0):
+        assert _EMUL.cot_set_tuning(22, tiny) == 0
+        y = torch.full((1, Co, NB), float("nan")).bfloat16()
+        assert _EMUL.cot_conv1x1_forward(P(x), None, Ci, P(w), P(b) if bias else None, P(y), 1, Ci, Co, NB, dt, None) == 0
+        gx = torch.full((1, Ci, NB), float("nan")).bfloat16()
+        rc = _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), 1, Ci, Co, NB, dt, None)
+        assert rc == (0 if Co % 8 == 0 else -2), _EMUL.cot_last_error()
+        if rc == 0:
+            assert torch.allclose(gx.float(), gxr, atol=3e-2, rtol=2e-2)
+            assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 1, P(ws), 1, Ci, Co, NB, dt, None) == 0
+            assert torch.allclose(gx.float(), 2 * gxr, atol=8e-2, rtol=3e-2)
+        gw = torch.full_like(w, float("nan"))
+        gb = torch.full((Co,), float("nan")).bfloat16() if bias else None
+        assert _EMUL.cot_conv1x1_backward_weight(P(gy), P(x), None, Ci, P(gw), P(gb) if bias else None, P(ws), 1, Ci, Co, NB, dt,
+                                                 None) == 0
+        assert torch.allclose(y.float(), yr, atol=3e-2, rtol=2e-2), (y.float() - yr).abs().max()
+        assert (gw.float() - gwr).abs().max() <= 1e-2 * gwr.abs().max() + 1e-2
+        if bias:
+            assert (gb.float() - gbr).abs().max() <= 1e-2 * gbr.abs().max() + 1e-2
+        res.append((y.clone(), gw.clone()))
+    assert _EMUL.cot_set_tuning(22, 1) == 0
+    assert torch.allclose(res[0][0].float(), res[1][0].float(), atol=3e-2, rtol=2e-2)
