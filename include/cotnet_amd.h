@@ -130,7 +130,19 @@ const char* cot_last_kernel(void);
  *   key 12: BatchNorm: fold the per-channel finalize step into the apply kernels (0|1; one launch less each way)
  *   key 13: BatchNorm: most workgroups of the flat (grid-stride) apply kernels (default 4096; <= 0 restores it)
  *   key 14: convolutions: launches of at least this many waves use the shallow register ring (default 8192;
- *           a huge value = deep rings everywhere, 1 = shallow everywhere; <= 0 restores the default) */
+ *           a huge value = deep rings everywhere, 1 = shallow everywhere; <= 0 restores the default)
+ *   key 15: LDS-pipelined convolution kernels (conv_lds.hip) on (1, default) / off (0: first-generation kernels)
+ *   key 16: conv_lds FLAT mode: images per workgroup (0 = auto)
+ *   key 17: conv_lds bit field -- bit 0 four-wave workgroups, bit 1 2-byte gathers instead of transposing LDS reads, bit 2 LDS
+ *           weight gradient off, bit 3 general LDS weight gradient everywhere, bit 4 its deep-layer rule off, bit 5 data
+ *           gradient on a transposed weight copy instead of reading the weight in place, bits 8..: 7 x 7 stage channel-block
+ *           rule (0 default, 1 off, n > 1 workgroup-count threshold)
+ *   key 18: BatchNorm: per-channel sample count up to which the fp64 one-wave-per-channel path is taken (default 256)
+ *   key 19: weight gradients (register kernels): partial-sum bytes allowed as a percentage of the input bytes (default 50)
+ *   key 20: the same for the LDS weight gradient (default 25 aligned planes / 100 general form)
+ *   key 21: BatchNorm channel-resident kernels (1 default, 0 off, 256 / 512 / 1024 = forced workgroup size)
+ *   key 22: one-image 1x1 convolutions on the staging-free kernels of conv_tiny.hip (1 default, 0 off)
+ * Keys 11, 19, 20 change split counts: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* 0 if the device probe confirmed the DPP wave_shr/wave_shl semantics the v2 kernels rely on, 1 if the
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */
@@ -152,7 +164,8 @@ int cot_radix_mix_backward(const void* gout, const void* y, const void* k, const
  * nn.Conv2d(kernel_size=1, stride=1, groups=1) forward and both gradients.  COT_BF16 (fp32 accumulation; channel counts
  * that are not multiples of 8 return COT_ERR_UNSUPPORTED and the caller keeps nn.Conv2d -- or uses cot_conv1x1g_* with
  * groups = 1) and COT_F32 (the reference's own precision, `amp: False`: fp32 MFMA, any channel counts, one input tensor:
- * x2 / gx2 must be NULL and the bias is fp32).
+ * x2 / gx2 must be NULL and the bias is fp32).  ONE image of at most 256 pixels (N == 1: the `se` branch of the single-node
+ * layers, whose "pixels" are the batch) runs on staging-free kernels (csrc/conv_tiny.hip).
  *     y[n][co][p] = sum_ci weight[co][ci] * x[n][ci][p] + bias[co]         weight [Co][Ci] row-major, bias NULL or [Co]
  * x may be given as TWO channel slabs that the reference concatenates first (`torch.cat([x, k], dim=1)`,
  * models/cotnet.py:81): x1 = [N][c1][HW], x2 = [N][Ci-c1][HW]; x2 == NULL means one tensor and c1 must equal Ci.
