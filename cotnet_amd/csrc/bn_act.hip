@@ -297,6 +297,31 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const T* __restrict__ dy, co
 }
 
 
+// ---- inference mode (nn.BatchNorm2d.eval(): running statistics): y = act(gamma*(x - running_mean)/sqrt(running_var + eps)
+// + beta [+ residual]) in one pass -- the forward-only configuration (BASELINE config 2) otherwise runs torch's batch_norm,
+// the activation and the residual add as separate passes
+template <typename T, int V, int ACT>
+__global__ __launch_bounds__(256) void bn_infer_fwd(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                   const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                   int C, int HW, int64_t nvec) {
+    for (ChannelWalk w((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, HW / V, C);
+         w.i < nvec; w.next()) {
+        const int c = w.c;
+        const float a = gamma[c] / sqrtf(rvar[c] + eps), mu = rmean[c], b = beta[c];
+        const Vec<T, V> xv = ldv<T, V>(x + w.i * V);
+        Vec<T, V> rv, o;
+        if (res) rv = ldv<T, V>(res + w.i * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float z = ((float)xv.v[k] - mu) * a + b;  // (centred first, as torch does: no cancellation against a large mean)
+            if (res) z += (float)rv.v[k];
+            o.v[k] = (T)act_fwd<ACT>(z);
+        }
+        stv<T, V>(y + w.i * V, o);
+    }
+}
+
 // ---- "folded" variants (cot_set_tuning key 12): the per-channel finalize step lives in the apply kernel's prologue.
 // Grid (C, SPLIT) like the partial kernels, so the channel is block-uniform: every thread merges the SPLIT chunk
 // statistics of its channel (a few dozen flops), block (c, 0) writes mean / rstd / running statistics.  One launch less
@@ -592,6 +617,32 @@ __global__ __launch_bounds__(64) void bn_small_bwd(const T* __restrict__ dy, con
         if (dres) dres[i] = (T)(float)g;
     }
 }
+
+template <typename T>
+int bn_act_inference(const void* x, const void* res, void* y, const float* gamma, const float* beta, const float* rmean,
+                     const float* rvar, int N, int C, int HW, float eps, int act, hipStream_t s) {
+    const int v = pick_vec(sizeof(T), HW);
+#define BN_I(V_, A_)                                                                                                  \
+    COT_LAUNCH((bn_infer_fwd<T, V_, A_>), dim3(flat_grid((int64_t)N * C * HW / V_)), dim3(256), 0, s, (const T*)x,     \
+               (const T*)res, (T*)y, rmean, rvar, gamma, beta, eps, C, HW, (int64_t)N * C * HW / V_)
+#define BN_IV(V_)                                 \
+    do {                                          \
+        if (act == ACT_RELU) BN_I(V_, ACT_RELU);  \
+        else if (act == ACT_SILU) BN_I(V_, ACT_SILU); \
+        else BN_I(V_, ACT_NONE);                  \
+    } while (0)
+    if (v == 8 && sizeof(T) <= 2) BN_IV(8);
+    else if (v >= 4) BN_IV(4);
+    else if (v == 2) BN_IV(2);
+    else BN_IV(1);
+#undef BN_IV
+#undef BN_I
+    return check_launch("bn_infer_fwd");
+}
+template int bn_act_inference<float>(const void*, const void*, void*, const float*, const float*, const float*, const float*,
+                                     int, int, int, float, int, hipStream_t);
+template int bn_act_inference<bf16_t>(const void*, const void*, void*, const float*, const float*, const float*, const float*,
+                                      int, int, int, float, int, hipStream_t);
 
 // ---- channel-resident kernels: N*H*W small enough for one workgroup to hold a channel in registers -------------------------
 // The 14 x 14 and 7 x 7 stages (and 28 x 28 in bf16) have 4-63 K samples per channel: the streaming path's four launches

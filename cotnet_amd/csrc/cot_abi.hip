@@ -104,6 +104,9 @@ template <typename T>
 int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, long long*,
                    float*, int, int, int, float, float, int, hipStream_t);
 template <typename T>
+int bn_act_inference(const void*, const void*, void*, const float*, const float*, const float*, const float*, int, int, int,
+                     float, int, hipStream_t);
+template <typename T>
 int bn_act_backward(const void*, const void*, const void*, void*, void*, const float*, const float*, const float*,
                     const float*, float*, float*, float*, int, int, int, int, hipStream_t);
 template <typename T>
@@ -844,6 +847,19 @@ int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, 
     if (dtype == COT_BF16)
         return bn_act_backward<bf16_t>(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
                                        workspace, N, C, HW, act, s);
+    return set_error(COT_ERR_UNSUPPORTED, "bn_act: dtype %d (float32 / bfloat16 only)", dtype);
+}
+
+int cot_bn_act_inference(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, int N, int C, int HW, float eps, int act, int dtype,
+                         void* stream) {
+    if (!x || !y || !gamma || !beta || !running_mean || !running_var) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act");
+    int rc = check_align16({x, residual, y});
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == COT_F32) return bn_act_inference<float>(x, residual, y, gamma, beta, running_mean, running_var, N, C, HW, eps, act, s);
+    if (dtype == COT_BF16) return bn_act_inference<bf16_t>(x, residual, y, gamma, beta, running_mean, running_var, N, C, HW, eps, act, s);
     return set_error(COT_ERR_UNSUPPORTED, "bn_act: dtype %d (float32 / bfloat16 only)", dtype);
 }
 

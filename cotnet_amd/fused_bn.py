@@ -6,8 +6,9 @@ running statistics updated with torch's momentum / unbiased-variance convention)
 two backward instead of one pass per module (models/cotnet.py:231-235 bn1+act1, :248-262 bn3 + residual + act3,
 :43-47 key_embed BN+ReLU, :89-90 bn + SiLU).  Device code: csrc/bn_act.hip behind cot_bn_act_forward/_backward.
 
-The fused path is taken for training-mode NCHW-contiguous fp32 / bf16 CUDA tensors; anything else (eval mode,
-channels_last, fp64, momentum=None, CPU) takes the plain torch modules, so results and state are identical either way.
+The fused path is taken for training-mode NCHW-contiguous fp32 / bf16 CUDA tensors, and -- one pass, running statistics --
+for eval-mode modules under torch.no_grad() (cot_bn_act_inference); anything else (eval mode with autograd, channels_last,
+fp64, momentum=None, CPU) takes the plain torch modules, so results and state are identical either way.
 """
 import ctypes
 import os
@@ -92,8 +93,25 @@ def _torch_path(x, bn, act, residual):
     return y
 
 
+def _inference(x, bn, act, residual):
+    """eval-mode BatchNorm (running statistics) + activation (+ residual) as one pass; no autograd (the caller checked)"""
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    rc = _lib.lib().cot_bn_act_inference(_p(x), _p(residual), _p(y), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+                                         _p(bn.running_var), N, C, H * W, float(bn.eps), _ACTS[act], _DT[x.dtype], _stream())
+    if rc:
+        _lib.check(rc, "cot_bn_act_inference")
+    return y
+
+
 def fused_bn_act(x, bn, act=None, residual=None):
     """act(bn(x) [+ residual]) with `bn` an nn.BatchNorm2d.  Fused HIP kernels when eligible, torch otherwise."""
+    if (ENABLED and not bn.training and not torch.is_grad_enabled() and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4
+            and x.dtype in _DT and x.is_contiguous() and bn.affine and bn.track_running_stats and bn.running_mean is not None
+            and bn.weight.dtype == torch.float32 and bn.running_mean.dtype == torch.float32 and x.data_ptr() % 16 == 0
+            and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous()
+                                      and residual.data_ptr() % 16 == 0))):
+        return _inference(x, bn, act, residual)  # forward-only evaluation under torch.no_grad()
     # (tensors are assumed to live on the current device, as everywhere in a one-process-per-GPU job)
     ok = (ENABLED and bn.training and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
           and x.is_contiguous() and bn.affine and bn.track_running_stats and bn.momentum is not None

@@ -341,6 +341,11 @@ int cot_bn_act_forward(const void* x, const void* residual, void* y, const float
 int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
                         const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                         float* workspace, int N, int C, int HW, int act, int dtype, void* stream);
+/* inference mode (nn.BatchNorm2d.eval()): y = act(gamma*(x - running_mean)/sqrt(running_var + eps) + beta [+ residual]) in one
+ * pass; nothing is updated. */
+int cot_bn_act_inference(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, int N, int C, int HW, float eps, int act, int dtype,
+                         void* stream);
 
 /* Per-launch device timing for bench.py's roofline object.  Between cot_profile_begin() and cot_profile_end()
  * every aggregation kernel (every kernel of the library when the environment has COT_PROFILE_ALL=1) is launched with start/stop events attached to its dispatch (hipExtLaunchKernelGGL),

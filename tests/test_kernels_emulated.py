@@ -1909,3 +1909,24 @@ def test_one_image_convolutions_of_the_se_branch(Ci, Co, NB, bias):
         res.append((y.clone(), gw.clone()))
     assert _EMUL.cot_set_tuning(22, 1) == 0
     assert torch.allclose(res[0][0].float(), res[1][0].float(), atol=3e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W,act,use_res", [(2, 8, 7, 7, 1, True), (3, 16, 8, 8, 2, False), (1, 4, 5, 3, 0, False), (4, 6, 1, 1, 1, False)])
+def test_bn_inference_kernel(N, C, H, W, act, use_res, dtype):
+    """cot_bn_act_inference (eval-mode BatchNorm from the running statistics + activation + residual, one pass)"""
+    torch.manual_seed(N * C + H)
+    x = (torch.randn(N, C, H, W) * 1.5 + 0.7).to(dtype)
+    res = torch.randn(N, C, H, W).to(dtype) if use_res else None
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.2
+    rm, rv = torch.randn(C) * 0.3, torch.rand(C) + 0.5
+    z = torch.nn.functional.batch_norm(x.float(), rm, rv, gamma, beta, False, 0.1, 1e-5)
+    if use_res:
+        z = z + res.float()
+    yr = {0: lambda t: t, 1: torch.relu, 2: torch.nn.functional.silu}[act](z)
+    y = torch.full_like(x, float("nan"))
+    rc = _EMUL.cot_bn_act_inference(P(x), P(res) if use_res else None, P(y), P(gamma), P(beta), P(rm), P(rv), N, C, H * W, 1e-5, act,
+                                    _lib.dtype_code(dtype), None)
+    assert rc == 0, _EMUL.cot_last_error()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert ((y.float() - yr).abs() <= tol * (1 + yr.abs())).all()
