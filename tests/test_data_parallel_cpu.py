@@ -210,3 +210,90 @@ def test_grad_sink_lets_a_producer_write_its_bucket_slot():
     assert gw2.data_ptr() != slot[id(lin.weight)].data_ptr()
     red.remove()
     grad_sink.unregister_all()
+
+
+def _worker_fused_nodes(rank, world, port, q):
+    """the measured configuration under data parallelism: single-node Bottlenecks whose kernels write parameter gradients
+    straight into the flat bf16 buckets (grad_sink), FlatSGD's reducer all-reducing them -- on the host-emulated library, two
+    ranks with different data, checked against the mean of the gradients each rank computes alone"""
+    import copy
+    import ctypes
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cotnet_amd.aggregation_zeropad as az
+        from cotnet_amd import (_lib, conv1x1 as c1, conv3x3g as c3, cot_layer_fused as clf, flat_sgd, fused_bn,
+                                group_norm9 as g9, head_fused as hf, pool3x3 as p3, radix_tail, stem7x7 as s7)
+        from cotnet_amd.cotnet import Bottleneck
+        from cotnet_amd.flat_sgd import FlatSGD, to_mixed_bf16
+        from cotnet_amd.resnet import ResNet
+        from tests import test_kernels_emulated as tke
+        if tke._EMUL is None:
+            q.put((rank, 0, "skip"))
+            return
+        _lib.lib = lambda: tke._EMUL
+        for mod in (clf, c1, c3, fused_bn, radix_tail, g9, flat_sgd, p3, hf, s7):
+            mod._DEVICE_ONLY = False
+        clf.ENABLED = True
+        c1.MODE = c3.MODE = g9.MODE = p3.MODE = hf.MODE = s7.MODE = "hip"
+        az.aggregation_zeropad = lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: tke._EmulAggregation.apply(i, w)
+        solo = [dist.new_group([r]) for r in range(world)]  # (every rank takes part in creating every group)
+
+        torch.manual_seed(3)  # same weights on both ranks
+        base = ResNet(Bottleneck, [1, 1, 1, 1], num_classes=10)
+        for mod in base.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.eps = 0.5
+                nn.init.uniform_(mod.weight, 0.5, 1.0)  # (bn3 starts at zero: no gradient would reach the branches)
+        base = to_mixed_bf16(base).train()
+        torch.manual_seed(40 + rank)  # different data
+        x, t = torch.randn(2, 3, 32, 32).bfloat16(), torch.randint(0, 10, (2,))
+
+        def grads(process_group):
+            model = copy.deepcopy(base)
+            opt = FlatSGD(model, lr=0.1, process_group=process_group, broadcast_params=False)
+            opt.zero_grad()
+            nn.functional.cross_entropy(model(x).float(), t).backward()
+            opt.reducer.finish()
+            return [b.flat.detach().float().clone() for b in opt.reducer.buckets], opt
+
+        local, _ = grads(solo[rank])
+        want = []
+        for g in local:
+            parts = [torch.empty_like(g) for _ in range(world)]
+            dist.all_gather(parts, g)
+            want.append(torch.stack(parts).mean(0))
+        got, opt = grads(None)
+        assert opt.reducer.enabled and len(got) == len(want)
+        for a, b in zip(got, want):
+            assert torch.isfinite(a).all() and b.abs().max() > 0
+            # bf16 buckets: the average is rounded once more than the fp32 mean of the two rounded gradients
+            assert torch.allclose(a, b, atol=2e-2 * b.abs().max().item(), rtol=2e-2), (a - b).abs().max()
+        opt.step()  # the fused SGD kernel on the averaged buckets
+        ps = [b.pflat.detach().float().clone() for b in opt.reducer.buckets]
+        for p in ps:
+            parts = [torch.empty_like(p) for _ in range(world)]
+            dist.all_gather(parts, p)
+            assert torch.equal(parts[0], parts[1])  # the ranks stay in lock step
+        q.put((rank, len(got), "ok"))
+    except Exception as e:
+        q.put((rank, -1, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_node_layers_with_gradient_sink_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fused_nodes, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    if any(msg == "skip" for _, _, msg in results):
+        pytest.skip("host emulation build unavailable")
+    for rank, _, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
