@@ -634,4 +634,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    _rc = main()
+    sys.exit(_rc if isinstance(_rc, int) else 0)  # (the launcher form returns the ranks' exit code)

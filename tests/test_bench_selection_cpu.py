@@ -175,3 +175,20 @@ def test_verdict_reaches_every_rank_through_the_rendezvous_store():
     assert r.returncode == 0, r.stderr[-600:]
     got = sorted(ln for ln in r.stdout.splitlines() if ln.startswith("VERDICT"))
     assert got == ["VERDICT rank0 new", "VERDICT rank1 new"], r.stdout[-300:]
+
+
+def test_bench_spawns_its_own_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` without a launcher (how the driver calls it): re-executes itself under
+    torch.distributed.run with two ranks on 127.0.0.1; in the GPU-less container every rank must stop with the "no CPU path"
+    message instead of benchmarking anything (round-1 verdict: an assert on WORLD_SIZE killed this invocation)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    # (the launcher terminates the other rank as soon as one has failed: one or two messages)
+    assert "launching 2 ranks" in out and out.count("there is no CPU path") >= 1, out[-2000:]
+    assert '"metric"' not in r.stdout   # no benchmark line from a run that measured nothing
