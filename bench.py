@@ -602,7 +602,12 @@ def main():
             agg_total = sum(k["total_ms"] for k in kernels) / timing_steps  # ms of aggregation kernels per step
             roofline = {"bound": "hbm", "kernel": k0["kernel"], "shape": k0["shape"], "dtype": k0["dtype"],
                         "achieved": k0["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k0["frac"],
-                        "traffic": traffic, "avg_us": k0["avg_us"],
+                        "traffic": traffic,
+                        "traffic_source": ("HBM-side bytes per launch of this kernel and shape from rocprofv3 --pmc FETCH_SIZE / "
+                                           "WRITE_SIZE passes (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), scripts/"
+                                           "agg_traffic_from_pmc.py -> profiles/agg_traffic.json; the evidence session "
+                                           "(scripts/gpu_evidence_session.sh) refreshes it right before this run") if traffic else None,
+                        "avg_us": k0["avg_us"],
                         "timing": f"dispatch-attached HIP events (on the launch stream) over {timing_steps} repeats of the "
                                   "step right after the un-instrumented timed region",
                         "agg_share_of_step": round(agg_total / (elapsed / args.steps * 1e3), 4), "kernels": kernels}

@@ -17,6 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python scripts/agg_traffic_from_pmc.py $O/ev_pmc_FETCH_SIZE $O/ev_pmc_WRITE_SIZE --out $O/ev_agg_traffic.json
+python scripts/agg_traffic_from_pmc.py $O/ev_pmc_FETCH_SIZE $O/ev_pmc_WRITE_SIZE --out profiles/agg_traffic.json > /dev/null   # the bench line below reports THIS session's counters
 timeout 200 python scripts/bench_agg_abi.py --variants v3d --iters 20 --rounds 5 --out $O/ev_agg_abi.json > $O/ev_agg_abi.log 2>&1; tail -20 $O/ev_agg_abi.log | cut -c1-200
 timeout 300 python scripts/bench_conv_abi.py --iters 20 --json $O/ev_conv_abi.json > $O/ev_conv_abi.log 2>&1; tail -5 $O/ev_conv_abi.log | cut -c1-200
 T1=$(date +%s)
