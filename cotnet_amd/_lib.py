@@ -14,6 +14,16 @@ COT_F32, COT_F64, COT_BF16, COT_F16 = 0, 1, 2, 3
 COT_NCHW, COT_NHWC = 0, 1
 
 _lib = None
+_SHAPE_CACHES = []  # dicts of shape -> workspace size held by the Python wrappers (see register_cache)
+
+
+def register_cache(d):
+    """Workspace sizes are pure functions of (shape, tuning state).  The wrappers cache them per shape; every cache is
+    registered here and emptied whenever a tuning key changes (several keys -- 11, 15, 17, 19, 20 -- change what
+    cot_conv1x1_workspace / cot_conv3x3g_workspace return: a stale, smaller size would let a weight-gradient kernel write
+    its partial sums past the end of the workspace; the ABI has no size argument to catch that)."""
+    _SHAPE_CACHES.append(d)
+    return d
 
 
 class AggGeom(ctypes.Structure):
@@ -120,6 +130,13 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if L.cot_abi_version() != 1:
             raise RuntimeError(f"libcotnet_hip.so ABI version {L.cot_abi_version()} != 1")
+        raw_set_tuning = L.cot_set_tuning
+
+        def cot_set_tuning(key, value):  # every caller (tests, bench.py --tune, COT_TUNING) goes through this wrapper
+            for d in _SHAPE_CACHES:
+                d.clear()
+            return raw_set_tuning(key, value)
+        L.cot_set_tuning = cot_set_tuning
         # developer knobs: COT_TUNING="12=1,9=0" -> cot_set_tuning(12, 1), cot_set_tuning(9, 0)  (include/cotnet_amd.h)
         for item in filter(None, os.environ.get("COT_TUNING", "").split(",")):
             k, v = item.split("=")

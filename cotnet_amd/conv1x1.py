@@ -68,7 +68,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if _DEVICE_ONLY else None
 
 
-_WS = {}  # (N, Ci, Co, HW, has_bias) -> backward workspace bytes (pure function of the shape)
+_WS = _lib.register_cache({})  # (N, Ci, Co, HW, has_bias) -> backward workspace bytes (pure function of the shape)
 
 
 def _ws_bytes(N, Ci, Co, HW, has_bias):

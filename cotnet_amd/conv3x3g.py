@@ -20,7 +20,7 @@ MODE = os.environ.get("COT_CONV3X3", "")
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
 
 _MASKS = {}  # (H, W, device) -> uint8 tensor holding the per-pixel tap-validity table (read-only after creation)
-_WS = {}     # (N, Cin, Cout, G, H, W) -> workspace bytes
+_WS = _lib.register_cache({})     # (N, Cin, Cout, G, H, W) -> workspace bytes
 
 
 def _p(t):

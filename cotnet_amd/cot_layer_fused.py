@@ -47,7 +47,7 @@ def _ck(rc, what):
         _lib.check(rc, what)
 
 
-_SIZES = {}  # (N, C, H, W, A) -> (workspace bytes, bn workspace floats for C, C/2 and the se branch's A channels)
+_SIZES = _lib.register_cache({})  # (N, C, H, W, A) -> (workspace bytes, bn workspace floats for C, C/2 and the se branch's A channels)
 _MASKS = {}
 
 
@@ -381,7 +381,7 @@ def _block_plan(blk):
     return p
 
 
-_BSIZES = {}
+_BSIZES = _lib.register_cache({})
 
 
 def _block_sizes(L, N, Cin, Cw, Cout, HW):

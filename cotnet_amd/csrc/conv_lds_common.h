@@ -1,0 +1,211 @@
+// conv_lds_common.h -- pieces shared by the LDS-DMA pipelined convolution kernels (conv_lds.hip, conv_lds2.hip): the
+// hand-counted copy / wait / barrier primitives, the epilogue through LDS, the 1x1 kernels' argument block.
+#pragma once
+#include <atomic>
+
+#include "cot_common.h"
+#include "mfma_common.h"
+
+namespace cot {
+
+// Opt a kernel in to more than the default 64 KB of dynamic LDS (160 KB per CU on gfx950), once per DEVICE: `raised` is the
+// calling launch function's own static bit mask (one per kernel instantiation).  Returns false when the runtime refuses --
+// the caller then reports "not covered" and the previous kernel generation runs instead of an opaque launch failure.
+inline bool raise_dynamic_lds_once(std::atomic<uint32_t>& raised, const void* func) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
+    if ((raised.load(std::memory_order_relaxed) >> dev) & 1u) return true;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    raised.fetch_or(1u << dev, std::memory_order_relaxed);
+    return true;
+}
+
+// ---- hand-counted LDS-DMA pipeline primitives ----------------------------------------------------------------------
+// The compiler's own bookkeeping drains every outstanding LDS-DMA (s_waitcnt vmcnt(0)) in front of the first LDS read it
+// cannot prove disjoint from the DMA's destination -- i.e. in front of every K step's fragment reads -- which turns a
+// multi-stage pipeline into load-wait-compute (seen in the first version's ISA).  So the copies are issued from an asm
+// statement the compiler does not count (cdna_hip_programming.md 5.7: M0 = wave-uniform LDS base, set and restored in the
+// same statement), completion is tracked by hand with counted s_waitcnt vmcnt(N), and the workgroup barrier is the raw
+// s_barrier behind an lgkmcnt(0) (LDS reads of the step done; nothing else pending).
+#ifndef COT_GLDS16  // (tests/emul pre-defines the three primitives for its host build)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds_wave_base));
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+// ds_read_b64_tr_b16: every lane passes the address of 4 consecutive bf16 (8-byte aligned); within each group of 16 lanes,
+// lane L (0..15) pointing at row (L>>2), columns 4*(L&3).. of a 4 x 16 block receives rows 0..3 of column L -- a free 4x4
+// transposition (mapping confirmed on the MI355X by scripts/ubench_trprobe.py).  Two of them build the 8-deep K fragment of
+// a K-strided operand that otherwise takes eight 2-byte reads and four permutes.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ s16x4_t lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+}
+// Scalar-base form (round 3): source = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset, destination =
+// wave-uniform LDS byte address (M0) + lane*16.  A K step then moves only the SCALAR base -- the per-lane offsets are loop
+// constants -- and M0 is written by the compiler's own scalar code ("{m0}" binds the operand to the register; the s_nop covers
+// the M0-write -> LDS-DMA hazard the compiler cannot see inside an asm statement).  The pointer form above costs ~30
+// instructions per copy in 64-bit vector address arithmetic, readfirstlanes and M0 save/restore: with two waves per SIMD
+// that WAS the K step of the deep layers (profiles/r03_*: step time independent of the tile's size).
+// Probed on the MI355X (scripts/probe3.py): aligned, 2-byte-aligned and scattered sources land as expected.
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "{m0}"(lds_addr) : "memory");
+}
+// LDS byte address of a pointer into the dynamic LDS array (what M0 / DS instructions take)
+#define COT_LDS_ADDR(p) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(p))
+#define COT_GLDS16S(sbase, voff, lds_addr) cot::glds16_s((sbase), (voff), (lds_addr))
+#define COT_LDS_READ_TR16(p) cot::lds_read_tr16((p))
+#define COT_GLDS16(gptr, lds_wave_base) cot::glds16((gptr), (lds_wave_base))
+#define COT_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// nothing is scheduled across this point (register-only instructions -- MFMAs -- move freely across asm statements otherwise:
+// the fragment-prefetch loop needs "issue the next step's LDS reads, THEN multiply", and got the opposite without it)
+#define COT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// lgkmcnt(0) + s_barrier in ONE asm statement (no LDS access can be scheduled between the two), followed by the same wait as
+// a builtin: a no-op for the hardware, but it tells the compiler's own wait-count bookkeeping that every earlier LDS read has
+// returned -- without it the compiler, which cannot see inside the asm, guards the first use of registers loaded BEFORE the
+// barrier with an lgkmcnt(N) that also drains the reads issued AFTER it (seen in the ISA of the fragment-prefetch loop: the
+// MFMAs of step k waited for most of step k+1's fragments).
+#define COT_LDS_BARRIER()                                                   \
+    do {                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+        __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0), vmcnt / expcnt: no wait */ \
+    } while (0)
+#else
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+#endif
+
+// `ahead` stages (G copies each, per wave) were issued after the one about to be read: leave exactly those in flight
+template <int G, int A> struct WaitBehind {
+    static __device__ __forceinline__ void go(int ahead) {
+        if (ahead >= A) COT_WAIT_VM(A * G);
+        else WaitBehind<G, A - 1>::go(ahead);
+    }
+};
+template <int G> struct WaitBehind<G, 0> {
+    static __device__ __forceinline__ void go(int) { COT_WAIT_VM(0); }
+};
+
+// ---- epilogue through LDS (shared by the 1x1 and the grouped 3x3 kernels).  In the C/D map a lane holds 4 consecutive
+// pixels of ONE channel and the 16 lanes of a group 16 different channels: stored directly that is 32 contiguous bytes per
+// channel row and instruction.  Instead the tile goes to LDS in its memory order (rounded to bf16, bias added) and is
+// copied out in full 16-byte pieces, 256 contiguous bytes per 16 lanes: BIG = rows of BPX pixels; FLAT = per image one
+// contiguous [channels][H*W] block (whatever H*W is -- the channel block of an image IS one flat range of y).
+struct EpiArgs {
+    bf16_t* y1;
+    bf16_t* y2;          // second channel slab of the output (NULL: m1 == M)
+    const bf16_t* bias;  // indexed by the global channel (may be NULL)
+    int m1, M, HW, N, ni;
+    int n0, p0, m0;      // first image, first pixel (BIG), first channel of the tile
+    int mv, ncols;       // valid channels / columns of the tile
+    int accumulate;      // bit 0: y1 += result, bit 1: y2 += result
+};
+
+template <int CB, int MB, int FLAT, int WAVES>
+__device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], const EpiArgs& a) {
+    constexpr int NT = 64 * WAVES, BPX = 16 * WAVES * CB;
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int HW = a.HW, M = a.M, m0 = a.m0, n0 = a.n0, p0 = a.p0, ncols = a.ncols, mv = a.mv;
+    COT_LDS_BARRIER();  // every wave is done with the last stage: the stage memory is free
+    bf16_t* const ot = reinterpret_cast<bf16_t*>(cot_smem);
+    constexpr int OS = BPX + 8;                      // BIG: padded row stride of the tile image (bank spread)
+    const int nimg = FLAT ? min(a.ni, a.N - n0) : 1;
+    const int per = mv * HW, pers = (per + 7) & ~7;  // FLAT: elements of one image's channel block, its (16-byte) LDS stride
+#pragma unroll
+    for (int mbk = 0; mbk < MB; ++mbk) {
+        const int ml = mbk * 16 + i16;
+        const float bs = (a.bias && ml < mv) ? (float)a.bias[m0 + ml] : 0.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int col = (wave * CB + cb) * 16 + 4 * g;
+            bf16_t o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[cb][mbk][r] + bs);
+            if (!FLAT) {
+                __builtin_memcpy(__builtin_assume_aligned(ot + ml * OS + col, 8), o, 8);
+            } else if (HW % 4 == 0) {
+                if (col < ncols && ml < mv) {  // 4 consecutive columns stay inside one image
+                    const int img = col / HW, p = col - img * HW;
+                    __builtin_memcpy(__builtin_assume_aligned(ot + img * pers + ml * HW + p, 8), o, 8);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = col + r;
+                    if (c < ncols && ml < mv) {
+                        const int img = c / HW, p = c - img * HW;
+                        ot[img * pers + ml * HW + p] = o[r];
+                    }
+                }
+            }
+        }
+    }
+    COT_LDS_BARRIER();
+    // copy out: 16 bytes per lane.  Output slabs (y1 | y2 at channel m1): a block lies in one slab or, when it straddles m1,
+    // rows are routed one by one (m1 % 8 == 0 is checked on the host, so flat 16-byte pieces never straddle the slabs).
+    if (!FLAT) {
+        constexpr int cpr = BPX / 8;
+        for (int q = tid; q < mv * cpr; q += NT) {
+            const int row = q / cpr, c = q - row * cpr;
+            if (c * 8 >= ncols) continue;
+            const int m = m0 + row;
+            const bool second = m >= a.m1;
+            bf16_t* dst = (second ? a.y2 + ((int64_t)n0 * (M - a.m1) + (m - a.m1)) * HW : a.y1 + ((int64_t)n0 * a.m1 + m) * HW) + p0 + c * 8;
+            Vec<bf16_t, 8> v = *reinterpret_cast<const Vec<bf16_t, 8>*>(ot + row * OS + c * 8);
+            if ((a.accumulate >> (second ? 1 : 0)) & 1) {
+                const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(dst);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
+            }
+            stv<bf16_t, 8>(dst, v);
+        }
+    } else {
+        const int cpi_o = pers / 8;  // (one image's channel block is contiguous in y -- inside one slab -- and in LDS)
+        for (int q = tid; q < nimg * cpi_o; q += NT) {
+            const int img = q / cpi_o, c = q - img * cpi_o;
+            const int e0 = c * 8;                 // first element of the piece inside the block
+            const int m = m0 + e0 / HW;           // its channel decides the slab (pieces do not straddle m1)
+            const bool second = m >= a.m1;
+            bf16_t* blk = second ? a.y2 + ((int64_t)(n0 + img) * (M - a.m1) + (m0 - a.m1)) * HW
+                                 : a.y1 + ((int64_t)(n0 + img) * a.m1 + m0) * HW;
+            const bool accu = (a.accumulate >> (second ? 1 : 0)) & 1;
+            const bf16_t* src = ot + img * pers + e0;
+            if (e0 + 8 <= per) {
+                Vec<bf16_t, 8> v = *reinterpret_cast<const Vec<bf16_t, 8>*>(src);
+                if (accu) {
+                    const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(blk + e0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
+                }
+                stv<bf16_t, 8>(blk + e0, v);
+            } else {  // the block's last, partial piece (mv * HW % 8 != 0: only when mv is not a multiple of 8)
+                for (int e = e0; e < per; ++e) blk[e] = (bf16_t)(accu ? (float)src[e - e0] + (float)blk[e] : (float)src[e - e0]);
+            }
+        }
+    }
+}
+
+struct C1LdsArgs {
+    const bf16_t* x1;
+    const bf16_t* x2;  // second channel slab of the input (NULL: k1 == K)
+    const bf16_t* w;   // wpacked 0: [M][K] row-major; 1: K-step-major [K/32][M][32]; 2: the TRANSPOSE [K][M] row-major (WT kernels)
+    const bf16_t* bias;
+    bf16_t* y1;
+    bf16_t* y2;        // second channel slab of the output (NULL: m1 == M)
+    int k1, m1, N, K, M, HW;
+    int accumulate;    // bit 0: y1 += result, bit 1: y2 += result
+    int wpacked;
+    int mblocks;       // output-channel blocks of BM
+    int ptiles;        // pixel tiles per image (BIG) / image groups (FLAT)
+    int ni;            // FLAT: images per workgroup
+    int xcd_remap;
+};
+
+}  // namespace cot

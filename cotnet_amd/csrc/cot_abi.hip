@@ -128,6 +128,7 @@ extern int g_wgrad_lds_cap_pct;
 extern int g_bn_chan;
 // implemented in conv_lds.hip
 extern int g_conv_lds_tune[3];
+extern int g_conv_lds2_tune;
 static inline bool g_conv_lds_tune_wgrad_off() { return (g_conv_lds_tune[2] >> 2) & 1; }  // tuning key 17 bit 2 (A/B)
 bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
 int conv1x1_lds_gemm(const void*, const void*, int, const void*, int, const void*, void*, void*, int, int, int, int, int, int,
@@ -312,6 +313,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 22) {
         g_conv_tiny = value ? 1 : 0;
+        return COT_OK;
+    }
+    if (key == 23) {
+        g_conv_lds2_tune = value;
         return COT_OK;
     }
     if (key == 21) {

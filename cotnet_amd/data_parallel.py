@@ -176,6 +176,7 @@ class GradBucketReducer:
             torch._foreach_copy_(dst, src)
         for p in b.params:
             p.grad = None
+            grad_sink.release(p)
         b.fired.clear()
 
     def _view(self, b, param):
@@ -254,6 +255,7 @@ class GradBucketReducer:
             for b in self.buckets:
                 for p in b.params:
                     p.grad = None
+                    grad_sink.release(p)
             return
         for b in self.buckets:
             b.flat.zero_()
@@ -262,9 +264,21 @@ class GradBucketReducer:
                     p.grad = self._view(b, p)
 
     def remove(self):
+        """detach from the module: hooks off, gradient-sink entries dropped (they hold strong references to every parameter
+        and bucket view -- a reducer that is merely garbage-collected would keep its flat buffers alive on the GPU)"""
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self.grad_mode == "copy":
+            for b in self.buckets:
+                for p in b.params:
+                    grad_sink.unregister(p)
+
+    def __del__(self):
+        try:
+            self.remove()
+        except Exception:  # interpreter shutdown
+            pass
 
 
 def distribute_bn(module, process_group=None, reduce=True):

@@ -34,7 +34,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if _DEVICE_ONLY else None
 
 
-_WS = {}  # (N, C) -> workspace floats (pure function of the shape; avoids a library call per launch)
+_WS = _lib.register_cache({})  # (N, C) -> workspace floats (pure function of the shape; avoids a library call per launch)
 _DT = {torch.float32: _lib.COT_F32, torch.bfloat16: _lib.COT_BF16}
 
 

@@ -8,27 +8,46 @@ for a parameter the single-node layers (cot_layer_fused, head_fused, stem7x7) al
 pointer IS the parameter's slot in the bucket; the tensor returned to autograd is a fresh alias of that slot (so that
 AccumulateGrad adopts it instead of cloning), and the bucket fill recognises it and skips the copy.
 
-Only the FIRST gradient of a step may use the slot (`param.grad is None`); a second backward before zero_grad falls back
-to an ordinary tensor, which autograd then accumulates as usual.
+A slot is LENT at most once per step: `param.grad is None` alone does not say "first gradient", because AccumulateGrad
+sets `.grad` only after every producer of a backward pass has run -- a parameter used twice in one graph (a shared layer, a
+two-view loss, the model called twice before backward) would hand the same slot to both producers, the second kernel would
+overwrite the first, and autograd would add the two aliases: 2x the last gradient instead of the sum.  So the
+entry carries a `lent` flag, set by out_like() and cleared when the reducer has consumed the bucket (`release`, called
+from GradBucketReducer._fill / zero_grad); a second request in the same step gets an ordinary tensor, which autograd
+accumulates as usual.
 """
 import torch
 
-_SINK = {}  # id(param) -> (param, view into the flat gradient bucket)
+_SINK = {}  # id(param) -> [param, view into the flat gradient bucket, lent this step]
 
 
 def register(param, view):
-    _SINK[id(param)] = (param, view)
+    _SINK[id(param)] = [param, view, False]
+
+
+def unregister(param):
+    e = _SINK.get(id(param))
+    if e is not None and e[0] is param:
+        del _SINK[id(param)]
 
 
 def unregister_all():
     _SINK.clear()
 
 
+def release(param):
+    """the reducer is done with this step's gradient of `param`: its slot may be lent again"""
+    e = _SINK.get(id(param))
+    if e is not None and e[0] is param:
+        e[2] = False
+
+
 def out_like(param):
     """tensor for the gradient of `param`: an alias of its bucket slot when a sink is registered and this is the step's first
-    gradient for it, else a fresh tensor"""
+    request for it, else a fresh tensor"""
     e = _SINK.get(id(param))
-    if e is not None and e[0] is param and param.grad is None and e[1].dtype == param.dtype:
+    if e is not None and e[0] is param and not e[2] and param.grad is None and e[1].dtype == param.dtype:
+        e[2] = True
         return e[1].detach()  # new tensor object, same storage: autograd may adopt it
     return torch.empty_like(param)
 

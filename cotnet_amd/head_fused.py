@@ -19,7 +19,7 @@ from . import _lib, grad_sink
 MODE = os.environ.get("COT_HEAD", "")
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
 BF16 = _lib.COT_BF16
-_WS = {}
+_WS = _lib.register_cache({})
 
 
 def _p(t):

@@ -18,7 +18,7 @@ from . import _lib, grad_sink
 
 MODE = os.environ.get("COT_STEM", "")
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
-_WS = {}
+_WS = _lib.register_cache({})
 
 
 def _stream():

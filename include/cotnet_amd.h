@@ -133,7 +133,7 @@ const char* cot_last_kernel(void);
  *           a huge value = deep rings everywhere, 1 = shallow everywhere; <= 0 restores the default)
  *   key 15: LDS-pipelined convolution kernels (conv_lds.hip) on (1, default) / off (0: first-generation kernels)
  *   key 16: conv_lds FLAT mode: images per workgroup (0 = auto)
- *   key 17: conv_lds bit field -- bit 0 four-wave workgroups, bit 1 2-byte gathers instead of transposing LDS reads, bit 2 LDS
+ *   key 17: conv_lds bit field -- bit 0 (retired: four-wave workgroups), bit 1 2-byte gathers instead of transposing LDS reads, bit 2 LDS
  *           weight gradient off, bit 3 general LDS weight gradient everywhere, bit 4 its deep-layer rule off, bit 5 data
  *           gradient on a transposed weight copy instead of reading the weight in place, bits 8..: 7 x 7 stage channel-block
  *           rule (0 default, 1 off, n > 1 workgroup-count threshold)
@@ -142,7 +142,9 @@ const char* cot_last_kernel(void);
  *   key 20: the same for the LDS weight gradient (default 25 aligned planes / 100 general form)
  *   key 21: BatchNorm channel-resident kernels (1 default, 0 off, 256 / 512 / 1024 = forced workgroup size)
  *   key 22: one-image 1x1 convolutions on the staging-free kernels of conv_tiny.hip (1 default, 0 off)
- * Keys 11, 19, 20 change split counts: query cot_*_workspace after setting them. */
+ *   key 23: third-generation 1x1 forward / data-gradient kernel (conv_lds2.hip) bit field -- bit 0 off (second generation
+ *           instead), bit 1 no fragment prefetch in the small-image (FLAT) kernels, bit 2 fragment prefetch in the BIG kernels
+ * Keys 11, 15, 17 (bits 2-4), 19, 20 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* 0 if the device probe confirmed the DPP wave_shr/wave_shl semantics the v2 kernels rely on, 1 if the
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <initializer_list>
 #include <thread>
@@ -79,8 +80,16 @@ struct Sched {
     uint64_t slot[16][64];
     uint64_t wide[16][64][4];  // MFMA operands: [lane][0..1] = A fragment (8 bf16), [lane][2..3] = B fragment
     const std::function<void()>* body = nullptr;
+    // LDS-DMA copies issued and not yet waited for, per lane (g_dma_mode 1: a copy lands only when a counted wait retires it)
+    struct Copy { void* dst; const void* src; };
+    std::vector<std::deque<Copy>> pend;
 };
 inline int g_sched_order = 0;  // see run_block
+// 0: an LDS-DMA copy lands the moment it is issued (the EARLIEST legal time: exposes write-after-read hazards -- a stage
+//    re-filled while somebody may still read it);  1: it lands when the issuing lane's `s_waitcnt vmcnt(N)` retires it (the
+//    LATEST legal time: exposes read-after-write hazards -- a fragment read that the vmcnt arithmetic does not cover reads
+//    stale bytes).  Results must be identical under both.
+inline int g_dma_mode = 0;
 inline thread_local Sched* t_sched = nullptr;
 inline thread_local int t_lane = 0, t_wave = 0;
 
@@ -113,6 +122,8 @@ inline void lane_entry() {  // first frame of every coroutine
     Sched& S = *t_sched;
     (*S.body)();
     const int me = S.cur, w = me >> 6;
+    for (auto& c : S.pend[me]) std::memcpy(c.dst, c.src, 16);  // (s_endpgm: outstanding copies still land)
+    S.pend[me].clear();
     S.done[me] = 1;
     // a finished lane no longer takes part in barriers; release anybody who was only waiting for it
     if (--S.live_wave[w] > 0 && S.wave_arrived[w] >= S.live_wave[w]) { S.wave_arrived[w] = 0; ++S.wave_gen[w]; }
@@ -219,6 +230,7 @@ inline void run_block(Sched& S, unsigned bx, unsigned by, unsigned block_threads
     S.nthreads = n;
     S.lane_sp.assign(n, nullptr);
     S.done.assign(n, 0);
+    S.pend.assign(n, {});
     if (S.stacks.size() < (size_t)n * kStack) S.stacks.resize((size_t)n * kStack);
     S.live_block = n;
     S.block_arrived = 0;
@@ -285,6 +297,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 }  // namespace emul
 
 extern "C" __attribute__((weak)) void emul_set_order(int order) { emul::g_sched_order = order; }
+extern "C" __attribute__((weak)) void emul_set_dma_mode(int mode) { emul::g_dma_mode = mode; }
 inline void __syncthreads() { emul::block_barrier(); }
 // dynamic LDS: `extern __shared__ ... char cot_smem[]` in a kernel refers to this array
 #define __shared__ thread_local  // one workgroup at a time per OS thread
@@ -293,10 +306,29 @@ namespace cot { alignas(16) inline thread_local char cot_smem[160 * 1024]; }  //
 #define COT_ASYNC_COPY16(gptr, lds_wave_base) \
     std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)
 
-// the hand-counted LDS-DMA pipeline primitives of conv_lds.hip: the copy lands at once, the waits are no-ops, the barrier
-// is the block barrier (so the emulation checks index arithmetic and barrier placement, not the vmcnt arithmetic)
-#define COT_GLDS16(gptr, lds_wave_base) \
-    std::memcpy((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr), 16)
+// the hand-counted LDS-DMA pipeline primitives of conv_lds*.hip: copies land at once (g_dma_mode 0) or when a counted wait of
+// the issuing lane retires them (g_dma_mode 1, which checks the vmcnt arithmetic); the barrier is the block barrier
+namespace emul {
+inline void dma16(void* dst, const void* src) {
+    if (g_dma_mode == 0) { std::memcpy(dst, src, 16); return; }
+    Sched& S = *t_sched;
+    S.pend[S.cur].push_back({dst, src});
+}
+inline void wait_vm(int n) {  // s_waitcnt vmcnt(n): the oldest copies complete until n are left
+    if (g_dma_mode == 0) return;
+    Sched& S = *t_sched;
+    auto& q = S.pend[S.cur];
+    while ((int)q.size() > n) {
+        std::memcpy(q.front().dst, q.front().src, 16);
+        q.pop_front();
+    }
+}
+}  // namespace emul
+#define COT_GLDS16(gptr, lds_wave_base) emul::dma16((char*)(lds_wave_base) + emul::t_lane * 16, (const void*)(gptr))
+// scalar-base form: LDS "addresses" are byte offsets into cot_smem
+#define COT_LDS_ADDR(p) ((unsigned)((const char*)(p) - (const char*)cot::cot_smem))
+#define COT_GLDS16S(sbase, voff, lds_addr) \
+    emul::dma16((char*)cot::cot_smem + (lds_addr) + emul::t_lane * 16, (const char*)(sbase) + (voff))
 // ds_read_b64_tr_b16 (mapping measured on the MI355X, scripts/ubench_trprobe.py): within each group of 16 lanes, lane Li
 // receives element (Li & 3) of the four lanes 4e + (Li >> 2), e = 0..3
 typedef __attribute__((ext_vector_type(4))) short emul_s16x4;
@@ -316,8 +348,9 @@ inline emul_s16x4 emul_read_tr16(const void* p) {
     return r;
 }
 #define COT_LDS_READ_TR16(p) emul_read_tr16((p))
-#define COT_WAIT_VM(N) ((void)0)
+#define COT_WAIT_VM(N) emul::wait_vm((N))
 #define COT_LDS_BARRIER() emul::block_barrier()
+#define COT_SCHED_FENCE() ((void)0)
 
 #define COT_MFMA_16X16X32_BF16(a, b, c) emul::mfma_16x16x32_bf16((a), (b), (c))
 #define COT_MFMA_16X16X4_F32(a, b, c) emul::mfma_16x16x4_f32((a), (b), (c))
@@ -357,3 +390,4 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy
 inline hipError_t hipDeviceSynchronize() { return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }

@@ -584,6 +584,23 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
     assert _EMUL.cot_set_tuning(11, 2048) == 0
 
 
+# (cot_set_tuning(17), cot_set_tuning(23), LDS-DMA landing mode of the emulator): key 17 bit 1 = 2-byte gathers instead of
+# transposing reads, 256 = 128-channel blocks even for few tiles; key 23 bit 0 = second-generation kernel (conv_lds.hip), bit 1
+# = no fragment prefetch in the FLAT kernels, bit 2 = fragment prefetch in the BIG kernels; landing mode 1 = a copy lands only
+# when the issuing lane's counted vmcnt wait retires it (checks the hand-counted waits), 0 = at once (checks re-fill hazards)
+_LDS_VARIANTS = [(0, 0, 0), (0, 0, 1), (2, 0, 1), (256, 0, 0), (0, 6, 0), (0, 6, 1), (2, 6, 1), (0, 1, 0), (0, 1, 1), (2, 1, 1)]
+
+
+@pytest.fixture
+def lds_variant(request):
+    k17, k23, dma = request.param
+    assert _EMUL.cot_set_tuning(17, k17) == 0 and _EMUL.cot_set_tuning(23, k23) == 0
+    _EMUL.emul_set_dma_mode(dma)
+    yield k17
+    _EMUL.emul_set_dma_mode(0)
+    assert _EMUL.cot_set_tuning(17, 0) == 0 and _EMUL.cot_set_tuning(23, 0) == 0
+
+
 @pytest.mark.parametrize("N,Ci,Co,H,W,c1,bias", [
     (2, 64, 32, 16, 24, 0, False),    # BIG: HW = 384 = 3 tiles of 128, M <= 32
     (1, 96, 200, 20, 20, 32, True),   # BIG: HW = 400 (partial last tile of 16 pixels), two slabs, two m-blocks (200 > 128)
@@ -593,12 +610,16 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
     (1, 64, 24, 1, 80, 0, True),      # FLAT: the se branch's "one image whose pixels are the batch" (80 columns)
     (5, 32, 16, 8, 8, 0, False),      # FLAT: HW = 64, four images per workgroup + one left over
     (2, 160, 72, 14, 14, 0, False),   # FLAT: five K steps (pipeline wraps), M = 72
+    (2, 512, 64, 14, 14, 256, False), # FLAT: 16 K steps (the steady-state loop of the six-stage ring), slab switch at step 8
+    (1, 256, 32, 16, 24, 0, True),    # BIG: 8 K steps (steady state of the three-stage ring)
+    (6, 320, 48, 7, 7, 0, False),     # FLAT 7 x 7: 10 K steps, 2-byte gathers, 48 of 64 channels, second image group partial
 ])
-@pytest.mark.parametrize("waves4", [0, 1, 2, 256])  # cot_set_tuning(17): bit 0 = 4-wave workgroups, bit 1 = 2-byte gathers instead of transposing reads; 256 = 128-channel blocks even for few tiles
-def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias, waves4):
-    """second-generation 1x1 kernels (csrc/conv_lds.hip): every case satisfies K % 32 == 0 so the LDS path is the one
-    that runs (cot_last_kernel is checked); forward, data gradient (through the transposed-weight workspace), the
-    accumulate flags of both output slabs, against torch in fp32 on the same bf16-rounded operands"""
+@pytest.mark.parametrize("lds_variant", _LDS_VARIANTS, indirect=True)
+def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias, lds_variant):
+    """LDS-pipelined 1x1 kernels (csrc/conv_lds2.hip, and conv_lds.hip behind cot_set_tuning(23) bit 0): every case satisfies
+    K % 32 == 0 so the LDS path is the one that runs; forward, data gradient, the accumulate flags of both output slabs,
+    against torch in fp32 on the same bf16-rounded operands"""
+    waves4 = lds_variant
     torch.manual_seed(11)
     HW = H * W
     x = torch.randn(N, Ci, H, W).bfloat16()
@@ -613,7 +634,7 @@ def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias, waves4):
     cc1 = c1 if split else Ci
     dt = _lib.dtype_code(torch.bfloat16)
     PN = lambda t: P(t) if t is not None else None
-    assert _EMUL.cot_set_tuning(15, 1) == 0 and _EMUL.cot_set_tuning(17, waves4) == 0  # 8- / 4-wave workgroups
+    assert _EMUL.cot_set_tuning(15, 1) == 0
     y = torch.full((N, Co, H, W), float("nan")).bfloat16()
     assert _EMUL.cot_conv1x1_forward(P(x1), PN(x2), cc1, P(w), PN(b), P(y), N, Ci, Co, HW, dt, None) == 0, _EMUL.cot_last_error()
     assert torch.allclose(y.float(), yref.detach(), atol=2e-2, rtol=2e-2), (y.float() - yref).abs().max()
@@ -640,7 +661,6 @@ def test_conv1x1_lds_kernels(N, Ci, Co, H, W, c1, bias, waves4):
         assert torch.allclose(a1.float(), want1, atol=5e-2, rtol=2e-2)
         if split:
             assert torch.allclose(a2.float(), base2.float() + xf.grad[:, cc1:], atol=5e-2, rtol=2e-2)
-    assert _EMUL.cot_set_tuning(17, 0) == 0
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 16, 16), (3, 3, 7, 9), (1, 4, 32, 32)])
@@ -1832,12 +1852,13 @@ def test_split_attn_radix1_and_blurpool_modules_on_emulated_kernels(monkeypatch)
     (1, 512, 160, 1, 80, 0),     # the se branch's shape (one "image" of 80 pixels), four channel blocks, five K steps
     (3, 128, 256, 16, 16, 0),    # BIG / FLAT border (H*W = 256), eight K steps: the six-stage ring wraps
 ])
-@pytest.mark.parametrize("waves4", [0, 1, 256])
-def test_conv1x1_lds_data_gradient_reads_the_weight_in_place(N, Ci, Co, H, W, c1, waves4):
+@pytest.mark.parametrize("lds_variant", [(0, 0, 0), (0, 0, 1), (256, 0, 1), (0, 6, 1), (0, 1, 1)], indirect=True)
+def test_conv1x1_lds_data_gradient_reads_the_weight_in_place(N, Ci, Co, H, W, c1, lds_variant):
     """cot_conv1x1_backward_data on the LDS kernels with the [Co][Ci] weight tensor read in place as the transposed operand
     (WT kernels: transposing LDS reads, chunk-permuted rows) must equal -- bit for bit: same products, same order -- the
     form that multiplies a transposed copy (cot_set_tuning(17) bit 5), and both the fp32 reference"""
     torch.manual_seed(17)
+    waves4 = lds_variant
     HW, dt = H * W, _lib.dtype_code(torch.bfloat16)
     w = (torch.randn(Co, Ci) / Co ** 0.5).bfloat16()
     gy = torch.randn(N, Co, H, W).bfloat16()
