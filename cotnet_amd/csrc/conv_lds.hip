@@ -822,7 +822,7 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int 
     a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.w = (const bf16_t*)w; a.bias = (const bf16_t*)bias;
     a.y1 = (bf16_t*)y1; a.y2 = (bf16_t*)y2;
     a.k1 = x2 ? k1 : K; a.m1 = y2 ? m1 : M; a.N = N; a.K = K; a.M = M; a.HW = HW; a.accumulate = accumulate;
-    a.ni = 1; a.xcd_remap = 0; a.wpacked = wpacked;
+    a.ni = 1; a.xcd_remap = 0; a.wpacked = wpacked; a.ablate = 0;
     const int u16 = (g_conv_lds_tune[2] >> 1) & 1;  // tuning key 17 bit 1: 2-byte gathers everywhere (A/B; default: transposing reads)
     const bool wt = wpacked == 2;
     if (wt && (M % 8 != 0 || M < 8)) return -1;

@@ -30,6 +30,7 @@ extern int g_conv_lds_tune[3];
 // off in the FLAT kernels (default on); bit 2 = fragment prefetch on in the BIG kernels (default off: it costs registers, i.e.
 // workgroups per CU, where the layers are bandwidth-bound)
 int g_conv_lds2_tune = 0;
+int g_conv_ablate = 0;  // cot_set_tuning key 24 (diagnostic: see C1LdsArgs::ablate)
 
 // template parameters as conv1x1_lds_fwd (conv_lds.hip); PF = fragment prefetch (register double buffer)
 template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD, int WT, int PF>
@@ -50,15 +51,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
 
     unsigned b = blockIdx.x;
     if (a.xcd_remap && (gridDim.x & 7u) == 0) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
-    const int mb = b % a.mblocks;  // consecutive (same-XCD) workgroups share the X tile
-    const int t = b / a.mblocks;
+    // (integer divisions are expanded into vector code: the explicit readfirstlanes keep what derives from them scalar)
+    const int mb = uniform((int)(b % (unsigned)a.mblocks));  // consecutive (same-XCD) workgroups share the X tile
+    const int t = uniform((int)(b / (unsigned)a.mblocks));
     int n0, p0, ncols;  // first image, first pixel, valid columns of this tile
     if (FLAT) {
         n0 = t * a.ni;
         p0 = 0;
         ncols = min(a.ni, a.N - n0) * HW;
     } else {
-        n0 = t / a.ptiles;
+        n0 = uniform(t / a.ptiles);
         p0 = (t - n0 * a.ptiles) * BPX;
         ncols = min(BPX, HW - p0);
     }
@@ -193,7 +195,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             }
         }
     };
+    const int abl = a.ablate;  // (diagnostic switches, all zero in production: scalar branches)
     auto multiply = [&](const bf16x8_t (&af)[CB], const bf16x8_t (&bfr)[MB]) __attribute__((always_inline)) {
+        if (abl & 4) {
+            acc[0][0] = COT_MFMA_16X16X32_BF16(af[0], bfr[0], acc[0][0]);
+            return;
+        }
 #pragma unroll
         for (int mbk = 0; mbk < MB; ++mbk)
 #pragma unroll
@@ -215,18 +222,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
         COT_LDS_BARRIER();
         bf16x8_t a0[CB], b0[MB], a1[CB], b1[MB];
         read_frags(0, a0, b0);
+        if (abl & 2) read_frags(0, a1, b1);
         int slot = 0;  // ring slot of step ks
         // STEADY: ks + NS < nk is known (full wait count, the re-fill always happens): the loop body carries no conditions
         auto step = [&](auto steady, int ks, const bf16x8_t (&ac)[CB], const bf16x8_t (&bc)[MB], bf16x8_t (&an)[CB],
                         bf16x8_t (&bn)[MB]) __attribute__((always_inline)) {
             constexpr bool STEADY = decltype(steady)::value;
             if (STEADY || ks + 1 < nk) {
-                if (STEADY) COT_WAIT_VM((NS - 2) * G);
-                else WaitBehind<G, NS - 2>::go(min(NS - 2, nk - 2 - ks));
-                COT_LDS_BARRIER();
-                if (STEADY || ks + NS < nk) stage(ks + NS, slot);
+                if (!(abl & 16)) {
+                    if (STEADY) COT_WAIT_VM((NS - 2) * G);
+                    else WaitBehind<G, NS - 2>::go(min(NS - 2, nk - 2 - ks));
+                }
+                if (!(abl & 8)) COT_LDS_BARRIER();
+                if ((STEADY || ks + NS < nk) && !(abl & 1)) stage(ks + NS, slot);
                 slot = slot + 1 == NS ? 0 : slot + 1;
-                read_frags(slot, an, bn);
+                if (!(abl & 2)) read_frags(slot, an, bn);
                 COT_SCHED_FENCE();  // the reads are in flight BEFORE the multiplies start (they hide the LDS round trip)
             }
             multiply(ac, bc);
@@ -247,12 +257,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             if (s0 < nk) stage(s0, s0);
         int slot = 0, fill = NS - 1;  // slot of step ks; slot the next stage goes to
         for (int ks = 0; ks < nk; ++ks) {
-            WaitBehind<G, NS - 2>::go(min(NS - 2, nk - 1 - ks));  // this wave's copies of stage ks have landed
-            COT_LDS_BARRIER();                                // everybody's have; nobody still reads stage ks-1's slot
-            if (ks + NS - 1 < nk) stage(ks + NS - 1, fill);
+            if (!(abl & 16)) WaitBehind<G, NS - 2>::go(min(NS - 2, nk - 1 - ks));  // this wave's copies of stage ks have landed
+            if (!(abl & 8)) COT_LDS_BARRIER();                // everybody's have; nobody still reads stage ks-1's slot
+            if (ks + NS - 1 < nk && !(abl & 1)) stage(ks + NS - 1, fill);
             fill = fill + 1 == NS ? 0 : fill + 1;
             bf16x8_t af[CB], bfr[MB];
-            read_frags(slot, af, bfr);
+            read_frags((abl & 2) ? 0 : slot, af, bfr);
             slot = slot + 1 == NS ? 0 : slot + 1;
             multiply(af, bfr);
         }
@@ -285,6 +295,7 @@ static int launch_c1v2(const C1LdsArgs& a, int tiles, hipStream_t stream) {
 // same contract and dispatch rules as conv1x1_lds_gemm (conv_lds.hip), which calls this unless tuning key 23 bit 0 is set
 int conv1x1_lds_gemm2(const C1LdsArgs& a0, hipStream_t stream) {
     C1LdsArgs a = a0;
+    a.ablate = g_conv_ablate;
     const int N = a.N, M = a.M, HW = a.HW;
     // per-lane offsets are 32-bit: a workgroup's images / the weight rows must lie within 2 GB of the scalar bases
     const int64_t slab = (int64_t)std::max(a.k1, a.K - a.k1) * HW * 2;

@@ -81,6 +81,22 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #endif
 
+// DIAGNOSTIC time stamps (cot_debug_stamps): lane 0 of wave 0 stores s_memtime into slot `i` of its workgroup's record
+// (8 x 8 bytes per workgroup; slot 7 = XCC id).  `p` is NULL in production: one scalar test per stamp.
+#ifndef COT_STAMP
+#define COT_STAMP(p, i)                                                                                    \
+    do {                                                                                                   \
+        if ((p) && threadIdx.x == 0) {                                                                     \
+            (p)[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();                              \
+            if ((i) == 0) {                                                                                \
+                unsigned xcc_;                                                                             \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                        \
+                (p)[(size_t)blockIdx.x * 8 + 7] = xcc_ & 15u;                                              \
+            }                                                                                              \
+        }                                                                                                  \
+    } while (0)
+#endif
+
 // `ahead` stages (G copies each, per wave) were issued after the one about to be read: leave exactly those in flight
 template <int G, int A> struct WaitBehind {
     static __device__ __forceinline__ void go(int ahead) {
@@ -206,6 +222,8 @@ struct C1LdsArgs {
     int ptiles;        // pixel tiles per image (BIG) / image groups (FLAT)
     int ni;            // FLAT: images per workgroup
     int xcd_remap;
+    int ablate;        // DIAGNOSTIC (cot_set_tuning key 24; results become wrong): bit 0 no copies after the prologue, bit 1 no
+                       // fragment reads in the loop, bit 2 one MFMA per step, bit 3 no barriers, bit 4 no vmcnt waits
 };
 
 }  // namespace cot

@@ -1,0 +1,439 @@
+// conv_wgrad2.hip -- 1x1 weight gradient, third generation (the weight gradients of
+// models/cotnet.py:51-62 embed / conv1x1 and :206-224 Bottleneck conv1 / conv3):
+//     dW[m][j] = sum over (n, p) of dY[n][m][p] * X[n][j][p]      (+ db[m] = sum dY)
+// Both operands are contiguous along the reduction index (pixels), so both MFMA fragments are 16-byte LDS reads.  What the
+// second generation (conv_lds.hip conv1x1_wgrad_lds<GEN>) spent its time on was not the product: every K step re-derived
+// each thread's (image, pixel) position with vector arithmetic, ran divergent tensor-end checks per copy, and its one tile
+// shape (128 x 128) left half of the rows of a 64-channel layer empty (profiles/r02_conv_abi.log: 3-10 % of the HBM
+// roofline on the 14 x 14 / 7 x 7 layers, 20-40 % at 56 x 56).  Here
+//   * the reduction runs per image in steps of 32 pixels; a copy is `global_load_lds_dwordx4 voff, s[base]`
+//     (conv_lds_common.h glds16_s): per-lane offsets are loop constants -- one set for ordinary steps, one for the last step
+//     of an image -- and the K step moves scalar pointers only;
+//   * a plane that is not a multiple of 8 / 32 pixels needs no tensor-end special case: the chunk that would run over the
+//     row's end is read 8 pixels ENDING at the row's end instead (always inside the row), the pixels it then repeats -- and
+//     the chunks entirely past the row -- are removed by SELECTION from the dY fragment (the same row's own data, so a
+//     non-finite value there is one the true sum contains anyway); both operands shift alike, so the k pairing holds;
+//   * tile shapes follow the layer: 128 x 128, 64 x 256, 256 x 64, 64 x 64, 32 x 128 (dY rows x X rows), 8 waves each;
+//   * the 16-byte chunks of a row are stored permuted by pos = chunk ^ ((-(row >> 2)) & 3): the four 16-lane groups a
+//     ds_read_b128 is served in ({0-3,12-15,20-27}, ... -- MI355X_MICROARCH.md) then touch 16 different slots (the old
+//     permutation chunk ^ ((row >> 2) & 3) was 2-way conflicting: measured 0.5 conflict cycles per LDS cycle);
+//   * MFMA roles: A = X rows, B = dY rows, so a lane ends up with FOUR CONSECUTIVE j of one dW row: 16-byte stores of the
+//     fp32 partial sums (8-byte stores of bf16 when the launch is not split).
+// Slices of the reduction are summed by the deterministic reduce kernel of conv1x1.hip (no atomics).
+#include <algorithm>
+
+#include "cot_common.h"
+#include "mfma_common.h"
+#include "conv_lds_common.h"
+
+namespace cot {
+
+// cot_set_tuning key 25: bit 0 = off (second-generation kernels instead); bit 1 = fragment prefetch on; bit 2 = the old
+// chunk permutation (A/B of the bank-conflict fix); bits 8..15 = partial-sum cap in percent of the input bytes (0 = 100);
+// bits 16..23 = target workgroups per CU x 4 (0 = 4, i.e. one); bits 24..30 = forced slice count (tests)
+int g_wgrad2_tune = 0;
+extern int g_conv_ablate;
+extern unsigned long long* g_debug_stamps;
+
+struct Wg2Args {
+    const bf16_t* gy;
+    const bf16_t* x1;
+    const bf16_t* x2;
+    float* part;   // [S][M][Jp] partial sums (S > 1)
+    bf16_t* gw;    // [M][J]   (S == 1: written directly)
+    bf16_t* gb;    // [M] or NULL
+    int k1, N, M, J, HW, has_bias, S, jtiles, mtiles, T;
+    int spi;       // K steps per image = ceil(cpi / 4)
+    int cpi;       // 8-pixel chunks per image = ceil(HW / 8)
+    int oldswz;
+    int xcd_remap;
+    int ablate;    // DIAGNOSTIC (cot_set_tuning key 24; results become wrong): see C1LdsArgs::ablate
+    unsigned long long* stamps;  // DIAGNOSTIC (cot_debug_stamps): per workgroup 6 x s_memtime (start, set up, first data, loop done,
+                                 // stores issued, end) + the XCC id; NULL in production
+};
+
+template <int WM, int AM, int AJ, int NS, int PF>
+__global__ __launch_bounds__(512, 4) void conv1x1_wgrad_lds2(const Wg2Args a) {  // (<= 128 registers: two workgroups per CU)
+    constexpr int WJ = 8 / WM, TM = WM * AM * 16, TJ = WJ * AJ * 16;
+    constexpr int RBM = TM / 16, RBJ = TJ / 16, RB = RBM + RBJ;  // 16-row blocks of the dY / X parts of a stage
+    constexpr int G = (RB + 7) / 8;                               // copies per wave and stage
+    constexpr int STG = RB * 512;                                 // elements per stage ([RB * 16 rows][32 pixels])
+    static_assert((NS - 1) * G <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    bf16_t* const sm = reinterpret_cast<bf16_t*>(cot_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), i16 = lane & 15, g = lane >> 4;
+    COT_STAMP(a.stamps, 0);
+    const int wm = wave / WJ, wj = wave % WJ;
+    const int HW = a.HW, M = a.M, J = a.J, Jp = J + (a.has_bias ? 1 : 0);
+    const int spi = a.spi, cpi = a.cpi, rem = HW & 7;
+    unsigned b = blockIdx.x;
+    if (a.xcd_remap && (gridDim.x & 7u) == 0) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
+    // (integer divisions are expanded into VECTOR code; without the explicit readfirstlanes everything derived from them --
+    // the copies' base pointers, the loop counters, the branch conditions -- ends up in VGPRs / under exec masks)
+    const int jt = uniform((int)(b % (unsigned)a.jtiles));
+    const int rest = uniform((int)(b / (unsigned)a.jtiles));
+    const int mt = uniform(rest % a.mtiles), sl = uniform(rest / a.mtiles);
+    const int m0 = mt * TM, j0 = jt * TJ;
+    const int t0 = uniform((int)((unsigned)a.T * (unsigned)sl / (unsigned)a.S));  // (T * S < 2^31: checked on the host)
+    const int t1 = uniform((int)((unsigned)a.T * (unsigned)(sl + 1) / (unsigned)a.S));
+    const int nst = t1 - t0;
+    auto f = [&](int row) { return a.oldswz ? ((row >> 2) & 3) : ((-(row >> 2)) & 3); };
+
+    // ---- this wave's copies: 16-row block rb = wave + 8 i (blocks past the stage: block RB-1 again, same bytes to the same place)
+    unsigned voff[G], voffl[G];   // per-lane byte offsets: ordinary steps (base = image row + step), last step of an image (base = image row)
+    const bf16_t* img[G];         // scalar: row r0 of the copy's block in the image being staged
+    int64_t istr[G];              // scalar: elements from one image to the next in that tensor
+    unsigned ldst[G];             // scalar: byte offset of the block inside a stage
+    const int n_first = uniform(t0 / spi);
+    int s_s = t0 - n_first * spi;  // step inside the image of the NEXT stage to issue
+    {
+        const int n_s = n_first;
+        const int rowl = lane >> 2, pos = lane & 3;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int rb = min(wave + 8 * i, RB - 1);
+            const int ch = pos ^ f(rb * 16 + rowl);  // the 8-pixel chunk of the step this lane fetches
+            int r0, r;
+            const bf16_t* base;
+            int64_t stride;
+            if (rb < RBM) {
+                const int rr = m0 + rb * 16;
+                r0 = min(rr, M - 1);
+                r = min(rr + rowl, M - 1);  // rows past the matrix: copies of the last row, never stored
+                base = a.gy + (int64_t)r0 * HW;
+                stride = (int64_t)M * HW;
+            } else {
+                const int rr = j0 + (rb - RBM) * 16;
+                r0 = min(rr, J - 1);
+                r = min(rr + rowl, J - 1);  // (the bias column's "row" J is made of ones at fragment level)
+                const bool second = a.x2 && r0 >= a.k1;  // k1 % 16 == 0 (host): a block lies in one slab
+                base = second ? a.x2 + (int64_t)(r0 - a.k1) * HW : a.x1 + (int64_t)r0 * HW;
+                stride = (int64_t)(second ? J - a.k1 : (a.x2 ? a.k1 : J)) * HW;
+            }
+            img[i] = base + n_s * stride;
+            istr[i] = stride;
+            ldst[i] = (unsigned)(rb * 1024);
+            voff[i] = (unsigned)((r - r0) * HW + ch * 8) * 2u;
+            const int c = 4 * (spi - 1) + ch;  // chunk index inside the image in its last step
+            const int pl = (c < cpi - 1 || (c == cpi - 1 && rem == 0)) ? c * 8 : HW - 8;
+            voffl[i] = (unsigned)((r - r0) * HW + pl) * 2u;
+        }
+    }
+    const unsigned lds0 = COT_LDS_ADDR(sm);
+    auto stage = [&](int slot) __attribute__((always_inline)) {
+        const bool last = s_s == spi - 1;
+        const unsigned d = lds0 + (unsigned)(slot * STG * 2);
+#pragma unroll
+        for (int i = 0; i < G; ++i) COT_GLDS16S(last ? img[i] : img[i] + s_s * 32, last ? voffl[i] : voff[i], d + ldst[i]);
+        if (last) {
+            s_s = 0;
+#pragma unroll
+            for (int i = 0; i < G; ++i) img[i] += istr[i];
+        } else {
+            ++s_s;
+        }
+    };
+
+    // ---- fragments: row i16 of a 16-row block, k chunk g (at its permuted position)
+    int yoff[AM], xoff[AJ];
+    bool ones[AJ];
+#pragma unroll
+    for (int q = 0; q < AM; ++q) {
+        const int row = (wm * AM + q) * 16 + i16;
+        yoff[q] = row * 32 + ((g ^ f(row)) & 3) * 8;
+    }
+#pragma unroll
+    for (int u = 0; u < AJ; ++u) {
+        const int row = RBM * 16 + (wj * AJ + u) * 16 + i16;
+        xoff[u] = row * 32 + ((g ^ f(row)) & 3) * 8;
+        ones[u] = a.has_bias && j0 + (wj * AJ + u) * 16 + i16 == J;  // the bias gradient rides along as an X row of ones
+    }
+    // the last step of an image: lane group g holds chunk c = 4 (spi-1) + g; elements below `lo` repeat earlier pixels (the
+    // chunk was read ending at the row's end) or lie past the row altogether: cleared in the dY fragments
+    uint32_t mk[4];
+    {
+        const int c = 4 * (spi - 1) + g;
+        const int lo = (c < cpi - 1 || (c == cpi - 1 && rem == 0)) ? 0 : (c == cpi - 1 ? 8 - rem : 8);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) mk[d] = (2 * d >= lo ? 0x0000ffffu : 0u) | (2 * d + 1 >= lo ? 0xffff0000u : 0u);
+    }
+    const bool tails = (HW & 31) != 0;  // (else every chunk of the last step is whole: nothing to clear)
+    int s_c = t0 - n_first * spi;       // step inside the image of the stage being READ next
+
+    f32x4_t acc[AJ][AM];
+#pragma unroll
+    for (int u = 0; u < AJ; ++u)
+#pragma unroll
+        for (int q = 0; q < AM; ++q) acc[u][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto read_frags = [&](int slot, uint32_t (&yq)[AM][4], uint32_t (&xq)[AJ][4]) __attribute__((always_inline)) {
+        const bf16_t* sb = sm + slot * STG;
+        const bool lastc = tails && s_c == spi - 1;
+        s_c = s_c + 1 == spi ? 0 : s_c + 1;
+#pragma unroll
+        for (int u = 0; u < AJ; ++u) {
+            __builtin_memcpy(xq[u], __builtin_assume_aligned(sb + xoff[u], 16), 16);
+            if (a.has_bias && ones[u]) {  // (scalar test first: layers without a bias skip the selects)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xq[u][e] = 0x3f803f80u;  // bf16 1.0 twice (dY's tail mask keeps the sum right)
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < AM; ++q) {
+            __builtin_memcpy(yq[q], __builtin_assume_aligned(sb + yoff[q], 16), 16);
+            if (lastc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yq[q][e] &= mk[e];
+            }
+        }
+    };
+    const int abl = a.ablate;
+    auto multiply = [&](const uint32_t (&yq)[AM][4], const uint32_t (&xq)[AJ][4]) __attribute__((always_inline)) {
+        if (abl & 4) {
+            acc[0][0] = COT_MFMA_16X16X32_BF16(packed_as_frag(xq[0]), packed_as_frag(yq[0]), acc[0][0]);
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < AJ; ++u)
+#pragma unroll
+            for (int q = 0; q < AM; ++q) acc[u][q] = COT_MFMA_16X16X32_BF16(packed_as_frag(xq[u]), packed_as_frag(yq[q]), acc[u][q]);
+    };
+
+    COT_STAMP(a.stamps, 1);
+    if (PF) {  // (pipeline structure and vmcnt arithmetic as conv_lds2.hip conv1x1_lds_fwd2)
+#pragma unroll
+        for (int s0 = 0; s0 < NS; ++s0)
+            if (s0 < nst) stage(s0);
+        WaitBehind<G, NS - 1>::go(min(NS - 1, nst - 1));
+        COT_LDS_BARRIER();
+        uint32_t y0[AM][4], x0[AJ][4], y1[AM][4], x1[AJ][4];
+        read_frags(0, y0, x0);
+        int slot = 0;
+        auto step = [&](auto steady, int ks, const uint32_t (&yc)[AM][4], const uint32_t (&xc)[AJ][4], uint32_t (&yn)[AM][4],
+                        uint32_t (&xn)[AJ][4]) __attribute__((always_inline)) {
+            constexpr bool STEADY = decltype(steady)::value;
+            if (STEADY || ks + 1 < nst) {
+                if (STEADY) COT_WAIT_VM((NS - 2) * G);
+                else WaitBehind<G, NS - 2>::go(min(NS - 2, nst - 2 - ks));
+                COT_LDS_BARRIER();
+                if (STEADY || ks + NS < nst) stage(slot);
+                slot = slot + 1 == NS ? 0 : slot + 1;
+                read_frags(slot, yn, xn);
+                COT_SCHED_FENCE();
+            }
+            multiply(yc, xc);
+            COT_SCHED_FENCE();
+        };
+        int ks = 0;
+        for (; ks + 1 + NS < nst; ks += 2) {
+            step(std::true_type{}, ks, y0, x0, y1, x1);
+            step(std::true_type{}, ks + 1, y1, x1, y0, x0);
+        }
+        for (; ks < nst; ks += 2) {
+            step(std::false_type{}, ks, y0, x0, y1, x1);
+            if (ks + 1 < nst) step(std::false_type{}, ks + 1, y1, x1, y0, x0);
+        }
+    } else {
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+            if (s0 < nst) stage(s0);
+        int slot = 0, fill = NS - 1;
+        auto step = [&](auto steady, int ks) __attribute__((always_inline)) {
+            constexpr bool STEADY = decltype(steady)::value;
+            if (!(abl & 16)) {
+                if (STEADY) COT_WAIT_VM((NS - 2) * G);
+                else WaitBehind<G, NS - 2>::go(min(NS - 2, nst - 1 - ks));  // this wave's copies of stage ks have landed
+            }
+            if (!(abl & 8)) COT_LDS_BARRIER();                     // everybody's have; nobody still reads stage ks-1's slot
+            if ((STEADY || ks + NS - 1 < nst) && !(abl & 1)) stage(fill);
+            fill = fill + 1 == NS ? 0 : fill + 1;
+            uint32_t yq[AM][4], xq[AJ][4];
+            read_frags((abl & 2) ? 0 : slot, yq, xq);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            multiply(yq, xq);
+        };
+        int ks = 0;
+        if (nst > NS) {  // (the first step apart, so that the arrival of the first data can be stamped)
+            step(std::true_type{}, 0);
+            ks = 1;
+            COT_STAMP(a.stamps, 2);
+        }
+        for (; ks + NS - 1 < nst; ++ks) step(std::true_type{}, ks);
+        for (; ks < nst; ++ks) step(std::false_type{}, ks);
+    }
+    COT_STAMP(a.stamps, 3);
+
+    // ---- D[i = X row j][col = dY row m]: lane holds j = jb + 4g .. 4g+3 of dW row m = mb + i16
+    float* const ps = a.part + (int64_t)sl * M * Jp;
+    const bool vec = (Jp & 3) == 0;  // rows of the output start on 16-byte (fp32) / 8-byte (bf16) boundaries
+#pragma unroll
+    for (int q = 0; q < AM; ++q) {
+        const int m = m0 + (wm * AM + q) * 16 + i16;
+        if (m >= M) continue;
+#pragma unroll
+        for (int u = 0; u < AJ; ++u) {
+            const int jj = j0 + (wj * AJ + u) * 16 + 4 * g;
+            if (jj >= Jp) continue;
+            if (a.S > 1) {
+                float* p = ps + (int64_t)m * Jp + jj;
+                if (vec) {
+                    *reinterpret_cast<f32x4_t*>(__builtin_assume_aligned(p, 16)) = acc[u][q];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (jj + r < Jp) p[r] = acc[u][q][r];
+                }
+            } else if (vec) {  // (no bias: Jp == J)
+                Vec<bf16_t, 4> o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.v[r] = (bf16_t)acc[u][q][r];
+                stv<bf16_t, 4>(a.gw + (int64_t)m * J + jj, o);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (jj + r < J) a.gw[(int64_t)m * J + jj + r] = (bf16_t)acc[u][q][r];
+                    else if (jj + r == J && a.has_bias) a.gb[m] = (bf16_t)acc[u][q][r];
+                }
+            }
+        }
+    }
+    COT_STAMP(a.stamps, 4);
+    if (a.stamps) {
+        COT_WAIT_VM(0);
+        COT_STAMP(a.stamps, 5);
+    }
+}
+
+// tile shape for a layer: 0 = 128 x 128, 1 = 64 x 256, 2 = 256 x 64, 3 = 64 x 64, 4 = 32 x 128   (dY rows x X rows)
+static inline int wgrad2_shape(int M, int Jp, int* TM, int* TJ) {
+    int s;
+    if (M <= 32 && Jp > 64) s = 4;
+    else if (M <= 64) s = Jp <= 64 ? 3 : 1;
+    else if (Jp <= 64) s = 2;
+    else s = 0;
+    static const int tm[5] = {128, 64, 256, 64, 32}, tj[5] = {128, 256, 64, 64, 128};
+    *TM = tm[s];
+    *TJ = tj[s];
+    return s;
+}
+
+bool conv1x1_wgrad2_covers(int N, int HW, int M, int J, int k1, bool two_slabs) {
+    if (g_wgrad2_tune & 1) return false;
+    if (HW < 8 || (two_slabs && k1 % 16 != 0)) return false;
+    if ((int64_t)N * ceil_div(ceil_div(HW, 8), 4) * 1025 >= ((int64_t)1 << 31)) return false;  // (32-bit slice arithmetic in the kernel)
+    // per-lane offsets are 32-bit and relative to an image row: 16 rows of a plane must lie within 2 GB (they always do)
+    return (int64_t)HW * 16 * 2 < ((int64_t)1 << 30) && N > 0 && M > 0 && J > 0;
+}
+
+// number of slices of the reduction (also sizes the workspace)
+int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias) {
+    const int Jp = J + (has_bias ? 1 : 0);
+    int TM, TJ;
+    wgrad2_shape(M, Jp, &TM, &TJ);
+    const int64_t tiles = (int64_t)ceil_div(M, TM) * ceil_div(Jp, TJ);
+    const int cpi = ceil_div(HW, 8), spi = ceil_div(cpi, 4);
+    const int64_t T = (int64_t)N * spi;
+    const int force = (g_wgrad2_tune >> 24) & 127;  // (tests: bits 24..30 force the slice count)
+    if (force) return (int)std::min<int64_t>(force, T);
+    const int per_cu4 = (g_wgrad2_tune >> 16) & 255;
+    // ONE workgroup per CU: measured on the MI355X over all CoTNet-50 layers (profiles/r03_wgrad_policy_ab.log, us per step):
+    // two per CU / partial sums <= 50 % of the inputs 2475, one per CU 2250, one per CU and <= 100 % 2121 (second
+    // generation: 2747) -- every extra slice is another M x J fp32 matrix written and read again
+    int64_t S = ceil_div64((int64_t)64 * (per_cu4 > 0 ? per_cu4 : 4), tiles);
+    const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
+    const int pct = (g_wgrad2_tune >> 8) & 255;
+    const int64_t cap = in_bytes * (pct > 0 ? pct : 100) / 100 / out_bytes;  // partial sums are written once and read once
+    if (S > cap) S = cap;
+    if (S > T / 8) S = T / 8;
+    if (S > 1024) S = 1024;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+int conv1x1_wgrad_reduce_launch(const float* part, int S, int M, int J, int has_bias, void* gw, void* gb, hipStream_t stream);
+
+// Sum of a FEW slices of a LARGE matrix (the deep layers: 0.26 .. 1 M outputs, 2 .. 16 slices).  The reduce kernel of
+// conv1x1.hip gives a workgroup 32 outputs and spreads the slices over its 8 lane groups -- right for the small matrices of
+// the first stages with their hundreds of slices, but here it is 32768 workgroups moving 128 bytes per slice each: 42 of the
+// 57 us of the 2048 -> 512 @7x7 weight gradient were spent outside the GEMM (profiles/r03_wgrad_ablate.log).  This one gives
+// every lane four consecutive outputs: 16-byte loads per slice, one 8-byte bf16 store.  (no bias column: [M][J] is flat)
+__global__ __launch_bounds__(256) void wgrad_reduce_wide(const float* __restrict__ part, int S, int64_t tot4,
+                                                        bf16_t* __restrict__ gw) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= tot4) return;
+    const f32x4_t* p = reinterpret_cast<const f32x4_t*>(part) + e;
+    f32x4_t s0 = p[0], s1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int sl = 1;
+    for (; sl + 1 < S; sl += 2) {
+        s0 += p[(int64_t)sl * tot4];
+        s1 += p[(int64_t)(sl + 1) * tot4];
+    }
+    if (sl < S) s0 += p[(int64_t)sl * tot4];
+    s0 += s1;
+    Vec<bf16_t, 4> o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.v[r] = (bf16_t)s0[r];
+    stv<bf16_t, 4>(gw + e * 4, o);
+}
+
+static int wgrad2_reduce(const float* part, int S, int M, int J, int has_bias, void* gw, void* gb, hipStream_t stream) {
+    const int64_t tot = (int64_t)M * J;
+    if (!has_bias && (J & 3) == 0 && S <= 64 && tot >= 32768 && !((g_wgrad2_tune >> 4) & 1)) {  // (bit 4: always the general kernel, A/B)
+        COT_LAUNCH(wgrad_reduce_wide, dim3((unsigned)ceil_div64(tot / 4, 256)), dim3(256), 0, stream, part, S, tot / 4, (bf16_t*)gw);
+        return check_launch("wgrad_reduce_wide");
+    }
+    return conv1x1_wgrad_reduce_launch(part, S, M, J, has_bias, gw, gb, stream);
+}
+
+template <int WM, int AM, int AJ, int PF, int NS>
+static int launch_wg2(const Wg2Args& a, int64_t blocks, hipStream_t stream) {
+    constexpr int WJ = 8 / WM, RB = WM * AM + WJ * AJ;
+    const size_t lds = (size_t)NS * RB * 1024;
+    static std::atomic<uint32_t> raised{0};
+    if (lds > 64 * 1024 && !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv1x1_wgrad_lds2<WM, AM, AJ, NS, PF>)))
+        return -1;
+    COT_LAUNCH((conv1x1_wgrad_lds2<WM, AM, AJ, NS, PF>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    return check_launch("conv1x1_wgrad_lds2");
+}
+
+// returns COT_OK, an error, or -1 when not covered (the caller then takes the second-generation kernels)
+int conv1x1_wgrad2_run(const void* gy, const void* x1, const void* x2, int k1, void* gw, void* gb, float* workspace, int N,
+                       int J, int M, int HW, hipStream_t stream) {
+    if (!conv1x1_wgrad2_covers(N, HW, M, J, k1, x2 != nullptr)) return -1;
+    Wg2Args a;
+    a.gy = (const bf16_t*)gy; a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.part = workspace;
+    a.gw = (bf16_t*)gw; a.gb = (bf16_t*)gb; a.k1 = x2 ? k1 : J; a.N = N; a.M = M; a.J = J; a.HW = HW;
+    a.has_bias = gb ? 1 : 0;
+    const int Jp = J + a.has_bias;
+    int TM, TJ;
+    const int shape = wgrad2_shape(M, Jp, &TM, &TJ);
+    a.S = conv1x1_wgrad2_splits(N, M, J, HW, a.has_bias);
+    a.mtiles = ceil_div(M, TM);
+    a.jtiles = ceil_div(Jp, TJ);
+    a.cpi = ceil_div(HW, 8);
+    a.spi = ceil_div(a.cpi, 4);
+    a.T = N * a.spi;
+    a.oldswz = (g_wgrad2_tune >> 2) & 1;
+    a.ablate = g_conv_ablate;
+    a.stamps = g_debug_stamps;
+    const int64_t blocks = (int64_t)a.jtiles * a.mtiles * a.S;
+    a.xcd_remap = blocks % 8 == 0;
+    const bool pf = (g_wgrad2_tune >> 1) & 1;
+    int rc;
+    const bool deep = (g_wgrad2_tune >> 3) & 1;  // bit 3: eight stages (one workgroup per CU, seven stages in flight) instead of four
+#define COT_WG2(WM_, AM_, AJ_)                                                                              \
+    (pf ? launch_wg2<WM_, AM_, AJ_, 1, 4>(a, blocks, stream)                                               \
+        : (deep ? launch_wg2<WM_, AM_, AJ_, 0, 8>(a, blocks, stream) : launch_wg2<WM_, AM_, AJ_, 0, 4>(a, blocks, stream)))
+    switch (shape) {
+        case 0: rc = COT_WG2(2, 4, 2); break;
+        case 1: rc = COT_WG2(1, 4, 2); break;
+        case 2: rc = COT_WG2(4, 4, 2); break;
+        case 3: rc = COT_WG2(2, 2, 1); break;
+        default: rc = COT_WG2(1, 2, 1); break;
+    }
+#undef COT_WG2
+    if (rc || a.S == 1) return rc;
+    return wgrad2_reduce(workspace, a.S, M, J, a.has_bias, gw, gb, stream);
+}
+
+}  // namespace cot

@@ -129,6 +129,8 @@ extern int g_bn_chan;
 // implemented in conv_lds.hip
 extern int g_conv_lds_tune[3];
 extern int g_conv_lds2_tune;
+extern int g_conv_ablate;
+unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
 static inline bool g_conv_lds_tune_wgrad_off() { return (g_conv_lds_tune[2] >> 2) & 1; }  // tuning key 17 bit 2 (A/B)
 bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
 int conv1x1_lds_gemm(const void*, const void*, int, const void*, int, const void*, void*, void*, int, int, int, int, int, int,
@@ -137,6 +139,10 @@ int transpose_bf16(const void* src, void* dst, int R, int C, int pack, hipStream
 bool conv1x1_wgrad_lds_covers(int N, int HW, int M, int J);
 int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad_lds_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
+extern int g_wgrad2_tune;  // conv_wgrad2.hip (third-generation weight gradient)
+bool conv1x1_wgrad2_covers(int N, int HW, int M, int J, int k1, bool two_slabs);
+int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias);
+int conv1x1_wgrad2_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 int conv3x3g_lds_gemm(const void*, const void*, void*, void*, int, int, int, int, int, int, int, int, hipStream_t);
 // implemented in stem7x7.hip
 int stem7x7_splits(int N, int H, int W);
@@ -319,6 +325,14 @@ int cot_set_tuning(int key, int value) {
         g_conv_lds2_tune = value;
         return COT_OK;
     }
+    if (key == 25) {
+        g_wgrad2_tune = value;
+        return COT_OK;
+    }
+    if (key == 24) {  // DIAGNOSTIC: timing ablations of the third-generation 1x1 kernel (results become wrong)
+        g_conv_ablate = value;
+        return COT_OK;
+    }
     if (key == 21) {
         g_bn_chan = value > 0 ? value : 0;  // 0 off, 1 on, 256 / 512 / 1024: on with that workgroup size (A/B)
         return COT_OK;
@@ -335,6 +349,12 @@ int cot_set_tuning(int key, int value) {
     return COT_OK;
 }
 int cot_xchg_mode(void) { return xchg_mode(); }
+/* DIAGNOSTIC (not in the header's contract): device buffer of 8 x uint64 per workgroup the instrumented kernels (third-generation
+ * weight gradient) write s_memtime stamps into; NULL switches it off */
+int cot_debug_stamps(void* device_buffer) {
+    g_debug_stamps = (unsigned long long*)device_buffer;
+    return COT_OK;
+}
 
 int cot_sgd_step(void* param, void* master, void* momentum_buf, const void* grad, int64_t n, float lr, float momentum,
                  float weight_decay, float grad_scale, int nesterov, int param_dtype, int grad_dtype, void* stream) {
@@ -378,6 +398,7 @@ int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias) {
     const int64_t wt = (int64_t)Ci * Co * 2;
     int splits = conv1x1_wgrad_splits(N, Co, Ci, HW, has_bias);
     if (conv1x1_wgrad_lds_covers(N, HW, Co, Ci)) splits = std::max(splits, conv1x1_wgrad_lds_splits(N, Co, Ci, HW, has_bias));
+    splits = std::max(splits, conv1x1_wgrad2_splits(N, Co, Ci, HW, has_bias));  // (whichever kernel ends up running)
     const int64_t part = (int64_t)splits * Co * (Ci + (has_bias ? 1 : 0)) * 4;
     return ((wt > part ? wt : part) + 255) / 256 * 256;
 }
@@ -437,6 +458,10 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
                                      (hipStream_t)stream);
     if (!x2 && HW % 8 == 0 && conv_tiny_covers(N, Ci, Co, HW))
         return conv_tiny_backward_weight(gy, x1, gweight, gbias, Ci, Co, HW, (hipStream_t)stream);
+    if (conv1x1_wgrad2_covers(N, HW, Co, Ci, c1, x2 != nullptr)) {
+        rc = conv1x1_wgrad2_run(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
+        if (rc != -1) return rc;
+    }
     if (conv1x1_wgrad_lds_covers(N, HW, Co, Ci) && !g_conv_lds_tune_wgrad_off())
         return conv1x1_wgrad_lds_run(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
     return conv1x1_wgrad(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);

@@ -538,7 +538,9 @@ def _conv1x1_ref(x, w, b):
     (1, 328, 136, 8, 8, 200, True),   # deep K over two slabs, M = 136 (data gradient: K = 136, 4.25 steps)
 ])
 @pytest.mark.parametrize("splits", [0, 3, -1])   # -1: the general (any H*W) LDS weight-gradient kernel, cot_set_tuning(17, 8)
-def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
+def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits, request):
+    assert _EMUL.cot_set_tuning(25, 1) == 0  # (the third-generation weight gradient has its own test below)
+    request.addfinalizer(lambda: _EMUL.cot_set_tuning(25, 0))
     if splits < 0:
         assert _EMUL.cot_set_tuning(17, 8) == 0
         splits = 0
@@ -582,6 +584,80 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits):
     if bias:
         assert (gb.float() - bf.grad).abs().max().item() <= 1e-2 * bf.grad.abs().max().item() + 1e-2
     assert _EMUL.cot_set_tuning(11, 2048) == 0
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,c1,bias", [
+    (2, 256, 64, 8, 16, 0, False),    # 64 x 256 tile; H*W = 128: whole steps only
+    (3, 128, 32, 7, 7, 0, False),     # 32 x 128 tile; H*W = 49: two steps per image, the second 17 pixels (tail chunk + an empty one)
+    (2, 64, 64, 14, 14, 0, False),    # 64 x 64 tile; H*W = 196: 25 chunks, the last step is the 4-pixel tail chunk alone
+    (2, 64, 256, 8, 8, 0, False),     # 256 x 64 tile
+    (2, 64, 256, 8, 8, 0, True),      # ... with a bias: 65 columns -> 128 x 128 tiles, unaligned output rows
+    (1, 200, 136, 12, 12, 64, True),  # 128 x 128 tiles, partial in both directions, two input slabs, H*W = 144 (4.5 steps)
+    (5, 48, 72, 3, 5, 16, True),      # H*W = 15: two chunks, the second read 8 pixels back from the row's end
+    (4, 32, 72, 5, 8, 0, True),       # the embed[3] shape class (72 x 33): one 128 x 128 tile mostly empty
+    (2, 512, 128, 4, 4, 256, False),  # H*W = 16; four column tiles, slab switch on a tile boundary
+    (7, 96, 80, 7, 7, 0, False),      # odd image count, slices cut inside images
+    (2, 256, 128, 4, 8, 0, False),    # 32768 outputs: forced slice counts take the wide (four outputs per lane) reduce kernel
+])
+@pytest.mark.parametrize("variant", [(0, 0, 0), (0, 0, 1), (2, 0, 1), (2, 3, 0), (0, 3, 1), (2, 5, 1), (4, 2, 1), (0, 127, 1)])
+def test_conv1x1_weight_gradient_third_generation(N, Ci, Co, H, W, c1, bias, variant):
+    """csrc/conv_wgrad2.hip behind cot_conv1x1_backward_weight: every tile shape, planes that are / are not multiples of 8 and
+    32 pixels, two slabs, the bias column, forced slice counts (cot_set_tuning(25) bits 24..), fragment prefetch (bit 1), the
+    old chunk permutation (bit 2), LDS-DMA landing modes of the emulator -- against fp32 on the bf16-rounded operands, and
+    against the second-generation kernels"""
+    bits, force, dma = variant
+    torch.manual_seed(23)
+    HW, dt = H * W, _lib.dtype_code(torch.bfloat16)
+    x = torch.randn(N, Ci, H, W).bfloat16()
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    gwr = torch.einsum("nohw,nchw->oc", gy.float(), x.float())
+    gbr = gy.float().sum((0, 2, 3))
+    split = c1 > 0
+    x1 = x[:, :c1].contiguous() if split else x
+    x2 = x[:, c1:].contiguous() if split else None
+    cc1 = c1 if split else Ci
+    PN = lambda t: P(t) if t is not None else None
+    try:
+        assert _EMUL.cot_set_tuning(25, bits | (force << 24)) == 0
+        _EMUL.emul_set_dma_mode(dma)
+        ws = torch.full((_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 1 if bias else 0),), 0x7f, dtype=torch.uint8)
+        gw = torch.full((Co, Ci), float("nan")).bfloat16()
+        gb = torch.full((Co,), float("nan")).bfloat16() if bias else None
+        rc = _EMUL.cot_conv1x1_backward_weight(P(gy), P(x1), PN(x2), cc1, P(gw), PN(gb), P(ws), N, Ci, Co, HW, dt, None)
+        assert rc == 0, _EMUL.cot_last_error()
+        scale = gwr.abs().max().item()
+        assert (gw.float() - gwr).abs().max().item() <= 1e-2 * scale + 1e-2
+        if bias:
+            assert (gb.float() - gbr).abs().max().item() <= 1e-2 * gbr.abs().max().item() + 1e-2
+        # the previous generation on the same data (same products, different summation order)
+        assert _EMUL.cot_set_tuning(25, 1) == 0
+        gw0 = torch.full_like(gw, float("nan"))
+        gb0 = torch.full_like(gb, float("nan")) if bias else None
+        ws0 = torch.full((_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 1 if bias else 0),), 0x7f, dtype=torch.uint8)
+        assert _EMUL.cot_conv1x1_backward_weight(P(gy), P(x1), PN(x2), cc1, P(gw0), PN(gb0), P(ws0), N, Ci, Co, HW, dt, None) == 0
+        assert (gw.float() - gw0.float()).abs().max().item() <= 2e-2 * scale + 1e-2
+    finally:
+        _EMUL.emul_set_dma_mode(0)
+        assert _EMUL.cot_set_tuning(25, 0) == 0
+
+
+def test_conv1x1_weight_gradient_third_generation_non_finite_rows():
+    """a NaN / Inf in a row of X or dY must reach exactly the outputs that row feeds: the repeated pixels of a tail chunk and
+    the clamped copies of rows past the matrix are removed by selection, so nothing leaks sideways"""
+    torch.manual_seed(3)
+    N, Ci, Co, H, W = 3, 64, 40, 7, 7
+    HW, dt = H * W, _lib.dtype_code(torch.bfloat16)
+    x = torch.randn(N, Ci, H, W).bfloat16()
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    x[1, 5, 6, 6] = float("nan")      # the last pixel of a row (inside the tail chunk)
+    gy[2, 39, 0, 3] = float("inf")    # the last dY row (the one the clamped rows copy)
+    ref = torch.einsum("nohw,nchw->oc", gy.float(), x.float())
+    ws = torch.full((_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 0),), 0x7f, dtype=torch.uint8)
+    gw = torch.zeros(Co, Ci).bfloat16()
+    assert _EMUL.cot_conv1x1_backward_weight(P(gy), P(x), None, Ci, P(gw), None, P(ws), N, Ci, Co, HW, dt, None) == 0
+    assert torch.equal(torch.isfinite(gw.float()), torch.isfinite(ref))
+    fin = torch.isfinite(ref)
+    assert (gw.float()[fin] - ref[fin]).abs().max() <= 1e-2 * ref[fin].abs().max() + 1e-2
 
 
 # (cot_set_tuning(17), cot_set_tuning(23), LDS-DMA landing mode of the emulator): key 17 bit 1 = 2-byte gathers instead of
