@@ -67,7 +67,7 @@ def parse():
                          "on a fresh box and the default kernel set has no MIOpen call to tune")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--bucket-mb", type=float, default=48.0)
+    ap.add_argument("--bucket-mb", type=float, default=10.0, help="flat gradient bucket size (MiB): the all-reduce granularity")
     ap.add_argument("--conv1x1", default=None, choices=["module", "hip", "matmul"],
                     help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
     ap.add_argument("--ema", type=float, default=None, metavar="DECAY",

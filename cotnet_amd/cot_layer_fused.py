@@ -47,6 +47,57 @@ def _ck(rc, what):
         _lib.check(rc, what)
 
 
+# ---- weight gradients on a side stream.  A parameter gradient is needed only when the step's backward is over, while the
+# data-gradient chain it hangs off is the critical path: 100 weight-gradient launches (+ their split reduces) per CoTNet-50
+# step, ~3 ms of device time in which 256-workgroup GEMM slices and their launch ramps sit between bandwidth-bound
+# BatchNorm / data-gradient kernels that never need all the matrix pipes.  So every weight gradient of a node's backward is
+# issued on ONE extra HIP stream per device: it waits (event) for what the compute stream has produced so far, runs beside
+# the rest of the node's backward, and the compute stream joins it (event) before the node returns -- i.e. before autograd
+# hands the gradients to anybody.  Rules that keep this race-free:
+#   * a tensor read by a side-stream launch is never written again inside the node (no buffer reuse for them below) and is
+#     kept referenced until the join (the caching allocator could otherwise hand its memory to a later compute-stream tensor);
+#   * the side stream is in-order, so its launches share ONE persistent workspace of their own (partial sums are consumed by
+#     the same launch's reduce); the compute stream's workspace is never touched by it.
+# COT_WGRAD_STREAM=0 (or cot_layer_fused.SIDE_WGRAD = False) issues everything on the compute stream as before (A/B, tests).
+SIDE_WGRAD = os.environ.get("COT_WGRAD_STREAM", "1") != "0"
+_SIDE_STREAMS = {}  # device index -> [torch.cuda.Stream, workspace tensor]
+
+
+class _Side:
+    """the side stream for one node's backward (or a pass-through onto the compute stream when switched off / on CPU tensors)"""
+    __slots__ = ("on", "main", "stream", "st", "ws", "keep")
+
+    def __init__(self, dev, ws_bytes, main_ws):
+        self.on = SIDE_WGRAD and _DEVICE_ONLY and dev.type == "cuda"
+        self.keep = []
+        if not self.on:
+            self.st, self.ws = _stream(), main_ws
+            return
+        ent = _SIDE_STREAMS.get(dev.index)
+        if ent is None:
+            ent = _SIDE_STREAMS[dev.index] = [torch.cuda.Stream(device=dev), None]
+        self.main = torch.cuda.current_stream(dev)
+        self.stream = ent[0]
+        if ent[1] is None or ent[1].numel() < ws_bytes:
+            with torch.cuda.stream(self.stream):  # (owned by the side stream's pool; grown, never shrunk)
+                ent[1] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        self.ws = ent[1]
+        self.st = ctypes.c_void_p(self.stream.cuda_stream)
+
+    def ready(self, *tensors):
+        """call right before a side-stream launch that reads `tensors`: everything the compute stream has issued so far is
+        ordered before it, and the tensors stay alive until join()"""
+        if self.on:
+            self.stream.wait_stream(self.main)
+            self.keep.extend(tensors)
+        return self.st
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.stream)
+            self.keep.clear()
+
+
 _SIZES = _lib.register_cache({})  # (N, C, H, W, A) -> (workspace bytes, bn workspace floats for C, C/2 and the se branch's A channels)
 _MASKS = {}
 
@@ -203,8 +254,9 @@ def _cot_forward(L, layer, x):
 _N_SAVED = 22  # tensors _cot_forward hands back for the backward pass
 
 
-def _cot_backward(L, layer, saved, geom, gout):
-    """-> (dx, gradients of _Plan.params in that order)"""
+def _cot_backward(L, layer, saved, geom, gout, side=None):
+    """-> (dx, gradients of _Plan.params in that order).  `side`: the caller's side stream for the weight gradients (a
+    Bottleneck node passes its own and joins it itself); None = this call opens and joins one."""
     (x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y, gapT, hpre, h,
      s_a) = saved
     N, C, H, W = x.shape
@@ -216,6 +268,9 @@ def _cot_backward(L, layer, saved, geom, gout):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     masks = _masks(L, H, W, dev)
     st = _stream()
+    own_side = side is None
+    if own_side:
+        side = _Side(dev, ws_bytes, ws)
     ke0, ke1, em0, em1, em3, cv0, cv1 = pl.ke0, pl.ke1, pl.em0, pl.em1, pl.em3, pl.cv0, pl.cv1
     se0, sebn, se3 = pl.se0, pl.sebn, pl.se3
     gout = gout.contiguous()
@@ -228,15 +283,15 @@ def _cot_backward(L, layer, saved, geom, gout):
     _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st),
         "cot_conv1x1_backward_data")
     g_w3, g_b3 = grad_sink.out_like(se3.weight), grad_sink.out_like(se3.bias)
-    _ck(L.cot_conv1x1_backward_weight(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(ws), 1, A, 2 * C, N, BF16,
-                                      st), "cot_conv1x1_backward_weight")
+    _ck(L.cot_conv1x1_backward_weight(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(side.ws), 1, A, 2 * C, N, BF16,
+                                      side.ready(glogT, h)), "cot_conv1x1_backward_weight")
     ghpre = row(A)
     d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, None, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
     _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st),
         "cot_conv1x1_backward_data")
     g_w0, g_b0 = grad_sink.out_like(se0.weight), grad_sink.out_like(se0.bias)
-    _ck(L.cot_conv1x1_backward_weight(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(ws), 1, C, A, N, BF16, st),
-        "cot_conv1x1_backward_weight")
+    _ck(L.cot_conv1x1_backward_weight(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(side.ws), 1, C, A, N, BF16,
+                                      side.ready(ghpre, gapT)), "cot_conv1x1_backward_weight")
     gy, gk = torch.empty_like(y), torch.empty_like(k)
     _ck(L.cot_radix_mix_backward_apply(_p(gout), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, BF16, st),
         "cot_radix_mix_backward_apply")
@@ -253,8 +308,8 @@ def _cot_backward(L, layer, saved, geom, gout):
     _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gx), None, C, 0, _p(ws), N, C, C, HW, BF16, st),
         "cot_conv1x1_backward_data")
     g_wv = grad_sink.out_like(cv0.weight)
-    _ck(L.cot_conv1x1_backward_weight(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(ws), N, C, C, HW, BF16, st),
-        "cot_conv1x1_backward_weight")
+    _ck(L.cot_conv1x1_backward_weight(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(side.ws), N, C, C, HW, BF16,
+                                      side.ready(gv_pre, x)), "cot_conv1x1_backward_weight")
     # logits branch: GroupNorm, conv1x1(+bias), bn+relu, conv1x1 on [x | k] -> dx +=, dk +=
     gn = pl.gn
     if HW <= 8192:
@@ -270,24 +325,26 @@ def _cot_backward(L, layer, saved, geom, gout):
     _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), N, Ch, Ce, HW, BF16,
                                     st), "cot_conv1x1_backward_data")
     g_we3, g_be3 = grad_sink.out_like(em3.weight), grad_sink.out_like(em3.bias)
-    _ck(L.cot_conv1x1_backward_weight(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(ws), N, Ch, Ce, HW, BF16,
-                                      st), "cot_conv1x1_backward_weight")
+    _ck(L.cot_conv1x1_backward_weight(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(side.ws), N, Ch, Ce, HW, BF16,
+                                      side.ready(ge3, e1)), "cot_conv1x1_backward_weight")
     ge0 = torch.empty_like(e0)
     d_em_w, d_em_b = _bn_bwd(L, ge1, e0, None, ge0, em1, s_e, N, Ch, HW, 1, nws_h)  # (ReLU mask recomputed from e0)
     _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gx), _p(gk), C, 3, _p(ws), N, 2 * C, Ch, HW, BF16,
                                     st), "cot_conv1x1_backward_data")
     g_we0 = grad_sink.out_like(em0.weight)
-    _ck(L.cot_conv1x1_backward_weight(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(ws), N, 2 * C, Ch, HW, BF16, st),
-        "cot_conv1x1_backward_weight")
+    _ck(L.cot_conv1x1_backward_weight(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(side.ws), N, 2 * C, Ch, HW, BF16,
+                                      side.ready(ge0, x, k)), "cot_conv1x1_backward_weight")
     # key branch: bn+relu, grouped 3x3 -> dx +=
     gk_pre = gv  # (reuse: gv is dead)
     d_ke_w, d_ke_b = _bn_bwd(L, gk, k_pre, None, gk_pre, ke1, s_k, N, C, HW, 1, nws_c)
     G = ke0.groups
+    g_wk = grad_sink.out_like(ke0.weight)
+    _ck(L.cot_conv3x3g_backward_weight(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(side.ws), N, C, C, G, H, W, BF16,
+                                       side.ready(gk_pre, x, masks)), "cot_conv3x3g_backward_weight")
     _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx), 1, _p(masks), _p(ws), N, C, C, G, H, W,
                                      BF16, st), "cot_conv3x3g_backward_data")
-    g_wk = grad_sink.out_like(ke0.weight)
-    _ck(L.cot_conv3x3g_backward_weight(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(ws), N, C, C, G, H, W, BF16, st),
-        "cot_conv3x3g_backward_weight")
+    if own_side:
+        side.join()
     # order = _Plan.params
     return gx, (g_wk, d_ke_w, d_ke_b, g_we0, d_em_w, d_em_b, g_we3, g_be3, g_gn_w, g_gn_b, g_wv, d_cv_w, d_cv_b,
                 d_bn_w, d_bn_b, g_w0, g_b0, d_sa_w, d_sa_b, g_w3, g_b3)
@@ -454,6 +511,9 @@ class _BottleneckNode(Function):
         ws_a, nws_w, _ = _block_sizes(L, N, Cin, Cw, Cout, HW)
         ws_b, _, nws_o = _block_sizes(L, N, Cin, Cw, Cout, HWo)
         ws = torch.empty(max(ws_a, ws_b), dtype=torch.uint8, device=dev)
+        cN, cC, cH, cW = saved[0].shape
+        cpl = _plan(bp.cot)
+        side = _Side(dev, max(ws_a, ws_b, _sizes(L, cN, cC, cH, cW, cpl.se0.out_channels, cpl.ke0.groups)[0]), ws)
         gout = gout.contiguous()
         # bn3 + residual + relu: dx of the normalisation and the residual's gradient in one pass
         g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
@@ -462,9 +522,9 @@ class _BottleneckNode(Function):
         _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_cot_out), None, Cw, 0, _p(ws), N, Cw, Cout, HWo,
                                         BF16, st), "cot_conv1x1_backward_data")
         g_w3 = grad_sink.out_like(bp.conv3.weight)
-        _ck(L.cot_conv1x1_backward_weight(_p(g_c3), _p(cot_out), None, Cw, _p(g_w3), None, _p(ws), N, Cw, Cout, HWo, BF16,
-                                          st), "cot_conv1x1_backward_weight")
-        g_p1, g_cot = _cot_backward(L, bp.cot, saved, ctx.geom, g_cot_out)
+        _ck(L.cot_conv1x1_backward_weight(_p(g_c3), _p(cot_out), None, Cw, _p(g_w3), None, _p(side.ws), N, Cw, Cout, HWo, BF16,
+                                          side.ready(g_c3, cot_out)), "cot_conv1x1_backward_weight")
+        g_p1, g_cot = _cot_backward(L, bp.cot, saved, ctx.geom, g_cot_out, side)
         if bp.avd:
             g_a1 = torch.empty_like(a1)
             _ck(L.cot_avgpool3x3s2_backward(_p(g_p1), _p(g_a1), N * Cw, H, W, BF16, st), "cot_avgpool3x3s2_backward")
@@ -476,7 +536,8 @@ class _BottleneckNode(Function):
         g_ds = ()
         if ctx.has_ds:
             d0, s_d, xs = extra[8], extra[9], extra[10]
-            g_d0 = g_c3  # (reuse: consumed by conv3's backward)
+            # (g_c3 is still being read by conv3's weight gradient on the side stream: no reuse of its buffer here)
+            g_d0 = torch.empty_like(g_c3) if side.on else g_c3
             d_ds_w, d_ds_b = _bn_bwd(L, g_res, d0, None, g_d0, bp.ds_bn, s_d, N, Cout, HWo, 0, nws_o)
             if bp.ds_stride == 2:  # the projection saw every second pixel: its data gradient lands there, zeros elsewhere
                 g_xs = torch.empty_like(xs)
@@ -489,16 +550,17 @@ class _BottleneckNode(Function):
                 _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(gx), None, Cin, 0, _p(ws), N, Cin,
                                                 Cout, HWo, BF16, st), "cot_conv1x1_backward_data")
             g_wd = grad_sink.out_like(bp.ds_conv.weight)
-            _ck(L.cot_conv1x1_backward_weight(_p(g_d0), _p(xs), None, Cin, _p(g_wd), None, _p(ws), N, Cin, Cout, HWo, BF16,
-                                              st), "cot_conv1x1_backward_weight")
+            _ck(L.cot_conv1x1_backward_weight(_p(g_d0), _p(xs), None, Cin, _p(g_wd), None, _p(side.ws), N, Cin, Cout, HWo, BF16,
+                                              side.ready(g_d0, xs)), "cot_conv1x1_backward_weight")
             g_ds = (g_wd, d_ds_w, d_ds_b)
         else:
             gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
+        g_w1 = grad_sink.out_like(bp.conv1.weight)  # (issued before its data gradient: the two overlap)
+        _ck(L.cot_conv1x1_backward_weight(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, Cw, HW, BF16,
+                                          side.ready(g_c1, x)), "cot_conv1x1_backward_weight")
         _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16,
                                         st), "cot_conv1x1_backward_data")
-        g_w1 = grad_sink.out_like(bp.conv1.weight)
-        _ck(L.cot_conv1x1_backward_weight(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(ws), N, Cin, Cw, HW, BF16, st),
-            "cot_conv1x1_backward_weight")
+        side.join()
         return (None, gx, g_w1, d_bn1_w, d_bn1_b) + g_cot + (g_w3, d_bn3_w, d_bn3_b) + g_ds
 
 

@@ -12,8 +12,9 @@ per step.  This module does that MI355X-first:
     a dedicated communication stream that waits on an event recorded on the compute stream -- the collective
     overlaps with the rest of backward;
   * xGMI is a point-to-point fabric (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by ONE link, and
-    each collective pays a fixed launch latency, so buckets are few and large (default 48 MiB -> 2 buckets for
-    CoTNet-50's 88.8 MB of fp32 gradients) rather than DDP's 25 MiB NVSwitch-tuned default;
+    each collective pays a fixed launch latency, so buckets are few and large -- but not so large that nothing is
+    left to overlap: default 10 MiB = five buckets for CoTNet-50's 44 MB of bf16 gradients (nine for 88.8 MB of fp32),
+    four of them in flight before backward ends (round 2's 48 MiB was ONE bucket that completed with the stem);
   * no host synchronisation anywhere: `finish()` only makes the compute stream wait for the communication
     work (the reference synchronises the host twice per step, train.py:282,:290).
 
@@ -42,7 +43,7 @@ class _Bucket:
 
 
 class GradBucketReducer:
-    def __init__(self, module, process_group=None, bucket_mb=48.0, broadcast_params=True, grad_dtype=None,
+    def __init__(self, module, process_group=None, bucket_mb=10.0, broadcast_params=True, grad_dtype=None,
                  group_fn=None, grad_mode="view", flatten_params=False, force_collectives=False):
         """group_fn(name, param) -> hashable key: parameters with different keys never share a bucket (used by
         FlatSGD to keep weight-decay groups / dtypes apart).  grad_mode "view": p.grad is a view into the bucket and

@@ -42,9 +42,15 @@ def _decay_group(name, p):
 
 
 class FlatSGD:
-    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0, nesterov=True, bucket_mb=48.0, process_group=None,
+    def __init__(self, model, lr, momentum=0.9, weight_decay=0.0, nesterov=True, bucket_mb=10.0, process_group=None,
                  broadcast_params=True, ema_decay=None, force_collectives=False):
-        """ema_decay: also keep an exponential moving average of the weights (the reference's ModelEmaV2,
+        """bucket_mb: size of the flat gradient buckets.  10 MiB cuts CoTNet-50's 44 MB of bf16 weight gradients into five
+        buckets in the order backward produces them (classifier and stage 4 first, the stem last), so four all-reduces are
+        already on the communication stream when backward ends and only the last, small one is exposed; round 2's 48 MiB
+        made ONE bucket whose last member is the stem's weight -- nothing could overlap (tests/test_data_parallel_cpu.py).
+        A 10 MB ring all-reduce over 8 GPUs moves 17.5 MB per link direction: ~0.12 ms at xGMI's ~153 GB/s, well above the
+        collective's fixed latency.
+        ema_decay: also keep an exponential moving average of the weights (the reference's ModelEmaV2,
         utils/model_ema.py, `model_ema: True` / decay 0.9999 in its recipes): one flat kernel per bucket after the SGD
         kernel instead of one elementwise op per state_dict tensor; floating-point buffers (BatchNorm running statistics)
         are averaged with one multi-tensor lerp.  `ema_state_dict()` returns it under the model's state_dict keys."""
