@@ -72,6 +72,10 @@ def parse():
                     help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
     ap.add_argument("--ema", type=float, default=None, metavar="DECAY",
                     help="also keep the reference recipe's weight EMA (model_ema_decay 0.9999) in the step, flat kernel")
+    ap.add_argument("--recipe", action="store_true",
+                    help="the reference recipe's regularisation in the step (cot_experiments/CoTNet-50-350epoch/config.yaml:21-26: "
+                         "drop 0.25, drop_path 0.1, model_ema decay 0.9999): stochastic depth inside the single-node Bottlenecks, "
+                         "head dropout on the library path, flat EMA kernel")
     ap.add_argument("--kernels", default="auto", choices=["auto", "round1", "new"],
                     help="which kernel set the step runs on: round1 = MIOpen convolutions + node-per-op layers (the "
                          "configuration measured in round 1); new = hand-written 1x1 / grouped-3x3 / GroupNorm kernels inside "
@@ -479,7 +483,9 @@ def main():
     torch.manual_seed(1234 + rank)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     torch.backends.cudnn.deterministic = args.deterministic
-    model = cotnet_amd.create_model(args.model, num_classes=1000).to(dev)
+    if args.recipe and args.ema is None:
+        args.ema = 0.9999
+    model = cotnet_amd.create_model(args.model, num_classes=1000, **(dict(drop_rate=0.25, drop_path_rate=0.1) if args.recipe else {})).to(dev)
     mf = torch.channels_last if args.layout == "nhwc" else torch.contiguous_format
     if args.layout == "nhwc":
         model = model.to(memory_format=torch.channels_last)
@@ -623,6 +629,7 @@ def main():
                        "layout": args.layout, "precision": ("bf16 weights+activations, fp32 master weights / norm params, fused flat SGD" if mixed
                                      else "bf16 autocast, fp32 weights" if amp else "fp32"),
                        "kernel_selection": selection, **({"tune": args.tune} if args.tune else {}),
+                       **({"recipe": "drop 0.25, drop_path 0.1, model_ema 0.9999 (reference config.yaml:21-26)"} if args.recipe else {}),
                        "conv1x1": __import__("cotnet_amd.conv1x1", fromlist=["MODE"]).MODE or "module",
                        "conv3x3": __import__("cotnet_amd.conv3x3g", fromlist=["MODE"]).MODE or "module",
                        "group_norm9": __import__("cotnet_amd.group_norm9", fromlist=["MODE"]).MODE or "module",

@@ -163,21 +163,73 @@ def _plan(layer):
     return p
 
 
-def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act, residual=None):
-    """stats: fp32 [2*C + workspace] -> mean = stats[:C], rstd = stats[C:2C]"""
+def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act, residual=None, ps=None):
+    """stats: fp32 [2*C + workspace] -> mean = stats[:C], rstd = stats[C:2C].  ps: per-sample scale of the normalised branch
+    (stochastic depth: 0 or 1 / keep, fp32 [N]) or None"""
+    if ps is not None:
+        _ck(L.cot_bn_act_forward_ps(_p(x), _p(residual), _p(y), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
+                                    _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _p(stats[nws_off:]),
+                                    _p(ps), N, C, HW, float(bn.eps), float(bn.momentum), act, BF16, _stream()),
+            "cot_bn_act_forward_ps")
+        return
     _ck(L.cot_bn_act_forward(_p(x), _p(residual), _p(y), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
                              _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _p(stats[nws_off:]),
                              N, C, HW, float(bn.eps), float(bn.momentum), act, BF16, _stream()), "cot_bn_act_forward")
 
 
-def _bn_bwd(L, dy, x, y, dx, bn, stats, N, C, HW, act, nws, dres=None):
+def _bn_bwd(L, dy, x, y, dx, bn, stats, N, C, HW, act, nws, dres=None, ps=None):
     """-> (dgamma, dbeta): the parameters' slots in the flat gradient buckets when registered (grad_sink), else fresh"""
     dg, db = grad_sink.out_like(bn.weight), grad_sink.out_like(bn.bias)
     ws = torch.empty(max(nws, 1), dtype=torch.float32, device=dy.device)
+    if ps is not None:
+        _ck(L.cot_bn_act_backward_ps(_p(dy), _p(x), _p(y), _p(dx), _p(dres), _p(bn.weight), _p(bn.bias), _p(stats),
+                                     _p(stats[C:]), _p(dg), _p(db), _p(ws), _p(ps), N, C, HW, act, BF16, _stream()),
+            "cot_bn_act_backward_ps")
+        return dg, db
     _ck(L.cot_bn_act_backward(_p(dy), _p(x), _p(y), _p(dx), _p(dres), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
                               _p(dg), _p(db), _p(ws), N, C, HW, act, BF16, _stream()),
         "cot_bn_act_backward")
     return dg, db
+
+
+# ---- stochastic depth (models/cotnet.py:256-257; models/layers/drop.py:140-168: per sample, the block's branch is dropped with
+# probability p and scaled by 1 / (1 - p) otherwise) inside the single-node Bottleneck: the per-sample scale goes into the
+# bn3 + residual + ReLU kernels (cot_bn_act_*_ps).  One vectorised draw per step serves every block of a model
+# (prepare_drop_path, called by ResNet.forward_features): 3 small launches per step instead of 4 per block.
+_DP_PLANS = weakref.WeakKeyDictionary()  # model -> (blocks with an active DropPath, their keep probabilities on the device)
+
+
+def prepare_drop_path(model, x):
+    if not (ENABLED and model.training):
+        return
+    ent = _DP_PLANS.get(model)
+    if ent is None or ent[1].device != x.device:
+        blocks = [m for m in model.modules() if getattr(m, "drop_path", None) is not None and getattr(m.drop_path, "drop_prob", 0.0)]
+        keep = torch.tensor([1.0 - float(b.drop_path.drop_prob) for b in blocks], dtype=torch.float32, device=x.device)
+        ent = _DP_PLANS[model] = (blocks, keep)
+    blocks, keep = ent
+    if not blocks:
+        return
+    u = torch.rand((len(blocks), x.shape[0]), dtype=torch.float32, device=x.device)
+    ps_all = u.add_(keep[:, None]).floor_().div_(keep[:, None])  # 0 or 1 / keep  (drop.py:165-167)
+    for i, b in enumerate(blocks):
+        b._ps_next = ps_all[i]
+
+
+def _drop_path_scale(blk, N, dev):
+    """this forward's per-sample scale for `blk` (None: no stochastic depth); consumes what prepare_drop_path laid out"""
+    dp = blk.drop_path
+    if dp is None or not dp.drop_prob or not blk.training:
+        return None
+    ps = getattr(dp, "fixed_scale", None)  # (tests: a module that applies a GIVEN per-sample scale)
+    if ps is not None:
+        return ps.to(device=dev, dtype=torch.float32).contiguous()
+    ps = getattr(blk, "_ps_next", None)
+    blk._ps_next = None
+    if ps is None or ps.shape[0] != N or ps.device != dev:  # (block used outside a ResNet.forward: draw its own)
+        keep = 1.0 - float(dp.drop_prob)
+        ps = torch.rand(N, dtype=torch.float32, device=dev).add_(keep).floor_().div_(keep)
+    return ps
 
 
 def _cot_forward(L, layer, x):
@@ -421,7 +473,8 @@ class _BlockPlan:
                      and c.stride == (self.ds_stride, self.ds_stride) and c.bias is None and _bn_static_ok(ds[-1]))
         self.static_ok = (
             ds_ok and avd_ok and isinstance(blk.conv2, CotLayer) and blk.drop_block is None
-            and blk.drop_path is None and blk.se is None and isinstance(blk.act1, nn.ReLU)
+            and (blk.drop_path is None or hasattr(blk.drop_path, "drop_prob")) and blk.se is None
+            and isinstance(blk.act1, nn.ReLU)
             and isinstance(blk.act3, nn.ReLU) and _conv_ok(blk.conv1, 1, 1) and blk.conv1.bias is None
             and _conv_ok(blk.conv3, 1, 1) and blk.conv3.bias is None and _bn_static_ok(blk.bn1)
             and _bn_static_ok(blk.bn3) and blk.conv1.in_channels % 8 == 0 and blk.conv3.out_channels % 8 == 0
@@ -489,9 +542,11 @@ class _BottleneckNode(Function):
         else:
             xs, d0, res, s_d = None, None, x, None
         s_3 = stat(Cout, nws_o)
-        _bn_fwd(L, c3, y, bp.bn3, s_3, 2 * Cout, N, Cout, HWo, 1, residual=res)
-        ctx.blk, ctx.geom, ctx.has_ds = blk, geom, bp.ds_conv is not None
-        extra = (x, c1, a1, s_1, cot_out, c3, y, s_3) + ((d0, s_d, xs) if bp.ds_conv is not None else ())
+        ps = _drop_path_scale(blk, N, dev)  # stochastic depth: per-sample 0 or 1 / keep on the normalised branch
+        _bn_fwd(L, c3, y, bp.bn3, s_3, 2 * Cout, N, Cout, HWo, 1, residual=res, ps=ps)
+        ctx.blk, ctx.geom, ctx.has_ds, ctx.has_ps = blk, geom, bp.ds_conv is not None, ps is not None
+        extra = (x, c1, a1, s_1, cot_out, c3, y, s_3) + ((d0, s_d, xs) if bp.ds_conv is not None else ()) + \
+            ((ps,) if ps is not None else ())
         ctx.save_for_backward(*(saved + extra))
         return y
 
@@ -517,7 +572,8 @@ class _BottleneckNode(Function):
         gout = gout.contiguous()
         # bn3 + residual + relu: dx of the normalisation and the residual's gradient in one pass
         g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
-        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, bp.bn3, s_3, N, Cout, HWo, 1, nws_o, dres=g_res)
+        ps = extra[-1] if ctx.has_ps else None
+        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, bp.bn3, s_3, N, Cout, HWo, 1, nws_o, dres=g_res, ps=ps)
         g_cot_out = torch.empty_like(cot_out)
         _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_cot_out), None, Cw, 0, _p(ws), N, Cw, Cout, HWo,
                                         BF16, st), "cot_conv1x1_backward_data")

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const T* __restrict__ dy, c
                                                     const T* __restrict__ y, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float* __restrict__ part, int N,
-                                                    int C, int HW, int nper) {
+                                                    int C, int HW, int nper, const float* __restrict__ ps) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* smem = reinterpret_cast<float*>(cot_smem);
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
@@ -237,10 +237,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const T* __restrict__ dy, c
         const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
         Vec<T, V> yv;
         if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + off);
+        const float sc = ps ? ps[n0 + w.n] : 1.f;  // stochastic depth: the normalised branch was scaled per sample
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = act_bwd<ACT>((float)dv.v[k], ACT == ACT_RELU_Y ? (float)yv.v[k] : xh * ga + be);
+            const float g = sc * act_bwd<ACT>((float)dv.v[k], ACT == ACT_RELU_Y ? (float)yv.v[k] : xh * ga + be);
             acc[0] += g;
             acc[1] += g * xh;
         }
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_fold(const T* __restrict__ x
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
                                                         long long* __restrict__ num_batches_tracked, int N, int C, int HW,
-                                                        int nper, float eps, float momentum) {
+                                                        int nper, float eps, float momentum, const float* __restrict__ ps) {
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     float n = 0.f, m = 0.f, M2 = 0.f;
     for (int q = 0; q < split; ++q) {
@@ -366,9 +367,10 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_fold(const T* __restrict__ x
         const Vec<T, V> xv = ldv<T, V>(x + off);
         Vec<T, V> rv, o;
         if (res) rv = ldv<T, V>(res + off);
+        const float sc = ps ? ps[n0 + w.n] : 1.f;  // stochastic depth (models/cotnet.py:256-257): 0 or 1 / keep per sample
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float z = (float)xv.v[k] * a + b;
+            float z = ((float)xv.v[k] * a + b) * sc;
             if (res) z += (float)rv.v[k];
             o.v[k] = (T)act_fwd<ACT>(z);
         }
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ d
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ part, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int N, int C, int HW, int nper,
-                                                        float inv_m) {
+                                                        float inv_m, const float* __restrict__ ps) {
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     float sb = 0.f, sg = 0.f;
     for (int q = 0; q < split; ++q) {
@@ -404,12 +406,13 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ d
         const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
         Vec<T, V> yv, o, og;
         if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + off);
+        const float sc = ps ? ps[n0 + w.n] : 1.f;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
             const float g = act_bwd<ACT>((float)dv.v[k], ACT == ACT_RELU_Y ? (float)yv.v[k] : xh * ga + be);
-            o.v[k] = (T)(gr * (g - k1 - xh * k2));
-            og.v[k] = (T)g;
+            o.v[k] = (T)(gr * (sc * g - k1 - xh * k2));
+            og.v[k] = (T)g;  // (the residual's gradient is not scaled)
         }
         stv<T, V>(dx + off, o);
         if (dres) stv<T, V>(dres + off, og);
@@ -447,13 +450,13 @@ int bn_workspace_floats(int N, int C) {
 template <typename T, int V, int ACT>
 static int bn_fwd_launch_act(const T* x, const T* res, T* y, const float* gamma, const float* beta, float* mean,
                              float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW,
-                             float eps, float mom, hipStream_t s) {
+                             float eps, float mom, const float* ps, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
     COT_LAUNCH((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
-    if (g_bn_fold) {
+    if (g_bn_fold || ps) {  // (the per-sample scale lives in the kernels that walk a channel image by image)
         COT_LAUNCH((bn_apply_fwd_fold<T, V, ACT>), dim3(C, split), dim3(256), 0, s, x, res, y, (const float*)ws, gamma,
-                   beta, mean, rstd, rmean, rvar, nbt, N, C, HW, nper, eps, mom);
+                   beta, mean, rstd, rmean, rvar, nbt, N, C, HW, nper, eps, mom, ps);
         return check_launch("bn_act_forward");
     }
     COT_LAUNCH(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
@@ -467,8 +470,8 @@ static int bn_fwd_launch_act(const T* x, const T* res, T* y, const float* gamma,
 template <typename T, int V>
 static int bn_fwd_launch(const T* x, const T* res, T* y, const float* gamma, const float* beta, float* mean,
                          float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW,
-                         float eps, float mom, int act, hipStream_t s) {
-#define BN_FA(A_) return bn_fwd_launch_act<T, V, A_>(x, res, y, gamma, beta, mean, rstd, rmean, rvar, nbt, ws, N, C, HW, eps, mom, s)
+                         float eps, float mom, int act, const float* ps, hipStream_t s) {
+#define BN_FA(A_) return bn_fwd_launch_act<T, V, A_>(x, res, y, gamma, beta, mean, rstd, rmean, rvar, nbt, ws, N, C, HW, eps, mom, ps, s)
     if (act == ACT_RELU) BN_FA(ACT_RELU);
     if (act == ACT_SILU) BN_FA(ACT_SILU);
     BN_FA(ACT_NONE);
@@ -478,14 +481,14 @@ static int bn_fwd_launch(const T* x, const T* res, T* y, const float* gamma, con
 template <typename T, int V, int ACT>
 static int bn_bwd_launch_act(const T* dy, const T* x, const T* y, T* dx, T* dres, const float* gamma, const float* beta,
                              const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ws, int N, int C,
-                             int HW, hipStream_t s) {
+                             int HW, const float* ps, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
     COT_LAUNCH((bn_bwd_reduce<T, V, ACT>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma,
-               beta, ws, N, C, HW, nper);
-    if (g_bn_fold) {
+               beta, ws, N, C, HW, nper, ps);
+    if (g_bn_fold || ps) {
         COT_LAUNCH((bn_apply_bwd_fold<T, V, ACT>), dim3(C, split), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma,
-                   beta, (const float*)ws, dgamma, dbeta, N, C, HW, nper, 1.0f / (float)((int64_t)N * HW));
+                   beta, (const float*)ws, dgamma, dbeta, N, C, HW, nper, 1.0f / (float)((int64_t)N * HW), ps);
         return check_launch("bn_act_backward");
     }
     COT_LAUNCH(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
@@ -498,8 +501,8 @@ static int bn_bwd_launch_act(const T* dy, const T* x, const T* y, T* dx, T* dres
 template <typename T, int V>
 static int bn_bwd_launch(const T* dy, const T* x, const T* y, T* dx, T* dres, const float* gamma, const float* beta,
                          const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ws, int N, int C,
-                         int HW, int act, hipStream_t s) {
-#define BN_BA(A_) return bn_bwd_launch_act<T, V, A_>(dy, x, y, dx, dres, gamma, beta, mean, rstd, dgamma, dbeta, ws, N, C, HW, s)
+                         int HW, int act, const float* ps, hipStream_t s) {
+#define BN_BA(A_) return bn_bwd_launch_act<T, V, A_>(dy, x, y, dx, dres, gamma, beta, mean, rstd, dgamma, dbeta, ws, N, C, HW, ps, s)
     if (act == ACT_RELU && y) BN_BA(ACT_RELU_Y);  // sign of the saved output (required when there was a residual)
     if (act == ACT_RELU) BN_BA(ACT_RELU);
     if (act == ACT_SILU) BN_BA(ACT_SILU);
@@ -683,7 +686,8 @@ __global__ __launch_bounds__(1024) void bn_chan_fwd(const T* __restrict__ x, con
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float* __restrict__ mean, float* __restrict__ rstd,
                                                    float* __restrict__ rmean, float* __restrict__ rvar,
-                                                   long long* __restrict__ nbt, int N, int C, int HW, float eps, float mom) {
+                                                   long long* __restrict__ nbt, int N, int C, int HW, float eps, float mom,
+                                                   const float* __restrict__ ps) {
     constexpr int R = ChanRounds<T, V, false>::value;
     __shared__ double red[16];
     const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
@@ -736,9 +740,10 @@ __global__ __launch_bounds__(1024) void bn_chan_fwd(const T* __restrict__ x, con
         if (off[r] >= 0) {
             Vec<T, V> rv, o;
             if (res) rv = ldv<T, V>(res + off[r]);
+            const float sc = ps ? ps[(r * NT + t) / vpp] : 1.f;  // (stochastic depth: per-sample scale of the normalised branch)
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                float z = (float)xv[r].v[k] * a + b;
+                float z = ((float)xv[r].v[k] * a + b) * sc;
                 if (res) z += (float)rv.v[k];
                 o.v[k] = (T)act_fwd<ACT>(z);
             }
@@ -751,7 +756,7 @@ __global__ __launch_bounds__(1024) void bn_chan_bwd(const T* __restrict__ dy, co
                                                    T* __restrict__ dx, T* __restrict__ dres, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, int N, int C, int HW) {
+                                                   float* __restrict__ dbeta, int N, int C, int HW, const float* __restrict__ ps) {
     constexpr int R = ChanRounds<T, V, true>::value;
     __shared__ double red[32];
     const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
@@ -775,10 +780,11 @@ __global__ __launch_bounds__(1024) void bn_chan_bwd(const T* __restrict__ dy, co
 #pragma unroll
                 for (int k = 0; k < V; ++k) dv[r].v[k] = (float)yv.v[k] > 0.f ? dv[r].v[k] : (T)0.f;
             }
+            const float sc = ps ? ps[n] : 1.f;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const float xh = ((float)xv[r].v[k] - m) * rs;
-                const float g = ACT == ACT_RELU_Y ? (float)dv[r].v[k] : act_bwd<ACT>((float)dv[r].v[k], xh * ga + be);
+                const float g = sc * (ACT == ACT_RELU_Y ? (float)dv[r].v[k] : act_bwd<ACT>((float)dv[r].v[k], xh * ga + be));
                 sg += g;
                 sgx += g * xh;
             }
@@ -796,11 +802,12 @@ __global__ __launch_bounds__(1024) void bn_chan_bwd(const T* __restrict__ dy, co
     for (int r = 0; r < R; ++r)
         if (off[r] >= 0) {
             Vec<T, V> o, og;
+            const float sc = ps ? ps[(r * NT + t) / vpp] : 1.f;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const float xh = ((float)xv[r].v[k] - m) * rs;
                 const float g = ACT == ACT_RELU_Y ? (float)dv[r].v[k] : act_bwd<ACT>((float)dv[r].v[k], xh * ga + be);
-                o.v[k] = (T)(gr * (g - k1 - xh * k2));
+                o.v[k] = (T)(gr * (sc * g - k1 - xh * k2));
                 og.v[k] = (T)g;
             }
             stv<T, V>(dx + off[r], o);
@@ -837,9 +844,9 @@ template <typename T, bool BWD> static int bn_chan_rounds(int V) {
 template <typename T>
 int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* mean,
                    float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW, float eps,
-                   float mom, int act, hipStream_t s) {
-#define BN_F(VV) return bn_fwd_launch<T, VV>((const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, ws, N, C, HW, eps, mom, act, s)
-    if ((int64_t)N * HW <= g_bn_small_m) {
+                   float mom, int act, const float* ps, hipStream_t s) {
+#define BN_F(VV) return bn_fwd_launch<T, VV>((const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, ws, N, C, HW, eps, mom, act, ps, s)
+    if ((int64_t)N * HW <= g_bn_small_m && !ps) {
         const dim3 grid(C), block(64);  // one wave per channel
 #define BN_SF(A_) COT_LAUNCH((bn_small_fwd<T, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom)
         if (act == ACT_RELU) BN_SF(ACT_RELU);
@@ -850,7 +857,7 @@ int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, 
     }
     if (const int cv = bn_chan_vec<T, false>(N, C, HW)) {
         const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, false>(cv)));
-#define BN_CF(V_, A_) COT_LAUNCH((bn_chan_fwd<T, V_, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom)
+#define BN_CF(V_, A_) COT_LAUNCH((bn_chan_fwd<T, V_, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom, ps)
 #define BN_CFV(V_)                                \
     do {                                          \
         if (act == ACT_RELU) BN_CF(V_, ACT_RELU); \
@@ -875,9 +882,9 @@ int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, 
 template <typename T>
 int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dres, const float* gamma,
                     const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ws,
-                    int N, int C, int HW, int act, hipStream_t s) {
-#define BN_B(VV) return bn_bwd_launch<T, VV>((const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, ws, N, C, HW, act, s)
-    if ((int64_t)N * HW <= g_bn_small_m) {
+                    int N, int C, int HW, int act, const float* ps, hipStream_t s) {
+#define BN_B(VV) return bn_bwd_launch<T, VV>((const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, ws, N, C, HW, act, ps, s)
+    if ((int64_t)N * HW <= g_bn_small_m && !ps) {
         const dim3 grid(C), block(64);  // one wave per channel
 #define BN_SB(A_) COT_LAUNCH((bn_small_bwd<T, A_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, rstd, dgamma, dbeta, N, C, HW)
         if (act == ACT_RELU && y) BN_SB(ACT_RELU_Y);
@@ -889,7 +896,7 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
     }
     if (const int cv = bn_chan_vec<T, true>(N, C, HW)) {
         const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, true>(cv)));
-#define BN_CB(V_, A_) COT_LAUNCH((bn_chan_bwd<T, V_, A_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW)
+#define BN_CB(V_, A_) COT_LAUNCH((bn_chan_bwd<T, V_, A_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW, ps)
 #define BN_CBV(V_)                                         \
     do {                                                   \
         if (act == ACT_RELU && y) BN_CB(V_, ACT_RELU_Y);   \
@@ -913,13 +920,14 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
 }
 
 template int bn_act_forward<float>(const void*, const void*, void*, const float*, const float*, float*, float*, float*,
-                                   float*, long long*, float*, int, int, int, float, float, int, hipStream_t);
+                                   float*, long long*, float*, int, int, int, float, float, int, const float*, hipStream_t);
 template int bn_act_forward<bf16_t>(const void*, const void*, void*, const float*, const float*, float*, float*, float*,
-                                    float*, long long*, float*, int, int, int, float, float, int, hipStream_t);
+                                    float*, long long*, float*, int, int, int, float, float, int, const float*, hipStream_t);
 template int bn_act_backward<float>(const void*, const void*, const void*, void*, void*, const float*, const float*,
-                                    const float*, const float*, float*, float*, float*, int, int, int, int, hipStream_t);
+                                    const float*, const float*, float*, float*, float*, int, int, int, int, const float*,
+                                    hipStream_t);
 template int bn_act_backward<bf16_t>(const void*, const void*, const void*, void*, void*, const float*, const float*,
-                                     const float*, const float*, float*, float*, float*, int, int, int, int,
+                                     const float*, const float*, float*, float*, float*, int, int, int, int, const float*,
                                      hipStream_t);
 
 }  // namespace cot

@@ -102,13 +102,13 @@ int bn_workspace_floats(int N, int C);
 extern int g_bn_fold, g_bn_grid_cap, g_bn_small_m;
 template <typename T>
 int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, long long*,
-                   float*, int, int, int, float, float, int, hipStream_t);
+                   float*, int, int, int, float, float, int, const float*, hipStream_t);
 template <typename T>
 int bn_act_inference(const void*, const void*, void*, const float*, const float*, const float*, const float*, int, int, int,
                      float, int, hipStream_t);
 template <typename T>
 int bn_act_backward(const void*, const void*, const void*, void*, void*, const float*, const float*, const float*,
-                    const float*, float*, float*, float*, int, int, int, int, hipStream_t);
+                    const float*, float*, float*, float*, int, int, int, int, const float*, hipStream_t);
 template <typename T>
 int agg_softmax_forward_nchw(const T*, const T*, T*, T*, const cot_agg_geom&, hipStream_t);
 template <typename T>
@@ -839,10 +839,10 @@ int cot_input_normalize(const void* x_u8, void* y, const float* mean, const floa
 
 int cot_bn_act_workspace(int N, int C) { return (N > 0 && C > 0) ? bn_workspace_floats(N, C) : 0; }
 
-int cot_bn_act_forward(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
-                       float* save_mean, float* save_rstd, float* running_mean, float* running_var,
-                       int64_t* num_batches_tracked, float* workspace, int N, int C, int HW, float eps, float momentum,
-                       int act, int dtype, void* stream) {
+int cot_bn_act_forward_ps(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                          float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                          int64_t* num_batches_tracked, float* workspace, const float* sample_scale, int N, int C, int HW,
+                          float eps, float momentum, int act, int dtype, void* stream) {
     if (!x || !y || !gamma || !beta || !save_mean || !save_rstd || !workspace)
         return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act");
@@ -853,16 +853,22 @@ int cot_bn_act_forward(const void* x, const void* residual, void* y, const float
     hipStream_t s = (hipStream_t)stream;
     if (dtype == COT_F32)
         return bn_act_forward<float>(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var,
-                                     (long long*)num_batches_tracked, workspace, N, C, HW, eps, momentum, act, s);
+                                     (long long*)num_batches_tracked, workspace, N, C, HW, eps, momentum, act, sample_scale, s);
     if (dtype == COT_BF16)
         return bn_act_forward<bf16_t>(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var,
-                                      (long long*)num_batches_tracked, workspace, N, C, HW, eps, momentum, act, s);
+                                      (long long*)num_batches_tracked, workspace, N, C, HW, eps, momentum, act, sample_scale, s);
     return set_error(COT_ERR_UNSUPPORTED, "bn_act: dtype %d (float32 / bfloat16 only)", dtype);
 }
-
-int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
-                        const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
-                        float* workspace, int N, int C, int HW, int act, int dtype, void* stream) {
+int cot_bn_act_forward(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                       float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, float* workspace, int N, int C, int HW, float eps, float momentum,
+                       int act, int dtype, void* stream) {
+    return cot_bn_act_forward_ps(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var,
+                                 num_batches_tracked, workspace, NULL, N, C, HW, eps, momentum, act, dtype, stream);
+}
+int cot_bn_act_backward_ps(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
+                           const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                           float* workspace, const float* sample_scale, int N, int C, int HW, int act, int dtype, void* stream) {
     if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace)
         return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if (act == 1 && !y && dresidual)
@@ -873,11 +879,17 @@ int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == COT_F32)
         return bn_act_backward<float>(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
-                                      workspace, N, C, HW, act, s);
+                                      workspace, N, C, HW, act, sample_scale, s);
     if (dtype == COT_BF16)
         return bn_act_backward<bf16_t>(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
-                                       workspace, N, C, HW, act, s);
+                                       workspace, N, C, HW, act, sample_scale, s);
     return set_error(COT_ERR_UNSUPPORTED, "bn_act: dtype %d (float32 / bfloat16 only)", dtype);
+}
+int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
+                        const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                        float* workspace, int N, int C, int HW, int act, int dtype, void* stream) {
+    return cot_bn_act_backward_ps(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta, workspace, NULL,
+                                  N, C, HW, act, dtype, stream);
 }
 
 int cot_bn_act_inference(const void* x, const void* residual, void* y, const float* gamma, const float* beta,

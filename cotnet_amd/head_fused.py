@@ -37,13 +37,17 @@ def _ck(rc, what):
 
 class _Head(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, drop_p=0.0):
         L = _lib.lib()
         N, C, H, W = x.shape
         O = weight.shape[0]
         st = _stream()
         gapT = torch.empty((C, N), dtype=x.dtype, device=x.device)
         _ck(L.cot_radix_gap_t(_p(x), None, _p(gapT), N, C, H * W, BF16, st), "cot_radix_gap_t")
+        ctx.mask = None
+        if drop_p > 0.0:  # F.dropout on the pooled descriptor (reference recipe: drop 0.25): C x N elements, two tiny launches
+            ctx.mask = (torch.rand((C, N), dtype=torch.float32, device=x.device) >= drop_p).to(x.dtype).div_(1.0 - drop_p)
+            gapT = gapT * ctx.mask
         logT = torch.empty((O, N), dtype=x.dtype, device=x.device)
         _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(weight), _p(bias), _p(logT), 1, C, O, N, BF16, st),
             "cot_conv1x1_forward")
@@ -71,8 +75,10 @@ class _Head(Function):
         gb = torch.empty(O, dtype=weight.dtype, device=g.device) if ctx.has_bias else None
         _ck(L.cot_conv1x1_backward_weight(_p(gT), _p(gapT), None, C, _p(gw), _p(gb), _p(ws), 1, C, O, N, BF16, st),
             "cot_conv1x1_backward_weight")
+        if ctx.mask is not None:
+            ggapT = ggapT * ctx.mask
         gx = (ggapT.t().float() / (H * W)).to(g.dtype).reshape(N, C, 1, 1).expand(N, C, H, W)  # d mean_hw
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def eligible(pool, fc, x):
@@ -83,8 +89,12 @@ def eligible(pool, fc, x):
             and fc.out_features % 8 == 0 and x.data_ptr() % 16 == 0)
 
 
-def head(pool, fc, x):
-    """fc(pool(x)); see the module docstring for when the library kernels serve it"""
+def head(pool, fc, x, drop_p=0.0):
+    """fc(dropout(pool(x), drop_p)); see the module docstring for when the library kernels serve it (drop_p: the caller
+    passes 0 outside training, models/resnet.py:607-609)"""
     if MODE == "hip" and eligible(pool, fc, x):
-        return _Head.apply(x, fc.weight, fc.bias)
-    return fc(pool(x))
+        return _Head.apply(x, fc.weight, fc.bias, float(drop_p))
+    x = pool(x)
+    if drop_p > 0.0:
+        x = torch.nn.functional.dropout(x, p=float(drop_p), training=True)
+    return fc(x)

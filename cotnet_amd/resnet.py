@@ -9,6 +9,7 @@ every CoT recipe leaves it at 0).
 import torch.nn.functional as F
 from torch import nn
 
+from . import cot_layer_fused
 from .fused_bn import fused_bn_act
 from .layers import AvgPool2dSame, DropPath, create_classifier
 from .pool3x3 import pool
@@ -161,6 +162,7 @@ class ResNet(nn.Module):
         self.global_pool, self.fc = create_classifier(self.num_features, self.num_classes, pool_type=global_pool)
 
     def forward_features(self, x):
+        cot_layer_fused.prepare_drop_path(self, x)  # (single-node blocks: one vectorised stochastic-depth draw per step)
         if isinstance(self.act1, nn.ReLU):
             x = fused_bn_act(stem_conv(self.conv1, x), self.bn1, "relu")  # stem BN + ReLU in one pass over 112x112
         else:
@@ -170,7 +172,5 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         x = self.forward_features(x)
-        if not self.drop_rate:
-            return head(self.global_pool, self.fc, x)  # fc(global_pool(x)), on the library's kernels when opted in
-        x = F.dropout(self.global_pool(x), p=float(self.drop_rate), training=self.training)
-        return self.fc(x)
+        # fc(dropout(global_pool(x))) (models/resnet.py:605-611), on the library's kernels when eligible
+        return head(self.global_pool, self.fc, x, float(self.drop_rate) if (self.drop_rate and self.training) else 0.0)

@@ -347,6 +347,17 @@ int cot_bn_act_forward(const void* x, const void* residual, void* y, const float
 int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
                         const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                         float* workspace, int N, int C, int HW, int act, int dtype, void* stream);
+/* The same with stochastic depth folded in (models/cotnet.py:250-262 bn3 -> drop_path -> += residual -> act3; models/layers/
+ * drop.py:140-168): `sample_scale` [N] fp32 on the device holds, per sample, 0 (path dropped) or 1 / keep_prob:
+ *     y = act(sample_scale[n] * (gamma*(x-mean_c)*rstd_c + beta) + residual)
+ * backward: dresidual = dy*act', the BatchNorm backward runs on sample_scale[n] * dy*act'.  NULL = no scaling. */
+int cot_bn_act_forward_ps(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                          float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                          int64_t* num_batches_tracked, float* workspace, const float* sample_scale, int N, int C, int HW,
+                          float eps, float momentum, int act, int dtype, void* stream);
+int cot_bn_act_backward_ps(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
+                           const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                           float* workspace, const float* sample_scale, int N, int C, int HW, int act, int dtype, void* stream);
 /* inference mode (nn.BatchNorm2d.eval()): y = act(gamma*(x - running_mean)/sqrt(running_var + eps) + beta [+ residual]) in one
  * pass; nothing is updated. */
 int cot_bn_act_inference(const void* x, const void* residual, void* y, const float* gamma, const float* beta,

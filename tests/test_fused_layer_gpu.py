@@ -93,3 +93,61 @@ def test_single_node_bottleneck_against_fp32_truth(kind):
     truth.check_against_truth(blk, x, g, cand=truth.SINGLE_NODE)
     *_, node = truth.run(blk, x, g, want_module=True, **truth.SINGLE_NODE)
     assert node.startswith("_BottleneckNode")
+
+
+class _FixedDropPath(torch.nn.Module):
+    """stochastic depth with a GIVEN per-sample scale (0 or 1 / keep): what models/layers/drop.py:140-168 computes, minus the draw"""
+
+    def __init__(self, scale, p):
+        super().__init__()
+        self.drop_prob = p
+        self.register_buffer("fixed_scale", scale)
+
+    def forward(self, x):
+        return x * self.fixed_scale.view(-1, 1, 1, 1).to(x.dtype) if self.training else x
+
+
+@pytest.mark.parametrize("kind,hw", [("identity", 28), ("project", 14), ("stride2", 28), ("identity", 7)])
+def test_single_node_bottleneck_with_stochastic_depth_against_fp32_truth(kind, hw):
+    """the reference recipe's drop_path (config.yaml:21-26) on the single-node path: the per-sample scale is folded into the
+    bn3 + residual + ReLU kernels (cot_bn_act_*_ps: streaming at 28 x 28, channel-resident at 14 x 14 / 7 x 7); same mask in
+    the fp32 truth, the baseline (module per op) and the candidate"""
+    from cotnet_amd.resnet import downsample_conv
+    torch.manual_seed(11)
+    stride = 2 if kind == "stride2" else 1
+    inpl = 256 if kind == "identity" else 128
+    ds = None if kind == "identity" else downsample_conv(inpl, 256, 1, stride=stride)
+    N, keep = 8, 0.75
+    scale = torch.tensor([0, 1, 1, 0, 1, 1, 1, 0], dtype=torch.float32, device=DEV) / keep
+    blk = Bottleneck(inpl, 64, stride=stride, downsample=ds, drop_path=_FixedDropPath(scale, 1 - keep)).to(DEV).train()
+    with torch.no_grad():
+        blk.bn3.weight.fill_(0.8)
+    blk = to_mixed_bf16(blk)
+    x = torch.randn(N, inpl, hw, hw, device=DEV).bfloat16()
+    g = torch.randn(N, 256, hw // stride, hw // stride, device=DEV).bfloat16()
+    truth.check_against_truth(blk, x, g, cand=truth.SINGLE_NODE)
+    y, _, _, _, node = truth.run(blk, x, g, want_module=True, **truth.SINGLE_NODE)
+    assert node.startswith("_BottleneckNode")
+    if kind == "identity":  # a dropped sample passes relu(x) on
+        assert torch.equal(y[0], torch.relu(x[0].float()))
+
+
+def test_recipe_model_runs_on_the_single_node_path():
+    """cotnet50 built with the reference recipe's regularisation (drop 0.25, drop_path 0.1): every Bottleneck is still one
+    autograd node, the head applies its dropout on the library path, one step trains"""
+    import cotnet_amd
+    torch.manual_seed(0)
+    model = to_mixed_bf16(cotnet_amd.create_model("cotnet50", num_classes=1000, drop_rate=0.25, drop_path_rate=0.1).to(DEV)).train()
+    x = torch.randn(4, 3, 224, 224, device=DEV).bfloat16()
+    t = torch.randint(0, 1000, (4,), device=DEV)
+    with truth.switches(**truth.SINGLE_NODE):
+        names = []
+        hooks = [m.register_forward_hook(lambda mod, i, o: names.append(o.grad_fn.name() if o.grad_fn is not None else ""))
+                 for m in model.modules() if isinstance(m, Bottleneck)]
+        logits = model(x)
+        loss = torch.nn.functional.cross_entropy(logits.float(), t)
+        loss.backward()
+        for h in hooks:
+            h.remove()
+    assert len(names) == 16 and all(n.startswith("_BottleneckNode") for n in names)
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad.float()).all() for p in model.parameters())

@@ -344,6 +344,51 @@ def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold):
         assert ((dres.float() - rr.grad).abs() <= gtol * (1 + rr.grad.abs())).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(6, 8, 7, 7), (5, 16, 14, 14), (12, 2, 28, 28), (30, 2, 7, 7), (4, 3, 3, 3)])
+@pytest.mark.parametrize("path", ["stream", "chan"])
+def test_bn_act_with_stochastic_depth(N, C, H, W, dtype, path):
+    """cot_bn_act_forward_ps / _backward_ps: y = relu(s_n * bn(x) + residual) with a per-sample scale s_n in {0, 1 / keep}
+    (models/cotnet.py:250-262 with models/layers/drop.py:140-168) against torch autograd in fp32 on the same inputs -- the
+    streaming kernels (the scale forces the image-by-image form; tiny tensors leave the fp64 small-batch path) and the
+    channel-resident ones"""
+    assert _EMUL.cot_set_tuning(21, 1 if path == "chan" else 0) == 0 and _EMUL.cot_set_tuning(18, 256) == 0
+    g = torch.Generator().manual_seed(N + C * H)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.7).to(dtype)
+    res = torch.randn(N, C, H, W, generator=g).to(dtype)
+    dy = torch.randn(N, C, H, W, generator=g).to(dtype)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    keep = 0.8
+    ps = (torch.rand(N, generator=g) < keep).float() / keep
+    ps[0], ps[1] = 0.0, 1.0 / keep  # both kinds present
+    xr, rr = x.float().requires_grad_(True), res.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    yr = torch.relu(z * ps.view(N, 1, 1, 1) + rr)
+    yr.backward(dy.float())
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(C), torch.empty(C)
+    ws = torch.empty(_EMUL.cot_bn_act_workspace(N, C))
+    dt = _lib.dtype_code(dtype)
+    rc = _EMUL.cot_bn_act_forward_ps(P(x), P(res), P(y), P(gamma), P(beta), P(mean), P(rstd), None, None, None, P(ws), P(ps),
+                                     N, C, H * W, 1e-5, 0.1, 1, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert ((y.float() - yr.detach()).abs() <= tol * (1 + yr.detach().abs())).all()
+    assert torch.equal(y[0].float(), torch.relu(res[0].float()).to(dtype).float())  # a dropped sample passes its residual on
+    dx, dres = torch.empty_like(x), torch.empty_like(x)
+    dgamma, dbeta = torch.empty(C), torch.empty(C)
+    rc = _EMUL.cot_bn_act_backward_ps(P(dy), P(x), P(y), P(dx), P(dres), P(gamma), P(beta), P(mean), P(rstd), P(dgamma),
+                                      P(dbeta), P(ws), P(ps), N, C, H * W, 1, dt, None)
+    assert rc == 0, _EMUL.cot_last_error()
+    if dtype == torch.bfloat16:
+        return  # (ReLU mask from the rounded output: gradients are checked in fp32)
+    gtol = 1e-4
+    assert ((dx - xr.grad).abs() <= gtol * (1 + xr.grad.abs())).all()
+    assert ((dres - rr.grad).abs() <= gtol * (1 + rr.grad.abs())).all()
+    assert torch.allclose(dgamma, gr.grad, rtol=1e-3, atol=1e-3) and torch.allclose(dbeta, br.grad, rtol=1e-3, atol=1e-3)
+
+
 @pytest.mark.parametrize("H", [8, 7])
 def test_ring_depth_choice_does_not_change_results(H):
     """tuning key 14 moves the launch size from which the convolutions use the shallow register ring: shallow everywhere
@@ -1295,7 +1340,8 @@ def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(m
     assert abs(loss_a - loss_b) < 2e-2 * abs(loss_a)
     for ga, gb in zip(grads_a, grads_b):
         assert torch.isfinite(gb).all()
-        assert (ga - gb).abs().mean() < 0.2 * ga.abs().mean()
+        # (bn3.weight starts at zero: a 10 MiB bucket that holds only weights INSIDE the residual branches is exactly zero)
+        assert (ga - gb).abs().mean() <= 0.2 * ga.abs().mean()
     for cache in caches:
         cache.clear()
 
