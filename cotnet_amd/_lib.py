@@ -58,6 +58,7 @@ SYMBOLS = {
     "cot_aggmix_backward_weight": (_I, [_P, _P, _P, _P, _G, _I, _I, _I, _P]),
     "cot_set_tuning": (_I, [_I, _I]),
     "cot_xchg_mode": (_I, []),
+    "cot_launch_log": (_I, [ctypes.c_char_p, _I]),
     "cot_radix_gap": (_I, [_P, _P, _P, ctypes.c_int64, _I, _I, _P]),
     "cot_radix_mix": (_I, [_P, _P, _P, _P, ctypes.c_int64, _I, _I, _P]),
     "cot_radix_mix_backward": (_I, [_P] * 7 + [ctypes.c_int64, _I, _I, _P]),

@@ -27,7 +27,7 @@ from torch.autograd import Function
 
 from . import _lib
 
-MODE = os.environ.get("COT_CONV1X1", "")
+MODE = os.environ.get("COT_CONV1X1", "hip")  # default: the library's kernels; COT_CONV1X1=module opts out
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
 
 

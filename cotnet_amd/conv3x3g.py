@@ -16,7 +16,7 @@ from torch.autograd import Function
 
 from . import _lib
 
-MODE = os.environ.get("COT_CONV3X3", "")
+MODE = os.environ.get("COT_CONV3X3", "hip")  # default: the library's kernels; COT_CONV3X3=module opts out
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
 
 _MASKS = {}  # (H, W, device) -> uint8 tensor holding the per-pixel tap-validity table (read-only after creation)

@@ -28,7 +28,7 @@ from torch.autograd import Function
 
 from . import _lib, grad_sink
 
-ENABLED = os.environ.get("COT_FUSED_LAYER", "") == "1"
+ENABLED = os.environ.get("COT_FUSED_LAYER", "1") != "0"  # default on; COT_FUSED_LAYER=0 = one autograd node per op
 _DEVICE_ONLY = True  # tests drive the node on CPU tensors through the host-emulated kernels
 BF16 = _lib.COT_BF16
 

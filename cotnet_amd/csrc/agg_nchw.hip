@@ -883,6 +883,7 @@ int set_tuning_nchw(int key, int value) {
 // One-time device probe: does v_mov_b32_dpp wave_shr:1 / wave_shl:1 move data the way the v2 kernels assume?
 int xchg_mode() {
     if (g_tune[3] >= 0) return g_tune[3];
+    if (g_dry_run) return 0;  // (no device to probe: report the path every MI355X takes)
     static const int probed = []() {
         int* d = nullptr;
         if (hipMalloc((void**)&d, 128 * sizeof(int)) != hipSuccess) return 1;

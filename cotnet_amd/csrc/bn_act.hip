@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-int g_bn_fold = 0;          // cot_set_tuning key 12
+int g_bn_fold = 1;          // cot_set_tuning key 12 (default on since round 3: 202 fewer launches per CoTNet-50 step, profiles/r02_bn_fold_ab.txt)
 int g_bn_grid_cap = 4096;  // cot_set_tuning key 13: most workgroups of a flat (grid-stride) BatchNorm apply kernel
 static inline int pick_vec(size_t esize, int HW) {
     int lim = (int)(16 / esize);

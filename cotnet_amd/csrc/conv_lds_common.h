@@ -12,6 +12,7 @@ namespace cot {
 // calling launch function's own static bit mask (one per kernel instantiation).  Returns false when the runtime refuses --
 // the caller then reports "not covered" and the previous kernel generation runs instead of an opaque launch failure.
 inline bool raise_dynamic_lds_once(std::atomic<uint32_t>& raised, const void* func) {
+    if (g_dry_run) return true;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
     if ((raised.load(std::memory_order_relaxed) >> dev) & 1u) return true;

@@ -10,6 +10,8 @@
 #include <mutex>
 #include <vector>
 
+#include <string>
+
 #include "cot_common.h"
 
 namespace cot {
@@ -25,7 +27,16 @@ int set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+int g_dry_run = 0;
+static thread_local std::string t_dry_log;
+void dry_note(const char* where, const char* kernel, dim3 grid, dim3 block, size_t shmem) {
+    char buf[768];
+    snprintf(buf, sizeof(buf), "%s | %s | grid %u x %u | block %u | lds %zu\n", kernel, where, grid.x, grid.y, block.x, shmem);
+    t_dry_log += buf;
+}
+
 int check_launch(const char* what) {
+    if (g_dry_run) return COT_OK;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(COT_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return COT_OK;
@@ -325,6 +336,10 @@ int cot_set_tuning(int key, int value) {
         g_conv_lds2_tune = value;
         return COT_OK;
     }
+    if (key == 26) {  // dry run: record launches instead of issuing them (see cot_launch_log)
+        g_dry_run = value ? 1 : 0;
+        return COT_OK;
+    }
     if (key == 25) {
         g_wgrad2_tune = value;
         return COT_OK;
@@ -348,7 +363,15 @@ int cot_set_tuning(int key, int value) {
     if (set_tuning_nchw(key, value) != 0) return set_error(COT_ERR_INVALID_ARG, "unknown tuning key %d", key);
     return COT_OK;
 }
-int cot_xchg_mode(void) { return xchg_mode(); }
+int cot_xchg_mode(void) { return g_dry_run ? 0 : xchg_mode(); }
+int cot_launch_log(char* buf, int cap) {
+    if (!buf || cap <= 0) return (int)t_dry_log.size();
+    const int n = (int)std::min<size_t>(t_dry_log.size(), (size_t)cap - 1);
+    memcpy(buf, t_dry_log.data(), n);
+    buf[n] = 0;
+    t_dry_log.clear();
+    return n;
+}
 /* DIAGNOSTIC (not in the header's contract): device buffer of 8 x uint64 per workgroup the instrumented kernels (third-generation
  * weight gradient) write s_memtime stamps into; NULL switches it off */
 int cot_debug_stamps(void* device_buffer) {

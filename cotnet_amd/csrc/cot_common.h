@@ -61,9 +61,20 @@ void end_launch(const char* name, hipEvent_t e0, hipEvent_t e1);
 }  // namespace prof
 }  // namespace cot
 
+// Dry run (cot_set_tuning key 26 = 1): nothing is launched and no HIP API is called; every would-be launch is appended to a
+// thread-local log instead -- the launcher's instantiation (__PRETTY_FUNCTION__ carries the template arguments), the kernel's
+// source name, grid and block -- which cot_launch_log() hands out.  This is how the dispatch table (which kernel variant
+// every layer of the BASELINE configurations takes) is pinned by a test that needs no GPU (tests/test_dispatch_table.py).
+namespace cot {
+extern int g_dry_run;
+void dry_note(const char* where, const char* kernel, dim3 grid, dim3 block, size_t shmem);
+}  // namespace cot
+
 #define COT_LAUNCH(KERNEL, GRID, BLOCK, SHMEM, STREAM, ...)                                             \
     do {                                                                                                \
-        if (cot::prof::enabled_for(#KERNEL)) {                                                          \
+        if (cot::g_dry_run) {                                                                           \
+            cot::dry_note(__PRETTY_FUNCTION__, #KERNEL, GRID, BLOCK, SHMEM);                            \
+        } else if (cot::prof::enabled_for(#KERNEL)) {                                                   \
             hipEvent_t e0_, e1_;                                                                        \
             cot::prof::begin_launch(&e0_, &e1_);                                                        \
             hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, e0_, e1_, 0, __VA_ARGS__);        \

@@ -13,7 +13,7 @@ from torch.autograd import Function
 
 from . import _lib
 
-MODE = os.environ.get("COT_GN9", "")
+MODE = os.environ.get("COT_GN9", "hip")  # default: the library's kernel; COT_GN9=module opts out
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
 
 

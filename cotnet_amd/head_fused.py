@@ -16,7 +16,7 @@ from torch.autograd import Function
 
 from . import _lib, grad_sink
 
-MODE = os.environ.get("COT_HEAD", "")
+MODE = os.environ.get("COT_HEAD", "hip")  # default: the library's kernels; COT_HEAD=module opts out
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
 BF16 = _lib.COT_BF16
 _WS = _lib.register_cache({})

@@ -16,7 +16,7 @@ from torch.autograd import Function
 
 from . import _lib
 
-MODE = os.environ.get("COT_POOL", "")
+MODE = os.environ.get("COT_POOL", "hip")  # default: the library's kernels; COT_POOL=module opts out
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
 _DT = {torch.float32: _lib.COT_F32, torch.bfloat16: _lib.COT_BF16}
 

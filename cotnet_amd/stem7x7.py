@@ -16,7 +16,7 @@ from torch.autograd import Function
 
 from . import _lib, grad_sink
 
-MODE = os.environ.get("COT_STEM", "")
+MODE = os.environ.get("COT_STEM", "hip")  # default: the library's kernels; COT_STEM=module opts out
 _DEVICE_ONLY = True  # tests drive the autograd wiring on CPU tensors through the host-emulated kernels
 _WS = _lib.register_cache({})
 

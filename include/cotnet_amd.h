@@ -127,7 +127,7 @@ const char* cot_last_kernel(void);
  *   key 9: 1x1-convolution kernels XCD-aware wave order (0|1)   key 10: 16-row tiles per wave, forward (0 auto|2|4)
  *   key 11: weight-gradient target wave count (sizes the split of the reduction AND therefore cot_*_workspace: query the
  *           workspace after setting it); negative = force -value splits
- *   key 12: BatchNorm: fold the per-channel finalize step into the apply kernels (0|1; one launch less each way)
+ *   key 12: BatchNorm: fold the per-channel finalize step into the apply kernels (1 default | 0; one launch less each way)
  *   key 13: BatchNorm: most workgroups of the flat (grid-stride) apply kernels (default 4096; <= 0 restores it)
  *   key 14: convolutions: launches of at least this many waves use the shallow register ring (default 8192;
  *           a huge value = deep rings everywhere, 1 = shallow everywhere; <= 0 restores the default)
@@ -148,8 +148,13 @@ const char* cot_last_kernel(void);
  *   key 25: third-generation 1x1 weight gradient (conv_wgrad2.hip) bit field -- bit 0 off, bit 1 fragment prefetch, bit 2 old
  *           LDS chunk permutation, bit 3 eight stages, bit 4 general reduce kernel only, bits 8..15 partial-sum cap in % of the
  *           input bytes (0 = 100), bits 16..23 target workgroups per CU x 4 (0 = 4), bits 24..30 forced slice count (tests)
+ *   key 26: dry run (1): no kernel is launched, no HIP call is made; launches are recorded for cot_launch_log()
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
+/* Dry-run log of the calling thread (cot_set_tuning(26, 1)): one line per launch the library WOULD have issued --
+ * "kernel | launcher instantiation | grid | block | lds".  Copies up to cap-1 bytes into buf (NUL-terminated), clears the log
+ * and returns the bytes copied; buf == NULL returns the pending size.  Used to pin the dispatch table without a GPU. */
+int cot_launch_log(char* buf, int cap);
 /* 0 if the device probe confirmed the DPP wave_shr/wave_shl semantics the v2 kernels rely on, 1 if the
  * library fell back to ds_bpermute.  Launches a 64-thread probe kernel on the null stream on first call. */
 int cot_xchg_mode(void);
