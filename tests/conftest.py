@@ -73,6 +73,9 @@ AGG_FIXTURES = ["agg_selftest_k5_heads2", "agg_selftest_k1_heads2", "agg_config1
 MIX_FIXTURES = ["agg_mix_selftest", "agg_mix_heads2"]
 LAYER_FIXTURES = ["layer_cotlayer_d32", "layer_coxtlayer_d32", "layer_cotlayer_d64_7x7"]
 MODEL_FIXTURES = ["model_cotnet50", "model_cotnext50_2x48d", "model_se_cotnetd_50"]
+# CoTNet-50's four stage geometries at B = 2 (compact fixtures: weights from the seed, outputs at sampled positions + sums)
+REAL_LAYER_FIXTURES = ["layer_cotlayer_s1_64x56", "layer_cotlayer_s2_128x28", "layer_cotlayer_s3_256x14", "layer_cotlayer_s4_512x7"]
+K_OUT, K_GRAD = 16384, 8192
 
 
 def randomize_norm_state(module, rng):
@@ -96,3 +99,53 @@ def layer_case(gold):
     x = rng_tensor(rng, (meta["B"], meta["dim"], meta["H"], meta["W"]), torch.float32)
     gout = rng_tensor(rng, (meta["B"], meta["dim"], meta["H"], meta["W"]), torch.float32)
     return meta, sd, x, gout
+
+
+def sample_idx(n, k):
+    """positions a compact fixture stores (tests/golden/make_golden.sample_idx)"""
+    return np.unique(np.linspace(0, n - 1, min(n, k)).astype(np.int64))
+
+
+def real_layer_case(gold):
+    """-> (meta, layer with the reference's weights, x, gout) for a compact layer fixture: same seed + same construction order
+    give the reference's initial weights (checked against the fixture's per-parameter fp64 sums), the normalisation state and
+    the inputs come from the stored numpy seed exactly as the generator drew them"""
+    meta = json.loads(str(gold["meta"]))
+    seed = int(gold["seed"])
+    from cotnet_amd import cotnet
+    rng = np.random.Generator(np.random.PCG64(seed))
+    torch.manual_seed(seed)
+    layer = getattr(cotnet, meta["cls"])(meta["dim"], 3).float()
+    for m in layer.modules():  # tests/golden/make_golden.randomize_norm_state, same draws in the same order
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.GroupNorm)):
+            with torch.no_grad():
+                m.weight.copy_(torch.from_numpy(1.0 + 0.2 * rng.standard_normal(m.weight.shape)).to(m.weight.dtype))
+                m.bias.copy_(torch.from_numpy(0.1 * rng.standard_normal(m.bias.shape)).to(m.bias.dtype))
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.copy_(torch.from_numpy(0.1 * rng.standard_normal(m.running_mean.shape)))
+                    m.running_var.copy_(torch.from_numpy(1.0 + 0.2 * rng.random(m.running_var.shape)))
+    for k, v in layer.state_dict().items():
+        if v.is_floating_point():
+            want = meta["probe"][k]
+            assert abs(float(v.double().sum()) - want) <= 1e-6 * max(1.0, abs(want)), f"weights differ from the reference's: {k}"
+    x = rng_tensor(rng, (meta["B"], meta["dim"], meta["H"], meta["W"]), torch.float32)
+    gout = rng_tensor(rng, (meta["B"], meta["dim"], meta["H"], meta["W"]), torch.float32)
+    return meta, layer, x, gout
+
+
+def check_real_layer(gold, mode, layer, y, gx, tol=1e-3):
+    """compare a run of `layer` with the compact fixture: sampled positions at `tol` (scaled by the tensor's magnitude for the
+    parameter gradients, as the small-layer tests do) and the full-tensor sums"""
+    tensors = {"y": y, "gx": gx, "g_embed3_w": layer.embed[3].weight.grad, "g_embed0_w": layer.embed[0].weight.grad,
+               "g_key0_w": layer.key_embed[0].weight.grad, "g_conv1x1_w": layer.conv1x1[0].weight.grad,
+               "g_bn_w": layer.bn.weight.grad}
+    for key, t in tensors.items():
+        flat = t.detach().float().cpu().reshape(-1)
+        idx = sample_idx(flat.numel(), K_OUT if key in ("y", "gx") else K_GRAD)
+        ref = torch.from_numpy(gold[f"{mode}_{key}"])
+        scale = max(1.0, float(gold[f"{mode}_{key}_absmax"]))
+        err = (flat[idx] - ref).abs().max().item()
+        assert err <= tol * scale, (mode, key, err, scale)
+        # the whole tensor through its sum: an error outside the sampled positions moves it (bound: n terms of size tol)
+        dsum = abs(flat.double().sum().item() - float(gold[f"{mode}_{key}_sum"]))
+        assert dsum <= tol * scale * max(1.0, flat.numel() ** 0.5), (mode, key, "sum", dsum)

@@ -211,6 +211,58 @@ def make_layer_fixtures(ref_cotnet):
         print(f"layer_{name}: y {out['eval_y'].shape}")
 
 
+# CoTNet-50's four stage geometries ((C, H) = (64, 56), (128, 28), (256, 14), (512, 7)), B = 2.  Full tensors would
+# be ~30 MB of fixtures, so these are COMPACT: the weights are not stored (same seed + same construction order = the
+# reference's initial weights; per-parameter fp64 sums are stored as a probe), and outputs / gradients are stored at K evenly
+# spaced flat positions plus their full fp64 sums.
+REAL_LAYER_CASES = [
+    ("cotlayer_s1_64x56", "CotLayer", 64, 2, 56, 56, 51),
+    ("cotlayer_s2_128x28", "CotLayer", 128, 2, 28, 28, 52),
+    ("cotlayer_s3_256x14", "CotLayer", 256, 2, 14, 14, 53),
+    ("cotlayer_s4_512x7", "CotLayer", 512, 2, 7, 7, 54),
+]
+K_OUT, K_GRAD = 16384, 8192
+
+
+def sample_idx(n, k):
+    return np.unique(np.linspace(0, n - 1, min(n, k)).astype(np.int64))
+
+
+def make_real_layer_fixtures(ref_cotnet):
+    for name, cls, dim, B, H, W, seed in REAL_LAYER_CASES:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        torch.manual_seed(seed)
+        layer = getattr(ref_cotnet, cls)(dim, 3).float()
+        randomize_norm_state(layer, rng)
+        state = {k: v.clone() for k, v in layer.state_dict().items()}
+        probe = {k: float(v.double().sum()) for k, v in state.items() if v.is_floating_point()}
+        x = rng_tensor(rng, (B, dim, H, W), torch.float32)
+        gout = rng_tensor(rng, (B, dim, H, W), torch.float32)
+        out = {}
+        for mode in ("eval", "train"):
+            layer.load_state_dict(state)
+            layer.train(mode == "train")
+            layer.zero_grad()
+            xin = x.clone().requires_grad_(True)
+            y = layer(xin)
+            y.backward(gout)
+            tensors = {"y": y.detach(), "gx": xin.grad, "g_embed3_w": layer.embed[3].weight.grad,
+                       "g_embed0_w": layer.embed[0].weight.grad, "g_key0_w": layer.key_embed[0].weight.grad,
+                       "g_conv1x1_w": layer.conv1x1[0].weight.grad, "g_bn_w": layer.bn.weight.grad}
+            for key, t in tensors.items():
+                flat = t.detach().reshape(-1)
+                idx = sample_idx(flat.numel(), K_OUT if key in ("y", "gx") else K_GRAD)
+                out[f"{mode}_{key}"] = flat[idx].numpy().copy()
+                out[f"{mode}_{key}_sum"] = np.float64(flat.double().sum().item())
+                out[f"{mode}_{key}_absmax"] = np.float64(flat.abs().max().item())
+            if mode == "train":
+                out["train_bn_running_mean"] = layer.bn.running_mean.numpy().copy()
+                out["train_bn_running_var"] = layer.bn.running_var.numpy().copy()
+        np.savez_compressed(os.path.join(HERE, f"layer_{name}.npz"), seed=np.int64(seed),
+                            meta=json.dumps(dict(cls=cls, dim=dim, B=B, H=H, W=W, compact=True, probe=probe)), **out)
+        print(f"layer_{name}: {os.path.getsize(os.path.join(HERE, f'layer_{name}.npz')) / 1e3:.0f} KB")
+
+
 MODEL_CASES = [
     # entry point, input size, seed
     ("cotnet50", 64, 41),
@@ -253,7 +305,12 @@ def make_model_fixtures(models):
 
 if __name__ == "__main__":
     assert build_ref.reference_available(), "the reference checkout is required to regenerate fixtures"
-    make_op_fixtures()
+    if "--real-layers-only" not in sys.argv:
+        make_op_fixtures()
     models, ref_cotnet, ref_hybrid = import_reference_models()
+    if "--real-layers-only" in sys.argv:
+        make_real_layer_fixtures(ref_cotnet)
+        sys.exit(0)
     make_layer_fixtures(ref_cotnet)
+    make_real_layer_fixtures(ref_cotnet)
     make_model_fixtures(models)

@@ -16,7 +16,8 @@ import torch
 import cotnet_amd
 from cotnet_amd import cotnet
 from oracle import unfold_oracle
-from tests.conftest import GOLDEN, LAYER_FIXTURES, MODEL_FIXTURES, layer_case, load_golden, rng_tensor
+from tests.conftest import (GOLDEN, LAYER_FIXTURES, MODEL_FIXTURES, REAL_LAYER_FIXTURES, check_real_layer, layer_case, load_golden,
+                            real_layer_case, rng_tensor)
 
 README_PARAMS_M = {  # reference README.md:45-52
     "cotnet50": 22.2, "cotnext50_2x48d": 30.1, "cotnet101": 38.3, "cotnext101_2x48d": 53.4,
@@ -96,6 +97,24 @@ def test_layer_wiring_matches_reference_fixture(name, oracle_aggregation):
             assert (p.grad - ref).abs().max() <= tol * max(1.0, ref.abs().max().item())
     assert (layer.bn.running_mean - torch.from_numpy(gold["train_bn_running_mean"])).abs().max() < 1e-5
     assert (layer.bn.running_var - torch.from_numpy(gold["train_bn_running_var"])).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("name", REAL_LAYER_FIXTURES)
+def test_layer_wiring_at_the_real_stage_geometries(name, oracle_aggregation):
+    """CoTNet-50's four stage geometries (B = 2) against fixtures of the reference's CotLayer: the module wiring on CPU (the
+    aggregation is the oracle here; tests/test_layers_gpu.py runs the same fixtures on the HIP kernels)"""
+    gold = load_golden(name)
+    meta, layer, x, gout = real_layer_case(gold)
+    state = {k: v.clone() for k, v in layer.state_dict().items()}
+    for mode in ("eval", "train"):
+        layer.load_state_dict(state)
+        layer.train(mode == "train")
+        layer.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        y = layer(xin)
+        y.backward(gout)
+        check_real_layer(gold, mode, layer, y, xin.grad)
+    assert (layer.bn.running_mean - torch.from_numpy(gold["train_bn_running_mean"])).abs().max() < 1e-5
 
 
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
