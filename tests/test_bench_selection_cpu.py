@@ -7,6 +7,8 @@ import bench
 
 
 def _args():
+    import os
+    os.environ["COT_NO_PROBE_CACHE"] = "1"  # (these tests fake the child: no verdict may be read from / written to the cache)
     return types.SimpleNamespace(batch=80, img=224, model="cotnet50")
 
 
@@ -158,7 +160,51 @@ def test_probe_rejects_a_kernel_set_with_a_broken_convolution(monkeypatch, capsy
         rec = out["sets"][name]
         assert "error" not in rec, rec
         assert not rec["parity"], (name, rec)
-        assert rec["worst_param_ratio_to_round1"] > bench.GATE_PARAM or rec["worst_bucket_ratio_to_round1"] > bench.GATE_BUCKET
+        assert rec["worst_block_ratio_to_gate"] > 1.0 and rec["worst_block"].startswith("layer1."), rec
+
+
+def test_block_gate_rejects_a_gradient_of_the_right_magnitude_and_accepts_honest_noise():
+    """VERDICT r2 weak #1a: round 2's whole-model gate compared noise with noise (both kernel sets ~1.3 from the fp32 truth: a
+    set emitting garbage of the right magnitude passed `<= 1.5 x round1`).  The per-block gate on tensors of a real block's
+    size (stage 1 of CoTNet-50 at B = 16): a candidate whose input gradient is a PERMUTATION of the true one -- same
+    magnitude, same distribution, wrong values -- is rejected; a candidate with independent noise of round1's size is accepted."""
+    import torch
+    torch.manual_seed(0)
+    shape = (16, 256, 56, 56)
+    truth_rec = {"layer1.0": {"x": torch.randn(shape), "gy": torch.randn(shape), "y": torch.randn(shape).relu_(),
+                              "gx": torch.randn(shape), "gp": {"conv1.weight": torch.randn(64, 256, 1, 1)}}}
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.conv3, self.bn3 = torch.nn.Conv2d(256, 64, 1, bias=False), None, None
+    model = torch.nn.Module()
+    model.layer1 = torch.nn.Sequential(Blk())
+
+    def noisy(rel, seed):
+        def run(name, r):
+            g = torch.Generator().manual_seed(seed)
+            n = lambda t: t + rel * t.abs().mean() * 1.2533 * torch.randn(t.shape, generator=g)  # mean |noise| = rel * mean |t|
+            return n(r["y"]), n(r["gx"]), {k: n(v) for k, v in r["gp"].items()}
+        return run
+
+    def garbage(name, r):
+        y, _, gp = noisy(0.05, 3)(name, r)
+        gx = r["gx"].reshape(-1)[torch.randperm(r["gx"].numel(), generator=torch.Generator().manual_seed(5))].view_as(r["gx"])
+        return y, gx, gp
+    ref = bench.block_errors(model, truth_rec, noisy(0.05, 1))
+    good = bench.block_errors(model, truth_rec, noisy(0.06, 2))
+    bad = bench.block_errors(model, truth_rec, garbage)
+    assert abs(ref["layer1.0"][1] - 0.05) < 5e-3 and bad["layer1.0"][1] > 1.0  # a permutation sits ~1.13 from the truth
+    rec = {}
+    bench.block_gate(rec, good, ref)
+    assert rec["parity"] and rec["finite"], rec
+    bench.block_gate(rec, bad, ref)
+    assert not rec["parity"] and rec["worst_block"] == "layer1.0.gx" and rec["worst_block_ratio_to_gate"] > 10, rec
+    nan = {k: v for k, v in good.items()}
+    nan["layer1.0"] = good["layer1.0"][:3] + (False,)
+    bench.block_gate(rec, nan, ref)
+    assert not rec["parity"]
 
 
 def test_verdict_reaches_every_rank_through_the_rendezvous_store():
