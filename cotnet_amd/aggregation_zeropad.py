@@ -89,7 +89,21 @@ def profile_end(max_records=65536):
     out = []
     for r in buf[:n]:
         g = r.geom
-        if g.kh == 0:  # a non-aggregation launch of the library (fused BatchNorm / SGD): duration only
+        if g.kh == 0 and r.kind >= 10:  # a convolution / BatchNorm call (cot_abi.hip annotate_op): algorithmic bytes of the CALL
+            N, Ci, Co, HW, G = g.N, g.C, g.W, g.H, max(g.heads, 1)
+            e = torch.empty((), dtype=dts[r.dtype]).element_size()
+            name = {10: "conv1x1_fwd", 11: "conv1x1_dgrad", 12: "conv1x1_wgrad", 13: "conv3x3g_fwd", 14: "conv3x3g_dgrad",
+                    15: "conv3x3g_wgrad", 20: "bn_fwd", 21: "bn_bwd"}[r.kind]
+            if r.kind < 20:
+                taps = 9 if r.kind >= 13 else 1
+                nbytes = e * (N * HW * (Ci + Co) + taps * Ci * Co // G)   # activations in + out (or in + in), the weights once
+            elif r.kind == 20:
+                nbytes = e * N * Ci * HW * (2 + (r.flags & 1))              # x read, y written (+ residual read)
+            else:
+                nbytes = e * N * Ci * HW * (3 + (r.flags & 1) + ((r.flags >> 1) & 1))  # dy, x read, dx written (+ dres, + y)
+            out.append(("op:" + name, (N, Ci, Co, HW, G, r.flags, 0), dts[r.dtype], 0, float(r.ms), nbytes, r.kernel.decode()))
+            continue
+        if g.kh == 0:  # another launch of the library (SGD, pooling, ...): duration only
             out.append(("other", (0, 0, 0, 0, 0, 0, 0), None, 0, float(r.ms), 0, r.kernel.decode()))
             continue
         dt = dts[r.dtype]

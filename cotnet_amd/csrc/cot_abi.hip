@@ -90,6 +90,15 @@ static void annotate(const cot_agg_geom& g, int dtype, int layout, int kind, int
         g_recs[i].pub.flags = flags;
     }
 }
+// non-aggregation ops (kh == 0 marks them): kind 10/11/12 = 1x1 convolution forward / data gradient / weight gradient,
+// 13/14/15 = grouped 3x3, 20/21 = BatchNorm(+act) forward / backward; geom.N = N, .C = input channels, .W = output channels,
+// .H = pixels per image, .heads = groups, flags = op-specific (BatchNorm: bit 0 residual, bit 1 saved output read)
+static void annotate_op(int kind, int N, int Ci, int Co, int HW, int groups, int dtype, int flags) {
+    cot_agg_geom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.C = Ci; g.W = Co; g.H = HW; g.heads = groups;
+    annotate(g, dtype, 0, kind, flags);
+}
 }  // namespace prof
 
 // implemented in agg_nchw.hip / agg_nhwc.hip / agg_mix.hip
@@ -426,7 +435,7 @@ int64_t cot_conv1x1_workspace(int N, int Ci, int Co, int HW, int has_bias) {
     return ((wt > part ? wt : part) + 255) / 256 * 256;
 }
 
-int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, int N,
+static int cot_conv1x1_forward_impl(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, int N,
                         int Ci, int Co, int HW, int dtype, void* stream) {
     int rc = conv1x1_validate(N, Ci, Co, HW, c1, x2 != nullptr, dtype, Ci);
     if (rc) return rc;
@@ -440,8 +449,16 @@ int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weig
     }
     return conv1x1_gemm(x1, x2, c1, weight, bias, y, nullptr, Co, N, Ci, Co, HW, 0, 0, (hipStream_t)stream);
 }
+int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, int N,
+                        int Ci, int Co, int HW, int dtype, void* stream) {
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_conv1x1_forward_impl(x1, x2, c1, weight, bias, y, N, Ci, Co, HW, dtype, stream);
+    if (p) prof::annotate_op(10, N, Ci, Co, HW, 1, dtype, 0);
+    return rc;
+}
 
-int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, int accumulate,
+static int cot_conv1x1_backward_data_impl(const void* gy, const void* weight, void* gx1, void* gx2, int c1, int accumulate,
                               void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream) {
     int rc = conv1x1_validate(N, Ci, Co, HW, c1, gx2 != nullptr, dtype, Co);
     if (rc) return rc;
@@ -469,8 +486,16 @@ int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, voi
     return conv1x1_gemm(gy, nullptr, Co, weight, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3, 1,
                         (hipStream_t)stream);
 }
+int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, int accumulate,
+                              void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream) {
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_conv1x1_backward_data_impl(gy, weight, gx1, gx2, c1, accumulate, workspace, N, Ci, Co, HW, dtype, stream);
+    if (p) prof::annotate_op(11, N, Ci, Co, HW, 1, dtype, 0);
+    return rc;
+}
 
-int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, int c1, void* gweight, void* gbias,
+static int cot_conv1x1_backward_weight_impl(const void* gy, const void* x1, const void* x2, int c1, void* gweight, void* gbias,
                                 void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream) {
     int rc = conv1x1_validate(N, Ci, Co, HW, c1, x2 != nullptr, dtype, 8);
     if (rc) return rc;
@@ -488,6 +513,14 @@ int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, 
     if (conv1x1_wgrad_lds_covers(N, HW, Co, Ci) && !g_conv_lds_tune_wgrad_off())
         return conv1x1_wgrad_lds_run(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
     return conv1x1_wgrad(gy, x1, x2, c1, gweight, gbias, (float*)workspace, N, Ci, Co, HW, (hipStream_t)stream);
+}
+int cot_conv1x1_backward_weight(const void* gy, const void* x1, const void* x2, int c1, void* gweight, void* gbias,
+                                void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream) {
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_conv1x1_backward_weight_impl(gy, x1, x2, c1, gweight, gbias, workspace, N, Ci, Co, HW, dtype, stream);
+    if (p) prof::annotate_op(12, N, Ci, Co, HW, 1, dtype, 0);
+    return rc;
 }
 
 static int conv3x3g_validate(int N, int Cin, int Cout, int G, int H, int W, int dtype, int kdim_per_group) {
@@ -523,7 +556,7 @@ int64_t cot_conv3x3g_workspace(int N, int Cin, int Cout, int groups, int H, int 
     return ((wb > part ? wb : part) + 255) / 256 * 256;
 }
 
-int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void* masks, void* workspace, int N, int Cin,
+static int cot_conv3x3g_forward_impl(const void* x, const void* weight, void* y, const void* masks, void* workspace, int N, int Cin,
                          int Cout, int groups, int H, int W, int dtype, void* stream) {
     int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, Cin / (groups > 0 ? groups : 1));
     if (rc) return rc;
@@ -535,8 +568,16 @@ int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void*
     if (rc != -1) return rc;
     return conv3x3g_gemm(x, weight, y, masks, N, Cin, Cout, groups, H, W, 0, 0, (hipStream_t)stream);
 }
+int cot_conv3x3g_forward(const void* x, const void* weight, void* y, const void* masks, void* workspace, int N, int Cin,
+                         int Cout, int groups, int H, int W, int dtype, void* stream) {
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_conv3x3g_forward_impl(x, weight, y, masks, workspace, N, Cin, Cout, groups, H, W, dtype, stream);
+    if (p) prof::annotate_op(13, N, Cin, Cout, H * W, groups, dtype, 0);
+    return rc;
+}
 
-int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int accumulate, const void* masks,
+static int cot_conv3x3g_backward_data_impl(const void* gy, const void* weight, void* gx, int accumulate, const void* masks,
                                void* workspace, int N, int Cin, int Cout, int groups, int H, int W, int dtype,
                                void* stream) {
     int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, Cout / (groups > 0 ? groups : 1));
@@ -550,8 +591,17 @@ int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int
     if (rc != -1) return rc;
     return conv3x3g_gemm(gy, weight, gx, masks, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
 }
+int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int accumulate, const void* masks,
+                               void* workspace, int N, int Cin, int Cout, int groups, int H, int W, int dtype,
+                               void* stream) {
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_conv3x3g_backward_data_impl(gy, weight, gx, accumulate, masks, workspace, N, Cin, Cout, groups, H, W, dtype, stream);
+    if (p) prof::annotate_op(14, N, Cin, Cout, H * W, groups, dtype, 0);
+    return rc;
+}
 
-int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
+static int cot_conv3x3g_backward_weight_impl(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
                                  int Cin, int Cout, int groups, int H, int W, int dtype, void* stream) {
     int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, 8);
     if (rc) return rc;
@@ -561,6 +611,14 @@ int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, c
         return convg_backward_weight(gy, x, gweight, nullptr, (float*)workspace, N, Cin, Cout, groups, H, W, 3, dtype,
                                      (hipStream_t)stream);
     return conv3x3g_wgrad(gy, x, gweight, masks, (float*)workspace, N, Cin, Cout, groups, H, W, (hipStream_t)stream);
+}
+int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
+                                 int Cin, int Cout, int groups, int H, int W, int dtype, void* stream) {
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_conv3x3g_backward_weight_impl(gy, x, gweight, masks, workspace, N, Cin, Cout, groups, H, W, dtype, stream);
+    if (p) prof::annotate_op(15, N, Cin, Cout, H * W, groups, dtype, 0);
+    return rc;
 }
 
 int cot_agg_softmax_forward(const void* x, const void* logits, void* out, void* probs, const cot_agg_geom* g, int dtype,
@@ -862,7 +920,7 @@ int cot_input_normalize(const void* x_u8, void* y, const float* mean, const floa
 
 int cot_bn_act_workspace(int N, int C) { return (N > 0 && C > 0) ? bn_workspace_floats(N, C) : 0; }
 
-int cot_bn_act_forward_ps(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+static int cot_bn_act_forward_ps_impl(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                           float* save_mean, float* save_rstd, float* running_mean, float* running_var,
                           int64_t* num_batches_tracked, float* workspace, const float* sample_scale, int N, int C, int HW,
                           float eps, float momentum, int act, int dtype, void* stream) {
@@ -882,6 +940,16 @@ int cot_bn_act_forward_ps(const void* x, const void* residual, void* y, const fl
                                       (long long*)num_batches_tracked, workspace, N, C, HW, eps, momentum, act, sample_scale, s);
     return set_error(COT_ERR_UNSUPPORTED, "bn_act: dtype %d (float32 / bfloat16 only)", dtype);
 }
+int cot_bn_act_forward_ps(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                          float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                          int64_t* num_batches_tracked, float* workspace, const float* sample_scale, int N, int C, int HW,
+                          float eps, float momentum, int act, int dtype, void* stream) {
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_bn_act_forward_ps_impl(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var, num_batches_tracked, workspace, sample_scale, N, C, HW, eps, momentum, act, dtype, stream);
+    if (p) prof::annotate_op(20, N, C, C, HW, 1, dtype, (residual ? 1 : 0));
+    return rc;
+}
 int cot_bn_act_forward(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                        float* save_mean, float* save_rstd, float* running_mean, float* running_var,
                        int64_t* num_batches_tracked, float* workspace, int N, int C, int HW, float eps, float momentum,
@@ -889,7 +957,7 @@ int cot_bn_act_forward(const void* x, const void* residual, void* y, const float
     return cot_bn_act_forward_ps(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var,
                                  num_batches_tracked, workspace, NULL, N, C, HW, eps, momentum, act, dtype, stream);
 }
-int cot_bn_act_backward_ps(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
+static int cot_bn_act_backward_ps_impl(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
                            const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                            float* workspace, const float* sample_scale, int N, int C, int HW, int act, int dtype, void* stream) {
     if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace)
@@ -907,6 +975,15 @@ int cot_bn_act_backward_ps(const void* dy, const void* x, const void* y, void* d
         return bn_act_backward<bf16_t>(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
                                        workspace, N, C, HW, act, sample_scale, s);
     return set_error(COT_ERR_UNSUPPORTED, "bn_act: dtype %d (float32 / bfloat16 only)", dtype);
+}
+int cot_bn_act_backward_ps(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
+                           const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                           float* workspace, const float* sample_scale, int N, int C, int HW, int act, int dtype, void* stream) {
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_bn_act_backward_ps_impl(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta, workspace, sample_scale, N, C, HW, act, dtype, stream);
+    if (p) prof::annotate_op(21, N, C, C, HW, 1, dtype, (dresidual ? 1 : 0) | (y ? 2 : 0));
+    return rc;
 }
 int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
                         const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,

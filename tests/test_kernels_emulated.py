@@ -809,6 +809,7 @@ def test_input_normalize_matches_the_reference_loader_arithmetic(shape):
 
 
 def test_conv1x1_lds_kernel_is_the_one_that_runs():
+    torch.manual_seed(8)
     x = torch.randn(1, 64, 16, 16).bfloat16()
     w = torch.randn(32, 64).bfloat16()
     y = torch.zeros(1, 32, 16, 16).bfloat16()
@@ -816,7 +817,8 @@ def test_conv1x1_lds_kernel_is_the_one_that_runs():
     assert _EMUL.cot_set_tuning(15, 1) == 0
     assert _EMUL.cot_conv1x1_lds_covers(64, 64, 0, 256) == 1 and _EMUL.cot_conv1x1_lds_covers(40, 40, 0, 256) == 0
     assert _EMUL.cot_conv1x1_forward(P(x), None, 64, P(w), None, P(y), 1, 64, 32, 256, dt, None) == 0
-    assert (y.float() - torch.einsum("oc,nchw->nohw", w.float(), x.float())).abs().max() < 0.1
+    ref = torch.einsum("oc,nchw->nohw", w.float(), x.float())
+    assert (y.float() - ref).abs().max() < 0.01 * ref.abs().max()  # (one bf16 rounding of outputs up to ~30)
 
 
 def test_conv1x1_rejects_what_it_does_not_cover():
