@@ -28,7 +28,7 @@
 
 namespace cot {
 
-// cot_set_tuning key 25: bit 0 = off (second-generation kernels instead); bit 1 = fragment prefetch on; bit 2 = the old
+// cot_set_tuning key 25: bit 0 = off (second-generation kernels instead); bit 1 = fragment prefetch OFF; bit 2 = the old
 // chunk permutation (A/B of the bank-conflict fix); bits 8..15 = partial-sum cap in percent of the input bytes (0 = 100);
 // bits 16..23 = target workgroups per CU x 4 (0 = 4, i.e. one); bits 24..30 = forced slice count (tests)
 int g_wgrad2_tune = 0;
@@ -52,11 +52,15 @@ struct Wg2Args {
                                  // stores issued, end) + the XCC id; NULL in production
 };
 
-template <int WM, int AM, int AJ, int NS, int PF>
-__global__ __launch_bounds__(512, 4) void conv1x1_wgrad_lds2(const Wg2Args a) {  // (<= 128 registers: two workgroups per CU)
-    constexpr int WJ = 8 / WM, TM = WM * AM * 16, TJ = WJ * AJ * 16;
+// WAVES = 8 (one workgroup per CU fills it) or 4: three 48 KB workgroups per CU, each with its own barrier -- their copy /
+// fragment-read / MFMA phases fall out of step with each other, which is the only overlap a barrier-per-step loop gets
+// (phase stamps, profiles/r03_wgrad_phase_stamps.log: per step ~240 cycles issuing two copies, ~350 waiting for the six
+// fragment reads that all eight waves issue at once, ~300 issuing MFMAs, strictly one after the other)
+template <int WAVES, int WM, int AM, int AJ, int NS, int PF>
+__global__ __launch_bounds__(64 * WAVES, 4) void conv1x1_wgrad_lds2(const Wg2Args a) {  // (<= 128 registers)
+    constexpr int WJ = WAVES / WM, TM = WM * AM * 16, TJ = WJ * AJ * 16;
     constexpr int RBM = TM / 16, RBJ = TJ / 16, RB = RBM + RBJ;  // 16-row blocks of the dY / X parts of a stage
-    constexpr int G = (RB + 7) / 8;                               // copies per wave and stage
+    constexpr int G = (RB + WAVES - 1) / WAVES;                   // copies per wave and stage
     constexpr int STG = RB * 512;                                 // elements per stage ([RB * 16 rows][32 pixels])
     static_assert((NS - 1) * G <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_wgrad_lds2(const Wg2Args a) { 
     const int nst = t1 - t0;
     auto f = [&](int row) { return a.oldswz ? ((row >> 2) & 3) : ((-(row >> 2)) & 3); };
 
-    // ---- this wave's copies: 16-row block rb = wave + 8 i (blocks past the stage: block RB-1 again, same bytes to the same place)
+    // ---- this wave's copies: 16-row block rb = wave + WAVES i (blocks past the stage: block RB-1 again, same bytes to the same place)
     unsigned voff[G], voffl[G];   // per-lane byte offsets: ordinary steps (base = image row + step), last step of an image (base = image row)
     const bf16_t* img[G];         // scalar: row r0 of the copy's block in the image being staged
     int64_t istr[G];              // scalar: elements from one image to the next in that tensor
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_wgrad_lds2(const Wg2Args a) { 
         const int rowl = lane >> 2, pos = lane & 3;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const int rb = min(wave + 8 * i, RB - 1);
+            const int rb = min(wave + WAVES * i, RB - 1);
             const int ch = pos ^ f(rb * 16 + rowl);  // the 8-pixel chunk of the step this lane fetches
             int r0, r;
             const bf16_t* base;
@@ -240,17 +244,30 @@ __global__ __launch_bounds__(512, 4) void conv1x1_wgrad_lds2(const Wg2Args a) { 
         int slot = 0, fill = NS - 1;
         auto step = [&](auto steady, int ks) __attribute__((always_inline)) {
             constexpr bool STEADY = decltype(steady)::value;
+            // DIAGNOSTIC: phase stamps of steps 8..15 of workgroup 0 (records 2048.. of the stamps buffer): 0 loop top, 1 copies
+            // of the stage landed, 2 barrier passed, 3 copies issued, 4 fragments in registers, 5 MFMAs issued
+            const bool tr = a.stamps && blockIdx.x == 0 && ks >= 8 && ks < 16;
+            unsigned long long* const tp = a.stamps + (size_t)(2048 + (tr ? ks - 8 : 0)) * 8 - (size_t)blockIdx.x * 8;
+            if (tr) COT_STAMP(tp, 0);
             if (!(abl & 16)) {
                 if (STEADY) COT_WAIT_VM((NS - 2) * G);
                 else WaitBehind<G, NS - 2>::go(min(NS - 2, nst - 1 - ks));  // this wave's copies of stage ks have landed
             }
+            if (tr) COT_STAMP(tp, 1);
             if (!(abl & 8)) COT_LDS_BARRIER();                     // everybody's have; nobody still reads stage ks-1's slot
+            if (tr) COT_STAMP(tp, 2);
             if ((STEADY || ks + NS - 1 < nst) && !(abl & 1)) stage(fill);
             fill = fill + 1 == NS ? 0 : fill + 1;
+            if (tr) COT_STAMP(tp, 3);
             uint32_t yq[AM][4], xq[AJ][4];
             read_frags((abl & 2) ? 0 : slot, yq, xq);
             slot = slot + 1 == NS ? 0 : slot + 1;
+            if (tr) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the fragments have arrived
+                COT_STAMP(tp, 4);
+            }
             multiply(yq, xq);
+            if (tr) COT_STAMP(tp, 5);
         };
         int ks = 0;
         if (nst > NS) {  // (the first step apart, so that the arrival of the first data can be stamped)
@@ -310,8 +327,8 @@ static inline int wgrad2_shape(int M, int Jp, int* TM, int* TJ) {
     if (M <= 32 && Jp > 64) s = 4;
     else if (M <= 64) s = Jp <= 64 ? 3 : 1;
     else if (Jp <= 64) s = 2;
-    else s = 0;
-    static const int tm[5] = {128, 64, 256, 64, 32}, tj[5] = {128, 256, 64, 64, 128};
+    else s = ((g_wgrad2_tune >> 5) & 1) ? 5 : 0;  // (bit 5: 64 x 128 tiles on four-wave workgroups, three per CU)
+    static const int tm[6] = {128, 64, 256, 64, 32, 64}, tj[6] = {128, 256, 64, 64, 128, 128};
     *TM = tm[s];
     *TJ = tj[s];
     return s;
@@ -340,6 +357,7 @@ int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias) {
     // two per CU / partial sums <= 50 % of the inputs 2475, one per CU 2250, one per CU and <= 100 % 2121 (second
     // generation: 2747) -- every extra slice is another M x J fp32 matrix written and read again
     int64_t S = ceil_div64((int64_t)64 * (per_cu4 > 0 ? per_cu4 : 4), tiles);
+    if (((g_wgrad2_tune >> 5) & 1) && TM == 64 && TJ == 128 && !per_cu4) S = ceil_div64(768, tiles);  // three small workgroups per CU
     const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
     const int pct = (g_wgrad2_tune >> 8) & 255;
     const int64_t cap = in_bytes * (pct > 0 ? pct : 100) / 100 / out_bytes;  // partial sums are written once and read once
@@ -385,14 +403,14 @@ static int wgrad2_reduce(const float* part, int S, int M, int J, int has_bias, v
     return conv1x1_wgrad_reduce_launch(part, S, M, J, has_bias, gw, gb, stream);
 }
 
-template <int WM, int AM, int AJ, int PF, int NS>
+template <int WM, int AM, int AJ, int PF, int NS, int WAVES = 8>
 static int launch_wg2(const Wg2Args& a, int64_t blocks, hipStream_t stream) {
-    constexpr int WJ = 8 / WM, RB = WM * AM + WJ * AJ;
+    constexpr int WJ = WAVES / WM, RB = WM * AM + WJ * AJ;
     const size_t lds = (size_t)NS * RB * 1024;
     static std::atomic<uint32_t> raised{0};
-    if (lds > 64 * 1024 && !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv1x1_wgrad_lds2<WM, AM, AJ, NS, PF>)))
+    if (lds > 64 * 1024 && !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv1x1_wgrad_lds2<WAVES, WM, AM, AJ, NS, PF>)))
         return -1;
-    COT_LAUNCH((conv1x1_wgrad_lds2<WM, AM, AJ, NS, PF>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    COT_LAUNCH((conv1x1_wgrad_lds2<WAVES, WM, AM, AJ, NS, PF>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
     return check_launch("conv1x1_wgrad_lds2");
 }
 
@@ -418,13 +436,14 @@ int conv1x1_wgrad2_run(const void* gy, const void* x1, const void* x2, int k1, v
     a.stamps = g_debug_stamps;
     const int64_t blocks = (int64_t)a.jtiles * a.mtiles * a.S;
     a.xcd_remap = blocks % 8 == 0;
-    const bool pf = (g_wgrad2_tune >> 1) & 1;
+    const bool pf = !((g_wgrad2_tune >> 1) & 1);  // fragment prefetch: default on (2272 -> 2089 us per step over CoTNet-50's layers, profiles/r03_wgrad_pf_ab.log)
     int rc;
     const bool deep = (g_wgrad2_tune >> 3) & 1;  // bit 3: eight stages (one workgroup per CU, seven stages in flight) instead of four
 #define COT_WG2(WM_, AM_, AJ_)                                                                              \
     (pf ? launch_wg2<WM_, AM_, AJ_, 1, 4>(a, blocks, stream)                                               \
         : (deep ? launch_wg2<WM_, AM_, AJ_, 0, 8>(a, blocks, stream) : launch_wg2<WM_, AM_, AJ_, 0, 4>(a, blocks, stream)))
     switch (shape) {
+        case 5: rc = pf ? launch_wg2<1, 4, 2, 1, 4, 4>(a, blocks, stream) : launch_wg2<1, 4, 2, 0, 4, 4>(a, blocks, stream); break;
         case 0: rc = COT_WG2(2, 4, 2); break;
         case 1: rc = COT_WG2(1, 4, 2); break;
         case 2: rc = COT_WG2(4, 4, 2); break;

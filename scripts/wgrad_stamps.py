@@ -67,13 +67,19 @@ def main():
         t0 = t[:, 0].min()
         span = (t[:, 5].max() - t0).item()
         # ticks per microsecond: s_memtime runs at a fixed 100 MHz on gfx9 family parts
-        tpu = 100.0
+        tpu = 1.0
         d = (t[:, 1:6] - t[:, 0:5]) / tpu
         med, mx = d.median(0).values.tolist(), d.max(0).values.tolist()
         skew = ((t[:, 0] - t0) / tpu).max().item()
         xcc = torch.bincount(s[:, 7].clamp(0, 15), minlength=8).tolist()
-        print(f"{name:26s} {wall:8.1f} {len(s):5d} | " + "  ".join(f"{a:5.1f}/{b:5.1f}" for a, b in zip(med, mx)) +
-              f" | skew {skew:5.1f}  kernel span {span / tpu:6.1f} us  per-XCC {xcc}")
+        print(f"{name:26s} {wall:8.1f} {len(s):5d} | " + "  ".join(f"{a:5.1f}/{b:5.1f}" for a, b in zip(med, mx)) + "  (x100 ticks)")
+        ph = stamps.view(-1, 8)[2048:2056, :6].cpu().double()
+        if (ph[:, 0] != 0).all():
+            d = ph[:, 1:] - ph[:, :-1]
+            nxt = ph[1:, 0] - ph[:-1, 5]
+            print("      step phases (ticks, wave 0 of workgroup 0, steps 8..15): wait-copies | barrier | issue copies | fragments | issue MFMAs ; to next top")
+            for i in range(8):
+                print("      " + "  ".join(f"{int(v):6d}" for v in d[i].tolist()) + (f"  ; {int(nxt[i]):6d}" if i < 7 else ""))
 
 
 if __name__ == "__main__":

@@ -352,6 +352,7 @@ inline emul_s16x4 emul_read_tr16(const void* p) {
 #define COT_LDS_BARRIER() emul::block_barrier()
 #define COT_SCHED_FENCE() ((void)0)
 #define COT_STAMP(p, i) ((void)0)
+inline void __builtin_amdgcn_s_waitcnt(int) {}
 
 #define COT_MFMA_16X16X32_BF16(a, b, c) emul::mfma_16x16x32_bf16((a), (b), (c))
 #define COT_MFMA_16X16X4_F32(a, b, c) emul::mfma_16x16x4_f32((a), (b), (c))

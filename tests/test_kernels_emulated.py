@@ -645,7 +645,8 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits, request):
     (7, 96, 80, 7, 7, 0, False),      # odd image count, slices cut inside images
     (2, 256, 128, 4, 8, 0, False),    # 32768 outputs: forced slice counts take the wide (four outputs per lane) reduce kernel
 ])
-@pytest.mark.parametrize("variant", [(0, 0, 0), (0, 0, 1), (2, 0, 1), (2, 3, 0), (0, 3, 1), (2, 5, 1), (4, 2, 1), (0, 127, 1)])
+@pytest.mark.parametrize("variant", [(0, 0, 0), (0, 0, 1), (2, 0, 1), (2, 3, 0), (0, 3, 1), (2, 5, 1), (4, 2, 1), (0, 127, 1),
+                                     (32, 0, 1), (34, 3, 1), (32, 2, 0)])  # (32: four-wave workgroups, 64 x 128 tiles)
 def test_conv1x1_weight_gradient_third_generation(N, Ci, Co, H, W, c1, bias, variant):
     """csrc/conv_wgrad2.hip behind cot_conv1x1_backward_weight: every tile shape, planes that are / are not multiples of 8 and
     32 pixels, two slabs, the bias column, forced slice counts (cot_set_tuning(25) bits 24..), fragment prefetch (bit 1), the
