@@ -212,7 +212,11 @@ def apply_kernel_set(name):
     _lib.check(_lib.lib().cot_set_tuning(12, fold), "cot_set_tuning")
 
 
-GATE_BLOCK, GATE_FLOOR = 1.5, 2e-3  # per block: candidate error vs fp32 truth <= GATE_BLOCK x round1's error + GATE_FLOOR
+# per block: candidate error vs fp32 truth <= GATE x round1's error + GATE_FLOOR.  Outputs 1.5x; gradients 2.5x: a block's bf16
+# input / parameter gradients sit 4-15 % from the truth and two correct kernel sets differ by up to 1.6x in that figure on a
+# single block (measured on the MI355X: CoTNeXt-101 layer1.2 0.146 vs 0.090, median over the blocks 1.0x) -- a defect is a
+# wrong term, i.e. an error of O(1): 5-10x
+GATE_BLOCK, GATE_GRAD, GATE_FLOOR = 1.5, 2.5, 2e-3
 
 
 def probe_model(make_model, dev, seed):
@@ -315,7 +319,7 @@ def block_gate(rec, errs, ref_errs):
         r = ref_errs[name]
         ok = ok and e[3]
         for k, what in enumerate(("y", "gx", "params")):
-            ratio = e[k] / (GATE_BLOCK * r[k] + GATE_FLOOR)
+            ratio = e[k] / ((GATE_BLOCK if k == 0 else GATE_GRAD) * r[k] + GATE_FLOOR)
             if ratio > worst:
                 worst, worst_at = ratio, f"{name}.{what}"
     rec.update(finite=bool(ok), worst_block_ratio_to_gate=round(worst, 3), worst_block=worst_at,
