@@ -20,6 +20,14 @@
 //   * MFMA roles: A = X rows, B = dY rows, so a lane ends up with FOUR CONSECUTIVE j of one dW row: 16-byte stores of the
 //     fp32 partial sums (8-byte stores of bf16 when the launch is not split).
 // Slices of the reduction are summed by the deterministic reduce kernel of conv1x1.hip (no atomics).
+//
+// What bounds the K loop (round 3, profiles/r03_wgrad_loop_study.md): NOT its instruction stream.  Per step and CU the loop
+// moves (TM + TJ) x 64 bytes from L2 into LDS, and the time per step is that byte count at ~27 GB/s per CU whatever the loop
+// looks like -- scalar-light addressing, fragment prefetch, copies on loader waves of their own, one barrier per four
+// steps all measured within 3 % of each other, while the same loop with the copies removed runs 2.5x faster.  A CU
+// fetching 16 rows x 64 B pieces from rows that start on no 64-byte boundary (392 / 98 bytes per row) gets 23 B/clk from L2
+// even alone with warm lines (scripts/ubench/ldpath.hip: flat 1 KB pieces 60 B/clk, 8 rows x 128 B 35 B/clk); with the
+// first touch of every line coming from HBM at the same time it is 13-14 B/clk.  Hence the K64 form below.
 #include <algorithm>
 
 #include "cot_common.h"
@@ -28,9 +36,12 @@
 
 namespace cot {
 
-// cot_set_tuning key 25: bit 0 = off (second-generation kernels instead); bit 1 = fragment prefetch OFF; bit 2 = the old
-// chunk permutation (A/B of the bank-conflict fix); bits 8..15 = partial-sum cap in percent of the input bytes (0 = 100);
-// bits 16..23 = target workgroups per CU x 4 (0 = 4, i.e. one); bits 24..30 = forced slice count (tests)
+// cot_set_tuning key 25: bit 0 = off (second-generation kernels instead); bit 1 = the plain form (no fragment prefetch, 32-pixel
+// stages, every wave copies: the reference point of the A/Bs and the form that carries the phase stamps); bit 2 = the old
+// chunk permutation of that form (A/B of the bank-conflict fix); bit 6 = 32-pixel stages for every plane; bit 7 = 64-pixel
+// stages + loader waves for every plane (default: planes of more than 64 pixels); bits 8..15 = partial-sum cap in percent
+// of the input bytes (0 = 100); bits 16..23 = target workgroups per CU x 4 (0 = 4, i.e. one); bits 24..30 = forced slice
+// count (tests)
 int g_wgrad2_tune = 0;
 extern int g_conv_ablate;
 extern unsigned long long* g_debug_stamps;
@@ -52,22 +63,33 @@ struct Wg2Args {
                                  // stores issued, end) + the XCC id; NULL in production
 };
 
-// WAVES = 8 (one workgroup per CU fills it) or 4: three 48 KB workgroups per CU, each with its own barrier -- their copy /
-// fragment-read / MFMA phases fall out of step with each other, which is the only overlap a barrier-per-step loop gets
-// (phase stamps, profiles/r03_wgrad_phase_stamps.log: per step ~240 cycles issuing two copies, ~350 waiting for the six
-// fragment reads that all eight waves issue at once, ~300 issuing MFMAs, strictly one after the other)
-template <int WAVES, int WM, int AM, int AJ, int NS, int PF>
-__global__ __launch_bounds__(64 * WAVES, 4) void conv1x1_wgrad_lds2(const Wg2Args a) {  // (<= 128 registers)
+// Three forms of the K loop over one set of tile shapes (WAVES = 8 consumer waves, WM x (8 / WM) of them, AM x AJ MFMA tiles each):
+//   PF = 0          every wave copies; per step: wait, barrier, issue the refill, read the fragments, multiply
+//   PF = 1, LW = 0  ... the fragments of step k+1 are read into a second register set before step k multiplies
+//   LW > 0 (K64)    LW extra LOADER waves issue every copy, the consumer waves only read fragments and issue MFMAs; a stage
+//                   holds 64 pixels (two MFMA k blocks) of every row and is copied in pieces of 8 rows x 128 bytes instead of
+//                   16 rows x 64 bytes: the same bytes in half as many, twice as long runs per row -- the vector-memory path
+//                   works on 128-byte lines and the deep layers' rows start on no particular boundary.  One meeting per stage:
+//                   before it the loaders have seen the stage land, after it they refill the slot the consumers have left.
+template <int WAVES, int WM, int AM, int AJ, int NS, int PF, int LW = 0, int K64 = 0>
+__global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? 3 : 2) : 4) void conv1x1_wgrad_lds2(const Wg2Args a) {  // (the prefetching form holds two fragment sets: more than 128 registers)
     constexpr int WJ = WAVES / WM, TM = WM * AM * 16, TJ = WJ * AJ * 16;
     constexpr int RBM = TM / 16, RBJ = TJ / 16, RB = RBM + RBJ;  // 16-row blocks of the dY / X parts of a stage
-    constexpr int G = (RB + WAVES - 1) / WAVES;                   // copies per wave and stage
-    constexpr int STG = RB * 512;                                 // elements per stage ([RB * 16 rows][32 pixels])
+    constexpr int KB = K64 ? 2 : 1, KC = 4 * KB;                  // MFMA k blocks (32 pixels) / 8-pixel chunks per row and stage
+    constexpr int SB = KC * 16;                                   // bytes per row and stage
+    constexpr int CW = LW ? LW : WAVES;                           // waves that copy
+    constexpr int G = (RB * KB + CW - 1) / CW;                    // copies (1 KB pieces) per copying wave and stage
+    static_assert(LW == 0 || PF, "loader waves: prefetching form only");
+    static_assert(K64 == 0 || LW > 0, "64-pixel stages: loader form only");
+    constexpr int STG = RB * 512 * KB;                            // elements per stage ([RB * 16 rows][32 KB pixels])
     static_assert((NS - 1) * G <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     bf16_t* const sm = reinterpret_cast<bf16_t*>(cot_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), i16 = lane & 15, g = lane >> 4;
     COT_STAMP(a.stamps, 0);
-    const int wm = wave / WJ, wj = wave % WJ;
+    const bool loader = LW && wave >= WAVES;        // (wave-uniform)
+    const int cwv = LW ? wave - WAVES : wave;       // index among the copying waves
+    const int wm = (loader ? 0 : wave) / WJ, wj = (loader ? 0 : wave) % WJ;
     const int HW = a.HW, M = a.M, J = a.J, Jp = J + (a.has_bias ? 1 : 0);
     const int spi = a.spi, cpi = a.cpi, rem = HW & 7;
     unsigned b = blockIdx.x;
@@ -81,21 +103,29 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv1x1_wgrad_lds2(const Wg2Arg
     const int t0 = uniform((int)((unsigned)a.T * (unsigned)sl / (unsigned)a.S));  // (T * S < 2^31: checked on the host)
     const int t1 = uniform((int)((unsigned)a.T * (unsigned)(sl + 1) / (unsigned)a.S));
     const int nst = t1 - t0;
-    auto f = [&](int row) { return a.oldswz ? ((row >> 2) & 3) : ((-(row >> 2)) & 3); };
+    // chunk permutation inside a row (applied to the SOURCE address; the image in LDS is lane-linear): bank-conflict-free
+    // ds_read_b128 fragments (SQ_LDS_BANK_CONFLICT = 0, profiles/r03_conv_sq_counters.txt)
+    auto f = [&](int row) { return K64 ? ((row >> 1) & 7) : (a.oldswz ? ((row >> 2) & 3) : ((-(row >> 2)) & 3)); };
 
-    // ---- this wave's copies: 16-row block rb = wave + WAVES i (blocks past the stage: block RB-1 again, same bytes to the same place)
-    unsigned voff[G], voffl[G];   // per-lane byte offsets: ordinary steps (base = image row + step), last step of an image (base = image row)
-    const bf16_t* img[G];         // scalar: row r0 of the copy's block in the image being staged
-    int64_t istr[G];              // scalar: elements from one image to the next in that tensor
-    unsigned ldst[G];             // scalar: byte offset of the block inside a stage
+    // ---- this wave's copies: 16-row block rb = wave + WAVES i (blocks past the stage: block RB-1 again, same bytes to the same place).
+    // Scalar state per copy: ONE running byte pointer `sp` (the step's base, minus a bias that keeps every per-lane offset
+    // non-negative) that advances 64 bytes per ordinary step and `wrapb` bytes at an image's last step; per-lane state: two
+    // constant offsets (ordinary steps / the last step of an image).  The K step's scalar work is what the loop is made of
+    // (SQ counters, profiles/r03_conv_sq_counters.txt: 8 scalar instructions and 1.6 branches per MFMA before this form).
+    unsigned voff[G] = {}, voffl[G] = {};
+    const char* sp[G] = {};
+    int wrapb[G] = {};
+    unsigned ldst[G] = {};        // scalar: byte offset of the block inside a stage
     const int n_first = uniform(t0 / spi);
     int s_s = t0 - n_first * spi;  // step inside the image of the NEXT stage to issue
-    {
-        const int n_s = n_first;
-        const int rowl = lane >> 2, pos = lane & 3;
+    if (!LW || loader) {
+        const int bias = SB * spi;
+        const int pos = lane & (KC - 1);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const int rb = min(wave + WAVES * i, RB - 1);
+            const int unit = min(cwv + CW * i, RB * KB - 1);  // (pieces past the stage: the last one again, same bytes to the same place)
+            const int rb = unit / KB;
+            const int rowl = K64 ? (unit % KB) * 8 + (lane >> 3) : (lane >> 2);  // row inside the 16-row block
             const int ch = pos ^ f(rb * 16 + rowl);  // the 8-pixel chunk of the step this lane fetches
             int r0, r;
             const bf16_t* base;
@@ -114,54 +144,58 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv1x1_wgrad_lds2(const Wg2Arg
                 base = second ? a.x2 + (int64_t)(r0 - a.k1) * HW : a.x1 + (int64_t)r0 * HW;
                 stride = (int64_t)(second ? J - a.k1 : (a.x2 ? a.k1 : J)) * HW;
             }
-            img[i] = base + n_s * stride;
-            istr[i] = stride;
-            ldst[i] = (unsigned)(rb * 1024);
-            voff[i] = (unsigned)((r - r0) * HW + ch * 8) * 2u;
-            const int c = 4 * (spi - 1) + ch;  // chunk index inside the image in its last step
+            sp[i] = reinterpret_cast<const char*>(base + n_first * stride) + (s_s * SB - bias);
+            wrapb[i] = (int)(stride * 2) - (spi - 1) * SB;  // (2 * stride < 2^31: checked on the host)
+            ldst[i] = (unsigned)(unit * 1024);
+            voff[i] = (unsigned)(((r - r0) * HW + ch * 8) * 2 + bias);
+            const int c = KC * (spi - 1) + ch;  // chunk index inside the image in its last step
             const int pl = (c < cpi - 1 || (c == cpi - 1 && rem == 0)) ? c * 8 : HW - 8;
-            voffl[i] = (unsigned)((r - r0) * HW + pl) * 2u;
+            voffl[i] = (unsigned)(((r - r0) * HW + pl) * 2 - (spi - 1) * SB + bias);
         }
     }
     const unsigned lds0 = COT_LDS_ADDR(sm);
-    auto stage = [&](int slot) __attribute__((always_inline)) {
+    // issue the next stage's copies into the slot at LDS byte address `slot_addr` (wave-uniform)
+    auto stage = [&](unsigned slot_addr) __attribute__((always_inline)) {
         const bool last = s_s == spi - 1;
-        const unsigned d = lds0 + (unsigned)(slot * STG * 2);
 #pragma unroll
-        for (int i = 0; i < G; ++i) COT_GLDS16S(last ? img[i] : img[i] + s_s * 32, last ? voffl[i] : voff[i], d + ldst[i]);
-        if (last) {
-            s_s = 0;
-#pragma unroll
-            for (int i = 0; i < G; ++i) img[i] += istr[i];
-        } else {
-            ++s_s;
+        for (int i = 0; i < G; ++i) {
+            COT_GLDS16S(sp[i], last ? voffl[i] : voff[i], slot_addr + ldst[i]);
+            sp[i] += last ? wrapb[i] : SB;
         }
+        s_s = last ? 0 : s_s + 1;
     };
 
     // ---- fragments: row i16 of a 16-row block, k chunk g (at its permuted position)
-    int yoff[AM], xoff[AJ];
+    int yoff[KB][AM], xoff[KB][AJ];
     bool ones[AJ];
 #pragma unroll
-    for (int q = 0; q < AM; ++q) {
-        const int row = (wm * AM + q) * 16 + i16;
-        yoff[q] = row * 32 + ((g ^ f(row)) & 3) * 8;
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int q = 0; q < AM; ++q) {
+            const int row = (wm * AM + q) * 16 + i16;
+            yoff[kb][q] = row * (KC * 8) + (((4 * kb + g) ^ f(row)) & (KC - 1)) * 8;
+        }
+#pragma unroll
+        for (int u = 0; u < AJ; ++u) {
+            const int row = RBM * 16 + (wj * AJ + u) * 16 + i16;
+            xoff[kb][u] = row * (KC * 8) + (((4 * kb + g) ^ f(row)) & (KC - 1)) * 8;
+        }
     }
 #pragma unroll
-    for (int u = 0; u < AJ; ++u) {
-        const int row = RBM * 16 + (wj * AJ + u) * 16 + i16;
-        xoff[u] = row * 32 + ((g ^ f(row)) & 3) * 8;
-        ones[u] = a.has_bias && j0 + (wj * AJ + u) * 16 + i16 == J;  // the bias gradient rides along as an X row of ones
-    }
+    for (int u = 0; u < AJ; ++u) ones[u] = a.has_bias && j0 + (wj * AJ + u) * 16 + i16 == J;  // the bias gradient rides along as an X row of ones
     // the last step of an image: lane group g holds chunk c = 4 (spi-1) + g; elements below `lo` repeat earlier pixels (the
-    // chunk was read ending at the row's end) or lie past the row altogether: cleared in the dY fragments
-    uint32_t mk[4];
-    {
-        const int c = 4 * (spi - 1) + g;
+    // chunk was read ending at the row's end) or lie past the row altogether: cleared in the X fragments (the operand with
+    // fewer fragments; its row of ones for the bias gradient is cleared the same way, which is what that sum needs) --
+    // by an AND with a mask that is all ones in every other step: no branch
+    uint32_t mk[KB][4];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int c = KC * (spi - 1) + 4 * kb + g;
         const int lo = (c < cpi - 1 || (c == cpi - 1 && rem == 0)) ? 0 : (c == cpi - 1 ? 8 - rem : 8);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) mk[d] = (2 * d >= lo ? 0x0000ffffu : 0u) | (2 * d + 1 >= lo ? 0xffff0000u : 0u);
+        for (int d = 0; d < 4; ++d) mk[kb][d] = (2 * d >= lo ? 0x0000ffffu : 0u) | (2 * d + 1 >= lo ? 0xffff0000u : 0u);
     }
-    const bool tails = (HW & 31) != 0;  // (else every chunk of the last step is whole: nothing to clear)
+    const bool tails = (HW & (KC * 8 - 1)) != 0;  // (else every chunk of the last step is whole: nothing to clear)
     int s_c = t0 - n_first * spi;       // step inside the image of the stage being READ next
 
     f32x4_t acc[AJ][AM];
@@ -170,28 +204,56 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv1x1_wgrad_lds2(const Wg2Arg
 #pragma unroll
         for (int q = 0; q < AM; ++q) acc[u][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto read_frags = [&](int slot, uint32_t (&yq)[AM][4], uint32_t (&xq)[AJ][4]) __attribute__((always_inline)) {
-        const bf16_t* sb = sm + slot * STG;
-        const bool lastc = tails && s_c == spi - 1;
-        s_c = s_c + 1 == spi ? 0 : s_c + 1;
+    // fragments of the stage at `sb` (slot base; a compile-time slot folds into the reads' immediate offsets): loads only -- the
+    // clean-up below is applied when the fragments are USED, one step later, so that nothing waits for the reads here.
+    // Returns whether the stage was the last step of an image.
+    auto read_kblock = [&](auto kbc, const bf16_t* sb, uint32_t (&yq)[AM][4], uint32_t (&xq)[AJ][4]) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value;
 #pragma unroll
-        for (int u = 0; u < AJ; ++u) {
-            __builtin_memcpy(xq[u], __builtin_assume_aligned(sb + xoff[u], 16), 16);
-            if (a.has_bias && ones[u]) {  // (scalar test first: layers without a bias skip the selects)
+        for (int q = 0; q < AM; ++q) __builtin_memcpy(yq[q], __builtin_assume_aligned(sb + yoff[kb][q], 16), 16);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xq[u][e] = 0x3f803f80u;  // bf16 1.0 twice (dY's tail mask keeps the sum right)
-            }
+        for (int u = 0; u < AJ; ++u) __builtin_memcpy(xq[u], __builtin_assume_aligned(sb + xoff[kb][u], 16), 16);
+    };
+    auto next_is_last = [&]() __attribute__((always_inline)) {  // the stage about to be read: last step of its image?
+        const bool lastc = s_c == spi - 1;
+        s_c = lastc ? 0 : s_c + 1;
+        return lastc;
+    };
+    auto read_frags = [&](const bf16_t* sb, uint32_t (&yq)[AM][4], uint32_t (&xq)[AJ][4]) __attribute__((always_inline)) {
+        const bool lastc = next_is_last();
+        read_kblock(std::integral_constant<int, 0>{}, sb, yq, xq);
+        return lastc;
+    };
+    // the X fragments' clean-up: the bias row becomes ones; in the last step of an image the repeated / out-of-row elements are
+    // cleared (mask OR all-ones in every other step: data flow, no branch)
+    auto fix_kblock = [&](auto kbc, uint32_t (&xq)[AJ][4], bool lastc) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value;
+        if (a.has_bias) {  // (wave-uniform: layers without a bias skip the selects)
+#pragma unroll
+            for (int u = 0; u < AJ; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xq[u][e] = ones[u] ? 0x3f803f80u : xq[u][e];  // bf16 1.0 twice
         }
+        if (tails) {  // (wave-uniform, loop-invariant)
+            const uint32_t pass = lastc ? 0u : 0xffffffffu;
 #pragma unroll
-        for (int q = 0; q < AM; ++q) {
-            __builtin_memcpy(yq[q], __builtin_assume_aligned(sb + yoff[q], 16), 16);
-            if (lastc) {
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t m = mk[kb][e] | pass;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) yq[q][e] &= mk[e];
+                for (int u = 0; u < AJ; ++u) xq[u][e] &= m;
             }
         }
     };
+    auto fix_frags = [&](uint32_t (&xq)[AJ][4], bool lastc) __attribute__((always_inline)) {
+        fix_kblock(std::integral_constant<int, 0>{}, xq, lastc);
+    };
     const int abl = a.ablate;
+    auto mma = [&](const uint32_t (&yq)[AM][4], const uint32_t (&xq)[AJ][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < AJ; ++u)
+#pragma unroll
+            for (int q = 0; q < AM; ++q) acc[u][q] = COT_MFMA_16X16X32_BF16(packed_as_frag(xq[u]), packed_as_frag(yq[q]), acc[u][q]);
+    };
     auto multiply = [&](const uint32_t (&yq)[AM][4], const uint32_t (&xq)[AJ][4]) __attribute__((always_inline)) {
         if (abl & 4) {
             acc[0][0] = COT_MFMA_16X16X32_BF16(packed_as_frag(xq[0]), packed_as_frag(yq[0]), acc[0][0]);
@@ -204,43 +266,125 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv1x1_wgrad_lds2(const Wg2Arg
     };
 
     COT_STAMP(a.stamps, 1);
-    if (PF) {  // (pipeline structure and vmcnt arithmetic as conv_lds2.hip conv1x1_lds_fwd2)
+    auto slot_addr = [&](int slot) { return lds0 + (unsigned)(slot * STG * 2); };
+    if (PF) {
+        // Ring of NS slots, stage s in slot s % NS; iteration ks multiplies the fragments of step ks, read one iteration earlier
+        // (structure and vmcnt arithmetic: conv_lds2.hip conv1x1_lds_fwd2).  The steady state is unrolled NS times so that
+        // every slot is a compile-time constant: LDS addresses become immediates of the reads, M0 one scalar add.
+        static_assert(LW > 0 || NS % 2 == 0, "the register double buffer alternates per step");
+        if constexpr (LW > 0) {
+            if (loader) {
+                int kiss = 0, slot = 0;  // next stage to issue, its slot
+                auto issue = [&]() __attribute__((always_inline)) {
+                    if (kiss < nst) {
+                        if (!(a.ablate & 1) || kiss < NS) stage(slot_addr(slot));  // (DIAGNOSTIC bit 0: only the first ring-full is copied)
+                        slot = slot + 1 == NS ? 0 : slot + 1;
+                        ++kiss;
+                    }
+                };
+#pragma unroll
+                for (int b = 0; b < NS - 1; ++b) issue();
+                for (int need = 1; need <= nst; ++need) {     // one meeting per stage, as the consumers below
+                    WaitBehind<G, NS - 2>::go(kiss - need);  // stage need-1 has landed; the younger ones stay in flight
+                    COT_LDS_BARRIER();
+                    issue();                                 // into the slot the consumers have just left
+                }
+                return;
+            }
+            COT_LDS_BARRIER();
+            // k blocks kk = 0 .. KB nst - 1 (stage kk / KB), fragments of block kk+1 on their way while block kk multiplies
+            uint32_t y0[AM][4], x0[AJ][4], y1[AM][4], x1[AJ][4];
+            bool lcur = next_is_last();  // of the stage the block in registers belongs to
+            read_kblock(std::integral_constant<int, 0>{}, sm, y0, x0);
+            int slot = 0;                // slot of the stage being read
+            const int nkk = KB * nst;
+            auto sub = [&](auto kbc, int kk, const uint32_t (&yc)[AM][4], uint32_t (&xc)[AJ][4], uint32_t (&yn)[AM][4],
+                           uint32_t (&xn)[AJ][4]) __attribute__((always_inline)) {
+                constexpr int kb = decltype(kbc)::value, nkb = (kb + 1) % KB;
+                const bool lc = lcur;
+                if (kk + 1 < nkk) {
+                    if (nkb == 0) {  // the next block opens a stage: meet (everything read so far is in registers: the slot behind is free)
+                        slot = slot + 1 == NS ? 0 : slot + 1;
+                        COT_LDS_BARRIER();
+                        lcur = next_is_last();
+                    }
+                    read_kblock(std::integral_constant<int, nkb>{}, sm + slot * STG, yn, xn);
+                    COT_SCHED_FENCE();
+                }
+                fix_kblock(kbc, xc, lc);
+                mma(yc, xc);
+                COT_SCHED_FENCE();
+            };
+            for (int kk = 0; kk < nkk; kk += 2) {
+                sub(std::integral_constant<int, 0>{}, kk, y0, x0, y1, x1);
+                if (kk + 1 < nkk) sub(std::integral_constant<int, KB - 1>{}, kk + 1, y1, x1, y0, x0);
+            }
+        } else {
 #pragma unroll
         for (int s0 = 0; s0 < NS; ++s0)
-            if (s0 < nst) stage(s0);
+            if (s0 < nst) stage(slot_addr(s0));
         WaitBehind<G, NS - 1>::go(min(NS - 1, nst - 1));
         COT_LDS_BARRIER();
         uint32_t y0[AM][4], x0[AJ][4], y1[AM][4], x1[AJ][4];
-        read_frags(0, y0, x0);
-        int slot = 0;
-        auto step = [&](auto steady, int ks, const uint32_t (&yc)[AM][4], const uint32_t (&xc)[AJ][4], uint32_t (&yn)[AM][4],
-                        uint32_t (&xn)[AJ][4]) __attribute__((always_inline)) {
-            constexpr bool STEADY = decltype(steady)::value;
-            if (STEADY || ks + 1 < nst) {
-                if (STEADY) COT_WAIT_VM((NS - 2) * G);
-                else WaitBehind<G, NS - 2>::go(min(NS - 2, nst - 2 - ks));
-                COT_LDS_BARRIER();
-                if (STEADY || ks + NS < nst) stage(slot);
-                slot = slot + 1 == NS ? 0 : slot + 1;
-                read_frags(slot, yn, xn);
-                COT_SCHED_FENCE();
-            }
-            multiply(yc, xc);
+        bool l0 = read_frags(sm, y0, x0), l1 = false;
+        auto steady = [&](auto slot_c, int ks0, const uint32_t (&yc)[AM][4], uint32_t (&xc)[AJ][4], bool lc, uint32_t (&yn)[AM][4],
+                          uint32_t (&xn)[AJ][4], bool& ln) __attribute__((always_inline)) {
+            constexpr int U = decltype(slot_c)::value, NXT = (U + 1) % NS;
+            // DIAGNOSTIC (as in the other form below): 0 loop top, 1 own copies landed, 2 barrier passed, 3 next fragments'
+            // reads issued, 4 copies issued, 5 MFMAs issued
+            const bool tr = a.stamps && blockIdx.x == 0 && ks0 + U >= 8 && ks0 + U < 16;
+            unsigned long long* const tp = a.stamps + (size_t)(2048 + (tr ? ks0 + U - 8 : 0)) * 8 - (size_t)blockIdx.x * 8;
+            if (tr) COT_STAMP(tp, 0);
+            if (!LW) COT_WAIT_VM((NS - 2) * G);  // stage ks+1 has landed (this wave's copies); the NS-2 younger stages stay in flight
+            if (tr) COT_STAMP(tp, 1);
+            COT_LDS_BARRIER();          // ... everybody's; and nobody reads slot U any more (its fragments are in registers)
+            if (tr) COT_STAMP(tp, 2);
+            ln = read_frags(sm + NXT * STG, yn, xn);
+            COT_SCHED_FENCE();          // the reads are in flight BEFORE copies and MFMAs are issued
+            if (tr) COT_STAMP(tp, 3);
+            if (!LW) stage(lds0 + (unsigned)(U * STG * 2));
             COT_SCHED_FENCE();
+            if (tr) COT_STAMP(tp, 4);
+            fix_frags(xc, lc);
+            mma(yc, xc);
+            COT_SCHED_FENCE();
+            if (tr) COT_STAMP(tp, 5);
         };
         int ks = 0;
-        for (; ks + 1 + NS < nst; ks += 2) {
-            step(std::true_type{}, ks, y0, x0, y1, x1);
-            step(std::true_type{}, ks + 1, y1, x1, y0, x0);
+        if (NS == 4) {
+            for (; ks + 2 * NS - 1 < nst; ks += NS) {  // (steps ks .. ks+NS-1 all re-fill: ks + NS-1 + NS < nst)
+                steady(std::integral_constant<int, 0>{}, ks, y0, x0, l0, y1, x1, l1);
+                steady(std::integral_constant<int, 1>{}, ks, y1, x1, l1, y0, x0, l0);
+                steady(std::integral_constant<int, 2 % NS>{}, ks, y0, x0, l0, y1, x1, l1);
+                steady(std::integral_constant<int, 3 % NS>{}, ks, y1, x1, l1, y0, x0, l0);
+            }
         }
+        int slot = 0;  // (ks is a multiple of NS here)
+        auto step = [&](int k, const uint32_t (&yc)[AM][4], uint32_t (&xc)[AJ][4], bool lc, uint32_t (&yn)[AM][4],
+                        uint32_t (&xn)[AJ][4], bool& ln) __attribute__((always_inline)) {
+            if (k + 1 < nst) {
+                if (!LW) WaitBehind<G, NS - 2>::go(min(NS - 2, nst - 2 - k));
+                COT_LDS_BARRIER();
+                const int freed = slot;
+                slot = slot + 1 == NS ? 0 : slot + 1;
+                ln = read_frags(sm + slot * STG, yn, xn);
+                COT_SCHED_FENCE();
+                if (!LW && k + NS < nst) stage(slot_addr(freed));
+                COT_SCHED_FENCE();
+            }
+            fix_frags(xc, lc);
+            mma(yc, xc);
+            COT_SCHED_FENCE();
+        };
         for (; ks < nst; ks += 2) {
-            step(std::false_type{}, ks, y0, x0, y1, x1);
-            if (ks + 1 < nst) step(std::false_type{}, ks + 1, y1, x1, y0, x0);
+            step(ks, y0, x0, l0, y1, x1, l1);
+            if (ks + 1 < nst) step(ks + 1, y1, x1, l1, y0, x0, l0);
+        }
         }
     } else {
 #pragma unroll
         for (int s0 = 0; s0 < NS - 1; ++s0)
-            if (s0 < nst) stage(s0);
+            if (s0 < nst) stage(slot_addr(s0));
         int slot = 0, fill = NS - 1;
         auto step = [&](auto steady, int ks) __attribute__((always_inline)) {
             constexpr bool STEADY = decltype(steady)::value;
@@ -256,11 +400,12 @@ __global__ __launch_bounds__(64 * WAVES, 4) void conv1x1_wgrad_lds2(const Wg2Arg
             if (tr) COT_STAMP(tp, 1);
             if (!(abl & 8)) COT_LDS_BARRIER();                     // everybody's have; nobody still reads stage ks-1's slot
             if (tr) COT_STAMP(tp, 2);
-            if ((STEADY || ks + NS - 1 < nst) && !(abl & 1)) stage(fill);
+            if ((STEADY || ks + NS - 1 < nst) && !(abl & 1)) stage(slot_addr(fill));
             fill = fill + 1 == NS ? 0 : fill + 1;
             if (tr) COT_STAMP(tp, 3);
             uint32_t yq[AM][4], xq[AJ][4];
-            read_frags((abl & 2) ? 0 : slot, yq, xq);
+            const bool lq = read_frags(sm + ((abl & 2) ? 0 : slot) * STG, yq, xq);
+            fix_frags(xq, lq);
             slot = slot + 1 == NS ? 0 : slot + 1;
             if (tr) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the fragments have arrived
@@ -327,8 +472,8 @@ static inline int wgrad2_shape(int M, int Jp, int* TM, int* TJ) {
     if (M <= 32 && Jp > 64) s = 4;
     else if (M <= 64) s = Jp <= 64 ? 3 : 1;
     else if (Jp <= 64) s = 2;
-    else s = ((g_wgrad2_tune >> 5) & 1) ? 5 : 0;  // (bit 5: 64 x 128 tiles on four-wave workgroups, three per CU)
-    static const int tm[6] = {128, 64, 256, 64, 32, 64}, tj[6] = {128, 256, 64, 64, 128, 128};
+    else s = 0;
+    static const int tm[5] = {128, 64, 256, 64, 32}, tj[5] = {128, 256, 64, 64, 128};
     *TM = tm[s];
     *TJ = tj[s];
     return s;
@@ -338,8 +483,19 @@ bool conv1x1_wgrad2_covers(int N, int HW, int M, int J, int k1, bool two_slabs) 
     if (g_wgrad2_tune & 1) return false;
     if (HW < 8 || (two_slabs && k1 % 16 != 0)) return false;
     if ((int64_t)N * ceil_div(ceil_div(HW, 8), 4) * 1025 >= ((int64_t)1 << 31)) return false;  // (32-bit slice arithmetic in the kernel)
+    if ((int64_t)std::max(M, J) * HW * 2 >= ((int64_t)1 << 31)) return false;                    // (image strides in bytes as int)
     // per-lane offsets are 32-bit and relative to an image row: 16 rows of a plane must lie within 2 GB (they always do)
     return (int64_t)HW * 16 * 2 < ((int64_t)1 << 30) && N > 0 && M > 0 && J > 0;
+}
+
+// 64-pixel stages + loader waves (see the kernel): planes of more than 64 pixels.  Measured over CoTNet-50's layers against the
+// prefetching 32-pixel form (profiles/r03_wgrad_k64_ab.log): 56 x 56 +-1 %, 28 x 28 -7 %, 14 x 14 -10 %; 7 x 7 (one 64-pixel
+// stage per image, 15 of its 64 pixels padding either way) +3 %, so those stay on the 32-pixel form.
+static inline bool wgrad2_k64(int HW) {
+    if ((g_wgrad2_tune >> 1) & 1) return false;  // the plain form
+    if ((g_wgrad2_tune >> 6) & 1) return false;
+    if ((g_wgrad2_tune >> 7) & 1) return true;
+    return HW > 64;
 }
 
 // number of slices of the reduction (also sizes the workspace)
@@ -348,7 +504,7 @@ int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias) {
     int TM, TJ;
     wgrad2_shape(M, Jp, &TM, &TJ);
     const int64_t tiles = (int64_t)ceil_div(M, TM) * ceil_div(Jp, TJ);
-    const int cpi = ceil_div(HW, 8), spi = ceil_div(cpi, 4);
+    const int cpi = ceil_div(HW, 8), spi = ceil_div(cpi, wgrad2_k64(HW) ? 8 : 4);
     const int64_t T = (int64_t)N * spi;
     const int force = (g_wgrad2_tune >> 24) & 127;  // (tests: bits 24..30 force the slice count)
     if (force) return (int)std::min<int64_t>(force, T);
@@ -357,7 +513,6 @@ int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias) {
     // two per CU / partial sums <= 50 % of the inputs 2475, one per CU 2250, one per CU and <= 100 % 2121 (second
     // generation: 2747) -- every extra slice is another M x J fp32 matrix written and read again
     int64_t S = ceil_div64((int64_t)64 * (per_cu4 > 0 ? per_cu4 : 4), tiles);
-    if (((g_wgrad2_tune >> 5) & 1) && TM == 64 && TJ == 128 && !per_cu4) S = ceil_div64(768, tiles);  // three small workgroups per CU
     const int64_t in_bytes = (int64_t)N * HW * (M + J) * 2, out_bytes = (int64_t)M * Jp * 4;
     const int pct = (g_wgrad2_tune >> 8) & 255;
     const int64_t cap = in_bytes * (pct > 0 ? pct : 100) / 100 / out_bytes;  // partial sums are written once and read once
@@ -403,14 +558,14 @@ static int wgrad2_reduce(const float* part, int S, int M, int J, int has_bias, v
     return conv1x1_wgrad_reduce_launch(part, S, M, J, has_bias, gw, gb, stream);
 }
 
-template <int WM, int AM, int AJ, int PF, int NS, int WAVES = 8>
+template <int WM, int AM, int AJ, int PF, int NS, int WAVES = 8, int LW = 0, int K64 = 0>
 static int launch_wg2(const Wg2Args& a, int64_t blocks, hipStream_t stream) {
     constexpr int WJ = WAVES / WM, RB = WM * AM + WJ * AJ;
-    const size_t lds = (size_t)NS * RB * 1024;
+    const size_t lds = (size_t)NS * RB * 1024 * (K64 ? 2 : 1);
     static std::atomic<uint32_t> raised{0};
-    if (lds > 64 * 1024 && !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv1x1_wgrad_lds2<WAVES, WM, AM, AJ, NS, PF>)))
+    if (lds > 64 * 1024 && !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv1x1_wgrad_lds2<WAVES, WM, AM, AJ, NS, PF, LW, K64>)))
         return -1;
-    COT_LAUNCH((conv1x1_wgrad_lds2<WAVES, WM, AM, AJ, NS, PF>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, stream, a);
+    COT_LAUNCH((conv1x1_wgrad_lds2<WAVES, WM, AM, AJ, NS, PF, LW, K64>), dim3((unsigned)blocks), dim3(64 * (WAVES + LW)), lds, stream, a);
     return check_launch("conv1x1_wgrad_lds2");
 }
 
@@ -429,7 +584,8 @@ int conv1x1_wgrad2_run(const void* gy, const void* x1, const void* x2, int k1, v
     a.mtiles = ceil_div(M, TM);
     a.jtiles = ceil_div(Jp, TJ);
     a.cpi = ceil_div(HW, 8);
-    a.spi = ceil_div(a.cpi, 4);
+    const bool k64 = wgrad2_k64(HW);
+    a.spi = ceil_div(a.cpi, k64 ? 8 : 4);
     a.T = N * a.spi;
     a.oldswz = (g_wgrad2_tune >> 2) & 1;
     a.ablate = g_conv_ablate;
@@ -438,12 +594,12 @@ int conv1x1_wgrad2_run(const void* gy, const void* x1, const void* x2, int k1, v
     a.xcd_remap = blocks % 8 == 0;
     const bool pf = !((g_wgrad2_tune >> 1) & 1);  // fragment prefetch: default on (2272 -> 2089 us per step over CoTNet-50's layers, profiles/r03_wgrad_pf_ab.log)
     int rc;
-    const bool deep = (g_wgrad2_tune >> 3) & 1;  // bit 3: eight stages (one workgroup per CU, seven stages in flight) instead of four
-#define COT_WG2(WM_, AM_, AJ_)                                                                              \
-    (pf ? launch_wg2<WM_, AM_, AJ_, 1, 4>(a, blocks, stream)                                               \
-        : (deep ? launch_wg2<WM_, AM_, AJ_, 0, 8>(a, blocks, stream) : launch_wg2<WM_, AM_, AJ_, 0, 4>(a, blocks, stream)))
+    // ring: four stages; three 40 KB stages for the 320-row tiles in the 64-pixel form (160 KB of LDS)
+#define COT_WG2(WM_, AM_, AJ_)                                                                                         \
+    (k64 ? (WM_ * AM_ + (8 / WM_) * AJ_ > 16 ? launch_wg2<WM_, AM_, AJ_, 1, 3, 8, 4, 1>(a, blocks, stream)            \
+                                             : launch_wg2<WM_, AM_, AJ_, 1, 4, 8, 4, 1>(a, blocks, stream))           \
+         : (pf ? launch_wg2<WM_, AM_, AJ_, 1, 4>(a, blocks, stream) : launch_wg2<WM_, AM_, AJ_, 0, 4>(a, blocks, stream)))
     switch (shape) {
-        case 5: rc = pf ? launch_wg2<1, 4, 2, 1, 4, 4>(a, blocks, stream) : launch_wg2<1, 4, 2, 0, 4, 4>(a, blocks, stream); break;
         case 0: rc = COT_WG2(2, 4, 2); break;
         case 1: rc = COT_WG2(1, 4, 2); break;
         case 2: rc = COT_WG2(4, 4, 2); break;

@@ -145,9 +145,11 @@ const char* cot_last_kernel(void);
  *   key 23: third-generation 1x1 forward / data-gradient kernel (conv_lds2.hip) bit field -- bit 0 off (second generation
  *           instead), bit 1 no fragment prefetch in the small-image (FLAT) kernels, bit 2 fragment prefetch in the BIG kernels
  *   key 24: DIAGNOSTIC timing ablations of the third-generation 1x1 kernel (results become wrong; 0 = off)
- *   key 25: third-generation 1x1 weight gradient (conv_wgrad2.hip) bit field -- bit 0 off, bit 1 no fragment prefetch, bit 2 old
- *           LDS chunk permutation, bit 3 eight stages, bit 4 general reduce kernel only, bit 5 four-wave workgroups (64 x 128 tiles), bits 8..15 partial-sum cap in % of the
- *           input bytes (0 = 100), bits 16..23 target workgroups per CU x 4 (0 = 4), bits 24..30 forced slice count (tests)
+ *   key 25: third-generation 1x1 weight gradient (conv_wgrad2.hip) bit field -- bit 0 off, bit 1 the plain K loop (no fragment
+ *           prefetch, 32-pixel stages), bit 2 old LDS chunk permutation of the 32-pixel forms, bit 4 general reduce kernel only,
+ *           bit 6 32-pixel stages for every plane, bit 7 64-pixel stages + loader waves for every plane (default: planes of more
+ *           than 64 pixels), bits 8..15 partial-sum cap in % of the input bytes (0 = 100), bits 16..23 target workgroups per
+ *           CU x 4 (0 = 4), bits 24..30 forced slice count (tests)
  *   key 26: dry run (1): no kernel is launched, no HIP call is made; launches are recorded for cot_launch_log()
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);

@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out; export TMPDIR=/tmp; O=gpurun_out
+for t in "24=0" "24=8" "24=0" "24=8"; do
+  echo "== tune $t" >> $O/r3s18_wgrad_ab.log
+  timeout 300 python scripts/bench_conv_abi.py --modes 1 --tune "$t" 2>&1 | grep "^s[0-9e]" | awk -F'|' '{print substr($1,1,30) "|" $3}' >> $O/r3s18_wgrad_ab.log
+done

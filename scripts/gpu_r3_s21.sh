@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out; export TMPDIR=/tmp; O=gpurun_out
+for t in "25=0" "25=64" "25=0" "25=64"; do
+  echo "== tune $t" >> $O/r3s21_wgrad_ab.log
+  timeout 300 python scripts/bench_conv_abi.py --modes 1 --tune "$t" 2>&1 | grep "^s[0-9e]" | awk -F'|' '{print substr($1,1,30) "|" $3}' >> $O/r3s21_wgrad_ab.log
+done
+timeout 300 python scripts/wgrad_stamps.py --tune 25=64 > $O/r3s21_stamps_lw.log 2>&1

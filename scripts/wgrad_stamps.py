@@ -72,12 +72,12 @@ def main():
         med, mx = d.median(0).values.tolist(), d.max(0).values.tolist()
         skew = ((t[:, 0] - t0) / tpu).max().item()
         xcc = torch.bincount(s[:, 7].clamp(0, 15), minlength=8).tolist()
-        print(f"{name:26s} {wall:8.1f} {len(s):5d} | " + "  ".join(f"{a:5.1f}/{b:5.1f}" for a, b in zip(med, mx)) + "  (x100 ticks)")
+        print(f"{name:26s} {wall:8.1f} {len(s):5d} | " + "  ".join(f"{a:5.1f}/{b:5.1f}" for a, b in zip(med, mx)) + "  (ticks)")
         ph = stamps.view(-1, 8)[2048:2056, :6].cpu().double()
         if (ph[:, 0] != 0).all():
             d = ph[:, 1:] - ph[:, :-1]
             nxt = ph[1:, 0] - ph[:-1, 5]
-            print("      step phases (ticks, wave 0 of workgroup 0, steps 8..15): wait-copies | barrier | issue copies | fragments | issue MFMAs ; to next top")
+            print("      step phases (ticks, wave 0 of workgroup 0, steps 8..15): wait-copies | barrier | [prefetching form: issue reads | issue copies; else: issue copies | fragments] | issue MFMAs ; to next top")
             for i in range(8):
                 print("      " + "  ".join(f"{int(v):6d}" for v in d[i].tolist()) + (f"  ; {int(nxt[i]):6d}" if i < 7 else ""))
 

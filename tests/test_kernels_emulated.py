@@ -644,14 +644,17 @@ def test_conv1x1_mfma_kernels(N, Ci, Co, H, W, c1, bias, splits, request):
     (2, 512, 128, 4, 4, 256, False),  # H*W = 16; four column tiles, slab switch on a tile boundary
     (7, 96, 80, 7, 7, 0, False),      # odd image count, slices cut inside images
     (2, 256, 128, 4, 8, 0, False),    # 32768 outputs: forced slice counts take the wide (four outputs per lane) reduce kernel
+    (6, 64, 64, 16, 16, 0, False),    # 48 steps in one slice: the unrolled steady-state loop, image wraps inside it
+    (9, 128, 128, 7, 7, 0, True),     # 18 steps of a tail-every-second-step plane with a bias, steady loop included
 ])
-@pytest.mark.parametrize("variant", [(0, 0, 0), (0, 0, 1), (2, 0, 1), (2, 3, 0), (0, 3, 1), (2, 5, 1), (4, 2, 1), (0, 127, 1),
-                                     (32, 0, 1), (34, 3, 1), (32, 2, 0)])  # (32: four-wave workgroups, 64 x 128 tiles)
+@pytest.mark.parametrize("variant", [(0, 0, 0), (0, 0, 1), (0, 3, 1), (0, 127, 1), (2, 0, 1), (2, 3, 0), (6, 2, 1), (64, 0, 1), (64, 5, 1),
+                                     (68, 2, 1), (128, 0, 1), (128, 2, 1), (128, 5, 0)])
 def test_conv1x1_weight_gradient_third_generation(N, Ci, Co, H, W, c1, bias, variant):
     """csrc/conv_wgrad2.hip behind cot_conv1x1_backward_weight: every tile shape, planes that are / are not multiples of 8 and
-    32 pixels, two slabs, the bias column, forced slice counts (cot_set_tuning(25) bits 24..), fragment prefetch (bit 1), the
-    old chunk permutation (bit 2), LDS-DMA landing modes of the emulator -- against fp32 on the bf16-rounded operands, and
-    against the second-generation kernels"""
+    32 / 64 pixels, two slabs, the bias column, forced slice counts (cot_set_tuning(25) bits 24..), the three forms of the K loop
+    (default: 64-pixel stages + loader waves on planes of more than 64 pixels, prefetching 32-pixel stages below; bit 1 the
+    plain form; bits 6 / 7 one form for every plane), the old chunk permutation (bit 2), LDS-DMA landing modes of the emulator
+    -- against fp32 on the bf16-rounded operands, and against the second-generation kernels"""
     bits, force, dma = variant
     torch.manual_seed(23)
     HW, dt = H * W, _lib.dtype_code(torch.bfloat16)
