@@ -163,6 +163,24 @@ def _plan(layer):
     return p
 
 
+def _new_guarded(N, C, H, W, dtype, dev):
+    """[N, C, H, W] tensor with W + 1 (rounded up to 8) elements of the same allocation before and behind it: the grouped 3x3
+    weight gradient's LDS-staged kernel copies x at pixel + tap offset in whole 16-byte pieces
+    (cot_conv3x3g_backward_weight_guarded; what lies in the margins never reaches a sum)"""
+    lead = (W + 1 + 7) // 8 * 8
+    n = N * C * H * W
+    flat = torch.empty(n + 2 * lead, dtype=dtype, device=dev)
+    return flat[lead:lead + n].view(N, C, H, W)
+
+
+def _guard_elems(t):
+    """elements of t's own allocation before its first and behind its last element (0 for a tensor that fills its storage)"""
+    if not t.is_contiguous():
+        return 0
+    total = t.untyped_storage().nbytes() // t.element_size()
+    return max(0, min(t.storage_offset(), total - t.storage_offset() - t.numel()))
+
+
 def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act, residual=None, ps=None):
     """stats: fp32 [2*C + workspace] -> mean = stats[:C], rstd = stats[C:2C].  ps: per-sample scale of the normalised branch
     (stochastic depth: 0 or 1 / keep, fp32 [N]) or None"""
@@ -391,8 +409,8 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     d_ke_w, d_ke_b = _bn_bwd(L, gk, k_pre, None, gk_pre, ke1, s_k, N, C, HW, 1, nws_c)
     G = ke0.groups
     g_wk = grad_sink.out_like(ke0.weight)
-    _ck(L.cot_conv3x3g_backward_weight(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(side.ws), N, C, C, G, H, W, BF16,
-                                       side.ready(gk_pre, x, masks)), "cot_conv3x3g_backward_weight")
+    _ck(L.cot_conv3x3g_backward_weight_guarded(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(side.ws), N, C, C, G, H, W, BF16,
+                                               _guard_elems(x), side.ready(gk_pre, x, masks)), "cot_conv3x3g_backward_weight")
     _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx), 1, _p(masks), _p(ws), N, C, C, G, H, W,
                                      BF16, st), "cot_conv3x3g_backward_data")
     if own_side:
@@ -518,13 +536,14 @@ class _BottleneckNode(Function):
         _, _, nws_o = _block_sizes(L, N, Cin, Cw, Cout, HWo)
         new = lambda c, h, w: torch.empty((N, c, h, w), dtype=x.dtype, device=dev)  # noqa: E731
         stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
-        c1, a1 = new(Cw, H, W), new(Cw, H, W)
+        # (the CoT layer's input -- a1, or its pooled version -- is what the grouped 3x3 weight gradient reads shifted: margins)
+        c1, a1 = new(Cw, H, W), (new(Cw, H, W) if bp.avd else _new_guarded(N, Cw, H, W, x.dtype, dev))
         _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(bp.conv1.weight), None, _p(c1), N, Cin, Cw, HW, BF16, st),
             "cot_conv1x1_forward")
         s_1 = stat(Cw, nws_w)
         _bn_fwd(L, c1, a1, bp.bn1, s_1, 2 * Cw, N, Cw, HW, 1)
         if bp.avd:
-            p1 = new(Cw, Ho, Wo)
+            p1 = _new_guarded(N, Cw, Ho, Wo, x.dtype, dev)
             _ck(L.cot_avgpool3x3s2_forward(_p(a1), _p(p1), N * Cw, H, W, BF16, st), "cot_avgpool3x3s2_forward")
         else:
             p1 = a1

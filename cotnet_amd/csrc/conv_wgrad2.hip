@@ -59,6 +59,10 @@ struct Wg2Args {
     int oldswz;
     int xcd_remap;
     int ablate;    // DIAGNOSTIC (cot_set_tuning key 24; results become wrong): see C1LdsArgs::ablate
+    // grouped 3x3 weight gradient (TAPS kernels): per group, M = Cout / G rows of dY against J = 9 Kc "virtual rows" of X, row
+    // (tap, ci) = X's channel ci read at pixel + off(tap); gw is [Cout][Kc][3][3]
+    int G, Kc, cy, cx, W;          // groups, input channels per group, channels per image of dY / X, image width
+    const uint16_t* masks;         // conv3x3g_masks table: bit t of masks[p] = pixel p has an in-image neighbour for tap t
     unsigned long long* stamps;  // DIAGNOSTIC (cot_debug_stamps): per workgroup 6 x s_memtime (start, set up, first data, loop done,
                                  // stores issued, end) + the XCC id; NULL in production
 };
@@ -71,8 +75,16 @@ struct Wg2Args {
 //                   16 rows x 64 bytes: the same bytes in half as many, twice as long runs per row -- the vector-memory path
 //                   works on 128-byte lines and the deep layers' rows start on no particular boundary.  One meeting per stage:
 //                   before it the loaders have seen the stage land, after it they refill the slot the consumers have left.
-template <int WAVES, int WM, int AM, int AJ, int NS, int PF, int LW = 0, int K64 = 0>
-__global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? 3 : 2) : 4) void conv1x1_wgrad_lds2(const Wg2Args a) {  // (the prefetching form holds two fragment sets: more than 128 registers)
+//
+// TAPS (K64 form, nine consumer waves): the weight gradient of the grouped 3 x 3 convolution (models/cotnet.py:43-47 key_embed)
+//     dW[m][ci][tap] = sum over (n, p) of dY[n][m][p] * X[n][ci][p + off(tap)]   (0 where the neighbour is outside the image)
+// is the same product with nine shifted views of X as extra rows: a 16-row block of the X part is 16 channels of ONE tap,
+// copied from `x + off(tap)` (the caller guarantees W + 1 readable elements either side of the tensor), and what the shift
+// pulls in from the neighbouring row / channel / image is cleared in the fragment with the tap's bit of the validity table
+// (by AND: the garbage may be Inf / NaN).  conv3x3g_wgrad_mfma (conv3x3g.hip) gives every WAVE its own 64 columns and loads
+// each shifted row straight from L2: 4.7 % of the HBM roofline (profiles/r02_conv_abi.log).
+template <int WAVES, int WM, int AM, int AJ, int NS, int PF, int LW = 0, int K64 = 0, int TAPS = 0>
+__global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? (WAVES > 8 ? 4 : 3) : 2) : 4) void conv1x1_wgrad_lds2(const Wg2Args a) {  // (the prefetching form holds two fragment sets: more than 128 registers)
     constexpr int WJ = WAVES / WM, TM = WM * AM * 16, TJ = WJ * AJ * 16;
     constexpr int RBM = TM / 16, RBJ = TJ / 16, RB = RBM + RBJ;  // 16-row blocks of the dY / X parts of a stage
     constexpr int KB = K64 ? 2 : 1, KC = 4 * KB;                  // MFMA k blocks (32 pixels) / 8-pixel chunks per row and stage
@@ -81,6 +93,7 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? 3 : 2) : 4) void conv
     constexpr int G = (RB * KB + CW - 1) / CW;                    // copies (1 KB pieces) per copying wave and stage
     static_assert(LW == 0 || PF, "loader waves: prefetching form only");
     static_assert(K64 == 0 || LW > 0, "64-pixel stages: loader form only");
+    static_assert(TAPS == 0 || K64, "3 x 3 taps: 64-pixel loader form only");
     constexpr int STG = RB * 512 * KB;                            // elements per stage ([RB * 16 rows][32 KB pixels])
     static_assert((NS - 1) * G <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
@@ -98,7 +111,8 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? 3 : 2) : 4) void conv
     // the copies' base pointers, the loop counters, the branch conditions -- ends up in VGPRs / under exec masks)
     const int jt = uniform((int)(b % (unsigned)a.jtiles));
     const int rest = uniform((int)(b / (unsigned)a.jtiles));
-    const int mt = uniform(rest % a.mtiles), sl = uniform(rest / a.mtiles);
+    const int mt = uniform(rest % a.mtiles), r2 = uniform(rest / a.mtiles);
+    const int sl = TAPS ? uniform(r2 % a.S) : r2, grp = TAPS ? uniform(r2 / a.S) : 0;
     const int m0 = mt * TM, j0 = jt * TJ;
     const int t0 = uniform((int)((unsigned)a.T * (unsigned)sl / (unsigned)a.S));  // (T * S < 2^31: checked on the host)
     const int t1 = uniform((int)((unsigned)a.T * (unsigned)(sl + 1) / (unsigned)a.S));
@@ -134,8 +148,15 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? 3 : 2) : 4) void conv
                 const int rr = m0 + rb * 16;
                 r0 = min(rr, M - 1);
                 r = min(rr + rowl, M - 1);  // rows past the matrix: copies of the last row, never stored
-                base = a.gy + (int64_t)r0 * HW;
-                stride = (int64_t)M * HW;
+                base = a.gy + (int64_t)(TAPS ? grp * M + r0 : r0) * HW;
+                stride = (int64_t)(TAPS ? a.cy : M) * HW;
+            } else if (TAPS) {
+                const int rr = j0 + (rb - RBM) * 16;
+                r0 = min(rr, J - 1) & ~15;            // (Kc % 16 == 0: a block is 16 channels of one tap)
+                r = min(rr + rowl, J - 1);
+                const int tap = r0 / a.Kc, ci0 = r0 - tap * a.Kc;
+                base = a.x1 + (int64_t)(grp * a.Kc + ci0) * HW + ((tap / 3 - 1) * a.W + (tap % 3 - 1));
+                stride = (int64_t)a.cx * HW;
             } else {
                 const int rr = j0 + (rb - RBM) * 16;
                 r0 = min(rr, J - 1);
@@ -291,33 +312,63 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? 3 : 2) : 4) void conv
                 }
                 return;
             }
+            // TAPS: validity table in the chunk domain of the K loop, behind the ring: entry [c][e] belongs to element e of chunk c
+            // of an image (chunk cpi-1 of a plane that is no multiple of 8 was read ending at the row's end: its first 8 - rem
+            // elements repeat pixels and are cleared like the chunks past the row)
+            uint16_t* const tbl = reinterpret_cast<uint16_t*>(sm + NS * STG);
+            int xtap[AJ] = {};
+            if (TAPS) {
+                for (int i = tid; i < spi * KC * 8; i += 64 * WAVES) {
+                    const int c = i >> 3, e = i & 7;
+                    const bool whole = c < cpi - 1 || (c == cpi - 1 && rem == 0);
+                    const int px = whole ? i : HW - 8 + e;
+                    tbl[i] = (c >= cpi || (!whole && e < 8 - rem)) ? (uint16_t)0 : a.masks[px];
+                }
+#pragma unroll
+                for (int u = 0; u < AJ; ++u) xtap[u] = uniform(min(j0 + (wj * AJ + u) * 16, J - 1) / a.Kc);
+            }
             COT_LDS_BARRIER();
             // k blocks kk = 0 .. KB nst - 1 (stage kk / KB), fragments of block kk+1 on their way while block kk multiplies
-            uint32_t y0[AM][4], x0[AJ][4], y1[AM][4], x1[AJ][4];
-            bool lcur = next_is_last();  // of the stage the block in registers belongs to
+            uint32_t y0[AM][4], x0[AJ][4], y1[AM][4], x1[AJ][4], v0[4] = {}, v1[4] = {};
+            int scur = s_c;              // step inside its image of the stage being read
+            bool lcur = next_is_last();  // ... is it the image's last?  (of the stage the block in registers belongs to)
+            auto read_valid = [&](auto kbc, int st, uint32_t (&vq)[4]) __attribute__((always_inline)) {
+                constexpr int kb = decltype(kbc)::value;
+                if (TAPS) __builtin_memcpy(vq, __builtin_assume_aligned(tbl + ((KC * st + 4 * kb + g) << 3), 16), 16);
+            };
+            auto fix_taps = [&](uint32_t (&xq)[AJ][4], const uint32_t (&vq)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < AJ; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xq[u][e] &= ((vq[e] >> xtap[u]) & 0x00010001u) * 0xffffu;
+            };
             read_kblock(std::integral_constant<int, 0>{}, sm, y0, x0);
+            read_valid(std::integral_constant<int, 0>{}, scur, v0);
             int slot = 0;                // slot of the stage being read
             const int nkk = KB * nst;
-            auto sub = [&](auto kbc, int kk, const uint32_t (&yc)[AM][4], uint32_t (&xc)[AJ][4], uint32_t (&yn)[AM][4],
-                           uint32_t (&xn)[AJ][4]) __attribute__((always_inline)) {
+            auto sub = [&](auto kbc, int kk, const uint32_t (&yc)[AM][4], uint32_t (&xc)[AJ][4], const uint32_t (&vc)[4],
+                           uint32_t (&yn)[AM][4], uint32_t (&xn)[AJ][4], uint32_t (&vn)[4]) __attribute__((always_inline)) {
                 constexpr int kb = decltype(kbc)::value, nkb = (kb + 1) % KB;
                 const bool lc = lcur;
                 if (kk + 1 < nkk) {
                     if (nkb == 0) {  // the next block opens a stage: meet (everything read so far is in registers: the slot behind is free)
                         slot = slot + 1 == NS ? 0 : slot + 1;
                         COT_LDS_BARRIER();
+                        scur = s_c;
                         lcur = next_is_last();
                     }
                     read_kblock(std::integral_constant<int, nkb>{}, sm + slot * STG, yn, xn);
+                    read_valid(std::integral_constant<int, nkb>{}, scur, vn);
                     COT_SCHED_FENCE();
                 }
-                fix_kblock(kbc, xc, lc);
+                if (TAPS) fix_taps(xc, vc);
+                else fix_kblock(kbc, xc, lc);
                 mma(yc, xc);
                 COT_SCHED_FENCE();
             };
             for (int kk = 0; kk < nkk; kk += 2) {
-                sub(std::integral_constant<int, 0>{}, kk, y0, x0, y1, x1);
-                if (kk + 1 < nkk) sub(std::integral_constant<int, KB - 1>{}, kk + 1, y1, x1, y0, x0);
+                sub(std::integral_constant<int, 0>{}, kk, y0, x0, v0, y1, x1, v1);
+                if (kk + 1 < nkk) sub(std::integral_constant<int, KB - 1>{}, kk + 1, y1, x1, v1, y0, x0, v0);
             }
         } else {
 #pragma unroll
@@ -426,7 +477,7 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? 3 : 2) : 4) void conv
     COT_STAMP(a.stamps, 3);
 
     // ---- D[i = X row j][col = dY row m]: lane holds j = jb + 4g .. 4g+3 of dW row m = mb + i16
-    float* const ps = a.part + (int64_t)sl * M * Jp;
+    float* const ps = a.part + (int64_t)sl * (TAPS ? a.cy : M) * Jp;
     const bool vec = (Jp & 3) == 0;  // rows of the output start on 16-byte (fp32) / 8-byte (bf16) boundaries
 #pragma unroll
     for (int q = 0; q < AM; ++q) {
@@ -436,8 +487,14 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? 3 : 2) : 4) void conv
         for (int u = 0; u < AJ; ++u) {
             const int jj = j0 + (wj * AJ + u) * 16 + 4 * g;
             if (jj >= Jp) continue;
+            if (TAPS && a.S == 1) {  // single slice: straight into [Cout][Kc][3][3] (column jj = tap Kc + ci -> ci 9 + tap)
+                const int tap = jj / a.Kc, ci = jj - tap * a.Kc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.gw[((int64_t)(grp * M + m) * a.Kc + ci + r) * 9 + tap] = (bf16_t)acc[u][q][r];
+                continue;
+            }
             if (a.S > 1) {
-                float* p = ps + (int64_t)m * Jp + jj;
+                float* p = ps + (int64_t)(TAPS ? grp * M + m : m) * Jp + jj;
                 if (vec) {
                     *reinterpret_cast<f32x4_t*>(__builtin_assume_aligned(p, 16)) = acc[u][q];
                 } else {
@@ -609,6 +666,109 @@ int conv1x1_wgrad2_run(const void* gy, const void* x1, const void* x2, int k1, v
 #undef COT_WG2
     if (rc || a.S == 1) return rc;
     return wgrad2_reduce(workspace, a.S, M, J, a.has_bias, gw, gb, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// grouped 3 x 3 weight gradient on the TAPS kernels
+
+// gw[row][ci][tap] = sum over slices of part[s][row][tap Kc + ci]  (fixed order: deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_taps(const float* __restrict__ part, int S, int rows, int Kc,
+                                                         bf16_t* __restrict__ gw) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x, tot = (int64_t)rows * Kc * 9;
+    if (o >= tot) return;
+    const int tap = (int)(o % 9);
+    const int64_t rc = o / 9;
+    const int ci = (int)(rc % Kc);
+    const int64_t row = rc / Kc;
+    const float* p = part + row * (9 * Kc) + tap * Kc + ci;
+    float s0 = 0.f, s1 = 0.f;
+    int sl = 0;
+    for (; sl + 1 < S; sl += 2) {
+        s0 += p[(int64_t)sl * tot];
+        s1 += p[(int64_t)(sl + 1) * tot];
+    }
+    if (sl < S) s0 += p[(int64_t)sl * tot];
+    gw[o] = (bf16_t)(s0 + s1);
+}
+
+// tile of a layer: rows of dY per workgroup (all of the group's, at most 64) x 144 or 288 virtual rows of X
+static inline void taps_tile(int Mg, int Kc, int* AM, int* AJ) {
+    *AM = Mg >= 64 ? 4 : Mg / 16;
+    *AJ = (Kc == 32 || Kc == 64) ? 2 : 1;
+}
+
+bool conv3x3g_wgrad2_covers(int N, int Cin, int Cout, int G, int H, int W, int x_guard) {
+    if (g_wgrad2_tune & 1) return false;
+    if (G <= 0 || Cin % G || Cout % G) return false;
+    const int Kc = Cin / G, Mg = Cout / G, HW = H * W;
+    if (Kc % 16 || (Mg != 16 && Mg != 32 && Mg % 64) || HW < 8 || W + 1 > x_guard) return false;
+    if ((int64_t)N * ceil_div(ceil_div(HW, 8), 8) * 1025 >= ((int64_t)1 << 31)) return false;
+    if ((int64_t)std::max(Cin, Cout) * HW * 2 >= ((int64_t)1 << 31)) return false;
+    return (int64_t)ceil_div(HW, 64) * 64 * 2 <= 16 * 1024 && N > 0;  // (the validity table sits behind the ring in LDS)
+}
+
+int conv3x3g_wgrad2_splits(int N, int Cin, int Cout, int G, int HW) {
+    const int Kc = Cin / G, Mg = Cout / G;
+    int AM, AJ;
+    taps_tile(Mg, Kc, &AM, &AJ);
+    const int64_t tiles = (int64_t)G * ceil_div(Mg, AM * 16) * ceil_div(9 * Kc, 144 * AJ);
+    const int64_t T = (int64_t)N * ceil_div(ceil_div(HW, 8), 8);
+    const int force = (g_wgrad2_tune >> 24) & 127;
+    if (force) return (int)std::min<int64_t>(force, T);
+    int64_t S = ceil_div64(256, tiles);
+    const int64_t in_bytes = (int64_t)N * HW * (Cin + Cout) * 2, out_bytes = (int64_t)Cout * 9 * Kc * 4;
+    const int64_t cap = std::max<int64_t>(in_bytes / out_bytes, T >= 64 ? 4 : 1);  // (partial sums <= the inputs, but not one long chain)
+    if (S > cap) S = cap;
+    if (S > T / 4) S = T / 4;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+template <int AM, int AJ, int NS>
+static int launch_taps(const Wg2Args& a, int64_t blocks, int tbl_bytes, hipStream_t stream) {
+    constexpr int RB = AM + 9 * AJ;
+    const size_t lds = (size_t)NS * RB * 2048 + (size_t)tbl_bytes;
+    static std::atomic<uint32_t> raised{0};
+    if (lds > 64 * 1024 && !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv1x1_wgrad_lds2<9, 1, AM, AJ, NS, 1, 4, 1, 1>)))
+        return -1;
+    COT_LAUNCH((conv1x1_wgrad_lds2<9, 1, AM, AJ, NS, 1, 4, 1, 1>), dim3((unsigned)blocks), dim3(64 * 13), lds, stream, a);
+    return check_launch("conv3x3g wgrad (taps)");
+}
+
+// returns COT_OK, an error, or -1 when not covered (the caller then takes conv3x3g_wgrad_mfma)
+int conv3x3g_wgrad2_run(const void* gy, const void* x, void* gw, const void* masks, float* workspace, int N, int Cin, int Cout,
+                        int G, int H, int W, int x_guard, hipStream_t stream) {
+    if (!conv3x3g_wgrad2_covers(N, Cin, Cout, G, H, W, x_guard)) return -1;
+    const int Kc = Cin / G, Mg = Cout / G, HW = H * W;
+    Wg2Args a = {};
+    a.gy = (const bf16_t*)gy; a.x1 = (const bf16_t*)x; a.x2 = nullptr; a.part = workspace; a.gw = (bf16_t*)gw; a.gb = nullptr;
+    a.N = N; a.M = Mg; a.J = 9 * Kc; a.k1 = a.J; a.HW = HW; a.has_bias = 0;
+    a.G = G; a.Kc = Kc; a.cy = Cout; a.cx = Cin; a.W = W; a.masks = (const uint16_t*)masks;
+    int AM, AJ;
+    taps_tile(Mg, Kc, &AM, &AJ);
+    a.S = conv3x3g_wgrad2_splits(N, Cin, Cout, G, HW);
+    a.mtiles = ceil_div(Mg, AM * 16);
+    a.jtiles = ceil_div(a.J, 144 * AJ);
+    a.cpi = ceil_div(HW, 8);
+    a.spi = ceil_div(a.cpi, 8);
+    a.T = N * a.spi;
+    a.ablate = g_conv_ablate;
+    a.stamps = nullptr;
+    const int64_t blocks = (int64_t)a.jtiles * a.mtiles * a.S * G;
+    a.xcd_remap = blocks % 8 == 0;
+    const int tbl = a.spi * 64 * 2;
+    int rc;
+    if (AM == 1 && AJ == 1) rc = launch_taps<1, 1, 4>(a, blocks, tbl, stream);
+    else if (AM == 2 && AJ == 1) rc = launch_taps<2, 1, 4>(a, blocks, tbl, stream);
+    else if (AM == 2 && AJ == 2) rc = launch_taps<2, 2, 3>(a, blocks, tbl, stream);
+    else if (AM == 4 && AJ == 2) rc = launch_taps<4, 2, 3>(a, blocks, tbl, stream);
+    else if (AM == 4 && AJ == 1) rc = launch_taps<4, 1, 4>(a, blocks, tbl, stream);
+    else if (AM == 1 && AJ == 2) rc = launch_taps<1, 2, 4>(a, blocks, tbl, stream);
+    else return -1;
+    if (rc || a.S == 1) return rc;
+    const int64_t tot = (int64_t)Cout * Kc * 9;
+    COT_LAUNCH(wgrad_reduce_taps, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, stream, workspace, a.S, Cout, Kc, (bf16_t*)gw);
+    return check_launch("wgrad_reduce_taps");
 }
 
 }  // namespace cot

@@ -163,6 +163,9 @@ extern int g_wgrad2_tune;  // conv_wgrad2.hip (third-generation weight gradient)
 bool conv1x1_wgrad2_covers(int N, int HW, int M, int J, int k1, bool two_slabs);
 int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad2_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
+bool conv3x3g_wgrad2_covers(int N, int Cin, int Cout, int G, int H, int W, int x_guard);
+int conv3x3g_wgrad2_splits(int N, int Cin, int Cout, int G, int HW);
+int conv3x3g_wgrad2_run(const void*, const void*, void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
 int conv3x3g_lds_gemm(const void*, const void*, void*, void*, int, int, int, int, int, int, int, int, hipStream_t);
 // implemented in stem7x7.hip
 int stem7x7_splits(int N, int H, int W);
@@ -552,7 +555,10 @@ int cot_conv3x3g_masks(void* masks, int H, int W, void* stream) {
 int64_t cot_conv3x3g_workspace(int N, int Cin, int Cout, int groups, int H, int W) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || H <= 0 || W <= 0 || Cin % groups || Cout % groups) return 0;
     const int64_t wb = (int64_t)Cout * (Cin / groups) * 10 * 2;  // repacked weights of the LDS kernels (10 taps: one of zeros)
-    const int64_t part = (int64_t)conv3x3g_wgrad_splits(N, Cin, Cout, groups, H * W) * Cout * (Cin / groups) * 9 * 4;
+    int splits = conv3x3g_wgrad_splits(N, Cin, Cout, groups, H * W);
+    if (conv3x3g_wgrad2_covers(N, Cin, Cout, groups, H, W, 1 << 30))  // (whichever kernel ends up running)
+        splits = std::max(splits, conv3x3g_wgrad2_splits(N, Cin, Cout, groups, H * W));
+    const int64_t part = (int64_t)splits * Cout * (Cin / groups) * 9 * 4;
     return ((wb > part ? wb : part) + 255) / 256 * 256;
 }
 
@@ -602,7 +608,7 @@ int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int
 }
 
 static int cot_conv3x3g_backward_weight_impl(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
-                                 int Cin, int Cout, int groups, int H, int W, int dtype, void* stream) {
+                                 int Cin, int Cout, int groups, int H, int W, int dtype, int x_guard, void* stream) {
     int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, 8);
     if (rc) return rc;
     if (!gy || !x || !gweight || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
@@ -610,15 +616,24 @@ static int cot_conv3x3g_backward_weight_impl(const void* gy, const void* x, void
     if (conv3x3g_general(Cin, Cout, groups, dtype))
         return convg_backward_weight(gy, x, gweight, nullptr, (float*)workspace, N, Cin, Cout, groups, H, W, 3, dtype,
                                      (hipStream_t)stream);
+    // the LDS-staged kernel reads X at pixel + tap offset through whole 16-byte pieces: it needs W + 1 readable elements
+    // before and behind the tensor (x_guard: what the caller guarantees)
+    rc = conv3x3g_wgrad2_run(gy, x, gweight, masks, (float*)workspace, N, Cin, Cout, groups, H, W, x_guard, (hipStream_t)stream);
+    if (rc >= 0) return rc;
     return conv3x3g_wgrad(gy, x, gweight, masks, (float*)workspace, N, Cin, Cout, groups, H, W, (hipStream_t)stream);
+}
+int cot_conv3x3g_backward_weight_guarded(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
+                                         int Cin, int Cout, int groups, int H, int W, int dtype, int x_guard_elems, void* stream) {
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_conv3x3g_backward_weight_impl(gy, x, gweight, masks, workspace, N, Cin, Cout, groups, H, W, dtype,
+                                                     x_guard_elems < 0 ? 0 : x_guard_elems, stream);
+    if (p) prof::annotate_op(15, N, Cin, Cout, H * W, groups, dtype, 0);
+    return rc;
 }
 int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
                                  int Cin, int Cout, int groups, int H, int W, int dtype, void* stream) {
-    const bool p = prof::enabled();
-    if (p) prof::mark();
-    const int rc = cot_conv3x3g_backward_weight_impl(gy, x, gweight, masks, workspace, N, Cin, Cout, groups, H, W, dtype, stream);
-    if (p) prof::annotate_op(15, N, Cin, Cout, H * W, groups, dtype, 0);
-    return rc;
+    return cot_conv3x3g_backward_weight_guarded(gy, x, gweight, masks, workspace, N, Cin, Cout, groups, H, W, dtype, 0, stream);
 }
 
 int cot_agg_softmax_forward(const void* x, const void* logits, void* out, void* probs, const cot_agg_geom* g, int dtype,

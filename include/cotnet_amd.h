@@ -215,6 +215,13 @@ int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int
                                void* stream);
 int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
                                  int Cin, int Cout, int groups, int H, int W, int dtype, void* stream);
+/* The same with a promise about the memory around x: `x_guard_elems` elements before x[0] and behind x[N*Cin*H*W - 1] belong
+ * to the caller's allocation and may be READ (their contents do not matter).  With x_guard_elems >= W + 1 the COT_BF16 weight
+ * gradient of layers with 16 | Cin/groups and Cout/groups in {16, 32, 64 k} runs on the LDS-staged kernel (conv_wgrad2.hip,
+ * TAPS form: nine shifted views of x as extra rows of the 1x1 weight gradient's GEMM); otherwise, and always with 0, on
+ * the per-wave kernel.  Same results up to the order of the fp32 sums; deterministic either way. */
+int cot_conv3x3g_backward_weight_guarded(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
+                                         int Cin, int Cout, int groups, int H, int W, int dtype, int x_guard_elems, void* stream);
 
 /* ---- grouped 1x1 convolution, NCHW (CoXtLayer.embed[0] = Conv2d(2*dim, dim/2, 1, groups=2),
  * embed[3] = Conv2d(dim/2, 9*dim/8, 1, groups=2) with bias, conv1x1[0] = Conv2d(dim, dim, 1, groups=2),

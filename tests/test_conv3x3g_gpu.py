@@ -71,6 +71,49 @@ def test_weight_gradient_is_deterministic(monkeypatch):
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
 
 
+@pytest.mark.parametrize("N,C,G,H", [(80, 64, 4, 56), (80, 128, 4, 28), (80, 256, 4, 14), (80, 512, 4, 7), (5, 64, 4, 12), (3, 128, 1, 9)])
+def test_weight_gradient_lds_staged_kernel(N, C, G, H):
+    """cot_conv3x3g_backward_weight_guarded (csrc/conv_wgrad2.hip, TAPS form) at the batch the benchmark runs and at ragged
+    sizes: x lives inside an allocation whose margins are NaN (what the shifted 16-byte copies read there must be cleared by
+    selection); against torch's conv2d weight gradient in fp32 on the same operands; twice -> same bits; and the kernel that ran
+    is the LDS-staged one"""
+    import ctypes
+    from cotnet_amd import _lib
+    L = _lib.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(C + H)
+    HW, lead = H * H, (H + 1 + 7) // 8 * 8
+    flat = torch.full((N * C * HW + 2 * lead,), float("nan"), device=DEV).bfloat16()
+    x = flat[lead:lead + N * C * HW].view(N, C, H, H)
+    x.copy_(torch.randn(N, C, H, H, device=DEV))
+    gy = torch.randn(N, C, H, H, device=DEV).bfloat16()
+    wf = torch.zeros(C, C // G, 3, 3, device=DEV, requires_grad=True)
+    F.conv2d(x.float(), wf, None, 1, 1, 1, G).backward(gy.float())
+    masks = torch.empty(int(L.cot_conv3x3g_masks_bytes(H, H)), dtype=torch.uint8, device=DEV)
+    assert L.cot_conv3x3g_masks(P(masks), H, H, st) == 0
+    ws = torch.empty(int(L.cot_conv3x3g_workspace(N, C, C, G, H, H)), dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        gw = torch.full((C, C // G, 3, 3), float("nan"), device=DEV).bfloat16()
+        ws.fill_(0x7f)
+        rc = L.cot_conv3x3g_backward_weight_guarded(P(gy), P(x), P(gw), P(masks), P(ws), N, C, C, G, H, H, _lib.COT_BF16, lead, st)
+        assert rc == 0, L.cot_last_error()
+        torch.cuda.synchronize()
+        outs.append(gw)
+    try:  # which kernels the call takes: a dry run (nothing is launched) fills the launch log
+        assert L.cot_set_tuning(26, 1) == 0
+        assert L.cot_conv3x3g_backward_weight_guarded(P(gy), P(x), P(gw), P(masks), P(ws), N, C, C, G, H, H, _lib.COT_BF16, lead, st) == 0
+        buf = ctypes.create_string_buffer(4096)
+        L.cot_launch_log(buf, 4096)
+    finally:
+        assert L.cot_set_tuning(26, 0) == 0
+    assert b"conv1x1_wgrad_lds2<9, 1" in buf.value and b"block 832" in buf.value, buf.value
+    assert torch.equal(outs[0], outs[1])
+    scale = wf.grad.abs().max().item()
+    assert (outs[0].float() - wf.grad).abs().max().item() <= 1e-2 * scale
+
+
 def test_cot_layer_with_all_hip_convolutions():
     """CotLayer forward+backward with every convolution on the hand-written kernels: not further from the fp32 truth
     than the default (MIOpen) path (tests/truth.py)"""

@@ -131,6 +131,9 @@ def build_table():
                     rec(tag + " fwd", L.cot_conv3x3g_forward(PTR, PTR, PTR, PTR, PTR, N, Ci, Co, g, H, W, BF, None))
                     rec(tag + " dgrad", L.cot_conv3x3g_backward_data(PTR, PTR, PTR, 0, PTR, PTR, N, Ci, Co, g, H, W, BF, None))
                     rec(tag + " wgrad", L.cot_conv3x3g_backward_weight(PTR, PTR, PTR, PTR, PTR, N, Ci, Co, g, H, W, BF, None))
+                    # (the single-node Bottleneck allocates the CoT layer's input with margins: cot_layer_fused._new_guarded)
+                    rec(tag + " wgrad(guarded)", L.cot_conv3x3g_backward_weight_guarded(PTR, PTR, PTR, PTR, PTR, N, Ci, Co, g, H, W, BF,
+                                                                                        (W + 8) // 8 * 8, None))
                 elif kind == "bn":
                     N, C, HW = shp
                     rec(tag + " fwd", L.cot_bn_act_forward(PTR, None, PTR, PTR, PTR, PTR, PTR, PTR, PTR, PTR, PTR, N, C, HW, 1e-5, 0.1, 1,
@@ -185,6 +188,8 @@ def test_no_benchmark_layer_falls_off_the_tuned_kernels():
                 assert names[0] == "conv1x1_wgrad_lds2", (key, launches)
         if key.startswith("cotnet50") and " conv3x3 " in key and (key.endswith(" fwd") or key.endswith(" dgrad")):
             assert "conv3x3g_lds_fwd" in names, (key, launches)
+        if key.startswith("cotnet50") and " conv3x3 " in key and key.endswith(" wgrad(guarded)"):
+            assert names[0] == "conv1x1_wgrad_lds2" and "block=832" in launches[0], (key, launches)  # (the TAPS form: 9 + 4 waves)
         if " agg " in key:
             assert all("k3_lds" in n for n in names), (key, launches)
     grouped = [k for k in table if k.startswith("cotnext") and " conv1x1 " in k and k.split()[2].split("x")[3] == "2"]

