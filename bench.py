@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-seconds", type=float, default=30.0,
+                    help="untimed settling before the warm-up steps: chunks of 10 steps until three agree within 1 %% (0 = off)")
     ap.add_argument("--batch", type=int, default=80, help="images per GPU (reference recipe: 80)")
     ap.add_argument("--model", default="cotnet50")
     ap.add_argument("--img", type=int, default=224)
@@ -603,6 +605,29 @@ def main():
         torch.cuda.synchronize()
 
     roctx_window(resume=False)
+    # Settling (untimed, before the W warm-up steps): a fresh box runs the first tens of seconds of sustained load ~5 % slower than
+    # it does afterwards, whatever ran before in the process (gpurun_out/r3s30_ab.log: 17.11 / 17.10 ms for the first two
+    # processes on a box, 16.37 / 16.04 / 16.37 / 16.03 for the next four, alternating two kernel sets) -- device power
+    # management, not this program's warm-up.  Chunks of 10 steps until three in a row agree within 1 % (all ranks take the
+    # slowest rank's time, so they stop together), at most --settle-seconds.  Reported in the line as `settle`.
+    settle = {"steps": 0, "first_chunk_ms": None, "last_chunk_ms": None, "seconds": 0.0}
+    if args.settle_seconds > 0:
+        t_s, hist = time.perf_counter(), []
+        while True:
+            barrier()
+            c0 = time.perf_counter()
+            for _ in range(10):
+                loss = step()
+            torch.cuda.synchronize()
+            ct = torch.tensor([time.perf_counter() - c0, time.perf_counter() - t_s], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+            hist.append(float(ct[0].item()) * 100.0)  # ms per step
+            settle["steps"] += 10
+            done = len(hist) >= 3 and max(hist[-3:]) <= 1.01 * min(hist[-3:])
+            if done or float(ct[1].item()) >= args.settle_seconds:
+                break
+        settle.update(first_chunk_ms=round(hist[0], 3), last_chunk_ms=round(hist[-1], 3), seconds=round(time.perf_counter() - t_s, 2))
     for _ in range(args.warmup):
         loss = step()
     barrier()
@@ -723,7 +748,7 @@ def main():
         line = {
             "metric": f"images/sec {MODEL_TITLES.get(args.model, args.model)} {args.img}^2 " + ("fwd+bwd" if args.mode == "train" else "fwd"),
             "value": round(B * world * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "steps": args.steps, "warmup": args.warmup, "settle": settle, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if amp else "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} {args.img}x{args.img} {'fwd+bwd+SGD-nesterov' if args.mode == 'train' else 'forward-only'}, "

@@ -19,6 +19,8 @@ module's ordinary forward.  Verified against the unfused reference formula throu
 MI355X: ~1290 launches and 19.1 ms per step with every kernel from cotnet_amd/csrc.
 """
 import ctypes
+import functools
+import threading
 import os
 import weakref
 
@@ -38,8 +40,30 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
+_TLS = threading.local()  # .st: the compute stream's handle for the node invocation running on this thread
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if _DEVICE_ONLY else None
+    if not _DEVICE_ONLY:
+        return None
+    st = getattr(_TLS, "st", None)
+    return st if st is not None else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _one_stream_query(fn):
+    """torch.cuda.current_stream() costs ~9 us and a node makes ~100 launches: ask once per forward / backward of a node (the
+    current stream cannot change inside one; forward and backward run on different threads, hence thread-local).  Measured:
+    1.3 ms of a step's ~12 ms of host time (gpurun_out/r3_cpu_profile.log)"""
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        if not _DEVICE_ONLY or getattr(_TLS, "st", None) is not None:
+            return fn(*a, **k)
+        _TLS.st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        try:
+            return fn(*a, **k)
+        finally:
+            _TLS.st = None
+    return wrapped
 
 
 def _ck(rc, what):
@@ -422,6 +446,7 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
 
 class _CotLayerNode(Function):
     @staticmethod
+    @_one_stream_query
     def forward(ctx, layer, x, *params):
         # params (_Plan.params) are only here so that autograd routes their gradients; values are read off `layer`
         out, saved, geom = _cot_forward(_lib.lib(), layer, x)
@@ -430,6 +455,7 @@ class _CotLayerNode(Function):
         return out
 
     @staticmethod
+    @_one_stream_query
     def backward(ctx, gout):
         gx, gparams = _cot_backward(_lib.lib(), ctx.layer, ctx.saved_tensors, ctx.geom, gout)
         return (None, gx) + gparams
@@ -524,6 +550,7 @@ def _block_sizes(L, N, Cin, Cw, Cout, HW):
 
 class _BottleneckNode(Function):
     @staticmethod
+    @_one_stream_query
     def forward(ctx, blk, x, *params):
         L = _lib.lib()
         bp = _block_plan(blk)
@@ -570,6 +597,7 @@ class _BottleneckNode(Function):
         return y
 
     @staticmethod
+    @_one_stream_query
     def backward(ctx, gout):
         L = _lib.lib()
         blk = ctx.blk

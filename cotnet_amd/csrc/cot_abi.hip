@@ -160,6 +160,7 @@ bool conv1x1_wgrad_lds_covers(int N, int HW, int M, int J);
 int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad_lds_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_wgrad2_tune;  // conv_wgrad2.hip (third-generation weight gradient)
+extern int g_pool_tile;    // pool3x3.hip (plane-tile pooling kernels)
 bool conv1x1_wgrad2_covers(int N, int HW, int M, int J, int k1, bool two_slabs);
 int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad2_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
@@ -354,6 +355,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 25) {
         g_wgrad2_tune = value;
+        return COT_OK;
+    }
+    if (key == 27) {
+        g_pool_tile = value ? 1 : 0;
         return COT_OK;
     }
     if (key == 24) {  // DIAGNOSTIC: timing ablations of the third-generation 1x1 kernel (results become wrong)

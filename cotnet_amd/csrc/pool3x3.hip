@@ -8,6 +8,8 @@
 // recomputes the arg-max from x with torch's tie rule (first maximum in row-major window order, `>` comparison, NaN
 // wins -- after a ReLU ties at zero are the common case), so no index tensor exists.
 // One thread per output pixel (forward) / input pixel (backward, gather form: no atomics), threads along W.
+#include <algorithm>
+
 #include "cot_common.h"
 
 namespace cot {
@@ -211,6 +213,156 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_tap(const T* __restrict_
     }
 }
 
+// ---- row-block form of the four kernels a CoTNet step runs (average pooling forward / backward, max pooling with byte taps
+// forward / backward), for even W.  The one-lane-per-pixel kernels above are bound by their instruction count, not by
+// memory: two 64-bit divisions, nine (or four) separately addressed and bounds-checked 2-byte loads and one 2-byte store per
+// pixel -- 119 us for the gradient of the 56 x 56 -> 28 x 28 average pooling of a stride-2 block (80 MB of traffic, 13 us at
+// the roofline), 155 us for the stem's max pooling; staging whole planes through LDS with the same per-pixel arithmetic
+// measured no faster (gpurun_out/r3s29_pool.log).  Here a lane owns BG consecutive windows of one output row: it loads
+// the 2 BG + 1 input columns of each of the three rows once (one wide load + the left neighbour) and produces BG outputs
+// (forward), or loads BG + 1 columns of two gradient rows and produces a 2 x 2 BG block of the input gradient (backward) --
+// the index arithmetic is paid once per lane, accesses are 4 .. 16 bytes wide.  Same sums in the same order: identical results.
+template <typename T, int BG, bool MAXP>  // forward: y (and the arg-max taps of the max pooling)
+__global__ __launch_bounds__(256) void pool3x3s2_fwd_blk(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ tap,
+                                                         int64_t planes, int H, int W, int Ho, int Wo) {
+    const int NB = Wo / BG;  // (Wo % BG == 0: host)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ho * NB) return;
+    const int bg = (int)(i % NB), oh = (int)((i / NB) % Ho);
+    const int64_t pl = i / ((int64_t)NB * Ho);
+    const int ow0 = bg * BG;
+    const T* xp = x + pl * H * W;
+    float acc[BG];
+    int am[BG];
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+        acc[j] = MAXP ? -INFINITY : 0.f;
+        am[j] = -1;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = 2 * oh - 1 + kh;
+        if (h < 0 || h >= H) continue;
+        float L[2 * BG + 1];
+        const T* rp = xp + h * W + 2 * ow0;
+        L[0] = ow0 > 0 ? (float)rp[-1] : 0.f;
+        const Vec<T, 2 * BG> v = ldv<T, 2 * BG>(rp);
+#pragma unroll
+        for (int c = 0; c < 2 * BG; ++c) L[1 + c] = (float)v.v[c];
+#pragma unroll
+        for (int j = 0; j < BG; ++j)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                if (kw == 0 && ow0 + j == 0) continue;  // column -1
+                const float val = L[2 * j + kw];
+                if (MAXP) {  // torch's rule: first maximum in row-major window order, NaN wins
+                    if (val > acc[j] || val != val || am[j] < 0) {
+                        acc[j] = val;
+                        am[j] = kh * 3 + kw;
+                    }
+                } else {
+                    acc[j] += val;
+                }
+            }
+    }
+    Vec<T, BG> o;
+    Vec<uint8_t, BG> ot;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+        o.v[j] = (T)(MAXP ? acc[j] : acc[j] * (1.f / 9.f));
+        ot.v[j] = (uint8_t)am[j];
+    }
+    const int64_t oi = pl * Ho * Wo + (int64_t)oh * Wo + ow0;
+    stv<T, BG>(y + oi, o);
+    if (MAXP && tap) stv<uint8_t, BG>(tap + oi, ot);
+}
+
+template <typename T, int BG, bool MAXP>  // backward: a lane = rows 2a, 2a+1, columns 2 b0 .. 2 (b0 + BG) - 1 of the input gradient
+__global__ __launch_bounds__(256) void pool3x3s2_bwd_blk(const T* __restrict__ gy, const uint8_t* __restrict__ tap, T* __restrict__ gx,
+                                                         int64_t planes, int H, int W, int Ho, int Wo) {
+    const int Ha = (H + 1) / 2, NB = Wo / BG;  // (W even: Wo = W / 2 column pairs)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ha * NB) return;
+    const int bg = (int)(i % NB), a = (int)((i / NB) % Ha);
+    const int64_t pl = i / ((int64_t)NB * Ha);
+    const int b0 = bg * BG;
+    const T* gp = gy + pl * Ho * Wo;
+    const uint8_t* tp = MAXP ? tap + pl * Ho * Wo : nullptr;
+    float g[2][BG + 1];
+    int t[2][BG + 1];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oh = a + r;
+        const bool okr = oh < Ho;
+        if (okr) {
+            const Vec<T, BG> v = ldv<T, BG>(gp + oh * Wo + b0);
+#pragma unroll
+            for (int c = 0; c < BG; ++c) g[r][c] = (float)v.v[c];
+            g[r][BG] = b0 + BG < Wo ? (float)gp[oh * Wo + b0 + BG] : 0.f;
+            if (MAXP) {
+                const Vec<uint8_t, BG> tv = ldv<uint8_t, BG>(tp + oh * Wo + b0);
+#pragma unroll
+                for (int c = 0; c < BG; ++c) t[r][c] = (int)tv.v[c];
+                t[r][BG] = b0 + BG < Wo ? (int)tp[oh * Wo + b0 + BG] : -1;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c <= BG; ++c) {
+                g[r][c] = 0.f;
+                t[r][c] = -1;
+            }
+        }
+    }
+    const bool right_ok = b0 + BG < Wo;  // (column b0 + BG exists)
+    Vec<T, 2 * BG> o0, o1;
+#pragma unroll
+    for (int c = 0; c < BG; ++c) {
+        const bool rc = c + 1 < BG || right_ok;  // window column b + 1 exists
+        float s00, s01, s10, s11;
+        if (MAXP) {  // pixel (2a, 2b) is tap 4 of window (a, b); (2a, 2b+1): tap 5 of (a, b), 3 of (a, b+1); (2a+1, 2b): 7 / 1;
+                     // (2a+1, 2b+1): 8 / 6 / 2 / 0 of (a, b) / (a, b+1) / (a+1, b) / (a+1, b+1); windows ascending
+            s00 = t[0][c] == 4 ? g[0][c] : 0.f;
+            s01 = 0.f; s10 = 0.f; s11 = 0.f;
+            if (t[0][c] == 5) s01 += g[0][c];
+            if (t[0][c + 1] == 3) s01 += g[0][c + 1];
+            if (t[0][c] == 7) s10 += g[0][c];
+            if (t[1][c] == 1) s10 += g[1][c];
+            if (t[0][c] == 8) s11 += g[0][c];
+            if (t[0][c + 1] == 6) s11 += g[0][c + 1];
+            if (t[1][c] == 2) s11 += g[1][c];
+            if (t[1][c + 1] == 0) s11 += g[1][c + 1];
+        } else {  // windows (oh, ow) ascending, as the per-pixel kernel adds them
+            s00 = g[0][c];
+            s01 = g[0][c];
+            if (rc) s01 += g[0][c + 1];
+            s10 = g[0][c];
+            if (a + 1 < Ho) s10 += g[1][c];
+            s11 = g[0][c];
+            if (rc) s11 += g[0][c + 1];
+            if (a + 1 < Ho) {
+                s11 += g[1][c];
+                if (rc) s11 += g[1][c + 1];
+            }
+            s00 *= 1.f / 9.f; s01 *= 1.f / 9.f; s10 *= 1.f / 9.f; s11 *= 1.f / 9.f;
+        }
+        o0.v[2 * c] = (T)s00; o0.v[2 * c + 1] = (T)s01;
+        o1.v[2 * c] = (T)s10; o1.v[2 * c + 1] = (T)s11;
+    }
+    T* o = gx + pl * H * W + (int64_t)(2 * a) * W + 2 * b0;
+    stv<T, 2 * BG>(o, o0);
+    if (2 * a + 1 < H) stv<T, 2 * BG>(o + W, o1);
+}
+
+int g_pool_tile = 1;  // cot_set_tuning key 27: 0 = one lane per pixel only
+// windows per lane of the row-block form (0: not eligible): W even, every wide access naturally aligned
+static int pool_blk_group(int op, int H, int W, int Ho, int Wo) {
+    if (!g_pool_tile || !(op == 0 || op == 1 || op == 4 || op == 5) || (W & 1) || W < 2) return 0;
+    const bool odd_planes = ((H * W) & 7) || ((Ho * Wo) & 7);  // (planes do not all start on 16-byte boundaries: narrower groups)
+    if (Wo % 4 == 0 && !odd_planes) return 4;
+    if (Wo % 2 == 0 && !(((H * W) & 3) || ((Ho * Wo) & 3))) return 2;
+    return (((H * W) & 1) || ((Ho * Wo) & 1)) ? 0 : 1;
+}
+
 // ---- BlurPool2d(filt_size = 3, stride = 2): reflection padding by one pixel, depthwise binomial filter [1 2 1] x [1 2 1] / 16,
 // stride 2 (the anti-aliased down-sampling of SE-CoTNetD, reference models/layers/blur_pool.py:53-58 -- there a
 // ReflectionPad2d + a grouped F.conv2d whose weight is the filter repeated per channel: MIOpen runs a depthwise convolution
@@ -279,6 +431,21 @@ int pool3x3s2(int op, const void* a, const void* b, void* out, int64_t planes, i
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;  // floor((H + 2 - 3) / 2) + 1
     const int64_t n_out = planes * Ho * Wo, n_in = planes * H * W;
     const dim3 block(256);
+    if (const int BG = pool_blk_group(op, H, W, Ho, Wo)) {
+        const bool bwd = op == 1 || op == 5;
+        const int64_t lanes = planes * (bwd ? (H + 1) / 2 : Ho) * (Wo / BG);
+        const dim3 grid((unsigned)ceil_div64(lanes, 256));
+#define COT_POOL_BLK(BG_)                                                                                                       \
+    switch (op) {                                                                                                              \
+        case 0: COT_LAUNCH((pool3x3s2_fwd_blk<T, BG_, false>), grid, block, 0, stream, (const T*)a, (T*)out, nullptr, planes, H, W, Ho, Wo); break; \
+        case 4: COT_LAUNCH((pool3x3s2_fwd_blk<T, BG_, true>), grid, block, 0, stream, (const T*)a, (T*)out, (uint8_t*)const_cast<void*>(b), planes, H, W, Ho, Wo); break; \
+        case 1: COT_LAUNCH((pool3x3s2_bwd_blk<T, BG_, false>), grid, block, 0, stream, (const T*)a, nullptr, (T*)out, planes, H, W, Ho, Wo); break; \
+        default: COT_LAUNCH((pool3x3s2_bwd_blk<T, BG_, true>), grid, block, 0, stream, (const T*)a, (const uint8_t*)b, (T*)out, planes, H, W, Ho, Wo); break; \
+    }
+        if (BG == 4) { COT_POOL_BLK(4) } else if (BG == 2) { COT_POOL_BLK(2) } else { COT_POOL_BLK(1) }
+#undef COT_POOL_BLK
+        return check_launch("pool3x3s2 (row blocks)");
+    }
     switch (op) {
         case 0: COT_LAUNCH((avgpool3x3s2_fwd<T>), dim3((unsigned)ceil_div64(n_out, 256)), block, 0, stream, (const T*)a, (T*)out, planes, H, W, Ho, Wo); break;
         case 1: COT_LAUNCH((avgpool3x3s2_bwd<T>), dim3((unsigned)ceil_div64(n_in, 256)), block, 0, stream, (const T*)a, (T*)out, planes, H, W, Ho, Wo); break;

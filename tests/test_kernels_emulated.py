@@ -17,9 +17,10 @@ try:
     for _name, (_res, _args) in _lib.SYMBOLS.items():
         getattr(_EMUL, _name).restype = _res
         getattr(_EMUL, _name).argtypes = _args
-except (FileNotFoundError, OSError, Exception) as e:  # no host clang: skip, the GPU tests still gate parity
+except FileNotFoundError as e:  # no host compiler: skip, the GPU tests still gate parity
     _EMUL = None
     _WHY = repr(e)
+# (a build that succeeds but does not load -- an undefined symbol -- is an error, not a reason to skip 1000 tests)
 
 pytestmark = pytest.mark.skipif(_EMUL is None, reason="host emulation build unavailable")
 
@@ -1463,8 +1464,42 @@ def test_conv1x1_with_64_rows_per_wave(N, Ci, Co, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 4, 7, 7), (2, 2, 14, 14), (1, 2, 5, 9), (1, 1, 1, 1), (1, 2, 2, 3)])
-def test_pooling_kernels_match_torch(N, C, H, W, dtype):
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 4, 7, 7), (2, 2, 14, 14), (1, 2, 5, 9), (1, 1, 1, 1), (1, 2, 2, 3), (2, 24, 28, 28),
+                                     (1, 40, 14, 14), (3, 11, 7, 7), (1, 3, 56, 56)])
+@pytest.mark.parametrize("tile", [1, 0])
+def test_pooling_kernels_match_torch(N, C, H, W, dtype, tile, request):
+    assert _EMUL.cot_set_tuning(27, tile) == 0  # (1: whole planes through LDS where eligible; 0: one lane per pixel)
+    request.addfinalizer(lambda: _EMUL.cot_set_tuning(27, 1))
+    _pooling_kernels_match_torch(N, C, H, W, dtype)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 24, 28, 28), (3, 11, 7, 7), (1, 6, 56, 56), (2, 5, 13, 9)])
+def test_pooling_plane_tile_form_is_bit_identical(N, C, H, W):
+    """the plane-tile kernels do the per-pixel kernels' arithmetic in the same order: same bits, taps included"""
+    torch.manual_seed(5)
+    dt = _lib.dtype_code(torch.bfloat16)
+    x = torch.relu(torch.randn(N, C, H, W)).bfloat16()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = torch.randn(N, C, Ho, Wo).bfloat16()
+    res = []
+    try:
+        for tile in (1, 0):
+            assert _EMUL.cot_set_tuning(27, tile) == 0
+            y, ya = torch.full_like(gy, float("nan")), torch.full_like(gy, float("nan"))
+            gx, gxa = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+            taps = torch.full((N, C, Ho, Wo), 255, dtype=torch.uint8)
+            assert _EMUL.cot_maxpool3x3s2_forward_taps(P(x), P(y), P(taps), N * C, H, W, dt, None) == 0
+            assert _EMUL.cot_maxpool3x3s2_backward_taps(P(gy), P(taps), P(gx), N * C, H, W, dt, None) == 0
+            assert _EMUL.cot_avgpool3x3s2_forward(P(x), P(ya), N * C, H, W, dt, None) == 0
+            assert _EMUL.cot_avgpool3x3s2_backward(P(gy), P(gxa), N * C, H, W, dt, None) == 0
+            res.append((y, taps, gx, ya, gxa))
+    finally:
+        assert _EMUL.cot_set_tuning(27, 1) == 0
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def _pooling_kernels_match_torch(N, C, H, W, dtype):
     """csrc/pool3x3.hip against nn.MaxPool2d(3, 2, 1) / nn.AvgPool2d(3, 2, padding=1); the max pooling is exercised on a
     ReLU output (ties at zero everywhere): the recomputed arg-max must follow torch's first-maximum rule exactly"""
     torch.manual_seed(31)
