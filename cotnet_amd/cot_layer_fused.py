@@ -83,17 +83,39 @@ def _ck(rc, what):
 #   * the side stream is in-order, so its launches share ONE persistent workspace of their own (partial sums are consumed by
 #     the same launch's reduce); the compute stream's workspace is never touched by it.
 # COT_WGRAD_STREAM=0 (or cot_layer_fused.SIDE_WGRAD = False) issues everything on the compute stream as before (A/B, tests).
+#
+# COT_WGRAD_LAZY=1 (default): the node's weight-gradient launches are QUEUED and issued together when its backward ends --
+# one event pair for the node instead of one per launch (ten per Bottleneck: each pair is ~8 us of host time and a barrier
+# packet on both queues) -- and the compute stream does not join them there: they run beside the NEXT node's backward.  The
+# compute stream joins the side stream (a) at the next node's flush, which is also when the tensors the previous node's
+# launches read are released, and (b) when the backward pass ends (autograd engine callback), i.e. before an optimizer or
+# anybody else on the compute stream can see the gradients; a gradient bucket that launches its all-reduce mid-backward makes
+# its communication stream wait for the side stream (grad_sink.producer_streams).
 SIDE_WGRAD = os.environ.get("COT_WGRAD_STREAM", "1") != "0"
+LAZY_WGRAD = os.environ.get("COT_WGRAD_LAZY", "1") != "0"
 _SIDE_STREAMS = {}  # device index -> [torch.cuda.Stream, workspace tensor]
+_SIDE_PENDING = {}  # device index -> {"keep": tensors read by launches the compute stream has not joined yet, "cb": callback queued}
+
+
+def _join_pending(dev_index):
+    """the compute stream waits for everything issued on the side stream so far; the tensors those launches read are released"""
+    ent, pend = _SIDE_STREAMS.get(dev_index), _SIDE_PENDING.get(dev_index)
+    if ent is None or pend is None:
+        return
+    if pend["keep"]:
+        torch.cuda.current_stream(torch.device("cuda", dev_index)).wait_stream(ent[0])
+        pend["keep"] = []
+    pend["cb"] = False
 
 
 class _Side:
     """the side stream for one node's backward (or a pass-through onto the compute stream when switched off / on CPU tensors)"""
-    __slots__ = ("on", "main", "stream", "st", "ws", "keep")
+    __slots__ = ("on", "main", "stream", "st", "ws", "keep", "lazy", "queue", "dev")
 
     def __init__(self, dev, ws_bytes, main_ws):
         self.on = SIDE_WGRAD and _DEVICE_ONLY and dev.type == "cuda"
-        self.keep = []
+        self.lazy = self.on and LAZY_WGRAD
+        self.keep, self.queue, self.dev = [], [], dev
         if not self.on:
             self.st, self.ws = _stream(), main_ws
             return
@@ -107,6 +129,17 @@ class _Side:
                 ent[1] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self.ws = ent[1]
         self.st = ctypes.c_void_p(self.stream.cuda_stream)
+        if self.lazy and dev.index not in _SIDE_PENDING:
+            _SIDE_PENDING[dev.index] = {"keep": [], "cb": False}
+            grad_sink.register_producer_stream(self.stream, lambda i=dev.index: _join_pending(i))
+
+    def run(self, fn, *tensors):
+        """fn(stream handle) launches ONE weight gradient that reads `tensors` (all of them final when this is called)"""
+        if self.lazy:
+            self.queue.append(fn)
+            self.keep.extend(tensors)
+        else:
+            fn(self.ready(*tensors))
 
     def ready(self, *tensors):
         """call right before a side-stream launch that reads `tensors`: everything the compute stream has issued so far is
@@ -117,7 +150,22 @@ class _Side:
         return self.st
 
     def join(self):
-        if self.on:
+        if self.lazy:
+            pend = _SIDE_PENDING[self.dev.index]
+            if pend["keep"]:  # the previous node's launches: long done by now; their inputs may go
+                self.main.wait_stream(self.stream)
+            pend["keep"] = self.keep
+            self.stream.wait_stream(self.main)
+            for fn in self.queue:
+                fn(self.st)
+            self.queue, self.keep = [], []
+            if not pend["cb"]:  # join when the backward pass ends
+                pend["cb"] = True
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(lambda i=self.dev.index: _join_pending(i))
+                except RuntimeError:  # (not inside the engine's backward: join now)
+                    _join_pending(self.dev.index)
+        elif self.on:
             self.main.wait_stream(self.stream)
             self.keep.clear()
 
@@ -377,15 +425,13 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st),
         "cot_conv1x1_backward_data")
     g_w3, g_b3 = grad_sink.out_like(se3.weight), grad_sink.out_like(se3.bias)
-    _ck(L.cot_conv1x1_backward_weight(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(side.ws), 1, A, 2 * C, N, BF16,
-                                      side.ready(glogT, h)), "cot_conv1x1_backward_weight")
+    side.run(lambda st_, a_=(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(side.ws), 1, A, 2 * C, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), glogT, h)
     ghpre = row(A)
     d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, None, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
     _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st),
         "cot_conv1x1_backward_data")
     g_w0, g_b0 = grad_sink.out_like(se0.weight), grad_sink.out_like(se0.bias)
-    _ck(L.cot_conv1x1_backward_weight(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(side.ws), 1, C, A, N, BF16,
-                                      side.ready(ghpre, gapT)), "cot_conv1x1_backward_weight")
+    side.run(lambda st_, a_=(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(side.ws), 1, C, A, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ghpre, gapT)
     gy, gk = torch.empty_like(y), torch.empty_like(k)
     _ck(L.cot_radix_mix_backward_apply(_p(gout), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, BF16, st),
         "cot_radix_mix_backward_apply")
@@ -402,8 +448,7 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gx), None, C, 0, _p(ws), N, C, C, HW, BF16, st),
         "cot_conv1x1_backward_data")
     g_wv = grad_sink.out_like(cv0.weight)
-    _ck(L.cot_conv1x1_backward_weight(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(side.ws), N, C, C, HW, BF16,
-                                      side.ready(gv_pre, x)), "cot_conv1x1_backward_weight")
+    side.run(lambda st_, a_=(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(side.ws), N, C, C, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), gv_pre, x)
     # logits branch: GroupNorm, conv1x1(+bias), bn+relu, conv1x1 on [x | k] -> dx +=, dk +=
     gn = pl.gn
     if HW <= 8192:
@@ -419,22 +464,20 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), N, Ch, Ce, HW, BF16,
                                     st), "cot_conv1x1_backward_data")
     g_we3, g_be3 = grad_sink.out_like(em3.weight), grad_sink.out_like(em3.bias)
-    _ck(L.cot_conv1x1_backward_weight(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(side.ws), N, Ch, Ce, HW, BF16,
-                                      side.ready(ge3, e1)), "cot_conv1x1_backward_weight")
+    side.run(lambda st_, a_=(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(side.ws), N, Ch, Ce, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge3, e1)
     ge0 = torch.empty_like(e0)
     d_em_w, d_em_b = _bn_bwd(L, ge1, e0, None, ge0, em1, s_e, N, Ch, HW, 1, nws_h)  # (ReLU mask recomputed from e0)
     _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gx), _p(gk), C, 3, _p(ws), N, 2 * C, Ch, HW, BF16,
                                     st), "cot_conv1x1_backward_data")
     g_we0 = grad_sink.out_like(em0.weight)
-    _ck(L.cot_conv1x1_backward_weight(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(side.ws), N, 2 * C, Ch, HW, BF16,
-                                      side.ready(ge0, x, k)), "cot_conv1x1_backward_weight")
+    side.run(lambda st_, a_=(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(side.ws), N, 2 * C, Ch, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge0, x, k)
     # key branch: bn+relu, grouped 3x3 -> dx +=
     gk_pre = gv  # (reuse: gv is dead)
     d_ke_w, d_ke_b = _bn_bwd(L, gk, k_pre, None, gk_pre, ke1, s_k, N, C, HW, 1, nws_c)
     G = ke0.groups
     g_wk = grad_sink.out_like(ke0.weight)
-    _ck(L.cot_conv3x3g_backward_weight_guarded(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(side.ws), N, C, C, G, H, W, BF16,
-                                               _guard_elems(x), side.ready(gk_pre, x, masks)), "cot_conv3x3g_backward_weight")
+    side.run(lambda st_, a_=(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(side.ws), N, C, C, G, H, W, BF16,
+                                               _guard_elems(x)): _ck(L.cot_conv3x3g_backward_weight_guarded(*a_, st_), "cot_conv3x3g_backward_weight"), gk_pre, x, masks)
     _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx), 1, _p(masks), _p(ws), N, C, C, G, H, W,
                                      BF16, st), "cot_conv3x3g_backward_data")
     if own_side:
@@ -625,8 +668,7 @@ class _BottleneckNode(Function):
         _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_cot_out), None, Cw, 0, _p(ws), N, Cw, Cout, HWo,
                                         BF16, st), "cot_conv1x1_backward_data")
         g_w3 = grad_sink.out_like(bp.conv3.weight)
-        _ck(L.cot_conv1x1_backward_weight(_p(g_c3), _p(cot_out), None, Cw, _p(g_w3), None, _p(side.ws), N, Cw, Cout, HWo, BF16,
-                                          side.ready(g_c3, cot_out)), "cot_conv1x1_backward_weight")
+        side.run(lambda st_, a_=(_p(g_c3), _p(cot_out), None, Cw, _p(g_w3), None, _p(side.ws), N, Cw, Cout, HWo, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, cot_out)
         g_p1, g_cot = _cot_backward(L, bp.cot, saved, ctx.geom, g_cot_out, side)
         if bp.avd:
             g_a1 = torch.empty_like(a1)
@@ -653,14 +695,12 @@ class _BottleneckNode(Function):
                 _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(gx), None, Cin, 0, _p(ws), N, Cin,
                                                 Cout, HWo, BF16, st), "cot_conv1x1_backward_data")
             g_wd = grad_sink.out_like(bp.ds_conv.weight)
-            _ck(L.cot_conv1x1_backward_weight(_p(g_d0), _p(xs), None, Cin, _p(g_wd), None, _p(side.ws), N, Cin, Cout, HWo, BF16,
-                                              side.ready(g_d0, xs)), "cot_conv1x1_backward_weight")
+            side.run(lambda st_, a_=(_p(g_d0), _p(xs), None, Cin, _p(g_wd), None, _p(side.ws), N, Cin, Cout, HWo, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_d0, xs)
             g_ds = (g_wd, d_ds_w, d_ds_b)
         else:
             gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
         g_w1 = grad_sink.out_like(bp.conv1.weight)  # (issued before its data gradient: the two overlap)
-        _ck(L.cot_conv1x1_backward_weight(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, Cw, HW, BF16,
-                                          side.ready(g_c1, x)), "cot_conv1x1_backward_weight")
+        side.run(lambda st_, a_=(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, Cw, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, x)
         _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16,
                                         st), "cot_conv1x1_backward_data")
         side.join()

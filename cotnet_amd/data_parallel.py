@@ -174,6 +174,7 @@ class GradBucketReducer:
             else:
                 v.zero_()  # parameter unused this step
         if dst:
+            grad_sink.sync_producers()  # (a gradient kernel on a side stream may still be writing what is copied here)
             torch._foreach_copy_(dst, src)
         for p in b.params:
             p.grad = None
@@ -198,6 +199,8 @@ class GradBucketReducer:
             b.ready_event.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(b.ready_event)
+                for ps in grad_sink.producer_streams():  # weight gradients written in place by a side stream (cot_layer_fused)
+                    self.comm_stream.wait_stream(ps)
                 b.work = self._all_reduce(b.flat)
         else:
             b.work = self._all_reduce(b.flat)

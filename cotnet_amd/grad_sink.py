@@ -19,6 +19,22 @@ accumulates as usual.
 import torch
 
 _SINK = {}  # id(param) -> [param, view into the flat gradient bucket, lent this step]
+_PRODUCERS = []  # (stream, join): streams other than the compute stream on which gradient kernels run (cot_layer_fused's side stream)
+
+
+def register_producer_stream(stream, join):
+    """`stream` carries kernels that write parameter gradients; `join()` makes the current (compute) stream wait for it"""
+    _PRODUCERS.append((stream, join))
+
+
+def producer_streams():
+    return [s for s, _ in _PRODUCERS]
+
+
+def sync_producers():
+    """the compute stream waits for every gradient kernel issued so far on a producer stream"""
+    for _, join in _PRODUCERS:
+        join()
 
 
 def register(param, view):
