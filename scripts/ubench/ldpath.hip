@@ -66,10 +66,12 @@ __global__ __launch_bounds__(512) void stream(const char* __restrict__ src, size
     if (acc[0] == 0x12345678u && acc[1] == 77u) sink[threadIdx.x] = acc[2] ^ acc[3];
 }
 
+static int g_blocks = 256;  // workgroups (= CUs used): argv[1]
+
 template <int MODE, int DEPTH>
 static void run(const char* name, const char* src, size_t region, size_t wg_stride, int shape, int rs, unsigned step, uint32_t* sink,
                 double clock_ghz) {
-    const int iters = 400, blocks = 256;
+    const int iters = 400, blocks = g_blocks;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const size_t lds = (size_t)8 * DEPTH * 1024;
@@ -87,7 +89,9 @@ static void run(const char* name, const char* src, size_t region, size_t wg_stri
            bytes / us * 1e-3 / blocks, bytes / us * 1e-3 / blocks / clock_ghz, clock_ghz);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_blocks = atoi(argv[1]);
+    printf("workgroups: %d\n", g_blocks);
     const size_t total = (size_t)1 << 30;
     char* src;
     uint32_t* sink;
@@ -99,7 +103,12 @@ int main() {
     // step between consecutive pieces of a wave: flat 1 KB; row shapes advance 64 / 128 B along the rows (rows stay 16 / 8 x rs apart)
     struct { const char* nm; int shape, rs; unsigned step; } pat[] = {
         {"flat 1 KB pieces", 0, 0, 1024}, {"16 rows x 64 B, rows 392 B apart", 1, 392, 6272}, {"8 rows x 128 B, rows 392 B apart", 2, 392, 3136},
-        {"16 rows x 64 B, rows 6272 B apart (aligned)", 1, 6272, 64}, {"8 rows x 128 B, rows 6272 B apart (aligned)", 2, 6272, 128}};
+        {"16 rows x 64 B, rows 6272 B apart (aligned)", 1, 6272, 64}, {"8 rows x 128 B, rows 6272 B apart (aligned)", 2, 6272, 128},
+        // weight tiles read in place: row = output channel, K * 2 bytes apart (K = 256 .. 2048: powers of two)
+        {"16 rows x 64 B, rows 512 B apart", 1, 512, 64}, {"16 rows x 64 B, rows 1024 B apart", 1, 1024, 64},
+        {"16 rows x 64 B, rows 2048 B apart", 1, 2048, 64}, {"16 rows x 64 B, rows 4096 B apart", 1, 4096, 64},
+        {"8 rows x 128 B, rows 2048 B apart", 2, 2048, 128}, {"8 rows x 128 B, rows 4096 B apart", 2, 4096, 128},
+        {"16 rows x 64 B, rows 2112 B apart (2048 + 64)", 1, 2112, 64}};
     for (int loc = 0; loc < 2; ++loc) {
         const size_t region = loc ? private_region : shared_region, stride = loc ? private_region : 0;
         printf("== source %s\n", loc ? "private 4 MB per workgroup (HBM stream)" : "2 MB shared by all workgroups (L2 hits)");
