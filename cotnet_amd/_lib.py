@@ -68,6 +68,8 @@ SYMBOLS = {
     "cot_radix_mix_backward_apply": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
     "cot_group_norm9_forward": (_I, [_P] * 6 + [_I, _I, _I, ctypes.c_float, _I, _P]),
     "cot_group_norm9_backward": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
+    "cot_subsample2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
+    "cot_subsample2_backward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_avgpool3x3s2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_avgpool3x3s2_backward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_maxpool3x3s2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),

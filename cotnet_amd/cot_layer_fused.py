@@ -622,7 +622,11 @@ class _BottleneckNode(Function):
         _ck(L.cot_conv1x1_forward(_p(cot_out), None, Cw, _p(bp.conv3.weight), None, _p(c3), N, Cw, Cout, HWo, BF16, st),
             "cot_conv1x1_forward")
         if bp.ds_conv is not None:  # projection shortcut: bn(conv1x1(x)), on every second pixel in a stride-2 block
-            xs = x[:, :, ::2, ::2].contiguous() if bp.ds_stride == 2 else x
+            if bp.ds_stride == 2 and H % 2 == 0 and W % 2 == 0:  # every second pixel: one pass, 16-byte accesses (pool3x3.hip)
+                xs = torch.empty((N, Cin, H // 2, W // 2), dtype=x.dtype, device=dev)
+                _ck(L.cot_subsample2_forward(_p(x), _p(xs), N * Cin, H, W, BF16, st), "cot_subsample2_forward")
+            else:
+                xs = x[:, :, ::2, ::2].contiguous() if bp.ds_stride == 2 else x
             d0, res = new(Cout, Ho, Wo), new(Cout, Ho, Wo)
             _ck(L.cot_conv1x1_forward(_p(xs), None, Cin, _p(bp.ds_conv.weight), None, _p(d0), N, Cin, Cout, HWo, BF16,
                                       st), "cot_conv1x1_forward")
@@ -688,8 +692,12 @@ class _BottleneckNode(Function):
                 g_xs = torch.empty_like(xs)
                 _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(g_xs), None, Cin, 0, _p(ws), N, Cin,
                                                 Cout, HWo, BF16, st), "cot_conv1x1_backward_data")
-                gx = torch.zeros_like(x)
-                gx[:, :, ::2, ::2] = g_xs
+                if H % 2 == 0 and W % 2 == 0:  # values back in place and the zeros around them in one pass
+                    gx = torch.empty_like(x)
+                    _ck(L.cot_subsample2_backward(_p(g_xs), _p(gx), N * Cin, H, W, BF16, st), "cot_subsample2_backward")
+                else:
+                    gx = torch.zeros_like(x)
+                    gx[:, :, ::2, ::2] = g_xs
             else:
                 gx = torch.empty_like(x)
                 _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(gx), None, Cin, 0, _p(ws), N, Cin,

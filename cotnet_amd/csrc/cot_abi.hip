@@ -160,7 +160,8 @@ bool conv1x1_wgrad_lds_covers(int N, int HW, int M, int J);
 int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad_lds_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
 extern int g_wgrad2_tune;  // conv_wgrad2.hip (third-generation weight gradient)
-extern int g_pool_tile;    // pool3x3.hip (plane-tile pooling kernels)
+extern int g_pool_tile;    // pool3x3.hip (row-block pooling kernels)
+template <typename T> int subsample2(int bwd, const void* a, void* out, int64_t planes, int H, int W, hipStream_t stream);
 bool conv1x1_wgrad2_covers(int N, int HW, int M, int J, int k1, bool two_slabs);
 int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad2_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
@@ -818,6 +819,21 @@ static int pool_call(int op, const void* a, const void* b, void* out, int64_t pl
     if (dtype == COT_F32) return pool3x3s2<float>(op, a, b, out, planes, H, W, (hipStream_t)stream);
     if (dtype == COT_BF16) return pool3x3s2<bf16_t>(op, a, b, out, planes, H, W, (hipStream_t)stream);
     return set_error(COT_ERR_UNSUPPORTED, "cot_*pool3x3s2_*: dtype %d (float32 / bfloat16 only)", dtype);
+}
+static int subsample_call(int bwd, const void* a, void* out, int64_t planes, int H, int W, int dtype, void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive planes/H/W");
+    if (!a || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    int rc = COT_ERR_UNSUPPORTED;
+    if (dtype == COT_F32) rc = subsample2<float>(bwd, a, out, planes, H, W, (hipStream_t)stream);
+    else if (dtype == COT_BF16) rc = subsample2<bf16_t>(bwd, a, out, planes, H, W, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_subsample2_*: even H and W, float32 / bfloat16 (H %d W %d dtype %d given)", H, W, dtype);
+    return rc;
+}
+int cot_subsample2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream) {
+    return subsample_call(0, x, y, planes, H, W, dtype, stream);
+}
+int cot_subsample2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream) {
+    return subsample_call(1, gy, gx, planes, H, W, dtype, stream);
 }
 int cot_avgpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream) {
     return pool_call(0, x, nullptr, y, planes, H, W, dtype, stream);

@@ -353,6 +353,62 @@ __global__ __launch_bounds__(256) void pool3x3s2_bwd_blk(const T* __restrict__ g
     if (2 * a + 1 < H) stv<T, 2 * BG>(o + W, o1);
 }
 
+// ---- every second pixel of every second row (the input of a stride-2 1x1 projection shortcut, models/resnet.py downsample:
+// nn.Conv2d(kernel_size=1, stride=2) reads exactly x[:, :, ::2, ::2]) and its gradient (the values back in place, zeros
+// elsewhere) -- as torch ops: a strided copy forward, a fill plus a strided copy backward (35 + 18 + 35 us for 80 x 256 x 56 x 56).
+// Even H and W; a lane owns BG output pixels (forward) / a 2 x 2 BG block of the input gradient (backward).
+template <typename T, int BG>
+__global__ __launch_bounds__(256) void subsample2_fwd_blk(const T* __restrict__ x, T* __restrict__ y, int64_t planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2, NB = Wo / BG;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ho * NB) return;
+    const int bg = (int)(i % NB), oh = (int)((i / NB) % Ho);
+    const int64_t pl = i / ((int64_t)NB * Ho);
+    const Vec<T, 2 * BG> v = ldv<T, 2 * BG>(x + pl * H * W + (int64_t)(2 * oh) * W + 2 * bg * BG);
+    Vec<T, BG> o;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) o.v[j] = v.v[2 * j];
+    stv<T, BG>(y + pl * Ho * Wo + (int64_t)oh * Wo + bg * BG, o);
+}
+
+template <typename T, int BG>
+__global__ __launch_bounds__(256) void subsample2_bwd_blk(const T* __restrict__ gy, T* __restrict__ gx, int64_t planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2, NB = Wo / BG;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ho * NB) return;
+    const int bg = (int)(i % NB), oh = (int)((i / NB) % Ho);
+    const int64_t pl = i / ((int64_t)NB * Ho);
+    const Vec<T, BG> g = ldv<T, BG>(gy + pl * Ho * Wo + (int64_t)oh * Wo + bg * BG);
+    Vec<T, 2 * BG> o0, o1;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+        o0.v[2 * j] = g.v[j];
+        o0.v[2 * j + 1] = (T)0.f;
+        o1.v[2 * j] = (T)0.f;
+        o1.v[2 * j + 1] = (T)0.f;
+    }
+    T* o = gx + pl * H * W + (int64_t)(2 * oh) * W + 2 * bg * BG;
+    stv<T, 2 * BG>(o, o0);
+    stv<T, 2 * BG>(o + W, o1);
+}
+
+template <typename T>
+int subsample2(int bwd, const void* a, void* out, int64_t planes, int H, int W, hipStream_t stream) {
+    if ((H & 1) || (W & 1)) return COT_ERR_UNSUPPORTED;
+    const int Ho = H / 2, Wo = W / 2;
+    const bool odd16 = ((H * W) & 7) || ((Ho * Wo) & 7), odd8 = ((H * W) & 3) || ((Ho * Wo) & 3);
+    const int BG = (Wo % 4 == 0 && !odd16) ? 4 : ((Wo % 2 == 0 && !odd8) ? 2 : 1);
+    const dim3 grid((unsigned)ceil_div64(planes * Ho * (Wo / BG), 256)), block(256);
+#define COT_SUB2(BG_)                                                                                                  \
+    if (bwd) COT_LAUNCH((subsample2_bwd_blk<T, BG_>), grid, block, 0, stream, (const T*)a, (T*)out, planes, H, W);     \
+    else COT_LAUNCH((subsample2_fwd_blk<T, BG_>), grid, block, 0, stream, (const T*)a, (T*)out, planes, H, W)
+    if (BG == 4) { COT_SUB2(4); } else if (BG == 2) { COT_SUB2(2); } else { COT_SUB2(1); }
+#undef COT_SUB2
+    return check_launch("subsample2");
+}
+template int subsample2<float>(int, const void*, void*, int64_t, int, int, hipStream_t);
+template int subsample2<bf16_t>(int, const void*, void*, int64_t, int, int, hipStream_t);
+
 int g_pool_tile = 1;  // cot_set_tuning key 27: 0 = one lane per pixel only
 // windows per lane of the row-block form (0: not eligible): W even, every wide access naturally aligned
 static int pool_blk_group(int op, int H, int W, int Ho, int Wo) {

@@ -303,6 +303,11 @@ int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, 
  *   cot_maxpool3x3s2_forward_taps / _backward_taps: the same pooling with the arg-max kept as ONE BYTE per output window
  *                       (taps [planes][Ho][Wo], value kh*3 + kw of the winning element): the backward reads dY and the taps
  *                       and never touches x (torch keeps an int64 index per window). */
+/*   cot_subsample2_*    x[:, :, ::2, ::2] -- what a stride-2 1x1 projection shortcut reads (models/resnet.py downsample: nn.Conv2d(
+ *                       kernel_size=1, stride=2)) -- as its own contiguous tensor y [planes][H/2][W/2], and the gradient of that
+ *                       selection (gx [planes][H][W]: gy's values in place, zeros elsewhere, every element written).  Even H, W. */
+int cot_subsample2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);
+int cot_subsample2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream);
 int cot_avgpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);
 int cot_avgpool3x3s2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream);
 int cot_maxpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);

@@ -1473,6 +1473,25 @@ def test_pooling_kernels_match_torch(N, C, H, W, dtype, tile, request):
     _pooling_kernels_match_torch(N, C, H, W, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 8, 56, 56), (1, 6, 28, 28), (3, 5, 14, 14), (1, 3, 2, 2), (2, 2, 6, 10), (1, 1, 4, 12)])
+def test_subsample2_kernels_are_exact(N, C, H, W, dtype):
+    """cot_subsample2_*: x[:, :, ::2, ::2] and its gradient (NaN-prefilled outputs: every element is written)"""
+    torch.manual_seed(2)
+    dt = _lib.dtype_code(dtype)
+    x = torch.randn(N, C, H, W).to(dtype)
+    y = torch.full((N, C, H // 2, W // 2), float("nan")).to(dtype)
+    assert _EMUL.cot_subsample2_forward(P(x), P(y), N * C, H, W, dt, None) == 0, _EMUL.cot_last_error()
+    assert torch.equal(y, x[:, :, ::2, ::2])
+    gy = torch.randn(N, C, H // 2, W // 2).to(dtype)
+    gx = torch.full_like(x, float("nan"))
+    assert _EMUL.cot_subsample2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
+    ref = torch.zeros_like(x)
+    ref[:, :, ::2, ::2] = gy
+    assert torch.equal(gx, ref)
+    assert _EMUL.cot_subsample2_forward(P(x), P(y), N * C, H + 1, W, dt, None) != 0  # odd sizes: the caller keeps torch's ops
+
+
 @pytest.mark.parametrize("N,C,H,W", [(2, 24, 28, 28), (3, 11, 7, 7), (1, 6, 56, 56), (2, 5, 13, 9)])
 def test_pooling_plane_tile_form_is_bit_identical(N, C, H, W):
     """the plane-tile kernels do the per-pixel kernels' arithmetic in the same order: same bits, taps included"""
