@@ -739,6 +739,7 @@ def lds_variant(request):
     (2, 160, 72, 14, 14, 0, False),   # FLAT: five K steps (pipeline wraps), M = 72
     (2, 512, 64, 14, 14, 256, False), # FLAT: 16 K steps (the steady-state loop of the six-stage ring), slab switch at step 8
     (1, 256, 32, 16, 24, 0, True),    # BIG: 8 K steps (steady state of the three-stage ring)
+    (2, 1024, 136, 14, 14, 0, False), # FLAT: 32 K steps (s3 conv1's depth): many rounds of the steady / ping-pong loop, two m-blocks
     (6, 320, 48, 7, 7, 0, False),     # FLAT 7 x 7: 10 K steps, 2-byte gathers, 48 of 64 channels, second image group partial
 ])
 @pytest.mark.parametrize("lds_variant", _LDS_VARIANTS, indirect=True)
