@@ -32,7 +32,20 @@ __global__ __launch_bounds__(512) void stream(const char* __restrict__ src, size
     unsigned pos = (unsigned)wave * step;  // byte position of this wave's next piece inside the region
     u32x4 acc = {0, 0, 0, 0};
     u32x4 r[DEPTH];
-    if (MODE == 0) {
+    if (MODE == 3 && wave >= 4) {  // the other half of the workgroup keeps the LDS busy with 16-byte reads for as long as the copies run
+        volatile int* stop = reinterpret_cast<volatile int*>(smem + 159 * 1024);
+        u32x4 a = {0, 0, 0, 0};
+        const u32x4* base4 = reinterpret_cast<const u32x4*>(smem + 64 * 1024);
+        for (int it = 0; it < iters * DEPTH; ++it) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) a ^= base4[(lane + 64 * ((it + r) & 15)) & 1023];
+        }
+        if (a[0] == 0x12345678u && a[1] == 77u) sink[threadIdx.x] = a[2] ^ a[3];
+        (void)stop;
+        __syncthreads();
+        return;
+    }
+    if (MODE == 0 || MODE == 3) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
@@ -62,7 +75,7 @@ __global__ __launch_bounds__(512) void stream(const char* __restrict__ src, size
         }
     }
     __syncthreads();
-    if (MODE != 2) acc = *reinterpret_cast<u32x4*>(smem + (threadIdx.x * 16) % (8 * DEPTH * 1024));
+    if (MODE != 2) acc = *reinterpret_cast<u32x4*>(smem + (threadIdx.x * 16) % (4 * DEPTH * 1024));
     if (acc[0] == 0x12345678u && acc[1] == 77u) sink[threadIdx.x] = acc[2] ^ acc[3];
 }
 
@@ -74,7 +87,7 @@ static void run(const char* name, const char* src, size_t region, size_t wg_stri
     const int iters = 400, blocks = g_blocks;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const size_t lds = (size_t)8 * DEPTH * 1024;
+    const size_t lds = MODE == 3 ? (size_t)160 * 1024 : (size_t)8 * DEPTH * 1024;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stream<MODE, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (int w = 0; w < 2; ++w) stream<MODE, DEPTH><<<blocks, 512, lds>>>(src, region, wg_stride, iters, shape, rs, step, sink);
     CK(hipEventRecord(e0));
@@ -84,7 +97,7 @@ static void run(const char* name, const char* src, size_t region, size_t wg_stri
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    const double us = ms * 1e3 / reps, bytes = (double)blocks * 8 * iters * DEPTH * 1024;
+    const double us = ms * 1e3 / reps, bytes = (double)blocks * (MODE == 3 ? 4 : 8) * iters * DEPTH * 1024;
     printf("%-44s depth %2d  %8.1f us  %7.2f TB/s chip  %6.1f GB/s per CU  %5.1f B/clk/CU @%.1f GHz\n", name, DEPTH, us, bytes / us * 1e-6,
            bytes / us * 1e-3 / blocks, bytes / us * 1e-3 / blocks / clock_ghz, clock_ghz);
 }
@@ -118,10 +131,9 @@ int main(int argc, char** argv) {
             run<0, 4>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
             run<0, 8>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
             run<0, 16>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
-            snprintf(nm, sizeof nm, "load+ds_write| %s", p.nm);
-            run<1, 4>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
-            run<1, 8>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
-            run<1, 16>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
+            snprintf(nm, sizeof nm, "LDS-DMA (4 waves) + 4 waves of ds_read_b128 | %s", p.nm);
+            run<3, 8>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
+            run<3, 16>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
             snprintf(nm, sizeof nm, "load only    | %s", p.nm);
             run<2, 8>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
             run<2, 16>(nm, src, region, stride, p.shape, p.rs, p.step, sink, ghz);
