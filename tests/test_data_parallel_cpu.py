@@ -393,3 +393,41 @@ def test_grad_sink_lends_a_slot_once_per_step():
         assert torch.allclose(slot, g1.t() @ x1 + g2.t() @ x2, atol=1e-5), (slot - (g1.t() @ x1 + g2.t() @ x2)).abs().max()
     red.remove()
     assert not grad_sink._SINK  # remove() drops the reducer's entries (they hold strong references to the flat buffers)
+
+
+def test_guarded_activation_buffer_and_its_promise():
+    """cot_layer_fused._new_guarded / _guard_elems: the CoT layer's input sits inside a larger allocation with at least W + 1
+    elements either side (what cot_conv3x3g_backward_weight_guarded is promised); a tensor that fills its storage, or a
+    non-contiguous view, promises nothing"""
+    from cotnet_amd import cot_layer_fused as clf
+    for (N, C, H, W) in [(2, 8, 14, 14), (1, 4, 7, 7), (3, 2, 56, 56), (1, 1, 5, 9)]:
+        t = clf._new_guarded(N, C, H, W, torch.bfloat16, torch.device("cpu"))
+        assert t.shape == (N, C, H, W) and t.is_contiguous() and t.data_ptr() % 16 == 0
+        g = clf._guard_elems(t)
+        assert g >= W + 1 and g % 8 == 0
+        flat = t.untyped_storage()
+        assert t.storage_offset() == g and flat.nbytes() // 2 == N * C * H * W + 2 * g
+    plain = torch.empty(2, 4, 6, 6, dtype=torch.bfloat16)
+    assert clf._guard_elems(plain) == 0
+    assert clf._guard_elems(plain[:, :, ::2, ::2]) == 0
+    assert clf._guard_elems(torch.empty(100, dtype=torch.bfloat16)[10:82].view(2, 4, 3, 3)) == 10
+
+
+def test_producer_stream_registry_joins_before_a_bucket_copy():
+    """grad_sink.register_producer_stream: a side stream that writes gradients is joined before the reducer copies gradients
+    into a bucket (and its streams are what a bucket's communication stream waits for)"""
+    from cotnet_amd import grad_sink
+    calls = []
+    n0 = len(grad_sink.producer_streams())
+    grad_sink.register_producer_stream("stream-object", lambda: calls.append("joined"))
+    try:
+        assert grad_sink.producer_streams()[n0:] == ["stream-object"]
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+        red = GradBucketReducer(model, bucket_mb=1.0, grad_mode="copy", flatten_params=True)
+        model(torch.randn(3, 8)).sum().backward()  # (plain autograd gradients: not in place -> the bucket fill copies them)
+        assert calls and all(c == "joined" for c in calls)
+        red.remove()
+    finally:
+        del grad_sink._PRODUCERS[n0:]
+
