@@ -647,11 +647,20 @@ def main():
     if not args.no_kernel_timing:
         timing_steps = 3
         os.environ["COT_PROFILE_ALL"] = "1"  # events on every launch of the library (outside the timed region)
-        agg_mod.profile_begin()
-        for _ in range(timing_steps):
-            step()
-        torch.cuda.synchronize()
-        recs = agg_mod.profile_end()
+        # Every launch on ONE stream for these steps: an event pair around a launch also counts the time the kernel waits for CUs
+        # that a weight gradient on the side stream still holds (42.1 us for the 56 x 56 aggregation backward against 38.1 in the
+        # rocprofv3 trace of the un-instrumented step, profiles/r03: its own duration is what the roofline object is about)
+        from cotnet_amd import cot_layer_fused as _clf
+        _side = _clf.SIDE_WGRAD
+        _clf.SIDE_WGRAD = False
+        try:
+            agg_mod.profile_begin()
+            for _ in range(timing_steps):
+                step()
+            torch.cuda.synchronize()
+            recs = agg_mod.profile_end()
+        finally:
+            _clf.SIDE_WGRAD = _side
     final_loss = float(loss)
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -739,7 +748,8 @@ def main():
                                            "(scripts/gpu_evidence_session.sh) refreshes it right before this run") if traffic else None,
                         "avg_us": k0["avg_us"],
                         "timing": f"dispatch-attached HIP events (on the launch stream) over {timing_steps} repeats of the "
-                                  "step right after the un-instrumented timed region",
+                                  "step right after the un-instrumented timed region, every launch on one stream (no weight "
+                                  "gradients beside the kernel being timed)",
                         "agg_share_of_step": round(agg_total / (elapsed / args.steps * 1e3), 4), "kernels": kernels,
                         "conv_bn_families": op_families, "conv_bn_calls": op_rows[:40],
                         "conv_bn_note": "per CALL of the C ABI (all launches of the call), dispatch-attached events; frac_hbm = algorithmic "
