@@ -956,6 +956,33 @@ def test_conv3x3_grouped_weight_gradient_lds_staged(N, Ci, Co, G, H, W, force, d
         assert _EMUL.cot_set_tuning(25, 0) == 0
 
 
+def test_conv3x3_grouped_weight_gradient_guard_decides_the_kernel():
+    """cot_conv3x3g_backward_weight_guarded: with fewer than W + 1 readable elements promised around x (or a geometry the TAPS
+    form does not cover) the per-wave kernel runs -- same answer; the dry-run launch log names which"""
+    torch.manual_seed(4)
+    dt = _lib.dtype_code(torch.bfloat16)
+    buf = ctypes.create_string_buffer(4096)
+
+    def kernels(N, Ci, Co, G, H, W, guard):
+        masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+        x, gy = torch.zeros(N, Ci, H, W).bfloat16(), torch.zeros(N, Co, H, W).bfloat16()
+        gw = torch.empty(Co, Ci // G, 3, 3).bfloat16()
+        ws = torch.empty(_EMUL.cot_conv3x3g_workspace(N, Ci, Co, G, H, W), dtype=torch.uint8)
+        try:
+            assert _EMUL.cot_set_tuning(26, 1) == 0
+            assert _EMUL.cot_conv3x3g_backward_weight_guarded(P(gy), P(x), P(gw), P(masks), P(ws), N, Ci, Co, G, H, W, dt, guard, None) == 0
+            _EMUL.cot_launch_log(buf, 4096)
+        finally:
+            assert _EMUL.cot_set_tuning(26, 0) == 0
+        return buf.value.decode()
+    assert "conv1x1_wgrad_lds2" in kernels(2, 64, 64, 4, 14, 14, 15) and "wgrad_reduce" in kernels(8, 64, 64, 4, 14, 14, 15)
+    assert "conv3x3g_wgrad_mfma" in kernels(2, 64, 64, 4, 14, 14, 14)      # one element short of W + 1
+    assert "conv3x3g_wgrad_mfma" in kernels(2, 64, 64, 4, 14, 14, 0)
+    assert "conv3x3g_wgrad_mfma" in kernels(2, 96, 96, 4, 14, 14, 64)      # 24 channels per group: not a multiple of 16
+    assert "conv1x1_wgrad_lds2" in kernels(2, 64, 768, 4, 7, 7, 8)         # 192 dY rows per group: three row tiles
+    assert "conv3x3g_wgrad_mfma" in kernels(2, 64, 192, 4, 7, 7, 8)        # 48 dY rows per group: no tile for that
+
+
 @pytest.mark.parametrize("N,C,G,H,W", [
     (1, 64, 4, 24, 24),    # BIG, Kc = Mg = 16 (two taps per K step), two row tiles of 12 rows
     (1, 128, 4, 30, 20),   # BIG, Kc = 32, three row tiles (14, 14, 2 rows): halo rows past the image at both ends

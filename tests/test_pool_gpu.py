@@ -63,3 +63,28 @@ def test_blur_pool_matches_the_reference_formula(N, C, H, dtype, monkeypatch):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert torch.allclose(ya.float(), yb.float(), atol=tol, rtol=tol)
     assert torch.allclose(xa.grad.float(), xb.grad.float(), atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H", [(80, 256, 56), (80, 512, 28), (80, 1024, 14), (3, 5, 6), (2, 3, 2)])
+def test_subsample2_is_exact(N, C, H, dtype):
+    """cot_subsample2_*: the input of a stride-2 1x1 projection shortcut (x[:, :, ::2, ::2]) and its gradient, bit-exact; the
+    gradient kernel writes every element (NaN-prefilled output)"""
+    import ctypes
+    from cotnet_amd import _lib
+    L = _lib.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(H)
+    dt = _lib.dtype_code(dtype)
+    x = torch.randn(N, C, H, H, device=DEV).to(dtype)
+    y = torch.full((N, C, H // 2, H // 2), float("nan"), device=DEV).to(dtype)
+    assert L.cot_subsample2_forward(P(x), P(y), N * C, H, H, dt, st) == 0, L.cot_last_error()
+    assert torch.equal(y, x[:, :, ::2, ::2])
+    gy = torch.randn_like(y)
+    gx = torch.full_like(x, float("nan"))
+    assert L.cot_subsample2_backward(P(gy), P(gx), N * C, H, H, dt, st) == 0, L.cot_last_error()
+    ref = torch.zeros_like(x)
+    ref[:, :, ::2, ::2] = gy
+    assert torch.equal(gx, ref)
+
