@@ -428,9 +428,13 @@ static inline int pick_vec(size_t esize, int HW) {
         if (V <= lim && HW % V == 0) return V;
     return 1;
 }
+// cot_set_tuning key 28: workgroups a streaming BatchNorm kernel aims for (C x SPLIT).  1024 since round 3 (was 2048): fewer, longer
+// workgroups and half as many partial statistics to merge in the apply kernel's prologue -- forward 64 ch x 56^2 29.7 -> 23.3 us,
+// 32 ch x 56^2 25.6 -> 20.6, 256 ch x 56^2 75.9 -> 73.3, backward equal or 1-3 % better (profiles/r03_bn_split_target_sweep.log)
+int g_bn_split_target = 1024;
 static inline void pick_split(int N, int C, int* split, int* nper) {
     int s = 1;
-    while (C * s < 2048 && s * 2 <= N) s *= 2;   // >= 8 blocks per CU of reduction work when the batch allows
+    while (C * s < g_bn_split_target && s * 2 <= N) s *= 2;   // >= 8 blocks per CU of reduction work when the batch allows
     *nper = (N + s - 1) / s;
     *split = (N + *nper - 1) / *nper;
 }

@@ -119,7 +119,7 @@ int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int,
 int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
 int ema_flat(void*, const void*, int64_t, float, int, hipStream_t);
 int bn_workspace_floats(int N, int C);
-extern int g_bn_fold, g_bn_grid_cap, g_bn_small_m;
+extern int g_bn_fold, g_bn_grid_cap, g_bn_small_m, g_bn_split_target;
 template <typename T>
 int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, long long*,
                    float*, int, int, int, float, float, int, const float*, hipStream_t);
@@ -360,6 +360,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 27) {
         g_pool_tile = value ? 1 : 0;
+        return COT_OK;
+    }
+    if (key == 28) {
+        g_bn_split_target = value > 0 ? value : 1024;
         return COT_OK;
     }
     if (key == 24) {  // DIAGNOSTIC: timing ablations of the third-generation 1x1 kernel (results become wrong)

@@ -151,7 +151,9 @@ const char* cot_last_kernel(void);
  *           than 64 pixels), bits 8..15 partial-sum cap in % of the input bytes (0 = 100), bits 16..23 target workgroups per
  *           CU x 4 (0 = 4), bits 24..30 forced slice count (tests)
  *   key 26: dry run (1): no kernel is launched, no HIP call is made; launches are recorded for cot_launch_log()
- *   key 27: 3x3 / stride-2 poolings: 1 (default) = whole planes staged through LDS where they fit, 0 = one lane per pixel
+ *   key 27: 3x3 / stride-2 poolings: 1 (default) = row blocks (a lane owns a group of windows), 0 = one lane per pixel
+ *   key 28: streaming BatchNorm kernels: workgroups aimed for (channels x batch chunks; default 1024).  Changes
+ *           cot_bn_act_workspace: query it after setting the key
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* Dry-run log of the calling thread (cot_set_tuning(26, 1)): one line per launch the library WOULD have issued --
