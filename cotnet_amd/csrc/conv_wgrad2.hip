@@ -386,14 +386,14 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? (WAVES > 8 ? 4 : 3) :
             const bool tr = a.stamps && blockIdx.x == 0 && ks0 + U >= 8 && ks0 + U < 16;
             unsigned long long* const tp = a.stamps + (size_t)(2048 + (tr ? ks0 + U - 8 : 0)) * 8 - (size_t)blockIdx.x * 8;
             if (tr) COT_STAMP(tp, 0);
-            if (!LW) COT_WAIT_VM((NS - 2) * G);  // stage ks+1 has landed (this wave's copies); the NS-2 younger stages stay in flight
+            COT_WAIT_VM((NS - 2) * G);  // stage ks+1 has landed (this wave's copies); the NS-2 younger stages stay in flight
             if (tr) COT_STAMP(tp, 1);
             COT_LDS_BARRIER();          // ... everybody's; and nobody reads slot U any more (its fragments are in registers)
             if (tr) COT_STAMP(tp, 2);
             ln = read_frags(sm + NXT * STG, yn, xn);
             COT_SCHED_FENCE();          // the reads are in flight BEFORE copies and MFMAs are issued
             if (tr) COT_STAMP(tp, 3);
-            if (!LW) stage(lds0 + (unsigned)(U * STG * 2));
+            stage(lds0 + (unsigned)(U * STG * 2));
             COT_SCHED_FENCE();
             if (tr) COT_STAMP(tp, 4);
             fix_frags(xc, lc);
@@ -414,13 +414,13 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? (WAVES > 8 ? 4 : 3) :
         auto step = [&](int k, const uint32_t (&yc)[AM][4], uint32_t (&xc)[AJ][4], bool lc, uint32_t (&yn)[AM][4],
                         uint32_t (&xn)[AJ][4], bool& ln) __attribute__((always_inline)) {
             if (k + 1 < nst) {
-                if (!LW) WaitBehind<G, NS - 2>::go(min(NS - 2, nst - 2 - k));
+                WaitBehind<G, NS - 2>::go(min(NS - 2, nst - 2 - k));
                 COT_LDS_BARRIER();
                 const int freed = slot;
                 slot = slot + 1 == NS ? 0 : slot + 1;
                 ln = read_frags(sm + slot * STG, yn, xn);
                 COT_SCHED_FENCE();
-                if (!LW && k + NS < nst) stage(slot_addr(freed));
+                if (k + NS < nst) stage(slot_addr(freed));
                 COT_SCHED_FENCE();
             }
             fix_frags(xc, lc);
