@@ -94,7 +94,7 @@ def _ck(rc, what):
 SIDE_WGRAD = os.environ.get("COT_WGRAD_STREAM", "1") != "0"
 LAZY_WGRAD = os.environ.get("COT_WGRAD_LAZY", "1") != "0"
 _SIDE_STREAMS = {}  # device index -> [torch.cuda.Stream, workspace tensor]
-_SIDE_PENDING = {}  # device index -> {"keep": tensors read by launches the compute stream has not joined yet, "cb": callback queued}
+_SIDE_PENDING = {}  # device index -> {"keep": tensors read by launches the compute stream has not joined yet}
 
 
 def _join_pending(dev_index):
@@ -105,7 +105,6 @@ def _join_pending(dev_index):
     if pend["keep"]:
         torch.cuda.current_stream(torch.device("cuda", dev_index)).wait_stream(ent[0])
         pend["keep"] = []
-    pend["cb"] = False
 
 
 class _Side:
@@ -130,7 +129,7 @@ class _Side:
         self.ws = ent[1]
         self.st = ctypes.c_void_p(self.stream.cuda_stream)
         if self.lazy and dev.index not in _SIDE_PENDING:
-            _SIDE_PENDING[dev.index] = {"keep": [], "cb": False}
+            _SIDE_PENDING[dev.index] = {"keep": []}
             grad_sink.register_producer_stream(self.stream, lambda i=dev.index: _join_pending(i))
 
     def run(self, fn, *tensors):
@@ -159,12 +158,12 @@ class _Side:
             for fn in self.queue:
                 fn(self.st)
             self.queue, self.keep = [], []
-            if not pend["cb"]:  # join when the backward pass ends
-                pend["cb"] = True
-                try:
-                    torch.autograd.Variable._execution_engine.queue_callback(lambda i=self.dev.index: _join_pending(i))
-                except RuntimeError:  # (not inside the engine's backward: join now)
-                    _join_pending(self.dev.index)
+            # join when the backward pass ends.  Queued by EVERY flush (the first callback to run joins, the others find nothing
+            # pending): a flag "already queued" would survive a backward pass that died half-way and silence all later ones
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(lambda i=self.dev.index: _join_pending(i))
+            except RuntimeError:  # (not inside the engine's backward: join now)
+                _join_pending(self.dev.index)
         elif self.on:
             self.main.wait_stream(self.stream)
             self.keep.clear()
