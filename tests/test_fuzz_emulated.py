@@ -1,6 +1,7 @@
 """Randomised differential test of the MFMA convolution / GroupNorm / pooling kernels (host-emulated) against torch:
 random batch sizes, channel counts (multiples of 8), image sizes from 1x1 up, channel slabs, biases, forced split counts
-and rows-per-wave overrides -- the shapes nobody would think of writing down.  (480 further cases ran clean offline.)"""
+and rows-per-wave overrides -- the shapes nobody would think of writing down.  (480 further cases ran clean offline in round 2,
+1200 more -- with the LDS-staged grouped 3x3 weight gradient and the sub-sampling kernels added -- in round 3.)"""
 import ctypes
 import random
 
@@ -128,7 +129,52 @@ def case_pooling(rng):
     return ok, ("pooling", N, C, H, W)
 
 
-CASES = [case_conv1x1, case_conv1x1, case_conv3x3, case_group_norm, case_pooling]
+def case_conv3x3_guarded(rng):
+    """the LDS-staged grouped 3x3 weight gradient (conv_wgrad2.hip TAPS form): x inside a NaN-margined allocation"""
+    G = rng.choice([1, 2, 4])
+    Kc, Mg = rng.choice([16, 16, 32, 64]), rng.choice([16, 32, 64, 128])
+    N, H, W = rng.randint(1, 4), rng.randint(2, 15), rng.randint(2, 15)
+    if H * W < 8:
+        H = 4
+    Ci, Co, HW = G * Kc, G * Mg, H * W
+    guard = W + 1 + rng.randint(0, 9)
+    lead = guard + (-guard) % 8
+    flat = torch.full((N * Ci * HW + 2 * lead + 8,), float("nan")).bfloat16()
+    x = flat[lead:lead + N * Ci * HW].view(N, Ci, H, W)
+    x.copy_(torch.randn(N, Ci, H, W))
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    wf = torch.zeros(Co, Kc, 3, 3, requires_grad=True)
+    F.conv2d(x.float(), wf, None, 1, 1, 1, G).backward(gy.float())
+    masks = torch.empty(E.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert E.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    E.cot_set_tuning(25, rng.choice([0, 0, 1, 2, 3, 7]) << 24)  # forced slice counts (size the workspace afterwards)
+    E.emul_set_dma_mode(rng.choice([0, 1]))
+    try:
+        ws = torch.full((E.cot_conv3x3g_workspace(N, Ci, Co, G, H, W),), 0x7f, dtype=torch.uint8)
+        gw = torch.full((Co, Kc, 3, 3), float("nan")).bfloat16()
+        assert E.cot_conv3x3g_backward_weight_guarded(P(gy), P(x), P(gw), P(masks), P(ws), N, Ci, Co, G, H, W, BF, guard, None) == 0
+    finally:
+        E.cot_set_tuning(25, 0)
+        E.emul_set_dma_mode(0)
+    scale = wf.grad.abs().max().item()
+    ok = (gw.float() - wf.grad).abs().max().item() <= 1e-2 * scale + 1e-2
+    return ok, ("conv3x3 guarded wgrad", N, Ci, Co, G, H, W, guard)
+
+
+def case_subsample(rng):
+    N, C, H, W = rng.randint(1, 3), rng.randint(1, 9), 2 * rng.randint(1, 9), 2 * rng.randint(1, 9)
+    x = torch.randn(N, C, H, W).bfloat16()
+    y = torch.full((N, C, H // 2, W // 2), float("nan")).bfloat16()
+    assert E.cot_subsample2_forward(P(x), P(y), N * C, H, W, BF, None) == 0
+    gy = torch.randn(N, C, H // 2, W // 2).bfloat16()
+    gx = torch.full_like(x, float("nan"))
+    assert E.cot_subsample2_backward(P(gy), P(gx), N * C, H, W, BF, None) == 0
+    ref = torch.zeros_like(x)
+    ref[:, :, ::2, ::2] = gy
+    return torch.equal(y, x[:, :, ::2, ::2]) and torch.equal(gx, ref), ("subsample2", N, C, H, W)
+
+
+CASES = [case_conv1x1, case_conv1x1, case_conv3x3, case_conv3x3_guarded, case_group_norm, case_pooling, case_subsample]
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
