@@ -11,12 +11,12 @@ Data parallel: weak scaling (B per GPU fixed, reference recipe B=80: cot_experim
 gradients averaged with cotnet_amd.data_parallel.GradBucketReducer (RCCL all-reduce on a side stream).
 K steps are timed between barrier + torch.cuda.synchronize() pairs; the slowest rank's time is reported.
 
-Kernel set (`--kernels`, config.kernel_selection on the line): `round1` = the configuration measured in round 1 (MIOpen
-convolutions, one autograd node per op); `new` = hand-written 1x1 / grouped-3x3 / GroupNorm kernels inside single-node
-CotLayer / Bottleneck, written after round 1's GPU budget was spent.  The default `auto` lets a
-child process run both on this GPU from identical weights and input -- loss and flat gradient buckets must agree -- and
-time them; the step then runs on the faster verified set (round1 unless `new` is at least 3 % faster; any trouble in the
-child = round1).  With N > 1 rank 0 probes and publishes the verdict on the rendezvous store.
+Kernel set (`--kernels`, config.kernel_selection on the line): `new` (DEFAULT, the product) = every kernel of the step from
+cotnet_amd/csrc inside single-node CotLayer / Bottleneck -- if the library cannot serve a layer the run
+fails, it never falls back.  `round1` = MIOpen convolutions, one autograd node per op: a developer A/B baseline only; its
+line is marked `"baseline_only": true` and its metric says so.  `auto` = the round-2/3 probe (a child process checks
+`new` block by block against an fp32 truth and `round1`, and times both); when it does not end on `new` the run EXITS with
+status 3 instead of printing a MIOpen-backed headline.
 
 Extra objects on the line:
   roofline      the dominant aggregation kernel of the timed region (largest total device time): algorithmic bytes
@@ -78,11 +78,11 @@ def parse():
                     help="the reference recipe's regularisation in the step (cot_experiments/CoTNet-50-350epoch/config.yaml:21-26: "
                          "drop 0.25, drop_path 0.1, model_ema decay 0.9999): stochastic depth inside the single-node Bottlenecks, "
                          "head dropout on the library path, flat EMA kernel")
-    ap.add_argument("--kernels", default="auto", choices=["auto", "round1", "new"],
-                    help="which kernel set the step runs on: round1 = MIOpen convolutions + node-per-op layers (the "
-                         "configuration measured in round 1); new = hand-written 1x1 / grouped-3x3 / GroupNorm kernels inside "
-                         "single-node CotLayer / Bottleneck; auto (default) = a child process checks `new` against `round1` on "
-                         "this GPU (same loss and gradients) and times both, the faster verified one is used")
+    ap.add_argument("--kernels", default="new", choices=["auto", "round1", "new"],
+                    help="which kernel set the step runs on: new (default) = the library's own kernels inside single-node "
+                         "CotLayer / Bottleneck, no fallback; round1 = MIOpen convolutions + node-per-op layers (developer "
+                         "baseline; the line is marked baseline_only); auto = a child process checks `new` against an fp32 "
+                         "truth and `round1` on this GPU and times both -- the run exits with status 3 unless `new` wins")
     ap.add_argument("--tune", default="", metavar="KEY=VALUE[,KEY=VALUE...]",
                     help="developer A/B: cot_set_tuning(KEY, VALUE) after the kernel set is applied (include/cotnet_amd.h)")
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
@@ -523,7 +523,8 @@ def main():
         chosen = args.kernels
         if args.kernels == "auto":
             if not (args.dtype == "bf16" and args.precision == "mixed" and args.layout == "nchw"):
-                chosen, selection = "round1", {"mode": "auto", "note": "the new kernel set covers bf16 mixed-precision NCHW"}
+                raise SystemExit("bench.py --kernels auto: the probe covers bf16 mixed-precision NCHW only; run this configuration "
+                                 "with --kernels new (the library's general kernels) or --kernels round1 (baseline)")
             elif world == 1:
                 chosen, selection = choose_kernels(args)
             else:  # rank 0 probes on its GPU, everybody else waits for the verdict on the rendezvous store (CPU side)
@@ -537,6 +538,11 @@ def main():
         selection["chosen"] = chosen
         if rank == 0:
             print(f"[bench] kernel set: {chosen}  ({json.dumps(selection)[:600]})", file=sys.stderr, flush=True)
+        if args.kernels == "auto" and chosen != "new":
+            # a MIOpen-backed number must never stand in for the product's: no line at all
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(3)
         apply_kernel_set(chosen)
 
     import cotnet_amd
@@ -755,8 +761,11 @@ def main():
                         "conv_bn_note": "per CALL of the C ABI (all launches of the call), dispatch-attached events; frac_hbm = algorithmic "
                                         "bytes / time / 8 TB/s, frac_mfma = 2*N*HW*Ci*Co(*9)/groups / time / 2.5 PFLOP/s; weight gradients "
                                         "run on a side stream beside other kernels, so their times overlap the rest of the step"}
+        baseline_only = (not explicit and chosen == "round1") or (explicit and not __import__("cotnet_amd.cot_layer_fused", fromlist=["ENABLED"]).ENABLED)
         line = {
-            "metric": f"images/sec {MODEL_TITLES.get(args.model, args.model)} {args.img}^2 " + ("fwd+bwd" if args.mode == "train" else "fwd"),
+            "metric": f"images/sec {MODEL_TITLES.get(args.model, args.model)} {args.img}^2 " + ("fwd+bwd" if args.mode == "train" else "fwd")
+                      + (" [MIOpen / node-per-op developer baseline, NOT the product path]" if baseline_only else ""),
+            **({"baseline_only": True} if baseline_only else {}),
             "value": round(B * world * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "settle": settle, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

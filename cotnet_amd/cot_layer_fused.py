@@ -90,7 +90,10 @@ def _ck(rc, what):
 # compute stream joins the side stream (a) at the next node's flush, which is also when the tensors the previous node's
 # launches read are released, and (b) when the backward pass ends (autograd engine callback), i.e. before an optimizer or
 # anybody else on the compute stream can see the gradients; a gradient bucket that launches its all-reduce mid-backward makes
-# its communication stream wait for the side stream (grad_sink.producer_streams).
+# its communication stream wait for the side stream (grad_sink.producer_streams).  The un-joined form is taken ONLY by nodes
+# whose parameter gradients are all flat-bucket aliases that autograd merely adopts (_Side.adopted_only: FlatSGD / the
+# copy-mode reducer, the measured configuration); any node that hands autograd an ordinary gradient tensor, runs under
+# create_graph or sees a foreign hook joins its side stream before it returns, exactly like COT_WGRAD_LAZY=0.
 SIDE_WGRAD = os.environ.get("COT_WGRAD_STREAM", "1") != "0"
 LAZY_WGRAD = os.environ.get("COT_WGRAD_LAZY", "1") != "0"
 _SIDE_STREAMS = {}  # device index -> [torch.cuda.Stream, workspace tensor]
@@ -103,18 +106,23 @@ def _join_pending(dev_index):
     if ent is None or pend is None:
         return
     if pend["keep"]:
-        torch.cuda.current_stream(torch.device("cuda", dev_index)).wait_stream(ent[0])
+        cur = torch.cuda.current_stream(torch.device("cuda", dev_index))
+        cur.wait_stream(ent[0])
+        main = pend.get("main")  # the stream the node's backward ran on: the caller may sit on another one by now (backward
+        if main is not None and main != cur:  # under a different ambient stream, re-entrant backward)
+            main.wait_stream(ent[0])
         pend["keep"] = []
 
 
 class _Side:
     """the side stream for one node's backward (or a pass-through onto the compute stream when switched off / on CPU tensors)"""
-    __slots__ = ("on", "main", "stream", "st", "ws", "keep", "lazy", "queue", "dev")
+    __slots__ = ("on", "main", "stream", "st", "ws", "keep", "lazy", "queue", "dev", "fresh0", "params")
 
-    def __init__(self, dev, ws_bytes, main_ws):
+    def __init__(self, dev, ws_bytes, main_ws, params=()):
         self.on = SIDE_WGRAD and _DEVICE_ONLY and dev.type == "cuda"
         self.lazy = self.on and LAZY_WGRAD
         self.keep, self.queue, self.dev = [], [], dev
+        self.fresh0, self.params = grad_sink.fresh_count(), params
         if not self.on:
             self.st, self.ws = _stream(), main_ws
             return
@@ -148,16 +156,39 @@ class _Side:
             self.keep.extend(tensors)
         return self.st
 
+    def adopted_only(self):
+        """True when nobody can READ this node's parameter gradients before the backward pass ends: every one of them is an
+        alias of its flat-bucket slot (grad_sink: autograd adopts it, and the copy-mode reducer that owns the slot makes its
+        communication stream wait for the side stream), no graph is being recorded (create_graph=True makes AccumulateGrad
+        clone what it is handed) and no foreign tensor / post-accumulate hook sits on a parameter.  An ORDINARY gradient
+        tensor is accumulated by autograd on the compute stream right after the node returns (`p.grad += g` when a gradient
+        exists already: a second backward without zero_grad, micro-batches, a view-mode reducer, a parameter used twice) --
+        while the side stream may still be writing it.  Only the first kind of node may leave its weight
+        gradients un-joined."""
+        if grad_sink.fresh_count() != self.fresh0 or torch.is_grad_enabled():
+            return False
+        for p in self.params:
+            if p._backward_hooks:
+                return False
+            h = p._post_accumulate_grad_hooks
+            if h is not None and len(h) > 1:  # (one = the reducer that registered the sink)
+                return False
+        return True
+
     def join(self):
         if self.lazy:
             pend = _SIDE_PENDING[self.dev.index]
             if pend["keep"]:  # the previous node's launches: long done by now; their inputs may go
                 self.main.wait_stream(self.stream)
-            pend["keep"] = self.keep
+            pend["keep"], pend["main"] = self.keep, self.main
             self.stream.wait_stream(self.main)
             for fn in self.queue:
                 fn(self.st)
             self.queue, self.keep = [], []
+            if not self.adopted_only():  # somebody may read the gradients as soon as the node returns: join here
+                self.main.wait_stream(self.stream)
+                pend["keep"] = []
+                return
             # join when the backward pass ends.  Queued by EVERY flush (the first callback to run joins, the others find nothing
             # pending): a flag "already queued" would survive a backward pass that died half-way and silence all later ones
             try:
@@ -411,7 +442,7 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     st = _stream()
     own_side = side is None
     if own_side:
-        side = _Side(dev, ws_bytes, ws)
+        side = _Side(dev, ws_bytes, ws, pl.params)
     ke0, ke1, em0, em1, em3, cv0, cv1 = pl.ke0, pl.ke1, pl.em0, pl.em1, pl.em3, pl.cv0, pl.cv1
     se0, sebn, se3 = pl.se0, pl.sebn, pl.se3
     gout = gout.contiguous()
@@ -661,7 +692,7 @@ class _BottleneckNode(Function):
         ws = torch.empty(max(ws_a, ws_b), dtype=torch.uint8, device=dev)
         cN, cC, cH, cW = saved[0].shape
         cpl = _plan(bp.cot)
-        side = _Side(dev, max(ws_a, ws_b, _sizes(L, cN, cC, cH, cW, cpl.se0.out_channels, cpl.ke0.groups)[0]), ws)
+        side = _Side(dev, max(ws_a, ws_b, _sizes(L, cN, cC, cH, cW, cpl.se0.out_channels, cpl.ke0.groups)[0]), ws, bp.params)
         gout = gout.contiguous()
         # bn3 + residual + relu: dx of the normalisation and the residual's gradient in one pass
         g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)

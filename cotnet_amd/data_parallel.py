@@ -157,6 +157,7 @@ class GradBucketReducer:
         if param.grad is not None and param.grad.data_ptr() != self._expected_ptr(b, param):
             # someone replaced .grad (e.g. zero_grad(set_to_none=True)); fold it back into the bucket
             view = self._view(b, param)
+            grad_sink.sync_producers()  # (a producer's side stream may still be writing the tensor that is read here)
             view.copy_(param.grad)
             param.grad = view
         b.pending -= 1
@@ -275,8 +276,8 @@ class GradBucketReducer:
         self._hooks = []
         if self.grad_mode == "copy":
             for b in self.buckets:
-                for p in b.params:
-                    grad_sink.unregister(p)
+                for p, v in zip(b.params, b.views):
+                    grad_sink.unregister(p, v)  # (only this reducer's own entries: a successor may have re-registered p)
 
     def __del__(self):
         try:

@@ -19,6 +19,7 @@ accumulates as usual.
 import torch
 
 _SINK = {}  # id(param) -> [param, view into the flat gradient bucket, lent this step]
+_FRESH = [0]  # number of ORDINARY tensors out_like() has handed out (see fresh_count)
 _PRODUCERS = []  # (stream, join): streams other than the compute stream on which gradient kernels run (cot_layer_fused's side stream)
 
 
@@ -41,9 +42,11 @@ def register(param, view):
     _SINK[id(param)] = [param, view, False]
 
 
-def unregister(param):
+def unregister(param, view=None):
+    """drop the sink of `param`.  With `view` (the caller's own bucket view) only that owner's entry goes: a reducer that is
+    collected AFTER its successor registered the same parameters must not delete the successor's entries"""
     e = _SINK.get(id(param))
-    if e is not None and e[0] is param:
+    if e is not None and e[0] is param and (view is None or e[1] is view):
         del _SINK[id(param)]
 
 
@@ -65,7 +68,17 @@ def out_like(param):
     if e is not None and e[0] is param and not e[2] and param.grad is None and e[1].dtype == param.dtype:
         e[2] = True
         return e[1].detach()  # new tensor object, same storage: autograd may adopt it
+    _FRESH[0] += 1
     return torch.empty_like(param)
+
+
+def fresh_count():
+    """how many ordinary (non-sink) gradient tensors have been handed out so far.  A producer that issues its gradient
+    kernels on a side stream compares the count before and after its node: an ordinary tensor goes to autograd's
+    AccumulateGrad, which may READ it right after the node returns (`p.grad += g` when a gradient already exists, hooks,
+    create_graph) -- so such a node must join its side stream before it returns; a sink alias is only ever adopted, and
+    its consumer (the copy-mode reducer) synchronises with the producer streams itself."""
+    return _FRESH[0]
 
 
 def is_in_place(param, view):

@@ -212,6 +212,28 @@ def test_grad_sink_lets_a_producer_write_its_bucket_slot():
     grad_sink.unregister_all()
 
 
+def test_a_collected_reducer_leaves_its_successors_sinks_alone():
+    """rebinding `opt = FlatSGD(model)` creates the new reducer before the old one is collected; the old
+    one's remove() / __del__ must only drop ITS OWN gradient-sink entries"""
+    from cotnet_amd import grad_sink
+    from cotnet_amd.data_parallel import GradBucketReducer
+    lin = torch.nn.Linear(4, 3)
+    old = GradBucketReducer(lin, grad_mode="copy")
+    new = GradBucketReducer(lin, grad_mode="copy")
+    own = {id(p): v for b in new.buckets for p, v in zip(b.params, b.views)}
+    old.remove()
+    del old
+    for p in lin.parameters():
+        assert grad_sink._SINK[id(p)][1] is own[id(p)]
+    before = grad_sink.fresh_count()
+    assert grad_sink.out_like(lin.weight).data_ptr() == own[id(lin.weight)].data_ptr()   # still lent from the new bucket
+    assert grad_sink.fresh_count() == before
+    assert grad_sink.out_like(lin.weight).data_ptr() != own[id(lin.weight)].data_ptr()   # second request of the step: fresh
+    assert grad_sink.fresh_count() == before + 1
+    new.remove()
+    assert not any(id(p) in grad_sink._SINK for p in lin.parameters())
+
+
 def _worker_fused_nodes(rank, world, port, q):
     """the measured configuration under data parallelism: single-node Bottlenecks whose kernels write parameter gradients
     straight into the flat bf16 buckets (grad_sink), FlatSGD's reducer all-reducing them -- on the host-emulated library, two
