@@ -1,0 +1,360 @@
+// agg_dot2.hip -- fused aggregation_zeropad backward (gX and gW in one pass), bf16, 3x3 / stride 1 / pad 1, gfx950:
+// the packed-bf16 dot-product form of the LDS-staged kernel of agg_nchw.hip (agg_bwd_nchw_k3_lds).
+//
+// Semantics: cupy_layers/aggregation_zeropad.py:48-79 (input backward), :81-110 (weight backward); same tile / slab
+// staging as agg_bwd_nchw_k3_lds (a workgroup owns TR consecutive rows rho = wc*H + h of one image; per channel group
+// j the rows rho0-1 .. rho0+TR of gO and x are ONE contiguous range, copied by asynchronous global->LDS DMA).
+//
+// Why a second kernel.  The fp32-unpacked loop of agg_bwd_nchw_k3_lds spends ~100 VALU instructions per (channel, 2
+// pixels) for 36 multiply-adds: every bf16 value is unpacked to fp32, halo columns are moved and masked per channel, and
+// the per-lane accesses are 4 bytes wide.  Measured: 0.55 of the HBM roofline at N80 x C64 x 56 x 56 with 1.13x the
+// algorithmic traffic -- issue-bound, not bandwidth-bound.  Here the operands stay PACKED (two bf16 per
+// 32-bit word, as they lie in memory) and every multiply-add is half of a v_dot2c_f32_bf16 (D += A.lo*B.lo + A.hi*B.hi,
+// fp32 accumulate, products of bf16 values are exact in fp32):
+//   * gX[c][p] = sum over 3 rows of a 3-tap correlation along W.  Two dot2 per output pixel and row: the word holding
+//     columns (p-1, p) or (p, p+1) against a pre-packed weight pair, plus the neighbouring word against a pair with one
+//     zero half.  The 6*P weight pairs of an item are built ONCE (they are shared by the C/wC = 8 channels).
+//   * gW[tap][p] = sum over the 8 channels of x[c][p + off(tap)] * gO[c][p]: a dot product over CHANNELS.  Two
+//     channels' words are re-packed per column (v_perm_b32: (ch a, ch b) of one pixel in one word), then one dot2 per
+//     (tap, pixel) does two channels at once.
+//   * halo columns come from the neighbouring lanes by DPP row shifts on PACKED words (row_shr:1 / row_shl:1 inside a
+//     16-lane row, bound_ctrl zero fill); an image row occupies GS = 16 (or 8) lanes of which the last one or two are
+//     idle lanes that hold zeros, so the lane left of a row's first lane and right of its last lane always supplies
+//     ZERO: no per-channel row-end selection.
+//   * rows outside the image (and everything an idle / out-of-range lane reads) are redirected ONCE, at address
+//     computation, to a 16-byte zero chunk that follows every slab in LDS; all LDS offsets of the channel loop are
+//     immediates (W, P, tile shape and slab pitch are template parameters).
+// ~16-18 VALU instructions per (channel, pixel) instead of ~50, 8-byte accesses per lane instead of 4.
+//
+// Exactness: integer-valued data is bit-exact (exact products, exact fp32 sums); padded taps of gW are cleared by
+// SELECTION once per item (exact zeros whatever gO holds there, as the reference writes 0 without multiplying).
+#include "cot_common.h"
+
+namespace cot {
+
+// XCD-aware tile order (see logical_block in agg_nchw.hip): placement only, never results
+__device__ __forceinline__ unsigned logical_block_dot2(int xcd_remap) {
+    const unsigned b = blockIdx.x, nblk = gridDim.x;
+    if (!xcd_remap || (nblk & 7u) != 0) return b;
+    return (b & 7u) * (nblk >> 3) + (b >> 3);
+}
+
+#ifndef COT_DOT2_BF16  // (tests/emul pre-defines the three primitives for its host build)
+typedef __attribute__((ext_vector_type(2))) __bf16 cot_bf16x2;
+// acc + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (v_dot2c_f32_bf16)
+#define COT_DOT2_BF16(a, b, acc) \
+    __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(cot_bf16x2, (uint32_t)(a)), __builtin_bit_cast(cot_bf16x2, (uint32_t)(b)), (acc), false)
+// lane l <- lane l-1 / l+1 inside its 16-lane DPP row; the row's first / last lane <- 0 (bound_ctrl)
+#define COT_ROW_PREV(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x111, 0xf, 0xf, true))
+#define COT_ROW_NEXT(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x101, 0xf, 0xf, true))
+// v_perm_b32: (lo half of a, lo half of b) / (hi half of a, hi half of b)
+#define COT_PACK_LO(a, b) __builtin_amdgcn_perm((uint32_t)(b), (uint32_t)(a), 0x05040100u)
+#define COT_PACK_HI(a, b) __builtin_amdgcn_perm((uint32_t)(b), (uint32_t)(a), 0x07060302u)
+#endif
+
+__device__ __forceinline__ uint32_t pack_lo(uint32_t a, uint32_t b) { return COT_PACK_LO(a, b); }
+__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return COT_PACK_HI(a, b); }
+// (lo half of a, hi half of b)
+__device__ __forceinline__ uint32_t pack_lo_hi(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b & 0xffff0000u); }
+
+template <int W, int P, int GS, int NW>
+struct Dot2Shape {
+    static constexpr int SEGS = W / P;                 // active lanes of an image row's lane group
+    static constexpr int RW = 64 / GS;                 // image rows per wave
+    static constexpr int TR = NW * RW;                 // rows per workgroup
+    static constexpr int PW = P / 2;                   // 32-bit words per lane and row
+    static constexpr int CH = ((TR + 2) * W * 2 + 14 + 15) / 16;  // 16-byte data chunks per slab (rows + alignment slack)
+    static constexpr int PC = CH + 1;                  // slab pitch in chunks: data + one chunk of zeros
+    static constexpr int SLAB_B = PC * 16;
+    static constexpr int ZOFF = CH * 16;               // byte offset of the zero chunk inside a slab
+    static_assert(W % P == 0 && P % 2 == 0 && SEGS < GS && (GS == 16 || GS == 8), "lane group shape");
+};
+
+// gO and x slabs of JP channel groups (j0 ..), interleaved: slab 2*jj = gO, 2*jj + 1 = x.  The 64 chunks a wave copies per
+// round are consecutive in LDS whatever slab they belong to (destination = wave-uniform base + lane*16); the zero chunk
+// at each slab's end is skipped (its lane transfers nothing).
+template <typename S, int JP>
+__device__ __forceinline__ void dot2_stage(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ x, int64_t src0,
+                                           int64_t cstride, int64_t elems, char* smem) {
+    constexpr int TOTAL = 2 * JP * S::PC;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int nthr = blockDim.x;
+    for (int q0 = 0; q0 < TOTAL; q0 += nthr) {
+        const int q = q0 + tid;
+        const int s = q / S::PC, ch = q - s * S::PC;
+        if (q < TOTAL && ch < S::CH) {
+            const bf16_t* base = (s & 1) ? x : gout;
+            int64_t e = src0 + (int64_t)(s >> 1) * cstride + (int64_t)ch * 8;
+            if (e + 8 > elems) e = elems - 8;  // a chunk beyond the tensor: in-bounds bytes, never used as data
+            COT_ASYNC_COPY16(base + e, smem + (int64_t)(q0 + wave * 64) * 16);
+        }
+    }
+}
+
+// SAFE = 1: the half of a packed gO word that belongs to a column OUTSIDE an output's 3-tap window is cleared (one v_and per
+// such operand, 4 per row) instead of merely meeting a zero weight: a non-finite gO value then reaches exactly the gX
+// elements the reference's kernel puts it in (0 * NaN never happens).  SAFE = 0 saves those 12 instructions per channel;
+// finite data gives identical bits either way.
+template <int W, int P, int GS, int JP, int NW, int SAFE>
+__global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ x,
+                                                               const bf16_t* __restrict__ w, bf16_t* __restrict__ gx,
+                                                               bf16_t* __restrict__ gw, int C, int wC, int H, int tiles_per_n,
+                                                               int64_t elems, int xcd_remap) {
+    typedef Dot2Shape<W, P, GS, NW> S;
+    constexpr int PW = S::PW;
+    static_assert(JP % 2 == 0, "channels are processed in pairs");
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    char* smem = cot_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int J = C / wC, rows_n = wC * H;
+    const int64_t HW = (int64_t)H * W;
+    const unsigned lb = logical_block_dot2(xcd_remap);
+    const int tile = lb % tiles_per_n;
+    const int n = lb / tiles_per_n;
+    const int rho0 = tile * S::TR;
+    int64_t gs = (int64_t)(rho0 - 1) * W;  // first slab element (row rho0-1), rounded down to a 16-byte chunk
+    if (gs < 0) gs = 0;
+    gs &= ~(int64_t)7;
+    const int64_t cstride = (int64_t)wC * HW;
+    const int64_t img = (int64_t)n * C * HW;
+
+    dot2_stage<S, JP>(gout, x, img + gs, cstride, elems, smem);  // phase 0 is on its way while the weights are fetched
+    if (tid < 2 * JP) {  // the zero chunk behind every slab (never written by the DMA)
+        Vec<uint32_t, 4> z;
+        z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0u;
+        *reinterpret_cast<Vec<uint32_t, 4>*>(smem + tid * S::SLAB_B + S::ZOFF) = z;
+    }
+
+    // this lane's item
+    const int grp = lane / GS, seg = lane - grp * GS;
+    int rho = rho0 + wave * S::RW + grp;
+    const bool valid = seg < S::SEGS && rho < rows_n;
+    if (!valid) rho = rows_n - 1;  // (addresses stay inside the tensor; the lane reads zeros and stores nothing)
+    const int wc = rho / H, h = rho - wc * H;
+    const int w0 = valid ? seg * P : 0;
+    const int64_t plane = (int64_t)n * wC + wc;
+    const int lidx = (int)((int64_t)rho * W + w0 - gs);  // centre-row vector inside a slab, in elements
+    int base[3];  // byte offsets of rows h-1, h, h+1 inside a slab; rows outside the image -> the zero chunk
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const int hr = h - 1 + rr;
+        base[rr] = (valid && hr >= 0 && hr < H) ? (lidx + (rr - 1) * W) * 2 : S::ZOFF;
+    }
+
+    // ---- gX weight pairs: A_rr[d](c) = Wt[kh = 2 - rr][kw = 1 - d] at (row h-1+rr, column w0 + c)
+    uint32_t wpa[3][P], wpb[3][P];
+    {
+        const bf16_t* wp = w + plane * 9 * HW + w0;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const int kh = 2 - rr, hr = h - 1 + rr;
+            const bool rok = valid && hr >= 0 && hr < H;
+            const int hc = hr < 0 ? 0 : (hr >= H ? H - 1 : hr);
+            uint32_t tv[3][PW];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const Vec<uint32_t, PW> v = *reinterpret_cast<const Vec<uint32_t, PW>*>(wp + (int64_t)(kh * 3 + kw) * HW + (int64_t)hc * W);
+#pragma unroll
+                for (int k = 0; k < PW; ++k) tv[kw][k] = rok ? v.v[k] : 0u;  // (selection: a clamped row's weights never count)
+            }
+            const uint32_t tvL2 = COT_ROW_PREV(tv[2][PW - 1]);  // tap kw=2 at column w0-1 (hi half)
+            const uint32_t tvR0 = COT_ROW_NEXT(tv[0][0]);       // tap kw=0 at column w0+P (lo half)
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                if ((i & 1) == 0) {
+                    const uint32_t t2 = i == 0 ? tvL2 : tv[2][(i - 2) / 2 < 0 ? 0 : (i - 2) / 2];
+                    wpa[rr][i] = t2 & 0xffff0000u;                        // (0, A-1(i-1))
+                    wpb[rr][i] = pack_lo_hi(tv[1][i / 2], tv[0][i / 2]);  // (A0(i), A+1(i+1))
+                } else {
+                    const uint32_t t0 = i == P - 1 ? tvR0 : tv[0][(i + 1) / 2 >= PW ? PW - 1 : (i + 1) / 2];
+                    wpa[rr][i] = pack_lo_hi(tv[2][(i - 1) / 2], tv[1][(i - 1) / 2]);  // (A-1(i-1), A0(i))
+                    wpb[rr][i] = t0 & 0xffffu;                                        // (A+1(i+1), 0)
+                }
+            }
+        }
+    }
+    float gwacc[9][P];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < P; ++i) gwacc[t][i] = 0.f;
+
+    bf16_t* gxp = gx + img + (int64_t)rho * W + w0;
+    for (int j0 = 0; j0 < J; j0 += JP) {
+        if (j0 > 0) {
+            __syncthreads();  // everyone finished reading the previous phase's slabs
+            dot2_stage<S, JP>(gout, x, img + (int64_t)j0 * cstride + gs, cstride, elems, smem);
+        }
+        __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes every wave's chunks (and the zero chunks) visible
+#pragma unroll
+        for (int jp = 0; jp < JP; jp += 2) {
+            uint32_t g[2][3][PW], xs[2][3][PW];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    const Vec<uint32_t, PW> gv = *reinterpret_cast<const Vec<uint32_t, PW>*>(smem + (2 * (jp + c)) * S::SLAB_B + base[rr]);
+                    const Vec<uint32_t, PW> xv = *reinterpret_cast<const Vec<uint32_t, PW>*>(smem + (2 * (jp + c) + 1) * S::SLAB_B + base[rr]);
+#pragma unroll
+                    for (int k = 0; k < PW; ++k) {
+                        g[c][rr][k] = gv.v[k];
+                        xs[c][rr][k] = xv.v[k];
+                    }
+                }
+            // ---- gX of the two channels
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float acc[P];
+#pragma unroll
+                for (int i = 0; i < P; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    const uint32_t gL = COT_ROW_PREV(g[c][rr][PW - 1]);
+                    const uint32_t gR = COT_ROW_NEXT(g[c][rr][0]);
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+                        if ((i & 1) == 0) {
+                            uint32_t gm = i == 0 ? gL : g[c][rr][(i - 2) / 2 < 0 ? 0 : (i - 2) / 2];
+                            if (SAFE) gm &= 0xffff0000u;  // only column i-1 of this word is inside the window
+                            acc[i] = COT_DOT2_BF16(gm, wpa[rr][i], acc[i]);
+                            acc[i] = COT_DOT2_BF16(g[c][rr][i / 2], wpb[rr][i], acc[i]);
+                        } else {
+                            uint32_t gp = i == P - 1 ? gR : g[c][rr][(i + 1) / 2 >= PW ? PW - 1 : (i + 1) / 2];
+                            if (SAFE) gp &= 0xffffu;  // only column i+1
+                            acc[i] = COT_DOT2_BF16(g[c][rr][(i - 1) / 2], wpa[rr][i], acc[i]);
+                            acc[i] = COT_DOT2_BF16(gp, wpb[rr][i], acc[i]);
+                        }
+                    }
+                }
+                Vec<bf16_t, P> o;
+#pragma unroll
+                for (int i = 0; i < P; ++i) o.v[i] = (bf16_t)acc[i];
+                if (valid) stv<bf16_t, P>(gxp + (int64_t)(j0 + jp + c) * cstride, o);
+            }
+            // ---- gW: the two channels' words re-packed per column, one dot2 per (tap, pixel)
+            uint32_t gp2[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+                gp2[i] = (i & 1) ? pack_hi(g[0][1][i / 2], g[1][1][i / 2]) : pack_lo(g[0][1][i / 2], g[1][1][i / 2]);
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                uint32_t xp[P + 2];
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+                    xp[i + 1] = (i & 1) ? pack_hi(xs[0][rr][i / 2], xs[1][rr][i / 2]) : pack_lo(xs[0][rr][i / 2], xs[1][rr][i / 2]);
+                xp[0] = COT_ROW_PREV(xp[P]);
+                xp[P + 1] = COT_ROW_NEXT(xp[1]);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) gwacc[rr * 3 + kw][i] = COT_DOT2_BF16(xp[i + kw], gp2[i], gwacc[rr * 3 + kw][i]);
+            }
+        }
+    }
+    // taps that reach outside the image: exact zeros by selection, once per item (aggregation_zeropad.py:97-105)
+    {
+        const bool top = h > 0, bottom = h < H - 1, has_left = seg > 0, has_right = seg < S::SEGS - 1;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                gwacc[0 + kw][i] = top ? gwacc[0 + kw][i] : 0.f;
+                gwacc[6 + kw][i] = bottom ? gwacc[6 + kw][i] : 0.f;
+            }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            gwacc[kh * 3 + 0][0] = has_left ? gwacc[kh * 3 + 0][0] : 0.f;
+            gwacc[kh * 3 + 2][P - 1] = has_right ? gwacc[kh * 3 + 2][P - 1] : 0.f;
+        }
+    }
+    if (valid) {
+        bf16_t* gp = gw + plane * 9 * HW + (int64_t)h * W + w0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            Vec<bf16_t, P> o;
+#pragma unroll
+            for (int i = 0; i < P; ++i) o.v[i] = (bf16_t)gwacc[t][i];
+            stv<bf16_t, P>(gp + t * HW, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch.  Tuning (cot_set_tuning keys 29 / 30 / 31 / 32): on (1, default) / off; channel groups per LDS phase (0 = by width: 2 at 56, else 4);
+// XCD-aware tile order (-1 automatic as the fp32 kernel: planes up to 28 x 28, 0 off, 1 on); waves per workgroup (0 = by width: 2 at 28, else 4; 2 | 4 | 8);
+// key 33: SAFE operand masking (1 default; 0 = a non-finite gO may reach the next-nearest column of gX as well)
+// ------------------------------------------------------------------------------------------------
+static int g_dot2[5] = {1, 0, -1, 0, 1};
+int set_tuning_dot2(int key, int value) {
+    if (key < 0 || key > 4) return -1;
+    g_dot2[key] = value;
+    return 0;
+}
+
+template <int W, int P, int GS, int JP, int NW>
+static int launch_dot2_nw(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
+                          hipStream_t s) {
+    typedef Dot2Shape<W, P, GS, NW> S;
+    const bool safe = g_dot2[4] != 0;
+    const int tiles = (g.wC * g.H + S::TR - 1) / S::TR;
+    const size_t lds = (size_t)2 * JP * S::SLAB_B;
+    const int xcd = g_dot2[2] < 0 ? (g.H * g.W <= 28 * 28 ? 1 : 0) : g_dot2[2];
+    const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
+    if (safe)
+        COT_LAUNCH((agg_bwd_nchw_k3_dot2<W, P, GS, JP, NW, 1>), dim3((unsigned)((int64_t)tiles * g.N)), dim3(NW * 64), lds, s, gout, x,
+                   w, gx, gw, g.C, g.wC, g.H, tiles, ne, xcd);
+    else
+        COT_LAUNCH((agg_bwd_nchw_k3_dot2<W, P, GS, JP, NW, 0>), dim3((unsigned)((int64_t)tiles * g.N)), dim3(NW * 64), lds, s, gout, x,
+                   w, gx, gw, g.C, g.wC, g.H, tiles, ne, xcd);
+    return check_launch("agg_bwd_nchw_k3_dot2");
+}
+
+// defaults from the on-device A/B (profiles/r04_agg_dot2_variants.log, B = 80, inputs cache-warm as inside the model; us per
+// launch, JP x waves): 56 x 56: 2 x 4 31.0 | 4 x 4 32.1 | 4 x 2 34.1 | 8 x 4 39.8;  28 x 28: 4 x 2 18.3 | 4 x 4 18.9 | 2 x 4 18.9;
+// 14 x 14: 4 x 4 10.5 | 4 x 2 10.7 | 2 x 4 11.0  (the fp32-unpacked LDS kernel: 37.0 / 19.5 / 13.2)
+static inline int default_jp(int W) { return W == 56 ? 2 : 4; }
+static inline int default_nw(int W) { return W == 28 ? 2 : 4; }
+
+template <int W, int P, int GS, int JP>
+static int launch_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
+                       hipStream_t s) {
+    switch (g_dot2[3] > 0 ? g_dot2[3] : default_nw(W)) {  // (8 waves measured 20-25 % slower than 4 everywhere: not built)
+        case 2: return launch_dot2_nw<W, P, GS, JP, 2>(gout, x, w, gx, gw, g, s);
+        default: return launch_dot2_nw<W, P, GS, JP, 4>(gout, x, w, gx, gw, g, s);
+    }
+}
+
+template <int W, int P, int GS>
+static int launch_dot2_jp(int JP, const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
+                          hipStream_t s) {
+    switch (JP) {  // (8 channel groups per phase -- everything staged at once -- measured 25 % slower than 2 / 4: not built)
+        case 4: return launch_dot2<W, P, GS, 4>(gout, x, w, gx, gw, g, s);
+        default: return launch_dot2<W, P, GS, 2>(gout, x, w, gx, gw, g, s);
+    }
+}
+
+// -> -1: geometry not covered (caller keeps agg_bwd_nchw_k3_lds); else the launch status
+int agg_backward_nchw_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
+                           hipStream_t s) {
+    if (!g_dot2[0] || !gx || !gw || g.heads != 1 || g.wC <= 0 || g.C % g.wC != 0) return -1;
+    const int J = g.C / g.wC;
+    const int64_t HW = (int64_t)g.H * g.W;
+    if (J % 2 != 0 || ((int64_t)g.wC * HW) % 8 != 0 || (int64_t)g.N * g.C * HW < 8) return -1;
+    if ((int64_t)g.wC * HW * J * g.N >= ((int64_t)1 << 31)) return -1;  // (32-bit element offsets inside an image are fine; total < 2^31 keeps lidx arithmetic simple)
+    int JP = g_dot2[1] > 0 ? g_dot2[1] : default_jp(g.W);
+    if (JP > 4) JP = 4;
+    while (JP > 2 && J % JP != 0) JP >>= 1;
+    if (J % JP != 0) return -1;
+    switch (g.W) {
+        case 56: return launch_dot2_jp<56, 4, 16>(JP, gout, x, w, gx, gw, g, s);
+        case 28: return launch_dot2_jp<28, 4, 8>(JP, gout, x, w, gx, gw, g, s);
+        case 14: return launch_dot2_jp<14, 2, 8>(JP, gout, x, w, gx, gw, g, s);
+        // SE-CoTNetD at 320 x 320 (models/cotnet_hybrid.py: CoT layers at 40 x 40, 20 x 20 and 10 x 10)
+        case 40: return launch_dot2_jp<40, 4, 16>(JP, gout, x, w, gx, gw, g, s);
+        case 20: return launch_dot2_jp<20, 4, 8>(JP, gout, x, w, gx, gw, g, s);
+        case 10: return launch_dot2_jp<10, 2, 8>(JP, gout, x, w, gx, gw, g, s);
+        default: return -1;
+    }
+}
+
+}  // namespace cot

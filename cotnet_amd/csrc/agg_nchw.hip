@@ -1061,9 +1061,25 @@ static int launch_bwd_k3(const T* gout, const T* x, const T* w, T* gx, T* gw, co
     return launch_bwd_k3_sel<T, P, false, true>(gout, x, w, gx, gw, g, s);
 }
 
+// packed-bf16 dot-product form of the fused backward (agg_dot2.hip): -1 = geometry not covered
+int agg_backward_nchw_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
+                           hipStream_t s);
+template <typename T> static inline int try_dot2(const T*, const T*, const T*, T*, T*, const cot_agg_geom&, hipStream_t) { return -1; }
+template <> inline int try_dot2<bf16_t>(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw,
+                                        const cot_agg_geom& g, hipStream_t s) {
+    return agg_backward_nchw_dot2(gout, x, w, gx, gw, g, s);
+}
+
 template <typename T>
 int agg_backward_nchw(const T* gout, const T* x, const T* w, T* gx, T* gw, const cot_agg_geom& g, int Ho, int Wo,
                       hipStream_t s) {
+    if (is_k3_fast(g) && g.heads == 1 && gx && gw && g_tune[0] == 0 && g_tune[8] != 1) {  // (key 0 = 3 forces the LDS kernel below)
+        const int rc = try_dot2<T>(gout, x, w, gx, gw, g, s);
+        if (rc >= 0) {
+            g_last_kernel = "agg_bwd_nchw_k3_dot2<gx,gw>";
+            return rc;
+        }
+    }
     if (is_k3_fast(g) && g.heads == 1) {
         // P capped (default 4): the fused kernel keeps 18*P accumulate-type values of weights / weight-gradients live
         constexpr int LIM = (int)(16 / sizeof(T));

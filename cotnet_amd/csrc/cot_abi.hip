@@ -214,6 +214,7 @@ int input_normalize(const void*, void*, const float*, const float*, int64_t, int
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
 int set_tuning_nchw(int key, int value);
+int set_tuning_dot2(int key, int value);
 int xchg_mode();
 
 static int out_size(int in, int k, int s, int p, int d) {
@@ -380,6 +381,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 19) {
         g_wgrad_cap_pct = value > 0 ? value : 0;
+        return COT_OK;
+    }
+    if (key >= 29 && key <= 33) {
+        set_tuning_dot2(key - 29, value);
         return COT_OK;
     }
     if (set_tuning_nchw(key, value) != 0) return set_error(COT_ERR_INVALID_ARG, "unknown tuning key %d", key);

@@ -50,10 +50,18 @@ def main():
         "v3d_bP4_pad32": [(0, 3), (2, 4), (6, 32)],
         "v3d_xcd": [(0, 3), (7, 1)], "v3d_split": [(0, 3), (8, 1)], "v3d_xcd_split": [(0, 3), (7, 1), (8, 1)],
         "v3d_jp8": [(0, 3), (4, 8)], "v3d_jp2": [(0, 3), (4, 2)],
+        # automatic dispatch (key 0 = 0): bf16 fused backward on the packed dot-product kernel (agg_dot2.hip); keys 30 / 32 / 33 =
+        # channel groups per LDS phase, waves per workgroup, SAFE operand masking; "lds" = the same dispatch with it off
+        "lds": [(29, 0)], "dot2": [],
     }
+    for jp in (2, 4, 8):
+        for nw in (2, 4, 8):
+            for safe in (0, 1):
+                VAR[f"d2_jp{jp}_nw{nw}_s{safe}"] = [(30, jp), (32, nw), (33, safe)]
+                VAR[f"d2_jp{jp}_nw{nw}_s{safe}_xcd"] = [(30, jp), (32, nw), (33, safe), (31, 1)]
 
     def set_variant(name):
-        for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0)):
+        for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0), (29, 1), (30, 0), (31, -1), (32, 0), (33, 1)):
             L.cot_set_tuning(k, v)
         for k, v in VAR[name]:
             L.cot_set_tuning(k, v)
@@ -131,7 +139,7 @@ def main():
                 print(msg, flush=True)
             del sets
             torch.cuda.empty_cache()
-    for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0)):
+    for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0), (29, 1), (30, 0), (31, -1), (32, 0), (33, 1)):
         L.cot_set_tuning(k, v)
     if args.out:
         json.dump(rows, open(args.out, "w"), indent=1)

@@ -369,6 +369,27 @@ inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; 
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
     return emul::exchange<int>(src, ctrl == 0x138 ? -1 : +1, bound_ctrl ? 0 : old);  // bound_ctrl: no source lane -> 0
 }
+// agg_dot2.hip's primitives: DPP row shifts inside a 16-lane row with zero fill at the row's ends (row_shr:1 / row_shl:1,
+// bound_ctrl) and the packed-bf16 dot product v_dot2c_f32_bf16 (fp32 products of bf16 values are exact; the two products
+// are added to the accumulator one after the other here -- the hardware's internal order is checked on the GPU at the
+// tests' bf16 tolerance, integer-valued data is exact either way)
+namespace emul {
+inline uint32_t exchange_row16(uint32_t v, int delta) {
+    const int src = (t_lane & 15) + delta;
+    const uint32_t r = exchange<uint32_t>(v, delta, 0u);
+    return (src >= 0 && src < 16) ? r : 0u;
+}
+inline float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+    acc += bf16_bits_to_float((uint16_t)(a & 0xffffu)) * bf16_bits_to_float((uint16_t)(b & 0xffffu));
+    acc += bf16_bits_to_float((uint16_t)(a >> 16)) * bf16_bits_to_float((uint16_t)(b >> 16));
+    return acc;
+}
+}  // namespace emul
+#define COT_DOT2_BF16(a, b, acc) emul::dot2_bf16((uint32_t)(a), (uint32_t)(b), (acc))
+#define COT_ROW_PREV(v) emul::exchange_row16((uint32_t)(v), -1)
+#define COT_ROW_NEXT(v) emul::exchange_row16((uint32_t)(v), +1)
+#define COT_PACK_LO(a, b) (((uint32_t)(a) & 0xffffu) | ((uint32_t)(b) << 16))
+#define COT_PACK_HI(a, b) (((uint32_t)(a) >> 16) | ((uint32_t)(b) & 0xffff0000u))
 template <typename V> inline V __shfl_up(V v, int d) { return emul::exchange<V>(v, -d, v); }
 template <typename V> inline V __shfl_down(V v, int d) { return emul::exchange<V>(v, +d, v); }
 template <typename V> inline V __shfl_xor(V v, int m) { return emul::exchange<V>(v, (emul::t_lane ^ m) - emul::t_lane, v); }

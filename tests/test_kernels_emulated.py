@@ -109,7 +109,8 @@ def test_non_finite_values_propagate_as_in_the_reference(C, H, W, dtype):
     gout[1, 0, 0, W - 1] = float("inf")
     gout[1, 5, H - 1, 3] = float("nan")
     y, gx, gw, fk, bk = run(x, w, gout, 3, 1, 1, 1, 0, True)
-    assert "k3_lds" in fk and "k3_lds" in bk
+    # (bf16 at the model widths 10 / 14 / 20 / 28 / 40 / 56: the packed dot-product kernel, agg_dot2.hip, in its default SAFE form)
+    assert "k3_lds" in fk and ("k3_lds" in bk or (dtype == torch.bfloat16 and "k3_dot2" in bk))
     tol = 1e-5 if dtype == torch.float32 else 6e-2
     for got, want in zip((y, gx, gw), oracle_all(x.float(), w.float(), gout.float(), 3, 1, 1, 1)):
         got = got.float()
@@ -121,16 +122,18 @@ def test_non_finite_values_propagate_as_in_the_reference(C, H, W, dtype):
 
 @pytest.fixture
 def tuning():
-    def set_(version=0, fwd_p=4, bwd_p=2, xchg=0, jp=0, nw=4, pad=0, xcd=0, split=0):
-        for k, v in ((0, version), (1, fwd_p), (2, bwd_p), (3, xchg), (4, jp), (5, nw), (6, pad), (7, xcd), (8, split)):
+    def set_(version=0, fwd_p=4, bwd_p=2, xchg=0, jp=0, nw=4, pad=0, xcd=0, split=0, dot2=1, d_jp=0, d_xcd=-1, d_nw=0, d_safe=1):
+        for k, v in ((0, version), (1, fwd_p), (2, bwd_p), (3, xchg), (4, jp), (5, nw), (6, pad), (7, xcd), (8, split),
+                     (29, dot2), (30, d_jp), (31, d_xcd), (32, d_nw), (33, d_safe)):
             assert _EMUL.cot_set_tuning(k, v) == 0
     yield set_
     set_()
 
 
 _ALL_VARIANTS = ["v1", "v2_dpp", "v2_shfl", "v2_P8", "v3_lds", "v3_lds_P8_jp2", "v3_lds_jp8", "v3_lds_nw8_bP4",
-                 "v3_lds_xcd_split"]
-_SHAPES = [(16, 9, 56), (16, 11, 28), (32, 14, 14), (64, 7, 7), (16, 5, 8), (64, 56, 56), (128, 28, 28), (24, 6, 40)]
+                 "v3_lds_xcd_split", "dot2", "dot2_jp2_nw2_fast_xcd", "dot2_jp4_nw4", "dot2_off"]
+_SHAPES = [(16, 9, 56), (16, 11, 28), (32, 14, 14), (64, 7, 7), (16, 5, 8), (64, 56, 56), (128, 28, 28), (24, 6, 40), (16, 21, 20),
+           (32, 10, 10)]
 # every kernel generation x every shape x fp32 / bf16 (the coroutine emulator makes the full matrix a matter of seconds)
 _VERSION_CASES = [(c, h, w, dt, v) for (c, h, w) in _SHAPES for dt in (torch.float32, torch.bfloat16)
                   for v in _ALL_VARIANTS]
@@ -142,7 +145,11 @@ def test_k3_kernel_versions(C, H, W, dtype, variant, tuning):
     kw = {"v1": dict(version=1), "v2_dpp": dict(version=2), "v2_shfl": dict(version=2, xchg=1),
           "v2_P8": dict(version=2, fwd_p=8), "v3_lds": dict(version=3), "v3_lds_P8_jp2": dict(version=3, fwd_p=8, jp=2),
           "v3_lds_jp8": dict(version=3, jp=8), "v3_lds_nw8_bP4": dict(version=3, nw=8, bwd_p=4, pad=8),
-          "v3_lds_xcd_split": dict(version=3, xcd=1, split=1)}[variant]
+          "v3_lds_xcd_split": dict(version=3, xcd=1, split=1),
+          # automatic dispatch (version 0): bf16 fused backward at W = 14 / 28 / 56 takes the packed dot-product kernel
+          # (csrc/agg_dot2.hip) in its phase / workgroup / masking variants; everything else the LDS kernel
+          "dot2": dict(), "dot2_jp2_nw2_fast_xcd": dict(d_jp=2, d_nw=2, d_safe=0, d_xcd=1), "dot2_jp4_nw4": dict(d_jp=4, d_nw=4),
+          "dot2_off": dict(dot2=0)}[variant]
     tuning(**kw)
     g = torch.Generator().manual_seed(C + W)
     N, wC = 2, C // 8  # small channel counts keep the 256-host-thread emulation fast; indexing is size-agnostic
@@ -154,11 +161,12 @@ def test_k3_kernel_versions(C, H, W, dtype, variant, tuning):
     tol = 1e-5 if dtype == torch.float32 else 6e-2
     for got, want in ((y, oy), (gx, ogx), (gw, ogw)):
         assert ((got.float() - want).abs() <= tol * (1 + want.abs())).all(), (fk, bk)
-    want_tag = {"v1": "k3<", "v2": "k3_v2", "v3": "k3_lds"}[variant[:2]]
+    want_tag = {"v1": "k3<", "v2": "k3_v2", "v3": "k3_lds", "do": "k3_lds"}[variant[:2]]
     # the LDS kernels fall back to v2 when their slabs exceed the 64 KiB LDS budget (jp=8 / 8-wave tiles at fp32 W=28)
     may_fall_back = variant in ("v3_lds_jp8", "v3_lds_nw8_bP4")
     assert want_tag in fk or (may_fall_back and "k3_v2" in fk), (fk, bk)
-    assert want_tag in bk or (may_fall_back and "k3_v2" in bk), (fk, bk)
+    on_dot2 = variant.startswith("dot2") and variant != "dot2_off" and dtype == torch.bfloat16 and W in (10, 14, 20, 28, 40, 56)
+    assert ("k3_dot2" in bk) if on_dot2 else (want_tag in bk or (may_fall_back and "k3_v2" in bk)), (fk, bk)
     if variant == "v3_lds_xcd_split":
         assert bk.endswith("<gw>"), bk  # the split knob issues a gX launch then a gW launch
     # gx-only and gw-only launches of the same generation
@@ -168,7 +176,11 @@ def test_k3_kernel_versions(C, H, W, dtype, variant, tuning):
     gx2, gw2 = torch.empty_like(x), torch.empty_like(w)
     assert _EMUL.cot_agg_backward_input(P(gout), P(w), P(gx2), ctypes.byref(geo), dt, 0, None) == 0
     assert _EMUL.cot_agg_backward_weight(P(gout), P(x), P(gw2), ctypes.byref(geo), dt, 0, None) == 0
-    assert torch.equal(gx2, gx) and torch.equal(gw2, gw)
+    if on_dot2:  # (the single-gradient launches run the LDS kernel: other summation order, same values to a bf16 ulp)
+        assert ((gx2.float() - gx.float()).abs() <= 2.0 ** -7 * gx.float().abs() + 1e-6).all()
+        assert ((gw2.float() - gw.float()).abs() <= 2.0 ** -7 * gw.float().abs() + 1e-6).all()
+    else:
+        assert torch.equal(gx2, gx) and torch.equal(gw2, gw)
 
 
 @pytest.mark.parametrize("fused", [True, False])
