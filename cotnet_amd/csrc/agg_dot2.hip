@@ -28,7 +28,7 @@
 //
 // Exactness: integer-valued data is bit-exact (exact products, exact fp32 sums); padded taps of gW are cleared by
 // SELECTION once per item (exact zeros whatever gO holds there, as the reference writes 0 without multiplying).
-#include "cot_common.h"
+#include "conv_lds_common.h"
 
 namespace cot {
 
@@ -73,20 +73,29 @@ struct Dot2Shape {
 // gO and x slabs of JP channel groups (j0 ..), interleaved: slab 2*jj = gO, 2*jj + 1 = x.  The 64 chunks a wave copies per
 // round are consecutive in LDS whatever slab they belong to (destination = wave-uniform base + lane*16); the zero chunk
 // at each slab's end is skipped (its lane transfers nothing).
-template <typename S, int JP>
+// Dead rows: when the tile starts (ends) at a plane boundary its first (last) slab row lies outside the image -- no lane ever
+// reads it (the row is redirected to the zero chunk) -- so the chunks that lie entirely inside it are not copied: chunks
+// [0, dead_lo) and [dead_hi, CH).  With plane-aligned tiles (TR a divisor or a multiple of H) this removes the halo
+// re-reads of gO and x altogether (TR < H: one live halo row per tile is left).
+// ASM = 1: the copies are issued from an asm statement the compiler does not count (conv_lds_common.h), so that they may
+// stay in flight across the LDS reads of the phase being computed (the double-buffered form below tracks them by hand).
+template <typename S, int JP, int ASM>
 __device__ __forceinline__ void dot2_stage(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ x, int64_t src0,
-                                           int64_t cstride, int64_t elems, char* smem) {
+                                           int64_t cstride, int64_t elems, char* smem, int dead_lo, int dead_hi) {
     constexpr int TOTAL = 2 * JP * S::PC;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int nthr = blockDim.x;
     for (int q0 = 0; q0 < TOTAL; q0 += nthr) {
         const int q = q0 + tid;
         const int s = q / S::PC, ch = q - s * S::PC;
-        if (q < TOTAL && ch < S::CH) {
+        if (q < TOTAL && ch >= dead_lo && ch < dead_hi) {
             const bf16_t* base = (s & 1) ? x : gout;
             int64_t e = src0 + (int64_t)(s >> 1) * cstride + (int64_t)ch * 8;
             if (e + 8 > elems) e = elems - 8;  // a chunk beyond the tensor: in-bounds bytes, never used as data
-            COT_ASYNC_COPY16(base + e, smem + (int64_t)(q0 + wave * 64) * 16);
+            if (ASM)
+                COT_GLDS16(base + e, smem + (int64_t)(q0 + wave * 64) * 16);
+            else
+                COT_ASYNC_COPY16(base + e, smem + (int64_t)(q0 + wave * 64) * 16);
         }
     }
 }
@@ -95,7 +104,17 @@ __device__ __forceinline__ void dot2_stage(const bf16_t* __restrict__ gout, cons
 // such operand, 4 per row) instead of merely meeting a zero weight: a non-finite gO value then reaches exactly the gX
 // elements the reference's kernel puts it in (0 * NaN never happens).  SAFE = 0 saves those 12 instructions per channel;
 // finite data gives identical bits either way.
-template <int W, int P, int GS, int JP, int NW, int SAFE>
+// ROLL = 1 (used with JP = J = 8: EVERY channel group of the tile staged at once, one DMA latency per workgroup instead of
+// one per phase): the channel-pair loop is not unrolled, so the compiler keeps one pair's words in registers (~100 VGPRs)
+// instead of hoisting the LDS reads of the whole phase (187 at JP = 8 unrolled: two waves per SIMD).
+// DB = 1: two LDS buffers; phase p+1's slabs are copied while phase p is computed.  A workgroup's life was a chain of
+// (DMA latency -> compute) links, one per phase, with only the other three or four co-resident workgroups to fill the
+// gaps: ~30 KB in flight per CU, i.e. latency-bound at ~4.4 TB/s on cold inputs whatever the instruction count (the
+// fp32-unpacked kernel and this one measured the same 38 us cold).  Per phase: vmcnt(0) (the prefetched slabs, issued a
+// whole compute phase ago, and the previous phase's gX stores -- vmcnt counts both, and stores retire out of order with
+// loads, so a counted wait cannot single the copies out), ONE barrier (everybody's chunks visible AND everybody done
+// with the buffer about to be refilled), issue the next copies, compute.
+template <int W, int P, int GS, int JP, int NW, int SAFE, int ROLL, int DB>
 __global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ x,
                                                                const bf16_t* __restrict__ w, bf16_t* __restrict__ gx,
                                                                bf16_t* __restrict__ gw, int C, int wC, int H, int tiles_per_n,
@@ -118,8 +137,16 @@ __global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __
     const int64_t cstride = (int64_t)wC * HW;
     const int64_t img = (int64_t)n * C * HW;
 
-    dot2_stage<S, JP>(gout, x, img + gs, cstride, elems, smem);  // phase 0 is on its way while the weights are fetched
-    if (tid < 2 * JP) {  // the zero chunk behind every slab (never written by the DMA)
+    // chunks of the slab's first / last row that need no copy (see dot2_stage)
+    const int64_t top_end = ((rho0 % H) == 0) ? (int64_t)rho0 * W - gs : 0;                                   // elements
+    const int rlast = rho0 + S::TR;                                                                            // row behind the tile
+    const int64_t bot_beg = (rlast >= rows_n || (rlast % H) == 0) ? (int64_t)rlast * W - gs : (int64_t)S::CH * 8;
+    const int dead_lo = (int)(top_end / 8);
+    int dead_hi = (int)((bot_beg + 7) / 8);
+    if (dead_hi > S::CH) dead_hi = S::CH;
+    constexpr int BUF_B = 2 * JP * S::SLAB_B;
+    dot2_stage<S, JP, DB>(gout, x, img + gs, cstride, elems, smem, dead_lo, dead_hi);  // phase 0 is on its way while the weights are fetched
+    if (tid < 2 * JP * (DB ? 2 : 1)) {  // the zero chunk behind every slab (never written by the DMA)
         Vec<uint32_t, 4> z;
         z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0u;
         *reinterpret_cast<Vec<uint32_t, 4>*>(smem + tid * S::SLAB_B + S::ZOFF) = z;
@@ -181,20 +208,31 @@ __global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __
 
     bf16_t* gxp = gx + img + (int64_t)rho * W + w0;
     for (int j0 = 0; j0 < J; j0 += JP) {
-        if (j0 > 0) {
-            __syncthreads();  // everyone finished reading the previous phase's slabs
-            dot2_stage<S, JP>(gout, x, img + (int64_t)j0 * cstride + gs, cstride, elems, smem);
+        const char* sb = smem;
+        if (DB) {
+            COT_WAIT_VM(0);     // this phase's slabs (this wave's chunks) have landed; the previous phase's stores are out
+            COT_LDS_BARRIER();  // ... everybody's have, and everybody is done reading the other buffer
+            const int pb = (j0 / JP) & 1;
+            sb = smem + pb * BUF_B;
+            if (j0 + JP < J)
+                dot2_stage<S, JP, 1>(gout, x, img + (int64_t)(j0 + JP) * cstride + gs, cstride, elems, smem + (pb ^ 1) * BUF_B,
+                                     dead_lo, dead_hi);
+        } else {
+            if (j0 > 0) {
+                __syncthreads();  // everyone finished reading the previous phase's slabs
+                dot2_stage<S, JP, 0>(gout, x, img + (int64_t)j0 * cstride + gs, cstride, elems, smem, dead_lo, dead_hi);
+            }
+            __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes every wave's chunks (and the zero chunks) visible
         }
-        __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes every wave's chunks (and the zero chunks) visible
-#pragma unroll
+#pragma unroll(ROLL ? 1 : JP / 2)
         for (int jp = 0; jp < JP; jp += 2) {
             uint32_t g[2][3][PW], xs[2][3][PW];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr) {
-                    const Vec<uint32_t, PW> gv = *reinterpret_cast<const Vec<uint32_t, PW>*>(smem + (2 * (jp + c)) * S::SLAB_B + base[rr]);
-                    const Vec<uint32_t, PW> xv = *reinterpret_cast<const Vec<uint32_t, PW>*>(smem + (2 * (jp + c) + 1) * S::SLAB_B + base[rr]);
+                    const Vec<uint32_t, PW> gv = *reinterpret_cast<const Vec<uint32_t, PW>*>(sb + (2 * (jp + c)) * S::SLAB_B + base[rr]);
+                    const Vec<uint32_t, PW> xv = *reinterpret_cast<const Vec<uint32_t, PW>*>(sb + (2 * (jp + c) + 1) * S::SLAB_B + base[rr]);
 #pragma unroll
                     for (int k = 0; k < PW; ++k) {
                         g[c][rr][k] = gv.v[k];
@@ -281,12 +319,13 @@ __global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __
 
 // ------------------------------------------------------------------------------------------------
 // host dispatch.  Tuning (cot_set_tuning keys 29 / 30 / 31 / 32): on (1, default) / off; channel groups per LDS phase (0 = by width: 2 at 56, else 4);
-// XCD-aware tile order (-1 automatic as the fp32 kernel: planes up to 28 x 28, 0 off, 1 on); waves per workgroup (0 = by width: 2 at 28, else 4; 2 | 4 | 8);
-// key 33: SAFE operand masking (1 default; 0 = a non-finite gO may reach the next-nearest column of gX as well)
+// XCD-aware tile order (-1 automatic as the fp32 kernel: planes up to 28 x 28, 0 off, 1 on); waves per workgroup (0 = by width: 7 / 5 = plane-aligned tiles; 2 | 4 | 5 | 7);
+// key 33: SAFE operand masking (1 default; 0 = a non-finite gO may reach the next-nearest column of gX as well); key 34: double-
+// buffered slabs (1 default: phase p+1 is copied while phase p is computed; 0 = copy, wait, compute)
 // ------------------------------------------------------------------------------------------------
-static int g_dot2[5] = {1, 0, -1, 0, 1};
+static int g_dot2[6] = {1, 0, -1, 0, 1, 1};
 int set_tuning_dot2(int key, int value) {
-    if (key < 0 || key > 4) return -1;
+    if (key < 0 || key > 5) return -1;
     g_dot2[key] = value;
     return 0;
 }
@@ -297,29 +336,46 @@ static int launch_dot2_nw(const bf16_t* gout, const bf16_t* x, const bf16_t* w, 
     typedef Dot2Shape<W, P, GS, NW> S;
     const bool safe = g_dot2[4] != 0;
     const int tiles = (g.wC * g.H + S::TR - 1) / S::TR;
-    const size_t lds = (size_t)2 * JP * S::SLAB_B;
+    const bool db = g_dot2[5] != 0 && JP < 8;  // (JP = 8 stages everything at once: nothing to prefetch)
+    const size_t lds = (size_t)2 * JP * S::SLAB_B * (db ? 2 : 1);
     const int xcd = g_dot2[2] < 0 ? (g.H * g.W <= 28 * 28 ? 1 : 0) : g_dot2[2];
     const int64_t ne = (int64_t)g.N * g.C * g.H * g.W;
-    if (safe)
-        COT_LAUNCH((agg_bwd_nchw_k3_dot2<W, P, GS, JP, NW, 1>), dim3((unsigned)((int64_t)tiles * g.N)), dim3(NW * 64), lds, s, gout, x,
-                   w, gx, gw, g.C, g.wC, g.H, tiles, ne, xcd);
-    else
-        COT_LAUNCH((agg_bwd_nchw_k3_dot2<W, P, GS, JP, NW, 0>), dim3((unsigned)((int64_t)tiles * g.N)), dim3(NW * 64), lds, s, gout, x,
-                   w, gx, gw, g.C, g.wC, g.H, tiles, ne, xcd);
+    constexpr int ROLL = JP == 8 ? 1 : 0;
+    const dim3 grid((unsigned)((int64_t)tiles * g.N)), block(NW * 64);
+#define COT_DOT2_GO(SAFE_, DB_)                                                                                                \
+    COT_LAUNCH((agg_bwd_nchw_k3_dot2<W, P, GS, JP, NW, SAFE_, ROLL, DB_>), grid, block, lds, s, gout, x, w, gx, gw, g.C, g.wC, g.H, \
+               tiles, ne, xcd)
+    if (safe && db) COT_DOT2_GO(1, (JP < 8 ? 1 : 0));
+    else if (safe) COT_DOT2_GO(1, 0);
+    else if (db) COT_DOT2_GO(0, (JP < 8 ? 1 : 0));
+    else COT_DOT2_GO(0, 0);
+#undef COT_DOT2_GO
     return check_launch("agg_bwd_nchw_k3_dot2");
 }
 
-// defaults from the on-device A/B (profiles/r04_agg_dot2_variants.log, B = 80, inputs cache-warm as inside the model; us per
-// launch, JP x waves): 56 x 56: 2 x 4 31.0 | 4 x 4 32.1 | 4 x 2 34.1 | 8 x 4 39.8;  28 x 28: 4 x 2 18.3 | 4 x 4 18.9 | 2 x 4 18.9;
-// 14 x 14: 4 x 4 10.5 | 4 x 2 10.7 | 2 x 4 11.0  (the fp32-unpacked LDS kernel: 37.0 / 19.5 / 13.2)
-static inline int default_jp(int W) { return W == 56 ? 2 : 4; }
-static inline int default_nw(int W) { return W == 28 ? 2 : 4; }
+// defaults from the on-device A/Bs (profiles/r04_agg_dot2_variants.log, r04_agg_dot2_double_buffer.log; B = 80, us per launch
+// cold | cache-warm, SAFE form): 56 x 56: JP 2 x 4 waves double-buffered 36.6 | 30.6, single-buffered 39.0 | 31.7, JP 4 38.0 | 34.5,
+// JP 8 (everything staged at once, rolled pair loop) 42.2 | 35.5, 7 waves (plane-aligned tiles: no halo re-reads) 37.2 | 31.1,
+// 8 waves 47.9 | 39.6;  28 x 28: JP 4 22.3 | 18.5, JP 2 23.2 | 18.4;  14 x 14: JP 4 12.6 | 10.5, JP 2 13.0 | 10.7
+// (the fp32-unpacked LDS kernel: 38.9 | 36.7, 22.7 | 19.4, 14.8 | 13.2)
+static inline int default_jp(int W) { return W >= 40 ? 2 : 4; }
+static inline int default_nw(int W) { return 4; }
 
 template <int W, int P, int GS, int JP>
 static int launch_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
                        hipStream_t s) {
-    switch (g_dot2[3] > 0 ? g_dot2[3] : default_nw(W)) {  // (8 waves measured 20-25 % slower than 4 everywhere: not built)
+    // waves per workgroup: 7 (5) make TR = 28 or 56 (20 or 40) rows, i.e. tiles that start and end at plane boundaries of the
+    // 56 / 28 / 14 (40 / 20 / 10) row planes -- no halo rows left to re-read; anything else 4.  (8 waves measured 20-25 %
+    // slower than 4: not built.)
+    int nw = g_dot2[3] > 0 ? g_dot2[3] : default_nw(W);
+    if (nw == 5) nw = 4;
+    if (nw == 7) {
+        const int TRn = nw * (64 / GS);
+        if (!(TRn % g.H == 0 || g.H % TRn == 0)) nw = 4;
+    }
+    switch (nw) {
         case 2: return launch_dot2_nw<W, P, GS, JP, 2>(gout, x, w, gx, gw, g, s);
+        case 7: return launch_dot2_nw<W, P, GS, JP, 7>(gout, x, w, gx, gw, g, s);
         default: return launch_dot2_nw<W, P, GS, JP, 4>(gout, x, w, gx, gw, g, s);
     }
 }
@@ -327,7 +383,8 @@ static int launch_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf1
 template <int W, int P, int GS>
 static int launch_dot2_jp(int JP, const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
                           hipStream_t s) {
-    switch (JP) {  // (8 channel groups per phase -- everything staged at once -- measured 25 % slower than 2 / 4: not built)
+    switch (JP) {  // (8 = everything staged at once, channel-pair loop rolled)
+        case 8: return launch_dot2<W, P, GS, 8>(gout, x, w, gx, gw, g, s);
         case 4: return launch_dot2<W, P, GS, 4>(gout, x, w, gx, gw, g, s);
         default: return launch_dot2<W, P, GS, 2>(gout, x, w, gx, gw, g, s);
     }
@@ -342,7 +399,6 @@ int agg_backward_nchw_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w,
     if (J % 2 != 0 || ((int64_t)g.wC * HW) % 8 != 0 || (int64_t)g.N * g.C * HW < 8) return -1;
     if ((int64_t)g.wC * HW * J * g.N >= ((int64_t)1 << 31)) return -1;  // (32-bit element offsets inside an image are fine; total < 2^31 keeps lidx arithmetic simple)
     int JP = g_dot2[1] > 0 ? g_dot2[1] : default_jp(g.W);
-    if (JP > 4) JP = 4;
     while (JP > 2 && J % JP != 0) JP >>= 1;
     if (J % JP != 0) return -1;
     switch (g.W) {

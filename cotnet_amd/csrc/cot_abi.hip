@@ -383,7 +383,7 @@ int cot_set_tuning(int key, int value) {
         g_wgrad_cap_pct = value > 0 ? value : 0;
         return COT_OK;
     }
-    if (key >= 29 && key <= 33) {
+    if (key >= 29 && key <= 34) {
         set_tuning_dot2(key - 29, value);
         return COT_OK;
     }

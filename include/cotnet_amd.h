@@ -156,9 +156,10 @@ const char* cot_last_kernel(void);
  *           cot_bn_act_workspace: query it after setting the key
  *   key 29: bf16 fused aggregation backward on the packed dot-product kernel (agg_dot2.hip; 1 default, 0 = the fp32-unpacked
  *           LDS kernel)   key 30: its channel groups per LDS phase (0 = by width; 2 | 4 | 8)   key 31: its XCD-aware tile order
- *           (-1 automatic, 0 off, 1 on)   key 32: its waves per workgroup (0 = by width; 2 | 4 | 8)
+ *           (-1 automatic, 0 off, 1 on)   key 32: its waves per workgroup (0 = by width; 2 | 4 | 5 | 7)
  *   key 33: 1 (default) = operand halves outside an output's window are cleared, so Inf / NaN in gO reach exactly the gX
  *           elements the reference puts them in; 0 = they may also reach the next-nearest column (12 instructions per channel less)
+ *   key 34: 1 (default) = its slabs are double-buffered (phase p+1 copied while phase p is computed), 0 = copy, wait, compute
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* Dry-run log of the calling thread (cot_set_tuning(26, 1)): one line per launch the library WOULD have issued --

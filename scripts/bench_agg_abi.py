@@ -55,13 +55,14 @@ def main():
         "lds": [(29, 0)], "dot2": [],
     }
     for jp in (2, 4, 8):
-        for nw in (2, 4, 8):
+        for nw in (2, 4, 7):
             for safe in (0, 1):
                 VAR[f"d2_jp{jp}_nw{nw}_s{safe}"] = [(30, jp), (32, nw), (33, safe)]
+                VAR[f"d2_jp{jp}_nw{nw}_s{safe}_sb"] = [(30, jp), (32, nw), (33, safe), (34, 0)]
                 VAR[f"d2_jp{jp}_nw{nw}_s{safe}_xcd"] = [(30, jp), (32, nw), (33, safe), (31, 1)]
 
     def set_variant(name):
-        for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0), (29, 1), (30, 0), (31, -1), (32, 0), (33, 1)):
+        for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0), (29, 1), (30, 0), (31, -1), (32, 0), (33, 1), (34, 1)):
             L.cot_set_tuning(k, v)
         for k, v in VAR[name]:
             L.cot_set_tuning(k, v)
@@ -139,7 +140,7 @@ def main():
                 print(msg, flush=True)
             del sets
             torch.cuda.empty_cache()
-    for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0), (29, 1), (30, 0), (31, -1), (32, 0), (33, 1)):
+    for k, v in ((0, 0), (1, 4), (2, 2), (3, -1), (4, 0), (5, 4), (6, 0), (7, -1), (8, 0), (29, 1), (30, 0), (31, -1), (32, 0), (33, 1), (34, 1)):
         L.cot_set_tuning(k, v)
     if args.out:
         json.dump(rows, open(args.out, "w"), indent=1)

@@ -9,6 +9,9 @@ case $what in
   smoke) timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 > $O/${T}_smoke.log ;;
   aggab1) timeout 600 python scripts/bench_agg_abi.py --dtypes bf16 --shapes 0 --rounds 3 --variants lds,d2_jp4_nw4_s1,d2_jp4_nw4_s0,d2_jp2_nw4_s1,d2_jp8_nw4_s1,d2_jp4_nw2_s1,d2_jp4_nw8_s1,d2_jp2_nw2_s1,d2_jp8_nw8_s1,d2_jp2_nw8_s1 > $O/${T}_aggab1.log 2>&1
           timeout 300 python scripts/bench_agg_abi.py --dtypes bf16 --shapes 1,2 --rounds 3 --variants lds,d2_jp4_nw4_s1,d2_jp4_nw4_s0,d2_jp2_nw4_s1,d2_jp8_nw4_s1,d2_jp4_nw2_s1,d2_jp4_nw8_s1,d2_jp4_nw4_s1_xcd >> $O/${T}_aggab1.log 2>&1 ;;
+  aggab2) timeout 600 python scripts/bench_agg_abi.py --dtypes bf16 --shapes 0,1,2 --rounds 3 --variants lds,dot2,d2_jp2_nw4_s1,d2_jp2_nw7_s1,d2_jp4_nw7_s1,d2_jp2_nw7_s0,d2_jp2_nw7_s1_xcd,d2_jp2_nw4_s1_xcd > $O/${T}_aggab2.log 2>&1 ;;
+  aggab3) timeout 600 python scripts/bench_agg_abi.py --dtypes bf16 --shapes 0,1,2 --rounds 3 --variants lds,d2_jp2_nw4_s1,d2_jp8_nw4_s1,d2_jp8_nw4_s0,d2_jp8_nw2_s1,d2_jp8_nw4_s1_xcd,d2_jp4_nw4_s1 > $O/${T}_aggab3.log 2>&1 ;;
+  aggab4) timeout 600 python scripts/bench_agg_abi.py --dtypes bf16 --shapes 0,1,2 --rounds 3 --variants lds,d2_jp2_nw4_s1_sb,d2_jp2_nw4_s1,d2_jp4_nw4_s1,d2_jp2_nw2_s1,d2_jp4_nw2_s1,d2_jp2_nw4_s0,d2_jp2_nw4_s1_xcd,d2_jp2_nw7_s1 > $O/${T}_aggab4.log 2>&1 ;;
   aggparity) timeout 600 python -m pytest tests/test_dispatch_parity_gpu.py tests/test_agg_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "agg or Agg or oracle or n80 or N80" 2>&1 | tail -30 > $O/${T}_aggparity.log ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac

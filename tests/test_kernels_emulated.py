@@ -122,16 +122,16 @@ def test_non_finite_values_propagate_as_in_the_reference(C, H, W, dtype):
 
 @pytest.fixture
 def tuning():
-    def set_(version=0, fwd_p=4, bwd_p=2, xchg=0, jp=0, nw=4, pad=0, xcd=0, split=0, dot2=1, d_jp=0, d_xcd=-1, d_nw=0, d_safe=1):
+    def set_(version=0, fwd_p=4, bwd_p=2, xchg=0, jp=0, nw=4, pad=0, xcd=0, split=0, dot2=1, d_jp=0, d_xcd=-1, d_nw=0, d_safe=1, d_db=1):
         for k, v in ((0, version), (1, fwd_p), (2, bwd_p), (3, xchg), (4, jp), (5, nw), (6, pad), (7, xcd), (8, split),
-                     (29, dot2), (30, d_jp), (31, d_xcd), (32, d_nw), (33, d_safe)):
+                     (29, dot2), (30, d_jp), (31, d_xcd), (32, d_nw), (33, d_safe), (34, d_db)):
             assert _EMUL.cot_set_tuning(k, v) == 0
     yield set_
     set_()
 
 
 _ALL_VARIANTS = ["v1", "v2_dpp", "v2_shfl", "v2_P8", "v3_lds", "v3_lds_P8_jp2", "v3_lds_jp8", "v3_lds_nw8_bP4",
-                 "v3_lds_xcd_split", "dot2", "dot2_jp2_nw2_fast_xcd", "dot2_jp4_nw4", "dot2_off"]
+                 "v3_lds_xcd_split", "dot2", "dot2_jp2_nw2_fast_xcd", "dot2_jp4_nw4", "dot2_single_buffer", "dot2_jp4_single_buffer", "dot2_nw7", "dot2_jp8_roll", "dot2_off"]
 _SHAPES = [(16, 9, 56), (16, 11, 28), (32, 14, 14), (64, 7, 7), (16, 5, 8), (64, 56, 56), (128, 28, 28), (24, 6, 40), (16, 21, 20),
            (32, 10, 10)]
 # every kernel generation x every shape x fp32 / bf16 (the coroutine emulator makes the full matrix a matter of seconds)
@@ -148,7 +148,7 @@ def test_k3_kernel_versions(C, H, W, dtype, variant, tuning):
           "v3_lds_xcd_split": dict(version=3, xcd=1, split=1),
           # automatic dispatch (version 0): bf16 fused backward at W = 14 / 28 / 56 takes the packed dot-product kernel
           # (csrc/agg_dot2.hip) in its phase / workgroup / masking variants; everything else the LDS kernel
-          "dot2": dict(), "dot2_jp2_nw2_fast_xcd": dict(d_jp=2, d_nw=2, d_safe=0, d_xcd=1), "dot2_jp4_nw4": dict(d_jp=4, d_nw=4),
+          "dot2": dict(), "dot2_jp2_nw2_fast_xcd": dict(d_jp=2, d_nw=2, d_safe=0, d_xcd=1), "dot2_jp4_nw4": dict(d_jp=4, d_nw=4), "dot2_single_buffer": dict(d_db=0), "dot2_jp4_single_buffer": dict(d_db=0, d_jp=4), "dot2_nw7": dict(d_nw=7), "dot2_jp8_roll": dict(d_jp=8),
           "dot2_off": dict(dot2=0)}[variant]
     tuning(**kw)
     g = torch.Generator().manual_seed(C + W)
