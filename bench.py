@@ -83,6 +83,9 @@ def parse():
                          "CotLayer / Bottleneck, no fallback; round1 = MIOpen convolutions + node-per-op layers (developer "
                          "baseline; the line is marked baseline_only); auto = a child process checks `new` against an fp32 "
                          "truth and `round1` on this GPU and times both -- the run exits with status 3 unless `new` wins")
+    ap.add_argument("--grad-dtype", default="param", choices=["param", "fp32"],
+                    help="arithmetic of the gradient all-reduce: param (default) = the parameters' dtype (bf16 buckets), fp32 = fp32 "
+                         "buckets, the reference's own reduction (train.py:112-115) at twice the bytes on the wire")
     ap.add_argument("--tune", default="", metavar="KEY=VALUE[,KEY=VALUE...]",
                     help="developer A/B: cot_set_tuning(KEY, VALUE) after the kernel set is applied (include/cotnet_amd.h)")
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
@@ -576,7 +579,8 @@ def main():
     if args.mode == "train" and mixed:
         model.train()
         opt = FlatSGD(model, lr=0.25 * B * world / 640.0, momentum=0.9, weight_decay=4e-5, nesterov=True,
-                      bucket_mb=args.bucket_mb, ema_decay=args.ema)
+                      bucket_mb=args.bucket_mb, ema_decay=args.ema,
+                      grad_dtype=torch.float32 if args.grad_dtype == "fp32" else None)
 
         def step():
             opt.zero_grad()
@@ -781,7 +785,8 @@ def main():
                        "conv3x3": __import__("cotnet_amd.conv3x3g", fromlist=["MODE"]).MODE or "module",
                        "group_norm9": __import__("cotnet_amd.group_norm9", fromlist=["MODE"]).MODE or "module",
                        "cot_layer_single_node": __import__("cotnet_amd.cot_layer_fused", fromlist=["ENABLED"]).ENABLED,
-                       "grad_sync": "RCCL all-reduce (AVG), flat buckets, side stream" if world > 1 else "none (1 GPU)"},
+                       "grad_sync": (f"RCCL all-reduce (AVG), flat {'fp32' if args.grad_dtype == 'fp32' else 'parameter-dtype'} buckets, side stream"
+                                     if world > 1 else "none (1 GPU)")},
             "final_loss": round(final_loss, 4),
             "roofline": roofline,
         }

@@ -43,13 +43,18 @@ def _decay_group(name, p):
 
 class FlatSGD:
     def __init__(self, model, lr, momentum=0.9, weight_decay=0.0, nesterov=True, bucket_mb=10.0, process_group=None,
-                 broadcast_params=True, ema_decay=None, force_collectives=False):
+                 broadcast_params=True, ema_decay=None, force_collectives=False, grad_dtype=None):
         """bucket_mb: size of the flat gradient buckets.  10 MiB cuts CoTNet-50's 44 MB of bf16 weight gradients into five
         buckets in the order backward produces them (classifier and stage 4 first, the stem last), so four all-reduces are
         already on the communication stream when backward ends and only the last, small one is exposed; round 2's 48 MiB
         made ONE bucket whose last member is the stem's weight -- nothing could overlap (tests/test_data_parallel_cpu.py).
         A 10 MB ring all-reduce over 8 GPUs moves 17.5 MB per link direction: ~0.12 ms at xGMI's ~153 GB/s, well above the
         collective's fixed latency.
+        grad_dtype: dtype of the flat gradient buckets = the arithmetic of the all-reduce.  None (default): the parameter's own
+        (bf16 weights -> bf16 buckets, RCCL averages in bf16: one rounding of 2^-9 relative per ring hop, ~0.2 % over eight
+        ranks -- the size of the bf16 gradients' own rounding; tests/test_data_parallel_cpu.py bounds it); torch.float32:
+        the reference's arithmetic (DDP sums fp32 gradients, train.py:112-115) at twice the bytes on the wire -- the
+        weight-gradient kernels then write ordinary bf16 tensors and the bucket fill up-converts them (no gradient sink).
         ema_decay: also keep an exponential moving average of the weights (the reference's ModelEmaV2,
         utils/model_ema.py, `model_ema: True` / decay 0.9999 in its recipes): one flat kernel per bucket after the SGD
         kernel instead of one elementwise op per state_dict tensor; floating-point buffers (BatchNorm running statistics)
@@ -61,7 +66,7 @@ class FlatSGD:
         # are already in their storage dtype, so the master starts as the (exact) up-cast of the working copy.
         self.reducer = GradBucketReducer(model, process_group=process_group, bucket_mb=bucket_mb,
                                          broadcast_params=broadcast_params, group_fn=_decay_group, grad_mode="copy",
-                                         flatten_params=True, force_collectives=force_collectives)
+                                         flatten_params=True, force_collectives=force_collectives, grad_dtype=grad_dtype)
         self.state = []
         for b in self.reducer.buckets:
             master = b.pflat.float().clone() if b.pflat.dtype != torch.float32 else None

@@ -74,7 +74,10 @@ MIX_FIXTURES = ["agg_mix_selftest", "agg_mix_heads2"]
 LAYER_FIXTURES = ["layer_cotlayer_d32", "layer_coxtlayer_d32", "layer_cotlayer_d64_7x7"]
 MODEL_FIXTURES = ["model_cotnet50", "model_cotnext50_2x48d", "model_se_cotnetd_50"]
 # CoTNet-50's four stage geometries at B = 2 (compact fixtures: weights from the seed, outputs at sampled positions + sums)
-REAL_LAYER_FIXTURES = ["layer_cotlayer_s1_64x56", "layer_cotlayer_s2_128x28", "layer_cotlayer_s3_256x14", "layer_cotlayer_s4_512x7"]
+REAL_LAYER_FIXTURES = ["layer_cotlayer_s1_64x56", "layer_cotlayer_s2_128x28", "layer_cotlayer_s3_256x14", "layer_cotlayer_s4_512x7",
+                       # round 4: CoXtLayer at CoTNeXt's widths, cotnet_hybrid.CoTLayer at SE-CoTNetD-152-L's maps (320 x 320 input)
+                       "layer_coxtlayer_s1_96x56", "layer_coxtlayer_s2_192x28", "layer_coxtlayer_s3_384x14", "layer_coxtlayer_s4_768x7",
+                       "layer_hybrid_cotlayer_256x20", "layer_hybrid_cotlayer_512x10"]
 K_OUT, K_GRAD = 16384, 8192
 
 
@@ -112,10 +115,11 @@ def real_layer_case(gold):
     the inputs come from the stored numpy seed exactly as the generator drew them"""
     meta = json.loads(str(gold["meta"]))
     seed = int(gold["seed"])
-    from cotnet_amd import cotnet
+    from cotnet_amd import cotnet, cotnet_hybrid
     rng = np.random.Generator(np.random.PCG64(seed))
     torch.manual_seed(seed)
-    layer = getattr(cotnet, meta["cls"])(meta["dim"], 3).float()
+    mod = cotnet_hybrid if meta["cls"].startswith("hybrid.") else cotnet
+    layer = getattr(mod, meta["cls"].split(".")[-1])(meta["dim"], 3).float()
     for m in layer.modules():  # tests/golden/make_golden.randomize_norm_state, same draws in the same order
         if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.GroupNorm)):
             with torch.no_grad():

@@ -220,6 +220,16 @@ REAL_LAYER_CASES = [
     ("cotlayer_s2_128x28", "CotLayer", 128, 2, 28, 28, 52),
     ("cotlayer_s3_256x14", "CotLayer", 256, 2, 14, 14, 53),
     ("cotlayer_s4_512x7", "CotLayer", 512, 2, 7, 7, 54),
+    # CoTNeXt (BASELINE config 4, cotnext*_2x48d: width = floor(planes * 48 / 64) * 2 = 96 / 192 / 384 / 768): the grouped
+    # 1x1 convolutions, the groups-8 key embedding and the group -> batch fold at their real geometries (cotnet.py:106-178)
+    ("coxtlayer_s1_96x56", "CoXtLayer", 96, 2, 56, 56, 61),
+    ("coxtlayer_s2_192x28", "CoXtLayer", 192, 2, 28, 28, 62),
+    ("coxtlayer_s3_384x14", "CoXtLayer", 384, 2, 14, 14, 63),
+    ("coxtlayer_s4_768x7", "CoXtLayer", 768, 2, 7, 7, 64),
+    # SE-CoTNetD-152 at 320 x 320 (BASELINE config 5): the CoT layers of its 256- and 512-wide stages (cotnet_hybrid.py:48-116,
+    # :138,:155) see 20 x 20 and 10 x 10 maps
+    ("hybrid_cotlayer_256x20", "hybrid.CoTLayer", 256, 2, 20, 20, 65),
+    ("hybrid_cotlayer_512x10", "hybrid.CoTLayer", 512, 2, 10, 10, 66),
 ]
 K_OUT, K_GRAD = 16384, 8192
 
@@ -228,11 +238,14 @@ def sample_idx(n, k):
     return np.unique(np.linspace(0, n - 1, min(n, k)).astype(np.int64))
 
 
-def make_real_layer_fixtures(ref_cotnet):
+def make_real_layer_fixtures(ref_cotnet, ref_hybrid=None, only=None):
     for name, cls, dim, B, H, W, seed in REAL_LAYER_CASES:
+        if only is not None and not any(name.startswith(o) for o in only):
+            continue
         rng = np.random.Generator(np.random.PCG64(seed))
         torch.manual_seed(seed)
-        layer = getattr(ref_cotnet, cls)(dim, 3).float()
+        mod = ref_hybrid if cls.startswith("hybrid.") else ref_cotnet
+        layer = getattr(mod, cls.split(".")[-1])(dim, 3).float()
         randomize_norm_state(layer, rng)
         state = {k: v.clone() for k, v in layer.state_dict().items()}
         probe = {k: float(v.double().sum()) for k, v in state.items() if v.is_floating_point()}
@@ -308,9 +321,10 @@ if __name__ == "__main__":
     if "--real-layers-only" not in sys.argv:
         make_op_fixtures()
     models, ref_cotnet, ref_hybrid = import_reference_models()
-    if "--real-layers-only" in sys.argv:
-        make_real_layer_fixtures(ref_cotnet)
+    if "--real-layers-only" in sys.argv:  # [--only PREFIX,PREFIX...]: e.g. --only coxtlayer,hybrid (round 4's additions)
+        only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
+        make_real_layer_fixtures(ref_cotnet, ref_hybrid, only)
         sys.exit(0)
     make_layer_fixtures(ref_cotnet)
-    make_real_layer_fixtures(ref_cotnet)
+    make_real_layer_fixtures(ref_cotnet, ref_hybrid)
     make_model_fixtures(models)

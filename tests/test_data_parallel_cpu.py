@@ -212,6 +212,82 @@ def test_grad_sink_lets_a_producer_write_its_bucket_slot():
     grad_sink.unregister_all()
 
 
+def _worker_fp32_buckets(rank, world, port, q):
+    """bf16 parameters, fp32 gradient buckets (FlatSGD(grad_dtype=torch.float32)): the all-reduce is the reference's fp32 sum
+    (train.py:112-115) -- the buckets equal the fp32 mean of the ranks' bf16 gradients exactly, not a bf16 rounding of it"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cotnet_amd.flat_sgd import _decay_group
+        torch.manual_seed(3)
+        model = _net().bfloat16()
+        red = GradBucketReducer(model, bucket_mb=1.0, group_fn=_decay_group, grad_mode="copy", flatten_params=True,
+                                grad_dtype=torch.float32)
+        assert all(b.flat.dtype == torch.float32 for b in red.buckets)
+        torch.manual_seed(50 + rank)
+        x, t = torch.randn(4, 3, 6, 6).bfloat16(), torch.randint(0, 4, (4,))
+        ref = _net().bfloat16()
+        ref.load_state_dict(model.state_dict())
+        nn.functional.cross_entropy(ref(x).float(), t).backward()
+        want = {}
+        for n, p in ref.named_parameters():
+            g = [torch.empty_like(p.grad) for _ in range(world)]
+            dist.all_gather(g, p.grad.contiguous())
+            want[n] = torch.stack([v.float() for v in g]).mean(0)
+        red.zero_grad()
+        nn.functional.cross_entropy(model(x).float(), t).backward()
+        red.finish()
+        names = {p: n for n, p in model.named_parameters()}
+        inexact = 0
+        for b in red.buckets:
+            for p, v in zip(b.params, b.views):
+                assert torch.equal(v, want[names[p]]), (names[p], (v - want[names[p]]).abs().max())
+                inexact += int((v != v.bfloat16().float()).any())
+        assert inexact > 0  # (the fp32 mean of two bf16 values is in general NOT a bf16 value: nothing was rounded on the way)
+        q.put((rank, len(red.buckets), "ok"))
+    except Exception as e:
+        q.put((rank, -1, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fp32_gradient_buckets_reduce_exactly_like_the_reference():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fp32_buckets, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[2] == "ok" for r in res), res
+
+
+def test_bf16_ring_average_over_eight_ranks_stays_within_the_gradients_own_rounding():
+    """the default buckets are bf16 and RCCL's ring all-reduce (AVG) adds in the data type, one rounding per
+    hop.  Model of the 8-rank ring on real gradient statistics (each rank's bf16 gradient = a common signal + per-rank noise,
+    the regime of data-parallel SGD): reduce-scatter order (((g0 + g1) + g2) + ...) rounded to bf16 after every add, then the
+    division by the world size rounded once.  The drift from the fp32 mean of the same bf16 inputs must stay of the order of
+    ONE bf16 rounding (2^-9 relative to the element's magnitude) -- i.e. no larger than the error already made when each
+    rank's fp32 gradient was stored as bf16."""
+    torch.manual_seed(0)
+    world, n = 8, 1 << 18
+    signal = torch.randn(n) * torch.logspace(-4, 0, n)           # gradients span four decades
+    grads = [(signal + 0.5 * signal.abs().mean() * torch.randn(n)).bfloat16() for _ in range(world)]
+    exact = torch.stack([g.float() for g in grads]).mean(0)
+    acc = grads[0]
+    for g in grads[1:]:
+        acc = (acc.float() + g.float()).bfloat16()                # one bf16 rounding per ring hop
+    ring = (acc.float() / world).bfloat16().float()
+    scale = torch.stack([g.float().abs() for g in grads]).amax(0)  # the partial sums are bounded by world * max |g_r|
+    rel = ((ring - exact).abs() / scale.clamp_min(1e-30))
+    ulp = 2.0 ** -8                                               # bf16: 8 significand bits -> half an ulp = 2^-9 relative
+    assert rel.max().item() <= world * ulp / 2, rel.max().item()  # worst case: every hop rounds the same way
+    assert rel.mean().item() <= 1.5 * ulp / 2, rel.mean().item()  # typical: of the order of a single rounding
+
+
 def test_a_collected_reducer_leaves_its_successors_sinks_alone():
     """rebinding `opt = FlatSGD(model)` creates the new reducer before the old one is collected; the old
     one's remove() / __del__ must only drop ITS OWN gradient-sink entries"""

@@ -79,8 +79,9 @@ def _layer_fixture(name, memory_format, hip_convs):
 @pytest.mark.parametrize("path", ["nchw", "nchw-hip-convs"])
 @pytest.mark.parametrize("name", REAL_LAYER_FIXTURES)
 def test_layer_matches_reference_fixture_at_the_real_stage_geometries(name, path):
-    """CoTNet-50's four stage geometries -- (64, 56), (128, 28), (256, 14), (512, 7), B = 2 -- against fixtures of the
-    reference's own CotLayer (tests/golden/make_golden.py REAL_LAYER_CASES), fp32, eval and train mode, BASELINE's 1e-3:
+    """CoTNet-50's four stage geometries -- (64, 56), (128, 28), (256, 14), (512, 7), B = 2 --, CoTNeXt's CoXtLayer at (96, 56),
+    (192, 28), (384, 14), (768, 7) and SE-CoTNetD-152-L's cotnet_hybrid.CoTLayer at (256, 20), (512, 10) against fixtures of the
+    reference's own layers (tests/golden/make_golden.py REAL_LAYER_CASES), fp32, eval and train mode, BASELINE's 1e-3:
     `nchw` = library aggregation / BatchNorm / radix tail around MIOpen convolutions, `nchw-hip-convs` = every convolution
     and the GroupNorm on the library's fp32 kernels as well (VERDICT r2 missing #5)."""
     from tests import truth
