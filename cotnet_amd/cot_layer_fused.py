@@ -1,4 +1,4 @@
-"""CotLayer.forward as ONE autograd node (COT_FUSED_LAYER=1; part of bench.py's `new` kernel set).
+"""CotLayer / CoXtLayer .forward -- and the Bottleneck around them -- as ONE autograd node (default on; COT_FUSED_LAYER=0 opts out).
 
 Why: at the reference's batch (80 / GPU) the round-1 CoTNet-50 step on MI355X was bound by the host, not the device
 (~3100 launches, ~38 ms of Python/dispatch per step against 36 ms of kernels).  One CotLayer is ~14 autograd
@@ -13,8 +13,9 @@ evaluates the same function (models/cotnet.py:79-104) by calling the library's k
               kernels (`accumulate`), not by separate add kernels.
 
 Same parameters, buffers (running statistics, num_batches_tracked) and state_dict as the module it is applied to;
-eligible in training mode for bf16 NCHW tensors with dim % 64 == 0 (every CoTNet stage); anything else takes the
-module's ordinary forward.  Verified against the unfused reference formula through the host-emulated kernels
+eligible in training mode for bf16 NCHW tensors with dim % 64 == 0 (every CoTNet stage; CoXtLayer -- CoTNeXt's grouped
+variant, models/cotnet.py:106-178 -- with dim % 32 == 0: its grouped 1x1 convolutions run on cot_conv1x1g_*, [x, k] is
+interleaved once and the group -> batch fold is a view); anything else takes the module's ordinary forward.  Verified against the unfused reference formula through the host-emulated kernels
 (tests/test_kernels_emulated.py) and on the GPU against an fp32 truth by tests/test_fused_layer_gpu.py; round 2 on the
 MI355X: ~1290 launches and 19.1 ms per step with every kernel from cotnet_amd/csrc.
 """
@@ -204,14 +205,19 @@ _SIZES = _lib.register_cache({})  # (N, C, H, W, A) -> (workspace bytes, bn work
 _MASKS = {}
 
 
-def _sizes(L, N, C, H, W, A, G):
-    k = (N, C, H, W, A, G)
+def _sizes(L, N, C, H, W, A, G, grouped=False):
+    k = (N, C, H, W, A, G, grouped)
     v = _SIZES.get(k)
     if v is None:
         HW = H * W
-        ws = max(int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_conv1x1_workspace(N, 2 * C, C // 2, HW, 0)),
-                 int(L.cot_conv1x1_workspace(N, C // 2, 9 * C // 8, HW, 1)), int(L.cot_conv1x1_workspace(N, C, C, HW, 0)),
-                 int(L.cot_conv1x1_workspace(1, C, A, N, 1)), int(L.cot_conv1x1_workspace(1, A, 2 * C, N, 1)))
+        if grouped:  # CoXtLayer: the three 1x1 convolutions of the layer are grouped (groups = 2): general kernels' workspace
+            ws = max(int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_convg_workspace(N, 2 * C, C // 2, 2, H, W, 1)),
+                     int(L.cot_convg_workspace(N, C // 2, 9 * C // 8, 2, H, W, 1)), int(L.cot_convg_workspace(N, C, C, 2, H, W, 1)),
+                     int(L.cot_conv1x1_workspace(1, C, A, N, 1)), int(L.cot_conv1x1_workspace(1, A, 2 * C, N, 1)))
+        else:
+            ws = max(int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_conv1x1_workspace(N, 2 * C, C // 2, HW, 0)),
+                     int(L.cot_conv1x1_workspace(N, C // 2, 9 * C // 8, HW, 1)), int(L.cot_conv1x1_workspace(N, C, C, HW, 0)),
+                     int(L.cot_conv1x1_workspace(1, C, A, N, 1)), int(L.cot_conv1x1_workspace(1, A, 2 * C, N, 1)))
         v = _SIZES[k] = (ws, int(L.cot_bn_act_workspace(N, C)), int(L.cot_bn_act_workspace(N, C // 2)),
                          int(L.cot_bn_act_workspace(1, A)))
     return v
@@ -230,10 +236,14 @@ def _masks(L, H, W, device):
 class _Plan:
     """per-layer handles resolved once (nn.Sequential indexing and parameter walks cost more than a kernel launch)"""
     __slots__ = ("ke0", "ke1", "em0", "em1", "em3", "gn", "cv0", "cv1", "bn", "se0", "sebn", "se3", "params",
-                 "static_ok")
+                 "static_ok", "grouped")
 
     def __init__(self, layer):
         ke, em, cv = layer.key_embed, layer.embed, layer.conv1x1
+        # CoXtLayer (models/cotnet.py:106-178): the 1x1 convolutions are grouped (dw_group = 2), the key embedding has 8
+        # groups, [x, k] is channel-INTERLEAVED and the two groups are folded into the batch for the aggregation
+        g1 = int(getattr(layer, "dw_group", 1))
+        self.grouped = g1 == 2
         self.ke0, self.ke1, self.em0, self.em1, self.em3, self.gn = ke[0], ke[1], em[0], em[1], em[3], em[4]
         se = layer.se
         self.cv0, self.cv1, self.bn, self.se0, self.sebn, self.se3 = cv[0], cv[1], layer.bn, se[0], se[1], se[3]
@@ -242,12 +252,13 @@ class _Plan:
                        layer.bn.bias, se[0].weight, se[0].bias, se[1].weight, se[1].bias, se[3].weight, se[3].bias]
         C = layer.dim
         self.static_ok = (
-            C % 64 == 0 and layer.kernel_size == 3 and isinstance(layer.act, nn.SiLU) and layer.radix == 2
-            and _conv_ok(ke[0], 3) and ke[0].bias is None and (C // ke[0].groups) % 8 == 0
-            and isinstance(ke[2], nn.ReLU) and _conv_ok(em[0], 1, 1) and em[0].bias is None
-            and isinstance(em[2], nn.ReLU) and _conv_ok(em[3], 1, 1) and em[3].bias is not None
+            g1 in (1, 2) and C % (16 * g1 if self.grouped else 64) == 0 and layer.kernel_size == 3
+            and isinstance(layer.act, nn.SiLU) and layer.radix == 2
+            and _conv_ok(ke[0], 3) and ke[0].bias is None and (self.grouped or (C // ke[0].groups) % 8 == 0)
+            and isinstance(ke[2], nn.ReLU) and _conv_ok(em[0], 1, g1) and em[0].bias is None
+            and isinstance(em[2], nn.ReLU) and _conv_ok(em[3], 1, g1) and em[3].bias is not None
             and isinstance(em[4], nn.GroupNorm) and em[4].num_groups * 9 == em[4].num_channels and em[4].affine
-            and _conv_ok(cv[0], 1, 1) and cv[0].bias is None
+            and _conv_ok(cv[0], 1, g1) and cv[0].bias is None
             and len(se) == 4 and _conv_ok(se[0], 1, 1) and se[0].bias is not None and isinstance(se[2], nn.ReLU)
             and _conv_ok(se[3], 1, 1) and se[3].bias is not None and se[0].out_channels % 8 == 0
             and se[3].out_channels == 2 * C
@@ -359,7 +370,8 @@ def _cot_forward(L, layer, x):
     dev = x.device
     pl = _plan(layer)
     A = pl.se0.out_channels
-    ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups)
+    GX = pl.grouped
+    ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups, GX)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     masks = _masks(L, H, W, dev)
     st = _stream()
@@ -374,13 +386,22 @@ def _cot_forward(L, layer, x):
     _bn_fwd(L, k_pre, k, pl.ke1, s_k, 2 * C, N, C, HW, 1)
     # attention logits from [x | k]                                                             (ref :81-85)
     e0, e1 = new(Ch), new(Ch)
-    _ck(L.cot_conv1x1_forward(_p(x), _p(k), C, _p(pl.em0.weight), None, _p(e0), N, 2 * C, Ch, HW, BF16, st),
-        "cot_conv1x1_forward")
+    qk = None
+    if GX:  # CoXtLayer: [x0, k0, x1, k1, ...] so that each of the two groups sees matching halves of x and k (ref :153-154)
+        qk = torch.stack([x, k], dim=2).view(N, 2 * C, H, W)
+        _ck(L.cot_conv1x1g_forward(_p(qk), _p(pl.em0.weight), None, _p(e0), N, 2 * C, Ch, 2, HW, BF16, st), "cot_conv1x1g_forward")
+    else:
+        _ck(L.cot_conv1x1_forward(_p(x), _p(k), C, _p(pl.em0.weight), None, _p(e0), N, 2 * C, Ch, HW, BF16, st),
+            "cot_conv1x1_forward")
     s_e = stat(Ch, nws_h)
     _bn_fwd(L, e0, e1, pl.em1, s_e, 2 * Ch, N, Ch, HW, 1)
     e3 = new(Ce)
-    _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, HW, BF16, st),
-        "cot_conv1x1_forward")
+    if GX:
+        _ck(L.cot_conv1x1g_forward(_p(e1), _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, 2, HW, BF16, st),
+            "cot_conv1x1g_forward")
+    else:
+        _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, HW, BF16, st),
+            "cot_conv1x1_forward")
     gn = pl.gn
     if HW <= 8192:  # one (image, group) fits a workgroup's registers: 1 read + 1 write (csrc/group_norm9.hip)
         w = new(Ce)
@@ -392,12 +413,17 @@ def _cot_forward(L, layer, x):
         w, gn_mean, gn_rstd = torch.native_group_norm(e3, gn.weight, gn.bias, N, Ce, HW, gn.num_groups, gn.eps)
     # values                                                                                     (ref :87)
     v_pre, v = new(C), new(C)
-    _ck(L.cot_conv1x1_forward(_p(x), None, C, _p(pl.cv0.weight), None, _p(v_pre), N, C, C, HW, BF16, st),
-        "cot_conv1x1_forward")
+    if GX:
+        _ck(L.cot_conv1x1g_forward(_p(x), _p(pl.cv0.weight), None, _p(v_pre), N, C, C, 2, HW, BF16, st), "cot_conv1x1g_forward")
+    else:
+        _ck(L.cot_conv1x1_forward(_p(x), None, C, _p(pl.cv0.weight), None, _p(v_pre), N, C, C, HW, BF16, st),
+            "cot_conv1x1_forward")
     s_v = stat(C, nws_c)
     _bn_fwd(L, v_pre, v, pl.cv1, s_v, 2 * C, N, C, HW, 0)
     # local aggregation, bn + swish                                                              (ref :88-90)
-    geom = _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
+    # (CoXtLayer folds its two groups into the batch: [N, C] -> [2N, C/2], weights [2N, 1, C/16, 9]: views of the same memory)
+    geom = _lib.AggGeom(2 * N, C // 2, H, W, 1, C // 16, 3, 3, 1, 1, 1, 1, 1, 1) if GX else \
+        _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
     a, y = new(C), new(C)
     _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
     s_y = stat(C, nws_c)
@@ -420,23 +446,24 @@ def _cot_forward(L, layer, x):
         "cot_radix_mix_logits")
 
     return out, (x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y, gapT, hpre, h,
-                 s_a), geom
+                 s_a, qk), geom
 
 
-_N_SAVED = 22  # tensors _cot_forward hands back for the backward pass
+_N_SAVED = 23  # tensors _cot_forward hands back for the backward pass (the last one, qk, is None for a CotLayer)
 
 
 def _cot_backward(L, layer, saved, geom, gout, side=None):
     """-> (dx, gradients of _Plan.params in that order).  `side`: the caller's side stream for the weight gradients (a
     Bottleneck node passes its own and joins it itself); None = this call opens and joins one."""
     (x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y, gapT, hpre, h,
-     s_a) = saved
+     s_a, qk) = saved
     N, C, H, W = x.shape
     HW, Ch, Ce = H * W, C // 2, 9 * C // 8
     dev = x.device
     pl = _plan(layer)
     A = pl.se0.out_channels
-    ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups)
+    GX = pl.grouped
+    ws_bytes, nws_c, nws_h, nws_a = _sizes(L, N, C, H, W, A, pl.ke0.groups, GX)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     masks = _masks(L, H, W, dev)
     st = _stream()
@@ -475,10 +502,14 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     gv_pre = ga  # (reuse: ga is dead)
     d_cv_w, d_cv_b = _bn_bwd(L, gv, v_pre, None, gv_pre, cv1, s_v, N, C, HW, 0, nws_c)
     gx = torch.empty_like(x)
-    _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gx), None, C, 0, _p(ws), N, C, C, HW, BF16, st),
-        "cot_conv1x1_backward_data")
     g_wv = grad_sink.out_like(cv0.weight)
-    side.run(lambda st_, a_=(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(side.ws), N, C, C, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), gv_pre, x)
+    if GX:
+        _ck(L.cot_conv1x1g_backward_data(_p(gv_pre), _p(cv0.weight), _p(gx), 0, N, C, C, 2, HW, BF16, st), "cot_conv1x1g_backward_data")
+        side.run(lambda st_, a_=(_p(gv_pre), _p(x), _p(g_wv), None, _p(side.ws), N, C, C, 2, HW, BF16): _ck(L.cot_conv1x1g_backward_weight(*a_, st_), "cot_conv1x1g_backward_weight"), gv_pre, x)
+    else:
+        _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gx), None, C, 0, _p(ws), N, C, C, HW, BF16, st),
+            "cot_conv1x1_backward_data")
+        side.run(lambda st_, a_=(_p(gv_pre), _p(x), None, C, _p(g_wv), None, _p(side.ws), N, C, C, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), gv_pre, x)
     # logits branch: GroupNorm, conv1x1(+bias), bn+relu, conv1x1 on [x | k] -> dx +=, dk +=
     gn = pl.gn
     if HW <= 8192:
@@ -491,16 +522,28 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
             gw, e3, gn_mean, gn_rstd, gn.weight, N, Ce, HW, gn.num_groups, [True, True, True])
         ge3 = ge3.contiguous()
     ge1 = torch.empty_like(e1)
-    _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), N, Ch, Ce, HW, BF16,
-                                    st), "cot_conv1x1_backward_data")
     g_we3, g_be3 = grad_sink.out_like(em3.weight), grad_sink.out_like(em3.bias)
-    side.run(lambda st_, a_=(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(side.ws), N, Ch, Ce, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge3, e1)
+    if GX:
+        _ck(L.cot_conv1x1g_backward_data(_p(ge3), _p(em3.weight), _p(ge1), 0, N, Ch, Ce, 2, HW, BF16, st), "cot_conv1x1g_backward_data")
+        side.run(lambda st_, a_=(_p(ge3), _p(e1), _p(g_we3), _p(g_be3), _p(side.ws), N, Ch, Ce, 2, HW, BF16): _ck(L.cot_conv1x1g_backward_weight(*a_, st_), "cot_conv1x1g_backward_weight"), ge3, e1)
+    else:
+        _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), N, Ch, Ce, HW, BF16,
+                                        st), "cot_conv1x1_backward_data")
+        side.run(lambda st_, a_=(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(side.ws), N, Ch, Ce, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge3, e1)
     ge0 = torch.empty_like(e0)
     d_em_w, d_em_b = _bn_bwd(L, ge1, e0, None, ge0, em1, s_e, N, Ch, HW, 1, nws_h)  # (ReLU mask recomputed from e0)
-    _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gx), _p(gk), C, 3, _p(ws), N, 2 * C, Ch, HW, BF16,
-                                    st), "cot_conv1x1_backward_data")
     g_we0 = grad_sink.out_like(em0.weight)
-    side.run(lambda st_, a_=(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(side.ws), N, 2 * C, Ch, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge0, x, k)
+    if GX:  # gradient of the interleaved [x0, k0, x1, k1, ...]: de-interleaved into dx / dk (two strided adds)
+        gqk = torch.empty_like(qk)
+        _ck(L.cot_conv1x1g_backward_data(_p(ge0), _p(em0.weight), _p(gqk), 0, N, 2 * C, Ch, 2, HW, BF16, st), "cot_conv1x1g_backward_data")
+        gq5 = gqk.view(N, C, 2, H, W)
+        gx.add_(gq5[:, :, 0])
+        gk.add_(gq5[:, :, 1])
+        side.run(lambda st_, a_=(_p(ge0), _p(qk), _p(g_we0), None, _p(side.ws), N, 2 * C, Ch, 2, HW, BF16): _ck(L.cot_conv1x1g_backward_weight(*a_, st_), "cot_conv1x1g_backward_weight"), ge0, qk)
+    else:
+        _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gx), _p(gk), C, 3, _p(ws), N, 2 * C, Ch, HW, BF16,
+                                        st), "cot_conv1x1_backward_data")
+        side.run(lambda st_, a_=(_p(ge0), _p(x), _p(k), C, _p(g_we0), None, _p(side.ws), N, 2 * C, Ch, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge0, x, k)
     # key branch: bn+relu, grouped 3x3 -> dx +=
     gk_pre = gv  # (reuse: gv is dead)
     d_ke_w, d_ke_b = _bn_bwd(L, gk, k_pre, None, gk_pre, ke1, s_k, N, C, HW, 1, nws_c)
@@ -571,7 +614,7 @@ class _BlockPlan:
     __slots__ = ("conv1", "bn1", "cot", "conv3", "bn3", "ds_conv", "ds_bn", "ds_stride", "avd", "params", "static_ok")
 
     def __init__(self, blk):
-        from .cotnet import CotLayer
+        from .cotnet import CotLayer, CoXtLayer
         self.conv1, self.bn1, self.cot, self.conv3, self.bn3 = blk.conv1, blk.bn1, blk.conv2, blk.conv3, blk.bn3
         ds = blk.downsample
         self.ds_conv = self.ds_bn = None
@@ -589,7 +632,7 @@ class _BlockPlan:
             ds_ok = (isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.padding == (0, 0) and c.groups == 1
                      and c.stride == (self.ds_stride, self.ds_stride) and c.bias is None and _bn_static_ok(ds[-1]))
         self.static_ok = (
-            ds_ok and avd_ok and isinstance(blk.conv2, CotLayer) and blk.drop_block is None
+            ds_ok and avd_ok and isinstance(blk.conv2, (CotLayer, CoXtLayer)) and blk.drop_block is None
             and (blk.drop_path is None or hasattr(blk.drop_path, "drop_prob")) and blk.se is None
             and isinstance(blk.act1, nn.ReLU)
             and isinstance(blk.act3, nn.ReLU) and _conv_ok(blk.conv1, 1, 1) and blk.conv1.bias is None
@@ -692,7 +735,8 @@ class _BottleneckNode(Function):
         ws = torch.empty(max(ws_a, ws_b), dtype=torch.uint8, device=dev)
         cN, cC, cH, cW = saved[0].shape
         cpl = _plan(bp.cot)
-        side = _Side(dev, max(ws_a, ws_b, _sizes(L, cN, cC, cH, cW, cpl.se0.out_channels, cpl.ke0.groups)[0]), ws, bp.params)
+        side = _Side(dev, max(ws_a, ws_b, _sizes(L, cN, cC, cH, cW, cpl.se0.out_channels, cpl.ke0.groups, cpl.grouped)[0]), ws,
+                     bp.params)
         gout = gout.contiguous()
         # bn3 + residual + relu: dx of the normalisation and the residual's gradient in one pass
         g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)

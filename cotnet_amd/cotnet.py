@@ -168,6 +168,8 @@ class CoXtLayer(nn.Module):
             nn.Conv2d(attn_chs, self.radix * dim, 1))
 
     def forward(self, x):
+        if cot_layer_fused.ENABLED and cot_layer_fused.eligible(self, x):
+            return cot_layer_fused.cot_layer_forward(self, x)  # the whole layer as one autograd node
         batch_size, channels, height, width = x.size()
         k = fused_bn_act(conv3x3(self.key_embed[0], x), self.key_embed[1], "relu")
         # channel-interleave [x0,k0,x1,k1,...] so each of the 2 conv groups sees matching x/k halves (ref :153-154)

@@ -12,6 +12,11 @@ case $what in
   aggab2) timeout 600 python scripts/bench_agg_abi.py --dtypes bf16 --shapes 0,1,2 --rounds 3 --variants lds,dot2,d2_jp2_nw4_s1,d2_jp2_nw7_s1,d2_jp4_nw7_s1,d2_jp2_nw7_s0,d2_jp2_nw7_s1_xcd,d2_jp2_nw4_s1_xcd > $O/${T}_aggab2.log 2>&1 ;;
   aggab3) timeout 600 python scripts/bench_agg_abi.py --dtypes bf16 --shapes 0,1,2 --rounds 3 --variants lds,d2_jp2_nw4_s1,d2_jp8_nw4_s1,d2_jp8_nw4_s0,d2_jp8_nw2_s1,d2_jp8_nw4_s1_xcd,d2_jp4_nw4_s1 > $O/${T}_aggab3.log 2>&1 ;;
   aggab4) timeout 600 python scripts/bench_agg_abi.py --dtypes bf16 --shapes 0,1,2 --rounds 3 --variants lds,d2_jp2_nw4_s1_sb,d2_jp2_nw4_s1,d2_jp4_nw4_s1,d2_jp2_nw2_s1,d2_jp4_nw2_s1,d2_jp2_nw4_s0,d2_jp2_nw4_s1_xcd,d2_jp2_nw7_s1 > $O/${T}_aggab4.log 2>&1 ;;
+  coxt) timeout 900 python -m pytest tests/test_fused_layer_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 2>&1 | tail -25 > $O/${T}_coxt_tests.log
+        COT_KERNEL_SUMMARY=$O/${T}_cotnext101_kernels.json timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > $O/${T}_bench_cotnext101.json 2> $O/${T}_bench_cotnext101.err
+        timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > $O/${T}_bench_cotnext101_b.json 2>> $O/${T}_bench_cotnext101.err
+        COT_FUSED_LAYER=0 timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --conv1x1 hip --conv3x3 hip --gn9 > $O/${T}_bench_cotnext101_nodeperop.json 2>> $O/${T}_bench_cotnext101.err
+        COT_KERNEL_SUMMARY=$O/${T}_secotnetd_kernels.json timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline > $O/${T}_bench_secotnetd.json 2> $O/${T}_bench_secotnetd.err ;;
   aggparity) timeout 600 python -m pytest tests/test_dispatch_parity_gpu.py tests/test_agg_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "agg or Agg or oracle or n80 or N80" 2>&1 | tail -30 > $O/${T}_aggparity.log ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac

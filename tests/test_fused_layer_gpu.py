@@ -15,10 +15,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("N,C,H", [(8, 64, 56), (8, 128, 28), (8, 256, 14), (8, 512, 7)])
-def test_single_node_layer_against_fp32_truth(N, C, H):
+@pytest.mark.parametrize("cls,N,C,H", [("CotLayer", 8, 64, 56), ("CotLayer", 8, 128, 28), ("CotLayer", 8, 256, 14), ("CotLayer", 8, 512, 7),
+                                       # CoTNeXt's layer at its four real widths (cotnext*_2x48d: 96 / 192 / 384 / 768)
+                                       ("CoXtLayer", 8, 96, 56), ("CoXtLayer", 8, 192, 28), ("CoXtLayer", 8, 384, 14),
+                                       ("CoXtLayer", 8, 768, 7)])
+def test_single_node_layer_against_fp32_truth(cls, N, C, H):
+    from cotnet_amd import cotnet as cn
     torch.manual_seed(C)
-    layer = CotLayer(C, 3).to(DEV).train()
+    layer = getattr(cn, cls)(C, 3).to(DEV).train()
     with torch.no_grad():
         for p in layer.parameters():
             if p.ndim == 1:
@@ -76,15 +80,19 @@ def test_bottleneck_trains_with_the_single_node_layer():
     assert all(torch.isfinite(p.float()).all() for p in blk.parameters())
 
 
-@pytest.mark.parametrize("kind", ["identity", "project", "stride2"])
+@pytest.mark.parametrize("kind", ["identity", "project", "stride2", "coxt-identity", "coxt-project", "coxt-stride2"])
 def test_single_node_bottleneck_against_fp32_truth(kind):
-    """the whole Bottleneck as one node (identity shortcut / 1x1 projection / stride-2 block with avd pooling)"""
+    """the whole Bottleneck as one node (identity shortcut / 1x1 projection / stride-2 block with avd pooling); coxt-* = CoTNeXt's
+    block (cardinality 2, base width 48: a CoXtLayer of width 96 inside)"""
     from cotnet_amd.resnet import downsample_conv
     torch.manual_seed(7)
+    coxt = kind.startswith("coxt-")
+    kind = kind[5:] if coxt else kind
     stride = 2 if kind == "stride2" else 1
     inpl = 256 if kind == "identity" else 128
     ds = None if kind == "identity" else downsample_conv(inpl, 256, 1, stride=stride)
-    blk = Bottleneck(inpl, 64, stride=stride, downsample=ds).to(DEV).train()
+    blk = Bottleneck(inpl, 64, stride=stride, downsample=ds, **(dict(cardinality=2, base_width=48) if coxt else {})).to(DEV).train()
+    assert type(blk.conv2).__name__ == ("CoXtLayer" if coxt else "CotLayer")
     with torch.no_grad():
         blk.bn3.weight.fill_(0.8)
     blk = to_mixed_bf16(blk)
