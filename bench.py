@@ -19,6 +19,9 @@ line is marked `"baseline_only": true` and its metric says so.  `auto` = the rou
 status 3 instead of printing a MIOpen-backed headline.
 
 Extra objects on the line:
+  secondary     default run only (N = 1, CoTNet-50 B = 80): BASELINE configs 4 (CoTNeXt-101, B = 64) and 5 (SE-CoTNetD-152 320^2,
+                B = 64) and config 3 at the reference's fp32 precision, each measured by a short child run of this script on the
+                same GPU with the same kernel set and timing protocol (8 timed steps); `--no-secondary` skips them.
   roofline      the dominant aggregation kernel of the timed region (largest total device time): algorithmic bytes
                 per launch / mean launch duration.  Durations come from HIP start/stop events attached to each kernel
                 dispatch on its launch stream (hipExtLaunchKernelGGL inside libcotnet_hip.so, cot_profile_begin/_end),
@@ -69,6 +72,9 @@ def parse():
                          "on a fresh box and the default kernel set has no MIOpen call to tune")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` object of the default line (BASELINE configs 4 / 5 and the reference's fp32 precision "
+                         "measured by short child runs of this script on the same GPU)")
     ap.add_argument("--bucket-mb", type=float, default=10.0, help="flat gradient bucket size (MiB): the all-reduce granularity")
     ap.add_argument("--conv1x1", default=None, choices=["module", "hip", "matmul"],
                     help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
@@ -466,6 +472,43 @@ def choose_kernels(args):
         return "round1", info
 
 
+SECONDARY = [  # (key, what, extra arguments): BASELINE.json configs 4 and 5 on one GPU, and config 3 at the reference's own precision
+    ("cotnext101_2x48d_b64_224", "BASELINE config 4 on one GPU: CoTNeXt-101 2x48d 224^2, B = 64 (reference recipe batch), fwd+bwd+SGD",
+     ["--model", "cotnext101_2x48d", "--batch", "64"]),
+    ("se_cotnetd_152_L_b64_320", "BASELINE config 5 on one GPU: SE-CoTNetD-152 320^2, B = 64, fwd+bwd+SGD",
+     ["--model", "se_cotnetd_152_L", "--img", "320", "--batch", "64"]),
+    ("cotnet50_b80_224_fp32", "BASELINE config 3 at the reference's own precision (amp: False): CoTNet-50 224^2 fp32, B = 80",
+     ["--dtype", "fp32", "--batch", "80"]),
+]
+
+
+def secondary_lines(timeout_s=170):
+    """-> {key: {...}}: short runs (8 timed steps) of the other BASELINE configurations as child processes of this script on the
+    same GPU, same kernel set (`new`, no fallback), same timing protocol; a failure is recorded, never hidden, and never
+    touches the headline (which is complete before the first child starts)."""
+    import subprocess
+    out = {}
+    for key, what, extra in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "8", "--warmup", "3", "--settle-seconds", "8",
+               "--no-cpu-baseline", "--no-kernel-timing", "--no-secondary", "--kernels", "new"] + extra
+        t0 = time.perf_counter()
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "COT_KERNEL_SUMMARY")}
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+            line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+            if r.returncode != 0 or line is None:
+                out[key] = {"what": what, "error": f"exit {r.returncode}: {r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else 'no output'}"}
+                continue
+            d = json.loads(line)
+            out[key] = {"what": what, "metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                        "steps": d["steps"], "dtype": d["dtype"], "per_gpu_batch": d["config"]["per_gpu_batch"],
+                        "cot_layer_single_node": d["config"]["cot_layer_single_node"], "kernel_selection": d["config"]["kernel_selection"],
+                        "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:  # (timeout, JSON trouble: recorded)
+            out[key] = {"what": what, "error": repr(e)[:300]}
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-execute this command line under torch.distributed.run, one rank
     per GPU on 127.0.0.1 (the driver's own launch line).  Returns the launcher's exit code."""
@@ -792,6 +835,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        default_cfg = (args.model == "cotnet50" and args.img == 224 and args.batch == 80 and args.mode == "train" and mixed
+                       and not explicit and not args.tune and not args.recipe)
+        if world == 1 and default_cfg and not args.no_secondary:
+            torch.cuda.empty_cache()  # (the children run on this GPU while this process is idle)
+            line["secondary"] = secondary_lines()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -605,7 +605,8 @@ def cot_layer_forward(layer, x):
     return _CotLayerNode.apply(layer, x, *_plan(layer).params)
 
 
-# ---- the whole Bottleneck (models/cotnet.py:228-264) as one node: conv1 -> bn1+relu [-> 3x3/2 average pooling "avd"] ->
+# ---- the whole Bottleneck (models/cotnet.py:228-264; models/cotnet_hybrid.py:172-202 for SE-CoTNetD's CoT blocks, the same
+# sequence) as one node: conv1 -> bn1+relu [-> 3x3/2 average pooling "avd"] ->
 # CotLayer -> conv3 -> bn3 + residual + relu.  The residual branch may carry the stage's 1x1 projection (`downsample` =
 # [Identity,] conv1x1, BatchNorm); in a stride-2 block that projection has stride 2 = the stride-1 convolution on every
 # second pixel.  dx collects the residual gradient, the projection's and conv1's data gradients inside the kernels
@@ -621,9 +622,10 @@ class _BlockPlan:
         self.ds_stride = 1
         avd = blk.avd
         self.avd = avd is not None
+        # (cotnet_hybrid.CoTBottleneck pools AFTER the layer when avd_first is False, SE-CoTNetD-152's BlurPool: not this node)
         avd_ok = avd is None or (isinstance(avd, nn.AvgPool2d) and avd.kernel_size == 3 and avd.stride == 2
                                  and avd.padding == 1 and not avd.ceil_mode and avd.count_include_pad
-                                 and avd.divisor_override is None)
+                                 and avd.divisor_override is None and getattr(blk, "avd_first", True))
         ds_ok = ds is None and avd is None
         if isinstance(ds, nn.Sequential) and (len(ds) == 2 or (len(ds) == 3 and isinstance(ds[0], nn.Identity))):
             self.ds_conv, self.ds_bn = ds[-2], ds[-1]  # models/resnet.py:364-394: [pool,] conv, norm
@@ -633,7 +635,7 @@ class _BlockPlan:
                      and c.stride == (self.ds_stride, self.ds_stride) and c.bias is None and _bn_static_ok(ds[-1]))
         self.static_ok = (
             ds_ok and avd_ok and isinstance(blk.conv2, (CotLayer, CoXtLayer)) and blk.drop_block is None
-            and (blk.drop_path is None or hasattr(blk.drop_path, "drop_prob")) and blk.se is None
+            and (blk.drop_path is None or hasattr(blk.drop_path, "drop_prob")) and getattr(blk, "se", None) is None
             and isinstance(blk.act1, nn.ReLU)
             and isinstance(blk.act3, nn.ReLU) and _conv_ok(blk.conv1, 1, 1) and blk.conv1.bias is None
             and _conv_ok(blk.conv3, 1, 1) and blk.conv3.bias is None and _bn_static_ok(blk.bn1)

@@ -11,6 +11,7 @@ import math
 import torch.nn.functional as F
 from torch import nn
 
+from . import cot_layer_fused
 from .conv1x1 import conv1x1, run_downsample
 from .cotnet import CotLayer, _cfg
 from .fused_bn import fused_bn_act
@@ -84,6 +85,8 @@ class CoTBottleneck(nn.Module):
         nn.init.zeros_(self.bn3.weight)
 
     def forward(self, x):
+        if cot_layer_fused.ENABLED and isinstance(self.conv2, CotLayer) and cot_layer_fused.block_eligible(self, x):
+            return cot_layer_fused.block_forward(self, x)  # CoT block (identity shortcut / AvgPool-first stride) as one autograd node
         residual = x
         if self.drop_block is None:
             x = fused_bn_act(conv1x1(self.conv1, x), self.bn1, "relu")  # act1 is hard-wired ReLU (ref :124)

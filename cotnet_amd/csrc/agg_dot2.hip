@@ -114,6 +114,8 @@ __device__ __forceinline__ void dot2_stage(const bf16_t* __restrict__ gout, cons
 // whole compute phase ago, and the previous phase's gX stores -- vmcnt counts both, and stores retire out of order with
 // loads, so a counted wait cannot single the copies out), ONE barrier (everybody's chunks visible AND everybody done
 // with the buffer about to be refilled), issue the next copies, compute.
+// (Holding the allocation to 96 VGPRs -- five waves per SIMD instead of four -- spills 11 values into the channel loop: 56.7 us
+// against 34.7 at 56 x 56, profiles/r04_agg_dot2_in_model_tuning.log.  Not built.)
 template <int W, int P, int GS, int JP, int NW, int SAFE, int ROLL, int DB>
 __global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ x,
                                                                const bf16_t* __restrict__ w, bf16_t* __restrict__ gx,
@@ -345,9 +347,10 @@ static int launch_dot2_nw(const bf16_t* gout, const bf16_t* x, const bf16_t* w, 
 #define COT_DOT2_GO(SAFE_, DB_)                                                                                                \
     COT_LAUNCH((agg_bwd_nchw_k3_dot2<W, P, GS, JP, NW, SAFE_, ROLL, DB_>), grid, block, lds, s, gout, x, w, gx, gw, g.C, g.wC, g.H, \
                tiles, ne, xcd)
-    if (safe && db) COT_DOT2_GO(1, (JP < 8 ? 1 : 0));
+    constexpr int DBV = JP < 8 ? 1 : 0;
+    if (safe && db) COT_DOT2_GO(1, DBV);
     else if (safe) COT_DOT2_GO(1, 0);
-    else if (db) COT_DOT2_GO(0, (JP < 8 ? 1 : 0));
+    else if (db) COT_DOT2_GO(0, DBV);
     else COT_DOT2_GO(0, 0);
 #undef COT_DOT2_GO
     return check_launch("agg_bwd_nchw_k3_dot2");

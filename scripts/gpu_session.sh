@@ -17,6 +17,11 @@ case $what in
         timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > $O/${T}_bench_cotnext101_b.json 2>> $O/${T}_bench_cotnext101.err
         COT_FUSED_LAYER=0 timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --conv1x1 hip --conv3x3 hip --gn9 > $O/${T}_bench_cotnext101_nodeperop.json 2>> $O/${T}_bench_cotnext101.err
         COT_KERNEL_SUMMARY=$O/${T}_secotnetd_kernels.json timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline > $O/${T}_bench_secotnetd.json 2> $O/${T}_bench_secotnetd.err ;;
+  diagcoxt) timeout 300 python scripts/diag_coxt_fixture.py > $O/${T}_diag_coxt.log 2>&1 ;;
+  bench_sec) timeout 900 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
+  secotnetd) timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/${T}_bench_secotnetd.json 2> $O/${T}_bench_secotnetd.err
+             timeout 300 python -m pytest tests/test_se_gate_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "se_cotnetd or hybrid or model" 2>&1 | tail -8 > $O/${T}_secotnetd_tests.log ;;
+  tunes) for tn in "35=4" "35=5" "35=4" "35=5"; do timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 5 --tune $tn 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); r=l['roofline']; print('$tn', l['value'], l['ms_per_step'], r['kernel'], r['avg_us'], r['frac'], [ (k['shape'],k['avg_us']) for k in r['kernels'] if 'bwd' in k['kernel']])" >> $O/${T}_tunes.log 2>&1; done ;;
   aggparity) timeout 600 python -m pytest tests/test_dispatch_parity_gpu.py tests/test_agg_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "agg or Agg or oracle or n80 or N80" 2>&1 | tail -30 > $O/${T}_aggparity.log ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac
