@@ -78,8 +78,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
         if (FLAT) {
             const int img = q / cpi, c = q - img * cpi;
             const int nrel = min(n0 + img, a.N - 1) - n0;  // images past the batch: in-bounds bytes, never stored
-            xvA[ps] = (unsigned)(nrel * a.k1 * HW + c * 8) * 2u;
-            xvB[ps] = (unsigned)(nrel * KB * HW + c * 8) * 2u;
+            xvA[ps] = (unsigned)((int64_t)nrel * a.xs1 + c * 8) * 2u;
+            xvB[ps] = (unsigned)((int64_t)nrel * a.xs2 + c * 8) * 2u;
         } else {
             constexpr int cpr = BPX / 8;  // chunks per row
             const int row = q / cpr, c = q - row * cpr;
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             xvA[ps] = xvB[ps] = (unsigned)(row * HW + pc) * 2u;
         }
     }
-    const bf16_t* const xbaseA = a.x1 + (int64_t)n0 * a.k1 * HW;
-    const bf16_t* const xbaseB = a.x2 ? a.x2 + (int64_t)n0 * KB * HW : a.x1;
+    const bf16_t* const xbaseA = a.x1 + (int64_t)n0 * a.xs1;
+    const bf16_t* const xbaseB = a.x2 ? a.x2 + (int64_t)n0 * a.xs2 : a.x1;
     unsigned wv[WPASS];
 #pragma unroll
     for (int ps = 0; ps < WPASS; ++ps) {
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
 
     EpiArgs e;
     e.y1 = a.y1; e.y2 = a.y2; e.bias = a.bias; e.m1 = a.m1; e.M = M; e.HW = HW; e.N = a.N; e.ni = a.ni;
+    e.ys1 = a.ys1; e.ys2 = a.ys2;
     e.n0 = n0; e.p0 = p0; e.m0 = m0; e.mv = min(BM, M - m0); e.ncols = ncols; e.accumulate = a.accumulate;
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
@@ -298,7 +299,7 @@ int conv1x1_lds_gemm2(const C1LdsArgs& a0, hipStream_t stream) {
     a.ablate = g_conv_ablate;
     const int N = a.N, M = a.M, HW = a.HW;
     // per-lane offsets are 32-bit: a workgroup's images / the weight rows must lie within 2 GB of the scalar bases
-    const int64_t slab = (int64_t)std::max(a.k1, a.K - a.k1) * HW * 2;
+    const int64_t slab = std::max(a.xs1, a.xs2) * 2;  // bytes from one image to the next
     if ((HW <= 256 ? slab * (256 / HW + 1) : slab) >= ((int64_t)1 << 31) || (int64_t)M * a.K * 2 >= ((int64_t)1 << 31)) return -1;
     const bool wt = a.wpacked == 2;
     const bool pf_flat = !((g_conv_lds2_tune >> 1) & 1), pf_big = (g_conv_lds2_tune >> 2) & 1;

@@ -122,6 +122,8 @@ struct EpiArgs {
     int n0, p0, m0;      // first image, first pixel (BIG), first channel of the tile
     int mv, ncols;       // valid channels / columns of the tile
     int accumulate;      // bit 0: y1 += result, bit 1: y2 += result
+    int64_t ys1, ys2;    // elements from one image to the next in y1 / y2 (dense: m1 * HW, (M - m1) * HW; larger when the slab is
+                         // a channel range of a wider tensor: one group of a grouped convolution)
 };
 
 template <int CB, int MB, int FLAT, int WAVES>
@@ -174,7 +176,9 @@ __device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], cons
             if (c * 8 >= ncols) continue;
             const int m = m0 + row;
             const bool second = m >= a.m1;
-            bf16_t* dst = (second ? a.y2 + ((int64_t)n0 * (M - a.m1) + (m - a.m1)) * HW : a.y1 + ((int64_t)n0 * a.m1 + m) * HW) + p0 + c * 8;
+            // (written as one offset behind a selected base: the two-armed pointer expression crashed the compiler's simplifycfg)
+            const int64_t ioff = (int64_t)n0 * (second ? a.ys2 : a.ys1) + (int64_t)(second ? m - a.m1 : m) * HW + p0 + c * 8;
+            bf16_t* dst = (second ? a.y2 : a.y1) + ioff;
             Vec<bf16_t, 8> v = *reinterpret_cast<const Vec<bf16_t, 8>*>(ot + row * OS + c * 8);
             if ((a.accumulate >> (second ? 1 : 0)) & 1) {
                 const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(dst);
@@ -190,8 +194,8 @@ __device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], cons
             const int e0 = c * 8;                 // first element of the piece inside the block
             const int m = m0 + e0 / HW;           // its channel decides the slab (pieces do not straddle m1)
             const bool second = m >= a.m1;
-            bf16_t* blk = second ? a.y2 + ((int64_t)(n0 + img) * (M - a.m1) + (m0 - a.m1)) * HW
-                                 : a.y1 + ((int64_t)(n0 + img) * a.m1 + m0) * HW;
+            const int64_t boff = (int64_t)(n0 + img) * (second ? a.ys2 : a.ys1) + (int64_t)(second ? m0 - a.m1 : m0) * HW;
+            bf16_t* blk = (second ? a.y2 : a.y1) + boff;
             const bool accu = (a.accumulate >> (second ? 1 : 0)) & 1;
             const bf16_t* src = ot + img * pers + e0;
             if (e0 + 8 <= per) {
@@ -217,6 +221,8 @@ struct C1LdsArgs {
     bf16_t* y1;
     bf16_t* y2;        // second channel slab of the output (NULL: m1 == M)
     int k1, m1, N, K, M, HW;
+    int64_t xs1, xs2;  // elements from one image to the next in x1 / x2 (dense: k1 * HW, (K - k1) * HW), and in
+    int64_t ys1, ys2;  // y1 / y2 (dense: m1 * HW, (M - m1) * HW): a slab may be a channel range of a wider tensor
     int accumulate;    // bit 0: y1 += result, bit 1: y2 += result
     int wpacked;
     int mblocks;       // output-channel blocks of BM

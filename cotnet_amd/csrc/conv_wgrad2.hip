@@ -62,6 +62,7 @@ struct Wg2Args {
     // grouped 3x3 weight gradient (TAPS kernels): per group, M = Cout / G rows of dY against J = 9 Kc "virtual rows" of X, row
     // (tap, ci) = X's channel ci read at pixel + off(tap); gw is [Cout][Kc][3][3]
     int G, Kc, cy, cx, W;          // groups, input channels per group, channels per image of dY / X, image width
+    int sy, sx;                    // 1x1 form: channels per image of dY / x1 when they are channel ranges of wider tensors (0: dense)
     const uint16_t* masks;         // conv3x3g_masks table: bit t of masks[p] = pixel p has an in-image neighbour for tap t
     unsigned long long* stamps;  // DIAGNOSTIC (cot_debug_stamps): per workgroup 6 x s_memtime (start, set up, first data, loop done,
                                  // stores issued, end) + the XCC id; NULL in production
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? (WAVES > 8 ? 4 : 3) :
                 r0 = min(rr, M - 1);
                 r = min(rr + rowl, M - 1);  // rows past the matrix: copies of the last row, never stored
                 base = a.gy + (int64_t)(TAPS ? grp * M + r0 : r0) * HW;
-                stride = (int64_t)(TAPS ? a.cy : M) * HW;
+                stride = (int64_t)(TAPS ? a.cy : (a.sy ? a.sy : M)) * HW;
             } else if (TAPS) {
                 const int rr = j0 + (rb - RBM) * 16;
                 r0 = min(rr, J - 1) & ~15;            // (Kc % 16 == 0: a block is 16 channels of one tap)
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64 * (WAVES + LW), PF ? (LW ? (WAVES > 8 ? 4 : 3) :
                 r = min(rr + rowl, J - 1);  // (the bias column's "row" J is made of ones at fragment level)
                 const bool second = a.x2 && r0 >= a.k1;  // k1 % 16 == 0 (host): a block lies in one slab
                 base = second ? a.x2 + (int64_t)(r0 - a.k1) * HW : a.x1 + (int64_t)r0 * HW;
-                stride = (int64_t)(second ? J - a.k1 : (a.x2 ? a.k1 : J)) * HW;
+                stride = (int64_t)(second ? J - a.k1 : (a.x2 ? a.k1 : (a.sx ? a.sx : J))) * HW;
             }
             sp[i] = reinterpret_cast<const char*>(base + n_first * stride) + (s_s * SB - bias);
             wrapb[i] = (int)(stride * 2) - (spi - 1) * SB;  // (2 * stride < 2^31: checked on the host)
@@ -627,10 +628,14 @@ static int launch_wg2(const Wg2Args& a, int64_t blocks, hipStream_t stream) {
 }
 
 // returns COT_OK, an error, or -1 when not covered (the caller then takes the second-generation kernels)
+// sy / sx (channels; 0 = dense): dY / x1 are channel ranges of tensors with that many channels per image (one group of a grouped
+// convolution; single-slab calls only)
 int conv1x1_wgrad2_run(const void* gy, const void* x1, const void* x2, int k1, void* gw, void* gb, float* workspace, int N,
-                       int J, int M, int HW, hipStream_t stream) {
+                       int J, int M, int HW, hipStream_t stream, int sy, int sx) {
     if (!conv1x1_wgrad2_covers(N, HW, M, J, k1, x2 != nullptr)) return -1;
+    if ((sy || sx) && (x2 || (int64_t)std::max(sy, sx) * HW * 2 >= ((int64_t)1 << 31))) return -1;
     Wg2Args a;
+    a.sy = sy; a.sx = sx;
     a.gy = (const bf16_t*)gy; a.x1 = (const bf16_t*)x1; a.x2 = (const bf16_t*)x2; a.part = workspace;
     a.gw = (bf16_t*)gw; a.gb = (bf16_t*)gb; a.k1 = x2 ? k1 : J; a.N = N; a.M = M; a.J = J; a.HW = HW;
     a.has_bias = gb ? 1 : 0;

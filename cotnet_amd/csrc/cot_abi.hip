@@ -151,10 +151,11 @@ extern int g_conv_lds_tune[3];
 extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
 unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
+static int g_grouped_tuned = 1;  // tuning key 36: grouped 1x1 convolutions group by group on the tuned kernels
 static inline bool g_conv_lds_tune_wgrad_off() { return (g_conv_lds_tune[2] >> 2) & 1; }  // tuning key 17 bit 2 (A/B)
 bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
 int conv1x1_lds_gemm(const void*, const void*, int, const void*, int, const void*, void*, void*, int, int, int, int, int, int,
-                     hipStream_t);
+                     hipStream_t, int64_t xs = 0, int64_t ys = 0);
 int transpose_bf16(const void* src, void* dst, int R, int C, int pack, hipStream_t stream);
 bool conv1x1_wgrad_lds_covers(int N, int HW, int M, int J);
 int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias);
@@ -164,7 +165,8 @@ extern int g_pool_tile;    // pool3x3.hip (row-block pooling kernels)
 template <typename T> int subsample2(int bwd, const void* a, void* out, int64_t planes, int H, int W, hipStream_t stream);
 bool conv1x1_wgrad2_covers(int N, int HW, int M, int J, int k1, bool two_slabs);
 int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias);
-int conv1x1_wgrad2_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t);
+int conv1x1_wgrad2_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t, int sy = 0,
+                       int sx = 0);
 bool conv3x3g_wgrad2_covers(int N, int Cin, int Cout, int G, int H, int W, int x_guard);
 int conv3x3g_wgrad2_splits(int N, int Cin, int Cout, int G, int HW);
 int conv3x3g_wgrad2_run(const void*, const void*, void*, const void*, float*, int, int, int, int, int, int, int, hipStream_t);
@@ -381,6 +383,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 19) {
         g_wgrad_cap_pct = value > 0 ? value : 0;
+        return COT_OK;
+    }
+    if (key == 36) {
+        g_grouped_tuned = value ? 1 : 0;
         return COT_OK;
     }
     if (key >= 29 && key <= 34) {
@@ -885,7 +891,20 @@ static int conv1x1g_validate(int N, int Ci, int Co, int G, int HW, int dtype) {
 
 int64_t cot_convg_workspace(int N, int Cin, int Cout, int groups, int H, int W, int ksize) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || H <= 0 || W <= 0 || Cin % groups || Cout % groups) return 0;
-    return convg_workspace(N, Cin, Cout, groups, H, W, ksize);
+    int64_t ws = convg_workspace(N, Cin, Cout, groups, H, W, ksize);
+    if (ksize == 1 && groups > 1)  // a group's weight gradient may run on the tuned 1x1 kernel: its partial sums (one group at a time)
+        ws = std::max(ws, cot_conv1x1_workspace(N, Cin / groups, Cout / groups, H * W, 1));
+    return ws;
+}
+
+// Grouped 1x1 convolutions on the TUNED kernels (round 4): a group is an ordinary 1x1 convolution on a channel range of x and y,
+// i.e. the LDS-pipelined kernels with the image strides of the full tensors (conv_lds2.hip / conv_wgrad2.hip: xs / ys, sy / sx),
+// one launch per group.  Taken when the group's reduction depth is on the kernels' 32-channel grid and everything is 16-byte
+// aligned; the general kernels of conv_gen.hip (64 x 64 tiles, 2-byte staging loads) keep the rest.  Tuning key 36 = 0: general
+// kernels everywhere (A/B).
+static inline bool grouped_on_tuned(int Kg, int Mg, int HW, int groups, int dtype) {
+    return g_grouped_tuned && dtype == COT_BF16 && groups > 1 && groups <= 8 && Kg % 32 == 0 && Mg % 8 == 0 &&
+           conv1x1_lds_covers(Kg, Kg, false, HW);
 }
 
 int cot_conv1x1g_forward(const void* x, const void* weight, const void* bias, void* y, int N, int Ci, int Co, int groups,
@@ -894,6 +913,19 @@ int cot_conv1x1g_forward(const void* x, const void* weight, const void* bias, vo
     if (rc) return rc;
     if (!x || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x, weight, y}))) return rc;
+    const int Kg = Ci / groups, Mg = Co / groups;
+    if (grouped_on_tuned(Kg, Mg, HW, groups, dtype)) {
+        const bf16_t *xb = (const bf16_t*)x, *wb = (const bf16_t*)weight, *bb = (const bf16_t*)bias;
+        bf16_t* yb = (bf16_t*)y;
+        for (int g = 0; g < groups; ++g) {
+            rc = conv1x1_lds_gemm(xb + (int64_t)g * Kg * HW, nullptr, Kg, wb + (int64_t)g * Mg * Kg, 0, bb ? bb + g * Mg : nullptr,
+                                  yb + (int64_t)g * Mg * HW, nullptr, Mg, N, Kg, Mg, HW, 0, (hipStream_t)stream, (int64_t)Ci * HW,
+                                  (int64_t)Co * HW);
+            if (rc == -1 && g == 0) break;  // not covered after all: the general kernel does the whole convolution
+            if (rc) return rc == -1 ? set_error(COT_ERR_LAUNCH, "grouped 1x1: group %d fell off the tuned kernel", g) : rc;
+        }
+        if (rc == COT_OK) return rc;
+    }
     return convg_forward(x, weight, bias, y, N, Ci, Co, groups, HW, 1, 1, 0, dtype, (hipStream_t)stream);
 }
 
@@ -903,6 +935,18 @@ int cot_conv1x1g_backward_data(const void* gy, const void* weight, void* gx, int
     if (rc) return rc;
     if (!gy || !weight || !gx) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, weight, gx}))) return rc;
+    const int Kg = Ci / groups, Mg = Co / groups;
+    if (grouped_on_tuned(Mg, Kg, HW, groups, dtype)) {  // (the data gradient reduces over the group's OUTPUT channels)
+        const bf16_t *gb = (const bf16_t*)gy, *wb = (const bf16_t*)weight;
+        bf16_t* xb = (bf16_t*)gx;
+        for (int g = 0; g < groups; ++g) {  // the forward kernel on dY; W^T = the group's [Mg][Kg] block read in place (WT kernels)
+            rc = conv1x1_lds_gemm(gb + (int64_t)g * Mg * HW, nullptr, Mg, wb + (int64_t)g * Mg * Kg, 2, nullptr, xb + (int64_t)g * Kg * HW,
+                                  nullptr, Kg, N, Mg, Kg, HW, accumulate ? 1 : 0, (hipStream_t)stream, (int64_t)Co * HW, (int64_t)Ci * HW);
+            if (rc == -1 && g == 0) break;
+            if (rc) return rc == -1 ? set_error(COT_ERR_LAUNCH, "grouped 1x1 data gradient: group %d fell off the tuned kernel", g) : rc;
+        }
+        if (rc == COT_OK) return rc;
+    }
     return convg_backward_data(gy, weight, gx, N, Ci, Co, groups, HW, 1, 1, accumulate ? 1 : 0, dtype, (hipStream_t)stream);
 }
 
@@ -912,6 +956,21 @@ int cot_conv1x1g_backward_weight(const void* gy, const void* x, void* gweight, v
     if (rc) return rc;
     if (!gy || !x || !gweight || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, x, gweight, workspace}))) return rc;
+    const int Kg = Ci / groups, Mg = Co / groups;
+    // (any channel counts per group whose slabs start on 16-byte boundaries: the kernel clamps rows past a matrix' end)
+    if (g_grouped_tuned && dtype == COT_BF16 && groups > 1 && groups <= 8 && ((int64_t)Kg * HW) % 8 == 0 && ((int64_t)Mg * HW) % 8 == 0 &&
+        (Mg * Kg) % 8 == 0 && Kg % 8 == 0 && conv1x1_wgrad2_covers(N, HW, Mg, Kg, Kg, false)) {
+        // (the partial sums of group g are consumed by its own reduce launch before group g+1's kernel overwrites them: one stream)
+        const bf16_t *gb = (const bf16_t*)gy, *xb = (const bf16_t*)x;
+        bf16_t *wg = (bf16_t*)gweight, *bg = (bf16_t*)gbias;
+        for (int g = 0; g < groups; ++g) {
+            rc = conv1x1_wgrad2_run(gb + (int64_t)g * Mg * HW, xb + (int64_t)g * Kg * HW, nullptr, Kg, wg + (int64_t)g * Mg * Kg,
+                                    bg ? bg + g * Mg : nullptr, (float*)workspace, N, Kg, Mg, HW, (hipStream_t)stream, Co, Ci);
+            if (rc == -1 && g == 0) break;
+            if (rc) return rc == -1 ? set_error(COT_ERR_LAUNCH, "grouped 1x1 weight gradient: group %d fell off the tuned kernel", g) : rc;
+        }
+        if (rc == COT_OK) return rc;
+    }
     return convg_backward_weight(gy, x, gweight, gbias, (float*)workspace, N, Ci, Co, groups, HW, 1, 1, dtype,
                                  (hipStream_t)stream);
 }

@@ -22,6 +22,11 @@ case $what in
   secotnetd) timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/${T}_bench_secotnetd.json 2> $O/${T}_bench_secotnetd.err
              timeout 300 python -m pytest tests/test_se_gate_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "se_cotnetd or hybrid or model" 2>&1 | tail -8 > $O/${T}_secotnetd_tests.log ;;
   tunes) for tn in "35=4" "35=5" "35=4" "35=5"; do timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 5 --tune $tn 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); r=l['roofline']; print('$tn', l['value'], l['ms_per_step'], r['kernel'], r['avg_us'], r['frac'], [ (k['shape'],k['avg_us']) for k in r['kernels'] if 'bwd' in k['kernel']])" >> $O/${T}_tunes.log 2>&1; done ;;
+  layout) timeout 600 python scripts/bench_layout_study.py --json $O/${T}_layout.json > $O/${T}_layout.log 2>&1 ;;
+  grouped) timeout 600 python -m pytest tests/test_conv_general_gpu.py tests/test_fused_layer_gpu.py tests/test_conv1x1_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 2>&1 | tail -8 > $O/${T}_grouped_tests.log
+        COT_KERNEL_SUMMARY=$O/${T}_cotnext101_kernels.json timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > $O/${T}_bench_cotnext101_prof.json 2> $O/${T}_bench_cotnext101.err
+        timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/${T}_bench_cotnext101.json 2>> $O/${T}_bench_cotnext101.err
+        timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --tune 36=0 > $O/${T}_bench_cotnext101_general.json 2>> $O/${T}_bench_cotnext101.err ;;
   aggparity) timeout 600 python -m pytest tests/test_dispatch_parity_gpu.py tests/test_agg_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "agg or Agg or oracle or n80 or N80" 2>&1 | tail -30 > $O/${T}_aggparity.log ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac

@@ -194,8 +194,24 @@ def test_no_benchmark_layer_falls_off_the_tuned_kernels():
             assert all("k3_lds" in n or "k3_dot2" in n for n in names), (key, launches)
             if key.startswith("cotnet50") and key.endswith(" bwd") and "x7x7x" not in key:
                 assert all("k3_dot2" in n for n in names), (key, launches)
+    # CoTNeXt's grouped 1x1 convolutions (groups = 2): group by group on the tuned kernels wherever the depth of a group's
+    # reduction is on the 32-channel grid (forward: Ci / 2, data gradient: Co / 2) resp. its slabs are 16-byte aligned (weight
+    # gradient) -- one launch (+ reduce) per group --, else the general kernels
     grouped = [k for k in table if k.startswith("cotnext") and " conv1x1 " in k and k.split()[2].split("x")[3] == "2"]
-    assert grouped and all("convg_" in table[k][0] for k in grouped), [table[k][0] for k in grouped][:3]
+    assert grouped
+    n_tuned = 0
+    for k in grouped:
+        N, Ci, Co, g, H, W, s_, bias = map(int, k.split()[2].split("x"))
+        names = [ln.split("[")[0] for ln in table[k]]
+        depth = (Ci if k.endswith(" fwd") else Co) // g
+        if k.endswith(" fwd") or k.endswith(" dgrad"):
+            want_tuned = depth % 32 == 0 and (Co // g if k.endswith(" fwd") else Ci // g) % 8 == 0
+            assert (names == ["conv1x1_lds_fwd2"] * g) if want_tuned else all("convg_" in n for n in names), (k, table[k])
+            n_tuned += want_tuned
+        elif k.endswith(" wgrad"):
+            assert names[0] in ("conv1x1_wgrad_lds2", "gen::convg_wgrad_kernel"), (k, table[k])
+            n_tuned += names[0] == "conv1x1_wgrad_lds2"
+    assert n_tuned >= len(grouped) // 2, (n_tuned, len(grouped))
 
 
 if __name__ == "__main__":
