@@ -269,25 +269,29 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
 //     flipped) by a small kernel into the call's workspace (<= 1.2 MB), so W fragments are 16-byte rows as in the 1x1 case.
 // dst[((g*NT + tap)*Mo + mo)*Kk + kk] = forward:  w[((g*Mo + mo)*Kk + kk)*9 + tap]
 //                                        dgrad:    w[((g*Kk + kk)*Mo + mo)*9 + (8 - tap)]     (tap == 9: zeros)
-__global__ void conv3x3g_repack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ dst, int G, int Mo, int Kk, int NTAP,
+// Kp >= Kk: the K dimension of the repacked tiles, padded with ZEROS to the kernel's 32-channel chunks (groups of 24 / 48 channels:
+// CoXtLayer's key embedding, round 4) -- the staged chunk then also holds channels of the NEXT group, which meet zero weights.
+__global__ void conv3x3g_repack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ dst, int G, int Mo, int Kk, int Kp, int NTAP,
                                        int dgrad) {
-    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (int64_t)G * NTAP * Mo * Kk;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (int64_t)G * NTAP * Mo * Kp;
     if (o >= total) return;
-    const int kk = (int)(o % Kk);
-    int64_t r = o / Kk;
+    const int kk = (int)(o % Kp);
+    int64_t r = o / Kp;
     const int mo = (int)(r % Mo);
     r /= Mo;
     const int tap = (int)(r % NTAP), g = (int)(r / NTAP);
     bf16_t v = (bf16_t)0.0f;
-    if (tap < 9) v = dgrad ? w[(((int64_t)g * Kk + kk) * Mo + mo) * 9 + (8 - tap)] : w[(((int64_t)g * Mo + mo) * Kk + kk) * 9 + tap];
+    if (tap < 9 && kk < Kk)
+        v = dgrad ? w[(((int64_t)g * Kk + kk) * Mo + mo) * 9 + (8 - tap)] : w[(((int64_t)g * Mo + mo) * Kk + kk) * 9 + tap];
     dst[o] = v;
 }
 
 struct C3LdsArgs {
-    const bf16_t* x;   // [N][G*KK][H*W]
+    const bf16_t* x;   // [N][G*KX][H*W]
     const bf16_t* wr;  // repacked weights [G][NTAP][MM][KK]
     bf16_t* y;         // [N][G*MM][H*W]
     int N, G, KK, MM, H, W;
+    int KX;            // channels per group in x (KK = KX rounded up to the 32-channel chunks; the padding meets zero weights)
     int accumulate;
     int tiles;         // BIG: row tiles per image; FLAT: image groups
     int ni;            // FLAT: images per workgroup
@@ -328,7 +332,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
     }
     const int SLc = FLAT ? HW : a.SL;                          // channel stride inside a staged chunk
     const int xelems = FLAT ? a.ni * CH * HW : CH * a.SL;      // elements of a staged chunk
-    const int64_t x_total = (int64_t)a.N * G * KK * HW;
+    const int KX = a.KX;
+    const int64_t x_total = (int64_t)a.N * G * KX * HW;
 
     // ---- X copies of this thread (resolved once; a chunk step moves them CH channels = CH*HW elements)
     int64_t xoff[XP];
@@ -338,10 +343,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
         int64_t e;
         if (FLAT) {
             const int cpi = CH * HW / 8, img = q / cpi, c = q - img * cpi;
-            e = ((int64_t)min(n0 + img, a.N - 1) * G * KK + (int64_t)grp * KK) * HW + (int64_t)c * 8;
+            e = ((int64_t)min(n0 + img, a.N - 1) * G * KX + (int64_t)grp * KX) * HW + (int64_t)c * 8;
         } else {
             const int cpc = a.SL / 8, ch = q / cpc, c = q - ch * cpc;
-            e = ((int64_t)n0 * G * KK + (int64_t)grp * KK + ch) * HW + gs + c * 8;
+            e = ((int64_t)n0 * G * KX + (int64_t)grp * KX + ch) * HW + gs + c * 8;
         }
         xoff[ps] = e;
     }
@@ -450,7 +455,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
                 q4[hh][0] = p[(2 * hh) * SLc];
                 q4[hh][1] = p[(2 * hh + 1) * SLc];
             }
-            const bool valid = tapraw < 9 && ((amask[cb] >> tap) & 1);
+            // (a padded chunk's channels past the group's end belong to the next group: cleared by selection like the padded taps --
+            // their weights are zeros, but 0 * Inf / NaN must not reach the sum; KX % 8 == 0, so a lane's 8 channels go together)
+            const bool valid = tapraw < 9 && ((amask[cb] >> tap) & 1) && (K16 || cc * 32 + 8 * g < KX);
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh) {
                 q4[hh][0] = valid ? q4[hh][0] : (uint16_t)0;
@@ -491,12 +498,15 @@ static int launch_c3(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
     return check_launch("conv3x3g_lds_fwd");
 }
 
+// KK / MM: reduction / output channels per group.  MM: any multiple of 8 up to 128 (the tile's rows past MM are clamped copies,
+// never stored); KK: 16 (with MM == 16: two taps per K step) or any multiple of 8 from 24 on, rounded up to 32-channel chunks whose
+// padding is zeros in the repacked weights (round 4: groups of 24 / 48 / 96 channels, CoXtLayer.key_embed)
 bool conv3x3g_lds_covers(int KK, int MM, int H, int W) {
     if (!g_conv_lds_tune[0]) return false;
-    if (!(MM == 16 || MM == 32 || MM == 64 || MM == 128)) return false;
-    if (!((KK == 16 && MM == 16) || (KK % 32 == 0 && KK >= 32 && MM >= 32))) return false;
+    if (MM % 8 != 0 || MM < 16 || MM > 128) return false;
+    if (!((KK == 16 && MM == 16) || (KK % 8 == 0 && KK >= 24 && MM >= 24))) return false;
     const int HW = H * W;
-    if (HW <= 256) return HW % 8 == 0 || MM % 8 == 0;
+    if (HW <= 256) return HW % 8 == 0 || (MM % 8 == 0 && KK % 8 == 0);
     return HW % 8 == 0 && W % 4 == 0 && W <= 128;
 }
 
@@ -504,12 +514,13 @@ bool conv3x3g_lds_covers(int KK, int MM, int H, int W) {
 // workspace (>= G*10*MM*KK bf16).  Returns COT_OK, an error, or -1 when the geometry is not covered.
 int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, int Cin, int Cout, int G, int H, int W,
                       int mode, int accumulate, hipStream_t stream) {
-    const int KK = (mode == 0 ? Cin : Cout) / G, MM = (mode == 0 ? Cout : Cin) / G, HW = H * W;
-    if (!conv3x3g_lds_covers(KK, MM, H, W)) return -1;
-    const int K16 = KK == 16, NTAP = K16 ? 10 : 9;
+    const int KX = (mode == 0 ? Cin : Cout) / G, MM = (mode == 0 ? Cout : Cin) / G, HW = H * W;
+    if (!conv3x3g_lds_covers(KX, MM, H, W)) return -1;
+    const int K16 = KX == 16, NTAP = K16 ? 10 : 9;
+    const int KK = K16 ? 16 : (KX + 31) / 32 * 32;  // the repacked tiles' K: whole 32-channel chunks
     C3LdsArgs a;
     a.x = (const bf16_t*)x; a.wr = (const bf16_t*)ws; a.y = (bf16_t*)y;
-    a.N = N; a.G = G; a.KK = KK; a.MM = MM; a.H = H; a.W = W; a.accumulate = accumulate;
+    a.N = N; a.G = G; a.KK = KK; a.KX = KX; a.MM = MM; a.H = H; a.W = W; a.accumulate = accumulate;
     a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0;
     int64_t blocks;
     const bool flat = HW <= 256;
@@ -539,19 +550,19 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
     {   // repack the weights: [G][NTAP][MM][KK]
         const int64_t total = (int64_t)G * NTAP * MM * KK;
         COT_LAUNCH(conv3x3g_repack_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, (const bf16_t*)w,
-                   (bf16_t*)ws, G, MM, KK, NTAP, mode);
+                   (bf16_t*)ws, G, MM, KX, KK, NTAP, mode);
         int rc = check_launch("conv3x3g_repack_kernel");
         if (rc) return rc;
     }
     if (flat) {
         if (K16) return launch_c3<2, 1, 1, 1, 1>(a, blocks, stream);
-        if (MM == 32) return launch_c3<2, 2, 1, 0, 2>(a, blocks, stream);
-        if (MM == 64) return launch_c3<2, 4, 1, 0, 2>(a, blocks, stream);
+        if (MM <= 32) return launch_c3<2, 2, 1, 0, 2>(a, blocks, stream);
+        if (MM <= 64) return launch_c3<2, 4, 1, 0, 2>(a, blocks, stream);
         return launch_c3<2, 8, 1, 0, 2>(a, blocks, stream);
     }
     if (K16) return launch_c3<4, 1, 0, 1, 3>(a, blocks, stream);
-    if (MM == 32) return launch_c3<4, 2, 0, 0, 5>(a, blocks, stream);
-    if (MM == 64) return launch_c3<4, 4, 0, 0, 5>(a, blocks, stream);
+    if (MM <= 32) return launch_c3<4, 2, 0, 0, 5>(a, blocks, stream);
+    if (MM <= 64) return launch_c3<4, 4, 0, 0, 5>(a, blocks, stream);
     return launch_c3<4, 8, 0, 0, 5>(a, blocks, stream);
 }
 

@@ -152,6 +152,7 @@ extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
 unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
 static int g_grouped_tuned = 1;  // tuning key 36: grouped 1x1 convolutions group by group on the tuned kernels
+static int g_conv3x3_merge = 1;  // tuning key 37: merged-groups 3x3 weight gradient for group widths off the 8-channel grid
 static inline bool g_conv_lds_tune_wgrad_off() { return (g_conv_lds_tune[2] >> 2) & 1; }  // tuning key 17 bit 2 (A/B)
 bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
 int conv1x1_lds_gemm(const void*, const void*, int, const void*, int, const void*, void*, void*, int, int, int, int, int, int,
@@ -385,6 +386,10 @@ int cot_set_tuning(int key, int value) {
         g_wgrad_cap_pct = value > 0 ? value : 0;
         return COT_OK;
     }
+    if (key == 37) {
+        g_conv3x3_merge = value ? 1 : 0;
+        return COT_OK;
+    }
     if (key == 36) {
         g_grouped_tuned = value ? 1 : 0;
         return COT_OK;
@@ -563,6 +568,25 @@ static bool conv3x3g_general(int Cin, int Cout, int G, int dtype) {
     return dtype == COT_F32 || (Cin / G) % 8 != 0 || (Cout / G) % 8 != 0;
 }
 
+// Weight gradient of a grouped 3x3 convolution whose group width is off the MFMA kernels' 8-channel grid (CoXtLayer.key_embed at
+// dim 96: 8 groups of 12, models/cotnet.py:113-117): f neighbouring groups are MERGED into one of f*Kc channels the tuned kernels
+// tile, the gradient of that wider convolution is taken -- the wanted blocks are its diagonal, the f*(f-1) cross blocks are wasted
+// work on a kernel that is still >10x faster than the general 64 x 64-tile kernel on 12 x 12 blocks (1137 -> ~90 us at N64 x 96 x
+// 56 x 56) -- and the diagonal blocks are copied out.  f = the smallest of 2 / 4 / 8 that puts both widths on the grid; 0 = none.
+static int conv3x3g_merge_factor(int Cin, int Cout, int G) {
+    for (int f = 2; f <= 8; f *= 2)
+        if (G % f == 0 && !conv3x3g_general(Cin, Cout, G / f, COT_BF16)) return f;
+    return 0;
+}
+// gw[co][ci][t] = wide[co][(g % f) * Kc + ci][t], g = co / Mg  (wide: [Cout][f*Kc][9] of the merged convolution)
+__global__ __launch_bounds__(256) void conv3x3g_diag_blocks(const bf16_t* __restrict__ wide, bf16_t* __restrict__ gw, int Kc, int Mg,
+                                                            int f, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = i % 9, ci = (i / 9) % Kc, co = i / (9 * Kc);
+    gw[i] = wide[((int64_t)co * (f * Kc) + ((co / Mg) % f) * Kc + ci) * 9 + t];
+}
+
 int64_t cot_conv3x3g_masks_bytes(int H, int W) { return (H > 0 && W > 0) ? conv3x3g_masks_bytes(H, W) : 0; }
 
 int cot_conv3x3g_masks(void* masks, int H, int W, void* stream) {
@@ -575,12 +599,21 @@ int cot_conv3x3g_masks(void* masks, int H, int W, void* stream) {
 
 int64_t cot_conv3x3g_workspace(int N, int Cin, int Cout, int groups, int H, int W) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || H <= 0 || W <= 0 || Cin % groups || Cout % groups) return 0;
-    const int64_t wb = (int64_t)Cout * (Cin / groups) * 10 * 2;  // repacked weights of the LDS kernels (10 taps: one of zeros)
+    // repacked weights of the LDS kernels (10 taps: one of zeros; K padded to whole 32-channel chunks), forward or data gradient
+    const int64_t kpf = ((Cin / groups) + 31) / 32 * 32, kpd = ((Cout / groups) + 31) / 32 * 32;
+    const int64_t wb = std::max((int64_t)Cout * kpf, (int64_t)Cin * kpd) * 10 * 2;
     int splits = conv3x3g_wgrad_splits(N, Cin, Cout, groups, H * W);
     if (conv3x3g_wgrad2_covers(N, Cin, Cout, groups, H, W, 1 << 30))  // (whichever kernel ends up running)
         splits = std::max(splits, conv3x3g_wgrad2_splits(N, Cin, Cout, groups, H * W));
     const int64_t part = (int64_t)splits * Cout * (Cin / groups) * 9 * 4;
-    return ((wb > part ? wb : part) + 255) / 256 * 256;
+    int64_t ws = ((wb > part ? wb : part) + 255) / 256 * 256;
+    if (conv3x3g_general(Cin, Cout, groups, COT_BF16)) {
+        ws = std::max(ws, convg_workspace(N, Cin, Cout, groups, H, W, 3));
+        const int f = conv3x3g_merge_factor(Cin, Cout, groups);
+        if (f)  // merged-groups weight gradient: the wide gradient (bf16) followed by the merged convolution's own workspace
+            ws = std::max(ws, ((int64_t)Cout * (Cin / groups) * f * 9 * 2 + 255) / 256 * 256 + cot_conv3x3g_workspace(N, Cin, Cout, groups / f, H, W));
+    }
+    return ws;
 }
 
 static int cot_conv3x3g_forward_impl(const void* x, const void* weight, void* y, const void* masks, void* workspace, int N, int Cin,
@@ -634,9 +667,23 @@ static int cot_conv3x3g_backward_weight_impl(const void* gy, const void* x, void
     if (rc) return rc;
     if (!gy || !x || !gweight || !masks || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gy, x, gweight, masks, workspace}))) return rc;
-    if (conv3x3g_general(Cin, Cout, groups, dtype))
+    if (conv3x3g_general(Cin, Cout, groups, dtype)) {
+        const int f = (dtype == COT_BF16 && g_conv3x3_merge) ? conv3x3g_merge_factor(Cin, Cout, groups) : 0;
+        if (f) {
+            const int Kc = Cin / groups, Mg = Cout / groups;
+            bf16_t* wide = (bf16_t*)workspace;
+            char* rest = (char*)workspace + ((int64_t)Cout * Kc * f * 9 * 2 + 255) / 256 * 256;
+            rc = conv3x3g_wgrad2_run(gy, x, wide, masks, (float*)rest, N, Cin, Cout, groups / f, H, W, x_guard, (hipStream_t)stream);
+            if (rc < 0) rc = conv3x3g_wgrad(gy, x, wide, masks, (float*)rest, N, Cin, Cout, groups / f, H, W, (hipStream_t)stream);
+            if (rc) return rc;
+            const int total = Cout * Kc * 9;
+            COT_LAUNCH(conv3x3g_diag_blocks, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)wide,
+                       (bf16_t*)gweight, Kc, Mg, f, total);
+            return check_launch("conv3x3g_diag_blocks");
+        }
         return convg_backward_weight(gy, x, gweight, nullptr, (float*)workspace, N, Cin, Cout, groups, H, W, 3, dtype,
                                      (hipStream_t)stream);
+    }
     // the LDS-staged kernel reads X at pixel + tap offset through whole 16-byte pieces: it needs W + 1 readable elements
     // before and behind the tensor (x_guard: what the caller guarantees)
     rc = conv3x3g_wgrad2_run(gy, x, gweight, masks, (float*)workspace, N, Cin, Cout, groups, H, W, x_guard, (hipStream_t)stream);

@@ -162,6 +162,8 @@ const char* cot_last_kernel(void);
  *   key 34: 1 (default) = its slabs are double-buffered (phase p+1 copied while phase p is computed), 0 = copy, wait, compute
  *   key 36: grouped 1x1 convolutions (cot_conv1x1g_*) group by group on the tuned LDS-pipelined kernels where a group's depth is a
  *           multiple of 32 (1 default), 0 = general kernels everywhere
+ *   key 37: grouped 3x3 weight gradient with group widths off the 8-channel grid (12 per group): neighbouring groups merged, the
+ *           wider convolution's gradient taken on the tuned kernels and its diagonal blocks copied out (1 default), 0 = general kernel
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* Dry-run log of the calling thread (cot_set_tuning(26, 1)): one line per launch the library WOULD have issued --

@@ -210,8 +210,14 @@ if __name__ == "__main__":
         conv1x1(*shape)
     for shape in [(2, 64, 4, 8, 16), (2, 32, 4, 14, 14), (8, 64, 8, 7, 7), (1, 256, 4, 5, 4), (8, 16, 2, 1, 3),
                   # LDS kernels: BIG with row tiles whose halo runs past both ends of the tensor, FLAT with a partial image group
-                  (1, 128, 4, 30, 20), (1, 64, 4, 24, 24), (3, 256, 4, 7, 7)]:
+                  (1, 128, 4, 30, 20), (1, 64, 4, 24, 24), (3, 256, 4, 7, 7),
+                  # group widths padded to whole 32-channel chunks: the LAST group's padding lies behind the tensor (clamped copies)
+                  (1, 96, 2, 24, 16), (2, 192, 8, 8, 8), (3, 384, 8, 7, 7)]:
         conv3x3(*shape)
+    # grouped 1x1 convolutions group by group on the tuned kernels (image strides of the full tensors), weight gradient
+    # with 12-wide groups merged in pairs
+    for shape in [(2, 128, 96, 2, 8, 8, 1), (1, 64, 48, 2, 20, 18, 1), (2, 96, 96, 8, 6, 10, 3)]:
+        conv_general(*shape, torch.bfloat16)
     for shape in [(2, 2, 8, 8), (2, 1, 14, 14), (8, 2, 7, 7), (1, 1, 56, 56), (8, 2, 3, 5)]:
         gn9(*shape)
     for dtype in (torch.float32, torch.bfloat16):

@@ -1001,6 +1001,13 @@ def test_conv3x3_grouped_weight_gradient_guard_decides_the_kernel():
     (2, 256, 4, 14, 14),   # FLAT, Kc = 64: two channel chunks x 9 taps, one image per workgroup
     (3, 512, 4, 7, 7),     # FLAT, Kc = 128: four chunks (the X double buffer wraps), 7x7
     (5, 128, 4, 8, 8),     # FLAT, several images per workgroup?  (N*G small: one image each) + HW = 64
+    # round 4 -- group widths off the 32 / 16-32-64-128 grid (CoXtLayer.key_embed: 8 groups of 24 / 48 / 96): K padded to whole
+    # 32-channel chunks with zero weights (the staged padding = the next group's channels, or clamped bytes at the tensor's end),
+    # output tiles with rows past the group's end
+    (2, 192, 8, 28, 28),   # BIG, 24 per group: one chunk, 8 of its 32 channels padding; 24 of 32 tile rows
+    (2, 384, 8, 14, 14),   # FLAT, 48 per group: two chunks (the second half padding), 48 of 64 rows
+    (3, 768, 8, 7, 7),     # FLAT, 96 per group: three whole chunks, 96 of 128 rows, 7 x 7
+    (1, 96, 2, 24, 16),    # BIG, 48 per group, two groups, the last one's padding runs past the tensor
 ])
 def test_conv3x3_grouped_lds_kernels(N, C, G, H, W):
     """csrc/conv_lds.hip conv3x3g_lds_fwd (forward and data gradient incl. accumulate) against torch on the same rounded
@@ -1052,6 +1059,36 @@ def test_conv3x3_lds_masks_by_selection():
     assert _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
     assert torch.isnan(y[:, :Kc].float()).all()
     assert torch.allclose(y[:, Kc:].float(), yref, atol=2e-2, rtol=2e-2)
+
+
+def test_conv3x3_lds_padded_chunk_is_cleared_by_selection():
+    """groups of 48 channels on the LDS kernel: the second 32-channel chunk of group 0 is half group 1's channels.  They meet
+    zero weights -- and must be cleared by selection all the same: group 1 is all NaN here, group 0's outputs must not notice"""
+    torch.manual_seed(19)
+    N, C, G, H, W = 2, 96, 2, 6, 8
+    Kc = C // G
+    x = torch.randn(N, C, H, W).bfloat16()
+    x[:, Kc:] = float("nan")
+    w = (torch.randn(C, Kc, 3, 3) / 20).bfloat16()
+    yref = torch.nn.functional.conv2d(x[:, :Kc].float(), w[:Kc].float(), None, 1, 1)
+    dt = _lib.dtype_code(torch.bfloat16)
+    masks = torch.empty(_EMUL.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert _EMUL.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    ws = torch.empty(_EMUL.cot_conv3x3g_workspace(N, C, C, G, H, W), dtype=torch.uint8)
+    y = torch.empty(N, C, H, W).bfloat16()
+    assert _EMUL.cot_set_tuning(15, 1) == 0
+    buf = ctypes.create_string_buffer(1 << 12)
+    _EMUL.cot_launch_log(buf, len(buf))
+    assert _EMUL.cot_set_tuning(26, 1) == 0
+    try:
+        assert _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
+        _EMUL.cot_launch_log(buf, len(buf))
+    finally:
+        assert _EMUL.cot_set_tuning(26, 0) == 0
+    assert "conv3x3g_lds_fwd" in buf.value.decode(), buf.value
+    assert _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
+    assert torch.allclose(y[:, :Kc].float(), yref, atol=2e-2, rtol=2e-2)
+    assert torch.isnan(y[:, Kc:].float()).all()
 
 
 def test_conv3x3_grouped_unequal_channels_and_nan_neighbours():
@@ -1902,7 +1939,10 @@ def test_general_grouped_conv1x1_kernels(N, Ci, Co, G, H, W, bias, dtype):
 @pytest.mark.parametrize("N,C,G,H,W,dtype", [
     (2, 32, 4, 7, 7, torch.float32),      # CotLayer.key_embed geometry (8 per group) at the reference's precision
     (1, 96, 8, 6, 10, torch.float32),     # CoXtLayer.key_embed: 12 per group
-    (1, 96, 8, 6, 10, torch.bfloat16),    # the same in bf16: channel counts the tuned kernels do not tile
+    (1, 96, 8, 6, 10, torch.bfloat16),    # the same in bf16: the weight gradient merges pairs of groups (24-wide, on the MFMA kernels'
+                                          # grid) and copies the diagonal blocks out; forward / data gradient on the general kernels
+    (3, 96, 8, 12, 12, torch.bfloat16),   # ... several images, several splits of the reduction
+    (2, 72, 6, 5, 7, torch.bfloat16),     # 12 per group, 6 groups: merged in pairs as well
     (2, 48, 2, 1, 4, torch.bfloat16),     # 24 per group, one-row image
     (1, 130, 1, 3, 3, torch.float32),     # 130 channels: three output tiles, nine reduction steps per tap
 ])
