@@ -85,8 +85,12 @@ class CoTBottleneck(nn.Module):
         nn.init.zeros_(self.bn3.weight)
 
     def forward(self, x):
-        if cot_layer_fused.ENABLED and isinstance(self.conv2, CotLayer) and cot_layer_fused.block_eligible(self, x):
-            return cot_layer_fused.block_forward(self, x)  # CoT block (identity shortcut / AvgPool-first stride) as one autograd node
+        if cot_layer_fused.ENABLED:  # the whole block as one autograd node (identity-shortcut / AvgPool-first blocks of both kinds)
+            if isinstance(self.conv2, CotLayer):
+                if cot_layer_fused.block_eligible(self, x):
+                    return cot_layer_fused.block_forward(self, x)
+            elif cot_layer_fused.sa_block_eligible(self, x):
+                return cot_layer_fused.sa_block_forward(self, x)
         residual = x
         if self.drop_block is None:
             x = fused_bn_act(conv1x1(self.conv1, x), self.bn1, "relu")  # act1 is hard-wired ReLU (ref :124)

@@ -271,8 +271,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
 //                                        dgrad:    w[((g*Kk + kk)*Mo + mo)*9 + (8 - tap)]     (tap == 9: zeros)
 // Kp >= Kk: the K dimension of the repacked tiles, padded with ZEROS to the kernel's 32-channel chunks (groups of 24 / 48 channels:
 // CoXtLayer's key embedding, round 4) -- the staged chunk then also holds channels of the NEXT group, which meet zero weights.
+// MBLK > 1: a group's output channels are cut into MBLK blocks of Mo rows ("virtual groups" g' = g*MBLK + blk that share the
+// real group's input): dense 3x3 convolutions with more than 128 output channels per group (SE-CoTNetD's SplitAttn convs).
 __global__ void conv3x3g_repack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ dst, int G, int Mo, int Kk, int Kp, int NTAP,
-                                       int dgrad) {
+                                       int dgrad, int MBLK) {
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (int64_t)G * NTAP * Mo * Kp;
     if (o >= total) return;
     const int kk = (int)(o % Kp);
@@ -281,8 +283,9 @@ __global__ void conv3x3g_repack_kernel(const bf16_t* __restrict__ w, bf16_t* __r
     r /= Mo;
     const int tap = (int)(r % NTAP), g = (int)(r / NTAP);
     bf16_t v = (bf16_t)0.0f;
-    if (tap < 9 && kk < Kk)
-        v = dgrad ? w[(((int64_t)g * Kk + kk) * Mo + mo) * 9 + (8 - tap)] : w[(((int64_t)g * Mo + mo) * Kk + kk) * 9 + tap];
+    if (tap < 9 && kk < Kk)  // (g counts virtual groups: real group g / MBLK, block g % MBLK of its output rows)
+        v = dgrad ? w[(((int64_t)(g / MBLK) * Kk + kk) * ((int64_t)Mo * MBLK) + (g % MBLK) * Mo + mo) * 9 + (8 - tap)]
+                  : w[(((int64_t)g * Mo + mo) * Kk + kk) * 9 + tap];
     dst[o] = v;
 }
 
@@ -292,6 +295,7 @@ struct C3LdsArgs {
     bf16_t* y;         // [N][G*MM][H*W]
     int N, G, KK, MM, H, W;
     int KX;            // channels per group in x (KK = KX rounded up to the 32-channel chunks; the padding meets zero weights)
+    int MBLK, CX;      // output-row blocks per real group (G counts virtual groups = real groups x MBLK); channels per image of x
     int accumulate;
     int tiles;         // BIG: row tiles per image; FLAT: image groups
     int ni;            // FLAT: images per workgroup
@@ -333,7 +337,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
     const int SLc = FLAT ? HW : a.SL;                          // channel stride inside a staged chunk
     const int xelems = FLAT ? a.ni * CH * HW : CH * a.SL;      // elements of a staged chunk
     const int KX = a.KX;
-    const int64_t x_total = (int64_t)a.N * G * KX * HW;
+    const int64_t x_total = (int64_t)a.N * a.CX * HW;
+    const int xg = grp / a.MBLK;  // the real group: whose input channels this (virtual) group reads
 
     // ---- X copies of this thread (resolved once; a chunk step moves them CH channels = CH*HW elements)
     int64_t xoff[XP];
@@ -343,10 +348,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
         int64_t e;
         if (FLAT) {
             const int cpi = CH * HW / 8, img = q / cpi, c = q - img * cpi;
-            e = ((int64_t)min(n0 + img, a.N - 1) * G * KX + (int64_t)grp * KX) * HW + (int64_t)c * 8;
+            e = ((int64_t)min(n0 + img, a.N - 1) * a.CX + (int64_t)xg * KX) * HW + (int64_t)c * 8;
         } else {
             const int cpc = a.SL / 8, ch = q / cpc, c = q - ch * cpc;
-            e = ((int64_t)n0 * G * KX + (int64_t)grp * KX + ch) * HW + gs + c * 8;
+            e = ((int64_t)n0 * a.CX + (int64_t)xg * KX + ch) * HW + gs + c * 8;
         }
         xoff[ps] = e;
     }
@@ -503,26 +508,32 @@ static int launch_c3(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
 // padding is zeros in the repacked weights (round 4: groups of 24 / 48 / 96 channels, CoXtLayer.key_embed)
 bool conv3x3g_lds_covers(int KK, int MM, int H, int W) {
     if (!g_conv_lds_tune[0]) return false;
+    if (MM > 128 && MM % 128 == 0 && MM <= 1024) MM = 128;  // (blocks of 128 rows that share the group's input: MBLK)
     if (MM % 8 != 0 || MM < 16 || MM > 128) return false;
     if (!((KK == 16 && MM == 16) || (KK % 8 == 0 && KK >= 24 && MM >= 24))) return false;
     const int HW = H * W;
     if (HW <= 256) return HW % 8 == 0 || (MM % 8 == 0 && KK % 8 == 0);
-    return HW % 8 == 0 && W % 4 == 0 && W <= 128;
+    return HW % 8 == 0 && W % 4 == 0 && W <= 256;  // (wide rows -- 160 at SE-CoTNetD's 320 x 320 -- take fewer rows per tile)
 }
 
 // mode 0: y = conv(x, w);  mode 1: data gradient (x := dY, y := dX, weights transposed and flipped).  `ws`: the call's
 // workspace (>= G*10*MM*KK bf16).  Returns COT_OK, an error, or -1 when the geometry is not covered.
 int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, int Cin, int Cout, int G, int H, int W,
                       int mode, int accumulate, hipStream_t stream) {
-    const int KX = (mode == 0 ? Cin : Cout) / G, MM = (mode == 0 ? Cout : Cin) / G, HW = H * W;
-    if (!conv3x3g_lds_covers(KX, MM, H, W)) return -1;
+    const int KX = (mode == 0 ? Cin : Cout) / G, Mreal = (mode == 0 ? Cout : Cin) / G, HW = H * W;
+    if (!conv3x3g_lds_covers(KX, Mreal, H, W)) return -1;
+    const int MBLK = Mreal > 128 ? Mreal / 128 : 1, MM = Mreal / MBLK;
+    const int Greal = G;
+    G *= MBLK;  // virtual groups from here on
     const int K16 = KX == 16, NTAP = K16 ? 10 : 9;
     const int KK = K16 ? 16 : (KX + 31) / 32 * 32;  // the repacked tiles' K: whole 32-channel chunks
     C3LdsArgs a;
     a.x = (const bf16_t*)x; a.wr = (const bf16_t*)ws; a.y = (bf16_t*)y;
     a.N = N; a.G = G; a.KK = KK; a.KX = KX; a.MM = MM; a.H = H; a.W = W; a.accumulate = accumulate;
+    a.MBLK = MBLK; a.CX = Greal * KX;
     a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0;
     int64_t blocks;
+    int big_cols = 512;
     const bool flat = HW <= 256;
     if (flat) {
         int ni = 256 / HW;                      // CB = 2: 256 columns
@@ -534,10 +545,17 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
         a.tiles = ceil_div(N, ni);
         blocks = (int64_t)a.tiles * G;
     } else {
-        // BIG: TR image rows per tile (CB = 4: 512 columns), TR*W a multiple of 8, the staged chunk within XP passes
+        // BIG: TR image rows per tile (CB = 4: 512 columns; CB = 2: 256 columns when 512-column tiles would leave the chip
+        // under-filled -- 256 -> 256 at 20 x 20, B = 64: 128 workgroups of 400 columns vs 256 of 200), TR*W a multiple of 8, the
+        // staged chunk within XP passes
         const int CH = K16 ? 16 : 32, XPmax = K16 ? 3 : 5;
         int TR = 512 / W;
         if (TR > H) TR = H;
+        if ((int64_t)N * G * ceil_div(H, TR) < 256 && 256 / W >= 2) {
+            big_cols = 256;
+            TR = 256 / W;
+            if (TR > H) TR = H;
+        }
         const int nt = ceil_div(H, TR);
         TR = ceil_div(H, nt);  // balanced tiles
         while (TR > 1 && ((TR * W) % 8 != 0 || (int64_t)CH * (((TR + 2) * W + 8 + 7) / 8) > (int64_t)XPmax * 512)) --TR;
@@ -550,7 +568,7 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
     {   // repack the weights: [G][NTAP][MM][KK]
         const int64_t total = (int64_t)G * NTAP * MM * KK;
         COT_LAUNCH(conv3x3g_repack_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, (const bf16_t*)w,
-                   (bf16_t*)ws, G, MM, KX, KK, NTAP, mode);
+                   (bf16_t*)ws, G, MM, KX, KK, NTAP, mode, MBLK);
         int rc = check_launch("conv3x3g_repack_kernel");
         if (rc) return rc;
     }
@@ -559,6 +577,12 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
         if (MM <= 32) return launch_c3<2, 2, 1, 0, 2>(a, blocks, stream);
         if (MM <= 64) return launch_c3<2, 4, 1, 0, 2>(a, blocks, stream);
         return launch_c3<2, 8, 1, 0, 2>(a, blocks, stream);
+    }
+    if (big_cols == 256) {
+        if (K16) return launch_c3<2, 1, 0, 1, 3>(a, blocks, stream);
+        if (MM <= 32) return launch_c3<2, 2, 0, 0, 5>(a, blocks, stream);
+        if (MM <= 64) return launch_c3<2, 4, 0, 0, 5>(a, blocks, stream);
+        return launch_c3<2, 8, 0, 0, 5>(a, blocks, stream);
     }
     if (K16) return launch_c3<4, 1, 0, 1, 3>(a, blocks, stream);
     if (MM <= 32) return launch_c3<4, 2, 0, 0, 5>(a, blocks, stream);

@@ -192,8 +192,10 @@ class SplitAttnConv2d(nn.Module):
 
     def forward(self, x):
         x = conv3x3(self.conv, x)  # the module itself unless COT_CONV3X3=hip and the tensor qualifies
-        if (isinstance(self.bn0, nn.BatchNorm2d) and self.drop_block is None and isinstance(self.act0, nn.ReLU)):
-            x = fused_bn_act(x, self.bn0, "relu")  # one fused op when eligible, the same modules otherwise
+        a0 = "relu" if isinstance(self.act0, nn.ReLU) else ("silu" if isinstance(self.act0, nn.SiLU) else None)
+        if isinstance(self.bn0, nn.BatchNorm2d) and self.drop_block is None and a0 is not None:
+            # one fused op when eligible, the same modules otherwise (SE-CoTNetD passes act_layer = swish: models/cotnet_hybrid.py:143-146)
+            x = fused_bn_act(x, self.bn0, a0)
         else:
             if self.bn0 is not None:
                 x = self.bn0(x)

@@ -103,5 +103,6 @@ def se_mlp(gap, se):
     # BatchNorm over the batch alone ([B, A, 1, 1]): the library's small-batch fp64 path when eligible (csrc/bn_act.hip
     # "small batches": MIOpen's fp32 kernel is 300x off an fp64 evaluation here -- what kept the 7x7 layer above 1e-3)
     h4 = h[:, :, None, None]
-    h = fused_bn_act(h4.contiguous(), bn, "relu") if isinstance(act, nn.ReLU) else act(bn(h4))
+    a = "relu" if isinstance(act, nn.ReLU) else ("silu" if isinstance(act, nn.SiLU) else None)
+    h = fused_bn_act(h4.contiguous(), bn, a) if a is not None else act(bn(h4))
     return F.linear(h.flatten(1), c3.weight.flatten(1), c3.bias)

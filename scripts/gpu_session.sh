@@ -27,6 +27,12 @@ case $what in
         COT_KERNEL_SUMMARY=$O/${T}_cotnext101_kernels.json timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > $O/${T}_bench_cotnext101_prof.json 2> $O/${T}_bench_cotnext101.err
         timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/${T}_bench_cotnext101.json 2>> $O/${T}_bench_cotnext101.err
         timeout 400 python bench.py --model cotnext101_2x48d --batch 64 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --tune 36=0 > $O/${T}_bench_cotnext101_general.json 2>> $O/${T}_bench_cotnext101.err ;;
+  sec3x3) timeout 600 python -m pytest tests/test_conv3x3g_gpu.py tests/test_dispatch_parity_gpu.py tests/test_se_gate_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "conv3x3 or Conv3x3 or matches or se_" 2>&1 | tail -6 > $O/${T}_sec3x3_tests.log
+        COT_KERNEL_SUMMARY=$O/${T}_secotnetd_kernels.json timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline > $O/${T}_bench_secotnetd_prof.json 2> $O/${T}_bench_secotnetd.err
+        timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/${T}_bench_secotnetd.json 2>> $O/${T}_bench_secotnetd.err ;;
+  sablock) timeout 600 python -m pytest tests/test_fused_layer_gpu.py tests/test_se_gate_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 2>&1 | tail -8 > $O/${T}_sablock_tests.log
+        COT_KERNEL_SUMMARY=$O/${T}_secotnetd_kernels.json timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline > $O/${T}_bench_secotnetd_prof.json 2> $O/${T}_bench_secotnetd.err
+        timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/${T}_bench_secotnetd.json 2>> $O/${T}_bench_secotnetd.err ;;
   aggparity) timeout 600 python -m pytest tests/test_dispatch_parity_gpu.py tests/test_agg_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "agg or Agg or oracle or n80 or N80" 2>&1 | tail -30 > $O/${T}_aggparity.log ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac

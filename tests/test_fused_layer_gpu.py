@@ -103,6 +103,26 @@ def test_single_node_bottleneck_against_fp32_truth(kind):
     assert node.startswith("_BottleneckNode")
 
 
+@pytest.mark.parametrize("inpl,planes,hw", [(256, 64, 40), (512, 128, 20), (1024, 256, 20)])
+def test_single_node_split_attn_block_against_fp32_truth(inpl, planes, hw):
+    """SE-CoTNetD's SplitAttnConv2d(radix=1) bottleneck (identity shortcut) as ONE node (cot_layer_fused._SplitAttnBlockNode) at the
+    widths / maps of se_cotnetd_152_L (320 x 320 input): conv1 -> bn1+relu -> dense 3x3 -> bn0+swish -> SE gate -> conv3 -> bn3 +
+    residual + relu, against the fp32 truth; 256 -> 256 at 20 x 20 runs the LDS 3x3 kernel with two 128-row blocks per group"""
+    from cotnet_amd.cotnet_hybrid import CoTBottleneck
+    from cotnet_amd.layers import get_act_layer
+    torch.manual_seed(hw + planes)
+    blk = CoTBottleneck(2, inpl, planes, conv_dim={64, 128}, c4_dim=256, c4_idx={0, 2}, radix=1, act_layer=get_act_layer("swish")).to(DEV).train()
+    assert type(blk.conv2).__name__ == "SplitAttnConv2d"
+    with torch.no_grad():
+        blk.bn3.weight.fill_(0.8)
+    blk = to_mixed_bf16(blk)
+    x = torch.randn(8, inpl, hw, hw, device=DEV).bfloat16()
+    g = torch.randn(8, inpl, hw, hw, device=DEV).bfloat16()
+    truth.check_against_truth(blk, x, g, cand=truth.SINGLE_NODE)
+    *_, node = truth.run(blk, x, g, want_module=True, **truth.SINGLE_NODE)
+    assert node.startswith("_SplitAttnBlockNode")
+
+
 class _FixedDropPath(torch.nn.Module):
     """stochastic depth with a GIVEN per-sample scale (0 or 1 / keep): what models/layers/drop.py:140-168 computes, minus the draw"""
 

@@ -1008,6 +1008,11 @@ def test_conv3x3_grouped_weight_gradient_guard_decides_the_kernel():
     (2, 384, 8, 14, 14),   # FLAT, 48 per group: two chunks (the second half padding), 48 of 64 rows
     (3, 768, 8, 7, 7),     # FLAT, 96 per group: three whole chunks, 96 of 128 rows, 7 x 7
     (1, 96, 2, 24, 16),    # BIG, 48 per group, two groups, the last one's padding runs past the tensor
+    # more than 128 output channels per group (SE-CoTNetD's dense SplitAttn convolutions, 256 -> 256): row blocks of 128 as
+    # "virtual groups" that share the group's input
+    (2, 256, 1, 10, 10),   # FLAT, one real group, two row blocks, 8 channel chunks
+    (1, 512, 2, 20, 20),   # BIG, two real groups x two row blocks
+    (1, 64, 1, 6, 160),    # BIG, rows of 160 pixels (SE-CoTNetD's stem / first block at 320 x 320): one image row per tile
 ])
 def test_conv3x3_grouped_lds_kernels(N, C, G, H, W):
     """csrc/conv_lds.hip conv3x3g_lds_fwd (forward and data gradient incl. accumulate) against torch on the same rounded
@@ -1410,6 +1415,71 @@ def test_fused_bottleneck_node_on_emulated_kernels(project, monkeypatch):
         assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == p.dtype, n_
         if pr[n_].grad.float().abs().max() > 1e-3 * top and not n_.endswith("se.0.bias"):  # (bias before a BatchNorm)
             assert rel(p.grad, pr[n_].grad) < 0.12, (n_, rel(p.grad, pr[n_].grad))   # (a wrong term shows as > 0.3)
+    br, bf = dict(perop.named_buffers()), dict(node.named_buffers())
+    for n_ in br:
+        assert torch.allclose(bf[n_].float(), br[n_].float(), atol=1e-3, rtol=1e-3), n_
+    for cache in caches:
+        cache.clear()
+
+
+@pytest.mark.parametrize("act", ["swish", "relu"])
+def test_fused_split_attn_block_node_on_emulated_kernels(act, monkeypatch):
+    """SE-CoTNetD's SplitAttnConv2d(radix=1) bottleneck (models/cotnet_hybrid.py:138-146 + models/layers/split_attn.py:62-88) as
+    one autograd node (cot_layer_fused._SplitAttnBlockNode) against the same block node per op, both on the emulated kernels"""
+    import copy
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, radix_tail, se_gate
+    from cotnet_amd.cotnet_hybrid import CoTBottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    from cotnet_amd.layers import get_act_layer
+    torch.manual_seed(12)
+    N, H, W = 4, 6, 6
+    # width 64 is in conv_dim: a SplitAttn block; act_layer = swish is what the se_cotnetd_* entry points pass (:383-389)
+    node = CoTBottleneck(1, 256, 64, conv_dim={64}, c4_dim=256, c4_idx=set(), radix=1,
+                         act_layer=get_act_layer(act) if act == "swish" else torch.nn.ReLU).train()
+    assert type(node.conv2).__name__ == "SplitAttnConv2d"
+    with torch.no_grad():
+        for p in node.parameters():
+            if p.ndim == 1:
+                p.add_(0.3 * torch.randn_like(p))
+        node.bn3.weight.fill_(0.8)
+    node = to_mixed_bf16(node)
+    perop = copy.deepcopy(node)
+    x = torch.randn(N, 256, H, W).bfloat16()
+    g = torch.randn(N, 256, H, W).bfloat16()
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail, se_gate):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(c1, "MODE", "hip")
+    monkeypatch.setattr(c3, "MODE", "hip")
+    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, clf._SASIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
+    for cache in caches:
+        cache.clear()
+    monkeypatch.setattr(clf, "ENABLED", False)
+    xr = x.clone().requires_grad_(True)
+    yr = perop(xr)
+    assert "SplitAttn" not in yr.grad_fn.name()
+    yr.backward(g)
+    monkeypatch.setattr(clf, "ENABLED", True)
+    xf = x.clone().requires_grad_(True)
+    assert clf.sa_block_eligible(node, xf)
+    yf = node(xf)
+    assert yf.grad_fn.name().startswith("_SplitAttnBlockNode")
+    yf.backward(g)
+
+    def relmax(a, b):
+        return ((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-6)).item()
+
+    def rel(a, b):
+        return ((a.float() - b.float()).abs().mean() / (b.float().abs().mean() + 1e-6)).item()
+
+    assert relmax(yf, yr.detach()) < 1e-2
+    assert rel(xf.grad, xr.grad) < 6e-2
+    pr = dict(perop.named_parameters())
+    top = max(q.grad.float().abs().max() for q in pr.values())
+    for n_, p in node.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == p.dtype, n_
+        if pr[n_].grad.float().abs().max() > 1e-3 * top and not n_.endswith("fc1.bias"):  # (bias in front of a BatchNorm)
+            assert rel(p.grad, pr[n_].grad) < 0.12, (n_, rel(p.grad, pr[n_].grad))
     br, bf = dict(perop.named_buffers()), dict(node.named_buffers())
     for n_ in br:
         assert torch.allclose(bf[n_].float(), br[n_].float(), atol=1e-3, rtol=1e-3), n_
