@@ -68,6 +68,12 @@ SYMBOLS = {
     "cot_radix_mix_backward_apply": (_I, [_P] * 5 + [_I, _I, _I, _I, _P]),
     "cot_group_norm9_forward": (_I, [_P] * 6 + [_I, _I, _I, ctypes.c_float, _I, _P]),
     "cot_group_norm9_backward": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
+    "cot_gn9_stats_floats": (ctypes.c_int64, [_I, _I, _I]),
+    "cot_gn9_fused_covers": (_I, [_I] * 5),
+    "cot_conv1x1_forward_gn9": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cot_gn9_stats_finalize": (_I, [_P, _P, _P, _I, _I, _I, ctypes.c_float, _P]),
+    "cot_agg_gn9_forward": (_I, [_P] * 6 + [_I, _P, _G, _I, _P]),
+    "cot_agg_gn9_backward": (_I, [_P] * 7 + [_I, _P, _P, _G, _I, _P]),
     "cot_subsample2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_subsample2_backward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_avgpool3x3s2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),

@@ -201,6 +201,18 @@ class _Side:
             self.keep.clear()
 
 
+GN_FUSED = os.environ.get("COT_GN_FUSED", "1") != "0"  # GroupNorm-9 statistics in embed[3]'s epilogue + normalisation in the aggregation's prologue
+_GN_OK = _lib.register_cache({})
+
+
+def _gn_fused_ok(L, Ch, HW, W):
+    k = (Ch, HW, W)
+    v = _GN_OK.get(k)
+    if v is None:
+        v = _GN_OK[k] = bool(L.cot_gn9_fused_covers(Ch, Ch, 0, HW, W))
+    return v
+
+
 _SIZES = _lib.register_cache({})  # (N, C, H, W, A) -> (workspace bytes, bn workspace floats for C, C/2 and the se branch's A channels)
 _MASKS = {}
 
@@ -396,14 +408,26 @@ def _cot_forward(L, layer, x):
     s_e = stat(Ch, nws_h)
     _bn_fwd(L, e0, e1, pl.em1, s_e, 2 * Ch, N, Ch, HW, 1)
     e3 = new(Ce)
+    gn = pl.gn
+    # GroupNorm of the logits fused into its neighbours: statistics out of embed[3]'s epilogue, normalisation in the
+    # aggregation's prologue -- the normalised tensor `w` is never materialised (stages with planes of more than 256 pixels)
+    fused_gn = GN_FUSED and not GX and _gn_fused_ok(L, Ch, HW, W)
     if GX:
         _ck(L.cot_conv1x1g_forward(_p(e1), _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, 2, HW, BF16, st),
             "cot_conv1x1g_forward")
+    elif fused_gn:
+        part = torch.empty(int(L.cot_gn9_stats_floats(N, Ce, HW)), dtype=torch.float32, device=dev)
+        _ck(L.cot_conv1x1_forward_gn9(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), _p(part), N, Ch, Ce, HW, BF16, st),
+            "cot_conv1x1_forward_gn9")
     else:
         _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, HW, BF16, st),
             "cot_conv1x1_forward")
-    gn = pl.gn
-    if HW <= 8192:  # one (image, group) fits a workgroup's registers: 1 read + 1 write (csrc/group_norm9.hip)
+    if fused_gn:
+        w = None
+        gn_mean = torch.empty(2 * N * gn.num_groups, dtype=torch.float32, device=dev)
+        gn_rstd = gn_mean[N * gn.num_groups:]
+        _ck(L.cot_gn9_stats_finalize(_p(part), _p(gn_mean), _p(gn_rstd), N, Ce, HW, float(gn.eps), st), "cot_gn9_stats_finalize")
+    elif HW <= 8192:  # one (image, group) fits a workgroup's registers: 1 read + 1 write (csrc/group_norm9.hip)
         w = new(Ce)
         gn_mean = torch.empty(2 * N * gn.num_groups, dtype=torch.float32, device=dev)
         gn_rstd = gn_mean[N * gn.num_groups:]
@@ -425,7 +449,11 @@ def _cot_forward(L, layer, x):
     geom = _lib.AggGeom(2 * N, C // 2, H, W, 1, C // 16, 3, 3, 1, 1, 1, 1, 1, 1) if GX else \
         _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
     a, y = new(C), new(C)
-    _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
+    if fused_gn:
+        _ck(L.cot_agg_gn9_forward(_p(v), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(gn.bias), gn.num_groups, _p(a),
+                                  ctypes.byref(geom), BF16, st), "cot_agg_gn9_forward")
+    else:
+        _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
     s_y = stat(C, nws_c)
     _bn_fwd(L, a, y, pl.bn, s_y, 2 * C, N, C, HW, 2)
     # radix-2 split attention                                                                    (ref :92-104)
@@ -495,9 +523,14 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     # bn + swish, aggregation
     ga = torch.empty_like(a)
     d_bn_w, d_bn_b = _bn_bwd(L, gy, a, None, ga, pl.bn, s_y, N, C, HW, 2, nws_c)
-    gv, gw = torch.empty_like(v), torch.empty_like(w)
-    _ck(L.cot_agg_backward(_p(ga), _p(v), _p(w), _p(gv), _p(gw), ctypes.byref(geom), BF16, _lib.COT_NCHW, st),
-        "cot_agg_backward")
+    gv, gw = torch.empty_like(v), torch.empty_like(e3)
+    if w is None:  # (the forward normalised the logits inside the aggregation: so does the backward; gw = d / d normalised weights)
+        gn_ = pl.gn
+        _ck(L.cot_agg_gn9_backward(_p(ga), _p(v), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn_.weight), _p(gn_.bias), gn_.num_groups,
+                                   _p(gv), _p(gw), ctypes.byref(geom), BF16, st), "cot_agg_gn9_backward")
+    else:
+        _ck(L.cot_agg_backward(_p(ga), _p(v), _p(w), _p(gv), _p(gw), ctypes.byref(geom), BF16, _lib.COT_NCHW, st),
+            "cot_agg_backward")
     # values branch: bn, conv1x1 -> first contribution to dx
     gv_pre = ga  # (reuse: ga is dead)
     d_cv_w, d_cv_b = _bn_bwd(L, gv, v_pre, None, gv_pre, cv1, s_v, N, C, HW, 0, nws_c)

@@ -116,11 +116,29 @@ __device__ __forceinline__ void dot2_stage(const bf16_t* __restrict__ gout, cons
 // with the buffer about to be refilled), issue the next copies, compute.
 // (Holding the allocation to 96 VGPRs -- five waves per SIMD instead of four -- spills 11 values into the channel loop: 56.7 us
 // against 34.7 at 56 x 56, profiles/r04_agg_dot2_in_model_tuning.log.  Not built.)
+// GroupNorm-9 prologue (gn.mean != NULL): `w` holds the RAW logits; the weights are normalised on the fly with the formula and
+// the rounding point of csrc/group_norm9.hip (see Gn9Dot2 / agg_fwd_nchw_k3_lds<SM = 2>), `gw` is the gradient w.r.t. the
+// NORMALISED weights (what cot_group_norm9_backward takes as dy).
+struct Gn9Dot2 {
+    const float* mean;
+    const float* rstd;
+    const bf16_t* gamma;
+    const bf16_t* beta;
+    int gimg;
+};
+__device__ __forceinline__ uint32_t gn9_word(uint32_t v, float ga, float be) {
+    const float lo = __builtin_bit_cast(float, v << 16) * ga + be, hi = __builtin_bit_cast(float, v & 0xffff0000u) * ga + be;
+    Vec<bf16_t, 2> o;
+    o.v[0] = (bf16_t)lo;
+    o.v[1] = (bf16_t)hi;
+    return __builtin_bit_cast(uint32_t, o);
+}
+
 template <int W, int P, int GS, int JP, int NW, int SAFE, int ROLL, int DB>
 __global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ x,
                                                                const bf16_t* __restrict__ w, bf16_t* __restrict__ gx,
                                                                bf16_t* __restrict__ gw, int C, int wC, int H, int tiles_per_n,
-                                                               int64_t elems, int xcd_remap) {
+                                                               int64_t elems, int xcd_remap, Gn9Dot2 gn) {
     typedef Dot2Shape<W, P, GS, NW> S;
     constexpr int PW = S::PW;
     static_assert(JP % 2 == 0, "channels are processed in pairs");
@@ -174,6 +192,13 @@ __global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __
     uint32_t wpa[3][P], wpb[3][P];
     {
         const bf16_t* wp = w + plane * 9 * HW + w0;
+        float gmu = 0.f, grs = 1.f;
+        int gq = 0;
+        if (gn.mean) {
+            gmu = gn.mean[plane];
+            grs = gn.rstd[plane];
+            gq = (int)(plane % gn.gimg);
+        }
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) {
             const int kh = 2 - rr, hr = h - 1 + rr;
@@ -182,7 +207,12 @@ __global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __
             uint32_t tv[3][PW];
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const Vec<uint32_t, PW> v = *reinterpret_cast<const Vec<uint32_t, PW>*>(wp + (int64_t)(kh * 3 + kw) * HW + (int64_t)hc * W);
+                Vec<uint32_t, PW> v = *reinterpret_cast<const Vec<uint32_t, PW>*>(wp + (int64_t)(kh * 3 + kw) * HW + (int64_t)hc * W);
+                if (gn.mean) {  // (wave-uniform) GroupNorm of the logits, as the forward pass computed it
+                    const float ga = (float)gn.gamma[gq * 9 + kh * 3 + kw] * grs, be = (float)gn.beta[gq * 9 + kh * 3 + kw] - gmu * ga;
+#pragma unroll
+                    for (int k = 0; k < PW; ++k) v.v[k] = gn9_word(v.v[k], ga, be);
+                }
 #pragma unroll
                 for (int k = 0; k < PW; ++k) tv[kw][k] = rok ? v.v[k] : 0u;  // (selection: a clamped row's weights never count)
             }
@@ -334,7 +364,7 @@ int set_tuning_dot2(int key, int value) {
 
 template <int W, int P, int GS, int JP, int NW>
 static int launch_dot2_nw(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
-                          hipStream_t s) {
+                          hipStream_t s, const Gn9Dot2& gn) {
     typedef Dot2Shape<W, P, GS, NW> S;
     const bool safe = g_dot2[4] != 0;
     const int tiles = (g.wC * g.H + S::TR - 1) / S::TR;
@@ -346,7 +376,7 @@ static int launch_dot2_nw(const bf16_t* gout, const bf16_t* x, const bf16_t* w, 
     const dim3 grid((unsigned)((int64_t)tiles * g.N)), block(NW * 64);
 #define COT_DOT2_GO(SAFE_, DB_)                                                                                                \
     COT_LAUNCH((agg_bwd_nchw_k3_dot2<W, P, GS, JP, NW, SAFE_, ROLL, DB_>), grid, block, lds, s, gout, x, w, gx, gw, g.C, g.wC, g.H, \
-               tiles, ne, xcd)
+               tiles, ne, xcd, gn)
     constexpr int DBV = JP < 8 ? 1 : 0;
     if (safe && db) COT_DOT2_GO(1, DBV);
     else if (safe) COT_DOT2_GO(1, 0);
@@ -366,7 +396,7 @@ static inline int default_nw(int W) { return 4; }
 
 template <int W, int P, int GS, int JP>
 static int launch_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
-                       hipStream_t s) {
+                       hipStream_t s, const Gn9Dot2& gn) {
     // waves per workgroup: 7 (5) make TR = 28 or 56 (20 or 40) rows, i.e. tiles that start and end at plane boundaries of the
     // 56 / 28 / 14 (40 / 20 / 10) row planes -- no halo rows left to re-read; anything else 4.  (8 waves measured 20-25 %
     // slower than 4: not built.)
@@ -377,25 +407,38 @@ static int launch_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf1
         if (!(TRn % g.H == 0 || g.H % TRn == 0)) nw = 4;
     }
     switch (nw) {
-        case 2: return launch_dot2_nw<W, P, GS, JP, 2>(gout, x, w, gx, gw, g, s);
-        case 7: return launch_dot2_nw<W, P, GS, JP, 7>(gout, x, w, gx, gw, g, s);
-        default: return launch_dot2_nw<W, P, GS, JP, 4>(gout, x, w, gx, gw, g, s);
+        case 2: return launch_dot2_nw<W, P, GS, JP, 2>(gout, x, w, gx, gw, g, s, gn);
+        case 7: return launch_dot2_nw<W, P, GS, JP, 7>(gout, x, w, gx, gw, g, s, gn);
+        default: return launch_dot2_nw<W, P, GS, JP, 4>(gout, x, w, gx, gw, g, s, gn);
     }
 }
 
 template <int W, int P, int GS>
 static int launch_dot2_jp(int JP, const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
-                          hipStream_t s) {
+                          hipStream_t s, const Gn9Dot2& gn) {
     switch (JP) {  // (8 = everything staged at once, channel-pair loop rolled)
-        case 8: return launch_dot2<W, P, GS, 8>(gout, x, w, gx, gw, g, s);
-        case 4: return launch_dot2<W, P, GS, 4>(gout, x, w, gx, gw, g, s);
-        default: return launch_dot2<W, P, GS, 2>(gout, x, w, gx, gw, g, s);
+        case 8: return launch_dot2<W, P, GS, 8>(gout, x, w, gx, gw, g, s, gn);
+        case 4: return launch_dot2<W, P, GS, 4>(gout, x, w, gx, gw, g, s, gn);
+        default: return launch_dot2<W, P, GS, 2>(gout, x, w, gx, gw, g, s, gn);
     }
 }
 
 // -> -1: geometry not covered (caller keeps agg_bwd_nchw_k3_lds); else the launch status
+static int dot2_run(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g, hipStream_t s,
+                    const Gn9Dot2& gn);
 int agg_backward_nchw_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
                            hipStream_t s) {
+    return dot2_run(gout, x, w, gx, gw, g, s, Gn9Dot2{nullptr, nullptr, nullptr, nullptr, 1});
+}
+// the same with the GroupNorm-9 prologue (w = raw logits); -1: geometry not covered
+int agg_gn9_backward_nchw_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* logits, const float* mean, const float* rstd,
+                               const bf16_t* gamma, const bf16_t* beta, int gimg, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g,
+                               hipStream_t s) {
+    if (!mean || !rstd || !gamma || !beta || gimg <= 0) return -1;
+    return dot2_run(gout, x, logits, gx, gw, g, s, Gn9Dot2{mean, rstd, gamma, beta, gimg});
+}
+static int dot2_run(const bf16_t* gout, const bf16_t* x, const bf16_t* w, bf16_t* gx, bf16_t* gw, const cot_agg_geom& g, hipStream_t s,
+                    const Gn9Dot2& gn) {
     if (!g_dot2[0] || !gx || !gw || g.heads != 1 || g.wC <= 0 || g.C % g.wC != 0) return -1;
     const int J = g.C / g.wC;
     const int64_t HW = (int64_t)g.H * g.W;
@@ -405,13 +448,13 @@ int agg_backward_nchw_dot2(const bf16_t* gout, const bf16_t* x, const bf16_t* w,
     while (JP > 2 && J % JP != 0) JP >>= 1;
     if (J % JP != 0) return -1;
     switch (g.W) {
-        case 56: return launch_dot2_jp<56, 4, 16>(JP, gout, x, w, gx, gw, g, s);
-        case 28: return launch_dot2_jp<28, 4, 8>(JP, gout, x, w, gx, gw, g, s);
-        case 14: return launch_dot2_jp<14, 2, 8>(JP, gout, x, w, gx, gw, g, s);
+        case 56: return launch_dot2_jp<56, 4, 16>(JP, gout, x, w, gx, gw, g, s, gn);
+        case 28: return launch_dot2_jp<28, 4, 8>(JP, gout, x, w, gx, gw, g, s, gn);
+        case 14: return launch_dot2_jp<14, 2, 8>(JP, gout, x, w, gx, gw, g, s, gn);
         // SE-CoTNetD at 320 x 320 (models/cotnet_hybrid.py: CoT layers at 40 x 40, 20 x 20 and 10 x 10)
-        case 40: return launch_dot2_jp<40, 4, 16>(JP, gout, x, w, gx, gw, g, s);
-        case 20: return launch_dot2_jp<20, 4, 8>(JP, gout, x, w, gx, gw, g, s);
-        case 10: return launch_dot2_jp<10, 2, 8>(JP, gout, x, w, gx, gw, g, s);
+        case 40: return launch_dot2_jp<40, 4, 16>(JP, gout, x, w, gx, gw, g, s, gn);
+        case 20: return launch_dot2_jp<20, 4, 8>(JP, gout, x, w, gx, gw, g, s, gn);
+        case 10: return launch_dot2_jp<10, 2, 8>(JP, gout, x, w, gx, gw, g, s, gn);
         default: return -1;
     }
 }

@@ -607,11 +607,24 @@ __device__ __forceinline__ void stage_slabs(const T* __restrict__ base, int64_t 
 // F.softmax(w, dim=3) + LocalConvolution, models/lr_net.py:94-96): `w` holds LOGITS, the lane normalises its own
 // 9 taps per pixel in registers (the taps of a pixel all live in one lane, so no cross-lane reduction is needed),
 // writes the probabilities to `probs` (what backward needs) and aggregates with them.
+// SM = 2: GroupNorm-9 applied in the prologue (CotLayer's own normalisation of its logits, models/cotnet.py:55-56,:84-85): `w`
+// holds the RAW logits of embed[3], `gn` the statistics (from that convolution's epilogue, cot_conv1x1_forward_gn9 +
+// cot_gn9_stats_finalize) and the affine parameters; the lane normalises its own 9 x P values exactly as csrc/group_norm9.hip
+// does (ga = gamma * rstd, be = beta - mean * ga, x * ga + be, rounded once to the storage type) -- the normalised tensor is
+// never written.  heads == 1.
+template <typename T> struct Gn9Args {
+    const float* mean;   // [N * wC]  (plane = n * wC + wc = image * groups + group)
+    const float* rstd;
+    const T* gamma;      // [groups_per_image * 9]
+    const T* beta;
+    int gimg;            // GroupNorm groups per image (= wC, or 2 wC for CoXtLayer's group -> batch fold)
+};
+
 template <typename T, int P, int XCHG, int SM>
 __global__ __launch_bounds__(512) void agg_fwd_nchw_k3_lds(const T* __restrict__ x, const T* __restrict__ w,
                                                           T* __restrict__ out, int heads, int C, int wC, int H, int W,
                                                           int R, int tiles_per_nh, int sle, int64_t x_elems,
-                                                          T* __restrict__ probs, int xcd_remap) {
+                                                          T* __restrict__ probs, int xcd_remap, Gn9Args<T> gn) {
     typedef typename AccOf<T>::type A;
     constexpr int VE = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
@@ -645,7 +658,18 @@ __global__ __launch_bounds__(512) void agg_fwd_nchw_k3_lds(const T* __restrict__
         const T* wp = w + (nh * wC + wc) * 9 * HW + (int64_t)h * W + w0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[t] = ldv<T, P>(wp + t * HW);
-        if (SM) {
+        if (SM == 2) {
+            const int64_t pl = nh * wC + wc;
+            const int gq = (int)(pl % gn.gimg);
+            const A mu = (A)gn.mean[pl], rs = (A)gn.rstd[pl];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const A ga = (A)gn.gamma[gq * 9 + t] * rs, be = (A)gn.beta[gq * 9 + t] - mu * ga;
+#pragma unroll
+                for (int i = 0; i < P; ++i) wr[t].v[i] = (T)((A)wr[t].v[i] * ga + be);
+            }
+        }
+        if (SM == 1) {
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 A m = (A)wr[0].v[i];
@@ -959,10 +983,10 @@ static int launch_fwd_k3(const T* x, const T* w, T* out, const cot_agg_geom& g, 
             const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
             if (xchg_mode() == 0)
                 COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
-                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, xcd_order(g.H, g.W));
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, xcd_order(g.H, g.W), Gn9Args<T>{});
             else
                 COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1, 0>), grid, block, p.lds_bytes, s, x, w, out, g.heads, g.C,
-                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, xcd_order(g.H, g.W));
+                                   g.wC, g.H, g.W, p.R, p.tiles, p.sle, xe, (T*)nullptr, xcd_order(g.H, g.W), Gn9Args<T>{});
             g_last_kernel = "agg_fwd_nchw_k3_lds";
             return check_launch(g_last_kernel);
         }
@@ -1118,10 +1142,10 @@ static int launch_softmax_fwd(const T* x, const T* logits, T* out, T* probs, con
     const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
     if (xchg_mode() == 0)
         COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 0, 1>), grid, block, p.lds_bytes, s, x, logits, out, g.heads, g.C, g.wC,
-                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, xcd_order(g.H, g.W));
+                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, xcd_order(g.H, g.W), Gn9Args<T>{});
     else
         COT_LAUNCH((agg_fwd_nchw_k3_lds<T, P, 1, 1>), grid, block, p.lds_bytes, s, x, logits, out, g.heads, g.C, g.wC,
-                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, xcd_order(g.H, g.W));
+                   g.H, g.W, p.R, p.tiles, p.sle, xe, probs, xcd_order(g.H, g.W), Gn9Args<T>{});
     g_last_kernel = "agg_fwd_nchw_k3_lds<softmax>";
     return check_launch(g_last_kernel);
 }
@@ -1142,6 +1166,35 @@ static int launch_softmax_bwd(const T* gout, const T* x, const T* probs, T* gx, 
                    glogits, g.C, g.wC, g.H, g.W, p.R, p.tiles, p.sle, JP, ne, xcd_order(g.H, g.W));
     g_last_kernel = "agg_bwd_nchw_k3_lds<softmax>";
     return check_launch(g_last_kernel);
+}
+
+// GroupNorm-9 prologue (SM = 2): bf16, the model geometries of the LDS kernel; COT_ERR_UNSUPPORTED otherwise
+template <int P>
+static int launch_gn9_fwd(const bf16_t* x, const bf16_t* logits, bf16_t* out, const cot_agg_geom& g, const Gn9Args<bf16_t>& gn,
+                          hipStream_t s) {
+    const LdsPlan p = plan_lds<bf16_t>(g, P, g.C / g.wC);
+    if (!p.ok) return COT_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((int64_t)p.tiles * g.N)), block(p.nthreads);
+    const int64_t xe = (int64_t)g.N * g.C * g.H * g.W;
+    if (xchg_mode() == 0)
+        COT_LAUNCH((agg_fwd_nchw_k3_lds<bf16_t, P, 0, 2>), grid, block, p.lds_bytes, s, x, logits, out, 1, g.C, g.wC, g.H, g.W, p.R,
+                   p.tiles, p.sle, xe, (bf16_t*)nullptr, xcd_order(g.H, g.W), gn);
+    else
+        COT_LAUNCH((agg_fwd_nchw_k3_lds<bf16_t, P, 1, 2>), grid, block, p.lds_bytes, s, x, logits, out, 1, g.C, g.wC, g.H, g.W, p.R,
+                   p.tiles, p.sle, xe, (bf16_t*)nullptr, xcd_order(g.H, g.W), gn);
+    g_last_kernel = "agg_fwd_nchw_k3_lds<gn9>";
+    return check_launch(g_last_kernel);
+}
+int agg_gn9_forward_nchw(const bf16_t* x, const bf16_t* logits, const float* mean, const float* rstd, const bf16_t* gamma,
+                         const bf16_t* beta, int gimg, bf16_t* out, const cot_agg_geom& g, hipStream_t s) {
+    if (!is_k3_fast(g) || g.heads != 1) return COT_ERR_UNSUPPORTED;
+    const Gn9Args<bf16_t> gn{mean, rstd, gamma, beta, gimg};
+    switch (pick_P<bf16_t>(g.W, g_tune[1])) {
+        case 8: return launch_gn9_fwd<8>(x, logits, out, g, gn, s);
+        case 4: return launch_gn9_fwd<4>(x, logits, out, g, gn, s);
+        case 2: return launch_gn9_fwd<2>(x, logits, out, g, gn, s);
+        default: return COT_ERR_UNSUPPORTED;
+    }
 }
 
 template <typename T>

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
 
     EpiArgs e;
     e.y1 = a.y1; e.y2 = a.y2; e.bias = a.bias; e.m1 = a.m1; e.M = M; e.HW = HW; e.N = a.N; e.ni = a.ni;
-    e.ys1 = a.ys1; e.ys2 = a.ys2;
+    e.ys1 = a.ys1; e.ys2 = a.ys2; e.stats = a.stats; e.ptiles = a.ptiles;
     e.n0 = n0; e.p0 = p0; e.m0 = m0; e.mv = min(BM, M - m0); e.ncols = ncols; e.accumulate = a.accumulate;
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
@@ -315,6 +315,7 @@ int conv1x1_lds_gemm2(const C1LdsArgs& a0, hipStream_t stream) {
         if (tr) COT_C2W(CB_, MB_, FLAT_, NS_, 1, 0);                                                       \
         COT_C2W(CB_, MB_, FLAT_, NS_, 0, 0);                                                               \
     } while (0)
+    if (a.stats && HW <= 256) return -1;  // (epilogue statistics: 128-pixel tiles only)
     if (HW > 256) {  // BIG: 128-pixel tiles of one image; three stages, several workgroups per CU
         a.ptiles = ceil_div(HW, 128);
         const int tiles = N * a.ptiles;

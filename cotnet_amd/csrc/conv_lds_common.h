@@ -124,6 +124,10 @@ struct EpiArgs {
     int accumulate;      // bit 0: y1 += result, bit 1: y2 += result
     int64_t ys1, ys2;    // elements from one image to the next in y1 / y2 (dense: m1 * HW, (M - m1) * HW; larger when the slab is
                          // a channel range of a wider tensor: one group of a grouped convolution)
+    float* stats;        // NULL, or [N][ptiles][M][2]: per (image, pixel tile, channel) the sum and the sum of squares of the
+    int ptiles;          // tile's outputs AS STORED (rounded to bf16) -- the statistics of the consumer's normalisation come out
+                         // of the producing GEMM's epilogue (GroupNorm of the attention logits, cot_conv1x1_forward_gn9;
+                         // SURVEY 7.6).  BIG tiles only.
 };
 
 template <int CB, int MB, int FLAT, int WAVES>
@@ -167,6 +171,32 @@ __device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], cons
         }
     }
     COT_LDS_BARRIER();
+    if (!FLAT && a.stats) {
+        // one wave per channel row of the tile image in LDS: 2 columns per lane and round, fp32 sums over <= BPX values, wave
+        // reduction in a fixed order (deterministic); columns past the tile's end count as nothing
+        float* const srow = a.stats + (((int64_t)n0 * a.ptiles + p0 / BPX) * M + m0) * 2;
+        for (int r = wave; r < mv; r += WAVES) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c0 = 0; c0 < BPX; c0 += 128) {
+                const int c = c0 + 2 * lane;
+                if (c < ncols) {  // (ncols % 8 == 0: a lane's two columns are valid together)
+                    const float v0 = (float)ot[r * OS + c], v1 = (float)ot[r * OS + c + 1];
+                    s1 += v0 + v1;
+                    s2 += v0 * v0 + v1 * v1;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s1 += __shfl_xor(s1, o);
+                s2 += __shfl_xor(s2, o);
+            }
+            if (lane == 0) {
+                srow[2 * r] = s1;
+                srow[2 * r + 1] = s2;
+            }
+        }
+    }
     // copy out: 16 bytes per lane.  Output slabs (y1 | y2 at channel m1): a block lies in one slab or, when it straddles m1,
     // rows are routed one by one (m1 % 8 == 0 is checked on the host, so flat 16-byte pieces never straddle the slabs).
     if (!FLAT) {
@@ -223,6 +253,7 @@ struct C1LdsArgs {
     int k1, m1, N, K, M, HW;
     int64_t xs1, xs2;  // elements from one image to the next in x1 / x2 (dense: k1 * HW, (K - k1) * HW), and in
     int64_t ys1, ys2;  // y1 / y2 (dense: m1 * HW, (M - m1) * HW): a slab may be a channel range of a wider tensor
+    float* stats;      // NULL or the epilogue statistics workspace (EpiArgs::stats; BIG tiles only)
     int accumulate;    // bit 0: y1 += result, bit 1: y2 += result
     int wpacked;
     int mblocks;       // output-channel blocks of BM

@@ -156,7 +156,12 @@ static int g_conv3x3_merge = 1;  // tuning key 37: merged-groups 3x3 weight grad
 static inline bool g_conv_lds_tune_wgrad_off() { return (g_conv_lds_tune[2] >> 2) & 1; }  // tuning key 17 bit 2 (A/B)
 bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
 int conv1x1_lds_gemm(const void*, const void*, int, const void*, int, const void*, void*, void*, int, int, int, int, int, int,
-                     hipStream_t, int64_t xs = 0, int64_t ys = 0);
+                     hipStream_t, int64_t xs = 0, int64_t ys = 0, float* stats = nullptr);
+int gn9_stats_finalize(const float*, float*, float*, int, int, int, float, hipStream_t);
+int agg_gn9_forward_nchw(const bf16_t*, const bf16_t*, const float*, const float*, const bf16_t*, const bf16_t*, int, bf16_t*,
+                         const cot_agg_geom&, hipStream_t);
+int agg_gn9_backward_nchw_dot2(const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, const bf16_t*, const bf16_t*, int,
+                               bf16_t*, bf16_t*, const cot_agg_geom&, hipStream_t);
 int transpose_bf16(const void* src, void* dst, int R, int C, int pack, hipStream_t stream);
 bool conv1x1_wgrad_lds_covers(int N, int HW, int M, int J);
 int conv1x1_wgrad_lds_splits(int N, int M, int J, int HW, int has_bias);
@@ -484,6 +489,65 @@ int cot_conv1x1_forward(const void* x1, const void* x2, int c1, const void* weig
     if (p) prof::mark();
     const int rc = cot_conv1x1_forward_impl(x1, x2, c1, weight, bias, y, N, Ci, Co, HW, dtype, stream);
     if (p) prof::annotate_op(10, N, Ci, Co, HW, 1, dtype, 0);
+    return rc;
+}
+
+/* ---- GroupNorm-9 fused into its neighbours (SURVEY 7.6 / VERDICT r3 J1): statistics out of the producing convolution's
+ * epilogue, normalisation in the aggregation's prologue.  See include/cotnet_amd.h. */
+int64_t cot_gn9_stats_floats(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    return (int64_t)N * ceil_div(HW, 128) * C * 2;
+}
+int cot_gn9_fused_covers(int Ci, int c1, int two_slabs, int HW, int W) {
+    const bool w_ok = W == 56 || W == 28 || W == 14 || W == 40 || W == 20 || W == 10;  // (the packed dot-product backward's widths)
+    return (HW > 256 && HW % 8 == 0 && w_ok && HW % W == 0 && conv1x1_lds_covers(Ci, c1, two_slabs != 0, HW)) ? 1 : 0;
+}
+int cot_conv1x1_forward_gn9(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, float* stats,
+                            int N, int Ci, int Co, int HW, int dtype, void* stream) {
+    int rc = conv1x1_validate(N, Ci, Co, HW, c1, x2 != nullptr, dtype, Ci);
+    if (rc) return rc;
+    if (!x1 || !weight || !y || !stats) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x1, x2, weight, y, stats}))) return rc;
+    if (dtype != COT_BF16 || Co % 9 != 0)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_forward_gn9: COT_BF16, output channels a multiple of 9 (Co = %d)", Co);
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    rc = conv1x1_lds_gemm(x1, x2, c1, weight, 0, bias, y, nullptr, Co, N, Ci, Co, HW, 0, (hipStream_t)stream, 0, 0, stats);
+    if (p) prof::annotate_op(10, N, Ci, Co, HW, 1, dtype, 0);
+    if (rc == -1) return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_forward_gn9: geometry not covered (cot_gn9_fused_covers)");
+    return rc;
+}
+int cot_gn9_stats_finalize(const float* stats, float* mean, float* rstd, int N, int C, int HW, float eps, void* stream) {
+    if (N <= 0 || C <= 0 || HW <= 0 || C % 9 != 0) return set_error(COT_ERR_INVALID_ARG, "bad geometry N=%d C=%d HW=%d", N, C, HW);
+    if (!stats || !mean || !rstd) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    return gn9_stats_finalize(stats, mean, rstd, N, C, HW, eps, (hipStream_t)stream);
+}
+int cot_agg_gn9_forward(const void* x, const void* logits, const float* mean, const float* rstd, const void* gamma, const void* beta,
+                        int groups_per_image, void* out, const cot_agg_geom* g, int dtype, void* stream) {
+    int Ho, Wo, rc = validate(g, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !logits || !mean || !rstd || !gamma || !beta || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x, logits, out}))) return rc;
+    if (dtype != COT_BF16 || groups_per_image <= 0) return set_error(COT_ERR_UNSUPPORTED, "cot_agg_gn9_*: COT_BF16 only");
+    rc = agg_gn9_forward_nchw((const bf16_t*)x, (const bf16_t*)logits, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta,
+                              groups_per_image, (bf16_t*)out, *g, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_agg_gn9_forward: geometry not covered (3x3, stride 1, pad 1, one head)");
+    else g_kernel = last_kernel_nchw();
+    return rc;
+}
+int cot_agg_gn9_backward(const void* gout, const void* x, const void* logits, const float* mean, const float* rstd, const void* gamma,
+                         const void* beta, int groups_per_image, void* gx, void* gw, const cot_agg_geom* g, int dtype, void* stream) {
+    int Ho, Wo, rc = validate(g, &Ho, &Wo);
+    if (rc) return rc;
+    if (!gout || !x || !logits || !mean || !rstd || !gamma || !beta || !gx || !gw) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gout, x, logits, gx, gw}))) return rc;
+    if (dtype != COT_BF16 || groups_per_image <= 0) return set_error(COT_ERR_UNSUPPORTED, "cot_agg_gn9_*: COT_BF16 only");
+    const bool k3 = g->kh == 3 && g->kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->dh == 1 && g->dw == 1;
+    rc = k3 ? agg_gn9_backward_nchw_dot2((const bf16_t*)gout, (const bf16_t*)x, (const bf16_t*)logits, mean, rstd, (const bf16_t*)gamma,
+                                         (const bf16_t*)beta, groups_per_image, (bf16_t*)gx, (bf16_t*)gw, *g, (hipStream_t)stream)
+            : -1;
+    if (rc == -1) return set_error(COT_ERR_UNSUPPORTED, "cot_agg_gn9_backward: geometry not covered (cot_gn9_fused_covers)");
+    g_kernel = "agg_bwd_nchw_k3_dot2<gx,gw,gn9>";
     return rc;
 }
 

@@ -371,6 +371,39 @@ static int gn9_config(int HW) {
         default: { CALL(512, 2); } break;     \
     }
 
+// (mean, rstd) of the GroupNorm-9 groups from the producing convolution's EPILOGUE statistics (conv_lds_common.h tile_epilogue:
+// part [N][PT][C][2] = per image, 128-pixel tile and channel the sum and the sum of squares of the stored outputs): one wave per
+// (image, group), PT x 9 entries added in fp64 in a fixed order.  Replaces the statistics half of gn9_fwd_kernel; the
+// normalisation itself happens in the consumer's prologue (agg_fwd_nchw_k3_lds<SM = 2>, agg_bwd_nchw_k3_dot2 with Gn9Dot2).
+__global__ __launch_bounds__(64) void gn9_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, int G, int C, int PT, int HW, float eps) {
+    const int ng = blockIdx.x, n = ng / G, g = ng - n * G, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = lane; e < PT * 9; e += 64) {
+        const int pt = e / 9, cl = e - pt * 9;
+        const float* p = part + (((int64_t)n * PT + pt) * C + g * 9 + cl) * 2;
+        s1 += (double)p[0];
+        s2 += (double)p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (lane == 0) {
+        const double cnt = 9.0 * (double)HW, m = s1 / cnt;
+        double var = s2 / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[ng] = (float)m;
+        rstd[ng] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+int gn9_stats_finalize(const float* part, float* mean, float* rstd, int N, int C, int HW, float eps, hipStream_t stream) {
+    const int G = C / 9, PT = ceil_div(HW, 128);
+    COT_LAUNCH(gn9_stats_finalize_kernel, dim3((unsigned)(N * G)), dim3(64), 0, stream, part, mean, rstd, G, C, PT, HW, eps);
+    return check_launch("gn9_stats_finalize");
+}
+
 int gn9_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N, int C,
                 int HW, float eps, hipStream_t stream) {
     const int cfg = gn9_config(HW), G = C / 9;

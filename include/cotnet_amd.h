@@ -296,6 +296,29 @@ int cot_group_norm9_backward(const void* dy, const void* x, const float* mean, c
                              void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int dtype,
                              void* stream);
 
+/* ---- GroupNorm-9 fused into its producer and its consumer (reference: models/cotnet.py:55-56 embed[3] -> embed[4],
+ * :84-88 w.view(...) -> local_conv).  The statistics come out of the EPILOGUE of the 1x1 convolution that writes the logits, the
+ * normalisation is applied in the PROLOGUE of the aggregation kernels; the normalised tensor is never written or read:
+ *   cot_conv1x1_forward_gn9   = cot_conv1x1_forward that also fills `stats` (cot_gn9_stats_floats(N, Co, HW) floats: per image,
+ *                               128-pixel tile and channel the sum and sum of squares of the stored bf16 outputs)
+ *   cot_gn9_stats_finalize    -> mean / rstd [N * Co/9] (fp64 sums, one wave per (image, group))
+ *   cot_agg_gn9_forward       = cot_agg_forward whose weight tensor is GroupNorm-9(logits): logits [N, wC*9, H, W] raw, mean / rstd
+ *                               indexed by plane n*wC + wc, gamma / beta [groups_per_image*9] (group of a plane = plane %
+ *                               groups_per_image: wC, or 2*wC when two convolution groups are folded into the batch)
+ *   cot_agg_gn9_backward      = cot_agg_backward on the same operands; gw = gradient w.r.t. the NORMALISED weights = the `dy` of
+ *                               cot_group_norm9_backward(dy, x = logits, mean, rstd, ...), which stays the backward of the norm
+ * COT_BF16, 3x3 / stride 1 / pad 1 / one head, planes of more than 256 pixels with a width the packed dot-product backward covers:
+ * cot_gn9_fused_covers(Ci, c1, two_slabs, HW, W) says whether a layer qualifies (else COT_ERR_UNSUPPORTED: compose the three ops). */
+int64_t cot_gn9_stats_floats(int N, int C, int HW);
+int cot_gn9_fused_covers(int Ci, int c1, int two_slabs, int HW, int W);
+int cot_conv1x1_forward_gn9(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, float* stats,
+                            int N, int Ci, int Co, int HW, int dtype, void* stream);
+int cot_gn9_stats_finalize(const float* stats, float* mean, float* rstd, int N, int C, int HW, float eps, void* stream);
+int cot_agg_gn9_forward(const void* x, const void* logits, const float* mean, const float* rstd, const void* gamma, const void* beta,
+                        int groups_per_image, void* out, const cot_agg_geom* g, int dtype, void* stream);
+int cot_agg_gn9_backward(const void* gout, const void* x, const void* logits, const float* mean, const float* rstd, const void* gamma,
+                         const void* beta, int groups_per_image, void* gx, void* gw, const cot_agg_geom* g, int dtype, void* stream);
+
 /* ---- the backbone's first convolution: 7x7, stride 2, padding 3, 3 -> 64 channels, NCHW, COT_BF16 (reference:
  * models/resnet.py:539-555, conv1 of the default stem), forward and weight gradient (the network input takes no gradient).
  * weight [64][3][7][7] as torch stores it; x [N][3][H][W]; y / gy [N][64][Ho][Wo], Ho = (H - 1)/2 + 1.  Covered when Wo is a

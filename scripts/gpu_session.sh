@@ -33,6 +33,8 @@ case $what in
   sablock) timeout 600 python -m pytest tests/test_fused_layer_gpu.py tests/test_se_gate_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 2>&1 | tail -8 > $O/${T}_sablock_tests.log
         COT_KERNEL_SUMMARY=$O/${T}_secotnetd_kernels.json timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline > $O/${T}_bench_secotnetd_prof.json 2> $O/${T}_bench_secotnetd.err
         timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/${T}_bench_secotnetd.json 2>> $O/${T}_bench_secotnetd.err ;;
+  gnfuse) timeout 600 python -m pytest tests/test_gn_fusion_gpu.py tests/test_fused_layer_gpu.py tests/test_group_norm9_gpu.py tests/test_conv1x1_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 2>&1 | tail -8 > $O/${T}_gnfuse_tests.log
+        for gf in 1 0 1 0; do COT_GN_FUSED=$gf timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('COT_GN_FUSED=$gf', l['value'], l['ms_per_step'])" >> $O/${T}_gnfuse_ab.log 2>&1; done ;;
   aggparity) timeout 600 python -m pytest tests/test_dispatch_parity_gpu.py tests/test_agg_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "agg or Agg or oracle or n80 or N80" 2>&1 | tail -30 > $O/${T}_aggparity.log ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac

@@ -111,7 +111,8 @@ def test_single_node_split_attn_block_against_fp32_truth(inpl, planes, hw):
     from cotnet_amd.cotnet_hybrid import CoTBottleneck
     from cotnet_amd.layers import get_act_layer
     torch.manual_seed(hw + planes)
-    blk = CoTBottleneck(2, inpl, planes, conv_dim={64, 128}, c4_dim=256, c4_idx={0, 2}, radix=1, act_layer=get_act_layer("swish")).to(DEV).train()
+    # (block index 1: in the 256-wide stage the even blocks are CoT layers, the odd ones SplitAttn convolutions -- c4_idx)
+    blk = CoTBottleneck(1, inpl, planes, conv_dim={64, 128}, c4_dim=256, c4_idx={0, 2}, radix=1, act_layer=get_act_layer("swish")).to(DEV).train()
     assert type(blk.conv2).__name__ == "SplitAttnConv2d"
     with torch.no_grad():
         blk.bn3.weight.fill_(0.8)

@@ -1176,6 +1176,49 @@ def test_data_gradients_can_accumulate_into_their_outputs():
     assert torch.allclose(g.float(), fresh.float() + base.float(), atol=3e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("N,Ch,C,H,W", [(2, 32, 64, 28, 28), (1, 32, 64, 56, 56), (1, 64, 128, 20, 40)])
+def test_group_norm9_fused_into_producer_and_consumer(N, Ch, C, H, W):
+    """SURVEY 7.6 / VERDICT r3 J1: the GroupNorm of the attention logits without a kernel of its own.  (1) cot_conv1x1_forward_gn9
+    writes the same bits as cot_conv1x1_forward and its epilogue statistics, finalised, equal the GroupNorm kernel's mean / rstd;
+    (2) the aggregation kernels with the normalisation in their prologue (cot_agg_gn9_*) reproduce GroupNorm-9 followed by the
+    plain aggregation BIT FOR BIT when given the same statistics (same formula, same rounding point); (3) end to end with the
+    epilogue statistics the result moves by at most an ulp of a few weights"""
+    torch.manual_seed(C + H)
+    Ce, HW, G = 9 * C // 8, H * W, C // 8
+    e1 = torch.randn(N, Ch, H, W).bfloat16()
+    w3, b3 = (torch.randn(Ce, Ch) / Ch ** 0.5).bfloat16(), torch.randn(Ce).bfloat16()
+    gamma, beta = (1 + 0.3 * torch.randn(Ce)).bfloat16(), (0.2 * torch.randn(Ce)).bfloat16()
+    assert _EMUL.cot_gn9_fused_covers(Ch, Ch, 0, HW, W) == 1
+    part = torch.full((_EMUL.cot_gn9_stats_floats(N, Ce, HW),), float("nan"))
+    e3, e3b = torch.empty(N, Ce, H, W).bfloat16(), torch.empty(N, Ce, H, W).bfloat16()
+    assert _EMUL.cot_conv1x1_forward_gn9(P(e1), None, Ch, P(w3), P(b3), P(e3), P(part), N, Ch, Ce, HW, 2, None) == 0, _EMUL.cot_last_error()
+    assert _EMUL.cot_conv1x1_forward(P(e1), None, Ch, P(w3), P(b3), P(e3b), N, Ch, Ce, HW, 2, None) == 0
+    assert torch.equal(e3, e3b) and torch.isfinite(part).all()
+    mean, rstd = torch.empty(N * G), torch.empty(N * G)
+    assert _EMUL.cot_gn9_stats_finalize(P(part), P(mean), P(rstd), N, Ce, HW, 1e-5, None) == 0
+    xg = e3.float().view(N, G, -1)
+    assert torch.allclose(mean, xg.mean(2).flatten(), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(rstd, (xg.var(2, unbiased=False) + 1e-5).rsqrt().flatten(), atol=1e-5, rtol=1e-5)
+    wn, m2, r2 = torch.empty_like(e3), torch.empty(N * G), torch.empty(N * G)
+    assert _EMUL.cot_group_norm9_forward(P(e3), P(gamma), P(beta), P(wn), P(m2), P(r2), N, Ce, HW, 1e-5, 2, None) == 0
+    v, go = torch.randn(N, C, H, W).bfloat16(), torch.randn(N, C, H, W).bfloat16()
+    geo = _lib.AggGeom(N, C, H, W, 1, G, 3, 3, 1, 1, 1, 1, 1, 1)
+    a1, a2 = torch.empty_like(v), torch.empty_like(v)
+    assert _EMUL.cot_agg_gn9_forward(P(v), P(e3), P(m2), P(r2), P(gamma), P(beta), G, P(a1), ctypes.byref(geo), 2, None) == 0, _EMUL.cot_last_error()
+    assert _EMUL.cot_last_kernel().decode() == "agg_fwd_nchw_k3_lds<gn9>"
+    assert _EMUL.cot_agg_forward(P(v), P(wn), P(a2), ctypes.byref(geo), 2, 0, None) == 0
+    assert torch.equal(a1, a2)
+    gx1, gw1, gx2, gw2 = torch.empty_like(v), torch.empty_like(e3), torch.empty_like(v), torch.empty_like(e3)
+    assert _EMUL.cot_agg_gn9_backward(P(go), P(v), P(e3), P(m2), P(r2), P(gamma), P(beta), G, P(gx1), P(gw1), ctypes.byref(geo), 2, None) == 0
+    assert _EMUL.cot_last_kernel().decode() == "agg_bwd_nchw_k3_dot2<gx,gw,gn9>"
+    assert _EMUL.cot_agg_backward(P(go), P(v), P(wn), P(gx2), P(gw2), ctypes.byref(geo), 2, 0, None) == 0
+    assert torch.equal(gx1, gx2) and torch.equal(gw1, gw2)
+    assert _EMUL.cot_agg_gn9_forward(P(v), P(e3), P(mean), P(rstd), P(gamma), P(beta), G, P(a1), ctypes.byref(geo), 2, None) == 0
+    assert (a1.float() - a2.float()).abs().max() <= 2.0 ** -7 * a2.float().abs().max()
+    # not covered: small planes (the 14 x 14 / 7 x 7 stages keep the GroupNorm kernel), widths off the packed backward's list
+    assert _EMUL.cot_gn9_fused_covers(Ch, Ch, 0, 14 * 14, 14) == 0 and _EMUL.cot_gn9_fused_covers(Ch, Ch, 0, 24 * 24, 24) == 0
+
+
 def _plan_grouped(clf, layer):
     return clf._plan(layer).grouped
 
@@ -1203,8 +1246,9 @@ class _EmulAggregation(torch.autograd.Function):
         return gx, gw
 
 
-@pytest.mark.parametrize("cls,C", [("CotLayer", 64), ("CoXtLayer", 96), ("CoXtLayer", 64)])
-def test_fused_cot_layer_node_on_emulated_kernels(cls, C, monkeypatch):
+@pytest.mark.parametrize("cls,C,H", [("CotLayer", 64, 6), ("CoXtLayer", 96, 6), ("CoXtLayer", 64, 6),
+                                     ("CotLayer", 64, 28)])  # 28 x 28: GroupNorm fused into embed[3]'s epilogue / the aggregation
+def test_fused_cot_layer_node_on_emulated_kernels(cls, C, H, monkeypatch):
     """cotnet_amd.cot_layer_fused: the whole CotLayer / CoXtLayer as one autograd node (hand-written backward chain) against
     the module's ordinary node-per-op forward, both on the host-emulated kernels: same arithmetic and rounding points, so the
     two must agree to a few bf16 ulps (the only difference: dx / dk are summed in fp32 inside the kernels)."""
@@ -1213,7 +1257,7 @@ def test_fused_cot_layer_node_on_emulated_kernels(cls, C, monkeypatch):
     from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, cotnet as cn, fused_bn, radix_tail
     from cotnet_amd.flat_sgd import to_mixed_bf16
     torch.manual_seed(4)
-    N, H, W = 3, 6, 6
+    N, W = (3 if H == 6 else 2), H
     node = getattr(cn, cls)(C, 3).train()
     with torch.no_grad():
         for p in node.parameters():
@@ -1240,6 +1284,9 @@ def test_fused_cot_layer_node_on_emulated_kernels(cls, C, monkeypatch):
     assert "CotLayerNode" not in yr.grad_fn.name()
     yr.backward(g)
     assert _plan_grouped(clf, node) == (cls == "CoXtLayer")
+    launched = []
+    orig_gn9 = _EMUL.cot_agg_gn9_forward
+    monkeypatch.setattr(_EMUL, "cot_agg_gn9_forward", lambda *a: (launched.append(1), orig_gn9(*a))[1], raising=False)
 
     monkeypatch.setattr(clf, "ENABLED", True)
     xf = x.clone().requires_grad_(True)
@@ -1247,6 +1294,7 @@ def test_fused_cot_layer_node_on_emulated_kernels(cls, C, monkeypatch):
     yf = node(xf)
     assert yf.grad_fn.name().startswith("_CotLayerNode")
     yf.backward(g)
+    assert bool(launched) == (H == 28 and cls == "CotLayer")  # the fused GroupNorm path ran exactly where it is covered
 
     def rel(a, b):
         return ((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-6)).item()
