@@ -786,7 +786,7 @@ def main():
                        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
         roofline = None
         if kernels:
-            k0 = kernels[0]
+            k0 = next((k for k in kernels if k["GBs"] > 0), kernels[0])  # (a launch without byte annotation never is the headline kernel)
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "agg_traffic.json")
             if os.path.exists(tpath):

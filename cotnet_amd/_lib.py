@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcotnet_hip.so")
+# COT_LIB_PATH: developer A/B of two builds of the library on one box (scripts/gpu_session.sh); the product loads the in-tree one
+LIB_PATH = os.environ.get("COT_LIB_PATH") or os.path.join(_HERE, "lib", "libcotnet_hip.so")
 
 COT_F32, COT_F64, COT_BF16, COT_F16 = 0, 1, 2, 3
 COT_NCHW, COT_NHWC = 0, 1
@@ -138,6 +139,8 @@ def lib():
                 "(hipcc --offload-arch=gfx950). cotnet_amd has no CPU or eager fallback.")
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("COT_LIB_PATH") and not hasattr(L, name):
+                continue  # (developer A/B against an OLDER build of the library: entry points it lacks are simply not bound)
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
         if L.cot_abi_version() != 1:

@@ -529,10 +529,13 @@ int cot_agg_gn9_forward(const void* x, const void* logits, const float* mean, co
     if (!x || !logits || !mean || !rstd || !gamma || !beta || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x, logits, out}))) return rc;
     if (dtype != COT_BF16 || groups_per_image <= 0) return set_error(COT_ERR_UNSUPPORTED, "cot_agg_gn9_*: COT_BF16 only");
+    const bool p = prof::enabled();
+    if (p) prof::mark();
     rc = agg_gn9_forward_nchw((const bf16_t*)x, (const bf16_t*)logits, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta,
                               groups_per_image, (bf16_t*)out, *g, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_agg_gn9_forward: geometry not covered (3x3, stride 1, pad 1, one head)");
     else g_kernel = last_kernel_nchw();
+    if (p) prof::annotate(*g, dtype, COT_NCHW, 0, 0);  // (same algorithmic bytes as the plain aggregation: x, logits read, out written)
     return rc;
 }
 int cot_agg_gn9_backward(const void* gout, const void* x, const void* logits, const float* mean, const float* rstd, const void* gamma,
@@ -543,11 +546,14 @@ int cot_agg_gn9_backward(const void* gout, const void* x, const void* logits, co
     if ((rc = check_align16({gout, x, logits, gx, gw}))) return rc;
     if (dtype != COT_BF16 || groups_per_image <= 0) return set_error(COT_ERR_UNSUPPORTED, "cot_agg_gn9_*: COT_BF16 only");
     const bool k3 = g->kh == 3 && g->kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->dh == 1 && g->dw == 1;
+    const bool p = prof::enabled();
+    if (p) prof::mark();
     rc = k3 ? agg_gn9_backward_nchw_dot2((const bf16_t*)gout, (const bf16_t*)x, (const bf16_t*)logits, mean, rstd, (const bf16_t*)gamma,
                                          (const bf16_t*)beta, groups_per_image, (bf16_t*)gx, (bf16_t*)gw, *g, (hipStream_t)stream)
             : -1;
     if (rc == -1) return set_error(COT_ERR_UNSUPPORTED, "cot_agg_gn9_backward: geometry not covered (cot_gn9_fused_covers)");
     g_kernel = "agg_bwd_nchw_k3_dot2<gx,gw,gn9>";
+    if (p) prof::annotate(*g, dtype, COT_NCHW, 1, 3);
     return rc;
 }
 

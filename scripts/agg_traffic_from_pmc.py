@@ -21,7 +21,7 @@ def per_kernel(root, counter):
             if row["Counter_Name"] != counter:
                 continue
             name = row["Kernel_Name"]
-            for k in ("agg_fwd_nchw_k3_lds", "agg_bwd_nchw_k3_lds"):
+            for k in ("agg_fwd_nchw_k3_lds", "agg_bwd_nchw_k3_lds", "agg_bwd_nchw_k3_dot2"):
                 if k in name:
                     acc.setdefault(k, []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}

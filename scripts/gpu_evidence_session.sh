@@ -1,6 +1,6 @@
 #!/bin/bash
-# evidence session (rounds 2-3): full GPU suite, kernel trace of the `new` set, PMC traffic of the aggregation kernels, per-op
-# benches through the C ABI, the default bench line and the forward-only line (BASELINE config 2)
+# evidence session (round 4): full GPU suite, smoke, kernel trace of the default step, PMC traffic of the aggregation kernels,
+# per-op benches through the C ABI, the default bench line (with its secondary configurations) and the forward-only line
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -13,18 +13,16 @@ timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 bash scripts/gpu_trace_new.sh ev_trace > $O/ev_trace_sh.log 2>&1; tail -3 $O/ev_trace_sh.log | cut -c1-200
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 90 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$O/ev_pmc_$c -o pmc -- python $R/scripts/bench_agg_abi.py --shapes 0 --dtypes bf16 --variants v3d --iters 4 --rounds 1 > $R/$O/ev_pmc_$c.log 2>&1
+  timeout 90 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$O/ev_pmc_$c -o pmc -- python $R/scripts/bench_agg_abi.py --shapes 0 --dtypes bf16 --variants dot2 --iters 4 --rounds 1 > $R/$O/ev_pmc_$c.log 2>&1
 done
 cd $R
 python scripts/agg_traffic_from_pmc.py $O/ev_pmc_FETCH_SIZE $O/ev_pmc_WRITE_SIZE --out $O/ev_agg_traffic.json
 python scripts/agg_traffic_from_pmc.py $O/ev_pmc_FETCH_SIZE $O/ev_pmc_WRITE_SIZE --out profiles/agg_traffic.json > /dev/null   # the bench line below reports THIS session's counters
-timeout 200 python scripts/bench_agg_abi.py --variants v3d --iters 20 --rounds 5 --out $O/ev_agg_abi.json > $O/ev_agg_abi.log 2>&1; tail -20 $O/ev_agg_abi.log | cut -c1-200
+timeout 200 python scripts/bench_agg_abi.py --variants lds,dot2 --iters 20 --rounds 5 --out $O/ev_agg_abi.json > $O/ev_agg_abi.log 2>&1; tail -20 $O/ev_agg_abi.log | cut -c1-200
 timeout 300 python scripts/bench_conv_abi.py --iters 20 --json $O/ev_conv_abi.json > $O/ev_conv_abi.log 2>&1; tail -5 $O/ev_conv_abi.log | cut -c1-200
-timeout 200 python scripts/bench_conv3x3g_wgrad.py > $O/ev_conv3x3g_wgrad.log 2>&1; tail -8 $O/ev_conv3x3g_wgrad.log | cut -c1-200
-timeout 200 python scripts/bench_pool.py > $O/ev_pool.log 2>&1; tail -8 $O/ev_pool.log | cut -c1-200
 T1=$(date +%s)
-timeout 600 python bench.py > $O/ev_bench_default.json 2> $O/ev_bench_default.err; echo "bench rc=$? wall=$(( $(date +%s) - T1 ))s"
+timeout 900 python bench.py > $O/ev_bench_default.json 2> $O/ev_bench_default.err; echo "bench rc=$? wall=$(( $(date +%s) - T1 ))s"
 cut -c1-600 $O/ev_bench_default.json
-timeout 300 python bench.py --mode fwd --kernels new --no-cpu-baseline > $O/ev_bench_fwd.json 2> $O/ev_bench_fwd.err || tail -5 $O/ev_bench_fwd.err; cut -c1-300 $O/ev_bench_fwd.json
-timeout 300 python bench.py --recipe --kernels new --no-cpu-baseline > $O/ev_bench_recipe.json 2> $O/ev_bench_recipe.err; cut -c1-300 $O/ev_bench_recipe.json
+timeout 300 python bench.py --mode fwd --no-cpu-baseline > $O/ev_bench_fwd.json 2> $O/ev_bench_fwd.err || tail -5 $O/ev_bench_fwd.err; cut -c1-300 $O/ev_bench_fwd.json
+timeout 300 python bench.py --recipe --no-cpu-baseline > $O/ev_bench_recipe.json 2> $O/ev_bench_recipe.err; cut -c1-300 $O/ev_bench_recipe.json
 echo "session wall=$(( $(date +%s) - T0 ))s"

@@ -35,6 +35,9 @@ case $what in
         timeout 400 python bench.py --model se_cotnetd_152_L --img 320 --batch 64 --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/${T}_bench_secotnetd.json 2>> $O/${T}_bench_secotnetd.err ;;
   gnfuse) timeout 600 python -m pytest tests/test_gn_fusion_gpu.py tests/test_fused_layer_gpu.py tests/test_group_norm9_gpu.py tests/test_conv1x1_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 2>&1 | tail -8 > $O/${T}_gnfuse_tests.log
         for gf in 1 0 1 0; do COT_GN_FUSED=$gf timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('COT_GN_FUSED=$gf', l['value'], l['ms_per_step'])" >> $O/${T}_gnfuse_ab.log 2>&1; done ;;
+  libab) for lp in cotnet_amd/lib/libcotnet_hip_2786414.so "" cotnet_amd/lib/libcotnet_hip_2786414.so ""; do COT_GN_FUSED=0 COT_LIB_PATH=$lp timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('lib=${lp:-HEAD}', l['value'], l['ms_per_step'])" >> $O/${T}_libab.log 2>&1; done
+        COT_KERNEL_SUMMARY=$O/${T}_head_kernels.json timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
+        COT_GN_FUSED=0 COT_LIB_PATH=cotnet_amd/lib/libcotnet_hip_2786414.so COT_KERNEL_SUMMARY=$O/${T}_old_kernels.json timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1 ;;
   aggparity) timeout 600 python -m pytest tests/test_dispatch_parity_gpu.py tests/test_agg_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "agg or Agg or oracle or n80 or N80" 2>&1 | tail -30 > $O/${T}_aggparity.log ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac

@@ -2,7 +2,7 @@
 """Experiment: the benchmark's training step captured in ONE hipGraph (torch.cuda.CUDAGraph) and replayed, against the eager step
 from the same initial state: loss per step (must match: same kernels, same data, deterministic) and ms per step.
 
-    python scripts/try_graph_step.py [steps]"""
+    python scripts/try_graph_step.py [steps [model [batch [resolution]]]]"""
 import copy
 import os
 import sys
@@ -16,20 +16,23 @@ import cotnet_amd  # noqa: E402
 from cotnet_amd.flat_sgd import FlatSGD, to_mixed_bf16  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+MODEL = sys.argv[2] if len(sys.argv) > 2 else "cotnet50"
+BATCH = int(sys.argv[3]) if len(sys.argv) > 3 else 80
+RES = int(sys.argv[4]) if len(sys.argv) > 4 else 224
 bench.apply_kernel_set("new")
 dev = torch.device("cuda:0")
 
 
 def make():
     torch.manual_seed(0)
-    model = to_mixed_bf16(cotnet_amd.create_model("cotnet50", num_classes=1000).to(dev)).train()
+    model = to_mixed_bf16(cotnet_amd.create_model(MODEL, num_classes=1000).to(dev)).train()
     opt = FlatSGD(model, lr=0.03, momentum=0.9, weight_decay=4e-5, nesterov=True)
     return model, opt
 
 
 torch.manual_seed(1)
-x = torch.randn(80, 3, 224, 224, device=dev).bfloat16()
-t = torch.randint(0, 1000, (80,), device=dev)
+x = torch.randn(BATCH, 3, RES, RES, device=dev).bfloat16()
+t = torch.randint(0, 1000, (BATCH,), device=dev)
 
 
 def run(graphed):
