@@ -192,30 +192,55 @@ __global__ __launch_bounds__(NW * 64) void agg_bwd_nchw_k3_dot2(const bf16_t* __
     uint32_t wpa[3][P], wpb[3][P];
     {
         const bf16_t* wp = w + plane * 9 * HW + w0;
+        // every load of the prologue issued before the first use: (GroupNorm prologue) the 20 statistics / affine values, then
+        // the 27 weight vectors -- one memory latency.  (Loading gamma / beta per tap inside the wave-uniform `if` made nine dependent
+        // round trips of it: 43.6 us against 35 us per launch at 56 x 56 in the model, gpurun_out/r4u.)
         float gmu = 0.f, grs = 1.f;
-        int gq = 0;
-        if (gn.mean) {
+        bf16_t gam[9], bet[9];  // (kept as loaded: a conversion here would wait for the loads before the weights' are issued)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) gam[t] = bet[t] = __builtin_bit_cast(bf16_t, (uint16_t)0);
+        if (gn.mean) {  // (wave-uniform; issued first, consumed after the weight loads below are on their way too)
             gmu = gn.mean[plane];
             grs = gn.rstd[plane];
-            gq = (int)(plane % gn.gimg);
+            const int gq = (int)((unsigned)plane % (unsigned)gn.gimg);  // (planes < 2^31: dot2_run; a 64-bit modulo is a ~130-instruction routine)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                gam[t] = gn.gamma[gq * 9 + t];
+                bet[t] = gn.beta[gq * 9 + t];
+            }
         }
+        uint32_t tw[3][3][PW];
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) {
             const int kh = 2 - rr, hr = h - 1 + rr;
-            const bool rok = valid && hr >= 0 && hr < H;
             const int hc = hr < 0 ? 0 : (hr >= H ? H - 1 : hr);
-            uint32_t tv[3][PW];
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                Vec<uint32_t, PW> v = *reinterpret_cast<const Vec<uint32_t, PW>*>(wp + (int64_t)(kh * 3 + kw) * HW + (int64_t)hc * W);
-                if (gn.mean) {  // (wave-uniform) GroupNorm of the logits, as the forward pass computed it
-                    const float ga = (float)gn.gamma[gq * 9 + kh * 3 + kw] * grs, be = (float)gn.beta[gq * 9 + kh * 3 + kw] - gmu * ga;
+                const Vec<uint32_t, PW> v = *reinterpret_cast<const Vec<uint32_t, PW>*>(wp + (int64_t)(kh * 3 + kw) * HW + (int64_t)hc * W);
 #pragma unroll
-                    for (int k = 0; k < PW; ++k) v.v[k] = gn9_word(v.v[k], ga, be);
-                }
-#pragma unroll
-                for (int k = 0; k < PW; ++k) tv[kw][k] = rok ? v.v[k] : 0u;  // (selection: a clamped row's weights never count)
+                for (int k = 0; k < PW; ++k) tw[rr][kw][k] = v.v[k];
             }
+        }
+        if (gn.mean) {  // GroupNorm of the logits, as the forward pass computed it
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int t = (2 - rr) * 3 + kw;
+                    const float ga = (float)gam[t] * grs, be = (float)bet[t] - gmu * ga;
+#pragma unroll
+                    for (int k = 0; k < PW; ++k) tw[rr][kw][k] = gn9_word(tw[rr][kw][k], ga, be);
+                }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const int hr = h - 1 + rr;
+            const bool rok = valid && hr >= 0 && hr < H;
+            uint32_t tv[3][PW];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int k = 0; k < PW; ++k) tv[kw][k] = rok ? tw[rr][kw][k] : 0u;  // (selection: a clamped row's weights never count)
             const uint32_t tvL2 = COT_ROW_PREV(tv[2][PW - 1]);  // tap kw=2 at column w0-1 (hi half)
             const uint32_t tvR0 = COT_ROW_NEXT(tv[0][0]);       // tap kw=0 at column w0+P (lo half)
 #pragma unroll

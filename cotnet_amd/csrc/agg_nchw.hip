@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512) void agg_fwd_nchw_k3_lds(const T* __restrict__
         for (int t = 0; t < 9; ++t) wr[t] = ldv<T, P>(wp + t * HW);
         if (SM == 2) {
             const int64_t pl = nh * wC + wc;
-            const int gq = (int)(pl % gn.gimg);
+            const int gq = (int)((unsigned)pl % (unsigned)gn.gimg);  // (planes < 2^31: launch_gn9_fwd)
             const A mu = (A)gn.mean[pl], rs = (A)gn.rstd[pl];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -1187,7 +1187,7 @@ static int launch_gn9_fwd(const bf16_t* x, const bf16_t* logits, bf16_t* out, co
 }
 int agg_gn9_forward_nchw(const bf16_t* x, const bf16_t* logits, const float* mean, const float* rstd, const bf16_t* gamma,
                          const bf16_t* beta, int gimg, bf16_t* out, const cot_agg_geom& g, hipStream_t s) {
-    if (!is_k3_fast(g) || g.heads != 1) return COT_ERR_UNSUPPORTED;
+    if (!is_k3_fast(g) || g.heads != 1 || (int64_t)g.N * g.wC >= ((int64_t)1 << 31)) return COT_ERR_UNSUPPORTED;
     const Gn9Args<bf16_t> gn{mean, rstd, gamma, beta, gimg};
     switch (pick_P<bf16_t>(g.W, g_tune[1])) {
         case 8: return launch_gn9_fwd<8>(x, logits, out, g, gn, s);

@@ -412,7 +412,8 @@ template int subsample2<bf16_t>(int, const void*, void*, int64_t, int, int, hipS
 int g_pool_tile = 1;  // cot_set_tuning key 27: 0 = one lane per pixel only
 // windows per lane of the row-block form (0: not eligible): W even, every wide access naturally aligned
 static int pool_blk_group(int op, int H, int W, int Ho, int Wo) {
-    if (!g_pool_tile || !(op == 0 || op == 1 || op == 4 || op == 5) || (W & 1) || W < 2) return 0;
+    if (!g_pool_tile || !(op == 0 || op == 1 || op == 4 || op == 5 || op == 6 || op == 7) || (W & 1) || W < 2) return 0;
+    if ((op == 6 || op == 7) && H < 2) return 0;
     const bool odd_planes = ((H * W) & 7) || ((Ho * Wo) & 7);  // (planes do not all start on 16-byte boundaries: narrower groups)
     if (Wo % 4 == 0 && !odd_planes) return 4;
     if (Wo % 2 == 0 && !(((H * W) & 3) || ((Ho * Wo) & 3))) return 2;
@@ -482,13 +483,115 @@ __global__ __launch_bounds__(256) void blurpool3x3s2_bwd(const T* __restrict__ g
     gx[i] = (T)s;
 }
 
+// row-block forms (even W, wide naturally aligned accesses -- pool_blk_group): the per-pixel kernels above pay two 64-bit
+// divisions and nine (or up to sixteen) separately addressed 2-byte loads per pixel: 407 us per launch averaged over the four
+// BlurPool gradients of SE-CoTNetD-152 at 320 x 320, B = 64 (gpurun_out/r4q_secotnetd_kernels.json; the stem's 64 x 64 x 160 x 160
+// plane set alone moves 262 MB = 33 us at the roofline).  Forward: a lane owns BG consecutive outputs of one output row, loads
+// 2 BG + 1 columns of each of the three (reflected) input rows.  Backward: a lane owns a 2 x 2 BG block of the input gradient
+// (rows 2a, 2a+1), loads BG + 1 columns of gradient rows a, a+1.  W even means no reflection at the right edge (the last
+// window ends at column W - 1); the left one (column -1 -> 1) and both vertical ones are handled.  Sums in the order of the
+// per-pixel kernels (rows outer, columns inner, ascending): identical results.
+template <typename T, int BG>
+__global__ __launch_bounds__(256) void blurpool3x3s2_fwd_blk(const T* __restrict__ x, T* __restrict__ y, int64_t planes, int H,
+                                                            int W, int Ho, int Wo) {
+    const int NB = Wo / BG;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ho * NB) return;
+    const int bg = (int)(i % NB), oh = (int)((i / NB) % Ho);
+    const int64_t pl = i / ((int64_t)NB * Ho);
+    const int ow0 = bg * BG;
+    const T* xp = x + pl * H * W;
+    float acc[BG];
+#pragma unroll
+    for (int j = 0; j < BG; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = reflect1(2 * oh - 1 + kh, H);
+        const T* rp = xp + (int64_t)h * W + 2 * ow0;
+        float L[2 * BG + 1];
+        L[0] = (float)(ow0 > 0 ? rp[-1] : rp[1]);  // column -1 reflects onto column 1
+        const Vec<T, 2 * BG> v = ldv<T, 2 * BG>(rp);
+#pragma unroll
+        for (int c = 0; c < 2 * BG; ++c) L[1 + c] = (float)v.v[c];
+#pragma unroll
+        for (int j = 0; j < BG; ++j) {
+            float r = 0.f;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) r += binom3(kw) * L[2 * j + kw];
+            acc[j] += binom3(kh) * r;
+        }
+    }
+    Vec<T, BG> o;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) o.v[j] = (T)acc[j];
+    stv<T, BG>(y + pl * Ho * Wo + (int64_t)oh * Wo + ow0, o);
+}
+
+template <typename T, int BG>
+__global__ __launch_bounds__(256) void blurpool3x3s2_bwd_blk(const T* __restrict__ gy, T* __restrict__ gx, int64_t planes, int H,
+                                                            int W, int Ho, int Wo) {
+    const int NB = Wo / BG, HB = (H + 1) / 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * HB * NB) return;
+    const int bg = (int)(i % NB), a = (int)((i / NB) % HB);
+    const int64_t pl = i / ((int64_t)NB * HB);
+    const int b0 = bg * BG;
+    const T* gp = gy + pl * Ho * Wo;
+    // rows 2a and 2a+1 read windows a and a+1 only (blur_w is zero elsewhere: direct taps reach (h-1)/2 .. (h+1)/2, the top
+    // reflection adds window 0 to row 1, the bottom one the last window to row H-2 -- both inside {a, a+1})
+    float g[2][BG + 1];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oh = a + r;
+        if (oh < Ho) {
+            const Vec<T, BG> v = ldv<T, BG>(gp + (int64_t)oh * Wo + b0);
+#pragma unroll
+            for (int c = 0; c < BG; ++c) g[r][c] = (float)v.v[c];
+            g[r][BG] = b0 + BG < Wo ? (float)gp[(int64_t)oh * Wo + b0 + BG] : 0.f;
+        } else {
+#pragma unroll
+            for (int c = 0; c <= BG; ++c) g[r][c] = 0.f;
+        }
+    }
+    Vec<T, 2 * BG> o[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int h = 2 * a + rr;
+        float wh[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) wh[r] = (h < H && a + r < Ho) ? blur_w(h, a + r, H) : 0.f;
+#pragma unroll
+        for (int c = 0; c < BG; ++c) {
+            // column 2(b0+c): window b0+c (weight 1/2); column 2(b0+c)+1: windows b0+c (1/4, + 1/4 reflected when it is column 1)
+            // and b0+c+1 (1/4, when it exists)
+            const float we = 0.5f, wo0 = (b0 + c == 0) ? 0.5f : 0.25f, wo1 = (b0 + c + 1 < Wo) ? 0.25f : 0.f;
+            float se = 0.f, so = 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (wh[r] == 0.f) continue;
+                float re = 0.f, ro = 0.f;
+                re += we * g[r][c];
+                ro += wo0 * g[r][c];
+                if (wo1 != 0.f) ro += wo1 * g[r][c + 1];
+                se += wh[r] * re;
+                so += wh[r] * ro;
+            }
+            o[rr].v[2 * c] = (T)se;
+            o[rr].v[2 * c + 1] = (T)so;
+        }
+    }
+    T* op = gx + pl * H * W + (int64_t)(2 * a) * W + 2 * b0;
+    stv<T, 2 * BG>(op, o[0]);
+    if (2 * a + 1 < H) stv<T, 2 * BG>(op + W, o[1]);
+}
+
 template <typename T>
 int pool3x3s2(int op, const void* a, const void* b, void* out, int64_t planes, int H, int W, hipStream_t stream) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;  // floor((H + 2 - 3) / 2) + 1
     const int64_t n_out = planes * Ho * Wo, n_in = planes * H * W;
     const dim3 block(256);
     if (const int BG = pool_blk_group(op, H, W, Ho, Wo)) {
-        const bool bwd = op == 1 || op == 5;
+        const bool bwd = op == 1 || op == 5 || op == 7;
         const int64_t lanes = planes * (bwd ? (H + 1) / 2 : Ho) * (Wo / BG);
         const dim3 grid((unsigned)ceil_div64(lanes, 256));
 #define COT_POOL_BLK(BG_)                                                                                                       \
@@ -496,6 +599,8 @@ int pool3x3s2(int op, const void* a, const void* b, void* out, int64_t planes, i
         case 0: COT_LAUNCH((pool3x3s2_fwd_blk<T, BG_, false>), grid, block, 0, stream, (const T*)a, (T*)out, nullptr, planes, H, W, Ho, Wo); break; \
         case 4: COT_LAUNCH((pool3x3s2_fwd_blk<T, BG_, true>), grid, block, 0, stream, (const T*)a, (T*)out, (uint8_t*)const_cast<void*>(b), planes, H, W, Ho, Wo); break; \
         case 1: COT_LAUNCH((pool3x3s2_bwd_blk<T, BG_, false>), grid, block, 0, stream, (const T*)a, nullptr, (T*)out, planes, H, W, Ho, Wo); break; \
+        case 6: COT_LAUNCH((blurpool3x3s2_fwd_blk<T, BG_>), grid, block, 0, stream, (const T*)a, (T*)out, planes, H, W, Ho, Wo); break; \
+        case 7: COT_LAUNCH((blurpool3x3s2_bwd_blk<T, BG_>), grid, block, 0, stream, (const T*)a, (T*)out, planes, H, W, Ho, Wo); break; \
         default: COT_LAUNCH((pool3x3s2_bwd_blk<T, BG_, true>), grid, block, 0, stream, (const T*)a, (const uint8_t*)b, (T*)out, planes, H, W, Ho, Wo); break; \
     }
         if (BG == 4) { COT_POOL_BLK(4) } else if (BG == 2) { COT_POOL_BLK(2) } else { COT_POOL_BLK(1) }

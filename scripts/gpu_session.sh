@@ -39,6 +39,9 @@ case $what in
         COT_KERNEL_SUMMARY=$O/${T}_head_kernels.json timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
         COT_GN_FUSED=0 COT_LIB_PATH=cotnet_amd/lib/libcotnet_hip_2786414.so COT_KERNEL_SUMMARY=$O/${T}_old_kernels.json timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1 ;;
   aggparity) timeout 600 python -m pytest tests/test_dispatch_parity_gpu.py tests/test_agg_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "agg or Agg or oracle or n80 or N80" 2>&1 | tail -30 > $O/${T}_aggparity.log ;;
+  graph) timeout 200 python scripts/try_graph_step.py 10 cotnext101_2x48d 64 224 > $O/${T}_graph_cotnext.log 2>&1; tail -3 $O/${T}_graph_cotnext.log | cut -c1-300
+         timeout 300 python scripts/try_graph_step.py 10 se_cotnetd_152_L 64 320 > $O/${T}_graph_secot.log 2>&1; tail -3 $O/${T}_graph_secot.log | cut -c1-300 ;;
+  roofobj) timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); r=l['roofline']; print(l['value'], {k: r[k] for k in ('kernel','shape','achieved','frac','traffic','avg_us')}); [print(k) for k in r['kernels']]" ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac
 done

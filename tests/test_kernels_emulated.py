@@ -2204,7 +2204,8 @@ def test_coxt_layer_on_emulated_kernels(dtype, monkeypatch):
 # SE-CoTNetD's extra layers: BlurPool2d and the sigmoid gate of SplitAttnConv2d(radix=1)
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 4, 7, 7), (2, 2, 14, 10), (1, 2, 5, 9), (1, 1, 2, 2), (1, 2, 3, 2), (1, 1, 2, 5)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 4, 7, 7), (2, 2, 14, 10), (1, 2, 5, 9), (1, 1, 2, 2), (1, 2, 3, 2), (1, 1, 2, 5),
+                                     (2, 2, 16, 16), (1, 3, 7, 8), (2, 1, 20, 20), (1, 2, 5, 12), (1, 2, 3, 24), (1, 1, 9, 6)])
 def test_blurpool_kernels_match_the_reference_formula(N, C, H, W, dtype):
     """cot_blurpool3x3s2_* against ReflectionPad2d(1) + depthwise conv2d with the binomial filter, stride 2
     (models/layers/blur_pool.py:53-58 as restated in cotnet_amd.layers.BlurPool2d)"""
@@ -2225,6 +2226,15 @@ def test_blurpool_kernels_match_the_reference_formula(N, C, H, W, dtype):
     assert torch.allclose(y.double(), yr.detach(), atol=tol, rtol=tol)
     assert torch.allclose(gx.double(), xr.grad, atol=tol, rtol=tol)
     assert _EMUL.cot_blurpool3x3s2_forward(P(x), P(y), N * C, 1, W, dt, None) == -2   # reflection needs two rows
+    # the row-block form (even W: a lane owns 1 / 2 / 4 windows of a row) adds in the order of the per-pixel form: same bits
+    y1, gx1 = torch.full_like(y, float("nan")), torch.full_like(gx, float("nan"))
+    assert _EMUL.cot_set_tuning(27, 0) == 0
+    try:
+        assert _EMUL.cot_blurpool3x3s2_forward(P(x), P(y1), N * C, H, W, dt, None) == 0
+        assert _EMUL.cot_blurpool3x3s2_backward(P(gy), P(gx1), N * C, H, W, dt, None) == 0
+    finally:
+        assert _EMUL.cot_set_tuning(27, 1) == 0
+    assert torch.equal(y1, y) and torch.equal(gx1, gx)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
