@@ -77,6 +77,8 @@ SYMBOLS = {
     "cot_agg_gn9_backward": (_I, [_P] * 7 + [_I, _P, _P, _G, _I, _P]),
     "cot_subsample2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_subsample2_backward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
+    "cot_avgpool2x2s2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
+    "cot_avgpool2x2s2_backward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_avgpool3x3s2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_avgpool3x3s2_backward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),
     "cot_maxpool3x3s2_forward": (_I, [_P, _P, ctypes.c_int64, _I, _I, _I, _P]),

@@ -225,6 +225,7 @@ def run_downsample(ds, x):
     BatchNorm kernels instead of MIOpen."""
     if MODE and isinstance(ds, torch.nn.Sequential):
         from .fused_bn import fused_bn_act
+        from .pool3x3 import pool
         for m in ds:
             if isinstance(m, torch.nn.Conv2d):
                 if (MODE == "hip" and m.kernel_size == (1, 1) and m.stride == (2, 2) and m.padding == (0, 0)
@@ -236,6 +237,8 @@ def run_downsample(ds, x):
                     x = conv1x1(m, x)
             elif isinstance(m, torch.nn.BatchNorm2d):
                 x = fused_bn_act(x, m, None)  # (falls back to the module itself when not eligible)
+            elif isinstance(m, torch.nn.AvgPool2d):
+                x = pool(m, x)  # (downsample_avg's 2 x 2 pooling on the library's kernel when eligible, else the module)
             else:
                 x = m(x)
         return x

@@ -17,7 +17,7 @@ from .cotnet import CotLayer, _cfg
 from .fused_bn import fused_bn_act
 from .layers import BlurPool2d, SplitAttnConv2d, create_classifier, get_act_layer
 from .registry import build_model_with_cfg, register_model
-from .resnet import init_weights, make_blocks, make_stem
+from .resnet import init_weights, make_blocks, make_stem, stem_forward
 
 default_cfgs = {
     "cot_basic": _cfg(url=""),
@@ -158,7 +158,7 @@ class CoTHybridNet(nn.Module):
         self.global_pool, self.fc = create_classifier(self.num_features, self.num_classes, pool_type=global_pool)
 
     def forward_features(self, x):
-        x = self.act1(self.bn1(self.conv1(x)))  # no max-pool (ref :431)
+        x = stem_forward(self.conv1, self.bn1, self.act1, x)  # no max-pool (ref :431)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
     def forward(self, x):

@@ -169,6 +169,7 @@ int conv1x1_wgrad_lds_run(const void*, const void*, const void*, int, void*, voi
 extern int g_wgrad2_tune;  // conv_wgrad2.hip (third-generation weight gradient)
 extern int g_pool_tile;    // pool3x3.hip (row-block pooling kernels)
 template <typename T> int subsample2(int bwd, const void* a, void* out, int64_t planes, int H, int W, hipStream_t stream);
+template <typename T> int avgpool2x2s2(int bwd, const void* a, void* out, int64_t planes, int H, int W, hipStream_t stream);
 bool conv1x1_wgrad2_covers(int N, int HW, int M, int J, int k1, bool two_slabs);
 int conv1x1_wgrad2_splits(int N, int M, int J, int HW, int has_bias);
 int conv1x1_wgrad2_run(const void*, const void*, const void*, int, void*, void*, float*, int, int, int, int, hipStream_t, int sy = 0,
@@ -966,6 +967,21 @@ int cot_subsample2_forward(const void* x, void* y, int64_t planes, int H, int W,
 }
 int cot_subsample2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream) {
     return subsample_call(1, gy, gx, planes, H, W, dtype, stream);
+}
+static int avgpool2_call(int bwd, const void* a, void* out, int64_t planes, int H, int W, int dtype, void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive planes/H/W");
+    if (!a || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    int rc = COT_ERR_UNSUPPORTED;
+    if (dtype == COT_F32) rc = avgpool2x2s2<float>(bwd, a, out, planes, H, W, (hipStream_t)stream);
+    else if (dtype == COT_BF16) rc = avgpool2x2s2<bf16_t>(bwd, a, out, planes, H, W, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_avgpool2x2s2_*: even H and W, float32 / bfloat16 (H %d W %d dtype %d given)", H, W, dtype);
+    return rc;
+}
+int cot_avgpool2x2s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream) {
+    return avgpool2_call(0, x, y, planes, H, W, dtype, stream);
+}
+int cot_avgpool2x2s2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream) {
+    return avgpool2_call(1, gy, gx, planes, H, W, dtype, stream);
 }
 int cot_avgpool3x3s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream) {
     return pool_call(0, x, nullptr, y, planes, H, W, dtype, stream);

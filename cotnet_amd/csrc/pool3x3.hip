@@ -409,6 +409,65 @@ int subsample2(int bwd, const void* a, void* out, int64_t planes, int H, int W, 
 template int subsample2<float>(int, const void*, void*, int64_t, int, int, hipStream_t);
 template int subsample2<bf16_t>(int, const void*, void*, int64_t, int, int, hipStream_t);
 
+// ---- nn.AvgPool2d(2, 2) on even planes (the pooling in front of the 1x1 projection of an `avg_down` shortcut, models/resnet.py:
+// 377-394 downsample_avg: AvgPool2d(2, stride, ceil_mode=True, count_include_pad=False) -- on even H and W every window is a full
+// 2 x 2 block, so neither flag matters).  torch's avg_pool2d_backward took 585 us per launch in SE-CoTNetD-152's step (gpurun_out/
+// r4v_secot_per_shape.csv: 4 launches, 2.3 ms) for a broadcast of g / 4.  A lane owns BG outputs (forward: two rows of 2 BG inputs)
+// or the 2 x 2 BG input-gradient block under BG outputs (backward).  Sum in torch's order (row-major window), divided by 4.
+template <typename T, int BG>
+__global__ __launch_bounds__(256) void avgpool2x2s2_fwd_blk(const T* __restrict__ x, T* __restrict__ y, int64_t planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2, NB = Wo / BG;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ho * NB) return;
+    const int bg = (int)(i % NB), oh = (int)((i / NB) % Ho);
+    const int64_t pl = i / ((int64_t)NB * Ho);
+    const T* rp = x + pl * H * W + (int64_t)(2 * oh) * W + 2 * bg * BG;
+    const Vec<T, 2 * BG> r0 = ldv<T, 2 * BG>(rp), r1 = ldv<T, 2 * BG>(rp + W);
+    Vec<T, BG> o;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+        float sum = (float)r0.v[2 * j];
+        sum += (float)r0.v[2 * j + 1];
+        sum += (float)r1.v[2 * j];
+        sum += (float)r1.v[2 * j + 1];
+        o.v[j] = (T)(sum * 0.25f);
+    }
+    stv<T, BG>(y + pl * Ho * Wo + (int64_t)oh * Wo + bg * BG, o);
+}
+
+template <typename T, int BG>
+__global__ __launch_bounds__(256) void avgpool2x2s2_bwd_blk(const T* __restrict__ gy, T* __restrict__ gx, int64_t planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2, NB = Wo / BG;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ho * NB) return;
+    const int bg = (int)(i % NB), oh = (int)((i / NB) % Ho);
+    const int64_t pl = i / ((int64_t)NB * Ho);
+    const Vec<T, BG> g = ldv<T, BG>(gy + pl * Ho * Wo + (int64_t)oh * Wo + bg * BG);
+    Vec<T, 2 * BG> o;
+#pragma unroll
+    for (int j = 0; j < BG; ++j) o.v[2 * j] = o.v[2 * j + 1] = (T)((float)g.v[j] * 0.25f);
+    T* op = gx + pl * H * W + (int64_t)(2 * oh) * W + 2 * bg * BG;
+    stv<T, 2 * BG>(op, o);
+    stv<T, 2 * BG>(op + W, o);
+}
+
+template <typename T>
+int avgpool2x2s2(int bwd, const void* a, void* out, int64_t planes, int H, int W, hipStream_t stream) {
+    if ((H & 1) || (W & 1)) return COT_ERR_UNSUPPORTED;
+    const int Ho = H / 2, Wo = W / 2;
+    const bool odd16 = ((H * W) & 7) || ((Ho * Wo) & 7) || (W & 7), odd8 = ((H * W) & 3) || ((Ho * Wo) & 3) || (W & 3);
+    const int BG = (Wo % 4 == 0 && !odd16) ? 4 : ((Wo % 2 == 0 && !odd8) ? 2 : 1);
+    const dim3 grid((unsigned)ceil_div64(planes * Ho * (Wo / BG), 256)), block(256);
+#define COT_AVG2(BG_)                                                                                                    \
+    if (bwd) COT_LAUNCH((avgpool2x2s2_bwd_blk<T, BG_>), grid, block, 0, stream, (const T*)a, (T*)out, planes, H, W);     \
+    else COT_LAUNCH((avgpool2x2s2_fwd_blk<T, BG_>), grid, block, 0, stream, (const T*)a, (T*)out, planes, H, W)
+    if (BG == 4) { COT_AVG2(4); } else if (BG == 2) { COT_AVG2(2); } else { COT_AVG2(1); }
+#undef COT_AVG2
+    return check_launch("avgpool2x2s2");
+}
+template int avgpool2x2s2<float>(int, const void*, void*, int64_t, int, int, hipStream_t);
+template int avgpool2x2s2<bf16_t>(int, const void*, void*, int64_t, int, int, hipStream_t);
+
 int g_pool_tile = 1;  // cot_set_tuning key 27: 0 = one lane per pixel only
 // windows per lane of the row-block form (0: not eligible): W even, every wide access naturally aligned
 static int pool_blk_group(int op, int H, int W, int Ho, int Wo) {

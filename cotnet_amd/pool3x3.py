@@ -5,6 +5,7 @@ padding=1)` (the "avd" pooling of stride-2 bottlenecks, models/cotnet.py:216) wi
 memory speed -- torch's max_pool_backward / avg_pool2d_backward were 436 us and 3 x 163 us of the round-1 step for ~30 us of
 traffic each; the max-pool forward keeps the arg-max as one byte per window (torch's tie rule) and the backward reads that instead
 of an int64 index tensor (or x).
+Also `nn.AvgPool2d(2, 2)` on even planes (the pooling of an `avg_down` shortcut, models/resnet.py:377-394).
 Any other module or tensor (other geometry, ceil_mode, fp64, channels-last, CPU) takes the module itself.
 """
 import ctypes
@@ -53,6 +54,29 @@ class _AvgPool(Function):
         rc = _lib.lib().cot_avgpool3x3s2_backward(_p(gy), _p(gx), N * C, H, W, _DT[gy.dtype], _stream())
         if rc:
             _lib.check(rc, "cot_avgpool3x3s2_backward")
+        return gx
+
+
+class _AvgPool2(Function):
+    """nn.AvgPool2d(2, 2) on even planes (downsample_avg's pooling, models/resnet.py:377-394)"""
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        rc = _lib.lib().cot_avgpool2x2s2_forward(_p(x), _p(y), N * C, H, W, _DT[x.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_avgpool2x2s2_forward")
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty(ctx.shape, dtype=gy.dtype, device=gy.device)
+        rc = _lib.lib().cot_avgpool2x2s2_backward(_p(gy), _p(gx), N * C, H, W, _DT[gy.dtype], _stream())
+        if rc:
+            _lib.check(rc, "cot_avgpool2x2s2_backward")
         return gx
 
 
@@ -124,6 +148,10 @@ def eligible(module, x):
     if isinstance(module, nn.MaxPool2d):
         return (_pair(module.kernel_size) == (3, 3) and _pair(module.stride) == (2, 2) and _pair(module.padding) == (1, 1)
                 and _pair(module.dilation) == (1, 1) and not module.ceil_mode and not module.return_indices)
+    if isinstance(module, nn.AvgPool2d) and _pair(module.kernel_size) == (2, 2):
+        # even planes: every window is a full 2 x 2 block whatever ceil_mode / count_include_pad say
+        return (_pair(module.stride) == (2, 2) and _pair(module.padding) == (0, 0) and module.divisor_override is None
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
     if isinstance(module, nn.AvgPool2d):
         return (_pair(module.kernel_size) == (3, 3) and _pair(module.stride) == (2, 2) and _pair(module.padding) == (1, 1)
                 and not module.ceil_mode and module.count_include_pad and module.divisor_override is None)
@@ -133,5 +161,7 @@ def eligible(module, x):
 def pool(module, x):
     """`module(x)`; the two backbone poolings go through the HIP kernels when COT_POOL=hip and the tensor qualifies"""
     if MODE == "hip" and eligible(module, x):
-        return (_MaxPool if isinstance(module, nn.MaxPool2d) else _AvgPool).apply(x)
+        if isinstance(module, nn.MaxPool2d):
+            return _MaxPool.apply(x)
+        return (_AvgPool2 if _pair(module.kernel_size) == (2, 2) else _AvgPool).apply(x)
     return module(x)

@@ -104,6 +104,28 @@ def make_stem(in_chans, stem_width, stem_type, norm_layer, act_layer):
     return conv1, inplanes
 
 
+def stem_forward(conv1, bn1, act1, x):
+    """act1(bn1(conv1(x))) (resnet.py:593-596; cotnet_hybrid.py:431).  Every BatchNorm + ReLU pair -- the two inside a deep
+    stem's nn.Sequential and bn1 / act1 behind it -- is one fused pass of the library (MIOpen's BatchNorm took 0.74 - 1 ms per
+    call on SE-CoTNetD's 64 x 64..128 x 160 x 160 stem tensors, six calls per step: gpurun_out/r4v_secot_per_shape.csv); the
+    7 x 7 convolution of the plain stem goes through `stem_conv`, a deep stem's 3 x 3 convolutions stay the modules."""
+    relu = isinstance(act1, nn.ReLU)
+    if isinstance(conv1, nn.Sequential):
+        mods = list(conv1)
+        i = 0
+        while i < len(mods):
+            if (i + 2 < len(mods) and isinstance(mods[i], nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d)
+                    and isinstance(mods[i + 2], nn.ReLU)):
+                x = fused_bn_act(mods[i](x), mods[i + 1], "relu")  # (falls back to the modules' own arithmetic when not eligible)
+                i += 3
+            else:
+                x = mods[i](x)
+                i += 1
+    else:
+        x = stem_conv(conv1, x) if relu else conv1(x)
+    return fused_bn_act(x, bn1, "relu") if relu else act1(bn1(x))
+
+
 def init_weights(model, zero_init_last_bn=True):
     """kaiming-normal(fan_out, relu) on every Conv2d, BN gamma=1 beta=0, then bn3.weight=0 per block
     (resnet.py:575-584).  GroupNorm / Linear keep torch defaults, as in the reference."""
@@ -163,10 +185,7 @@ class ResNet(nn.Module):
 
     def forward_features(self, x):
         cot_layer_fused.prepare_drop_path(self, x)  # (single-node blocks: one vectorised stochastic-depth draw per step)
-        if isinstance(self.act1, nn.ReLU):
-            x = fused_bn_act(stem_conv(self.conv1, x), self.bn1, "relu")  # stem BN + ReLU in one pass over 112x112
-        else:
-            x = self.act1(self.bn1(self.conv1(x)))
+        x = stem_forward(self.conv1, self.bn1, self.act1, x)  # stem BN + ReLU in one pass over 112x112
         x = pool(self.maxpool, x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 

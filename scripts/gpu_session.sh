@@ -42,6 +42,12 @@ case $what in
   graph) timeout 200 python scripts/try_graph_step.py 10 cotnext101_2x48d 64 224 > $O/${T}_graph_cotnext.log 2>&1; tail -3 $O/${T}_graph_cotnext.log | cut -c1-300
          timeout 300 python scripts/try_graph_step.py 10 se_cotnetd_152_L 64 320 > $O/${T}_graph_secot.log 2>&1; tail -3 $O/${T}_graph_secot.log | cut -c1-300 ;;
   roofobj) timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); r=l['roofline']; print(l['value'], {k: r[k] for k in ('kernel','shape','achieved','frac','traffic','avg_us')}); [print(k) for k in r['kernels']]" ;;
+  r4v) timeout 600 python -m pytest tests/test_pool_gpu.py tests/test_gn_fusion_gpu.py tests/test_fused_layer_gpu.py tests/test_agg_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 2>&1 | tail -8 > $O/${T}_tests.log; tail -3 $O/${T}_tests.log
+       bash scripts/gpu_trace_new.sh ${T}_secot --model se_cotnetd_152_L --img 320 --batch 64 > $O/${T}_trace_sh.log 2>&1; tail -2 $O/${T}_trace_sh.log | cut -c1-200 ;;
+  r4w) timeout 600 python -m pytest tests/test_pool_gpu.py tests/test_layers_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 2>&1 | tail -8 > $O/${T}_tests.log; tail -3 $O/${T}_tests.log
+       timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 10 --warmup 3 --model se_cotnetd_152_L --img 320 --batch 64 2>/dev/null | cut -c1-200
+       bash scripts/gpu_trace_new.sh ${T}_cotnext --model cotnext101_2x48d --batch 64 > $O/${T}_trace_sh.log 2>&1
+       bash scripts/gpu_trace_new.sh ${T}_fp32 --dtype fp32 --batch 80 >> $O/${T}_trace_sh.log 2>&1 ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac
 done

@@ -2238,6 +2238,40 @@ def test_blurpool_kernels_match_the_reference_formula(N, C, H, W, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 2, 16, 16), (2, 1, 20, 20), (1, 3, 6, 10), (1, 2, 2, 2), (1, 1, 4, 24), (1, 5, 2, 6)])
+def test_avgpool2x2_kernels_match_the_module(N, C, H, W, dtype, monkeypatch):
+    """cot_avgpool2x2s2_* against nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False) -- downsample_avg's pooling
+    (models/resnet.py:377-394) -- bit for bit (same sum order, one division), every element of the gradient written; odd
+    planes are refused; `pool()` / `run_downsample` route the module onto the kernel"""
+    from cotnet_amd import conv1x1 as c1, pool3x3 as p3
+    torch.manual_seed(53)
+    dt = _lib.dtype_code(dtype)
+    mod = torch.nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False)
+    x = torch.randn(N, C, H, W).to(dtype)
+    gy = torch.randn(N, C, H // 2, W // 2).to(dtype)
+    xr = x.clone().requires_grad_(True)
+    yr = mod(xr)
+    yr.backward(gy)
+    y, gx = torch.full_like(yr, float("nan")), torch.full_like(x, float("nan"))
+    assert _EMUL.cot_avgpool2x2s2_forward(P(x), P(y), N * C, H, W, dt, None) == 0
+    assert _EMUL.cot_avgpool2x2s2_backward(P(gy), P(gx), N * C, H, W, dt, None) == 0
+    assert torch.equal(y, yr.detach()) and torch.equal(gx, xr.grad)
+    assert _EMUL.cot_avgpool2x2s2_forward(P(x), P(y), N * C, H + 1, W, dt, None) == -2
+    assert _EMUL.cot_avgpool2x2s2_backward(P(gy), P(gx), N * C, H, W - 1, dt, None) == -2
+    # module routing
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    monkeypatch.setattr(p3, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(p3, "MODE", "hip")
+    assert p3.eligible(mod, x) and not p3.eligible(mod, x[:, :, :-1]) and not p3.eligible(torch.nn.AvgPool2d(2, 1), x)
+    xa = x.clone().requires_grad_(True)
+    ds = torch.nn.Sequential(mod, torch.nn.Identity())
+    ya = c1.run_downsample(ds, xa)
+    assert "AvgPool2" in type(ya.grad_fn).__name__
+    ya.backward(gy)
+    assert torch.equal(ya.detach(), yr.detach()) and torch.equal(xa.grad, xr.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,C,H,W", [(2, 8, 8, 8), (3, 4, 7, 7), (1, 6, 5, 3), (2, 2, 20, 20)])
 def test_se_gate_kernels(B, C, H, W, dtype):
     torch.manual_seed(53)

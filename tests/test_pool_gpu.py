@@ -66,6 +66,27 @@ def test_blur_pool_matches_the_reference_formula(N, C, H, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H", [(64, 256, 80), (64, 512, 40), (64, 1024, 20), (3, 5, 6), (2, 3, 2)])
+def test_avgpool2x2_of_the_avg_down_shortcut_is_exact(N, C, H, dtype, monkeypatch):
+    """nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False) of downsample_avg (models/resnet.py:377-394) at the tensor
+    sizes of se_cotnetd_152_L at 320 x 320, B = 64: `pool()` takes the library's kernel, forward and gradient equal torch's
+    bit for bit"""
+    torch.manual_seed(H)
+    mod = nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False)
+    x = torch.randn(N, C, H, H, device=DEV).to(dtype)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    monkeypatch.setattr(p3, "MODE", "hip")
+    assert p3.eligible(mod, xa)
+    ya = p3.pool(mod, xa)
+    assert "AvgPool2" in type(ya.grad_fn).__name__
+    yb = mod(xb)
+    g = torch.randn_like(yb)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,C,H", [(80, 256, 56), (80, 512, 28), (80, 1024, 14), (3, 5, 6), (2, 3, 2)])
 def test_subsample2_is_exact(N, C, H, dtype):
     """cot_subsample2_*: the input of a stride-2 1x1 projection shortcut (x[:, :, ::2, ::2]) and its gradient, bit-exact; the
