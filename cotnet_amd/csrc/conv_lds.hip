@@ -306,14 +306,18 @@ struct C3LdsArgs {
 
 // K16: KK == 16 (two taps per K step, 5 steps); else KK % 32 == 0 (9 steps per 32-channel chunk).  XP = X copies per thread
 // and chunk (compile-time so that the vmcnt arithmetic is uniform; the host picks TR / ni to fit).
-template <int CB, int MB, int FLAT, int K16, int XP, int WAVES>
+// NSW: weight-tile ring (NSW - 1 steps' copies in flight ahead of the one being read).  The loop is bound by the round trip of
+// those copies, not by its arithmetic: with 3 buffers a step took 1.2 - 1.5 us whatever its MFMA count (CoTNet-50's 14 x 14 and
+// 7 x 7 key embeddings: 18 / 36 steps, 27 / 42 us per launch, profiles/r04_rocprofv3_kernel_trace_new_per_shape.csv).
+template <int CB, int MB, int FLAT, int K16, int XP, int WAVES, int NSW>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArgs a) {
     constexpr int NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB;
     constexpr int CH = K16 ? 16 : 32;                 // channels per staged chunk
     constexpr int WPASS = (BM * 4 + NT - 1) / NT;
-    constexpr int XST = XP * NT * 8, WST = WPASS * NT * 8, NSW = 3;
+    constexpr int XST = XP * NT * 8, WST = WPASS * NT * 8, D = NSW - 1;
     constexpr int GW = WPASS, GX = XP;
-    static_assert(GW + GX <= 63, "vmcnt range");
+    static_assert((D - 1) * GW + GX <= 63, "vmcnt range");
+    static_assert(D >= 2 && D - 1 <= (K16 ? 5 : 9), "at most one X stage among the copies in flight");
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     bf16_t* const wsm = reinterpret_cast<bf16_t*>(cot_smem);  // [NSW][WST] then [2][XST]
     bf16_t* const xsm = wsm + NSW * WST;
@@ -430,18 +434,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
 #pragma unroll
         for (int mbk = 0; mbk < MB; ++mbk) acc[cb][mbk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    stage(0);
-    if (nsteps > 1) stage(1);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nsteps) stage(d);
     for (int s = 0; s < nsteps; ++s) {
-        // leave exactly the copies of step s+1 in flight (NSW = 3: one step ahead besides the one being read)
-        if (s + 1 < nsteps) {
-            if ((s + 1) % spc == 0) COT_WAIT_VM(GW + GX);
-            else COT_WAIT_VM(GW);
-        } else {
-            COT_WAIT_VM(0);
-        }
+        // leave exactly the copies of steps s+1 .. s+D-1 in flight; when one of them opens a chunk its X copies (issued with it,
+        // ahead of its W copies) stay in flight too
+        const int ahead = min(D - 1, nsteps - 1 - s);
+        const int nxt = (s / spc + 1) * spc;  // first step of the next chunk
+        if (nxt <= s + ahead) WaitBehindX<GW, GX, D - 1>::go(ahead);
+        else WaitBehind<GW, D - 1>::go(ahead);
         COT_LDS_BARRIER();
-        if (s + 2 < nsteps) stage(s + 2);
+        if (s + D < nsteps) stage(s + D);
         const int cc = s / spc, tp = s - cc * spc;
         const uint16_t* xb = reinterpret_cast<const uint16_t*>(xsm + (cc & 1) * XST);
         const bf16_t* wb = wsm + (s % NSW) * WST;
@@ -485,22 +489,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
-template <int CB, int MB, int FLAT, int K16, int XP>
-static int launch_c3(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
+int g_conv3x3_ring = 5;  // cot_set_tuning key 38: weight-tile ring of conv3x3g_lds_fwd (3 | 5)
+template <int CB, int MB, int FLAT, int K16, int XP, int NSW>
+static int launch_c3n(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
     constexpr int WAVES = 8, NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB;
     constexpr int XST = XP * NT * 8, WST = ((BM * 4 + NT - 1) / NT) * NT * 8;
     const int ncc = K16 ? 1 : a.KK / 32;
-    size_t lds = (size_t)(3 * WST + (ncc > 1 ? 2 : 1) * XST) * sizeof(bf16_t);
+    size_t lds = (size_t)(NSW * WST + (ncc > 1 ? 2 : 1) * XST) * sizeof(bf16_t);
     const size_t otile = (FLAT ? (size_t)a.ni * (((size_t)BM * a.H * a.W + 7) & ~(size_t)7) : (size_t)BM * (BPX + 8)) * sizeof(bf16_t);
     if (otile > lds) lds = otile;
     C3LdsArgs b = a;
     b.xcd_remap = (blocks % 8 == 0) ? 1 : 0;
     static std::atomic<uint32_t> raised{0};
     if (lds > 64 * 1024 &&
-        !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv3x3g_lds_fwd<CB, MB, FLAT, K16, XP, WAVES>)))
+        !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv3x3g_lds_fwd<CB, MB, FLAT, K16, XP, WAVES, NSW>)))
         return -1;  // (not covered: the caller takes the first-generation kernel)
-    COT_LAUNCH((conv3x3g_lds_fwd<CB, MB, FLAT, K16, XP, WAVES>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
+    COT_LAUNCH((conv3x3g_lds_fwd<CB, MB, FLAT, K16, XP, WAVES, NSW>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
     return check_launch("conv3x3g_lds_fwd");
+}
+template <int CB, int MB, int FLAT, int K16, int XP>
+static int launch_c3(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
+    if (g_conv3x3_ring >= 5) return launch_c3n<CB, MB, FLAT, K16, XP, 5>(a, blocks, stream);
+    return launch_c3n<CB, MB, FLAT, K16, XP, 3>(a, blocks, stream);
 }
 
 // KK / MM: reduction / output channels per group.  MM: any multiple of 8 up to 128 (the tile's rows past MM are clamped copies,

@@ -108,6 +108,16 @@ template <int G, int A> struct WaitBehind {
 template <int G> struct WaitBehind<G, 0> {
     static __device__ __forceinline__ void go(int) { COT_WAIT_VM(0); }
 };
+// the same when GX further copies (the next chunk's X stage, issued ahead of its stage's own G copies) are among those in flight
+template <int G, int GX, int A> struct WaitBehindX {
+    static __device__ __forceinline__ void go(int ahead) {
+        if (ahead >= A) COT_WAIT_VM(A * G + GX);
+        else WaitBehindX<G, GX, A - 1>::go(ahead);
+    }
+};
+template <int G, int GX> struct WaitBehindX<G, GX, 0> {
+    static __device__ __forceinline__ void go(int) { COT_WAIT_VM(0); }
+};
 
 // ---- epilogue through LDS (shared by the 1x1 and the grouped 3x3 kernels).  In the C/D map a lane holds 4 consecutive
 // pixels of ONE channel and the 16 lanes of a group 16 different channels: stored directly that is 32 contiguous bytes per

@@ -148,6 +148,7 @@ extern int g_wgrad_lds_cap_pct;
 extern int g_bn_chan;
 // implemented in conv_lds.hip
 extern int g_conv_lds_tune[3];
+extern int g_conv3x3_ring;
 extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
 unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
@@ -342,6 +343,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key >= 15 && key <= 17) {
         g_conv_lds_tune[key - 15] = value;
+        return COT_OK;
+    }
+    if (key == 38) {
+        g_conv3x3_ring = value >= 5 ? 5 : 3;
         return COT_OK;
     }
     if (key == 18) {

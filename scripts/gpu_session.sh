@@ -48,6 +48,8 @@ case $what in
        timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 10 --warmup 3 --model se_cotnetd_152_L --img 320 --batch 64 2>/dev/null | cut -c1-200
        bash scripts/gpu_trace_new.sh ${T}_cotnext --model cotnext101_2x48d --batch 64 > $O/${T}_trace_sh.log 2>&1
        bash scripts/gpu_trace_new.sh ${T}_fp32 --dtype fp32 --batch 80 >> $O/${T}_trace_sh.log 2>&1 ;;
+  ring) for r in 3 5 3 5; do echo "== ring $r"; timeout 200 python scripts/bench_conv_abi.py --iters 20 --modes 1 --only "g4" --tune 38=$r 2>/dev/null | grep "g4"; done > $O/${T}_ring.log 2>&1; cat $O/${T}_ring.log | cut -c1-120
+        for r in 3 5; do COT_TUNING=38=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('ring $r', l['value'], l['ms_per_step'])"; done ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac
 done

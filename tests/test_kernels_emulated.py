@@ -1014,9 +1014,14 @@ def test_conv3x3_grouped_weight_gradient_guard_decides_the_kernel():
     (1, 512, 2, 20, 20),   # BIG, two real groups x two row blocks
     (1, 64, 1, 6, 160),    # BIG, rows of 160 pixels (SE-CoTNetD's stem / first block at 320 x 320): one image row per tile
 ])
-def test_conv3x3_grouped_lds_kernels(N, C, G, H, W):
+@pytest.mark.parametrize("ring,dma", [(5, 0), (5, 1), (3, 1)])
+def test_conv3x3_grouped_lds_kernels(N, C, G, H, W, ring, dma, request):
     """csrc/conv_lds.hip conv3x3g_lds_fwd (forward and data gradient incl. accumulate) against torch on the same rounded
-    operands, and against the first-generation kernel"""
+    operands, and against the first-generation kernel; both weight-tile rings (tuning key 38), copies landing at the earliest
+    and at the latest legal time (the vmcnt arithmetic and the buffer re-use of the ring)"""
+    assert _EMUL.cot_set_tuning(38, ring) == 0
+    _EMUL.emul_set_dma_mode(dma)
+    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(38, 5), _EMUL.emul_set_dma_mode(0)))
     torch.manual_seed(17)
     x = torch.randn(N, C, H, W).bfloat16()
     w = (torch.randn(C, C // G, 3, 3) / (9 * C // G) ** 0.5).bfloat16()

@@ -35,9 +35,12 @@ def test_matches_torch_pooling(kind, N, C, H, dtype, monkeypatch):
 def test_other_poolings_keep_the_module(monkeypatch):
     monkeypatch.setattr(p3, "MODE", "hip")
     x = torch.randn(2, 4, 8, 8, device=DEV)
-    for mod in (nn.MaxPool2d(2, 2), nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False), nn.MaxPool2d(3, 1, 1)):
+    for mod in (nn.MaxPool2d(2, 2), nn.AvgPool2d(2, 1), nn.AvgPool2d(2, 2, padding=1), nn.MaxPool2d(3, 1, 1)):
         assert not p3.eligible(mod, x)
         assert torch.equal(p3.pool(mod, x), mod(x))
+    odd = x[:, :, :7, :7].contiguous()  # (a 2 x 2 average pooling with ceil_mode on an odd plane has partial windows: the module)
+    mod = nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False)
+    assert not p3.eligible(mod, odd) and torch.equal(p3.pool(mod, odd), mod(odd))
     assert not p3.eligible(nn.MaxPool2d(3, 2, 1), x.double())
 
 
