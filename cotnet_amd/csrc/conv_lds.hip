@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
-int g_conv3x3_ring = 5;  // cot_set_tuning key 38: weight-tile ring of conv3x3g_lds_fwd (3 | 5)
+int g_conv3x3_ring = 3;  // (cot_set_tuning key 38: kept for A/B builds; see launch_c3)
 template <int CB, int MB, int FLAT, int K16, int XP, int NSW>
 static int launch_c3n(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
     constexpr int WAVES = 8, NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB;
@@ -509,8 +509,327 @@ static int launch_c3n(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
 }
 template <int CB, int MB, int FLAT, int K16, int XP>
 static int launch_c3(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
-    if (g_conv3x3_ring >= 5) return launch_c3n<CB, MB, FLAT, K16, XP, 5>(a, blocks, stream);
+    // (a ring of 5 -- four steps' copies in flight -- measured no faster anywhere and slower at 56 x 56: gpurun_out/r4x_ring.log;
+    // only the ring of 3 is built)
     return launch_c3n<CB, MB, FLAT, K16, XP, 3>(a, blocks, stream);
+}
+
+// ====================================================================================================================
+// Third form of the 3x3 kernel ("chunk-resident", round 4): ALL taps of a 32-channel chunk's weights sit in LDS beside the
+// chunk's input rows -- one wait + one barrier per CHUNK instead of per (chunk, tap) step, the nine taps of a chunk run without
+// any synchronisation and the next chunk's copies (input rows + weights, into the other pair of buffers) overlap them.
+// Why: the per-step ring is bound by the serial chain inside a step (barrier -> address arithmetic -> 2-byte gathers -> LDS
+// latency -> pack / select -> MFMA) at two waves per SIMD, not by memory or by the copies' round trip -- CoTNet-50's 14 x 14 /
+// 7 x 7 key embeddings took 27 / 42 us for 18 / 36 steps (0.9 us per step + 12 us), a deeper weight ring changed nothing
+// (gpurun_out/r4x_ring.log), and the loop issued ~250 instructions per step and wave for 8 MFMAs.  Here, per (column block, tap):
+// eight 2-byte reads whose addresses are (a per-lane offset, fixed for the kernel) + (a per-row scalar) + (the tap's column as an
+// immediate), four v_perm, one bit-field extract of the tap's validity bit as a mask, four v_and -- and no barrier, so the
+// scheduler overlaps one tap's reads with the previous tap's MFMAs.
+// Masked positions are not clamped: their addresses stay inside the workgroup's LDS (the input buffers lie behind the weight
+// buffers, 1 KB of slack follows them) and whatever they read is cleared by the AND.
+// Output rows come in blocks of at most 64 per workgroup ("virtual groups" sharing the real group's input, as MBLK above).
+template <int CB, int MB, int FLAT, int K16, int XP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArgs a) {
+    constexpr int NT = 64 * WAVES, BM = 16 * MB;
+    constexpr int CH = K16 ? 16 : 32, SPC = K16 ? 5 : 9;
+    constexpr int WPIECES = SPC * BM * 4, WP = (WPIECES + NT - 1) / NT;
+    constexpr int WBUF = WP * NT * 8, XST = XP * NT * 8;  // elements per weight / input buffer
+    static_assert(WP + XP <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int H = a.H, W = a.W, HW = H * W, KK = a.KK, MM = a.MM, G = a.G;
+    const int ncc = K16 ? 1 : KK / 32, nb = ncc > 1 ? 2 : 1;
+    bf16_t* const wsm = reinterpret_cast<bf16_t*>(cot_smem);  // [nb][WBUF] then [nb][XST] then slack
+    bf16_t* const xsm = wsm + nb * WBUF;
+
+    unsigned b = blockIdx.x;
+    if (a.xcd_remap && (gridDim.x & 7u) == 0) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
+    const int grp = b % G;
+    const int t = b / G;
+    int n0, r0 = 0, ncols, gs = 0;
+    if (FLAT) {
+        n0 = t * a.ni;
+        ncols = min(a.ni, a.N - n0) * HW;
+    } else {
+        n0 = t / a.tiles;
+        r0 = (t - n0 * a.tiles) * a.TR;
+        ncols = min(a.TR, H - r0) * W;
+        gs = max(0, (r0 - 1) * W) & ~7;
+    }
+    const int SLc = FLAT ? HW : a.SL;
+    const int xelems = FLAT ? a.ni * CH * HW : CH * a.SL;
+    const int KX = a.KX;
+    const int64_t x_total = (int64_t)a.N * a.CX * HW;
+    const int xg = grp / a.MBLK;
+
+    // ---- copies of this thread: input rows (as in conv3x3g_lds_fwd), and the chunk's weights: piece q = (tap step, row, swizzled
+    // 8-channel position) lands at element 8 q of the buffer
+    int64_t xoff[XP];
+#pragma unroll
+    for (int ps = 0; ps < XP; ++ps) {
+        const int q = min(ps * NT + tid, xelems / 8 - 1);
+        int64_t e;
+        if (FLAT) {
+            const int cpi = CH * HW / 8, img = q / cpi, c = q - img * cpi;
+            e = ((int64_t)min(n0 + img, a.N - 1) * a.CX + (int64_t)xg * KX) * HW + (int64_t)c * 8;
+        } else {
+            const int cpc = a.SL / 8, ch = q / cpc, c = q - ch * cpc;
+            e = ((int64_t)n0 * a.CX + (int64_t)xg * KX + ch) * HW + gs + c * 8;
+        }
+        xoff[ps] = e;
+    }
+    int woff[WP];
+#pragma unroll
+    for (int ps = 0; ps < WP; ++ps) {
+        const int q = min(ps * NT + tid, WPIECES - 1);
+        const int tp = q / (BM * 4), within = q - tp * (BM * 4);
+        const int row = within >> 2, pos = within & 3, c = pos ^ ((row >> 2) & 3);
+        const int rr = min(row, MM - 1);
+        if (K16) woff[ps] = ((2 * tp + (c >> 1)) * MM + rr) * 16 + (c & 1) * 8;  // tap 2 tp + (c >> 1) ("tap 9": zeros), channels 8 (c & 1)..
+        else woff[ps] = (tp * MM + rr) * KK + c * 8;
+    }
+    const bf16_t* wgrp = a.wr + (int64_t)grp * (K16 ? 10 : 9) * MM * KK;
+    auto stage = [&](int cc) __attribute__((always_inline)) {
+        bf16_t* xd = xsm + (cc & 1) * XST;
+#pragma unroll
+        for (int ps = 0; ps < XP; ++ps) {
+            int64_t e = xoff[ps] + (int64_t)cc * CH * HW;
+            if (e + 8 > x_total) e = x_total - 8;  // (the last tile's halo row past the tensor: in-bounds bytes, masked)
+            COT_GLDS16(a.x + e, xd + (ps * NT + wave * 64) * 8);
+        }
+        bf16_t* wd = wsm + (cc & 1) * WBUF;
+#pragma unroll
+        for (int ps = 0; ps < WP; ++ps) COT_GLDS16(wgrp + woff[ps] + cc * 32, wd + (ps * NT + wave * 64) * 8);
+    };
+    stage(0);
+
+    // ---- per-lane byte offsets (inside an input buffer) of the lane's column in every column block, per channel of its 8;
+    // validity bits of the 9 taps
+    int aoff[CB][8];
+    unsigned amask[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int col = (wave * CB + cb) * 16 + i16;
+        int h, w, base;
+        bool ok;
+        if (FLAT) {
+            const int cc = min(col, a.ni * HW - 1), img = cc / HW, p = cc - img * HW;
+            h = p / W; w = p - h * W;
+            base = img * CH * HW + p;
+            ok = col < ncols;
+        } else {
+            const int cc = min(col, a.TR * W - 1);
+            h = r0 + cc / W; w = cc - (cc / W) * W;
+            base = r0 * W + cc - gs;
+            ok = col < ncols;
+        }
+        unsigned m = 0;
+        if (ok) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int hh = h + tp / 3 - 1, ww = w + tp % 3 - 1;
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W) m |= 1u << tp;
+            }
+        }
+        if (K16 && (g >> 1)) m >>= 1;  // (lane groups 2, 3 take the step's second tap: bit 2t of m is tap 2t + 1; "tap 9" = bit 8 = 0)
+        amask[cb] = m;
+        const int b0 = base + (K16 ? 8 * (g & 1) : 8 * g) * SLc;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) aoff[cb][k] = (b0 + k * SLc) * 2;
+    }
+    int boff[MB];
+#pragma unroll
+    for (int mbk = 0; mbk < MB; ++mbk) {
+        const int row = mbk * 16 + i16;
+        boff[mbk] = (row * 32 + (g ^ ((row >> 2) & 3)) * 8) * 2;
+    }
+    f32x4_t acc[CB][MB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int mbk = 0; mbk < MB; ++mbk) acc[cb][mbk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const char* const xs0 = reinterpret_cast<const char*>(xsm);
+    const char* const ws0 = reinterpret_cast<const char*>(wsm);
+    for (int cc = 0; cc < ncc; ++cc) {
+        COT_WAIT_VM(0);     // this chunk's rows and weights (this wave's pieces) have landed ...
+        COT_LDS_BARRIER();  // ... everybody's have, and everybody is done with the other pair of buffers
+        if (cc + 1 < ncc) stage(cc + 1);
+        const char* xb = xs0 + (cc & 1) * (XST * 2);
+        const char* wb = ws0 + (cc & 1) * (WBUF * 2);
+        // (a padded chunk's channels past the group's end belong to the next group: cleared like the padded taps; KX % 8 == 0)
+        const bool chan_ok = K16 || cc * 32 + 8 * g < KX;
+        unsigned am[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) am[cb] = chan_ok ? amask[cb] : 0u;
+        if (!K16) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const char* xr = xb + ((dy - 1) * W - 1) * 2;  // (scalar) row dy, column -1: the taps' columns are immediates 0, 2, 4
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int tap = dy * 3 + dx;
+                    bf16x8_t af[CB];
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        uint32_t q[4];
+#pragma unroll
+                        for (int hh = 0; hh < 4; ++hh) {
+                            const uint32_t lo = *reinterpret_cast<const uint16_t*>(xr + aoff[cb][2 * hh] + 2 * dx);
+                            const uint32_t hi = *reinterpret_cast<const uint16_t*>(xr + aoff[cb][2 * hh + 1] + 2 * dx);
+                            q[hh] = lo | (hi << 16);
+                        }
+                        const uint32_t msk = (uint32_t)(((int32_t)(am[cb] << (31 - tap))) >> 31);  // all ones / zero
+#pragma unroll
+                        for (int hh = 0; hh < 4; ++hh) q[hh] &= msk;
+                        __builtin_memcpy(&af[cb], q, 16);
+                    }
+#pragma unroll
+                    for (int mbk = 0; mbk < MB; ++mbk) {
+                        bf16x8_t bf;
+                        __builtin_memcpy(&bf, __builtin_assume_aligned(wb + tap * (BM * 64) + boff[mbk], 16), 16);
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) acc[cb][mbk] = COT_MFMA_16X16X32_BF16(af[cb], bf, acc[cb][mbk]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tp = 0; tp < 5; ++tp) {
+                // two taps per step: lane groups 0, 1 take tap 2 tp, groups 2, 3 tap 2 tp + 1 (step 4: "tap 9", masked, any address)
+                const int ta = 2 * tp, tb = tp < 4 ? 2 * tp + 1 : 8;
+                const int sa = ((ta / 3 - 1) * W + ta % 3 - 1) * 2, sb = ((tb / 3 - 1) * W + tb % 3 - 1) * 2;
+                const int sh = (g >> 1) ? sb : sa;
+                bf16x8_t af[CB];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    uint32_t q[4];
+#pragma unroll
+                    for (int hh = 0; hh < 4; ++hh) {
+                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(xb + aoff[cb][2 * hh] + sh);
+                        const uint32_t hi = *reinterpret_cast<const uint16_t*>(xb + aoff[cb][2 * hh + 1] + sh);
+                        q[hh] = lo | (hi << 16);
+                    }
+                    const uint32_t msk = (uint32_t)(((int32_t)(am[cb] << (31 - 2 * tp))) >> 31);
+#pragma unroll
+                    for (int hh = 0; hh < 4; ++hh) q[hh] &= msk;
+                    __builtin_memcpy(&af[cb], q, 16);
+                }
+#pragma unroll
+                for (int mbk = 0; mbk < MB; ++mbk) {
+                    bf16x8_t bf;
+                    __builtin_memcpy(&bf, __builtin_assume_aligned(wb + tp * (BM * 64) + boff[mbk], 16), 16);
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) acc[cb][mbk] = COT_MFMA_16X16X32_BF16(af[cb], bf, acc[cb][mbk]);
+                }
+            }
+        }
+    }
+    EpiArgs e;
+    e.y1 = a.y; e.y2 = nullptr; e.bias = nullptr; e.m1 = G * MM; e.M = G * MM; e.HW = HW; e.N = a.N; e.ni = a.ni;
+    e.ys1 = (int64_t)G * MM * HW; e.ys2 = 0; e.stats = nullptr; e.ptiles = 0;
+    e.n0 = n0; e.p0 = r0 * W; e.m0 = grp * MM; e.mv = MM; e.ncols = ncols; e.accumulate = a.accumulate;
+    tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
+}
+
+int g_conv3x3_res = 1;  // cot_set_tuning key 39: 1 (default) = the chunk-resident form where it is covered, 0 = the per-step ring
+template <int CB, int MB, int FLAT, int K16, int XP>
+static int launch_c3res(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
+    constexpr int WAVES = 8, NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB, SPC = K16 ? 5 : 9;
+    constexpr int WBUF = ((SPC * BM * 4 + NT - 1) / NT) * NT * 8, XST = XP * NT * 8;
+    const int nb = (K16 ? 1 : a.KK / 32) > 1 ? 2 : 1;
+    size_t lds = (size_t)nb * (WBUF + XST) * sizeof(bf16_t) + 1024;
+    const size_t otile = (FLAT ? (size_t)a.ni * (((size_t)BM * a.H * a.W + 7) & ~(size_t)7) : (size_t)BM * (BPX + 8)) * sizeof(bf16_t);
+    if (otile > lds) lds = otile;
+    if (lds > 160 * 1024) return -1;
+    C3LdsArgs b = a;
+    b.xcd_remap = (blocks % 8 == 0) ? 1 : 0;
+    static std::atomic<uint32_t> raised{0};
+    if (lds > 64 * 1024 &&
+        !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv3x3g_lds_res<CB, MB, FLAT, K16, XP, WAVES>)))
+        return -1;
+    COT_LAUNCH((conv3x3g_lds_res<CB, MB, FLAT, K16, XP, WAVES>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
+    return check_launch("conv3x3g_lds_res");
+}
+
+bool conv3x3g_lds_covers(int KK, int MM, int H, int W);
+// rows per output block of the chunk-resident form (0: not covered): at most 64, a multiple of 8, the group's rows in equal blocks
+static int c3res_rows(int KX, int Mreal) {
+    if (KX == 16 && Mreal == 16) return 16;
+    if (KX == 16) return 0;
+    const int nblk = (Mreal + 63) / 64;
+    if (Mreal % nblk != 0 || (Mreal / nblk) % 8 != 0) return 0;
+    return Mreal / nblk;
+}
+// -> -1: not covered (the caller takes the per-step ring); `ws`: the repacked weights' workspace as for conv3x3g_lds_gemm
+static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, int N, int Cin, int Cout, int G, int H, int W, int mode,
+                             int accumulate, hipStream_t stream) {
+    const int KX = (mode == 0 ? Cin : Cout) / G, Mreal = (mode == 0 ? Cout : Cin) / G, HW = H * W;
+    if (!g_conv3x3_res || !conv3x3g_lds_covers(KX, Mreal, H, W)) return -1;
+    const int MM = c3res_rows(KX, Mreal);
+    if (!MM) return -1;
+    const int MBLK = Mreal / MM, Greal = G;
+    G *= MBLK;
+    const int K16 = KX == 16, NTAP = K16 ? 10 : 9;
+    const int KK = K16 ? 16 : (KX + 31) / 32 * 32, ncc = K16 ? 1 : KK / 32;
+    const int MB = K16 ? 1 : (MM <= 32 ? 2 : 4);
+    C3LdsArgs a;
+    a.x = (const bf16_t*)x; a.wr = (const bf16_t*)ws; a.y = (bf16_t*)y;
+    a.N = N; a.G = G; a.KK = KK; a.KX = KX; a.MM = MM; a.H = H; a.W = W; a.accumulate = accumulate;
+    a.MBLK = MBLK; a.CX = Greal * KX;
+    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0;
+    int64_t blocks;
+    const bool flat = HW <= 256;
+    int cols = 256, XPsel = 0;
+    if (flat) {
+        int ni = 256 / HW;
+        const int want = (N * G + 127) / 128;
+        if (ni > want) ni = want;
+        if (ni > N) ni = N;
+        if (ni < 1) ni = 1;
+        a.ni = ni;
+        a.tiles = ceil_div(N, ni);
+        blocks = (int64_t)a.tiles * G;
+    } else {
+        // BIG: 512-column tiles (CB = 4) for up to 32 output rows, 256-column ones (CB = 2) for 64 rows (register budget) and
+        // whenever 512 columns would leave the chip under-filled; the staged chunk within XPmax passes of 16-byte copies
+        const int CH = K16 ? 16 : 32;
+        const int XPmax = K16 ? 3 : ((ncc > 1 && MB == 4) ? 3 : 5);  // (two buffer pairs of 40 KB weights + XP x 8 KB rows each)
+        cols = MB == 4 ? 256 : 512;
+        int TR = cols / W;
+        if (TR > H) TR = H;
+        if (cols == 512 && (int64_t)N * G * ceil_div(H, TR > 0 ? TR : 1) < 256 && 256 / W >= 2) {
+            cols = 256;
+            TR = 256 / W;
+            if (TR > H) TR = H;
+        }
+        if (TR < 1) return -1;
+        const int nt = ceil_div(H, TR);
+        TR = ceil_div(H, nt);
+        while (TR > 1 && ((TR * W) % 8 != 0 || (int64_t)CH * (((TR + 2) * W + 8 + 7) / 8) > (int64_t)XPmax * 512)) --TR;
+        if ((TR * W) % 8 != 0 || (int64_t)CH * (((TR + 2) * W + 8 + 7) / 8) > (int64_t)XPmax * 512) return -1;
+        a.TR = TR;
+        a.SL = ((TR + 2) * W + 8 + 7) / 8 * 8;
+        a.tiles = ceil_div(H, TR);
+        blocks = (int64_t)N * a.tiles * G;
+        XPsel = (int)ceil_div64((int64_t)CH * (a.SL / 8), 512);
+    }
+    {   // repack the weights: [G][NTAP][MM][KK]
+        const int64_t total = (int64_t)G * NTAP * MM * KK;
+        COT_LAUNCH(conv3x3g_repack_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, (const bf16_t*)w,
+                   (bf16_t*)ws, G, MM, KX, KK, NTAP, mode, MBLK);
+        int rc = check_launch("conv3x3g_repack_kernel");
+        if (rc) return rc;
+    }
+    if (flat) {
+        if (K16) return launch_c3res<2, 1, 1, 1, 1>(a, blocks, stream);
+        if (MB == 2) return launch_c3res<2, 2, 1, 0, 2>(a, blocks, stream);
+        return launch_c3res<2, 4, 1, 0, 2>(a, blocks, stream);
+    }
+    if (K16) return cols == 512 ? launch_c3res<4, 1, 0, 1, 3>(a, blocks, stream) : launch_c3res<2, 1, 0, 1, 3>(a, blocks, stream);
+    if (MB == 2) return cols == 512 ? launch_c3res<4, 2, 0, 0, 5>(a, blocks, stream) : launch_c3res<2, 2, 0, 0, 5>(a, blocks, stream);
+    if (XPsel <= 3) return launch_c3res<2, 4, 0, 0, 3>(a, blocks, stream);
+    return launch_c3res<2, 4, 0, 0, 5>(a, blocks, stream);
 }
 
 // KK / MM: reduction / output channels per group.  MM: any multiple of 8 up to 128 (the tile's rows past MM are clamped copies,
@@ -532,6 +851,10 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
                       int mode, int accumulate, hipStream_t stream) {
     const int KX = (mode == 0 ? Cin : Cout) / G, Mreal = (mode == 0 ? Cout : Cin) / G, HW = H * W;
     if (!conv3x3g_lds_covers(KX, Mreal, H, W)) return -1;
+    {
+        const int rc = conv3x3g_res_gemm(x, w, y, ws, N, Cin, Cout, G, H, W, mode, accumulate, stream);
+        if (rc != -1) return rc;
+    }
     const int MBLK = Mreal > 128 ? Mreal / 128 : 1, MM = Mreal / MBLK;
     const int Greal = G;
     G *= MBLK;  // virtual groups from here on

@@ -149,6 +149,7 @@ extern int g_bn_chan;
 // implemented in conv_lds.hip
 extern int g_conv_lds_tune[3];
 extern int g_conv3x3_ring;
+extern int g_conv3x3_res;
 extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
 unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
@@ -347,6 +348,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 38) {
         g_conv3x3_ring = value >= 5 ? 5 : 3;
+        return COT_OK;
+    }
+    if (key == 39) {
+        g_conv3x3_res = value ? 1 : 0;
         return COT_OK;
     }
     if (key == 18) {

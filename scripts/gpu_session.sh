@@ -50,6 +50,11 @@ case $what in
        bash scripts/gpu_trace_new.sh ${T}_fp32 --dtype fp32 --batch 80 >> $O/${T}_trace_sh.log 2>&1 ;;
   ring) for r in 3 5 3 5; do echo "== ring $r"; timeout 200 python scripts/bench_conv_abi.py --iters 20 --modes 1 --only "g4" --tune 38=$r 2>/dev/null | grep "g4"; done > $O/${T}_ring.log 2>&1; cat $O/${T}_ring.log | cut -c1-120
         for r in 3 5; do COT_TUNING=38=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('ring $r', l['value'], l['ms_per_step'])"; done ;;
+  res3) timeout 600 python -m pytest tests/test_conv3x3g_gpu.py tests/test_dispatch_parity_gpu.py tests/test_fused_layer_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "conv3x3 or layer or block" 2>&1 | tail -6 > $O/${T}_tests.log; tail -3 $O/${T}_tests.log
+        for r in 0 1 0 1; do echo "== res $r"; timeout 200 python scripts/bench_conv_abi.py --iters 20 --modes 1 --only "g4" --tune 39=$r 2>/dev/null | grep "g4"; done > $O/${T}_res3.log 2>&1; cat $O/${T}_res3.log | cut -c1-120
+        for r in 0 1 0 1; do COT_TUNING=39=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('res $r', l['value'], l['ms_per_step'])"; done
+        for r in 0 1; do COT_TUNING=39=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 8 --warmup 3 --model se_cotnetd_152_L --img 320 --batch 64 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('secot res $r', l['value'], l['ms_per_step'])"; done
+        for r in 0 1; do COT_TUNING=39=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 8 --warmup 3 --model cotnext101_2x48d --batch 64 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('cotnext res $r', l['value'], l['ms_per_step'])"; done ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac
 done

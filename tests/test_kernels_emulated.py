@@ -1014,14 +1014,14 @@ def test_conv3x3_grouped_weight_gradient_guard_decides_the_kernel():
     (1, 512, 2, 20, 20),   # BIG, two real groups x two row blocks
     (1, 64, 1, 6, 160),    # BIG, rows of 160 pixels (SE-CoTNetD's stem / first block at 320 x 320): one image row per tile
 ])
-@pytest.mark.parametrize("ring,dma", [(5, 0), (5, 1), (3, 1)])
-def test_conv3x3_grouped_lds_kernels(N, C, G, H, W, ring, dma, request):
-    """csrc/conv_lds.hip conv3x3g_lds_fwd (forward and data gradient incl. accumulate) against torch on the same rounded
-    operands, and against the first-generation kernel; both weight-tile rings (tuning key 38), copies landing at the earliest
-    and at the latest legal time (the vmcnt arithmetic and the buffer re-use of the ring)"""
-    assert _EMUL.cot_set_tuning(38, ring) == 0
+@pytest.mark.parametrize("res,dma", [(1, 0), (1, 1), (0, 1)])
+def test_conv3x3_grouped_lds_kernels(N, C, G, H, W, res, dma, request):
+    """csrc/conv_lds.hip conv3x3g_lds_res (chunk-resident weights, tuning key 39 = 1) and conv3x3g_lds_fwd (per-step ring, 0):
+    forward and data gradient incl. accumulate against torch on the same rounded operands, and against the first-generation
+    kernel; LDS copies landing at the earliest and at the latest legal time (the vmcnt arithmetic and the buffer re-use)"""
+    assert _EMUL.cot_set_tuning(39, res) == 0
     _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(38, 5), _EMUL.emul_set_dma_mode(0)))
+    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(39, 1), _EMUL.emul_set_dma_mode(0)))
     torch.manual_seed(17)
     x = torch.randn(N, C, H, W).bfloat16()
     w = (torch.randn(C, C // G, 3, 3) / (9 * C // G) ** 0.5).bfloat16()
@@ -1038,6 +1038,21 @@ def test_conv3x3_grouped_lds_kernels(N, C, G, H, W, ring, dma, request):
         assert _EMUL.cot_set_tuning(15, gen) == 0
         y = torch.full_like(x, float("nan"))
         assert _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0, _EMUL.cot_last_error()
+        if gen == 1:  # which form ran (dry-run log of the same call)
+            assert _EMUL.cot_set_tuning(26, 1) == 0
+            try:
+                buf = ctypes.create_string_buffer(4096)
+                _EMUL.cot_launch_log(buf, 4096)  # (clears the log)
+                _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None)
+                _EMUL.cot_launch_log(buf, 4096)
+                log = buf.value.decode()
+            finally:
+                assert _EMUL.cot_set_tuning(26, 0) == 0
+            assert "conv3x3g_lds_res" in log or "conv3x3g_lds_fwd" in log, log
+            if not res:
+                assert "conv3x3g_lds_res" not in log, log
+            elif (C // G) % 8 == 0 and W <= 80:  # (every case of this list but the 160-pixel rows takes the chunk-resident form)
+                assert "conv3x3g_lds_res" in log, log
         gx = torch.full_like(x, float("nan"))
         assert _EMUL.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), 0, P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
         base = torch.randn(N, C, H, W).bfloat16()
@@ -1071,9 +1086,13 @@ def test_conv3x3_lds_masks_by_selection():
     assert torch.allclose(y[:, Kc:].float(), yref, atol=2e-2, rtol=2e-2)
 
 
-def test_conv3x3_lds_padded_chunk_is_cleared_by_selection():
-    """groups of 48 channels on the LDS kernel: the second 32-channel chunk of group 0 is half group 1's channels.  They meet
-    zero weights -- and must be cleared by selection all the same: group 1 is all NaN here, group 0's outputs must not notice"""
+@pytest.mark.parametrize("res", [1, 0])
+def test_conv3x3_lds_padded_chunk_is_cleared_by_selection(res, request):
+    """groups of 48 channels on the LDS kernels (chunk-resident form / per-step ring): the second 32-channel chunk of group 0 is
+    half group 1's channels.  They meet zero weights -- and must be cleared by selection all the same: group 1 is all NaN here,
+    group 0's outputs must not notice"""
+    assert _EMUL.cot_set_tuning(39, res) == 0
+    request.addfinalizer(lambda: _EMUL.cot_set_tuning(39, 1))
     torch.manual_seed(19)
     N, C, G, H, W = 2, 96, 2, 6, 8
     Kc = C // G
@@ -1095,7 +1114,7 @@ def test_conv3x3_lds_padded_chunk_is_cleared_by_selection():
         _EMUL.cot_launch_log(buf, len(buf))
     finally:
         assert _EMUL.cot_set_tuning(26, 0) == 0
-    assert "conv3x3g_lds_fwd" in buf.value.decode(), buf.value
+    assert ("conv3x3g_lds_res" if res else "conv3x3g_lds_fwd") in buf.value.decode(), buf.value
     assert _EMUL.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
     assert torch.allclose(y[:, :Kc].float(), yref, atol=2e-2, rtol=2e-2)
     assert torch.isnan(y[:, Kc:].float()).all()
