@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
-int g_conv3x3_res = 1;  // cot_set_tuning key 39: 1 (default) = the chunk-resident form where it is covered, 0 = the per-step ring
+int g_conv3x3_res = 1;  // cot_set_tuning key 39: 1 (default) = the chunk-resident form for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step ring
 template <int CB, int MB, int FLAT, int K16, int XP>
 static int launch_c3res(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
     constexpr int WAVES = 8, NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB, SPC = K16 ? 5 : 9;
@@ -755,7 +755,9 @@ static int launch_c3res(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) 
 bool conv3x3g_lds_covers(int KK, int MM, int H, int W);
 // rows per output block of the chunk-resident form (0: not covered): at most 64, a multiple of 8, the group's rows in equal blocks
 static int c3res_rows(int KX, int Mreal) {
-    if (KX == 16 && Mreal == 16) return 16;
+    // 16-channel groups (two taps per K step, per-lane tap offsets): the per-step ring measured faster at 56 x 56 (42.8 us against
+    // 46.3 us per call, B = 80: gpurun_out/r4y_res3.log) -- the chunk-resident K16 instantiations stay built for tuning key 39 = 2
+    if (KX == 16 && Mreal == 16) return g_conv3x3_res == 2 ? 16 : 0;
     if (KX == 16) return 0;
     const int nblk = (Mreal + 63) / 64;
     if (Mreal % nblk != 0 || (Mreal / nblk) % 8 != 0) return 0;

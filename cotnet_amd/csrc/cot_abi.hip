@@ -351,7 +351,7 @@ int cot_set_tuning(int key, int value) {
         return COT_OK;
     }
     if (key == 39) {
-        g_conv3x3_res = value ? 1 : 0;
+        g_conv3x3_res = value == 2 ? 2 : (value ? 1 : 0);
         return COT_OK;
     }
     if (key == 18) {

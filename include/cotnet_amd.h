@@ -166,7 +166,8 @@ const char* cot_last_kernel(void);
  *           wider convolution's gradient taken on the tuned kernels and its diagonal blocks copied out (1 default), 0 = general kernel
  *   key 38: (A/B builds only) weight-tile ring of the per-step form of the LDS-staged 3x3 kernel
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
- *           chunk in LDS, one barrier per chunk) where it is covered, 0 = the per-step ring everywhere
+ *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
+ *           ring everywhere
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* Dry-run log of the calling thread (cot_set_tuning(26, 1)): one line per launch the library WOULD have issued --
