@@ -76,7 +76,7 @@ v["KTOT"] = f"{tot:.1f}"
 v["FAMILIES"] = ", ".join(f"{k} {x:.2f}" for k, x in sorted(fam.items(), key=lambda kv: -kv[1]))
 try:
     t = [json.loads(ln) for ln in open(os.path.join(G, "ev_trace_prof.log")) if ln.startswith("{")]
-    v["TRACE_MS"] = f"{t[-1]['ms_per_step']:.1f} under the profiler"
+    v["TRACE_MS"] = f"{t[-1]['ms_per_step']:.1f} ms under the profiler"
 except Exception:  # noqa: BLE001
     v["TRACE_MS"] = "?"
 json.dump(v, sys.stdout, indent=1, ensure_ascii=False)
