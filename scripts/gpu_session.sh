@@ -55,6 +55,7 @@ case $what in
         for r in 0 1 0 1; do COT_TUNING=39=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('res $r', l['value'], l['ms_per_step'])"; done
         for r in 0 1; do COT_TUNING=39=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 8 --warmup 3 --model se_cotnetd_152_L --img 320 --batch 64 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('secot res $r', l['value'], l['ms_per_step'])"; done
         for r in 0 1; do COT_TUNING=39=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 8 --warmup 3 --model cotnext101_2x48d --batch 64 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('cotnext res $r', l['value'], l['ms_per_step'])"; done ;;
+  parity2) timeout 900 python -m pytest tests/test_dispatch_parity_gpu.py tests/test_fused_bn_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -x 2>&1 | tail -15 > $O/${T}_parity2.log; tail -6 $O/${T}_parity2.log | cut -c1-300 ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac
 done

@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TABLE = json.load(open(os.path.join(ROOT, "tests", "golden", "dispatch_table.json")))
 CFG = "cotnet50_b80_224"
 KEYS = sorted(k for k in TABLE if k.startswith(CFG + " "))
+# BASELINE configs 4 / 5 at their one-GPU benchmark batch (bench.py's `secondary` lines): the same walk.  (Entries without a pass
+# suffix are the table's notes about modules outside the library -- strided 3x3 convolutions of a deep stem.)
+OTHER_CFGS = ("cotnext101_2x48d_b64_224", "se_cotnetd_152_L_b64_320")
+OTHER_KEYS = sorted(k for k in TABLE if k.split(" ")[0] in OTHER_CFGS and len(k.split(" ", 3)) == 4)
 BF = _lib.COT_BF16
 
 
@@ -91,9 +95,41 @@ def _bench_tuning():
     assert L.cot_set_tuning(12, 1) == 0
 
 
+def _conv1x1g(key, shp, what):
+    """grouped 1x1 (CoXtLayer, groups = 2): cot_conv1x1g_* -- group by group on the tuned kernels or the general kernel"""
+    N, Ci, Co, g, H, W, s, bias = shp
+    assert s == 1
+    HW = H * W
+    L, pin = _lib.lib(), _Pinned(key)
+    seed = Ci * 5 + Co + HW
+    x = _randn(N, Ci, H, W, seed=seed)
+    w = _randn(Co, Ci // g, 1, 1, seed=seed + 1, scale=(Ci // g) ** -0.5)
+    b = _randn(Co, seed=seed + 2) if bias else None
+    gy = _randn(N, Co, H, W, seed=seed + 3)
+    ws = torch.empty(max(int(L.cot_convg_workspace(N, Ci, Co, g, HW, 1, 1)), 256), dtype=torch.uint8, device=DEV)
+    ws.fill_(0xFF)
+    st = _st()
+    if what == "fwd":
+        y = torch.full((N, Co, H, W), float("nan"), device=DEV).bfloat16()
+        pin.issue(lambda: L.cot_conv1x1g_forward(P(x), P(w), P(b), P(y), N, Ci, Co, g, HW, BF, st))
+        _close(y, F.conv2d(x.float(), w.float(), b.float() if bias else None, groups=g))
+    elif what == "dgrad":
+        gx = torch.full((N, Ci, H, W), float("nan"), device=DEV).bfloat16()
+        pin.issue(lambda: L.cot_conv1x1g_backward_data(P(gy), P(w), P(gx), 0, N, Ci, Co, g, HW, BF, st))
+        _close(gx, F.conv_transpose2d(gy.float(), w.float(), None, groups=g))
+    else:
+        gw = torch.full((Co, Ci // g, 1, 1), float("nan"), device=DEV).bfloat16()
+        gb = torch.full((Co,), float("nan"), device=DEV).bfloat16() if bias else None
+        pin.issue(lambda: L.cot_conv1x1g_backward_weight(P(gy), P(x), P(gw), P(gb), P(ws), N, Ci, Co, g, HW, BF, st))
+        _close(gw, torch.nn.grad.conv2d_weight(x.float(), (Co, Ci // g, 1, 1), gy.float(), groups=g))
+        if bias:
+            _close(gb, gy.float().sum((0, 2, 3)))
+
+
 def _conv1x1(key, shp, what):
     N, Ci, Co, g, H, W, s, bias = shp
-    assert g == 1
+    if g != 1:
+        return _conv1x1g(key, shp, what)
     if s != 1:
         H, W = (H - 1) // s + 1, (W - 1) // s + 1
     HW = H * W
@@ -295,8 +331,7 @@ def _pool(key, kind, shp, what):
         assert torch.equal(y, F.max_pool2d(x, 3, 2, 1))
 
 
-@pytest.mark.parametrize("key", KEYS, ids=[k[len(CFG) + 1:].replace(" ", "-") for k in KEYS])
-def test_headline_dispatch_entry(key):
+def _run_entry(key):
     _, kind, shape, what = key.split(" ", 3)
     shp = tuple(int(v) for v in shape.split("x"))
     if kind == "conv1x1":
@@ -315,7 +350,22 @@ def test_headline_dispatch_entry(key):
         raise AssertionError(f"no parity case for table entry {key!r}")
 
 
+@pytest.mark.parametrize("key", KEYS, ids=[k[len(CFG) + 1:].replace(" ", "-") for k in KEYS])
+def test_headline_dispatch_entry(key):
+    _run_entry(key)
+
+
+@pytest.mark.parametrize("key", OTHER_KEYS, ids=[k.replace(" ", "-") for k in OTHER_KEYS])
+def test_secondary_config_dispatch_entry(key):
+    """CoTNeXt-101 2x48d (B = 64) and SE-CoTNetD-152 at 320 x 320 (B = 64): grouped 1x1 convolutions group by group on the tuned
+    kernels, groups-8 / dense 3x3 convolutions on the LDS kernels (K padding, row blocks, 160-pixel rows), the N' = 2B fold of the
+    aggregation, the 40 / 20 / 10-pixel planes"""
+    _run_entry(key)
+
+
 def test_every_headline_entry_has_a_case():
     kinds = {k.split(" ")[1] for k in KEYS}
     assert kinds <= {"conv1x1", "conv3x3", "bn", "gn", "agg", "AvgPool2d", "MaxPool2d"}, kinds
     assert len(KEYS) >= 170
+    assert {k.split(" ")[1] for k in OTHER_KEYS} <= {"conv1x1", "conv3x3", "bn", "gn", "agg", "AvgPool2d", "MaxPool2d"}
+    assert len(OTHER_KEYS) >= 380
