@@ -72,6 +72,9 @@ def parse():
                          "on a fresh box and the default kernel set has no MIOpen call to tune")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (forward, backward, side-stream weight gradients, optimizer) into ONE HIP graph after the "
+                         "settling steps and replay it in the warm-up and timed steps (one GPU; DESIGN.md 5.3)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object of the default line (BASELINE configs 4 / 5 and the reference's fp32 precision "
                          "measured by short child runs of this script on the same GPU)")
@@ -657,6 +660,11 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    if args.graph:
+        assert world == 1, "--graph: one GPU (a bucket's all-reduce inside a captured step is not exercised)"
+        gstream = torch.cuda.Stream()
+        torch.cuda.set_stream(gstream)  # a capture-capable (non-default) stream for everything from here on
+
     roctx_window(resume=False)
     # Settling (untimed, before the W warm-up steps): a fresh box runs the first tens of seconds of sustained load ~5 % slower than
     # it does afterwards, whatever ran before in the process (gpurun_out/r3s30_ab.log: 17.11 / 17.10 ms for the first two
@@ -681,6 +689,20 @@ def main():
             if done or float(ct[1].item()) >= args.settle_seconds:
                 break
         settle.update(first_chunk_ms=round(hist[0], 3), last_chunk_ms=round(hist[-1], 3), seconds=round(time.perf_counter() - t_s, 2))
+    eager_step = step
+    if args.graph:
+        # (every step of this process -- the settling ones too -- ran on `gstream`, see below: autograd's AccumulateGrad nodes
+        # remember the stream they were created under, and a node created under the default stream makes the engine synchronise
+        # with it during capture, which aborts the process)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=gstream):
+            graph_loss = eager_step()
+        torch.cuda.synchronize()
+
+        def step():  # noqa: F811
+            graph.replay()
+            return graph_loss
     for _ in range(args.warmup):
         loss = step()
     barrier()
@@ -692,10 +714,17 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    issued = time.perf_counter() - t0  # (host time to ISSUE the steps: the loop returns when the last launch is queued)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     roctx_window(resume=False)
+    # host time to issue ONE step into an empty queue (the loop above blocks on the launch queue whenever the device is the
+    # slower side, so `issued` only bounds it from above)
+    t1 = time.perf_counter()
+    step()
+    issue_one = time.perf_counter() - t1
+    torch.cuda.synchronize()
     recs, timing_steps = [], 0
     if not args.no_kernel_timing:
         timing_steps = 3
@@ -709,12 +738,12 @@ def main():
         try:
             agg_mod.profile_begin()
             for _ in range(timing_steps):
-                step()
+                eager_step()  # (dispatch-attached events need real launches: never the graph)
             torch.cuda.synchronize()
             recs = agg_mod.profile_end()
         finally:
             _clf.SIDE_WGRAD = _side
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -831,12 +860,16 @@ def main():
                        "grad_sync": (f"RCCL all-reduce (AVG), flat {'fp32' if args.grad_dtype == 'fp32' else 'parameter-dtype'} buckets, side stream"
                                      if world > 1 else "none (1 GPU)")},
             "final_loss": round(final_loss, 4),
+            # host time to issue a step (the timed loop's own duration before the final synchronize; with the device the longer
+            # of the two the loop blocks on the launch queue, so this is an upper bound of the host's own work)
+            "host_issue_ms_per_step": round(issued / args.steps * 1e3, 3), "host_issue_ms_one_step_idle_queue": round(issue_one * 1e3, 3),
+            **({"graph": "whole step captured in one HIP graph after the settling steps; warm-up and timed steps are replays"} if args.graph else {}),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         default_cfg = (args.model == "cotnet50" and args.img == 224 and args.batch == 80 and args.mode == "train" and mixed
-                       and not explicit and not args.tune and not args.recipe)
+                       and not explicit and not args.tune and not args.recipe and not args.graph)
         if world == 1 and default_cfg and not args.no_secondary:
             torch.cuda.empty_cache()  # (the children run on this GPU while this process is idle)
             line["secondary"] = secondary_lines()
