@@ -660,11 +660,13 @@ template int bn_act_inference<bf16_t>(const void*, const void*, void*, const flo
 // 2 reads + 1 write and one launch (streaming: 4 reads + 1 write, 2 launches).  Statistics: mean, then the centred sum of
 // squares from the registers (two-pass, no cancellation), per-lane fp32 partials added in fp64 across the workgroup.
 int g_bn_chan = 1;  // cot_set_tuning key 21: 1 = on where eligible (default), 0 = streaming kernels only
+int g_bn_chan7 = 1;  // cot_set_tuning key 40: 7-element accesses on odd planes that are multiples of 7 (1 default, 0 = element-wise)
 
 template <typename T, int V, bool BWD> struct ChanRounds {  // most rounds (vectors per lane) of a channel-resident kernel:
     // 64 elements per lane forward; the backward holds two tensors and takes 32 in bf16 (128 registers per lane is all a
     // 1024-lane workgroup gets)
-    static constexpr int value = sizeof(T) <= 2 ? (V == 8 ? (BWD ? 4 : 8) : (V == 4 ? (BWD ? 8 : 16) : 16)) : (V == 4 ? 8 : 16);
+    static constexpr int value = V == 7 ? (BWD ? 4 : 8)
+                                 : (sizeof(T) <= 2 ? (V == 8 ? (BWD ? 4 : 8) : (V == 4 ? (BWD ? 8 : 16) : 16)) : (V == 4 ? 8 : 16));
 };
 
 // sums of NV doubles over the workgroup, result in every lane; fixed order (deterministic)
@@ -819,14 +821,21 @@ __global__ __launch_bounds__(1024) void bn_chan_bwd(const T* __restrict__ dy, co
         }
 }
 
+template <typename T, bool BWD> static int bn_chan_rounds(int V) {
+    return V == 8 ? ChanRounds<T, 8, BWD>::value
+                  : (V == 7 ? ChanRounds<T, 7, BWD>::value : (V == 4 ? ChanRounds<T, 4, BWD>::value : ChanRounds<T, 1, BWD>::value));
+}
 // vector width of the channel-resident kernels for this tensor, 0 = not eligible (streaming kernels)
 template <typename T, bool BWD> static int bn_chan_vec(int N, int C, int HW) {
     if (!g_bn_chan || (int64_t)N * C * HW >= ((int64_t)1 << 31)) return 0;
     int V = pick_vec(sizeof(T), HW);
     if (V == 2) V = 1;  // (V = 2 has no instantiation: H*W = 2 * odd does not occur in the networks)
     if (sizeof(T) > 2 && V == 8) V = 4;
+    // odd planes that are multiples of 7 (7 x 7: every BatchNorm of the last stage): 7 elements per lane and access instead of
+    // one 2-byte element (0.13 of the HBM roofline on 2048 x 49 planes that way)
+    if (V == 1 && HW % 7 == 0 && g_bn_chan7) V = 7;
     const int64_t MV = (int64_t)N * HW / V;
-    const int rounds = V == 8 ? ChanRounds<T, 8, BWD>::value : (V == 4 ? ChanRounds<T, 4, BWD>::value : ChanRounds<T, 1, BWD>::value);
+    const int rounds = bn_chan_rounds<T, BWD>(V);
     return MV <= (int64_t)1024 * rounds ? V : 0;
 }
 // lanes per workgroup (256 / 512 / 1024): at least what `rounds` vectors per lane need to cover the channel, and beyond
@@ -840,9 +849,6 @@ static inline int bn_chan_threads(int N, int C, int HW, int V, int rounds) {
     const int need = MV <= (int64_t)256 * rounds ? 256 : (MV <= (int64_t)512 * rounds ? 512 : 1024);
     const int fill = C <= 256 ? 1024 : (C <= 512 ? 512 : 256);
     return need > fill ? need : fill;
-}
-template <typename T, bool BWD> static int bn_chan_rounds(int V) {
-    return V == 8 ? ChanRounds<T, 8, BWD>::value : (V == 4 ? ChanRounds<T, 4, BWD>::value : ChanRounds<T, 1, BWD>::value);
 }
 
 template <typename T>
@@ -869,6 +875,7 @@ int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, 
         else BN_CF(V_, ACT_NONE);                 \
     } while (0)
         if (cv == 8) BN_CFV((sizeof(T) <= 2 ? 8 : 4));
+        else if (cv == 7) BN_CFV(7);
         else if (cv == 4) BN_CFV(4);
         else BN_CFV(1);
 #undef BN_CFV
@@ -909,6 +916,7 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
         else BN_CB(V_, ACT_NONE);                          \
     } while (0)
         if (cv == 8) BN_CBV((sizeof(T) <= 2 ? 8 : 4));
+        else if (cv == 7) BN_CBV(7);
         else if (cv == 4) BN_CBV(4);
         else BN_CBV(1);
 #undef BN_CBV

@@ -24,6 +24,9 @@ template <typename T, typename A> __device__ __forceinline__ void st(T* p, A v) 
 
 // POD vector of V elements with natural (V*sizeof(T)) alignment so the compiler emits one wide access
 template <typename T, int V> struct alignas(sizeof(T) * V) Vec { T v[V]; };
+// 7 elements with ELEMENT alignment (7 x 7 planes: rows of 49 elements start on odd multiples of 2 bytes): the access is split by
+// the compiler into the widest pieces an unaligned address allows (global memory takes unaligned dword accesses on gfx950)
+template <typename T> struct alignas(sizeof(T)) Vec<T, 7> { T v[7]; };
 
 template <typename T, int V> __device__ __forceinline__ Vec<T, V> ldv(const T* p) {
     return *reinterpret_cast<const Vec<T, V>*>(p);

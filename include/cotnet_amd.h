@@ -168,6 +168,8 @@ const char* cot_last_kernel(void);
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
  *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
  *           ring everywhere
+ *   key 40: channel-resident BatchNorm on odd planes that are multiples of 7 (7 x 7): 1 (default) = 7 elements per access,
+ *           0 = element by element
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* Dry-run log of the calling thread (cot_set_tuning(26, 1)): one line per launch the library WOULD have issued --

@@ -303,12 +303,17 @@ def test_fused_sgd_kernel_matches_torch_formula(pdt, gdt, nesterov):
 @pytest.mark.parametrize("act,use_res", [(0, False), (1, False), (1, True), (2, False), (0, True)])
 @pytest.mark.parametrize("N,C,H,W", [(6, 8, 7, 7), (5, 16, 14, 14), (3, 4, 8, 8),
                                      (40, 3, 14, 14), (12, 2, 28, 28), (30, 2, 7, 7)])  # (1024-lane workgroups, 2-3 rounds)
-@pytest.mark.parametrize("fold", [0, 1, "chan"])
-def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold):
+@pytest.mark.parametrize("fold", [0, 1, "chan", "chan-elementwise"])
+def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold, request):
     # fold 0 / 1: streaming kernels with the finalize step as a launch / folded; "chan": the channel-resident kernels
-    # (one workgroup keeps a channel in registers: 1 launch each way)
-    if fold == "chan":
+    # (one workgroup keeps a channel in registers: 1 launch each way; 7 x 7 planes with 7-element unaligned accesses, or --
+    # "chan-elementwise", tuning key 40 = 0 -- element by element)
+    if fold == "chan-elementwise" and (H * W) % 7 != 0:
+        pytest.skip("key 40 only matters on odd planes that are multiples of 7")
+    if str(fold).startswith("chan"):
         assert _EMUL.cot_set_tuning(21, 1) == 0
+        assert _EMUL.cot_set_tuning(40, 0 if fold == "chan-elementwise" else 1) == 0
+        request.addfinalizer(lambda: _EMUL.cot_set_tuning(40, 1))
     else:
         assert _EMUL.cot_set_tuning(12, fold) == 0
     """csrc/bn_act.hip (host-emulated) against torch's batch_norm + activation + residual, forward and backward"""
