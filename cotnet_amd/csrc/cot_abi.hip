@@ -147,6 +147,7 @@ extern int g_wgrad_cap_pct;
 extern int g_wgrad_lds_cap_pct;
 extern int g_bn_chan;
 extern int g_bn_chan7;
+extern int g_stem_lds;
 // implemented in conv_lds.hip
 extern int g_conv_lds_tune[3];
 extern int g_conv3x3_ring;
@@ -389,6 +390,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 24) {  // DIAGNOSTIC: timing ablations of the third-generation 1x1 kernel (results become wrong)
         g_conv_ablate = value;
+        return COT_OK;
+    }
+    if (key == 41) {
+        g_stem_lds = value ? 1 : 0;
         return COT_OK;
     }
     if (key == 40) {

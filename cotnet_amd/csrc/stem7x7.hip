@@ -96,6 +96,100 @@ stem7x7_fwd_mfma(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf1
         }
 }
 
+// ---- forward with the input patch staged in LDS (round 4).  The kernel above gathers its B operand from global memory: 160
+// bounds-predicated 2-byte loads per lane for 80 MFMAs (226 us for 80 x 3 x 224 x 224: 152 MB of traffic, 19 us at the roofline).
+// Here a workgroup owns 256 consecutive output pixels of one image (4 waves x 64); the input rows those pixels read -- NR rows x 3
+// channels, each row with 8 zero elements in front and behind (the horizontal padding; rows outside the image are zeros too) --
+// are copied to LDS once with 16-byte accesses, and every B element is a 2-byte LDS read at (lane's patch position) + (the tap's
+// offset, from a 160-entry table in LDS: 8 entries per lane group and K step come with one ds_read_b128) + (the column set as an
+// immediate).  Weights: [64][168] in LDS (row stride 336 B: the 16 rows of a fragment read fall on distinct banks).  Same sums in
+// the same order as the kernel above: identical results.
+__global__ void __launch_bounds__(256)
+stem7x7_fwd_lds(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int H, int W, int Ho, int Wo,
+                int tiles_per_image, int NR, int RS) {
+    constexpr int WS = 168;  // weight row stride (elements)
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    bf16_t* As = reinterpret_cast<bf16_t*>(cot_smem);                      // [64][WS], zero beyond tap 146
+    uint16_t* toff = reinterpret_cast<uint16_t*>(As + kStemCo * WS);       // [160] tap -> element offset inside the patch
+    bf16_t* patch = reinterpret_cast<bf16_t*>(toff + kStemKp);             // [3][NR][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    const int n = blockIdx.x / tiles_per_image, tile = blockIdx.x - n * tiles_per_image;
+    const int HWo = Ho * Wo;
+    const int pfirst = tile * 256;
+    const int ih_base = 2 * (pfirst / Wo) - 3;  // first input row of the patch
+    for (int i = tid; i < kStemCo * WS; i += 256) {
+        const int m = i / WS, k = i - m * WS;
+        As[i] = k < kStemK ? w[m * kStemK + k] : (bf16_t)0.0f;
+    }
+    if (tid < kStemKp) {
+        int ci, kh, kw;
+        stem_tap(min(tid, kStemK - 1), ci, kh, kw);
+        toff[tid] = (uint16_t)((ci * NR + kh) * RS + kw);
+    }
+    {
+        const int cpr = RS / 8, chunks = 3 * NR * cpr;  // 16-byte pieces per patch row (first and last: the zero margins)
+        const bf16_t* xn = x + (int64_t)n * 3 * H * W;
+        for (int q = tid; q < chunks; q += 256) {
+            const int row = q / cpr, c = q - row * cpr;
+            const int ci = row / NR, ih = ih_base + (row - ci * NR);
+            Vec<bf16_t, 8> v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)0.0f;
+            if (c >= 1 && 8 * (c - 1) < W && ih >= 0 && ih < H) v = ldv<bf16_t, 8>(xn + ((int64_t)ci * H + ih) * W + 8 * (c - 1));
+            stv<bf16_t, 8>(patch + (int64_t)row * RS + 8 * c, v);
+        }
+    }
+    __syncthreads();
+    const int p0 = pfirst + wave * 64 + 4 * j;  // this lane's 4 consecutive output pixels (one row: Wo % 4 == 0)
+    const int pc = min(p0, HWo - 4);
+    const int oh = pc / Wo, ow0 = pc - oh * Wo;
+    const uint16_t* pl = reinterpret_cast<const uint16_t*>(patch) + (2 * oh - 3 - ih_base) * RS + 8 + 2 * ow0 - 3;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int step = 0; step < kStemKp / 32; ++step) {
+        const int kb = 32 * step + 8 * g;
+        uint16_t to[8];
+        __builtin_memcpy(to, __builtin_assume_aligned(toff + kb, 16), 16);
+        uint16_t q[4][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint16_t* pe = pl + to[e];
+            const bool kok = step < 4 || kb + e < kStemK;  // (the padded taps: zeros by selection -- their weights are zeros, but 0 * Inf is not)
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) {
+                const uint16_t v = pe[2 * cs];
+                q[cs][e] = kok ? v : (uint16_t)0;
+            }
+        }
+        bf16x8_t bfrag[4];
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs) __builtin_memcpy(&bfrag[cs], q[cs], 16);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bf16x8_t af;
+            __builtin_memcpy(&af, __builtin_assume_aligned(As + (16 * a + j) * WS + kb, 16), 16);
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) acc[a][cs] = COT_MFMA_16X16X32_BF16(af, bfrag[cs], acc[a][cs]);
+        }
+    }
+    if (p0 >= HWo) return;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = 16 * a + 4 * g + i;
+            bf16_t o[4];
+#pragma unroll
+            for (int cs = 0; cs < 4; ++cs) o[cs] = (bf16_t)acc[a][cs][i];
+            store_piece<4, 8>(y + ((int64_t)n * kStemCo + co) * HWo + p0, o, HWo - p0);
+        }
+}
+
 // part[s][co][k] = sum over slice s of (n, pixel) of dY[n][co][p] * x[n][ci][2*oh - 3 + kh][2*ow - 3 + kw]
 // one wave = (80 of the 160 tap columns, slice s); 4 waves per workgroup
 __global__ void __launch_bounds__(256)
@@ -167,6 +261,7 @@ static bool stem_geometry(int H, int W, int* Ho, int* Wo) {
     return H > 0 && W > 0 && (*Wo % 8) == 0 && ((*Ho * *Wo) % 32) == 0;
 }
 
+int g_stem_lds = 1;  // cot_set_tuning key 41: 1 (default) = forward with the input patch staged in LDS, 0 = gathers from global memory
 int stem7x7_splits(int N, int H, int W) {
     int Ho, Wo;
     if (!stem_geometry(H, W, &Ho, &Wo)) return 0;
@@ -179,6 +274,17 @@ int stem7x7_splits(int N, int H, int W) {
 int stem7x7_forward(const void* x, const void* w, void* y, int N, int H, int W, hipStream_t stream) {
     int Ho, Wo;
     if (!stem_geometry(H, W, &Ho, &Wo)) return COT_ERR_UNSUPPORTED;
+    if (g_stem_lds && W % 8 == 0 && Wo % 4 == 0 && (Ho * Wo) % 4 == 0) {
+        // patch rows: a tile of 256 pixels touches at most 255 / Wo + 2 output rows
+        const int rows = 255 / Wo + 2, NR = 2 * (rows - 1) + 7, RS = W + 16;
+        const size_t lds = ((size_t)kStemCo * 168 + kStemKp + (size_t)3 * NR * RS) * 2;
+        if (lds <= 64 * 1024 && (3 * NR + 6) * RS + 8 < 65536) {
+            const int tiles = ceil_div(Ho * Wo, 256);
+            COT_LAUNCH(stem7x7_fwd_lds, dim3((unsigned)((int64_t)N * tiles)), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)w,
+                       (bf16_t*)y, H, W, Ho, Wo, tiles, NR, RS);
+            return check_launch("stem7x7_fwd_lds");
+        }
+    }
     const int tpi = ceil_div(Ho * Wo, 64);
     const int64_t waves = (int64_t)N * tpi;
     COT_LAUNCH(stem7x7_fwd_mfma, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), kStemCo * kStemKp * 2, stream,

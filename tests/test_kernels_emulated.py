@@ -1842,9 +1842,11 @@ def test_classifier_head_on_emulated_kernels(monkeypatch):
     hf._WS.clear()
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (1, 16, 64), (3, 32, 16)])
+@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (1, 16, 64), (3, 32, 16), (1, 64, 48), (2, 8, 16)])
 def test_stem_convolution_kernels(N, H, W):
-    """csrc/stem7x7.hip (7x7 / stride 2 / padding 3, 3 -> 64) forward and weight gradient against torch in fp32"""
+    """csrc/stem7x7.hip (7x7 / stride 2 / padding 3, 3 -> 64) forward and weight gradient against torch in fp32; the forward
+    with the input patch staged in LDS (default) and with the operand gathered from global memory (tuning key 41 = 0) agree
+    bit for bit -- also when the input holds Inf (the padded taps 147..159 are cleared by selection, not by their zero weights)"""
     torch.manual_seed(19)
     dt = _lib.dtype_code(torch.bfloat16)
     x = torch.randn(N, 3, H, W).bfloat16()
@@ -1857,6 +1859,29 @@ def test_stem_convolution_kernels(N, H, W):
     y = torch.full((N, 64, Ho, Wo), float("nan")).bfloat16()
     assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(y), N, H, W, dt, None) == 0, _EMUL.cot_last_error()
     assert torch.allclose(y.float(), yr.detach(), atol=2e-2, rtol=2e-2), (y.float() - yr).abs().max()
+    xi = x.clone()
+    xi[:, 1, H // 2, W // 2] = float("inf")
+    outs = []
+    for lds in (1, 0):
+        assert _EMUL.cot_set_tuning(41, lds) == 0
+        try:
+            ya, yb = torch.full_like(y, float("nan")), torch.full_like(y, float("nan"))
+            assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(ya), N, H, W, dt, None) == 0
+            assert _EMUL.cot_stem7x7s2_forward(P(xi), P(w), P(yb), N, H, W, dt, None) == 0
+            buf = ctypes.create_string_buffer(2048)
+            _EMUL.cot_launch_log(buf, 2048)
+            assert _EMUL.cot_set_tuning(26, 1) == 0
+            _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(ya), N, H, W, dt, None)
+            assert _EMUL.cot_set_tuning(26, 0) == 0
+            _EMUL.cot_launch_log(buf, 2048)
+            assert ("stem7x7_fwd_lds" if lds else "stem7x7_fwd_mfma") in buf.value.decode(), buf.value
+        finally:
+            assert _EMUL.cot_set_tuning(26, 0) == 0 and _EMUL.cot_set_tuning(41, 1) == 0
+        outs.append((ya, yb))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], y)
+    fin = torch.isfinite(outs[1][1].float())
+    assert torch.equal(torch.isfinite(outs[0][1].float()), fin) and not fin.all() and fin.float().mean() > 0.5
+    assert torch.equal(outs[0][1][fin], outs[1][1][fin])
     nb = _EMUL.cot_stem7x7s2_workspace(N, H, W)
     assert nb > 0
     ws, gw = torch.empty(nb, dtype=torch.uint8), torch.full_like(w, float("nan"))
