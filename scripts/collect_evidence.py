@@ -22,7 +22,7 @@ def line(name):
 
 
 copies = {"ev_pytest.log": "pytest_gpu.log", "ev_smoke.log": "smoke.log", "ev_bench_default.json": "bench_default.json",
-          "ev_bench_fwd.json": "bench_fwd.json", "ev_bench_recipe.json": "bench_recipe.json", "ev_agg_abi.log": "agg_abi.log",
+          "ev_bench_fwd.json": "bench_fwd.json", "ev_bench_fwd_graph.json": "bench_fwd_graph.json", "ev_bench_recipe.json": "bench_recipe.json", "ev_agg_abi.log": "agg_abi.log",
           "ev_conv_abi.log": "conv_abi.log", "ev_trace_per_shape.csv": "rocprofv3_kernel_trace_new_per_shape.csv",
           "ev_trace_trace_kernel_stats.csv": "rocprofv3_kernel_stats_new.csv", "ev_agg_traffic.json": "agg_traffic_session.json"}
 for src, dst in copies.items():
@@ -43,7 +43,9 @@ for key, tag in (("cotnext101_2x48d_b64_224", "C4"), ("se_cotnetd_152_L_b64_320"
     e = sec.get(key, {})
     v[f"{tag}_IMGS"] = round(e["value"]) if "value" in e else "failed"
     v[f"{tag}_MS"] = f"{e['ms_per_step']:.1f}" if "ms_per_step" in e else "-"
-for name, tag in (("ev_bench_fwd.json", "FWD"), ("ev_bench_recipe.json", "RECIPE")):
+for name, tag in (("ev_bench_fwd.json", "FWD"), ("ev_bench_fwd_graph.json", "FWDG"), ("ev_bench_recipe.json", "RECIPE")):
+    if not os.path.exists(os.path.join(G, name)):
+        continue
     e = line(name)
     v[f"{tag}_IMGS"], v[f"{tag}_MS"] = round(e["value"]), f"{e['ms_per_step']:.2f}"
 m = re.search(r"(\d+) passed", open(os.path.join(G, "ev_pytest.log")).read())

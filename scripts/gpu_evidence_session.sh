@@ -24,5 +24,6 @@ T1=$(date +%s)
 timeout 900 python bench.py > $O/ev_bench_default.json 2> $O/ev_bench_default.err; echo "bench rc=$? wall=$(( $(date +%s) - T1 ))s"
 cut -c1-600 $O/ev_bench_default.json
 timeout 300 python bench.py --mode fwd --no-cpu-baseline > $O/ev_bench_fwd.json 2> $O/ev_bench_fwd.err || tail -5 $O/ev_bench_fwd.err; cut -c1-300 $O/ev_bench_fwd.json
+timeout 300 python bench.py --mode fwd --graph --no-cpu-baseline --no-kernel-timing > $O/ev_bench_fwd_graph.json 2> $O/ev_bench_fwd_graph.err || tail -5 $O/ev_bench_fwd_graph.err; cut -c1-200 $O/ev_bench_fwd_graph.json
 timeout 300 python bench.py --recipe --no-cpu-baseline > $O/ev_bench_recipe.json 2> $O/ev_bench_recipe.err; cut -c1-300 $O/ev_bench_recipe.json
 echo "session wall=$(( $(date +%s) - T0 ))s"
