@@ -118,6 +118,9 @@ SYMBOLS = {
     "cot_bn_act_backward": (_I, [_P] * 12 + [_I, _I, _I, _I, _I, _P]),
     "cot_bn_act_forward_ps": (_I, [_P] * 12 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "cot_bn_act_backward_ps": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P]),
+    "cot_bn_relu_mask_bytes": (ctypes.c_int64, [_I, _I, _I, _I]),
+    "cot_bn_act_forward_mask": (_I, [_P] * 13 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
+    "cot_bn_act_backward_mask": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P]),
     "cot_bn_act_inference": (_I, [_P] * 7 + [_I, _I, _I, ctypes.c_float, _I, _I, _P]),
     "cot_profile_begin": (_I, []),
     "cot_profile_end": (_I, [ctypes.POINTER(ProfileRec), _I]),

@@ -306,9 +306,31 @@ def _guard_elems(t):
     return max(0, min(t.storage_offset(), total - t.storage_offset() - t.numel()))
 
 
-def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act, residual=None, ps=None):
+RELU_MASK = os.environ.get("COT_BN_RELU_MASK", "1") != "0"  # bn3 + residual + ReLU: backward reads a 1-bit sign mask, not y
+_MASK_BYTES = _lib.register_cache({})
+
+
+def _relu_mask(L, N, C, HW, dev):
+    """uint8 tensor for the ReLU sign mask of a bn + residual + ReLU over [N, C, HW] (cot_bn_act_*_mask), or None when the
+    library does not take one for this geometry (then the backward reads the saved output as before)"""
+    if not RELU_MASK:
+        return None
+    k = (N, C, HW)
+    nb = _MASK_BYTES.get(k)
+    if nb is None:
+        nb = _MASK_BYTES[k] = int(L.cot_bn_relu_mask_bytes(N, C, HW, BF16))
+    return torch.empty(nb, dtype=torch.uint8, device=dev) if nb > 0 else None
+
+
+def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act, residual=None, ps=None, mask=None):
     """stats: fp32 [2*C + workspace] -> mean = stats[:C], rstd = stats[C:2C].  ps: per-sample scale of the normalised branch
-    (stochastic depth: 0 or 1 / keep, fp32 [N]) or None"""
+    (stochastic depth: 0 or 1 / keep, fp32 [N]) or None.  mask: `_relu_mask` tensor to fill (act = ReLU with a residual)"""
+    if mask is not None:
+        _ck(L.cot_bn_act_forward_mask(_p(x), _p(residual), _p(y), _p(mask), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
+                                      _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _p(stats[nws_off:]),
+                                      _p(ps), N, C, HW, float(bn.eps), float(bn.momentum), act, BF16, _stream()),
+            "cot_bn_act_forward_mask")
+        return
     if ps is not None:
         _ck(L.cot_bn_act_forward_ps(_p(x), _p(residual), _p(y), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
                                     _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _p(stats[nws_off:]),
@@ -320,10 +342,16 @@ def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act, residual=None, ps=None):
                              N, C, HW, float(bn.eps), float(bn.momentum), act, BF16, _stream()), "cot_bn_act_forward")
 
 
-def _bn_bwd(L, dy, x, y, dx, bn, stats, N, C, HW, act, nws, dres=None, ps=None):
-    """-> (dgamma, dbeta): the parameters' slots in the flat gradient buckets when registered (grad_sink), else fresh"""
+def _bn_bwd(L, dy, x, y, dx, bn, stats, N, C, HW, act, nws, dres=None, ps=None, mask=None):
+    """-> (dgamma, dbeta): the parameters' slots in the flat gradient buckets when registered (grad_sink), else fresh.
+    mask: the sign mask the forward wrote (then `y` is not read)"""
     dg, db = grad_sink.out_like(bn.weight), grad_sink.out_like(bn.bias)
     ws = torch.empty(max(nws, 1), dtype=torch.float32, device=dy.device)
+    if mask is not None:
+        _ck(L.cot_bn_act_backward_mask(_p(dy), _p(x), _p(mask), _p(dx), _p(dres), _p(bn.weight), _p(bn.bias), _p(stats),
+                                       _p(stats[C:]), _p(dg), _p(db), _p(ws), _p(ps), N, C, HW, act, BF16, _stream()),
+            "cot_bn_act_backward_mask")
+        return dg, db
     if ps is not None:
         _ck(L.cot_bn_act_backward_ps(_p(dy), _p(x), _p(y), _p(dx), _p(dres), _p(bn.weight), _p(bn.bias), _p(stats),
                                      _p(stats[C:]), _p(dg), _p(db), _p(ws), _p(ps), N, C, HW, act, BF16, _stream()),
@@ -744,10 +772,11 @@ class _BottleneckNode(Function):
             xs, d0, res, s_d = None, None, x, None
         s_3 = stat(Cout, nws_o)
         ps = _drop_path_scale(blk, N, dev)  # stochastic depth: per-sample 0 or 1 / keep on the normalised branch
-        _bn_fwd(L, c3, y, bp.bn3, s_3, 2 * Cout, N, Cout, HWo, 1, residual=res, ps=ps)
-        ctx.blk, ctx.geom, ctx.has_ds, ctx.has_ps = blk, geom, bp.ds_conv is not None, ps is not None
+        m3 = _relu_mask(L, N, Cout, HWo, dev)
+        _bn_fwd(L, c3, y, bp.bn3, s_3, 2 * Cout, N, Cout, HWo, 1, residual=res, ps=ps, mask=m3)
+        ctx.blk, ctx.geom, ctx.has_ds, ctx.has_ps, ctx.has_mask = blk, geom, bp.ds_conv is not None, ps is not None, m3 is not None
         extra = (x, c1, a1, s_1, cot_out, c3, y, s_3) + ((d0, s_d, xs) if bp.ds_conv is not None else ()) + \
-            ((ps,) if ps is not None else ())
+            ((m3,) if m3 is not None else ()) + ((ps,) if ps is not None else ())
         ctx.save_for_backward(*(saved + extra))
         return y
 
@@ -776,7 +805,8 @@ class _BottleneckNode(Function):
         # bn3 + residual + relu: dx of the normalisation and the residual's gradient in one pass
         g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
         ps = extra[-1] if ctx.has_ps else None
-        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, bp.bn3, s_3, N, Cout, HWo, 1, nws_o, dres=g_res, ps=ps)
+        m3 = extra[-2 if ctx.has_ps else -1] if ctx.has_mask else None
+        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, bp.bn3, s_3, N, Cout, HWo, 1, nws_o, dres=g_res, ps=ps, mask=m3)
         g_cot_out = torch.empty_like(cot_out)
         _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_cot_out), None, Cw, 0, _p(ws), N, Cw, Cout, HWo,
                                         BF16, st), "cot_conv1x1_backward_data")
@@ -942,9 +972,11 @@ class _SplitAttnBlockNode(Function):
         _ck(L.cot_conv1x1_forward(_p(out2), None, Cw, _p(sp.conv3.weight), None, _p(c3), N, Cw, Cin, HW, BF16, st), "cot_conv1x1_forward")
         s_3 = stat(Cin, nws_o)
         ps = _drop_path_scale(blk, N, dev)
-        _bn_fwd(L, c3, y, sp.bn3, s_3, 2 * Cin, N, Cin, HW, 1, residual=x, ps=ps)
-        ctx.blk, ctx.has_ps = blk, ps is not None
-        ctx.save_for_backward(x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3, *((ps,) if ps is not None else ()))
+        m3 = _relu_mask(L, N, Cin, HW, dev)
+        _bn_fwd(L, c3, y, sp.bn3, s_3, 2 * Cin, N, Cin, HW, 1, residual=x, ps=ps, mask=m3)
+        ctx.blk, ctx.has_ps, ctx.has_mask = blk, ps is not None, m3 is not None
+        ctx.save_for_backward(x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3,
+                              *((m3,) if m3 is not None else ()), *((ps,) if ps is not None else ()))
         return y
 
     @staticmethod
@@ -955,7 +987,8 @@ class _SplitAttnBlockNode(Function):
         sp = _sa_plan(blk)
         t = ctx.saved_tensors
         x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3 = t[:16]
-        ps = t[16] if ctx.has_ps else None
+        m3 = t[16] if ctx.has_mask else None
+        ps = t[-1] if ctx.has_ps else None
         N, Cin, H, W = x.shape
         Cw, A, G = sp.conv.out_channels, sp.fc1.out_channels, sp.conv.groups
         HW = H * W
@@ -966,7 +999,7 @@ class _SplitAttnBlockNode(Function):
         side = _Side(dev, ws_bytes, ws, sp.params)
         gout = gout.contiguous()
         g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
-        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, sp.bn3, s_3, N, Cin, HW, 1, nws_o, dres=g_res, ps=ps)
+        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, sp.bn3, s_3, N, Cin, HW, 1, nws_o, dres=g_res, ps=ps, mask=m3)
         g_out2 = torch.empty_like(out2)
         _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(sp.conv3.weight), _p(g_out2), None, Cw, 0, _p(ws), N, Cw, Cin, HW, BF16, st),
             "cot_conv1x1_backward_data")

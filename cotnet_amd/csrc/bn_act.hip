@@ -162,6 +162,17 @@ __global__ void bn_stats_finalize(const float* __restrict__ part, int C, int spl
     }
 }
 
+// ---- ReLU sign mask (round 4): bn3 + residual + ReLU is the one BatchNorm whose backward needs the sign of its OUTPUT (z + residual
+// decides it); reading the whole output tensor back for one bit per element is 1/5 of that backward's traffic on the step's largest
+// tensors.  With 8 elements per access the forward kernels also write one BYTE per vector (bit k = output element k > 0, taken from
+// the ROUNDED output so that it is exactly the test the backward made on y), the backward kernels read that byte instead of y.
+template <typename T, int V> __device__ __forceinline__ uint8_t sign_bits(const Vec<T, V>& o) {
+    unsigned b = 0;
+#pragma unroll
+    for (int k = 0; k < V && k < 8; ++k) b |= ((float)o.v[k] > 0.f ? 1u : 0u) << k;
+    return (uint8_t)b;
+}
+
 template <int ACT> __device__ __forceinline__ float act_fwd(float z) {
     if (ACT == ACT_RELU || ACT == ACT_RELU_Y) return z > 0.f ? z : 0.f;
     if (ACT == ACT_SILU) return z / (1.f + __expf(-z));
@@ -173,7 +184,8 @@ template <typename T, int V, int ACT>
 __global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, const T* __restrict__ res,
                                                    T* __restrict__ y, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, int C, int HW, int64_t nvec) {
+                                                   const float* __restrict__ beta, int C, int HW, int64_t nvec,
+                                                   uint8_t* __restrict__ mask) {
     // two interleaved streams per thread, one grid stride apart: the loads of both are issued before either is used
     // (see bn_stats_partial); elements are independent, so the order does not matter here
     auto apply = [&](int c, int64_t i, const Vec<T, V>& xv, const Vec<T, V>& rv) __attribute__((always_inline)) {
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, con
             o.v[k] = (T)act_fwd<ACT>(z);
         }
         stv<T, V>(y + i * V, o);
+        if (V == 8 && mask) mask[i] = sign_bits<T, V>(o);
     };
     const int64_t start = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
     ChannelWalk wa(start, 2 * stride, HW / V, C), wb(start + stride, 2 * stride, HW / V, C);
@@ -223,25 +236,30 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce(const T* __restrict__ dy, c
                                                     const T* __restrict__ y, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float* __restrict__ part, int N,
-                                                    int C, int HW, int nper, const float* __restrict__ ps) {
+                                                    int C, int HW, int nper, const float* __restrict__ ps,
+                                                    const uint8_t* __restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* smem = reinterpret_cast<float*>(cot_smem);
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     const int n0 = s * nper, n1 = min(N, n0 + nper);
     const int vpp = HW / V;
     const float m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
+    const bool use_mask = V == 8 && ACT == ACT_RELU_Y && mask;
     float acc[2] = {0.f, 0.f};
 #pragma unroll 2
     for (PlaneWalk w(threadIdx.x, blockDim.x, vpp); w.n < n1 - n0; w.next()) {
         const int64_t off = ((int64_t)(n0 + w.n) * C + c) * HW + (int64_t)w.v * V;
         const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
         Vec<T, V> yv;
-        if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + off);
+        unsigned mb = 0;
+        if (use_mask) mb = mask[off >> 3];
+        else if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + off);
         const float sc = ps ? ps[n0 + w.n] : 1.f;  // stochastic depth: the normalised branch was scaled per sample
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = sc * act_bwd<ACT>((float)dv.v[k], ACT == ACT_RELU_Y ? (float)yv.v[k] : xh * ga + be);
+            const float yk = ACT == ACT_RELU_Y ? (use_mask ? (float)((mb >> (k & 7)) & 1u) : (float)yv.v[k]) : xh * ga + be;
+            const float g = sc * act_bwd<ACT>((float)dv.v[k], yk);
             acc[0] += g;
             acc[1] += g * xh;
         }
@@ -274,7 +292,9 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const T* __restrict__ dy, co
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                   int C, int HW, int64_t nvec, float inv_m) {
+                                                   int C, int HW, int64_t nvec, float inv_m,
+                                                   const uint8_t* __restrict__ mask) {
+    const bool use_mask = V == 8 && ACT == ACT_RELU_Y && mask;
 #pragma unroll 2
     for (ChannelWalk w((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, HW / V, C);
          w.i < nvec; w.next()) {
@@ -284,11 +304,14 @@ __global__ __launch_bounds__(256) void bn_apply_bwd(const T* __restrict__ dy, co
         const float k1 = dbeta[c] * inv_m, k2 = dgamma[c] * inv_m, gr = ga * r;
         const Vec<T, V> dv = ldv<T, V>(dy + i * V), xv = ldv<T, V>(x + i * V);
         Vec<T, V> yv, o, og;
-        if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + i * V);
+        unsigned mb = 0;
+        if (use_mask) mb = mask[i];
+        else if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + i * V);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = act_bwd<ACT>((float)dv.v[k], ACT == ACT_RELU_Y ? (float)yv.v[k] : xh * ga + be);
+            const float yk = ACT == ACT_RELU_Y ? (use_mask ? (float)((mb >> (k & 7)) & 1u) : (float)yv.v[k]) : xh * ga + be;
+            const float g = act_bwd<ACT>((float)dv.v[k], yk);
             o.v[k] = (T)(gr * (g - k1 - xh * k2));
             og.v[k] = (T)g;
         }
@@ -334,7 +357,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_fold(const T* __restrict__ x
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
                                                         long long* __restrict__ num_batches_tracked, int N, int C, int HW,
-                                                        int nper, float eps, float momentum, const float* __restrict__ ps) {
+                                                        int nper, float eps, float momentum, const float* __restrict__ ps,
+                                                        uint8_t* __restrict__ mask) {
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     float n = 0.f, m = 0.f, M2 = 0.f;
     for (int q = 0; q < split; ++q) {
@@ -375,6 +399,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_fold(const T* __restrict__ x
             o.v[k] = (T)act_fwd<ACT>(z);
         }
         stv<T, V>(y + off, o);
+        if (V == 8 && mask) mask[off >> 3] = sign_bits<T, V>(o);
     }
 }
 
@@ -385,7 +410,9 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ d
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ part, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int N, int C, int HW, int nper,
-                                                        float inv_m, const float* __restrict__ ps) {
+                                                        float inv_m, const float* __restrict__ ps,
+                                                        const uint8_t* __restrict__ mask) {
+    const bool use_mask = V == 8 && ACT == ACT_RELU_Y && mask;
     const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
     float sb = 0.f, sg = 0.f;
     for (int q = 0; q < split; ++q) {
@@ -405,12 +432,15 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ d
         const int64_t off = ((int64_t)(n0 + w.n) * C + c) * HW + (int64_t)w.v * V;
         const Vec<T, V> dv = ldv<T, V>(dy + off), xv = ldv<T, V>(x + off);
         Vec<T, V> yv, o, og;
-        if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + off);
+        unsigned mb = 0;
+        if (use_mask) mb = mask[off >> 3];
+        else if (ACT == ACT_RELU_Y) yv = ldv<T, V>(y + off);
         const float sc = ps ? ps[n0 + w.n] : 1.f;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float xh = ((float)xv.v[k] - m) * r;
-            const float g = act_bwd<ACT>((float)dv.v[k], ACT == ACT_RELU_Y ? (float)yv.v[k] : xh * ga + be);
+            const float yk = ACT == ACT_RELU_Y ? (use_mask ? (float)((mb >> (k & 7)) & 1u) : (float)yv.v[k]) : xh * ga + be;
+            const float g = act_bwd<ACT>((float)dv.v[k], yk);
             o.v[k] = (T)(gr * (sc * g - k1 - xh * k2));
             og.v[k] = (T)g;  // (the residual's gradient is not scaled)
         }
@@ -420,6 +450,8 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_fold(const T* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// the sign mask of the current call (set by cot_bn_act_{forward,backward}_mask around the call; NULL otherwise)
+thread_local uint8_t* t_bn_mask = nullptr;
 int g_bn_fold = 1;          // cot_set_tuning key 12 (default on since round 3: 202 fewer launches per CoTNet-50 step, profiles/r02_bn_fold_ab.txt)
 int g_bn_grid_cap = 4096;  // cot_set_tuning key 13: most workgroups of a flat (grid-stride) BatchNorm apply kernel
 static inline int pick_vec(size_t esize, int HW) {
@@ -445,6 +477,15 @@ static inline unsigned flat_grid(int64_t nvec) {
     return (unsigned)b;
 }
 
+// bytes of the ReLU sign mask for this tensor, 0 = not supported (the backward then reads the saved output): 8 elements per access
+// on every kernel family that can serve the tensor, i.e. 2-byte elements, planes that are multiples of 8, and not the one-wave fp64
+// path of tiny batches
+extern int g_bn_small_m;
+int64_t bn_relu_mask_bytes(int N, int C, int HW, int esize) {
+    if (esize != 2 || HW % 8 != 0 || (int64_t)N * HW <= g_bn_small_m) return 0;
+    return (int64_t)N * C * HW / 8;
+}
+
 int bn_workspace_floats(int N, int C) {
     int split, nper;
     pick_split(N, C, &split, &nper);
@@ -457,17 +498,18 @@ static int bn_fwd_launch_act(const T* x, const T* res, T* y, const float* gamma,
                              float eps, float mom, const float* ps, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
+    uint8_t* const mk = V == 8 ? t_bn_mask : nullptr;  // (read HERE: a launch macro may evaluate its arguments on another thread)
     COT_LAUNCH((bn_stats_partial<T, V>), dim3(C, split), dim3(256), 48 * sizeof(float), s, x, ws, N, C, HW, nper);
     if (g_bn_fold || ps) {  // (the per-sample scale lives in the kernels that walk a channel image by image)
         COT_LAUNCH((bn_apply_fwd_fold<T, V, ACT>), dim3(C, split), dim3(256), 0, s, x, res, y, (const float*)ws, gamma,
-                   beta, mean, rstd, rmean, rvar, nbt, N, C, HW, nper, eps, mom, ps);
+                   beta, mean, rstd, rmean, rvar, nbt, N, C, HW, nper, eps, mom, ps, mk);
         return check_launch("bn_act_forward");
     }
     COT_LAUNCH(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean,
                rstd, rmean, rvar, nbt);
     const int64_t nvec = (int64_t)N * C * HW / V;
     COT_LAUNCH((bn_apply_fwd<T, V, ACT>), dim3(flat_grid(nvec)), dim3(256), 0, s, x, res, y, (const float*)mean,
-               (const float*)rstd, gamma, beta, C, HW, nvec);
+               (const float*)rstd, gamma, beta, C, HW, nvec, mk);
     return check_launch("bn_act_forward");
 }
 
@@ -488,17 +530,18 @@ static int bn_bwd_launch_act(const T* dy, const T* x, const T* y, T* dx, T* dres
                              int HW, const float* ps, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
+    const uint8_t* const mk = V == 8 ? t_bn_mask : nullptr;  // (read here, see bn_fwd_launch_act)
     COT_LAUNCH((bn_bwd_reduce<T, V, ACT>), dim3(C, split), dim3(256), 48 * sizeof(float), s, dy, x, y, mean, rstd, gamma,
-               beta, ws, N, C, HW, nper, ps);
+               beta, ws, N, C, HW, nper, ps, mk);
     if (g_bn_fold || ps) {
         COT_LAUNCH((bn_apply_bwd_fold<T, V, ACT>), dim3(C, split), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma,
-                   beta, (const float*)ws, dgamma, dbeta, N, C, HW, nper, 1.0f / (float)((int64_t)N * HW), ps);
+                   beta, (const float*)ws, dgamma, dbeta, N, C, HW, nper, 1.0f / (float)((int64_t)N * HW), ps, mk);
         return check_launch("bn_act_backward");
     }
     COT_LAUNCH(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, dgamma, dbeta);
     const int64_t nvec = (int64_t)N * C * HW / V;
     COT_LAUNCH((bn_apply_bwd<T, V, ACT>), dim3(flat_grid(nvec)), dim3(256), 0, s, dy, x, y, dx, dres, mean, rstd, gamma,
-               beta, (const float*)dgamma, (const float*)dbeta, C, HW, nvec, 1.0f / (float)((int64_t)N * HW));
+               beta, (const float*)dgamma, (const float*)dbeta, C, HW, nvec, 1.0f / (float)((int64_t)N * HW), mk);
     return check_launch("bn_act_backward");
 }
 
@@ -693,7 +736,7 @@ __global__ __launch_bounds__(1024) void bn_chan_fwd(const T* __restrict__ x, con
                                                    float* __restrict__ mean, float* __restrict__ rstd,
                                                    float* __restrict__ rmean, float* __restrict__ rvar,
                                                    long long* __restrict__ nbt, int N, int C, int HW, float eps, float mom,
-                                                   const float* __restrict__ ps) {
+                                                   const float* __restrict__ ps, uint8_t* __restrict__ mask) {
     constexpr int R = ChanRounds<T, V, false>::value;
     __shared__ double red[16];
     const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
@@ -754,6 +797,7 @@ __global__ __launch_bounds__(1024) void bn_chan_fwd(const T* __restrict__ x, con
                 o.v[k] = (T)act_fwd<ACT>(z);
             }
             stv<T, V>(y + off[r], o);
+            if (V == 8 && mask) mask[off[r] >> 3] = sign_bits<T, V>(o);
         }
 }
 
@@ -762,7 +806,8 @@ __global__ __launch_bounds__(1024) void bn_chan_bwd(const T* __restrict__ dy, co
                                                    T* __restrict__ dx, T* __restrict__ dres, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, int N, int C, int HW, const float* __restrict__ ps) {
+                                                   float* __restrict__ dbeta, int N, int C, int HW, const float* __restrict__ ps,
+                                                   const uint8_t* __restrict__ mask) {
     constexpr int R = ChanRounds<T, V, true>::value;
     __shared__ double red[32];
     const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
@@ -782,9 +827,15 @@ __global__ __launch_bounds__(1024) void bn_chan_bwd(const T* __restrict__ dy, co
             xv[r] = ldv<T, V>(x + off[r]);
             dv[r] = ldv<T, V>(dy + off[r]);
             if (ACT == ACT_RELU_Y) {  // the saved output's sign decides: fold it into dy now (exact), y is not kept
-                const Vec<T, V> yv = ldv<T, V>(y + off[r]);
+                if (V == 8 && mask) {
+                    const unsigned mb = mask[off[r] >> 3];
 #pragma unroll
-                for (int k = 0; k < V; ++k) dv[r].v[k] = (float)yv.v[k] > 0.f ? dv[r].v[k] : (T)0.f;
+                    for (int k = 0; k < V; ++k) dv[r].v[k] = ((mb >> (k & 7)) & 1u) ? dv[r].v[k] : (T)0.f;
+                } else {
+                    const Vec<T, V> yv = ldv<T, V>(y + off[r]);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) dv[r].v[k] = (float)yv.v[k] > 0.f ? dv[r].v[k] : (T)0.f;
+                }
             }
             const float sc = ps ? ps[n] : 1.f;
 #pragma unroll
@@ -867,7 +918,8 @@ int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, 
     }
     if (const int cv = bn_chan_vec<T, false>(N, C, HW)) {
         const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, false>(cv)));
-#define BN_CF(V_, A_) COT_LAUNCH((bn_chan_fwd<T, V_, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom, ps)
+        uint8_t* const mk = cv == 8 ? t_bn_mask : nullptr;
+#define BN_CF(V_, A_) COT_LAUNCH((bn_chan_fwd<T, V_, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom, ps, (V_) == 8 ? mk : nullptr)
 #define BN_CFV(V_)                                \
     do {                                          \
         if (act == ACT_RELU) BN_CF(V_, ACT_RELU); \
@@ -907,7 +959,8 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
     }
     if (const int cv = bn_chan_vec<T, true>(N, C, HW)) {
         const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, true>(cv)));
-#define BN_CB(V_, A_) COT_LAUNCH((bn_chan_bwd<T, V_, A_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW, ps)
+        const uint8_t* const mk = cv == 8 ? t_bn_mask : nullptr;
+#define BN_CB(V_, A_) COT_LAUNCH((bn_chan_bwd<T, V_, A_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW, ps, (V_) == 8 ? mk : nullptr)
 #define BN_CBV(V_)                                         \
     do {                                                   \
         if (act == ACT_RELU && y) BN_CB(V_, ACT_RELU_Y);   \

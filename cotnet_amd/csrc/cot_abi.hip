@@ -119,6 +119,8 @@ int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int,
 int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
 int ema_flat(void*, const void*, int64_t, float, int, hipStream_t);
 int bn_workspace_floats(int N, int C);
+int64_t bn_relu_mask_bytes(int N, int C, int HW, int esize);
+extern thread_local uint8_t* t_bn_mask;
 extern int g_bn_fold, g_bn_grid_cap, g_bn_small_m, g_bn_split_target;
 template <typename T>
 int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, long long*,
@@ -1247,6 +1249,39 @@ int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, 
                         float* workspace, int N, int C, int HW, int act, int dtype, void* stream) {
     return cot_bn_act_backward_ps(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta, workspace, NULL,
                                   N, C, HW, act, dtype, stream);
+}
+
+// ---- the same pair with the ReLU sign mask (bn3 + residual + ReLU): the forward also writes one byte per 8 output elements, the
+// backward reads those instead of the saved output
+int64_t cot_bn_relu_mask_bytes(int N, int C, int HW, int dtype) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    return bn_relu_mask_bytes(N, C, HW, dtype == COT_BF16 ? 2 : (dtype == COT_F32 ? 4 : 0));
+}
+struct BnMaskScope {  // (the kernels' launch code reads the mask of the call in flight from a thread-local)
+    explicit BnMaskScope(uint8_t* m) { t_bn_mask = m; }
+    ~BnMaskScope() { t_bn_mask = nullptr; }
+};
+int cot_bn_act_forward_mask(const void* x, const void* residual, void* y, void* relu_mask, const float* gamma, const float* beta,
+                            float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float* workspace, const float* sample_scale, int N, int C, int HW,
+                            float eps, float momentum, int act, int dtype, void* stream) {
+    if (!relu_mask) return set_error(COT_ERR_INVALID_ARG, "relu_mask is NULL (cot_bn_act_forward_ps is the call without one)");
+    if (act != 1 || cot_bn_relu_mask_bytes(N, C, HW, dtype) == 0)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_forward_mask: ReLU, and a geometry cot_bn_relu_mask_bytes accepts");
+    BnMaskScope scope((uint8_t*)relu_mask);
+    return cot_bn_act_forward_ps(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var, num_batches_tracked,
+                                 workspace, sample_scale, N, C, HW, eps, momentum, act, dtype, stream);
+}
+int cot_bn_act_backward_mask(const void* dy, const void* x, const void* relu_mask, void* dx, void* dresidual, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                             float* workspace, const float* sample_scale, int N, int C, int HW, int act, int dtype, void* stream) {
+    if (!relu_mask) return set_error(COT_ERR_INVALID_ARG, "relu_mask is NULL");
+    if (act != 1 || cot_bn_relu_mask_bytes(N, C, HW, dtype) == 0)
+        return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_backward_mask: ReLU, and a geometry cot_bn_relu_mask_bytes accepts");
+    BnMaskScope scope((uint8_t*)const_cast<void*>(relu_mask));
+    // (`y` of the ordinary entry point only selects the sign-from-output kernels; with a mask they never dereference it)
+    return cot_bn_act_backward_ps(dy, x, /*y=*/relu_mask, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta, workspace,
+                                  sample_scale, N, C, HW, act, dtype, stream);
 }
 
 int cot_bn_act_inference(const void* x, const void* residual, void* y, const float* gamma, const float* beta,

@@ -426,6 +426,18 @@ int cot_bn_act_forward_ps(const void* x, const void* residual, void* y, const fl
 int cot_bn_act_backward_ps(const void* dy, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
                            const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                            float* workspace, const float* sample_scale, int N, int C, int HW, int act, int dtype, void* stream);
+/* ReLU sign mask for bn3 + residual + ReLU (models/cotnet.py:250-262): its backward needs the sign of its OUTPUT; instead of reading
+ * the saved output back (1/5 of that backward's traffic) the forward can also write one byte per 8 output elements (bit k = element
+ * k > 0, from the rounded output) and the backward read those.  cot_bn_relu_mask_bytes: size of `relu_mask` for this tensor, 0 = not
+ * supported (use the _ps entry points with the saved output).  act must be 1 (ReLU); results are identical to the _ps pair's. */
+int64_t cot_bn_relu_mask_bytes(int N, int C, int HW, int dtype);
+int cot_bn_act_forward_mask(const void* x, const void* residual, void* y, void* relu_mask, const float* gamma, const float* beta,
+                            float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float* workspace, const float* sample_scale, int N, int C, int HW,
+                            float eps, float momentum, int act, int dtype, void* stream);
+int cot_bn_act_backward_mask(const void* dy, const void* x, const void* relu_mask, void* dx, void* dresidual, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                             float* workspace, const float* sample_scale, int N, int C, int HW, int act, int dtype, void* stream);
 /* inference mode (nn.BatchNorm2d.eval()): y = act(gamma*(x - running_mean)/sqrt(running_var + eps) + beta [+ residual]) in one
  * pass; nothing is updated. */
 int cot_bn_act_inference(const void* x, const void* residual, void* y, const float* gamma, const float* beta,

@@ -67,6 +67,10 @@ print('key40=$r', l['value'], l['ms_per_step'], [(r['op'], r['shape'], r['ms_per
         for r in 0 1 0 1; do COT_TUNING=41=$r COT_KERNEL_SUMMARY=$O/${T}_k$r.json timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "
 import sys,json; l=json.loads(sys.stdin.read()); k=json.load(open('$O/${T}_k$r.json'))['kernels']
 print('key41=$r', l['value'], l['ms_per_step'], [(r['kernel'], r['avg_us']) for r in k if 'stem' in r['kernel']])"; done ;;
+  mask) timeout 600 python -m pytest tests/test_fused_layer_gpu.py tests/test_fused_bn_gpu.py tests/test_side_stream_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 2>&1 | tail -3
+        for r in 0 1 0 1; do COT_BN_RELU_MASK=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "
+import sys,json; l=json.loads(sys.stdin.read()); f=l['roofline']['conv_bn_families']
+print('relu_mask=$r', l['value'], l['ms_per_step'], 'bn_bwd', f['bn_bwd'], 'bn_fwd', f['bn_fwd'], 'loss', l['final_loss'])"; done ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac
 done

@@ -363,6 +363,66 @@ def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold, reque
         assert ((dres.float() - rr.grad).abs() <= gtol * (1 + rr.grad.abs())).all()
 
 
+@pytest.mark.parametrize("ps_on", [False, True])
+@pytest.mark.parametrize("fold", [0, 1, "chan"])
+@pytest.mark.parametrize("N,C,H,W", [(5, 4, 8, 8), (3, 2, 16, 24), (40, 2, 4, 4)])
+def test_bn_relu_sign_mask_equals_the_saved_output_path(N, C, H, W, fold, ps_on, request):
+    """cot_bn_act_forward_mask / _backward_mask (bn3 + residual + ReLU, round 4): the forward also writes one byte per 8 output
+    elements, the backward reads those instead of y -- outputs, statistics and every gradient bit-identical to the _ps pair,
+    on the three kernel families; the mask is exactly (y > 0); geometries the mask does not cover are refused"""
+    if fold == "chan":
+        assert _EMUL.cot_set_tuning(21, 1) == 0
+    else:
+        assert _EMUL.cot_set_tuning(12, fold) == 0
+    g = torch.Generator().manual_seed(N + C * H)
+    dt = _lib.dtype_code(torch.bfloat16)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3).bfloat16()
+    res, dy = torch.randn(N, C, H, W, generator=g).bfloat16(), torch.randn(N, C, H, W, generator=g).bfloat16()
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    ps = (torch.rand(N, generator=g) > 0.3).float() / 0.7 if ps_on else None
+    nb = _EMUL.cot_bn_relu_mask_bytes(N, C, H * W, dt)
+    assert nb == N * C * H * W // 8
+    assert _EMUL.cot_bn_relu_mask_bytes(N, C, 49, dt) == 0   # odd plane
+    assert _EMUL.cot_set_tuning(18, 256) == 0                # (the one-wave fp64 path of tiny batches takes no mask)
+    assert _EMUL.cot_bn_relu_mask_bytes(2, C, 64, dt) == 0 and _EMUL.cot_bn_relu_mask_bytes(8, C, 64, dt) == 8 * C * 8
+    assert _EMUL.cot_set_tuning(18, 0) == 0
+    assert _EMUL.cot_bn_relu_mask_bytes(N, C, H * W, _lib.dtype_code(torch.float32)) == 0
+    outs = []
+    for use_mask in (False, True):
+        y = torch.full_like(x, float("nan"))
+        mean, rstd, rm, rv = torch.empty(C), torch.empty(C), torch.zeros(C), torch.ones(C)
+        nbt = torch.zeros((), dtype=torch.int64)
+        ws = torch.empty(_EMUL.cot_bn_act_workspace(N, C))
+        mask = torch.full((nb,), 0xAA, dtype=torch.uint8)
+        if use_mask:
+            rc = _EMUL.cot_bn_act_forward_mask(P(x), P(res), P(y), P(mask), P(gamma), P(beta), P(mean), P(rstd), P(rm), P(rv), P(nbt),
+                                               P(ws), P(ps) if ps_on else None, N, C, H * W, 1e-5, 0.1, 1, dt, None)
+        else:
+            rc = _EMUL.cot_bn_act_forward_ps(P(x), P(res), P(y), P(gamma), P(beta), P(mean), P(rstd), P(rm), P(rv), P(nbt), P(ws),
+                                             P(ps) if ps_on else None, N, C, H * W, 1e-5, 0.1, 1, dt, None)
+        assert rc == 0, _EMUL.cot_last_error()
+        if use_mask:
+            bits = (y.float().reshape(-1, 8) > 0).to(torch.uint8)
+            want = (bits << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8)
+            assert torch.equal(mask, want)
+        dx, dres = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+        dg, db = torch.empty(C), torch.empty(C)
+        if use_mask:
+            rc = _EMUL.cot_bn_act_backward_mask(P(dy), P(x), P(mask), P(dx), P(dres), P(gamma), P(beta), P(mean), P(rstd), P(dg), P(db),
+                                                P(ws), P(ps) if ps_on else None, N, C, H * W, 1, dt, None)
+        else:
+            rc = _EMUL.cot_bn_act_backward_ps(P(dy), P(x), P(y), P(dx), P(dres), P(gamma), P(beta), P(mean), P(rstd), P(dg), P(db),
+                                              P(ws), P(ps) if ps_on else None, N, C, H * W, 1, dt, None)
+        assert rc == 0, _EMUL.cot_last_error()
+        outs.append((y, mean, rstd, rm, rv, dx, dres, dg, db))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert _EMUL.cot_bn_act_forward_mask(P(x), P(res), P(y), P(mask), P(gamma), P(beta), P(mean), P(rstd), P(rm), P(rv), P(nbt), P(ws),
+                                         None, N, C, 49, 1e-5, 0.1, 1, dt, None) == -2
+    assert _EMUL.cot_bn_act_forward_mask(P(x), P(res), P(y), P(mask), P(gamma), P(beta), P(mean), P(rstd), P(rm), P(rv), P(nbt), P(ws),
+                                         None, N, C, H * W, 1e-5, 0.1, 2, dt, None) == -2   # SiLU: no mask
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,C,H,W", [(6, 8, 7, 7), (5, 16, 14, 14), (12, 2, 28, 28), (30, 2, 7, 7), (4, 3, 3, 3)])
 @pytest.mark.parametrize("path", ["stream", "chan"])
