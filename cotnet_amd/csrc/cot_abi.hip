@@ -1280,8 +1280,12 @@ int cot_bn_act_backward_mask(const void* dy, const void* x, const void* relu_mas
         return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_backward_mask: ReLU, and a geometry cot_bn_relu_mask_bytes accepts");
     BnMaskScope scope((uint8_t*)const_cast<void*>(relu_mask));
     // (`y` of the ordinary entry point only selects the sign-from-output kernels; with a mask they never dereference it)
-    return cot_bn_act_backward_ps(dy, x, /*y=*/relu_mask, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta, workspace,
-                                  sample_scale, N, C, HW, act, dtype, stream);
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    const int rc = cot_bn_act_backward_ps_impl(dy, x, /*y=*/relu_mask, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
+                                               workspace, sample_scale, N, C, HW, act, dtype, stream);
+    if (p) prof::annotate_op(21, N, C, C, HW, 1, dtype, (dresidual ? 1 : 0));  // (no saved-output read: the mask is 1/16 of it)
+    return rc;
 }
 
 int cot_bn_act_inference(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
