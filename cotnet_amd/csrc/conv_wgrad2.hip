@@ -676,24 +676,28 @@ int conv1x1_wgrad2_run(const void* gy, const void* x1, const void* x2, int k1, v
 // ------------------------------------------------------------------------------------------------------------------
 // grouped 3 x 3 weight gradient on the TAPS kernels
 
-// gw[row][ci][tap] = sum over slices of part[s][row][tap Kc + ci]  (fixed order: deterministic)
+// gw[row][ci][tap] = sum over slices of part[s][row][tap Kc + ci]  (fixed order: deterministic).  A lane owns four consecutive
+// ci of one (row, tap) -- 16-byte loads along the partial sums' own layout -- and scatters four 2-byte results (the first form
+// walked the OUTPUT order, i.e. read 4 bytes every Kc floats: 19 us per call for the 14 x 14 layers, as long as the GEMM itself).
 __global__ __launch_bounds__(256) void wgrad_reduce_taps(const float* __restrict__ part, int S, int rows, int Kc,
                                                          bf16_t* __restrict__ gw) {
-    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x, tot = (int64_t)rows * Kc * 9;
-    if (o >= tot) return;
-    const int tap = (int)(o % 9);
-    const int64_t rc = o / 9;
-    const int ci = (int)(rc % Kc);
-    const int64_t row = rc / Kc;
-    const float* p = part + row * (9 * Kc) + tap * Kc + ci;
-    float s0 = 0.f, s1 = 0.f;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x, tot = (int64_t)rows * Kc * 9, tot4 = tot >> 2;  // (Kc % 16 == 0)
+    if (e >= tot4) return;
+    const int64_t o = e * 4;
+    const int64_t row = o / (9 * Kc);
+    const int rem = (int)(o - row * (9 * Kc)), tap = rem / Kc, ci = rem - tap * Kc;
+    const f32x4_t* p = reinterpret_cast<const f32x4_t*>(part) + e;
+    f32x4_t s0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, s1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
     int sl = 0;
     for (; sl + 1 < S; sl += 2) {
-        s0 += p[(int64_t)sl * tot];
-        s1 += p[(int64_t)(sl + 1) * tot];
+        s0 += p[(int64_t)sl * tot4];
+        s1 += p[(int64_t)(sl + 1) * tot4];
     }
-    if (sl < S) s0 += p[(int64_t)sl * tot];
-    gw[o] = (bf16_t)(s0 + s1);
+    if (sl < S) s0 += p[(int64_t)sl * tot4];
+    s0 += s1;
+    bf16_t* dst = gw + (row * Kc + ci) * 9 + tap;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r * 9] = (bf16_t)s0[r];
 }
 
 // tile of a layer: rows of dY per workgroup (all of the group's, at most 64) x 144 or 288 virtual rows of X
@@ -772,7 +776,7 @@ int conv3x3g_wgrad2_run(const void* gy, const void* x, void* gw, const void* mas
     else return -1;
     if (rc || a.S == 1) return rc;
     const int64_t tot = (int64_t)Cout * Kc * 9;
-    COT_LAUNCH(wgrad_reduce_taps, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, stream, workspace, a.S, Cout, Kc, (bf16_t*)gw);
+    COT_LAUNCH(wgrad_reduce_taps, dim3((unsigned)ceil_div64(tot / 4, 256)), dim3(256), 0, stream, workspace, a.S, Cout, Kc, (bf16_t*)gw);
     return check_launch("wgrad_reduce_taps");
 }
 
