@@ -681,20 +681,30 @@ int conv1x1_wgrad2_run(const void* gy, const void* x1, const void* x2, int k1, v
 // walked the OUTPUT order, i.e. read 4 bytes every Kc floats: 19 us per call for the 14 x 14 layers, as long as the GEMM itself).
 __global__ __launch_bounds__(256) void wgrad_reduce_taps(const float* __restrict__ part, int S, int rows, int Kc,
                                                          bf16_t* __restrict__ gw) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x, tot = (int64_t)rows * Kc * 9, tot4 = tot >> 2;  // (Kc % 16 == 0)
-    if (e >= tot4) return;
+    // 64 columns (of four floats) x 4 slice lanes per workgroup: lane group q sums the slices q, q + 4, ..; the four partial sums
+    // meet in LDS in a fixed order.  (The 56 x 56 layers have 9216 outputs and 64 slices: one lane per four outputs walked 64
+    // dependent loads on nine workgroups -- 32 us, at the very end of the backward pass.)
+    __shared__ f32x4_t red[3][64];
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + col, tot = (int64_t)rows * Kc * 9, tot4 = tot >> 2;  // (Kc % 16 == 0)
+    f32x4_t s0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, s1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (e < tot4) {
+        const f32x4_t* p = reinterpret_cast<const f32x4_t*>(part) + e;
+        int sl = q;
+        for (; sl + 4 < S; sl += 8) {
+            s0 += p[(int64_t)sl * tot4];
+            s1 += p[(int64_t)(sl + 4) * tot4];
+        }
+        if (sl < S) s0 += p[(int64_t)sl * tot4];
+        s0 += s1;
+    }
+    if (q > 0) red[q - 1][col] = s0;
+    __syncthreads();
+    if (q != 0 || e >= tot4) return;
+    s0 = (s0 + red[0][col]) + (red[1][col] + red[2][col]);
     const int64_t o = e * 4;
     const int64_t row = o / (9 * Kc);
     const int rem = (int)(o - row * (9 * Kc)), tap = rem / Kc, ci = rem - tap * Kc;
-    const f32x4_t* p = reinterpret_cast<const f32x4_t*>(part) + e;
-    f32x4_t s0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, s1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    int sl = 0;
-    for (; sl + 1 < S; sl += 2) {
-        s0 += p[(int64_t)sl * tot4];
-        s1 += p[(int64_t)(sl + 1) * tot4];
-    }
-    if (sl < S) s0 += p[(int64_t)sl * tot4];
-    s0 += s1;
     bf16_t* dst = gw + (row * Kc + ci) * 9 + tap;
 #pragma unroll
     for (int r = 0; r < 4; ++r) dst[r * 9] = (bf16_t)s0[r];
@@ -776,7 +786,7 @@ int conv3x3g_wgrad2_run(const void* gy, const void* x, void* gw, const void* mas
     else return -1;
     if (rc || a.S == 1) return rc;
     const int64_t tot = (int64_t)Cout * Kc * 9;
-    COT_LAUNCH(wgrad_reduce_taps, dim3((unsigned)ceil_div64(tot / 4, 256)), dim3(256), 0, stream, workspace, a.S, Cout, Kc, (bf16_t*)gw);
+    COT_LAUNCH(wgrad_reduce_taps, dim3((unsigned)ceil_div64(tot / 4, 64)), dim3(256), 0, stream, workspace, a.S, Cout, Kc, (bf16_t*)gw);
     return check_launch("wgrad_reduce_taps");
 }
 
