@@ -254,6 +254,111 @@ stem7x7_wgrad_mfma(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, 
         }
 }
 
+// ---- weight gradient with the input rows staged in LDS (round 4).  The kernel above gathers its B operand -- 8 stride-2 taps per
+// fragment -- from global memory: 40 two-byte loads per lane and 32-pixel step, 165 us per launch at the very end of the backward
+// pass.  Here a workgroup (4 waves) owns a slice of the (image, output-row PAIR) sequence; per pair it stages the nine input rows x
+// three channels the pair's 2 Wo pixels read (whole rows with zero margins, 16-byte copies, the next pair's rows fetched into
+// registers while this pair is multiplied: one barrier per pair) and takes every B element from LDS at (tap offset) + (pixel
+// position) + (8 immediates).  The four waves split dW: wave w owns tap columns 80 (w & 1) .. +79 and output channels 32 (w >> 1) ..
+// +31.  Partial sums in the layout of the kernel above (same reduce).  2 Wo % 32 == 0, Ho even, W % 8 == 0.
+__global__ void __launch_bounds__(256)
+stem7x7_wgrad_lds(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, float* __restrict__ part, int N, int H, int W, int Ho,
+                  int Wo, int S, int RS) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    bf16_t* const patch = reinterpret_cast<bf16_t*>(cot_smem);  // [2][27][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, lg = lane >> 4;
+    const int cb = wave & 1, mh = wave >> 1, s = blockIdx.x;
+    const int HWo = Ho * Wo, ppi = Ho / 2;  // row pairs per image
+    const int T = N * ppi, t0 = (int)((int64_t)T * s / S), t1 = (int)((int64_t)T * (s + 1) / S);
+    const int cpr = RS / 8, chunks = 27 * cpr;
+    constexpr int NCH = 4;  // 16-byte pieces per thread and pair (host: chunks <= 4 * 256)
+    int toff[5];
+    bool tok[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int k = cb * 80 + q * 16 + i16;
+        int ci, kh, kw;
+        stem_tap(min(k, kStemK - 1), ci, kh, kw);
+        tok[q] = k < kStemK;
+        toff[q] = (ci * 9 + kh) * RS + 8 - 3 + kw;
+    }
+    f32x4_t acc[2][5];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[a][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    Vec<bf16_t, 8> hold[NCH];
+    auto fetch = [&](int t) __attribute__((always_inline)) {  // rows of pair t -> registers (zeros outside the image / in the margins)
+        const int n = t / ppi, pr = t - n * ppi, ih0 = 4 * pr - 3;
+        const bf16_t* xn = x + (int64_t)n * 3 * H * W;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int qd = j * 256 + tid;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hold[j].v[e] = (bf16_t)0.0f;
+            if (qd < chunks) {
+                const int row = qd / cpr, c = qd - row * cpr;
+                const int ci = row / 9, ih = ih0 + (row - ci * 9);
+                if (c >= 1 && 8 * (c - 1) < W && ih >= 0 && ih < H) hold[j] = ldv<bf16_t, 8>(xn + ((int64_t)ci * H + ih) * W + 8 * (c - 1));
+            }
+        }
+    };
+    auto put = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int qd = j * 256 + tid;
+            if (qd < chunks) stv<bf16_t, 8>(patch + (int64_t)buf * 27 * RS + (int64_t)qd * 8, hold[j]);
+        }
+    };
+    if (t0 < t1) {
+        fetch(t0);
+        put(0);
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        if (t + 1 < t1) fetch(t + 1);
+        const int n = t / ppi, pr = t - n * ppi;
+        const uint16_t* pb = reinterpret_cast<const uint16_t*>(patch) + buf * 27 * RS;
+        const bf16_t* gyn = gy + (int64_t)n * kStemCo * HWo + (int64_t)(2 * pr) * Wo;  // the pair's 2 Wo pixels are contiguous in dY
+        for (int ks = 0; ks < 2 * Wo; ks += 32) {
+            const int p = ks + 8 * lg;            // 8 consecutive pixels of one output row (Wo % 8 == 0)
+            const int r2 = p >= Wo ? 1 : 0, ow = p - r2 * Wo;
+            const int pbase = 2 * r2 * RS + 2 * ow;  // (input row 2 (2 pr + r2) - 3 = patch row 2 r2; column 2 ow - 3 = index 8 + 2 ow - 3)
+            bf16x8_t af[2], bfr[5];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                __builtin_memcpy(&af[a], __builtin_assume_aligned(gyn + (int64_t)(32 * mh + 16 * a + i16) * HWo + p, 16), 16);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const uint16_t* pe = pb + pbase + toff[q];
+                uint16_t v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tok[q] ? pe[2 * e] : (uint16_t)0;
+                __builtin_memcpy(&bfr[q], v, 16);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) acc[a][q] = COT_MFMA_16X16X32_BF16(af[a], bfr[q], acc[a][q]);
+        }
+        if (t + 1 < t1) put(buf ^ 1);
+        __syncthreads();
+    }
+    float* ps = part + (int64_t)s * kStemCo * kStemK;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = 32 * mh + 16 * a + 4 * lg + i;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int k = cb * 80 + q * 16 + i16;
+                if (k < kStemK) ps[co * kStemK + k] = acc[a][q][i];
+            }
+        }
+}
+
 // host side
 static bool stem_geometry(int H, int W, int* Ho, int* Wo) {
     *Ho = (H + 6 - 7) / 2 + 1;
@@ -261,10 +366,19 @@ static bool stem_geometry(int H, int W, int* Ho, int* Wo) {
     return H > 0 && W > 0 && (*Wo % 8) == 0 && ((*Ho * *Wo) % 32) == 0;
 }
 
-int g_stem_lds = 1;  // cot_set_tuning key 41: 1 (default) = forward with the input patch staged in LDS, 0 = gathers from global memory
+int g_stem_lds = 1;  // cot_set_tuning key 41: 1 (default) = forward / weight gradient with the input rows staged in LDS, 0 = gathers from global memory
+// geometry of the LDS-staged weight gradient (0: not covered): slices of ~8 output-row pairs
+static int stem_wgrad_lds_slices(int N, int H, int W, int Ho, int Wo) {
+    if (!g_stem_lds || W % 8 != 0 || (2 * Wo) % 32 != 0 || (Ho & 1) || 27 * ((W + 16) / 8) > 4 * 256) return 0;
+    const int64_t T = (int64_t)N * (Ho / 2);
+    int64_t S = T / 8;
+    if (S > 1024) S = 1024;
+    return (int)(S < 1 ? 1 : S);
+}
 int stem7x7_splits(int N, int H, int W) {
     int Ho, Wo;
     if (!stem_geometry(H, W, &Ho, &Wo)) return 0;
+    if (const int sl = stem_wgrad_lds_slices(N, H, W, Ho, Wo)) return sl;
     const int64_t T = (int64_t)N * (Ho * Wo / 32);
     int64_t S = 512;
     if (S > T / 16) S = T / 16;
@@ -295,6 +409,14 @@ int stem7x7_forward(const void* x, const void* w, void* y, int N, int H, int W, 
 int stem7x7_wgrad(const void* gy, const void* x, void* gw, float* workspace, int N, int H, int W, hipStream_t stream) {
     int Ho, Wo;
     if (!stem_geometry(H, W, &Ho, &Wo)) return COT_ERR_UNSUPPORTED;
+    if (const int SL = stem_wgrad_lds_slices(N, H, W, Ho, Wo)) {
+        const int RS = W + 16;
+        COT_LAUNCH(stem7x7_wgrad_lds, dim3((unsigned)SL), dim3(256), (size_t)2 * 27 * RS * 2, stream, (const bf16_t*)gy, (const bf16_t*)x,
+                   workspace, N, H, W, Ho, Wo, SL, RS);
+        int rc = check_launch("stem7x7_wgrad_lds");
+        if (rc) return rc;
+        return conv1x1_wgrad_reduce_launch(workspace, SL, kStemCo, kStemK, 0, gw, nullptr, stream);
+    }
     const int S = stem7x7_splits(N, H, W), spi = Ho * Wo / 32;
     const int64_t waves = (int64_t)S * 2;
     COT_LAUNCH(stem7x7_wgrad_mfma, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, stream, (const bf16_t*)gy,

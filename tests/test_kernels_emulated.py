@@ -1947,6 +1947,25 @@ def test_stem_convolution_kernels(N, H, W):
     ws, gw = torch.empty(nb, dtype=torch.uint8), torch.full_like(w, float("nan"))
     assert _EMUL.cot_stem7x7s2_backward_weight(P(gy), P(x), P(gw), P(ws), N, H, W, dt, None) == 0
     assert (gw.float() - wf.grad).abs().max() <= 1e-2 * wf.grad.abs().max() + 1e-2
+    # the gather form (tuning key 41 = 0; its own slice count and workspace) agrees to the rounding of the slices' fp32 sums
+    assert _EMUL.cot_set_tuning(41, 0) == 0
+    try:
+        ws0 = torch.empty(_EMUL.cot_stem7x7s2_workspace(N, H, W), dtype=torch.uint8)
+        gw0 = torch.full_like(w, float("nan"))
+        assert _EMUL.cot_stem7x7s2_backward_weight(P(gy), P(x), P(gw0), P(ws0), N, H, W, dt, None) == 0
+    finally:
+        assert _EMUL.cot_set_tuning(41, 1) == 0
+    assert (gw.float() - gw0.float()).abs().max() <= 4e-3 * wf.grad.abs().max() + 1e-3
+    buf = ctypes.create_string_buffer(2048)
+    _EMUL.cot_launch_log(buf, 2048)
+    assert _EMUL.cot_set_tuning(26, 1) == 0
+    try:
+        _EMUL.cot_stem7x7s2_backward_weight(P(gy), P(x), P(gw0), P(ws), N, H, W, dt, None)
+    finally:
+        assert _EMUL.cot_set_tuning(26, 0) == 0
+    _EMUL.cot_launch_log(buf, 2048)
+    staged = W % 8 == 0 and (2 * Wo) % 32 == 0 and Ho % 2 == 0
+    assert ("stem7x7_wgrad_lds" if staged else "stem7x7_wgrad_mfma") in buf.value.decode(), buf.value
     assert _EMUL.cot_stem7x7s2_workspace(N, 30, 30) == 0   # output width 15: not covered
     assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(y), N, 30, 30, dt, None) == -2
 
