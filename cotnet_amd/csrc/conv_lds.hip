@@ -296,6 +296,7 @@ struct C3LdsArgs {
     int N, G, KK, MM, H, W;
     int KX;            // channels per group in x (KK = KX rounded up to the 32-channel chunks; the padding meets zero weights)
     int MBLK, CX;      // output-row blocks per real group (G counts virtual groups = real groups x MBLK); channels per image of x
+    int wsingle;       // chunk-resident form: ONE weight buffer (re-filled behind a barrier after each chunk) -- two workgroups per CU
     int accumulate;
     int tiles;         // BIG: row tiles per image; FLAT: image groups
     int ni;            // FLAT: images per workgroup
@@ -539,8 +540,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const int H = a.H, W = a.W, HW = H * W, KK = a.KK, MM = a.MM, G = a.G;
     const int ncc = K16 ? 1 : KK / 32, nb = ncc > 1 ? 2 : 1;
-    bf16_t* const wsm = reinterpret_cast<bf16_t*>(cot_smem);  // [nb][WBUF] then [nb][XST] then slack
-    bf16_t* const xsm = wsm + nb * WBUF;
+    const int nbw = a.wsingle ? 1 : nb;                       // weight buffers
+    bf16_t* const wsm = reinterpret_cast<bf16_t*>(cot_smem);  // [nbw][WBUF] then [nb][XST] then slack
+    bf16_t* const xsm = wsm + nbw * WBUF;
 
     unsigned b = blockIdx.x;
     if (a.xcd_remap && (gridDim.x & 7u) == 0) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
         else woff[ps] = (tp * MM + rr) * KK + c * 8;
     }
     const bf16_t* wgrp = a.wr + (int64_t)grp * (K16 ? 10 : 9) * MM * KK;
-    auto stage = [&](int cc) __attribute__((always_inline)) {
+    auto stage_x = [&](int cc) __attribute__((always_inline)) {
         bf16_t* xd = xsm + (cc & 1) * XST;
 #pragma unroll
         for (int ps = 0; ps < XP; ++ps) {
@@ -597,11 +599,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
             if (e + 8 > x_total) e = x_total - 8;  // (the last tile's halo row past the tensor: in-bounds bytes, masked)
             COT_GLDS16(a.x + e, xd + (ps * NT + wave * 64) * 8);
         }
-        bf16_t* wd = wsm + (cc & 1) * WBUF;
+    };
+    auto stage_w = [&](int cc) __attribute__((always_inline)) {
+        bf16_t* wd = wsm + (nbw == 2 ? (cc & 1) * WBUF : 0);
 #pragma unroll
         for (int ps = 0; ps < WP; ++ps) COT_GLDS16(wgrp + woff[ps] + cc * 32, wd + (ps * NT + wave * 64) * 8);
     };
-    stage(0);
+    stage_x(0);
+    stage_w(0);
 
     // ---- per-lane byte offsets (inside an input buffer) of the lane's column in every column block, per channel of its 8;
     // validity bits of the 9 taps
@@ -654,9 +659,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
     for (int cc = 0; cc < ncc; ++cc) {
         COT_WAIT_VM(0);     // this chunk's rows and weights (this wave's pieces) have landed ...
         COT_LDS_BARRIER();  // ... everybody's have, and everybody is done with the other pair of buffers
-        if (cc + 1 < ncc) stage(cc + 1);
+        if (cc + 1 < ncc) {
+            stage_x(cc + 1);
+            if (nbw == 2) stage_w(cc + 1);
+        }
         const char* xb = xs0 + (cc & 1) * (XST * 2);
-        const char* wb = ws0 + (cc & 1) * (WBUF * 2);
+        const char* wb = ws0 + (nbw == 2 ? (cc & 1) * (WBUF * 2) : 0);
         // (a padded chunk's channels past the group's end belong to the next group: cleared like the padded taps; KX % 8 == 0)
         const bool chan_ok = K16 || cc * 32 + 8 * g < KX;
         unsigned am[CB];
@@ -724,6 +732,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
                 }
             }
         }
+        if (nbw == 1 && cc + 1 < ncc) {  // one weight buffer: everybody is done with this chunk's weights, then the next chunk's go in
+            COT_LDS_BARRIER();
+            stage_w(cc + 1);
+        }
     }
     EpiArgs e;
     e.y1 = a.y; e.y2 = nullptr; e.bias = nullptr; e.m1 = G * MM; e.M = G * MM; e.HW = HW; e.N = a.N; e.ni = a.ni;
@@ -732,6 +744,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
+int g_conv3x3_wsingle = 1;  // cot_set_tuning key 42: chunk-resident 3x3 with one weight buffer where it buys a second workgroup per CU
 int g_conv3x3_res = 1;  // cot_set_tuning key 39: 1 (default) = the chunk-resident form for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step ring
 template <int CB, int MB, int FLAT, int K16, int XP>
 static int launch_c3res(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
@@ -740,9 +753,19 @@ static int launch_c3res(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) 
     const int nb = (K16 ? 1 : a.KK / 32) > 1 ? 2 : 1;
     size_t lds = (size_t)nb * (WBUF + XST) * sizeof(bf16_t) + 1024;
     const size_t otile = (FLAT ? (size_t)a.ni * (((size_t)BM * a.H * a.W + 7) & ~(size_t)7) : (size_t)BM * (BPX + 8)) * sizeof(bf16_t);
+    C3LdsArgs b = a;
+    b.wsingle = 0;
+    // ONE weight buffer where that makes room for a second workgroup per CU (<= 80 KB) and the launch is more than one round of
+    // workgroups at one per CU: the copy of the next chunk's weights is then exposed once per chunk, and hidden by the neighbour
+    // (14 x 14 key embedding: 320 workgroups = two rounds at one per CU)
+    const size_t lds1 = (size_t)(WBUF + nb * XST) * sizeof(bf16_t) + 1024;
+    if (nb == 2 && (g_conv3x3_wsingle == 2 ||  // (2: wherever there are two chunks -- tests)
+                    (g_conv3x3_wsingle && lds > 80 * 1024 && lds1 <= 80 * 1024 && otile <= 80 * 1024 && blocks > 256))) {
+        b.wsingle = 1;
+        lds = lds1;
+    }
     if (otile > lds) lds = otile;
     if (lds > 160 * 1024) return -1;
-    C3LdsArgs b = a;
     b.xcd_remap = (blocks % 8 == 0) ? 1 : 0;
     static std::atomic<uint32_t> raised{0};
     if (lds > 64 * 1024 &&
@@ -779,7 +802,7 @@ static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, in
     a.x = (const bf16_t*)x; a.wr = (const bf16_t*)ws; a.y = (bf16_t*)y;
     a.N = N; a.G = G; a.KK = KK; a.KX = KX; a.MM = MM; a.H = H; a.W = W; a.accumulate = accumulate;
     a.MBLK = MBLK; a.CX = Greal * KX;
-    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0;
+    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0; a.wsingle = 0;
     int64_t blocks;
     const bool flat = HW <= 256;
     int cols = 256, XPsel = 0;
@@ -866,7 +889,7 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
     a.x = (const bf16_t*)x; a.wr = (const bf16_t*)ws; a.y = (bf16_t*)y;
     a.N = N; a.G = G; a.KK = KK; a.KX = KX; a.MM = MM; a.H = H; a.W = W; a.accumulate = accumulate;
     a.MBLK = MBLK; a.CX = Greal * KX;
-    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0;
+    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0; a.wsingle = 0;
     int64_t blocks;
     int big_cols = 512;
     const bool flat = HW <= 256;

@@ -171,6 +171,7 @@ const char* cot_last_kernel(void);
  *   key 40: channel-resident BatchNorm on odd planes that are multiples of 7 (7 x 7): 1 (default) = 7 elements per access,
  *           0 = element by element
  *   key 41: stem 7x7 forward: 1 (default) = input patch staged in LDS, 0 = operand gathered from global memory
+ *   key 42: chunk-resident 3x3 form: 1 (default) = one weight buffer where that makes room for a second workgroup per CU, 0 = always two
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* Dry-run log of the calling thread (cot_set_tuning(26, 1)): one line per launch the library WOULD have issued --
