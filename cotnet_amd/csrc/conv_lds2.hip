@@ -30,6 +30,7 @@ extern int g_conv_lds_tune[3];
 // off in the FLAT kernels (default on); bit 2 = fragment prefetch on in the BIG kernels (default off: it costs registers, i.e.
 // workgroups per CU, where the layers are bandwidth-bound)
 int g_conv_lds2_tune = 0;
+int g_conv_flat_ns3 = 1;  // cot_set_tuning key 43: FLAT 128-row tiles take three stages instead of six when the launch exceeds one workgroup per CU
 int g_conv_ablate = 0;  // cot_set_tuning key 24 (diagnostic: see C1LdsArgs::ablate)
 
 // template parameters as conv1x1_lds_fwd (conv_lds.hip); PF = fragment prefetch (register double buffer)
@@ -342,6 +343,9 @@ int conv1x1_lds_gemm2(const C1LdsArgs& a0, hipStream_t stream) {
         COT_C2(2, 4, 1, 6);
     }
     a.mblocks = ceil_div(M, 128);
+    // more than one round of workgroups at one per CU (six stages = 144 KB of LDS): three stages (72 KB) let two workgroups share a
+    // CU -- 256 -> 1024 @14x14, B = 80: 640 workgroups, three rounds
+    if (g_conv_flat_ns3 == 2 || (g_conv_flat_ns3 && (int64_t)tiles * a.mblocks > 256)) COT_C2(2, 8, 1, 3);  // (2: always -- tests)
     COT_C2(2, 8, 1, 6);
 #undef COT_C2
 #undef COT_C2W

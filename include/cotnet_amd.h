@@ -172,6 +172,8 @@ const char* cot_last_kernel(void);
  *           0 = element by element
  *   key 41: stem 7x7 forward: 1 (default) = input patch staged in LDS, 0 = operand gathered from global memory
  *   key 42: chunk-resident 3x3 form: 1 (default) = one weight buffer where that makes room for a second workgroup per CU, 0 = always two
+ *   key 43: 1x1 forward / data gradient on whole small images (H*W <= 256), 128-row tiles: 1 (default) = three LDS stages instead of
+ *           six when the launch has more than one workgroup per CU (two then share a CU), 0 = always six
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* Dry-run log of the calling thread (cot_set_tuning(26, 1)): one line per launch the library WOULD have issued --

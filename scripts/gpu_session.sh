@@ -80,6 +80,9 @@ print('run $r', l['value'], l['ms_per_step'], [(r['kernel'], r['avg_us'], r['ms_
            for r in 0 1 0 1; do echo "== key42 $r"; timeout 200 python scripts/bench_conv_abi.py --iters 20 --modes 1 --only "C256 g4" --tune 42=$r 2>/dev/null | grep "g4"; done
            for r in 0 1 0 1; do COT_TUNING=42=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('key42=$r', l['value'], l['ms_per_step'])"; done
            for r in 0 1; do COT_TUNING=42=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 8 --warmup 3 --model cotnext101_2x48d --batch 64 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('cotnext key42=$r', l['value'], l['ms_per_step'])"; done ;;
+  ns3) timeout 600 python -m pytest tests/test_conv1x1_gpu.py tests/test_dispatch_parity_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "conv1x1" 2>&1 | tail -2
+       for r in 0 1 0 1; do echo "== key43 $r"; timeout 200 python scripts/bench_conv_abi.py --iters 20 --only "s3" --tune 43=$r 2>/dev/null | grep "s3 "; done
+       for r in 0 1 0 1; do COT_TUNING=43=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('key43=$r', l['value'], l['ms_per_step'])"; done ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac
 done

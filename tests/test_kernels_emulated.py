@@ -363,6 +363,43 @@ def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold, reque
         assert ((dres.float() - rr.grad).abs() <= gtol * (1 + rr.grad.abs())).all()
 
 
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("N,Ci,Co,H", [(3, 64, 256, 14), (6, 96, 160, 7), (2, 32, 136, 10)])
+def test_conv1x1_flat_three_stage_ring(N, Ci, Co, H, dma, request):
+    """conv1x1_lds_fwd2 on whole small images with THREE LDS stages (tuning key 43; chosen when a launch has more than one
+    workgroup per CU, forced here): forward and data gradient equal the six-stage form bit for bit, under both LDS-DMA landing
+    models (the ring's vmcnt arithmetic depends on the stage count)"""
+    torch.manual_seed(29)
+    dt = _lib.dtype_code(torch.bfloat16)
+    HW = H * H
+    x = torch.randn(N, Ci, H, H).bfloat16()
+    w = (torch.randn(Co, Ci, 1, 1) * Ci ** -0.5).bfloat16()
+    gy = torch.randn(N, Co, H, H).bfloat16()
+    ws = torch.empty(max(_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 0), 256), dtype=torch.uint8)
+    _EMUL.emul_set_dma_mode(dma)
+    assert _EMUL.cot_set_tuning(17, 1 << 8) == 0  # (no 64-row blocks for few-tile launches: the 128-row tiles are the subject)
+    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(43, 1), _EMUL.cot_set_tuning(17, 0), _EMUL.emul_set_dma_mode(0)))
+    outs = []
+    for ns3 in (2, 0):
+        assert _EMUL.cot_set_tuning(43, ns3) == 0
+        y, gx = torch.full((N, Co, H, H), float("nan")).bfloat16(), torch.full_like(x, float("nan"))
+        assert _EMUL.cot_conv1x1_forward(P(x), None, Ci, P(w), None, P(y), N, Ci, Co, HW, dt, None) == 0, _EMUL.cot_last_error()
+        assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, HW, dt, None) == 0
+        outs.append((y, gx))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.nn.functional.conv2d(x.float(), w.float())
+    assert torch.allclose(outs[0][0].float(), ref, atol=2e-2, rtol=2e-2)
+    buf = ctypes.create_string_buffer(2048)
+    _EMUL.cot_launch_log(buf, 2048)
+    assert _EMUL.cot_set_tuning(43, 2) == 0 and _EMUL.cot_set_tuning(26, 1) == 0
+    try:
+        _EMUL.cot_conv1x1_forward(P(x), None, Ci, P(w), None, P(y), N, Ci, Co, HW, dt, None)
+    finally:
+        assert _EMUL.cot_set_tuning(26, 0) == 0
+    _EMUL.cot_launch_log(buf, 2048)
+    assert "NS=3" in buf.value.decode() or "NS = 3" in buf.value.decode(), buf.value
+
+
 @pytest.mark.parametrize("ps_on", [False, True])
 @pytest.mark.parametrize("fold", [0, 1, "chan"])
 @pytest.mark.parametrize("N,C,H,W", [(5, 4, 8, 8), (3, 2, 16, 24), (40, 2, 4, 4)])
