@@ -744,6 +744,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
+int g_conv3x3_cols = 1;  // cot_set_tuning key 44: one-chunk groups pick 512- or 256-column tiles by rounds of workgroups (0 = always 512 where the chip is filled)
 int g_conv3x3_wsingle = 1;  // cot_set_tuning key 42: chunk-resident 3x3 with one weight buffer where it buys a second workgroup per CU
 int g_conv3x3_res = 1;  // cot_set_tuning key 39: 1 (default) = the chunk-resident form for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step ring
 template <int CB, int MB, int FLAT, int K16, int XP>
@@ -828,6 +829,21 @@ static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, in
             TR = 256 / W;
             if (TR > H) TR = H;
         }
+        // one chunk, up to 32 rows: rounds of workgroups decide (SQ counters).  512-column tiles take 65 KB (two per CU),
+        // 256-column ones with three row passes 49 KB (three per CU) and ~0.65 of the time each: 128 -> 128 g4 @28x28, B = 80 is 640
+        // workgroups = two rounds of 512 slots, or 1280 = two rounds of 768 slots of the smaller kind
+        if (cols == 512 && ncc == 1 && !K16 && g_conv3x3_cols && 256 / W >= 2 && H > 0) {
+            auto rows_of = [&](int c) { int t = c / W; if (t > H) t = H; const int n = ceil_div(H, t); return ceil_div(H, n); };
+            const int TR5 = rows_of(512), TR2 = rows_of(256);
+            const int64_t b5 = (int64_t)N * G * ceil_div(H, TR5), b2 = (int64_t)N * G * ceil_div(H, TR2);
+            const bool fits3 = (int64_t)CH * (((TR2 + 2) * W + 8 + 7) / 8) <= (int64_t)3 * 512 && (TR2 * W) % 8 == 0;
+            const double c5 = (double)ceil_div64(b5, 512), c2 = (double)ceil_div64(b2, 768) * 0.65;
+            if (fits3 && c2 < c5) {
+                cols = 256;
+                TR = 256 / W;
+                if (TR > H) TR = H;
+            }
+        }
         if (TR < 1) return -1;
         const int nt = ceil_div(H, TR);
         TR = ceil_div(H, nt);
@@ -852,6 +868,7 @@ static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, in
         return launch_c3res<2, 4, 1, 0, 2>(a, blocks, stream);
     }
     if (K16) return cols == 512 ? launch_c3res<4, 1, 0, 1, 3>(a, blocks, stream) : launch_c3res<2, 1, 0, 1, 3>(a, blocks, stream);
+    if (MB == 2 && cols == 256 && XPsel <= 3) return launch_c3res<2, 2, 0, 0, 3>(a, blocks, stream);
     if (MB == 2) return cols == 512 ? launch_c3res<4, 2, 0, 0, 5>(a, blocks, stream) : launch_c3res<2, 2, 0, 0, 5>(a, blocks, stream);
     if (XPsel <= 3) return launch_c3res<2, 4, 0, 0, 3>(a, blocks, stream);
     return launch_c3res<2, 4, 0, 0, 5>(a, blocks, stream);

@@ -155,6 +155,7 @@ extern int g_conv_lds_tune[3];
 extern int g_conv3x3_ring;
 extern int g_conv3x3_res;
 extern int g_conv3x3_wsingle;
+extern int g_conv3x3_cols;
 extern int g_conv_flat_ns3;
 extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
@@ -394,6 +395,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 24) {  // DIAGNOSTIC: timing ablations of the third-generation 1x1 kernel (results become wrong)
         g_conv_ablate = value;
+        return COT_OK;
+    }
+    if (key == 44) {
+        g_conv3x3_cols = value ? 1 : 0;
         return COT_OK;
     }
     if (key == 43) {

@@ -83,6 +83,10 @@ print('run $r', l['value'], l['ms_per_step'], [(r['kernel'], r['avg_us'], r['ms_
   ns3) timeout 600 python -m pytest tests/test_conv1x1_gpu.py tests/test_dispatch_parity_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "conv1x1" 2>&1 | tail -2
        for r in 0 1 0 1; do echo "== key43 $r"; timeout 200 python scripts/bench_conv_abi.py --iters 20 --only "s3" --tune 43=$r 2>/dev/null | grep "s3 "; done
        for r in 0 1 0 1; do COT_TUNING=43=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('key43=$r', l['value'], l['ms_per_step'])"; done ;;
+  cols) timeout 600 python -m pytest tests/test_conv3x3g_gpu.py tests/test_dispatch_parity_gpu.py tests/test_fused_layer_gpu.py -m gpu -q -p no:cacheprovider --timeout 300 -k "conv3x3 or layer or block" 2>&1 | tail -2
+        for r in 0 1 0 1; do echo "== key44 $r"; timeout 200 python scripts/bench_conv_abi.py --iters 20 --modes 1 --only "C128 g4" --tune 44=$r 2>/dev/null | grep "g4"; done
+        for r in 0 1 0 1; do COT_TUNING=44=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('key44=$r', l['value'], l['ms_per_step'])"; done
+        for r in 0 1; do COT_TUNING=44=$r timeout 300 python bench.py --no-secondary --no-cpu-baseline --no-kernel-timing --steps 8 --warmup 3 --model cotnext101_2x48d --batch 64 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('cotnext key44=$r', l['value'], l['ms_per_step'])"; done ;;
   bench) timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err ;;
 esac
 done
