@@ -832,21 +832,33 @@ static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, in
         // one chunk, up to 32 rows: rounds of workgroups decide (SQ counters).  512-column tiles take 65 KB (two per CU),
         // 256-column ones with three row passes 49 KB (three per CU) and ~0.65 of the time each: 128 -> 128 g4 @28x28, B = 80 is 640
         // workgroups = two rounds of 512 slots, or 1280 = two rounds of 768 slots of the smaller kind
+        int TRpick = 0;  // rows per tile chosen by the rule below (0: the balanced rule that follows)
         if (cols == 512 && ncc == 1 && !K16 && g_conv3x3_cols && 256 / W >= 2 && H > 0) {
-            auto rows_of = [&](int c) { int t = c / W; if (t > H) t = H; const int n = ceil_div(H, t); return ceil_div(H, n); };
-            const int TR5 = rows_of(512), TR2 = rows_of(256);
-            const int64_t b5 = (int64_t)N * G * ceil_div(H, TR5), b2 = (int64_t)N * G * ceil_div(H, TR2);
-            const bool fits3 = (int64_t)CH * (((TR2 + 2) * W + 8 + 7) / 8) <= (int64_t)3 * 512 && (TR2 * W) % 8 == 0;
-            const double c5 = (double)ceil_div64(b5, 512), c2 = (double)ceil_div64(b2, 768) * 0.65;
-            if (fits3 && c2 < c5) {
-                cols = 256;
-                TR = 256 / W;
-                if (TR > H) TR = H;
+            // fewest tiles of at most c columns whose rows are 16-byte multiples and whose chunk fits `xp` row passes (0: none)
+            auto rows_for = [&](int c, int xp) {
+                const int tmax = std::min(c / W, H);
+                for (int n = ceil_div(H, tmax); n <= H; ++n)
+                    for (int t = ceil_div(H, n); t <= tmax && ceil_div(H, t) == n; ++t)
+                        if ((t * W) % 8 == 0 && (int64_t)CH * (((t + 2) * W + 8 + 7) / 8) <= (int64_t)xp * 512) return t;
+                return 0;
+            };
+            const int TR5 = rows_for(512, 5), TR2 = rows_for(256, 3);
+            if (TR5 > 0 && TR2 > 0) {
+                const int64_t b5 = (int64_t)N * G * ceil_div(H, TR5), b2 = (int64_t)N * G * ceil_div(H, TR2);
+                const double c5 = (double)ceil_div64(b5, 512) * (0.3 + 0.7 * TR5 * W / 512.0);
+                const double c2 = (double)ceil_div64(b2, 768) * (0.3 + 0.7 * TR2 * W / 512.0);
+                if (c2 < c5) {
+                    cols = 256;
+                    TRpick = TR2;
+                }
             }
         }
+        if (TRpick) TR = TRpick;
         if (TR < 1) return -1;
-        const int nt = ceil_div(H, TR);
-        TR = ceil_div(H, nt);
+        if (!TRpick) {
+            const int nt = ceil_div(H, TR);
+            TR = ceil_div(H, nt);
+        }
         while (TR > 1 && ((TR * W) % 8 != 0 || (int64_t)CH * (((TR + 2) * W + 8 + 7) / 8) > (int64_t)XPmax * 512)) --TR;
         if ((TR * W) % 8 != 0 || (int64_t)CH * (((TR + 2) * W + 8 + 7) / 8) > (int64_t)XPmax * 512) return -1;
         a.TR = TR;
