@@ -813,6 +813,26 @@ static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, in
         if (ni > want) ni = want;
         if (ni > N) ni = N;
         if (ni < 1) ni = 1;
+        // multi-chunk groups on small planes: the 256-column tile above, or a 128-column one (CB = 1: half the gathers per wave and
+        // chunk, one row pass) -- by rounds of workgroups.  7 x 7, 128 -> 128 per group, B = 80: 16 tiles x 8 row blocks = 128
+        // workgroups (half the chip) of 245 columns, or 40 x 8 = 320 of 98 columns, two per CU with one weight buffer
+        if (!K16 && ncc > 1 && g_conv3x3_cols && HW <= 128) {
+            int ni1 = 128 / HW;
+            if (ni1 > N) ni1 = N;
+            const int wbuf = (MB == 4 ? 40 : 24) * 1024;
+            auto cost = [&](int nimg, int cb, int xp) {
+                const int64_t bl = (int64_t)ceil_div(N, nimg) * G;
+                const int64_t l2 = 2 * (wbuf + xp * 8192) + 1024, l1 = wbuf + 2 * xp * 8192 + 1024;
+                const int64_t l = (l2 > 80 * 1024 && l1 <= 80 * 1024 && bl > 256) ? l1 : l2;   // (launch_c3res' one-weight-buffer rule)
+                const int wpc = (int)std::min<int64_t>(4, (160 * 1024) / l);
+                return (double)ceil_div64(bl, (int64_t)256 * wpc) * (0.3 + 0.7 * nimg * HW / 256.0) * (l == l1 && l != l2 ? 1.15 : 1.0);
+            };
+            const int xp2 = (int)ceil_div64((int64_t)ni * 32 * HW / 8, 512), xp1 = (int)ceil_div64((int64_t)ni1 * 32 * HW / 8, 512);
+            if (xp1 == 1 && xp2 <= 2 && (g_conv3x3_cols == 2 || cost(ni1, 1, 1) < cost(ni, 2, 2))) {  // (2: always -- tests)
+                ni = ni1;
+                cols = 128;
+            }
+        }
         a.ni = ni;
         a.tiles = ceil_div(N, ni);
         blocks = (int64_t)a.tiles * G;
@@ -876,6 +896,7 @@ static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, in
     }
     if (flat) {
         if (K16) return launch_c3res<2, 1, 1, 1, 1>(a, blocks, stream);
+        if (cols == 128) return MB == 2 ? launch_c3res<1, 2, 1, 0, 1>(a, blocks, stream) : launch_c3res<1, 4, 1, 0, 1>(a, blocks, stream);
         if (MB == 2) return launch_c3res<2, 2, 1, 0, 2>(a, blocks, stream);
         return launch_c3res<2, 4, 1, 0, 2>(a, blocks, stream);
     }

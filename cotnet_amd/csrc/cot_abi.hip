@@ -398,7 +398,7 @@ int cot_set_tuning(int key, int value) {
         return COT_OK;
     }
     if (key == 44) {
-        g_conv3x3_cols = value ? 1 : 0;
+        g_conv3x3_cols = value == 2 ? 2 : (value ? 1 : 0);
         return COT_OK;
     }
     if (key == 43) {
