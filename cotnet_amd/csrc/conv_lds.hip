@@ -274,10 +274,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
 // MBLK > 1: a group's output channels are cut into MBLK blocks of Mo rows ("virtual groups" g' = g*MBLK + blk that share the
 // real group's input): dense 3x3 convolutions with more than 128 output channels per group (SE-CoTNetD's SplitAttn convs).
 __global__ void conv3x3g_repack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ dst, int G, int Mo, int Kk, int Kp, int NTAP,
-                                       int dgrad, int MBLK) {
+                                       int dgrad, int MBLK, int perm) {
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (int64_t)G * NTAP * Mo * Kp;
     if (o >= total) return;
-    const int kk = (int)(o % Kp);
+    int kk = (int)(o % Kp);
+    if (perm) {  // position 8 g + j of a 32-channel chunk holds channel 4 j + g (C3LdsArgs::perm)
+        const int r = kk & 31;
+        kk = (kk & ~31) + 4 * (r & 7) + (r >> 3);
+    }
     int64_t r = o / Kp;
     const int mo = (int)(r % Mo);
     r /= Mo;
@@ -297,6 +301,8 @@ struct C3LdsArgs {
     int KX;            // channels per group in x (KK = KX rounded up to the 32-channel chunks; the padding meets zero weights)
     int MBLK, CX;      // output-row blocks per real group (G counts virtual groups = real groups x MBLK); channels per image of x
     int wsingle;       // chunk-resident form: ONE weight buffer (re-filled behind a barrier after each chunk) -- two workgroups per CU
+    int perm;          // chunk-resident form: K position 8 g + j of a 32-channel chunk holds channel 4 j + g (else 8 g + j), in x's gathers
+                       // and in the repacked weights alike: the four lane groups of a 2-byte gather then read CONSECUTIVE channel rows
     int accumulate;
     int tiles;         // BIG: row tiles per image; FLAT: image groups
     int ni;            // FLAT: images per workgroup
@@ -638,9 +644,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
         }
         if (K16 && (g >> 1)) m >>= 1;  // (lane groups 2, 3 take the step's second tap: bit 2t of m is tap 2t + 1; "tap 9" = bit 8 = 0)
         amask[cb] = m;
-        const int b0 = base + (K16 ? 8 * (g & 1) : 8 * g) * SLc;
+        const int b0 = base + (K16 ? 8 * (g & 1) : (a.perm ? g : 8 * g)) * SLc;
+        const int kst = (!K16 && a.perm) ? 4 * SLc : SLc;  // channel stride between the lane's 8 K positions
 #pragma unroll
-        for (int k = 0; k < 8; ++k) aoff[cb][k] = (b0 + k * SLc) * 2;
+        for (int k = 0; k < 8; ++k) aoff[cb][k] = (b0 + k * kst) * 2;
     }
     int boff[MB];
 #pragma unroll
@@ -666,7 +673,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
         const char* xb = xs0 + (cc & 1) * (XST * 2);
         const char* wb = ws0 + (nbw == 2 ? (cc & 1) * (WBUF * 2) : 0);
         // (a padded chunk's channels past the group's end belong to the next group: cleared like the padded taps; KX % 8 == 0)
-        const bool chan_ok = K16 || cc * 32 + 8 * g < KX;
+        // interleaved K order: the lane's position j is channel 4 j + g, valid while 4 j + g < KX - 32 cc, i.e. (KX % 8 == 0) j < kwv * 2
+        const bool chan_ok = K16 || a.perm || cc * 32 + 8 * g < KX;
+        const int kwv = (!K16 && a.perm) ? min(4, (KX - cc * 32) / 8) : 4;  // valid 2-channel words of the lane's fragment
         unsigned am[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) am[cb] = chan_ok ? amask[cb] : 0u;
@@ -689,7 +698,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
                         }
                         const uint32_t msk = (uint32_t)(((int32_t)(am[cb] << (31 - tap))) >> 31);  // all ones / zero
 #pragma unroll
-                        for (int hh = 0; hh < 4; ++hh) q[hh] &= msk;
+                        for (int hh = 0; hh < 4; ++hh) q[hh] = hh < kwv ? (q[hh] & msk) : 0u;
                         __builtin_memcpy(&af[cb], q, 16);
                     }
 #pragma unroll
@@ -744,6 +753,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
+int g_conv3x3_perm = 1;  // cot_set_tuning key 45: K order inside a chunk by LDS banks (0 = always blocked, 2 = always interleaved)
 int g_conv3x3_cols = 1;  // cot_set_tuning key 44: one-chunk groups pick 512- or 256-column tiles by rounds of workgroups (0 = always 512 where the chip is filled)
 int g_conv3x3_wsingle = 1;  // cot_set_tuning key 42: chunk-resident 3x3 with one weight buffer where it buys a second workgroup per CU
 int g_conv3x3_res = 1;  // cot_set_tuning key 39: 1 (default) = the chunk-resident form for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step ring
@@ -803,7 +813,7 @@ static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, in
     a.x = (const bf16_t*)x; a.wr = (const bf16_t*)ws; a.y = (bf16_t*)y;
     a.N = N; a.G = G; a.KK = KK; a.KX = KX; a.MM = MM; a.H = H; a.W = W; a.accumulate = accumulate;
     a.MBLK = MBLK; a.CX = Greal * KX;
-    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0; a.wsingle = 0;
+    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0; a.wsingle = 0; a.perm = 0;
     int64_t blocks;
     const bool flat = HW <= 256;
     int cols = 256, XPsel = 0;
@@ -891,10 +901,30 @@ static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, in
         blocks = (int64_t)N * a.tiles * G;
         XPsel = (int)ceil_div64((int64_t)CH * (a.SL / 8), 512);
     }
+    // K order inside a chunk by LDS banks: a 2-byte gather reads, per lane group g, 16 consecutive pixels (32 bytes = 8 banks) of
+    // one channel row; the four groups' rows are 8 SLc elements apart in the blocked order (channels 8 g + j), SLc in the interleaved
+    // one (4 j + g).  Take the interleaved order when its four windows share fewer banks than the blocked ones
+    // (228-dword rows of the 28 x 28 tiles: blocked = two windows on the same banks; 144-dword rows: all four)
+    a.perm = 0;
+    if (!K16 && g_conv3x3_perm) {
+        const int slc = flat ? HW : a.SL;
+        auto overlap = [&](int step_elems) {  // banks shared by the four groups' windows (9 banks each: the +-1 column taps start on an odd element)
+            int lo[4], sum = 0;
+            for (int q = 0; q < 4; ++q) lo[q] = (int)(((int64_t)q * step_elems * 2 / 4) % 64);
+            for (int p1 = 0; p1 < 4; ++p1)
+                for (int p2 = p1 + 1; p2 < 4; ++p2) {
+                    int d = (lo[p1] - lo[p2] + 64) % 64;
+                    if (d > 32) d = 64 - d;
+                    if (d < 9) sum += 9 - d;
+                }
+            return sum;
+        };
+        if (g_conv3x3_perm == 2 || overlap(slc) < overlap(8 * slc)) a.perm = 1;
+    }
     {   // repack the weights: [G][NTAP][MM][KK]
         const int64_t total = (int64_t)G * NTAP * MM * KK;
         COT_LAUNCH(conv3x3g_repack_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, (const bf16_t*)w,
-                   (bf16_t*)ws, G, MM, KX, KK, NTAP, mode, MBLK);
+                   (bf16_t*)ws, G, MM, KX, KK, NTAP, mode, MBLK, a.perm);
         int rc = check_launch("conv3x3g_repack_kernel");
         if (rc) return rc;
     }
@@ -943,7 +973,7 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
     a.x = (const bf16_t*)x; a.wr = (const bf16_t*)ws; a.y = (bf16_t*)y;
     a.N = N; a.G = G; a.KK = KK; a.KX = KX; a.MM = MM; a.H = H; a.W = W; a.accumulate = accumulate;
     a.MBLK = MBLK; a.CX = Greal * KX;
-    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0; a.wsingle = 0;
+    a.ni = 1; a.TR = 0; a.SL = 0; a.tiles = 1; a.xcd_remap = 0; a.wsingle = 0; a.perm = 0;
     int64_t blocks;
     int big_cols = 512;
     const bool flat = HW <= 256;
@@ -980,7 +1010,7 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
     {   // repack the weights: [G][NTAP][MM][KK]
         const int64_t total = (int64_t)G * NTAP * MM * KK;
         COT_LAUNCH(conv3x3g_repack_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, (const bf16_t*)w,
-                   (bf16_t*)ws, G, MM, KX, KK, NTAP, mode, MBLK);
+                   (bf16_t*)ws, G, MM, KX, KK, NTAP, mode, MBLK, 0);
         int rc = check_launch("conv3x3g_repack_kernel");
         if (rc) return rc;
     }

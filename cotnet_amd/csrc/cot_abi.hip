@@ -156,6 +156,7 @@ extern int g_conv3x3_ring;
 extern int g_conv3x3_res;
 extern int g_conv3x3_wsingle;
 extern int g_conv3x3_cols;
+extern int g_conv3x3_perm;
 extern int g_conv_flat_ns3;
 extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
@@ -395,6 +396,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 24) {  // DIAGNOSTIC: timing ablations of the third-generation 1x1 kernel (results become wrong)
         g_conv_ablate = value;
+        return COT_OK;
+    }
+    if (key == 45) {
+        g_conv3x3_perm = value == 2 ? 2 : (value ? 1 : 0);
         return COT_OK;
     }
     if (key == 44) {

@@ -176,6 +176,8 @@ const char* cot_last_kernel(void);
  *           six when the launch has more than one workgroup per CU (two then share a CU), 0 = always six
  *   key 44: chunk-resident 3x3 form, groups of <= 32 channels on planes > 256 pixels: 1 (default) = 512- or 256-column tiles by
  *           rounds of workgroups, 0 = 512-column tiles wherever they fill the chip
+ *   key 45: chunk-resident 3x3 form, order of the 32 channels of a chunk along K: 1 (default) = blocked or interleaved by LDS bank
+ *           windows of the staged rows, 0 = always blocked, 2 = always interleaved
  * Keys 11, 15, 17 (bits 2-4), 19, 20, 25 change split counts / kernel choice: query cot_*_workspace after setting them. */
 int cot_set_tuning(int key, int value);
 /* Dry-run log of the calling thread (cot_set_tuning(26, 1)): one line per launch the library WOULD have issued --

@@ -1116,14 +1116,14 @@ def test_conv3x3_grouped_weight_gradient_guard_decides_the_kernel():
     (1, 512, 2, 20, 20),   # BIG, two real groups x two row blocks
     (1, 64, 1, 6, 160),    # BIG, rows of 160 pixels (SE-CoTNetD's stem / first block at 320 x 320): one image row per tile
 ])
-@pytest.mark.parametrize("res,dma", [(2, 0), (2, 1), (0, 1), (-2, 0), (-2, 1)])  # (-2: chunk-resident with ONE weight buffer wherever there are two chunks, key 42 = 2, and 128-column tiles on small planes, key 44 = 2)
+@pytest.mark.parametrize("res,dma", [(2, 0), (2, 1), (0, 1), (-2, 0), (-2, 1)])  # (-2: chunk-resident with ONE weight buffer wherever there are two chunks, key 42 = 2, 128-column tiles on small planes, key 44 = 2, and the interleaved K order everywhere, key 45 = 2; the others: K order by banks / always blocked)
 def test_conv3x3_grouped_lds_kernels(N, C, G, H, W, res, dma, request):
     """csrc/conv_lds.hip conv3x3g_lds_res (chunk-resident weights, tuning key 39 = 1) and conv3x3g_lds_fwd (per-step ring, 0):
     forward and data gradient incl. accumulate against torch on the same rounded operands, and against the first-generation
     kernel; LDS copies landing at the earliest and at the latest legal time (the vmcnt arithmetic and the buffer re-use)"""
-    assert _EMUL.cot_set_tuning(39, abs(res)) == 0 and _EMUL.cot_set_tuning(42, 2 if res < 0 else 0) == 0 and _EMUL.cot_set_tuning(44, 2 if res < 0 else 1) == 0
+    assert _EMUL.cot_set_tuning(39, abs(res)) == 0 and _EMUL.cot_set_tuning(42, 2 if res < 0 else 0) == 0 and _EMUL.cot_set_tuning(44, 2 if res < 0 else 1) == 0 and _EMUL.cot_set_tuning(45, 2 if res < 0 else (1 if dma else 0)) == 0
     _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(39, 1), _EMUL.cot_set_tuning(42, 1), _EMUL.cot_set_tuning(44, 1), _EMUL.emul_set_dma_mode(0)))  # (2: 16-channel groups too)
+    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(39, 1), _EMUL.cot_set_tuning(42, 1), _EMUL.cot_set_tuning(44, 1), _EMUL.cot_set_tuning(45, 1), _EMUL.emul_set_dma_mode(0)))  # (2: 16-channel groups too)
     torch.manual_seed(17)
     x = torch.randn(N, C, H, W).bfloat16()
     w = (torch.randn(C, C // G, 3, 3) / (9 * C // G) ** 0.5).bfloat16()
@@ -1188,13 +1188,13 @@ def test_conv3x3_lds_masks_by_selection():
     assert torch.allclose(y[:, Kc:].float(), yref, atol=2e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("res", [1, 0])
+@pytest.mark.parametrize("res", [1, 0, -1])  # (-1: chunk-resident with the interleaved K order, tuning key 45 = 2)
 def test_conv3x3_lds_padded_chunk_is_cleared_by_selection(res, request):
     """groups of 48 channels on the LDS kernels (chunk-resident form / per-step ring): the second 32-channel chunk of group 0 is
     half group 1's channels.  They meet zero weights -- and must be cleared by selection all the same: group 1 is all NaN here,
     group 0's outputs must not notice"""
-    assert _EMUL.cot_set_tuning(39, res) == 0
-    request.addfinalizer(lambda: _EMUL.cot_set_tuning(39, 1))
+    assert _EMUL.cot_set_tuning(39, abs(res)) == 0 and _EMUL.cot_set_tuning(45, 2 if res < 0 else 0) == 0
+    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(39, 1), _EMUL.cot_set_tuning(45, 1)))
     torch.manual_seed(19)
     N, C, G, H, W = 2, 96, 2, 6, 8
     Kc = C // G
