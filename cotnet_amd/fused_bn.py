@@ -118,7 +118,8 @@ def fused_bn_act(x, bn, act=None, residual=None):
           and bn.weight.dtype == torch.float32 and x.data_ptr() % 16 == 0
           and bn.num_batches_tracked is not None and bn.num_batches_tracked.dtype == torch.int64
           and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype
-                                    and residual.is_contiguous() and residual.data_ptr() % 16 == 0)))
+                                    and residual.is_contiguous() and residual.data_ptr() % 16 == 0))
+          and not (residual is not None and _ACTS.get(act) == 2))  # (SiLU after a residual add: the kernels have no backward for it)
     if not ok:
         return _torch_path(x, bn, act, residual)
     # num_batches_tracked += 1 (nn.BatchNorm2d.forward's bookkeeping) is done by the statistics kernel itself

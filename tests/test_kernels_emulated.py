@@ -363,6 +363,37 @@ def test_bn_act_kernels_match_torch(N, C, H, W, act, use_res, dtype, fold, reque
         assert ((dres.float() - rr.grad).abs() <= gtol * (1 + rr.grad.abs())).all()
 
 
+def test_bn_silu_after_a_residual_add_has_no_backward(monkeypatch):
+    """SiLU'(z) needs z = bn(x) + residual, which the backward entry point is not given: the call is refused instead of returning
+    the gradient of SiLU(bn(x)) (found by the round-4 fuzz); `fused_bn_act` keeps such a block on torch"""
+    from cotnet_amd import fused_bn
+    N, C, HW = 4, 3, 16
+    x, res, dy = torch.randn(N, C, 4, 4), torch.randn(N, C, 4, 4), torch.randn(N, C, 4, 4)
+    y, dx, dres = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    gamma, beta, mean, rstd, dg, db = torch.ones(C), torch.zeros(C), torch.empty(C), torch.empty(C), torch.empty(C), torch.empty(C)
+    ws = torch.empty(_EMUL.cot_bn_act_workspace(N, C))
+    assert _EMUL.cot_bn_act_forward(P(x), P(res), P(y), P(gamma), P(beta), P(mean), P(rstd), None, None, None, P(ws), N, C, HW, 1e-5,
+                                    0.1, 2, 0, None) == 0
+    z = torch.nn.functional.batch_norm(x, None, None, gamma, beta, True) + res
+    assert torch.allclose(y, torch.nn.functional.silu(z), atol=1e-5)
+    assert _EMUL.cot_bn_act_backward(P(dy), P(x), P(y), P(dx), P(dres), P(gamma), P(beta), P(mean), P(rstd), P(dg), P(db), P(ws),
+                                     N, C, HW, 2, 0, None) == -2
+    assert _EMUL.cot_bn_act_backward(P(dy), P(x), P(y), P(dx), None, P(gamma), P(beta), P(mean), P(rstd), P(dg), P(db), P(ws),
+                                     N, C, HW, 2, 0, None) == 0
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    monkeypatch.setattr(fused_bn, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(fused_bn, "ENABLED", True)
+    bn = torch.nn.BatchNorm2d(C)
+    xa, ra = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    ya = fused_bn.fused_bn_act(xa, bn, "silu", ra)
+    assert "BNAct" not in type(ya.grad_fn).__name__
+    ya.backward(dy)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    torch.nn.functional.silu(torch.nn.functional.batch_norm(xr, None, None, bn.weight, bn.bias, True) + rr).backward(dy)
+    assert torch.allclose(xa.grad, xr.grad, atol=1e-5) and torch.allclose(ra.grad, rr.grad, atol=1e-5)
+    assert "BNAct" in type(fused_bn.fused_bn_act(xa, bn, "silu", None).grad_fn).__name__
+
+
 @pytest.mark.parametrize("dma", [0, 1])
 @pytest.mark.parametrize("N,Ci,Co,H", [(3, 64, 256, 14), (6, 96, 160, 7), (2, 32, 136, 10)])
 def test_conv1x1_flat_three_stage_ring(N, Ci, Co, H, dma, request):
