@@ -1243,8 +1243,8 @@ static int cot_bn_act_backward_ps_impl(const void* dy, const void* x, const void
         return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if (act == 1 && !y && dresidual)
         return set_error(COT_ERR_INVALID_ARG, "ReLU backward after a residual add needs the saved output y");
-    if (act == 2 && dresidual)  // (SiLU' needs z = bn(x) + residual: neither is an argument here; the reference has no such block)
-        return set_error(COT_ERR_UNSUPPORTED, "SiLU backward after a residual add is not covered");
+    if (act == 2 && (dresidual || sample_scale))  // (SiLU' needs z = s_n * bn(x) + residual; the kernels recompute bn(x) alone.  The reference has no such block)
+        return set_error(COT_ERR_UNSUPPORTED, "SiLU backward after a residual add / a per-sample scale is not covered");
     if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act");
     int rc = check_align16({dy, x, y, dx, dresidual});
     if (rc) return rc;

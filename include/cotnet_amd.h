@@ -414,7 +414,8 @@ int cot_input_normalize(const void* x_u8, void* y, const float* mean, const floa
  * gamma/beta/statistics are fp32; x/residual/y are `dtype` (COT_F32 or COT_BF16).  workspace: cot_bn_act_workspace
  * floats.  backward: dx, dgamma, dbeta (and dresidual = dy*act' when non-NULL); ReLU with a residual needs the saved
  * output y (its sign is the mask); without a residual y may be NULL and the mask is recomputed from x.  SiLU after a residual add
- * has a forward only: its backward returns COT_ERR_UNSUPPORTED (the reference has no such block). */
+ * (or, in the _ps form, a per-sample scale) has a forward only: its backward returns COT_ERR_UNSUPPORTED (the reference has no
+ * such block). */
 int cot_bn_act_workspace(int N, int C);
 int cot_bn_act_forward(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                        float* save_mean, float* save_rstd, float* running_mean, float* running_var,

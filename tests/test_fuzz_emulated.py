@@ -410,8 +410,89 @@ def case_agg_gn9(rng):
     return torch.equal(a1, a2) and torch.equal(gx1, gx2) and torch.equal(gw1, gw2), ("agg gn9", N, C, H, W)
 
 
+def case_bn_ps(rng):
+    """cot_bn_act_*_ps: y = act(s_n * bn(x) [+ residual]) with a per-sample scale (stochastic depth), every act / residual
+    combination in fp32 against torch autograd; SiLU has no backward in this form (refused)"""
+    N, C = rng.randint(2, 24), rng.randint(1, 5)
+    H, W = rng.choice([(7, 7), (4, 4), (8, 8), (3, 5), (14, 14), (2, 2)])
+    act, use_res, give_y = rng.choice([0, 1, 2]), rng.random() < 0.6, rng.random() < 0.5
+    keys = {12: rng.choice([0, 1]), 18: rng.choice([0, 256]), 21: rng.choice([0, 1]), 40: rng.choice([0, 1])}
+    HW, dt = H * W, tke._lib.dtype_code(torch.float32)
+    x, dy = torch.randn(N, C, H, W) * 1.5 + 0.7, torch.randn(N, C, H, W)
+    res = torch.randn(N, C, H, W) if use_res else None
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.2
+    ps = (torch.rand(N) < 0.7).float() / 0.7
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if use_res else None
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5) * ps.view(N, 1, 1, 1)
+    if use_res:
+        z = z + rr
+    yr = {0: lambda t: t, 1: torch.relu, 2: F.silu}[act](z)
+    yr.backward(dy)
+    for k, v in keys.items():
+        assert E.cot_set_tuning(k, v) == 0
+    try:
+        y, mean, rstd = torch.full_like(x, float("nan")), torch.empty(C), torch.empty(C)
+        ws = torch.empty(E.cot_bn_act_workspace(N, C))
+        assert E.cot_bn_act_forward_ps(P(x), P(res), P(y), P(gamma), P(beta), P(mean), P(rstd), None, None, None, P(ws), P(ps),
+                                       N, C, HW, 1e-5, 0.1, act, dt, None) == 0
+        dx, dres = torch.full_like(x, float("nan")), (torch.full_like(x, float("nan")) if use_res else None)
+        dg, db = torch.empty(C), torch.empty(C)
+        need_y = act == 1 and use_res
+        rc = E.cot_bn_act_backward_ps(P(dy), P(x), P(y) if (need_y or give_y) else None, P(dx), P(dres), P(gamma), P(beta), P(mean),
+                                      P(rstd), P(dg), P(db), P(ws), P(ps), N, C, HW, act, dt, None)
+    finally:
+        E.cot_set_tuning(12, 1), E.cot_set_tuning(18, 256), E.cot_set_tuning(21, 1), E.cot_set_tuning(40, 1)
+    desc = ("bn ps", N, C, H, W, act, use_res, give_y, keys)
+    if act == 2:
+        return rc == -2 and ((y - yr.detach()).abs() <= 2e-5 * (1 + yr.detach().abs())).all().item(), desc
+    ok = rc == 0 and ((y - yr.detach()).abs() <= 2e-5 * (1 + yr.detach().abs())).all().item()
+    ok = ok and ((dx - xr.grad).abs() <= 2e-4 * (1 + xr.grad.abs().max())).all().item()
+    ok = ok and torch.allclose(dg, gr.grad, rtol=2e-3, atol=2e-3 * (1 + gr.grad.abs().max().item()))
+    ok = ok and torch.allclose(db, br.grad, rtol=2e-3, atol=2e-3 * (1 + br.grad.abs().max().item()))
+    if use_res:
+        ok = ok and ((dres - rr.grad).abs() <= 2e-4 * (1 + rr.grad.abs())).all().item()
+    return ok, desc
+
+
+def case_aggregation(rng):
+    """the operator itself (cupy_layers/aggregation_zeropad.py:20-110): random kernel / stride / padding / dilation (rectangular
+    too), heads, weight sharing, both layouts, fused and split backward, fp64 / fp32 / bf16 storage against the C oracle --
+    the k = 3 fast paths (LDS forward, dot2 backward at the widths it owns) and the generic kernels alike"""
+    from oracle import unfold_oracle
+    fast = rng.random() < 0.5
+    if fast:  # k3 s1 p1 d1, one head, C / wC = 8: the CoT layer's form, plane sizes around the tuned ones
+        k, s, p, d, heads = (3, 3), (1, 1), (1, 1), (1, 1), 1
+        wC = rng.choice([1, 2, 4, 8, 16])
+        C, H, W = 8 * wC, rng.randint(1, 30), rng.choice([1, 3, 7, 8, 14, 16, 20, 28, 31, 40, 56])
+    else:
+        k = (rng.choice([1, 3, 5, 7]), rng.choice([1, 3, 5]))
+        s, d = (rng.randint(1, 3), rng.randint(1, 3)), (rng.randint(1, 2), rng.randint(1, 2))
+        p = (rng.randint(0, 3), rng.randint(0, 3))
+        heads, wC = rng.randint(1, 2), rng.randint(1, 4)
+        C, H, W = wC * rng.randint(1, 4), rng.randint(1, 14), rng.randint(1, 14)
+    N = rng.randint(1, 2)
+    if (H + 2 * p[0] - d[0] * (k[0] - 1) - 1) < 0 or (W + 2 * p[1] - d[1] * (k[1] - 1) - 1) < 0:
+        return True, ("aggregation: empty output", k, s, p, d, H, W)
+    Ho, Wo = unfold_oracle.out_hw(H, W, k, s, p, d)
+    dtype = rng.choice([torch.float64, torch.float32, torch.bfloat16] + [torch.bfloat16] * (2 if fast else 0))
+    layout, fused = rng.choice([0, 0, 1]), rng.random() < 0.6
+    x = torch.randn(N, C, H, W, dtype=torch.float64).to(dtype)
+    w = torch.randn(N, heads, wC, k[0] * k[1], Ho, Wo, dtype=torch.float64).to(dtype)
+    g = torch.randn(N, heads * C, Ho, Wo, dtype=torch.float64).to(dtype)
+    y, gx, gw, fk, bk = tke.run(x, w, g, k, s, p, d, layout, fused)
+    oy, ogx, ogw = tke.oracle_all(x.double(), w.double(), g.double(), k, s, p, d)
+    taps = k[0] * k[1]
+    tol = {torch.float64: 1e-12, torch.float32: 2e-5, torch.bfloat16: 1.2e-2}[dtype]
+    def near(a, b, n):  # n terms of magnitude ~1 each
+        return ((a.double() - b).abs() <= tol * (n ** 0.5 + b.abs())).all().item()
+    ok = near(y, oy, taps) and near(gx, ogx, taps * heads) and near(gw, ogw, C // wC)
+    return ok, ("aggregation", N, C, H, W, heads, wC, k, s, p, d, str(dtype), layout, fused, fk, bk)
+
+
 CASES = [case_conv1x1, case_conv1x1, case_conv3x3, case_conv3x3_guarded, case_group_norm, case_pooling, case_subsample]
-CASES_R4 = [case_conv3x3_lds, case_conv3x3_lds, case_bn, case_bn, case_stem, case_pool2, case_conv1x1_stages, case_agg_gn9]
+CASES_R4 = [case_conv3x3_lds, case_conv3x3_lds, case_bn, case_bn, case_stem, case_pool2, case_conv1x1_stages, case_agg_gn9, case_bn_ps, case_aggregation, case_aggregation]
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
@@ -432,7 +513,7 @@ def test_random_shapes(seed):
 
 @pytest.mark.parametrize("seed", [41, 42])
 def test_random_shapes_round4_kernels(seed):
-    """(2880 further cases of this list ran clean offline in round 4; its first run found SiLU + residual: backward now refused)"""
+    """(4480 further cases of this list ran clean offline in round 4; its first run found SiLU + residual: backward now refused)"""
     rng = random.Random(seed)
     torch.manual_seed(seed)
     failures = []
