@@ -491,8 +491,74 @@ def case_aggregation(rng):
     return ok, ("aggregation", N, C, H, W, heads, wC, k, s, p, d, str(dtype), layout, fused, fk, bk)
 
 
+def case_conv_general(rng):
+    """conv_gen.hip and the routing around it: grouped 1x1 (any group width: tuned kernels group by group where they fit, the
+    general kernels otherwise) and grouped 3x3 at widths off the tuned grid (12 / 20 / 40 ... per group, odd channel counts in
+    fp32), fp32 and bf16, forward / data gradient (accumulate) / weight gradient (+ bias) against torch in fp64"""
+    dtype = rng.choice([torch.float32, torch.bfloat16])
+    dt = tke._lib.dtype_code(dtype)
+    atol, rtol = tke._tol(dtype)
+    G = rng.choice([1, 2, 3, 4, 8])
+    N, H, W = rng.randint(1, 3), rng.randint(1, 11), rng.randint(1, 11)
+    step = 1 if dtype == torch.float32 else 4
+    if rng.random() < 0.5:   # grouped 1x1
+        Ci, Co = G * step * rng.randint(1, 12), G * step * rng.randint(1, 12)
+        if rng.random() < 0.3 and dtype == torch.bfloat16:
+            Ci = G * 32 * rng.randint(1, 2)  # (the tuned kernels' grid)
+            Co = G * 8 * rng.randint(1, 6)
+        HW, bias, acc = H * W, rng.random() < 0.5, rng.choice([0, 1])
+        x, gy = torch.randn(N, Ci, H, W).to(dtype), torch.randn(N, Co, H, W).to(dtype)
+        w = (torch.randn(Co, Ci // G) / (Ci // G) ** 0.5).to(dtype)
+        b = torch.randn(Co).to(dtype) if bias else None
+        xf, wf = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        bf = b.double().requires_grad_(True) if bias else None
+        yr = F.conv2d(xf, wf.view(Co, Ci // G, 1, 1), bf, 1, 0, 1, G)
+        yr.backward(gy.double())
+        y = torch.full((N, Co, H, W), float("nan")).to(dtype)
+        desc = ("general 1x1", N, Ci, Co, G, H, W, str(dtype), bias, acc)
+        rc = E.cot_conv1x1g_forward(P(x), P(w), P(b), P(y), N, Ci, Co, G, HW, dt, None)
+        if rc == -2:
+            return True, ("general 1x1: refused",) + desc[1:]
+        init = torch.randn(N, Ci, H, W).to(dtype)
+        gx = init.clone() if acc else torch.full_like(x, float("nan"))
+        ok = rc == 0 and E.cot_conv1x1g_backward_data(P(gy), P(w), P(gx), acc, N, Ci, Co, G, HW, dt, None) == 0
+        ws = torch.full((E.cot_convg_workspace(N, Ci, Co, G, HW, 1, 1) // 4,), float("nan"))
+        gw, gb = torch.full_like(w, float("nan")), (torch.full_like(b, float("nan")) if bias else None)
+        ok = ok and E.cot_conv1x1g_backward_weight(P(gy), P(x), P(gw), P(gb), P(ws), N, Ci, Co, G, HW, dt, None) == 0
+        want = xf.grad + (init.double() if acc else 0)
+        ok = ok and torch.allclose(y.double(), yr.detach(), atol=4 * atol, rtol=rtol)
+        ok = ok and torch.allclose(gx.double(), want, atol=8 * atol, rtol=2 * rtol)
+        ok = ok and (gw.double() - wf.grad.view(Co, Ci // G)).abs().max().item() <= rtol * wf.grad.abs().max().item() + atol
+        if bias:
+            ok = ok and (gb.double() - bf.grad).abs().max().item() <= rtol * bf.grad.abs().max().item() + atol
+        return ok, desc
+    C = G * step * rng.randint(1, 10)
+    x, gy = torch.randn(N, C, H, W).to(dtype), torch.randn(N, C, H, W).to(dtype)
+    w = (torch.randn(C, C // G, 3, 3) / (9 * C // G) ** 0.5).to(dtype)
+    xf, wf = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xf, wf, None, 1, 1, 1, G)
+    yr.backward(gy.double())
+    masks = torch.empty(E.cot_conv3x3g_masks_bytes(H, W), dtype=torch.uint8)
+    assert E.cot_conv3x3g_masks(P(masks), H, W, None) == 0
+    ws = torch.full((max(E.cot_conv3x3g_workspace(N, C, C, G, H, W), E.cot_convg_workspace(N, C, C, G, H, W, 3), 256) // 4,), float("nan"))
+    y, gw, acc = torch.full_like(x, float("nan")), torch.full_like(w, float("nan")), rng.choice([0, 1])
+    init = torch.randn(N, C, H, W).to(dtype)
+    gx = init.clone() if acc else torch.full_like(x, float("nan"))
+    desc = ("general 3x3", N, C, G, H, W, str(dtype), acc)
+    rc = E.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, C, C, G, H, W, dt, None)
+    if rc == -2:
+        return True, ("general 3x3: refused",) + desc[1:]
+    ok = rc == 0 and E.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), acc, P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
+    ok = ok and E.cot_conv3x3g_backward_weight(P(gy), P(x), P(gw), P(masks), P(ws), N, C, C, G, H, W, dt, None) == 0
+    want = xf.grad + (init.double() if acc else 0)
+    ok = ok and torch.allclose(y.double(), yr.detach(), atol=4 * atol, rtol=rtol)
+    ok = ok and torch.allclose(gx.double(), want, atol=8 * atol, rtol=2 * rtol)
+    ok = ok and (gw.double() - wf.grad).abs().max().item() <= rtol * wf.grad.abs().max().item() + atol
+    return ok, desc
+
+
 CASES = [case_conv1x1, case_conv1x1, case_conv3x3, case_conv3x3_guarded, case_group_norm, case_pooling, case_subsample]
-CASES_R4 = [case_conv3x3_lds, case_conv3x3_lds, case_bn, case_bn, case_stem, case_pool2, case_conv1x1_stages, case_agg_gn9, case_bn_ps, case_aggregation, case_aggregation]
+CASES_R4 = [case_conv3x3_lds, case_conv3x3_lds, case_bn, case_bn, case_stem, case_pool2, case_conv1x1_stages, case_agg_gn9, case_bn_ps, case_aggregation, case_aggregation, case_conv_general, case_conv_general]
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
