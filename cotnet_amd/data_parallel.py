@@ -147,6 +147,12 @@ class GradBucketReducer:
     # ------------------------------------------------------------------------------------------
     def _on_grad_ready(self, param):
         b = self._bucket_of[param]
+        if b.pending <= 0 and (self.grad_mode == "copy" or (self.enabled and not self.defer_comm)):
+            # a second backward pass before finish(): the bucket is already filled / its all-reduce in flight, so one micro-batch
+            # would be overwritten (copy mode) or left out of the average.  The reference runs one backward per step
+            # (train.py:264-274); a single process in view mode may accumulate (nothing was launched)
+            raise RuntimeError("GradBucketReducer: a gradient arrived after its bucket was handed over -- call finish() once per "
+                               "backward()")
         if self.grad_mode == "copy":
             b.fired.add(param)
             b.pending -= 1

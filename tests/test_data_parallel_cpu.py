@@ -165,6 +165,33 @@ def test_single_process_is_a_noop_with_flat_buckets():
     assert red.buckets[0].flat.abs().sum() == 0 and all(p.grad is not None for p in model.parameters())
 
 
+def test_a_second_backward_before_finish_is_refused_where_it_would_lose_a_gradient():
+    """copy mode hands the gradients over when a bucket's last one arrives: a second backward() before finish() would overwrite
+    them, so the hook raises; a single process in view mode accumulates in place as autograd does"""
+    torch.manual_seed(3)
+    x, t = torch.randn(4, 3, 6, 6), torch.randint(0, 4, (4,))
+    model = _net()
+    red = GradBucketReducer(model, grad_mode="copy", broadcast_params=False)
+    red.zero_grad()
+    nn.functional.cross_entropy(model(x), t).backward()
+    with pytest.raises(RuntimeError, match="once per"):
+        nn.functional.cross_entropy(model(x), t).backward()
+    red.finish()
+    red.zero_grad()
+    nn.functional.cross_entropy(model(x), t).backward()   # the next step is unaffected
+    red.finish()
+    red.remove()
+    model = _net()
+    red = GradBucketReducer(model, grad_mode="view", broadcast_params=False)
+    red.zero_grad()
+    nn.functional.cross_entropy(model(x), t).backward()
+    once = [p.grad.clone() for p in model.parameters()]
+    nn.functional.cross_entropy(model(x), t).backward()
+    red.finish()
+    for p, g in zip(model.parameters(), once):
+        assert torch.allclose(p.grad, 2 * g, atol=1e-6)
+
+
 def test_grad_sink_lets_a_producer_write_its_bucket_slot():
     """cotnet_amd.grad_sink: a custom backward that writes a parameter's gradient straight into the flat bucket (what the
     single-node layers do on the GPU) -- autograd adopts the alias, the bucket fill skips the copy, values are right; a
