@@ -281,3 +281,33 @@ def test_window_softmax_composes_when_not_fusable():
     y = aggregation_zeropad_softmax(x.to(DEV), logits.to(DEV), 5, 1, 2, 1)   # 5x5, heads=2, fp64: composed path
     want = cref.forward(x, torch.softmax(logits, dim=3), 5, 1, 2, 1)
     assert (y.cpu() - want).abs().max() < 1e-9
+
+
+def test_tensors_beyond_2_31_elements_index_correctly():
+    """maximum sizes: N*C*H*W = 2.16e9 > 2^31 elements in every tensor (the reference's kernels index with `int`,
+    cupy_layers/aggregation_zeropad.py:24-29, and would wrap here; a 288 GB device holds such a batch many times over).  Offsets
+    past 2^31 are where the LAST images live: the first and the last images of the big batch must equal the same images run as
+    a batch of their own, forward and both gradients (a wrapped offset reads another image: O(1) error)"""
+    N, C, H, W = 10752, 64, 56, 56
+    assert N * C * H * W > 2 ** 31
+    free, _ = torch.cuda.mem_get_info()
+    if free < 48e9:
+        pytest.skip("needs ~30 GB of device memory")
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(N, C, H, W, device=DEV, dtype=torch.bfloat16, generator=g).requires_grad_(True)
+    w = torch.randn(N, 1, C // 8, 9, H, W, device=DEV, dtype=torch.bfloat16, generator=g).requires_grad_(True)
+    gy = torch.randn(N, C, H, W, device=DEV, dtype=torch.bfloat16, generator=g)
+    y = aggregation_zeropad(x, w, 3, 1, 1, 1)
+    fk = _lib.last_kernel()
+    y.backward(gy)
+    bk = _lib.last_kernel()
+    torch.cuda.synchronize()
+    assert fk.startswith("agg_fwd_nchw_k3") and bk.startswith("agg_bwd_nchw_k3"), (fk, bk)
+    for sl in (slice(0, 3), slice(N - 3, N)):
+        xs, ws = x.detach()[sl].clone().requires_grad_(True), w.detach()[sl].clone().requires_grad_(True)
+        ys = aggregation_zeropad(xs, ws, 3, 1, 1, 1)
+        ys.backward(gy[sl].clone())
+        torch.cuda.synchronize()
+        for got, want in ((y.detach()[sl], ys.detach()), (x.grad[sl], xs.grad), (w.grad[sl], ws.grad)):
+            want = want.float()
+            assert (got.float() - want).abs().max().item() <= 2e-2 * want.abs().max().item(), (sl, fk, bk)
