@@ -86,3 +86,36 @@ def test_fused_batchnorm_beyond_2_31_elements():
     gz = dy.float() * (y.detach() > 0)
     assert torch.allclose(bn.bias.grad, gz.sum((0, 2, 3)), rtol=1e-3, atol=1.0)
     assert torch.allclose(bn.weight.grad, (gz * xhat).sum((0, 2, 3)), rtol=1e-3, atol=1.0)
+
+
+def test_grouped_conv3x3_beyond_2_31_elements(monkeypatch):
+    """CotLayer.key_embed's convolution (64 channels, 4 groups, 56 x 56) on the same batch: last images against torch on the slice,
+    weight gradient against the sum over two halves"""
+    from cotnet_amd import conv3x3g as c3
+    _room(60)
+    monkeypatch.setattr(c3, "MODE", "hip")
+    g = torch.Generator(device=DEV).manual_seed(7)
+    conv = nn.Conv2d(C, C, 3, padding=1, groups=4, bias=False).to(DEV).bfloat16()
+    x = torch.randn(N, C, H, H, device=DEV, dtype=torch.bfloat16, generator=g).requires_grad_(True)
+    gy = torch.randn(N, C, H, H, device=DEV, dtype=torch.bfloat16, generator=g)
+    assert c3.eligible(conv, x)
+    y = c3.conv3x3(conv, x)
+    assert "Conv3x3G" in type(y.grad_fn).__name__
+    y.backward(gy)
+    torch.cuda.synchronize()
+    wf = conv.weight.detach().float()
+    for sl in (slice(0, 2), slice(N - 2, N)):
+        xs = x.detach()[sl].float().requires_grad_(True)
+        ys = F.conv2d(xs, wf, None, 1, 1, 1, 4)
+        ys.backward(gy[sl].float())
+        assert _near(y.detach()[sl], ys.detach()), sl
+        assert _near(x.grad[sl], xs.grad), sl
+    gw_full = conv.weight.grad.detach().float().clone()
+    gw_sum = torch.zeros_like(gw_full)
+    for sl in (slice(0, N // 2), slice(N // 2, N)):
+        conv.weight.grad = None
+        xs = x.detach()[sl].requires_grad_(True)
+        c3.conv3x3(conv, xs).backward(gy[sl])
+        gw_sum += conv.weight.grad.detach().float()
+    torch.cuda.synchronize()
+    assert _near(gw_full, gw_sum), (gw_full - gw_sum).abs().max().item()
