@@ -5,7 +5,7 @@ padding=1)` (the "avd" pooling of stride-2 bottlenecks, models/cotnet.py:216) wi
 memory speed -- torch's max_pool_backward / avg_pool2d_backward were 436 us and 3 x 163 us of the round-1 step for ~30 us of
 traffic each; the max-pool forward keeps the arg-max as one byte per window (torch's tie rule) and the backward reads that instead
 of an int64 index tensor (or x).
-Also `nn.AvgPool2d(2, 2)` on even planes (the pooling of an `avg_down` shortcut, models/resnet.py:377-394).
+Also `nn.AvgPool2d(2, 2)` on even planes (the pooling of an `avg_down` shortcut, models/resnet.py:380-394).
 Any other module or tensor (other geometry, ceil_mode, fp64, channels-last, CPU) takes the module itself.
 """
 import ctypes
@@ -58,7 +58,7 @@ class _AvgPool(Function):
 
 
 class _AvgPool2(Function):
-    """nn.AvgPool2d(2, 2) on even planes (downsample_avg's pooling, models/resnet.py:377-394)"""
+    """nn.AvgPool2d(2, 2) on even planes (downsample_avg's pooling, models/resnet.py:380-394)"""
     @staticmethod
     def forward(ctx, x):
         N, C, H, W = x.shape

@@ -358,7 +358,7 @@ int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, 
 int cot_subsample2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);
 int cot_subsample2_backward(const void* gy, void* gx, int64_t planes, int H, int W, int dtype, void* stream);
 /*   cot_avgpool2x2s2_*  nn.AvgPool2d(2, 2) on even H, W: the pooling in front of the 1x1 projection of an `avg_down` shortcut
- *                       (models/resnet.py:377-394 downsample_avg, used by cotnet_hybrid.py's SE-CoTNetD; with even planes its
+ *                       (models/resnet.py:380-394 downsample_avg, used by cotnet_hybrid.py's SE-CoTNetD; with even planes its
  *                       ceil_mode / count_include_pad flags change nothing).  y [planes][H/2][W/2]; backward writes every element
  *                       of gx [planes][H][W] (= gy / 4 under its window).  COT_F32 / COT_BF16; odd H or W: COT_ERR_UNSUPPORTED. */
 int cot_avgpool2x2s2_forward(const void* x, void* y, int64_t planes, int H, int W, int dtype, void* stream);

@@ -2454,7 +2454,7 @@ def test_blurpool_kernels_match_the_reference_formula(N, C, H, W, dtype):
 @pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 2, 16, 16), (2, 1, 20, 20), (1, 3, 6, 10), (1, 2, 2, 2), (1, 1, 4, 24), (1, 5, 2, 6)])
 def test_avgpool2x2_kernels_match_the_module(N, C, H, W, dtype, monkeypatch):
     """cot_avgpool2x2s2_* against nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False) -- downsample_avg's pooling
-    (models/resnet.py:377-394) -- bit for bit (same sum order, one division), every element of the gradient written; odd
+    (models/resnet.py:380-394) -- bit for bit (same sum order, one division), every element of the gradient written; odd
     planes are refused; `pool()` / `run_downsample` route the module onto the kernel"""
     from cotnet_amd import conv1x1 as c1, pool3x3 as p3
     torch.manual_seed(53)

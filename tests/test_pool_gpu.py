@@ -71,7 +71,7 @@ def test_blur_pool_matches_the_reference_formula(N, C, H, dtype, monkeypatch):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,C,H", [(64, 256, 80), (64, 512, 40), (64, 1024, 20), (3, 5, 6), (2, 3, 2)])
 def test_avgpool2x2_of_the_avg_down_shortcut_is_exact(N, C, H, dtype, monkeypatch):
-    """nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False) of downsample_avg (models/resnet.py:377-394) at the tensor
+    """nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False) of downsample_avg (models/resnet.py:380-394) at the tensor
     sizes of se_cotnetd_152_L at 320 x 320, B = 64: `pool()` takes the library's kernel, forward and gradient equal torch's
     bit for bit"""
     torch.manual_seed(H)
