@@ -2661,3 +2661,21 @@ def test_bn_inference_kernel(N, C, H, W, act, use_res, dtype):
     assert rc == 0, _EMUL.cot_last_error()
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert ((y.float() - yr).abs() <= tol * (1 + yr.abs())).all()
+
+
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("M,Nn,K,tm", [(300, 128, 64, 0), (200, 256, 96, 64), (129, 128, 32, 128), (515, 256, 256, 128), (1, 128, 32, 0)])
+def test_k_contiguous_study_gemm(M, Nn, K, tm, dma, request):
+    """csrc/gemm_kc.hip (layout study; on no model's path): Y[M][Nn] = X[M][K] * Wt[Nn][K]^T on the four-stage LDS-DMA
+    ring with swizzled slots, both landing times of the copies, partial row tiles, K of one to eight steps; what it does not
+    cover is refused"""
+    torch.manual_seed(M + K)
+    x, w = torch.randn(M, K).bfloat16(), (torch.randn(Nn, K) / K ** 0.5).bfloat16()
+    y = torch.full((M, Nn), float("nan")).bfloat16()
+    _EMUL.emul_set_dma_mode(dma)
+    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
+    assert _EMUL.cot_study_gemm_kc(P(x), P(w), P(y), M, Nn, K, tm, None) == 0
+    ref = x.float() @ w.float().t()
+    assert (y.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert _EMUL.cot_study_gemm_kc(P(x), P(w), P(y), M, Nn, K + 8, tm, None) == -2   # K off the 32-channel step
+    assert _EMUL.cot_study_gemm_kc(P(x), P(w), P(y), M, Nn + 64, K, tm, None) == -2  # output channels off the 128-column tile
