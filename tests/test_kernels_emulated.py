@@ -2679,3 +2679,27 @@ def test_k_contiguous_study_gemm(M, Nn, K, tm, dma, request):
     assert (y.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
     assert _EMUL.cot_study_gemm_kc(P(x), P(w), P(y), M, Nn, K + 8, tm, None) == -2   # K off the 32-channel step
     assert _EMUL.cot_study_gemm_kc(P(x), P(w), P(y), M, Nn + 64, K, tm, None) == -2  # output channels off the 128-column tile
+
+
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("M,K,k1,Nn,bias,acc,tm", [(98, 512, 256, 128, False, 0, 0),   # embed[0] on [x | k] at 7 x 7, two images
+                                                   (392, 128, 128, 288, True, 0, 64),   # embed[3]: bias, 9 * C / 8 outputs
+                                                   (200, 96, 32, 36, True, 1, 128),     # two slabs + bias + accumulate, one partial tile
+                                                   (130, 256, 256, 260, False, 1, 0)])  # three column tiles, the last 4 wide
+def test_k_contiguous_conv1x1_form(M, K, k1, Nn, bias, acc, tm, dma, request):
+    """the same kernel with what the CoT block's 1x1 convolutions need in a channels-last layout (cot_study_conv1x1_nhwc): the input
+    as two channel slabs (no cat), bias, accumulation into the output, output widths that are multiples of 4"""
+    torch.manual_seed(M + Nn)
+    x, w = torch.randn(M, K).bfloat16(), (torch.randn(Nn, K) / K ** 0.5).bfloat16()
+    b = torch.randn(Nn).bfloat16() if bias else None
+    x1, x2 = x[:, :k1].contiguous(), (x[:, k1:].contiguous() if k1 < K else None)
+    init = torch.randn(M, Nn).bfloat16()
+    y = init.clone() if acc else torch.full((M, Nn), float("nan")).bfloat16()
+    _EMUL.emul_set_dma_mode(dma)
+    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
+    none = ctypes.c_void_p(None)
+    assert _EMUL.cot_study_conv1x1_nhwc(P(x1), P(x2) if x2 is not None else none, k1, P(w), P(b) if bias else none, P(y), acc, M, Nn, K,
+                                        tm, None) == 0
+    ref = x.float() @ w.float().t() + (b.float() if bias else 0) + (init.float() if acc else 0)
+    assert (y.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert _EMUL.cot_study_conv1x1_nhwc(P(x1), none, k1, P(w), none, P(y), 0, M, Nn + 2, K, tm, None) == -2   # width off the 4-channel store
