@@ -164,3 +164,170 @@ extern "C" int cot_study_conv1x1_nhwc(const void* x1, const void* x2, int k1, co
                                       int M, int Nn, int K, int tm, void* stream) {
     return cot::gemm_kc_forward(x1, x2, k1, wt, bias, y, accumulate, M, Nn, K, tm, (hipStream_t)stream);
 }
+
+namespace cot {
+
+// ---- weight gradient of the same convolution, channels-last:  dW[Co][Ci] = sum over m of dY[m][co] * X[m][ci] ---------------------
+// Here the reduction index (the pixel m) is the OUTER index of both operands, so the fragments (8 consecutive m of one channel) are
+// columns of the staged tiles: two ds_read_b64_tr_b16 each.  A stage holds 32 rows x 128 channels of X and of dY (rows of 256
+// bytes = 16 chunks; a copy instruction moves 4 rows); lane (row, slot c) fetches chunk c ^ s(row), s(row) = 2 * ((row & 3) |
+// ((row >> 3) & 1) << 2): the sixteen 32-byte windows a transposing read of one wave touches then cover the 64 banks exactly twice.
+// X is the MFMA's A operand: a lane's four accumulators are four consecutive ci of one co -- a 16-byte store into the fp32 partial
+// sums part[slice][Co][Ci]; the reduction over pixels is split into `slices` ranges of 32-row steps, one workgroup each, and
+// gemm_kc_wgrad_reduce adds the slices in order and rounds once (deterministic, no atomics).  Channel tiles past Ci / Co clamp
+// their chunks (those products are never stored); rows past M in the very last step are cleared in LDS by the lanes that copied them.
+__device__ __forceinline__ int kc_swz(int row) { return (((row & 3) | (((row >> 3) & 1) << 2)) << 1); }
+
+__global__ __launch_bounds__(256) void gemm_kc_wgrad(const bf16_t* __restrict__ X, const bf16_t* __restrict__ dY,
+                                                    float* __restrict__ part, int M, int Ci, int Co, int tci, int tco, int slices) {
+    constexpr int NS = 4, TB = 32 * 256, ST = 2 * TB, G = 4;  // tile bytes, stage bytes, copies per wave and stage
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = blockIdx.x % slices, tile = blockIdx.x / slices;
+    const int ti = tile % tci, to = tile / tci;
+    const int ci0 = ti * 128, co0 = to * 128;
+    const int KT = ceil_div(M, 32);
+    const int k0 = (int)((int64_t)KT * sl / slices), k1 = (int)((int64_t)KT * (sl + 1) / slices);
+
+    // copy sources: instruction q (0, 1) of this wave = rows 8 * wave + 4 * q .. + 3 of the stage, slot (lane & 15)
+    const bf16_t* xs[2];
+    const bf16_t* ys[2];
+    int crow[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        crow[q] = 8 * wave + 4 * q + (lane >> 4);
+        const int gc = (lane & 15) ^ kc_swz(crow[q]);
+        int cx = ci0 + gc * 8, cy = co0 + gc * 8;
+        cx = cx < Ci ? cx : Ci - 8;
+        cy = cy < Co ? cy : Co - 8;
+        xs[q] = X + cx;
+        ys[q] = dY + cy;
+    }
+    auto issue = [&](int stage, int kt) {
+        char* base = cot_smem + stage * ST;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int m = kt * 32 + crow[q];
+            m = m < M ? m : M - 1;  // (cleared after it has landed: see below)
+            COT_GLDS16(xs[q] + (int64_t)m * Ci, base + (8 * wave + 4 * q) * 256);
+            COT_GLDS16(ys[q] + (int64_t)m * Co, base + TB + (8 * wave + 4 * q) * 256);
+        }
+    };
+
+    // fragment addresses: 16-lane group g reads rows 8g .. 8g+7 (two transposing reads of 4 rows) of a 16-channel block
+    const int wm = wave >> 1, wn = wave & 1;  // ci half, co half of the 128 x 128 tile
+    const int g = lane >> 4, L = lane & 15;
+    const int frow = 8 * g + (L >> 2);
+    const int fsw = kc_swz(frow);  // (the same for frow + 4)
+    int xo[4], yo[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int cxk = wm * 8 + b * 2 + ((L & 3) >> 1), cyk = wn * 8 + b * 2 + ((L & 3) >> 1);
+        xo[b] = frow * 256 + ((cxk ^ fsw) << 4) + (L & 1) * 8;
+        yo[b] = TB + frow * 256 + ((cyk ^ fsw) << 4) + (L & 1) * 8;
+    }
+
+    f32x4_t acc[4][4];  // [co block][ci block]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int steps = k1 - k0;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < steps) issue(s, k0 + s);
+    for (int t = 0; t < steps; ++t) {
+        const int left = steps - 1 - t;
+        WaitBehind<G, NS - 2>::go(left < NS - 2 ? left : NS - 2);
+        char* st = cot_smem + (t % NS) * ST;
+        if ((k0 + t) * 32 + 32 > M) {  // the last step of the tensor: rows past M hold a copy of row M - 1 -- clear this lane's pieces
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if ((k0 + t) * 32 + crow[q] >= M) {
+                    *reinterpret_cast<f32x4_t*>(st + (8 * wave + 4 * q) * 256 + lane * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4_t*>(st + TB + (8 * wave + 4 * q) * 256 + lane * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        COT_LDS_BARRIER();
+        if (t + NS - 1 < steps) issue((t + NS - 1) % NS, k0 + t + NS - 1);
+        bf16x8_t xf[4], yf[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            s16x4_t lo = COT_LDS_READ_TR16(st + xo[b]), hi = COT_LDS_READ_TR16(st + xo[b] + 4 * 256);
+            __builtin_memcpy(&xf[b], &lo, 8);
+            __builtin_memcpy(reinterpret_cast<char*>(&xf[b]) + 8, &hi, 8);
+            lo = COT_LDS_READ_TR16(st + yo[b]);
+            hi = COT_LDS_READ_TR16(st + yo[b] + 4 * 256);
+            __builtin_memcpy(&yf[b], &lo, 8);
+            __builtin_memcpy(reinterpret_cast<char*>(&yf[b]) + 8, &hi, 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = COT_MFMA_16X16X32_BF16(xf[i], yf[j], acc[j][i]);
+    }
+
+    // D[i = 4 * (lane >> 4) + e][j = lane & 15]: i = ci inside its 16-block, j = co
+    float* pp = part + (int64_t)sl * Co * Ci;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + wn * 64 + j * 16 + L;
+        if (co < Co) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ci = ci0 + wm * 64 + i * 16 + 4 * g;
+                if (ci < Ci)  // (Ci % 8 == 0: four channels inside or outside together)
+                    *reinterpret_cast<f32x4_t*>(pp + (int64_t)co * Ci + ci) = acc[j][i];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_kc_wgrad_reduce(const float* __restrict__ part, bf16_t* __restrict__ dW, int64_t n4, int slices) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4_t s = *reinterpret_cast<const f32x4_t*>(part + 4 * i);
+    for (int k = 1; k < slices; ++k) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(part + (int64_t)k * 4 * n4 + 4 * i);
+        s += v;
+    }
+    Vec<bf16_t, 4> o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)s[e];
+    stv<bf16_t, 4>(dW + 4 * i, o);
+}
+
+// slices of the reduction: enough workgroups for two per CU, at least four 32-row steps each (0 = choose; > 0 = forced, tests)
+static int gemm_kc_wgrad_slices(int M, int Ci, int Co, int forced) {
+    const int KT = ceil_div(M, 32), tiles = ceil_div(Ci, 128) * ceil_div(Co, 128);
+    int s = forced > 0 ? forced : ceil_div(512, tiles);
+    if (forced <= 0 && s > KT / 4) s = KT / 4;
+    if (s > KT) s = KT;
+    return s < 1 ? 1 : s;
+}
+size_t gemm_kc_wgrad_workspace(int M, int Ci, int Co, int forced) {
+    return (size_t)gemm_kc_wgrad_slices(M, Ci, Co, forced) * Co * Ci * sizeof(float);
+}
+int gemm_kc_wgrad_run(const void* x, const void* dy, void* dw, void* workspace, int M, int Ci, int Co, int forced, hipStream_t s) {
+    if (!x || !dy || !dw || !workspace || M <= 0 || Ci <= 0 || Co <= 0) return -1;
+    if (Ci % 8 || Co % 8 || ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace) % 16) return -2;
+    const int slices = gemm_kc_wgrad_slices(M, Ci, Co, forced), tci = ceil_div(Ci, 128), tco = ceil_div(Co, 128);
+    const int64_t blocks = (int64_t)tci * tco * slices;
+    if (blocks >= ((int64_t)1 << 31)) return -2;
+    COT_LAUNCH(gemm_kc_wgrad, dim3((unsigned)blocks), dim3(256), 4 * 2 * 32 * 256, s, (const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, M,
+               Ci, Co, tci, tco, slices);
+    const int64_t n4 = (int64_t)Co * Ci / 4;
+    COT_LAUNCH(gemm_kc_wgrad_reduce, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, (const float*)workspace, (bf16_t*)dw, n4, slices);
+    return check_launch("gemm_kc_wgrad");
+}
+
+}  // namespace cot
+
+extern "C" size_t cot_study_conv1x1_nhwc_wgrad_workspace(int M, int Ci, int Co, int slices) {
+    return cot::gemm_kc_wgrad_workspace(M, Ci, Co, slices);
+}
+extern "C" int cot_study_conv1x1_nhwc_wgrad(const void* x, const void* dy, void* dw, void* workspace, int M, int Ci, int Co, int slices,
+                                            void* stream) {
+    return cot::gemm_kc_wgrad_run(x, dy, dw, workspace, M, Ci, Co, slices, (hipStream_t)stream);
+}

@@ -53,3 +53,25 @@ for N, HW, K, Nn in [(80, 196, 1024, 256), (80, 196, 256, 1024), (80, 49, 2048, 
     tn = timed(lambda: L.cot_conv1x1_forward(P(xn), None, K, P(w), None, P(yn), N, K, Nn, HW, 2, stream))
     best = min(ts)
     print(f"{K:5d} -> {Nn:5d}  HW {HW:4d}       {ts[0]:10.1f} / {ts[1]:8.1f} us {tv:13.1f} us {tn:7.1f} us   {2.0 * M * K * Nn / best / 1e6:7.0f}   {err:.3f}")
+
+
+# weight gradient, channels-last (gemm_kc_wgrad + reduce) beside the NCHW kernel's (cot_conv1x1_backward_weight)
+L.cot_study_conv1x1_nhwc_wgrad_workspace.restype = ctypes.c_size_t
+L.cot_conv1x1_workspace.restype = ctypes.c_size_t
+print(f"\n{'weight gradient (N80)':28s} {'own K-contig':>14s} {'own NCHW':>10s}   max|err| / max|ref|")
+for N, HW, K, Nn in [(80, 196, 1024, 256), (80, 196, 256, 1024), (80, 49, 2048, 512), (80, 49, 512, 2048), (80, 196, 256, 256), (80, 49, 512, 512)]:
+    M = N * HW
+    x = torch.randn(M, K, device=dev).bfloat16()
+    dy = torch.randn(M, Nn, device=dev).bfloat16()
+    dw = torch.empty(Nn, K, device=dev, dtype=torch.bfloat16)
+    ws = torch.empty(L.cot_study_conv1x1_nhwc_wgrad_workspace(M, K, Nn, 0), device=dev, dtype=torch.uint8)
+    assert L.cot_study_conv1x1_nhwc_wgrad(P(x), P(dy), P(dw), P(ws), M, K, Nn, 0, stream) == 0
+    torch.cuda.synchronize()
+    ref = dy.float().t() @ x.float()
+    err = (dw.float() - ref).abs().max().item() / ref.abs().max().item()
+    tk = timed(lambda: L.cot_study_conv1x1_nhwc_wgrad(P(x), P(dy), P(dw), P(ws), M, K, Nn, 0, stream))
+    xn = torch.randn(N, K, HW, device=dev).bfloat16()
+    gn = torch.randn(N, Nn, HW, device=dev).bfloat16()
+    wsn = torch.empty(max(L.cot_conv1x1_workspace(N, K, Nn, HW, 0), 256), device=dev, dtype=torch.uint8)
+    tn = timed(lambda: L.cot_conv1x1_backward_weight(P(gn), P(xn), None, K, P(dw), None, P(wsn), N, K, Nn, HW, 2, stream))
+    print(f"{K:5d} -> {Nn:5d}  HW {HW:4d}       {tk:11.1f} us {tn:7.1f} us   {err:.4f}")

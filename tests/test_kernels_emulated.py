@@ -2703,3 +2703,27 @@ def test_k_contiguous_conv1x1_form(M, K, k1, Nn, bias, acc, tm, dma, request):
     ref = x.float() @ w.float().t() + (b.float() if bias else 0) + (init.float() if acc else 0)
     assert (y.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
     assert _EMUL.cot_study_conv1x1_nhwc(P(x1), none, k1, P(w), none, P(y), 0, M, Nn + 2, K, tm, None) == -2   # width off the 4-channel store
+
+
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("M,Ci,Co,slices", [(392, 256, 128, 0),   # 14 x 14, two images: 12 whole steps + 8 rows, chosen slices
+                                            (98, 128, 288, 2),    # 7 x 7: a partial last step; Co = 9 * C / 8 (three column tiles)
+                                            (33, 40, 72, 1),      # channel tiles of 40 / 72: clamped chunks; one row in the last step
+                                            (500, 136, 8, 7),     # more slices than a slice has steps for
+                                            (1, 8, 8, 0)])
+def test_k_contiguous_weight_gradient(M, Ci, Co, slices, dma, request):
+    """csrc/gemm_kc.hip, channels-last weight gradient dW[Co][Ci] = sum_m dY[m][co] X[m][ci] (study kernel): staged rows
+    read as columns by transposing LDS reads through the slot swizzle, rows past M cleared in LDS, channel tiles past the tensor
+    clamped, slices of the pixel range summed in order by the reduce kernel"""
+    _EMUL.cot_study_conv1x1_nhwc_wgrad_workspace.restype = ctypes.c_size_t
+    torch.manual_seed(M + Ci)
+    x, dy = torch.randn(M, Ci).bfloat16(), torch.randn(M, Co).bfloat16()
+    nb = _EMUL.cot_study_conv1x1_nhwc_wgrad_workspace(M, Ci, Co, slices)
+    assert nb >= Co * Ci * 4 and nb % (Co * Ci * 4) == 0
+    ws, dw = torch.full((nb // 4,), float("nan")), torch.full((Co, Ci), float("nan")).bfloat16()
+    _EMUL.emul_set_dma_mode(dma)
+    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
+    assert _EMUL.cot_study_conv1x1_nhwc_wgrad(P(x), P(dy), P(dw), P(ws), M, Ci, Co, slices, None) == 0
+    ref = dy.float().t() @ x.float()
+    assert (dw.float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-2
+    assert _EMUL.cot_study_conv1x1_nhwc_wgrad(P(x), P(dy), P(dw), P(ws), M, Ci + 4, Co, slices, None) == -2
