@@ -2727,3 +2727,56 @@ def test_k_contiguous_weight_gradient(M, Ci, Co, slices, dma, request):
     ref = dy.float().t() @ x.float()
     assert (dw.float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-2
     assert _EMUL.cot_study_conv1x1_nhwc_wgrad(P(x), P(dy), P(dw), P(ws), M, Ci + 4, Co, slices, None) == -2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act,use_res,give_y", [(0, False, False), (1, False, False), (1, False, True), (1, True, True), (2, False, False), (0, True, False)])
+@pytest.mark.parametrize("M,C", [(392, 256), (98, 512), (300, 64), (5, 8), (1000, 32)])
+def test_batchnorm_channels_last_study_kernels(M, C, act, use_res, give_y, dtype):
+    """csrc/bn_nhwc.hip (study kernels for the channels-last route): training-mode BatchNorm + activation + residual on
+    x[M][C] -- column reductions over row slabs merged by bn_act.hip's finalize kernels, flat apply kernels -- forward, running
+    statistics and every gradient against torch on the same values viewed as [1, C, M, 1]"""
+    F = torch.nn.functional
+    dt = _lib.dtype_code(dtype)
+    if dtype == torch.float32 and C % 4:
+        pytest.skip("fp32: 4 channels per access")
+    g = torch.Generator().manual_seed(M + C + act)
+    x = (torch.randn(M, C, generator=g) * 1.5 + 0.7).to(dtype)
+    res = torch.randn(M, C, generator=g).to(dtype) if use_res else None
+    dy = torch.randn(M, C, generator=g).to(dtype)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    xr = x.float().requires_grad_(True)
+    rr = res.float().requires_grad_(True) if use_res else None
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(xr.t().reshape(1, C, M, 1), rm_ref, rv_ref, gr, br, True, 0.1, 1e-5).reshape(C, M).t()
+    if use_res:
+        z = z + rr
+    yr = {0: lambda t: t, 1: torch.relu, 2: F.silu}[act](z)
+    yr.backward(dy.float())
+    nws = _EMUL.cot_study_bn_nhwc_workspace(M, C, dt)
+    assert nws > 0
+    ws, y = torch.full((nws,), float("nan")), torch.full_like(x, float("nan"))
+    mean, rstd, nbt = torch.empty(C), torch.empty(C), torch.tensor(3, dtype=torch.int64)
+    none = ctypes.c_void_p(None)
+    assert _EMUL.cot_study_bn_nhwc_forward(P(x), P(res) if use_res else none, P(y), P(gamma), P(beta), P(mean), P(rstd), P(rm), P(rv), P(nbt),
+                                           P(ws), M, C, ctypes.c_float(1e-5), ctypes.c_float(0.1), act, dt, None) == 0
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert int(nbt) == 4 and ((y.float() - yr.detach()).abs() <= tol * (1 + yr.detach().abs())).all()
+    assert torch.allclose(rm, rm_ref, atol=1e-5) and torch.allclose(rv, rv_ref, atol=1e-4, rtol=1e-4)
+    dx, dres = torch.full_like(x, float("nan")), (torch.full_like(x, float("nan")) if use_res else None)
+    dg, db = torch.empty(C), torch.empty(C)
+    assert _EMUL.cot_study_bn_nhwc_backward(P(dy), P(x), P(y) if give_y else none, P(dx), P(dres) if use_res else none, P(gamma), P(beta),
+                                            P(mean), P(rstd), P(dg), P(db), P(ws), M, C, act, dt, None) == 0
+    if not (act == 1 and dtype == torch.bfloat16):  # (bf16 ReLU masks come from the rounded output: checked in fp32)
+        gt = 2e-4 if dtype == torch.float32 else 3e-2
+        assert ((dx.float() - xr.grad).abs() <= gt * (1 + xr.grad.abs().max())).all()
+        assert torch.allclose(dg, gr.grad, rtol=gt * 10, atol=gt * 10 * (1 + gr.grad.abs().max().item()))
+        assert torch.allclose(db, br.grad, rtol=gt * 10, atol=gt * 10 * (1 + br.grad.abs().max().item()))
+        if use_res:
+            assert ((dres.float() - rr.grad).abs() <= gt * (1 + rr.grad.abs())).all()
+    assert _EMUL.cot_study_bn_nhwc_workspace(M, 24, dt) == 0   # 24 / 8 = 3 threads per row: not covered
+    if act == 2:
+        assert _EMUL.cot_study_bn_nhwc_backward(P(dy), P(x), none, P(dx), P(dx), P(gamma), P(beta), P(mean), P(rstd), P(dg), P(db), P(ws), M,
+                                                C, 2, dt, None) == -2
