@@ -331,3 +331,132 @@ extern "C" int cot_study_conv1x1_nhwc_wgrad(const void* x, const void* dy, void*
                                             void* stream) {
     return cot::gemm_kc_wgrad_run(x, dy, dw, workspace, M, Ci, Co, slices, (hipStream_t)stream);
 }
+
+namespace cot {
+
+// ---- grouped 3x3 convolution (stride 1, padding 1), channels-last: key_embed[0] of the CoT layer (models/cotnet.py:43-47) ------------
+//        Y[m][g * Mg + j] = sum over taps t, channels i of  X[m + shift(t)][g * Kc + i] * Wr[g * Mg + j][t][i]
+// With channels innermost this IS the kernel above: nine times the K steps, the weight rows repacked [Co][9][Kc] (so that the weight
+// side is a plain K-contiguous row of 9 * Kc), and on the activation side a lane's copy source moves to the shifted pixel's row for
+// each tap -- or, where the tap leaves the image, to a 16-byte block of zeros (`zeros`: any device buffer of >= 16 zero bytes), with
+// no stride along K.  A data gradient is the same call with the taps reversed and the per-group weights transposed by the caller's
+// repack.  TN = 64 when a group has 64 output channels (a column tile must not straddle groups).
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void conv3x3g_kc(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wr, const bf16_t* __restrict__ zeros,
+                                                  bf16_t* __restrict__ Y, int M, int H, int W, int C, int Kc, int Mg, int tiles_g,
+                                                  int accumulate) {
+    constexpr int NS = 4, MI = TM / 32, NJ = TN / 32;
+    constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, ST = A_BYTES + B_BYTES;
+    constexpr int CA = TM / 64, CB = TN / 64, G = CA + CB;  // copy instructions per wave and stage
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mt = blockIdx.x, nt = blockIdx.y;
+    const int grp = nt / tiles_g, n0 = grp * Mg + (nt - grp * tiles_g) * TN;
+    const int m0 = mt * TM, Co = (int)gridDim.y / tiles_g * Mg, KS = Kc / 32, K9 = 9 * Kc, KT = 9 * KS;
+
+    const int r = lane >> 2, kc = (lane & 3) ^ ((r >> 2) & 3);
+    int am[CA], ah[CA], aw[CA];
+    const bf16_t* bsrc[CB];
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+        int row = m0 + (wave * CA + q) * 16 + r;
+        row = row < M ? row : M - 1;
+        am[q] = row;
+        const int pix = row % (H * W);
+        ah[q] = pix / W;
+        aw[q] = pix - ah[q] * W;
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+        // TN = 64: the four waves copy 16 rows each (one instruction per wave); TN = 128: two instructions per wave
+        const int row = n0 + (wave * CB + q) * 16 + r;
+        bsrc[q] = Wr + (int64_t)row * K9 + kc * 8;
+    }
+    auto issue = [&](int stage, int kt) {
+        char* base = cot_smem + stage * ST;
+        const int tap = kt / KS, ks = kt - tap * KS;  // (wave-uniform)
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int q = 0; q < CA; ++q) {
+            const bool in = (unsigned)(ah[q] + dy) < (unsigned)H && (unsigned)(aw[q] + dx) < (unsigned)W;
+            const bf16_t* src = in ? X + (int64_t)(am[q] + dy * W + dx) * C + grp * Kc + ks * 32 + kc * 8 : zeros;
+            COT_GLDS16(src, base + (wave * CA + q) * 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < CB; ++q) COT_GLDS16(bsrc[q] + kt * 32, base + A_BYTES + (wave * CB + q) * 1024);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fslot = ((lane >> 4) ^ ((fr >> 2) & 3)) * 16;
+    const int xoff = (wm * (TM / 2) + fr) * 64 + fslot;
+    const int woff = A_BYTES + (wn * (TN / 2) + fr) * 64 + fslot;
+    f32x4_t acc[NJ][MI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < KT) issue(s, s);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int left = KT - 1 - kt;
+        WaitBehind<G, NS - 2>::go(left < NS - 2 ? left : NS - 2);
+        COT_LDS_BARRIER();
+        if (kt + NS - 1 < KT) issue((kt + NS - 1) % NS, kt + NS - 1);
+        const char* st = cot_smem + (kt % NS) * ST;
+        bf16x8_t xf[MI], wf[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(st + xoff + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(st + woff + j * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[j][i] = COT_MFMA_16X16X32_BF16(wf[j], xf[i], acc[j][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (TM / 2) + i * 16 + (lane & 15);
+        if (m < M) {
+            bf16_t* yp = Y + (int64_t)m * Co + n0 + wn * (TN / 2) + 4 * (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                Vec<bf16_t, 4> o, old;
+                if (accumulate) old = ldv<bf16_t, 4>(yp + j * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)(acc[j][i][e] + (accumulate ? (float)old.v[e] : 0.f));
+                stv<bf16_t, 4>(yp + j * 16, o);
+            }
+        }
+    }
+}
+
+// x [N*H*W][C], wr [C_out][9][Kc] (C_out = groups * Mg; Kc = C / groups), y [N*H*W][C_out]
+int conv3x3g_kc_forward(const void* x, const void* wr, const void* zeros, void* y, int accumulate, int N, int H, int W, int C, int Co,
+                        int groups, hipStream_t s) {
+    if (!x || !wr || !zeros || !y || N <= 0 || H <= 0 || W <= 0 || groups <= 0 || C % groups || Co % groups) return -1;
+    const int Kc = C / groups, Mg = Co / groups;
+    if (Kc % 32 || (Mg != 64 && Mg % 128) || ((uintptr_t)x | (uintptr_t)wr | (uintptr_t)zeros | (uintptr_t)y) % 16) return -2;
+    const int64_t M64 = (int64_t)N * H * W;
+    if (M64 * (C > Co ? C : Co) >= ((int64_t)1 << 31)) return -2;  // (32-bit row indices in the copy sources)
+    const int M = (int)M64, TN = Mg == 64 ? 64 : 128, tiles_g = Mg / TN;
+    const int TM = (int64_t)ceil_div(M, 128) * groups * tiles_g >= 256 ? 128 : 64;
+    const dim3 grid(ceil_div(M, TM), groups * tiles_g), block(256);
+#define C3KC(TM_, TN_)                                                                                                              \
+    COT_LAUNCH((conv3x3g_kc<TM_, TN_>), grid, block, 4 * (TM_ * 64 + TN_ * 64), s, (const bf16_t*)x, (const bf16_t*)wr, (const bf16_t*)zeros, \
+               (bf16_t*)y, M, H, W, C, Kc, Mg, tiles_g, accumulate)
+    if (TM == 128 && TN == 128) C3KC(128, 128);
+    else if (TM == 128) C3KC(128, 64);
+    else if (TN == 128) C3KC(64, 128);
+    else C3KC(64, 64);
+#undef C3KC
+    return check_launch("conv3x3g_kc");
+}
+
+}  // namespace cot
+
+extern "C" int cot_study_conv3x3g_nhwc(const void* x, const void* wr, const void* zeros, void* y, int accumulate, int N, int H, int W, int C,
+                                       int Co, int groups, void* stream) {
+    return cot::conv3x3g_kc_forward(x, wr, zeros, y, accumulate, N, H, W, C, Co, groups, (hipStream_t)stream);
+}

@@ -2780,3 +2780,42 @@ def test_batchnorm_channels_last_study_kernels(M, C, act, use_res, give_y, dtype
     if act == 2:
         assert _EMUL.cot_study_bn_nhwc_backward(P(dy), P(x), none, P(dx), P(dx), P(gamma), P(beta), P(mean), P(rstd), P(dg), P(db), P(ws), M,
                                                 C, 2, dt, None) == -2
+
+
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("N,H,W,G,Kc,acc", [(2, 7, 7, 4, 64, 0),    # CotLayer.key_embed at 7 x 7: 64 channels per group (64-column tiles)
+                                            (1, 14, 14, 2, 128, 1),  # 128 per group, accumulate
+                                            (3, 5, 9, 1, 64, 0),     # dense, non-square
+                                            (1, 1, 1, 4, 64, 0),     # one pixel: eight of nine taps outside
+                                            (2, 3, 2, 2, 32, 1)])    # 32 in / 64 out per group: one K step per tap
+def test_k_contiguous_grouped_conv3x3(N, H, W, G, Kc, acc, dma, request):
+    """csrc/gemm_kc.hip conv3x3g_kc (study kernel): the grouped 3x3 convolution of a channels-last activation as the
+    K-contiguous GEMM with nine times the K steps -- shifted source rows per tap, a block of zeros where the tap leaves the image,
+    weights repacked [Co][9][Kc] -- forward, and the data gradient as the same call on the flipped / transposed repack"""
+    F = torch.nn.functional
+    Mg = 64 if Kc != 128 else 128
+    C, Co = G * Kc, G * Mg
+    torch.manual_seed(H * W + Kc)
+    x = torch.randn(N, H, W, C).bfloat16()
+    w = (torch.randn(Co, Kc, 3, 3) / (9 * Kc) ** 0.5).bfloat16()
+    gy = torch.randn(N, H, W, Co).bfloat16()
+    xf, wf = x.float().permute(0, 3, 1, 2).requires_grad_(True), w.float()
+    yr = F.conv2d(xf, wf, None, 1, 1, 1, G)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    zeros = torch.zeros(64).bfloat16()
+    _EMUL.emul_set_dma_mode(dma)
+    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
+    wr = w.permute(0, 2, 3, 1).contiguous()                                  # [Co][3][3][Kc]
+    init = torch.randn(N, H, W, Co).bfloat16()
+    y = init.clone() if acc else torch.full((N, H, W, Co), float("nan")).bfloat16()
+    assert _EMUL.cot_study_conv3x3g_nhwc(P(x), P(wr), P(zeros), P(y), acc, N, H, W, C, Co, G, None) == 0
+    ref = yr.detach().permute(0, 2, 3, 1) + (init.float() if acc else 0)
+    assert (y.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    # data gradient: per group the weights transposed, the taps reversed -- [C][9][Mg]
+    wt = w.view(G, Mg, Kc, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(C, 3, 3, Mg).contiguous()
+    if Kc in (64, 128):  # (the data gradient's "output" width is Kc: 64 or a multiple of 128)
+        gx = torch.full((N, H, W, C), float("nan")).bfloat16()
+        assert _EMUL.cot_study_conv3x3g_nhwc(P(gy), P(wt), P(zeros), P(gx), 0, N, H, W, Co, C, G, None) == 0
+        gref = xf.grad.permute(0, 2, 3, 1)
+        assert (gx.float() - gref).abs().max() <= 2e-2 * gref.abs().max()
+    assert _EMUL.cot_study_conv3x3g_nhwc(P(x), P(wr), P(zeros), P(y), 0, N, H, W, C, G * 96, G, None) == -2   # 96 outputs per group
