@@ -178,14 +178,31 @@ namespace cot {
 // their chunks (those products are never stored); rows past M in the very last step are cleared in LDS by the lanes that copied them.
 __device__ __forceinline__ int kc_swz(int row) { return (((row & 3) | (((row >> 3) & 1) << 2)) << 1); }
 
+// TAPS (the grouped 3x3 convolution's weight gradient, dW[g * Mg + j][t][i] = sum_m dY[m][g * Mg + j] * X[m + shift(t)][g * Kc + i]):
+// blockIdx.y = group * 9 + tap; X and dY are then [M][ldx] / [M][ldy] with the group's channel window at xc / yc (Ci / Co = the
+// window's widths, at most 128: one tile), the X rows of a step come from the shifted pixels (the zero block where the tap leaves
+// the image) and the partial sums go to part[slice][(g * Mg + j) * 9 + t][i].
+struct KcTaps {
+    const bf16_t* zeros;
+    int H, W, ldx, ldy, Kc, Mg;
+};
+template <bool TAPS>
 __global__ __launch_bounds__(256) void gemm_kc_wgrad(const bf16_t* __restrict__ X, const bf16_t* __restrict__ dY,
-                                                    float* __restrict__ part, int M, int Ci, int Co, int tci, int tco, int slices) {
+                                                    float* __restrict__ part, int M, int Ci, int Co, int tci, int tco, int slices,
+                                                    KcTaps tp) {
     constexpr int NS = 4, TB = 32 * 256, ST = 2 * TB, G = 4;  // tile bytes, stage bytes, copies per wave and stage
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sl = blockIdx.x % slices, tile = blockIdx.x / slices;
     const int ti = tile % tci, to = tile / tci;
     const int ci0 = ti * 128, co0 = to * 128;
+    const int grp = TAPS ? (int)blockIdx.y / 9 : 0, tap = TAPS ? (int)blockIdx.y - grp * 9 : 0;
+    const int tdy = tap / 3 - 1, tdx = tap - (tap / 3) * 3 - 1;
+    const int ldx = TAPS ? tp.ldx : Ci, ldy = TAPS ? tp.ldy : Co;
+    if (TAPS) {
+        X += grp * tp.Kc;
+        dY += grp * tp.Mg;
+    }
     const int KT = ceil_div(M, 32);
     const int k0 = (int)((int64_t)KT * sl / slices), k1 = (int)((int64_t)KT * (sl + 1) / slices);
 
@@ -209,8 +226,14 @@ __global__ __launch_bounds__(256) void gemm_kc_wgrad(const bf16_t* __restrict__ 
         for (int q = 0; q < 2; ++q) {
             int m = kt * 32 + crow[q];
             m = m < M ? m : M - 1;  // (cleared after it has landed: see below)
-            COT_GLDS16(xs[q] + (int64_t)m * Ci, base + (8 * wave + 4 * q) * 256);
-            COT_GLDS16(ys[q] + (int64_t)m * Co, base + TB + (8 * wave + 4 * q) * 256);
+            const bf16_t* xsrc = xs[q] + (int64_t)m * ldx;
+            if (TAPS) {
+                const int pix = m % (tp.H * tp.W), h = pix / tp.W, w = pix - h * tp.W;
+                const bool in = (unsigned)(h + tdy) < (unsigned)tp.H && (unsigned)(w + tdx) < (unsigned)tp.W;
+                xsrc = in ? xsrc + (int64_t)(tdy * tp.W + tdx) * ldx : tp.zeros;
+            }
+            COT_GLDS16(xsrc, base + (8 * wave + 4 * q) * 256);
+            COT_GLDS16(ys[q] + (int64_t)m * ldy, base + TB + (8 * wave + 4 * q) * 256);
         }
     };
 
@@ -269,16 +292,19 @@ __global__ __launch_bounds__(256) void gemm_kc_wgrad(const bf16_t* __restrict__ 
     }
 
     // D[i = 4 * (lane >> 4) + e][j = lane & 15]: i = ci inside its 16-block, j = co
-    float* pp = part + (int64_t)sl * Co * Ci;
+    // plain: part[slice][Co][Ci]; TAPS: part[slice][groups * Mg][9][Kc], this workgroup's rows (g * Mg + co) * 9 + tap
+    const int64_t slab = TAPS ? (int64_t)(gridDim.y / 9) * tp.Mg * 9 * tp.Kc : (int64_t)Co * Ci;
+    float* pp = part + sl * slab;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int co = co0 + wn * 64 + j * 16 + L;
         if (co < Co) {
+            float* row = TAPS ? pp + ((int64_t)(grp * tp.Mg + co) * 9 + tap) * tp.Kc : pp + (int64_t)co * Ci;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ci = ci0 + wm * 64 + i * 16 + 4 * g;
                 if (ci < Ci)  // (Ci % 8 == 0: four channels inside or outside together)
-                    *reinterpret_cast<f32x4_t*>(pp + (int64_t)co * Ci + ci) = acc[j][i];
+                    *reinterpret_cast<f32x4_t*>(row + ci) = acc[j][i];
             }
         }
     }
@@ -315,15 +341,50 @@ int gemm_kc_wgrad_run(const void* x, const void* dy, void* dw, void* workspace, 
     const int slices = gemm_kc_wgrad_slices(M, Ci, Co, forced), tci = ceil_div(Ci, 128), tco = ceil_div(Co, 128);
     const int64_t blocks = (int64_t)tci * tco * slices;
     if (blocks >= ((int64_t)1 << 31)) return -2;
-    COT_LAUNCH(gemm_kc_wgrad, dim3((unsigned)blocks), dim3(256), 4 * 2 * 32 * 256, s, (const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, M,
-               Ci, Co, tci, tco, slices);
+    COT_LAUNCH((gemm_kc_wgrad<false>), dim3((unsigned)blocks), dim3(256), 4 * 2 * 32 * 256, s, (const bf16_t*)x, (const bf16_t*)dy,
+               (float*)workspace, M, Ci, Co, tci, tco, slices, KcTaps{});
     const int64_t n4 = (int64_t)Co * Ci / 4;
     COT_LAUNCH(gemm_kc_wgrad_reduce, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, (const float*)workspace, (bf16_t*)dw, n4, slices);
     return check_launch("gemm_kc_wgrad");
 }
 
+// grouped 3x3 weight gradient, channels-last: x [N*H*W][C], dy [N*H*W][Co] -> dwr [Co][9][Kc] (the forward's repacked layout)
+static int conv3x3g_kc_wgrad_slices(int M, int groups, int forced) {
+    const int KT = ceil_div(M, 32);
+    int s = forced > 0 ? forced : ceil_div(512, groups * 9);
+    if (forced <= 0 && s > KT / 4) s = KT / 4;
+    if (s > KT) s = KT;
+    return s < 1 ? 1 : s;
+}
+size_t conv3x3g_kc_wgrad_workspace(int N, int H, int W, int C, int Co, int groups, int forced) {
+    return (size_t)conv3x3g_kc_wgrad_slices(N * H * W, groups, forced) * Co * 9 * (C / groups) * sizeof(float);
+}
+int conv3x3g_kc_wgrad_run(const void* x, const void* dy, const void* zeros, void* dwr, void* workspace, int N, int H, int W, int C, int Co,
+                          int groups, int forced, hipStream_t s) {
+    if (!x || !dy || !zeros || !dwr || !workspace || N <= 0 || H <= 0 || W <= 0 || groups <= 0 || C % groups || Co % groups) return -1;
+    const int Kc = C / groups, Mg = Co / groups;
+    if (Kc % 8 || Mg % 8 || Kc > 128 || Mg > 128 || ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)zeros | (uintptr_t)dwr | (uintptr_t)workspace) % 16)
+        return -2;
+    const int64_t M64 = (int64_t)N * H * W;
+    if (M64 * (C > Co ? C : Co) >= ((int64_t)1 << 31)) return -2;
+    const int M = (int)M64, slices = conv3x3g_kc_wgrad_slices(M, groups, forced);
+    const KcTaps tp{(const bf16_t*)zeros, H, W, C, Co, Kc, Mg};
+    COT_LAUNCH((gemm_kc_wgrad<true>), dim3((unsigned)slices, (unsigned)(groups * 9)), dim3(256), 4 * 2 * 32 * 256, s, (const bf16_t*)x,
+               (const bf16_t*)dy, (float*)workspace, M, Kc, Mg, 1, 1, slices, tp);
+    const int64_t n4 = (int64_t)Co * 9 * Kc / 4;
+    COT_LAUNCH(gemm_kc_wgrad_reduce, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, (const float*)workspace, (bf16_t*)dwr, n4, slices);
+    return check_launch("conv3x3g_kc_wgrad");
+}
+
 }  // namespace cot
 
+extern "C" size_t cot_study_conv3x3g_nhwc_wgrad_workspace(int N, int H, int W, int C, int Co, int groups, int slices) {
+    return cot::conv3x3g_kc_wgrad_workspace(N, H, W, C, Co, groups, slices);
+}
+extern "C" int cot_study_conv3x3g_nhwc_wgrad(const void* x, const void* dy, const void* zeros, void* dwr, void* workspace, int N, int H, int W,
+                                             int C, int Co, int groups, int slices, void* stream) {
+    return cot::conv3x3g_kc_wgrad_run(x, dy, zeros, dwr, workspace, N, H, W, C, Co, groups, slices, (hipStream_t)stream);
+}
 extern "C" size_t cot_study_conv1x1_nhwc_wgrad_workspace(int M, int Ci, int Co, int slices) {
     return cot::gemm_kc_wgrad_workspace(M, Ci, Co, slices);
 }

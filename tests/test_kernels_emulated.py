@@ -2819,3 +2819,27 @@ def test_k_contiguous_grouped_conv3x3(N, H, W, G, Kc, acc, dma, request):
         gref = xf.grad.permute(0, 2, 3, 1)
         assert (gx.float() - gref).abs().max() <= 2e-2 * gref.abs().max()
     assert _EMUL.cot_study_conv3x3g_nhwc(P(x), P(wr), P(zeros), P(y), 0, N, H, W, C, G * 96, G, None) == -2   # 96 outputs per group
+
+
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("N,H,W,G,Kc,Mg,slices", [(2, 7, 7, 4, 64, 64, 0), (1, 14, 14, 2, 128, 128, 3), (3, 5, 9, 1, 32, 64, 1),
+                                                  (1, 1, 1, 4, 8, 16, 0), (2, 3, 2, 2, 40, 24, 2)])
+def test_k_contiguous_grouped_conv3x3_weight_gradient(N, H, W, G, Kc, Mg, slices, dma, request):
+    """gemm_kc_wgrad<TAPS> (study kernel): the grouped 3x3 weight gradient of a channels-last activation -- per (group,
+    tap) the channels-last weight-gradient GEMM on the shifted pixel rows (zero block outside the image) -- into the forward's
+    repacked layout [Co][9][Kc], against torch"""
+    F = torch.nn.functional
+    _EMUL.cot_study_conv3x3g_nhwc_wgrad_workspace.restype = ctypes.c_size_t
+    C, Co = G * Kc, G * Mg
+    torch.manual_seed(H + W + Kc)
+    x, gy = torch.randn(N, H, W, C).bfloat16(), torch.randn(N, H, W, Co).bfloat16()
+    wf = torch.zeros(Co, Kc, 3, 3, requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), wf, None, 1, 1, 1, G).backward(gy.float().permute(0, 3, 1, 2))
+    ref = wf.grad.permute(0, 2, 3, 1).reshape(Co, 9, Kc)
+    zeros = torch.zeros(64).bfloat16()
+    nb = _EMUL.cot_study_conv3x3g_nhwc_wgrad_workspace(N, H, W, C, Co, G, slices)
+    ws, dwr = torch.full((nb // 4,), float("nan")), torch.full((Co, 9, Kc), float("nan")).bfloat16()
+    _EMUL.emul_set_dma_mode(dma)
+    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
+    assert _EMUL.cot_study_conv3x3g_nhwc_wgrad(P(x), P(gy), P(zeros), P(dwr), P(ws), N, H, W, C, Co, G, slices, None) == 0
+    assert (dwr.float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-2
