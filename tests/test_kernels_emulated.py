@@ -2843,3 +2843,38 @@ def test_k_contiguous_grouped_conv3x3_weight_gradient(N, H, W, G, Kc, Mg, slices
     request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
     assert _EMUL.cot_study_conv3x3g_nhwc_wgrad(P(x), P(gy), P(zeros), P(dwr), P(ws), N, H, W, C, Co, G, slices, None) == 0
     assert (dwr.float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,G,HW", [(2, 32, 196), (3, 64, 49), (1, 8, 100), (2, 1, 4), (1, 2, 1)])
+def test_group_norm9_channels_last_study_kernels(N, G, HW, dtype):
+    """csrc/gn9_nhwc.hip (study kernels): GroupNorm-9 on channels-last logits x[N][HW][9 * G] -- a thread owns the 9
+    consecutive channels of a group in a row -- forward, saved statistics and all three gradients against torch's group_norm on
+    the same values viewed as [N, C, HW, 1]"""
+    F = torch.nn.functional
+    dt, C = _lib.dtype_code(dtype), 9 * G
+    g = torch.Generator().manual_seed(N + G + HW)
+    x = (torch.randn(N, HW, C, generator=g) * 1.7 + 0.4).to(dtype)
+    dy = torch.randn(N, HW, C, generator=g).to(dtype)
+    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).to(dtype), (0.2 * torch.randn(C, generator=g)).to(dtype)
+    xr, gr, br = x.float().requires_grad_(True), gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
+    yr = F.group_norm(xr.permute(0, 2, 1).reshape(N, C, HW, 1), G, gr, br, 1e-5).reshape(N, C, HW).permute(0, 2, 1)
+    yr.backward(dy.float())
+    y, mean, rstd = torch.full_like(x, float("nan")), torch.empty(N * G), torch.empty(N * G)
+    assert _EMUL.cot_study_group_norm9_nhwc_forward(P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, C, HW, ctypes.c_float(1e-5), dt,
+                                                    None) == 0
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert ((y.float() - yr.detach()).abs() <= tol * (1 + yr.detach().abs())).all()
+    xg = x.float().permute(0, 2, 1).reshape(N, G, 9 * HW)
+    assert torch.allclose(mean, xg.mean(2).flatten(), atol=1e-4, rtol=1e-4)
+    dx, dg, db = torch.full_like(x, float("nan")), torch.full_like(gamma, float("nan")), torch.full_like(beta, float("nan"))
+    ws = torch.full((N * C * 2,), float("nan"))
+    assert _EMUL.cot_study_group_norm9_nhwc_backward(P(dy), P(x), P(mean), P(rstd), P(gamma), P(dx), P(dg), P(db), P(ws), N, C, HW, dt,
+                                                     None) == 0
+    if 9 * HW >= 36:  # (tiny groups: 1 / sigma amplifies the rounding)
+        gt = 3e-4 if dtype == torch.float32 else 3e-2
+        assert ((dx.float() - xr.grad).abs() <= gt * (1 + xr.grad.abs().max())).all()
+        assert torch.allclose(dg.float(), gr.grad, rtol=gt * 4, atol=gt * 4 * (1 + gr.grad.abs().max().item()))
+        assert torch.allclose(db.float(), br.grad, rtol=gt * 4, atol=gt * 4 * (1 + br.grad.abs().max().item()))
+    assert _EMUL.cot_study_group_norm9_nhwc_forward(P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, 9 * 3, HW, ctypes.c_float(1e-5), dt,
+                                                    None) == -2   # three groups per row: not a power of two
