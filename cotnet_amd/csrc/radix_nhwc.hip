@@ -1,0 +1,156 @@
+// radix_nhwc.hip -- STUDY (the channels-last route): the radix-2 tail of the CoT layer (models/cotnet.py:92-104) on
+// channels-last tensors y, k [N][HW][C]; csrc/radix_tail.hip is the NCHW implementation, the arithmetic is the same:
+//     gap[n][c]    = mean over pixels of (y + k)                                   (the `se` branch's input)
+//     out          = y * attn[n][c][0] + k * attn[n][c][1]
+//     gy = gout * a0,  gk = gout * a1,  gattn[n][c][0] = sum_p gout * y,  gattn[n][c][1] = sum_p gout * k
+// A thread owns V consecutive channels (16 bytes) and walks down an image's rows: whole rows are contiguous, the per-(image,
+// channel) sums are column sums inside one workgroup (one workgroup per image).  Exported as cot_study_radix_nhwc_*.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "cot_common.h"
+
+namespace cot {
+
+template <int NV>
+__device__ __forceinline__ void radix_col_sum(float (&v)[NV], float* sm, int TPR, int RP, int cg, int rl) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sm[(rl * TPR + cg) * NV + k] = v[k];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            float a = 0.f;
+            for (int j = 0; j < RP; ++j) a += sm[(j * TPR + cg) * NV + k];
+            v[k] = a;
+        }
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_nhwc_gap(const T* __restrict__ y, const T* __restrict__ k, T* __restrict__ gap, int HW, int C) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    float* sm = reinterpret_cast<float*>(cot_smem);
+    const int n = blockIdx.x, TPR = C / V, RP = 256 / TPR, cg = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    const int64_t base = (int64_t)n * HW * C + cg * V;
+    float s[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] = 0.f;
+    for (int r = rl; r < HW; r += RP) {
+        const Vec<T, V> a = ldv<T, V>(y + base + (int64_t)r * C), b = ldv<T, V>(k + base + (int64_t)r * C);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] += (float)a.v[e] + (float)b.v[e];
+    }
+    radix_col_sum<V>(s, sm, TPR, RP, cg, rl);
+    if (rl == 0) {
+        Vec<T, V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) o.v[e] = (T)(s[e] / (float)HW);
+        stv<T, V>(gap + (int64_t)n * C + cg * V, o);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_nhwc_mix(const T* __restrict__ y, const T* __restrict__ k, const T* __restrict__ attn,
+                                                     T* __restrict__ out, int HW, int C, int64_t nvec) {
+    const int vpr = C / V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / vpr;
+        const int c0 = (int)(i - row * vpr) * V, n = (int)(row / HW);
+        const Vec<T, V> a = ldv<T, V>(y + i * V), b = ldv<T, V>(k + i * V);
+        const Vec<T, V> w0 = ldv<T, V>(attn + ((int64_t)n * C + c0) * 2), w1 = ldv<T, V>(attn + ((int64_t)n * C + c0) * 2 + V);
+        Vec<T, V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            // attn[n][c0 + e][0 / 1] = element 2e / 2e + 1 of the 2V consecutive values (w0 | w1)
+            const float a0 = (float)(2 * e < V ? w0.v[(2 * e) % V] : w1.v[(2 * e) % V]);
+            const float a1 = (float)(2 * e + 1 < V ? w0.v[(2 * e + 1) % V] : w1.v[(2 * e + 1) % V]);
+            o.v[e] = (T)((float)a.v[e] * a0 + (float)b.v[e] * a1);
+        }
+        stv<T, V>(out + i * V, o);
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_nhwc_mix_bwd(const T* __restrict__ gout, const T* __restrict__ y, const T* __restrict__ k,
+                                                         const T* __restrict__ attn, T* __restrict__ gy, T* __restrict__ gk,
+                                                         T* __restrict__ gattn, int HW, int C) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    float* sm = reinterpret_cast<float*>(cot_smem);
+    const int n = blockIdx.x, TPR = C / V, RP = 256 / TPR, cg = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    const int64_t base = (int64_t)n * HW * C + cg * V;
+    float a0[V], a1[V], s[2 * V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        a0[e] = (float)attn[((int64_t)n * C + cg * V + e) * 2];
+        a1[e] = (float)attn[((int64_t)n * C + cg * V + e) * 2 + 1];
+        s[2 * e] = s[2 * e + 1] = 0.f;
+    }
+    for (int r = rl; r < HW; r += RP) {
+        const int64_t off = base + (int64_t)r * C;
+        const Vec<T, V> g = ldv<T, V>(gout + off), a = ldv<T, V>(y + off), b = ldv<T, V>(k + off);
+        Vec<T, V> oy, ok;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float gv = (float)g.v[e];
+            oy.v[e] = (T)(gv * a0[e]);
+            ok.v[e] = (T)(gv * a1[e]);
+            s[2 * e] += gv * (float)a.v[e];
+            s[2 * e + 1] += gv * (float)b.v[e];
+        }
+        stv<T, V>(gy + off, oy);
+        stv<T, V>(gk + off, ok);
+    }
+    radix_col_sum<2 * V>(s, sm, TPR, RP, cg, rl);
+    if (rl == 0) {
+#pragma unroll
+        for (int e = 0; e < 2 * V; ++e) gattn[((int64_t)n * C + cg * V) * 2 + e] = (T)s[e];
+    }
+}
+
+template <typename T, int V> static bool radix_nhwc_covers(int C) {
+    return C > 0 && C % V == 0 && C / V <= 256 && 256 % (C / V) == 0;
+}
+template <typename T, int V>
+static int radix_nhwc_run(int what, const void* gout, const void* y, const void* k, const void* attn, void* o1, void* o2, void* o3, int N,
+                          int HW, int C, hipStream_t s) {
+    if (!radix_nhwc_covers<T, V>(C)) return -2;
+    if (what == 0) {
+        COT_LAUNCH((radix_nhwc_gap<T, V>), dim3(N), dim3(256), 256 * V * sizeof(float), s, (const T*)y, (const T*)k, (T*)o1, HW, C);
+    } else if (what == 1) {
+        const int64_t nvec = (int64_t)N * HW * C / V;
+        int64_t b = ceil_div64(nvec, 256 * 2);
+        b = b < 1 ? 1 : (b > 2048 ? 2048 : b);
+        COT_LAUNCH((radix_nhwc_mix<T, V>), dim3((unsigned)b), dim3(256), 0, s, (const T*)y, (const T*)k, (const T*)attn, (T*)o1, HW, C, nvec);
+    } else {
+        COT_LAUNCH((radix_nhwc_mix_bwd<T, V>), dim3(N), dim3(256), 256 * 2 * V * sizeof(float), s, (const T*)gout, (const T*)y, (const T*)k,
+                   (const T*)attn, (T*)o1, (T*)o2, (T*)o3, HW, C);
+    }
+    return check_launch("radix_nhwc");
+}
+
+}  // namespace cot
+
+// y, k, out, gout, gy, gk: [N][HW][C]; gap: [N][C]; attn, gattn: [N][C][2].  dtype COT_F32 (0) / COT_BF16 (2); C / (16 bytes' worth of
+// channels) a power of two up to 256
+#define RADIX_NHWC_DISPATCH(...)                                                                      \
+    do {                                                                                              \
+        if (N <= 0 || HW <= 0 || C <= 0) return -1;                                                   \
+        if (dtype == 2) return cot::radix_nhwc_run<cot::bf16_t, 8>(__VA_ARGS__, N, HW, C, (hipStream_t)stream); \
+        if (dtype == 0) return cot::radix_nhwc_run<float, 4>(__VA_ARGS__, N, HW, C, (hipStream_t)stream);      \
+        return -2;                                                                                    \
+    } while (0)
+extern "C" int cot_study_radix_nhwc_gap(const void* y, const void* k, void* gap, int N, int HW, int C, int dtype, void* stream) {
+    if (!y || !k || !gap) return -1;
+    RADIX_NHWC_DISPATCH(0, nullptr, y, k, nullptr, gap, nullptr, nullptr);
+}
+extern "C" int cot_study_radix_nhwc_mix(const void* y, const void* k, const void* attn, void* out, int N, int HW, int C, int dtype, void* stream) {
+    if (!y || !k || !attn || !out) return -1;
+    RADIX_NHWC_DISPATCH(1, nullptr, y, k, attn, out, nullptr, nullptr);
+}
+extern "C" int cot_study_radix_nhwc_mix_backward(const void* gout, const void* y, const void* k, const void* attn, void* gy, void* gk,
+                                                 void* gattn, int N, int HW, int C, int dtype, void* stream) {
+    if (!gout || !y || !k || !attn || !gy || !gk || !gattn) return -1;
+    RADIX_NHWC_DISPATCH(2, gout, y, k, attn, gy, gk, gattn);
+}

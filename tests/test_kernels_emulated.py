@@ -2878,3 +2878,32 @@ def test_group_norm9_channels_last_study_kernels(N, G, HW, dtype):
         assert torch.allclose(db.float(), br.grad, rtol=gt * 4, atol=gt * 4 * (1 + br.grad.abs().max().item()))
     assert _EMUL.cot_study_group_norm9_nhwc_forward(P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, 9 * 3, HW, ctypes.c_float(1e-5), dt,
                                                     None) == -2   # three groups per row: not a power of two
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,HW,C", [(2, 196, 256), (3, 49, 512), (1, 100, 64), (2, 1, 8), (1, 4, 16)])
+def test_radix_tail_channels_last_study_kernels(N, HW, C, dtype):
+    """csrc/radix_nhwc.hip (study kernels): the radix-2 tail on channels-last y, k [N][HW][C] -- pooled descriptor,
+    mix, and the mix's backward with its per-(image, channel) column sums -- against autograd on the reference formula
+    (models/cotnet.py:92-104)"""
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(N + HW + C)
+    y, k, go = (torch.randn(N, HW, C, generator=g).to(dtype) for _ in range(3))
+    attn = torch.softmax(torch.randn(N, C, 2, generator=g), 2).to(dtype)
+    yr, kr, ar = y.float().requires_grad_(True), k.float().requires_grad_(True), attn.float().requires_grad_(True)
+    gap_ref = (yr + kr).mean(1)
+    out_ref = yr * ar[:, None, :, 0] + kr * ar[:, None, :, 1]
+    out_ref.backward(go.float())
+    gap, out = torch.full((N, C), float("nan")).to(dtype), torch.full_like(y, float("nan"))
+    gy, gk, ga = torch.full_like(y, float("nan")), torch.full_like(y, float("nan")), torch.full_like(attn, float("nan"))
+    assert _EMUL.cot_study_radix_nhwc_gap(P(y), P(k), P(gap), N, HW, C, dt, None) == 0
+    assert _EMUL.cot_study_radix_nhwc_mix(P(y), P(k), P(attn), P(out), N, HW, C, dt, None) == 0
+    assert _EMUL.cot_study_radix_nhwc_mix_backward(P(go), P(y), P(k), P(attn), P(gy), P(gk), P(ga), N, HW, C, dt, None) == 0
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+
+    def near(a, b, f=1.0):
+        return ((a.float() - b).abs() <= f * tol * (1 + b.abs())).all()
+
+    assert near(gap, gap_ref.detach()) and near(out, out_ref.detach()) and near(gy, yr.grad) and near(gk, kr.grad)
+    assert near(ga, ar.grad, 4 * max(1.0, HW ** 0.5 / 4))
+    assert _EMUL.cot_study_radix_nhwc_gap(P(y), P(k), P(gap), N, HW, 24, dt, None) == -2   # 3 (6) threads per row: not covered
