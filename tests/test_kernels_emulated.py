@@ -2907,3 +2907,17 @@ def test_radix_tail_channels_last_study_kernels(N, HW, C, dtype):
     assert near(gap, gap_ref.detach()) and near(out, out_ref.detach()) and near(gy, yr.grad) and near(gk, kr.grad)
     assert near(ga, ar.grad, 4 * max(1.0, HW ** 0.5 / 4))
     assert _EMUL.cot_study_radix_nhwc_gap(P(y), P(k), P(gap), N, HW, 24, dt, None) == -2   # 3 (6) threads per row: not covered
+
+
+@pytest.mark.parametrize("N,C,HW", [(2, 256, 196), (3, 72, 49), (1, 5, 3), (2, 130, 65), (1, 64, 64)])
+def test_layout_change_between_nchw_and_channels_last(N, C, HW):
+    """csrc/layout_nhwc.hip (study kernels): per image [C][HW] <-> [HW][C] through 64 x 64 LDS tiles, exact, every element
+    written, partial tiles on both sides"""
+    torch.manual_seed(C + HW)
+    x = torch.randn(N, C, HW).bfloat16()
+    y = torch.full((N, HW, C), float("nan")).bfloat16()
+    assert _EMUL.cot_study_nchw_to_nhwc(P(x), P(y), N, C, HW, None) == 0
+    assert torch.equal(y, x.permute(0, 2, 1).contiguous())
+    z = torch.full((N, C, HW), float("nan")).bfloat16()
+    assert _EMUL.cot_study_nhwc_to_nchw(P(y), P(z), N, C, HW, None) == 0
+    assert torch.equal(z, x)
