@@ -2921,3 +2921,92 @@ def test_layout_change_between_nchw_and_channels_last(N, C, HW):
     z = torch.full((N, C, HW), float("nan")).bfloat16()
     assert _EMUL.cot_study_nhwc_to_nchw(P(y), P(z), N, C, HW, None) == 0
     assert torch.equal(z, x)
+
+
+def test_cot_layer_forward_composed_from_the_channels_last_study_kernels():
+    """the whole CotLayer(256) forward (models/cotnet.py:79-104) on channels-last tensors, composed from the study kernels of DESIGN 5.8
+    -- grouped 3x3 and 1x1 convolutions on the K-contiguous GEMM ([x, k] as two slabs, bias), BatchNorm (+ ReLU / SiLU), GroupNorm-9,
+    the NHWC aggregation, radix tail with the `se` branch as the same GEMM / BatchNorm on the [N][C] descriptor -- against an fp32
+    evaluation of the same module's formula on the bf16-rounded parameters: the kernel set is functionally complete for a layer"""
+    import cotnet_amd.cotnet as cn
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    F = torch.nn.functional
+    torch.manual_seed(11)
+    N, H, W, D = 4, 5, 4, 256
+    HW, M, dt = H * W, N * H * W, _lib.dtype_code(torch.bfloat16)
+    layer = cn.CotLayer(D, 3).train()
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.ndim == 1:
+                p.add_(0.2 * torch.randn_like(p))
+    layer = to_mixed_bf16(layer)
+    x = torch.randn(N, H, W, D).bfloat16()                       # channels-last input [M][D]
+    none, zeros = ctypes.c_void_p(None), torch.zeros(64).bfloat16()
+    f32 = ctypes.c_float
+
+    def conv(x1, x2, k1, conv_mod, rows):
+        w = conv_mod.weight.detach().reshape(conv_mod.out_channels, -1).contiguous()
+        b = conv_mod.bias.detach().contiguous() if conv_mod.bias is not None else None
+        y = torch.full((rows, w.shape[0]), float("nan")).bfloat16()
+        assert _EMUL.cot_study_conv1x1_nhwc(P(x1), P(x2) if x2 is not None else none, k1, P(w), P(b) if b is not None else none, P(y), 0,
+                                            rows, w.shape[0], w.shape[1], 0, None) == 0
+        return y
+
+    def bn(t, mod, act, rows):
+        C = t.shape[-1]
+        y, mean, rstd = torch.full_like(t, float("nan")), torch.empty(C), torch.empty(C)
+        ws = torch.empty(_EMUL.cot_study_bn_nhwc_workspace(rows, C, dt))
+        assert _EMUL.cot_study_bn_nhwc_forward(P(t), none, P(y), P(mod.weight.detach()), P(mod.bias.detach()), P(mean), P(rstd), none, none,
+                                               none, P(ws), rows, C, f32(mod.eps), f32(0.1), act, dt, None) == 0
+        return y
+
+    # ---- the layer on the study kernels
+    ke = layer.key_embed[0]
+    wr = ke.weight.detach().permute(0, 2, 3, 1).contiguous()     # [Co][3][3][Kc]
+    k = torch.full((M, D), float("nan")).bfloat16()
+    assert _EMUL.cot_study_conv3x3g_nhwc(P(x), P(wr), P(zeros), P(k), 0, N, H, W, D, D, 4, None) == 0
+    k = bn(k, layer.key_embed[1], 1, M)
+    xm = x.reshape(M, D)
+    e = bn(conv(xm, k, D, layer.embed[0], M), layer.embed[1], 1, M)
+    e = conv(e, None, e.shape[1], layer.embed[3], M)             # [M][9 * D / 8], bias
+    G = D // 8
+    wn, gm, gr = torch.full_like(e, float("nan")), torch.empty(N * G), torch.empty(N * G)
+    gn = layer.embed[4]
+    assert _EMUL.cot_study_group_norm9_nhwc_forward(P(e), P(gn.weight.detach()), P(gn.bias.detach()), P(wn), P(gm), P(gr), N, 9 * G, HW,
+                                                    f32(gn.eps), dt, None) == 0
+    v = bn(conv(xm, None, D, layer.conv1x1[0], M), layer.conv1x1[1], 0, M)
+    geo = _lib.AggGeom(N, D, H, W, 1, G, 3, 3, 1, 1, 1, 1, 1, 1)
+    agg = torch.full((M, D), float("nan")).bfloat16()
+    assert _EMUL.cot_agg_forward(P(v), P(wn), P(agg), ctypes.byref(geo), dt, 1, None) == 0, _EMUL.cot_last_error()
+    y = bn(agg, layer.bn, 2, M)
+    gap = torch.full((N, D), float("nan")).bfloat16()
+    assert _EMUL.cot_study_radix_nhwc_gap(P(y), P(k), P(gap), N, HW, D, dt, None) == 0
+    s0 = bn(conv(gap, None, D, layer.se[0], N), layer.se[1], 1, N)
+    logits = conv(s0, None, s0.shape[1], layer.se[3], N)        # [N][2 * D] = [N][D][2]
+    attn = torch.softmax(logits.float().view(N, D, 2), 2).bfloat16().contiguous()
+    out = torch.full((M, D), float("nan")).bfloat16()
+    assert _EMUL.cot_study_radix_nhwc_mix(P(y), P(k), P(attn), P(out), N, HW, D, dt, None) == 0
+
+    # ---- the same formula in fp32 torch on the rounded parameters (NCHW)
+    def tbn(t, mod):
+        return F.batch_norm(t, None, None, mod.weight.float(), mod.bias.float(), True, 0.1, mod.eps)
+    xt = x.float().permute(0, 3, 1, 2)
+    kt = torch.relu(tbn(F.conv2d(xt, ke.weight.float(), None, 1, 1, 1, 4), layer.key_embed[1]))
+    et = torch.relu(tbn(F.conv2d(torch.cat([xt, kt], 1), layer.embed[0].weight.float()), layer.embed[1]))
+    et = F.group_norm(F.conv2d(et, layer.embed[3].weight.float(), layer.embed[3].bias.float()), G, gn.weight.float(), gn.bias.float(), gn.eps)
+    vt = tbn(F.conv2d(xt, layer.conv1x1[0].weight.float()), layer.conv1x1[1])
+    at = cref.forward(vt.contiguous(), et.reshape(N, 1, G, 9, H, W).contiguous(), 3, 1, 1, 1)
+    yt = F.silu(tbn(at, layer.bn))
+    gt = (yt + kt).mean((2, 3), keepdim=True)
+    st = F.conv2d(torch.relu(tbn(F.conv2d(gt, layer.se[0].weight.float(), layer.se[0].bias.float()), layer.se[1])),
+                  layer.se[3].weight.float(), layer.se[3].bias.float())
+    a_t = torch.softmax(st.view(N, D, 2), 2)
+    ot = yt * a_t[:, :, 0, None, None] + kt * a_t[:, :, 1, None, None]
+
+    def rel(a, b):   # a: channels-last [M][C], b: NCHW
+        b = b.permute(0, 2, 3, 1).reshape(a.shape)
+        return ((a.float() - b).abs().mean() / b.abs().mean()).item()
+
+    # measured: 0.002 / 0.003 / 0.002 / 0.005 / 0.004 (bf16 rounding of every intermediate); a wiring error gives O(1)
+    assert rel(k, kt) < 6e-3 and rel(wn, et) < 1e-2 and rel(v, vt) < 6e-3 and rel(y, yt) < 1.5e-2, (rel(k, kt), rel(wn, et), rel(v, vt), rel(y, yt))
+    assert rel(out, ot) < 2e-2, rel(out, ot)
