@@ -109,6 +109,86 @@ __global__ __launch_bounds__(256) void radix_nhwc_mix_bwd(const T* __restrict__ 
     }
 }
 
+// the backward in two launches, as the NCHW path has it (cot_radix_mix_backward_reduce / _apply): the column sums first -- gattn feeds
+// the `se` branch's backward, whose result ggap [N][C] (gradient of the pooled descriptor) is an input of the element-wise half:
+//     gy = gout * a0 + ggap / HW,   gk = gout * a1 + ggap / HW
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_nhwc_mix_bwd_reduce(const T* __restrict__ gout, const T* __restrict__ y, const T* __restrict__ k,
+                                                                T* __restrict__ gattn, int HW, int C) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    float* sm = reinterpret_cast<float*>(cot_smem);
+    const int n = blockIdx.x, TPR = C / V, RP = 256 / TPR, cg = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    const int64_t base = (int64_t)n * HW * C + cg * V;
+    float s[2 * V];
+#pragma unroll
+    for (int e = 0; e < 2 * V; ++e) s[e] = 0.f;
+    for (int r = rl; r < HW; r += RP) {
+        const int64_t off = base + (int64_t)r * C;
+        const Vec<T, V> g = ldv<T, V>(gout + off), a = ldv<T, V>(y + off), b = ldv<T, V>(k + off);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            s[2 * e] += (float)g.v[e] * (float)a.v[e];
+            s[2 * e + 1] += (float)g.v[e] * (float)b.v[e];
+        }
+    }
+    radix_col_sum<2 * V>(s, sm, TPR, RP, cg, rl);
+    if (rl == 0) {
+#pragma unroll
+        for (int e = 0; e < 2 * V; ++e) gattn[((int64_t)n * C + cg * V) * 2 + e] = (T)s[e];
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void radix_nhwc_mix_bwd_apply(const T* __restrict__ gout, const T* __restrict__ attn, const T* __restrict__ ggap,
+                                                               T* __restrict__ gy, T* __restrict__ gk, int HW, int C, int64_t nvec) {
+    const int vpr = C / V;
+    const float inv = 1.0f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / vpr;
+        const int c0 = (int)(i - row * vpr) * V, n = (int)(row / HW);
+        const Vec<T, V> g = ldv<T, V>(gout + i * V);
+        const Vec<T, V> w0 = ldv<T, V>(attn + ((int64_t)n * C + c0) * 2), w1 = ldv<T, V>(attn + ((int64_t)n * C + c0) * 2 + V);
+        Vec<T, V> gg, oy, ok;
+        if (ggap) gg = ldv<T, V>(ggap + (int64_t)n * C + c0);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float a0 = (float)(2 * e < V ? w0.v[(2 * e) % V] : w1.v[(2 * e) % V]);
+            const float a1 = (float)(2 * e + 1 < V ? w0.v[(2 * e + 1) % V] : w1.v[(2 * e + 1) % V]);
+            const float add = ggap ? (float)gg.v[e] * inv : 0.f;
+            oy.v[e] = (T)((float)g.v[e] * a0 + add);
+            ok.v[e] = (T)((float)g.v[e] * a1 + add);
+        }
+        stv<T, V>(gy + i * V, oy);
+        stv<T, V>(gk + i * V, ok);
+    }
+}
+
+// out[c] = sum over the M rows of x[m][c] (the bias gradient of a channels-last 1x1 convolution): one workgroup per 64 * V channels
+// ... of a column block, rows in RP lanes; fp32 sums, rounded once
+template <typename T, int V>
+__global__ __launch_bounds__(256) void nhwc_col_sum(const T* __restrict__ x, T* __restrict__ out, int M, int C) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    float* sm = reinterpret_cast<float*>(cot_smem);
+    const int TPR = 32, RP = 8, cg = threadIdx.x % TPR, rl = threadIdx.x / TPR;  // 32 x V channels per workgroup, 8 row lanes
+    const int c0 = (blockIdx.x * TPR + cg) * V;
+    float s[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] = 0.f;
+    if (c0 < C)
+        for (int r = rl; r < M; r += RP) {
+            const Vec<T, V> a = ldv<T, V>(x + (int64_t)r * C + c0);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s[e] += (float)a.v[e];
+        }
+    radix_col_sum<V>(s, sm, TPR, RP, cg, rl);
+    if (rl == 0 && c0 < C) {
+        Vec<T, V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) o.v[e] = (T)s[e];
+        stv<T, V>(out + c0, o);
+    }
+}
+
 template <typename T, int V> static bool radix_nhwc_covers(int C) {
     return C > 0 && C % V == 0 && C / V <= 256 && 256 % (C / V) == 0;
 }
@@ -123,9 +203,18 @@ static int radix_nhwc_run(int what, const void* gout, const void* y, const void*
         int64_t b = ceil_div64(nvec, 256 * 2);
         b = b < 1 ? 1 : (b > 2048 ? 2048 : b);
         COT_LAUNCH((radix_nhwc_mix<T, V>), dim3((unsigned)b), dim3(256), 0, s, (const T*)y, (const T*)k, (const T*)attn, (T*)o1, HW, C, nvec);
-    } else {
+    } else if (what == 2) {
         COT_LAUNCH((radix_nhwc_mix_bwd<T, V>), dim3(N), dim3(256), 256 * 2 * V * sizeof(float), s, (const T*)gout, (const T*)y, (const T*)k,
                    (const T*)attn, (T*)o1, (T*)o2, (T*)o3, HW, C);
+    } else if (what == 3) {
+        COT_LAUNCH((radix_nhwc_mix_bwd_reduce<T, V>), dim3(N), dim3(256), 256 * 2 * V * sizeof(float), s, (const T*)gout, (const T*)y,
+                   (const T*)k, (T*)o1, HW, C);
+    } else {  // 4: apply; `y` carries ggap (may be NULL)
+        const int64_t nvec = (int64_t)N * HW * C / V;
+        int64_t b = ceil_div64(nvec, 256 * 2);
+        b = b < 1 ? 1 : (b > 2048 ? 2048 : b);
+        COT_LAUNCH((radix_nhwc_mix_bwd_apply<T, V>), dim3((unsigned)b), dim3(256), 0, s, (const T*)gout, (const T*)attn, (const T*)y, (T*)o1,
+                   (T*)o2, HW, C, nvec);
     }
     return check_launch("radix_nhwc");
 }
@@ -153,4 +242,30 @@ extern "C" int cot_study_radix_nhwc_mix_backward(const void* gout, const void* y
                                                  void* gattn, int N, int HW, int C, int dtype, void* stream) {
     if (!gout || !y || !k || !attn || !gy || !gk || !gattn) return -1;
     RADIX_NHWC_DISPATCH(2, gout, y, k, attn, gy, gk, gattn);
+}
+extern "C" int cot_study_radix_nhwc_mix_backward_reduce(const void* gout, const void* y, const void* k, void* gattn, int N, int HW, int C,
+                                                        int dtype, void* stream) {
+    if (!gout || !y || !k || !gattn) return -1;
+    RADIX_NHWC_DISPATCH(3, gout, y, k, nullptr, gattn, nullptr, nullptr);
+}
+extern "C" int cot_study_radix_nhwc_mix_backward_apply(const void* gout, const void* attn, const void* ggap, void* gy, void* gk, int N, int HW,
+                                                       int C, int dtype, void* stream) {
+    if (!gout || !attn || !gy || !gk) return -1;
+    RADIX_NHWC_DISPATCH(4, gout, ggap, nullptr, attn, gy, gk, nullptr);
+}
+// out[C] = column sums of x[M][C] (bias gradient of a channels-last convolution); C a multiple of 8 (bf16) / 4 (fp32)
+extern "C" int cot_study_nhwc_col_sum(const void* x, void* out, int M, int C, int dtype, void* stream) {
+    if (!x || !out || M <= 0 || C <= 0) return -1;
+    if (dtype == 2) {
+        if (C % 8) return -2;
+        COT_LAUNCH((cot::nhwc_col_sum<cot::bf16_t, 8>), dim3(cot::ceil_div(C, 256)), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
+                   (const cot::bf16_t*)x, (cot::bf16_t*)out, M, C);
+    } else if (dtype == 0) {
+        if (C % 4) return -2;
+        COT_LAUNCH((cot::nhwc_col_sum<float, 4>), dim3(cot::ceil_div(C, 128)), dim3(256), 256 * 4 * sizeof(float), (hipStream_t)stream,
+                   (const float*)x, (float*)out, M, C);
+    } else {
+        return -2;
+    }
+    return cot::check_launch("nhwc_col_sum");
 }
