@@ -1,0 +1,174 @@
+"""STUDY: the CotLayer (models/cotnet.py:79-104) forward and backward on channels-last tensors [N*H*W][C] as the
+sequence of launches a single-node implementation would issue, on the study kernels `cot_study_*` (csrc/gemm_kc.hip, bn_nhwc.hip,
+gn9_nhwc.hip, radix_nhwc.hip) plus the NHWC aggregation of the C ABI.  Not wired into any model: the host-emulated tests
+(tests/test_kernels_emulated.py::test_cot_layer_*_composed_from_the_channels_last_study_kernels) check it against the module's
+formula, scripts/bench_cot_layer_channels_last.py times it on the GPU beside the NCHW single-node layer.
+
+`lib` is the loaded library (ctypes), `stream` a ctypes void pointer or None; tensors live wherever `x` lives.  Training mode only
+(batch statistics; running statistics are not updated here), bf16 only."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+BF = _lib.COT_BF16
+_F = ctypes.c_float
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(None)
+
+
+def _ok(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"cotnet_amd channels-last study: {what} returned {rc}")
+
+
+class Plan:
+    """repacked / transposed copies of a CotLayer's weights (bf16): what a channels-last node would keep per optimizer step"""
+
+    def __init__(self, layer):
+        def w2(c):
+            return c.weight.detach().reshape(c.out_channels, -1).contiguous()
+        self.layer = layer
+        D = layer.dim
+        self.D, self.G = D, D // 8
+        ke = layer.key_embed[0]
+        self.groups = ke.groups
+        Kc = D // self.groups
+        self.wr = ke.weight.detach().permute(0, 2, 3, 1).contiguous()                                   # [Co][3][3][Kc]
+        self.wr_t = (ke.weight.detach().view(self.groups, Kc, Kc, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1)
+                     .reshape(D, 3, 3, Kc).contiguous())                                                   # data gradient's repack
+        self.w_e0, self.w_e3, self.w_v = w2(layer.embed[0]), w2(layer.embed[3]), w2(layer.conv1x1[0])
+        self.w_s0, self.w_s3 = w2(layer.se[0]), w2(layer.se[3])
+        self.w_e0x_t, self.w_e0k_t = self.w_e0[:, :D].t().contiguous(), self.w_e0[:, D:].t().contiguous()
+        self.w_e3_t, self.w_v_t = self.w_e3.t().contiguous(), self.w_v.t().contiguous()
+        self.w_s0_t, self.w_s3_t = self.w_s0.t().contiguous(), self.w_s3.t().contiguous()
+        self.zeros = torch.zeros(64, dtype=torch.bfloat16, device=ke.weight.device)
+
+
+class _Ops:
+    def __init__(self, lib, stream, like):
+        self.L, self.s, self.like = lib, stream, like
+        lib.cot_study_conv1x1_nhwc_wgrad_workspace.restype = ctypes.c_size_t
+        lib.cot_study_conv3x3g_nhwc_wgrad_workspace.restype = ctypes.c_size_t
+
+    def new(self, *shape, dtype=torch.bfloat16):
+        return torch.empty(shape, dtype=dtype, device=self.like.device)
+
+    def gemm(self, x1, x2, k1, w, b, rows, y=None, acc=0):
+        y = self.new(rows, w.shape[0]) if y is None else y
+        _ok(self.L.cot_study_conv1x1_nhwc(_p(x1), _p(x2), k1, _p(w), _p(b), _p(y), acc, rows, w.shape[0], w.shape[1], 0, self.s), "conv1x1")
+        return y
+
+    def wgrad(self, xin, dy, rows):
+        Ci, Co = xin.shape[1], dy.shape[1]
+        ws = self.new(self.L.cot_study_conv1x1_nhwc_wgrad_workspace(rows, Ci, Co, 0), dtype=torch.uint8)
+        dw = self.new(Co, Ci)
+        _ok(self.L.cot_study_conv1x1_nhwc_wgrad(_p(xin), _p(dy), _p(dw), _p(ws), rows, Ci, Co, 0, self.s), "conv1x1 wgrad")
+        return dw
+
+    def colsum(self, t, rows):
+        o = self.new(t.shape[1])
+        _ok(self.L.cot_study_nhwc_col_sum(_p(t), _p(o), rows, t.shape[1], BF, self.s), "col_sum")
+        return o
+
+    def bn_f(self, t, mod, act, rows):
+        C = t.shape[-1]
+        y, mean, rstd = torch.empty_like(t), self.new(C, dtype=torch.float32), self.new(C, dtype=torch.float32)
+        ws = self.new(self.L.cot_study_bn_nhwc_workspace(rows, C, BF), dtype=torch.float32)
+        _ok(self.L.cot_study_bn_nhwc_forward(_p(t), _p(None), _p(y), _p(mod.weight.detach()), _p(mod.bias.detach()), _p(mean), _p(rstd),
+                                             _p(None), _p(None), _p(None), _p(ws), rows, C, _F(mod.eps), _F(0.1), act, BF, self.s), "bn fwd")
+        return y, (mean, rstd)
+
+    def bn_b(self, dy, t, y, st, mod, act, rows):
+        C = t.shape[-1]
+        dx, dg, db = torch.empty_like(t), self.new(C, dtype=torch.float32), self.new(C, dtype=torch.float32)
+        ws = self.new(self.L.cot_study_bn_nhwc_workspace(rows, C, BF), dtype=torch.float32)
+        _ok(self.L.cot_study_bn_nhwc_backward(_p(dy), _p(t), _p(y), _p(dx), _p(None), _p(mod.weight.detach()), _p(mod.bias.detach()), _p(st[0]),
+                                              _p(st[1]), _p(dg), _p(db), _p(ws), rows, C, act, BF, self.s), "bn bwd")
+        return dx, dg, db
+
+
+def forward(lib, plan, x, N, H, W, stream=None):
+    """x [N][H][W][D] bf16 contiguous -> (out [N*H*W][D], saved tensors for `backward`)"""
+    ly, D, G = plan.layer, plan.D, plan.G
+    HW, M = H * W, N * H * W
+    o = _Ops(lib, stream, x)
+    xm = x.reshape(M, D)
+    k_pre = o.new(M, D)
+    _ok(lib.cot_study_conv3x3g_nhwc(_p(x), _p(plan.wr), _p(plan.zeros), _p(k_pre), 0, N, H, W, D, D, plan.groups, stream), "conv3x3")
+    k, k_st = o.bn_f(k_pre, ly.key_embed[1], 1, M)
+    e0_pre = o.gemm(xm, k, D, plan.w_e0, None, M)                      # embed[0] on [x | k], no cat
+    e0, e0_st = o.bn_f(e0_pre, ly.embed[1], 1, M)
+    e3 = o.gemm(e0, None, e0.shape[1], plan.w_e3, ly.embed[3].bias.detach(), M)
+    gn = ly.embed[4]
+    wn, gm, gr = torch.empty_like(e3), o.new(N * G, dtype=torch.float32), o.new(N * G, dtype=torch.float32)
+    _ok(lib.cot_study_group_norm9_nhwc_forward(_p(e3), _p(gn.weight.detach()), _p(gn.bias.detach()), _p(wn), _p(gm), _p(gr), N, 9 * G, HW,
+                                               _F(gn.eps), BF, stream), "gn9")
+    v_pre = o.gemm(xm, None, D, plan.w_v, None, M)
+    v, v_st = o.bn_f(v_pre, ly.conv1x1[1], 0, M)
+    geo = _lib.AggGeom(N, D, H, W, 1, G, 3, 3, 1, 1, 1, 1, 1, 1)
+    agg = o.new(M, D)
+    _ok(lib.cot_agg_forward(_p(v), _p(wn), _p(agg), ctypes.byref(geo), BF, _lib.COT_NHWC, stream), "aggregation")
+    y, y_st = o.bn_f(agg, ly.bn, 2, M)
+    gap = o.new(N, D)
+    _ok(lib.cot_study_radix_nhwc_gap(_p(y), _p(k), _p(gap), N, HW, D, BF, stream), "radix gap")
+    s0_pre = o.gemm(gap, None, D, plan.w_s0, ly.se[0].bias.detach(), N)   # the `se` branch: GEMMs / BatchNorm on the [N][C] descriptor
+    s0, s0_st = o.bn_f(s0_pre, ly.se[1], 1, N)
+    logits = o.gemm(s0, None, s0.shape[1], plan.w_s3, ly.se[3].bias.detach(), N)
+    attn = torch.softmax(logits.float().view(N, D, 2), 2).to(torch.bfloat16).contiguous()   # (host-side op here; radix_tail.hip has it fused)
+    out = o.new(M, D)
+    _ok(lib.cot_study_radix_nhwc_mix(_p(y), _p(k), _p(attn), _p(out), N, HW, D, BF, stream), "radix mix")
+    saved = dict(x=x, xm=xm, k_pre=k_pre, k=k, k_st=k_st, e0_pre=e0_pre, e0=e0, e0_st=e0_st, e3=e3, wn=wn, gm=gm, gr=gr, v_pre=v_pre, v=v,
+                 v_st=v_st, agg=agg, y=y, y_st=y_st, gap=gap, s0_pre=s0_pre, s0=s0, s0_st=s0_st, attn=attn, geo=geo, N=N, H=H, W=W)
+    return out, saved
+
+
+def backward(lib, plan, sv, gout, stream=None):
+    """gout [N*H*W][D] -> (gx [N*H*W][D], {parameter name: gradient})"""
+    ly, D, G = plan.layer, plan.D, plan.G
+    N, H, W = sv["N"], sv["H"], sv["W"]
+    HW, M = H * W, N * H * W
+    o = _Ops(lib, stream, gout)
+    g = {}
+    gattn = o.new(N, D, 2)
+    _ok(lib.cot_study_radix_nhwc_mix_backward_reduce(_p(gout), _p(sv["y"]), _p(sv["k"]), _p(gattn), N, HW, D, BF, stream), "radix reduce")
+    af, gf = sv["attn"].float(), gattn.float()
+    glog = (af * (gf - (af * gf).sum(2, keepdim=True))).reshape(N, 2 * D).to(torch.bfloat16).contiguous()   # softmax backward (host-side op)
+    g["se.3.weight"], g["se.3.bias"] = o.wgrad(sv["s0"], glog, N), o.colsum(glog, N)
+    gs0 = o.gemm(glog, None, 2 * D, plan.w_s3_t, None, N)
+    gs0_pre, g["se.1.weight"], g["se.1.bias"] = o.bn_b(gs0, sv["s0_pre"], sv["s0"], sv["s0_st"], ly.se[1], 1, N)
+    g["se.0.weight"], g["se.0.bias"] = o.wgrad(sv["gap"], gs0_pre, N), o.colsum(gs0_pre, N)
+    ggap = o.gemm(gs0_pre, None, gs0_pre.shape[1], plan.w_s0_t, None, N)
+    gy, gk = o.new(M, D), o.new(M, D)
+    _ok(lib.cot_study_radix_nhwc_mix_backward_apply(_p(gout), _p(sv["attn"]), _p(ggap), _p(gy), _p(gk), N, HW, D, BF, stream), "radix apply")
+    gagg, g["bn.weight"], g["bn.bias"] = o.bn_b(gy, sv["agg"], None, sv["y_st"], ly.bn, 2, M)
+    gv, gwn = o.new(M, D), torch.empty_like(sv["wn"])
+    _ok(lib.cot_agg_backward(_p(gagg), _p(sv["v"]), _p(sv["wn"]), _p(gv), _p(gwn), ctypes.byref(sv["geo"]), BF, _lib.COT_NHWC, stream),
+        "aggregation backward")
+    gv_pre, g["conv1x1.1.weight"], g["conv1x1.1.bias"] = o.bn_b(gv, sv["v_pre"], None, sv["v_st"], ly.conv1x1[1], 0, M)
+    g["conv1x1.0.weight"] = o.wgrad(sv["xm"], gv_pre, M)
+    gx = o.gemm(gv_pre, None, D, plan.w_v_t, None, M)                                        # the values' branch starts gx
+    gn = ly.embed[4]
+    ge3, dgg, dgb = torch.empty_like(sv["e3"]), torch.empty_like(gn.weight.detach()), torch.empty_like(gn.bias.detach())
+    gws = o.new(N * 9 * G * 2, dtype=torch.float32)
+    _ok(lib.cot_study_group_norm9_nhwc_backward(_p(gwn), _p(sv["e3"]), _p(sv["gm"]), _p(sv["gr"]), _p(gn.weight.detach()), _p(ge3), _p(dgg),
+                                                _p(dgb), _p(gws), N, 9 * G, HW, BF, stream), "gn9 backward")
+    g["embed.4.weight"], g["embed.4.bias"] = dgg, dgb
+    g["embed.3.weight"], g["embed.3.bias"] = o.wgrad(sv["e0"], ge3, M), o.colsum(ge3, M)
+    ge0 = o.gemm(ge3, None, ge3.shape[1], plan.w_e3_t, None, M)
+    ge0_pre, g["embed.1.weight"], g["embed.1.bias"] = o.bn_b(ge0, sv["e0_pre"], sv["e0"], sv["e0_st"], ly.embed[1], 1, M)
+    g["embed.0.weight"] = torch.cat([o.wgrad(sv["xm"], ge0_pre, M), o.wgrad(sv["k"], ge0_pre, M)], 1)
+    o.gemm(ge0_pre, None, ge0_pre.shape[1], plan.w_e0x_t, None, M, y=gx, acc=1)              # gx += embed[0]'s [x | .] half
+    o.gemm(ge0_pre, None, ge0_pre.shape[1], plan.w_e0k_t, None, M, y=gk, acc=1)              # gk += its [. | k] half
+    gk_pre, g["key_embed.1.weight"], g["key_embed.1.bias"] = o.bn_b(gk, sv["k_pre"], sv["k"], sv["k_st"], ly.key_embed[1], 1, M)
+    Kc = D // plan.groups
+    ws3 = o.new(lib.cot_study_conv3x3g_nhwc_wgrad_workspace(N, H, W, D, D, plan.groups, 0), dtype=torch.uint8)
+    dwr = o.new(D, 9, Kc)
+    _ok(lib.cot_study_conv3x3g_nhwc_wgrad(_p(sv["x"]), _p(gk_pre), _p(plan.zeros), _p(dwr), _p(ws3), N, H, W, D, D, plan.groups, 0, stream),
+        "conv3x3 wgrad")
+    g["key_embed.0.weight"] = dwr.view(D, 3, 3, Kc).permute(0, 3, 1, 2)
+    _ok(lib.cot_study_conv3x3g_nhwc(_p(gk_pre), _p(plan.wr_t), _p(plan.zeros), _p(gx), 1, N, H, W, D, D, plan.groups, stream), "conv3x3 dgrad")
+    return gx, g

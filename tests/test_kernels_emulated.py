@@ -2923,109 +2923,15 @@ def test_layout_change_between_nchw_and_channels_last(N, C, HW):
     assert torch.equal(z, x)
 
 
-def test_cot_layer_forward_composed_from_the_channels_last_study_kernels():
-    """the whole CotLayer(256) forward (models/cotnet.py:79-104) on channels-last tensors, composed from the study kernels of DESIGN 5.8
-    -- grouped 3x3 and 1x1 convolutions on the K-contiguous GEMM ([x, k] as two slabs, bias), BatchNorm (+ ReLU / SiLU), GroupNorm-9,
-    the NHWC aggregation, radix tail with the `se` branch as the same GEMM / BatchNorm on the [N][C] descriptor -- against an fp32
-    evaluation of the same module's formula on the bf16-rounded parameters: the kernel set is functionally complete for a layer"""
+def _cl_layer_and_truth(seed, with_grad):
+    """a CotLayer(256) in bf16 with perturbed affine parameters, a channels-last input, and the module's formula in fp32 torch (NCHW)
+    on the rounded parameters -> (layer, x, N, H, W, intermediates of the truth, parameters of the truth, truth input)"""
     import cotnet_amd.cotnet as cn
     from cotnet_amd.flat_sgd import to_mixed_bf16
     F = torch.nn.functional
-    torch.manual_seed(11)
+    torch.manual_seed(seed)
     N, H, W, D = 4, 5, 4, 256
-    HW, M, dt = H * W, N * H * W, _lib.dtype_code(torch.bfloat16)
-    layer = cn.CotLayer(D, 3).train()
-    with torch.no_grad():
-        for p in layer.parameters():
-            if p.ndim == 1:
-                p.add_(0.2 * torch.randn_like(p))
-    layer = to_mixed_bf16(layer)
-    x = torch.randn(N, H, W, D).bfloat16()                       # channels-last input [M][D]
-    none, zeros = ctypes.c_void_p(None), torch.zeros(64).bfloat16()
-    f32 = ctypes.c_float
-
-    def conv(x1, x2, k1, conv_mod, rows):
-        w = conv_mod.weight.detach().reshape(conv_mod.out_channels, -1).contiguous()
-        b = conv_mod.bias.detach().contiguous() if conv_mod.bias is not None else None
-        y = torch.full((rows, w.shape[0]), float("nan")).bfloat16()
-        assert _EMUL.cot_study_conv1x1_nhwc(P(x1), P(x2) if x2 is not None else none, k1, P(w), P(b) if b is not None else none, P(y), 0,
-                                            rows, w.shape[0], w.shape[1], 0, None) == 0
-        return y
-
-    def bn(t, mod, act, rows):
-        C = t.shape[-1]
-        y, mean, rstd = torch.full_like(t, float("nan")), torch.empty(C), torch.empty(C)
-        ws = torch.empty(_EMUL.cot_study_bn_nhwc_workspace(rows, C, dt))
-        assert _EMUL.cot_study_bn_nhwc_forward(P(t), none, P(y), P(mod.weight.detach()), P(mod.bias.detach()), P(mean), P(rstd), none, none,
-                                               none, P(ws), rows, C, f32(mod.eps), f32(0.1), act, dt, None) == 0
-        return y
-
-    # ---- the layer on the study kernels
-    ke = layer.key_embed[0]
-    wr = ke.weight.detach().permute(0, 2, 3, 1).contiguous()     # [Co][3][3][Kc]
-    k = torch.full((M, D), float("nan")).bfloat16()
-    assert _EMUL.cot_study_conv3x3g_nhwc(P(x), P(wr), P(zeros), P(k), 0, N, H, W, D, D, 4, None) == 0
-    k = bn(k, layer.key_embed[1], 1, M)
-    xm = x.reshape(M, D)
-    e = bn(conv(xm, k, D, layer.embed[0], M), layer.embed[1], 1, M)
-    e = conv(e, None, e.shape[1], layer.embed[3], M)             # [M][9 * D / 8], bias
     G = D // 8
-    wn, gm, gr = torch.full_like(e, float("nan")), torch.empty(N * G), torch.empty(N * G)
-    gn = layer.embed[4]
-    assert _EMUL.cot_study_group_norm9_nhwc_forward(P(e), P(gn.weight.detach()), P(gn.bias.detach()), P(wn), P(gm), P(gr), N, 9 * G, HW,
-                                                    f32(gn.eps), dt, None) == 0
-    v = bn(conv(xm, None, D, layer.conv1x1[0], M), layer.conv1x1[1], 0, M)
-    geo = _lib.AggGeom(N, D, H, W, 1, G, 3, 3, 1, 1, 1, 1, 1, 1)
-    agg = torch.full((M, D), float("nan")).bfloat16()
-    assert _EMUL.cot_agg_forward(P(v), P(wn), P(agg), ctypes.byref(geo), dt, 1, None) == 0, _EMUL.cot_last_error()
-    y = bn(agg, layer.bn, 2, M)
-    gap = torch.full((N, D), float("nan")).bfloat16()
-    assert _EMUL.cot_study_radix_nhwc_gap(P(y), P(k), P(gap), N, HW, D, dt, None) == 0
-    s0 = bn(conv(gap, None, D, layer.se[0], N), layer.se[1], 1, N)
-    logits = conv(s0, None, s0.shape[1], layer.se[3], N)        # [N][2 * D] = [N][D][2]
-    attn = torch.softmax(logits.float().view(N, D, 2), 2).bfloat16().contiguous()
-    out = torch.full((M, D), float("nan")).bfloat16()
-    assert _EMUL.cot_study_radix_nhwc_mix(P(y), P(k), P(attn), P(out), N, HW, D, dt, None) == 0
-
-    # ---- the same formula in fp32 torch on the rounded parameters (NCHW)
-    def tbn(t, mod):
-        return F.batch_norm(t, None, None, mod.weight.float(), mod.bias.float(), True, 0.1, mod.eps)
-    xt = x.float().permute(0, 3, 1, 2)
-    kt = torch.relu(tbn(F.conv2d(xt, ke.weight.float(), None, 1, 1, 1, 4), layer.key_embed[1]))
-    et = torch.relu(tbn(F.conv2d(torch.cat([xt, kt], 1), layer.embed[0].weight.float()), layer.embed[1]))
-    et = F.group_norm(F.conv2d(et, layer.embed[3].weight.float(), layer.embed[3].bias.float()), G, gn.weight.float(), gn.bias.float(), gn.eps)
-    vt = tbn(F.conv2d(xt, layer.conv1x1[0].weight.float()), layer.conv1x1[1])
-    at = cref.forward(vt.contiguous(), et.reshape(N, 1, G, 9, H, W).contiguous(), 3, 1, 1, 1)
-    yt = F.silu(tbn(at, layer.bn))
-    gt = (yt + kt).mean((2, 3), keepdim=True)
-    st = F.conv2d(torch.relu(tbn(F.conv2d(gt, layer.se[0].weight.float(), layer.se[0].bias.float()), layer.se[1])),
-                  layer.se[3].weight.float(), layer.se[3].bias.float())
-    a_t = torch.softmax(st.view(N, D, 2), 2)
-    ot = yt * a_t[:, :, 0, None, None] + kt * a_t[:, :, 1, None, None]
-
-    def rel(a, b):   # a: channels-last [M][C], b: NCHW
-        b = b.permute(0, 2, 3, 1).reshape(a.shape)
-        return ((a.float() - b).abs().mean() / b.abs().mean()).item()
-
-    # measured: 0.002 / 0.003 / 0.002 / 0.005 / 0.004 (bf16 rounding of every intermediate); a wiring error gives O(1)
-    assert rel(k, kt) < 6e-3 and rel(wn, et) < 1e-2 and rel(v, vt) < 6e-3 and rel(y, yt) < 1.5e-2, (rel(k, kt), rel(wn, et), rel(v, vt), rel(y, yt))
-    assert rel(out, ot) < 2e-2, rel(out, ot)
-
-
-def test_cot_layer_backward_composed_from_the_channels_last_study_kernels():
-    """the CotLayer(256) BACKWARD on channels-last tensors, composed from the study kernels in the order a node would
-    issue them: radix tail (column sums, then the element-wise half with the pooled descriptor's gradient), the `se` branch as GEMMs /
-    BatchNorm on [N][C], BatchNorm / GroupNorm-9 backwards, the NHWC aggregation backward, data gradients as the forward GEMM on
-    transposed weights (accumulating where branches join), weight gradients, bias gradients as column sums -- every input and
-    parameter gradient against autograd on the module's formula in fp32"""
-    import cotnet_amd.cotnet as cn
-    from cotnet_amd.flat_sgd import to_mixed_bf16
-    F = torch.nn.functional
-    _EMUL.cot_study_conv1x1_nhwc_wgrad_workspace.restype = ctypes.c_size_t
-    _EMUL.cot_study_conv3x3g_nhwc_wgrad_workspace.restype = ctypes.c_size_t
-    torch.manual_seed(12)
-    N, H, W, D = 4, 5, 4, 256
-    HW, M, G, dt = H * W, N * H * W, D // 8, _lib.dtype_code(torch.bfloat16)
     layer = cn.CotLayer(D, 3).train()
     with torch.no_grad():
         for p in layer.parameters():
@@ -3033,121 +2939,14 @@ def test_cot_layer_backward_composed_from_the_channels_last_study_kernels():
                 p.add_(0.2 * torch.randn_like(p))
     layer = to_mixed_bf16(layer)
     x = torch.randn(N, H, W, D).bfloat16()
-    gout = torch.randn(M, D).bfloat16()
-    none, zeros, f32 = ctypes.c_void_p(None), torch.zeros(64).bfloat16(), ctypes.c_float
-    nan = lambda *shape: torch.full(shape, float("nan")).bfloat16()  # noqa: E731
-
-    def w2(conv_mod):
-        return conv_mod.weight.detach().reshape(conv_mod.out_channels, -1).contiguous()
-
-    def gemm(x1, x2, k1, w, b, rows, y=None, acc=0):
-        y = nan(rows, w.shape[0]) if y is None else y
-        assert _EMUL.cot_study_conv1x1_nhwc(P(x1), P(x2) if x2 is not None else none, k1, P(w), P(b) if b is not None else none, P(y), acc,
-                                            rows, w.shape[0], w.shape[1], 0, None) == 0
-        return y
-
-    def wgrad(xin, dy, rows):
-        Ci, Co = xin.shape[1], dy.shape[1]
-        ws = torch.empty(_EMUL.cot_study_conv1x1_nhwc_wgrad_workspace(rows, Ci, Co, 0), dtype=torch.uint8)
-        dw = nan(Co, Ci)
-        assert _EMUL.cot_study_conv1x1_nhwc_wgrad(P(xin), P(dy), P(dw), P(ws), rows, Ci, Co, 0, None) == 0
-        return dw
-
-    def colsum(t, rows):
-        o = nan(t.shape[1])
-        assert _EMUL.cot_study_nhwc_col_sum(P(t), P(o), rows, t.shape[1], dt, None) == 0
-        return o
-
-    def bn_f(t, mod, act, rows):
-        C = t.shape[-1]
-        y, mean, rstd = torch.full_like(t, float("nan")), torch.empty(C), torch.empty(C)
-        ws = torch.empty(_EMUL.cot_study_bn_nhwc_workspace(rows, C, dt))
-        assert _EMUL.cot_study_bn_nhwc_forward(P(t), none, P(y), P(mod.weight.detach()), P(mod.bias.detach()), P(mean), P(rstd), none, none,
-                                               none, P(ws), rows, C, f32(mod.eps), f32(0.1), act, dt, None) == 0
-        return y, (mean, rstd)
-
-    def bn_b(dy, t, y, st, mod, act, rows):
-        C = t.shape[-1]
-        dx, dg, db = torch.full_like(t, float("nan")), torch.empty(C), torch.empty(C)
-        ws = torch.empty(_EMUL.cot_study_bn_nhwc_workspace(rows, C, dt))
-        assert _EMUL.cot_study_bn_nhwc_backward(P(dy), P(t), P(y) if y is not None else none, P(dx), none, P(mod.weight.detach()),
-                                                P(mod.bias.detach()), P(st[0]), P(st[1]), P(dg), P(db), P(ws), rows, C, act, dt, None) == 0
-        return dx, dg, db
-
-    # ---- forward (as in the forward test), keeping what the backward reads
-    ke, gn = layer.key_embed[0], layer.embed[4]
-    wr = ke.weight.detach().permute(0, 2, 3, 1).contiguous()
-    k_pre = nan(M, D)
-    assert _EMUL.cot_study_conv3x3g_nhwc(P(x), P(wr), P(zeros), P(k_pre), 0, N, H, W, D, D, 4, None) == 0
-    k, k_st = bn_f(k_pre, layer.key_embed[1], 1, M)
-    xm = x.reshape(M, D)
-    e0_pre = gemm(xm, k, D, w2(layer.embed[0]), None, M)
-    e0, e0_st = bn_f(e0_pre, layer.embed[1], 1, M)
-    e3 = gemm(e0, None, e0.shape[1], w2(layer.embed[3]), layer.embed[3].bias.detach(), M)
-    wn, gm, gr = torch.full_like(e3, float("nan")), torch.empty(N * G), torch.empty(N * G)
-    assert _EMUL.cot_study_group_norm9_nhwc_forward(P(e3), P(gn.weight.detach()), P(gn.bias.detach()), P(wn), P(gm), P(gr), N, 9 * G, HW,
-                                                    f32(gn.eps), dt, None) == 0
-    v_pre = gemm(xm, None, D, w2(layer.conv1x1[0]), None, M)
-    v, v_st = bn_f(v_pre, layer.conv1x1[1], 0, M)
-    geo = _lib.AggGeom(N, D, H, W, 1, G, 3, 3, 1, 1, 1, 1, 1, 1)
-    agg = nan(M, D)
-    assert _EMUL.cot_agg_forward(P(v), P(wn), P(agg), ctypes.byref(geo), dt, 1, None) == 0
-    y, y_st = bn_f(agg, layer.bn, 2, M)
-    gap = nan(N, D)
-    assert _EMUL.cot_study_radix_nhwc_gap(P(y), P(k), P(gap), N, HW, D, dt, None) == 0
-    s0_pre = gemm(gap, None, D, w2(layer.se[0]), layer.se[0].bias.detach(), N)
-    s0, s0_st = bn_f(s0_pre, layer.se[1], 1, N)
-    logits = gemm(s0, None, s0.shape[1], w2(layer.se[3]), layer.se[3].bias.detach(), N)
-    attn = torch.softmax(logits.float().view(N, D, 2), 2).bfloat16().contiguous()
-
-    # ---- backward
-    grads = {}
-    gattn = nan(N, D, 2)
-    assert _EMUL.cot_study_radix_nhwc_mix_backward_reduce(P(gout), P(y), P(k), P(gattn), N, HW, D, dt, None) == 0
-    af, gf = attn.float(), gattn.float()
-    glog = (af * (gf - (af * gf).sum(2, keepdim=True))).reshape(N, 2 * D).bfloat16().contiguous()     # softmax backward (host side)
-    grads["se.3.weight"], grads["se.3.bias"] = wgrad(s0, glog, N), colsum(glog, N)
-    gs0 = gemm(glog, None, 2 * D, w2(layer.se[3]).t().contiguous(), None, N)
-    gs0_pre, grads["se.1.weight"], grads["se.1.bias"] = bn_b(gs0, s0_pre, s0, s0_st, layer.se[1], 1, N)
-    grads["se.0.weight"], grads["se.0.bias"] = wgrad(gap, gs0_pre, N), colsum(gs0_pre, N)
-    ggap = gemm(gs0_pre, None, gs0_pre.shape[1], w2(layer.se[0]).t().contiguous(), None, N)
-    gy, gk = nan(M, D), nan(M, D)
-    assert _EMUL.cot_study_radix_nhwc_mix_backward_apply(P(gout), P(attn), P(ggap), P(gy), P(gk), N, HW, D, dt, None) == 0
-    gagg, grads["bn.weight"], grads["bn.bias"] = bn_b(gy, agg, None, y_st, layer.bn, 2, M)
-    gv, gwn = nan(M, D), torch.full_like(wn, float("nan"))
-    assert _EMUL.cot_agg_backward(P(gagg), P(v), P(wn), P(gv), P(gwn), ctypes.byref(geo), dt, 1, None) == 0
-    gv_pre, grads["conv1x1.1.weight"], grads["conv1x1.1.bias"] = bn_b(gv, v_pre, None, v_st, layer.conv1x1[1], 0, M)
-    grads["conv1x1.0.weight"] = wgrad(xm, gv_pre, M)
-    gx = gemm(gv_pre, None, D, w2(layer.conv1x1[0]).t().contiguous(), None, M)                       # gx  = branch of the values
-    ge3, dgg, dgb = torch.full_like(e3, float("nan")), torch.full_like(gn.weight.detach(), float("nan")), torch.full_like(gn.bias.detach(), float("nan"))
-    gws = torch.empty(N * 9 * G * 2)
-    assert _EMUL.cot_study_group_norm9_nhwc_backward(P(gwn), P(e3), P(gm), P(gr), P(gn.weight.detach()), P(ge3), P(dgg), P(dgb), P(gws), N,
-                                                     9 * G, HW, dt, None) == 0
-    grads["embed.4.weight"], grads["embed.4.bias"] = dgg, dgb
-    grads["embed.3.weight"], grads["embed.3.bias"] = wgrad(e0, ge3, M), colsum(ge3, M)
-    ge0 = gemm(ge3, None, ge3.shape[1], w2(layer.embed[3]).t().contiguous(), None, M)
-    ge0_pre, grads["embed.1.weight"], grads["embed.1.bias"] = bn_b(ge0, e0_pre, e0, e0_st, layer.embed[1], 1, M)
-    grads["embed.0.weight"] = torch.cat([wgrad(xm, ge0_pre, M), wgrad(k, ge0_pre, M)], 1)
-    we0 = w2(layer.embed[0])
-    gemm(ge0_pre, None, ge0_pre.shape[1], we0[:, :D].t().contiguous(), None, M, y=gx, acc=1)         # gx += the [x | .] half of embed[0]
-    gemm(ge0_pre, None, ge0_pre.shape[1], we0[:, D:].t().contiguous(), None, M, y=gk, acc=1)         # gk += the [. | k] half
-    gk_pre, grads["key_embed.1.weight"], grads["key_embed.1.bias"] = bn_b(gk, k_pre, k, k_st, layer.key_embed[1], 1, M)
-    ws3 = torch.empty(_EMUL.cot_study_conv3x3g_nhwc_wgrad_workspace(N, H, W, D, D, 4, 0), dtype=torch.uint8)
-    dwr = nan(D, 9, D // 4)
-    assert _EMUL.cot_study_conv3x3g_nhwc_wgrad(P(x), P(gk_pre), P(zeros), P(dwr), P(ws3), N, H, W, D, D, 4, 0, None) == 0
-    grads["key_embed.0.weight"] = dwr.view(D, 3, 3, D // 4).permute(0, 3, 1, 2)
-    wt = ke.weight.detach().view(4, D // 4, D // 4, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(D, 3, 3, D // 4).contiguous()
-    assert _EMUL.cot_study_conv3x3g_nhwc(P(gk_pre), P(wt), P(zeros), P(gx), 1, N, H, W, D, D, 4, None) == 0   # gx += key embedding
-
-    # ---- autograd on the module's formula in fp32 (NCHW), parameters rounded as the kernels see them
-    prm = {n_: p.detach().float().requires_grad_(True) for n_, p in layer.named_parameters()}
+    prm = {n_: p.detach().float().requires_grad_(with_grad) for n_, p in layer.named_parameters()}
 
     def tbn(t, name):
         return F.batch_norm(t, None, None, prm[name + ".weight"], prm[name + ".bias"], True, 0.1, 1e-5)
-    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(with_grad)
     kt = torch.relu(tbn(F.conv2d(xt, prm["key_embed.0.weight"], None, 1, 1, 1, 4), "key_embed.1"))
     et = torch.relu(tbn(F.conv2d(torch.cat([xt, kt], 1), prm["embed.0.weight"]), "embed.1"))
-    et = F.group_norm(F.conv2d(et, prm["embed.3.weight"], prm["embed.3.bias"]), G, prm["embed.4.weight"], prm["embed.4.bias"], gn.eps)
+    et = F.group_norm(F.conv2d(et, prm["embed.3.weight"], prm["embed.3.bias"]), G, prm["embed.4.weight"], prm["embed.4.bias"], layer.embed[4].eps)
     vt = tbn(F.conv2d(xt, prm["conv1x1.0.weight"]), "conv1x1.1")
     at = unfold_oracle.aggregation_unfold(vt, et.reshape(N, 1, G, 9, H, W), 3, 1, 1, 1)
     yt = F.silu(tbn(at, "bn"))
@@ -3155,7 +2954,40 @@ def test_cot_layer_backward_composed_from_the_channels_last_study_kernels():
     st = F.conv2d(torch.relu(tbn(F.conv2d(gt, prm["se.0.weight"], prm["se.0.bias"]), "se.1")), prm["se.3.weight"], prm["se.3.bias"])
     a_t = torch.softmax(st.view(N, D, 2), 2)
     ot = yt * a_t[:, :, 0, None, None] + kt * a_t[:, :, 1, None, None]
-    ot.backward(gout.float().view(N, H, W, D).permute(0, 3, 1, 2))
+    return layer, x, (N, H, W), dict(k=kt, wn=et, v=vt, y=yt, out=ot), prm, xt
+
+
+def test_cot_layer_forward_composed_from_the_channels_last_study_kernels():
+    """the whole CotLayer(256) forward (models/cotnet.py:79-104) on channels-last tensors as cotnet_amd.channels_last_study issues it
+    on the study kernels of DESIGN 5.8 -- grouped 3x3 and 1x1 convolutions on the K-contiguous GEMM ([x, k] as two slabs, bias),
+    BatchNorm (+ ReLU / SiLU), GroupNorm-9, the NHWC aggregation, radix tail with the `se` branch as the same GEMM / BatchNorm on the
+    [N][C] descriptor -- against an fp32 evaluation of the module's formula on the bf16-rounded parameters"""
+    from cotnet_amd import channels_last_study as cls
+    layer, x, (N, H, W), truth_t, _, _ = _cl_layer_and_truth(11, False)
+    out, sv = cls.forward(_EMUL, cls.Plan(layer), x, N, H, W)
+
+    def rel(a, b):   # a: channels-last [M][C], b: NCHW
+        b = b.permute(0, 2, 3, 1).reshape(a.shape)
+        return ((a.float() - b).abs().mean() / b.abs().mean()).item()
+    errs = [rel(sv["k"], truth_t["k"]), rel(sv["wn"], truth_t["wn"]), rel(sv["v"], truth_t["v"]), rel(sv["y"], truth_t["y"]), rel(out, truth_t["out"])]
+    # measured: 0.002 / 0.003 / 0.002 / 0.005 / 0.004 (bf16 rounding of every intermediate); a wiring error gives O(1)
+    assert errs[0] < 6e-3 and errs[1] < 1e-2 and errs[2] < 6e-3 and errs[3] < 1.5e-2 and errs[4] < 2e-2, errs
+
+
+def test_cot_layer_backward_composed_from_the_channels_last_study_kernels():
+    """the CotLayer(256) BACKWARD on channels-last tensors in the order a node would issue it (cotnet_amd.channels_last_study): radix
+    tail (column sums, then the element-wise half with the pooled descriptor's gradient), the `se` branch as GEMMs / BatchNorm on
+    [N][C], BatchNorm / GroupNorm-9 backwards, the NHWC aggregation backward, data gradients as the forward GEMM on transposed weights
+    (accumulating where branches join), weight gradients, bias gradients as column sums -- the input gradient and every parameter
+    gradient against autograd on the module's formula in fp32"""
+    from cotnet_amd import channels_last_study as cls
+    layer, x, (N, H, W), truth_t, prm, xt = _cl_layer_and_truth(12, True)
+    M, D = N * H * W, 256
+    gout = torch.randn(M, D).bfloat16()
+    plan = cls.Plan(layer)
+    _, sv = cls.forward(_EMUL, plan, x, N, H, W)
+    gx, grads = cls.backward(_EMUL, plan, sv, gout)
+    truth_t["out"].backward(gout.float().view(N, H, W, D).permute(0, 3, 1, 2))
 
     def rel(a, b):
         a, b = a.float().reshape(-1), b.float().reshape(-1)
@@ -3166,6 +2998,5 @@ def test_cot_layer_backward_composed_from_the_channels_last_study_kernels():
         assert n_ in grads, n_
         if p.grad.abs().max().item() > 1e-3 * top and n_ != "se.0.bias":  # (a bias in front of a BatchNorm: true gradient zero)
             errs[n_] = rel(grads[n_].reshape(p.shape), p.grad)
-    worst = max(errs.values())
     # measured: 0.006 .. 0.032 over the input and the 20 parameter gradients (bf16 chain, four-sample `se` BatchNorm); a missing term gives > 0.3
-    assert worst < 6e-2, sorted(errs.items(), key=lambda t: -t[1])[:6]
+    assert len(errs) == 21 and max(errs.values()) < 6e-2, sorted(errs.items(), key=lambda t: -t[1])[:6]
