@@ -172,3 +172,75 @@ def backward(lib, plan, sv, gout, stream=None):
     g["key_embed.0.weight"] = dwr.view(D, 3, 3, Kc).permute(0, 3, 1, 2)
     _ok(lib.cot_study_conv3x3g_nhwc(_p(gk_pre), _p(plan.wr_t), _p(plan.zeros), _p(gx), 1, N, H, W, D, D, plan.groups, stream), "conv3x3 dgrad")
     return gx, g
+
+
+# ---- the stride-1 Bottleneck without a projection (models/cotnet.py:228-264; five of layer3's six blocks, two of layer4's three) ----------
+class BlockPlan:
+    def __init__(self, blk):
+        assert blk.downsample is None and blk.avd is None and blk.se is None and blk.drop_block is None and blk.drop_path is None
+        self.blk = blk
+        self.layer = Plan(blk.conv2)
+        self.w1 = blk.conv1.weight.detach().reshape(blk.conv1.out_channels, -1).contiguous()
+        self.w3 = blk.conv3.weight.detach().reshape(blk.conv3.out_channels, -1).contiguous()
+        self.w1_t, self.w3_t = self.w1.t().contiguous(), self.w3.t().contiguous()
+
+
+def block_forward(lib, plan, x, N, H, W, stream=None):
+    """x [N][H][W][C] -> (out [N*H*W][C], saved)"""
+    blk, M = plan.blk, N * H * W
+    o = _Ops(lib, stream, x)
+    xm = x.reshape(M, x.shape[-1])
+    t1_pre = o.gemm(xm, None, xm.shape[1], plan.w1, None, M)
+    t1, t1_st = o.bn_f(t1_pre, blk.bn1, 1, M)
+    t2, sv = forward(lib, plan.layer, t1.view(N, H, W, -1), N, H, W, stream)
+    t3_pre = o.gemm(t2, None, t2.shape[1], plan.w3, None, M)
+    C = t3_pre.shape[1]
+    out, mean, rstd = torch.empty_like(t3_pre), o.new(C, dtype=torch.float32), o.new(C, dtype=torch.float32)
+    ws = o.new(lib.cot_study_bn_nhwc_workspace(M, C, BF), dtype=torch.float32)
+    _ok(lib.cot_study_bn_nhwc_forward(_p(t3_pre), _p(xm), _p(out), _p(blk.bn3.weight.detach()), _p(blk.bn3.bias.detach()), _p(mean), _p(rstd),
+                                      _p(None), _p(None), _p(None), _p(ws), M, C, _F(blk.bn3.eps), _F(0.1), 1, BF, stream), "bn3 + residual")
+    return out, dict(xm=xm, t1_pre=t1_pre, t1=t1, t1_st=t1_st, layer=sv, t2=t2, t3_pre=t3_pre, out=out, st3=(mean, rstd), N=N, H=H, W=W)
+
+
+def block_backward(lib, plan, sv, gout, stream=None):
+    """-> (gx [N*H*W][C], {parameter name: gradient})"""
+    blk = plan.blk
+    N, H, W = sv["N"], sv["H"], sv["W"]
+    M = N * H * W
+    o = _Ops(lib, stream, gout)
+    g = {}
+    C = gout.shape[1]
+    g3, gx, dg, db = torch.empty_like(gout), torch.empty_like(gout), o.new(C, dtype=torch.float32), o.new(C, dtype=torch.float32)
+    ws = o.new(lib.cot_study_bn_nhwc_workspace(M, C, BF), dtype=torch.float32)
+    _ok(lib.cot_study_bn_nhwc_backward(_p(gout), _p(sv["t3_pre"]), _p(sv["out"]), _p(g3), _p(gx), _p(blk.bn3.weight.detach()),
+                                       _p(blk.bn3.bias.detach()), _p(sv["st3"][0]), _p(sv["st3"][1]), _p(dg), _p(db), _p(ws), M, C, 1, BF, stream),
+        "bn3 backward")                                                         # gx = the shortcut's share (dresidual)
+    g["bn3.weight"], g["bn3.bias"] = dg, db
+    g["conv3.weight"] = o.wgrad(sv["t2"], g3, M)
+    g2 = o.gemm(g3, None, C, plan.w3_t, None, M)
+    g1, lg = backward(lib, plan.layer, sv["layer"], g2, stream)
+    g.update({"conv2." + k: v for k, v in lg.items()})
+    g1_pre, g["bn1.weight"], g["bn1.bias"] = o.bn_b(g1, sv["t1_pre"], sv["t1"], sv["t1_st"], blk.bn1, 1, M)
+    g["conv1.weight"] = o.wgrad(sv["xm"], g1_pre, M)
+    o.gemm(g1_pre, None, g1_pre.shape[1], plan.w1_t, None, M, y=gx, acc=1)      # gx += the branch
+    return gx, g
+
+
+class BottleneckCL(torch.autograd.Function):
+    """out = BottleneckCL.apply(lib, plan, x_channels_last, *parameters): the block as ONE autograd node on channels-last tensors; the
+    parameters (in `plan.blk.named_parameters()` order) are arguments only so that autograd routes their gradients"""
+
+    @staticmethod
+    def forward(ctx, lib, plan, x, *params):
+        N, H, W, _ = x.shape
+        out, sv = block_forward(lib, plan, x.contiguous(), N, H, W)
+        ctx.lib, ctx.plan, ctx.sv = lib, plan, sv
+        return out.view(N, H, W, -1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        sv = ctx.sv
+        M = sv["N"] * sv["H"] * sv["W"]
+        gx, g = block_backward(ctx.lib, ctx.plan, sv, gout.contiguous().view(M, -1))
+        names = [n for n, _ in ctx.plan.blk.named_parameters()]
+        return (None, None, gx.view(gout.shape)) + tuple(g[n].reshape(p.shape).to(p.dtype) for n, p in zip(names, ctx.plan.blk.parameters()))
