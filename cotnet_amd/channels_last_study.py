@@ -244,3 +244,71 @@ class BottleneckCL(torch.autograd.Function):
         gx, g = block_backward(ctx.lib, ctx.plan, sv, gout.contiguous().view(M, -1))
         names = [n for n, _ in ctx.plan.blk.named_parameters()]
         return (None, None, gx.view(gout.shape)) + tuple(g[n].reshape(p.shape).to(p.dtype) for n, p in zip(names, ctx.plan.blk.parameters()))
+
+
+# ---- routing a stage (nn.Sequential of Bottlenecks, NCHW in / NCHW out) through the channels-last node where it applies ------------------
+class _ToCL(torch.autograd.Function):
+    """[N][C][H][W] -> [N][H][W][C] (csrc/layout_nhwc.hip); the gradient takes the way back"""
+
+    @staticmethod
+    def forward(ctx, lib, x):
+        N, C, H, W = x.shape
+        x = x.contiguous()  # (kept in a name: the pointer handed to the library must outlive the call)
+        y = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+        _ok(lib.cot_study_nchw_to_nhwc(_p(x), _p(y), N, C, H * W, None), "nchw_to_nhwc")
+        ctx.lib = lib
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W, C = g.shape
+        g = g.contiguous()
+        gx = torch.empty((N, C, H, W), dtype=g.dtype, device=g.device)
+        _ok(ctx.lib.cot_study_nhwc_to_nchw(_p(g), _p(gx), N, C, H * W, None), "nhwc_to_nchw")
+        return None, gx
+
+
+class _FromCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lib, x):
+        N, H, W, C = x.shape
+        x = x.contiguous()
+        y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
+        _ok(lib.cot_study_nhwc_to_nchw(_p(x), _p(y), N, C, H * W, None), "nhwc_to_nchw")
+        ctx.lib = lib
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = g.shape
+        g = g.contiguous()
+        gx = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
+        _ok(ctx.lib.cot_study_nchw_to_nhwc(_p(g), _p(gx), N, C, H * W, None), "nchw_to_nhwc")
+        return None, gx
+
+
+def block_eligible(blk, x):
+    """the stride-1 CoT Bottleneck in training mode, bf16, at widths the study kernels cover (CoTNet-50's layer3 / layer4: 256 / 512)"""
+    from .cotnet import Bottleneck, CotLayer
+    if not (isinstance(blk, Bottleneck) and isinstance(blk.conv2, CotLayer) and blk.training and torch.is_grad_enabled()):
+        return False
+    if blk.downsample is not None or blk.avd is not None or blk.se is not None or blk.drop_block is not None or blk.drop_path is not None:
+        return False
+    D = blk.conv2.dim
+    return (x.dtype == torch.bfloat16 and blk.conv1.weight.dtype == torch.bfloat16 and blk.conv1.in_channels % 32 == 0 and D % 256 == 0
+            and D <= 2048 and blk.conv2.key_embed[0].groups == 4 and isinstance(blk.act1, torch.nn.ReLU) and isinstance(blk.act3, torch.nn.ReLU))
+
+
+def run_stage(lib, stage, x):
+    """stage(x) with every run of consecutive eligible blocks on BottleneckCL between two layout changes; the other blocks as they are"""
+    cl = False
+    for blk in stage:
+        if block_eligible(blk, x if not cl else x.permute(0, 3, 1, 2)):
+            if not cl:
+                x, cl = _ToCL.apply(lib, x), True
+            x = BottleneckCL.apply(lib, BlockPlan(blk), x, *blk.parameters())
+        else:
+            if cl:
+                x, cl = _FromCL.apply(lib, x), False
+            x = blk(x)
+    return _FromCL.apply(lib, x) if cl else x

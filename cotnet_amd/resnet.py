@@ -6,6 +6,7 @@ act1, maxpool, layer1..4, global_pool, fc; blocks as nn.Sequential children "0",
 reference's, so state_dict keys are identical.  DropBlock is not provided (drop_block_rate must be 0 --
 every CoT recipe leaves it at 0).
 """
+import os
 import torch.nn.functional as F
 from torch import nn
 
@@ -187,7 +188,13 @@ class ResNet(nn.Module):
         cot_layer_fused.prepare_drop_path(self, x)  # (single-node blocks: one vectorised stochastic-depth draw per step)
         x = stem_forward(self.conv1, self.bn1, self.act1, x)  # stem BN + ReLU in one pass over 112x112
         x = pool(self.maxpool, x)
-        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.layer2(self.layer1(x))
+        if os.environ.get("COT_CHANNELS_LAST_STUDY", "0") == "1":
+            # STUDY switch (default off): the stride-1 blocks of the 14 x 14 / 7 x 7 stages as channels-last nodes on the
+            # study kernels, a layout change either side of each run of them
+            from . import _lib, channels_last_study
+            return channels_last_study.run_stage(_lib.lib(), self.layer4, channels_last_study.run_stage(_lib.lib(), self.layer3, x))
+        return self.layer4(self.layer3(x))
 
     def forward(self, x):
         x = self.forward_features(x)
