@@ -20,6 +20,11 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(None)
 
 
+def _stream(t):
+    """the launch stream for tensors like `t`: torch's current stream on the GPU, none for the host emulator's CPU tensors"""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else None
+
+
 def _ok(rc, what):
     if rc != 0:
         raise RuntimeError(f"cotnet_amd channels-last study: {what} returned {rc}")
@@ -233,7 +238,7 @@ class BottleneckCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lib, plan, x, *params):
         N, H, W, _ = x.shape
-        out, sv = block_forward(lib, plan, x.contiguous(), N, H, W)
+        out, sv = block_forward(lib, plan, x.contiguous(), N, H, W, _stream(x))
         ctx.lib, ctx.plan, ctx.sv = lib, plan, sv
         return out.view(N, H, W, -1)
 
@@ -241,7 +246,7 @@ class BottleneckCL(torch.autograd.Function):
     def backward(ctx, gout):
         sv = ctx.sv
         M = sv["N"] * sv["H"] * sv["W"]
-        gx, g = block_backward(ctx.lib, ctx.plan, sv, gout.contiguous().view(M, -1))
+        gx, g = block_backward(ctx.lib, ctx.plan, sv, gout.contiguous().view(M, -1), _stream(gout))
         names = [n for n, _ in ctx.plan.blk.named_parameters()]
         return (None, None, gx.view(gout.shape)) + tuple(g[n].reshape(p.shape).to(p.dtype) for n, p in zip(names, ctx.plan.blk.parameters()))
 
@@ -255,7 +260,7 @@ class _ToCL(torch.autograd.Function):
         N, C, H, W = x.shape
         x = x.contiguous()  # (kept in a name: the pointer handed to the library must outlive the call)
         y = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
-        _ok(lib.cot_study_nchw_to_nhwc(_p(x), _p(y), N, C, H * W, None), "nchw_to_nhwc")
+        _ok(lib.cot_study_nchw_to_nhwc(_p(x), _p(y), N, C, H * W, _stream(x)), "nchw_to_nhwc")
         ctx.lib = lib
         return y
 
@@ -264,7 +269,7 @@ class _ToCL(torch.autograd.Function):
         N, H, W, C = g.shape
         g = g.contiguous()
         gx = torch.empty((N, C, H, W), dtype=g.dtype, device=g.device)
-        _ok(ctx.lib.cot_study_nhwc_to_nchw(_p(g), _p(gx), N, C, H * W, None), "nhwc_to_nchw")
+        _ok(ctx.lib.cot_study_nhwc_to_nchw(_p(g), _p(gx), N, C, H * W, _stream(g)), "nhwc_to_nchw")
         return None, gx
 
 
@@ -274,7 +279,7 @@ class _FromCL(torch.autograd.Function):
         N, H, W, C = x.shape
         x = x.contiguous()
         y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device)
-        _ok(lib.cot_study_nhwc_to_nchw(_p(x), _p(y), N, C, H * W, None), "nhwc_to_nchw")
+        _ok(lib.cot_study_nhwc_to_nchw(_p(x), _p(y), N, C, H * W, _stream(x)), "nhwc_to_nchw")
         ctx.lib = lib
         return y
 
@@ -283,7 +288,7 @@ class _FromCL(torch.autograd.Function):
         N, C, H, W = g.shape
         g = g.contiguous()
         gx = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
-        _ok(ctx.lib.cot_study_nchw_to_nhwc(_p(g), _p(gx), N, C, H * W, None), "nchw_to_nhwc")
+        _ok(ctx.lib.cot_study_nchw_to_nhwc(_p(g), _p(gx), N, C, H * W, _stream(g)), "nchw_to_nhwc")
         return None, gx
 
 
