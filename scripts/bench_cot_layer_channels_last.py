@@ -80,3 +80,36 @@ for H, D in ((14, 256), (7, 512)):
         print(f"CotLayer({D}) at {H}x{H}, B = {N}, fwd + bwd, {name}: kernels {total:.3f} ms in {n} launches; wall {wall_ms(fn):.3f} ms / iteration")
         for k, v in by.most_common(8):
             print(f"      {v:7.3f} ms  {k}")
+
+# the whole stride-1 Bottleneck: BottleneckCL (one node on channels-last tensors) beside the product's _BottleneckNode
+from cotnet_amd.cotnet import Bottleneck  # noqa: E402
+
+for H, cin, planes in ((14, 1024, 256), (7, 2048, 512)):
+    torch.manual_seed(cin)
+    blk = Bottleneck(cin, planes).to(dev).train()
+    with torch.no_grad():
+        blk.bn3.weight.fill_(0.8)
+    blk = to_mixed_bf16(blk)
+    bplan = cls.BlockPlan(blk)
+    x_cl = torch.randn(N, H, H, cin, device=dev).bfloat16().requires_grad_(True)
+    g_cl = torch.randn(N, H, H, cin, device=dev).bfloat16()
+    x_nc = x_cl.detach().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    g_nc = g_cl.permute(0, 3, 1, 2).contiguous()
+
+    def run_cl():
+        cls.BottleneckCL.apply(L, bplan, x_cl, *blk.parameters()).backward(g_cl)
+        for p in blk.parameters():
+            p.grad = None
+        x_cl.grad = None
+
+    def run_nc():
+        with truth.switches(**truth.SINGLE_NODE):
+            y = blk(x_nc)
+            assert y.grad_fn.name().startswith("_BottleneckNode"), y.grad_fn.name()
+            y.backward(g_nc)
+        for p in blk.parameters():
+            p.grad = None
+        x_nc.grad = None
+    for name, fn in (("channels-last node (study kernels)", run_cl), ("NCHW single node (product)", run_nc)):
+        total, by, n = device_ms(fn)
+        print(f"Bottleneck({cin}, {planes}) at {H}x{H}, B = {N}, fwd + bwd, {name}: kernels {total:.3f} ms in {n} launches; wall {wall_ms(fn):.3f} ms / iteration")
