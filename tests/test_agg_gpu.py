@@ -290,6 +290,7 @@ def test_tensors_beyond_2_31_elements_index_correctly():
     a batch of their own, forward and both gradients (a wrapped offset reads another image: O(1) error)"""
     N, C, H, W = 10752, 64, 56, 56
     assert N * C * H * W > 2 ** 31
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < 48e9:
         pytest.skip("needs ~30 GB of device memory")

@@ -16,6 +16,7 @@ N, C, H = 10752, 64, 56
 
 
 def _room(gb):
+    torch.cuda.empty_cache()  # (blocks cached by earlier tests of the same process count as used otherwise)
     free, _ = torch.cuda.mem_get_info()
     if free < gb * 1e9:
         pytest.skip(f"needs ~{gb} GB of device memory")
