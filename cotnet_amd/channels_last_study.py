@@ -47,9 +47,6 @@ class Plan:
                      .reshape(D, 3, 3, Kc).contiguous())                                                   # data gradient's repack
         self.w_e0, self.w_e3, self.w_v = w2(layer.embed[0]), w2(layer.embed[3]), w2(layer.conv1x1[0])
         self.w_s0, self.w_s3 = w2(layer.se[0]), w2(layer.se[3])
-        self.w_e0x_t, self.w_e0k_t = self.w_e0[:, :D].t().contiguous(), self.w_e0[:, D:].t().contiguous()
-        self.w_e3_t, self.w_v_t = self.w_e3.t().contiguous(), self.w_v.t().contiguous()
-        self.w_s0_t, self.w_s3_t = self.w_s0.t().contiguous(), self.w_s3.t().contiguous()
         self.zeros = torch.zeros(64, dtype=torch.bfloat16, device=ke.weight.device)
 
 
@@ -65,6 +62,15 @@ class _Ops:
     def gemm(self, x1, x2, k1, w, b, rows, y=None, acc=0):
         y = self.new(rows, w.shape[0]) if y is None else y
         _ok(self.L.cot_study_conv1x1_nhwc(_p(x1), _p(x2), k1, _p(w), _p(b), _p(y), acc, rows, w.shape[0], w.shape[1], 0, self.s), "conv1x1")
+        return y
+
+    def dgrad(self, dy, w, rows, y=None, acc=0, col0=0, ncols=None):
+        """y[:, :ncols] (+)= dy @ w[:, col0 : col0 + ncols] straight from the convolution's weight w [Co][Ci] (no transposed copy)"""
+        K, ldb = w.shape
+        ncols = ldb if ncols is None else ncols
+        y = self.new(rows, ncols) if y is None else y
+        wp = ctypes.c_void_p(w.data_ptr() + 2 * col0)
+        _ok(self.L.cot_study_conv1x1_nhwc_dgrad(_p(dy), wp, _p(y), acc, rows, ncols, K, ldb, y.shape[1], 0, self.s), "conv1x1 dgrad")
         return y
 
     def wgrad(self, xin, dy, rows):
@@ -143,10 +149,10 @@ def backward(lib, plan, sv, gout, stream=None):
     af, gf = sv["attn"].float(), gattn.float()
     glog = (af * (gf - (af * gf).sum(2, keepdim=True))).reshape(N, 2 * D).to(torch.bfloat16).contiguous()   # softmax backward (host-side op)
     g["se.3.weight"], g["se.3.bias"] = o.wgrad(sv["s0"], glog, N), o.colsum(glog, N)
-    gs0 = o.gemm(glog, None, 2 * D, plan.w_s3_t, None, N)
+    gs0 = o.dgrad(glog, plan.w_s3, N)
     gs0_pre, g["se.1.weight"], g["se.1.bias"] = o.bn_b(gs0, sv["s0_pre"], sv["s0"], sv["s0_st"], ly.se[1], 1, N)
     g["se.0.weight"], g["se.0.bias"] = o.wgrad(sv["gap"], gs0_pre, N), o.colsum(gs0_pre, N)
-    ggap = o.gemm(gs0_pre, None, gs0_pre.shape[1], plan.w_s0_t, None, N)
+    ggap = o.dgrad(gs0_pre, plan.w_s0, N)
     gy, gk = o.new(M, D), o.new(M, D)
     _ok(lib.cot_study_radix_nhwc_mix_backward_apply(_p(gout), _p(sv["attn"]), _p(ggap), _p(gy), _p(gk), N, HW, D, BF, stream), "radix apply")
     gagg, g["bn.weight"], g["bn.bias"] = o.bn_b(gy, sv["agg"], None, sv["y_st"], ly.bn, 2, M)
@@ -155,7 +161,7 @@ def backward(lib, plan, sv, gout, stream=None):
         "aggregation backward")
     gv_pre, g["conv1x1.1.weight"], g["conv1x1.1.bias"] = o.bn_b(gv, sv["v_pre"], None, sv["v_st"], ly.conv1x1[1], 0, M)
     g["conv1x1.0.weight"] = o.wgrad(sv["xm"], gv_pre, M)
-    gx = o.gemm(gv_pre, None, D, plan.w_v_t, None, M)                                        # the values' branch starts gx
+    gx = o.dgrad(gv_pre, plan.w_v, M)                                                          # the values' branch starts gx
     gn = ly.embed[4]
     ge3, dgg, dgb = torch.empty_like(sv["e3"]), torch.empty_like(gn.weight.detach()), torch.empty_like(gn.bias.detach())
     gws = o.new(N * 9 * G * 2, dtype=torch.float32)
@@ -163,11 +169,11 @@ def backward(lib, plan, sv, gout, stream=None):
                                                 _p(dgb), _p(gws), N, 9 * G, HW, BF, stream), "gn9 backward")
     g["embed.4.weight"], g["embed.4.bias"] = dgg, dgb
     g["embed.3.weight"], g["embed.3.bias"] = o.wgrad(sv["e0"], ge3, M), o.colsum(ge3, M)
-    ge0 = o.gemm(ge3, None, ge3.shape[1], plan.w_e3_t, None, M)
+    ge0 = o.dgrad(ge3, plan.w_e3, M)
     ge0_pre, g["embed.1.weight"], g["embed.1.bias"] = o.bn_b(ge0, sv["e0_pre"], sv["e0"], sv["e0_st"], ly.embed[1], 1, M)
     g["embed.0.weight"] = torch.cat([o.wgrad(sv["xm"], ge0_pre, M), o.wgrad(sv["k"], ge0_pre, M)], 1)
-    o.gemm(ge0_pre, None, ge0_pre.shape[1], plan.w_e0x_t, None, M, y=gx, acc=1)              # gx += embed[0]'s [x | .] half
-    o.gemm(ge0_pre, None, ge0_pre.shape[1], plan.w_e0k_t, None, M, y=gk, acc=1)              # gk += its [. | k] half
+    o.dgrad(ge0_pre, plan.w_e0, M, y=gx, acc=1, col0=0, ncols=D)                               # gx += embed[0]'s [x | .] half
+    o.dgrad(ge0_pre, plan.w_e0, M, y=gk, acc=1, col0=D, ncols=D)                               # gk += its [. | k] half
     gk_pre, g["key_embed.1.weight"], g["key_embed.1.bias"] = o.bn_b(gk, sv["k_pre"], sv["k"], sv["k_st"], ly.key_embed[1], 1, M)
     Kc = D // plan.groups
     ws3 = o.new(lib.cot_study_conv3x3g_nhwc_wgrad_workspace(N, H, W, D, D, plan.groups, 0), dtype=torch.uint8)
@@ -187,7 +193,6 @@ class BlockPlan:
         self.layer = Plan(blk.conv2)
         self.w1 = blk.conv1.weight.detach().reshape(blk.conv1.out_channels, -1).contiguous()
         self.w3 = blk.conv3.weight.detach().reshape(blk.conv3.out_channels, -1).contiguous()
-        self.w1_t, self.w3_t = self.w1.t().contiguous(), self.w3.t().contiguous()
 
 
 def block_forward(lib, plan, x, N, H, W, stream=None):
@@ -222,12 +227,12 @@ def block_backward(lib, plan, sv, gout, stream=None):
         "bn3 backward")                                                         # gx = the shortcut's share (dresidual)
     g["bn3.weight"], g["bn3.bias"] = dg, db
     g["conv3.weight"] = o.wgrad(sv["t2"], g3, M)
-    g2 = o.gemm(g3, None, C, plan.w3_t, None, M)
+    g2 = o.dgrad(g3, plan.w3, M)
     g1, lg = backward(lib, plan.layer, sv["layer"], g2, stream)
     g.update({"conv2." + k: v for k, v in lg.items()})
     g1_pre, g["bn1.weight"], g["bn1.bias"] = o.bn_b(g1, sv["t1_pre"], sv["t1"], sv["t1_st"], blk.bn1, 1, M)
     g["conv1.weight"] = o.wgrad(sv["xm"], g1_pre, M)
-    o.gemm(g1_pre, None, g1_pre.shape[1], plan.w1_t, None, M, y=gx, acc=1)      # gx += the branch
+    o.dgrad(g1_pre, plan.w1, M, y=gx, acc=1)                                    # gx += the branch
     return gx, g
 
 

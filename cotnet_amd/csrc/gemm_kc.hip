@@ -521,3 +521,129 @@ extern "C" int cot_study_conv3x3g_nhwc(const void* x, const void* wr, const void
                                        int Co, int groups, void* stream) {
     return cot::conv3x3g_kc_forward(x, wr, zeros, y, accumulate, N, H, W, C, Co, groups, (hipStream_t)stream);
 }
+
+namespace cot {
+
+// ---- data gradient without a transposed weight copy:  Y[M][N] (+)= X[M][K] * B[K][N]   (B = the convolution's own weight [Co][Ci], K = Co,
+// N = Ci; row stride ldb so that a column range of a wider weight -- one slab of embed[0]'s [x | k] -- can be addressed) ----------------------
+// X side as in gemm_kc_tn (rows of 64 bytes, ds_read_b128 fragments).  B side as in gemm_kc_wgrad: a stage holds 32 k-rows x 128 columns
+// (rows of 256 bytes, four rows per copy instruction, chunk slots swizzled by kc_swz), the fragment of 16 columns x 8 k is two
+// transposing reads.  B is the MFMA's A operand again: four consecutive output columns per lane, 8-byte stores.
+template <int TM>
+__global__ __launch_bounds__(256) void gemm_kc_nn(const bf16_t* __restrict__ X, const bf16_t* __restrict__ B, bf16_t* __restrict__ Y, int accumulate,
+                                                  int M, int N, int K, int ldb, int ldy, int ntn) {
+    constexpr int NS = 4, MI = TM / 32, A_BYTES = TM * 64, B_BYTES = 32 * 256, ST = A_BYTES + B_BYTES;
+    constexpr int CA = TM / 64, CB = 2, G = CA + CB;
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    const int m0 = mt * TM, n0 = nt * 128;
+
+    const int r = lane >> 2, kc = (lane & 3) ^ ((r >> 2) & 3);
+    const bf16_t* asrc[CA];
+    const bf16_t* bsrc[CB];
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+        int row = m0 + (wave * CA + q) * 16 + r;
+        row = row < M ? row : M - 1;
+        asrc[q] = X + (int64_t)row * K + kc * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {  // rows 8 * wave + 4 * q + (lane >> 4) of the k-step, slot (lane & 15)
+        const int brow = 8 * wave + 4 * q + (lane >> 4);
+        int col = n0 + (((lane & 15) ^ kc_swz(brow)) << 3);
+        col = col < N ? col : N - 8;
+        bsrc[q] = B + (int64_t)brow * ldb + col;
+    }
+    auto issue = [&](int stage, int kt) {
+        char* base = cot_smem + stage * ST;
+#pragma unroll
+        for (int q = 0; q < CA; ++q) COT_GLDS16(asrc[q] + kt * 32, base + (wave * CA + q) * 1024);
+#pragma unroll
+        for (int q = 0; q < CB; ++q) COT_GLDS16(bsrc[q] + (int64_t)kt * 32 * ldb, base + A_BYTES + (8 * wave + 4 * q) * 256);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fslot = ((lane >> 4) ^ ((fr >> 2) & 3)) * 16;
+    const int xoff = (wm * (TM / 2) + fr) * 64 + fslot;
+    const int g = lane >> 4, L = lane & 15, frow = 8 * g + (L >> 2), fsw = kc_swz(frow);
+    int bo[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bo[b] = A_BYTES + frow * 256 + (((wn * 8 + b * 2 + ((L & 3) >> 1)) ^ fsw) << 4) + (L & 1) * 8;
+
+    f32x4_t acc[4][MI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = K / 32;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < KT) issue(s, s);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int left = KT - 1 - kt;
+        WaitBehind<G, NS - 2>::go(left < NS - 2 ? left : NS - 2);
+        COT_LDS_BARRIER();
+        if (kt + NS - 1 < KT) issue((kt + NS - 1) % NS, kt + NS - 1);
+        const char* st = cot_smem + (kt % NS) * ST;
+        bf16x8_t xf[MI], wf[4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(st + xoff + i * 16 * 64);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            s16x4_t lo = COT_LDS_READ_TR16(st + bo[b]), hi = COT_LDS_READ_TR16(st + bo[b] + 4 * 256);
+            __builtin_memcpy(&wf[b], &lo, 8);
+            __builtin_memcpy(reinterpret_cast<char*>(&wf[b]) + 8, &hi, 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[j][i] = COT_MFMA_16X16X32_BF16(wf[j], xf[i], acc[j][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (TM / 2) + i * 16 + (lane & 15);
+        if (m < M) {
+            const int nb = n0 + wn * 64 + 4 * (lane >> 4);
+            bf16_t* yp = Y + (int64_t)m * ldy + nb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (nb + j * 16 < N) {
+                    Vec<bf16_t, 4> o, old;
+                    if (accumulate) old = ldv<bf16_t, 4>(yp + j * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)(acc[j][i][e] + (accumulate ? (float)old.v[e] : 0.f));
+                    stv<bf16_t, 4>(yp + j * 16, o);
+                }
+            }
+        }
+    }
+}
+
+int gemm_kc_nn_run(const void* x, const void* b, void* y, int accumulate, int M, int N, int K, int ldb, int ldy, int tm, hipStream_t s) {
+    if (!x || !b || !y || M <= 0 || N <= 0 || K <= 0 || ldb < N || ldy < N) return -1;
+    if (K % 32 || N % 8 || ldb % 8 || ldy % 4 || ((uintptr_t)x | (uintptr_t)b) % 16 || (uintptr_t)y % 8) return -2;
+    const int ntn = ceil_div(N, 128);
+    if (tm == 0) tm = (int64_t)ceil_div(M, 128) * ntn >= 256 ? 128 : 64;
+    if (tm != 64 && tm != 128) return -1;
+    const int64_t blocks = (int64_t)ceil_div(M, tm) * ntn;
+    if (blocks >= ((int64_t)1 << 31)) return -2;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (tm == 128)
+        COT_LAUNCH((gemm_kc_nn<128>), grid, block, 4 * (128 * 64 + 32 * 256), s, (const bf16_t*)x, (const bf16_t*)b, (bf16_t*)y, accumulate, M, N, K,
+                   ldb, ldy, ntn);
+    else
+        COT_LAUNCH((gemm_kc_nn<64>), grid, block, 4 * (64 * 64 + 32 * 256), s, (const bf16_t*)x, (const bf16_t*)b, (bf16_t*)y, accumulate, M, N, K,
+                   ldb, ldy, ntn);
+    return check_launch("gemm_kc_nn");
+}
+
+}  // namespace cot
+
+// dx [M][ldy] (+)= dy [M][K] * w [K][ldb] on the columns [0, N) of w and dx: the data gradient of a channels-last 1x1 convolution straight
+// from the convolution's weight (K = its output channels, N = its input channels or one slab of them)
+extern "C" int cot_study_conv1x1_nhwc_dgrad(const void* dy, const void* w, void* dx, int accumulate, int M, int N, int K, int ldb, int ldy, int tm,
+                                            void* stream) {
+    return cot::gemm_kc_nn_run(dy, w, dx, accumulate, M, N, K, ldb, ldy, tm, (hipStream_t)stream);
+}

@@ -75,3 +75,19 @@ for N, HW, K, Nn in [(80, 196, 1024, 256), (80, 196, 256, 1024), (80, 49, 2048, 
     wsn = torch.empty(max(L.cot_conv1x1_workspace(N, K, Nn, HW, 0), 256), device=dev, dtype=torch.uint8)
     tn = timed(lambda: L.cot_conv1x1_backward_weight(P(gn), P(xn), None, K, P(dw), None, P(wsn), N, K, Nn, HW, 2, stream))
     print(f"{K:5d} -> {Nn:5d}  HW {HW:4d}       {tk:11.1f} us {tn:7.1f} us   {err:.4f}")
+
+
+# data gradient straight from the untransposed weight (gemm_kc_nn) beside the forward form on a transposed copy
+print(f"\n{'data gradient (N80)':28s} {'NN form':>10s} {'TN form on W^T':>16s}")
+for N, HW, K, Nn in [(80, 196, 256, 1024), (80, 196, 1024, 256), (80, 49, 512, 2048), (80, 49, 2048, 512)]:   # K = Co, Nn = Ci
+    M = N * HW
+    dy = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(K, Nn, device=dev) / K ** 0.5).bfloat16()    # the convolution's weight [Co][Ci]
+    wt = w.t().contiguous()
+    dx = torch.empty(M, Nn, device=dev, dtype=torch.bfloat16)
+    assert L.cot_study_conv1x1_nhwc_dgrad(P(dy), P(w), P(dx), 0, M, Nn, K, Nn, Nn, 0, stream) == 0
+    torch.cuda.synchronize()
+    err = (dx.float() - dy.float() @ w.float()).abs().max().item()
+    t1 = timed(lambda: L.cot_study_conv1x1_nhwc_dgrad(P(dy), P(w), P(dx), 0, M, Nn, K, Nn, Nn, 0, stream))
+    t2 = timed(lambda: L.cot_study_gemm_kc(P(dy), P(wt), P(dx), M, Nn, K, 0, stream)) if Nn % 128 == 0 else float("nan")
+    print(f"{K:5d} -> {Nn:5d}  HW {HW:4d}       {t1:7.1f} us {t2:13.1f} us   max|err| {err:.3f}")

@@ -3119,3 +3119,27 @@ def test_stage_routed_through_the_channels_last_node(monkeypatch):
         assert p.grad is not None, n_
         if q.grad.float().abs().max() > 1e-3 * top and not n_.endswith("se.0.bias"):
             assert rel(p.grad, q.grad) < 0.18, (n_, rel(p.grad, q.grad))
+
+
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("M,K,Nt,N,c0,acc,tm", [(392, 256, 1024, 1024, 0, 0, 0), (98, 128, 512, 256, 256, 1, 64), (200, 288, 128, 128, 0, 0, 128),
+                                                (33, 32, 40, 24, 8, 1, 0), (1, 64, 8, 8, 0, 0, 0)])
+def test_k_contiguous_data_gradient_from_the_untransposed_weight(M, K, Nt, N, c0, acc, tm, dma, request):
+    """gemm_kc_nn (cot_study_conv1x1_nhwc_dgrad): dx[M][N] (+)= dy[M][K] * w[K][N] straight from the convolution's weight [Co][Ci] --
+    the weight side staged as k-rows and read as columns by transposing LDS reads (as the weight-gradient kernel does), a column
+    window of a wider weight / output (one slab of embed[0]'s [x | k]), accumulate; nothing outside the window is touched"""
+    torch.manual_seed(M + K)
+    dy, w = torch.randn(M, K).bfloat16(), (torch.randn(K, Nt) / K ** 0.5).bfloat16()
+    init = torch.randn(M, Nt).bfloat16()
+    dx = init.clone()
+    if not acc:
+        dx[:, c0:c0 + N] = float("nan")
+    _EMUL.emul_set_dma_mode(dma)
+    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
+    assert _EMUL.cot_study_conv1x1_nhwc_dgrad(P(dy), ctypes.c_void_p(w.data_ptr() + 2 * c0), ctypes.c_void_p(dx.data_ptr() + 2 * c0), acc, M, N,
+                                              K, Nt, Nt, tm, None) == 0
+    ref = init.float().clone()
+    ref[:, c0:c0 + N] = dy.float() @ w.float()[:, c0:c0 + N] + (init.float()[:, c0:c0 + N] if acc else 0)
+    assert (dx.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert torch.equal(dx[:, :c0], init[:, :c0]) and torch.equal(dx[:, c0 + N:], init[:, c0 + N:])
+    assert _EMUL.cot_study_conv1x1_nhwc_dgrad(P(dy), P(w), P(dx), 0, M, N, K + 8, Nt, Nt, tm, None) == -2
