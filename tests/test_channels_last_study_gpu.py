@@ -49,6 +49,9 @@ def test_conv1x1_forms(HW, K, Nn, k1, bias):
     dw = torch.full((Nn, K), float("nan"), device=DEV).bfloat16()
     assert L.cot_study_conv1x1_nhwc_wgrad(P(x), P(dy), P(dw), P(ws), M, K, Nn, 0, S()) == 0
     assert near(dw, dy.float().t() @ x.float(), 1e-2)
+    dx = torch.full((M, K), float("nan"), device=DEV).bfloat16()   # data gradient straight from the untransposed weight [Co][Ci]
+    assert L.cot_study_conv1x1_nhwc_dgrad(P(dy), P(w), P(dx), 0, M, K, Nn, K, K, 0, S()) == 0
+    assert near(dx, dy.float() @ w.float())
 
 
 @pytest.mark.parametrize("H,D", [(14, 256), (7, 512)])
