@@ -650,7 +650,7 @@ def case_channels_last_study(rng):
     E.cot_study_conv3x3g_nhwc_wgrad_workspace.restype = ctypes.c_size_t
     none = ctypes.c_void_p(None)
     dma = rng.choice([0, 1])
-    which = rng.choice(["conv1x1", "wgrad1x1", "conv3x3", "wgrad3x3"])
+    which = rng.choice(["conv1x1", "wgrad1x1", "conv3x3", "wgrad3x3", "dgrad1x1"])
     E.emul_set_dma_mode(dma)
     try:
         if which == "conv1x1":
@@ -666,6 +666,20 @@ def case_channels_last_study(rng):
             rc = E.cot_study_conv1x1_nhwc(P(x1), P(x2) if split else none, k1, P(w), P(b) if bias else none, P(y), acc, M, Nn, K, tm, None)
             ref = x.float() @ w.float().t() + (b.float() if bias else 0) + (init.float() if acc else 0)
             return rc == 0 and (y.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), (which, M, K, Nn, tm, k1, bias, acc, dma)
+        if which == "dgrad1x1":  # straight from the untransposed weight, a column window of a wider weight / output
+            M, K, Nt, tm, acc = rng.randint(1, 300), 32 * rng.randint(1, 8), 8 * rng.randint(1, 60), rng.choice([0, 64, 128]), rng.choice([0, 1])
+            Nw = 8 * rng.randint(1, Nt // 8)
+            c0 = 8 * rng.randint(0, (Nt - Nw) // 8)
+            dy, w, init = torch.randn(M, K).bfloat16(), (torch.randn(K, Nt) / K ** 0.5).bfloat16(), torch.randn(M, Nt).bfloat16()
+            dx = init.clone()
+            if not acc:
+                dx[:, c0:c0 + Nw] = float("nan")
+            rc = E.cot_study_conv1x1_nhwc_dgrad(P(dy), ctypes.c_void_p(w.data_ptr() + 2 * c0), ctypes.c_void_p(dx.data_ptr() + 2 * c0), acc, M, Nw, K,
+                                                Nt, Nt, tm, None)
+            ref = init.float().clone()
+            ref[:, c0:c0 + Nw] = dy.float() @ w.float()[:, c0:c0 + Nw] + (init.float()[:, c0:c0 + Nw] if acc else 0)
+            ok = rc == 0 and (dx.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+            return ok and torch.equal(dx[:, :c0], init[:, :c0]) and torch.equal(dx[:, c0 + Nw:], init[:, c0 + Nw:]), (which, M, K, Nt, Nw, c0, tm, acc, dma)
         if which == "wgrad1x1":
             M, Ci, Co, sl = rng.choice([1, 7, 31, 32, 33, 64, 100, 392, 500]), 8 * rng.randint(1, 40), 8 * rng.randint(1, 40), rng.choice([0, 0, 1, 2, 3, 7])
             x, dy = torch.randn(M, Ci).bfloat16(), torch.randn(M, Co).bfloat16()
