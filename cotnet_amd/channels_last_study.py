@@ -73,11 +73,14 @@ class _Ops:
         _ok(self.L.cot_study_conv1x1_nhwc_dgrad(_p(dy), wp, _p(y), acc, rows, ncols, K, ldb, y.shape[1], 0, self.s), "conv1x1 dgrad")
         return y
 
-    def wgrad(self, xin, dy, rows):
+    def wgrad(self, xin, dy, rows, dw=None, col0=0):
+        """dW [Co][Ci] = dy^T xin -- or, with `dw` given, into the column window [col0, col0 + Ci) of that wider gradient"""
         Ci, Co = xin.shape[1], dy.shape[1]
         ws = self.new(self.L.cot_study_conv1x1_nhwc_wgrad_workspace(rows, Ci, Co, 0), dtype=torch.uint8)
-        dw = self.new(Co, Ci)
-        _ok(self.L.cot_study_conv1x1_nhwc_wgrad(_p(xin), _p(dy), _p(dw), _p(ws), rows, Ci, Co, 0, self.s), "conv1x1 wgrad")
+        if dw is None:
+            dw = self.new(Co, Ci)
+        _ok(self.L.cot_study_conv1x1_nhwc_wgrad_window(_p(xin), _p(dy), ctypes.c_void_p(dw.data_ptr() + 2 * col0), dw.shape[1], _p(ws), rows, Ci,
+                                                       Co, 0, self.s), "conv1x1 wgrad")
         return dw
 
     def colsum(self, t, rows):
@@ -129,7 +132,8 @@ def forward(lib, plan, x, N, H, W, stream=None):
     s0_pre = o.gemm(gap, None, D, plan.w_s0, ly.se[0].bias.detach(), N)   # the `se` branch: GEMMs / BatchNorm on the [N][C] descriptor
     s0, s0_st = o.bn_f(s0_pre, ly.se[1], 1, N)
     logits = o.gemm(s0, None, s0.shape[1], plan.w_s3, ly.se[3].bias.detach(), N)
-    attn = torch.softmax(logits.float().view(N, D, 2), 2).to(torch.bfloat16).contiguous()   # (host-side op here; radix_tail.hip has it fused)
+    attn = o.new(N, D, 2)                                                # softmax over the radix pair of each (image, channel)
+    _ok(lib.cot_study_radix_softmax2(_p(logits), _p(attn), N * D, BF, stream), "radix softmax")
     out = o.new(M, D)
     _ok(lib.cot_study_radix_nhwc_mix(_p(y), _p(k), _p(attn), _p(out), N, HW, D, BF, stream), "radix mix")
     saved = dict(x=x, xm=xm, k_pre=k_pre, k=k, k_st=k_st, e0_pre=e0_pre, e0=e0, e0_st=e0_st, e3=e3, wn=wn, gm=gm, gr=gr, v_pre=v_pre, v=v,
@@ -146,8 +150,8 @@ def backward(lib, plan, sv, gout, stream=None):
     g = {}
     gattn = o.new(N, D, 2)
     _ok(lib.cot_study_radix_nhwc_mix_backward_reduce(_p(gout), _p(sv["y"]), _p(sv["k"]), _p(gattn), N, HW, D, BF, stream), "radix reduce")
-    af, gf = sv["attn"].float(), gattn.float()
-    glog = (af * (gf - (af * gf).sum(2, keepdim=True))).reshape(N, 2 * D).to(torch.bfloat16).contiguous()   # softmax backward (host-side op)
+    glog = o.new(N, 2 * D)
+    _ok(lib.cot_study_radix_softmax2_backward(_p(sv["attn"]), _p(gattn), _p(glog), N * D, BF, stream), "radix softmax backward")
     g["se.3.weight"], g["se.3.bias"] = o.wgrad(sv["s0"], glog, N), o.colsum(glog, N)
     gs0 = o.dgrad(glog, plan.w_s3, N)
     gs0_pre, g["se.1.weight"], g["se.1.bias"] = o.bn_b(gs0, sv["s0_pre"], sv["s0"], sv["s0_st"], ly.se[1], 1, N)
@@ -171,7 +175,10 @@ def backward(lib, plan, sv, gout, stream=None):
     g["embed.3.weight"], g["embed.3.bias"] = o.wgrad(sv["e0"], ge3, M), o.colsum(ge3, M)
     ge0 = o.dgrad(ge3, plan.w_e3, M)
     ge0_pre, g["embed.1.weight"], g["embed.1.bias"] = o.bn_b(ge0, sv["e0_pre"], sv["e0"], sv["e0_st"], ly.embed[1], 1, M)
-    g["embed.0.weight"] = torch.cat([o.wgrad(sv["xm"], ge0_pre, M), o.wgrad(sv["k"], ge0_pre, M)], 1)
+    gw0 = o.new(ge0_pre.shape[1], 2 * D)                                                      # embed[0]'s weight gradient: the [x | k] slabs
+    o.wgrad(sv["xm"], ge0_pre, M, dw=gw0, col0=0)                                             # ... written into their column windows
+    o.wgrad(sv["k"], ge0_pre, M, dw=gw0, col0=D)
+    g["embed.0.weight"] = gw0
     o.dgrad(ge0_pre, plan.w_e0, M, y=gx, acc=1, col0=0, ncols=D)                               # gx += embed[0]'s [x | .] half
     o.dgrad(ge0_pre, plan.w_e0, M, y=gk, acc=1, col0=D, ncols=D)                               # gk += its [. | k] half
     gk_pre, g["key_embed.1.weight"], g["key_embed.1.bias"] = o.bn_b(gk, sv["k_pre"], sv["k"], sv["k_st"], ly.key_embed[1], 1, M)

@@ -310,7 +310,10 @@ __global__ __launch_bounds__(256) void gemm_kc_wgrad(const bf16_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_kc_wgrad_reduce(const float* __restrict__ part, bf16_t* __restrict__ dW, int64_t n4, int slices) {
+// ci4 / ldw: a row of the result has ci4 groups of four channels and goes to dW + row * ldw (ldw = 4 * ci4: dense; larger: a column
+// window of a wider gradient -- one slab of embed[0]'s [x | k] weight)
+__global__ __launch_bounds__(256) void gemm_kc_wgrad_reduce(const float* __restrict__ part, bf16_t* __restrict__ dW, int64_t n4, int slices,
+                                                           int ci4, int ldw) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     f32x4_t s = *reinterpret_cast<const f32x4_t*>(part + 4 * i);
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(256) void gemm_kc_wgrad_reduce(const float* __restr
     Vec<bf16_t, 4> o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)s[e];
-    stv<bf16_t, 4>(dW + 4 * i, o);
+    const int64_t row = i / ci4;
+    stv<bf16_t, 4>(dW + row * ldw + 4 * (i - row * ci4), o);
 }
 
 // slices of the reduction: enough workgroups for two per CU, at least four 32-row steps each (0 = choose; > 0 = forced, tests)
@@ -335,8 +339,10 @@ static int gemm_kc_wgrad_slices(int M, int Ci, int Co, int forced) {
 size_t gemm_kc_wgrad_workspace(int M, int Ci, int Co, int forced) {
     return (size_t)gemm_kc_wgrad_slices(M, Ci, Co, forced) * Co * Ci * sizeof(float);
 }
-int gemm_kc_wgrad_run(const void* x, const void* dy, void* dw, void* workspace, int M, int Ci, int Co, int forced, hipStream_t s) {
+int gemm_kc_wgrad_run(const void* x, const void* dy, void* dw, void* workspace, int M, int Ci, int Co, int forced, hipStream_t s, int ldw = 0) {
     if (!x || !dy || !dw || !workspace || M <= 0 || Ci <= 0 || Co <= 0) return -1;
+    if (ldw == 0) ldw = Ci;
+    if (ldw < Ci || ldw % 4) return -2;
     if (Ci % 8 || Co % 8 || ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace) % 16) return -2;
     const int slices = gemm_kc_wgrad_slices(M, Ci, Co, forced), tci = ceil_div(Ci, 128), tco = ceil_div(Co, 128);
     const int64_t blocks = (int64_t)tci * tco * slices;
@@ -344,7 +350,8 @@ int gemm_kc_wgrad_run(const void* x, const void* dy, void* dw, void* workspace, 
     COT_LAUNCH((gemm_kc_wgrad<false>), dim3((unsigned)blocks), dim3(256), 4 * 2 * 32 * 256, s, (const bf16_t*)x, (const bf16_t*)dy,
                (float*)workspace, M, Ci, Co, tci, tco, slices, KcTaps{});
     const int64_t n4 = (int64_t)Co * Ci / 4;
-    COT_LAUNCH(gemm_kc_wgrad_reduce, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, (const float*)workspace, (bf16_t*)dw, n4, slices);
+    COT_LAUNCH(gemm_kc_wgrad_reduce, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, (const float*)workspace, (bf16_t*)dw, n4, slices, Ci / 4,
+               ldw);
     return check_launch("gemm_kc_wgrad");
 }
 
@@ -372,7 +379,8 @@ int conv3x3g_kc_wgrad_run(const void* x, const void* dy, const void* zeros, void
     COT_LAUNCH((gemm_kc_wgrad<true>), dim3((unsigned)slices, (unsigned)(groups * 9)), dim3(256), 4 * 2 * 32 * 256, s, (const bf16_t*)x,
                (const bf16_t*)dy, (float*)workspace, M, Kc, Mg, 1, 1, slices, tp);
     const int64_t n4 = (int64_t)Co * 9 * Kc / 4;
-    COT_LAUNCH(gemm_kc_wgrad_reduce, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, (const float*)workspace, (bf16_t*)dwr, n4, slices);
+    COT_LAUNCH(gemm_kc_wgrad_reduce, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, (const float*)workspace, (bf16_t*)dwr, n4, slices,
+               9 * Kc / 4, 9 * Kc);
     return check_launch("conv3x3g_kc_wgrad");
 }
 
@@ -391,6 +399,11 @@ extern "C" size_t cot_study_conv1x1_nhwc_wgrad_workspace(int M, int Ci, int Co, 
 extern "C" int cot_study_conv1x1_nhwc_wgrad(const void* x, const void* dy, void* dw, void* workspace, int M, int Ci, int Co, int slices,
                                             void* stream) {
     return cot::gemm_kc_wgrad_run(x, dy, dw, workspace, M, Ci, Co, slices, (hipStream_t)stream);
+}
+// the same into a column window of a wider gradient: rows of dw are ldw elements apart (dw already points at the window's first column)
+extern "C" int cot_study_conv1x1_nhwc_wgrad_window(const void* x, const void* dy, void* dw, int ldw, void* workspace, int M, int Ci, int Co,
+                                                   int slices, void* stream) {
+    return cot::gemm_kc_wgrad_run(x, dy, dw, workspace, M, Ci, Co, slices, (hipStream_t)stream, ldw);
 }
 
 namespace cot {

@@ -189,6 +189,27 @@ __global__ __launch_bounds__(256) void nhwc_col_sum(const T* __restrict__ x, T* 
     }
 }
 
+// attn[i][0..1] = softmax(logits[i][0..1]) over the radix pair (models/cotnet.py:99-101: view(B, C, radix), softmax(dim=2)); its backward
+// glogits = attn * (gattn - sum_r attn * gattn).  n2 = number of pairs (N * C); fp32 arithmetic, one rounding
+template <typename T>
+__global__ __launch_bounds__(256) void radix_softmax2(const T* __restrict__ logits, T* __restrict__ attn, int64_t n2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n2) return;
+    const float a = (float)logits[2 * i], b = (float)logits[2 * i + 1], m = fmaxf(a, b);
+    const float ea = __expf(a - m), eb = __expf(b - m), inv = 1.0f / (ea + eb);
+    attn[2 * i] = (T)(ea * inv);
+    attn[2 * i + 1] = (T)(eb * inv);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void radix_softmax2_bwd(const T* __restrict__ attn, const T* __restrict__ gattn, T* __restrict__ glogits, int64_t n2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n2) return;
+    const float a0 = (float)attn[2 * i], a1 = (float)attn[2 * i + 1], g0 = (float)gattn[2 * i], g1 = (float)gattn[2 * i + 1];
+    const float dot = a0 * g0 + a1 * g1;
+    glogits[2 * i] = (T)(a0 * (g0 - dot));
+    glogits[2 * i + 1] = (T)(a1 * (g1 - dot));
+}
+
 template <typename T, int V> static bool radix_nhwc_covers(int C) {
     return C > 0 && C % V == 0 && C / V <= 256 && 256 % (C / V) == 0;
 }
@@ -268,4 +289,23 @@ extern "C" int cot_study_nhwc_col_sum(const void* x, void* out, int M, int C, in
         return -2;
     }
     return cot::check_launch("nhwc_col_sum");
+}
+extern "C" int cot_study_radix_softmax2(const void* logits, void* attn, int64_t pairs, int dtype, void* stream) {
+    if (!logits || !attn || pairs <= 0) return -1;
+    const dim3 grid((unsigned)cot::ceil_div64(pairs, 256));
+    if (dtype == 2) COT_LAUNCH((cot::radix_softmax2<cot::bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const cot::bf16_t*)logits, (cot::bf16_t*)attn, pairs);
+    else if (dtype == 0) COT_LAUNCH((cot::radix_softmax2<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)logits, (float*)attn, pairs);
+    else return -2;
+    return cot::check_launch("radix_softmax2");
+}
+extern "C" int cot_study_radix_softmax2_backward(const void* attn, const void* gattn, void* glogits, int64_t pairs, int dtype, void* stream) {
+    if (!attn || !gattn || !glogits || pairs <= 0) return -1;
+    const dim3 grid((unsigned)cot::ceil_div64(pairs, 256));
+    if (dtype == 2)
+        COT_LAUNCH((cot::radix_softmax2_bwd<cot::bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const cot::bf16_t*)attn, (const cot::bf16_t*)gattn,
+                   (cot::bf16_t*)glogits, pairs);
+    else if (dtype == 0)
+        COT_LAUNCH((cot::radix_softmax2_bwd<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)attn, (const float*)gattn, (float*)glogits, pairs);
+    else return -2;
+    return cot::check_launch("radix_softmax2_backward");
 }

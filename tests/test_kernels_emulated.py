@@ -3143,3 +3143,27 @@ def test_k_contiguous_data_gradient_from_the_untransposed_weight(M, K, Nt, N, c0
     assert (dx.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
     assert torch.equal(dx[:, :c0], init[:, :c0]) and torch.equal(dx[:, c0 + N:], init[:, c0 + N:])
     assert _EMUL.cot_study_conv1x1_nhwc_dgrad(P(dy), P(w), P(dx), 0, M, N, K + 8, Nt, Nt, tm, None) == -2
+
+
+def test_radix_pair_softmax_and_weight_gradient_window():
+    """the last host-side pieces of the channels-last layer moved onto kernels: softmax over the radix pair and its backward
+    (cot_study_radix_softmax2*), a weight gradient written into a column window of a wider gradient (embed[0]'s [x | k] slabs)"""
+    _EMUL.cot_study_conv1x1_nhwc_wgrad_workspace.restype = ctypes.c_size_t
+    torch.manual_seed(3)
+    lg, ga = (2 * torch.randn(5, 24, 2)).bfloat16(), torch.randn(5, 24, 2).bfloat16()
+    attn, gl = torch.full_like(lg, float("nan")), torch.full_like(lg, float("nan"))
+    assert _EMUL.cot_study_radix_softmax2(P(lg), P(attn), 5 * 24, 2, None) == 0
+    lr = lg.float().requires_grad_(True)
+    ar = torch.softmax(lr, 2)
+    assert torch.allclose(attn.float(), ar.detach(), atol=4e-3)
+    assert _EMUL.cot_study_radix_softmax2_backward(P(attn), P(ga), P(gl), 5 * 24, 2, None) == 0
+    af = attn.float()
+    assert torch.allclose(gl.float(), af * (ga.float() - (af * ga.float()).sum(2, keepdim=True)), atol=1e-2, rtol=2e-2)
+    M, Ci, Co = 70, 40, 24
+    x, dy = torch.randn(M, Ci).bfloat16(), torch.randn(M, Co).bfloat16()
+    wide = torch.full((Co, 3 * Ci), 7.0).bfloat16()
+    ws = torch.empty(_EMUL.cot_study_conv1x1_nhwc_wgrad_workspace(M, Ci, Co, 0), dtype=torch.uint8)
+    assert _EMUL.cot_study_conv1x1_nhwc_wgrad_window(P(x), P(dy), ctypes.c_void_p(wide.data_ptr() + 2 * Ci), 3 * Ci, P(ws), M, Ci, Co, 0, None) == 0
+    ref = dy.float().t() @ x.float()
+    assert (wide[:, Ci:2 * Ci].float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-2
+    assert (wide[:, :Ci] == 7).all() and (wide[:, 2 * Ci:] == 7).all()
