@@ -30,6 +30,17 @@ def _ok(rc, what):
         raise RuntimeError(f"cotnet_amd channels-last study: {what} returned {rc}")
 
 
+_ZEROS = {}
+
+
+def _zeros(device):
+    """one block of zeros per device: the source of a 3x3 tap outside the image"""
+    z = _ZEROS.get(device)
+    if z is None:
+        z = _ZEROS[device] = torch.zeros(64, dtype=torch.bfloat16, device=device)
+    return z
+
+
 class Plan:
     """repacked / transposed copies of a CotLayer's weights (bf16): what a channels-last node would keep per optimizer step"""
 
@@ -47,7 +58,7 @@ class Plan:
                      .reshape(D, 3, 3, Kc).contiguous())                                                   # data gradient's repack
         self.w_e0, self.w_e3, self.w_v = w2(layer.embed[0]), w2(layer.embed[3]), w2(layer.conv1x1[0])
         self.w_s0, self.w_s3 = w2(layer.se[0]), w2(layer.se[3])
-        self.zeros = torch.zeros(64, dtype=torch.bfloat16, device=ke.weight.device)
+        self.zeros = _zeros(ke.weight.device)
 
 
 class _Ops:
