@@ -144,7 +144,7 @@ def forward(lib, plan, x, N, H, W, stream=None):
     s0, s0_st = o.bn_f(s0_pre, ly.se[1], 1, N)
     logits = o.gemm(s0, None, s0.shape[1], plan.w_s3, ly.se[3].bias.detach(), N)
     attn = o.new(N, D, 2)                                                # softmax over the radix pair of each (image, channel)
-    _ok(lib.cot_study_radix_softmax2(_p(logits), _p(attn), N * D, BF, stream), "radix softmax")
+    _ok(lib.cot_study_radix_softmax2(_p(logits), _p(attn), ctypes.c_int64(N * D), BF, stream), "radix softmax")
     out = o.new(M, D)
     _ok(lib.cot_study_radix_nhwc_mix(_p(y), _p(k), _p(attn), _p(out), N, HW, D, BF, stream), "radix mix")
     saved = dict(x=x, xm=xm, k_pre=k_pre, k=k, k_st=k_st, e0_pre=e0_pre, e0=e0, e0_st=e0_st, e3=e3, wn=wn, gm=gm, gr=gr, v_pre=v_pre, v=v,
@@ -162,7 +162,7 @@ def backward(lib, plan, sv, gout, stream=None):
     gattn = o.new(N, D, 2)
     _ok(lib.cot_study_radix_nhwc_mix_backward_reduce(_p(gout), _p(sv["y"]), _p(sv["k"]), _p(gattn), N, HW, D, BF, stream), "radix reduce")
     glog = o.new(N, 2 * D)
-    _ok(lib.cot_study_radix_softmax2_backward(_p(sv["attn"]), _p(gattn), _p(glog), N * D, BF, stream), "radix softmax backward")
+    _ok(lib.cot_study_radix_softmax2_backward(_p(sv["attn"]), _p(gattn), _p(glog), ctypes.c_int64(N * D), BF, stream), "radix softmax backward")
     g["se.3.weight"], g["se.3.bias"] = o.wgrad(sv["s0"], glog, N), o.colsum(glog, N)
     gs0 = o.dgrad(glog, plan.w_s3, N)
     gs0_pre, g["se.1.weight"], g["se.1.bias"] = o.bn_b(gs0, sv["s0_pre"], sv["s0"], sv["s0_st"], ly.se[1], 1, N)

@@ -3152,11 +3152,11 @@ def test_radix_pair_softmax_and_weight_gradient_window():
     torch.manual_seed(3)
     lg, ga = (2 * torch.randn(5, 24, 2)).bfloat16(), torch.randn(5, 24, 2).bfloat16()
     attn, gl = torch.full_like(lg, float("nan")), torch.full_like(lg, float("nan"))
-    assert _EMUL.cot_study_radix_softmax2(P(lg), P(attn), 5 * 24, 2, None) == 0
+    assert _EMUL.cot_study_radix_softmax2(P(lg), P(attn), ctypes.c_int64(5 * 24), 2, None) == 0
     lr = lg.float().requires_grad_(True)
     ar = torch.softmax(lr, 2)
     assert torch.allclose(attn.float(), ar.detach(), atol=4e-3)
-    assert _EMUL.cot_study_radix_softmax2_backward(P(attn), P(ga), P(gl), 5 * 24, 2, None) == 0
+    assert _EMUL.cot_study_radix_softmax2_backward(P(attn), P(ga), P(gl), ctypes.c_int64(5 * 24), 2, None) == 0
     af = attn.float()
     assert torch.allclose(gl.float(), af * (ga.float() - (af * ga.float()).sum(2, keepdim=True)), atol=1e-2, rtol=2e-2)
     M, Ci, Co = 70, 40, 24
