@@ -96,7 +96,8 @@ class _Ops:
 
     def colsum(self, t, rows):
         o = self.new(t.shape[1])
-        _ok(self.L.cot_study_nhwc_col_sum(_p(t), _p(o), rows, t.shape[1], BF, self.s), "col_sum")
+        ws = self.new(self.L.cot_study_nhwc_col_sum_workspace(rows, t.shape[1]), dtype=torch.float32)
+        _ok(self.L.cot_study_nhwc_col_sum(_p(t), _p(o), _p(ws), rows, t.shape[1], BF, self.s), "col_sum")
         return o
 
     def bn_f(self, t, mod, act, rows):

@@ -165,28 +165,40 @@ __global__ __launch_bounds__(256) void radix_nhwc_mix_bwd_apply(const T* __restr
 
 // out[c] = sum over the M rows of x[m][c] (the bias gradient of a channels-last 1x1 convolution): one workgroup per 64 * V channels
 // ... of a column block, rows in RP lanes; fp32 sums, rounded once
+// grid (column blocks of 32 * V channels, row slabs): fp32 partial sums part[slab][C]; nhwc_col_sum_finish adds the slabs in order
 template <typename T, int V>
-__global__ __launch_bounds__(256) void nhwc_col_sum(const T* __restrict__ x, T* __restrict__ out, int M, int C) {
+__global__ __launch_bounds__(256) void nhwc_col_sum(const T* __restrict__ x, float* __restrict__ part, int M, int C, int rows_per) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* sm = reinterpret_cast<float*>(cot_smem);
     const int TPR = 32, RP = 8, cg = threadIdx.x % TPR, rl = threadIdx.x / TPR;  // 32 x V channels per workgroup, 8 row lanes
     const int c0 = (blockIdx.x * TPR + cg) * V;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
     float s[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) s[e] = 0.f;
     if (c0 < C)
-        for (int r = rl; r < M; r += RP) {
+        for (int r = r0 + rl; r < r1; r += RP) {
             const Vec<T, V> a = ldv<T, V>(x + (int64_t)r * C + c0);
 #pragma unroll
             for (int e = 0; e < V; ++e) s[e] += (float)a.v[e];
         }
     radix_col_sum<V>(s, sm, TPR, RP, cg, rl);
     if (rl == 0 && c0 < C) {
-        Vec<T, V> o;
 #pragma unroll
-        for (int e = 0; e < V; ++e) o.v[e] = (T)s[e];
-        stv<T, V>(out + c0, o);
+        for (int e = 0; e < V; ++e) part[(int64_t)blockIdx.y * C + c0 + e] = s[e];
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_col_sum_finish(const float* __restrict__ part, T* __restrict__ out, int C, int slabs) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += part[(int64_t)k * C + c];
+    out[c] = (T)s;
+}
+static int nhwc_col_sum_slabs(int M) {
+    int s = M / 64;  // at least 64 rows per slab, at most 128 slabs
+    return s < 1 ? 1 : (s > 128 ? 128 : s);
 }
 
 // attn[i][0..1] = softmax(logits[i][0..1]) over the radix pair (models/cotnet.py:99-101: view(B, C, radix), softmax(dim=2)); its backward
@@ -274,17 +286,23 @@ extern "C" int cot_study_radix_nhwc_mix_backward_apply(const void* gout, const v
     if (!gout || !attn || !gy || !gk) return -1;
     RADIX_NHWC_DISPATCH(4, gout, ggap, nullptr, attn, gy, gk, nullptr);
 }
-// out[C] = column sums of x[M][C] (bias gradient of a channels-last convolution); C a multiple of 8 (bf16) / 4 (fp32)
-extern "C" int cot_study_nhwc_col_sum(const void* x, void* out, int M, int C, int dtype, void* stream) {
-    if (!x || !out || M <= 0 || C <= 0) return -1;
+// out[C] = column sums of x[M][C] (bias gradient of a channels-last convolution); C a multiple of 8 (bf16) / 4 (fp32); workspace:
+// cot_study_nhwc_col_sum_workspace(M, C) floats
+extern "C" int cot_study_nhwc_col_sum_workspace(int M, int C) { return M > 0 && C > 0 ? cot::nhwc_col_sum_slabs(M) * C : 0; }
+extern "C" int cot_study_nhwc_col_sum(const void* x, void* out, float* workspace, int M, int C, int dtype, void* stream) {
+    if (!x || !out || !workspace || M <= 0 || C <= 0) return -1;
+    const int slabs = cot::nhwc_col_sum_slabs(M), rows_per = cot::ceil_div(M, slabs);
+    hipStream_t s = (hipStream_t)stream;
     if (dtype == 2) {
         if (C % 8) return -2;
-        COT_LAUNCH((cot::nhwc_col_sum<cot::bf16_t, 8>), dim3(cot::ceil_div(C, 256)), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
-                   (const cot::bf16_t*)x, (cot::bf16_t*)out, M, C);
+        COT_LAUNCH((cot::nhwc_col_sum<cot::bf16_t, 8>), dim3(cot::ceil_div(C, 256), slabs), dim3(256), 256 * 8 * sizeof(float), s, (const cot::bf16_t*)x,
+                   workspace, M, C, rows_per);
+        COT_LAUNCH((cot::nhwc_col_sum_finish<cot::bf16_t>), dim3(cot::ceil_div(C, 256)), dim3(256), 0, s, (const float*)workspace, (cot::bf16_t*)out, C, slabs);
     } else if (dtype == 0) {
         if (C % 4) return -2;
-        COT_LAUNCH((cot::nhwc_col_sum<float, 4>), dim3(cot::ceil_div(C, 128)), dim3(256), 256 * 4 * sizeof(float), (hipStream_t)stream,
-                   (const float*)x, (float*)out, M, C);
+        COT_LAUNCH((cot::nhwc_col_sum<float, 4>), dim3(cot::ceil_div(C, 128), slabs), dim3(256), 256 * 4 * sizeof(float), s, (const float*)x, workspace, M,
+                   C, rows_per);
+        COT_LAUNCH((cot::nhwc_col_sum_finish<float>), dim3(cot::ceil_div(C, 256)), dim3(256), 0, s, (const float*)workspace, (float*)out, C, slabs);
     } else {
         return -2;
     }

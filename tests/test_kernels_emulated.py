@@ -3167,3 +3167,19 @@ def test_radix_pair_softmax_and_weight_gradient_window():
     ref = dy.float().t() @ x.float()
     assert (wide[:, Ci:2 * Ci].float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-2
     assert (wide[:, :Ci] == 7).all() and (wide[:, 2 * Ci:] == 7).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C", [(15, 288), (392, 128), (1000, 72), (1, 8), (8200, 16)])
+def test_channels_last_column_sums(M, C, dtype):
+    """cot_study_nhwc_col_sum (the bias gradient of a channels-last convolution): row slabs across workgroups, fp32 partial sums added
+    in slab order, one rounding"""
+    dt = _lib.dtype_code(dtype)
+    torch.manual_seed(M + C)
+    x = torch.randn(M, C).to(dtype)
+    o = torch.full((C,), float("nan")).to(dtype)
+    ws = torch.full((_EMUL.cot_study_nhwc_col_sum_workspace(M, C),), float("nan"))
+    assert _EMUL.cot_study_nhwc_col_sum(P(x), P(o), P(ws), M, C, dt, None) == 0
+    ref = x.float().sum(0)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert ((o.float() - ref).abs() <= tol * (M ** 0.5 + ref.abs())).all()
