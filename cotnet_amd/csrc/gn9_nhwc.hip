@@ -1,6 +1,6 @@
 // gn9_nhwc.hip -- STUDY (the channels-last route): GroupNorm with 9 channels per group on channels-last attention
 // logits x[N][HW][9 * G] (CotLayer.embed[4] = nn.GroupNorm(dim/8, 9*dim/8), models/cotnet.py:56; csrc/group_norm9.hip is the NCHW
-// implementation).  A group is 9 consecutive channels of every pixel of one image: one workgroup per image, a thread owns one
+// implementation).  A group is 9 consecutive channels of every pixel of one image: a few workgroups per image (each a range of groups), a thread owns one
 // group of a row (18 contiguous bytes; a wave reads 64 such blocks back to back) and walks down the rows; statistics with the
 // group's first element as shift, two passes over the image inside the launch (the second one hits L2: an image's logits are
 // 9 * G * HW * 2 bytes = 113 KB at 14 x 14).  Exported as cot_study_group_norm9_nhwc_*; host-emulated tests only.
@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256) void gn9_nhwc_fwd(const T* __restrict__ x, con
                                                    float eps) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* sm = reinterpret_cast<float*>(cot_smem);
-    const int n = blockIdx.x, RP = 256 / G, wc = threadIdx.x % G, rl = threadIdx.x / G, C = 9 * G;
+    // gridDim.y workgroups share an image's groups: GL groups each, 256 / GL row lanes
+    const int GL = G / (int)gridDim.y, n = blockIdx.x, RP = 256 / GL, wl = threadIdx.x % GL, rl = threadIdx.x / GL, C = 9 * G;
+    const int wc = blockIdx.y * GL + wl;
     const T* xi = x + (int64_t)n * HW * C + wc * 9;
     T* yi = y + (int64_t)n * HW * C + wc * 9;
     const float shift = (float)xi[0];
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void gn9_nhwc_fwd(const T* __restrict__ x, con
             s[1] += d * d;
         }
     }
-    gn9_group_sum<2>(s, sm, G, RP, wc, rl);
+    gn9_group_sum<2>(s, sm, GL, RP, wl, rl);
     const float cnt = 9.f * (float)HW, md = s[0] / cnt, mu = shift + md;
     const float var = fmaxf(s[1] / cnt - md * md, 0.f), rs = 1.0f / sqrtf(var + eps);
     if (rl == 0) {
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(256) void gn9_nhwc_bwd(const T* __restrict__ dy, co
                                                    float* __restrict__ part, int HW, int G) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* sm = reinterpret_cast<float*>(cot_smem);
-    const int n = blockIdx.x, RP = 256 / G, wc = threadIdx.x % G, rl = threadIdx.x / G, C = 9 * G;
+    const int GL = G / (int)gridDim.y, n = blockIdx.x, RP = 256 / GL, wl = threadIdx.x % GL, rl = threadIdx.x / GL, C = 9 * G;
+    const int wc = blockIdx.y * GL + wl;
     const int64_t base = (int64_t)n * HW * C + wc * 9;
     const float mu = mean[n * G + wc], rs = rstd[n * G + wc];
     float ga[9];
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void gn9_nhwc_bwd(const T* __restrict__ dy, co
             v[11 + t] += d * xh;
         }
     }
-    gn9_group_sum<20>(v, sm, G, RP, wc, rl);
+    gn9_group_sum<20>(v, sm, GL, RP, wl, rl);
     if (rl == 0) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -125,11 +128,18 @@ __global__ __launch_bounds__(256) void gn9_nhwc_param_reduce(const float* __rest
     dbeta[c] = (T)b;
 }
 
+// workgroups per image: enough for ~512 in the launch, at least 4 groups each (G a power of two)
+static int gn9_nhwc_split(int N, int G) {
+    int s = 1;
+    while (s * 2 * N <= 512 && G / (s * 2) >= 4) s *= 2;
+    return s;
+}
+
 template <typename T>
 static int gn9_nhwc_run_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N, int C, int HW,
                             float eps, hipStream_t s) {
     const int G = C / 9;
-    COT_LAUNCH((gn9_nhwc_fwd<T>), dim3(N), dim3(256), 256 * 2 * sizeof(float), s, (const T*)x, (const T*)gamma, (const T*)beta, (T*)y, mean, rstd,
+    COT_LAUNCH((gn9_nhwc_fwd<T>), dim3(N, gn9_nhwc_split(N, G)), dim3(256), 256 * 2 * sizeof(float), s, (const T*)x, (const T*)gamma, (const T*)beta, (T*)y, mean, rstd,
                HW, G, eps);
     return check_launch("gn9_nhwc_forward");
 }
@@ -137,7 +147,7 @@ template <typename T>
 static int gn9_nhwc_run_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, void* dx, void* dgamma,
                             void* dbeta, float* ws, int N, int C, int HW, hipStream_t s) {
     const int G = C / 9;
-    COT_LAUNCH((gn9_nhwc_bwd<T>), dim3(N), dim3(256), 256 * 20 * sizeof(float), s, (const T*)dy, (const T*)x, mean, rstd, (const T*)gamma, (T*)dx,
+    COT_LAUNCH((gn9_nhwc_bwd<T>), dim3(N, gn9_nhwc_split(N, G)), dim3(256), 256 * 20 * sizeof(float), s, (const T*)dy, (const T*)x, mean, rstd, (const T*)gamma, (T*)dx,
                ws, HW, G);
     COT_LAUNCH((gn9_nhwc_param_reduce<T>), dim3(ceil_div(C, 256)), dim3(256), 0, s, (const float*)ws, (T*)dgamma, (T*)dbeta, N, C);
     return check_launch("gn9_nhwc_backward");
