@@ -32,7 +32,9 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void radix_nhwc_gap(const T* __restrict__ y, const T* __restrict__ k, T* __restrict__ gap, int HW, int C) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* sm = reinterpret_cast<float*>(cot_smem);
-    const int n = blockIdx.x, TPR = C / V, RP = 256 / TPR, cg = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    // gridDim.y workgroups share an image's channels: TPR threads per row each, 256 / TPR row lanes
+    const int n = blockIdx.x, TPR = C / V / (int)gridDim.y, RP = 256 / TPR, cl = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    const int cg = blockIdx.y * TPR + cl;
     const int64_t base = (int64_t)n * HW * C + cg * V;
     float s[V];
 #pragma unroll
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void radix_nhwc_gap(const T* __restrict__ y, c
 #pragma unroll
         for (int e = 0; e < V; ++e) s[e] += (float)a.v[e] + (float)b.v[e];
     }
-    radix_col_sum<V>(s, sm, TPR, RP, cg, rl);
+    radix_col_sum<V>(s, sm, TPR, RP, cl, rl);
     if (rl == 0) {
         Vec<T, V> o;
 #pragma unroll
@@ -78,7 +80,9 @@ __global__ __launch_bounds__(256) void radix_nhwc_mix_bwd(const T* __restrict__ 
                                                          T* __restrict__ gattn, int HW, int C) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* sm = reinterpret_cast<float*>(cot_smem);
-    const int n = blockIdx.x, TPR = C / V, RP = 256 / TPR, cg = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    // gridDim.y workgroups share an image's channels: TPR threads per row each, 256 / TPR row lanes
+    const int n = blockIdx.x, TPR = C / V / (int)gridDim.y, RP = 256 / TPR, cl = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    const int cg = blockIdx.y * TPR + cl;
     const int64_t base = (int64_t)n * HW * C + cg * V;
     float a0[V], a1[V], s[2 * V];
 #pragma unroll
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256) void radix_nhwc_mix_bwd(const T* __restrict__ 
         stv<T, V>(gy + off, oy);
         stv<T, V>(gk + off, ok);
     }
-    radix_col_sum<2 * V>(s, sm, TPR, RP, cg, rl);
+    radix_col_sum<2 * V>(s, sm, TPR, RP, cl, rl);
     if (rl == 0) {
 #pragma unroll
         for (int e = 0; e < 2 * V; ++e) gattn[((int64_t)n * C + cg * V) * 2 + e] = (T)s[e];
@@ -117,7 +121,9 @@ __global__ __launch_bounds__(256) void radix_nhwc_mix_bwd_reduce(const T* __rest
                                                                 T* __restrict__ gattn, int HW, int C) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* sm = reinterpret_cast<float*>(cot_smem);
-    const int n = blockIdx.x, TPR = C / V, RP = 256 / TPR, cg = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    // gridDim.y workgroups share an image's channels: TPR threads per row each, 256 / TPR row lanes
+    const int n = blockIdx.x, TPR = C / V / (int)gridDim.y, RP = 256 / TPR, cl = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+    const int cg = blockIdx.y * TPR + cl;
     const int64_t base = (int64_t)n * HW * C + cg * V;
     float s[2 * V];
 #pragma unroll
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void radix_nhwc_mix_bwd_reduce(const T* __rest
             s[2 * e + 1] += (float)g.v[e] * (float)b.v[e];
         }
     }
-    radix_col_sum<2 * V>(s, sm, TPR, RP, cg, rl);
+    radix_col_sum<2 * V>(s, sm, TPR, RP, cl, rl);
     if (rl == 0) {
 #pragma unroll
         for (int e = 0; e < 2 * V; ++e) gattn[((int64_t)n * C + cg * V) * 2 + e] = (T)s[e];
@@ -229,18 +235,20 @@ template <typename T, int V>
 static int radix_nhwc_run(int what, const void* gout, const void* y, const void* k, const void* attn, void* o1, void* o2, void* o3, int N,
                           int HW, int C, hipStream_t s) {
     if (!radix_nhwc_covers<T, V>(C)) return -2;
+    int split = 1;  // workgroups per image: ~512 in the launch, at least 4 threads per row each
+    while (split * 2 * N <= 512 && C / V / (split * 2) >= 4) split *= 2;
     if (what == 0) {
-        COT_LAUNCH((radix_nhwc_gap<T, V>), dim3(N), dim3(256), 256 * V * sizeof(float), s, (const T*)y, (const T*)k, (T*)o1, HW, C);
+        COT_LAUNCH((radix_nhwc_gap<T, V>), dim3(N, split), dim3(256), 256 * V * sizeof(float), s, (const T*)y, (const T*)k, (T*)o1, HW, C);
     } else if (what == 1) {
         const int64_t nvec = (int64_t)N * HW * C / V;
         int64_t b = ceil_div64(nvec, 256 * 2);
         b = b < 1 ? 1 : (b > 2048 ? 2048 : b);
         COT_LAUNCH((radix_nhwc_mix<T, V>), dim3((unsigned)b), dim3(256), 0, s, (const T*)y, (const T*)k, (const T*)attn, (T*)o1, HW, C, nvec);
     } else if (what == 2) {
-        COT_LAUNCH((radix_nhwc_mix_bwd<T, V>), dim3(N), dim3(256), 256 * 2 * V * sizeof(float), s, (const T*)gout, (const T*)y, (const T*)k,
+        COT_LAUNCH((radix_nhwc_mix_bwd<T, V>), dim3(N, split), dim3(256), 256 * 2 * V * sizeof(float), s, (const T*)gout, (const T*)y, (const T*)k,
                    (const T*)attn, (T*)o1, (T*)o2, (T*)o3, HW, C);
     } else if (what == 3) {
-        COT_LAUNCH((radix_nhwc_mix_bwd_reduce<T, V>), dim3(N), dim3(256), 256 * 2 * V * sizeof(float), s, (const T*)gout, (const T*)y,
+        COT_LAUNCH((radix_nhwc_mix_bwd_reduce<T, V>), dim3(N, split), dim3(256), 256 * 2 * V * sizeof(float), s, (const T*)gout, (const T*)y,
                    (const T*)k, (T*)o1, HW, C);
     } else {  // 4: apply; `y` carries ggap (may be NULL)
         const int64_t nvec = (int64_t)N * HW * C / V;
