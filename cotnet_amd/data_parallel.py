@@ -76,11 +76,11 @@ class GradBucketReducer:
         cap = int(bucket_mb * 1024 * 1024)
         self.buckets = []
         self._bucket_of = {}
-        open_buckets = {}  # (key, dtype) -> [params, bytes]; keeps reverse registration order inside each group
+        open_buckets = {}  # (key, param dtype, grad dtype) -> [params, bytes]; keeps reverse registration order inside each group
         order = []
         for p in reversed(params):
             dt = grad_dtype or p.dtype
-            k = (keys[p], dt)
+            k = (keys[p], p.dtype, dt)  # a bucket's flat PARAMETER buffer has one dtype too (fp32 BatchNorm beside bf16 biases)
             nbytes = p.numel() * torch.empty((), dtype=dt).element_size()
             cur = open_buckets.get(k)
             if cur is not None and cur[1] + nbytes > cap:
@@ -94,7 +94,7 @@ class GradBucketReducer:
         for k, cur in open_buckets.items():
             if cur[0]:
                 order.append((k, cur[0]))
-        for (key, dt), plist in order:
+        for (key, _pdt, dt), plist in order:
             self._make_bucket(plist, dt, key, flatten_params)
 
         if grad_mode == "copy":  # kernels that produce parameter gradients may write the bucket slots directly
@@ -107,7 +107,8 @@ class GradBucketReducer:
     # ------------------------------------------------------------------------------------------
     def _make_bucket(self, params, dtype, key=None, flatten_params=False):
         # every parameter starts on a 16-byte boundary so flat-buffer kernels can use 16-byte accesses per tensor
-        esz = torch.empty((), dtype=dtype).element_size()
+        # (in BOTH flat buffers: with fp32 gradients of bf16 parameters the offset granule comes from the narrower element)
+        esz = min(torch.empty((), dtype=dtype).element_size(), params[0].element_size() if flatten_params else 16)
         align = max(1, 16 // esz)
         offs, total = [], 0
         for p in params:
@@ -152,7 +153,7 @@ class GradBucketReducer:
             # would be overwritten (copy mode) or left out of the average.  The reference runs one backward per step
             # (train.py:264-274); a single process in view mode may accumulate (nothing was launched)
             raise RuntimeError("GradBucketReducer: a gradient arrived after its bucket was handed over -- call finish() once per "
-                               "backward()")
+                               "backward() (after an abandoned step, zero_grad() resets the buckets)")
         if self.grad_mode == "copy":
             b.fired.add(param)
             b.pending -= 1
@@ -261,7 +262,21 @@ class GradBucketReducer:
 
     def zero_grad(self):
         """zero the flat buckets (keeps the .grad views alive; use instead of optimizer.zero_grad(set_to_none=True)).
-        In copy mode nothing accumulates, so this only drops stale .grad tensors."""
+        In copy mode nothing accumulates, so this only drops stale .grad tensors.  Also the recovery path after a step that was
+        abandoned between backward() and finish() (exception, skipped NaN step): in-flight all-reduces are waited for and
+        every bucket's bookkeeping is reset, so the next backward() starts a fresh step."""
+        for b in self.buckets:
+            if b.work is not None:
+                if self.on_gpu:
+                    with torch.cuda.stream(self.comm_stream):
+                        b.work.wait()
+                else:
+                    b.work.wait()
+                b.work = None
+            b.fired.clear()
+            b.pending = len(b.params)
+        if self.on_gpu and self.enabled:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         if self.grad_mode == "copy":
             for b in self.buckets:
                 for p in b.params:

@@ -556,3 +556,49 @@ def test_producer_stream_registry_joins_before_a_bucket_copy():
     finally:
         del grad_sink._PRODUCERS[n0:]
 
+
+
+def test_fp32_gradient_buckets_on_the_mixed_precision_model():
+    """fp32 gradient buckets on the framework's own mixed model (fp32 BatchNorm parameters beside bf16 biases in
+    the 'no_decay' group): a bucket holds ONE parameter dtype, and every parameter AND every gradient slot starts on a 16-byte
+    boundary (the kernels' check_align16) although the offset granule of fp32 gradients alone would be 4 elements = 8 bytes of bf16"""
+    from cotnet_amd import create_model
+    from cotnet_amd.data_parallel import GradBucketReducer
+    from cotnet_amd.flat_sgd import _decay_group, to_mixed_bf16
+    model = to_mixed_bf16(create_model("cotnet50", num_classes=10))
+    red = GradBucketReducer(model, group_fn=_decay_group, grad_mode="copy", flatten_params=True, grad_dtype=torch.float32)
+    try:
+        assert {b.flat.dtype for b in red.buckets} == {torch.float32}
+        for b in red.buckets:
+            assert len({p.dtype for p in b.params}) == 1 and b.pflat.dtype == b.params[0].dtype
+            for p, v in zip(b.params, b.views):
+                assert p.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+                assert p.data_ptr() >= b.pflat.data_ptr() and p.data_ptr() < b.pflat.data_ptr() + b.pflat.numel() * b.pflat.element_size()
+        assert sum(len(b.params) for b in red.buckets) == sum(1 for p in model.parameters() if p.requires_grad)
+    finally:
+        red.remove()
+
+
+def test_zero_grad_recovers_from_a_step_abandoned_before_finish():
+    """backward() without finish() (exception in the loop, skipped step) must not wedge every later backward"""
+    from cotnet_amd.data_parallel import GradBucketReducer
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4))
+    for mode in ("copy", "view"):
+        red = GradBucketReducer(m, grad_mode=mode)
+        try:
+            m(torch.randn(3, 8)).sum().backward()       # step abandoned here: no finish()
+            if mode == "copy":
+                with pytest.raises(RuntimeError, match="zero_grad"):
+                    m(torch.randn(3, 8)).sum().backward()
+            red.zero_grad()
+            x = torch.randn(3, 8)
+            m(x).sum().backward()
+            red.finish()
+            got = [v.clone() for b in red.buckets for v in b.views]
+            red.zero_grad()
+            ref = torch.autograd.grad(m(x).sum(), [p for b in red.buckets for p in b.params])
+            for g, r in zip(got, ref):
+                assert torch.equal(g, r)
+        finally:
+            red.remove()
