@@ -121,6 +121,15 @@ SYMBOLS = {
     "cot_bn_relu_mask_bytes": (ctypes.c_int64, [_I, _I, _I, _I]),
     "cot_bn_act_forward_mask": (_I, [_P] * 13 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "cot_bn_act_backward_mask": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P]),
+    "cot_bn_act_lay_covers": (_I, [_I, _I, _I, _I]),
+    "cot_bn_act_forward_lay": (_I, [_P] * 12 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _I, _P]),
+    "cot_bn_act_backward_lay": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _I, _P]),
+    "cot_radix_gap_t_lay": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cot_radix_mix_logits_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
+    "cot_radix_mix_backward_reduce_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
+    "cot_radix_mix_backward_apply_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
+    "cot_group_norm9_forward_lay": (_I, [_P] * 6 + [_I, _I, _I, ctypes.c_float, _I, _I, _P]),
+    "cot_group_norm9_backward_lay": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P]),
     "cot_bn_act_inference": (_I, [_P] * 7 + [_I, _I, _I, ctypes.c_float, _I, _I, _P]),
     "cot_profile_begin": (_I, []),
     "cot_profile_end": (_I, [ctypes.POINTER(ProfileRec), _I]),

@@ -119,6 +119,11 @@ int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int,
 int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
 int ema_flat(void*, const void*, int64_t, float, int, hipStream_t);
 int bn_workspace_floats(int N, int C);
+int bn_act_lay_covers(int N, int C, int HW);
+int bn_act_forward_lay(const void*, const void*, void*, void*, const float*, const float*, float*, float*, float*, float*, long long*, int,
+                       int, int, float, float, int, const float*, int, hipStream_t);
+int bn_act_backward_lay(const void*, const void*, const void*, const void*, void*, void*, const float*, const float*, const float*,
+                        const float*, float*, float*, int, int, int, int, const float*, int, hipStream_t);
 int64_t bn_relu_mask_bytes(int N, int C, int HW, int esize);
 extern thread_local uint8_t* t_bn_mask;
 extern int g_bn_fold, g_bn_grid_cap, g_bn_small_m, g_bn_split_target;
@@ -195,9 +200,9 @@ int stem7x7_wgrad(const void*, const void*, void*, float*, int, int, int, hipStr
 // implemented in pool3x3.hip
 template <typename T> int pool3x3s2(int, const void*, const void*, void*, int64_t, int, int, hipStream_t);
 // implemented in group_norm9.hip
-int gn9_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, hipStream_t);
+int gn9_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, int, hipStream_t);
 int gn9_backward(const void*, const void*, const float*, const float*, const void*, void*, void*, void*, float*, int, int,
-                 int, hipStream_t);
+                 int, int, hipStream_t);
 int gn9f_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, hipStream_t);
 int gn9f_backward(const void*, const void*, const float*, const float*, const void*, void*, void*, void*, float*, int, int,
                   int, hipStream_t);
@@ -219,16 +224,16 @@ int conv3x3g_masks(void*, int, int, hipStream_t);
 int conv3x3g_gemm(const void*, const void*, void*, const void*, int, int, int, int, int, int, int, int, hipStream_t);
 int conv3x3g_wgrad_splits(int N, int Cin, int Cout, int G, int HW);
 int conv3x3g_wgrad(const void*, const void*, void*, const void*, float*, int, int, int, int, int, int, hipStream_t);
-template <typename T> int radix_gap_t(const void*, const void*, void*, int, int, int, hipStream_t);
+template <typename T> int radix_gap_t(const void*, const void*, void*, int, int, int, int, hipStream_t);
 template <typename T> int se_gap(const void*, void*, int64_t, int, hipStream_t);
 template <typename T> int se_gate(const void*, const void*, void*, int64_t, int, hipStream_t);
 template <typename T> int se_gate_bwd(const void*, const void*, const void*, void*, void*, int64_t, int, hipStream_t);
 template <typename T>
-int radix_mix_logits(const void*, const void*, const void*, void*, void*, int, int, int, hipStream_t);
+int radix_mix_logits(const void*, const void*, const void*, void*, void*, int, int, int, int, hipStream_t);
 template <typename T>
-int radix_mix_bwd_reduce(const void*, const void*, const void*, const void*, void*, int, int, int, hipStream_t);
+int radix_mix_bwd_reduce(const void*, const void*, const void*, const void*, void*, int, int, int, int, hipStream_t);
 template <typename T>
-int radix_mix_bwd_apply(const void*, const void*, const void*, void*, void*, int, int, int, hipStream_t);
+int radix_mix_bwd_apply(const void*, const void*, const void*, void*, void*, int, int, int, int, hipStream_t);
 int input_normalize(const void*, void*, const float*, const float*, int64_t, int, int, int, hipStream_t);  // input_norm.hip
 const char* last_kernel_nchw();
 const char* last_kernel_nhwc();
@@ -916,46 +921,61 @@ int cot_radix_mix_backward(const void* gout, const void* y, const void* k, const
 }
 
 int cot_radix_gap_t(const void* y, const void* k, void* gapT, int N, int C, int HW, int dtype, void* stream) {
+    return cot_radix_gap_t_lay(y, k, gapT, N, C, HW, 0, dtype, stream);
+}
+int cot_radix_gap_t_lay(const void* y, const void* k, void* gapT, int N, int C, int HW, int lay, int dtype, void* stream) {
     int rc = tail_check((int64_t)N * C, HW, dtype);
     if (rc) return rc;
     if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive N=%d C=%d", N, C);
     if (!y || !gapT) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");  // k == NULL: pool y alone
     if ((rc = check_align16({y, k}))) return rc;
-    return dtype == COT_F32 ? radix_gap_t<float>(y, k, gapT, N, C, HW, (hipStream_t)stream)
-                            : radix_gap_t<bf16_t>(y, k, gapT, N, C, HW, (hipStream_t)stream);
+    return dtype == COT_F32 ? radix_gap_t<float>(y, k, gapT, N, C, HW, lay, (hipStream_t)stream)
+                            : radix_gap_t<bf16_t>(y, k, gapT, N, C, HW, lay, (hipStream_t)stream);
 }
 
 int cot_radix_mix_logits(const void* y, const void* k, const void* logitsT, void* out, void* attn, int N, int C, int HW,
                          int dtype, void* stream) {
+    return cot_radix_mix_logits_lay(y, k, logitsT, out, attn, N, C, HW, 0, dtype, stream);
+}
+int cot_radix_mix_logits_lay(const void* y, const void* k, const void* logitsT, void* out, void* attn, int N, int C, int HW, int lay,
+                             int dtype, void* stream) {
     int rc = tail_check((int64_t)N * C, HW, dtype);
     if (rc) return rc;
     if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive N=%d C=%d", N, C);
     if (!y || !k || !logitsT || !out || !attn) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({y, k, out}))) return rc;
-    return dtype == COT_F32 ? radix_mix_logits<float>(y, k, logitsT, out, attn, N, C, HW, (hipStream_t)stream)
-                            : radix_mix_logits<bf16_t>(y, k, logitsT, out, attn, N, C, HW, (hipStream_t)stream);
+    return dtype == COT_F32 ? radix_mix_logits<float>(y, k, logitsT, out, attn, N, C, HW, lay, (hipStream_t)stream)
+                            : radix_mix_logits<bf16_t>(y, k, logitsT, out, attn, N, C, HW, lay, (hipStream_t)stream);
 }
 
 int cot_radix_mix_backward_reduce(const void* gout, const void* y, const void* k, const void* attn, void* glogitsT, int N,
                                   int C, int HW, int dtype, void* stream) {
+    return cot_radix_mix_backward_reduce_lay(gout, y, k, attn, glogitsT, N, C, HW, 0, dtype, stream);
+}
+int cot_radix_mix_backward_reduce_lay(const void* gout, const void* y, const void* k, const void* attn, void* glogitsT, int N,
+                                      int C, int HW, int lay, int dtype, void* stream) {
     int rc = tail_check((int64_t)N * C, HW, dtype);
     if (rc) return rc;
     if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive N=%d C=%d", N, C);
     if (!gout || !y || !k || !attn || !glogitsT) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gout, y, k}))) return rc;
-    return dtype == COT_F32 ? radix_mix_bwd_reduce<float>(gout, y, k, attn, glogitsT, N, C, HW, (hipStream_t)stream)
-                            : radix_mix_bwd_reduce<bf16_t>(gout, y, k, attn, glogitsT, N, C, HW, (hipStream_t)stream);
+    return dtype == COT_F32 ? radix_mix_bwd_reduce<float>(gout, y, k, attn, glogitsT, N, C, HW, lay, (hipStream_t)stream)
+                            : radix_mix_bwd_reduce<bf16_t>(gout, y, k, attn, glogitsT, N, C, HW, lay, (hipStream_t)stream);
 }
 
 int cot_radix_mix_backward_apply(const void* gout, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C,
                                  int HW, int dtype, void* stream) {
+    return cot_radix_mix_backward_apply_lay(gout, attn, ggapT, gy, gk, N, C, HW, 0, dtype, stream);
+}
+int cot_radix_mix_backward_apply_lay(const void* gout, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C,
+                                     int HW, int lay, int dtype, void* stream) {
     int rc = tail_check((int64_t)N * C, HW, dtype);
     if (rc) return rc;
     if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive N=%d C=%d", N, C);
     if (!gout || !attn || !ggapT || !gy || !gk) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({gout, gy, gk}))) return rc;
-    return dtype == COT_F32 ? radix_mix_bwd_apply<float>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream)
-                            : radix_mix_bwd_apply<bf16_t>(gout, attn, ggapT, gy, gk, N, C, HW, (hipStream_t)stream);
+    return dtype == COT_F32 ? radix_mix_bwd_apply<float>(gout, attn, ggapT, gy, gk, N, C, HW, lay, (hipStream_t)stream)
+                            : radix_mix_bwd_apply<bf16_t>(gout, attn, ggapT, gy, gk, N, C, HW, lay, (hipStream_t)stream);
 }
 
 int64_t cot_stem7x7s2_workspace(int N, int H, int W) {
@@ -1160,12 +1180,17 @@ static int gn9_validate(int N, int C, int HW, int dtype) {
 
 int cot_group_norm9_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N,
                             int C, int HW, float eps, int dtype, void* stream) {
+    return cot_group_norm9_forward_lay(x, gamma, beta, y, mean, rstd, N, C, HW, eps, 0, dtype, stream);
+}
+int cot_group_norm9_forward_lay(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N,
+                                int C, int HW, float eps, int lay, int dtype, void* stream) {
     int rc = gn9_validate(N, C, HW, dtype);
+    if (lay && dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_group_norm9_*_lay: COT_BF16 only");
     if (rc) return rc;
     if (!x || !gamma || !beta || !y || !mean || !rstd) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x, y}))) return rc;
     if (dtype == COT_F32) return gn9f_forward(x, gamma, beta, y, mean, rstd, N, C, HW, eps, (hipStream_t)stream);
-    rc = gn9_forward(x, gamma, beta, y, mean, rstd, N, C, HW, eps, (hipStream_t)stream);
+    rc = gn9_forward(x, gamma, beta, y, mean, rstd, N, C, HW, eps, lay, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_group_norm9_forward: %d pixels per plane exceed one workgroup", HW);
     return rc;
 }
@@ -1173,14 +1198,20 @@ int cot_group_norm9_forward(const void* x, const void* gamma, const void* beta, 
 int cot_group_norm9_backward(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma,
                              void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int dtype,
                              void* stream) {
+    return cot_group_norm9_backward_lay(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, N, C, HW, 0, dtype, stream);
+}
+int cot_group_norm9_backward_lay(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma,
+                                 void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int lay, int dtype,
+                                 void* stream) {
     int rc = gn9_validate(N, C, HW, dtype);
+    if (lay && dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_group_norm9_*_lay: COT_BF16 only");
     if (rc) return rc;
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace)
         return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({dy, x, dx}))) return rc;
     if (dtype == COT_F32)
         return gn9f_backward(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, N, C, HW, (hipStream_t)stream);
-    rc = gn9_backward(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, N, C, HW, (hipStream_t)stream);
+    rc = gn9_backward(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, N, C, HW, lay, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_group_norm9_backward: %d pixels per plane exceed one workgroup", HW);
     return rc;
 }
@@ -1271,6 +1302,51 @@ int cot_bn_act_backward(const void* dy, const void* x, const void* y, void* dx, 
                         float* workspace, int N, int C, int HW, int act, int dtype, void* stream) {
     return cot_bn_act_backward_ps(dy, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta, workspace, NULL,
                                   N, C, HW, act, dtype, stream);
+}
+
+// ---- per-tensor layouts: the channel-resident bf16 kernels with one layout bit per tensor, a second output and a second
+// upstream gradient
+int cot_bn_act_lay_covers(int N, int C, int HW, int dtype) {
+    return (dtype == COT_BF16 && N > 0 && C > 0 && HW > 0 && bn_act_lay_covers(N, C, HW)) ? 1 : 0;
+}
+int cot_bn_act_forward_lay(const void* x, const void* residual, void* y, void* y2, const float* gamma, const float* beta, float* save_mean,
+                           float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           const float* sample_scale, int N, int C, int HW, float eps, float momentum, int act, int lay, int dtype,
+                           void* stream) {
+    if (!x || !y || !gamma || !beta || !save_mean || !save_rstd) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2 || (lay & ~15)) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act/lay");
+    if ((running_mean == NULL) != (running_var == NULL))
+        return set_error(COT_ERR_INVALID_ARG, "running_mean and running_var must be given together");
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_*_lay: COT_BF16 only (dtype %d given)", dtype);
+    int rc = check_align16({x, residual, y, y2});
+    if (rc) return rc;
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    rc = bn_act_forward_lay(x, residual, y, y2, gamma, beta, save_mean, save_rstd, running_mean, running_var, (long long*)num_batches_tracked,
+                            N, C, HW, eps, momentum, act, sample_scale, lay, (hipStream_t)stream);
+    if (rc == -2) return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_forward_lay: N=%d C=%d HW=%d is off the channel-resident kernels (cot_bn_act_lay_covers)", N, C, HW);
+    if (p) prof::annotate_op(20, N, C, C, HW, 1, dtype, (residual ? 1 : 0) | (y2 ? 4 : 0));
+    return rc;
+}
+int cot_bn_act_backward_lay(const void* dy, const void* dy2, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
+                            const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                            const float* sample_scale, int N, int C, int HW, int act, int lay, int dtype, void* stream) {
+    if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_rstd || !dgamma || !dbeta)
+        return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (act == 1 && !y && dresidual) return set_error(COT_ERR_INVALID_ARG, "ReLU backward after a residual add needs the saved output y");
+    if (act == 2 && (dresidual || sample_scale))
+        return set_error(COT_ERR_UNSUPPORTED, "SiLU backward after a residual add / a per-sample scale is not covered");
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2 || (lay & ~63)) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act/lay");
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_*_lay: COT_BF16 only (dtype %d given)", dtype);
+    int rc = check_align16({dy, dy2, x, y, dx, dresidual});
+    if (rc) return rc;
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    rc = bn_act_backward_lay(dy, dy2, x, y, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta, N, C, HW, act, sample_scale, lay,
+                             (hipStream_t)stream);
+    if (rc == -2) return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_backward_lay: N=%d C=%d HW=%d is off the channel-resident kernels (cot_bn_act_lay_covers)", N, C, HW);
+    if (p) prof::annotate_op(21, N, C, C, HW, 1, dtype, (dresidual ? 1 : 0) | (y ? 2 : 0) | (dy2 ? 4 : 0));
+    return rc;
 }
 
 // ---- the same pair with the ReLU sign mask (bn3 + residual + ReLU): the forward also writes one byte per 8 output elements, the

@@ -49,31 +49,35 @@ template <int NT, int R, int AL>
 __global__ void __launch_bounds__(NT)
 gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int G, int HW,
-               float eps) {
+               float eps, int lay) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];  // 16 floats per reduced value
     float* smem = reinterpret_cast<float*>(cot_smem);
     const int t = threadIdx.x, g = blockIdx.x % G;
     const int wend = 64 * (uniform(t >> 6) + 1);        // one past this wave's last thread index
-    const int64_t base = (int64_t)blockIdx.x * 9 * HW;  // (n*G + g) * 9 channels
     const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
+    // per-tensor layout (round 5): bit 0 = x, bit 1 = y channel-major ([C][N][HW]: the group's channels are N*HW apart)
+    const int nimg = gridDim.x / G, img = blockIdx.x / G;
+    const int64_t nchw = (int64_t)blockIdx.x * 9 * HW, cmaj = ((int64_t)g * 9 * nimg + img) * HW;  // (n*G + g) * 9 channels
+    const int64_t base = (lay & 1) ? cmaj : nchw, xcs = (lay & 1) ? (int64_t)nimg * HW : HW;
+    const int64_t ybase = (lay & 2) ? cmaj : nchw, ycs = (lay & 2) ? (int64_t)nimg * HW : HW;
     uint32_t v[9][R][4];
     bool tail[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) tail[r] = 8 * (r * NT + wend) > HW;
-    if (base + 9 * (int64_t)HW + 8 <= total) {  // every workgroup but the tensor's last: loads only, in a straight line
+    if (base + 8 * xcs + HW + 8 <= total) {  // every workgroup but the tensor's last: loads only, in a straight line
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int cl = 0; cl < 9; ++cl)
-                load_packed<8, AL>(v[cl][r], x + base + (int64_t)cl * HW + min(8 * (r * NT + t), HW), 8, true);
+                load_packed<8, AL>(v[cl][r], x + base + cl * xcs + min(8 * (r * NT + t), HW), 8, true);
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int p = 8 * (r * NT + t);
 #pragma unroll
             for (int cl = 0; cl < 9; ++cl)
-                load_packed<8, AL>(v[cl][r], x + base + (int64_t)cl * HW + min(p, HW), HW - p,
-                                   !tail[r] || base + (int64_t)(cl + 1) * HW + 8 <= total);
+                load_packed<8, AL>(v[cl][r], x + base + cl * xcs + min(p, HW), HW - p,
+                                   !tail[r] || base + cl * xcs + HW + 8 <= total);
         }
     }
 #pragma unroll
@@ -119,7 +123,7 @@ gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, c
             bf16_t o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(packed_get(v[cl][r], e) * ga + be);
-            if (p < HW) store_piece<8, AL>(y + base + (int64_t)cl * HW + p, o, HW - p);
+            if (p < HW) store_piece<8, AL>(y + ybase + cl * ycs + p, o, HW - p);
         }
     }
 }
@@ -128,25 +132,30 @@ template <int NT, int R, int AL>
 __global__ void __launch_bounds__(NT)
 gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean_in,
                const float* __restrict__ rstd_in, const bf16_t* __restrict__ gamma, bf16_t* __restrict__ dx,
-               float* __restrict__ part, int G, int HW) {
+               float* __restrict__ part, int G, int HW, int lay) {
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* smem = reinterpret_cast<float*>(cot_smem);
     const int t = threadIdx.x, g = blockIdx.x % G;
     const int wend = 64 * (uniform(t >> 6) + 1);
-    const int64_t base = (int64_t)blockIdx.x * 9 * HW;
     const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
+    // per-tensor layout: bit 0 = dy, bit 1 = x, bit 2 = dx channel-major
+    const int nimg = gridDim.x / G, img = blockIdx.x / G;
+    const int64_t nchw = (int64_t)blockIdx.x * 9 * HW, cmaj = ((int64_t)g * 9 * nimg + img) * HW, cms = (int64_t)nimg * HW;
+    const int64_t gbase = (lay & 1) ? cmaj : nchw, gcs = (lay & 1) ? cms : HW;
+    const int64_t base = (lay & 2) ? cmaj : nchw, xcs = (lay & 2) ? cms : HW;
+    const int64_t dbase = (lay & 4) ? cmaj : nchw, dcs = (lay & 4) ? cms : HW;
     uint32_t xv[9][R][4], gv[9][R][4];
     bool tail[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) tail[r] = 8 * (r * NT + wend) > HW;
-    if (base + 9 * (int64_t)HW + 8 <= total) {  // every workgroup but the tensor's last: loads only, in a straight line
+    if (base + 8 * xcs + HW + 8 <= total && gbase + 8 * gcs + HW + 8 <= total) {  // every workgroup but the tensor's last: loads only
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int cl = 0; cl < 9; ++cl) {
-                const int64_t o = base + (int64_t)cl * HW + min(8 * (r * NT + t), HW);
-                load_packed<8, AL>(xv[cl][r], x + o, 8, true);
-                load_packed<8, AL>(gv[cl][r], dy + o, 8, true);
+                const int o = min(8 * (r * NT + t), HW);
+                load_packed<8, AL>(xv[cl][r], x + base + cl * xcs + o, 8, true);
+                load_packed<8, AL>(gv[cl][r], dy + gbase + cl * gcs + o, 8, true);
             }
     } else {
 #pragma unroll
@@ -154,9 +163,8 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
             const int p = 8 * (r * NT + t);
 #pragma unroll
             for (int cl = 0; cl < 9; ++cl) {
-                const bool wide = !tail[r] || base + (int64_t)(cl + 1) * HW + 8 <= total;
-                load_packed<8, AL>(xv[cl][r], x + base + (int64_t)cl * HW + min(p, HW), HW - p, wide);
-                load_packed<8, AL>(gv[cl][r], dy + base + (int64_t)cl * HW + min(p, HW), HW - p, wide);
+                load_packed<8, AL>(xv[cl][r], x + base + cl * xcs + min(p, HW), HW - p, !tail[r] || base + cl * xcs + HW + 8 <= total);
+                load_packed<8, AL>(gv[cl][r], dy + gbase + cl * gcs + min(p, HW), HW - p, !tail[r] || gbase + cl * gcs + HW + 8 <= total);
             }
         }
     }
@@ -220,7 +228,7 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
                 const float xh = (packed_get(xv[cl][r], e) - mean) * rstd;
                 o[e] = (bf16_t)(rstd * (ga * packed_get(gv[cl][r], e) - c1 - xh * c2));
             }
-            if (p < HW) store_piece<8, AL>(dx + base + (int64_t)cl * HW + p, o, HW - p);
+            if (p < HW) store_piece<8, AL>(dx + dbase + cl * dcs + p, o, HW - p);
         }
     }
 }
@@ -405,34 +413,34 @@ int gn9_stats_finalize(const float* part, float* mean, float* rstd, int N, int C
 }
 
 int gn9_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N, int C,
-                int HW, float eps, hipStream_t stream) {
+                int HW, float eps, int lay, hipStream_t stream) {
     const int cfg = gn9_config(HW), G = C / 9;
     if (!cfg) return COT_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)((int64_t)N * G));
 #define GN9_FWD(NT_, R_)                                                                                             \
     if (HW % 8 == 0)                                                                                                 \
         COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 16>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma, \
-                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps);                                         \
+                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay);                                    \
     else                                                                                                             \
         COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 2>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma,  \
-                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps)
+                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay)
     GN9_SWITCH(cfg, GN9_FWD)
 #undef GN9_FWD
     return check_launch("gn9_fwd_kernel");
 }
 
 int gn9_backward(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, void* dx,
-                 void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, hipStream_t stream) {
+                 void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int lay, hipStream_t stream) {
     const int cfg = gn9_config(HW), G = C / 9;
     if (!cfg) return COT_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)((int64_t)N * G));
 #define GN9_BWD(NT_, R_)                                                                                             \
     if (HW % 8 == 0)                                                                                                 \
         COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 16>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,    \
-                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW);                                 \
+                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay);                            \
     else                                                                                                             \
         COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 2>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,     \
-                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW)
+                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay)
     GN9_SWITCH(cfg, GN9_BWD)
 #undef GN9_BWD
     int rc = check_launch("gn9_bwd_kernel");

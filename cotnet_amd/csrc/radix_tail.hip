@@ -96,16 +96,22 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_kernel(const T* __restrict_
 //   radix_mix_logits     a0 = softmax over the pair (logitsT[2c][n], logitsT[2c+1][n]); out = y*a0 + k*a1; attn saved
 //   radix_mix_bwd_reduce s0 = sum g*y, s1 = sum g*k;  glogitsT[2c][n] = a0*a1*(s0 - s1) = -glogitsT[2c+1][n]
 //   radix_mix_bwd_apply  gy = g*a0 + ggapT[c][n]/HW,  gk = g*a1 + ggapT[c][n]/HW
+// per-tensor layout bit (round 5): 0 = plane (n, c) at (n*C + c)*HW (NCHW), 1 = at (c*N + n)*HW (channel-major)
+__device__ __forceinline__ int64_t tail_base(int cm, int n, int c, int N, int C, int HW) {
+    return ((int64_t)(cm ? c * N + n : n * C + c)) * HW;
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void radix_gap_t_kernel(const T* __restrict__ y, const T* __restrict__ k,
-                                                         T* __restrict__ gapT, int N, int C, int HW) {
+                                                         T* __restrict__ gapT, int N, int C, int HW, int lay) {
     const int lane = threadIdx.x & 63;
     const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (plane >= (int64_t)N * C) return;
-    const T* yp = y + plane * HW;
+    const int n = (int)(plane / C), c = (int)(plane % C);
+    const T* yp = y + tail_base(lay & 1, n, c, N, C, HW);
     float acc = 0.f;
     if (k) {
-        const T* kp = k + plane * HW;
+        const T* kp = k + tail_base(lay & 2, n, c, N, C, HW);
         for (int i = lane * V; i < HW; i += 64 * V) {
             const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
 #pragma unroll
@@ -119,14 +125,13 @@ __global__ __launch_bounds__(256) void radix_gap_t_kernel(const T* __restrict__ 
         }
     }
     acc = wave_sum_f(acc);
-    const int n = (int)(plane / C), c = (int)(plane % C);
     if (lane == 0) gapT[(int64_t)c * N + n] = (T)(acc / (float)HW);
 }
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void radix_mix_logits_kernel(const T* __restrict__ y, const T* __restrict__ k,
                                                               const T* __restrict__ logitsT, T* __restrict__ out,
-                                                              T* __restrict__ attn, int N, int C, int HW) {
+                                                              T* __restrict__ attn, int N, int C, int HW, int lay) {
     const int lane = threadIdx.x & 63;
     const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (plane >= (int64_t)N * C) return;
@@ -137,9 +142,9 @@ __global__ __launch_bounds__(256) void radix_mix_logits_kernel(const T* __restri
         attn[plane * 2] = (T)a0;
         attn[plane * 2 + 1] = (T)a1;
     }
-    const T* yp = y + plane * HW;
-    const T* kp = k + plane * HW;
-    T* op = out + plane * HW;
+    const T* yp = y + tail_base(lay & 1, n, c, N, C, HW);
+    const T* kp = k + tail_base(lay & 2, n, c, N, C, HW);
+    T* op = out + tail_base(lay & 4, n, c, N, C, HW);
     for (int i = lane * V; i < HW; i += 64 * V) {
         const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
         Vec<T, V> o;
@@ -152,14 +157,17 @@ __global__ __launch_bounds__(256) void radix_mix_logits_kernel(const T* __restri
 template <typename T, int V>
 __global__ __launch_bounds__(256) void radix_mix_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                   const T* __restrict__ k, const T* __restrict__ attn,
-                                                                  T* __restrict__ glogitsT, int N, int C, int HW) {
+                                                                  T* __restrict__ glogitsT, int N, int C, int HW, int lay) {
     const int lane = threadIdx.x & 63;
     const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (plane >= (int64_t)N * C) return;
-    const int64_t base = plane * HW;
+    const int n = (int)(plane / C), c = (int)(plane % C);
+    const T* gp = g + tail_base(lay & 1, n, c, N, C, HW);
+    const T* yp = y + tail_base(lay & 2, n, c, N, C, HW);
+    const T* kp = k + tail_base(lay & 4, n, c, N, C, HW);
     float s0 = 0.f, s1 = 0.f;
     for (int i = lane * V; i < HW; i += 64 * V) {
-        const Vec<T, V> gv = ldv<T, V>(g + base + i), a = ldv<T, V>(y + base + i), b = ldv<T, V>(k + base + i);
+        const Vec<T, V> gv = ldv<T, V>(gp + i), a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const float gg = (float)gv.v[j];
@@ -172,7 +180,6 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_reduce_kernel(const T* __re
     if (lane == 0) {
         const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
         const float gl = a0 * a1 * (s0 - s1);  // softmax backward for a pair: gl0 = a0*(s0 - (a0*s0 + a1*s1))
-        const int n = (int)(plane / C), c = (int)(plane % C);
         glogitsT[(int64_t)(2 * c) * N + n] = (T)gl;
         glogitsT[(int64_t)(2 * c + 1) * N + n] = (T)(-gl);
     }
@@ -181,16 +188,18 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_reduce_kernel(const T* __re
 template <typename T, int V>
 __global__ __launch_bounds__(256) void radix_mix_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ attn,
                                                                  const T* __restrict__ ggapT, T* __restrict__ gy,
-                                                                 T* __restrict__ gk, int N, int C, int HW) {
+                                                                 T* __restrict__ gk, int N, int C, int HW, int lay) {
     const int lane = threadIdx.x & 63;
     const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (plane >= (int64_t)N * C) return;
     const int n = (int)(plane / C), c = (int)(plane % C);
     const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
     const float add = (float)ggapT[(int64_t)c * N + n] / (float)HW;  // d mean_hw(y + k)
-    const int64_t base = plane * HW;
+    const T* gp = g + tail_base(lay & 1, n, c, N, C, HW);
+    T* gyp = gy + tail_base(lay & 2, n, c, N, C, HW);
+    T* gkp = gk + tail_base(lay & 4, n, c, N, C, HW);
     for (int i = lane * V; i < HW; i += 64 * V) {
-        const Vec<T, V> gv = ldv<T, V>(g + base + i);
+        const Vec<T, V> gv = ldv<T, V>(gp + i);
         Vec<T, V> oy, ok;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -198,8 +207,8 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_apply_kernel(const T* __res
             oy.v[j] = (T)(gg * a0 + add);
             ok.v[j] = (T)(gg * a1 + add);
         }
-        stv<T, V>(gy + base + i, oy);
-        stv<T, V>(gk + base + i, ok);
+        stv<T, V>(gyp + i, oy);
+        stv<T, V>(gkp + i, ok);
     }
 }
 
@@ -317,31 +326,31 @@ int se_gate_bwd(const void* g, const void* x, const void* logit, void* gx, void*
     return check_launch("se_gate_bwd");
 }
 
-template <typename T> int radix_gap_t(const void* y, const void* k, void* gapT, int N, int C, int HW, hipStream_t s) {
+template <typename T> int radix_gap_t(const void* y, const void* k, void* gapT, int N, int C, int HW, int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
-    TAIL_DISPATCH(radix_gap_t_kernel, (const T*)y, (const T*)k, (T*)gapT, N, C, HW);
+    TAIL_DISPATCH(radix_gap_t_kernel, (const T*)y, (const T*)k, (T*)gapT, N, C, HW, lay);
     return check_launch("radix_gap_t");
 }
 template <typename T>
 int radix_mix_logits(const void* y, const void* k, const void* logitsT, void* out, void* attn, int N, int C, int HW,
-                     hipStream_t s) {
+                     int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
-    TAIL_DISPATCH(radix_mix_logits_kernel, (const T*)y, (const T*)k, (const T*)logitsT, (T*)out, (T*)attn, N, C, HW);
+    TAIL_DISPATCH(radix_mix_logits_kernel, (const T*)y, (const T*)k, (const T*)logitsT, (T*)out, (T*)attn, N, C, HW, lay);
     return check_launch("radix_mix_logits");
 }
 template <typename T>
 int radix_mix_bwd_reduce(const void* g, const void* y, const void* k, const void* attn, void* glogitsT, int N, int C,
-                         int HW, hipStream_t s) {
+                         int HW, int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
     TAIL_DISPATCH(radix_mix_bwd_reduce_kernel, (const T*)g, (const T*)y, (const T*)k, (const T*)attn, (T*)glogitsT, N,
-                  C, HW);
+                  C, HW, lay);
     return check_launch("radix_mix_bwd_reduce");
 }
 template <typename T>
 int radix_mix_bwd_apply(const void* g, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C, int HW,
-                        hipStream_t s) {
+                        int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
-    TAIL_DISPATCH(radix_mix_bwd_apply_kernel, (const T*)g, (const T*)attn, (const T*)ggapT, (T*)gy, (T*)gk, N, C, HW);
+    TAIL_DISPATCH(radix_mix_bwd_apply_kernel, (const T*)g, (const T*)attn, (const T*)ggapT, (T*)gy, (T*)gk, N, C, HW, lay);
     return check_launch("radix_mix_bwd_apply");
 }
 
@@ -350,15 +359,15 @@ int radix_mix_bwd_apply(const void* g, const void* attn, const void* ggapT, void
     template int radix_mix<T>(const void*, const void*, const void*, void*, int64_t, int, hipStream_t);            \
     template int radix_mix_bwd<T>(const void*, const void*, const void*, const void*, void*, void*, void*, int64_t, \
                                   int, hipStream_t);                                                               \
-    template int radix_gap_t<T>(const void*, const void*, void*, int, int, int, hipStream_t);                      \
+    template int radix_gap_t<T>(const void*, const void*, void*, int, int, int, int, hipStream_t);                      \
     template int se_gap<T>(const void*, void*, int64_t, int, hipStream_t);                                         \
     template int se_gate<T>(const void*, const void*, void*, int64_t, int, hipStream_t);                           \
     template int se_gate_bwd<T>(const void*, const void*, const void*, void*, void*, int64_t, int, hipStream_t);   \
-    template int radix_mix_logits<T>(const void*, const void*, const void*, void*, void*, int, int, int,           \
+    template int radix_mix_logits<T>(const void*, const void*, const void*, void*, void*, int, int, int, int,      \
                                      hipStream_t);                                                                 \
     template int radix_mix_bwd_reduce<T>(const void*, const void*, const void*, const void*, void*, int, int, int, \
-                                         hipStream_t);                                                             \
-    template int radix_mix_bwd_apply<T>(const void*, const void*, const void*, void*, void*, int, int, int,        \
+                                         int, hipStream_t);                                                        \
+    template int radix_mix_bwd_apply<T>(const void*, const void*, const void*, void*, void*, int, int, int, int,   \
                                         hipStream_t);
 INST(float)
 INST(bf16_t)

@@ -447,6 +447,42 @@ int cot_bn_act_forward_mask(const void* x, const void* residual, void* y, void* 
 int cot_bn_act_backward_mask(const void* dy, const void* x, const void* relu_mask, void* dx, void* dresidual, const float* gamma,
                              const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
                              float* workspace, const float* sample_scale, int N, int C, int HW, int act, int dtype, void* stream);
+/* ---- per-tensor layouts for the deep stages (round 5).  The 1x1 convolutions and BatchNorms of a Bottleneck
+ * (models/cotnet.py:228-264, :43-62) take any layout in which a channel's samples are contiguous; stored "channel-major" --
+ * [C][N][HW], element (n, c, p) at (c*N + n)*HW + p -- a channel is ONE row of N*HW elements and the ordinary entry points above
+ * (cot_conv1x1_*, cot_bn_act_*) serve it with N = 1, HW' = N*HW (measured 1.2-1.5x faster than [N][C][HW] on the 14 x 14 / 7 x 7
+ * layers, profiles/r05_probe_cnhw.log).  The plane kernels between them (grouped 3x3, aggregation) stay NCHW; the layout changes
+ * inside kernels that move every element anyway.  `lay` is a bit mask with one bit per tensor argument in the order given below:
+ * 0 = NCHW, 1 = channel-major.  COT_BF16 only.
+ *   cot_bn_act_forward_lay    cot_bn_act_forward_ps with a second output y2 (NULL: none) of the same values; lay bits: 1 x, 2 residual,
+ *                             4 y, 8 y2.  cot_bn_act_lay_covers(N, C, HW, dtype) == 1 where the channel-resident kernels hold a
+ *                             channel (else COT_ERR_UNSUPPORTED: keep one layout)
+ *   cot_bn_act_backward_lay   cot_bn_act_backward_ps whose upstream gradient is dy + dy2 (dy2 NULL: dy alone; fp32 sum, one
+ *                             rounding); lay bits: 1 dy, 2 dy2, 4 x, 8 y, 16 dx, 32 dresidual
+ *   cot_radix_*_lay           lay bits in argument order of the plane tensors: gap_t: 1 y, 2 k;  mix_logits: 1 y, 2 k, 4 out;
+ *                             backward_reduce: 1 gout, 2 y, 4 k;  backward_apply: 1 gout, 2 gy, 4 gk.  (attn, gapT, logitsT keep
+ *                             their index order)
+ *   cot_group_norm9_*_lay     forward: 1 x, 2 y;  backward: 1 dy, 2 x, 4 dx */
+int cot_bn_act_lay_covers(int N, int C, int HW, int dtype);
+int cot_bn_act_forward_lay(const void* x, const void* residual, void* y, void* y2, const float* gamma, const float* beta, float* save_mean,
+                           float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           const float* sample_scale, int N, int C, int HW, float eps, float momentum, int act, int lay, int dtype,
+                           void* stream);
+int cot_bn_act_backward_lay(const void* dy, const void* dy2, const void* x, const void* y, void* dx, void* dresidual, const float* gamma,
+                            const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                            const float* sample_scale, int N, int C, int HW, int act, int lay, int dtype, void* stream);
+int cot_radix_gap_t_lay(const void* y, const void* k, void* gapT, int N, int C, int HW, int lay, int dtype, void* stream);
+int cot_radix_mix_logits_lay(const void* y, const void* k, const void* logitsT, void* out, void* attn, int N, int C, int HW, int lay,
+                             int dtype, void* stream);
+int cot_radix_mix_backward_reduce_lay(const void* gout, const void* y, const void* k, const void* attn, void* glogitsT, int N,
+                                      int C, int HW, int lay, int dtype, void* stream);
+int cot_radix_mix_backward_apply_lay(const void* gout, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C,
+                                     int HW, int lay, int dtype, void* stream);
+int cot_group_norm9_forward_lay(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N,
+                                int C, int HW, float eps, int lay, int dtype, void* stream);
+int cot_group_norm9_backward_lay(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma,
+                                 void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int lay, int dtype,
+                                 void* stream);
 /* inference mode (nn.BatchNorm2d.eval()): y = act(gamma*(x - running_mean)/sqrt(running_var + eps) + beta [+ residual]) in one
  * pass; nothing is updated. */
 int cot_bn_act_inference(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
