@@ -28,7 +28,7 @@ from . import grad_sink
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "pending", "work", "ready_event", "key", "views", "pflat", "fired")
+    __slots__ = ("flat", "params", "pending", "work", "ready_event", "key", "views", "pflat", "fired", "offs")
 
     def __init__(self, flat, params, key=None):
         self.flat = flat
@@ -40,6 +40,7 @@ class _Bucket:
         self.views = []      # per-parameter views into `flat`
         self.pflat = None    # flat PARAMETER storage (flatten_params=True)
         self.fired = set()
+        self.offs = []
 
 
 class GradBucketReducer:
@@ -116,6 +117,7 @@ class GradBucketReducer:
             total += (p.numel() + align - 1) // align * align
         flat = torch.zeros(total, dtype=dtype, device=self.device)
         b = _Bucket(flat, params, key)
+        b.offs = offs        # element offset of every parameter's slot (the same in the gradient and the parameter buffer)
         if flatten_params:
             b.pflat = torch.zeros(total, dtype=params[0].dtype, device=self.device)
         for p, off in zip(params, offs):

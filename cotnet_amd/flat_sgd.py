@@ -116,11 +116,8 @@ class FlatSGD:
         by_param = {}
         esz = {}
         for b, st in zip(self.reducer.buckets, self.state):
-            off = 0
-            align = max(1, 16 // b.flat.element_size())
-            for p in b.params:
+            for p, off in zip(b.params, b.offs):
                 by_param[p] = st["ema"][off:off + p.numel()].view_as(p)
-                off += (p.numel() + align - 1) // align * align
         by_buf = {id(bf): e for bf, e in zip(self._buf_src, self._buf_ema)}
         out = {}
         params = dict(self.model.named_parameters())
@@ -141,9 +138,6 @@ class FlatSGD:
         out = {}
         for b, st in zip(self.reducer.buckets, self.state):
             src = st["master"] if st["master"] is not None else b.pflat
-            off = 0
-            esz_align = max(1, 16 // b.flat.element_size())
-            for p in b.params:
+            for p, off in zip(b.params, b.offs):
                 out[p] = src[off:off + p.numel()].view_as(p)
-                off += (p.numel() + esz_align - 1) // esz_align * esz_align
         return out

@@ -189,6 +189,8 @@ class ResNet(nn.Module):
         x = stem_forward(self.conv1, self.bn1, self.act1, x)  # stem BN + ReLU in one pass over 112x112
         x = pool(self.maxpool, x)
         x = self.layer2(self.layer1(x))
+        for stage in (self.layer3, self.layer4):  # (which blocks hand a channel-major tensor to their successor: DESIGN 5.8)
+            cot_layer_fused.plan_stage_layouts(stage)
         if os.environ.get("COT_CHANNELS_LAST_STUDY", "0") == "1":
             # STUDY switch (default off): the stride-1 blocks of the 14 x 14 / 7 x 7 stages as channels-last nodes on the
             # study kernels, a layout change either side of each run of them

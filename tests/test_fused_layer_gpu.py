@@ -180,3 +180,35 @@ def test_recipe_model_runs_on_the_single_node_path():
             h.remove()
     assert len(names) == 16 and all(n.startswith("_BottleneckNode") for n in names)
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad.float()).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("N,planes,H,blocks", [(80, 256, 14, 3), (80, 512, 7, 2), (8, 256, 14, 2)])
+def test_channel_major_deep_stage_blocks_against_fp32_truth(N, planes, H, blocks):
+    """a run of identity Bottlenecks of layer3 / layer4 (models/cotnet.py:181-264) at the benchmark batch through the channel-major
+    node (cot_layer_fused._BottleneckCMNode: NCHW in -> channel-major between the blocks -> NCHW out): no further from
+    an fp32 evaluation of the same modules than the NCHW single-node path is, same gradients / buffers surface"""
+    from torch import nn
+    torch.manual_seed(planes + H)
+    inpl = 4 * planes
+    stage = nn.Sequential(*[Bottleneck(inpl, planes) for _ in range(blocks)]).to(DEV).train()
+    with torch.no_grad():
+        for p in stage.parameters():
+            if p.ndim == 1:
+                p.add_(0.3 * torch.randn_like(p))
+        for b in stage:
+            b.bn3.weight.fill_(0.8)
+    stage = to_mixed_bf16(stage)
+    with truth.switches(cm=True):
+        clf.plan_stage_layouts(stage)
+    assert [b._next_cm for b in stage] == [True] * (blocks - 1) + [False]
+    x = torch.randn(N, inpl, H, H, device=DEV).bfloat16()
+    g = torch.randn(N, inpl, H, H, device=DEV).bfloat16()
+    cand, base = dict(truth.SINGLE_NODE, cm=True), dict(truth.SINGLE_NODE, cm=False)
+    truth.check_against_truth(stage, x, g, cand=cand, base=base)
+    yc, gxc, gc, mc, node = truth.run(stage, x, g, want_module=True, **cand)
+    yb, gxb, gb, mb, node_b = truth.run(stage, x, g, want_module=True, **base)
+    assert node.startswith("_BottleneckCMNode") and node_b.startswith("_BottleneckNode")
+    assert set(gc) == set(gb) == {n for n, _ in stage.named_parameters()}
+    assert truth.err(yc, yb) < 2e-2 and truth.err(gxc, gxb) < 8e-2
+    for (n_, a), (_, b) in zip(mc.named_buffers(), mb.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), atol=2e-3, rtol=2e-3), n_

@@ -45,3 +45,79 @@ def test_radix_tail_layouts(HW):
 @pytest.mark.parametrize("HW", [196, 49, 784])
 def test_group_norm9_layouts(HW):
     lc.gn9_case(_EMUL, "cpu", None, 3, 4, HW)
+
+
+@pytest.mark.parametrize("H,blocks", [(14, 3), (7, 2)])
+def test_channel_major_bottlenecks_against_the_nchw_single_node(H, blocks, monkeypatch):
+    """a run of identity Bottlenecks of a deep stage (models/cotnet.py:181-264) through cot_layer_fused._BottleneckCMNode -- first block
+    NCHW in / channel-major out, middle ones channel-major both sides, last one back to NCHW -- against the same blocks through the
+    NCHW single-node path (_BottleneckNode), both on the host-emulated kernels.  Same kernels and rounding points; what differs is the
+    order of a few sums (channel rows of N*HW elements instead of N rows of HW), so the two agree to bf16 ulps, with a few flipped ReLU
+    decisions at bn3 (compared like tests/test_kernels_emulated.py::test_fused_bottleneck_node_on_emulated_kernels)."""
+    import copy
+
+    import torch
+    from torch import nn
+
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, radix_tail
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    torch.manual_seed(6 + H)
+    N, W = 6 if H == 14 else 8, H
+    stage = nn.Sequential(*[Bottleneck(256, 64).train() for _ in range(blocks)])
+    with torch.no_grad():
+        for p in stage.parameters():
+            if p.ndim == 1:
+                p.add_(0.3 * torch.randn_like(p))
+        for b in stage:
+            b.bn3.weight.fill_(0.8)
+    stage = to_mixed_bf16(stage)
+    ref = copy.deepcopy(stage)
+    x = torch.randn(N, 256, H, W).bfloat16()
+    g = torch.randn(N, 256, H, W).bfloat16()
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, clf._CM_SIZES, clf._CM_OK)
+    for cache in caches:
+        cache.clear()
+    monkeypatch.setattr(clf, "ENABLED", True)
+
+    monkeypatch.setattr(clf, "CM_LAYOUT", False)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    assert yr.grad_fn.name().startswith("_BottleneckNode")
+    yr.backward(g)
+
+    monkeypatch.setattr(clf, "CM_LAYOUT", True)
+    clf.plan_stage_layouts(stage)
+    assert [b._next_cm for b in stage] == [True] * (blocks - 1) + [False]
+    xf = x.clone().requires_grad_(True)
+    h, seen = xf, []
+    for b in stage:
+        assert clf.cm_block_eligible(b, h)
+        h = b(h)
+        assert h.grad_fn.name().startswith("_BottleneckCMNode")
+        seen.append(clf._is_cm(h))
+    assert seen == [True] * (blocks - 1) + [False] and h.is_contiguous()
+    h.backward(g)
+
+    def relmax(a, b):
+        return ((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-6)).item()
+
+    def rel(a, b):
+        return ((a.float() - b.float()).abs().mean() / (b.float().abs().mean() + 1e-6)).item()
+
+    assert relmax(h, yr.detach()) < 1e-2
+    assert rel(xf.grad, xr.grad) < 6e-2 and xf.grad.is_contiguous()
+    pr = dict(ref.named_parameters())
+    top = max(q.grad.float().abs().max() for q in pr.values())
+    for n_, p in stage.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == p.dtype, n_
+        if pr[n_].grad.float().abs().max() > 1e-3 * top and not n_.endswith("se.0.bias"):
+            assert rel(p.grad, pr[n_].grad) < 0.12, (n_, rel(p.grad, pr[n_].grad))
+    br, bf = dict(ref.named_buffers()), dict(stage.named_buffers())
+    for n_ in br:
+        assert torch.allclose(bf[n_].float(), br[n_].float(), atol=1e-3, rtol=1e-3), n_
+    for cache in caches:
+        cache.clear()

@@ -19,12 +19,12 @@ import torch
 @contextlib.contextmanager
 def switches(**kw):
     """set module-level switches for the duration: conv1x1 / conv3x3 / gn9 / pool / head / stem = "hip" | "";
-    fused_layer / fused_bn / fused_tail = bool"""
+    fused_layer / fused_bn / fused_tail = bool; cm = bool (channel-major deep-stage blocks, cot_layer_fused.CM_LAYOUT)"""
     from cotnet_amd import (conv1x1 as c1, conv3x3g as c3, cot_layer_fused as clf, fused_bn, group_norm9 as g9,
                             head_fused as hf, pool3x3 as p3, radix_tail, stem7x7 as s7)
     table = {"conv1x1": (c1, "MODE"), "conv3x3": (c3, "MODE"), "gn9": (g9, "MODE"), "pool": (p3, "MODE"),
              "head": (hf, "MODE"), "stem": (s7, "MODE"), "fused_layer": (clf, "ENABLED"), "fused_bn": (fused_bn, "ENABLED"),
-             "fused_tail": (radix_tail, "ENABLED")}
+             "fused_tail": (radix_tail, "ENABLED"), "cm": (clf, "CM_LAYOUT")}
     old = {}
     try:
         for k, v in kw.items():
