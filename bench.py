@@ -75,6 +75,11 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (forward, backward, side-stream weight gradients, optimizer) into ONE HIP graph after the "
                          "settling steps and replay it in the warm-up and timed steps (one GPU; DESIGN.md 5.3)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="developer switch: on ONE GPU, run the N > 1 code path -- a world-of-one RCCL communicator, the buckets' "
+                         "all-reduces on the communication stream, fp32 buckets, deferred communication around a graph")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not re-measure roofline.traffic with two rocprofv3 --pmc child passes (then the tracked table is carried)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object of the default line (BASELINE configs 4 / 5 and the reference's fp32 precision "
                          "measured by short child runs of this script on the same GPU)")
@@ -92,9 +97,11 @@ def parse():
                          "CotLayer / Bottleneck, no fallback; round1 = MIOpen convolutions + node-per-op layers (developer "
                          "baseline; the line is marked baseline_only); auto = a child process checks `new` against an fp32 "
                          "truth and `round1` on this GPU and times both -- the run exits with status 3 unless `new` wins")
-    ap.add_argument("--grad-dtype", default="param", choices=["param", "fp32"],
-                    help="arithmetic of the gradient all-reduce: param (default) = the parameters' dtype (bf16 buckets), fp32 = fp32 "
-                         "buckets, the reference's own reduction (train.py:112-115) at twice the bytes on the wire")
+    ap.add_argument("--grad-dtype", default="auto", choices=["auto", "param", "fp32"],
+                    help="arithmetic of the gradient all-reduce: fp32 = fp32 buckets, the reference's own reduction (DDP sums fp32 "
+                         "gradients, train.py:112-115); param = the parameters' dtype (bf16 buckets, half the bytes on the wire, one "
+                         "bf16 rounding per ring hop); auto (default) = fp32 whenever there IS a reduction (N > 1), param on one GPU "
+                         "(nothing is reduced: the bucket is only the optimizer's input)")
     ap.add_argument("--tune", default="", metavar="KEY=VALUE[,KEY=VALUE...]",
                     help="developer A/B: cot_set_tuning(KEY, VALUE) after the kernel set is applied (include/cotnet_amd.h)")
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
@@ -482,6 +489,10 @@ SECONDARY = [  # (key, what, extra arguments): BASELINE.json configs 4 and 5 on 
      ["--model", "se_cotnetd_152_L", "--img", "320", "--batch", "64"]),
     ("cotnet50_b80_224_fp32", "BASELINE config 3 at the reference's own precision (amp: False): CoTNet-50 224^2 fp32, B = 80",
      ["--dtype", "fp32", "--batch", "80"]),
+    ("cotnet50_b80_224_fwd", "BASELINE config 2: CoTNet-50 224^2 bf16 forward-only (eval mode), one GPU, B = 80, eager",
+     ["--mode", "fwd", "--batch", "80"]),
+    ("cotnet50_b80_224_fwd_graph", "BASELINE config 2 with the forward captured in one HIP graph (replays)",
+     ["--mode", "fwd", "--batch", "80", "--graph"]),
 ]
 
 
@@ -505,11 +516,52 @@ def secondary_lines(timeout_s=170):
             d = json.loads(line)
             out[key] = {"what": what, "metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                         "steps": d["steps"], "dtype": d["dtype"], "per_gpu_batch": d["config"]["per_gpu_batch"],
-                        "cot_layer_single_node": d["config"]["cot_layer_single_node"], "kernel_selection": d["config"]["kernel_selection"],
+                        "nodes_per_step": d["config"].get("nodes_per_step"), "kernel_selection": d["config"]["kernel_selection"],
                         "wall_s": round(time.perf_counter() - t0, 1)}
         except Exception as e:  # (timeout, JSON trouble: recorded)
             out[key] = {"what": what, "error": repr(e)[:300]}
     return out
+
+
+def measure_agg_traffic(key, timeout_s=90):
+    """roofline.traffic measured IN this run: two child passes of scripts/bench_agg_abi.py under `rocprofv3 --pmc FETCH_SIZE` / `--pmc
+    WRITE_SIZE` (separate passes, kernel trace only -- the guide's HBM recipe), HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE
+    (KB -> bytes; the gfx950 half-count correction of FETCH_SIZE).  -> (bytes or None, how / why not)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if rp is None:
+        return None, "rocprofv3 not on PATH"
+    kernel, shape, dtype = key.split("|")
+    if dtype != "bfloat16" or shape != "N80xC64x56x56":
+        return None, f"no in-run PMC recipe for {shape} {dtype}"
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        from agg_traffic_from_pmc import per_kernel
+        vals = {}
+        with tempfile.TemporaryDirectory(prefix="cot_pmc_", dir="/tmp") as tmp:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "COT_KERNEL_SUMMARY", "COT_PROFILE_ALL")}
+            env["TMPDIR"] = "/tmp"
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(tmp, counter)
+                cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+                       os.path.join(ROOT, "scripts", "bench_agg_abi.py"), "--shapes", "0", "--dtypes", "bf16", "--variants", "dot2",
+                       "--iters", "4", "--rounds", "1"]
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                if r.returncode != 0:
+                    return None, f"rocprofv3 --pmc {counter} pass exited {r.returncode}"
+                got, _ = per_kernel(out, counter)
+                if kernel not in got:
+                    return None, f"{kernel} not in the {counter} pass"
+                vals[counter] = got[kernel]
+        return int(round(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)), (
+            "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes (separate, kernel trace only) over "
+            "scripts/bench_agg_abi.py at this kernel and shape; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB units, gfx950 correction)")
+    except Exception as e:  # (timeout, CSV layout, ...: the tracked table is carried and labelled so)
+        return None, f"in-run PMC passes failed: {type(e).__name__}: {e}"[:200]
+    finally:
+        sys.path.pop(0)
 
 
 def spawn_ranks(n):
@@ -556,6 +608,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    reducing = world > 1 or args.force_collectives  # (there is a gradient all-reduce)
+    if args.grad_dtype == "auto":
+        args.grad_dtype = "fp32" if reducing else "param"
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -564,10 +619,24 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if reducing:
+        # RCCL writes a version banner to the C-level stdout (it surfaces when the process exits): the contract is ONE JSON line on
+        # stdout, so file descriptor 1 goes to stderr for everything but this script's own print
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(keep, "w", buffering=1)
     if world > 1:
         import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", init_method="env://", device_id=dev, timeout=datetime.timedelta(minutes=30))
+    elif args.force_collectives:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
     if not explicit:
         chosen = args.kernels
         if args.kernels == "auto":
@@ -625,7 +694,7 @@ def main():
     if args.mode == "train" and mixed:
         model.train()
         opt = FlatSGD(model, lr=0.25 * B * world / 640.0, momentum=0.9, weight_decay=4e-5, nesterov=True,
-                      bucket_mb=args.bucket_mb, ema_decay=args.ema,
+                      bucket_mb=args.bucket_mb, ema_decay=args.ema, force_collectives=args.force_collectives,
                       grad_dtype=torch.float32 if args.grad_dtype == "fp32" else None)
 
         def step():
@@ -633,6 +702,12 @@ def main():
             loss = torch.nn.functional.cross_entropy(model(x).float(), t)
             loss.backward()
             opt.step()
+            return loss
+
+        def step_compute_only():  # (graph capture with N > 1: forward + backward fill the flat buckets, no collective inside)
+            opt.zero_grad()
+            loss = torch.nn.functional.cross_entropy(model(x).float(), t)
+            loss.backward()
             return loss
     elif args.mode == "train":
         model.train()
@@ -661,7 +736,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.graph:
-        assert world == 1, "--graph: one GPU (a bucket's all-reduce inside a captured step is not exercised)"
+        assert not reducing or (args.mode == "train" and mixed), "--graph with N > 1: the mixed-precision training step (FlatSGD buckets)"
         gstream = torch.cuda.Stream()
         torch.cuda.set_stream(gstream)  # a capture-capable (non-default) stream for everything from here on
 
@@ -696,13 +771,29 @@ def main():
         # with it during capture, which aborts the process)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=gstream):
-            graph_loss = eager_step()
-        torch.cuda.synchronize()
+        if reducing:
+            # N > 1: forward + backward (+ the bucket fills) are the graph; the gradient hooks run once, at capture, with
+            # communication deferred (GradBucketReducer.defer_comm), and every replay is followed by the buckets' all-reduces on
+            # the communication stream and the flat SGD kernels (FlatSGD.step(deferred=True): ~2 launches per bucket, no host
+            # synchronisation) -- the reference's order: backward, all-reduce, optimizer (train.py:264-293)
+            opt.reducer.defer_comm = True
+            barrier()
+            with torch.cuda.graph(graph, stream=gstream):
+                graph_loss = step_compute_only()
+            torch.cuda.synchronize()
 
-        def step():  # noqa: F811
-            graph.replay()
-            return graph_loss
+            def step():  # noqa: F811
+                graph.replay()
+                opt.step(deferred=True)
+                return graph_loss
+        else:
+            with torch.cuda.graph(graph, stream=gstream):
+                graph_loss = eager_step()
+            torch.cuda.synchronize()
+
+            def step():  # noqa: F811
+                graph.replay()
+                return graph_loss
     for _ in range(args.warmup):
         loss = step()
     barrier()
@@ -725,6 +816,17 @@ def main():
     step()
     issue_one = time.perf_counter() - t1
     torch.cuda.synchronize()
+    # what actually ran: one more eager step with the node counters on (residual blocks of the model vs the single-node kinds taken)
+    from cotnet_amd import cot_layer_fused as _clf0
+    if args.graph and reducing:
+        opt.reducer.defer_comm = False  # (the eager steps from here on reduce from their hooks again)
+    _clf0.reset_node_counts()
+    eager_step()
+    torch.cuda.synchronize()
+    n_blocks = sum(1 for m in model.modules() if type(m).__name__ in ("Bottleneck", "CoTBottleneck"))
+    nodes_per_step = dict(_clf0.NODE_COUNTS, residual_blocks=n_blocks)
+    nodes_per_step["single_node_blocks"] = (f"{nodes_per_step['bottleneck'] + nodes_per_step['bottleneck_channel_major'] + nodes_per_step['split_attn_block']}"
+                                            f"/{n_blocks}")
     recs, timing_steps = [], 0
     if not args.no_kernel_timing:
         timing_steps = 3
@@ -816,18 +918,21 @@ def main():
         roofline = None
         if kernels:
             k0 = next((k for k in kernels if k["GBs"] > 0), kernels[0])  # (a launch without byte annotation never is the headline kernel)
-            traffic = None
+            traffic, traffic_src = None, None
+            tkey = f"{k0['kernel']}|{k0['shape']}|{k0['dtype']}"
+            if world == 1 and not args.no_pmc:
+                traffic, traffic_src = measure_agg_traffic(tkey)
             tpath = os.path.join(ROOT, "profiles", "agg_traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(f"{k0['kernel']}|{k0['shape']}|{k0['dtype']}")
+            if traffic is None and os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(tkey)
+                traffic_src = ("CARRIED from profiles/agg_traffic.json (the builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE session, "
+                               "scripts/agg_traffic_from_pmc.py: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction) -- not re-measured in this run"
+                               + (f": {traffic_src}" if traffic_src else ""))
             agg_total = sum(k["total_ms"] for k in kernels) / timing_steps  # ms of aggregation kernels per step
             roofline = {"bound": "hbm", "kernel": k0["kernel"], "shape": k0["shape"], "dtype": k0["dtype"],
                         "achieved": k0["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k0["frac"],
                         "traffic": traffic,
-                        "traffic_source": ("HBM-side bytes per launch of this kernel and shape from rocprofv3 --pmc FETCH_SIZE / "
-                                           "WRITE_SIZE passes (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), scripts/"
-                                           "agg_traffic_from_pmc.py -> profiles/agg_traffic.json; the evidence session "
-                                           "(scripts/gpu_evidence_session.sh) refreshes it right before this run") if traffic else None,
+                        "traffic_source": traffic_src if traffic else None,
                         "avg_us": k0["avg_us"],
                         "timing": f"dispatch-attached HIP events (on the launch stream) over {timing_steps} repeats of the "
                                   "step right after the un-instrumented timed region, every launch on one stream (no weight "
@@ -856,14 +961,17 @@ def main():
                        "conv1x1": __import__("cotnet_amd.conv1x1", fromlist=["MODE"]).MODE or "module",
                        "conv3x3": __import__("cotnet_amd.conv3x3g", fromlist=["MODE"]).MODE or "module",
                        "group_norm9": __import__("cotnet_amd.group_norm9", fromlist=["MODE"]).MODE or "module",
-                       "cot_layer_single_node": __import__("cotnet_amd.cot_layer_fused", fromlist=["ENABLED"]).ENABLED,
+                       "cot_layer_single_node_enabled": __import__("cotnet_amd.cot_layer_fused", fromlist=["ENABLED"]).ENABLED,
+                       "nodes_per_step": nodes_per_step,
                        "grad_sync": (f"RCCL all-reduce (AVG), flat {'fp32' if args.grad_dtype == 'fp32' else 'parameter-dtype'} buckets, side stream"
-                                     if world > 1 else "none (1 GPU)")},
+                                     if reducing else "none (1 GPU)")},
             "final_loss": round(final_loss, 4),
             # host time to issue a step (the timed loop's own duration before the final synchronize; with the device the longer
             # of the two the loop blocks on the launch queue, so this is an upper bound of the host's own work)
             "host_issue_ms_per_step": round(issued / args.steps * 1e3, 3), "host_issue_ms_one_step_idle_queue": round(issue_one * 1e3, 3),
-            **({"graph": "whole step captured in one HIP graph after the settling steps; warm-up and timed steps are replays"} if args.graph else {}),
+            **({"graph": ("forward + backward + bucket fills captured in one HIP graph after the settling steps; every warm-up / timed step = one "
+                          "replay, then the buckets' all-reduces (RCCL, communication stream) and the flat SGD kernels issued eagerly") if reducing
+                else "whole step captured in one HIP graph after the settling steps; warm-up and timed steps are replays"} if args.graph else {}),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -874,7 +982,7 @@ def main():
             torch.cuda.empty_cache()  # (the children run on this GPU while this process is idle)
             line["secondary"] = secondary_lines()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 
 

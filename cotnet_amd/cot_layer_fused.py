@@ -661,8 +661,18 @@ def eligible(layer, x):
             and pl.ke1.training)
 
 
+# how many times each node kind ran since the last reset (bench.py reports what actually executed, per step)
+NODE_COUNTS = {"cot_layer": 0, "bottleneck": 0, "bottleneck_channel_major": 0, "split_attn_block": 0}
+
+
+def reset_node_counts():
+    for k in NODE_COUNTS:
+        NODE_COUNTS[k] = 0
+
+
 def cot_layer_forward(layer, x):
     """layer(x) through the single-node path; caller checks `eligible` first"""
+    NODE_COUNTS["cot_layer"] += 1
     return _CotLayerNode.apply(layer, x, *_plan(layer).params)
 
 
@@ -870,6 +880,7 @@ def block_eligible(blk, x):
 
 
 def block_forward(blk, x):
+    NODE_COUNTS["bottleneck"] += 1
     return _BottleneckNode.apply(blk, x, *_block_plan(blk).params)
 
 
@@ -1052,6 +1063,7 @@ def sa_block_eligible(blk, x):
 
 
 def sa_block_forward(blk, x):
+    NODE_COUNTS["split_attn_block"] += 1
     return _SplitAttnBlockNode.apply(blk, x, *_sa_plan(blk).params)
 
 
@@ -1154,6 +1166,7 @@ def cm_block_eligible(blk, x):
 
 
 def cm_block_forward(blk, x):
+    NODE_COUNTS["bottleneck_channel_major"] += 1
     return _BottleneckCMNode.apply(blk, x, *_block_plan(blk).params)
 
 

@@ -28,7 +28,7 @@ from . import grad_sink
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "pending", "work", "ready_event", "key", "views", "pflat", "fired", "offs")
+    __slots__ = ("flat", "params", "pending", "work", "ready_event", "key", "views", "pflat", "fired", "offs", "rflat")
 
     def __init__(self, flat, params, key=None):
         self.flat = flat
@@ -41,16 +41,23 @@ class _Bucket:
         self.pflat = None    # flat PARAMETER storage (flatten_params=True)
         self.fired = set()
         self.offs = []
+        self.rflat = None    # the REDUCTION buffer when it is wider than the gradients' own dtype (reduce_dtype)
 
 
 class GradBucketReducer:
     def __init__(self, module, process_group=None, bucket_mb=10.0, broadcast_params=True, grad_dtype=None,
-                 group_fn=None, grad_mode="view", flatten_params=False, force_collectives=False):
+                 group_fn=None, grad_mode="view", flatten_params=False, force_collectives=False, reduce_dtype=None):
         """group_fn(name, param) -> hashable key: parameters with different keys never share a bucket (used by
         FlatSGD to keep weight-decay groups / dtypes apart).  grad_mode "view": p.grad is a view into the bucket and
         autograd accumulates in place (one small add per parameter); "copy": autograd hands over its gradient tensor
         and the bucket is filled with ONE multi-tensor copy when its last gradient arrives (p.grad is then dropped).
-        flatten_params=True additionally moves the parameters themselves into one flat buffer per bucket."""
+        flatten_params=True additionally moves the parameters themselves into one flat buffer per bucket.
+        reduce_dtype (e.g. torch.float32): the gradients are produced and collected in their own dtype exactly as without it (kernels
+        write bf16 weight gradients straight into the bucket slots, grad_sink), and a bucket whose dtype is narrower is widened by ONE
+        flat copy on the communication stream into a second buffer `rflat`, which is what the all-reduce sums -- the reference's
+        fp32 reduction (train.py:112-115) -- and what `reduced(b)` hands to the optimizer.  grad_dtype instead makes the bucket
+        itself wide: every producer then writes an ordinary tensor and the bucket fill converts (2 ms per CoTNet-50 step more
+        than this form on one MI355X, profiles/r05_grad_reduction_paths.log).  Without a process group nothing is widened."""
         assert grad_mode in ("view", "copy")
         self.grad_mode = grad_mode
         self.defer_comm = False  # True: hooks only fill the buckets; all-reduces are issued by allreduce_all()
@@ -97,6 +104,10 @@ class GradBucketReducer:
                 order.append((k, cur[0]))
         for (key, _pdt, dt), plist in order:
             self._make_bucket(plist, dt, key, flatten_params)
+        if reduce_dtype is not None and self.enabled:
+            for b in self.buckets:
+                if b.flat.element_size() < torch.empty((), dtype=reduce_dtype).element_size():
+                    b.rflat = torch.zeros(b.flat.numel(), dtype=reduce_dtype, device=self.device)
 
         if grad_mode == "copy":  # kernels that produce parameter gradients may write the bucket slots directly
             for b in self.buckets:
@@ -211,9 +222,18 @@ class GradBucketReducer:
                 self.comm_stream.wait_event(b.ready_event)
                 for ps in grad_sink.producer_streams():  # weight gradients written in place by a side stream (cot_layer_fused)
                     self.comm_stream.wait_stream(ps)
-                b.work = self._all_reduce(b.flat)
+                if b.rflat is not None:
+                    b.rflat.copy_(b.flat)  # (widening, on the communication stream: behind every producer, ahead of the collective)
+                b.work = self._all_reduce(self.reduced(b))
         else:
-            b.work = self._all_reduce(b.flat)
+            if b.rflat is not None:
+                b.rflat.copy_(b.flat)
+            b.work = self._all_reduce(self.reduced(b))
+
+    @staticmethod
+    def reduced(b):
+        """the buffer that holds the bucket's all-reduced gradients after finish() / allreduce_all()"""
+        return b.rflat if b.rflat is not None else b.flat
 
     def _all_reduce(self, flat):
         if self._avg_op:

@@ -50,11 +50,12 @@ class FlatSGD:
         made ONE bucket whose last member is the stem's weight -- nothing could overlap (tests/test_data_parallel_cpu.py).
         A 10 MB ring all-reduce over 8 GPUs moves 17.5 MB per link direction: ~0.12 ms at xGMI's ~153 GB/s, well above the
         collective's fixed latency.
-        grad_dtype: dtype of the flat gradient buckets = the arithmetic of the all-reduce.  None (default): the parameter's own
-        (bf16 weights -> bf16 buckets, RCCL averages in bf16: one rounding of 2^-9 relative per ring hop, ~0.2 % over eight
-        ranks -- the size of the bf16 gradients' own rounding; tests/test_data_parallel_cpu.py bounds it); torch.float32:
-        the reference's arithmetic (DDP sums fp32 gradients, train.py:112-115) at twice the bytes on the wire -- the
-        weight-gradient kernels then write ordinary bf16 tensors and the bucket fill up-converts them (no gradient sink).
+        grad_dtype: the arithmetic of the all-reduce.  None (default): the parameter's own (bf16 weights -> bf16 buckets, RCCL
+        averages in bf16: one rounding of 2^-9 relative per ring hop, ~0.2 % over eight ranks -- the size of the bf16 gradients'
+        own rounding; tests/test_data_parallel_cpu.py bounds it); torch.float32: the reference's arithmetic (DDP sums fp32
+        gradients, train.py:112-115) at twice the bytes on the wire -- the gradients are produced in bf16 as always (kernels write
+        them straight into the bucket slots) and each bucket is widened by one flat copy on the communication stream right before
+        its all-reduce (GradBucketReducer reduce_dtype); the SGD kernel then reads the fp32 averages.
         ema_decay: also keep an exponential moving average of the weights (the reference's ModelEmaV2,
         utils/model_ema.py, `model_ema: True` / decay 0.9999 in its recipes): one flat kernel per bucket after the SGD
         kernel instead of one elementwise op per state_dict tensor; floating-point buffers (BatchNorm running statistics)
@@ -66,7 +67,7 @@ class FlatSGD:
         # are already in their storage dtype, so the master starts as the (exact) up-cast of the working copy.
         self.reducer = GradBucketReducer(model, process_group=process_group, bucket_mb=bucket_mb,
                                          broadcast_params=broadcast_params, group_fn=_decay_group, grad_mode="copy",
-                                         flatten_params=True, force_collectives=force_collectives, grad_dtype=grad_dtype)
+                                         flatten_params=True, force_collectives=force_collectives, reduce_dtype=grad_dtype)
         self.state = []
         for b in self.reducer.buckets:
             master = b.pflat.float().clone() if b.pflat.dtype != torch.float32 else None
@@ -96,9 +97,9 @@ class FlatSGD:
             wd = self.weight_decay if key == "decay" else 0.0
             rc = L.cot_sgd_step(ctypes.c_void_p(b.pflat.data_ptr()),
                                 ctypes.c_void_p(st["master"].data_ptr()) if st["master"] is not None else None,
-                                ctypes.c_void_p(st["mom"].data_ptr()), ctypes.c_void_p(b.flat.data_ptr()),
+                                ctypes.c_void_p(st["mom"].data_ptr()), ctypes.c_void_p(self.reducer.reduced(b).data_ptr()),
                                 b.pflat.numel(), self.lr, self.momentum, wd, 1.0, 1 if self.nesterov else 0,
-                                _lib.dtype_code(b.pflat.dtype), _lib.dtype_code(b.flat.dtype), stream)
+                                _lib.dtype_code(b.pflat.dtype), _lib.dtype_code(self.reducer.reduced(b).dtype), stream)
             _lib.check(rc, "cot_sgd_step")
             if self.ema_decay is not None:
                 src = st["master"] if st["master"] is not None else b.pflat

@@ -602,3 +602,67 @@ def test_zero_grad_recovers_from_a_step_abandoned_before_finish():
                 assert torch.equal(g, r)
         finally:
             red.remove()
+
+
+def _worker_reduce_dtype(rank, world, port, q):
+    """bf16 gradient buckets, fp32 REDUCTION buffers (GradBucketReducer reduce_dtype = what FlatSGD(grad_dtype=torch.float32) builds):
+    `reduced(b)` equals the fp32 mean of the ranks' bf16 gradients exactly; with communication deferred too (the graph-replay form:
+    hooks only fill, allreduce_all() afterwards)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cotnet_amd.flat_sgd import _decay_group
+        torch.manual_seed(3)
+        model = _net().bfloat16()
+        red = GradBucketReducer(model, bucket_mb=1.0, group_fn=_decay_group, grad_mode="copy", flatten_params=True,
+                                reduce_dtype=torch.float32)
+        assert all(b.flat.dtype == torch.bfloat16 and b.rflat is not None and b.rflat.dtype == torch.float32 for b in red.buckets)
+        torch.manual_seed(50 + rank)
+        x, t = torch.randn(4, 3, 6, 6).bfloat16(), torch.randint(0, 4, (4,))
+        ref = _net().bfloat16()
+        ref.load_state_dict(model.state_dict())
+        nn.functional.cross_entropy(ref(x).float(), t).backward()
+        want = {}
+        for n, p in ref.named_parameters():
+            g = [torch.empty_like(p.grad) for _ in range(world)]
+            dist.all_gather(g, p.grad.contiguous())
+            want[n] = torch.stack([v.float() for v in g]).mean(0)
+        names = {p: n for n, p in model.named_parameters()}
+        for defer in (False, True):
+            red.defer_comm = defer
+            red.zero_grad()
+            for b in red.buckets:
+                b.rflat.fill_(float("nan"))
+            nn.functional.cross_entropy(model(x).float(), t).backward()
+            if defer:
+                red.allreduce_all()
+            else:
+                red.finish()
+            inexact = 0
+            for b in red.buckets:
+                r = red.reduced(b)
+                assert r is b.rflat
+                for p, off in zip(b.params, b.offs):
+                    v = r[off:off + p.numel()].view_as(p)
+                    assert torch.equal(v, want[names[p]]), (defer, names[p], (v - want[names[p]]).abs().max())
+                    inexact += int((v != v.bfloat16().float()).any())
+            assert inexact > 0  # (nothing was rounded to bf16 on the way)
+        q.put((rank, len(red.buckets), "ok"))
+    except Exception as e:
+        q.put((rank, -1, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fp32_reduction_of_bf16_buckets_with_and_without_deferred_communication():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_reduce_dtype, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[2] == "ok" for r in res), res
