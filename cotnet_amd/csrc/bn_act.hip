@@ -162,12 +162,6 @@ __global__ void bn_stats_finalize(const float* __restrict__ part, int C, int spl
     }
 }
 
-// host entry points of the two finalize kernels for the channels-last kernels of bn_nhwc.hip (same partial-sum layouts)
-void bn_launch_stats_finalize(const float* part, int C, int split, float eps, float momentum, float* mean, float* rstd,
-                              float* running_mean, float* running_var, long long* nbt, hipStream_t s) {
-    COT_LAUNCH(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, part, C, split, eps, momentum, mean, rstd, running_mean,
-               running_var, nbt);
-}
 
 // ---- ReLU sign mask (round 4): bn3 + residual + ReLU is the one BatchNorm whose backward needs the sign of its OUTPUT (z + residual
 // decides it); reading the whole output tensor back for one bit per element is 1/5 of that backward's traffic on the step's largest
@@ -292,9 +286,6 @@ __global__ void bn_bwd_finalize(const float* __restrict__ part, int C, int split
     dgamma[c] = sg;
 }
 
-void bn_launch_bwd_finalize(const float* part, int C, int split, float* dgamma, float* dbeta, hipStream_t s) {
-    COT_LAUNCH(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, part, C, split, dgamma, dbeta);
-}
 
 // ---- backward apply: dx (and dresidual = g) ---------------------------------------------------------------------
 template <typename T, int V, int ACT>

@@ -30,6 +30,7 @@ extern int g_conv_lds_tune[3];
 // off in the FLAT kernels (default on); bit 2 = fragment prefetch on in the BIG kernels (default off: it costs registers, i.e.
 // workgroups per CU, where the layers are bandwidth-bound)
 int g_conv_lds2_tune = 0;
+int g_conv_big_fill = 200;  // cot_set_tuning key 46: BIG tiles -- output-channel blocks of 64 / 32 instead of 128 while the launch has fewer workgroups than this (0 = off; 200 measured best of 0 / 200 / 400 / 800, profiles/r05_probe_cnhw_fill.log)
 int g_conv_flat_ns3 = 1;  // cot_set_tuning key 43: FLAT 128-row tiles take three stages instead of six when the launch exceeds one workgroup per CU
 int g_conv_ablate = 0;  // cot_set_tuning key 24 (diagnostic: see C1LdsArgs::ablate)
 
@@ -323,6 +324,14 @@ int conv1x1_lds_gemm2(const C1LdsArgs& a0, hipStream_t stream) {
         const bool tr = true, pf = pf_big;
         if (M <= 32) { a.mblocks = 1; COT_C2(1, 2, 0, 3); }
         if (M <= 64) { a.mblocks = 1; COT_C2(1, 4, 0, 3); }
+        // few tiles (round 5: the channel-major deep layers are ONE image of N*HW pixels -- 31 tiles at 7 x 7, 123 at 14 x 14, B = 80):
+        // narrower output-channel blocks multiply the workgroups; these launches are bound by one workgroup's chain of K steps, not
+        // by the bytes the narrower blocks re-read (from L2)
+        if (g_conv_big_fill > 0 && (int64_t)tiles * ceil_div(M, 128) < g_conv_big_fill) {
+            if ((int64_t)tiles * ceil_div(M, 64) < g_conv_big_fill && M % 32 == 0) { a.mblocks = ceil_div(M, 32); COT_C2(1, 2, 0, 3); }
+            a.mblocks = ceil_div(M, 64);
+            COT_C2(1, 4, 0, 3);
+        }
         a.mblocks = ceil_div(M, 128);
         COT_C2(1, 8, 0, 3);
     }

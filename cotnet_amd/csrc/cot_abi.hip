@@ -163,6 +163,7 @@ extern int g_conv3x3_wsingle;
 extern int g_conv3x3_cols;
 extern int g_conv3x3_perm;
 extern int g_conv_flat_ns3;
+extern int g_conv_big_fill;
 extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
 unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
@@ -413,6 +414,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 43) {
         g_conv_flat_ns3 = value == 2 ? 2 : (value ? 1 : 0);
+        return COT_OK;
+    }
+    if (key == 46) {
+        g_conv_big_fill = value > 0 ? value : 0;
         return COT_OK;
     }
     if (key == 42) {

@@ -6,7 +6,6 @@ act1, maxpool, layer1..4, global_pool, fc; blocks as nn.Sequential children "0",
 reference's, so state_dict keys are identical.  DropBlock is not provided (drop_block_rate must be 0 --
 every CoT recipe leaves it at 0).
 """
-import os
 import torch.nn.functional as F
 from torch import nn
 
@@ -191,11 +190,6 @@ class ResNet(nn.Module):
         x = self.layer2(self.layer1(x))
         for stage in (self.layer3, self.layer4):  # (which blocks hand a channel-major tensor to their successor: DESIGN 5.8)
             cot_layer_fused.plan_stage_layouts(stage)
-        if os.environ.get("COT_CHANNELS_LAST_STUDY", "0") == "1":
-            # STUDY switch (default off): the stride-1 blocks of the 14 x 14 / 7 x 7 stages as channels-last nodes on the
-            # study kernels, a layout change either side of each run of them
-            from . import _lib, channels_last_study
-            return channels_last_study.run_stage(_lib.lib(), self.layer4, channels_last_study.run_stage(_lib.lib(), self.layer3, x))
         return self.layer4(self.layer3(x))
 
     def forward(self, x):

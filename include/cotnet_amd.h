@@ -165,6 +165,8 @@ const char* cot_last_kernel(void);
  *   key 37: grouped 3x3 weight gradient with group widths off the 8-channel grid (12 per group): neighbouring groups merged, the
  *           wider convolution's gradient taken on the tuned kernels and its diagonal blocks copied out (1 default), 0 = general kernel
  *   key 38: (A/B builds only) weight-tile ring of the per-step form of the LDS-staged 3x3 kernel
+ *   key 46: 1x1 forward / data gradient on 128-pixel tiles (planes of more than 256 pixels, i.e. also the channel-major rows of the
+ *           deep stages): output-channel blocks of 64 / 32 instead of 128 while the launch has fewer workgroups than `value` (200 default, 0 = off)
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
  *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
  *           ring everywhere

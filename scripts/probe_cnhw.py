@@ -17,6 +17,7 @@ from cotnet_amd import _lib  # noqa: E402
 
 L = _lib.lib()
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+TUNES = [a for a in sys.argv[2:] if "=" in a]  # e.g. 46=0 46=256 46=512: the channel-major form once per setting (cot_set_tuning)
 dev = torch.device("cuda:0")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 BF = _lib.COT_BF16
@@ -49,7 +50,10 @@ CONVS = [("s3 conv1  1024->256 @14", 1024, 256, 196, 0, False), ("s3 embed0  512
 print(f"{'1x1 convolution':26s} {'form':>14s} {'fwd us':>8s} {'dgrad us':>9s} {'wgrad us':>9s}")
 tot = {"nchw": [0, 0, 0], "cnhw": [0, 0, 0]}
 for name, Ci, Co, HW, split, bias in CONVS:
-    for form, (N, hw) in (("nchw", (B, HW)), ("cnhw", (1, B * HW))):
+    forms = [("nchw", (B, HW), None)] + ([("cnhw " + t, (1, B * HW), t) for t in TUNES] or [("cnhw", (1, B * HW), None)])
+    for form, (N, hw), tune in forms:
+        if tune:
+            assert L.cot_set_tuning(int(tune.split("=")[0]), int(tune.split("=")[1])) == 0
         nset = max(2, min(6, int(300e6 // ((Ci + Co) * N * hw * 2)) + 1))
         sets = []
         for _ in range(nset):
@@ -81,7 +85,7 @@ for name, Ci, Co, HW, split, bias in CONVS:
             print(f"{name:26s} {form:>14s}  unsupported: {e}")
             continue
         for k in range(3):
-            tot[form][k] += t[k]
+            tot.setdefault(form, [0, 0, 0])[k] += t[k]
         print(f"{name:26s} {form:>14s} {t[0]:8.1f} {t[1]:9.1f} {t[2]:9.1f}", flush=True)
 print("sum", {k: [round(x, 1) for x in v] for k, v in tot.items()})
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run at commit 5f0d3c1-era tree, before the NHWC study files it exercises were removed; kept as the record of how profiles/r05_channels_last_study_* were produced)
 # round 5, session 1: the channels-last study route on hardware: its GPU tests, the GEMM/layer micro-benchmarks
 # and a whole-step A/B of COT_CHANNELS_LAST_STUDY=1 against the default
 mkdir -p gpurun_out; export TMPDIR=/tmp; O=gpurun_out

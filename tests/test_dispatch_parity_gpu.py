@@ -331,9 +331,68 @@ def _pool(key, kind, shp, what):
         assert torch.equal(y, F.max_pool2d(x, 3, 2, 1))
 
 
+def _bn_lay(key, shp, what):
+    """the per-tensor-layout BatchNorm of the channel-major blocks (cot_bn_act_*_lay) in the table's representative form -- forward:
+    x channel-major, y NCHW + y2 channel-major (bn1); backward: dy and x channel-major, dy2 NCHW, dx channel-major (its mirror) --
+    against fp32 torch on the un-permuted tensors"""
+    N, C, HW = shp
+    L, pin = _lib.lib(), _Pinned(key)
+    seed = C + HW
+    x = (_randn(N, C, HW, 1, seed=seed).float() * 1.5 + 0.25).bfloat16()
+    gamma = (torch.rand(C, device=DEV) + 0.5).float()
+    beta = (torch.randn(C, device=DEV) * 0.2).float()
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    cmj = lambda t: t.transpose(0, 1).contiguous()  # noqa: E731
+    xc = cmj(x)
+    y = torch.full((N, C, HW, 1), float("nan"), device=DEV).bfloat16()
+    y2 = torch.full((C, N, HW, 1), float("nan"), device=DEV).bfloat16()
+    st = _st()
+    fwd = lambda: L.cot_bn_act_forward_lay(P(xc), None, P(y), P(y2), P(gamma), P(beta), P(mean), P(rstd), P(rm), P(rv), P(nbt), None,  # noqa: E731
+                                           N, C, HW, 1e-5, 0.1, 1, 1 | 8, BF, st)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_r, rv_r = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    yr = F.relu(F.batch_norm(xr, rm_r, rv_r, gr, br, True, 0.1, 1e-5))
+    if what == "fwd":
+        pin.issue(fwd)
+        _close(y, yr.detach())
+        assert torch.equal(cmj(y2), y)
+        _rel(mean, xr.detach().mean((0, 2, 3)), 1e-4)
+        _rel(rm, rm_r, 1e-3)
+        _rel(rv, rv_r, 1e-3)
+        assert int(nbt.item()) == 1
+        return
+    assert fwd() == 0
+    dy, dy2 = _randn(N, C, HW, 1, seed=seed + 1), _randn(N, C, HW, 1, seed=seed + 2)
+    dyc = cmj(dy)
+    dxc = torch.full((C, N, HW, 1), float("nan"), device=DEV).bfloat16()
+    dg, db = torch.full((C,), float("nan"), device=DEV), torch.full((C,), float("nan"), device=DEV)
+    pin.issue(lambda: L.cot_bn_act_backward_lay(P(dyc), P(dy2), P(xc), None, P(dxc), None, P(gamma), P(beta), P(mean), P(rstd), P(dg), P(db),
+                                                None, N, C, HW, 1, 1 | 4 | 16, BF, st))
+    dsum = (dy.float() + dy2.float()).bfloat16().float()  # (the kernel: fp32 sum of the two contributions, one rounding)
+    yr.backward(dsum)
+    pre = F.batch_norm(x.float(), None, None, gamma, beta, True, 0.0, 1e-5)
+    clear = pre.abs() > 1e-2
+    d = (cmj(dxc).float() - xr.grad).abs()
+    tol = 1e-2 * (xr.grad.abs() + xr.grad.abs().mean())
+    assert (d[clear] <= tol[clear]).all(), d[clear].max().item()
+    assert (~clear).float().mean().item() < 0.02
+    _rel(dg, gr.grad, 5e-3)
+    _rel(db, br.grad, 5e-3)
+
+
 def _run_entry(key):
     _, kind, shape, what = key.split(" ", 3)
     shp = tuple(int(v) for v in shape.split("x"))
+    if kind == "conv1x1cm":    # channel rows: ONE image of N*H*W pixels (cot_layer_fused._BottleneckCMNode)
+        N, Ci, Co, g, H, W, s, bias = shp
+        return _conv1x1(key, (1, Ci, Co, 1, 1, N * H * W, 1, bias), what)
+    if kind == "bncm":
+        return _bn(key, (1, shp[1], shp[0] * shp[2]), what)
+    if kind == "bnlay":
+        return _bn_lay(key, shp, what)
     if kind == "conv1x1":
         _conv1x1(key, shp, what)
     elif kind == "conv3x3":
@@ -365,7 +424,7 @@ def test_secondary_config_dispatch_entry(key):
 
 def test_every_headline_entry_has_a_case():
     kinds = {k.split(" ")[1] for k in KEYS}
-    assert kinds <= {"conv1x1", "conv3x3", "bn", "gn", "agg", "AvgPool2d", "MaxPool2d"}, kinds
-    assert len(KEYS) >= 170
+    assert kinds <= {"conv1x1", "conv3x3", "bn", "gn", "agg", "AvgPool2d", "MaxPool2d", "conv1x1cm", "bncm", "bnlay"}, kinds
+    assert len(KEYS) >= 240
     assert {k.split(" ")[1] for k in OTHER_KEYS} <= {"conv1x1", "conv3x3", "bn", "gn", "agg", "AvgPool2d", "MaxPool2d"}
     assert len(OTHER_KEYS) >= 380

@@ -154,6 +154,30 @@ def build_table():
                     N, C, H, W = shp
                     fn = L.cot_avgpool3x3s2_forward if kind == "AvgPool2d" else L.cot_maxpool3x3s2_forward
                     rec(tag + " fwd", fn(PTR, PTR, N * C, H, W, BF, None))
+                # ---- the channel-major forms of the deep stages' identity Bottlenecks (cot_layer_fused._BottleneckCMNode):
+                # the same 1x1 / BatchNorm entry points on channel rows (N = 1, HW' = N*HW) and the per-tensor-layout BatchNorm
+                if cfg == "cotnet50_b80_224" and kind == "conv1x1" and shp[3] == 1 and shp[6] == 1 and shp[4] * shp[5] in (196, 49):
+                    N, Ci, Co, g, H, W, s, bias = shp
+                    M = N * H * W
+                    cmt = f"{cfg} conv1x1cm {'x'.join(map(str, shp))}"
+                    rec(cmt + " fwd", L.cot_conv1x1_forward(PTR, None, Ci, PTR, PTR if bias else None, PTR, 1, Ci, Co, M, BF, None))
+                    rec(cmt + " dgrad", L.cot_conv1x1_backward_data(PTR, PTR, PTR, None, Ci, 0, PTR, 1, Ci, Co, M, BF, None))
+                    rec(cmt + " wgrad", L.cot_conv1x1_backward_weight(PTR, PTR, None, Ci, PTR, PTR if bias else None, PTR, 1, Ci, Co, M, BF,
+                                                                      None))
+                    if Ci % 2 == 0 and (Ci // 2) % 32 == 0 and not bias:
+                        rec(cmt + " fwd(two slabs)", L.cot_conv1x1_forward(PTR, PTR, Ci // 2, PTR, None, PTR, 1, Ci, Co, M, BF, None))
+                if cfg == "cotnet50_b80_224" and kind == "bn" and shp[2] in (196, 49):
+                    N, C, HW = shp
+                    cmt = f"{cfg} bncm {'x'.join(map(str, shp))}"
+                    rec(cmt + " fwd", L.cot_bn_act_forward(PTR, None, PTR, PTR, PTR, PTR, PTR, PTR, PTR, PTR, PTR, 1, C, N * HW, 1e-5, 0.1, 1,
+                                                           BF, None))
+                    rec(cmt + " bwd", L.cot_bn_act_backward(PTR, PTR, None, PTR, None, PTR, PTR, PTR, PTR, PTR, PTR, PTR, 1, C, N * HW, 1, BF,
+                                                            None))
+                    lyt = f"{cfg} bnlay {'x'.join(map(str, shp))}"
+                    rec(lyt + " fwd", L.cot_bn_act_forward_lay(PTR, None, PTR, PTR, PTR, PTR, PTR, PTR, PTR, PTR, PTR, None, N, C, HW, 1e-5, 0.1,
+                                                               1, 1 | 8, BF, None))
+                    rec(lyt + " bwd", L.cot_bn_act_backward_lay(PTR, PTR, PTR, None, PTR, None, PTR, PTR, PTR, PTR, PTR, PTR, None, N, C, HW, 1,
+                                                                1 | 4 | 16, BF, None))
     finally:
         L.cot_launch_log(buf, len(buf))
         assert L.cot_set_tuning(26, 0) == 0

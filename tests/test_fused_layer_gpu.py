@@ -156,7 +156,8 @@ def test_single_node_bottleneck_with_stochastic_depth_against_fp32_truth(kind, h
     g = torch.randn(N, 256, hw // stride, hw // stride, device=DEV).bfloat16()
     truth.check_against_truth(blk, x, g, cand=truth.SINGLE_NODE)
     y, _, _, _, node = truth.run(blk, x, g, want_module=True, **truth.SINGLE_NODE)
-    assert node.startswith("_BottleneckNode")
+    # (the 7 x 7 identity block is a deep-stage block: the channel-major node, its bn3 with the per-sample scale on cot_bn_act_*_lay)
+    assert node.startswith("_BottleneckCMNode" if (kind, hw) == ("identity", 7) else "_BottleneckNode")
     if kind == "identity":  # a dropped sample passes relu(x) on
         assert torch.equal(y[0], torch.relu(x[0].float()))
 
@@ -178,7 +179,9 @@ def test_recipe_model_runs_on_the_single_node_path():
         loss.backward()
         for h in hooks:
             h.remove()
-    assert len(names) == 16 and all(n.startswith("_BottleneckNode") for n in names)
+    # (one node per block: the identity blocks of layer3 / layer4 on the channel-major node -- N = 4 at 14 x 14 / 7 x 7 is below the
+    # channel-resident kernels' batch, so here they may also take the NCHW node)
+    assert len(names) == 16 and all(n.startswith(("_BottleneckNode", "_BottleneckCMNode")) for n in names)
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad.float()).all() for p in model.parameters())
 
 

@@ -2661,525 +2661,3 @@ def test_bn_inference_kernel(N, C, H, W, act, use_res, dtype):
     assert rc == 0, _EMUL.cot_last_error()
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert ((y.float() - yr).abs() <= tol * (1 + yr.abs())).all()
-
-
-@pytest.mark.parametrize("dma", [0, 1])
-@pytest.mark.parametrize("M,Nn,K,tm", [(300, 128, 64, 0), (200, 256, 96, 64), (129, 128, 32, 128), (515, 256, 256, 128), (1, 128, 32, 0)])
-def test_k_contiguous_study_gemm(M, Nn, K, tm, dma, request):
-    """csrc/gemm_kc.hip (layout study; on no model's path): Y[M][Nn] = X[M][K] * Wt[Nn][K]^T on the four-stage LDS-DMA
-    ring with swizzled slots, both landing times of the copies, partial row tiles, K of one to eight steps; what it does not
-    cover is refused"""
-    torch.manual_seed(M + K)
-    x, w = torch.randn(M, K).bfloat16(), (torch.randn(Nn, K) / K ** 0.5).bfloat16()
-    y = torch.full((M, Nn), float("nan")).bfloat16()
-    _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
-    assert _EMUL.cot_study_gemm_kc(P(x), P(w), P(y), M, Nn, K, tm, None) == 0
-    ref = x.float() @ w.float().t()
-    assert (y.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
-    assert _EMUL.cot_study_gemm_kc(P(x), P(w), P(y), M, Nn, K + 8, tm, None) == -2   # K off the 32-channel step
-    assert _EMUL.cot_study_gemm_kc(P(x), P(w), P(y), M, Nn + 64, K, tm, None) == -2  # output channels off the 128-column tile
-
-
-@pytest.mark.parametrize("dma", [0, 1])
-@pytest.mark.parametrize("M,K,k1,Nn,bias,acc,tm", [(98, 512, 256, 128, False, 0, 0),   # embed[0] on [x | k] at 7 x 7, two images
-                                                   (392, 128, 128, 288, True, 0, 64),   # embed[3]: bias, 9 * C / 8 outputs
-                                                   (200, 96, 32, 36, True, 1, 128),     # two slabs + bias + accumulate, one partial tile
-                                                   (130, 256, 256, 260, False, 1, 0)])  # three column tiles, the last 4 wide
-def test_k_contiguous_conv1x1_form(M, K, k1, Nn, bias, acc, tm, dma, request):
-    """the same kernel with what the CoT block's 1x1 convolutions need in a channels-last layout (cot_study_conv1x1_nhwc): the input
-    as two channel slabs (no cat), bias, accumulation into the output, output widths that are multiples of 4"""
-    torch.manual_seed(M + Nn)
-    x, w = torch.randn(M, K).bfloat16(), (torch.randn(Nn, K) / K ** 0.5).bfloat16()
-    b = torch.randn(Nn).bfloat16() if bias else None
-    x1, x2 = x[:, :k1].contiguous(), (x[:, k1:].contiguous() if k1 < K else None)
-    init = torch.randn(M, Nn).bfloat16()
-    y = init.clone() if acc else torch.full((M, Nn), float("nan")).bfloat16()
-    _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
-    none = ctypes.c_void_p(None)
-    assert _EMUL.cot_study_conv1x1_nhwc(P(x1), P(x2) if x2 is not None else none, k1, P(w), P(b) if bias else none, P(y), acc, M, Nn, K,
-                                        tm, None) == 0
-    ref = x.float() @ w.float().t() + (b.float() if bias else 0) + (init.float() if acc else 0)
-    assert (y.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
-    assert _EMUL.cot_study_conv1x1_nhwc(P(x1), none, k1, P(w), none, P(y), 0, M, Nn + 2, K, tm, None) == -2   # width off the 4-channel store
-
-
-@pytest.mark.parametrize("dma", [0, 1])
-@pytest.mark.parametrize("M,Ci,Co,slices", [(392, 256, 128, 0),   # 14 x 14, two images: 12 whole steps + 8 rows, chosen slices
-                                            (98, 128, 288, 2),    # 7 x 7: a partial last step; Co = 9 * C / 8 (three column tiles)
-                                            (33, 40, 72, 1),      # channel tiles of 40 / 72: clamped chunks; one row in the last step
-                                            (500, 136, 8, 7),     # more slices than a slice has steps for
-                                            (1, 8, 8, 0)])
-def test_k_contiguous_weight_gradient(M, Ci, Co, slices, dma, request):
-    """csrc/gemm_kc.hip, channels-last weight gradient dW[Co][Ci] = sum_m dY[m][co] X[m][ci] (study kernel): staged rows
-    read as columns by transposing LDS reads through the slot swizzle, rows past M cleared in LDS, channel tiles past the tensor
-    clamped, slices of the pixel range summed in order by the reduce kernel"""
-    _EMUL.cot_study_conv1x1_nhwc_wgrad_workspace.restype = ctypes.c_size_t
-    torch.manual_seed(M + Ci)
-    x, dy = torch.randn(M, Ci).bfloat16(), torch.randn(M, Co).bfloat16()
-    nb = _EMUL.cot_study_conv1x1_nhwc_wgrad_workspace(M, Ci, Co, slices)
-    assert nb >= Co * Ci * 4 and nb % (Co * Ci * 4) == 0
-    ws, dw = torch.full((nb // 4,), float("nan")), torch.full((Co, Ci), float("nan")).bfloat16()
-    _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
-    assert _EMUL.cot_study_conv1x1_nhwc_wgrad(P(x), P(dy), P(dw), P(ws), M, Ci, Co, slices, None) == 0
-    ref = dy.float().t() @ x.float()
-    assert (dw.float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-2
-    assert _EMUL.cot_study_conv1x1_nhwc_wgrad(P(x), P(dy), P(dw), P(ws), M, Ci + 4, Co, slices, None) == -2
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("act,use_res,give_y", [(0, False, False), (1, False, False), (1, False, True), (1, True, True), (2, False, False), (0, True, False)])
-@pytest.mark.parametrize("M,C", [(392, 256), (98, 512), (300, 64), (5, 8), (1000, 32)])
-def test_batchnorm_channels_last_study_kernels(M, C, act, use_res, give_y, dtype):
-    """csrc/bn_nhwc.hip (study kernels for the channels-last route): training-mode BatchNorm + activation + residual on
-    x[M][C] -- column reductions over row slabs merged by bn_act.hip's finalize kernels, flat apply kernels -- forward, running
-    statistics and every gradient against torch on the same values viewed as [1, C, M, 1]"""
-    F = torch.nn.functional
-    dt = _lib.dtype_code(dtype)
-    if dtype == torch.float32 and C % 4:
-        pytest.skip("fp32: 4 channels per access")
-    g = torch.Generator().manual_seed(M + C + act)
-    x = (torch.randn(M, C, generator=g) * 1.5 + 0.7).to(dtype)
-    res = torch.randn(M, C, generator=g).to(dtype) if use_res else None
-    dy = torch.randn(M, C, generator=g).to(dtype)
-    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
-    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
-    xr = x.float().requires_grad_(True)
-    rr = res.float().requires_grad_(True) if use_res else None
-    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    rm_ref, rv_ref = rm.clone(), rv.clone()
-    z = F.batch_norm(xr.t().reshape(1, C, M, 1), rm_ref, rv_ref, gr, br, True, 0.1, 1e-5).reshape(C, M).t()
-    if use_res:
-        z = z + rr
-    yr = {0: lambda t: t, 1: torch.relu, 2: F.silu}[act](z)
-    yr.backward(dy.float())
-    nws = _EMUL.cot_study_bn_nhwc_workspace(M, C, dt)
-    assert nws > 0
-    ws, y = torch.full((nws,), float("nan")), torch.full_like(x, float("nan"))
-    mean, rstd, nbt = torch.empty(C), torch.empty(C), torch.tensor(3, dtype=torch.int64)
-    none = ctypes.c_void_p(None)
-    assert _EMUL.cot_study_bn_nhwc_forward(P(x), P(res) if use_res else none, P(y), P(gamma), P(beta), P(mean), P(rstd), P(rm), P(rv), P(nbt),
-                                           P(ws), M, C, ctypes.c_float(1e-5), ctypes.c_float(0.1), act, dt, None) == 0
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
-    assert int(nbt) == 4 and ((y.float() - yr.detach()).abs() <= tol * (1 + yr.detach().abs())).all()
-    assert torch.allclose(rm, rm_ref, atol=1e-5) and torch.allclose(rv, rv_ref, atol=1e-4, rtol=1e-4)
-    dx, dres = torch.full_like(x, float("nan")), (torch.full_like(x, float("nan")) if use_res else None)
-    dg, db = torch.empty(C), torch.empty(C)
-    assert _EMUL.cot_study_bn_nhwc_backward(P(dy), P(x), P(y) if give_y else none, P(dx), P(dres) if use_res else none, P(gamma), P(beta),
-                                            P(mean), P(rstd), P(dg), P(db), P(ws), M, C, act, dt, None) == 0
-    if not (act == 1 and dtype == torch.bfloat16):  # (bf16 ReLU masks come from the rounded output: checked in fp32)
-        gt = 2e-4 if dtype == torch.float32 else 3e-2
-        assert ((dx.float() - xr.grad).abs() <= gt * (1 + xr.grad.abs().max())).all()
-        assert torch.allclose(dg, gr.grad, rtol=gt * 10, atol=gt * 10 * (1 + gr.grad.abs().max().item()))
-        assert torch.allclose(db, br.grad, rtol=gt * 10, atol=gt * 10 * (1 + br.grad.abs().max().item()))
-        if use_res:
-            assert ((dres.float() - rr.grad).abs() <= gt * (1 + rr.grad.abs())).all()
-    assert _EMUL.cot_study_bn_nhwc_workspace(M, 24, dt) == 0   # 24 / 8 = 3 threads per row: not covered
-    if act == 2:
-        assert _EMUL.cot_study_bn_nhwc_backward(P(dy), P(x), none, P(dx), P(dx), P(gamma), P(beta), P(mean), P(rstd), P(dg), P(db), P(ws), M,
-                                                C, 2, dt, None) == -2
-
-
-@pytest.mark.parametrize("dma", [0, 1])
-@pytest.mark.parametrize("N,H,W,G,Kc,acc", [(2, 7, 7, 4, 64, 0),    # CotLayer.key_embed at 7 x 7: 64 channels per group (64-column tiles)
-                                            (1, 14, 14, 2, 128, 1),  # 128 per group, accumulate
-                                            (3, 5, 9, 1, 64, 0),     # dense, non-square
-                                            (1, 1, 1, 4, 64, 0),     # one pixel: eight of nine taps outside
-                                            (2, 3, 2, 2, 32, 1)])    # 32 in / 64 out per group: one K step per tap
-def test_k_contiguous_grouped_conv3x3(N, H, W, G, Kc, acc, dma, request):
-    """csrc/gemm_kc.hip conv3x3g_kc (study kernel): the grouped 3x3 convolution of a channels-last activation as the
-    K-contiguous GEMM with nine times the K steps -- shifted source rows per tap, a block of zeros where the tap leaves the image,
-    weights repacked [Co][9][Kc] -- forward, and the data gradient as the same call on the flipped / transposed repack"""
-    F = torch.nn.functional
-    Mg = 64 if Kc != 128 else 128
-    C, Co = G * Kc, G * Mg
-    torch.manual_seed(H * W + Kc)
-    x = torch.randn(N, H, W, C).bfloat16()
-    w = (torch.randn(Co, Kc, 3, 3) / (9 * Kc) ** 0.5).bfloat16()
-    gy = torch.randn(N, H, W, Co).bfloat16()
-    xf, wf = x.float().permute(0, 3, 1, 2).requires_grad_(True), w.float()
-    yr = F.conv2d(xf, wf, None, 1, 1, 1, G)
-    yr.backward(gy.float().permute(0, 3, 1, 2))
-    zeros = torch.zeros(64).bfloat16()
-    _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
-    wr = w.permute(0, 2, 3, 1).contiguous()                                  # [Co][3][3][Kc]
-    init = torch.randn(N, H, W, Co).bfloat16()
-    y = init.clone() if acc else torch.full((N, H, W, Co), float("nan")).bfloat16()
-    assert _EMUL.cot_study_conv3x3g_nhwc(P(x), P(wr), P(zeros), P(y), acc, N, H, W, C, Co, G, None) == 0
-    ref = yr.detach().permute(0, 2, 3, 1) + (init.float() if acc else 0)
-    assert (y.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
-    # data gradient: per group the weights transposed, the taps reversed -- [C][9][Mg]
-    wt = w.view(G, Mg, Kc, 3, 3).flip(3, 4).permute(0, 2, 3, 4, 1).reshape(C, 3, 3, Mg).contiguous()
-    if Kc in (64, 128):  # (the data gradient's "output" width is Kc: 64 or a multiple of 128)
-        gx = torch.full((N, H, W, C), float("nan")).bfloat16()
-        assert _EMUL.cot_study_conv3x3g_nhwc(P(gy), P(wt), P(zeros), P(gx), 0, N, H, W, Co, C, G, None) == 0
-        gref = xf.grad.permute(0, 2, 3, 1)
-        assert (gx.float() - gref).abs().max() <= 2e-2 * gref.abs().max()
-    assert _EMUL.cot_study_conv3x3g_nhwc(P(x), P(wr), P(zeros), P(y), 0, N, H, W, C, G * 96, G, None) == -2   # 96 outputs per group
-
-
-@pytest.mark.parametrize("dma", [0, 1])
-@pytest.mark.parametrize("N,H,W,G,Kc,Mg,slices", [(2, 7, 7, 4, 64, 64, 0), (1, 14, 14, 2, 128, 128, 3), (3, 5, 9, 1, 32, 64, 1),
-                                                  (1, 1, 1, 4, 8, 16, 0), (2, 3, 2, 2, 40, 24, 2)])
-def test_k_contiguous_grouped_conv3x3_weight_gradient(N, H, W, G, Kc, Mg, slices, dma, request):
-    """gemm_kc_wgrad<TAPS> (study kernel): the grouped 3x3 weight gradient of a channels-last activation -- per (group,
-    tap) the channels-last weight-gradient GEMM on the shifted pixel rows (zero block outside the image) -- into the forward's
-    repacked layout [Co][9][Kc], against torch"""
-    F = torch.nn.functional
-    _EMUL.cot_study_conv3x3g_nhwc_wgrad_workspace.restype = ctypes.c_size_t
-    C, Co = G * Kc, G * Mg
-    torch.manual_seed(H + W + Kc)
-    x, gy = torch.randn(N, H, W, C).bfloat16(), torch.randn(N, H, W, Co).bfloat16()
-    wf = torch.zeros(Co, Kc, 3, 3, requires_grad=True)
-    F.conv2d(x.float().permute(0, 3, 1, 2), wf, None, 1, 1, 1, G).backward(gy.float().permute(0, 3, 1, 2))
-    ref = wf.grad.permute(0, 2, 3, 1).reshape(Co, 9, Kc)
-    zeros = torch.zeros(64).bfloat16()
-    nb = _EMUL.cot_study_conv3x3g_nhwc_wgrad_workspace(N, H, W, C, Co, G, slices)
-    ws, dwr = torch.full((nb // 4,), float("nan")), torch.full((Co, 9, Kc), float("nan")).bfloat16()
-    _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
-    assert _EMUL.cot_study_conv3x3g_nhwc_wgrad(P(x), P(gy), P(zeros), P(dwr), P(ws), N, H, W, C, Co, G, slices, None) == 0
-    assert (dwr.float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-2
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,G,HW", [(2, 32, 196), (3, 64, 49), (1, 8, 100), (2, 1, 4), (1, 2, 1)])
-def test_group_norm9_channels_last_study_kernels(N, G, HW, dtype):
-    """csrc/gn9_nhwc.hip (study kernels): GroupNorm-9 on channels-last logits x[N][HW][9 * G] -- a thread owns the 9
-    consecutive channels of a group in a row -- forward, saved statistics and all three gradients against torch's group_norm on
-    the same values viewed as [N, C, HW, 1]"""
-    F = torch.nn.functional
-    dt, C = _lib.dtype_code(dtype), 9 * G
-    g = torch.Generator().manual_seed(N + G + HW)
-    x = (torch.randn(N, HW, C, generator=g) * 1.7 + 0.4).to(dtype)
-    dy = torch.randn(N, HW, C, generator=g).to(dtype)
-    gamma, beta = (1 + 0.3 * torch.randn(C, generator=g)).to(dtype), (0.2 * torch.randn(C, generator=g)).to(dtype)
-    xr, gr, br = x.float().requires_grad_(True), gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
-    yr = F.group_norm(xr.permute(0, 2, 1).reshape(N, C, HW, 1), G, gr, br, 1e-5).reshape(N, C, HW).permute(0, 2, 1)
-    yr.backward(dy.float())
-    y, mean, rstd = torch.full_like(x, float("nan")), torch.empty(N * G), torch.empty(N * G)
-    assert _EMUL.cot_study_group_norm9_nhwc_forward(P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, C, HW, ctypes.c_float(1e-5), dt,
-                                                    None) == 0
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
-    assert ((y.float() - yr.detach()).abs() <= tol * (1 + yr.detach().abs())).all()
-    xg = x.float().permute(0, 2, 1).reshape(N, G, 9 * HW)
-    assert torch.allclose(mean, xg.mean(2).flatten(), atol=1e-4, rtol=1e-4)
-    dx, dg, db = torch.full_like(x, float("nan")), torch.full_like(gamma, float("nan")), torch.full_like(beta, float("nan"))
-    ws = torch.full((N * C * 2,), float("nan"))
-    assert _EMUL.cot_study_group_norm9_nhwc_backward(P(dy), P(x), P(mean), P(rstd), P(gamma), P(dx), P(dg), P(db), P(ws), N, C, HW, dt,
-                                                     None) == 0
-    if 9 * HW >= 36:  # (tiny groups: 1 / sigma amplifies the rounding)
-        gt = 3e-4 if dtype == torch.float32 else 3e-2
-        assert ((dx.float() - xr.grad).abs() <= gt * (1 + xr.grad.abs().max())).all()
-        assert torch.allclose(dg.float(), gr.grad, rtol=gt * 4, atol=gt * 4 * (1 + gr.grad.abs().max().item()))
-        assert torch.allclose(db.float(), br.grad, rtol=gt * 4, atol=gt * 4 * (1 + br.grad.abs().max().item()))
-    assert _EMUL.cot_study_group_norm9_nhwc_forward(P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), N, 9 * 3, HW, ctypes.c_float(1e-5), dt,
-                                                    None) == -2   # three groups per row: not a power of two
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,HW,C", [(2, 196, 256), (3, 49, 512), (1, 100, 64), (2, 1, 8), (1, 4, 16)])
-def test_radix_tail_channels_last_study_kernels(N, HW, C, dtype):
-    """csrc/radix_nhwc.hip (study kernels): the radix-2 tail on channels-last y, k [N][HW][C] -- pooled descriptor,
-    mix, and the mix's backward with its per-(image, channel) column sums -- against autograd on the reference formula
-    (models/cotnet.py:92-104)"""
-    dt = _lib.dtype_code(dtype)
-    g = torch.Generator().manual_seed(N + HW + C)
-    y, k, go = (torch.randn(N, HW, C, generator=g).to(dtype) for _ in range(3))
-    attn = torch.softmax(torch.randn(N, C, 2, generator=g), 2).to(dtype)
-    yr, kr, ar = y.float().requires_grad_(True), k.float().requires_grad_(True), attn.float().requires_grad_(True)
-    gap_ref = (yr + kr).mean(1)
-    out_ref = yr * ar[:, None, :, 0] + kr * ar[:, None, :, 1]
-    out_ref.backward(go.float())
-    gap, out = torch.full((N, C), float("nan")).to(dtype), torch.full_like(y, float("nan"))
-    gy, gk, ga = torch.full_like(y, float("nan")), torch.full_like(y, float("nan")), torch.full_like(attn, float("nan"))
-    assert _EMUL.cot_study_radix_nhwc_gap(P(y), P(k), P(gap), N, HW, C, dt, None) == 0
-    assert _EMUL.cot_study_radix_nhwc_mix(P(y), P(k), P(attn), P(out), N, HW, C, dt, None) == 0
-    assert _EMUL.cot_study_radix_nhwc_mix_backward(P(go), P(y), P(k), P(attn), P(gy), P(gk), P(ga), N, HW, C, dt, None) == 0
-    tol = 1e-5 if dtype == torch.float32 else 2e-2
-
-    def near(a, b, f=1.0):
-        return ((a.float() - b).abs() <= f * tol * (1 + b.abs())).all()
-
-    assert near(gap, gap_ref.detach()) and near(out, out_ref.detach()) and near(gy, yr.grad) and near(gk, kr.grad)
-    assert near(ga, ar.grad, 4 * max(1.0, HW ** 0.5 / 4))
-    assert _EMUL.cot_study_radix_nhwc_gap(P(y), P(k), P(gap), N, HW, 24, dt, None) == -2   # 3 (6) threads per row: not covered
-
-
-@pytest.mark.parametrize("N,C,HW", [(2, 256, 196), (3, 72, 49), (1, 5, 3), (2, 130, 65), (1, 64, 64)])
-def test_layout_change_between_nchw_and_channels_last(N, C, HW):
-    """csrc/layout_nhwc.hip (study kernels): per image [C][HW] <-> [HW][C] through 64 x 64 LDS tiles, exact, every element
-    written, partial tiles on both sides"""
-    torch.manual_seed(C + HW)
-    x = torch.randn(N, C, HW).bfloat16()
-    y = torch.full((N, HW, C), float("nan")).bfloat16()
-    assert _EMUL.cot_study_nchw_to_nhwc(P(x), P(y), N, C, HW, None) == 0
-    assert torch.equal(y, x.permute(0, 2, 1).contiguous())
-    z = torch.full((N, C, HW), float("nan")).bfloat16()
-    assert _EMUL.cot_study_nhwc_to_nchw(P(y), P(z), N, C, HW, None) == 0
-    assert torch.equal(z, x)
-
-
-def _cl_layer_and_truth(seed, with_grad):
-    """a CotLayer(256) in bf16 with perturbed affine parameters, a channels-last input, and the module's formula in fp32 torch (NCHW)
-    on the rounded parameters -> (layer, x, N, H, W, intermediates of the truth, parameters of the truth, truth input)"""
-    import cotnet_amd.cotnet as cn
-    from cotnet_amd.flat_sgd import to_mixed_bf16
-    F = torch.nn.functional
-    torch.manual_seed(seed)
-    N, H, W, D = 4, 5, 4, 256
-    G = D // 8
-    layer = cn.CotLayer(D, 3).train()
-    with torch.no_grad():
-        for p in layer.parameters():
-            if p.ndim == 1:
-                p.add_(0.2 * torch.randn_like(p))
-    layer = to_mixed_bf16(layer)
-    x = torch.randn(N, H, W, D).bfloat16()
-    prm = {n_: p.detach().float().requires_grad_(with_grad) for n_, p in layer.named_parameters()}
-
-    def tbn(t, name):
-        return F.batch_norm(t, None, None, prm[name + ".weight"], prm[name + ".bias"], True, 0.1, 1e-5)
-    xt = x.float().permute(0, 3, 1, 2).requires_grad_(with_grad)
-    kt = torch.relu(tbn(F.conv2d(xt, prm["key_embed.0.weight"], None, 1, 1, 1, 4), "key_embed.1"))
-    et = torch.relu(tbn(F.conv2d(torch.cat([xt, kt], 1), prm["embed.0.weight"]), "embed.1"))
-    et = F.group_norm(F.conv2d(et, prm["embed.3.weight"], prm["embed.3.bias"]), G, prm["embed.4.weight"], prm["embed.4.bias"], layer.embed[4].eps)
-    vt = tbn(F.conv2d(xt, prm["conv1x1.0.weight"]), "conv1x1.1")
-    at = unfold_oracle.aggregation_unfold(vt, et.reshape(N, 1, G, 9, H, W), 3, 1, 1, 1)
-    yt = F.silu(tbn(at, "bn"))
-    gt = (yt + kt).mean((2, 3), keepdim=True)
-    st = F.conv2d(torch.relu(tbn(F.conv2d(gt, prm["se.0.weight"], prm["se.0.bias"]), "se.1")), prm["se.3.weight"], prm["se.3.bias"])
-    a_t = torch.softmax(st.view(N, D, 2), 2)
-    ot = yt * a_t[:, :, 0, None, None] + kt * a_t[:, :, 1, None, None]
-    return layer, x, (N, H, W), dict(k=kt, wn=et, v=vt, y=yt, out=ot), prm, xt
-
-
-def test_cot_layer_forward_composed_from_the_channels_last_study_kernels():
-    """the whole CotLayer(256) forward (models/cotnet.py:79-104) on channels-last tensors as cotnet_amd.channels_last_study issues it
-    on the study kernels of DESIGN 5.8 -- grouped 3x3 and 1x1 convolutions on the K-contiguous GEMM ([x, k] as two slabs, bias),
-    BatchNorm (+ ReLU / SiLU), GroupNorm-9, the NHWC aggregation, radix tail with the `se` branch as the same GEMM / BatchNorm on the
-    [N][C] descriptor -- against an fp32 evaluation of the module's formula on the bf16-rounded parameters"""
-    from cotnet_amd import channels_last_study as cls
-    layer, x, (N, H, W), truth_t, _, _ = _cl_layer_and_truth(11, False)
-    out, sv = cls.forward(_EMUL, cls.Plan(layer), x, N, H, W)
-
-    def rel(a, b):   # a: channels-last [M][C], b: NCHW
-        b = b.permute(0, 2, 3, 1).reshape(a.shape)
-        return ((a.float() - b).abs().mean() / b.abs().mean()).item()
-    errs = [rel(sv["k"], truth_t["k"]), rel(sv["wn"], truth_t["wn"]), rel(sv["v"], truth_t["v"]), rel(sv["y"], truth_t["y"]), rel(out, truth_t["out"])]
-    # measured: 0.002 / 0.003 / 0.002 / 0.005 / 0.004 (bf16 rounding of every intermediate); a wiring error gives O(1)
-    assert errs[0] < 6e-3 and errs[1] < 1e-2 and errs[2] < 6e-3 and errs[3] < 1.5e-2 and errs[4] < 2e-2, errs
-
-
-def test_cot_layer_backward_composed_from_the_channels_last_study_kernels():
-    """the CotLayer(256) BACKWARD on channels-last tensors in the order a node would issue it (cotnet_amd.channels_last_study): radix
-    tail (column sums, then the element-wise half with the pooled descriptor's gradient), the `se` branch as GEMMs / BatchNorm on
-    [N][C], BatchNorm / GroupNorm-9 backwards, the NHWC aggregation backward, data gradients as the forward GEMM on transposed weights
-    (accumulating where branches join), weight gradients, bias gradients as column sums -- the input gradient and every parameter
-    gradient against autograd on the module's formula in fp32"""
-    from cotnet_amd import channels_last_study as cls
-    layer, x, (N, H, W), truth_t, prm, xt = _cl_layer_and_truth(12, True)
-    M, D = N * H * W, 256
-    gout = torch.randn(M, D).bfloat16()
-    plan = cls.Plan(layer)
-    _, sv = cls.forward(_EMUL, plan, x, N, H, W)
-    gx, grads = cls.backward(_EMUL, plan, sv, gout)
-    truth_t["out"].backward(gout.float().view(N, H, W, D).permute(0, 3, 1, 2))
-
-    def rel(a, b):
-        a, b = a.float().reshape(-1), b.float().reshape(-1)
-        return ((a - b).abs().mean() / (b.abs().mean() + 1e-12)).item()
-    errs = {"x": rel(gx, xt.grad.permute(0, 2, 3, 1))}
-    top = max(p.grad.abs().max().item() for p in prm.values())
-    for n_, p in prm.items():
-        assert n_ in grads, n_
-        if p.grad.abs().max().item() > 1e-3 * top and n_ != "se.0.bias":  # (a bias in front of a BatchNorm: true gradient zero)
-            errs[n_] = rel(grads[n_].reshape(p.shape), p.grad)
-    # measured: 0.006 .. 0.032 over the input and the 20 parameter gradients (bf16 chain, four-sample `se` BatchNorm); a missing term gives > 0.3
-    assert len(errs) == 21 and max(errs.values()) < 6e-2, sorted(errs.items(), key=lambda t: -t[1])[:6]
-
-
-def test_bottleneck_as_one_channels_last_autograd_node():
-    """cotnet_amd.channels_last_study.BottleneckCL: the stride-1 Bottleneck (models/cotnet.py:228-264) as one autograd node on
-    channels-last tensors -- conv1 / bn1 / CotLayer / conv3 / bn3 + residual + ReLU, every launch a study kernel -- against the
-    module itself evaluated in fp32 by plain torch modules (aggregation: the Unfold formula), output, input gradient, all 29 parameter
-    gradients"""
-    import copy
-    import cotnet_amd.aggregation_zeropad as azm
-    from cotnet_amd import channels_last_study as cls
-    from cotnet_amd.cotnet import Bottleneck
-    from cotnet_amd.flat_sgd import to_mixed_bf16
-    from tests import truth
-    torch.manual_seed(13)
-    N, H, W = 4, 4, 5
-    blk = Bottleneck(1024, 256).train()
-    with torch.no_grad():
-        for p in blk.parameters():
-            if p.ndim == 1:
-                p.add_(0.2 * torch.randn_like(p))
-        blk.bn3.weight.fill_(0.8)
-    blk = to_mixed_bf16(blk)
-    x = torch.randn(N, H, W, 1024).bfloat16().requires_grad_(True)
-    gout = torch.randn(N, H, W, 1024).bfloat16()
-    out = cls.BottleneckCL.apply(_EMUL, cls.BlockPlan(blk), x, *blk.parameters())
-    assert out.grad_fn.name().startswith("BottleneckCL")
-    out.backward(gout)
-    ref = copy.deepcopy(blk).float()
-    for p in ref.parameters():
-        p.grad = None
-    xt = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
-    orig = azm.aggregation_zeropad
-    azm.aggregation_zeropad = lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: unfold_oracle.aggregation_unfold(i, w, 3, 1, 1, 1)
-    try:
-        with truth.switches(**truth.PLAIN):
-            yt = ref(xt)
-            yt.backward(gout.float().permute(0, 3, 1, 2))
-    finally:
-        azm.aggregation_zeropad = orig
-
-    def rel(a, b):
-        a, b = a.float().reshape(-1), b.float().reshape(-1)
-        return ((a - b).abs().mean() / (b.abs().mean() + 1e-12)).item()
-    errs = {"out": rel(out.detach(), yt.detach().permute(0, 2, 3, 1)), "x": rel(x.grad, xt.grad.permute(0, 2, 3, 1))}
-    top = max(p.grad.abs().max().item() for p in ref.parameters())
-    for (n_, p), q in zip(blk.named_parameters(), ref.parameters()):
-        assert p.grad is not None and p.grad.shape == p.shape, n_
-        if q.grad.abs().max().item() > 1e-3 * top and not n_.endswith("se.0.bias"):
-            errs[n_] = rel(p.grad, q.grad)
-    # measured: output 0.005; gradients up to 0.076 in the mean (bf16 ulps flip a few ReLU masks at bn3, as in the NCHW node's test, whose
-    # bound this is; a wrong term shows as > 0.3)
-    assert len(errs) >= 28 and errs["out"] < 1e-2 and max(errs.values()) < 0.12, sorted(errs.items(), key=lambda t: -t[1])[:6]
-
-
-def test_stage_routed_through_the_channels_last_node(monkeypatch):
-    """channels_last_study.run_stage on a layer3-like stage (a stride-2 block with a projection, then two stride-1 blocks): the first
-    block stays on the product's NCHW node, the other two run as BottleneckCL between two layout changes -- output and every
-    gradient against the same stage run block by block on the NCHW single-node path (both on the emulated kernels, bf16)"""
-    import copy
-    import cotnet_amd.aggregation_zeropad as az
-    from cotnet_amd import channels_last_study as cls, cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, radix_tail, pool3x3 as p3
-    from cotnet_amd.cotnet import Bottleneck
-    from cotnet_amd.flat_sgd import to_mixed_bf16
-    from cotnet_amd.resnet import downsample_conv
-    torch.manual_seed(14)
-    stage = torch.nn.Sequential(Bottleneck(512, 256, stride=2, downsample=downsample_conv(512, 1024, 1, stride=2)), Bottleneck(1024, 256),
-                                Bottleneck(1024, 256)).train()
-    with torch.no_grad():
-        for p in stage.parameters():
-            if p.ndim == 1:
-                p.add_(0.2 * torch.randn_like(p))
-        for b in stage:
-            b.bn3.weight.fill_(0.8)
-    stage = to_mixed_bf16(stage)
-    other = copy.deepcopy(stage)
-    x = torch.randn(8, 512, 8, 8).bfloat16()    # (eight images: the `se` branch's BatchNorm over 3 samples puts BOTH paths 30-60 % from fp32)
-    g = torch.randn(8, 1024, 4, 4).bfloat16()
-    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
-    for mod in (clf, c1, c3, fused_bn, radix_tail, p3):
-        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
-    for mod in (c1, c3, p3):
-        monkeypatch.setattr(mod, "MODE", "hip")
-    monkeypatch.setattr(clf, "ENABLED", True)
-    monkeypatch.setattr(az, "aggregation_zeropad", lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
-    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
-    for c in caches:
-        c.clear()
-    xa = x.clone().requires_grad_(True)
-    assert [cls.block_eligible(b, xa) for b in stage] == [False, True, True]
-    ya = cls.run_stage(_EMUL, stage, xa)
-    names = set()
-    f, seen = [ya.grad_fn], set()
-    while f:
-        n_ = f.pop()
-        if n_ is None or n_ in seen:
-            continue
-        seen.add(n_)
-        names.add(n_.name())
-        f.extend(t for t, _ in n_.next_functions)
-    assert any(t.startswith("BottleneckCL") for t in names) and any(t.startswith("_BottleneckNode") for t in names)
-    assert any(t.startswith("_ToCL") for t in names) and any(t.startswith("_FromCL") for t in names)
-    ya.backward(g)
-    xb = x.clone().requires_grad_(True)
-    yb = other(xb)
-    yb.backward(g)
-    for c in caches:
-        c.clear()
-
-    def rel(a, b):
-        return ((a.float() - b.float()).abs().mean() / (b.float().abs().mean() + 1e-12)).item()
-    # measured: input gradients 0.098 apart in the mean (both 0.19 from an fp32 evaluation: eight-sample `se` BatchNorms, flipped ReLU masks),
-    # parameter gradients up to 0.12; a wrong term gives > 0.3
-    assert ((ya.float() - yb.float()).abs().max() / yb.float().abs().max()).item() < 3e-2
-    assert rel(xa.grad, xb.grad) < 0.15
-    top = max(q.grad.float().abs().max() for q in other.parameters())
-    for (n_, p), q in zip(stage.named_parameters(), other.parameters()):
-        assert p.grad is not None, n_
-        if q.grad.float().abs().max() > 1e-3 * top and not n_.endswith("se.0.bias"):
-            assert rel(p.grad, q.grad) < 0.18, (n_, rel(p.grad, q.grad))
-
-
-@pytest.mark.parametrize("dma", [0, 1])
-@pytest.mark.parametrize("M,K,Nt,N,c0,acc,tm", [(392, 256, 1024, 1024, 0, 0, 0), (98, 128, 512, 256, 256, 1, 64), (200, 288, 128, 128, 0, 0, 128),
-                                                (33, 32, 40, 24, 8, 1, 0), (1, 64, 8, 8, 0, 0, 0)])
-def test_k_contiguous_data_gradient_from_the_untransposed_weight(M, K, Nt, N, c0, acc, tm, dma, request):
-    """gemm_kc_nn (cot_study_conv1x1_nhwc_dgrad): dx[M][N] (+)= dy[M][K] * w[K][N] straight from the convolution's weight [Co][Ci] --
-    the weight side staged as k-rows and read as columns by transposing LDS reads (as the weight-gradient kernel does), a column
-    window of a wider weight / output (one slab of embed[0]'s [x | k]), accumulate; nothing outside the window is touched"""
-    torch.manual_seed(M + K)
-    dy, w = torch.randn(M, K).bfloat16(), (torch.randn(K, Nt) / K ** 0.5).bfloat16()
-    init = torch.randn(M, Nt).bfloat16()
-    dx = init.clone()
-    if not acc:
-        dx[:, c0:c0 + N] = float("nan")
-    _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: _EMUL.emul_set_dma_mode(0))
-    assert _EMUL.cot_study_conv1x1_nhwc_dgrad(P(dy), ctypes.c_void_p(w.data_ptr() + 2 * c0), ctypes.c_void_p(dx.data_ptr() + 2 * c0), acc, M, N,
-                                              K, Nt, Nt, tm, None) == 0
-    ref = init.float().clone()
-    ref[:, c0:c0 + N] = dy.float() @ w.float()[:, c0:c0 + N] + (init.float()[:, c0:c0 + N] if acc else 0)
-    assert (dx.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
-    assert torch.equal(dx[:, :c0], init[:, :c0]) and torch.equal(dx[:, c0 + N:], init[:, c0 + N:])
-    assert _EMUL.cot_study_conv1x1_nhwc_dgrad(P(dy), P(w), P(dx), 0, M, N, K + 8, Nt, Nt, tm, None) == -2
-
-
-def test_radix_pair_softmax_and_weight_gradient_window():
-    """the last host-side pieces of the channels-last layer moved onto kernels: softmax over the radix pair and its backward
-    (cot_study_radix_softmax2*), a weight gradient written into a column window of a wider gradient (embed[0]'s [x | k] slabs)"""
-    _EMUL.cot_study_conv1x1_nhwc_wgrad_workspace.restype = ctypes.c_size_t
-    torch.manual_seed(3)
-    lg, ga = (2 * torch.randn(5, 24, 2)).bfloat16(), torch.randn(5, 24, 2).bfloat16()
-    attn, gl = torch.full_like(lg, float("nan")), torch.full_like(lg, float("nan"))
-    assert _EMUL.cot_study_radix_softmax2(P(lg), P(attn), ctypes.c_int64(5 * 24), 2, None) == 0
-    lr = lg.float().requires_grad_(True)
-    ar = torch.softmax(lr, 2)
-    assert torch.allclose(attn.float(), ar.detach(), atol=4e-3)
-    assert _EMUL.cot_study_radix_softmax2_backward(P(attn), P(ga), P(gl), ctypes.c_int64(5 * 24), 2, None) == 0
-    af = attn.float()
-    assert torch.allclose(gl.float(), af * (ga.float() - (af * ga.float()).sum(2, keepdim=True)), atol=1e-2, rtol=2e-2)
-    M, Ci, Co = 70, 40, 24
-    x, dy = torch.randn(M, Ci).bfloat16(), torch.randn(M, Co).bfloat16()
-    wide = torch.full((Co, 3 * Ci), 7.0).bfloat16()
-    ws = torch.empty(_EMUL.cot_study_conv1x1_nhwc_wgrad_workspace(M, Ci, Co, 0), dtype=torch.uint8)
-    assert _EMUL.cot_study_conv1x1_nhwc_wgrad_window(P(x), P(dy), ctypes.c_void_p(wide.data_ptr() + 2 * Ci), 3 * Ci, P(ws), M, Ci, Co, 0, None) == 0
-    ref = dy.float().t() @ x.float()
-    assert (wide[:, Ci:2 * Ci].float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-2
-    assert (wide[:, :Ci] == 7).all() and (wide[:, 2 * Ci:] == 7).all()
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,C", [(15, 288), (392, 128), (1000, 72), (1, 8), (8200, 16)])
-def test_channels_last_column_sums(M, C, dtype):
-    """cot_study_nhwc_col_sum (the bias gradient of a channels-last convolution): row slabs across workgroups, fp32 partial sums added
-    in slab order, one rounding"""
-    dt = _lib.dtype_code(dtype)
-    torch.manual_seed(M + C)
-    x = torch.randn(M, C).to(dtype)
-    o = torch.full((C,), float("nan")).to(dtype)
-    ws = torch.full((_EMUL.cot_study_nhwc_col_sum_workspace(M, C),), float("nan"))
-    assert _EMUL.cot_study_nhwc_col_sum(P(x), P(o), P(ws), M, C, dt, None) == 0
-    ref = x.float().sum(0)
-    tol = 1e-5 if dtype == torch.float32 else 1e-2
-    assert ((o.float() - ref).abs() <= tol * (M ** 0.5 + ref.abs())).all()
