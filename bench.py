@@ -937,7 +937,11 @@ def main():
                         "timing": f"dispatch-attached HIP events (on the launch stream) over {timing_steps} repeats of the "
                                   "step right after the un-instrumented timed region, every launch on one stream (no weight "
                                   "gradients beside the kernel being timed)",
-                        "agg_share_of_step": round(agg_total / (elapsed / args.steps * 1e3), 4), "kernels": kernels,
+                        "agg_share_of_step": round(agg_total / (elapsed / args.steps * 1e3), 4),
+                        # every aggregation launch of the step, forward and backward, all four stages: algorithmic bytes / device time
+                        "frac_all_layers": round(sum(k["GBs"] * k["total_ms"] for k in kernels) / max(sum(k["total_ms"] for k in kernels), 1e-9)
+                                                 / HBM_PEAK_GBS, 4),
+                        "kernels": kernels,
                         "conv_bn_families": op_families, "conv_bn_calls": op_rows[:40],
                         "conv_bn_note": "per CALL of the C ABI (all launches of the call), dispatch-attached events; frac_hbm = algorithmic "
                                         "bytes / time / 8 TB/s, frac_mfma = 2*N*HW*Ci*Co(*9)/groups / time / 2.5 PFLOP/s; weight gradients "

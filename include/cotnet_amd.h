@@ -15,7 +15,10 @@
  *   - all pointers are DEVICE pointers (HBM) owned by the caller; kernels write EVERY element of their
  *     outputs (the reference allocates outputs uninitialised, aggregation_zeropad.py:123,:169,:178);
  *   - calls are asynchronous on `stream` (a hipStream_t cast to void*; NULL = the null stream),
- *     re-entrant, and keep no global mutable state besides a thread-local last-error string;
+ *     and re-entrant.  Process-global state is limited to (a) the thread-local last-error / last-kernel strings, (b) the
+ *     DEVELOPER knobs of cot_set_tuning (kernel-variant selectors for A/B measurements and tests; every default is the measured
+ *     best and a production caller never touches them -- they are read at launch time, so changing one while another thread
+ *     launches is a race the caller must avoid) and (c) the cot_profile_* recorder;
  *   - return value: COT_OK (0) or a negative cot_status; cot_last_error() describes the failure.
  *     The reference reports errors through Python asserts (aggregation_zeropad.py:117,:122,:189).
  */
