@@ -121,6 +121,10 @@ SYMBOLS = {
     "cot_bn_relu_mask_bytes": (ctypes.c_int64, [_I, _I, _I, _I]),
     "cot_bn_act_forward_mask": (_I, [_P] * 13 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "cot_bn_act_backward_mask": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P]),
+    "cot_conv1x1_stats_covers": (_I, [_I] * 4),
+    "cot_conv1x1_forward_stats": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cot_bn_tile_stats_finalize": (_I, [_P] * 6 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
+    "cot_bn_act_apply_forward": (_I, [_P] * 8 + [_I, _I, _I, _I, _I, _P]),
     "cot_bn_act_lay_covers": (_I, [_I, _I, _I, _I]),
     "cot_bn_act_forward_lay": (_I, [_P] * 12 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _I, _P]),
     "cot_bn_act_backward_lay": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _I, _P]),

@@ -732,14 +732,17 @@ template <int NV> __device__ __forceinline__ void block_allsum_d(double (&v)[NV]
     }
 }
 
-template <typename T, int V, int ACT>
+// RR: rounds (vectors per lane) this instance is unrolled for -- 0 = the most the registers hold (ChanRounds), else 2 / 4: a
+// 14 x 14 channel of 80 images is 3920 four-element vectors = FOUR rounds of a 1024-lane workgroup, and the sixteen-round instance
+// spent 128 registers (some of them in scratch) and twelve predicated-off rounds on it (round 5, profiles/r05_bn_chan_rounds_ab.log)
+template <typename T, int V, int ACT, int RR>
 __global__ __launch_bounds__(1024) void bn_chan_fwd(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float* __restrict__ mean, float* __restrict__ rstd,
                                                    float* __restrict__ rmean, float* __restrict__ rvar,
                                                    long long* __restrict__ nbt, int N, int C, int HW, float eps, float mom,
                                                    const float* __restrict__ ps, uint8_t* __restrict__ mask) {
-    constexpr int R = ChanRounds<T, V, false>::value;
+    constexpr int R = RR ? RR : ChanRounds<T, V, false>::value;
     __shared__ double red[16];
     const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
     const int vpp = HW / V, MV = N * vpp;
@@ -803,14 +806,14 @@ __global__ __launch_bounds__(1024) void bn_chan_fwd(const T* __restrict__ x, con
         }
 }
 
-template <typename T, int V, int ACT>
+template <typename T, int V, int ACT, int RR>
 __global__ __launch_bounds__(1024) void bn_chan_bwd(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                    T* __restrict__ dx, T* __restrict__ dres, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, int N, int C, int HW, const float* __restrict__ ps,
                                                    const uint8_t* __restrict__ mask) {
-    constexpr int R = ChanRounds<T, V, true>::value;
+    constexpr int R = RR ? RR : ChanRounds<T, V, true>::value;
     __shared__ double red[32];
     const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
     const int vpp = HW / V, MV = N * vpp;
@@ -904,6 +907,16 @@ static inline int bn_chan_threads(int N, int C, int HW, int V, int rounds) {
     return need > fill ? need : fill;
 }
 
+// the instance's round count for a channel of MV vectors on `threads` lanes: 2, 4 or 0 (= the full ChanRounds instance)
+int g_bn_chan_rr = 1;  // cot_set_tuning key 47: 1 (default) = short instances where they cover the channel, 0 = always the full one
+static inline int bn_chan_rr(int64_t MV, int threads, int full) {
+    if (!g_bn_chan_rr) return 0;
+    const int64_t need = (MV + threads - 1) / threads;
+    if (need <= 2 && full > 2) return 2;
+    if (need <= 4 && full > 4) return 4;
+    return 0;
+}
+
 template <typename T>
 int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* mean,
                    float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW, float eps,
@@ -921,7 +934,14 @@ int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, 
     if (const int cv = bn_chan_vec<T, false>(N, C, HW)) {
         const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, false>(cv)));
         uint8_t* const mk = cv == 8 ? t_bn_mask : nullptr;
-#define BN_CF(V_, A_) COT_LAUNCH((bn_chan_fwd<T, V_, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom, ps, (V_) == 8 ? mk : nullptr)
+        const int rr = bn_chan_rr((int64_t)N * HW / cv, (int)block.x, bn_chan_rounds<T, false>(cv));
+#define BN_CFR(V_, A_, R_) COT_LAUNCH((bn_chan_fwd<T, V_, A_, R_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom, ps, (V_) == 8 ? mk : nullptr)
+#define BN_CF(V_, A_)                      \
+    do {                                   \
+        if (rr == 2) BN_CFR(V_, A_, 2);    \
+        else if (rr == 4) BN_CFR(V_, A_, 4); \
+        else BN_CFR(V_, A_, 0);            \
+    } while (0)
 #define BN_CFV(V_)                                \
     do {                                          \
         if (act == ACT_RELU) BN_CF(V_, ACT_RELU); \
@@ -934,6 +954,7 @@ int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, 
         else BN_CFV(1);
 #undef BN_CFV
 #undef BN_CF
+#undef BN_CFR
         return check_launch("bn_chan_fwd");
     }
     const int v = pick_vec(sizeof(T), HW);
@@ -962,7 +983,14 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
     if (const int cv = bn_chan_vec<T, true>(N, C, HW)) {
         const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, true>(cv)));
         const uint8_t* const mk = cv == 8 ? t_bn_mask : nullptr;
-#define BN_CB(V_, A_) COT_LAUNCH((bn_chan_bwd<T, V_, A_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW, ps, (V_) == 8 ? mk : nullptr)
+        const int rr = bn_chan_rr((int64_t)N * HW / cv, (int)block.x, bn_chan_rounds<T, true>(cv));
+#define BN_CBR(V_, A_, R_) COT_LAUNCH((bn_chan_bwd<T, V_, A_, R_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW, ps, (V_) == 8 ? mk : nullptr)
+#define BN_CB(V_, A_)                      \
+    do {                                   \
+        if (rr == 2) BN_CBR(V_, A_, 2);    \
+        else if (rr == 4 && bn_chan_rounds<T, true>(V_) > 4) BN_CBR(V_, A_, 4); \
+        else BN_CBR(V_, A_, 0);            \
+    } while (0)
 #define BN_CBV(V_)                                         \
     do {                                                   \
         if (act == ACT_RELU && y) BN_CB(V_, ACT_RELU_Y);   \
@@ -976,6 +1004,7 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
         else BN_CBV(1);
 #undef BN_CBV
 #undef BN_CB
+#undef BN_CBR
         return check_launch("bn_chan_bwd");
     }
     const int v = pick_vec(sizeof(T), HW);
@@ -987,6 +1016,61 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
 }
 
 
+// ---- statistics from the PRODUCER's epilogue (round 5): the 1x1 convolution that writes a BatchNorm's
+// input also writes, per (image, 128-pixel tile, channel), the sum and the sum of squares of the bf16 values it stores
+// (conv_lds_common.h tile_epilogue, BIG tiles: planes of more than 256 pixels).  This kernel turns them into the channel's batch
+// statistics -- one wave per channel, N * PT entries added in fp64 in a fixed order -- and updates the running statistics exactly as
+// bn_stats_finalize does; bn_apply_fwd then normalises.  It replaces bn_stats_partial, i.e. one full read of the tensor.
+__global__ __launch_bounds__(64) void bn_tile_stats_finalize(const float* __restrict__ part, int N, int C, int PT, int HW, float eps,
+                                                            float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                            long long* __restrict__ num_batches_tracked) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c == 0 && lane == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = lane; e < N * PT; e += 64) {
+        const float* p = part + ((int64_t)e * C + c) * 2;
+        s1 += (double)p[0];
+        s2 += (double)p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (lane == 0) {
+        const double cnt = (double)N * HW, m = s1 / cnt;
+        double var = s2 / cnt - m * m;  // (fp64 on sums of bf16-exact squares: no visible cancellation at these counts)
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+int bn_tile_stats(const float* part, int N, int C, int HW, float eps, float mom, float* mean, float* rstd, float* rmean, float* rvar,
+                  long long* nbt, hipStream_t s) {
+    COT_LAUNCH(bn_tile_stats_finalize, dim3(C), dim3(64), 0, s, part, N, C, ceil_div(HW, 128), HW, eps, mom, mean, rstd, rmean, rvar, nbt);
+    return check_launch("bn_tile_stats_finalize");
+}
+// y = act(gamma * (x - mean_c) * rstd_c + beta [+ residual]) from GIVEN batch statistics (bf16; the flat apply kernel)
+int bn_apply_forward(const void* x, const void* res, void* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                     int N, int C, int HW, int act, hipStream_t s) {
+    typedef bf16_t T;
+    if (HW % 8 != 0) return -2;
+    const int64_t nvec = (int64_t)N * C * HW / 8;
+    uint8_t* const mk = t_bn_mask;
+#define BN_AF(A_) COT_LAUNCH((bn_apply_fwd<T, 8, A_>), dim3(flat_grid(nvec)), dim3(256), 0, s, (const T*)x, (const T*)res, (T*)y, mean, rstd, gamma, beta, C, HW, nvec, mk)
+    if (act == ACT_RELU) BN_AF(ACT_RELU);
+    else if (act == ACT_SILU) BN_AF(ACT_SILU);
+    else BN_AF(ACT_NONE);
+#undef BN_AF
+    return check_launch("bn_apply_fwd");
+}
+
 // ---- per-tensor layouts (round 5): the deep stages' Bottlenecks keep the operands of their 1x1 convolutions
 // "channel-major" -- [C][N][HW]: a channel's N planes are one contiguous row, the GEMM / BatchNorm calls see N = 1, HW' = N*HW --
 // while the plane kernels between them (grouped 3x3, aggregation) stay NCHW.  The layout changes where a BatchNorm already moves
@@ -996,14 +1080,14 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
 // lay bits: 0 = NCHW ((n*C + c)*HW), 1 = channel-major ((c*N + n)*HW).
 __device__ __forceinline__ int lay_off(int cm, int n, int c, int N, int C, int HW) { return cm ? (c * N + n) * HW : (n * C + c) * HW; }
 
-template <typename T, int V, int ACT>
+template <typename T, int V, int ACT, int RR>
 __global__ __launch_bounds__(1024) void bn_chan_fwd_lay(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                        T* __restrict__ y2, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ mean,
                                                        float* __restrict__ rstd, float* __restrict__ rmean, float* __restrict__ rvar,
                                                        long long* __restrict__ nbt, int N, int C, int HW, float eps, float mom,
                                                        const float* __restrict__ ps, int lay) {
-    constexpr int R = ChanRounds<T, V, false>::value;
+    constexpr int R = RR ? RR : ChanRounds<T, V, false>::value;
     __shared__ double red[16];
     const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
     const int vpp = HW / V, MV = N * vpp;
@@ -1071,14 +1155,14 @@ __global__ __launch_bounds__(1024) void bn_chan_fwd_lay(const T* __restrict__ x,
 
 // backward bits: 1 dy, 2 dy2, 4 x, 8 y, 16 dx, 32 dres.  dy2 != NULL: the upstream gradient is dy + dy2 (fp32 sum, one rounding --
 // what the data-gradient kernels' `accumulate` does when both contributions share a layout)
-template <typename T, int V, int ACT>
+template <typename T, int V, int ACT, int RR>
 __global__ __launch_bounds__(1024) void bn_chan_bwd_lay(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ x,
                                                        const T* __restrict__ y, T* __restrict__ dx, T* __restrict__ dres,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int HW,
                                                        const float* __restrict__ ps, int lay) {
-    constexpr int R = ChanRounds<T, V, true>::value;
+    constexpr int R = RR ? RR : ChanRounds<T, V, true>::value;
     __shared__ double red[32];
     const int c = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
     const int vpp = HW / V, MV = N * vpp;
@@ -1155,7 +1239,14 @@ int bn_act_forward_lay(const void* x, const void* res, void* y, void* y2, const 
     const int cv = bn_chan_vec<T, false>(N, C, HW);
     if (cv <= 1 || (int64_t)N * HW <= g_bn_small_m) return -2;
     const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, false>(cv)));
-#define BN_LF(V_, A_) COT_LAUNCH((bn_chan_fwd_lay<T, V_, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, (T*)y2, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom, ps, lay)
+    const int rr = bn_chan_rr((int64_t)N * HW / cv, (int)block.x, bn_chan_rounds<T, false>(cv));
+#define BN_LFR(V_, A_, R_) COT_LAUNCH((bn_chan_fwd_lay<T, V_, A_, R_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, (T*)y2, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom, ps, lay)
+#define BN_LF(V_, A_)                      \
+    do {                                   \
+        if (rr == 2) BN_LFR(V_, A_, 2);    \
+        else if (rr == 4) BN_LFR(V_, A_, 4); \
+        else BN_LFR(V_, A_, 0);            \
+    } while (0)
 #define BN_LFV(V_)                                \
     do {                                          \
         if (act == ACT_RELU) BN_LF(V_, ACT_RELU); \
@@ -1167,6 +1258,7 @@ int bn_act_forward_lay(const void* x, const void* res, void* y, void* y2, const 
     else BN_LFV(4);
 #undef BN_LFV
 #undef BN_LF
+#undef BN_LFR
     return check_launch("bn_chan_fwd_lay");
 }
 int bn_act_backward_lay(const void* dy, const void* dy2, const void* x, const void* y, void* dx, void* dres, const float* gamma,
@@ -1176,7 +1268,14 @@ int bn_act_backward_lay(const void* dy, const void* dy2, const void* x, const vo
     const int cv = bn_chan_vec<T, true>(N, C, HW);
     if (cv <= 1 || (int64_t)N * HW <= g_bn_small_m) return -2;
     const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, true>(cv)));
-#define BN_LB(V_, A_) COT_LAUNCH((bn_chan_bwd_lay<T, V_, A_>), grid, block, 0, s, (const T*)dy, (const T*)dy2, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW, ps, lay)
+    const int rr = bn_chan_rr((int64_t)N * HW / cv, (int)block.x, bn_chan_rounds<T, true>(cv));
+#define BN_LBR(V_, A_, R_) COT_LAUNCH((bn_chan_bwd_lay<T, V_, A_, R_>), grid, block, 0, s, (const T*)dy, (const T*)dy2, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW, ps, lay)
+#define BN_LB(V_, A_)                      \
+    do {                                   \
+        if (rr == 2) BN_LBR(V_, A_, 2);    \
+        else if (rr == 4 && bn_chan_rounds<T, true>(V_) > 4) BN_LBR(V_, A_, 4); \
+        else BN_LBR(V_, A_, 0);            \
+    } while (0)
 #define BN_LBV(V_)                                         \
     do {                                                   \
         if (act == ACT_RELU && y) BN_LB(V_, ACT_RELU_Y);   \
@@ -1189,6 +1288,7 @@ int bn_act_backward_lay(const void* dy, const void* dy2, const void* x, const vo
     else BN_LBV(4);
 #undef BN_LBV
 #undef BN_LB
+#undef BN_LBR
     return check_launch("bn_chan_bwd_lay");
 }
 

@@ -120,6 +120,8 @@ int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, flo
 int ema_flat(void*, const void*, int64_t, float, int, hipStream_t);
 int bn_workspace_floats(int N, int C);
 int bn_act_lay_covers(int N, int C, int HW);
+int bn_tile_stats(const float*, int, int, int, float, float, float*, float*, float*, float*, long long*, hipStream_t);
+int bn_apply_forward(const void*, const void*, void*, const float*, const float*, const float*, const float*, int, int, int, int, hipStream_t);
 int bn_act_forward_lay(const void*, const void*, void*, void*, const float*, const float*, float*, float*, float*, float*, long long*, int,
                        int, int, float, float, int, const float*, int, hipStream_t);
 int bn_act_backward_lay(const void*, const void*, const void*, const void*, void*, void*, const float*, const float*, const float*,
@@ -164,6 +166,7 @@ extern int g_conv3x3_cols;
 extern int g_conv3x3_perm;
 extern int g_conv_flat_ns3;
 extern int g_conv_big_fill;
+extern int g_bn_chan_rr;
 extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
 unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
@@ -420,6 +423,10 @@ int cot_set_tuning(int key, int value) {
         g_conv_big_fill = value > 0 ? value : 0;
         return COT_OK;
     }
+    if (key == 47) {
+        g_bn_chan_rr = value ? 1 : 0;
+        return COT_OK;
+    }
     if (key == 42) {
         g_conv3x3_wsingle = value == 2 ? 2 : (value ? 1 : 0);
         return COT_OK;
@@ -555,20 +562,38 @@ int cot_gn9_fused_covers(int Ci, int c1, int two_slabs, int HW, int W) {
     const bool w_ok = W == 56 || W == 28 || W == 14 || W == 40 || W == 20 || W == 10;  // (the packed dot-product backward's widths)
     return (HW > 256 && HW % 8 == 0 && w_ok && HW % W == 0 && conv1x1_lds_covers(Ci, c1, two_slabs != 0, HW)) ? 1 : 0;
 }
-int cot_conv1x1_forward_gn9(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, float* stats,
-                            int N, int Ci, int Co, int HW, int dtype, void* stream) {
+int cot_conv1x1_forward_stats(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, float* stats,
+                              int N, int Ci, int Co, int HW, int dtype, void* stream) {
     int rc = conv1x1_validate(N, Ci, Co, HW, c1, x2 != nullptr, dtype, Ci);
     if (rc) return rc;
     if (!x1 || !weight || !y || !stats) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({x1, x2, weight, y, stats}))) return rc;
-    if (dtype != COT_BF16 || Co % 9 != 0)
-        return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_forward_gn9: COT_BF16, output channels a multiple of 9 (Co = %d)", Co);
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_forward_stats: COT_BF16 only");
+    if (!cot_conv1x1_stats_covers(Ci, c1, x2 != nullptr, HW))
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_forward_stats: geometry not covered (cot_conv1x1_stats_covers)");
     const bool p = prof::enabled();
     if (p) prof::mark();
     rc = conv1x1_lds_gemm(x1, x2, c1, weight, 0, bias, y, nullptr, Co, N, Ci, Co, HW, 0, (hipStream_t)stream, 0, 0, stats);
     if (p) prof::annotate_op(10, N, Ci, Co, HW, 1, dtype, 0);
-    if (rc == -1) return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_forward_gn9: geometry not covered (cot_gn9_fused_covers)");
+    if (rc == -1) return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_forward_stats: geometry not covered (cot_conv1x1_stats_covers)");
     return rc;
+}
+int cot_conv1x1_stats_covers(int Ci, int c1, int two_slabs, int HW) {
+    return (HW > 256 && HW % 8 == 0 && conv1x1_lds_covers(Ci, c1, two_slabs != 0, HW)) ? 1 : 0;
+}
+int cot_conv1x1_forward_gn9(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, float* stats,
+                            int N, int Ci, int Co, int HW, int dtype, void* stream) {
+    if (Co % 9 != 0) return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_forward_gn9: output channels a multiple of 9 (Co = %d)", Co);
+    return cot_conv1x1_forward_stats(x1, x2, c1, weight, bias, y, stats, N, Ci, Co, HW, dtype, stream);
+}
+int cot_bn_tile_stats_finalize(const float* stats, float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, int N, int C, int HW, float eps, float momentum, void* stream) {
+    if (N <= 0 || C <= 0 || HW <= 0) return set_error(COT_ERR_INVALID_ARG, "bad geometry N=%d C=%d HW=%d", N, C, HW);
+    if (!stats || !save_mean || !save_rstd) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((running_mean == NULL) != (running_var == NULL))
+        return set_error(COT_ERR_INVALID_ARG, "running_mean and running_var must be given together");
+    return bn_tile_stats(stats, N, C, HW, eps, momentum, save_mean, save_rstd, running_mean, running_var, (long long*)num_batches_tracked,
+                         (hipStream_t)stream);
 }
 int cot_gn9_stats_finalize(const float* stats, float* mean, float* rstd, int N, int C, int HW, float eps, void* stream) {
     if (N <= 0 || C <= 0 || HW <= 0 || C % 9 != 0) return set_error(COT_ERR_INVALID_ARG, "bad geometry N=%d C=%d HW=%d", N, C, HW);
@@ -1388,6 +1413,23 @@ int cot_bn_act_backward_mask(const void* dy, const void* x, const void* relu_mas
     const int rc = cot_bn_act_backward_ps_impl(dy, x, /*y=*/relu_mask, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
                                                workspace, sample_scale, N, C, HW, act, dtype, stream);
     if (p) prof::annotate_op(21, N, C, C, HW, 1, dtype, (dresidual ? 1 : 0));  // (no saved-output read: the mask is 1/16 of it)
+    return rc;
+}
+
+int cot_bn_act_apply_forward(const void* x, const void* residual, void* y, void* relu_mask, const float* gamma, const float* beta,
+                             const float* mean, const float* rstd, int N, int C, int HW, int act, int dtype, void* stream) {
+    if (!x || !y || !gamma || !beta || !mean || !rstd) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW/act");
+    if (dtype != COT_BF16 || HW % 8 != 0) return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_apply_forward: COT_BF16, planes of a multiple of 8 pixels");
+    if (relu_mask && (act != 1 || cot_bn_relu_mask_bytes(N, C, HW, dtype) == 0))
+        return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_apply_forward: a sign mask needs ReLU and a geometry cot_bn_relu_mask_bytes accepts");
+    int rc = check_align16({x, residual, y});
+    if (rc) return rc;
+    BnMaskScope scope((uint8_t*)relu_mask);
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    rc = bn_apply_forward(x, residual, y, gamma, beta, mean, rstd, N, C, HW, act, (hipStream_t)stream);
+    if (p) prof::annotate_op(20, N, C, C, HW, 1, dtype, (residual ? 1 : 0) | 8);
     return rc;
 }
 

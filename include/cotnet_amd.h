@@ -170,6 +170,8 @@ const char* cot_last_kernel(void);
  *   key 38: (A/B builds only) weight-tile ring of the per-step form of the LDS-staged 3x3 kernel
  *   key 46: 1x1 forward / data gradient on 128-pixel tiles (planes of more than 256 pixels, i.e. also the channel-major rows of the
  *           deep stages): output-channel blocks of 64 / 32 instead of 128 while the launch has fewer workgroups than `value` (200 default, 0 = off)
+ *   key 47: channel-resident BatchNorm: instances unrolled for 2 / 4 rounds where they cover the channel (1 default), 0 = always the
+ *           full-capacity instance
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
  *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
  *           ring everywhere
@@ -488,6 +490,22 @@ int cot_group_norm9_forward_lay(const void* x, const void* gamma, const void* be
 int cot_group_norm9_backward_lay(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma,
                                  void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int lay, int dtype,
                                  void* stream);
+/* ---- BatchNorm statistics out of the producing convolution's epilogue (models/cotnet.py:51-62, :228-264: every
+ * conv1x1 -> BatchNorm pair of a Bottleneck).  On planes of more than 256 pixels (the 56 x 56 / 28 x 28 stages) the 1x1 kernels
+ * can write, per (image, 128-pixel tile, channel), the sum and the sum of squares of the bf16 values they store:
+ *   cot_conv1x1_forward_stats   = cot_conv1x1_forward that also fills `stats` (cot_gn9_stats_floats(N, Co, HW) floats); covered
+ *                                 where cot_conv1x1_stats_covers(Ci, c1, two_slabs, HW) == 1 (cot_conv1x1_forward_gn9 is this call)
+ *   cot_bn_tile_stats_finalize  -> the channels' batch mean / rstd (fp64 sums in a fixed order) + the running-statistics update of
+ *                                 nn.BatchNorm2d; replaces the statistics pass over the tensor
+ *   cot_bn_act_apply_forward    y = act(gamma * (x - mean_c) * rstd_c + beta [+ residual]) from those statistics, optionally with
+ *                                 the ReLU sign mask of cot_bn_act_forward_mask.  The backward is cot_bn_act_backward[_mask]. */
+int cot_conv1x1_stats_covers(int Ci, int c1, int two_slabs, int HW);
+int cot_conv1x1_forward_stats(const void* x1, const void* x2, int c1, const void* weight, const void* bias, void* y, float* stats,
+                              int N, int Ci, int Co, int HW, int dtype, void* stream);
+int cot_bn_tile_stats_finalize(const float* stats, float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, int N, int C, int HW, float eps, float momentum, void* stream);
+int cot_bn_act_apply_forward(const void* x, const void* residual, void* y, void* relu_mask, const float* gamma, const float* beta,
+                             const float* mean, const float* rstd, int N, int C, int HW, int act, int dtype, void* stream);
 /* inference mode (nn.BatchNorm2d.eval()): y = act(gamma*(x - running_mean)/sqrt(running_var + eps) + beta [+ residual]) in one
  * pass; nothing is updated. */
 int cot_bn_act_inference(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
