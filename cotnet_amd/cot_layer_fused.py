@@ -342,6 +342,40 @@ def _bn_fwd(L, x, y, bn, stats, nws_off, N, C, HW, act, residual=None, ps=None, 
                              N, C, HW, float(bn.eps), float(bn.momentum), act, BF16, _stream()), "cot_bn_act_forward")
 
 
+# BatchNorm statistics out of the producing 1x1 convolution's epilogue (SURVEY 7.6 / DESIGN 4.9c; COT_BN_EPILOGUE=0 opts out): on
+# planes of more than 256 pixels the convolution also writes per-tile sums of what it stores, a one-wave-per-channel finalize turns
+# them into mean / rstd (+ running statistics), and the flat apply kernel normalises -- the statistics pass over the tensor is gone
+BN_EPILOGUE = os.environ.get("COT_BN_EPILOGUE", "1") != "0"
+_EPI_OK = _lib.register_cache({})
+
+
+def _epi_ok(L, Ci, c1, two, HW):
+    k = (Ci, c1, two, HW)
+    v = _EPI_OK.get(k)
+    if v is None:
+        v = _EPI_OK[k] = bool(L.cot_conv1x1_stats_covers(Ci, c1, 1 if two else 0, HW))
+    return v
+
+
+def _conv_bn_fwd(L, x1, x2, c1, conv, y_pre, y, bn, stats, nws_off, N, Ci, Co, HW, act, residual=None, ps=None, mask=None):
+    """y_pre = conv1x1([x1 | x2]); y = act(bn(y_pre) [+ residual]) -- the models' conv -> BatchNorm pairs (models/cotnet.py:51-62,
+    :228-264).  stats: fp32 [2*Co + workspace] as for _bn_fwd."""
+    st = _stream()
+    bias = conv.bias
+    if BN_EPILOGUE and ps is None and _epi_ok(L, Ci, c1, x2 is not None, HW):
+        part = torch.empty(int(L.cot_gn9_stats_floats(N, Co, HW)), dtype=torch.float32, device=y.device)
+        _ck(L.cot_conv1x1_forward_stats(_p(x1), _p(x2), c1, _p(conv.weight), _p(bias), _p(y_pre), _p(part), N, Ci, Co, HW, BF16, st),
+            "cot_conv1x1_forward_stats")
+        _ck(L.cot_bn_tile_stats_finalize(_p(part), _p(stats), _p(stats[Co:]), _p(bn.running_mean), _p(bn.running_var),
+                                         _p(bn.num_batches_tracked), N, Co, HW, float(bn.eps), float(bn.momentum), st),
+            "cot_bn_tile_stats_finalize")
+        _ck(L.cot_bn_act_apply_forward(_p(y_pre), _p(residual), _p(y), _p(mask), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[Co:]),
+                                       N, Co, HW, act, BF16, st), "cot_bn_act_apply_forward")
+        return
+    _ck(L.cot_conv1x1_forward(_p(x1), _p(x2), c1, _p(conv.weight), _p(bias), _p(y_pre), N, Ci, Co, HW, BF16, st), "cot_conv1x1_forward")
+    _bn_fwd(L, y_pre, y, bn, stats, nws_off, N, Co, HW, act, residual=residual, ps=ps, mask=mask)
+
+
 def _bn_bwd(L, dy, x, y, dx, bn, stats, N, C, HW, act, nws, dres=None, ps=None, mask=None):
     """-> (dgamma, dbeta): the parameters' slots in the flat gradient buckets when registered (grad_sink), else fresh.
     mask: the sign mask the forward wrote (then `y` is not read)"""
@@ -430,11 +464,11 @@ def _cot_forward(L, layer, x):
     if GX:  # CoXtLayer: [x0, k0, x1, k1, ...] so that each of the two groups sees matching halves of x and k (ref :153-154)
         qk = torch.stack([x, k], dim=2).view(N, 2 * C, H, W)
         _ck(L.cot_conv1x1g_forward(_p(qk), _p(pl.em0.weight), None, _p(e0), N, 2 * C, Ch, 2, HW, BF16, st), "cot_conv1x1g_forward")
-    else:
-        _ck(L.cot_conv1x1_forward(_p(x), _p(k), C, _p(pl.em0.weight), None, _p(e0), N, 2 * C, Ch, HW, BF16, st),
-            "cot_conv1x1_forward")
     s_e = stat(Ch, nws_h)
-    _bn_fwd(L, e0, e1, pl.em1, s_e, 2 * Ch, N, Ch, HW, 1)
+    if GX:
+        _bn_fwd(L, e0, e1, pl.em1, s_e, 2 * Ch, N, Ch, HW, 1)
+    else:
+        _conv_bn_fwd(L, x, k, C, pl.em0, e0, e1, pl.em1, s_e, 2 * Ch, N, 2 * C, Ch, HW, 1)
     e3 = new(Ce)
     gn = pl.gn
     # GroupNorm of the logits fused into its neighbours: statistics out of embed[3]'s epilogue, normalisation in the
@@ -467,11 +501,11 @@ def _cot_forward(L, layer, x):
     v_pre, v = new(C), new(C)
     if GX:
         _ck(L.cot_conv1x1g_forward(_p(x), _p(pl.cv0.weight), None, _p(v_pre), N, C, C, 2, HW, BF16, st), "cot_conv1x1g_forward")
-    else:
-        _ck(L.cot_conv1x1_forward(_p(x), None, C, _p(pl.cv0.weight), None, _p(v_pre), N, C, C, HW, BF16, st),
-            "cot_conv1x1_forward")
     s_v = stat(C, nws_c)
-    _bn_fwd(L, v_pre, v, pl.cv1, s_v, 2 * C, N, C, HW, 0)
+    if GX:
+        _bn_fwd(L, v_pre, v, pl.cv1, s_v, 2 * C, N, C, HW, 0)
+    else:
+        _conv_bn_fwd(L, x, None, C, pl.cv0, v_pre, v, pl.cv1, s_v, 2 * C, N, C, C, HW, 0)
     # local aggregation, bn + swish                                                              (ref :88-90)
     # (CoXtLayer folds its two groups into the batch: [N, C] -> [2N, C/2], weights [2N, 1, C/16, 9]: views of the same memory)
     geom = _lib.AggGeom(2 * N, C // 2, H, W, 1, C // 16, 3, 3, 1, 1, 1, 1, 1, 1) if GX else \
@@ -754,10 +788,8 @@ class _BottleneckNode(Function):
         stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
         # (the CoT layer's input -- a1, or its pooled version -- is what the grouped 3x3 weight gradient reads shifted: margins)
         c1, a1 = new(Cw, H, W), (new(Cw, H, W) if bp.avd else _new_guarded(N, Cw, H, W, x.dtype, dev))
-        _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(bp.conv1.weight), None, _p(c1), N, Cin, Cw, HW, BF16, st),
-            "cot_conv1x1_forward")
         s_1 = stat(Cw, nws_w)
-        _bn_fwd(L, c1, a1, bp.bn1, s_1, 2 * Cw, N, Cw, HW, 1)
+        _conv_bn_fwd(L, x, None, Cin, bp.conv1, c1, a1, bp.bn1, s_1, 2 * Cw, N, Cin, Cw, HW, 1)
         if bp.avd:
             p1 = _new_guarded(N, Cw, Ho, Wo, x.dtype, dev)
             _ck(L.cot_avgpool3x3s2_forward(_p(a1), _p(p1), N * Cw, H, W, BF16, st), "cot_avgpool3x3s2_forward")
@@ -765,8 +797,6 @@ class _BottleneckNode(Function):
             p1 = a1
         cot_out, saved, geom = _cot_forward(L, bp.cot, p1)
         c3, y = new(Cout, Ho, Wo), new(Cout, Ho, Wo)
-        _ck(L.cot_conv1x1_forward(_p(cot_out), None, Cw, _p(bp.conv3.weight), None, _p(c3), N, Cw, Cout, HWo, BF16, st),
-            "cot_conv1x1_forward")
         if bp.ds_conv is not None:  # projection shortcut: bn(conv1x1(x)), on every second pixel in a stride-2 block
             if bp.ds_stride == 2 and H % 2 == 0 and W % 2 == 0:  # every second pixel: one pass, 16-byte accesses (pool3x3.hip)
                 xs = torch.empty((N, Cin, H // 2, W // 2), dtype=x.dtype, device=dev)
@@ -774,16 +804,14 @@ class _BottleneckNode(Function):
             else:
                 xs = x[:, :, ::2, ::2].contiguous() if bp.ds_stride == 2 else x
             d0, res = new(Cout, Ho, Wo), new(Cout, Ho, Wo)
-            _ck(L.cot_conv1x1_forward(_p(xs), None, Cin, _p(bp.ds_conv.weight), None, _p(d0), N, Cin, Cout, HWo, BF16,
-                                      st), "cot_conv1x1_forward")
             s_d = stat(Cout, nws_o)
-            _bn_fwd(L, d0, res, bp.ds_bn, s_d, 2 * Cout, N, Cout, HWo, 0)
+            _conv_bn_fwd(L, xs, None, Cin, bp.ds_conv, d0, res, bp.ds_bn, s_d, 2 * Cout, N, Cin, Cout, HWo, 0)
         else:
             xs, d0, res, s_d = None, None, x, None
         s_3 = stat(Cout, nws_o)
         ps = _drop_path_scale(blk, N, dev)  # stochastic depth: per-sample 0 or 1 / keep on the normalised branch
         m3 = _relu_mask(L, N, Cout, HWo, dev)
-        _bn_fwd(L, c3, y, bp.bn3, s_3, 2 * Cout, N, Cout, HWo, 1, residual=res, ps=ps, mask=m3)
+        _conv_bn_fwd(L, cot_out, None, Cw, bp.conv3, c3, y, bp.bn3, s_3, 2 * Cout, N, Cw, Cout, HWo, 1, residual=res, ps=ps, mask=m3)
         ctx.blk, ctx.geom, ctx.has_ds, ctx.has_ps, ctx.has_mask = blk, geom, bp.ds_conv is not None, ps is not None, m3 is not None
         extra = (x, c1, a1, s_1, cot_out, c3, y, s_3) + ((d0, s_d, xs) if bp.ds_conv is not None else ()) + \
             ((m3,) if m3 is not None else ()) + ((ps,) if ps is not None else ())
