@@ -125,45 +125,4 @@ def test_channel_major_bottlenecks_against_the_nchw_single_node(H, blocks, monke
 
 @pytest.mark.parametrize("N,Ci,Co,HW,act,res,mask", [(3, 64, 64, 784, 1, False, False), (2, 64, 256, 3136, 1, True, True), (2, 128, 32, 784, 0, False, False)])
 def test_batchnorm_statistics_from_the_convolution_epilogue(N, Ci, Co, HW, act, res, mask):
-    """conv1x1 -> BatchNorm with the statistics out of the convolution's epilogue (cot_conv1x1_forward_stats + cot_bn_tile_stats_finalize +
-    cot_bn_act_apply_forward; models/cotnet.py:59-62, :248-262) against the separate pair (cot_conv1x1_forward + cot_bn_act_forward[_mask]):
-    the same convolution output bit for bit, statistics equal to fp32 rounding (fp64 sums of the stored values vs the two-pass fp32
-    form), outputs within one bf16 rounding, identical sign masks wherever the outputs agree"""
-    import torch
-    L, P, BF = _EMUL, lc.P, lc.BF
-    torch.manual_seed(N + Ci + Co)
-    x = torch.randn(N, Ci, HW).bfloat16()
-    w = (torch.randn(Co, Ci) / Ci ** 0.5).bfloat16()
-    r = torch.randn(N, Co, HW).bfloat16() if res else None
-    gamma, beta = torch.rand(Co) + 0.5, torch.randn(Co) * 0.2
-    assert L.cot_conv1x1_stats_covers(Ci, Ci, 0, HW) == 1 and L.cot_conv1x1_stats_covers(Ci, Ci, 0, 196) == 0
-    part = torch.full((int(L.cot_gn9_stats_floats(N, Co, HW)),), float("nan"))
-    y0, y1 = torch.full((N, Co, HW), float("nan")).bfloat16(), torch.full((N, Co, HW), float("nan")).bfloat16()
-    assert L.cot_conv1x1_forward_stats(P(x), None, Ci, P(w), None, P(y0), P(part), N, Ci, Co, HW, BF, None) == 0, L.cot_last_error()
-    assert L.cot_conv1x1_forward(P(x), None, Ci, P(w), None, P(y1), N, Ci, Co, HW, BF, None) == 0
-    assert torch.equal(y0, y1) and torch.isfinite(part).all()
-    mean, rstd, rm, rv = torch.empty(Co), torch.empty(Co), torch.zeros(Co), torch.ones(Co)
-    nbt = torch.zeros((), dtype=torch.int64)
-    assert L.cot_bn_tile_stats_finalize(P(part), P(mean), P(rstd), P(rm), P(rv), P(nbt), N, Co, HW, 1e-5, 0.1, None) == 0
-    z = torch.full_like(y0, float("nan"))
-    mk = torch.zeros(int(L.cot_bn_relu_mask_bytes(N, Co, HW, BF)), dtype=torch.uint8) if mask else None
-    assert L.cot_bn_act_apply_forward(P(y0), P(r) if res else None, P(z), P(mk) if mask else None, P(gamma), P(beta), P(mean), P(rstd), N, Co,
-                                      HW, act, BF, None) == 0, L.cot_last_error()
-    m2, r2, rm2, rv2 = torch.empty(Co), torch.empty(Co), torch.zeros(Co), torch.ones(Co)
-    nbt2 = torch.zeros((), dtype=torch.int64)
-    ws = torch.empty(max(1, int(L.cot_bn_act_workspace(N, Co))))
-    z2 = torch.full_like(y0, float("nan"))
-    mk2 = torch.zeros_like(mk) if mask else None
-    if mask:
-        assert L.cot_bn_act_forward_mask(P(y0), P(r), P(z2), P(mk2), P(gamma), P(beta), P(m2), P(r2), P(rm2), P(rv2), P(nbt2), P(ws), None, N,
-                                         Co, HW, 1e-5, 0.1, act, BF, None) == 0, L.cot_last_error()
-    else:
-        assert L.cot_bn_act_forward(P(y0), P(r) if res else None, P(z2), P(gamma), P(beta), P(m2), P(r2), P(rm2), P(rv2), P(nbt2), P(ws), N, Co,
-                                    HW, 1e-5, 0.1, act, BF, None) == 0, L.cot_last_error()
-    assert torch.allclose(mean, m2, atol=1e-6, rtol=1e-5) and torch.allclose(rstd, r2, atol=0, rtol=2e-5)
-    assert torch.allclose(rm, rm2, atol=1e-6, rtol=1e-5) and torch.allclose(rv, rv2, atol=1e-6, rtol=2e-5) and int(nbt) == 1
-    d = (z.float() - z2.float()).abs()
-    assert (d <= 2.0 ** -7 * z2.float().abs() + 1e-6).all() and (d > 0).float().mean() < 0.02
-    if mask:
-        same = (z == z2).view(-1, 8).all(1)
-        assert torch.equal(mk[same], mk2[same])
+    lc.bn_epilogue_case(_EMUL, "cpu", None, N, Ci, Co, HW, act, res, mask)

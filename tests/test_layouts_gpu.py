@@ -37,3 +37,10 @@ def test_radix_tail_layouts(C, HW):
 @pytest.mark.parametrize("G,HW", [(32, 196), (64, 49)])
 def test_group_norm9_layouts(G, HW):
     lc.gn9_case(_lib.lib(), "cuda", _st(), B, G, HW)
+
+
+@pytest.mark.parametrize("Ci,Co,HW,act,res,mask", [(256, 64, 3136, 1, False, False), (64, 256, 3136, 1, True, True), (128, 32, 3136, 1, False, False),
+                                                   (64, 64, 3136, 0, False, False), (128, 512, 784, 1, True, True)])
+def test_batchnorm_statistics_from_the_convolution_epilogue(Ci, Co, HW, act, res, mask):
+    """the conv1x1 -> BatchNorm pairs of the 56 x 56 stage (and a 28 x 28 one) at the benchmark batch"""
+    lc.bn_epilogue_case(_lib.lib(), "cuda", _st(), B, Ci, Co, HW, act, res, mask)
