@@ -825,7 +825,7 @@ def main():
     torch.cuda.synchronize()
     n_blocks = sum(1 for m in model.modules() if type(m).__name__ in ("Bottleneck", "CoTBottleneck"))
     nodes_per_step = dict(_clf0.NODE_COUNTS, residual_blocks=n_blocks)
-    nodes_per_step["single_node_blocks"] = (f"{nodes_per_step['bottleneck'] + nodes_per_step['bottleneck_channel_major'] + nodes_per_step['split_attn_block']}"
+    nodes_per_step["single_node_blocks"] = (f"{nodes_per_step['bottleneck'] + nodes_per_step['bottleneck_channel_major'] + nodes_per_step['split_attn_block'] + nodes_per_step['bottleneck_eval']}"
                                             f"/{n_blocks}")
     recs, timing_steps = [], 0
     if not args.no_kernel_timing:

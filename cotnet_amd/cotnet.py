@@ -221,6 +221,8 @@ class Bottleneck(nn.Module):
         nn.init.zeros_(self.bn3.weight)
 
     def forward(self, x):
+        if cot_layer_fused.ENABLED and not self.training and cot_layer_fused.eval_block_eligible(self, x):
+            return cot_layer_fused.eval_block_forward(self, x)  # inference: the block's launches back to back, nothing kept
         if cot_layer_fused.ENABLED and cot_layer_fused.cm_block_eligible(self, x):
             return cot_layer_fused.cm_block_forward(self, x)  # deep-stage identity block: one node, 1x1 operands channel-major
         if cot_layer_fused.ENABLED and cot_layer_fused.block_eligible(self, x):

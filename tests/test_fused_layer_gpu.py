@@ -215,3 +215,37 @@ def test_channel_major_deep_stage_blocks_against_fp32_truth(N, planes, H, blocks
     assert truth.err(yc, yb) < 2e-2 and truth.err(gxc, gxb) < 8e-2
     for (n_, a), (_, b) in zip(mc.named_buffers(), mb.named_buffers()):
         assert torch.allclose(a.float(), b.float(), atol=2e-3, rtol=2e-3), n_
+
+
+@pytest.mark.parametrize("kind,N,hw", [("identity", 80, 14), ("identity", 80, 7), ("stride2", 16, 28), ("project", 16, 56)])
+def test_eval_mode_bottleneck_single_call_sequence_against_fp32(kind, N, hw):
+    """BASELINE config 2 (forward only, eval mode): cot_layer_fused.eval_block_forward no further from an fp32 evaluation of the same
+    block (running statistics) than the module path is"""
+    from cotnet_amd.resnet import downsample_conv
+    torch.manual_seed(5 + hw)
+    stride = 2 if kind == "stride2" else 1
+    planes = {14: 256, 7: 512}.get(hw, 64) if kind == "identity" else 64
+    inpl = 4 * planes if kind == "identity" else 2 * planes
+    ds = None if kind == "identity" else downsample_conv(inpl, 4 * planes, 1, stride=stride)
+    blk = Bottleneck(inpl, planes, stride=stride, downsample=ds).to(DEV)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    blk = to_mixed_bf16(blk).eval()
+    x = torch.randn(N, inpl, hw, hw, device=DEV).bfloat16()
+    with torch.no_grad():
+        with truth.switches(**truth.PLAIN):
+            yt = copy.deepcopy(blk).float()(x.float())
+        with truth.switches(**truth.ALL_HIP):
+            yb = blk(x).float()
+        with truth.switches(**truth.SINGLE_NODE):
+            assert clf.eval_block_eligible(blk, x)
+            clf.reset_node_counts()
+            yc = blk(x).float()
+            assert clf.NODE_COUNTS["bottleneck_eval"] == 1
+    torch.cuda.synchronize()
+    assert truth.err(yc, yt) <= 1.5 * truth.err(yb, yt) + 2e-3, (truth.err(yc, yt), truth.err(yb, yt))

@@ -126,3 +126,51 @@ def test_channel_major_bottlenecks_against_the_nchw_single_node(H, blocks, monke
 @pytest.mark.parametrize("N,Ci,Co,HW,act,res,mask", [(3, 64, 64, 784, 1, False, False), (2, 64, 256, 3136, 1, True, True), (2, 128, 32, 784, 0, False, False)])
 def test_batchnorm_statistics_from_the_convolution_epilogue(N, Ci, Co, HW, act, res, mask):
     lc.bn_epilogue_case(_EMUL, "cpu", None, N, Ci, Co, HW, act, res, mask)
+
+
+@pytest.mark.parametrize("kind,H", [("identity", 6), ("stride2", 12), ("project", 28)])
+def test_eval_mode_bottleneck_as_one_call_sequence(kind, H, monkeypatch):
+    """inference (BASELINE config 2): cot_layer_fused.eval_block_forward -- the block's kernels back to back on the running statistics,
+    autograd off -- against the module's ordinary eval forward (node per op, same emulated kernels where they are hand-written)"""
+    import copy
+
+    import torch
+
+    import cotnet_amd.aggregation_zeropad as az
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, pool3x3 as p3, radix_tail
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    from cotnet_amd.resnet import downsample_conv
+    from tests.test_kernels_emulated import _EmulAggregation
+    torch.manual_seed(21 + H)
+    stride = 2 if kind == "stride2" else 1
+    inpl = 256 if kind == "identity" else 128
+    ds = None if kind == "identity" else downsample_conv(inpl, 256, 1, stride=stride)
+    blk = Bottleneck(inpl, 64, stride=stride, downsample=ds)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    blk = to_mixed_bf16(blk).eval()
+    x = torch.randn(2, inpl, H, H).bfloat16()
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail, p3):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(az, "aggregation_zeropad", lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
+    for cache in (clf._SIZES, clf._MASKS, clf._BSIZES):
+        cache.clear()
+    with torch.no_grad():
+        monkeypatch.setattr(clf, "ENABLED", False)
+        ref = copy.deepcopy(blk)(x).float()
+        monkeypatch.setattr(clf, "ENABLED", True)
+        assert clf.eval_block_eligible(blk, x)
+        clf.reset_node_counts()
+        y = blk(x)
+        assert clf.NODE_COUNTS["bottleneck_eval"] == 1 and y.grad_fn is None
+    assert not clf.eval_block_eligible(blk, x)  # (autograd on again: the ordinary path)
+    assert ((y.float() - ref).abs() <= 2e-2 * (ref.abs() + ref.abs().mean())).all(), (y.float() - ref).abs().max()
+    for cache in (clf._SIZES, clf._MASKS, clf._BSIZES):
+        cache.clear()
