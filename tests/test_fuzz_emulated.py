@@ -642,6 +642,7 @@ def case_optimizer_and_input(rng):
     return ok and torch.equal(y, ref), ("input normalise", shape, str(dtype))
 
 
+CASES = [case_conv1x1, case_conv1x1, case_conv3x3, case_conv3x3_guarded, case_group_norm, case_pooling, case_subsample]
 CASES_R4 = [case_conv3x3_lds, case_conv3x3_lds, case_bn, case_bn, case_stem, case_pool2, case_conv1x1_stages, case_agg_gn9, case_bn_ps, case_aggregation, case_aggregation, case_conv_general, case_conv_general, case_elementwise, case_optimizer_and_input]
 
 
