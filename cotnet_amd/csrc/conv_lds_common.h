@@ -182,26 +182,37 @@ __device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], cons
     }
     COT_LDS_BARRIER();
     if (!FLAT && a.stats) {
-        // one wave per channel row of the tile image in LDS: 2 columns per lane and round, fp32 sums over <= BPX values, wave
-        // reduction in a fixed order (deterministic); columns past the tile's end count as nothing
+        // per (tile, channel) the sum and the sum of squares of the ROUNDED values, from the tile image in LDS.  TPR consecutive lanes
+        // share a channel row and take interleaved column pairs (pair q + TPR * j: one 4-byte read each; a wave's 64 lanes then touch 64
+        // different banks), add up in a fixed order and meet in log2(TPR) exchanges.  (Round 4's form -- one wave per row, a 6-step
+        // exchange per row, 16 rows per wave one after the other -- cost the BIG launches ~20 us each: profiles/r05_bn_epilogue_stats_ab.log)
+        constexpr int BM = 16 * MB;
+        constexpr int TPR = NT >= 16 * BM ? 16 : (NT >= 8 * BM ? 8 : (NT >= 4 * BM ? 4 : (NT >= 2 * BM ? 2 : 1)));  // lanes per row: 4 / 8 / 16 (1x1 tiles)
+        constexpr int RPP = NT / TPR;                                                                             // rows per pass
+        const int q = tid % TPR;
         float* const srow = a.stats + (((int64_t)n0 * a.ptiles + p0 / BPX) * M + m0) * 2;
-        for (int r = wave; r < mv; r += WAVES) {
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int c0 = 0; c0 < BPX; c0 += 128) {
-                const int c = c0 + 2 * lane;
-                if (c < ncols) {  // (ncols % 8 == 0: a lane's two columns are valid together)
-                    const float v0 = (float)ot[r * OS + c], v1 = (float)ot[r * OS + c + 1];
-                    s1 += v0 + v1;
-                    s2 += v0 * v0 + v1 * v1;
+        for (int r0 = 0; r0 < BM; r0 += RPP) {
+            const int r = r0 + tid / TPR;
+            float s1 = 0.f, s2 = 0.f;
+            if (r < mv) {
+#pragma unroll
+                for (int j = 0; j < (BPX / 2 + TPR - 1) / TPR; ++j) {
+                    const int c = 2 * (q + TPR * j);
+                    if (c < ncols) {  // (ncols % 8 == 0: a pair is valid as a whole)
+                        const uint32_t u = *reinterpret_cast<const uint32_t*>(ot + r * OS + c);
+                        const float v0 = __builtin_bit_cast(float, u << 16), v1 = __builtin_bit_cast(float, u & 0xffff0000u);
+                        s1 += v0 + v1;
+                        s2 += v0 * v0 + v1 * v1;
+                    }
                 }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
+            for (int o = TPR >> 1; o > 0; o >>= 1) {
                 s1 += __shfl_xor(s1, o);
                 s2 += __shfl_xor(s2, o);
             }
-            if (lane == 0) {
+            if (q == 0 && r < mv) {
                 srow[2 * r] = s1;
                 srow[2 * r + 1] = s2;
             }
