@@ -922,6 +922,11 @@ int bn_act_forward(const void* x, const void* res, void* y, const float* gamma, 
                    float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW, float eps,
                    float mom, int act, const float* ps, hipStream_t s) {
 #define BN_F(VV) return bn_fwd_launch<T, VV>((const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, ws, N, C, HW, eps, mom, act, ps, s)
+    // a sign mask is one byte per EIGHT elements: only the 8-element instances write / read it.  bn_relu_mask_bytes() hands out a
+    // mask size exactly for the geometries that take them; a call that reaches another instance with a mask set must not run
+    // (forward: the backward would read a mask nobody wrote; backward: the mask pointer stands in for y and a kernel that reads y
+    // would walk 16 times the mask's size -- ADVICE r4)
+    if (t_bn_mask && (sizeof(T) != 2 || pick_vec(sizeof(T), HW) != 8 || (int64_t)N * HW <= g_bn_small_m)) return -3;
     if ((int64_t)N * HW <= g_bn_small_m && !ps) {
         const dim3 grid(C), block(64);  // one wave per channel
 #define BN_SF(A_) COT_LAUNCH((bn_small_fwd<T, A_>), grid, block, 0, s, (const T*)x, (const T*)res, (T*)y, gamma, beta, mean, rstd, rmean, rvar, nbt, N, C, HW, eps, mom)
@@ -970,6 +975,7 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
                     const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ws,
                     int N, int C, int HW, int act, const float* ps, hipStream_t s) {
 #define BN_B(VV) return bn_bwd_launch<T, VV>((const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, ws, N, C, HW, act, ps, s)
+    if (t_bn_mask && (sizeof(T) != 2 || pick_vec(sizeof(T), HW) != 8 || (int64_t)N * HW <= g_bn_small_m)) return -3;  // (see bn_act_forward)
     if ((int64_t)N * HW <= g_bn_small_m && !ps) {
         const dim3 grid(C), block(64);  // one wave per channel
 #define BN_SB(A_) COT_LAUNCH((bn_small_bwd<T, A_>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, rstd, dgamma, dbeta, N, C, HW)

@@ -1397,8 +1397,10 @@ int cot_bn_act_forward_mask(const void* x, const void* residual, void* y, void* 
     if (act != 1 || cot_bn_relu_mask_bytes(N, C, HW, dtype) == 0)
         return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_forward_mask: ReLU, and a geometry cot_bn_relu_mask_bytes accepts");
     BnMaskScope scope((uint8_t*)relu_mask);
-    return cot_bn_act_forward_ps(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var, num_batches_tracked,
-                                 workspace, sample_scale, N, C, HW, eps, momentum, act, dtype, stream);
+    const int rc = cot_bn_act_forward_ps(x, residual, y, gamma, beta, save_mean, save_rstd, running_mean, running_var, num_batches_tracked,
+                                         workspace, sample_scale, N, C, HW, eps, momentum, act, dtype, stream);
+    if (rc == -3) return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_forward_mask: the kernel serving N=%d C=%d HW=%d cannot write a sign mask", N, C, HW);
+    return rc;
 }
 int cot_bn_act_backward_mask(const void* dy, const void* x, const void* relu_mask, void* dx, void* dresidual, const float* gamma,
                              const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
@@ -1413,6 +1415,7 @@ int cot_bn_act_backward_mask(const void* dy, const void* x, const void* relu_mas
     const int rc = cot_bn_act_backward_ps_impl(dy, x, /*y=*/relu_mask, dx, dresidual, gamma, beta, save_mean, save_rstd, dgamma, dbeta,
                                                workspace, sample_scale, N, C, HW, act, dtype, stream);
     if (p) prof::annotate_op(21, N, C, C, HW, 1, dtype, (dresidual ? 1 : 0));  // (no saved-output read: the mask is 1/16 of it)
+    if (rc == -3) return set_error(COT_ERR_UNSUPPORTED, "cot_bn_act_backward_mask: the kernel serving N=%d C=%d HW=%d cannot read a sign mask", N, C, HW);
     return rc;
 }
 

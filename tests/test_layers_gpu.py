@@ -90,6 +90,7 @@ def test_layer_matches_reference_fixture_at_the_real_stage_geometries(name, path
     meta, layer, x, gout = real_layer_case(gold)
     layer = layer.to(DEV)
     state = {k: v.clone() for k, v in layer.state_dict().items()}
+    vendor_defect = None
     with truth.switches(fused_layer=False, **sw):
         for mode in ("eval", "train"):
             layer.load_state_dict(state)
@@ -98,14 +99,23 @@ def test_layer_matches_reference_fixture_at_the_real_stage_geometries(name, path
             xin = x.to(DEV).requires_grad_(True)
             y = layer(xin)
             y.backward(gout.to(DEV))
-            # MIOpen's fp32 grouped 3x3 backward-data (groups 8, 24 channels per group, 28 x 28) is 1.2 % off in the eval-mode
-            # graph of this one fixture (profiles/r04_diag_coxt_s2_miopen_grouped3x3_eval.log: every combination with the
-            # LIBRARY's 3x3 kernel is at 2e-6, every one with MIOpen's at 5e-2, deterministic or not) -- the developer
-            # baseline's defect, not the product path's: that path gets the bar it can meet, `nchw-hip-convs` keeps 1e-3
-            loose = path == "nchw" and name == "layer_coxtlayer_s2_192x28" and mode == "eval"
-            check_real_layer(gold, mode, layer, y, xin.grad, tol=2e-2 if loose else 1e-3)
+            # BASELINE's 1e-3 everywhere.  One known offender of the DEVELOPER baseline path: MIOpen's fp32 grouped 3x3 backward-data
+            # (groups 8, 24 channels per group, 28 x 28) is 1.2 % off in the eval-mode graph of this one fixture
+            # (profiles/r04_diag_coxt_s2_miopen_grouped3x3_eval.log: every combination with the LIBRARY's 3x3 kernel is at 2e-6, every
+            # one with MIOpen's at 5e-2, deterministic or not).  The bar is not widened for it: the case is reported as an
+            # expected failure of the vendor convolution -- an XPASS in the summary means MIOpen's behaviour changed -- while
+            # `nchw-hip-convs`, the product path, has to meet 1e-3 here like everywhere else
+            known = path == "nchw" and name == "layer_coxtlayer_s2_192x28" and mode == "eval"
+            try:
+                check_real_layer(gold, mode, layer, y, xin.grad, tol=1e-3)
+            except AssertionError as e:
+                if not known:
+                    raise
+                vendor_defect = e
     assert "agg" in _lib.last_kernel()
     assert (layer.bn.running_mean.cpu() - torch.from_numpy(gold["train_bn_running_mean"])).abs().max() < 1e-4
+    if vendor_defect is not None:
+        pytest.xfail(f"MIOpen fp32 grouped 3x3 backward-data on the developer-baseline path: {vendor_defect}"[:300])
 
 
 @pytest.mark.parametrize("C,H", [(64, 56), (128, 28)])
