@@ -228,7 +228,9 @@ def bn_epilogue_case(L, dev, st, N, Ci, Co, HW, act, res, mask):
     assert torch.allclose(mean, m2, atol=1e-6, rtol=1e-5) and torch.allclose(rstd, r2, atol=0, rtol=2e-5)
     assert torch.allclose(rm, rm2, atol=1e-6, rtol=1e-5) and torch.allclose(rv, rv2, atol=1e-6, rtol=2e-5) and int(nbt) == 1
     d = (z.float() - z2.float()).abs()
-    assert (d <= 2.0 ** -7 * z2.float().abs() + 1e-6).all() and (d > 0).float().mean() < 0.10
+    # (one bf16 rounding of the output; where the normalised value and the residual cancel, the last-bit difference of the two
+    # statistics paths shows in absolute terms: 1e-4 on values of order one)
+    assert (d <= 2.0 ** -7 * z2.float().abs() + 1e-4).all() and (d > 0).float().mean() < 0.10
     if mask:
         same = (z == z2).view(-1, 8).all(1)
         assert torch.equal(mk[same], mk2[same])
