@@ -806,11 +806,8 @@ __global__ __launch_bounds__(1024) void bn_chan_fwd(const T* __restrict__ x, con
         }
 }
 
-// RR = 16 (bf16, 8-element vectors only): the WIDE backward instance -- 512 lanes that may use 256 registers each hold sixteen rounds
-// of both tensors, i.e. channels of up to 8192 vectors: the 28 x 28 BatchNorms of the benchmark batch (7840 vectors per channel),
-// whose backward otherwise takes the two-launch streaming path (4 reads + 1 write instead of 2 + 1)
 template <typename T, int V, int ACT, int RR>
-__global__ __launch_bounds__(RR == 16 ? 512 : 1024) void bn_chan_bwd(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+__global__ __launch_bounds__(1024) void bn_chan_bwd(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                    T* __restrict__ dx, T* __restrict__ dres, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, float* __restrict__ dgamma,
@@ -911,7 +908,6 @@ static inline int bn_chan_threads(int N, int C, int HW, int V, int rounds) {
 }
 
 // the instance's round count for a channel of MV vectors on `threads` lanes: 2, 4 or 0 (= the full ChanRounds instance)
-int g_bn_chan_wide = 1;  // cot_set_tuning key 48: 1 (default) = the wide (512 lanes x 16 rounds) backward instance where it covers the channel, 0 = streaming kernels there
 int g_bn_chan_rr = 1;  // cot_set_tuning key 47: 1 (default) = short instances where they cover the channel, 0 = always the full one
 static inline int bn_chan_rr(int64_t MV, int threads, int full) {
     if (!g_bn_chan_rr) return 0;
@@ -989,20 +985,6 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
         else BN_SB(ACT_NONE);
 #undef BN_SB
         return check_launch("bn_small_bwd");
-    }
-    if (sizeof(T) == 2 && g_bn_chan && g_bn_chan_wide && pick_vec(sizeof(T), HW) == 8 && (int64_t)N * C * HW < ((int64_t)1 << 31)) {
-        const int64_t MV = (int64_t)N * HW / 8;
-        if (MV > (int64_t)1024 * bn_chan_rounds<T, true>(8) && MV <= (int64_t)512 * 16) {
-            const dim3 grid(C), block(512);
-            const uint8_t* const mk = t_bn_mask;
-#define BN_CW(A_) COT_LAUNCH((bn_chan_bwd<T, (sizeof(T) <= 2 ? 8 : 4), A_, 16>), grid, block, 0, s, (const T*)dy, (const T*)x, (const T*)y, (T*)dx, (T*)dres, gamma, beta, mean, rstd, dgamma, dbeta, N, C, HW, ps, mk)
-            if (act == ACT_RELU && y) BN_CW(ACT_RELU_Y);
-            else if (act == ACT_RELU) BN_CW(ACT_RELU);
-            else if (act == ACT_SILU) BN_CW(ACT_SILU);
-            else BN_CW(ACT_NONE);
-#undef BN_CW
-            return check_launch("bn_chan_bwd<wide>");
-        }
     }
     if (const int cv = bn_chan_vec<T, true>(N, C, HW)) {
         const dim3 grid(C), block(bn_chan_threads(N, C, HW, cv, bn_chan_rounds<T, true>(cv)));

@@ -167,7 +167,6 @@ extern int g_conv3x3_perm;
 extern int g_conv_flat_ns3;
 extern int g_conv_big_fill;
 extern int g_bn_chan_rr;
-extern int g_bn_chan_wide;
 extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
 unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
@@ -426,10 +425,6 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 47) {
         g_bn_chan_rr = value ? 1 : 0;
-        return COT_OK;
-    }
-    if (key == 48) {
-        g_bn_chan_wide = value ? 1 : 0;
         return COT_OK;
     }
     if (key == 42) {

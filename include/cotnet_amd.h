@@ -172,8 +172,6 @@ const char* cot_last_kernel(void);
  *           deep stages): output-channel blocks of 64 / 32 instead of 128 while the launch has fewer workgroups than `value` (200 default, 0 = off)
  *   key 47: channel-resident BatchNorm: instances unrolled for 2 / 4 rounds where they cover the channel (1 default), 0 = always the
  *           full-capacity instance
- *   key 48: channel-resident BatchNorm backward on 512 lanes x 16 rounds for bf16 channels of 4097..8192 eight-element vectors (the
- *           28 x 28 stage at B = 80; 1 default), 0 = the streaming kernels there
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
  *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
  *           ring everywhere

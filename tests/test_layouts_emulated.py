@@ -174,38 +174,3 @@ def test_eval_mode_bottleneck_as_one_call_sequence(kind, H, monkeypatch):
     assert ((y.float() - ref).abs() <= 2e-2 * (ref.abs() + ref.abs().mean())).all(), (y.float() - ref).abs().max()
     for cache in (clf._SIZES, clf._MASKS, clf._BSIZES):
         cache.clear()
-
-
-@pytest.mark.parametrize("act,res", [(1, False), (2, False), (0, False), (1, True)])
-def test_wide_channel_resident_backward_against_the_streaming_kernels(act, res):
-    """bf16 channels of 4097..8192 eight-element vectors (the 28 x 28 BatchNorms at B = 80: 7840) take the backward in ONE launch on 512
-    lanes x 16 rounds (cot_set_tuning 48); against the two-launch streaming kernels on the same operands: same function, another
-    order of the sums"""
-    import torch
-    L, P, BF = _EMUL, lc.P, lc.BF
-    N, C, HW = 42, 3, 784
-    assert 4096 < N * HW // 8 <= 8192
-    torch.manual_seed(act + 7)
-    x = (torch.randn(N, C, HW) * 1.5 + 0.3).bfloat16()
-    r = torch.randn(N, C, HW).bfloat16() if res else None
-    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.2
-    mean, rstd = torch.empty(C), torch.empty(C)
-    ws = torch.empty(max(1, int(L.cot_bn_act_workspace(N, C))))
-    y = torch.empty_like(x)
-    assert L.cot_bn_act_forward(P(x), P(r) if res else None, P(y), P(gamma), P(beta), P(mean), P(rstd), None, None, None, P(ws), N, C, HW, 1e-5,
-                                0.1, act, BF, None) == 0
-    dy = torch.randn(N, C, HW).bfloat16()
-    outs = []
-    for wide in (1, 0):
-        assert L.cot_set_tuning(48, wide) == 0
-        dx, dres = torch.full_like(x, float("nan")), (torch.full_like(x, float("nan")) if res else None)
-        dg, db = torch.full((C,), float("nan")), torch.full((C,), float("nan"))
-        assert L.cot_bn_act_backward(P(dy), P(x), P(y) if res else None, P(dx), P(dres) if res else None, P(gamma), P(beta), P(mean), P(rstd),
-                                     P(dg), P(db), P(ws), N, C, HW, act, BF, None) == 0, L.cot_last_error()
-        outs.append((dx.float(), dres.float() if res else None, dg, db))
-    assert L.cot_set_tuning(48, 1) == 0
-    (dx1, dr1, dg1, db1), (dx0, dr0, dg0, db0) = outs
-    assert torch.isfinite(dx1).all() and torch.allclose(dg1, dg0, rtol=1e-4, atol=1e-3) and torch.allclose(db1, db0, rtol=1e-4, atol=1e-3)
-    assert ((dx1 - dx0).abs() <= 2.0 ** -7 * dx0.abs() + 1e-4).all()
-    if res:
-        assert torch.equal(dr1, dr0)
