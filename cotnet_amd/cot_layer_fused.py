@@ -1145,16 +1145,17 @@ def _cm_static_ok(blk):
     if not isinstance(blk, Bottleneck):
         return False
     bp = _block_plan(blk)
-    return (bp.static_ok and bp.ds_conv is None and not bp.avd and bp.conv1.in_channels == bp.conv3.out_channels
-            and not _plan(bp.cot).grouped)
+    return bp.static_ok and bp.ds_conv is None and not bp.avd and bp.conv1.in_channels == bp.conv3.out_channels
 
 
-def _cm_sizes(L, N, Cin, C, A, G, H, W):
-    k = (N, Cin, C, A, G, H, W)
+def _cm_sizes(L, N, Cin, C, A, G, H, W, grouped=False):
+    k = (N, Cin, C, A, G, H, W, grouped)
     v = _CM_SIZES.get(k)
     if v is None:
         HW, M = H * W, N * H * W
-        ws = max(int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_conv1x1_workspace(1, 2 * C, C // 2, M, 0)),
+        gws = max(int(L.cot_convg_workspace(1, 2 * C, C // 2, 2, M, 1, 1)), int(L.cot_convg_workspace(1, C // 2, 9 * C // 8, 2, M, 1, 1)),
+                  int(L.cot_convg_workspace(1, C, C, 2, M, 1, 1))) if grouped else 0
+        ws = max(gws, int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_conv1x1_workspace(1, 2 * C, C // 2, M, 0)),
                  int(L.cot_conv1x1_workspace(1, C // 2, 9 * C // 8, M, 1)), int(L.cot_conv1x1_workspace(1, C, C, M, 0)),
                  int(L.cot_conv1x1_workspace(1, C, A, N, 1)), int(L.cot_conv1x1_workspace(1, A, 2 * C, N, 1)),
                  int(L.cot_conv1x1_workspace(1, Cin, C, M, 0)), int(L.cot_conv1x1_workspace(1, C, Cin, M, 0)),
@@ -1164,15 +1165,17 @@ def _cm_sizes(L, N, Cin, C, A, G, H, W):
     return v
 
 
-def _cm_geometry_ok(L, N, Cin, C, H, W):
-    k = (N, Cin, C, H, W)
+def _cm_geometry_ok(L, N, Cin, C, H, W, grouped=False):
+    k = (N, Cin, C, H, W, grouped)
     v = _CM_OK.get(k)
     if v is None:
         HW = H * W
-        v = _CM_OK[k] = bool(HW <= 256 and (N * HW) % 8 == 0 and N > 1 and C % 64 == 0
-                             and L.cot_bn_act_lay_covers(N, C, HW, BF16) and L.cot_bn_act_lay_covers(N, Cin, HW, BF16)
-                             and L.cot_conv1x1_lds_covers(C, C, 0, N * HW) and L.cot_conv1x1_lds_covers(2 * C, C, 1, N * HW)
-                             and L.cot_conv1x1_lds_covers(Cin, Cin, 0, N * HW) and L.cot_conv1x1_lds_covers(C // 2, C // 2, 0, N * HW))
+        v = bool(HW <= 256 and (N * HW) % 8 == 0 and N > 1 and C % 64 == 0
+                 and L.cot_bn_act_lay_covers(N, C, HW, BF16) and L.cot_bn_act_lay_covers(N, Cin, HW, BF16)
+                 and L.cot_conv1x1_lds_covers(Cin, Cin, 0, N * HW) and L.cot_conv1x1_lds_covers(C, C, 0, N * HW))
+        if v and not grouped:
+            v = bool(L.cot_conv1x1_lds_covers(2 * C, C, 1, N * HW) and L.cot_conv1x1_lds_covers(C // 2, C // 2, 0, N * HW))
+        _CM_OK[k] = v  # (CoXtLayer's grouped 1x1s: cot_conv1x1g_* routes each group to the tuned or the general kernels itself)
     return v
 
 
@@ -1190,7 +1193,7 @@ def cm_block_eligible(blk, x):
             and bp.bn1.weight.dtype == torch.float32 and bp.bn1.training and bp.bn3.training
             and pl.ke0.weight.dtype == torch.bfloat16 and pl.em3.weight.dtype == torch.bfloat16 and pl.gn.weight.dtype == torch.bfloat16
             and pl.bn.weight.dtype == torch.float32 and pl.bn.training and pl.ke1.training
-            and _cm_geometry_ok(_lib.lib(), N, Cin, bp.conv1.out_channels, H, W))
+            and _cm_geometry_ok(_lib.lib(), N, Cin, bp.conv1.out_channels, H, W, pl.grouped))
 
 
 def cm_block_forward(blk, x):
@@ -1224,7 +1227,9 @@ class _BottleneckCMNode(Function):
         dev, st = x.device, _stream()
         in_cm = _is_cm(x)
         out_cm = bool(getattr(blk, "_next_cm", False))
-        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W)
+        GX = pl.grouped  # CoXtLayer (models/cotnet.py:106-178): grouped 1x1s (a group = a contiguous range of channel ROWS here), [x, k]
+        #                  interleaved row by row, the two groups folded into the batch for the aggregation (views of the NCHW tensors)
+        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W, GX)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         masks = _masks(L, H, W, dev)
         nchw = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
@@ -1249,11 +1254,19 @@ class _BottleneckCMNode(Function):
         _bn_fwd_lay(L, k_pre, None, k, None, pl.ke1, s_k, N, C, HW, 1, 4)
         # attention logits from [x | k]: two 1x1 convolutions on channel rows, GroupNorm writes the aggregation's weights NCHW (ref :81-85)
         e0, e1, e3 = cmj(Ch), cmj(Ch), cmj(Ce)
-        _ck(L.cot_conv1x1_forward(_p(a1c), _p(k), C, _p(pl.em0.weight), None, _p(e0), 1, 2 * C, Ch, M, BF16, st), "cot_conv1x1_forward")
+        qk = None
+        if GX:
+            qk = torch.stack([a1c, k], dim=1).view(2 * C, N, H, W)  # rows x0, k0, x1, k1, ... (ref :153-154)
+            _ck(L.cot_conv1x1g_forward(_p(qk), _p(pl.em0.weight), None, _p(e0), 1, 2 * C, Ch, 2, M, BF16, st), "cot_conv1x1g_forward")
+        else:
+            _ck(L.cot_conv1x1_forward(_p(a1c), _p(k), C, _p(pl.em0.weight), None, _p(e0), 1, 2 * C, Ch, M, BF16, st), "cot_conv1x1_forward")
         s_e = stat(Ch, nws_h1)
         _bn_fwd(L, e0, e1, pl.em1, s_e, 2 * Ch, 1, Ch, M, 1)
-        _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), 1, Ch, Ce, M, BF16, st),
-            "cot_conv1x1_forward")
+        if GX:
+            _ck(L.cot_conv1x1g_forward(_p(e1), _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), 1, Ch, Ce, 2, M, BF16, st), "cot_conv1x1g_forward")
+        else:
+            _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), 1, Ch, Ce, M, BF16, st),
+                "cot_conv1x1_forward")
         gn = pl.gn
         w = nchw(Ce)
         gn_mean = torch.empty(2 * N * gn.num_groups, dtype=torch.float32, device=dev)
@@ -1262,11 +1275,15 @@ class _BottleneckCMNode(Function):
                                           BF16, st), "cot_group_norm9_forward_lay")
         # values: 1x1 on channel rows, its BatchNorm writes NCHW                                                     (ref :87)
         v_pre, v = cmj(C), nchw(C)
-        _ck(L.cot_conv1x1_forward(_p(a1c), None, C, _p(pl.cv0.weight), None, _p(v_pre), 1, C, C, M, BF16, st), "cot_conv1x1_forward")
+        if GX:
+            _ck(L.cot_conv1x1g_forward(_p(a1c), _p(pl.cv0.weight), None, _p(v_pre), 1, C, C, 2, M, BF16, st), "cot_conv1x1g_forward")
+        else:
+            _ck(L.cot_conv1x1_forward(_p(a1c), None, C, _p(pl.cv0.weight), None, _p(v_pre), 1, C, C, M, BF16, st), "cot_conv1x1_forward")
         s_v = stat(C, 0)
         _bn_fwd_lay(L, v_pre, None, v, None, pl.cv1, s_v, N, C, HW, 0, 1)
         # aggregation, bn + swish (NCHW)                                                                            (ref :88-90)
-        geom = _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
+        geom = _lib.AggGeom(2 * N, C // 2, H, W, 1, C // 16, 3, 3, 1, 1, 1, 1, 1, 1) if GX else \
+            _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
         a, y = nchw(C), nchw(C)
         _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
         s_y = stat(C, nws_c)
@@ -1298,7 +1315,8 @@ class _BottleneckCMNode(Function):
             _bn_fwd_lay(L, c3, xb, yb, None, bp.bn3, s_3, N, Cin, HW, 1, 1 | (2 if in_cm else 0) | (4 if out_cm else 0), ps=ps)
         ctx.blk, ctx.geom, ctx.flags = blk, geom, (in_cm, out_cm, ps is not None, m3 is not None)
         ctx.save_for_backward(xb, c1, a1, a1c, s_1, k_pre, k, s_k, e0, e1, s_e, e3, w, gn_mean, gn_rstd, v_pre, v, s_v, a, y, s_y, attn,
-                              gapT, hpre, h, s_a, cot_out, c3, yb, s_3, *((m3,) if m3 is not None else ()), *((ps,) if ps is not None else ()))
+                              gapT, hpre, h, s_a, cot_out, c3, yb, s_3, qk if GX else s_3,
+                              *((m3,) if m3 is not None else ()), *((ps,) if ps is not None else ()))
         return _cm_view(yb) if out_cm else yb
 
     @staticmethod
@@ -1310,15 +1328,16 @@ class _BottleneckCMNode(Function):
         pl = _plan(bp.cot)
         t = ctx.saved_tensors
         (xb, c1, a1, a1c, s_1, k_pre, k, s_k, e0, e1, s_e, e3, w, gn_mean, gn_rstd, v_pre, v, s_v, a, y, s_y, attn,
-         gapT, hpre, h, s_a, cot_out, c3, yb, s_3) = t[:30]
+         gapT, hpre, h, s_a, cot_out, c3, yb, s_3, qk) = t[:31]
         in_cm, out_cm, has_ps, has_mask = ctx.flags
-        m3 = t[30] if has_mask else None
+        GX = pl.grouped
+        m3 = t[31] if has_mask else None
         ps = t[-1] if has_ps else None
         N, C, H, W = a1.shape
         Cin, A, G = c3.shape[0], pl.se0.out_channels, pl.ke0.groups
         HW, M, Ch, Ce = H * W, N * H * W, C // 2, 9 * C // 8
         dev, st = a1.device, _stream()
-        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W)
+        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W, GX)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         masks = _masks(L, H, W, dev)
         side = _Side(dev, ws_bytes, ws, bp.params)
@@ -1369,9 +1388,13 @@ class _BottleneckCMNode(Function):
         gv_pre = cmj(C)
         d_cv_w, d_cv_b = _bn_bwd_lay(L, gv, None, v_pre, None, gv_pre, None, cv1, s_v, N, C, HW, 0, 4 | 16)
         gxc = cmj(C)
-        _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gxc), None, C, 0, _p(ws), 1, C, C, M, BF16, st), "cot_conv1x1_backward_data")
         g_wv = grad_sink.out_like(cv0.weight)
-        side.run(lambda st_, a_=(_p(gv_pre), _p(a1c), None, C, _p(g_wv), None, _p(side.ws), 1, C, C, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), gv_pre, a1c)
+        if GX:
+            _ck(L.cot_conv1x1g_backward_data(_p(gv_pre), _p(cv0.weight), _p(gxc), 0, 1, C, C, 2, M, BF16, st), "cot_conv1x1g_backward_data")
+            side.run(lambda st_, a_=(_p(gv_pre), _p(a1c), _p(g_wv), None, _p(side.ws), 1, C, C, 2, M, BF16): _ck(L.cot_conv1x1g_backward_weight(*a_, st_), "cot_conv1x1g_backward_weight"), gv_pre, a1c)
+        else:
+            _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gxc), None, C, 0, _p(ws), 1, C, C, M, BF16, st), "cot_conv1x1_backward_data")
+            side.run(lambda st_, a_=(_p(gv_pre), _p(a1c), None, C, _p(g_wv), None, _p(side.ws), 1, C, C, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), gv_pre, a1c)
         # logits branch: GroupNorm (NCHW gradient in, channel-major out), 1x1 (+bias), bn + relu, 1x1 on [x | k] -> dx +=, dk +=
         gn = pl.gn
         ge3, g_gn_w, g_gn_b = cmj(Ce), grad_sink.out_like(gn.weight), grad_sink.out_like(gn.bias)
@@ -1379,14 +1402,26 @@ class _BottleneckCMNode(Function):
         _ck(L.cot_group_norm9_backward_lay(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), _p(g_gn_w), _p(g_gn_b), _p(gn_ws),
                                            N, Ce, HW, 2 | 4, BF16, st), "cot_group_norm9_backward_lay")
         ge1 = cmj(Ch)
-        _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), 1, Ch, Ce, M, BF16, st), "cot_conv1x1_backward_data")
         g_we3, g_be3 = grad_sink.out_like(em3.weight), grad_sink.out_like(em3.bias)
-        side.run(lambda st_, a_=(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(side.ws), 1, Ch, Ce, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge3, e1)
+        if GX:
+            _ck(L.cot_conv1x1g_backward_data(_p(ge3), _p(em3.weight), _p(ge1), 0, 1, Ch, Ce, 2, M, BF16, st), "cot_conv1x1g_backward_data")
+            side.run(lambda st_, a_=(_p(ge3), _p(e1), _p(g_we3), _p(g_be3), _p(side.ws), 1, Ch, Ce, 2, M, BF16): _ck(L.cot_conv1x1g_backward_weight(*a_, st_), "cot_conv1x1g_backward_weight"), ge3, e1)
+        else:
+            _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), 1, Ch, Ce, M, BF16, st), "cot_conv1x1_backward_data")
+            side.run(lambda st_, a_=(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(side.ws), 1, Ch, Ce, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge3, e1)
         ge0 = cmj(Ch)
         d_em_w, d_em_b = _bn_bwd(L, ge1, e0, None, ge0, em1, s_e, 1, Ch, M, 1, nws_h1)
-        _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gxc), _p(gk), C, 3, _p(ws), 1, 2 * C, Ch, M, BF16, st), "cot_conv1x1_backward_data")
         g_we0 = grad_sink.out_like(em0.weight)
-        side.run(lambda st_, a_=(_p(ge0), _p(a1c), _p(k), C, _p(g_we0), None, _p(side.ws), 1, 2 * C, Ch, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge0, a1c, k)
+        if GX:  # gradient of the row-interleaved [x0, k0, x1, k1, ...]: de-interleaved into dx / dk (two strided adds)
+            gqk = torch.empty_like(qk)
+            _ck(L.cot_conv1x1g_backward_data(_p(ge0), _p(em0.weight), _p(gqk), 0, 1, 2 * C, Ch, 2, M, BF16, st), "cot_conv1x1g_backward_data")
+            gq5 = gqk.view(C, 2, N, H, W)
+            gxc.add_(gq5[:, 0])
+            gk.add_(gq5[:, 1])
+            side.run(lambda st_, a_=(_p(ge0), _p(qk), _p(g_we0), None, _p(side.ws), 1, 2 * C, Ch, 2, M, BF16): _ck(L.cot_conv1x1g_backward_weight(*a_, st_), "cot_conv1x1g_backward_weight"), ge0, qk)
+        else:
+            _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gxc), _p(gk), C, 3, _p(ws), 1, 2 * C, Ch, M, BF16, st), "cot_conv1x1_backward_data")
+            side.run(lambda st_, a_=(_p(ge0), _p(a1c), _p(k), C, _p(g_we0), None, _p(side.ws), 1, 2 * C, Ch, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge0, a1c, k)
         # key branch: bn + relu (channel-major gradient in, NCHW out), grouped 3x3 -> the NCHW contribution to dx
         gk_pre = nchw(C)
         d_ke_w, d_ke_b = _bn_bwd_lay(L, gk, None, k_pre, None, gk_pre, None, ke1, s_k, N, C, HW, 1, 1)

@@ -185,15 +185,18 @@ def test_recipe_model_runs_on_the_single_node_path():
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad.float()).all() for p in model.parameters())
 
 
-@pytest.mark.parametrize("N,planes,H,blocks", [(80, 256, 14, 3), (80, 512, 7, 2), (8, 256, 14, 2)])
-def test_channel_major_deep_stage_blocks_against_fp32_truth(N, planes, H, blocks):
+@pytest.mark.parametrize("N,planes,H,blocks,coxt", [(80, 256, 14, 3, False), (80, 512, 7, 2, False), (8, 256, 14, 2, False),
+                                                      (64, 256, 14, 2, True), (64, 512, 7, 2, True)])  # (CoTNeXt-101 2x48d: widths 384 / 768, B = 64)
+def test_channel_major_deep_stage_blocks_against_fp32_truth(N, planes, H, blocks, coxt):
     """a run of identity Bottlenecks of layer3 / layer4 (models/cotnet.py:181-264) at the benchmark batch through the channel-major
     node (cot_layer_fused._BottleneckCMNode: NCHW in -> channel-major between the blocks -> NCHW out): no further from
     an fp32 evaluation of the same modules than the NCHW single-node path is, same gradients / buffers surface"""
     from torch import nn
     torch.manual_seed(planes + H)
     inpl = 4 * planes
-    stage = nn.Sequential(*[Bottleneck(inpl, planes) for _ in range(blocks)]).to(DEV).train()
+    kw = dict(cardinality=2, base_width=48) if coxt else {}
+    stage = nn.Sequential(*[Bottleneck(inpl, planes, **kw) for _ in range(blocks)]).to(DEV).train()
+    assert type(stage[0].conv2).__name__ == ("CoXtLayer" if coxt else "CotLayer")
     with torch.no_grad():
         for p in stage.parameters():
             if p.ndim == 1:

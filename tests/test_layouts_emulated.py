@@ -47,8 +47,8 @@ def test_group_norm9_layouts(HW):
     lc.gn9_case(_EMUL, "cpu", None, 3, 4, HW)
 
 
-@pytest.mark.parametrize("H,blocks", [(14, 3), (7, 2)])
-def test_channel_major_bottlenecks_against_the_nchw_single_node(H, blocks, monkeypatch):
+@pytest.mark.parametrize("H,blocks,coxt", [(14, 3, False), (7, 2, False), (14, 2, True)])
+def test_channel_major_bottlenecks_against_the_nchw_single_node(H, blocks, coxt, monkeypatch):
     """a run of identity Bottlenecks of a deep stage (models/cotnet.py:181-264) through cot_layer_fused._BottleneckCMNode -- first block
     NCHW in / channel-major out, middle ones channel-major both sides, last one back to NCHW -- against the same blocks through the
     NCHW single-node path (_BottleneckNode), both on the host-emulated kernels.  Same kernels and rounding points; what differs is the
@@ -64,7 +64,10 @@ def test_channel_major_bottlenecks_against_the_nchw_single_node(H, blocks, monke
     from cotnet_amd.flat_sgd import to_mixed_bf16
     torch.manual_seed(6 + H)
     N, W = 6 if H == 14 else 8, H
-    stage = nn.Sequential(*[Bottleneck(256, 64).train() for _ in range(blocks)])
+    # (coxt: CoTNeXt's block -- cardinality 2, base width 48 -> CoXtLayer(96 * planes / 64): grouped 1x1s, interleaved [x, k], group -> batch fold)
+    stage = nn.Sequential(*[Bottleneck(512, 128, cardinality=2, base_width=48).train() if coxt else Bottleneck(256, 64).train()
+                            for _ in range(blocks)])
+    assert type(stage[0].conv2).__name__ == ("CoXtLayer" if coxt else "CotLayer")
     with torch.no_grad():
         for p in stage.parameters():
             if p.ndim == 1:
@@ -73,8 +76,9 @@ def test_channel_major_bottlenecks_against_the_nchw_single_node(H, blocks, monke
             b.bn3.weight.fill_(0.8)
     stage = to_mixed_bf16(stage)
     ref = copy.deepcopy(stage)
-    x = torch.randn(N, 256, H, W).bfloat16()
-    g = torch.randn(N, 256, H, W).bfloat16()
+    inpl = 512 if coxt else 256
+    x = torch.randn(N, inpl, H, W).bfloat16()
+    g = torch.randn(N, inpl, H, W).bfloat16()
     monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
     for mod in (clf, c1, c3, fused_bn, radix_tail):
         monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
