@@ -1136,7 +1136,8 @@ def plan_stage_layouts(stage):
     blocks = list(stage.children())
     for i, b in enumerate(blocks):
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-        b._next_cm = bool(CM_LAYOUT and nxt is not None and _cm_static_ok(nxt))
+        # (an opening block takes NCHW: its conv1 / bn1 run at the input resolution, off the channel-resident kernels)
+        b._next_cm = bool(CM_LAYOUT and nxt is not None and _cm_static_ok(nxt) and not _block_plan(nxt).avd)
     stage._cm_planned = CM_LAYOUT
 
 
@@ -1145,11 +1146,17 @@ def _cm_static_ok(blk):
     if not isinstance(blk, Bottleneck):
         return False
     bp = _block_plan(blk)
-    return bp.static_ok and bp.ds_conv is None and not bp.avd and bp.conv1.in_channels == bp.conv3.out_channels
+    identity = bp.ds_conv is None and not bp.avd and bp.conv1.in_channels == bp.conv3.out_channels
+    # the stage's opening block (models/cotnet.py:228-264 with `avd` pooling in front of the layer and a stride-2 projection): conv1 /
+    # bn1 / the pooling stay NCHW at the input resolution, the layer, conv3, bn3 and the projection's BatchNorm go channel-major
+    opening = bp.ds_conv is not None and bp.avd and bp.ds_stride == 2
+    return bp.static_ok and (identity or opening)
 
 
-def _cm_sizes(L, N, Cin, C, A, G, H, W, grouped=False):
-    k = (N, Cin, C, A, G, H, W, grouped)
+def _cm_sizes(L, N, Cin, C, A, G, H, W, grouped=False, Cout=None):
+    """Cin / Cout: the block's input / output channels (Cout given = the stage's opening block: conv1 on 2H x 2W NCHW planes, the
+    projection on the sub-sampled input)"""
+    k = (N, Cin, C, A, G, H, W, grouped, Cout)
     v = _CM_SIZES.get(k)
     if v is None:
         HW, M = H * W, N * H * W
@@ -1158,10 +1165,11 @@ def _cm_sizes(L, N, Cin, C, A, G, H, W, grouped=False):
         ws = max(gws, int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_conv1x1_workspace(1, 2 * C, C // 2, M, 0)),
                  int(L.cot_conv1x1_workspace(1, C // 2, 9 * C // 8, M, 1)), int(L.cot_conv1x1_workspace(1, C, C, M, 0)),
                  int(L.cot_conv1x1_workspace(1, C, A, N, 1)), int(L.cot_conv1x1_workspace(1, A, 2 * C, N, 1)),
-                 int(L.cot_conv1x1_workspace(1, Cin, C, M, 0)), int(L.cot_conv1x1_workspace(1, C, Cin, M, 0)),
-                 int(L.cot_conv1x1_workspace(N, Cin, C, HW, 0)))
+                 int(L.cot_conv1x1_workspace(1, Cin, C, M, 0)), int(L.cot_conv1x1_workspace(1, C, Cout or Cin, M, 0)),
+                 int(L.cot_conv1x1_workspace(N, Cin, C, HW, 0)),
+                 *((int(L.cot_conv1x1_workspace(N, Cin, C, 4 * HW, 0)), int(L.cot_conv1x1_workspace(N, Cin, Cout, HW, 0))) if Cout else ()))
         v = _CM_SIZES[k] = (ws, int(L.cot_bn_act_workspace(N, C)), int(L.cot_bn_act_workspace(1, C)), int(L.cot_bn_act_workspace(1, C // 2)),
-                            int(L.cot_bn_act_workspace(1, A)), int(L.cot_bn_act_workspace(1, Cin)))
+                            int(L.cot_bn_act_workspace(1, A)), int(L.cot_bn_act_workspace(1, Cout or Cin)))
     return v
 
 
@@ -1189,11 +1197,15 @@ def cm_block_eligible(blk, x):
     bp = _block_plan(blk)
     pl = _plan(bp.cot)
     N, Cin, H, W = x.shape
+    if bp.avd:
+        if not (x.is_contiguous() and H % 2 == 0 and W % 2 == 0 and bp.ds_bn.training):
+            return False
+        H, W = H // 2, W // 2
     return (x.shape[1] == bp.conv1.in_channels and bp.conv1.weight.dtype == torch.bfloat16 and bp.conv3.weight.dtype == torch.bfloat16
             and bp.bn1.weight.dtype == torch.float32 and bp.bn1.training and bp.bn3.training
             and pl.ke0.weight.dtype == torch.bfloat16 and pl.em3.weight.dtype == torch.bfloat16 and pl.gn.weight.dtype == torch.bfloat16
             and pl.bn.weight.dtype == torch.float32 and pl.bn.training and pl.ke1.training
-            and _cm_geometry_ok(_lib.lib(), N, Cin, bp.conv1.out_channels, H, W, pl.grouped))
+            and _cm_geometry_ok(_lib.lib(), N, bp.conv3.out_channels, bp.conv1.out_channels, H, W, pl.grouped))
 
 
 def cm_block_forward(blk, x):
@@ -1221,15 +1233,17 @@ class _BottleneckCMNode(Function):
         L = _lib.lib()
         bp = _block_plan(blk)
         pl = _plan(bp.cot)
-        N, Cin, H, W = x.shape
-        C, A, G = bp.conv1.out_channels, pl.se0.out_channels, pl.ke0.groups
+        N, Cin, H0, W0 = x.shape
+        opening = bp.avd   # the stage's first block: 3x3/2 average pooling in front of the layer, stride-2 projection shortcut
+        H, W = (H0 // 2, W0 // 2) if opening else (H0, W0)
+        C, A, G, Cout = bp.conv1.out_channels, pl.se0.out_channels, pl.ke0.groups, bp.conv3.out_channels
         HW, M, Ch, Ce = H * W, N * H * W, C // 2, 9 * C // 8
         dev, st = x.device, _stream()
         in_cm = _is_cm(x)
         out_cm = bool(getattr(blk, "_next_cm", False))
         GX = pl.grouped  # CoXtLayer (models/cotnet.py:106-178): grouped 1x1s (a group = a contiguous range of channel ROWS here), [x, k]
         #                  interleaved row by row, the two groups folded into the batch for the aggregation (views of the NCHW tensors)
-        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W, GX)
+        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W, GX, Cout if opening else None)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         masks = _masks(L, H, W, dev)
         nchw = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
@@ -1237,15 +1251,27 @@ class _BottleneckCMNode(Function):
         stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
         xb = _cm_buf(x) if in_cm else x   # the dense buffer under x, either layout
 
-        # conv1 -> bn1 + relu -> a1 (NCHW with margins: the 3x3 weight gradient reads it shifted) and a1c (channel-major)
-        c1 = cmj(C) if in_cm else nchw(C)
-        if in_cm:
-            _ck(L.cot_conv1x1_forward(_p(xb), None, Cin, _p(bp.conv1.weight), None, _p(c1), 1, Cin, C, M, BF16, st), "cot_conv1x1_forward")
+        if opening:
+            # conv1 -> bn1 + relu on the 2H x 2W input planes (NCHW, the ordinary kernels), pooled to H x W: a1 (NCHW with margins) and
+            # its channel-major copy for the 1x1 convolutions
+            c1 = torch.empty((N, C, H0, W0), dtype=x.dtype, device=dev)
+            _ck(L.cot_conv1x1_forward(_p(xb), None, Cin, _p(bp.conv1.weight), None, _p(c1), N, Cin, C, H0 * W0, BF16, st), "cot_conv1x1_forward")
+            a1f = torch.empty_like(c1)
+            s_1 = stat(C, nws_c)
+            _bn_fwd(L, c1, a1f, bp.bn1, s_1, 2 * C, N, C, H0 * W0, 1)
+            a1 = _new_guarded(N, C, H, W, x.dtype, dev)
+            _ck(L.cot_avgpool3x3s2_forward(_p(a1f), _p(a1), N * C, H0, W0, BF16, st), "cot_avgpool3x3s2_forward")
+            a1c = a1.permute(1, 0, 2, 3).contiguous()
         else:
-            _ck(L.cot_conv1x1_forward(_p(xb), None, Cin, _p(bp.conv1.weight), None, _p(c1), N, Cin, C, HW, BF16, st), "cot_conv1x1_forward")
-        a1, a1c = _new_guarded(N, C, H, W, x.dtype, dev), cmj(C)
-        s_1 = stat(C, 0)
-        _bn_fwd_lay(L, c1, None, a1, a1c, bp.bn1, s_1, N, C, HW, 1, (1 if in_cm else 0) | 8)
+            # conv1 -> bn1 + relu -> a1 (NCHW with margins: the 3x3 weight gradient reads it shifted) and a1c (channel-major)
+            c1 = cmj(C) if in_cm else nchw(C)
+            if in_cm:
+                _ck(L.cot_conv1x1_forward(_p(xb), None, Cin, _p(bp.conv1.weight), None, _p(c1), 1, Cin, C, M, BF16, st), "cot_conv1x1_forward")
+            else:
+                _ck(L.cot_conv1x1_forward(_p(xb), None, Cin, _p(bp.conv1.weight), None, _p(c1), N, Cin, C, HW, BF16, st), "cot_conv1x1_forward")
+            a1, a1c = _new_guarded(N, C, H, W, x.dtype, dev), cmj(C)
+            s_1 = stat(C, 0)
+            _bn_fwd_lay(L, c1, None, a1, a1c, bp.bn1, s_1, N, C, HW, 1, (1 if in_cm else 0) | 8)
         # static context: grouped 3x3 (NCHW) -> bn + relu -> k (channel-major)                                   (ref :80)
         k_pre, k = nchw(C), cmj(C)
         _ck(L.cot_conv3x3g_forward(_p(a1), _p(pl.ke0.weight), _p(k_pre), _p(masks), _p(ws), N, C, C, G, H, W, BF16, st),
@@ -1300,22 +1326,34 @@ class _BottleneckCMNode(Function):
         attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
         cot_out = cmj(C)
         _ck(L.cot_radix_mix_logits_lay(_p(y), _p(k), _p(logitsT), _p(cot_out), _p(attn), N, C, HW, 2 | 4, BF16, st), "cot_radix_mix_logits_lay")
-        # conv3 -> bn3 + residual + relu
-        c3 = cmj(Cin)
-        _ck(L.cot_conv1x1_forward(_p(cot_out), None, C, _p(bp.conv3.weight), None, _p(c3), 1, C, Cin, M, BF16, st), "cot_conv1x1_forward")
+        # conv3 -> bn3 + residual + relu.  The residual: the block's input (identity) or bn(conv1x1(every second pixel of it))
+        c3 = cmj(Cout)
+        _ck(L.cot_conv1x1_forward(_p(cot_out), None, C, _p(bp.conv3.weight), None, _p(c3), 1, C, Cout, M, BF16, st), "cot_conv1x1_forward")
         ps = _drop_path_scale(blk, N, dev)
-        yb = cmj(Cin) if out_cm else nchw(Cin)
-        m3 = None
-        if in_cm and out_cm and ps is None:  # everything channel-major: the ordinary kernels on N*HW-element rows (16-byte accesses, sign mask)
-            s_3 = stat(Cin, nws_o1)
-            m3 = _relu_mask(L, 1, Cin, M, dev)
-            _bn_fwd(L, c3, yb, bp.bn3, s_3, 2 * Cin, 1, Cin, M, 1, residual=xb, mask=m3)
+        yb = cmj(Cout) if out_cm else nchw(Cout)
+        if opening:
+            xs = torch.empty((N, Cin, H, W), dtype=x.dtype, device=dev)
+            _ck(L.cot_subsample2_forward(_p(xb), _p(xs), N * Cin, H0, W0, BF16, st), "cot_subsample2_forward")
+            d0 = nchw(Cout)
+            _ck(L.cot_conv1x1_forward(_p(xs), None, Cin, _p(bp.ds_conv.weight), None, _p(d0), N, Cin, Cout, HW, BF16, st), "cot_conv1x1_forward")
+            res_cm = out_cm  # (the projection's BatchNorm writes the layout bn3 writes)
+            res = cmj(Cout) if res_cm else nchw(Cout)
+            s_d = stat(Cout, 0)
+            _bn_fwd_lay(L, d0, None, res, None, bp.ds_bn, s_d, N, Cout, HW, 0, 4 if res_cm else 0)
         else:
-            s_3 = stat(Cin, 0)
-            _bn_fwd_lay(L, c3, xb, yb, None, bp.bn3, s_3, N, Cin, HW, 1, 1 | (2 if in_cm else 0) | (4 if out_cm else 0), ps=ps)
-        ctx.blk, ctx.geom, ctx.flags = blk, geom, (in_cm, out_cm, ps is not None, m3 is not None)
+            xs = d0 = s_d = None
+            res, res_cm = xb, in_cm
+        m3 = None
+        if res_cm and out_cm and ps is None:  # everything channel-major: the ordinary kernels on N*HW-element rows (16-byte accesses, sign mask)
+            s_3 = stat(Cout, nws_o1)
+            m3 = _relu_mask(L, 1, Cout, M, dev)
+            _bn_fwd(L, c3, yb, bp.bn3, s_3, 2 * Cout, 1, Cout, M, 1, residual=res, mask=m3)
+        else:
+            s_3 = stat(Cout, 0)
+            _bn_fwd_lay(L, c3, res, yb, None, bp.bn3, s_3, N, Cout, HW, 1, 1 | (2 if res_cm else 0) | (4 if out_cm else 0), ps=ps)
+        ctx.blk, ctx.geom, ctx.flags = blk, geom, (in_cm, out_cm, ps is not None, m3 is not None, res_cm)
         ctx.save_for_backward(xb, c1, a1, a1c, s_1, k_pre, k, s_k, e0, e1, s_e, e3, w, gn_mean, gn_rstd, v_pre, v, s_v, a, y, s_y, attn,
-                              gapT, hpre, h, s_a, cot_out, c3, yb, s_3, qk if GX else s_3,
+                              gapT, hpre, h, s_a, cot_out, c3, yb, s_3, qk if GX else s_3, *((d0, s_d, xs) if opening else ()),
                               *((m3,) if m3 is not None else ()), *((ps,) if ps is not None else ()))
         return _cm_view(yb) if out_cm else yb
 
@@ -1329,15 +1367,19 @@ class _BottleneckCMNode(Function):
         t = ctx.saved_tensors
         (xb, c1, a1, a1c, s_1, k_pre, k, s_k, e0, e1, s_e, e3, w, gn_mean, gn_rstd, v_pre, v, s_v, a, y, s_y, attn,
          gapT, hpre, h, s_a, cot_out, c3, yb, s_3, qk) = t[:31]
-        in_cm, out_cm, has_ps, has_mask = ctx.flags
+        in_cm, out_cm, has_ps, has_mask, res_cm = ctx.flags
         GX = pl.grouped
-        m3 = t[31] if has_mask else None
+        opening = bp.avd
+        nx = 34 if opening else 31
+        d0, s_d, xs = t[31:34] if opening else (None, None, None)
+        m3 = t[nx] if has_mask else None
         ps = t[-1] if has_ps else None
         N, C, H, W = a1.shape
-        Cin, A, G = c3.shape[0], pl.se0.out_channels, pl.ke0.groups
+        Cin, Cout, A, G = bp.conv1.in_channels, c3.shape[0], pl.se0.out_channels, pl.ke0.groups
         HW, M, Ch, Ce = H * W, N * H * W, C // 2, 9 * C // 8
+        H0, W0 = (xb.shape[2], xb.shape[3]) if opening else (H, W)
         dev, st = a1.device, _stream()
-        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W, GX)
+        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W, GX, Cout if opening else None)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         masks = _masks(L, H, W, dev)
         side = _Side(dev, ws_bytes, ws, bp.params)
@@ -1351,18 +1393,18 @@ class _BottleneckCMNode(Function):
         else:
             gb = gout.contiguous()
         # bn3 + residual + relu
-        g_c3 = cmj(Cin)
-        g_res = cmj(Cin) if in_cm else nchw(Cin)
+        g_c3 = cmj(Cout)
+        g_res = cmj(Cout) if res_cm else nchw(Cout)
         if has_mask:
-            d_bn3_w, d_bn3_b = _bn_bwd(L, gb, c3, None, g_c3, bp.bn3, s_3, 1, Cin, M, 1, nws_o1, dres=g_res, mask=m3)
+            d_bn3_w, d_bn3_b = _bn_bwd(L, gb, c3, None, g_c3, bp.bn3, s_3, 1, Cout, M, 1, nws_o1, dres=g_res, mask=m3)
         else:
-            d_bn3_w, d_bn3_b = _bn_bwd_lay(L, gb, None, c3, yb, g_c3, g_res, bp.bn3, s_3, N, Cin, HW, 1,
-                                           (1 if out_cm else 0) | 4 | (8 if out_cm else 0) | 16 | (32 if in_cm else 0), ps=ps)
+            d_bn3_w, d_bn3_b = _bn_bwd_lay(L, gb, None, c3, yb, g_c3, g_res, bp.bn3, s_3, N, Cout, HW, 1,
+                                           (1 if out_cm else 0) | 4 | (8 if out_cm else 0) | 16 | (32 if res_cm else 0), ps=ps)
         g_out = cmj(C)
-        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_out), None, C, 0, _p(ws), 1, C, Cin, M, BF16, st),
+        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_out), None, C, 0, _p(ws), 1, C, Cout, M, BF16, st),
             "cot_conv1x1_backward_data")
         g_w3c = grad_sink.out_like(bp.conv3.weight)
-        side.run(lambda st_, a_=(_p(g_c3), _p(cot_out), None, C, _p(g_w3c), None, _p(side.ws), 1, C, Cin, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, cot_out)
+        side.run(lambda st_, a_=(_p(g_c3), _p(cot_out), None, C, _p(g_w3c), None, _p(side.ws), 1, C, Cout, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, cot_out)
         # radix mix -> pair-softmax backward -> se branch -> gap
         row = lambda c: torch.empty((c, N), dtype=a1.dtype, device=dev)  # noqa: E731
         glogT, gh, ggapT = row(2 * C), row(A), row(C)
@@ -1430,21 +1472,44 @@ class _BottleneckCMNode(Function):
         gx3 = nchw(C)
         _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx3), 0, _p(masks), _p(ws), N, C, C, G, H, W, BF16, st),
             "cot_conv3x3g_backward_data")
-        # bn1: the two contributions to da1 (channel-major from the 1x1s, NCHW from the 3x3) meet in its backward
-        g_c1 = cmj(C) if in_cm else nchw(C)
-        d_bn1_w, d_bn1_b = _bn_bwd_lay(L, gxc, gx3, c1, None, g_c1, None, bp.bn1, s_1, N, C, HW, 1, 1 | (4 if in_cm else 0) | (16 if in_cm else 0))
-        gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
         g_w1 = grad_sink.out_like(bp.conv1.weight)
-        if in_cm:
-            side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), 1, Cin, C, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
-            _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), 1, Cin, C, M, BF16, st), "cot_conv1x1_backward_data")
+        g_ds = ()
+        if opening:
+            # the pooled activation's gradient = the 3x3's NCHW contribution + the 1x1s' channel-major one (a strided add), back through the
+            # pooling, bn1 and conv1 at the input resolution; the projection: its BatchNorm takes the residual gradient in bn3's layout
+            gx3.add_(_cm_view(gxc))
+            g_a1f = torch.empty((N, C, H0, W0), dtype=a1.dtype, device=dev)
+            _ck(L.cot_avgpool3x3s2_backward(_p(gx3), _p(g_a1f), N * C, H0, W0, BF16, st), "cot_avgpool3x3s2_backward")
+            g_c1 = torch.empty_like(c1)
+            d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1f, c1, None, g_c1, bp.bn1, s_1, N, C, H0 * W0, 1, nws_c)
+            g_d0 = nchw(Cout)
+            d_ds_w, d_ds_b = _bn_bwd_lay(L, g_res, None, d0, None, g_d0, None, bp.ds_bn, s_d, N, Cout, HW, 0, 1 if res_cm else 0)
+            g_xs = torch.empty_like(xs)
+            _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(g_xs), None, Cin, 0, _p(ws), N, Cin, Cout, HW, BF16, st),
+                "cot_conv1x1_backward_data")
+            gx = torch.empty_like(xb)
+            _ck(L.cot_subsample2_backward(_p(g_xs), _p(gx), N * Cin, H0, W0, BF16, st), "cot_subsample2_backward")
+            g_wd = grad_sink.out_like(bp.ds_conv.weight)
+            side.run(lambda st_, a_=(_p(g_d0), _p(xs), None, Cin, _p(g_wd), None, _p(side.ws), N, Cin, Cout, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_d0, xs)
+            g_ds = (g_wd, d_ds_w, d_ds_b)
+            side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, C, H0 * W0, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
+            _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, C, H0 * W0, BF16, st),
+                "cot_conv1x1_backward_data")
         else:
-            side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, C, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
-            _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, C, HW, BF16, st), "cot_conv1x1_backward_data")
+            # bn1: the two contributions to da1 (channel-major from the 1x1s, NCHW from the 3x3) meet in its backward
+            g_c1 = cmj(C) if in_cm else nchw(C)
+            d_bn1_w, d_bn1_b = _bn_bwd_lay(L, gxc, gx3, c1, None, g_c1, None, bp.bn1, s_1, N, C, HW, 1, 1 | (4 if in_cm else 0) | (16 if in_cm else 0))
+            gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
+            if in_cm:
+                side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), 1, Cin, C, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
+                _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), 1, Cin, C, M, BF16, st), "cot_conv1x1_backward_data")
+            else:
+                side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, C, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
+                _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, C, HW, BF16, st), "cot_conv1x1_backward_data")
         side.join()
         g_cot = (g_wk, d_ke_w, d_ke_b, g_we0, d_em_w, d_em_b, g_we3, g_be3, g_gn_w, g_gn_b, g_wv, d_cv_w, d_cv_b, d_bn_w, d_bn_b,
                  g_w0, g_b0, d_sa_w, d_sa_b, g_w3, g_b3)
-        return (None, _cm_view(gx) if in_cm else gx, g_w1, d_bn1_w, d_bn1_b) + g_cot + (g_w3c, d_bn3_w, d_bn3_b)
+        return (None, _cm_view(gx) if in_cm else gx, g_w1, d_bn1_w, d_bn1_b) + g_cot + (g_w3c, d_bn3_w, d_bn3_b) + g_ds
 
 
 # ---- inference (BASELINE config 2: forward only, eval mode, no autograd).  The same launch sequence as _BottleneckNode.forward with

@@ -252,3 +252,35 @@ def test_eval_mode_bottleneck_single_call_sequence_against_fp32(kind, N, hw):
             assert clf.NODE_COUNTS["bottleneck_eval"] == 1
     torch.cuda.synchronize()
     assert truth.err(yc, yt) <= 1.5 * truth.err(yb, yt) + 2e-3, (truth.err(yc, yt), truth.err(yb, yt))
+
+
+@pytest.mark.parametrize("N,planes,H", [(80, 256, 28), (80, 512, 14)])
+def test_channel_major_stage_with_its_opening_block_against_fp32_truth(N, planes, H):
+    """layer3 / layer4 of CoTNet-50 from their stride-2 opening block on (avd pooling, projection shortcut) at the benchmark batch: the
+    opening block's layer / conv3 / bn3 / projection BatchNorm and the identity block behind it channel-major"""
+    from torch import nn
+    from cotnet_amd.resnet import downsample_conv
+    torch.manual_seed(planes + H)
+    inpl, outp = 2 * planes, 4 * planes
+    stage = nn.Sequential(Bottleneck(inpl, planes, stride=2, downsample=downsample_conv(inpl, outp, 1, stride=2)), Bottleneck(outp, planes)).to(DEV).train()
+    with torch.no_grad():
+        for p in stage.parameters():
+            if p.ndim == 1:
+                p.add_(0.3 * torch.randn_like(p))
+        for b in stage:
+            b.bn3.weight.fill_(0.8)
+    stage = to_mixed_bf16(stage)
+    with truth.switches(cm=True):
+        clf.plan_stage_layouts(stage)
+    assert [b._next_cm for b in stage] == [True, False]
+    x = torch.randn(N, inpl, H, H, device=DEV).bfloat16()
+    g = torch.randn(N, outp, H // 2, H // 2, device=DEV).bfloat16()
+    cand, base = dict(truth.SINGLE_NODE, cm=True), dict(truth.SINGLE_NODE, cm=False)
+    truth.check_against_truth(stage, x, g, cand=cand, base=base)
+    yc, gxc, gc, mc, node = truth.run(stage, x, g, want_module=True, **cand)
+    yb, gxb, gb, mb, node_b = truth.run(stage, x, g, want_module=True, **base)
+    assert node.startswith("_BottleneckCMNode") and node_b.startswith("_BottleneckNode")
+    assert set(gc) == set(gb) == {n for n, _ in stage.named_parameters()}
+    assert truth.err(yc, yb) < 2e-2 and truth.err(gxc, gxb) < 8e-2
+    for (n_, a), (_, b) in zip(mc.named_buffers(), mb.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), atol=2e-3, rtol=2e-3), n_

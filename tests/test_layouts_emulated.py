@@ -178,3 +178,73 @@ def test_eval_mode_bottleneck_as_one_call_sequence(kind, H, monkeypatch):
     assert ((y.float() - ref).abs() <= 2e-2 * (ref.abs() + ref.abs().mean())).all(), (y.float() - ref).abs().max()
     for cache in (clf._SIZES, clf._MASKS, clf._BSIZES):
         cache.clear()
+
+
+def test_channel_major_stage_with_its_opening_block(monkeypatch):
+    """a whole deep stage -- the stride-2 opening block (avd pooling in front of the layer, stride-2 projection shortcut; models/cotnet.py:
+    228-264, models/resnet.py:364-394) followed by identity blocks -- on the channel-major node: the opening block takes NCHW, runs its
+    layer / conv3 / bn3 / projection BatchNorm channel-major and hands a channel-major tensor on; against the NCHW single nodes"""
+    import copy
+
+    import torch
+    from torch import nn
+
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, pool3x3 as p3, radix_tail
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    from cotnet_amd.resnet import downsample_conv
+    torch.manual_seed(31)
+    N, H = 6, 28
+    stage = nn.Sequential(Bottleneck(128, 64, stride=2, downsample=downsample_conv(128, 256, 1, stride=2)).train(),
+                          Bottleneck(256, 64).train(), Bottleneck(256, 64).train())
+    assert stage[0].avd is not None
+    with torch.no_grad():
+        for p in stage.parameters():
+            if p.ndim == 1:
+                p.add_(0.3 * torch.randn_like(p))
+        for b in stage:
+            b.bn3.weight.fill_(0.8)
+    stage = to_mixed_bf16(stage)
+    ref = copy.deepcopy(stage)
+    x = torch.randn(N, 128, H, H).bfloat16()
+    g = torch.randn(N, 256, H // 2, H // 2).bfloat16()
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail, p3):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, clf._CM_SIZES, clf._CM_OK)
+    for cache in caches:
+        cache.clear()
+    monkeypatch.setattr(clf, "ENABLED", True)
+    monkeypatch.setattr(clf, "CM_LAYOUT", False)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g)
+    monkeypatch.setattr(clf, "CM_LAYOUT", True)
+    clf.plan_stage_layouts(stage)
+    assert [b._next_cm for b in stage] == [True, True, False]
+    xf = x.clone().requires_grad_(True)
+    h, seen = xf, []
+    for b in stage:
+        assert clf.cm_block_eligible(b, h)
+        h = b(h)
+        assert h.grad_fn.name().startswith("_BottleneckCMNode")
+        seen.append(clf._is_cm(h))
+    assert seen == [True, True, False]
+    h.backward(g)
+
+    def rel(a, b):
+        return ((a.float() - b.float()).abs().mean() / (b.float().abs().mean() + 1e-6)).item()
+
+    assert ((h.float() - yr.detach().float()).abs().max() / yr.detach().float().abs().max()).item() < 1e-2
+    assert rel(xf.grad, xr.grad) < 6e-2 and xf.grad.is_contiguous()
+    pr = dict(ref.named_parameters())
+    top = max(q.grad.float().abs().max() for q in pr.values())
+    for n_, p in stage.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, n_
+        if pr[n_].grad.float().abs().max() > 1e-3 * top and not n_.endswith("se.0.bias"):
+            assert rel(p.grad, pr[n_].grad) < 0.12, (n_, rel(p.grad, pr[n_].grad))
+    br, bf = dict(ref.named_buffers()), dict(stage.named_buffers())
+    for n_ in br:
+        assert torch.allclose(bf[n_].float(), br[n_].float(), atol=1e-3, rtol=1e-3), n_
+    for cache in caches:
+        cache.clear()
