@@ -1109,6 +1109,7 @@ def sa_block_forward(blk, x):
 # (HW, N*HW, W, 1) -- any torch consumer computes the right thing with it.  Same parameters, buffers and state_dict as the module
 # (models/cotnet.py:181-264).  COT_CM_LAYOUT=0 opts out.
 CM_LAYOUT = os.environ.get("COT_CM_LAYOUT", "1") != "0"
+CM_OPENING = os.environ.get("COT_CM_OPENING", "1") != "0"  # the stage's stride-2 opening block on the channel-major node too (A/B switch)
 _CM_SIZES = _lib.register_cache({})
 _CM_OK = _lib.register_cache({})
 
@@ -1149,7 +1150,7 @@ def _cm_static_ok(blk):
     identity = bp.ds_conv is None and not bp.avd and bp.conv1.in_channels == bp.conv3.out_channels
     # the stage's opening block (models/cotnet.py:228-264 with `avd` pooling in front of the layer and a stride-2 projection): conv1 /
     # bn1 / the pooling stay NCHW at the input resolution, the layer, conv3, bn3 and the projection's BatchNorm go channel-major
-    opening = bp.ds_conv is not None and bp.avd and bp.ds_stride == 2
+    opening = CM_OPENING and bp.ds_conv is not None and bp.avd and bp.ds_stride == 2
     return bp.static_ok and (identity or opening)
 
 
