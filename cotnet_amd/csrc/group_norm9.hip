@@ -421,6 +421,9 @@ int gn9_forward(const void* x, const void* gamma, const void* beta, void* y, flo
     if (HW % 8 == 0)                                                                                                 \
         COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 16>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma, \
                    (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay);                                    \
+    else if (HW % 4 == 0) /* 14 x 14: rows of 392 bytes start on 8-byte boundaries -- two 8-byte accesses per piece, not eight 2-byte ones */ \
+        COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 8>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma, \
+                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay);                                    \
     else                                                                                                             \
         COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 2>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma,  \
                    (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay)
@@ -437,6 +440,9 @@ int gn9_backward(const void* dy, const void* x, const float* mean, const float* 
 #define GN9_BWD(NT_, R_)                                                                                             \
     if (HW % 8 == 0)                                                                                                 \
         COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 16>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,    \
+                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay);                            \
+    else if (HW % 4 == 0)                                                                                            \
+        COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 8>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,     \
                    mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay);                            \
     else                                                                                                             \
         COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 2>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,     \
