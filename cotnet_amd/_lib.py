@@ -106,6 +106,10 @@ SYMBOLS = {
     "cot_conv3x3g_backward_data": (_I, [_P] * 3 + [_I] + [_P] * 2 + [_I] * 7 + [_P]),
     "cot_conv3x3g_backward_weight": (_I, [_P] * 5 + [_I] * 7 + [_P]),
     "cot_conv3x3g_backward_weight_guarded": (_I, [_P] * 5 + [_I] * 8 + [_P]),
+    "cot_conv3x3g_packed_bytes": (ctypes.c_int64, [_I] * 3),
+    "cot_conv3x3g_pack": (_I, [_P, _P] + [_I] * 8 + [_P]),
+    "cot_conv3x3g_forward_packed": (_I, [_P] * 3 + [_I] * 7 + [_P]),
+    "cot_conv3x3g_backward_data_packed": (_I, [_P] * 3 + [_I] * 8 + [_P]),
     "cot_convg_workspace": (ctypes.c_int64, [_I] * 7),
     "cot_conv1x1g_forward": (_I, [_P] * 4 + [_I] * 6 + [_P]),
     "cot_conv1x1g_backward_data": (_I, [_P] * 3 + [_I] * 7 + [_P]),

@@ -245,6 +245,104 @@ def _masks(L, H, W, device):
     return m
 
 
+# ---- grouped 3x3 weights packed ahead of time (round 5).  The LDS kernels run on a re-ordered copy of the weights;
+# the ordinary entry points make it per call (two 5 us launches per layer and step on the compute stream: 32 launches, 0.16 ms).  A
+# layer's weights change once per optimizer step and each packing is used once per step, so nothing is saved in work -- but the packing
+# need not sit on the critical path: right after the flat SGD kernels (FlatSGD.step -> after_optimizer_step) both packings of every
+# layer seen in the last forward are made on the weight-gradient side stream, into persistent buffers, and the next step's forward /
+# backward run `cot_conv3x3g_*_packed`.  Validity = (storage pointer, torch's version counter, the optimizer epoch below -- the flat
+# SGD kernel writes through raw pointers, which torch's counter does not see --, geometry).  Never inside a graph capture (a replay
+# would keep reading the packing of the capture): captured steps pack inline as before.  COT_PREPACK=0 opts out.
+PREPACK = os.environ.get("COT_PREPACK", "1") != "0"
+PARAM_EPOCH = [0]
+_PACKS = weakref.WeakKeyDictionary()   # nn.Conv2d -> {"geom": (N, C, G, H, W), 0: (key, buffer), 1: (key, buffer)}
+_PACK_EVENT = {}                       # device index -> event the compute stream has to wait for before its first packed launch
+
+
+def _capturing():
+    return _DEVICE_ONLY and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _pack_for(L, conv, mode, N, C, G, H, W):
+    """-> the valid packing of conv.weight for this call, or None (the caller then packs inline through the ordinary entry point).
+    Also remembers the geometry for after_optimizer_step."""
+    if not (PREPACK and _DEVICE_ONLY):
+        return None
+    e = _PACKS.get(conv)
+    if e is None:
+        e = _PACKS[conv] = {}
+    if _capturing():
+        e.pop("geom", None)
+        return None
+    wt = conv.weight
+    e["geom"] = (N, C, G, H, W)
+    ent = e.get(mode)
+    if ent is not None and ent[0] == (wt.data_ptr(), wt._version, PARAM_EPOCH[0], N, C, G, H, W):
+        ev = _PACK_EVENT.pop(wt.device.index, None)
+        if ev is not None:
+            torch.cuda.current_stream(wt.device).wait_event(ev)
+        return ent[1]
+    return None
+
+
+def after_optimizer_step(device):
+    """called by FlatSGD.step() once its kernels are issued: the parameters have changed (PARAM_EPOCH), and the 3x3 weights of the
+    layers the last forward ran are packed for the next step on the side stream"""
+    PARAM_EPOCH[0] += 1
+    if not (PREPACK and ENABLED and SIDE_WGRAD and _DEVICE_ONLY and device.type == "cuda") or _capturing():
+        return
+    ent = _SIDE_STREAMS.get(device.index)
+    if ent is None or not _PACKS:
+        return
+    L = _lib.lib()
+    side, cur = ent[0], torch.cuda.current_stream(device)
+    side.wait_stream(cur)  # behind the SGD kernels (and with them behind the whole backward pass that read the old packings)
+    st = ctypes.c_void_p(side.cuda_stream)
+    done = False
+    for conv, e in list(_PACKS.items()):
+        g = e.get("geom")
+        wt = conv.weight
+        if g is None or wt.device != device or wt.dtype != torch.bfloat16:
+            continue
+        N, C, G, H, W = g
+        key = (wt.data_ptr(), wt._version, PARAM_EPOCH[0], N, C, G, H, W)
+        for mode in (0, 1):
+            old = e.get(mode)
+            buf = old[1] if old is not None else None
+            if buf is None:
+                nb = int(L.cot_conv3x3g_packed_bytes(C, C, G))
+                if nb <= 0:
+                    break
+                buf = torch.empty(nb, dtype=torch.uint8, device=device)
+            if L.cot_conv3x3g_pack(_p(wt), _p(buf), mode, N, C, C, G, H, W, BF16, st) == 0:
+                e[mode] = (key, buf)
+                done = True
+            else:
+                e.pop(mode, None)  # (geometry off the LDS kernels: they gather the weights in place)
+    if done:
+        ev = torch.cuda.Event()
+        ev.record(side)
+        _PACK_EVENT[device.index] = ev
+
+
+def _conv3x3_fwd(L, conv, x, y, masks, ws, N, C, G, H, W):
+    pk = _pack_for(L, conv, 0, N, C, G, H, W)
+    if pk is not None:
+        _ck(L.cot_conv3x3g_forward_packed(_p(x), _p(pk), _p(y), N, C, C, G, H, W, BF16, _stream()), "cot_conv3x3g_forward_packed")
+    else:
+        _ck(L.cot_conv3x3g_forward(_p(x), _p(conv.weight), _p(y), _p(masks), _p(ws), N, C, C, G, H, W, BF16, _stream()), "cot_conv3x3g_forward")
+
+
+def _conv3x3_dgrad(L, conv, gy, gx, accumulate, masks, ws, N, C, G, H, W):
+    pk = _pack_for(L, conv, 1, N, C, G, H, W)
+    if pk is not None:
+        _ck(L.cot_conv3x3g_backward_data_packed(_p(gy), _p(pk), _p(gx), accumulate, N, C, C, G, H, W, BF16, _stream()),
+            "cot_conv3x3g_backward_data_packed")
+    else:
+        _ck(L.cot_conv3x3g_backward_data(_p(gy), _p(conv.weight), _p(gx), accumulate, _p(masks), _p(ws), N, C, C, G, H, W, BF16, _stream()),
+            "cot_conv3x3g_backward_data")
+
+
 class _Plan:
     """per-layer handles resolved once (nn.Sequential indexing and parameter walks cost more than a kernel launch)"""
     __slots__ = ("ke0", "ke1", "em0", "em1", "em3", "gn", "cv0", "cv1", "bn", "se0", "sebn", "se3", "params",
@@ -454,8 +552,7 @@ def _cot_forward(L, layer, x):
 
     # static context k = relu(bn(conv3x3_grouped(x)))                                             (ref :80)
     k_pre, k = new(C), new(C)
-    _ck(L.cot_conv3x3g_forward(_p(x), _p(pl.ke0.weight), _p(k_pre), _p(masks), _p(ws), N, C, C, pl.ke0.groups, H, W,
-                               BF16, st), "cot_conv3x3g_forward")
+    _conv3x3_fwd(L, pl.ke0, x, k_pre, masks, ws, N, C, pl.ke0.groups, H, W)
     s_k = stat(C, nws_c)
     _bn_fwd(L, k_pre, k, pl.ke1, s_k, 2 * C, N, C, HW, 1)
     # attention logits from [x | k]                                                             (ref :81-85)
@@ -646,8 +743,7 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     g_wk = grad_sink.out_like(ke0.weight)
     side.run(lambda st_, a_=(_p(gk_pre), _p(x), _p(g_wk), _p(masks), _p(side.ws), N, C, C, G, H, W, BF16,
                                                _guard_elems(x)): _ck(L.cot_conv3x3g_backward_weight_guarded(*a_, st_), "cot_conv3x3g_backward_weight"), gk_pre, x, masks)
-    _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx), 1, _p(masks), _p(ws), N, C, C, G, H, W,
-                                     BF16, st), "cot_conv3x3g_backward_data")
+    _conv3x3_dgrad(L, ke0, gk_pre, gx, 1, masks, ws, N, C, G, H, W)
     if own_side:
         side.join()
     # order = _Plan.params
@@ -993,8 +1089,7 @@ class _SplitAttnBlockNode(Function):
         s_1 = stat(Cw, nws_w)
         _bn_fwd(L, c1, a1, sp.bn1, s_1, 2 * Cw, N, Cw, HW, 1)
         c2, b2 = new(Cw), new(Cw)
-        _ck(L.cot_conv3x3g_forward(_p(a1), _p(sp.conv.weight), _p(c2), _p(masks), _p(ws), N, Cw, Cw, G, H, W, BF16, st),
-            "cot_conv3x3g_forward")
+        _conv3x3_fwd(L, sp.conv, a1, c2, masks, ws, N, Cw, G, H, W)
         s_0 = stat(Cw, nws_w)
         _bn_fwd(L, c2, b2, sp.bn0, s_0, 2 * Cw, N, Cw, HW, sp.act0)
         # the gate: pooled descriptor [N, Cw] -> fc1 -> BatchNorm over the batch + act -> fc2 -> x * sigmoid(logits)
@@ -1064,8 +1159,7 @@ class _SplitAttnBlockNode(Function):
         g_wc = grad_sink.out_like(sp.conv.weight)
         side.run(lambda st_, a_=(_p(g_c2), _p(a1), _p(g_wc), _p(masks), _p(side.ws), N, Cw, Cw, G, H, W, BF16, _guard_elems(a1)): _ck(L.cot_conv3x3g_backward_weight_guarded(*a_, st_), "cot_conv3x3g_backward_weight"), g_c2, a1, masks)
         g_a1 = g_b2  # (reuse: consumed by bn0's backward)
-        _ck(L.cot_conv3x3g_backward_data(_p(g_c2), _p(sp.conv.weight), _p(g_a1), 0, _p(masks), _p(ws), N, Cw, Cw, G, H, W, BF16, st),
-            "cot_conv3x3g_backward_data")
+        _conv3x3_dgrad(L, sp.conv, g_c2, g_a1, 0, masks, ws, N, Cw, G, H, W)
         g_c1 = torch.empty_like(c1)
         d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1, c1, None, g_c1, sp.bn1, s_1, N, Cw, HW, 1, nws_w)
         gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
@@ -1275,8 +1369,7 @@ class _BottleneckCMNode(Function):
             _bn_fwd_lay(L, c1, None, a1, a1c, bp.bn1, s_1, N, C, HW, 1, (1 if in_cm else 0) | 8)
         # static context: grouped 3x3 (NCHW) -> bn + relu -> k (channel-major)                                   (ref :80)
         k_pre, k = nchw(C), cmj(C)
-        _ck(L.cot_conv3x3g_forward(_p(a1), _p(pl.ke0.weight), _p(k_pre), _p(masks), _p(ws), N, C, C, G, H, W, BF16, st),
-            "cot_conv3x3g_forward")
+        _conv3x3_fwd(L, pl.ke0, a1, k_pre, masks, ws, N, C, G, H, W)
         s_k = stat(C, 0)
         _bn_fwd_lay(L, k_pre, None, k, None, pl.ke1, s_k, N, C, HW, 1, 4)
         # attention logits from [x | k]: two 1x1 convolutions on channel rows, GroupNorm writes the aggregation's weights NCHW (ref :81-85)
@@ -1471,8 +1564,7 @@ class _BottleneckCMNode(Function):
         g_wk = grad_sink.out_like(ke0.weight)
         side.run(lambda st_, a_=(_p(gk_pre), _p(a1), _p(g_wk), _p(masks), _p(side.ws), N, C, C, G, H, W, BF16, _guard_elems(a1)): _ck(L.cot_conv3x3g_backward_weight_guarded(*a_, st_), "cot_conv3x3g_backward_weight"), gk_pre, a1, masks)
         gx3 = nchw(C)
-        _ck(L.cot_conv3x3g_backward_data(_p(gk_pre), _p(ke0.weight), _p(gx3), 0, _p(masks), _p(ws), N, C, C, G, H, W, BF16, st),
-            "cot_conv3x3g_backward_data")
+        _conv3x3_dgrad(L, ke0, gk_pre, gx3, 0, masks, ws, N, C, G, H, W)
         g_w1 = grad_sink.out_like(bp.conv1.weight)
         g_ds = ()
         if opening:

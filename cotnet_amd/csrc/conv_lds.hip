@@ -255,6 +255,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
+// cot_conv3x3g_pack / cot_conv3x3g_*_packed (round 5): the weights of a layer change once per optimizer step, its two packings (forward,
+// data gradient) are each used once per step -- packing ahead of time saves no work but takes 32 small launches off the compute
+// stream's critical path (the host side packs on a side stream right after the optimizer step).  0 = pack and run (the ordinary entry
+// points), 1 = pack only, 2 = run on a packing made by an identical call in mode 1.
+thread_local int t_c3_pack = 0;
+
 // ====================================================================================================================
 // Grouped 3x3 convolution (stride 1, padding 1) -- CotLayer.key_embed[0] (models/cotnet.py:43-47; groups 4; CoXtLayer 8) --
 // on the same machinery: per group an implicit GEMM  Y (MM x HW) = sum over (tap, ci) Wr[tap][co][ci] * X[ci][p + off(tap)].
@@ -921,12 +927,12 @@ static int conv3x3g_res_gemm(const void* x, const void* w, void* y, void* ws, in
         };
         if (g_conv3x3_perm == 2 || overlap(slc) < overlap(8 * slc)) a.perm = 1;
     }
-    {   // repack the weights: [G][NTAP][MM][KK]
+    if (t_c3_pack != 2) {   // repack the weights: [G][NTAP][MM][KK]  (2 = `ws` already holds this call's packing: cot_conv3x3g_*_packed)
         const int64_t total = (int64_t)G * NTAP * MM * KK;
         COT_LAUNCH(conv3x3g_repack_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, (const bf16_t*)w,
                    (bf16_t*)ws, G, MM, KX, KK, NTAP, mode, MBLK, a.perm);
         int rc = check_launch("conv3x3g_repack_kernel");
-        if (rc) return rc;
+        if (rc || t_c3_pack == 1) return rc;  // (1 = pack only: cot_conv3x3g_pack)
     }
     if (flat) {
         if (K16) return launch_c3res<2, 1, 1, 1, 1>(a, blocks, stream);
@@ -1007,12 +1013,12 @@ int conv3x3g_lds_gemm(const void* x, const void* w, void* y, void* ws, int N, in
         a.tiles = ceil_div(H, TR);
         blocks = (int64_t)N * a.tiles * G;
     }
-    {   // repack the weights: [G][NTAP][MM][KK]
+    if (t_c3_pack != 2) {   // repack the weights: [G][NTAP][MM][KK]
         const int64_t total = (int64_t)G * NTAP * MM * KK;
         COT_LAUNCH(conv3x3g_repack_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, (const bf16_t*)w,
                    (bf16_t*)ws, G, MM, KX, KK, NTAP, mode, MBLK, 0);
         int rc = check_launch("conv3x3g_repack_kernel");
-        if (rc) return rc;
+        if (rc || t_c3_pack == 1) return rc;
     }
     if (flat) {
         if (K16) return launch_c3<2, 1, 1, 1, 1>(a, blocks, stream);

@@ -128,6 +128,7 @@ int bn_act_backward_lay(const void*, const void*, const void*, const void*, void
                         const float*, float*, float*, int, int, int, int, const float*, int, hipStream_t);
 int64_t bn_relu_mask_bytes(int N, int C, int HW, int esize);
 extern thread_local uint8_t* t_bn_mask;
+extern thread_local int t_c3_pack;
 extern int g_bn_fold, g_bn_grid_cap, g_bn_small_m, g_bn_split_target;
 template <typename T>
 int bn_act_forward(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, long long*,
@@ -806,6 +807,66 @@ int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int
     if (p) prof::mark();
     const int rc = cot_conv3x3g_backward_data_impl(gy, weight, gx, accumulate, masks, workspace, N, Cin, Cout, groups, H, W, dtype, stream);
     if (p) prof::annotate_op(14, N, Cin, Cout, H * W, groups, dtype, 0);
+    return rc;
+}
+
+// ---- packings made ahead of time (round 5): cot_conv3x3g_pack fills `packed` with exactly what the forward (mode 0) / data-gradient
+// (mode 1) call of the same geometry would pack into its workspace, the _packed entry points run on it without packing.
+struct C3PackScope {
+    explicit C3PackScope(int m) { t_c3_pack = m; }
+    ~C3PackScope() { t_c3_pack = 0; }
+};
+int64_t cot_conv3x3g_packed_bytes(int Cin, int Cout, int groups) {
+    if (Cin <= 0 || Cout <= 0 || groups <= 0 || Cin % groups || Cout % groups) return 0;
+    const int64_t kpf = ((Cin / groups) + 31) / 32 * 32, kpd = ((Cout / groups) + 31) / 32 * 32;
+    return (std::max((int64_t)Cout * kpf, (int64_t)Cin * kpd) * 10 * 2 + 255) / 256 * 256;
+}
+int cot_conv3x3g_pack(const void* weight, void* packed, int mode, int N, int Cin, int Cout, int groups, int H, int W, int dtype,
+                      void* stream) {
+    int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, (mode ? Cout : Cin) / (groups > 0 ? groups : 1));
+    if (rc) return rc;
+    if (!weight || !packed || (mode != 0 && mode != 1)) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer / mode not 0 | 1");
+    if ((rc = check_align16({weight, packed}))) return rc;
+    if (dtype != COT_BF16 || conv3x3g_general(Cin, Cout, groups, dtype))
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_pack: this convolution does not run on packed weights (general kernels)");
+    C3PackScope scope(1);
+    // (x / y are not touched in pack-only mode: the planner needs the geometry alone)
+    rc = conv3x3g_lds_gemm(packed, weight, packed, packed, N, Cin, Cout, groups, H, W, mode, 0, (hipStream_t)stream);
+    if (rc == -1) return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_pack: geometry off the LDS kernels (they gather the weights in place)");
+    return rc;
+}
+int cot_conv3x3g_forward_packed(const void* x, const void* packed, void* y, int N, int Cin, int Cout, int groups, int H, int W, int dtype,
+                                void* stream) {
+    int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, Cin / (groups > 0 ? groups : 1));
+    if (rc) return rc;
+    if (!x || !packed || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({x, packed, y}))) return rc;
+    if (dtype != COT_BF16 || conv3x3g_general(Cin, Cout, groups, dtype)) return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_forward_packed: general kernels");
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    {
+        C3PackScope scope(2);
+        rc = conv3x3g_lds_gemm(x, packed, y, const_cast<void*>(packed), N, Cin, Cout, groups, H, W, 0, 0, (hipStream_t)stream);
+    }
+    if (p) prof::annotate_op(13, N, Cin, Cout, H * W, groups, dtype, 0);
+    if (rc == -1) return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_forward_packed: geometry off the LDS kernels");
+    return rc;
+}
+int cot_conv3x3g_backward_data_packed(const void* gy, const void* packed, void* gx, int accumulate, int N, int Cin, int Cout, int groups,
+                                      int H, int W, int dtype, void* stream) {
+    int rc = conv3x3g_validate(N, Cin, Cout, groups, H, W, dtype, Cout / (groups > 0 ? groups : 1));
+    if (rc) return rc;
+    if (!gy || !packed || !gx) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if ((rc = check_align16({gy, packed, gx}))) return rc;
+    if (dtype != COT_BF16 || conv3x3g_general(Cin, Cout, groups, dtype)) return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_backward_data_packed: general kernels");
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    {
+        C3PackScope scope(2);
+        rc = conv3x3g_lds_gemm(gy, packed, gx, const_cast<void*>(packed), N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
+    }
+    if (p) prof::annotate_op(14, N, Cin, Cout, H * W, groups, dtype, 0);
+    if (rc == -1) return set_error(COT_ERR_UNSUPPORTED, "cot_conv3x3g_backward_data_packed: geometry off the LDS kernels");
     return rc;
 }
 

@@ -109,6 +109,9 @@ class FlatSGD:
         if self.ema_decay is not None and self._buf_src:
             torch._foreach_lerp_(self._buf_ema, [bf.float() if bf.dtype != torch.float32 else bf for bf in self._buf_src],
                                  1.0 - self.ema_decay)
+        if self.reducer.buckets:  # the parameters changed behind torch's version counters: caches keyed on them move on
+            from . import cot_layer_fused
+            cot_layer_fused.after_optimizer_step(self.reducer.buckets[0].pflat.device)
 
     def ema_state_dict(self):
         """the averaged weights under the model's own state_dict keys (fp32; integer buffers are copied as they are) --

@@ -257,6 +257,21 @@ int cot_conv3x3g_backward_weight(const void* gy, const void* x, void* gweight, c
 int cot_conv3x3g_backward_weight_guarded(const void* gy, const void* x, void* gweight, const void* masks, void* workspace, int N,
                                          int Cin, int Cout, int groups, int H, int W, int dtype, int x_guard_elems, void* stream);
 
+/* Packings made ahead of time (round 5).  The LDS kernels run on a re-ordered copy of the weights that the forward / data-gradient
+ * entry points above make per call in their workspace; a layer's weights change once per optimizer step, so a trainer can pack right
+ * after the step, off the critical path (cotnet_amd/cot_layer_fused.py does, on its side stream):
+ *   cot_conv3x3g_packed_bytes  size of one packing
+ *   cot_conv3x3g_pack          mode 0 = the packing cot_conv3x3g_forward would make for this geometry, 1 = cot_conv3x3g_backward_data's
+ *   cot_conv3x3g_*_packed      the same convolutions on such a packing (same geometry arguments as the pack call)
+ * COT_BF16, geometries the LDS kernels cover; otherwise COT_ERR_UNSUPPORTED (use the ordinary entry points). */
+int64_t cot_conv3x3g_packed_bytes(int Cin, int Cout, int groups);
+int cot_conv3x3g_pack(const void* weight, void* packed, int mode, int N, int Cin, int Cout, int groups, int H, int W, int dtype,
+                      void* stream);
+int cot_conv3x3g_forward_packed(const void* x, const void* packed, void* y, int N, int Cin, int Cout, int groups, int H, int W, int dtype,
+                                void* stream);
+int cot_conv3x3g_backward_data_packed(const void* gy, const void* packed, void* gx, int accumulate, int N, int Cin, int Cout, int groups,
+                                      int H, int W, int dtype, void* stream);
+
 /* ---- grouped 1x1 convolution, NCHW (CoXtLayer.embed[0] = Conv2d(2*dim, dim/2, 1, groups=2),
  * embed[3] = Conv2d(dim/2, 9*dim/8, 1, groups=2) with bias, conv1x1[0] = Conv2d(dim, dim, 1, groups=2),
  * models/cotnet.py:123-131).  weight [Co][Ci/groups] as torch stores it, bias NULL or [Co]; COT_BF16 or COT_F32, any channel

@@ -248,3 +248,34 @@ def test_channel_major_stage_with_its_opening_block(monkeypatch):
         assert torch.allclose(bf[n_].float(), br[n_].float(), atol=1e-3, rtol=1e-3), n_
     for cache in caches:
         cache.clear()
+
+
+@pytest.mark.parametrize("N,C,G,H", [(3, 256, 4, 14), (2, 512, 4, 7), (2, 64, 4, 56), (2, 128, 4, 28), (2, 384, 8, 14)])
+def test_conv3x3_on_weights_packed_ahead_of_time(N, C, G, H):
+    """cot_conv3x3g_pack + cot_conv3x3g_forward_packed / _backward_data_packed against the ordinary entry points (which pack per call):
+    bit-identical -- the key embedding of every stage (models/cotnet.py:43-47) and CoTNeXt's groups-8 form"""
+    import torch
+    L, P, BF = _EMUL, lc.P, lc.BF
+    torch.manual_seed(C + H)
+    x, gy = torch.randn(N, C, H, H).bfloat16(), torch.randn(N, C, H, H).bfloat16()
+    w = (torch.randn(C, C // G, 3, 3) / (9 * C // G) ** 0.5).bfloat16()
+    masks = torch.empty(int(L.cot_conv3x3g_masks_bytes(H, H)), dtype=torch.uint8)
+    assert L.cot_conv3x3g_masks(P(masks), H, H, None) == 0
+    ws = torch.empty(int(L.cot_conv3x3g_workspace(N, C, C, G, H, H)), dtype=torch.uint8)
+    y0, y1 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    gx0, gx1 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    assert L.cot_conv3x3g_forward(P(x), P(w), P(y0), P(masks), P(ws), N, C, C, G, H, H, BF, None) == 0
+    assert L.cot_conv3x3g_backward_data(P(gy), P(w), P(gx0), 0, P(masks), P(ws), N, C, C, G, H, H, BF, None) == 0
+    nb = int(L.cot_conv3x3g_packed_bytes(C, C, G))
+    pf, pd = torch.full((nb,), 0xEE, dtype=torch.uint8), torch.full((nb,), 0xEE, dtype=torch.uint8)
+    assert L.cot_conv3x3g_pack(P(w), P(pf), 0, N, C, C, G, H, H, BF, None) == 0, L.cot_last_error()
+    assert L.cot_conv3x3g_pack(P(w), P(pd), 1, N, C, C, G, H, H, BF, None) == 0, L.cot_last_error()
+    assert L.cot_conv3x3g_forward_packed(P(x), P(pf), P(y1), N, C, C, G, H, H, BF, None) == 0, L.cot_last_error()
+    assert L.cot_conv3x3g_backward_data_packed(P(gy), P(pd), P(gx1), 0, N, C, C, G, H, H, BF, None) == 0, L.cot_last_error()
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    acc = gx0.clone()
+    assert L.cot_conv3x3g_backward_data_packed(P(gy), P(pd), P(acc), 1, N, C, C, G, H, H, BF, None) == 0
+    ref = torch.full_like(x, float("nan"))
+    ref.copy_(gx0)
+    assert L.cot_conv3x3g_backward_data(P(gy), P(w), P(ref), 1, P(masks), P(ws), N, C, C, G, H, H, BF, None) == 0
+    assert torch.equal(acc, ref)
