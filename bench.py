@@ -74,7 +74,12 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (forward, backward, side-stream weight gradients, optimizer) into ONE HIP graph after the "
-                         "settling steps and replay it in the warm-up and timed steps (one GPU; DESIGN.md 5.3)")
+                         "settling steps and replay it in the warm-up and timed steps (DESIGN.md 5.3).  This is the DEFAULT for the "
+                         "mixed-precision training step (the step is 14.1 ms of device work and 13.5-15.7 ms of host work to issue it "
+                         "eagerly: a replay takes the host out of the measurement); N > 1: the compute part is the graph, the "
+                         "all-reduces and the SGD kernels follow every replay eagerly.  A failed capture falls back to eager steps "
+                         "and says so in the line")
+    ap.add_argument("--eager", action="store_true", help="issue every step launch by launch (no HIP graph)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="developer switch: on ONE GPU, run the N > 1 code path -- a world-of-one RCCL communicator, the buckets' "
                          "all-reduces on the communication stream, fp32 buckets, deferred communication around a graph")
@@ -735,6 +740,12 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    graph_explicit = args.graph
+    if args.graph and args.eager:
+        raise SystemExit("bench.py: --graph and --eager exclude each other")
+    if not args.eager and args.mode == "train" and mixed:
+        args.graph = True  # (default for the mixed-precision training step; see --graph)
+    graph_note = None
     if args.graph:
         assert not reducing or (args.mode == "train" and mixed), "--graph with N > 1: the mixed-precision training step (FlatSGD buckets)"
         gstream = torch.cuda.Stream()
@@ -771,26 +782,44 @@ def main():
         # with it during capture, which aborts the process)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        if reducing:
-            # N > 1: forward + backward (+ the bucket fills) are the graph; the gradient hooks run once, at capture, with
-            # communication deferred (GradBucketReducer.defer_comm), and every replay is followed by the buckets' all-reduces on
-            # the communication stream and the flat SGD kernels (FlatSGD.step(deferred=True): ~2 launches per bucket, no host
-            # synchronisation) -- the reference's order: backward, all-reduce, optimizer (train.py:264-293)
-            opt.reducer.defer_comm = True
-            barrier()
-            with torch.cuda.graph(graph, stream=gstream):
-                graph_loss = step_compute_only()
-            torch.cuda.synchronize()
-
+        captured = True
+        try:
+            if reducing:
+                # N > 1: forward + backward (+ the bucket fills) are the graph; the gradient hooks run once, at capture, with
+                # communication deferred (GradBucketReducer.defer_comm), and every replay is followed by the buckets' all-reduces on
+                # the communication stream and the flat SGD kernels (FlatSGD.step(deferred=True): ~2 launches per bucket, no host
+                # synchronisation) -- the reference's order: backward, all-reduce, optimizer (train.py:264-293)
+                opt.reducer.defer_comm = True
+                barrier()
+                with torch.cuda.graph(graph, stream=gstream):
+                    graph_loss = step_compute_only()
+                    if os.environ.get("COT_BENCH_FAIL_CAPTURE"):
+                        raise RuntimeError("COT_BENCH_FAIL_CAPTURE is set (test of the fallback)")
+            else:
+                with torch.cuda.graph(graph, stream=gstream):
+                    graph_loss = eager_step()
+                    if os.environ.get("COT_BENCH_FAIL_CAPTURE"):
+                        raise RuntimeError("COT_BENCH_FAIL_CAPTURE is set (test of the fallback)")
+        except Exception as e:  # a capture that does not work here must not cost the measurement: eager steps, and the line says so
+            captured = False
+            graph_note = f"capture failed ({type(e).__name__}: {str(e)[:200]}): the steps were issued eagerly"
+            print(f"[bench] {graph_note}", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        if world > 1:  # every rank or none (the two forms issue their collectives in different orders)
+            okt = torch.tensor([1 if captured else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if captured and int(okt.item()) == 0:
+                captured, graph_note = False, "capture failed on another rank: the steps were issued eagerly"
+        if not captured:
+            if reducing:
+                opt.reducer.defer_comm = False
+            args.graph = False
+        elif reducing:
             def step():  # noqa: F811
                 graph.replay()
                 opt.step(deferred=True)
                 return graph_loss
         else:
-            with torch.cuda.graph(graph, stream=gstream):
-                graph_loss = eager_step()
-            torch.cuda.synchronize()
-
             def step():  # noqa: F811
                 graph.replay()
                 return graph_loss
@@ -975,13 +1004,14 @@ def main():
             "host_issue_ms_per_step": round(issued / args.steps * 1e3, 3), "host_issue_ms_one_step_idle_queue": round(issue_one * 1e3, 3),
             **({"graph": ("forward + backward + bucket fills captured in one HIP graph after the settling steps; every warm-up / timed step = one "
                           "replay, then the buckets' all-reduces (RCCL, communication stream) and the flat SGD kernels issued eagerly") if reducing
-                else "whole step captured in one HIP graph after the settling steps; warm-up and timed steps are replays"} if args.graph else {}),
+                else "whole step captured in one HIP graph after the settling steps; warm-up and timed steps are replays"} if args.graph else
+               ({"graph": graph_note} if graph_note else {"graph": "off: every step issued launch by launch"})),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         default_cfg = (args.model == "cotnet50" and args.img == 224 and args.batch == 80 and args.mode == "train" and mixed
-                       and not explicit and not args.tune and not args.recipe and not args.graph)
+                       and not explicit and not args.tune and not args.recipe and not graph_explicit and not args.eager)
         if world == 1 and default_cfg and not args.no_secondary:
             torch.cuda.empty_cache()  # (the children run on this GPU while this process is idle)
             line["secondary"] = secondary_lines()
