@@ -18,5 +18,5 @@ T1=$(date +%s)
 timeout 900 python bench.py > $O/ev5_bench_default.json 2> $O/ev5_bench_default.err; echo "bench rc=$? wall=$(( $(date +%s) - T1 ))s"
 cut -c1-400 $O/ev5_bench_default.json
 timeout 300 python bench.py --recipe --no-cpu-baseline --no-secondary --no-pmc > $O/ev5_bench_recipe.json 2> $O/ev5_bench_recipe.err; cut -c1-300 $O/ev5_bench_recipe.json
-timeout 300 python bench.py --graph --no-cpu-baseline --no-secondary --no-pmc --no-kernel-timing > $O/ev5_bench_graph.json 2> $O/ev5_bench_graph.err; cut -c1-300 $O/ev5_bench_graph.json
+timeout 300 python bench.py --eager --no-cpu-baseline --no-secondary --no-pmc --no-kernel-timing > $O/ev5_bench_eager.json 2> $O/ev5_bench_eager.err; cut -c1-300 $O/ev5_bench_eager.json
 echo "session wall=$(( $(date +%s) - T0 ))s"
