@@ -52,8 +52,8 @@ tot = {"nchw": [0, 0, 0], "cnhw": [0, 0, 0]}
 for name, Ci, Co, HW, split, bias in CONVS:
     forms = [("nchw", (B, HW), None)] + ([("cnhw " + t, (1, B * HW), t) for t in TUNES] or [("cnhw", (1, B * HW), None)])
     for form, (N, hw), tune in forms:
-        if tune:
-            assert L.cot_set_tuning(int(tune.split("=")[0]), int(tune.split("=")[1])) == 0
+        for kv in (tune.split("+") if tune else []):  # ("48=2+49=4": several keys per variant)
+            assert L.cot_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1])) == 0
         nset = max(2, min(6, int(300e6 // ((Ci + Co) * N * hw * 2)) + 1))
         sets = []
         for _ in range(nset):
