@@ -1315,7 +1315,7 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int 
     a.k1 = x2 ? k1 : K; a.m1 = y2 ? m1 : M; a.N = N; a.K = K; a.M = M; a.HW = HW; a.accumulate = accumulate;
     a.xs1 = xs ? xs : (int64_t)a.k1 * HW; a.xs2 = (int64_t)(K - a.k1) * HW;
     a.ys1 = ys ? ys : (int64_t)a.m1 * HW; a.ys2 = (int64_t)(M - a.m1) * HW;
-    a.ni = 1; a.xcd_remap = 0; a.wpacked = wpacked; a.ablate = 0; a.stats = stats;
+    a.ni = 1; a.xcd_remap = 0; a.xswz = 0; a.wpacked = wpacked; a.ablate = 0; a.stats = stats;
     const int u16 = (g_conv_lds_tune[2] >> 1) & 1;  // tuning key 17 bit 1: 2-byte gathers everywhere (A/B; default: transposing reads)
     const bool wt = wpacked == 2;
     if (wt && (M % 8 != 0 || M < 8)) return -1;

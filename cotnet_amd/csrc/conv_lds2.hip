@@ -31,6 +31,7 @@ extern int g_conv_lds_tune[3];
 // workgroups per CU, where the layers are bandwidth-bound)
 int g_conv_lds2_tune = 0;
 int g_conv_big_fill = 200;  // cot_set_tuning key 46: BIG tiles -- output-channel blocks of 64 / 32 instead of 128 while the launch has fewer workgroups than this (0 = off; 200 measured best of 0 / 200 / 400 / 800, profiles/r05_probe_cnhw_fill.log)
+int g_conv_big_xswz = 1;  // cot_set_tuning key 48: BIG tiles -- bank-conflict-free (XOR-permuted) X stage, 0 = rows stored as they lie in memory
 int g_conv_flat_ns3 = 1;  // cot_set_tuning key 43: FLAT 128-row tiles take three stages instead of six when the launch exceeds one workgroup per CU
 int g_conv_ablate = 0;  // cot_set_tuning key 24 (diagnostic: see C1LdsArgs::ablate)
 
@@ -84,7 +85,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             xvB[ps] = (unsigned)((int64_t)nrel * a.xs2 + c * 8) * 2u;
         } else {
             constexpr int cpr = BPX / 8;  // chunks per row
-            const int row = q / cpr, c = q - row * cpr;
+            const int row = q / cpr, pos = q - row * cpr;
+            // xswz: position `pos` of k row `row` holds pixel chunk pos ^ 2*((row & 3) | ((row >> 3) & 1) << 2).  A stage row is
+            // 256 B = one sweep of the 64 banks, so the eight k rows a half-wave's transposing read touches (8g + 0..3, g = 0, 1
+            // or 2, 3; the same 32-byte column window in each) fell on the SAME eight banks: eight LDS cycles instead of one
+            // (SQ_LDS_BANK_CONFLICT 0.6 of SQ_LDS_IDX_ACTIVE, profiles/r03_conv_sq_counters.txt).  Permuted, they take eight
+            // different 32-byte windows; a row's chunks still come from the same 256 contiguous bytes of global memory.
+            const int c = (a.xswz && TRD) ? pos ^ (2 * ((row & 3) | (((row >> 3) & 1) << 2))) : pos;
             int pc = p0 + c * 8;
             if (pc + 8 > HW) pc = 0;  // partial last tile: columns never stored; any in-bounds bytes will do
             xvA[ps] = xvB[ps] = (unsigned)(row * HW + pc) * 2u;
@@ -139,6 +146,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             const int cc = min(col, a.ni * HW - (TRD ? 4 : 1));  // columns past the tile: any staged element
             const int img = cc / HW;
             aoff[cb] = img * BK * HW + (cc - img * HW) + row * HW;
+        } else if (TRD && a.xswz) {
+            const int sw = 2 * ((row & 3) | (((row >> 3) & 1) << 2));  // (row + 4, the second read: the same permutation)
+            aoff[cb] = (((col >> 3) ^ sw) << 3) + (col & 7) + row * BPX;
         } else {
             aoff[cb] = col + row * BPX;
         }
@@ -299,6 +309,7 @@ static int launch_c1v2(const C1LdsArgs& a, int tiles, hipStream_t stream) {
 int conv1x1_lds_gemm2(const C1LdsArgs& a0, hipStream_t stream) {
     C1LdsArgs a = a0;
     a.ablate = g_conv_ablate;
+    a.xswz = g_conv_big_xswz;
     const int N = a.N, M = a.M, HW = a.HW;
     // per-lane offsets are 32-bit: a workgroup's images / the weight rows must lie within 2 GB of the scalar bases
     const int64_t slab = std::max(a.xs1, a.xs2) * 2;  // bytes from one image to the next

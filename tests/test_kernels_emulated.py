@@ -431,6 +431,38 @@ def test_conv1x1_flat_three_stage_ring(N, Ci, Co, H, dma, request):
     assert "NS=3" in buf.value.decode() or "NS = 3" in buf.value.decode(), buf.value
 
 
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("N,Ci,Co,H,W,split", [(2, 160, 256, 20, 20, 0), (1, 64, 48, 28, 28, 32), (1, 96, 136, 1, 712, 0),
+                                                (1, 64, 32, 1, 1064, 0)])
+def test_conv1x1_big_tiles_permuted_x_stage(N, Ci, Co, H, W, split, dma, request):
+    """conv1x1_lds_fwd2 on 128-pixel tiles (H*W > 256): the X stage's 16-byte chunks XOR-permuted per k row against the bank
+    conflicts of the transposing reads (tuning key 48, default on) -- forward (one and two input slabs) and data gradient
+    bit-identical to the unpermuted stage, under both LDS-DMA landing models, partial last tiles included"""
+    torch.manual_seed(31)
+    dt = _lib.dtype_code(torch.bfloat16)
+    HW = H * W
+    x = torch.randn(N, Ci, H, W).bfloat16()
+    x1, x2 = (x[:, :split].contiguous(), x[:, split:].contiguous()) if split else (x, None)
+    w = (torch.randn(Co, Ci, 1, 1) * Ci ** -0.5).bfloat16()
+    gy = torch.randn(N, Co, H, W).bfloat16()
+    ws = torch.empty(max(_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 0), 256), dtype=torch.uint8)
+    _EMUL.emul_set_dma_mode(dma)
+    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(48, 1), _EMUL.emul_set_dma_mode(0)))
+    outs = []
+    for sw in (1, 0):
+        assert _EMUL.cot_set_tuning(48, sw) == 0
+        y, gx = torch.full((N, Co, H, W), float("nan")).bfloat16(), torch.full_like(x, float("nan"))
+        assert _EMUL.cot_conv1x1_forward(P(x1), P(x2) if split else None, split or Ci, P(w), None, P(y), N, Ci, Co, HW, dt,
+                                         None) == 0, _EMUL.cot_last_error()
+        assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, HW, dt, None) == 0
+        outs.append((y, gx))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.nn.functional.conv2d(x.float(), w.float())
+    assert torch.allclose(outs[0][0].float(), ref, atol=2e-2, rtol=2e-2)
+    gref = torch.nn.functional.conv_transpose2d(gy.float(), w.float())
+    assert torch.allclose(outs[0][1].float(), gref, atol=3e-2, rtol=3e-2)
+
+
 @pytest.mark.parametrize("ps_on", [False, True])
 @pytest.mark.parametrize("fold", [0, 1, "chan"])
 @pytest.mark.parametrize("N,C,H,W", [(5, 4, 8, 8), (3, 2, 16, 24), (40, 2, 4, 4)])
