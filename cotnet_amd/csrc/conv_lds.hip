@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
 #pragma unroll
     for (int ps = 0; ps < WPASS; ++ps) {
         const int q = min(ps * NT + tid, BM * 4 - 1);
-        const int row = q >> 2, pos = q & 3, c = pos ^ ((row >> 2) & 3);
+        const int row = q >> 2, pos = q & 3, c = pos ^ ((-(row >> 2)) & 3);
         const int rr = min(row, MM - 1);
         if (K16) woff[ps] = ((int64_t)(c >> 1) * MM + rr) * 16 + (c & 1) * 8;  // chunk c: tap 2t + (c>>1), channels 8*(c&1)..
         else woff[ps] = (int64_t)rr * KK + c * 8;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
 #pragma unroll
     for (int mbk = 0; mbk < MB; ++mbk) {
         const int row = mbk * 16 + i16;
-        boff[mbk] = row * 32 + (g ^ ((row >> 2) & 3)) * 8;
+        boff[mbk] = row * 32 + (g ^ ((-(row >> 2)) & 3)) * 8;
     }
     f32x4_t acc[CB][MB];
 #pragma unroll
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
     for (int ps = 0; ps < WP; ++ps) {
         const int q = min(ps * NT + tid, WPIECES - 1);
         const int tp = q / (BM * 4), within = q - tp * (BM * 4);
-        const int row = within >> 2, pos = within & 3, c = pos ^ ((row >> 2) & 3);
+        const int row = within >> 2, pos = within & 3, c = pos ^ ((-(row >> 2)) & 3);
         const int rr = min(row, MM - 1);
         if (K16) woff[ps] = ((2 * tp + (c >> 1)) * MM + rr) * 16 + (c & 1) * 8;  // tap 2 tp + (c >> 1) ("tap 9": zeros), channels 8 (c & 1)..
         else woff[ps] = (tp * MM + rr) * KK + c * 8;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
 #pragma unroll
     for (int mbk = 0; mbk < MB; ++mbk) {
         const int row = mbk * 16 + i16;
-        boff[mbk] = (row * 32 + (g ^ ((row >> 2) & 3)) * 8) * 2;
+        boff[mbk] = (row * 32 + (g ^ ((-(row >> 2)) & 3)) * 8) * 2;
     }
     f32x4_t acc[CB][MB];
 #pragma unroll
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
     const int t0 = (int)((int64_t)a.T * sl / a.S), t1 = (int)((int64_t)a.T * (sl + 1) / a.S);
 
     // this thread's piece of each stage: row tid/4, 8-pixel chunk tid%4 (swizzled LDS position as in the forward's W tile)
-    const int row = tid >> 2, pos = tid & 3, chunk = pos ^ ((row >> 2) & 3);
+    const int row = tid >> 2, pos = tid & 3, chunk = pos ^ ((-(row >> 2)) & 3);
     const int mrow = min(m0 + row, M - 1), jrow = min(j0 + row, J - 1);  // rows past the matrix: copies, never stored
     const bool second = a.x2 && jrow >= a.k1;
     const int xch = second ? J - a.k1 : (a.x2 ? a.k1 : J);               // channels per image of this row's X slab
@@ -1141,12 +1141,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wgrad_lds(const WgLdsArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int rw = wm * 64 + q * 16 + i16;
-        aoff[q] = rw * 32 + (g ^ ((rw >> 2) & 3)) * 8;
+        aoff[q] = rw * 32 + (g ^ ((-(rw >> 2)) & 3)) * 8;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int rw = wj * 32 + q * 16 + i16;
-        boff[q] = rw * 32 + (g ^ ((rw >> 2) & 3)) * 8;
+        boff[q] = rw * 32 + (g ^ ((-(rw >> 2)) & 3)) * 8;
         ones[q] = a.has_bias && j0 + rw == J;  // the bias gradient rides along as a column of ones
     }
     f32x4_t acc[4][2];

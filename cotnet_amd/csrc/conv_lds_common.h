@@ -281,7 +281,8 @@ struct C1LdsArgs {
     int ptiles;        // pixel tiles per image (BIG) / image groups (FLAT)
     int ni;            // FLAT: images per workgroup
     int xcd_remap;
-    int xswz;          // BIG tiles of conv_lds2.hip: the X stage's 16-byte chunks XOR-permuted per k row (see conv1x1_lds_fwd2)
+    int xswz;          // conv_lds2.hip: bit 0 = BIG tiles: the X stage's 16-byte chunks XOR-permuted per k row; bit 1 = the W tile's
+                       // chunk permutation in its conflict-free form (see conv1x1_lds_fwd2)
     int ablate;        // DIAGNOSTIC (cot_set_tuning key 24; results become wrong): bit 0 no copies after the prologue, bit 1 no
                        // fragment reads in the loop, bit 2 one MFMA per step, bit 3 no barriers, bit 4 no vmcnt waits
 };

@@ -436,7 +436,8 @@ def test_conv1x1_flat_three_stage_ring(N, Ci, Co, H, dma, request):
                                                 (1, 64, 32, 1, 1064, 0)])
 def test_conv1x1_big_tiles_permuted_x_stage(N, Ci, Co, H, W, split, dma, request):
     """conv1x1_lds_fwd2 on 128-pixel tiles (H*W > 256): the X stage's 16-byte chunks XOR-permuted per k row against the bank
-    conflicts of the transposing reads (tuning key 48, default on) -- forward (one and two input slabs) and data gradient
+    conflicts of the transposing reads, and the W tile's chunk permutation in the form that is conflict-free under the hardware's
+    ds_read_b128 lane groups (tuning key 48 bits 0 / 1, default on) -- forward (one and two input slabs) and data gradient
     bit-identical to the unpermuted stage, under both LDS-DMA landing models, partial last tiles included"""
     torch.manual_seed(31)
     dt = _lib.dtype_code(torch.bfloat16)
@@ -447,16 +448,17 @@ def test_conv1x1_big_tiles_permuted_x_stage(N, Ci, Co, H, W, split, dma, request
     gy = torch.randn(N, Co, H, W).bfloat16()
     ws = torch.empty(max(_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 0), 256), dtype=torch.uint8)
     _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(48, 1), _EMUL.emul_set_dma_mode(0)))
+    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(48, 3), _EMUL.emul_set_dma_mode(0)))
     outs = []
-    for sw in (1, 0):
+    for sw in (3, 0, 1, 2):  # (bit 0: the X stage, bit 1: the W tile's permutation in its conflict-free form)
         assert _EMUL.cot_set_tuning(48, sw) == 0
         y, gx = torch.full((N, Co, H, W), float("nan")).bfloat16(), torch.full_like(x, float("nan"))
         assert _EMUL.cot_conv1x1_forward(P(x1), P(x2) if split else None, split or Ci, P(w), None, P(y), N, Ci, Co, HW, dt,
                                          None) == 0, _EMUL.cot_last_error()
         assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, HW, dt, None) == 0
         outs.append((y, gx))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
     ref = torch.nn.functional.conv2d(x.float(), w.float())
     assert torch.allclose(outs[0][0].float(), ref, atol=2e-2, rtol=2e-2)
     gref = torch.nn.functional.conv_transpose2d(gy.float(), w.float())
