@@ -31,9 +31,22 @@ extern int g_conv_lds_tune[3];
 // workgroups per CU, where the layers are bandwidth-bound)
 int g_conv_lds2_tune = 0;
 int g_conv_big_fill = 200;  // cot_set_tuning key 46: BIG tiles -- output-channel blocks of 64 / 32 instead of 128 while the launch has fewer workgroups than this (0 = off; 200 measured best of 0 / 200 / 400 / 800, profiles/r05_probe_cnhw_fill.log)
-int g_conv_big_xswz = 3;  // cot_set_tuning key 48: bit 0 = BIG tiles: bank-conflict-free (XOR-permuted) X stage (0: rows stored as they lie in memory); bit 1 = W tile: the permutation that is conflict-free under the hardware's ds_read_b128 lane groups (0: rounds 2-4's)
+int g_conv_big_xswz = 7;  // cot_set_tuning key 48: bit 0 = BIG tiles: bank-conflict-free (XOR-permuted) X stage (0: rows stored as they lie in memory); bit 1 = W tile: the permutation that is conflict-free under the hardware's ds_read_b128 lane groups (0: rounds 2-4's); bit 2 = the transposed W tile's (data gradient), see wt_perm
 int g_conv_flat_ns3 = 1;  // cot_set_tuning key 43: FLAT 128-row tiles take three stages instead of six when the launch exceeds one workgroup per CU
 int g_conv_ablate = 0;  // cot_set_tuning key 24 (diagnostic: see C1LdsArgs::ablate)
+
+// Chunk permutation of the TRANSPOSED weight tile (WT kernels: k rows of CPR 16-byte channel chunks): position p of k row `row`
+// holds chunk p ^ wt_perm(row).  A half-wave's transposing read touches the eight rows 8g + q (g = 0, 1 or 2, 3; q = 0..3), 32
+// bytes of each; rows alias in the banks every 256 B / (16 B * CPR) rows, so the rows that alias must take different 32-byte windows:
+// window = ((g & 1) << 2 | q) >> (3 - log2(CPR / 2)).  fixed = 0: rounds 2-4's form ((g << 2 | q) & (CPR - 1)), which is that for
+// CPR = 8 but lets rows q and q ^ 1 share a window at CPR = 16 and rows of g = 0 / 1 at CPR = 4 (SQ_LDS_BANK_CONFLICT 0.47 / 0.41 of
+// SQ_LDS_IDX_ACTIVE in the data-gradient instances, profiles/r05_step_lds_conflicts_pmc.csv).  (row + 4: the same value.)
+template <int CPR> __device__ __forceinline__ int wt_perm(int row, int fixed) {
+    const int g1 = (row >> 3) & 1, q = row & 3;
+    if (!fixed) return ((((row >> 3) & 3) << 2) | q) & (CPR - 1);
+    constexpr int SH = CPR >= 16 ? 0 : (CPR == 8 ? 1 : 2);
+    return ((((g1 << 2) | q) >> SH) << 1) & (CPR - 1);
+}
 
 // template parameters as conv1x1_lds_fwd (conv_lds.hip); PF = fragment prefetch (register double buffer)
 template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD, int WT, int PF>
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
         if (WT) {
             constexpr int CPR = BM / 8;  // 16-byte chunks per k row
             const int row = q / CPR, pos = q - row * CPR;
-            const int c = pos ^ (((((row >> 3) & 3) << 2) | (row & 3)) & (CPR - 1));  // position `pos` holds channel chunk c
+            const int c = pos ^ wt_perm<CPR>(row, a.xswz & 4);  // position `pos` holds channel chunk c
             int mcol = m0 + c * 8;
             if (mcol + 8 > M) mcol = M - 8;  // channels past M (M % 8 == 0): in-bounds bytes, never stored
             wv[ps] = (unsigned)(row * M + mcol) * 2u;
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
         if (WT) {  // k row 8g + (i16 >> 2) (+4 for the second read), channels mbk*16 + 4*(i16 & 3) .. +3
             constexpr int CPR = BM / 8;
             const int row = 8 * g + (i16 >> 2), c = 2 * mbk + ((i16 & 3) >> 1);
-            const int pos = c ^ ((((g & 3) << 2) | (i16 >> 2)) & (CPR - 1));
+            const int pos = c ^ wt_perm<CPR>(row, a.xswz & 4);
             boff[mbk] = row * BM + pos * 8 + (i16 & 1) * 4;
         } else {
             const int row = mbk * 16 + i16;

@@ -430,7 +430,7 @@ int cot_set_tuning(int key, int value) {
         return COT_OK;
     }
     if (key == 48) {
-        g_conv_big_xswz = value & 3;
+        g_conv_big_xswz = value & 7;
         return COT_OK;
     }
     if (key == 42) {

@@ -433,7 +433,7 @@ def test_conv1x1_flat_three_stage_ring(N, Ci, Co, H, dma, request):
 
 @pytest.mark.parametrize("dma", [0, 1])
 @pytest.mark.parametrize("N,Ci,Co,H,W,split", [(2, 160, 256, 20, 20, 0), (1, 64, 48, 28, 28, 32), (1, 96, 136, 1, 712, 0),
-                                                (1, 64, 32, 1, 1064, 0)])
+                                                (1, 64, 32, 1, 1064, 0), (1, 256, 64, 1, 520, 0), (1, 128, 32, 1, 264, 0)])
 def test_conv1x1_big_tiles_permuted_x_stage(N, Ci, Co, H, W, split, dma, request):
     """conv1x1_lds_fwd2 on 128-pixel tiles (H*W > 256): the X stage's 16-byte chunks XOR-permuted per k row against the bank
     conflicts of the transposing reads, and the W tile's chunk permutation in the form that is conflict-free under the hardware's
@@ -448,9 +448,9 @@ def test_conv1x1_big_tiles_permuted_x_stage(N, Ci, Co, H, W, split, dma, request
     gy = torch.randn(N, Co, H, W).bfloat16()
     ws = torch.empty(max(_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 0), 256), dtype=torch.uint8)
     _EMUL.emul_set_dma_mode(dma)
-    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(48, 3), _EMUL.emul_set_dma_mode(0)))
+    request.addfinalizer(lambda: (_EMUL.cot_set_tuning(48, 7), _EMUL.emul_set_dma_mode(0)))
     outs = []
-    for sw in (3, 0, 1, 2):  # (bit 0: the X stage, bit 1: the W tile's permutation in its conflict-free form)
+    for sw in (7, 0, 1, 2, 4):  # (bit 0: the X stage, bits 1 / 2: the W tile's / transposed W tile's permutation, conflict-free form)
         assert _EMUL.cot_set_tuning(48, sw) == 0
         y, gx = torch.full((N, Co, H, W), float("nan")).bfloat16(), torch.full_like(x, float("nan"))
         assert _EMUL.cot_conv1x1_forward(P(x1), P(x2) if split else None, split or Ci, P(w), None, P(y), N, Ci, Co, HW, dt,
