@@ -172,6 +172,9 @@ const char* cot_last_kernel(void);
  *           deep stages): output-channel blocks of 64 / 32 instead of 128 while the launch has fewer workgroups than `value` (200 default, 0 = off)
  *   key 47: channel-resident BatchNorm: instances unrolled for 2 / 4 rounds where they cover the channel (1 default), 0 = always the
  *           full-capacity instance
+ *   key 48: LDS layouts of the 1x1 forward / data-gradient kernel against bank conflicts (7 default; results identical either way):
+ *           bit 0 = the X stage of 128-pixel tiles with its 16-byte chunks XOR-permuted per channel row, bit 1 / bit 2 = the weight
+ *           tile's / transposed weight tile's chunk permutation in the form that is conflict-free under the hardware's lane groups
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
  *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
  *           ring everywhere
