@@ -1,12 +1,12 @@
 #!/bin/bash
-# grouped 3x3, 16-channel groups on row tiles: odd channel-row stride (tuning key 49): per layer, then the whole step
+# after the LDS-layout fixes: fragment prefetch in the BIG tiles (23=4) and the few-tiles rule's threshold (46) again
 mkdir -p gpurun_out; export TMPDIR=/tmp; O=gpurun_out
-for v in 0 1 0 1; do COT_TUNING=49=$v timeout 300 python scripts/bench_conv_abi.py --iters 30 --only g4 2>&1 | grep -E "g4 .* 1  " | sed "s/^/49=$v /"; done | tee $O/slodd_abi.log | cut -c1-150
+timeout 300 python scripts/probe_cnhw.py 30 23=4+46=200 23=0+46=400 23=0+46=100 23=0+46=200 2>&1 | grep -v amdgpu.ids | sed -n 1,62p > $O/post_probe.log; cat $O/post_probe.log | cut -c1-120
 for rep in 1 2; do
-for t in "even:49=0" "odd:49=1"; do
+for t in "base:" "pf:23=4" "fill400:46=400" "fill100:46=100"; do
   name=${t%%:*}; tune=${t#*:}
-  COT_TUNING=$tune timeout 300 python bench.py --kernels new --steps 20 --warmup 6 --settle-seconds 5 --no-cpu-baseline --no-kernel-timing --no-secondary --no-pmc > $O/slodd_step_${name}_$rep.json 2> $O/slodd_step_${name}_$rep.err || tail -4 $O/slodd_step_${name}_$rep.err
+  COT_TUNING=$tune timeout 300 python bench.py --kernels new --steps 20 --warmup 6 --settle-seconds 5 --no-cpu-baseline --no-kernel-timing --no-secondary --no-pmc > $O/post_step_${name}_$rep.json 2> $O/post_step_${name}_$rep.err || tail -4 $O/post_step_${name}_$rep.err
   python -c "
 import json
-d=json.load(open('$O/slodd_step_${name}_$rep.json')); print('$name rep$rep', d['value'], d['ms_per_step'], d['final_loss'])"
-done; done | tee $O/slodd_step.log
+d=json.load(open('$O/post_step_${name}_$rep.json')); print('$name rep$rep', d['value'], d['ms_per_step'], d['final_loss'])"
+done; done | tee $O/post_step.log
