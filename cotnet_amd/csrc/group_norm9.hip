@@ -40,24 +40,41 @@ template <int NV> __device__ __forceinline__ void gn_block_sum_all(float (&v)[NV
     }
 }
 
+// SEG < 64 (round 5): SEG lanes per (image, group), 64 / SEG groups per wave -- small planes leave most of a wave idle otherwise
+// (8 pixels per lane: 7 lanes of 64 at 7 x 7, one wave per group: 5120 single-wave workgroups at B = 80; 11.1 -> 6.9 us forward,
+// 24.3 -> 13.2 us backward there, profiles/r05_gn9_packed_small_planes_ab.log).
+// The sums run over the SEG-lane segment (xor butterfly: every lane of the segment ends with the total).
+template <int NV, int SEG> __device__ __forceinline__ void gn_seg_sum_all(float (&v)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int o = SEG / 2; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+}
+
 // The group sits in registers PACKED (two bf16 per register; mfma_common.h "pieces"): all loads of a thread are issued
 // back to back and nothing touches them until the last one is on its way.  Rounds whose pieces run over a channel's end
 // (wave-uniform `tail`) are loaded wide all the same -- what follows is the next channel; lanes wholly past the end all
 // read the 16 bytes at the end -- unless that could leave the tensor (the end of the last (image, group)), and have
 // their excess elements cleared afterwards.
-template <int NT, int R, int AL>
+template <int NT, int R, int AL, int SEG = 64>
 __global__ void __launch_bounds__(NT)
 gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int G, int HW,
-               float eps, int lay) {
+               float eps, int lay, int NG) {
+    static_assert(SEG == 64 || (NT == 64 && R == 1 && (SEG == 32 || SEG == 16 || SEG == 8)), "packed form: one wave, one round");
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];  // 16 floats per reduced value
     float* smem = reinterpret_cast<float*>(cot_smem);
-    const int t = threadIdx.x, g = blockIdx.x % G;
-    const int wend = 64 * (uniform(t >> 6) + 1);        // one past this wave's last thread index
-    const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
+    // NG = (image, group) pairs of the tensor.  SEG == 64: one workgroup each; else 64 / SEG per wave (`live`: the last wave's spare segments)
+    const int t = SEG < 64 ? (int)threadIdx.x % SEG : (int)threadIdx.x;
+    int gid = SEG < 64 ? (int)blockIdx.x * (64 / SEG) + (int)threadIdx.x / SEG : (int)blockIdx.x;
+    const bool live = gid < NG;
+    if (!live) gid = NG - 1;
+    const int g = gid % G;
+    const int wend = SEG < 64 ? SEG : 64 * (uniform((int)threadIdx.x >> 6) + 1);  // one past the last lane index of this wave / segment
+    const int64_t total = (int64_t)NG * 9 * HW;  // elements in the tensor
     // per-tensor layout (round 5): bit 0 = x, bit 1 = y channel-major ([C][N][HW]: the group's channels are N*HW apart)
-    const int nimg = gridDim.x / G, img = blockIdx.x / G;
-    const int64_t nchw = (int64_t)blockIdx.x * 9 * HW, cmaj = ((int64_t)g * 9 * nimg + img) * HW;  // (n*G + g) * 9 channels
+    const int nimg = NG / G, img = gid / G;
+    const int64_t nchw = (int64_t)gid * 9 * HW, cmaj = ((int64_t)g * 9 * nimg + img) * HW;  // (n*G + g) * 9 channels
     const int64_t base = (lay & 1) ? cmaj : nchw, xcs = (lay & 1) ? (int64_t)nimg * HW : HW;
     const int64_t ybase = (lay & 2) ? cmaj : nchw, ycs = (lay & 2) ? (int64_t)nimg * HW : HW;
     uint32_t v[9][R][4];
@@ -94,7 +111,8 @@ gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, c
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[0] += packed_get(v[cl][r], e);
-    gn_block_sum_all<1>(s, smem);
+    if (SEG < 64) gn_seg_sum_all<1, SEG>(s);
+    else gn_block_sum_all<1>(s, smem);
     const float mean = s[0] * inv;
     float q[1] = {0.f};
 #pragma unroll
@@ -108,11 +126,12 @@ gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, c
                 if (!tail[r] || e < left) q[0] += d * d;
             }
     }
-    gn_block_sum_all<1>(q, smem);
+    if (SEG < 64) gn_seg_sum_all<1, SEG>(q);
+    else gn_block_sum_all<1>(q, smem);
     const float rstd = 1.f / sqrtf(q[0] * inv + eps);
-    if (t == 0) {
-        mean_out[blockIdx.x] = mean;
-        rstd_out[blockIdx.x] = rstd;
+    if (t == 0 && live) {
+        mean_out[gid] = mean;
+        rstd_out[gid] = rstd;
     }
 #pragma unroll
     for (int cl = 0; cl < 9; ++cl) {
@@ -123,24 +142,29 @@ gn9_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, c
             bf16_t o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(packed_get(v[cl][r], e) * ga + be);
-            if (p < HW) store_piece<8, AL>(y + ybase + cl * ycs + p, o, HW - p);
+            if (p < HW && live) store_piece<8, AL>(y + ybase + cl * ycs + p, o, HW - p);
         }
     }
 }
 
-template <int NT, int R, int AL>
+template <int NT, int R, int AL, int SEG = 64>
 __global__ void __launch_bounds__(NT)
 gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean_in,
                const float* __restrict__ rstd_in, const bf16_t* __restrict__ gamma, bf16_t* __restrict__ dx,
-               float* __restrict__ part, int G, int HW, int lay) {
+               float* __restrict__ part, int G, int HW, int lay, int NG) {
+    static_assert(SEG == 64 || (NT == 64 && R == 1 && (SEG == 32 || SEG == 16 || SEG == 8)), "packed form: one wave, one round");
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     float* smem = reinterpret_cast<float*>(cot_smem);
-    const int t = threadIdx.x, g = blockIdx.x % G;
-    const int wend = 64 * (uniform(t >> 6) + 1);
-    const int64_t total = (int64_t)gridDim.x * 9 * HW;  // elements in the tensor
+    const int t = SEG < 64 ? (int)threadIdx.x % SEG : (int)threadIdx.x;  // (see gn9_fwd_kernel)
+    int gid = SEG < 64 ? (int)blockIdx.x * (64 / SEG) + (int)threadIdx.x / SEG : (int)blockIdx.x;
+    const bool live = gid < NG;
+    if (!live) gid = NG - 1;
+    const int g = gid % G;
+    const int wend = SEG < 64 ? SEG : 64 * (uniform((int)threadIdx.x >> 6) + 1);
+    const int64_t total = (int64_t)NG * 9 * HW;  // elements in the tensor
     // per-tensor layout: bit 0 = dy, bit 1 = x, bit 2 = dx channel-major
-    const int nimg = gridDim.x / G, img = blockIdx.x / G;
-    const int64_t nchw = (int64_t)blockIdx.x * 9 * HW, cmaj = ((int64_t)g * 9 * nimg + img) * HW, cms = (int64_t)nimg * HW;
+    const int nimg = NG / G, img = gid / G;
+    const int64_t nchw = (int64_t)gid * 9 * HW, cmaj = ((int64_t)g * 9 * nimg + img) * HW, cms = (int64_t)nimg * HW;
     const int64_t gbase = (lay & 1) ? cmaj : nchw, gcs = (lay & 1) ? cms : HW;
     const int64_t base = (lay & 2) ? cmaj : nchw, xcs = (lay & 2) ? cms : HW;
     const int64_t dbase = (lay & 4) ? cmaj : nchw, dcs = (lay & 4) ? cms : HW;
@@ -168,7 +192,7 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
             }
         }
     }
-    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+    const float mean = mean_in[gid], rstd = rstd_in[gid];
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (tail[r]) {  // (dy alone decides: every use of x below is multiplied into a dy term or not stored)
@@ -204,7 +228,8 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
                 COT_KEEP_PACKED(xv[cl][r][i]);
                 COT_KEEP_PACKED(gv[cl][r][i]);
             }
-    gn_block_sum_all<18>(s, smem);
+    if (SEG < 64) gn_seg_sum_all<18, SEG>(s);
+    else gn_block_sum_all<18>(s, smem);
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int cl = 0; cl < 9; ++cl) {
@@ -215,7 +240,13 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
     const float inv = 1.f / (9.f * (float)HW);
     c1 *= inv;
     c2 *= inv;
-    if (t < 18) part[(int64_t)blockIdx.x * 18 + t] = s[t];
+    if (SEG < 64) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k)
+            if (t == k % SEG && live) part[(int64_t)gid * 18 + k] = s[k];
+    } else if (t < 18) {
+        part[(int64_t)gid * 18 + t] = s[t];
+    }
 #pragma unroll
     for (int cl = 0; cl < 9; ++cl) {
         const float ga = (float)gamma[g * 9 + cl];
@@ -228,7 +259,7 @@ gn9_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, cons
                 const float xh = (packed_get(xv[cl][r], e) - mean) * rstd;
                 o[e] = (bf16_t)(rstd * (ga * packed_get(gv[cl][r], e) - c1 - xh * c2));
             }
-            if (p < HW) store_piece<8, AL>(dx + dbase + cl * dcs + p, o, HW - p);
+            if (p < HW && live) store_piece<8, AL>(dx + dbase + cl * dcs + p, o, HW - p);
         }
     }
 }
@@ -412,21 +443,46 @@ int gn9_stats_finalize(const float* part, float* mean, float* rstd, int N, int C
     return check_launch("gn9_stats_finalize");
 }
 
+int g_gn9_pack = 1;  // cot_set_tuning key 49: planes of at most 128 pixels (7 x 7, 10 x 10) -- several (image, group) pairs per wave (1 default), 0 = one each
+// lanes per (image, group) of the packed form: the smallest of 8 / 16 / 32 that covers the plane's 8-pixel pieces, 64 = not packed
+static int gn9_seg(int HW) {
+    const int need = (HW + 7) / 8;
+    if (!g_gn9_pack || need > 16) return 64;  // (32 lanes per group at 14 x 14 -- 25 of them busy -- measured the same as one wave each)
+    return need <= 8 ? 8 : 16;
+}
+#define GN9_AL(KERNEL, SEG_, ...)                                                                            \
+    do {                                                                                                     \
+        if (HW % 8 == 0) COT_LAUNCH((KERNEL<64, 1, 16, SEG_>), pgrid, dim3(64), 0, stream, __VA_ARGS__);      \
+        else if (HW % 4 == 0) COT_LAUNCH((KERNEL<64, 1, 8, SEG_>), pgrid, dim3(64), 0, stream, __VA_ARGS__);  \
+        else COT_LAUNCH((KERNEL<64, 1, 2, SEG_>), pgrid, dim3(64), 0, stream, __VA_ARGS__);                   \
+    } while (0)
+#define GN9_PACKED(KERNEL, ...)                                          \
+    do {                                                                 \
+        const dim3 pgrid((unsigned)ceil_div(NG, 64 / seg));              \
+        if (seg == 8) GN9_AL(KERNEL, 8, __VA_ARGS__);                    \
+        else GN9_AL(KERNEL, 16, __VA_ARGS__);                            \
+    } while (0)
+
 int gn9_forward(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int N, int C,
                 int HW, float eps, int lay, hipStream_t stream) {
     const int cfg = gn9_config(HW), G = C / 9;
     if (!cfg) return COT_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)((int64_t)N * G));
+    const int seg = gn9_seg(HW), NG = N * G;
+    if (seg < 64) {
+        GN9_PACKED(gn9_fwd_kernel, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay, NG);
+        return check_launch("gn9_fwd_kernel");
+    }
 #define GN9_FWD(NT_, R_)                                                                                             \
     if (HW % 8 == 0)                                                                                                 \
         COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 16>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma, \
-                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay);                                    \
+                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay, (int)grid.x);                                    \
     else if (HW % 4 == 0) /* 14 x 14: rows of 392 bytes start on 8-byte boundaries -- two 8-byte accesses per piece, not eight 2-byte ones */ \
         COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 8>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma, \
-                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay);                                    \
+                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay, (int)grid.x);                                    \
     else                                                                                                             \
         COT_LAUNCH((gn9_fwd_kernel<NT_, R_, 2>), grid, dim3(NT_), 16 * 4, stream, (const bf16_t*)x, (const bf16_t*)gamma,  \
-                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay)
+                   (const bf16_t*)beta, (bf16_t*)y, mean, rstd, G, HW, eps, lay, (int)grid.x)
     GN9_SWITCH(cfg, GN9_FWD)
 #undef GN9_FWD
     return check_launch("gn9_fwd_kernel");
@@ -437,16 +493,25 @@ int gn9_backward(const void* dy, const void* x, const float* mean, const float* 
     const int cfg = gn9_config(HW), G = C / 9;
     if (!cfg) return COT_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)((int64_t)N * G));
+    const int seg = gn9_seg(HW), NG = N * G;
+    if (seg < 64) {
+        GN9_PACKED(gn9_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay, NG);
+        const int rc = check_launch("gn9_bwd_kernel");
+        if (rc) return rc;
+        COT_LAUNCH((gn9_bwd_params_kernel<bf16_t>), dim3(ceil_div(C, 32)), dim3(256), 0, stream, (const float*)workspace,
+                   (bf16_t*)dgamma, (bf16_t*)dbeta, N, C);
+        return check_launch("gn9_bwd_params_kernel");
+    }
 #define GN9_BWD(NT_, R_)                                                                                             \
     if (HW % 8 == 0)                                                                                                 \
         COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 16>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,    \
-                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay);                            \
+                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay, (int)grid.x);                            \
     else if (HW % 4 == 0)                                                                                            \
         COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 8>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,     \
-                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay);                            \
+                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay, (int)grid.x);                            \
     else                                                                                                             \
         COT_LAUNCH((gn9_bwd_kernel<NT_, R_, 2>), grid, dim3(NT_), 18 * 16 * 4, stream, (const bf16_t*)dy, (const bf16_t*)x,     \
-                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay)
+                   mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay, (int)grid.x)
     GN9_SWITCH(cfg, GN9_BWD)
 #undef GN9_BWD
     int rc = check_launch("gn9_bwd_kernel");

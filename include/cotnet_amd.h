@@ -175,6 +175,8 @@ const char* cot_last_kernel(void);
  *   key 48: LDS layouts of the 1x1 forward / data-gradient kernel against bank conflicts (7 default; results identical either way):
  *           bit 0 = the X stage of 128-pixel tiles with its 16-byte chunks XOR-permuted per channel row, bit 1 / bit 2 = the weight
  *           tile's / transposed weight tile's chunk permutation in the form that is conflict-free under the hardware's lane groups
+ *   key 49: GroupNorm of the attention logits on planes of at most 128 pixels (7 x 7, 10 x 10): several (image, group) pairs per
+ *           wave (1 default), 0 = one workgroup each
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
  *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
  *           ring everywhere

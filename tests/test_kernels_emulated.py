@@ -1549,10 +1549,15 @@ def test_radix_tail_channel_major_kernels(N, C, H, W, dtype):
     assert torch.allclose(gk.float(), kf.grad + add, atol=3 * tol, rtol=3 * tol)
 
 
+@pytest.mark.parametrize("pack", [1, 0])
 @pytest.mark.parametrize("N,G,H,W", [(2, 2, 8, 8), (1, 3, 24, 24), (2, 1, 14, 14), (3, 2, 7, 7), (1, 1, 40, 40),
-                                     (1, 1, 56, 56), (1, 2, 3, 5)])
-def test_group_norm9_kernels(N, G, H, W):
-    """cot_group_norm9_forward / _backward against torch's GroupNorm in fp32 on the same bf16-rounded operands"""
+                                     (1, 1, 56, 56), (1, 2, 3, 5), (5, 3, 7, 7), (3, 1, 14, 14), (3, 3, 10, 10), (1, 1, 16, 16)])
+def test_group_norm9_kernels(N, G, H, W, pack, request):
+    """cot_group_norm9_forward / _backward against torch's GroupNorm in fp32 on the same bf16-rounded operands; planes of at most
+    256 pixels with several (image, group) pairs per wave (tuning key 49, default) and with one each -- group counts that fill
+    the last wave and that do not"""
+    assert _EMUL.cot_set_tuning(49, pack) == 0
+    request.addfinalizer(lambda: _EMUL.cot_set_tuning(49, 1))
     torch.manual_seed(13)
     C, HW = 9 * G, H * W
     dt = _lib.dtype_code(torch.bfloat16)
