@@ -138,6 +138,7 @@ SYMBOLS = {
     "cot_radix_mix_backward_apply_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
     "cot_group_norm9_forward_lay": (_I, [_P] * 6 + [_I, _I, _I, ctypes.c_float, _I, _I, _P]),
     "cot_group_norm9_backward_lay": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P]),
+    "cot_group_norm9_backward_params": (_I, [_P] * 3 + [_I, _I, _I, _P]),
     "cot_bn_act_inference": (_I, [_P] * 7 + [_I, _I, _I, ctypes.c_float, _I, _I, _P]),
     "cot_profile_begin": (_I, []),
     "cot_profile_end": (_I, [ctypes.POINTER(ProfileRec), _I]),

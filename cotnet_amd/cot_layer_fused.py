@@ -707,8 +707,10 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     if HW <= 8192:
         ge3, g_gn_w, g_gn_b = torch.empty_like(e3), grad_sink.out_like(gn.weight), grad_sink.out_like(gn.bias)
         gn_ws = torch.empty(2 * N * Ce, dtype=torch.float32, device=dev)
-        _ck(L.cot_group_norm9_backward(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), _p(g_gn_w),
-                                       _p(g_gn_b), _p(gn_ws), N, Ce, HW, BF16, st), "cot_group_norm9_backward")
+        # (dx here; dgamma / dbeta -- a launch of their own -- beside the weight gradients)
+        _ck(L.cot_group_norm9_backward(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), None, None, _p(gn_ws), N, Ce, HW,
+                                       BF16, st), "cot_group_norm9_backward")
+        side.run(lambda st_, a_=(_p(gn_ws), _p(g_gn_w), _p(g_gn_b), N, Ce, BF16): _ck(L.cot_group_norm9_backward_params(*a_, st_), "cot_group_norm9_backward_params"), gn_ws)
     else:
         ge3, g_gn_w, g_gn_b = torch.ops.aten.native_group_norm_backward(
             gw, e3, gn_mean, gn_rstd, gn.weight, N, Ce, HW, gn.num_groups, [True, True, True])
@@ -1535,8 +1537,9 @@ class _BottleneckCMNode(Function):
         gn = pl.gn
         ge3, g_gn_w, g_gn_b = cmj(Ce), grad_sink.out_like(gn.weight), grad_sink.out_like(gn.bias)
         gn_ws = torch.empty(2 * N * Ce, dtype=torch.float32, device=dev)
-        _ck(L.cot_group_norm9_backward_lay(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), _p(g_gn_w), _p(g_gn_b), _p(gn_ws),
+        _ck(L.cot_group_norm9_backward_lay(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), None, None, _p(gn_ws),
                                            N, Ce, HW, 2 | 4, BF16, st), "cot_group_norm9_backward_lay")
+        side.run(lambda st_, a_=(_p(gn_ws), _p(g_gn_w), _p(g_gn_b), N, Ce, BF16): _ck(L.cot_group_norm9_backward_params(*a_, st_), "cot_group_norm9_backward_params"), gn_ws)
         ge1 = cmj(Ch)
         g_we3, g_be3 = grad_sink.out_like(em3.weight), grad_sink.out_like(em3.bias)
         if GX:

@@ -210,6 +210,7 @@ template <typename T> int pool3x3s2(int, const void*, const void*, void*, int64_
 int gn9_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, int, hipStream_t);
 int gn9_backward(const void*, const void*, const float*, const float*, const void*, void*, void*, void*, float*, int, int,
                  int, int, hipStream_t);
+int gn9_backward_params(const float* workspace, void* dgamma, void* dbeta, int N, int C, hipStream_t stream);
 int gn9f_forward(const void*, const void*, const void*, void*, float*, float*, int, int, int, float, hipStream_t);
 int gn9f_backward(const void*, const void*, const float*, const float*, const void*, void*, void*, void*, float*, int, int,
                   int, hipStream_t);
@@ -1307,7 +1308,7 @@ int cot_group_norm9_backward_lay(const void* dy, const void* x, const float* mea
     int rc = gn9_validate(N, C, HW, dtype);
     if (lay && dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_group_norm9_*_lay: COT_BF16 only");
     if (rc) return rc;
-    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace)
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !workspace || (!dgamma) != (!dbeta) || (!dgamma && dtype != COT_BF16))
         return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
     if ((rc = check_align16({dy, x, dx}))) return rc;
     if (dtype == COT_F32)
@@ -1315,6 +1316,13 @@ int cot_group_norm9_backward_lay(const void* dy, const void* x, const float* mea
     rc = gn9_backward(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, N, C, HW, lay, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_group_norm9_backward: %d pixels per plane exceed one workgroup", HW);
     return rc;
+}
+
+int cot_group_norm9_backward_params(const float* workspace, void* dgamma, void* dbeta, int N, int C, int dtype, void* stream) {
+    if (!workspace || !dgamma || !dbeta) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_group_norm9_backward_params: COT_BF16 only");
+    if (N <= 0 || C <= 0 || C % 9 != 0) return set_error(COT_ERR_INVALID_ARG, "bad N=%d / C=%d", N, C);
+    return gn9_backward_params(workspace, dgamma, dbeta, N, C, (hipStream_t)stream);
 }
 
 int cot_conv1x1_lds_covers(int K, int k1, int two_slabs, int HW) { return conv1x1_lds_covers(K, k1, two_slabs != 0, HW) ? 1 : 0; }

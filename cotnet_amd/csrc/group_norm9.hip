@@ -488,6 +488,13 @@ int gn9_forward(const void* x, const void* gamma, const void* beta, void* y, flo
     return check_launch("gn9_fwd_kernel");
 }
 
+// dgamma / dbeta from the per-(image, channel) sums gn9_bwd_kernel left in `workspace` ([N][C][2] floats): the second, tiny launch of
+// the backward -- its own entry point so that a caller may put it on the stream its other parameter gradients run on
+int gn9_backward_params(const float* workspace, void* dgamma, void* dbeta, int N, int C, hipStream_t stream) {
+    COT_LAUNCH((gn9_bwd_params_kernel<bf16_t>), dim3(ceil_div(C, 32)), dim3(256), 0, stream, workspace, (bf16_t*)dgamma, (bf16_t*)dbeta, N, C);
+    return check_launch("gn9_bwd_params_kernel");
+}
+
 int gn9_backward(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, void* dx,
                  void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int lay, hipStream_t stream) {
     const int cfg = gn9_config(HW), G = C / 9;
@@ -497,10 +504,8 @@ int gn9_backward(const void* dy, const void* x, const float* mean, const float* 
     if (seg < 64) {
         GN9_PACKED(gn9_bwd_kernel, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma, (bf16_t*)dx, workspace, G, HW, lay, NG);
         const int rc = check_launch("gn9_bwd_kernel");
-        if (rc) return rc;
-        COT_LAUNCH((gn9_bwd_params_kernel<bf16_t>), dim3(ceil_div(C, 32)), dim3(256), 0, stream, (const float*)workspace,
-                   (bf16_t*)dgamma, (bf16_t*)dbeta, N, C);
-        return check_launch("gn9_bwd_params_kernel");
+        if (rc || !dgamma) return rc;  // (dgamma == NULL: the caller launches gn9_backward_params itself, e.g. on another stream)
+        return gn9_backward_params(workspace, dgamma, dbeta, N, C, stream);
     }
 #define GN9_BWD(NT_, R_)                                                                                             \
     if (HW % 8 == 0)                                                                                                 \
@@ -515,10 +520,8 @@ int gn9_backward(const void* dy, const void* x, const float* mean, const float* 
     GN9_SWITCH(cfg, GN9_BWD)
 #undef GN9_BWD
     int rc = check_launch("gn9_bwd_kernel");
-    if (rc) return rc;
-    COT_LAUNCH((gn9_bwd_params_kernel<bf16_t>), dim3(ceil_div(C, 32)), dim3(256), 0, stream, (const float*)workspace,
-               (bf16_t*)dgamma, (bf16_t*)dbeta, N, C);
-    return check_launch("gn9_bwd_params_kernel");
+    if (rc || !dgamma) return rc;
+    return gn9_backward_params(workspace, dgamma, dbeta, N, C, stream);
 }
 
 int gn9f_backward(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, void* dx,

@@ -510,6 +510,10 @@ int cot_group_norm9_forward_lay(const void* x, const void* gamma, const void* be
 int cot_group_norm9_backward_lay(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma,
                                  void* dx, void* dgamma, void* dbeta, float* workspace, int N, int C, int HW, int lay, int dtype,
                                  void* stream);
+/* The GroupNorm backward is two launches: dx + per-(image, channel) sums into `workspace`, then dgamma / dbeta out of those sums.
+ * cot_group_norm9_backward[_lay] with dgamma == dbeta == NULL (COT_BF16) issues the first only; this entry point is the second --
+ * for callers that put parameter gradients on another stream (`workspace` must stay untouched until it has run). */
+int cot_group_norm9_backward_params(const float* workspace, void* dgamma, void* dbeta, int N, int C, int dtype, void* stream);
 /* ---- BatchNorm statistics out of the producing convolution's epilogue (models/cotnet.py:51-62, :228-264: every
  * conv1x1 -> BatchNorm pair of a Bottleneck).  On planes of more than 256 pixels (the 56 x 56 / 28 x 28 stages) the 1x1 kernels
  * can write, per (image, 128-pixel tile, channel), the sum and the sum of squares of the bf16 values they store:
