@@ -170,6 +170,7 @@ extern int g_conv_big_fill;
 extern int g_bn_chan_rr;
 extern int g_conv_big_xswz;
 extern int g_gn9_pack;
+extern int g_radix_pack7;
 extern int g_conv_lds2_tune;
 extern int g_conv_ablate;
 unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
@@ -437,6 +438,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 49) {
         g_gn9_pack = value ? 1 : 0;
+        return COT_OK;
+    }
+    if (key == 50) {
+        g_radix_pack7 = value ? 1 : 0;
         return COT_OK;
     }
     if (key == 42) {

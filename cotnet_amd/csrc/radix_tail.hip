@@ -101,40 +101,52 @@ __device__ __forceinline__ int64_t tail_base(int cm, int n, int c, int N, int C,
     return ((int64_t)(cm ? c * N + n : n * C + c)) * HW;
 }
 
-template <typename T, int V>
+// SEG < 64 (round 5): SEG lanes per plane, 64 / SEG planes per wave -- 7 x 7 planes as 7 lanes x 7 elements (V = 7, SEG = 8) instead of
+// 49 lanes x one 2-byte element and a wave per plane (40960 waves for 80 x 512 planes).  Sums: xor butterfly over the segment (every lane
+// ends with the total).  No early return in the kernels that shuffle: lanes of planes past the end follow along and store nothing.
+template <int SEG> __device__ __forceinline__ float seg_sum_f(float v) {
+    if (SEG == 64) return wave_sum_f(v);
+#pragma unroll
+    for (int o = SEG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T, int V, int SEG = 64>
 __global__ __launch_bounds__(256) void radix_gap_t_kernel(const T* __restrict__ y, const T* __restrict__ k,
                                                          T* __restrict__ gapT, int N, int C, int HW, int lay) {
-    const int lane = threadIdx.x & 63;
-    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (plane >= (int64_t)N * C) return;
+    const int lane = threadIdx.x & (SEG - 1);
+    int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
+    const bool live = plane < (int64_t)N * C;
+    if (SEG == 64 && !live) return;
+    if (!live) plane = (int64_t)N * C - 1;
     const int n = (int)(plane / C), c = (int)(plane % C);
     const T* yp = y + tail_base(lay & 1, n, c, N, C, HW);
     float acc = 0.f;
     if (k) {
         const T* kp = k + tail_base(lay & 2, n, c, N, C, HW);
-        for (int i = lane * V; i < HW; i += 64 * V) {
+        for (int i = lane * V; i < HW; i += SEG * V) {
             const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
 #pragma unroll
             for (int j = 0; j < V; ++j) acc += (float)a.v[j] + (float)b.v[j];
         }
     } else {  // plain global average pooling (the classifier head)
-        for (int i = lane * V; i < HW; i += 64 * V) {
+        for (int i = lane * V; i < HW; i += SEG * V) {
             const Vec<T, V> a = ldv<T, V>(yp + i);
 #pragma unroll
             for (int j = 0; j < V; ++j) acc += (float)a.v[j];
         }
     }
-    acc = wave_sum_f(acc);
-    if (lane == 0) gapT[(int64_t)c * N + n] = (T)(acc / (float)HW);
+    acc = seg_sum_f<SEG>(acc);
+    if (lane == 0 && live) gapT[(int64_t)c * N + n] = (T)(acc / (float)HW);
 }
 
-template <typename T, int V>
+template <typename T, int V, int SEG = 64>
 __global__ __launch_bounds__(256) void radix_mix_logits_kernel(const T* __restrict__ y, const T* __restrict__ k,
                                                               const T* __restrict__ logitsT, T* __restrict__ out,
                                                               T* __restrict__ attn, int N, int C, int HW, int lay) {
-    const int lane = threadIdx.x & 63;
-    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (plane >= (int64_t)N * C) return;
+    const int lane = threadIdx.x & (SEG - 1);
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
+    if (plane >= (int64_t)N * C) return;  // (no shuffles below)
     const int n = (int)(plane / C), c = (int)(plane % C);
     const float l0 = (float)logitsT[(int64_t)(2 * c) * N + n], l1 = (float)logitsT[(int64_t)(2 * c + 1) * N + n];
     const float a0 = 1.f / (1.f + __expf(l1 - l0)), a1 = 1.f - a0;  // softmax over the radix pair
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256) void radix_mix_logits_kernel(const T* __restri
     const T* yp = y + tail_base(lay & 1, n, c, N, C, HW);
     const T* kp = k + tail_base(lay & 2, n, c, N, C, HW);
     T* op = out + tail_base(lay & 4, n, c, N, C, HW);
-    for (int i = lane * V; i < HW; i += 64 * V) {
+    for (int i = lane * V; i < HW; i += SEG * V) {
         const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
         Vec<T, V> o;
 #pragma unroll
@@ -154,19 +166,21 @@ __global__ __launch_bounds__(256) void radix_mix_logits_kernel(const T* __restri
     }
 }
 
-template <typename T, int V>
+template <typename T, int V, int SEG = 64>
 __global__ __launch_bounds__(256) void radix_mix_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                   const T* __restrict__ k, const T* __restrict__ attn,
                                                                   T* __restrict__ glogitsT, int N, int C, int HW, int lay) {
-    const int lane = threadIdx.x & 63;
-    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (plane >= (int64_t)N * C) return;
+    const int lane = threadIdx.x & (SEG - 1);
+    int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
+    const bool live = plane < (int64_t)N * C;
+    if (SEG == 64 && !live) return;
+    if (!live) plane = (int64_t)N * C - 1;
     const int n = (int)(plane / C), c = (int)(plane % C);
     const T* gp = g + tail_base(lay & 1, n, c, N, C, HW);
     const T* yp = y + tail_base(lay & 2, n, c, N, C, HW);
     const T* kp = k + tail_base(lay & 4, n, c, N, C, HW);
     float s0 = 0.f, s1 = 0.f;
-    for (int i = lane * V; i < HW; i += 64 * V) {
+    for (int i = lane * V; i < HW; i += SEG * V) {
         const Vec<T, V> gv = ldv<T, V>(gp + i), a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -175,9 +189,9 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_reduce_kernel(const T* __re
             s1 += gg * (float)b.v[j];
         }
     }
-    s0 = wave_sum_f(s0);
-    s1 = wave_sum_f(s1);
-    if (lane == 0) {
+    s0 = seg_sum_f<SEG>(s0);
+    s1 = seg_sum_f<SEG>(s1);
+    if (lane == 0 && live) {
         const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
         const float gl = a0 * a1 * (s0 - s1);  // softmax backward for a pair: gl0 = a0*(s0 - (a0*s0 + a1*s1))
         glogitsT[(int64_t)(2 * c) * N + n] = (T)gl;
@@ -185,20 +199,20 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_reduce_kernel(const T* __re
     }
 }
 
-template <typename T, int V>
+template <typename T, int V, int SEG = 64>
 __global__ __launch_bounds__(256) void radix_mix_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ attn,
                                                                  const T* __restrict__ ggapT, T* __restrict__ gy,
                                                                  T* __restrict__ gk, int N, int C, int HW, int lay) {
-    const int lane = threadIdx.x & 63;
-    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (plane >= (int64_t)N * C) return;
+    const int lane = threadIdx.x & (SEG - 1);
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
+    if (plane >= (int64_t)N * C) return;  // (no shuffles below)
     const int n = (int)(plane / C), c = (int)(plane % C);
     const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
     const float add = (float)ggapT[(int64_t)c * N + n] / (float)HW;  // d mean_hw(y + k)
     const T* gp = g + tail_base(lay & 1, n, c, N, C, HW);
     T* gyp = gy + tail_base(lay & 2, n, c, N, C, HW);
     T* gkp = gk + tail_base(lay & 4, n, c, N, C, HW);
-    for (int i = lane * V; i < HW; i += 64 * V) {
+    for (int i = lane * V; i < HW; i += SEG * V) {
         const Vec<T, V> gv = ldv<T, V>(gp + i);
         Vec<T, V> oy, ok;
 #pragma unroll
@@ -295,6 +309,18 @@ static inline int tail_vec(size_t esize, int HW) {
         else COT_LAUNCH((KERNEL<T, 1>), grid, block, 0, s, __VA_ARGS__);                                   \
     } while (0)
 
+int g_radix_pack7 = 1;  // cot_set_tuning key 50: 7 x 7 planes of bf16 -- 8 planes per wave, 7 lanes x 7 elements each (1 default), 0 = one wave per plane
+// the channel-major-descriptor kernels (radix_gap_t / mix_logits / mix_bwd_reduce / mix_bwd_apply): 7 x 7 planes take the packed form
+#define TAIL_DISPATCH7(KERNEL, ...)                                                                                \
+    do {                                                                                                           \
+        if (HW == 49 && sizeof(T) == 2 && g_radix_pack7) {                                                         \
+            const dim3 grid7((unsigned)ceil_div64(planes, 32)), block7(256);                                       \
+            COT_LAUNCH((KERNEL<T, 7, 8>), grid7, block7, 0, s, __VA_ARGS__);                                       \
+        } else {                                                                                                   \
+            TAIL_DISPATCH(KERNEL, __VA_ARGS__);                                                                    \
+        }                                                                                                          \
+    } while (0)
+
 template <typename T> int radix_gap(const void* y, const void* k, void* gap, int64_t planes, int HW, hipStream_t s) {
     TAIL_DISPATCH(radix_gap_kernel, (const T*)y, (const T*)k, (T*)gap, planes, HW);
     return check_launch("radix_gap");
@@ -328,21 +354,21 @@ int se_gate_bwd(const void* g, const void* x, const void* logit, void* gx, void*
 
 template <typename T> int radix_gap_t(const void* y, const void* k, void* gapT, int N, int C, int HW, int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
-    TAIL_DISPATCH(radix_gap_t_kernel, (const T*)y, (const T*)k, (T*)gapT, N, C, HW, lay);
+    TAIL_DISPATCH7(radix_gap_t_kernel, (const T*)y, (const T*)k, (T*)gapT, N, C, HW, lay);
     return check_launch("radix_gap_t");
 }
 template <typename T>
 int radix_mix_logits(const void* y, const void* k, const void* logitsT, void* out, void* attn, int N, int C, int HW,
                      int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
-    TAIL_DISPATCH(radix_mix_logits_kernel, (const T*)y, (const T*)k, (const T*)logitsT, (T*)out, (T*)attn, N, C, HW, lay);
+    TAIL_DISPATCH7(radix_mix_logits_kernel, (const T*)y, (const T*)k, (const T*)logitsT, (T*)out, (T*)attn, N, C, HW, lay);
     return check_launch("radix_mix_logits");
 }
 template <typename T>
 int radix_mix_bwd_reduce(const void* g, const void* y, const void* k, const void* attn, void* glogitsT, int N, int C,
                          int HW, int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
-    TAIL_DISPATCH(radix_mix_bwd_reduce_kernel, (const T*)g, (const T*)y, (const T*)k, (const T*)attn, (T*)glogitsT, N,
+    TAIL_DISPATCH7(radix_mix_bwd_reduce_kernel, (const T*)g, (const T*)y, (const T*)k, (const T*)attn, (T*)glogitsT, N,
                   C, HW, lay);
     return check_launch("radix_mix_bwd_reduce");
 }
@@ -350,7 +376,7 @@ template <typename T>
 int radix_mix_bwd_apply(const void* g, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C, int HW,
                         int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
-    TAIL_DISPATCH(radix_mix_bwd_apply_kernel, (const T*)g, (const T*)attn, (const T*)ggapT, (T*)gy, (T*)gk, N, C, HW, lay);
+    TAIL_DISPATCH7(radix_mix_bwd_apply_kernel, (const T*)g, (const T*)attn, (const T*)ggapT, (T*)gy, (T*)gk, N, C, HW, lay);
     return check_launch("radix_mix_bwd_apply");
 }
 

@@ -177,6 +177,8 @@ const char* cot_last_kernel(void);
  *           tile's / transposed weight tile's chunk permutation in the form that is conflict-free under the hardware's lane groups
  *   key 49: GroupNorm of the attention logits on planes of at most 128 pixels (7 x 7, 10 x 10): several (image, group) pairs per
  *           wave (1 default), 0 = one workgroup each
+ *   key 50: radix-2 tail kernels with channel-major descriptors on 7 x 7 bf16 planes: eight planes per wave, 7 lanes x 7 elements
+ *           each (1 default), 0 = one wave per plane
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
  *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
  *           ring everywhere

@@ -1512,10 +1512,13 @@ def test_fused_cot_layer_node_on_emulated_kernels(cls, C, H, monkeypatch):
         cache.clear()
 
 
+@pytest.mark.parametrize("pack7", [1, 0])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,C,H,W", [(3, 8, 8, 8), (2, 16, 14, 14), (5, 12, 7, 7), (1, 4, 3, 5)])
-def test_radix_tail_channel_major_kernels(N, C, H, W, dtype):
+@pytest.mark.parametrize("N,C,H,W", [(3, 8, 8, 8), (2, 16, 14, 14), (5, 12, 7, 7), (1, 4, 3, 5), (3, 11, 7, 7), (1, 3, 7, 7)])
+def test_radix_tail_channel_major_kernels(N, C, H, W, dtype, pack7, request):
     """cot_radix_gap_t / _mix_logits / _mix_backward_reduce / _mix_backward_apply against the torch formulas"""
+    assert _EMUL.cot_set_tuning(50, pack7) == 0  # (7 x 7 bf16 planes: eight per wave, 7 lanes x 7 elements, or one wave each)
+    request.addfinalizer(lambda: _EMUL.cot_set_tuning(50, 1))
     torch.manual_seed(9)
     HW = H * W
     dt = _lib.dtype_code(dtype)
