@@ -521,7 +521,8 @@ def secondary_lines(timeout_s=170):
             d = json.loads(line)
             out[key] = {"what": what, "metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                         "steps": d["steps"], "dtype": d["dtype"], "per_gpu_batch": d["config"]["per_gpu_batch"],
-                        "nodes_per_step": d["config"].get("nodes_per_step"), "kernel_selection": d["config"]["kernel_selection"],
+                        "nodes_per_step": d["config"].get("nodes_per_step"), "module_fallbacks_per_step": d["config"].get("module_fallbacks_per_step"),
+                        "kernel_selection": d["config"]["kernel_selection"],
                         "wall_s": round(time.perf_counter() - t0, 1)}
         except Exception as e:  # (timeout, JSON trouble: recorded)
             out[key] = {"what": what, "error": repr(e)[:300]}
@@ -850,8 +851,11 @@ def main():
     if args.graph and reducing:
         opt.reducer.defer_comm = False  # (the eager steps from here on reduce from their hooks again)
     _clf0.reset_node_counts()
+    from cotnet_amd import _lib as _lib0
+    _lib0.FALLBACKS.clear()  # (calls a wrapper handed back to the torch module it wraps during this one step: {} on the BASELINE configurations' hot path)
     eager_step()
     torch.cuda.synchronize()
+    module_fallbacks = dict(_lib0.FALLBACKS)
     n_blocks = sum(1 for m in model.modules() if type(m).__name__ in ("Bottleneck", "CoTBottleneck"))
     nodes_per_step = dict(_clf0.NODE_COUNTS, residual_blocks=n_blocks)
     nodes_per_step["single_node_blocks"] = (f"{nodes_per_step['bottleneck'] + nodes_per_step['bottleneck_channel_major'] + nodes_per_step['split_attn_block'] + nodes_per_step['bottleneck_eval']}"
@@ -995,7 +999,7 @@ def main():
                        "conv3x3": __import__("cotnet_amd.conv3x3g", fromlist=["MODE"]).MODE or "module",
                        "group_norm9": __import__("cotnet_amd.group_norm9", fromlist=["MODE"]).MODE or "module",
                        "cot_layer_single_node_enabled": __import__("cotnet_amd.cot_layer_fused", fromlist=["ENABLED"]).ENABLED,
-                       "nodes_per_step": nodes_per_step,
+                       "nodes_per_step": nodes_per_step, "module_fallbacks_per_step": module_fallbacks,
                        "grad_sync": (f"RCCL all-reduce (AVG), flat {'fp32' if args.grad_dtype == 'fp32' else 'parameter-dtype'} buckets, side stream"
                                      if reducing else "none (1 GPU)")},
             "final_loss": round(final_loss, 4),

@@ -153,6 +153,24 @@ def build(verbose=False):
     return LIB_PATH
 
 
+# Module fallbacks.  Every wrapper (conv1x1, conv3x3g, fused_bn, group_norm9, pool3x3, stem7x7, head_fused) serves a tensor that is off its
+# kernels' grid with the torch module it wraps.  While the library's kernels were asked for (the wrapper's switch is on) and the tensor is
+# on a GPU, each such call is counted here per site (bench.py prints the counters as `module_fallbacks`), and COT_STRICT_DISPATCH=1
+# turns it into an error -- for deployments that must never leave the hand-written path silently.
+STRICT_DISPATCH = os.environ.get("COT_STRICT_DISPATCH", "0") == "1"
+FALLBACKS = {}
+
+
+def fallback(site, x=None, detail=""):
+    if x is not None and not getattr(x, "is_cuda", False):
+        return
+    FALLBACKS[site] = FALLBACKS.get(site, 0) + 1
+    if STRICT_DISPATCH:
+        shape = tuple(x.shape) if x is not None else ()
+        raise RuntimeError(f"{site}: {shape} {getattr(x, 'dtype', '')} {detail} is off the library's kernels and COT_STRICT_DISPATCH=1 "
+                           "(the torch module would have run)")
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -215,6 +215,8 @@ def conv1x1(conv, x, x2=None):
         return _Conv1x1gHip.apply(x, conv.weight, conv.bias, conv.groups)
     if MODE == "matmul" and eligible(conv, x):
         return _Conv1x1.apply(x, conv.weight, conv.bias)
+    if MODE == "hip":
+        _lib.fallback("conv1x1", x, f"-> {conv.out_channels}, kernel {tuple(conv.kernel_size)}, stride {tuple(conv.stride)}, groups {conv.groups}")
     return conv(x)
 
 

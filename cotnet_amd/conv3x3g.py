@@ -109,4 +109,6 @@ def conv3x3(conv, x):
     """`conv(x)` for an nn.Conv2d; see the module docstring for when the HIP kernels serve it"""
     if MODE == "hip" and eligible(conv, x):
         return _Conv3x3G.apply(x, conv.weight, conv.groups)
+    if MODE == "hip":
+        _lib.fallback("conv3x3", x, f"-> {conv.out_channels}, stride {tuple(conv.stride)}, groups {conv.groups}")
     return conv(x)

@@ -121,6 +121,8 @@ def fused_bn_act(x, bn, act=None, residual=None):
                                     and residual.is_contiguous() and residual.data_ptr() % 16 == 0))
           and not (residual is not None and _ACTS.get(act) == 2))  # (SiLU after a residual add: the kernels have no backward for it)
     if not ok:
+        if ENABLED:
+            _lib.fallback("fused_bn_act", x, f"act {act}, residual {residual is not None}, training {bn.training}")
         return _torch_path(x, bn, act, residual)
     # num_batches_tracked += 1 (nn.BatchNorm2d.forward's bookkeeping) is done by the statistics kernel itself
     return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,

@@ -64,4 +64,6 @@ def eligible(gn, x):
 def group_norm9(gn, x):
     if MODE == "hip" and eligible(gn, x):
         return _GroupNorm9.apply(x, gn.weight, gn.bias, float(gn.eps))
+    if MODE == "hip":
+        _lib.fallback("group_norm9", x, f"groups {gn.num_groups}")
     return gn(x)

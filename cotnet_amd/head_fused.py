@@ -97,6 +97,8 @@ def head(pool, fc, x, drop_p=0.0):
     passes 0 outside training, models/resnet.py:607-609)"""
     if MODE == "hip" and eligible(pool, fc, x):
         return _Head.apply(x, fc.weight, fc.bias, float(drop_p))
+    if MODE == "hip":
+        _lib.fallback("head", x)
     x = pool(x)
     if drop_p > 0.0:
         x = torch.nn.functional.dropout(x, p=float(drop_p), training=True)

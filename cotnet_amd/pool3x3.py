@@ -164,4 +164,6 @@ def pool(module, x):
         if isinstance(module, nn.MaxPool2d):
             return _MaxPool.apply(x)
         return (_AvgPool2 if _pair(module.kernel_size) == (2, 2) else _AvgPool).apply(x)
+    if MODE == "hip":
+        _lib.fallback("pool", x, type(module).__name__)
     return module(x)

@@ -116,14 +116,25 @@ def stem_forward(conv1, bn1, act1, x):
         while i < len(mods):
             if (i + 2 < len(mods) and isinstance(mods[i], nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d)
                     and isinstance(mods[i + 2], nn.ReLU)):
+                _module_conv(mods[i], x)
                 x = fused_bn_act(mods[i](x), mods[i + 1], "relu")  # (falls back to the modules' own arithmetic when not eligible)
                 i += 3
             else:
+                if isinstance(mods[i], nn.Conv2d):
+                    _module_conv(mods[i], x)
                 x = mods[i](x)
                 i += 1
     else:
         x = stem_conv(conv1, x) if relu else conv1(x)
     return fused_bn_act(x, bn1, "relu") if relu else act1(bn1(x))
+
+
+def _module_conv(conv, x):
+    """a deep stem's (strided) 3 x 3 convolutions are the torch modules by design: counted among the fallbacks (and refused under
+    COT_STRICT_DISPATCH=1) while the library's convolutions are switched on"""
+    from . import _lib, conv3x3g
+    if conv3x3g.MODE == "hip":
+        _lib.fallback("deep_stem_conv", x, f"-> {conv.out_channels}, kernel {tuple(conv.kernel_size)}, stride {tuple(conv.stride)}")
 
 
 def init_weights(model, zero_init_last_bn=True):

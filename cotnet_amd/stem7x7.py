@@ -72,4 +72,6 @@ def stem_conv(conv, x):
     """`conv(x)`; see the module docstring for when the library kernels serve it"""
     if MODE == "hip" and eligible(conv, x):
         return _Stem.apply(x, conv.weight)
+    if MODE == "hip":
+        _lib.fallback("stem_conv", x, f"-> {conv.out_channels}, kernel {tuple(conv.kernel_size)}")
     return conv(x)
