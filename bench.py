@@ -529,6 +529,25 @@ def secondary_lines(timeout_s=170):
     return out
 
 
+def aggmix_config5():
+    """BASELINE config 5's op-level shape: aggregation_zeropad_mix at (B = 64, C = 256, 20 x 20, wC = 32, heads = 1)
+    through the C ABI, HIP events on the launch stream, buffer sets rotating beyond the Infinity Cache; GB/s on the ALGORITHMIC
+    bytes e * (x + w1 + w2 + 2 out) forward (gout + w1 + w2 + gx / gout + x + gw1 + gw2 backward).  fp32 = the reference's dtype
+    for this op (cupy_layers/utils.py:8-12 rejects half), bf16 = the storage type of the rest of this line."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import bench_aggmix_abi as B
+        out = {"what": "aggregation_zeropad_mix, op level, B=64 C=256 20x20 wC=32 heads=1 (cupy_layers/aggregation_zeropad_mix.py:20-207)",
+               "peak_GBps": B.PEAK_GBS}
+        for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            out[name] = B.measure(64, dt, iters=20, rounds=5, cold=True)
+        return out
+    except Exception as e:  # (recorded, never hidden; the headline is complete before this runs)
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        sys.path.pop(0)
+
+
 def measure_agg_traffic(key, timeout_s=90):
     """roofline.traffic measured IN this run: two child passes of scripts/bench_agg_abi.py under `rocprofv3 --pmc FETCH_SIZE` / `--pmc
     WRITE_SIZE` (separate passes, kernel trace only -- the guide's HBM recipe), HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE
@@ -1019,6 +1038,7 @@ def main():
         if world == 1 and default_cfg and not args.no_secondary:
             torch.cuda.empty_cache()  # (the children run on this GPU while this process is idle)
             line["secondary"] = secondary_lines()
+            line["secondary"]["aggmix_config5"] = aggmix_config5()
         print(json.dumps(line), flush=True)
     if world > 1 or args.force_collectives:
         dist.destroy_process_group()

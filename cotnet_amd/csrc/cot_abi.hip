@@ -116,6 +116,8 @@ int aggmix_backward_input(const T*, const T*, const T*, T*, const cot_agg_geom&,
                           hipStream_t);
 template <typename T>
 int aggmix_backward_weight(const T*, const T*, T*, T*, const cot_agg_geom&, int, int, int, int, hipStream_t);
+const char* last_kernel_mix();
+extern int g_mix_tune[3];  // agg_mix.hip: [0] = 1 generic kernels only, [1] = lanes a tiled workgroup aims for, [2] = pixels per lane
 int sgd_flat(void*, void*, void*, const void*, int64_t, float, float, float, float, int, int, int, hipStream_t);
 int ema_flat(void*, const void*, int64_t, float, int, hipStream_t);
 int bn_workspace_floats(int N, int C);
@@ -442,6 +444,18 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 50) {
         g_radix_pack7 = value ? 1 : 0;
+        return COT_OK;
+    }
+    if (key == 51) {
+        g_mix_tune[0] = value ? 1 : 0;
+        return COT_OK;
+    }
+    if (key == 52) {
+        g_mix_tune[1] = value >= 64 ? value : 256;
+        return COT_OK;
+    }
+    if (key == 53) {
+        g_mix_tune[2] = value == 1 || value == 2 || value == 4 ? value : 0;
         return COT_OK;
     }
     if (key == 42) {
@@ -1628,13 +1642,18 @@ static int validate_mix(const cot_agg_geom* g, int p2h, int p2w, int* Ho, int* W
     return COT_OK;
 }
 
+static int mix_done(int rc) {
+    g_kernel = last_kernel_mix();
+    return rc;
+}
+
 int cot_aggmix_forward(const void* x, const void* w1, const void* w2, void* out, const cot_agg_geom* g, int p2h,
                        int p2w, int dtype, void* stream) {
     int Ho, Wo, rc = validate_mix(g, p2h, p2w, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w1 || !w2 || !out) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
-    DISPATCH_DTYPE(dtype, (aggmix_forward<T>((const T*)x, (const T*)w1, (const T*)w2, (T*)out, *g, p2h, p2w, Ho, Wo,
-                                             (hipStream_t)stream)));
+    DISPATCH_DTYPE(dtype, mix_done(aggmix_forward<T>((const T*)x, (const T*)w1, (const T*)w2, (T*)out, *g, p2h, p2w, Ho, Wo,
+                                                     (hipStream_t)stream)));
 }
 
 int cot_aggmix_backward_input(const void* gout, const void* w1, const void* w2, void* gx, const cot_agg_geom* g,
@@ -1642,8 +1661,8 @@ int cot_aggmix_backward_input(const void* gout, const void* w1, const void* w2, 
     int Ho, Wo, rc = validate_mix(g, p2h, p2w, &Ho, &Wo);
     if (rc) return rc;
     if (!gout || !w1 || !w2 || !gx) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
-    DISPATCH_DTYPE(dtype, (aggmix_backward_input<T>((const T*)gout, (const T*)w1, (const T*)w2, (T*)gx, *g, p2h, p2w,
-                                                    all_heads, Ho, Wo, (hipStream_t)stream)));
+    DISPATCH_DTYPE(dtype, mix_done(aggmix_backward_input<T>((const T*)gout, (const T*)w1, (const T*)w2, (T*)gx, *g, p2h, p2w,
+                                                            all_heads, Ho, Wo, (hipStream_t)stream)));
 }
 
 int cot_aggmix_backward_weight(const void* gout, const void* x, void* gw1, void* gw2, const cot_agg_geom* g, int p2h,
@@ -1651,8 +1670,8 @@ int cot_aggmix_backward_weight(const void* gout, const void* x, void* gw1, void*
     int Ho, Wo, rc = validate_mix(g, p2h, p2w, &Ho, &Wo);
     if (rc) return rc;
     if (!gout || !x || !gw1 || !gw2) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
-    DISPATCH_DTYPE(dtype, (aggmix_backward_weight<T>((const T*)gout, (const T*)x, (T*)gw1, (T*)gw2, *g, p2h, p2w, Ho,
-                                                     Wo, (hipStream_t)stream)));
+    DISPATCH_DTYPE(dtype, mix_done(aggmix_backward_weight<T>((const T*)gout, (const T*)x, (T*)gw1, (T*)gw2, *g, p2h, p2w, Ho,
+                                                             Wo, (hipStream_t)stream)));
 }
 
 }  // extern "C"

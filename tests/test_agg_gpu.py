@@ -239,14 +239,95 @@ def test_mix_all_heads_mode_is_the_true_gradient():
     assert (xg.grad.cpu() - xr.grad).abs().max() < 1e-9
 
 
-def test_mix_config5_shape_fp32():
-    """op-level shape BASELINE config 5 names: (B, C=256, 20x20, wC=32, heads=1); B reduced to 4 for the oracle"""
-    g = torch.Generator().manual_seed(4)
-    x = torch.randn(4, 256, 20, 20, generator=g)
-    w1 = torch.randn(4, 1, 32, 9, 20, 20, generator=g)
-    w2 = torch.randn(4, 1, 32, 25, 20, 20, generator=g)
-    y = aggregation_zeropad_mix(x.to(DEV), w1.to(DEV), w2.to(DEV), 3, 5, 1, 1, 2, 1)
-    assert (y.cpu() - cref.mix_forward(x, w1, w2, 1, 1, 2, 1)).abs().max() < 5e-5
+def _mix_gpu(x, w1, w2, gout, all_heads=False):
+    """forward + the three gradients on the GPU through the autograd Function (= the C ABI); CPU tensors in and out"""
+    xg, w1g, w2g = (t.to(DEV).requires_grad_(True) for t in (x, w1, w2))
+    AggregationZeropadMix.all_heads = all_heads
+    try:
+        y = aggregation_zeropad_mix(xg, w1g, w2g, 3, 5, 1, 1, 2, 1)
+        fk = _lib.last_kernel()
+        y.backward(gout.to(DEV))
+        bk = _lib.last_kernel()
+    finally:
+        AggregationZeropadMix.all_heads = False
+    torch.cuda.synchronize()
+    return y.detach().cpu(), xg.grad.cpu(), w1g.grad.cpu(), w2g.grad.cpu(), fk, bk
+
+
+def _mix_oracle(x, w1, w2, gout, all_heads=False):
+    return (cref.mix_forward(x, w1, w2, 1, 1, 2, 1), cref.mix_backward_input(gout, w1, w2, x.shape, 1, 1, 2, 1, all_heads),
+            *cref.mix_backward_weight(gout, x, w1.shape, w2.shape, 1, 1, 2, 1))
+
+
+def _mix_config5_inputs(dtype, heads=1, integer=False, N=64):
+    """the op-level shape BASELINE config 5 / SURVEY 8(d) name: (B = 64, C = 256, 20 x 20, wC = 32, heads = 1)"""
+    g = torch.Generator().manual_seed(4 + heads)
+    C, wC, H, W = 256, 32, 20, 20
+    if integer:
+        mk = lambda lo, hi, *shape: torch.randint(lo, hi, shape, generator=g).to(dtype)
+        return (mk(-4, 5, N, C, H, W), mk(-3, 4, N, heads, wC, 9, H, W), mk(-3, 4, N, heads, wC, 25, H, W),
+                mk(-2, 3, N, 2 * heads * C, H, W))
+    mk = lambda *shape: torch.randn(*shape, generator=g).to(dtype)
+    return mk(N, C, H, W), mk(N, heads, wC, 9, H, W), mk(N, heads, wC, 25, H, W), mk(N, 2 * heads * C, H, W)
+
+
+def test_mix_config5_shape_fp32_forward_and_both_gradients():
+    """full batch, every element of the four results against the C oracle (reference loop order): 1e-5"""
+    x, w1, w2, gout = _mix_config5_inputs(torch.float32)
+    *got, fk, bk = _mix_gpu(x, w1, w2, gout)
+    assert fk == "aggmix_fwd_tile" and bk in ("aggmix_bwd_input_tile", "aggmix_bwd_weight_tile"), (fk, bk)
+    for a, b in zip(got, _mix_oracle(x, w1, w2, gout)):
+        assert (a - b).abs().max() < 1e-5 * (1 + b.abs().max())
+    assert torch.all(got[2][:, :, :, 0, 0, :] == 0) and torch.all(got[3][:, :, :, 24, :, -1] == 0)  # padded taps: exact zeros
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mix_config5_shape_integer_data_is_bit_exact(dtype):
+    x, w1, w2, gout = _mix_config5_inputs(dtype, integer=True)
+    *got, fk, bk = _mix_gpu(x, w1, w2, gout)
+    f = torch.float32
+    for a, b in zip(got, _mix_oracle(x.to(f), w1.to(f), w2.to(f), gout.to(f))):
+        assert torch.equal(a.float(), b)
+
+
+def test_mix_config5_shape_bf16_storage_is_one_rounding_from_the_fp32_oracle():
+    x, w1, w2, gout = _mix_config5_inputs(torch.bfloat16)
+    *got, fk, bk = _mix_gpu(x, w1, w2, gout)
+    assert fk == "aggmix_fwd_tile", fk
+    f = torch.float32
+    for a, b in zip(got, _mix_oracle(x.to(f), w1.to(f), w2.to(f), gout.to(f))):
+        assert ((a.float() - b).abs() <= 2.0 ** -8 * b.abs() + 1e-5).all()  # half an ulp of bf16 (8 significand bits) + fp32 sum noise
+
+
+@pytest.mark.parametrize("all_heads", [False, True])
+def test_mix_config5_shape_two_heads(all_heads):
+    """heads = 2: the reference's input gradient sums head 0 only (mix.py:87-88, reproduced by default); `all_heads` = the complete one"""
+    x, w1, w2, gout = _mix_config5_inputs(torch.float32, heads=2, N=16)
+    *got, fk, bk = _mix_gpu(x, w1, w2, gout, all_heads)
+    want = _mix_oracle(x, w1, w2, gout, all_heads)
+    for a, b in zip(got, want):
+        assert (a - b).abs().max() < 1e-5 * (1 + b.abs().max())
+    if all_heads:  # ... which is what autograd gives for the Unfold formula (a quarter of the batch: the formula is slow)
+        xr = x[:4].clone().requires_grad_(True)
+        unfold_oracle.aggregation_mix_unfold(xr, w1[:4], w2[:4], 1, 1, 2, 1).backward(gout[:4])
+        assert (got[1][:4] - xr.grad).abs().max() < 1e-4
+    else:
+        assert (got[1] - _mix_oracle(x, w1, w2, gout, True)[1]).abs().max() > 0.1  # (the quirk is visible at two heads)
+
+
+def test_mix_tile_kernels_equal_the_generic_kernels():
+    """same sums in the same order: the LDS-tiled kernels and the one-lane-per-element kernels agree to fp32 rounding (the compiler
+    contracts multiply-adds differently in the two loop shapes; integer-valued data is bit-exact for both, test above)"""
+    x, w1, w2, gout = _mix_config5_inputs(torch.float32, N=8)
+    tile = _mix_gpu(x, w1, w2, gout)
+    _lib.lib().cot_set_tuning(51, 1)
+    try:
+        gen = _mix_gpu(x, w1, w2, gout)
+    finally:
+        _lib.lib().cot_set_tuning(51, 0)
+    assert tile[4] == "aggmix_fwd_tile" and gen[4] == "aggmix_fwd"
+    for a, b in zip(tile[:4], gen[:4]):
+        assert (a - b).abs().max() <= 2e-6 * (1 + b.abs().max())
 
 
 # ---- window softmax fused into the aggregation (SURVEY 8f rank 2) ------------------------------------------

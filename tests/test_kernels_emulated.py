@@ -269,6 +269,96 @@ def test_mix_kernels():
     assert (gw1 - o1).abs().max() < 1e-12 and (gw2 - o2).abs().max() < 1e-12
 
 
+def _mix_run(lib, x, w1, w2, gout, all_heads=0, p1=1, p2=2):
+    """the three mix entry points through the C ABI of `lib`; returns outputs and the kernels that served them"""
+    N, C, H, W = x.shape
+    heads, wC = w1.shape[1], w1.shape[2]
+    geo = _lib.AggGeom(N, C, H, W, heads, wC, 3, 3, 1, 1, p1, p1, 1, 1)
+    dt = _lib.dtype_code(x.dtype)
+    out, gx, gw1, gw2 = torch.empty_like(gout), torch.empty_like(x), torch.empty_like(w1), torch.empty_like(w2)
+    names = []
+    assert lib.cot_aggmix_forward(P(x), P(w1), P(w2), P(out), ctypes.byref(geo), p2, p2, dt, None) == 0, lib.cot_last_error()
+    names.append(lib.cot_last_kernel().decode())
+    assert lib.cot_aggmix_backward_input(P(gout), P(w1), P(w2), P(gx), ctypes.byref(geo), p2, p2, all_heads, dt, None) == 0
+    names.append(lib.cot_last_kernel().decode())
+    assert lib.cot_aggmix_backward_weight(P(gout), P(x), P(gw1), P(gw2), ctypes.byref(geo), p2, p2, dt, None) == 0
+    names.append(lib.cot_last_kernel().decode())
+    return out, gx, gw1, gw2, names
+
+
+# (C, wC, H, W, heads): W % 4 == 0 -> P = 4 (2 for fp64), W % 2 == 0 -> P = 2, odd -> P = 1; planes that are / are not 16-byte
+# multiples (LDS-DMA / element-wise staging); several weight channels per workgroup and one; the reference's self-test shape
+_MIX_TILE_SHAPES = [(8, 4, 6, 6, 1), (16, 4, 5, 8, 2), (6, 2, 4, 7, 1), (16, 2, 20, 20, 1), (8, 8, 3, 12, 2), (4, 4, 1, 4, 1),
+                    (8, 2, 9, 2, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,wC,H,W,heads", _MIX_TILE_SHAPES)
+@pytest.mark.parametrize("lanes,ppl", [(256, 0), (64, 0), (256, 1), (128, 2)])
+def test_mix_tile_kernels(C, wC, H, W, heads, dtype, lanes, ppl):
+    """the LDS-tiled kernels of csrc/agg_mix.hip (stride 1, padding 1 / 2) against the C oracle: fp64 / fp32 sum in the reference's
+    order (equal to the last bit on the host build), bf16 = the fp32 oracle on the rounded operands, one output rounding"""
+    g = torch.Generator().manual_seed(C * 7 + W)
+    N = 2
+    x = torch.randn(N, C, H, W, dtype=torch.float64, generator=g).to(dtype)
+    w1 = torch.randn(N, heads, wC, 9, H, W, dtype=torch.float64, generator=g).to(dtype)
+    w2 = torch.randn(N, heads, wC, 25, H, W, dtype=torch.float64, generator=g).to(dtype)
+    gout = torch.randn(N, 2 * heads * C, H, W, dtype=torch.float64, generator=g).to(dtype)
+    _EMUL.cot_set_tuning(52, lanes)
+    _EMUL.cot_set_tuning(53, ppl)  # pixels per lane: automatic / forced narrower
+    try:
+        out, gx, gw1, gw2, names = _mix_run(_EMUL, x, w1, w2, gout)
+        assert names == ["aggmix_fwd_tile", "aggmix_bwd_input_tile", "aggmix_bwd_weight_tile"], names
+        _EMUL.cot_set_tuning(51, 1)
+        ref = _mix_run(_EMUL, x, w1, w2, gout)
+        assert ref[4] == ["aggmix_fwd", "aggmix_bwd_input", "aggmix_bwd_weight"]
+    finally:
+        _EMUL.cot_set_tuning(51, 0)
+        _EMUL.cot_set_tuning(52, 256)
+        _EMUL.cot_set_tuning(53, 0)
+    od = torch.float32 if dtype == torch.bfloat16 else dtype
+    want = (cref.mix_forward(x.to(od), w1.to(od), w2.to(od), 1, 1, 2, 1),
+            cref.mix_backward_input(gout.to(od), w1.to(od), w2.to(od), x.shape, 1, 1, 2, 1, False),
+            *cref.mix_backward_weight(gout.to(od), x.to(od), w1.shape, w2.shape, 1, 1, 2, 1))
+    for got, gen, w in zip((out, gx, gw1, gw2), ref[:4], want):
+        if dtype == torch.bfloat16:
+            assert ((got.float() - w).abs() <= 2.0 ** -8 * w.abs() + 1e-6).all()
+        else:
+            assert torch.equal(got, w) and torch.equal(got, gen)
+    # padded taps of the weight gradients are exact zeros (mix.py:142-207 writes them explicitly)
+    assert torch.all(gw1[:, :, :, 0, 0, :] == 0) and torch.all(gw2[:, :, :, 24, :, -1] == 0) and torch.all(gw2[:, :, :, 4, 0, :] == 0)
+
+
+def test_mix_tile_kernels_integer_data_bit_exact():
+    g = torch.Generator().manual_seed(5)
+    N, C, wC, H, W, heads = 2, 16, 4, 20, 20, 2
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randint(-4, 5, (N, C, H, W), generator=g).to(dtype)
+        w1 = torch.randint(-3, 4, (N, heads, wC, 9, H, W), generator=g).to(dtype)
+        w2 = torch.randint(-3, 4, (N, heads, wC, 25, H, W), generator=g).to(dtype)
+        gout = torch.randint(-2, 3, (N, 2 * heads * C, H, W), generator=g).to(dtype)
+        out, gx, gw1, gw2, names = _mix_run(_EMUL, x, w1, w2, gout)
+        assert all(n.endswith("_tile") for n in names), names
+        f = torch.float32
+        assert torch.equal(out.float(), cref.mix_forward(x.to(f), w1.to(f), w2.to(f), 1, 1, 2, 1))
+        assert torch.equal(gx.float(), cref.mix_backward_input(gout.to(f), w1.to(f), w2.to(f), x.shape, 1, 1, 2, 1, False))
+        o1, o2 = cref.mix_backward_weight(gout.to(f), x.to(f), w1.shape, w2.shape, 1, 1, 2, 1)
+        assert torch.equal(gw1.float(), o1) and torch.equal(gw2.float(), o2)
+
+
+def test_mix_geometries_off_the_tile_grid_take_the_generic_kernels():
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 4, 6, 6, generator=g)
+    w1 = torch.randn(1, 2, 2, 9, 6, 6, generator=g)
+    w2 = torch.randn(1, 2, 2, 25, 6, 6, generator=g)
+    gout = torch.randn(1, 16, 6, 6, generator=g)
+    names = _mix_run(_EMUL, x, w1, w2, gout, all_heads=1)[4]  # the complete gradient over two heads: generic input backward
+    assert names == ["aggmix_fwd_tile", "aggmix_bwd_input", "aggmix_bwd_weight_tile"], names
+    w2b = torch.randn(1, 2, 2, 25, 6, 6, generator=g)
+    names = _mix_run(_EMUL, x, w1, w2b, gout, p2=3)[4]  # padding2 = 3: not the 5x5 'same' geometry
+    assert names == ["aggmix_fwd", "aggmix_bwd_input", "aggmix_bwd_weight"], names
+
+
 @pytest.mark.parametrize("pdt,gdt", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32),
                                      (torch.float32, torch.float32), (torch.float32, torch.bfloat16)])
 @pytest.mark.parametrize("nesterov", [0, 1])
