@@ -840,8 +840,11 @@ def main():
                 opt.step(deferred=True)
                 return graph_loss
         else:
+            from cotnet_amd.cot_layer_fused import invalidate_packs
+
             def step():  # noqa: F811
                 graph.replay()
+                invalidate_packs()  # (the replayed SGD kernels moved the weights behind torch's version counters)
                 return graph_loss
     for _ in range(args.warmup):
         loss = step()

@@ -285,6 +285,18 @@ def _pack_for(L, conv, mode, N, C, G, H, W):
     return None
 
 
+def invalidate_packs():
+    """Every weight packing made ahead of time is stale from here on: the next packed call packs inline again.
+
+    A packing is keyed on (storage pointer, torch's version counter, PARAM_EPOCH, geometry).  Two kinds of write move neither
+    counter by themselves and MUST call this: (1) replaying a HIP graph that captured the optimizer's kernels (the flat SGD kernel
+    writes through raw pointers; FlatSGD.step() bumps the epoch only when it runs in Python), (2) raw `.data` writes -- `p.data.
+    copy_()`, a broadcast of the module's state, an EMA swap-in.  GradBucketReducer.broadcast_module_state and bench.py's replay
+    loop call it; code that writes parameters behind torch's back has to as well."""
+    PARAM_EPOCH[0] += 1
+    _PACK_EVENT.clear()
+
+
 def after_optimizer_step(device):
     """called by FlatSGD.step() once its kernels are issued: the parameters have changed (PARAM_EPOCH), and the 3x3 weights of the
     layers the last forward ran are packed for the next step on the side stream"""
@@ -1228,14 +1240,18 @@ def _cm_buf(t):
 
 def plan_stage_layouts(stage):
     """mark, once per stage, the blocks whose successor can take a channel-major input (so that they write one)"""
-    if getattr(stage, "_cm_planned", None) == CM_LAYOUT:
-        return
     blocks = list(stage.children())
+    # the plan depends on both layout switches and on WHICH blocks the stage holds (a replaced block re-plans; ADVICE r5)
+    key = (CM_LAYOUT, CM_OPENING, tuple(id(b) for b in blocks), tuple(b.training for b in blocks))
+    if getattr(stage, "_cm_planned", None) == key:
+        return
     for i, b in enumerate(blocks):
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
         # (an opening block takes NCHW: its conv1 / bn1 run at the input resolution, off the channel-resident kernels)
-        b._next_cm = bool(CM_LAYOUT and nxt is not None and _cm_static_ok(nxt) and not _block_plan(nxt).avd)
-    stage._cm_planned = CM_LAYOUT
+        # (... and only a successor in training mode runs the channel-major node: an eval-mode block inside a training stage would
+        # take the module path on a strided tensor -- correct, but a silent performance cliff)
+        b._next_cm = bool(CM_LAYOUT and nxt is not None and nxt.training and _cm_static_ok(nxt) and not _block_plan(nxt).avd)
+    stage._cm_planned = key
 
 
 def _cm_static_ok(blk):
@@ -1630,8 +1646,15 @@ def eval_block_eligible(blk, x):
             and (bp.ds_conv is not None or (bp.conv1.in_channels == bp.conv3.out_channels and not bp.avd))):
         return False
     pl = _plan(bp.cot)
+    # every BatchNorm of the block runs on its RUNNING statistics here (cot_bn_act_inference): each one has to be in eval mode
+    # itself (a block in eval() with an inner BatchNorm put back into train() takes the module path), carry running statistics and
+    # fp32 parameters
+    bns = [bp.bn1, bp.bn3, pl.ke1, pl.em1, pl.cv1, pl.bn, pl.sebn] + ([bp.ds_bn] if bp.ds_conv is not None else [])
+    if not all((not bn.training) and bn.running_mean is not None and bn.running_var is not None and bn.weight is not None
+               and bn.weight.dtype == torch.float32 and bn.running_mean.dtype == torch.float32 for bn in bns):
+        return False
     return (not pl.grouped and pl.ke0.weight.dtype == torch.bfloat16 and pl.em3.weight.dtype == torch.bfloat16
-            and pl.gn.weight.dtype == torch.bfloat16 and pl.bn.weight.dtype == torch.float32 and x.shape[2] * x.shape[3] <= 8192 * 4)
+            and pl.gn.weight.dtype == torch.bfloat16 and x.shape[2] * x.shape[3] <= 8192 * 4)
 
 
 @_one_stream_query

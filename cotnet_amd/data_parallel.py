@@ -89,7 +89,12 @@ class GradBucketReducer:
         for p in reversed(params):
             dt = grad_dtype or p.dtype
             k = (keys[p], p.dtype, dt)  # a bucket's flat PARAMETER buffer has one dtype too (fp32 BatchNorm beside bf16 biases)
-            nbytes = p.numel() * torch.empty((), dtype=dt).element_size()
+            # bucket_mb bounds the MESSAGE: with a wider reduction dtype that is what goes on the wire (cutting at the
+            # gradients' own width made every fp32-reduced all-reduce 2x bucket_mb)
+            esz = torch.empty((), dtype=dt).element_size()
+            if reduce_dtype is not None and self.enabled:
+                esz = max(esz, torch.empty((), dtype=reduce_dtype).element_size())
+            nbytes = p.numel() * esz
             cur = open_buckets.get(k)
             if cur is not None and cur[1] + nbytes > cap:
                 order.append((k, cur[0]))
@@ -105,6 +110,10 @@ class GradBucketReducer:
         for (key, _pdt, dt), plist in order:
             self._make_bucket(plist, dt, key, flatten_params)
         if reduce_dtype is not None and self.enabled:
+            # the all-reduce sums `rflat`; in "view" mode every p.grad stays a view of the UN-reduced `flat`, so an optimizer
+            # that reads p.grad would step on local gradients without any error: only the copy-mode consumer (`reduced(b)`) is legal
+            if any(b.flat.element_size() < torch.empty((), dtype=reduce_dtype).element_size() for b in self.buckets):
+                assert grad_mode == "copy", "reduce_dtype wider than the gradients needs grad_mode='copy' (consumers read reduced(b))"
             for b in self.buckets:
                 if b.flat.element_size() < torch.empty((), dtype=reduce_dtype).element_size():
                     b.rflat = torch.zeros(b.flat.numel(), dtype=reduce_dtype, device=self.device)
@@ -157,6 +166,9 @@ class GradBucketReducer:
             for t in ts:
                 t.copy_(flat[off:off + t.numel()].view_as(t))
                 off += t.numel()
+        # (`.data` writes move neither torch's version counter nor the optimizer epoch: weight packings made ahead of time are stale)
+        from . import cot_layer_fused
+        cot_layer_fused.invalidate_packs()
 
     # ------------------------------------------------------------------------------------------
     def _on_grad_ready(self, param):

@@ -666,3 +666,26 @@ def test_fp32_reduction_of_bf16_buckets_with_and_without_deferred_communication(
     for p in procs:
         p.join(timeout=60)
     assert all(r[2] == "ok" for r in res), res
+
+
+def test_a_wider_reduction_dtype_is_refused_in_view_mode():
+    """with reduce_dtype the all-reduce sums a second buffer; in "view" mode p.grad would stay a view of the un-reduced one"""
+    import torch.distributed as dist
+    from cotnet_amd.data_parallel import GradBucketReducer
+    if dist.is_initialized():
+        pytest.skip("needs a fresh process group")
+    import socket
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        m = torch.nn.Linear(8, 8).bfloat16()
+        with pytest.raises(AssertionError, match="grad_mode='copy'"):
+            GradBucketReducer(m, grad_mode="view", force_collectives=True, reduce_dtype=torch.float32)
+        r = GradBucketReducer(m, grad_mode="copy", force_collectives=True, reduce_dtype=torch.float32, bucket_mb=1e-4)
+        # bucket_mb bounds the message in the REDUCTION dtype: 64 + 8 bf16 parameters = 288 bytes in fp32 > 104 bytes -> two buckets
+        assert len(r.buckets) == 2
+    finally:
+        dist.destroy_process_group()

@@ -85,3 +85,38 @@ def test_a_parameter_update_behind_torchs_back_invalidates_the_packing():
             conv.weight.mul_(1.0)                     # an in-place torch op: the version counter moves
         assert clf._pack_for(L, conv, 0, *g) is None
     torch.cuda.synchronize()
+
+
+def test_raw_data_writes_and_graph_replays_go_through_invalidate_packs():
+    """`p.data.copy_()` (a broadcast of the module's state, an EMA swap-in) and a replayed HIP graph that contains the optimizer move
+    neither torch's version counter nor the optimizer epoch: cot_layer_fused.invalidate_packs() is the public call that makes the next
+    forward pack inline again -- and the step after such a write computes on the NEW weights"""
+    torch.manual_seed(5)
+    blk = to_mixed_bf16(Bottleneck(256, 64).to(DEV).train())
+    x = torch.randn(16, 256, 14, 14, device=DEV).bfloat16()
+    conv = blk.conv2.key_embed[0]
+    with truth.switches(**truth.SINGLE_NODE):
+        opt = FlatSGD(blk, lr=0.01)
+        for _ in range(2):
+            opt.zero_grad()
+            blk(x).float().mean().backward()
+            opt.step()
+        L = __import__("cotnet_amd._lib", fromlist=["lib"]).lib()
+        g = clf._PACKS[conv]["geom"]
+        assert clf._pack_for(L, conv, 0, *g) is not None
+        new_w = (conv.weight.detach().float() * 0.5).bfloat16()
+        conv.weight.data.copy_(new_w)                 # version counter of the Parameter's .data alias: torch does move it here ...
+        ref = copy.deepcopy(blk)
+        clf.invalidate_packs()                        # ... but the contract does not rely on it
+        assert clf._pack_for(L, conv, 0, *g) is None
+        with torch.no_grad():
+            y = blk(x)
+        old = clf.PREPACK
+        clf.PREPACK = False
+        try:
+            with torch.no_grad():
+                y_ref = ref(x)
+        finally:
+            clf.PREPACK = old
+        assert torch.equal(y, y_ref)
+    torch.cuda.synchronize()
