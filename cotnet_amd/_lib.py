@@ -93,6 +93,9 @@ SYMBOLS = {
     "cot_stem7x7s2_workspace": (ctypes.c_int64, [_I, _I, _I]),
     "cot_stem7x7s2_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cot_stem7x7s2_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cot_stem3x3s2_workspace": (ctypes.c_int64, [_I, _I, _I, _I]),
+    "cot_stem3x3s2_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cot_stem3x3s2_backward_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cot_sgd_step": (_I, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                           _I, _I, _I, _P]),
     "cot_conv1x1_workspace": (ctypes.c_int64, [_I, _I, _I, _I, _I]),

@@ -207,6 +207,9 @@ int conv3x3g_lds_gemm(const void*, const void*, void*, void*, int, int, int, int
 int stem7x7_splits(int N, int H, int W);
 int stem7x7_forward(const void*, const void*, void*, int, int, int, hipStream_t);
 int stem7x7_wgrad(const void*, const void*, void*, float*, int, int, int, hipStream_t);
+int stem3x3s2_splits(int N, int H, int W, int Co);
+int stem3x3s2_forward(const void*, const void*, void*, int, int, int, int, hipStream_t);
+int stem3x3s2_wgrad(const void*, const void*, void*, float*, int, int, int, int, hipStream_t);
 // implemented in pool3x3.hip
 template <typename T> int pool3x3s2(int, const void*, const void*, void*, int64_t, int, int, hipStream_t);
 // implemented in group_norm9.hip
@@ -1125,6 +1128,36 @@ int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, 
     if (rc) return rc;
     rc = stem7x7_wgrad(gy, x, gweight, (float*)workspace, N, H, W, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_stem7x7s2_backward_weight: %dx%d input not covered", H, W);
+    return rc;
+}
+
+int64_t cot_stem3x3s2_workspace(int N, int H, int W, int Cout) {
+    if (N <= 0) return 0;
+    const int S = stem3x3s2_splits(N, H, W, Cout);
+    return S ? ((int64_t)S * Cout * 27 * 4 + 255) / 256 * 256 : 0;
+}
+
+int cot_stem3x3s2_forward(const void* x, const void* weight, void* y, int N, int H, int W, int Cout, int dtype, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d H=%d W=%d", N, H, W);
+    if (!x || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_stem3x3s2_*: only COT_BF16 (dtype %d given)", dtype);
+    int rc = check_align16({x, weight, y});
+    if (rc) return rc;
+    rc = stem3x3s2_forward(x, weight, y, N, H, W, Cout, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED)
+        set_error(rc, "cot_stem3x3s2_forward: %d output channels / the output of a %dx%d input not covered (32 or 64; Wo %% 8 == 0)", Cout, H, W);
+    return rc;
+}
+
+int cot_stem3x3s2_backward_weight(const void* gy, const void* x, void* gweight, void* workspace, int N, int H, int W, int Cout,
+                                  int dtype, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d H=%d W=%d", N, H, W);
+    if (!gy || !x || !gweight || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_stem3x3s2_*: only COT_BF16 (dtype %d given)", dtype);
+    int rc = check_align16({gy, x, gweight, workspace});
+    if (rc) return rc;
+    rc = stem3x3s2_wgrad(gy, x, gweight, (float*)workspace, N, H, W, Cout, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_stem3x3s2_backward_weight: %d channels / %dx%d input not covered", Cout, H, W);
     return rc;
 }
 

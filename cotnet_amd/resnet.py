@@ -108,7 +108,8 @@ def stem_forward(conv1, bn1, act1, x):
     """act1(bn1(conv1(x))) (resnet.py:593-596; cotnet_hybrid.py:431).  Every BatchNorm + ReLU pair -- the two inside a deep
     stem's nn.Sequential and bn1 / act1 behind it -- is one fused pass of the library (MIOpen's BatchNorm took 0.74 - 1 ms per
     call on SE-CoTNetD's 64 x 64..128 x 160 x 160 stem tensors, six calls per step: gpurun_out/r4v_secot_per_shape.csv); the
-    7 x 7 convolution of the plain stem goes through `stem_conv`, a deep stem's 3 x 3 convolutions stay the modules."""
+    7 x 7 convolution of the plain stem goes through `stem_conv`, a deep stem's stride-2 3 x 3 convolution through
+    `stem3x3_conv` (csrc/stem3x3.hip) and its two stride-1 ones through `conv3x3` (csrc/conv_lds.hip, groups = 1)."""
     relu = isinstance(act1, nn.ReLU)
     if isinstance(conv1, nn.Sequential):
         mods = list(conv1)
@@ -116,25 +117,27 @@ def stem_forward(conv1, bn1, act1, x):
         while i < len(mods):
             if (i + 2 < len(mods) and isinstance(mods[i], nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d)
                     and isinstance(mods[i + 2], nn.ReLU)):
-                _module_conv(mods[i], x)
-                x = fused_bn_act(mods[i](x), mods[i + 1], "relu")  # (falls back to the modules' own arithmetic when not eligible)
+                x = fused_bn_act(_deep_stem_conv(mods[i], x), mods[i + 1], "relu")  # (the modules' own arithmetic when not eligible)
                 i += 3
             else:
-                if isinstance(mods[i], nn.Conv2d):
-                    _module_conv(mods[i], x)
-                x = mods[i](x)
+                x = _deep_stem_conv(mods[i], x) if isinstance(mods[i], nn.Conv2d) else mods[i](x)
                 i += 1
     else:
         x = stem_conv(conv1, x) if relu else conv1(x)
     return fused_bn_act(x, bn1, "relu") if relu else act1(bn1(x))
 
 
-def _module_conv(conv, x):
-    """a deep stem's (strided) 3 x 3 convolutions are the torch modules by design: counted among the fallbacks (and refused under
-    COT_STRICT_DISPATCH=1) while the library's convolutions are switched on"""
-    from . import _lib, conv3x3g
+def _deep_stem_conv(conv, x):
+    """one 3 x 3 convolution of a deep stem on the library's kernels; what they do not cover takes the module and is counted among
+    the fallbacks (refused under COT_STRICT_DISPATCH=1) while the library's convolutions are switched on"""
+    from . import _lib, conv3x3g, stem3x3
+    if conv.in_channels == 3 and conv.stride == (2, 2):
+        return stem3x3.stem3x3_conv(conv, x)
+    if conv3x3g.MODE == "hip" and conv3x3g.eligible(conv, x):
+        return conv3x3g.conv3x3(conv, x)
     if conv3x3g.MODE == "hip":
         _lib.fallback("deep_stem_conv", x, f"-> {conv.out_channels}, kernel {tuple(conv.kernel_size)}, stride {tuple(conv.stride)}")
+    return conv(x)
 
 
 def init_weights(model, zero_init_last_bn=True):

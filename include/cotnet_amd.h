@@ -372,6 +372,18 @@ int cot_stem7x7s2_forward(const void* x, const void* weight, void* y, int N, int
 int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, void* workspace, int N, int H, int W,
                                   int dtype, void* stream);
 
+/* ---- a deep stem's first convolution: 3x3, stride 2, padding 1, 3 -> Cout channels (Cout = 32 or 64), no bias, NCHW, COT_BF16
+ * (replaces nn.Conv2d(in_chans, stem_chs_1, 3, stride=2, padding=1, bias=False), models/cotnet_hybrid.py:359 -- the SE-CoTNetD
+ * stems -- and the 'deep' stems of models/resnet.py), forward and weight gradient (the network input takes no gradient).
+ * weight [Cout][3][3][3] as torch stores it; x [N][3][H][W]; y / gy [N][Cout][Ho][Wo], Ho = (H - 1)/2 + 1.  Covered when Wo is a
+ * multiple of 8 and Ho*Wo of 32; otherwise COT_ERR_UNSUPPORTED / workspace 0 (caller keeps nn.Conv2d).  backward_weight is
+ * deterministic; workspace: cot_stem3x3s2_workspace(...) bytes.  (The stem's two stride-1 3x3 convolutions are cot_conv3x3g_*
+ * calls with groups = 1.) */
+int64_t cot_stem3x3s2_workspace(int N, int H, int W, int Cout);
+int cot_stem3x3s2_forward(const void* x, const void* weight, void* y, int N, int H, int W, int Cout, int dtype, void* stream);
+int cot_stem3x3s2_backward_weight(const void* gy, const void* x, void* gweight, void* workspace, int N, int H, int W, int Cout,
+                                  int dtype, void* stream);
+
 /* ---- the backbone's two 3x3 / stride-2 / padding-1 poolings, NCHW, `planes` = N*C images of H x W -> Ho = (H-1)/2 + 1:
  *   cot_avgpool3x3s2_*  nn.AvgPool2d(3, 2, padding=1) (count_include_pad: every window / 9) -- the "avd" pooling of
  *                       stride-2 bottlenecks, models/cotnet.py:216

@@ -125,6 +125,10 @@ def build_table():
                                                                            None))
                 elif kind == "conv3x3":
                     N, Ci, Co, g, H, W, s, bias = shp
+                    if s == 2 and Ci == 3 and g == 1 and not bias:  # a deep stem's first convolution: csrc/stem3x3.hip
+                        rec(tag + " fwd", L.cot_stem3x3s2_forward(PTR, PTR, PTR, N, H, W, Co, BF, None))
+                        rec(tag + " wgrad", L.cot_stem3x3s2_backward_weight(PTR, PTR, PTR, PTR, N, H, W, Co, BF, None))
+                        continue
                     if s != 1 or bias:
                         table[tag] = ["module (MIOpen): strided / biased 3x3 convolutions are outside the library"]
                         continue

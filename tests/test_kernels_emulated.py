@@ -2,6 +2,7 @@
 launch-loop shim (tests/emul/), driven through the C ABI with CPU pointers and compared with the oracle.
 This is not the parity gate (tests/test_agg_gpu.py on a real MI355X is); it exists so that indexing bugs are
 caught in the GPU-less build container."""
+import copy
 import ctypes
 import os
 
@@ -2180,6 +2181,71 @@ def test_stem_convolution_kernels(N, H, W):
     assert ("stem7x7_wgrad_lds" if staged else "stem7x7_wgrad_mfma") in buf.value.decode(), buf.value
     assert _EMUL.cot_stem7x7s2_workspace(N, 30, 30) == 0   # output width 15: not covered
     assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(y), N, 30, 30, dt, None) == -2
+
+
+@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 64), (1, 16, 64, 32), (3, 32, 16, 64), (1, 64, 48, 32), (2, 8, 16, 64)])
+def test_deep_stem_first_convolution_kernels(N, H, W, Co):
+    """csrc/stem3x3.hip (3x3 / stride 2 / padding 1, 3 -> 32 / 64: models/cotnet_hybrid.py:359) forward and weight gradient against torch
+    in fp32; an Inf in the input reaches exactly the outputs whose window holds it (the padded taps 27..31 are cleared by selection)"""
+    torch.manual_seed(23)
+    dt = _lib.dtype_code(torch.bfloat16)
+    x = torch.randn(N, 3, H, W).bfloat16()
+    w = (torch.randn(Co, 3, 3, 3) / 5).bfloat16()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = torch.randn(N, Co, Ho, Wo).bfloat16()
+    wf = w.float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(x.float(), wf, None, 2, 1)
+    yr.backward(gy.float())
+    y = torch.full((N, Co, Ho, Wo), float("nan")).bfloat16()
+    assert _EMUL.cot_stem3x3s2_forward(P(x), P(w), P(y), N, H, W, Co, dt, None) == 0, _EMUL.cot_last_error()
+    assert ((y.float() - yr.detach()).abs() <= 2.0 ** -8 * yr.detach().abs() + 1e-5).all()  # fp32 sums, one bf16 rounding
+    xi = x.clone()
+    xi[:, 1, H // 2, W // 2] = float("inf")
+    yi = torch.full_like(y, float("nan"))
+    assert _EMUL.cot_stem3x3s2_forward(P(xi), P(w), P(yi), N, H, W, Co, dt, None) == 0
+    want = torch.nn.functional.conv2d(xi.float(), w.float(), None, 2, 1)
+    assert torch.equal(torch.isfinite(yi.float()), torch.isfinite(want)) and not torch.isfinite(want).all()
+    nb = _EMUL.cot_stem3x3s2_workspace(N, H, W, Co)
+    assert nb > 0
+    ws, gw = torch.empty(nb, dtype=torch.uint8), torch.full_like(w, float("nan"))
+    assert _EMUL.cot_stem3x3s2_backward_weight(P(gy), P(x), P(gw), P(ws), N, H, W, Co, dt, None) == 0
+    assert (gw.float() - wf.grad).abs().max() <= 1e-2 * wf.grad.abs().max() + 1e-2
+    gw2 = torch.full_like(w, float("nan"))
+    assert _EMUL.cot_stem3x3s2_backward_weight(P(gy), P(x), P(gw2), P(ws), N, H, W, Co, dt, None) == 0
+    assert torch.equal(gw, gw2)                                   # deterministic
+    assert _EMUL.cot_stem3x3s2_workspace(N, 30, 30, Co) == 0      # output width 15: not covered
+    assert _EMUL.cot_stem3x3s2_workspace(N, H, W, 48) == 0        # a tiered stem's 48 channels: not covered
+    assert _EMUL.cot_stem3x3s2_forward(P(x), P(w), P(y), N, 30, 30, Co, dt, None) == -2
+
+
+def test_deep_stem_runs_on_the_library_kernels(monkeypatch):
+    """resnet.stem_forward on a deep stem (SE-CoTNetD's conv -> BN -> ReLU x 2 -> conv, models/cotnet_hybrid.py:359-368): every
+    convolution on the library's kernels -- no module fallback is counted -- and the result / gradients follow the modules'"""
+    from torch import nn
+    from cotnet_amd import conv3x3g, fused_bn, resnet, stem3x3, stem7x7
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    monkeypatch.setattr(_lib, "_lib", _EMUL)
+    for mod in (conv3x3g, stem7x7, fused_bn):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(conv3x3g, "MODE", "hip")
+    monkeypatch.setattr(stem7x7, "MODE", "hip")
+    torch.manual_seed(29)
+    conv1, inplanes = resnet.make_stem(3, 32, "deep", nn.BatchNorm2d, nn.ReLU)
+    stem = to_mixed_bf16(nn.ModuleDict(dict(conv1=conv1, bn1=nn.BatchNorm2d(inplanes), act1=nn.ReLU(inplace=True))).train())
+    x = torch.randn(2, 3, 32, 32).bfloat16()
+    _lib.FALLBACKS.clear()
+    y = resnet.stem_forward(stem["conv1"], stem["bn1"], stem["act1"], x)
+    assert not _lib.FALLBACKS, dict(_lib.FALLBACKS)
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref = copy.deepcopy(stem).float()
+    for p_ in ref.parameters():
+        p_.grad = None
+    yr = ref["act1"](ref["bn1"](ref["conv1"](x.float())))
+    yr.backward(g.float())
+    assert (y.float() - yr).abs().max() < 0.08 * (1 + yr.abs().max())
+    for (n_, a), (_, b) in zip(stem.named_parameters(), ref.named_parameters()):
+        assert a.grad is not None and (a.grad.float() - b.grad).norm() <= 0.15 * b.grad.norm() + 1e-3, n_  # (bf16 activations through three BatchNorms over 2 x 16 x 16 samples)
 
 
 def test_plans_of_the_single_node_layers_do_not_travel_with_the_module(monkeypatch):

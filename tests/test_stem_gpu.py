@@ -41,3 +41,57 @@ def test_weight_gradient_is_deterministic_and_other_inputs_keep_the_module(monke
     assert not s7.eligible(conv, x.clone().requires_grad_(True))               # an input that needs a gradient
     assert not s7.eligible(conv, torch.zeros(2, 3, 30, 30, device=DEV).bfloat16())   # output width 15
     assert not s7.eligible(conv.float(), x.float())
+
+
+# ---- a deep stem's three 3x3 convolutions (models/cotnet_hybrid.py:359-368): csrc/stem3x3.hip + conv_lds.hip, groups = 1 ----------
+@pytest.mark.parametrize("N,H,Co", [(8, 320, 64), (4, 224, 32), (2, 64, 64), (3, 32, 32)])
+def test_deep_stem_first_convolution_matches_torch(N, H, Co, monkeypatch):
+    from cotnet_amd import stem3x3 as s3
+    monkeypatch.setattr(s7, "MODE", "hip")
+    torch.manual_seed(H + Co)
+    conv = nn.Conv2d(3, Co, 3, stride=2, padding=1, bias=False).to(DEV).bfloat16()
+    x = torch.randn(N, 3, H, H, device=DEV).bfloat16()
+    assert s3.eligible(conv, x)
+    y = s3.stem3x3_conv(conv, x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    g1 = conv.weight.grad.clone()
+    wr = conv.weight.detach().float().requires_grad_(True)
+    yr = F.conv2d(x.float(), wr, None, 2, 1)
+    yr.backward(gy.float())
+    assert ((y.float() - yr).abs() <= 2.0 ** -8 * yr.abs() + 1e-5).all()     # fp32 sums of 27 exact products, one bf16 rounding
+    assert (g1.float() - wr.grad).abs().max() <= 1e-2 * wr.grad.abs().max()
+    conv.weight.grad = None
+    y2 = s3.stem3x3_conv(conv, x)
+    y2.backward(gy)
+    assert torch.equal(y, y2) and torch.equal(g1, conv.weight.grad)            # deterministic
+    assert not s3.eligible(conv, x.clone().requires_grad_(True))
+    assert not s3.eligible(conv, torch.zeros(2, 3, 30, 30, device=DEV).bfloat16())
+
+
+def test_se_cotnetd_stem_makes_no_module_fallback(monkeypatch):
+    """SE-CoTNetD's stem (stem_width 64) in the measured form -- bf16 weights, library kernels -- runs without a single module
+    convolution and follows an fp32 evaluation of the same modules"""
+    import copy
+    from cotnet_amd import _lib, conv3x3g, resnet
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    monkeypatch.setattr(s7, "MODE", "hip")
+    monkeypatch.setattr(conv3x3g, "MODE", "hip")
+    torch.manual_seed(31)
+    conv1, inplanes = resnet.make_stem(3, 64, "deep", nn.BatchNorm2d, nn.ReLU)
+    stem = nn.ModuleDict(dict(conv1=conv1, bn1=nn.BatchNorm2d(inplanes), act1=nn.ReLU(inplace=True))).to(DEV).train()
+    ref = copy.deepcopy(stem)
+    stem = to_mixed_bf16(stem)
+    x = torch.randn(4, 3, 320, 320, device=DEV).bfloat16()
+    _lib.FALLBACKS.clear()
+    y = resnet.stem_forward(stem["conv1"], stem["bn1"], stem["act1"], x)
+    assert not _lib.FALLBACKS, dict(_lib.FALLBACKS)
+    g = torch.randn_like(y)
+    y.backward(g)
+    for p_, q_ in zip(ref.parameters(), stem.parameters()):   # the same (rounded) weights in fp32
+        p_.data.copy_(q_.data.float())
+    yr = ref["act1"](ref["bn1"](ref["conv1"](x.float())))
+    yr.backward(g.float())
+    assert (y.float() - yr).norm() <= 2e-2 * yr.norm()
+    for (n_, a), (_, b) in zip(stem.named_parameters(), ref.named_parameters()):
+        assert (a.grad.float() - b.grad).norm() <= 0.1 * b.grad.norm() + 1e-3, n_
