@@ -85,6 +85,12 @@ def parse():
                          "all-reduces on the communication stream, fp32 buckets, deferred communication around a graph")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not re-measure roofline.traffic with two rocprofv3 --pmc child passes (then the tracked table is carried)")
+    ap.add_argument("--graph-collectives", choices=["on", "off"], default="off",
+                    help="N > 1 under --graph: on = capture the bucket all-reduces (stream-ordered RCCL calls on the communication stream) and "
+                         "the SGD kernels inside the step's graph -- one replay per step on every rank; off (default) = forward + backward are "
+                         "the graph, collectives and SGD issued after every replay.  Measured through a world-of-one communicator "
+                         "(profiles/r06_collectives.log): on 15.0 ms, off 14.4 ms, no process group 13.7 ms; a capture with collectives inside "
+                         "that FAILS takes the NCCL watchdog down with it, which is why it is not tried by default")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object of the default line (BASELINE configs 4 / 5 and the reference's fp32 precision "
                          "measured by short child runs of this script on the same GPU)")
@@ -802,50 +808,77 @@ def main():
         # with it during capture, which aborts the process)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        captured = True
+        captured, full = True, False
+
+        def agree(ok):
+            """every rank or none (the forms issue their collectives in different orders)"""
+            if world <= 1:
+                return ok
+            okt = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            return bool(int(okt.item()))
+        if reducing and args.graph_collectives == "on":
+            # N > 1, first choice: the WHOLE step is the graph -- forward, backward, the buckets' all-reduces on the communication
+            # stream as the gradient hooks launch them (RCCL collectives are capturable; they overlap backward inside the replay as
+            # they do eagerly) and the flat SGD kernels: one replay per step on every rank, nothing issued by the host afterwards
+            try:
+                barrier()
+                with torch.cuda.graph(graph, stream=gstream, capture_error_mode=os.environ.get("COT_BENCH_CAPTURE_MODE", "thread_local")):
+                    graph_loss = eager_step()
+                    if os.environ.get("COT_BENCH_FAIL_CAPTURE") == "full":
+                        raise RuntimeError("COT_BENCH_FAIL_CAPTURE=full is set (test of the fallback)")
+                full = True
+            except Exception as e:
+                graph_note = f"capture with the collectives inside failed ({type(e).__name__}: {str(e)[:160]})"
+                print(f"[bench] {graph_note}", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            if not agree(full):
+                full = False
+                opt.zero_grad()  # (bucket bookkeeping of the abandoned capture)
+                graph = torch.cuda.CUDAGraph()
         try:
-            if reducing:
-                # N > 1: forward + backward (+ the bucket fills) are the graph; the gradient hooks run once, at capture, with
-                # communication deferred (GradBucketReducer.defer_comm), and every replay is followed by the buckets' all-reduces on
-                # the communication stream and the flat SGD kernels (FlatSGD.step(deferred=True): ~2 launches per bucket, no host
-                # synchronisation) -- the reference's order: backward, all-reduce, optimizer (train.py:264-293)
+            if full:
+                pass
+            elif reducing:
+                # N > 1, second choice: forward + backward (+ the bucket fills) are the graph; the gradient hooks run once, at
+                # capture, with communication deferred (GradBucketReducer.defer_comm), and every replay is followed by the buckets'
+                # all-reduces on the communication stream and the flat SGD kernels (FlatSGD.step(deferred=True): ~2 launches per
+                # bucket, no host synchronisation) -- the reference's order: backward, all-reduce, optimizer (train.py:264-293)
                 opt.reducer.defer_comm = True
                 barrier()
                 with torch.cuda.graph(graph, stream=gstream):
                     graph_loss = step_compute_only()
-                    if os.environ.get("COT_BENCH_FAIL_CAPTURE"):
+                    if os.environ.get("COT_BENCH_FAIL_CAPTURE") in ("1", "all"):
                         raise RuntimeError("COT_BENCH_FAIL_CAPTURE is set (test of the fallback)")
             else:
                 with torch.cuda.graph(graph, stream=gstream):
                     graph_loss = eager_step()
-                    if os.environ.get("COT_BENCH_FAIL_CAPTURE"):
+                    if os.environ.get("COT_BENCH_FAIL_CAPTURE") in ("1", "all"):
                         raise RuntimeError("COT_BENCH_FAIL_CAPTURE is set (test of the fallback)")
         except Exception as e:  # a capture that does not work here must not cost the measurement: eager steps, and the line says so
             captured = False
             graph_note = f"capture failed ({type(e).__name__}: {str(e)[:200]}): the steps were issued eagerly"
             print(f"[bench] {graph_note}", file=sys.stderr, flush=True)
         torch.cuda.synchronize()
-        if world > 1:  # every rank or none (the two forms issue their collectives in different orders)
-            okt = torch.tensor([1 if captured else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            if captured and int(okt.item()) == 0:
-                captured, graph_note = False, "capture failed on another rank: the steps were issued eagerly"
+        if world > 1 and not agree(captured) and captured:
+            captured, graph_note = False, "capture failed on another rank: the steps were issued eagerly"
+        from cotnet_amd.cot_layer_fused import invalidate_packs
         if not captured:
             if reducing:
                 opt.reducer.defer_comm = False
+                opt.zero_grad()
             args.graph = False
-        elif reducing:
+        elif reducing and not full:
             def step():  # noqa: F811
                 graph.replay()
                 opt.step(deferred=True)
                 return graph_loss
         else:
-            from cotnet_amd.cot_layer_fused import invalidate_packs
-
             def step():  # noqa: F811
                 graph.replay()
                 invalidate_packs()  # (the replayed SGD kernels moved the weights behind torch's version counters)
                 return graph_loss
+        graph_form = "full" if (captured and (full or not reducing)) else ("deferred" if captured else "eager")
     for _ in range(args.warmup):
         loss = step()
     barrier()
@@ -970,6 +1003,27 @@ def main():
             f["bytes_weighted"] += r["frac_hbm"] * r["ms_per_step"]
         op_families = {k: {"ms_per_step": round(v["ms_per_step"], 3), "time_weighted_frac_hbm": round(v["bytes_weighted"] / max(v["ms_per_step"], 1e-9), 4)}
                        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+        # ---- the whole step against the machine: algorithmic bytes of every ANNOTATED library call of one step
+        # (aggregation launches, 1x1 / 3x3 convolution and BatchNorm calls) over the step's wall time and 8 TB/s; launches counted
+        # over every launch the library made (annotated or not: GroupNorm, radix tail, poolings, stem, SGD carry no byte count)
+        step_ms = elapsed / args.steps * 1e3
+        agg_bytes = sum(nb for kind, g, dtype, layout, ms, nb, kname in recs if kname.startswith("agg_")) / max(timing_steps, 1)
+        op_bytes = 0.0
+        for (op, shp), e in ops.items():
+            calls = max(1, round(e["launches"] / max(1, len(e["kernels"]))))
+            op_bytes += e["bytes"] * calls / max(timing_steps, 1)
+        lib_ms = sum(ms for kind, g, dtype, layout, ms, nb, kname in recs) / max(timing_steps, 1)
+        ann_ms = (sum(ms for kind, g, dtype, layout, ms, nb, kname in recs if kname.startswith("agg_") or str(kind).startswith("op:"))
+                  / max(timing_steps, 1))
+        step_roofline = {
+            "bytes": int(agg_bytes + op_bytes), "ms_per_step": round(step_ms, 3),
+            "frac": round((agg_bytes + op_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if step_ms > 0 else None,
+            "launches": round(len(recs) / max(timing_steps, 1), 1),
+            "launches_under_10us": round(sum(1 for r in recs if r[4] < 0.010) / max(timing_steps, 1), 1),
+            "ms_in_launches_under_10us": round(sum(r[4] for r in recs if r[4] < 0.010) / max(timing_steps, 1), 3),
+            "library_kernel_ms_per_step_single_stream": round(lib_ms, 3), "annotated_share_of_kernel_time": round(ann_ms / lib_ms, 4) if lib_ms else None,
+            "note": "bytes = algorithmic bytes (operands read once, results written once) of the aggregation / convolution / BatchNorm "
+                    "calls of one step; frac = bytes / ms_per_step / 8 TB/s: how far the STEP is from the HBM roofline"}
         roofline = None
         if kernels:
             k0 = next((k for k in kernels if k["GBs"] > 0), kernels[0])  # (a launch without byte annotation never is the headline kernel)
@@ -997,7 +1051,8 @@ def main():
                         "frac_all_layers": round(sum(k["GBs"] * k["total_ms"] for k in kernels) / max(sum(k["total_ms"] for k in kernels), 1e-9)
                                                  / HBM_PEAK_GBS, 4),
                         "kernels": kernels,
-                        "conv_bn_families": op_families, "conv_bn_calls": op_rows[:40],
+                        "step": step_roofline,
+                        "conv_bn_families": op_families, "conv_bn_calls": op_rows,
                         "conv_bn_note": "per CALL of the C ABI (all launches of the call), dispatch-attached events; frac_hbm = algorithmic "
                                         "bytes / time / 8 TB/s, frac_mfma = 2*N*HW*Ci*Co(*9)/groups / time / 2.5 PFLOP/s; weight gradients "
                                         "run on a side stream beside other kernels, so their times overlap the rest of the step"}
@@ -1029,8 +1084,11 @@ def main():
             # of the two the loop blocks on the launch queue, so this is an upper bound of the host's own work)
             "host_issue_ms_per_step": round(issued / args.steps * 1e3, 3), "host_issue_ms_one_step_idle_queue": round(issue_one * 1e3, 3),
             **({"graph": ("forward + backward + bucket fills captured in one HIP graph after the settling steps; every warm-up / timed step = one "
-                          "replay, then the buckets' all-reduces (RCCL, communication stream) and the flat SGD kernels issued eagerly") if reducing
-                else "whole step captured in one HIP graph after the settling steps; warm-up and timed steps are replays"} if args.graph else
+                          "replay, then the buckets' all-reduces (RCCL, communication stream) and the flat SGD kernels issued eagerly"
+                          + (f" [{graph_note}]" if graph_note else "")) if (reducing and graph_form == "deferred")
+                else ("whole step captured in one HIP graph after the settling steps" + (", the buckets' all-reduces (RCCL, communication "
+                      "stream, overlapping backward) and the flat SGD kernels inside it" if reducing else "") + "; warm-up and timed steps are replays")}
+               if args.graph else
                ({"graph": graph_note} if graph_note else {"graph": "off: every step issued launch by launch"})),
             "roofline": roofline,
         }

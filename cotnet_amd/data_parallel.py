@@ -248,10 +248,17 @@ class GradBucketReducer:
         return b.rflat if b.rflat is not None else b.flat
 
     def _all_reduce(self, flat):
+        # Inside a HIP-graph capture the collective is issued synchronously (in stream order on the communication stream, no
+        # Work object): `work.wait()` on a side stream of a capture segfaults in hipStreamEndCapture on ROCm 7.2 / torch 2.10
+        # (scripts/probe_rccl_capture.py, profiles/r06_rccl_capture_probe.log), the stream-ordered form captures and replays.
+        # The host does not block either way; finish() joins the communication stream.
+        capturing = self.on_gpu and torch.cuda.is_current_stream_capturing()
         if self._avg_op:
-            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        flat.div_(self.world)  # pre-divide, then SUM (gloo has no AVG)
-        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=not capturing)
+        else:
+            flat.div_(self.world)  # pre-divide, then SUM (gloo has no AVG)
+            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=not capturing)
+        return None if capturing else w
 
     # ------------------------------------------------------------------------------------------
     def finish(self):
