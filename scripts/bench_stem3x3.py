@@ -27,6 +27,10 @@ def timeit(fn, iters=10, warm=3):
 
 def main():
     dev = "cuda"
+    from cotnet_amd import _lib
+    for kv in filter(None, os.environ.get("COT_TUNE", "").split(",")):  # e.g. COT_TUNE=15:0,39:0
+        k, v = kv.split(":")
+        _lib.lib().cot_set_tuning(int(k), int(v))
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     torch.manual_seed(0)
     cases = [("3->64 s2 @320", nn.Conv2d(3, 64, 3, 2, 1, bias=False), (N, 3, 320, 320), False),
@@ -54,7 +58,15 @@ def main():
         ex = ((gx.float() - x.grad.float()).norm() / x.grad.float().norm()).item() if need_gx else 0.0
         t_of, t_ob = timeit(ours), timeit(lambda: fb(ours))
         t_mf, t_mb = timeit(lambda: conv(x)), timeit(lambda: fb(lambda: conv(x)))
-        print(f"{name:16s} ours fwd {t_of:8.1f} us fwd+bwd {t_ob:8.1f} us | module fwd {t_mf:8.1f} us fwd+bwd {t_mb:8.1f} us | "
+        parts = ""
+        if need_gx:  # the two gradients one at a time (autograd prunes the other)
+            xd = x.detach()
+            t_w = timeit(lambda: torch.autograd.grad(conv3x3g.conv3x3(conv, xd), conv.weight, g)) - t_of
+            conv.weight.requires_grad_(False)
+            t_d = timeit(lambda: torch.autograd.grad(conv3x3g.conv3x3(conv, x), x, g)) - t_of
+            conv.weight.requires_grad_(True)
+            parts = f" [dgrad {t_d:7.1f} wgrad {t_w:7.1f}]"
+        print(f"{name:16s} ours fwd {t_of:8.1f} us fwd+bwd {t_ob:8.1f} us{parts} | module fwd {t_mf:8.1f} us fwd+bwd {t_mb:8.1f} us | "
               f"rel err y {err:.1e} gw {ew:.1e} gx {ex:.1e}", flush=True)
 
 

@@ -163,8 +163,31 @@ def _conv1x1(key, shp, what):
             _close(gb, gy.float().sum((0, 2, 3)))
 
 
+def _stem3x3(key, shp, what):
+    """a deep stem's first convolution (3 x 3 / stride 2, 3 -> Co: csrc/stem3x3.hip) at the table's size"""
+    N, Ci, Co, G, H, W, s, bias = shp
+    L, pin = _lib.lib(), _Pinned(key)
+    x = _randn(N, 3, H, W, seed=H + Co)
+    w = _randn(Co, 3, 3, 3, seed=H + Co + 1, scale=27 ** -0.5)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    st = _st()
+    if what == "fwd":
+        y = torch.full((N, Co, Ho, Wo), float("nan"), device=DEV).bfloat16()
+        pin.issue(lambda: L.cot_stem3x3s2_forward(P(x), P(w), P(y), N, H, W, Co, BF, st))
+        _close(y, F.conv2d(x.float(), w.float(), None, 2, 1))
+    else:
+        gy = _randn(N, Co, Ho, Wo, seed=H + Co + 2)
+        ws = torch.empty(int(L.cot_stem3x3s2_workspace(N, H, W, Co)), dtype=torch.uint8, device=DEV)
+        ws.fill_(0xFF)
+        gw = torch.full((Co, 3, 3, 3), float("nan"), device=DEV).bfloat16()
+        pin.issue(lambda: L.cot_stem3x3s2_backward_weight(P(gy), P(x), P(gw), P(ws), N, H, W, Co, BF, st))
+        _close(gw, torch.nn.grad.conv2d_weight(x.float(), (Co, 3, 3, 3), gy.float(), 2, 1))
+
+
 def _conv3x3(key, shp, what):
     N, Ci, Co, G, H, W, s, bias = shp
+    if s == 2 and Ci == 3:
+        return _stem3x3(key, shp, what)
     L, pin = _lib.lib(), _Pinned(key)
     seed = Ci * 3 + H
     HW = H * W
