@@ -829,8 +829,15 @@ static int cot_conv3x3g_backward_data_impl(const void* gy, const void* weight, v
     if (conv3x3g_general(Cin, Cout, groups, dtype))
         return convg_backward_data(gy, weight, gx, N, Cin, Cout, groups, H, W, 3, accumulate ? 1 : 0, dtype,
                                    (hipStream_t)stream);
-    rc = conv3x3g_lds_gemm(gy, weight, gx, workspace, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
-    if (rc != -1) return rc;
+    // Dense convolutions on rows wider than 128 pixels (SE-CoTNetD's deep stem at 160 x 160, models/cotnet_hybrid.py:359-368): an
+    // LDS tile of the per-step ring holds ONE output row between two halo rows there, and the data gradient -- K = Cout up to 128
+    // channels deep -- runs faster on the first-generation register-ring kernel: 64 -> 64 986 -> 560 us, 64 -> 128 1784 -> 1183 us
+    // at B = 64 (the forward does not: 1012 vs 1140, 1237 vs 2058 us; profiles/r06_deep_stem_kernel_choice.log)
+    const bool wide_dense = groups == 1 && W > 128;
+    if (!wide_dense) {
+        rc = conv3x3g_lds_gemm(gy, weight, gx, workspace, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
+        if (rc != -1) return rc;
+    }
     return conv3x3g_gemm(gy, weight, gx, masks, N, Cin, Cout, groups, H, W, 1, accumulate ? 1 : 0, (hipStream_t)stream);
 }
 int cot_conv3x3g_backward_data(const void* gy, const void* weight, void* gx, int accumulate, const void* masks,
