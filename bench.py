@@ -823,7 +823,7 @@ def main():
             # they do eagerly) and the flat SGD kernels: one replay per step on every rank, nothing issued by the host afterwards
             try:
                 barrier()
-                with torch.cuda.graph(graph, stream=gstream, capture_error_mode=os.environ.get("COT_BENCH_CAPTURE_MODE", "thread_local")):
+                with torch.cuda.graph(graph, stream=gstream):
                     graph_loss = eager_step()
                     if os.environ.get("COT_BENCH_FAIL_CAPTURE") == "full":
                         raise RuntimeError("COT_BENCH_FAIL_CAPTURE=full is set (test of the fallback)")

@@ -252,7 +252,10 @@ def _masks(L, H, W, device):
 # layer seen in the last forward are made on the weight-gradient side stream, into persistent buffers, and the next step's forward /
 # backward run `cot_conv3x3g_*_packed`.  Validity = (storage pointer, torch's version counter, the optimizer epoch below -- the flat
 # SGD kernel writes through raw pointers, which torch's counter does not see --, geometry).  Never inside a graph capture (a replay
-# would keep reading the packing of the capture): captured steps pack inline as before.  COT_PREPACK=0 opts out.
+# would keep reading the packing of the capture): captured steps pack inline as before.  (Round 6 tried the scheme INSIDE a whole-step
+# capture -- packings re-made behind the captured SGD kernels, read by the next replay; loss trajectory identical to eager -- and
+# measured nothing: 13.82 / 13.80 ms with / without, profiles/r06_prepack_in_capture_ab.log; the inline packing launches are not on
+# a replayed step's critical path.  Not kept.)  COT_PREPACK=0 opts out.
 PREPACK = os.environ.get("COT_PREPACK", "1") != "0"
 PARAM_EPOCH = [0]
 _PACKS = weakref.WeakKeyDictionary()   # nn.Conv2d -> {"geom": (N, C, G, H, W), 0: (key, buffer), 1: (key, buffer)}
