@@ -179,6 +179,9 @@ const char* cot_last_kernel(void);
  *           wave (1 default), 0 = one workgroup each
  *   key 50: radix-2 tail kernels with channel-major descriptors on 7 x 7 bf16 planes: eight planes per wave, 7 lanes x 7 elements
  *           each (1 default), 0 = one wave per plane
+ *   key 51: aggregation_zeropad_mix: 1 = the one-lane-per-element kernels for every call (A/B; default 0 = LDS-tiled kernels where
+ *           the geometry is stride 1, padding 1 / 2);  key 52: lanes a tiled workgroup aims for (default 256);  key 53: pixels per lane
+ *           (0 = the planner's choice per direction, else 1 / 2 / 4)
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
  *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
  *           ring everywhere
