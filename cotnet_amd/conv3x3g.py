@@ -56,6 +56,24 @@ def _ws_bytes(N, Cin, Cout, G, H, W, dtype=torch.bfloat16):
     return v
 
 
+def new_guarded(N, C, H, W, dtype, dev):
+    """[N, C, H, W] tensor with W + 1 (rounded up to 8) elements of the same allocation before and behind it: the LDS-staged weight
+    gradient (cot_conv3x3g_backward_weight_guarded) copies x at pixel + tap offset in whole 16-byte pieces; what lies in the margins
+    never reaches a sum.  Producers whose output feeds a 3x3 convolution allocate it this way (fused_bn_act)."""
+    lead = (W + 1 + 7) // 8 * 8
+    n = N * C * H * W
+    flat = torch.empty(n + 2 * lead, dtype=dtype, device=dev)
+    return flat[lead:lead + n].view(N, C, H, W)
+
+
+def guard_elems(t):
+    """elements of t's own allocation before its first and behind its last element (0 for a tensor that fills its storage)"""
+    if not t.is_contiguous():
+        return 0
+    total = t.untyped_storage().nbytes() // t.element_size()
+    return max(0, min(t.storage_offset(), total - t.storage_offset() - t.numel()))
+
+
 class _Conv3x3G(Function):
     @staticmethod
     def forward(ctx, x, weight, groups):
@@ -90,8 +108,9 @@ class _Conv3x3G(Function):
                 _lib.check(rc, "cot_conv3x3g_backward_data")
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)
-            rc = L.cot_conv3x3g_backward_weight(_p(gy), _p(x), _p(gw), _p(masks), _p(ws), N, Cin, Cout, G, H, W,
-                                                _lib.dtype_code(x.dtype), _stream())
+            # (the margins x's own allocation has around it: with W + 1 or more the LDS-staged kernel runs, with 0 the per-wave one)
+            rc = L.cot_conv3x3g_backward_weight_guarded(_p(gy), _p(x), _p(gw), _p(masks), _p(ws), N, Cin, Cout, G, H, W,
+                                                        _lib.dtype_code(x.dtype), guard_elems(x), _stream())
             if rc:
                 _lib.check(rc, "cot_conv3x3g_backward_weight")
         return gx, gw, None

@@ -51,7 +51,10 @@ class _BNAct(Function):
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, nbt, eps, momentum, act):
         N, C, H, W = x.shape
         L = _lib.lib()
-        y = torch.empty_like(x)
+        # (with a row's worth of margins inside its own allocation: a 3x3 convolution that consumes y -- a deep stem's, SplitAttn's --
+        # then takes the LDS-staged weight gradient, cot_conv3x3g_backward_weight_guarded)
+        from .conv3x3g import new_guarded
+        y = new_guarded(N, C, H, W, x.dtype, x.device) if x.dtype == torch.bfloat16 else torch.empty_like(x)
         # one allocation for [mean | rstd | workspace]; host overhead matters: the step issues ~160 of these launches
         nws = _ws_floats(N, C)
         scratch = torch.empty(2 * C + nws, dtype=torch.float32, device=x.device)
