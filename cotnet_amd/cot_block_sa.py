@@ -1,0 +1,192 @@
+"""SE-CoTNetD's SplitAttn block as ONE autograd node (split out of cot_layer_fused.py in round 6; the switches, the side-stream machinery
+and the BatchNorm / convolution helpers live there and are imported below).  Imported by cot_layer_fused at its end: import THAT module.
+"""
+import weakref
+import torch
+from torch import nn
+from torch.autograd import Function
+from . import _lib, grad_sink
+from . import cot_layer_fused as clf
+from .cot_layer_fused import (  # noqa: E402  (helpers; the switches are read as clf.NAME at call time: tests rebind them there)
+    BF16, NODE_COUNTS, _Side, _bn_bwd, _bn_fwd, _bn_static_ok, _ck, _conv3x3_dgrad, _conv3x3_fwd, _conv_ok,
+    _drop_path_scale, _guard_elems, _masks, _new_guarded, _one_stream_query, _p, _relu_mask, _stream)
+
+# ---- SE-CoTNetD's OTHER block kind as one node: CoTBottleneck whose conv2 is SplitAttnConv2d(radix = 1) (models/cotnet_hybrid.py:
+# 138-146, :172-202; models/layers/split_attn.py:62-88) -- conv1 -> bn1+relu -> dense 3x3 -> bn0+act -> SE gate x * sigmoid(fc2(act(
+# bn(fc1(mean_hw x))))) -> conv3 -> bn3 + residual + relu.  29 of se_cotnetd_152's 50 blocks; with one autograd node per op they
+# left the step host-bound (71.9 ms per step for 47.9 ms of kernels, profiles/r04).  Identity-shortcut blocks (no avd pooling, no
+# projection: 26 of the 29); the three stage-opening blocks keep the module path.  The two fc layers act on [N, C] descriptors:
+# plain GEMMs (torch.addmm / matmul on the conv weights viewed as matrices), their BatchNorm over the batch on the library's
+# small-batch kernel.
+class _SABlockPlan:
+    __slots__ = ("conv1", "bn1", "conv", "bn0", "fc1", "sbn", "fc2", "conv3", "bn3", "params", "static_ok", "act0", "act1")
+
+    def __init__(self, blk):
+        from .layers import SplitAttnConv2d
+        sa = blk.conv2
+        self.conv1, self.bn1, self.conv3, self.bn3 = blk.conv1, blk.bn1, blk.conv3, blk.bn3
+        self.static_ok = False
+        self.params = []
+        if not (isinstance(sa, SplitAttnConv2d) and sa.radix == 1):
+            return
+        self.conv, self.bn0, self.fc1, self.sbn, self.fc2 = sa.conv, sa.bn0, sa.fc1, sa.bn1, sa.fc2
+        code = lambda m: 1 if isinstance(m, nn.ReLU) else (2 if isinstance(m, nn.SiLU) else -1)  # noqa: E731
+        self.act0, self.act1 = code(sa.act0), code(sa.act1)
+        C = sa.conv.out_channels
+        fc_ok = lambda c: (isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0)  # noqa: E731
+                           and c.groups == 1 and c.bias is not None)
+        self.static_ok = (
+            blk.downsample is None and blk.avd is None and blk.drop_block is None and sa.drop_block is None
+            and (blk.drop_path is None or hasattr(blk.drop_path, "drop_prob")) and getattr(blk, "se", None) is None
+            and isinstance(blk.act1, nn.ReLU) and isinstance(blk.act3, nn.ReLU)
+            and _conv_ok(blk.conv1, 1, 1) and blk.conv1.bias is None and _conv_ok(blk.conv3, 1, 1) and blk.conv3.bias is None
+            and _conv_ok(sa.conv, 3) and sa.conv.bias is None and sa.conv.in_channels == C and (C // sa.conv.groups) % 8 == 0
+            and blk.conv1.in_channels % 8 == 0 and blk.conv1.in_channels == blk.conv3.out_channels
+            and fc_ok(sa.fc1) and fc_ok(sa.fc2) and sa.fc1.in_channels == C and sa.fc2.out_channels == C
+            and sa.fc1.out_channels % 8 == 0 and self.act0 > 0 and self.act1 > 0
+            and all(_bn_static_ok(b) for b in (blk.bn1, blk.bn3, sa.bn0, sa.bn1)))
+        self.params = [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, sa.conv.weight, sa.bn0.weight, sa.bn0.bias, sa.fc1.weight,
+                       sa.fc1.bias, sa.bn1.weight, sa.bn1.bias, sa.fc2.weight, sa.fc2.bias, blk.conv3.weight, blk.bn3.weight,
+                       blk.bn3.bias]
+
+
+_SA_PLANS = weakref.WeakKeyDictionary()
+_SASIZES = _lib.register_cache({})
+
+
+def _sa_plan(blk):
+    p = _SA_PLANS.get(blk)
+    if p is None:
+        p = _SA_PLANS[blk] = _SABlockPlan(blk)
+    return p
+
+
+def _sa_sizes(L, N, Cin, Cw, A, G, H, W):
+    k = (N, Cin, Cw, A, G, H, W)
+    v = _SASIZES.get(k)
+    if v is None:
+        HW = H * W
+        ws = max(int(L.cot_conv1x1_workspace(N, Cin, Cw, HW, 0)), int(L.cot_conv1x1_workspace(N, Cw, Cin, HW, 0)),
+                 int(L.cot_conv3x3g_workspace(N, Cw, Cw, G, H, W)))
+        v = _SASIZES[k] = (ws, int(L.cot_bn_act_workspace(N, Cw)), int(L.cot_bn_act_workspace(N, Cin)), int(L.cot_bn_act_workspace(N, A)))
+    return v
+
+
+class _SplitAttnBlockNode(Function):
+    @staticmethod
+    @_one_stream_query
+    def forward(ctx, blk, x, *params):
+        L = _lib.lib()
+        sp = _sa_plan(blk)
+        N, Cin, H, W = x.shape
+        Cw, A, G = sp.conv.out_channels, sp.fc1.out_channels, sp.conv.groups
+        HW = H * W
+        dev, st = x.device, _stream()
+        ws_bytes, nws_w, nws_o, nws_a = _sa_sizes(L, N, Cin, Cw, A, G, H, W)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        masks = _masks(L, H, W, dev)
+        new = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
+        stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
+        c1, a1 = new(Cw), _new_guarded(N, Cw, H, W, x.dtype, dev)  # (the 3x3 weight gradient reads a1 shifted: margins)
+        _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(sp.conv1.weight), None, _p(c1), N, Cin, Cw, HW, BF16, st), "cot_conv1x1_forward")
+        s_1 = stat(Cw, nws_w)
+        _bn_fwd(L, c1, a1, sp.bn1, s_1, 2 * Cw, N, Cw, HW, 1)
+        c2, b2 = new(Cw), new(Cw)
+        _conv3x3_fwd(L, sp.conv, a1, c2, masks, ws, N, Cw, G, H, W)
+        s_0 = stat(Cw, nws_w)
+        _bn_fwd(L, c2, b2, sp.bn0, s_0, 2 * Cw, N, Cw, HW, sp.act0)
+        # the gate: pooled descriptor [N, Cw] -> fc1 -> BatchNorm over the batch + act -> fc2 -> x * sigmoid(logits)
+        gap = torch.empty((N, Cw), dtype=x.dtype, device=dev)
+        _ck(L.cot_se_gap(_p(b2), _p(gap), N * Cw, HW, BF16, st), "cot_se_gap")
+        hpre = torch.addmm(sp.fc1.bias, gap, sp.fc1.weight.view(A, Cw).t())
+        h = torch.empty_like(hpre)
+        s_s = stat(A, nws_a)
+        _bn_fwd(L, hpre, h, sp.sbn, s_s, 2 * A, N, A, 1, sp.act1)  # ([N, A, 1, 1]: N samples per channel)
+        logits = torch.addmm(sp.fc2.bias, h, sp.fc2.weight.view(Cw, A).t())
+        out2 = new(Cw)
+        _ck(L.cot_se_gate(_p(b2), _p(logits), _p(out2), N * Cw, HW, BF16, st), "cot_se_gate")
+        c3, y = new(Cin), new(Cin)
+        _ck(L.cot_conv1x1_forward(_p(out2), None, Cw, _p(sp.conv3.weight), None, _p(c3), N, Cw, Cin, HW, BF16, st), "cot_conv1x1_forward")
+        s_3 = stat(Cin, nws_o)
+        ps = _drop_path_scale(blk, N, dev)
+        m3 = _relu_mask(L, N, Cin, HW, dev)
+        _bn_fwd(L, c3, y, sp.bn3, s_3, 2 * Cin, N, Cin, HW, 1, residual=x, ps=ps, mask=m3)
+        ctx.blk, ctx.has_ps, ctx.has_mask = blk, ps is not None, m3 is not None
+        ctx.save_for_backward(x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3,
+                              *((m3,) if m3 is not None else ()), *((ps,) if ps is not None else ()))
+        return y
+
+    @staticmethod
+    @_one_stream_query
+    def backward(ctx, gout):
+        L = _lib.lib()
+        blk = ctx.blk
+        sp = _sa_plan(blk)
+        t = ctx.saved_tensors
+        x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3 = t[:16]
+        m3 = t[16] if ctx.has_mask else None
+        ps = t[-1] if ctx.has_ps else None
+        N, Cin, H, W = x.shape
+        Cw, A, G = sp.conv.out_channels, sp.fc1.out_channels, sp.conv.groups
+        HW = H * W
+        dev, st = x.device, _stream()
+        ws_bytes, nws_w, nws_o, nws_a = _sa_sizes(L, N, Cin, Cw, A, G, H, W)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        masks = _masks(L, H, W, dev)
+        side = _Side(dev, ws_bytes, ws, sp.params)
+        gout = gout.contiguous()
+        g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
+        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, sp.bn3, s_3, N, Cin, HW, 1, nws_o, dres=g_res, ps=ps, mask=m3)
+        g_out2 = torch.empty_like(out2)
+        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(sp.conv3.weight), _p(g_out2), None, Cw, 0, _p(ws), N, Cw, Cin, HW, BF16, st),
+            "cot_conv1x1_backward_data")
+        g_w3 = grad_sink.out_like(sp.conv3.weight)
+        side.run(lambda st_, a_=(_p(g_c3), _p(out2), None, Cw, _p(g_w3), None, _p(side.ws), N, Cw, Cin, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, out2)
+        # gate: dx of x * sigmoid(l) and dl in one pass; then the two fc layers (GEMMs on [N, .] descriptors) and their BatchNorm
+        g_b2, g_log = torch.empty_like(b2), torch.empty_like(logits)
+        _ck(L.cot_se_gate_backward(_p(g_out2), _p(b2), _p(logits), _p(g_b2), _p(g_log), N * Cw, HW, BF16, st), "cot_se_gate_backward")
+        W2, W1 = sp.fc2.weight.view(Cw, A), sp.fc1.weight.view(A, Cw)
+        g_h = torch.matmul(g_log, W2)
+        g_fc2_w, g_fc2_b = grad_sink.out_like(sp.fc2.weight), grad_sink.out_like(sp.fc2.bias)
+        torch.matmul(g_log.t(), h, out=g_fc2_w.view(Cw, A))
+        g_fc2_b.copy_(g_log.float().sum(0))
+        g_hpre = torch.empty_like(hpre)
+        d_sbn_w, d_sbn_b = _bn_bwd(L, g_h, hpre, None, g_hpre, sp.sbn, s_s, N, A, 1, sp.act1, nws_a)
+        g_gap = torch.matmul(g_hpre, W1)
+        g_fc1_w, g_fc1_b = grad_sink.out_like(sp.fc1.weight), grad_sink.out_like(sp.fc1.bias)
+        torch.matmul(g_hpre.t(), gap, out=g_fc1_w.view(A, Cw))
+        g_fc1_b.copy_(g_hpre.float().sum(0))
+        g_b2.add_((g_gap.float() / HW).to(g_b2.dtype).view(N, Cw, 1, 1))  # d mean_hw: the same value for every pixel of a plane
+        g_c2 = g_out2  # (reuse: consumed by the gate's backward)
+        d_bn0_w, d_bn0_b = _bn_bwd(L, g_b2, c2, None, g_c2, sp.bn0, s_0, N, Cw, HW, sp.act0, nws_w)
+        g_wc = grad_sink.out_like(sp.conv.weight)
+        side.run(lambda st_, a_=(_p(g_c2), _p(a1), _p(g_wc), _p(masks), _p(side.ws), N, Cw, Cw, G, H, W, BF16, _guard_elems(a1)): _ck(L.cot_conv3x3g_backward_weight_guarded(*a_, st_), "cot_conv3x3g_backward_weight"), g_c2, a1, masks)
+        g_a1 = g_b2  # (reuse: consumed by bn0's backward)
+        _conv3x3_dgrad(L, sp.conv, g_c2, g_a1, 0, masks, ws, N, Cw, G, H, W)
+        g_c1 = torch.empty_like(c1)
+        d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1, c1, None, g_c1, sp.bn1, s_1, N, Cw, HW, 1, nws_w)
+        gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
+        g_w1 = grad_sink.out_like(sp.conv1.weight)
+        side.run(lambda st_, a_=(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, Cw, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, x)
+        _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(sp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16, st),
+            "cot_conv1x1_backward_data")
+        side.join()
+        return (None, gx, g_w1, d_bn1_w, d_bn1_b, g_wc, d_bn0_w, d_bn0_b, g_fc1_w, g_fc1_b, d_sbn_w, d_sbn_b, g_fc2_w, g_fc2_b, g_w3,
+                d_bn3_w, d_bn3_b)
+
+
+def sa_block_eligible(blk, x):
+    """training-mode cotnet_hybrid.CoTBottleneck with a SplitAttnConv2d(radix=1) conv2, identity shortcut, on a bf16 NCHW tensor"""
+    if not (clf.ENABLED and blk.training and (x.is_cuda or not clf._DEVICE_ONLY) and x.dim() == 4 and x.dtype == torch.bfloat16
+            and x.is_contiguous() and x.data_ptr() % 16 == 0):
+        return False
+    sp = _sa_plan(blk)
+    return (sp.static_ok and x.shape[1] == sp.conv1.in_channels and sp.conv1.weight.dtype == torch.bfloat16
+            and sp.conv.weight.dtype == torch.bfloat16 and sp.fc1.weight.dtype == torch.bfloat16 and sp.conv3.weight.dtype == torch.bfloat16
+            and sp.bn1.weight.dtype == torch.float32 and sp.bn1.training and sp.bn0.training and sp.sbn.training and sp.bn3.training
+            and x.shape[0] >= 2)
+
+
+def sa_block_forward(blk, x):
+    NODE_COUNTS["split_attn_block"] += 1
+    return _SplitAttnBlockNode.apply(blk, x, *_sa_plan(blk).params)

@@ -1025,718 +1025,13 @@ def block_forward(blk, x):
     return _BottleneckNode.apply(blk, x, *_block_plan(blk).params)
 
 
-# ---- SE-CoTNetD's OTHER block kind as one node: CoTBottleneck whose conv2 is SplitAttnConv2d(radix = 1) (models/cotnet_hybrid.py:
-# 138-146, :172-202; models/layers/split_attn.py:62-88) -- conv1 -> bn1+relu -> dense 3x3 -> bn0+act -> SE gate x * sigmoid(fc2(act(
-# bn(fc1(mean_hw x))))) -> conv3 -> bn3 + residual + relu.  29 of se_cotnetd_152's 50 blocks; with one autograd node per op they
-# left the step host-bound (71.9 ms per step for 47.9 ms of kernels, profiles/r04).  Identity-shortcut blocks (no avd pooling, no
-# projection: 26 of the 29); the three stage-opening blocks keep the module path.  The two fc layers act on [N, C] descriptors:
-# plain GEMMs (torch.addmm / matmul on the conv weights viewed as matrices), their BatchNorm over the batch on the library's
-# small-batch kernel.
-class _SABlockPlan:
-    __slots__ = ("conv1", "bn1", "conv", "bn0", "fc1", "sbn", "fc2", "conv3", "bn3", "params", "static_ok", "act0", "act1")
-
-    def __init__(self, blk):
-        from .layers import SplitAttnConv2d
-        sa = blk.conv2
-        self.conv1, self.bn1, self.conv3, self.bn3 = blk.conv1, blk.bn1, blk.conv3, blk.bn3
-        self.static_ok = False
-        self.params = []
-        if not (isinstance(sa, SplitAttnConv2d) and sa.radix == 1):
-            return
-        self.conv, self.bn0, self.fc1, self.sbn, self.fc2 = sa.conv, sa.bn0, sa.fc1, sa.bn1, sa.fc2
-        code = lambda m: 1 if isinstance(m, nn.ReLU) else (2 if isinstance(m, nn.SiLU) else -1)  # noqa: E731
-        self.act0, self.act1 = code(sa.act0), code(sa.act1)
-        C = sa.conv.out_channels
-        fc_ok = lambda c: (isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0)  # noqa: E731
-                           and c.groups == 1 and c.bias is not None)
-        self.static_ok = (
-            blk.downsample is None and blk.avd is None and blk.drop_block is None and sa.drop_block is None
-            and (blk.drop_path is None or hasattr(blk.drop_path, "drop_prob")) and getattr(blk, "se", None) is None
-            and isinstance(blk.act1, nn.ReLU) and isinstance(blk.act3, nn.ReLU)
-            and _conv_ok(blk.conv1, 1, 1) and blk.conv1.bias is None and _conv_ok(blk.conv3, 1, 1) and blk.conv3.bias is None
-            and _conv_ok(sa.conv, 3) and sa.conv.bias is None and sa.conv.in_channels == C and (C // sa.conv.groups) % 8 == 0
-            and blk.conv1.in_channels % 8 == 0 and blk.conv1.in_channels == blk.conv3.out_channels
-            and fc_ok(sa.fc1) and fc_ok(sa.fc2) and sa.fc1.in_channels == C and sa.fc2.out_channels == C
-            and sa.fc1.out_channels % 8 == 0 and self.act0 > 0 and self.act1 > 0
-            and all(_bn_static_ok(b) for b in (blk.bn1, blk.bn3, sa.bn0, sa.bn1)))
-        self.params = [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, sa.conv.weight, sa.bn0.weight, sa.bn0.bias, sa.fc1.weight,
-                       sa.fc1.bias, sa.bn1.weight, sa.bn1.bias, sa.fc2.weight, sa.fc2.bias, blk.conv3.weight, blk.bn3.weight,
-                       blk.bn3.bias]
-
-
-_SA_PLANS = weakref.WeakKeyDictionary()
-_SASIZES = _lib.register_cache({})
-
-
-def _sa_plan(blk):
-    p = _SA_PLANS.get(blk)
-    if p is None:
-        p = _SA_PLANS[blk] = _SABlockPlan(blk)
-    return p
-
-
-def _sa_sizes(L, N, Cin, Cw, A, G, H, W):
-    k = (N, Cin, Cw, A, G, H, W)
-    v = _SASIZES.get(k)
-    if v is None:
-        HW = H * W
-        ws = max(int(L.cot_conv1x1_workspace(N, Cin, Cw, HW, 0)), int(L.cot_conv1x1_workspace(N, Cw, Cin, HW, 0)),
-                 int(L.cot_conv3x3g_workspace(N, Cw, Cw, G, H, W)))
-        v = _SASIZES[k] = (ws, int(L.cot_bn_act_workspace(N, Cw)), int(L.cot_bn_act_workspace(N, Cin)), int(L.cot_bn_act_workspace(N, A)))
-    return v
-
-
-class _SplitAttnBlockNode(Function):
-    @staticmethod
-    @_one_stream_query
-    def forward(ctx, blk, x, *params):
-        L = _lib.lib()
-        sp = _sa_plan(blk)
-        N, Cin, H, W = x.shape
-        Cw, A, G = sp.conv.out_channels, sp.fc1.out_channels, sp.conv.groups
-        HW = H * W
-        dev, st = x.device, _stream()
-        ws_bytes, nws_w, nws_o, nws_a = _sa_sizes(L, N, Cin, Cw, A, G, H, W)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        masks = _masks(L, H, W, dev)
-        new = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
-        stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
-        c1, a1 = new(Cw), _new_guarded(N, Cw, H, W, x.dtype, dev)  # (the 3x3 weight gradient reads a1 shifted: margins)
-        _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(sp.conv1.weight), None, _p(c1), N, Cin, Cw, HW, BF16, st), "cot_conv1x1_forward")
-        s_1 = stat(Cw, nws_w)
-        _bn_fwd(L, c1, a1, sp.bn1, s_1, 2 * Cw, N, Cw, HW, 1)
-        c2, b2 = new(Cw), new(Cw)
-        _conv3x3_fwd(L, sp.conv, a1, c2, masks, ws, N, Cw, G, H, W)
-        s_0 = stat(Cw, nws_w)
-        _bn_fwd(L, c2, b2, sp.bn0, s_0, 2 * Cw, N, Cw, HW, sp.act0)
-        # the gate: pooled descriptor [N, Cw] -> fc1 -> BatchNorm over the batch + act -> fc2 -> x * sigmoid(logits)
-        gap = torch.empty((N, Cw), dtype=x.dtype, device=dev)
-        _ck(L.cot_se_gap(_p(b2), _p(gap), N * Cw, HW, BF16, st), "cot_se_gap")
-        hpre = torch.addmm(sp.fc1.bias, gap, sp.fc1.weight.view(A, Cw).t())
-        h = torch.empty_like(hpre)
-        s_s = stat(A, nws_a)
-        _bn_fwd(L, hpre, h, sp.sbn, s_s, 2 * A, N, A, 1, sp.act1)  # ([N, A, 1, 1]: N samples per channel)
-        logits = torch.addmm(sp.fc2.bias, h, sp.fc2.weight.view(Cw, A).t())
-        out2 = new(Cw)
-        _ck(L.cot_se_gate(_p(b2), _p(logits), _p(out2), N * Cw, HW, BF16, st), "cot_se_gate")
-        c3, y = new(Cin), new(Cin)
-        _ck(L.cot_conv1x1_forward(_p(out2), None, Cw, _p(sp.conv3.weight), None, _p(c3), N, Cw, Cin, HW, BF16, st), "cot_conv1x1_forward")
-        s_3 = stat(Cin, nws_o)
-        ps = _drop_path_scale(blk, N, dev)
-        m3 = _relu_mask(L, N, Cin, HW, dev)
-        _bn_fwd(L, c3, y, sp.bn3, s_3, 2 * Cin, N, Cin, HW, 1, residual=x, ps=ps, mask=m3)
-        ctx.blk, ctx.has_ps, ctx.has_mask = blk, ps is not None, m3 is not None
-        ctx.save_for_backward(x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3,
-                              *((m3,) if m3 is not None else ()), *((ps,) if ps is not None else ()))
-        return y
-
-    @staticmethod
-    @_one_stream_query
-    def backward(ctx, gout):
-        L = _lib.lib()
-        blk = ctx.blk
-        sp = _sa_plan(blk)
-        t = ctx.saved_tensors
-        x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3 = t[:16]
-        m3 = t[16] if ctx.has_mask else None
-        ps = t[-1] if ctx.has_ps else None
-        N, Cin, H, W = x.shape
-        Cw, A, G = sp.conv.out_channels, sp.fc1.out_channels, sp.conv.groups
-        HW = H * W
-        dev, st = x.device, _stream()
-        ws_bytes, nws_w, nws_o, nws_a = _sa_sizes(L, N, Cin, Cw, A, G, H, W)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        masks = _masks(L, H, W, dev)
-        side = _Side(dev, ws_bytes, ws, sp.params)
-        gout = gout.contiguous()
-        g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
-        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, sp.bn3, s_3, N, Cin, HW, 1, nws_o, dres=g_res, ps=ps, mask=m3)
-        g_out2 = torch.empty_like(out2)
-        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(sp.conv3.weight), _p(g_out2), None, Cw, 0, _p(ws), N, Cw, Cin, HW, BF16, st),
-            "cot_conv1x1_backward_data")
-        g_w3 = grad_sink.out_like(sp.conv3.weight)
-        side.run(lambda st_, a_=(_p(g_c3), _p(out2), None, Cw, _p(g_w3), None, _p(side.ws), N, Cw, Cin, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, out2)
-        # gate: dx of x * sigmoid(l) and dl in one pass; then the two fc layers (GEMMs on [N, .] descriptors) and their BatchNorm
-        g_b2, g_log = torch.empty_like(b2), torch.empty_like(logits)
-        _ck(L.cot_se_gate_backward(_p(g_out2), _p(b2), _p(logits), _p(g_b2), _p(g_log), N * Cw, HW, BF16, st), "cot_se_gate_backward")
-        W2, W1 = sp.fc2.weight.view(Cw, A), sp.fc1.weight.view(A, Cw)
-        g_h = torch.matmul(g_log, W2)
-        g_fc2_w, g_fc2_b = grad_sink.out_like(sp.fc2.weight), grad_sink.out_like(sp.fc2.bias)
-        torch.matmul(g_log.t(), h, out=g_fc2_w.view(Cw, A))
-        g_fc2_b.copy_(g_log.float().sum(0))
-        g_hpre = torch.empty_like(hpre)
-        d_sbn_w, d_sbn_b = _bn_bwd(L, g_h, hpre, None, g_hpre, sp.sbn, s_s, N, A, 1, sp.act1, nws_a)
-        g_gap = torch.matmul(g_hpre, W1)
-        g_fc1_w, g_fc1_b = grad_sink.out_like(sp.fc1.weight), grad_sink.out_like(sp.fc1.bias)
-        torch.matmul(g_hpre.t(), gap, out=g_fc1_w.view(A, Cw))
-        g_fc1_b.copy_(g_hpre.float().sum(0))
-        g_b2.add_((g_gap.float() / HW).to(g_b2.dtype).view(N, Cw, 1, 1))  # d mean_hw: the same value for every pixel of a plane
-        g_c2 = g_out2  # (reuse: consumed by the gate's backward)
-        d_bn0_w, d_bn0_b = _bn_bwd(L, g_b2, c2, None, g_c2, sp.bn0, s_0, N, Cw, HW, sp.act0, nws_w)
-        g_wc = grad_sink.out_like(sp.conv.weight)
-        side.run(lambda st_, a_=(_p(g_c2), _p(a1), _p(g_wc), _p(masks), _p(side.ws), N, Cw, Cw, G, H, W, BF16, _guard_elems(a1)): _ck(L.cot_conv3x3g_backward_weight_guarded(*a_, st_), "cot_conv3x3g_backward_weight"), g_c2, a1, masks)
-        g_a1 = g_b2  # (reuse: consumed by bn0's backward)
-        _conv3x3_dgrad(L, sp.conv, g_c2, g_a1, 0, masks, ws, N, Cw, G, H, W)
-        g_c1 = torch.empty_like(c1)
-        d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1, c1, None, g_c1, sp.bn1, s_1, N, Cw, HW, 1, nws_w)
-        gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
-        g_w1 = grad_sink.out_like(sp.conv1.weight)
-        side.run(lambda st_, a_=(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, Cw, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, x)
-        _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(sp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16, st),
-            "cot_conv1x1_backward_data")
-        side.join()
-        return (None, gx, g_w1, d_bn1_w, d_bn1_b, g_wc, d_bn0_w, d_bn0_b, g_fc1_w, g_fc1_b, d_sbn_w, d_sbn_b, g_fc2_w, g_fc2_b, g_w3,
-                d_bn3_w, d_bn3_b)
-
-
-def sa_block_eligible(blk, x):
-    """training-mode cotnet_hybrid.CoTBottleneck with a SplitAttnConv2d(radix=1) conv2, identity shortcut, on a bf16 NCHW tensor"""
-    if not (ENABLED and blk.training and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4 and x.dtype == torch.bfloat16
-            and x.is_contiguous() and x.data_ptr() % 16 == 0):
-        return False
-    sp = _sa_plan(blk)
-    return (sp.static_ok and x.shape[1] == sp.conv1.in_channels and sp.conv1.weight.dtype == torch.bfloat16
-            and sp.conv.weight.dtype == torch.bfloat16 and sp.fc1.weight.dtype == torch.bfloat16 and sp.conv3.weight.dtype == torch.bfloat16
-            and sp.bn1.weight.dtype == torch.float32 and sp.bn1.training and sp.bn0.training and sp.sbn.training and sp.bn3.training
-            and x.shape[0] >= 2)
-
-
-def sa_block_forward(blk, x):
-    NODE_COUNTS["split_attn_block"] += 1
-    return _SplitAttnBlockNode.apply(blk, x, *_sa_plan(blk).params)
-
-
-# ---- channel-major Bottlenecks for the 14 x 14 / 7 x 7 stages (round 5; DESIGN 5.8).  The layers of these stages spend their time in
-# 1x1 convolutions and BatchNorms whose NCHW operands are N short rows per channel (392 / 98 bytes); stored channel-major --
-# [C][N][HW], a channel = ONE row of N*HW elements -- the SAME kernels, called with N = 1 and HW' = N*HW, run 1.2-1.5x faster
-# (profiles/r05_probe_cnhw.log).  So an identity-shortcut block keeps every operand of a 1x1 convolution channel-major and every
-# operand of a plane kernel (grouped 3x3, aggregation) NCHW; the layout changes inside the BatchNorm / GroupNorm / radix kernels that
-# sit between the two kinds anyway (cot_*_lay: one layout bit per tensor):
-#     x -conv1-> c1 -bn1+relu-> a1 (NCHW, for the 3x3) + a1c (channel-major, for the 1x1s)
-#     a1 -3x3-> k_pre (NCHW) -bn+relu-> k (cm);  [a1c | k] -1x1-> e0 -bn+relu-> e1 -1x1-> e3 (all cm) -GroupNorm-> w (NCHW)
-#     a1c -1x1-> v_pre (cm) -bn-> v (NCHW);  aggregation(v, w) -> a -bn+silu-> y (NCHW);  radix tail(y, k) -> out (cm)
-#     out -conv3-> c3 (cm) -bn3 + residual + relu-> block output (cm when the next block is one of these, else NCHW)
-# The block's input / output tensor objects stay honest: a channel-major activation is a [N, C, H, W] tensor whose strides are
-# (HW, N*HW, W, 1) -- any torch consumer computes the right thing with it.  Same parameters, buffers and state_dict as the module
-# (models/cotnet.py:181-264).  COT_CM_LAYOUT=0 opts out.
+# ---- the other node kinds live in their own modules (round 6 split): SplitAttn blocks, channel-major Bottlenecks, the
+# eval-mode call sequence.  They import this module's helpers, so they are imported HERE, at its end, and re-exported under the names
+# the wrappers, bench.py and the tests have always used.  The channel-major switches are attributes of THIS module (tests rebind them).
 CM_LAYOUT = os.environ.get("COT_CM_LAYOUT", "1") != "0"
 CM_OPENING = os.environ.get("COT_CM_OPENING", "1") != "0"  # the stage's stride-2 opening block on the channel-major node too (A/B switch)
-_CM_SIZES = _lib.register_cache({})
-_CM_OK = _lib.register_cache({})
-
-
-def _is_cm(t):
-    """[N, C, H, W] tensor stored [C][N][H][W] (dense)"""
-    N, C, H, W = t.shape
-    return N > 1 and C > 1 and t.stride() == (H * W, N * H * W, W, 1)
-
-
-def _cm_view(buf):
-    """dense [C, N, H, W] buffer -> the honest [N, C, H, W] tensor over it"""
-    return buf.permute(1, 0, 2, 3)
-
-
-def _cm_buf(t):
-    """the dense [C, N, H, W] buffer under a channel-major [N, C, H, W] tensor"""
-    return t.permute(1, 0, 2, 3)
-
-
-def plan_stage_layouts(stage):
-    """mark, once per stage, the blocks whose successor can take a channel-major input (so that they write one)"""
-    blocks = list(stage.children())
-    # the plan depends on both layout switches and on WHICH blocks the stage holds (a replaced block re-plans; ADVICE r5)
-    key = (CM_LAYOUT, CM_OPENING, tuple(id(b) for b in blocks), tuple(b.training for b in blocks))
-    if getattr(stage, "_cm_planned", None) == key:
-        return
-    for i, b in enumerate(blocks):
-        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-        # (an opening block takes NCHW: its conv1 / bn1 run at the input resolution, off the channel-resident kernels)
-        # (... and only a successor in training mode runs the channel-major node: an eval-mode block inside a training stage would
-        # take the module path on a strided tensor -- correct, but a silent performance cliff)
-        b._next_cm = bool(CM_LAYOUT and nxt is not None and nxt.training and _cm_static_ok(nxt) and not _block_plan(nxt).avd)
-    stage._cm_planned = key
-
-
-def _cm_static_ok(blk):
-    from .cotnet import Bottleneck
-    if not isinstance(blk, Bottleneck):
-        return False
-    bp = _block_plan(blk)
-    identity = bp.ds_conv is None and not bp.avd and bp.conv1.in_channels == bp.conv3.out_channels
-    # the stage's opening block (models/cotnet.py:228-264 with `avd` pooling in front of the layer and a stride-2 projection): conv1 /
-    # bn1 / the pooling stay NCHW at the input resolution, the layer, conv3, bn3 and the projection's BatchNorm go channel-major
-    opening = CM_OPENING and bp.ds_conv is not None and bp.avd and bp.ds_stride == 2
-    return bp.static_ok and (identity or opening)
-
-
-def _cm_sizes(L, N, Cin, C, A, G, H, W, grouped=False, Cout=None):
-    """Cin / Cout: the block's input / output channels (Cout given = the stage's opening block: conv1 on 2H x 2W NCHW planes, the
-    projection on the sub-sampled input)"""
-    k = (N, Cin, C, A, G, H, W, grouped, Cout)
-    v = _CM_SIZES.get(k)
-    if v is None:
-        HW, M = H * W, N * H * W
-        gws = max(int(L.cot_convg_workspace(1, 2 * C, C // 2, 2, M, 1, 1)), int(L.cot_convg_workspace(1, C // 2, 9 * C // 8, 2, M, 1, 1)),
-                  int(L.cot_convg_workspace(1, C, C, 2, M, 1, 1))) if grouped else 0
-        ws = max(gws, int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_conv1x1_workspace(1, 2 * C, C // 2, M, 0)),
-                 int(L.cot_conv1x1_workspace(1, C // 2, 9 * C // 8, M, 1)), int(L.cot_conv1x1_workspace(1, C, C, M, 0)),
-                 int(L.cot_conv1x1_workspace(1, C, A, N, 1)), int(L.cot_conv1x1_workspace(1, A, 2 * C, N, 1)),
-                 int(L.cot_conv1x1_workspace(1, Cin, C, M, 0)), int(L.cot_conv1x1_workspace(1, C, Cout or Cin, M, 0)),
-                 int(L.cot_conv1x1_workspace(N, Cin, C, HW, 0)),
-                 *((int(L.cot_conv1x1_workspace(N, Cin, C, 4 * HW, 0)), int(L.cot_conv1x1_workspace(N, Cin, Cout, HW, 0))) if Cout else ()))
-        v = _CM_SIZES[k] = (ws, int(L.cot_bn_act_workspace(N, C)), int(L.cot_bn_act_workspace(1, C)), int(L.cot_bn_act_workspace(1, C // 2)),
-                            int(L.cot_bn_act_workspace(1, A)), int(L.cot_bn_act_workspace(1, Cout or Cin)))
-    return v
-
-
-def _cm_geometry_ok(L, N, Cin, C, H, W, grouped=False):
-    k = (N, Cin, C, H, W, grouped)
-    v = _CM_OK.get(k)
-    if v is None:
-        HW = H * W
-        v = bool(HW <= 256 and (N * HW) % 8 == 0 and N > 1 and C % 64 == 0
-                 and L.cot_bn_act_lay_covers(N, C, HW, BF16) and L.cot_bn_act_lay_covers(N, Cin, HW, BF16)
-                 and L.cot_conv1x1_lds_covers(Cin, Cin, 0, N * HW) and L.cot_conv1x1_lds_covers(C, C, 0, N * HW))
-        if v and not grouped:
-            v = bool(L.cot_conv1x1_lds_covers(2 * C, C, 1, N * HW) and L.cot_conv1x1_lds_covers(C // 2, C // 2, 0, N * HW))
-        _CM_OK[k] = v  # (CoXtLayer's grouped 1x1s: cot_conv1x1g_* routes each group to the tuned or the general kernels itself)
-    return v
-
-
-def cm_block_eligible(blk, x):
-    """training-mode identity-shortcut cotnet.Bottleneck of a deep stage on a bf16 tensor that is NCHW-contiguous or channel-major"""
-    if not (ENABLED and CM_LAYOUT and blk.training and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4
-            and x.dtype == torch.bfloat16 and x.data_ptr() % 16 == 0 and (x.is_contiguous() or _is_cm(x))):
-        return False
-    if not _cm_static_ok(blk):
-        return False
-    bp = _block_plan(blk)
-    pl = _plan(bp.cot)
-    N, Cin, H, W = x.shape
-    if bp.avd:
-        if not (x.is_contiguous() and H % 2 == 0 and W % 2 == 0 and bp.ds_bn.training):
-            return False
-        H, W = H // 2, W // 2
-    return (x.shape[1] == bp.conv1.in_channels and bp.conv1.weight.dtype == torch.bfloat16 and bp.conv3.weight.dtype == torch.bfloat16
-            and bp.bn1.weight.dtype == torch.float32 and bp.bn1.training and bp.bn3.training
-            and pl.ke0.weight.dtype == torch.bfloat16 and pl.em3.weight.dtype == torch.bfloat16 and pl.gn.weight.dtype == torch.bfloat16
-            and pl.bn.weight.dtype == torch.float32 and pl.bn.training and pl.ke1.training
-            and _cm_geometry_ok(_lib.lib(), N, bp.conv3.out_channels, bp.conv1.out_channels, H, W, pl.grouped))
-
-
-def cm_block_forward(blk, x):
-    NODE_COUNTS["bottleneck_channel_major"] += 1
-    return _BottleneckCMNode.apply(blk, x, *_block_plan(blk).params)
-
-
-def _bn_fwd_lay(L, x, res, y, y2, bn, stats, N, C, HW, act, lay, ps=None):
-    _ck(L.cot_bn_act_forward_lay(_p(x), _p(res), _p(y), _p(y2), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
-                                 _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _p(ps), N, C, HW,
-                                 float(bn.eps), float(bn.momentum), act, lay, BF16, _stream()), "cot_bn_act_forward_lay")
-
-
-def _bn_bwd_lay(L, dy, dy2, x, y, dx, dres, bn, stats, N, C, HW, act, lay, ps=None):
-    dg, db = grad_sink.out_like(bn.weight), grad_sink.out_like(bn.bias)
-    _ck(L.cot_bn_act_backward_lay(_p(dy), _p(dy2), _p(x), _p(y), _p(dx), _p(dres), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]),
-                                  _p(dg), _p(db), _p(ps), N, C, HW, act, lay, BF16, _stream()), "cot_bn_act_backward_lay")
-    return dg, db
-
-
-class _BottleneckCMNode(Function):
-    @staticmethod
-    @_one_stream_query
-    def forward(ctx, blk, x, *params):
-        L = _lib.lib()
-        bp = _block_plan(blk)
-        pl = _plan(bp.cot)
-        N, Cin, H0, W0 = x.shape
-        opening = bp.avd   # the stage's first block: 3x3/2 average pooling in front of the layer, stride-2 projection shortcut
-        H, W = (H0 // 2, W0 // 2) if opening else (H0, W0)
-        C, A, G, Cout = bp.conv1.out_channels, pl.se0.out_channels, pl.ke0.groups, bp.conv3.out_channels
-        HW, M, Ch, Ce = H * W, N * H * W, C // 2, 9 * C // 8
-        dev, st = x.device, _stream()
-        in_cm = _is_cm(x)
-        out_cm = bool(getattr(blk, "_next_cm", False))
-        GX = pl.grouped  # CoXtLayer (models/cotnet.py:106-178): grouped 1x1s (a group = a contiguous range of channel ROWS here), [x, k]
-        #                  interleaved row by row, the two groups folded into the batch for the aggregation (views of the NCHW tensors)
-        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W, GX, Cout if opening else None)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        masks = _masks(L, H, W, dev)
-        nchw = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
-        cmj = lambda c: torch.empty((c, N, H, W), dtype=x.dtype, device=dev)   # noqa: E731  (dense channel-major buffers)
-        stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
-        xb = _cm_buf(x) if in_cm else x   # the dense buffer under x, either layout
-
-        if opening:
-            # conv1 -> bn1 + relu on the 2H x 2W input planes (NCHW, the ordinary kernels), pooled to H x W: a1 (NCHW with margins) and
-            # its channel-major copy for the 1x1 convolutions
-            c1 = torch.empty((N, C, H0, W0), dtype=x.dtype, device=dev)
-            _ck(L.cot_conv1x1_forward(_p(xb), None, Cin, _p(bp.conv1.weight), None, _p(c1), N, Cin, C, H0 * W0, BF16, st), "cot_conv1x1_forward")
-            a1f = torch.empty_like(c1)
-            s_1 = stat(C, nws_c)
-            _bn_fwd(L, c1, a1f, bp.bn1, s_1, 2 * C, N, C, H0 * W0, 1)
-            a1 = _new_guarded(N, C, H, W, x.dtype, dev)
-            _ck(L.cot_avgpool3x3s2_forward(_p(a1f), _p(a1), N * C, H0, W0, BF16, st), "cot_avgpool3x3s2_forward")
-            a1c = a1.permute(1, 0, 2, 3).contiguous()
-        else:
-            # conv1 -> bn1 + relu -> a1 (NCHW with margins: the 3x3 weight gradient reads it shifted) and a1c (channel-major)
-            c1 = cmj(C) if in_cm else nchw(C)
-            if in_cm:
-                _ck(L.cot_conv1x1_forward(_p(xb), None, Cin, _p(bp.conv1.weight), None, _p(c1), 1, Cin, C, M, BF16, st), "cot_conv1x1_forward")
-            else:
-                _ck(L.cot_conv1x1_forward(_p(xb), None, Cin, _p(bp.conv1.weight), None, _p(c1), N, Cin, C, HW, BF16, st), "cot_conv1x1_forward")
-            a1, a1c = _new_guarded(N, C, H, W, x.dtype, dev), cmj(C)
-            s_1 = stat(C, 0)
-            _bn_fwd_lay(L, c1, None, a1, a1c, bp.bn1, s_1, N, C, HW, 1, (1 if in_cm else 0) | 8)
-        # static context: grouped 3x3 (NCHW) -> bn + relu -> k (channel-major)                                   (ref :80)
-        k_pre, k = nchw(C), cmj(C)
-        _conv3x3_fwd(L, pl.ke0, a1, k_pre, masks, ws, N, C, G, H, W)
-        s_k = stat(C, 0)
-        _bn_fwd_lay(L, k_pre, None, k, None, pl.ke1, s_k, N, C, HW, 1, 4)
-        # attention logits from [x | k]: two 1x1 convolutions on channel rows, GroupNorm writes the aggregation's weights NCHW (ref :81-85)
-        e0, e1, e3 = cmj(Ch), cmj(Ch), cmj(Ce)
-        qk = None
-        if GX:
-            qk = torch.stack([a1c, k], dim=1).view(2 * C, N, H, W)  # rows x0, k0, x1, k1, ... (ref :153-154)
-            _ck(L.cot_conv1x1g_forward(_p(qk), _p(pl.em0.weight), None, _p(e0), 1, 2 * C, Ch, 2, M, BF16, st), "cot_conv1x1g_forward")
-        else:
-            _ck(L.cot_conv1x1_forward(_p(a1c), _p(k), C, _p(pl.em0.weight), None, _p(e0), 1, 2 * C, Ch, M, BF16, st), "cot_conv1x1_forward")
-        s_e = stat(Ch, nws_h1)
-        _bn_fwd(L, e0, e1, pl.em1, s_e, 2 * Ch, 1, Ch, M, 1)
-        if GX:
-            _ck(L.cot_conv1x1g_forward(_p(e1), _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), 1, Ch, Ce, 2, M, BF16, st), "cot_conv1x1g_forward")
-        else:
-            _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), 1, Ch, Ce, M, BF16, st),
-                "cot_conv1x1_forward")
-        gn = pl.gn
-        w = nchw(Ce)
-        gn_mean = torch.empty(2 * N * gn.num_groups, dtype=torch.float32, device=dev)
-        gn_rstd = gn_mean[N * gn.num_groups:]
-        _ck(L.cot_group_norm9_forward_lay(_p(e3), _p(gn.weight), _p(gn.bias), _p(w), _p(gn_mean), _p(gn_rstd), N, Ce, HW, float(gn.eps), 1,
-                                          BF16, st), "cot_group_norm9_forward_lay")
-        # values: 1x1 on channel rows, its BatchNorm writes NCHW                                                     (ref :87)
-        v_pre, v = cmj(C), nchw(C)
-        if GX:
-            _ck(L.cot_conv1x1g_forward(_p(a1c), _p(pl.cv0.weight), None, _p(v_pre), 1, C, C, 2, M, BF16, st), "cot_conv1x1g_forward")
-        else:
-            _ck(L.cot_conv1x1_forward(_p(a1c), None, C, _p(pl.cv0.weight), None, _p(v_pre), 1, C, C, M, BF16, st), "cot_conv1x1_forward")
-        s_v = stat(C, 0)
-        _bn_fwd_lay(L, v_pre, None, v, None, pl.cv1, s_v, N, C, HW, 0, 1)
-        # aggregation, bn + swish (NCHW)                                                                            (ref :88-90)
-        geom = _lib.AggGeom(2 * N, C // 2, H, W, 1, C // 16, 3, 3, 1, 1, 1, 1, 1, 1) if GX else \
-            _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
-        a, y = nchw(C), nchw(C)
-        _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
-        s_y = stat(C, nws_c)
-        _bn_fwd(L, a, y, pl.bn, s_y, 2 * C, N, C, HW, 2)
-        # radix-2 split attention: y NCHW, k channel-major, the mix written channel-major for conv3                (ref :92-104)
-        row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
-        gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
-        _ck(L.cot_radix_gap_t_lay(_p(y), _p(k), _p(gapT), N, C, HW, 2, BF16, st), "cot_radix_gap_t_lay")
-        _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st), "cot_conv1x1_forward")
-        s_a = stat(A, nws_a)
-        _bn_fwd(L, hpre, h, pl.sebn, s_a, 2 * A, 1, A, N, 1)
-        _ck(L.cot_conv1x1_forward(_p(h), None, A, _p(pl.se3.weight), _p(pl.se3.bias), _p(logitsT), 1, A, 2 * C, N, BF16, st),
-            "cot_conv1x1_forward")
-        attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
-        cot_out = cmj(C)
-        _ck(L.cot_radix_mix_logits_lay(_p(y), _p(k), _p(logitsT), _p(cot_out), _p(attn), N, C, HW, 2 | 4, BF16, st), "cot_radix_mix_logits_lay")
-        # conv3 -> bn3 + residual + relu.  The residual: the block's input (identity) or bn(conv1x1(every second pixel of it))
-        c3 = cmj(Cout)
-        _ck(L.cot_conv1x1_forward(_p(cot_out), None, C, _p(bp.conv3.weight), None, _p(c3), 1, C, Cout, M, BF16, st), "cot_conv1x1_forward")
-        ps = _drop_path_scale(blk, N, dev)
-        yb = cmj(Cout) if out_cm else nchw(Cout)
-        if opening:
-            xs = torch.empty((N, Cin, H, W), dtype=x.dtype, device=dev)
-            _ck(L.cot_subsample2_forward(_p(xb), _p(xs), N * Cin, H0, W0, BF16, st), "cot_subsample2_forward")
-            d0 = nchw(Cout)
-            _ck(L.cot_conv1x1_forward(_p(xs), None, Cin, _p(bp.ds_conv.weight), None, _p(d0), N, Cin, Cout, HW, BF16, st), "cot_conv1x1_forward")
-            res_cm = out_cm  # (the projection's BatchNorm writes the layout bn3 writes)
-            res = cmj(Cout) if res_cm else nchw(Cout)
-            s_d = stat(Cout, 0)
-            _bn_fwd_lay(L, d0, None, res, None, bp.ds_bn, s_d, N, Cout, HW, 0, 4 if res_cm else 0)
-        else:
-            xs = d0 = s_d = None
-            res, res_cm = xb, in_cm
-        m3 = None
-        if res_cm and out_cm and ps is None:  # everything channel-major: the ordinary kernels on N*HW-element rows (16-byte accesses, sign mask)
-            s_3 = stat(Cout, nws_o1)
-            m3 = _relu_mask(L, 1, Cout, M, dev)
-            _bn_fwd(L, c3, yb, bp.bn3, s_3, 2 * Cout, 1, Cout, M, 1, residual=res, mask=m3)
-        else:
-            s_3 = stat(Cout, 0)
-            _bn_fwd_lay(L, c3, res, yb, None, bp.bn3, s_3, N, Cout, HW, 1, 1 | (2 if res_cm else 0) | (4 if out_cm else 0), ps=ps)
-        ctx.blk, ctx.geom, ctx.flags = blk, geom, (in_cm, out_cm, ps is not None, m3 is not None, res_cm)
-        ctx.save_for_backward(xb, c1, a1, a1c, s_1, k_pre, k, s_k, e0, e1, s_e, e3, w, gn_mean, gn_rstd, v_pre, v, s_v, a, y, s_y, attn,
-                              gapT, hpre, h, s_a, cot_out, c3, yb, s_3, qk if GX else s_3, *((d0, s_d, xs) if opening else ()),
-                              *((m3,) if m3 is not None else ()), *((ps,) if ps is not None else ()))
-        return _cm_view(yb) if out_cm else yb
-
-    @staticmethod
-    @_one_stream_query
-    def backward(ctx, gout):
-        L = _lib.lib()
-        blk = ctx.blk
-        bp = _block_plan(blk)
-        pl = _plan(bp.cot)
-        t = ctx.saved_tensors
-        (xb, c1, a1, a1c, s_1, k_pre, k, s_k, e0, e1, s_e, e3, w, gn_mean, gn_rstd, v_pre, v, s_v, a, y, s_y, attn,
-         gapT, hpre, h, s_a, cot_out, c3, yb, s_3, qk) = t[:31]
-        in_cm, out_cm, has_ps, has_mask, res_cm = ctx.flags
-        GX = pl.grouped
-        opening = bp.avd
-        nx = 34 if opening else 31
-        d0, s_d, xs = t[31:34] if opening else (None, None, None)
-        m3 = t[nx] if has_mask else None
-        ps = t[-1] if has_ps else None
-        N, C, H, W = a1.shape
-        Cin, Cout, A, G = bp.conv1.in_channels, c3.shape[0], pl.se0.out_channels, pl.ke0.groups
-        HW, M, Ch, Ce = H * W, N * H * W, C // 2, 9 * C // 8
-        H0, W0 = (xb.shape[2], xb.shape[3]) if opening else (H, W)
-        dev, st = a1.device, _stream()
-        ws_bytes, nws_c, nws_c1, nws_h1, nws_a, nws_o1 = _cm_sizes(L, N, Cin, C, A, G, H, W, GX, Cout if opening else None)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        masks = _masks(L, H, W, dev)
-        side = _Side(dev, ws_bytes, ws, bp.params)
-        nchw = lambda c: torch.empty((N, c, H, W), dtype=a1.dtype, device=dev)  # noqa: E731
-        cmj = lambda c: torch.empty((c, N, H, W), dtype=a1.dtype, device=dev)   # noqa: E731
-        ke0, ke1, em0, em1, em3, cv0, cv1 = pl.ke0, pl.ke1, pl.em0, pl.em1, pl.em3, pl.cv0, pl.cv1
-        se0, sebn, se3 = pl.se0, pl.sebn, pl.se3
-        # the upstream gradient in the layout the forward wrote its output in
-        if out_cm:
-            gb = _cm_buf(gout) if _is_cm(gout) else gout.permute(1, 0, 2, 3).contiguous()
-        else:
-            gb = gout.contiguous()
-        # bn3 + residual + relu
-        g_c3 = cmj(Cout)
-        g_res = cmj(Cout) if res_cm else nchw(Cout)
-        if has_mask:
-            d_bn3_w, d_bn3_b = _bn_bwd(L, gb, c3, None, g_c3, bp.bn3, s_3, 1, Cout, M, 1, nws_o1, dres=g_res, mask=m3)
-        else:
-            d_bn3_w, d_bn3_b = _bn_bwd_lay(L, gb, None, c3, yb, g_c3, g_res, bp.bn3, s_3, N, Cout, HW, 1,
-                                           (1 if out_cm else 0) | 4 | (8 if out_cm else 0) | 16 | (32 if res_cm else 0), ps=ps)
-        g_out = cmj(C)
-        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_out), None, C, 0, _p(ws), 1, C, Cout, M, BF16, st),
-            "cot_conv1x1_backward_data")
-        g_w3c = grad_sink.out_like(bp.conv3.weight)
-        side.run(lambda st_, a_=(_p(g_c3), _p(cot_out), None, C, _p(g_w3c), None, _p(side.ws), 1, C, Cout, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, cot_out)
-        # radix mix -> pair-softmax backward -> se branch -> gap
-        row = lambda c: torch.empty((c, N), dtype=a1.dtype, device=dev)  # noqa: E731
-        glogT, gh, ggapT = row(2 * C), row(A), row(C)
-        _ck(L.cot_radix_mix_backward_reduce_lay(_p(g_out), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, 1 | 4, BF16, st),
-            "cot_radix_mix_backward_reduce_lay")
-        _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st), "cot_conv1x1_backward_data")
-        g_w3, g_b3 = grad_sink.out_like(se3.weight), grad_sink.out_like(se3.bias)
-        side.run(lambda st_, a_=(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(side.ws), 1, A, 2 * C, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), glogT, h)
-        ghpre = row(A)
-        d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, None, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
-        _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st), "cot_conv1x1_backward_data")
-        g_w0, g_b0 = grad_sink.out_like(se0.weight), grad_sink.out_like(se0.bias)
-        side.run(lambda st_, a_=(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(side.ws), 1, C, A, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ghpre, gapT)
-        gy, gk = nchw(C), cmj(C)
-        _ck(L.cot_radix_mix_backward_apply_lay(_p(g_out), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, 1 | 4, BF16, st),
-            "cot_radix_mix_backward_apply_lay")
-        # bn + swish, aggregation (NCHW)
-        ga = nchw(C)
-        d_bn_w, d_bn_b = _bn_bwd(L, gy, a, None, ga, pl.bn, s_y, N, C, HW, 2, nws_c)
-        gv, gw = nchw(C), nchw(Ce)
-        _ck(L.cot_agg_backward(_p(ga), _p(v), _p(w), _p(gv), _p(gw), ctypes.byref(ctx.geom), BF16, _lib.COT_NCHW, st), "cot_agg_backward")
-        # values branch: bn (NCHW gradient in, channel-major out), 1x1 -> first contribution to the channel-major dx
-        gv_pre = cmj(C)
-        d_cv_w, d_cv_b = _bn_bwd_lay(L, gv, None, v_pre, None, gv_pre, None, cv1, s_v, N, C, HW, 0, 4 | 16)
-        gxc = cmj(C)
-        g_wv = grad_sink.out_like(cv0.weight)
-        if GX:
-            _ck(L.cot_conv1x1g_backward_data(_p(gv_pre), _p(cv0.weight), _p(gxc), 0, 1, C, C, 2, M, BF16, st), "cot_conv1x1g_backward_data")
-            side.run(lambda st_, a_=(_p(gv_pre), _p(a1c), _p(g_wv), None, _p(side.ws), 1, C, C, 2, M, BF16): _ck(L.cot_conv1x1g_backward_weight(*a_, st_), "cot_conv1x1g_backward_weight"), gv_pre, a1c)
-        else:
-            _ck(L.cot_conv1x1_backward_data(_p(gv_pre), _p(cv0.weight), _p(gxc), None, C, 0, _p(ws), 1, C, C, M, BF16, st), "cot_conv1x1_backward_data")
-            side.run(lambda st_, a_=(_p(gv_pre), _p(a1c), None, C, _p(g_wv), None, _p(side.ws), 1, C, C, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), gv_pre, a1c)
-        # logits branch: GroupNorm (NCHW gradient in, channel-major out), 1x1 (+bias), bn + relu, 1x1 on [x | k] -> dx +=, dk +=
-        gn = pl.gn
-        ge3, g_gn_w, g_gn_b = cmj(Ce), grad_sink.out_like(gn.weight), grad_sink.out_like(gn.bias)
-        gn_ws = torch.empty(2 * N * Ce, dtype=torch.float32, device=dev)
-        _ck(L.cot_group_norm9_backward_lay(_p(gw), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(ge3), None, None, _p(gn_ws),
-                                           N, Ce, HW, 2 | 4, BF16, st), "cot_group_norm9_backward_lay")
-        side.run(lambda st_, a_=(_p(gn_ws), _p(g_gn_w), _p(g_gn_b), N, Ce, BF16): _ck(L.cot_group_norm9_backward_params(*a_, st_), "cot_group_norm9_backward_params"), gn_ws)
-        ge1 = cmj(Ch)
-        g_we3, g_be3 = grad_sink.out_like(em3.weight), grad_sink.out_like(em3.bias)
-        if GX:
-            _ck(L.cot_conv1x1g_backward_data(_p(ge3), _p(em3.weight), _p(ge1), 0, 1, Ch, Ce, 2, M, BF16, st), "cot_conv1x1g_backward_data")
-            side.run(lambda st_, a_=(_p(ge3), _p(e1), _p(g_we3), _p(g_be3), _p(side.ws), 1, Ch, Ce, 2, M, BF16): _ck(L.cot_conv1x1g_backward_weight(*a_, st_), "cot_conv1x1g_backward_weight"), ge3, e1)
-        else:
-            _ck(L.cot_conv1x1_backward_data(_p(ge3), _p(em3.weight), _p(ge1), None, Ch, 0, _p(ws), 1, Ch, Ce, M, BF16, st), "cot_conv1x1_backward_data")
-            side.run(lambda st_, a_=(_p(ge3), _p(e1), None, Ch, _p(g_we3), _p(g_be3), _p(side.ws), 1, Ch, Ce, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge3, e1)
-        ge0 = cmj(Ch)
-        d_em_w, d_em_b = _bn_bwd(L, ge1, e0, None, ge0, em1, s_e, 1, Ch, M, 1, nws_h1)
-        g_we0 = grad_sink.out_like(em0.weight)
-        if GX:  # gradient of the row-interleaved [x0, k0, x1, k1, ...]: de-interleaved into dx / dk (two strided adds)
-            gqk = torch.empty_like(qk)
-            _ck(L.cot_conv1x1g_backward_data(_p(ge0), _p(em0.weight), _p(gqk), 0, 1, 2 * C, Ch, 2, M, BF16, st), "cot_conv1x1g_backward_data")
-            gq5 = gqk.view(C, 2, N, H, W)
-            gxc.add_(gq5[:, 0])
-            gk.add_(gq5[:, 1])
-            side.run(lambda st_, a_=(_p(ge0), _p(qk), _p(g_we0), None, _p(side.ws), 1, 2 * C, Ch, 2, M, BF16): _ck(L.cot_conv1x1g_backward_weight(*a_, st_), "cot_conv1x1g_backward_weight"), ge0, qk)
-        else:
-            _ck(L.cot_conv1x1_backward_data(_p(ge0), _p(em0.weight), _p(gxc), _p(gk), C, 3, _p(ws), 1, 2 * C, Ch, M, BF16, st), "cot_conv1x1_backward_data")
-            side.run(lambda st_, a_=(_p(ge0), _p(a1c), _p(k), C, _p(g_we0), None, _p(side.ws), 1, 2 * C, Ch, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge0, a1c, k)
-        # key branch: bn + relu (channel-major gradient in, NCHW out), grouped 3x3 -> the NCHW contribution to dx
-        gk_pre = nchw(C)
-        d_ke_w, d_ke_b = _bn_bwd_lay(L, gk, None, k_pre, None, gk_pre, None, ke1, s_k, N, C, HW, 1, 1)
-        g_wk = grad_sink.out_like(ke0.weight)
-        side.run(lambda st_, a_=(_p(gk_pre), _p(a1), _p(g_wk), _p(masks), _p(side.ws), N, C, C, G, H, W, BF16, _guard_elems(a1)): _ck(L.cot_conv3x3g_backward_weight_guarded(*a_, st_), "cot_conv3x3g_backward_weight"), gk_pre, a1, masks)
-        gx3 = nchw(C)
-        _conv3x3_dgrad(L, ke0, gk_pre, gx3, 0, masks, ws, N, C, G, H, W)
-        g_w1 = grad_sink.out_like(bp.conv1.weight)
-        g_ds = ()
-        if opening:
-            # the pooled activation's gradient = the 3x3's NCHW contribution + the 1x1s' channel-major one (a strided add), back through the
-            # pooling, bn1 and conv1 at the input resolution; the projection: its BatchNorm takes the residual gradient in bn3's layout
-            gx3.add_(_cm_view(gxc))
-            g_a1f = torch.empty((N, C, H0, W0), dtype=a1.dtype, device=dev)
-            _ck(L.cot_avgpool3x3s2_backward(_p(gx3), _p(g_a1f), N * C, H0, W0, BF16, st), "cot_avgpool3x3s2_backward")
-            g_c1 = torch.empty_like(c1)
-            d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1f, c1, None, g_c1, bp.bn1, s_1, N, C, H0 * W0, 1, nws_c)
-            g_d0 = nchw(Cout)
-            d_ds_w, d_ds_b = _bn_bwd_lay(L, g_res, None, d0, None, g_d0, None, bp.ds_bn, s_d, N, Cout, HW, 0, 1 if res_cm else 0)
-            g_xs = torch.empty_like(xs)
-            _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(g_xs), None, Cin, 0, _p(ws), N, Cin, Cout, HW, BF16, st),
-                "cot_conv1x1_backward_data")
-            gx = torch.empty_like(xb)
-            _ck(L.cot_subsample2_backward(_p(g_xs), _p(gx), N * Cin, H0, W0, BF16, st), "cot_subsample2_backward")
-            g_wd = grad_sink.out_like(bp.ds_conv.weight)
-            side.run(lambda st_, a_=(_p(g_d0), _p(xs), None, Cin, _p(g_wd), None, _p(side.ws), N, Cin, Cout, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_d0, xs)
-            g_ds = (g_wd, d_ds_w, d_ds_b)
-            side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, C, H0 * W0, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
-            _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, C, H0 * W0, BF16, st),
-                "cot_conv1x1_backward_data")
-        else:
-            # bn1: the two contributions to da1 (channel-major from the 1x1s, NCHW from the 3x3) meet in its backward
-            g_c1 = cmj(C) if in_cm else nchw(C)
-            d_bn1_w, d_bn1_b = _bn_bwd_lay(L, gxc, gx3, c1, None, g_c1, None, bp.bn1, s_1, N, C, HW, 1, 1 | (4 if in_cm else 0) | (16 if in_cm else 0))
-            gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
-            if in_cm:
-                side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), 1, Cin, C, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
-                _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), 1, Cin, C, M, BF16, st), "cot_conv1x1_backward_data")
-            else:
-                side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, C, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
-                _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, C, HW, BF16, st), "cot_conv1x1_backward_data")
-        side.join()
-        g_cot = (g_wk, d_ke_w, d_ke_b, g_we0, d_em_w, d_em_b, g_we3, g_be3, g_gn_w, g_gn_b, g_wv, d_cv_w, d_cv_b, d_bn_w, d_bn_b,
-                 g_w0, g_b0, d_sa_w, d_sa_b, g_w3, g_b3)
-        return (None, _cm_view(gx) if in_cm else gx, g_w1, d_bn1_w, d_bn1_b) + g_cot + (g_w3c, d_bn3_w, d_bn3_b) + g_ds
-
-
-# ---- inference (BASELINE config 2: forward only, eval mode, no autograd).  The same launch sequence as _BottleneckNode.forward with
-# the BatchNorms on their running statistics (cot_bn_act_inference, in place: one pass each) and nothing kept for a backward:
-# ~25 C-ABI calls per block instead of ~25 autograd-tracked module calls -- the eager forward is bound by the host, not the device
-# (profiles/r04_bench_fwd.json: 6.26 ms to issue a 5.07 ms step).  Reference: models/cotnet.py:79-104, :228-264.
-def _bn_inf(L, x, bn, N, C, HW, act, residual=None, out=None):
-    y = x if out is None else out
-    _ck(L.cot_bn_act_inference(_p(x), _p(residual), _p(y), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), N, C, HW,
-                               float(bn.eps), act, BF16, _stream()), "cot_bn_act_inference")
-    return y
-
-
-def eval_block_eligible(blk, x):
-    """eval-mode cotnet.Bottleneck around an (ungrouped) CotLayer on a contiguous bf16 NCHW tensor, autograd off"""
-    if not (ENABLED and not blk.training and not torch.is_grad_enabled() and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4
-            and x.dtype == torch.bfloat16 and x.is_contiguous() and x.data_ptr() % 16 == 0):
-        return False
-    bp = _block_plan(blk)
-    if not (bp.static_ok and x.shape[1] == bp.conv1.in_channels and bp.conv1.weight.dtype == torch.bfloat16
-            and bp.conv3.weight.dtype == torch.bfloat16 and bp.bn1.weight.dtype == torch.float32
-            and (bp.ds_conv is not None or (bp.conv1.in_channels == bp.conv3.out_channels and not bp.avd))):
-        return False
-    pl = _plan(bp.cot)
-    # every BatchNorm of the block runs on its RUNNING statistics here (cot_bn_act_inference): each one has to be in eval mode
-    # itself (a block in eval() with an inner BatchNorm put back into train() takes the module path), carry running statistics and
-    # fp32 parameters (ADVICE r5)
-    bns = [bp.bn1, bp.bn3, pl.ke1, pl.em1, pl.cv1, pl.bn, pl.sebn] + ([bp.ds_bn] if bp.ds_conv is not None else [])
-    if not all((not bn.training) and bn.running_mean is not None and bn.running_var is not None and bn.weight is not None
-               and bn.weight.dtype == torch.float32 and bn.running_mean.dtype == torch.float32 for bn in bns):
-        return False
-    return (not pl.grouped and pl.ke0.weight.dtype == torch.bfloat16 and pl.em3.weight.dtype == torch.bfloat16
-            and pl.gn.weight.dtype == torch.bfloat16 and x.shape[2] * x.shape[3] <= 8192 * 4)
-
-
-@_one_stream_query
-def eval_block_forward(blk, x):
-    NODE_COUNTS["bottleneck_eval"] += 1
-    L = _lib.lib()
-    bp = _block_plan(blk)
-    pl = _plan(bp.cot)
-    N, Cin, H0, W0 = x.shape
-    C, Cout, A, G = bp.conv1.out_channels, bp.conv3.out_channels, pl.se0.out_channels, pl.ke0.groups
-    dev, st = x.device, _stream()
-    HW0 = H0 * W0
-    new = lambda c, h, w: torch.empty((N, c, h, w), dtype=x.dtype, device=dev)  # noqa: E731
-    a1 = new(C, H0, W0)
-    _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(bp.conv1.weight), None, _p(a1), N, Cin, C, HW0, BF16, st), "cot_conv1x1_forward")
-    _bn_inf(L, a1, bp.bn1, N, C, HW0, 1)
-    if bp.avd:
-        H, W = (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1
-        p1 = new(C, H, W)
-        _ck(L.cot_avgpool3x3s2_forward(_p(a1), _p(p1), N * C, H0, W0, BF16, st), "cot_avgpool3x3s2_forward")
-    else:
-        H, W, p1 = H0, W0, a1
-    HW, Ch, Ce = H * W, C // 2, 9 * C // 8
-    ws_bytes = _sizes(L, N, C, H, W, A, G, False)[0]
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    masks = _masks(L, H, W, dev)
-    k = new(C, H, W)
-    _ck(L.cot_conv3x3g_forward(_p(p1), _p(pl.ke0.weight), _p(k), _p(masks), _p(ws), N, C, C, G, H, W, BF16, st), "cot_conv3x3g_forward")
-    _bn_inf(L, k, pl.ke1, N, C, HW, 1)
-    e1 = new(Ch, H, W)
-    _ck(L.cot_conv1x1_forward(_p(p1), _p(k), C, _p(pl.em0.weight), None, _p(e1), N, 2 * C, Ch, HW, BF16, st), "cot_conv1x1_forward")
-    _bn_inf(L, e1, pl.em1, N, Ch, HW, 1)
-    e3, gn = new(Ce, H, W), pl.gn
-    gn_mean = torch.empty(2 * N * gn.num_groups, dtype=torch.float32, device=dev)
-    gn_rstd = gn_mean[N * gn.num_groups:]
-    v = new(C, H, W)
-    geom = _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
-    a = new(C, H, W)
-    if GN_FUSED and _gn_fused_ok(L, Ch, HW, W):
-        part = torch.empty(int(L.cot_gn9_stats_floats(N, Ce, HW)), dtype=torch.float32, device=dev)
-        _ck(L.cot_conv1x1_forward_gn9(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), _p(part), N, Ch, Ce, HW, BF16, st),
-            "cot_conv1x1_forward_gn9")
-        _ck(L.cot_gn9_stats_finalize(_p(part), _p(gn_mean), _p(gn_rstd), N, Ce, HW, float(gn.eps), st), "cot_gn9_stats_finalize")
-        _ck(L.cot_conv1x1_forward(_p(p1), None, C, _p(pl.cv0.weight), None, _p(v), N, C, C, HW, BF16, st), "cot_conv1x1_forward")
-        _bn_inf(L, v, pl.cv1, N, C, HW, 0)
-        _ck(L.cot_agg_gn9_forward(_p(v), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(gn.bias), gn.num_groups, _p(a),
-                                  ctypes.byref(geom), BF16, st), "cot_agg_gn9_forward")
-    else:
-        _ck(L.cot_conv1x1_forward(_p(e1), None, Ch, _p(pl.em3.weight), _p(pl.em3.bias), _p(e3), N, Ch, Ce, HW, BF16, st), "cot_conv1x1_forward")
-        if HW <= 8192:
-            w = new(Ce, H, W)
-            _ck(L.cot_group_norm9_forward(_p(e3), _p(gn.weight), _p(gn.bias), _p(w), _p(gn_mean), _p(gn_rstd), N, Ce, HW, float(gn.eps), BF16,
-                                          st), "cot_group_norm9_forward")
-        else:
-            w = torch.nn.functional.group_norm(e3, gn.num_groups, gn.weight, gn.bias, gn.eps)
-        _ck(L.cot_conv1x1_forward(_p(p1), None, C, _p(pl.cv0.weight), None, _p(v), N, C, C, HW, BF16, st), "cot_conv1x1_forward")
-        _bn_inf(L, v, pl.cv1, N, C, HW, 0)
-        _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
-    _bn_inf(L, a, pl.bn, N, C, HW, 2)
-    row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
-    gapT, h, logitsT = row(C), row(A), row(2 * C)
-    _ck(L.cot_radix_gap_t(_p(a), _p(k), _p(gapT), N, C, HW, BF16, st), "cot_radix_gap_t")
-    _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(h), 1, C, A, N, BF16, st), "cot_conv1x1_forward")
-    _bn_inf(L, h, pl.sebn, 1, A, N, 1)
-    _ck(L.cot_conv1x1_forward(_p(h), None, A, _p(pl.se3.weight), _p(pl.se3.bias), _p(logitsT), 1, A, 2 * C, N, BF16, st), "cot_conv1x1_forward")
-    attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
-    out = new(C, H, W)
-    _ck(L.cot_radix_mix_logits(_p(a), _p(k), _p(logitsT), _p(out), _p(attn), N, C, HW, BF16, st), "cot_radix_mix_logits")
-    y = new(Cout, H, W)
-    _ck(L.cot_conv1x1_forward(_p(out), None, C, _p(bp.conv3.weight), None, _p(y), N, C, Cout, HW, BF16, st), "cot_conv1x1_forward")
-    if bp.ds_conv is not None:
-        if bp.ds_stride == 2 and H0 % 2 == 0 and W0 % 2 == 0:
-            xs = new(Cin, H0 // 2, W0 // 2)
-            _ck(L.cot_subsample2_forward(_p(x), _p(xs), N * Cin, H0, W0, BF16, st), "cot_subsample2_forward")
-        else:
-            xs = x[:, :, ::2, ::2].contiguous() if bp.ds_stride == 2 else x
-        res = new(Cout, H, W)
-        _ck(L.cot_conv1x1_forward(_p(xs), None, Cin, _p(bp.ds_conv.weight), None, _p(res), N, Cin, Cout, HW, BF16, st), "cot_conv1x1_forward")
-        _bn_inf(L, res, bp.ds_bn, N, Cout, HW, 0)
-    else:
-        res = x
-    return _bn_inf(L, y, bp.bn3, N, Cout, HW, 1, residual=res)
+from .cot_block_sa import (_SABlockPlan, _SA_PLANS, _SASIZES, _sa_plan, _sa_sizes, _SplitAttnBlockNode, sa_block_eligible,  # noqa: E402,F401
+                           sa_block_forward)
+from .cot_block_cm import (_CM_OK, _CM_SIZES, _BottleneckCMNode, _bn_bwd_lay, _bn_fwd_lay, _cm_buf, _cm_geometry_ok, _cm_sizes,  # noqa: E402,F401
+                           _cm_static_ok, _cm_view, _is_cm, cm_block_eligible, cm_block_forward, plan_stage_layouts)
+from .cot_block_eval import _bn_inf, eval_block_eligible, eval_block_forward  # noqa: E402,F401
