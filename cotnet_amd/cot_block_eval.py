@@ -27,6 +27,7 @@ def eval_block_eligible(blk, x):
     bp = _block_plan(blk)
     if not (bp.static_ok and x.shape[1] == bp.conv1.in_channels and bp.conv1.weight.dtype == torch.bfloat16
             and bp.conv3.weight.dtype == torch.bfloat16 and bp.bn1.weight.dtype == torch.float32
+            and not bp.avd_post and not bp.ds_pool2  # (SE-CoTNetD's stage-opening blocks: training node only)
             and (bp.ds_conv is not None or (bp.conv1.in_channels == bp.conv3.out_channels and not bp.avd))):
         return False
     pl = _plan(bp.cot)

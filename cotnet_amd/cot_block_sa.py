@@ -15,11 +15,13 @@ from .cot_layer_fused import (  # noqa: E402  (helpers; the switches are read as
 # 138-146, :172-202; models/layers/split_attn.py:62-88) -- conv1 -> bn1+relu -> dense 3x3 -> bn0+act -> SE gate x * sigmoid(fc2(act(
 # bn(fc1(mean_hw x))))) -> conv3 -> bn3 + residual + relu.  29 of se_cotnetd_152's 50 blocks; with one autograd node per op they
 # left the step host-bound (71.9 ms per step for 47.9 ms of kernels, profiles/r04).  Identity-shortcut blocks (no avd pooling, no
-# projection: 26 of the 29); the three stage-opening blocks keep the module path.  The two fc layers act on [N, C] descriptors:
+# projection: 26 of the 29) and, since round 6, the stage-opening ones: a projection shortcut ([AvgPool2d(2, 2),] 1x1 convolution,
+# BatchNorm: the `avg_down` form, models/resnet.py:380-394) and BlurPool2d behind conv2 (avd_first False).  The two fc layers act on [N, C] descriptors:
 # plain GEMMs (torch.addmm / matmul on the conv weights viewed as matrices), their BatchNorm over the batch on the library's
 # small-batch kernel.
 class _SABlockPlan:
-    __slots__ = ("conv1", "bn1", "conv", "bn0", "fc1", "sbn", "fc2", "conv3", "bn3", "params", "static_ok", "act0", "act1")
+    __slots__ = ("conv1", "bn1", "conv", "bn0", "fc1", "sbn", "fc2", "conv3", "bn3", "params", "static_ok", "act0", "act1",
+                 "ds_conv", "ds_bn", "ds_pool2", "avd_post")
 
     def __init__(self, blk):
         from .layers import SplitAttnConv2d
@@ -35,19 +37,37 @@ class _SABlockPlan:
         C = sa.conv.out_channels
         fc_ok = lambda c: (isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0)  # noqa: E731
                            and c.groups == 1 and c.bias is not None)
+        from .layers import BlurPool2d
+        ds, avd = blk.downsample, blk.avd
+        self.ds_conv = self.ds_bn = None
+        self.ds_pool2 = False
+        self.avd_post = (avd is not None and not getattr(blk, "avd_first", True) and isinstance(avd, BlurPool2d) and avd.filt_size == 3
+                         and avd.stride == 2)
+        shape_ok = ds is None and avd is None
+        if isinstance(ds, nn.Sequential) and len(ds) == 3 and isinstance(ds[0], (nn.Identity, nn.AvgPool2d)):
+            pool = ds[0] if isinstance(ds[0], nn.AvgPool2d) else None
+            self.ds_pool2 = (pool is not None and pool.kernel_size == 2 and pool.stride == 2 and pool.padding == 0
+                             and pool.divisor_override is None)  # (ceil_mode / count_include_pad: no effect on even planes, checked at run time)
+            c = ds[1]
+            self.ds_conv, self.ds_bn = c, ds[2]
+            # stride 1: no pooling anywhere; stride 2: BlurPool behind conv2 AND the 2 x 2 average in the shortcut
+            shape_ok = (isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0)
+                        and c.groups == 1 and c.bias is None and _bn_static_ok(ds[2]) and c.in_channels == blk.conv1.in_channels
+                        and c.out_channels == blk.conv3.out_channels and c.out_channels % 8 == 0
+                        and ((avd is None and pool is None) or (self.avd_post and self.ds_pool2)))
         self.static_ok = (
-            blk.downsample is None and blk.avd is None and blk.drop_block is None and sa.drop_block is None
+            shape_ok and blk.drop_block is None and sa.drop_block is None
             and (blk.drop_path is None or hasattr(blk.drop_path, "drop_prob")) and getattr(blk, "se", None) is None
             and isinstance(blk.act1, nn.ReLU) and isinstance(blk.act3, nn.ReLU)
             and _conv_ok(blk.conv1, 1, 1) and blk.conv1.bias is None and _conv_ok(blk.conv3, 1, 1) and blk.conv3.bias is None
             and _conv_ok(sa.conv, 3) and sa.conv.bias is None and sa.conv.in_channels == C and (C // sa.conv.groups) % 8 == 0
-            and blk.conv1.in_channels % 8 == 0 and blk.conv1.in_channels == blk.conv3.out_channels
+            and blk.conv1.in_channels % 8 == 0 and (self.ds_conv is not None or blk.conv1.in_channels == blk.conv3.out_channels)
             and fc_ok(sa.fc1) and fc_ok(sa.fc2) and sa.fc1.in_channels == C and sa.fc2.out_channels == C
             and sa.fc1.out_channels % 8 == 0 and self.act0 > 0 and self.act1 > 0
             and all(_bn_static_ok(b) for b in (blk.bn1, blk.bn3, sa.bn0, sa.bn1)))
         self.params = [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, sa.conv.weight, sa.bn0.weight, sa.bn0.bias, sa.fc1.weight,
                        sa.fc1.bias, sa.bn1.weight, sa.bn1.bias, sa.fc2.weight, sa.fc2.bias, blk.conv3.weight, blk.bn3.weight,
-                       blk.bn3.bias]
+                       blk.bn3.bias] + ([self.ds_conv.weight, self.ds_bn.weight, self.ds_bn.bias] if self.ds_conv is not None else [])
 
 
 _SA_PLANS = weakref.WeakKeyDictionary()
@@ -61,14 +81,16 @@ def _sa_plan(blk):
     return p
 
 
-def _sa_sizes(L, N, Cin, Cw, A, G, H, W):
-    k = (N, Cin, Cw, A, G, H, W)
+def _sa_sizes(L, N, Cin, Cw, A, G, H, W, Cout=None, HWo=None):
+    """Cout / HWo: output channels / pixels of the block (a stage-opening block changes both; default: identity shortcut)"""
+    Cout, HWo = Cout or Cin, HWo or H * W
+    k = (N, Cin, Cw, A, G, H, W, Cout, HWo)
     v = _SASIZES.get(k)
     if v is None:
         HW = H * W
-        ws = max(int(L.cot_conv1x1_workspace(N, Cin, Cw, HW, 0)), int(L.cot_conv1x1_workspace(N, Cw, Cin, HW, 0)),
-                 int(L.cot_conv3x3g_workspace(N, Cw, Cw, G, H, W)))
-        v = _SASIZES[k] = (ws, int(L.cot_bn_act_workspace(N, Cw)), int(L.cot_bn_act_workspace(N, Cin)), int(L.cot_bn_act_workspace(N, A)))
+        ws = max(int(L.cot_conv1x1_workspace(N, Cin, Cw, HW, 0)), int(L.cot_conv1x1_workspace(N, Cw, Cout, HWo, 0)),
+                 int(L.cot_conv1x1_workspace(N, Cin, Cout, HWo, 0)), int(L.cot_conv3x3g_workspace(N, Cw, Cw, G, H, W)))
+        v = _SASIZES[k] = (ws, int(L.cot_bn_act_workspace(N, Cw)), int(L.cot_bn_act_workspace(N, Cout)), int(L.cot_bn_act_workspace(N, A)))
     return v
 
 
@@ -80,12 +102,14 @@ class _SplitAttnBlockNode(Function):
         sp = _sa_plan(blk)
         N, Cin, H, W = x.shape
         Cw, A, G = sp.conv.out_channels, sp.fc1.out_channels, sp.conv.groups
-        HW = H * W
+        Cout = sp.conv3.out_channels
+        Ho, Wo = (H // 2, W // 2) if sp.avd_post else (H, W)  # (even planes: sa_block_eligible)
+        HW, HWo = H * W, Ho * Wo
         dev, st = x.device, _stream()
-        ws_bytes, nws_w, nws_o, nws_a = _sa_sizes(L, N, Cin, Cw, A, G, H, W)
+        ws_bytes, nws_w, nws_o, nws_a = _sa_sizes(L, N, Cin, Cw, A, G, H, W, Cout, HWo)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         masks = _masks(L, H, W, dev)
-        new = lambda c: torch.empty((N, c, H, W), dtype=x.dtype, device=dev)  # noqa: E731
+        new = lambda c, h=H, w=W: torch.empty((N, c, h, w), dtype=x.dtype, device=dev)  # noqa: E731
         stat = lambda c, nws: torch.empty(2 * c + nws, dtype=torch.float32, device=dev)  # noqa: E731
         c1, a1 = new(Cw), _new_guarded(N, Cw, H, W, x.dtype, dev)  # (the 3x3 weight gradient reads a1 shifted: margins)
         _ck(L.cot_conv1x1_forward(_p(x), None, Cin, _p(sp.conv1.weight), None, _p(c1), N, Cin, Cw, HW, BF16, st), "cot_conv1x1_forward")
@@ -105,14 +129,32 @@ class _SplitAttnBlockNode(Function):
         logits = torch.addmm(sp.fc2.bias, h, sp.fc2.weight.view(Cw, A).t())
         out2 = new(Cw)
         _ck(L.cot_se_gate(_p(b2), _p(logits), _p(out2), N * Cw, HW, BF16, st), "cot_se_gate")
-        c3, y = new(Cin), new(Cin)
-        _ck(L.cot_conv1x1_forward(_p(out2), None, Cw, _p(sp.conv3.weight), None, _p(c3), N, Cw, Cin, HW, BF16, st), "cot_conv1x1_forward")
-        s_3 = stat(Cin, nws_o)
+        if sp.avd_post:  # anti-aliased down-sampling behind conv2 (cotnet_hybrid.py:196-199; blur_pool.py:53-58)
+            out2p = new(Cw, Ho, Wo)
+            _ck(L.cot_blurpool3x3s2_forward(_p(out2), _p(out2p), N * Cw, H, W, BF16, st), "cot_blurpool3x3s2_forward")
+        else:
+            out2p = out2
+        c3, y = new(Cout, Ho, Wo), new(Cout, Ho, Wo)
+        _ck(L.cot_conv1x1_forward(_p(out2p), None, Cw, _p(sp.conv3.weight), None, _p(c3), N, Cw, Cout, HWo, BF16, st), "cot_conv1x1_forward")
+        if sp.ds_conv is not None:  # projection shortcut: bn(conv1x1([avgpool2x2](x)))
+            if sp.ds_pool2:
+                xs = new(Cin, Ho, Wo)
+                _ck(L.cot_avgpool2x2s2_forward(_p(x), _p(xs), N * Cin, H, W, BF16, st), "cot_avgpool2x2s2_forward")
+            else:
+                xs = x
+            d0, res = new(Cout, Ho, Wo), new(Cout, Ho, Wo)
+            _ck(L.cot_conv1x1_forward(_p(xs), None, Cin, _p(sp.ds_conv.weight), None, _p(d0), N, Cin, Cout, HWo, BF16, st), "cot_conv1x1_forward")
+            s_d = stat(Cout, nws_o)
+            _bn_fwd(L, d0, res, sp.ds_bn, s_d, 2 * Cout, N, Cout, HWo, 0)
+        else:
+            xs, d0, res, s_d = None, None, x, None
+        s_3 = stat(Cout, nws_o)
         ps = _drop_path_scale(blk, N, dev)
-        m3 = _relu_mask(L, N, Cin, HW, dev)
-        _bn_fwd(L, c3, y, sp.bn3, s_3, 2 * Cin, N, Cin, HW, 1, residual=x, ps=ps, mask=m3)
+        m3 = _relu_mask(L, N, Cout, HWo, dev)
+        _bn_fwd(L, c3, y, sp.bn3, s_3, 2 * Cout, N, Cout, HWo, 1, residual=res, ps=ps, mask=m3)
         ctx.blk, ctx.has_ps, ctx.has_mask = blk, ps is not None, m3 is not None
-        ctx.save_for_backward(x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3,
+        ctx.save_for_backward(x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3, out2p,
+                              *((d0, s_d, xs) if sp.ds_conv is not None else ()),
                               *((m3,) if m3 is not None else ()), *((ps,) if ps is not None else ()))
         return y
 
@@ -123,25 +165,33 @@ class _SplitAttnBlockNode(Function):
         blk = ctx.blk
         sp = _sa_plan(blk)
         t = ctx.saved_tensors
-        x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3 = t[:16]
-        m3 = t[16] if ctx.has_mask else None
+        x, c1, a1, s_1, c2, b2, s_0, gap, hpre, h, s_s, logits, out2, c3, y, s_3, out2p = t[:17]
+        nds = 3 if sp.ds_conv is not None else 0
+        d0, s_d, xs = t[17:20] if nds else (None, None, None)
+        m3 = t[17 + nds] if ctx.has_mask else None
         ps = t[-1] if ctx.has_ps else None
         N, Cin, H, W = x.shape
         Cw, A, G = sp.conv.out_channels, sp.fc1.out_channels, sp.conv.groups
-        HW = H * W
+        Cout, Ho, Wo = y.shape[1], y.shape[2], y.shape[3]
+        HW, HWo = H * W, Ho * Wo
         dev, st = x.device, _stream()
-        ws_bytes, nws_w, nws_o, nws_a = _sa_sizes(L, N, Cin, Cw, A, G, H, W)
+        ws_bytes, nws_w, nws_o, nws_a = _sa_sizes(L, N, Cin, Cw, A, G, H, W, Cout, HWo)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         masks = _masks(L, H, W, dev)
         side = _Side(dev, ws_bytes, ws, sp.params)
         gout = gout.contiguous()
         g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
-        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, sp.bn3, s_3, N, Cin, HW, 1, nws_o, dres=g_res, ps=ps, mask=m3)
-        g_out2 = torch.empty_like(out2)
-        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(sp.conv3.weight), _p(g_out2), None, Cw, 0, _p(ws), N, Cw, Cin, HW, BF16, st),
+        d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, sp.bn3, s_3, N, Cout, HWo, 1, nws_o, dres=g_res, ps=ps, mask=m3)
+        g_out2p = torch.empty_like(out2p)
+        _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(sp.conv3.weight), _p(g_out2p), None, Cw, 0, _p(ws), N, Cw, Cout, HWo, BF16, st),
             "cot_conv1x1_backward_data")
         g_w3 = grad_sink.out_like(sp.conv3.weight)
-        side.run(lambda st_, a_=(_p(g_c3), _p(out2), None, Cw, _p(g_w3), None, _p(side.ws), N, Cw, Cin, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, out2)
+        side.run(lambda st_, a_=(_p(g_c3), _p(out2p), None, Cw, _p(g_w3), None, _p(side.ws), N, Cw, Cout, HWo, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, out2p)
+        if sp.avd_post:
+            g_out2 = torch.empty_like(out2)
+            _ck(L.cot_blurpool3x3s2_backward(_p(g_out2p), _p(g_out2), N * Cw, H, W, BF16, st), "cot_blurpool3x3s2_backward")
+        else:
+            g_out2 = g_out2p
         # gate: dx of x * sigmoid(l) and dl in one pass; then the two fc layers (GEMMs on [N, .] descriptors) and their BatchNorm
         g_b2, g_log = torch.empty_like(b2), torch.empty_like(logits)
         _ck(L.cot_se_gate_backward(_p(g_out2), _p(b2), _p(logits), _p(g_b2), _p(g_log), N * Cw, HW, BF16, st), "cot_se_gate_backward")
@@ -165,14 +215,30 @@ class _SplitAttnBlockNode(Function):
         _conv3x3_dgrad(L, sp.conv, g_c2, g_a1, 0, masks, ws, N, Cw, G, H, W)
         g_c1 = torch.empty_like(c1)
         d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1, c1, None, g_c1, sp.bn1, s_1, N, Cw, HW, 1, nws_w)
-        gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
+        g_ds = ()
+        if sp.ds_conv is not None:  # projection shortcut: BatchNorm, 1x1 convolution [, the 2 x 2 average] backwards -> first contribution to dx
+            g_d0 = torch.empty_like(g_c3) if side.on else g_c3  # (g_c3 is still read by conv3's weight gradient on the side stream)
+            d_ds_w, d_ds_b = _bn_bwd(L, g_res, d0, None, g_d0, sp.ds_bn, s_d, N, Cout, HWo, 0, nws_o)
+            g_xs = torch.empty_like(xs)
+            _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(sp.ds_conv.weight), _p(g_xs), None, Cin, 0, _p(ws), N, Cin, Cout, HWo, BF16, st),
+                "cot_conv1x1_backward_data")
+            if sp.ds_pool2:
+                gx = torch.empty_like(x)
+                _ck(L.cot_avgpool2x2s2_backward(_p(g_xs), _p(gx), N * Cin, H, W, BF16, st), "cot_avgpool2x2s2_backward")
+            else:
+                gx = g_xs
+            g_wd = grad_sink.out_like(sp.ds_conv.weight)
+            side.run(lambda st_, a_=(_p(g_d0), _p(xs), None, Cin, _p(g_wd), None, _p(side.ws), N, Cin, Cout, HWo, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_d0, xs)
+            g_ds = (g_wd, d_ds_w, d_ds_b)
+        else:
+            gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
         g_w1 = grad_sink.out_like(sp.conv1.weight)
         side.run(lambda st_, a_=(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, Cw, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, x)
         _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(sp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16, st),
             "cot_conv1x1_backward_data")
         side.join()
         return (None, gx, g_w1, d_bn1_w, d_bn1_b, g_wc, d_bn0_w, d_bn0_b, g_fc1_w, g_fc1_b, d_sbn_w, d_sbn_b, g_fc2_w, g_fc2_b, g_w3,
-                d_bn3_w, d_bn3_b)
+                d_bn3_w, d_bn3_b) + g_ds
 
 
 def sa_block_eligible(blk, x):
@@ -184,7 +250,8 @@ def sa_block_eligible(blk, x):
     return (sp.static_ok and x.shape[1] == sp.conv1.in_channels and sp.conv1.weight.dtype == torch.bfloat16
             and sp.conv.weight.dtype == torch.bfloat16 and sp.fc1.weight.dtype == torch.bfloat16 and sp.conv3.weight.dtype == torch.bfloat16
             and sp.bn1.weight.dtype == torch.float32 and sp.bn1.training and sp.bn0.training and sp.sbn.training and sp.bn3.training
-            and x.shape[0] >= 2)
+            and x.shape[0] >= 2 and not (sp.avd_post and (x.shape[2] % 2 or x.shape[3] % 2))
+            and (sp.ds_bn is None or sp.ds_bn.training))
 
 
 def sa_block_forward(blk, x):

@@ -830,7 +830,8 @@ def cot_layer_forward(layer, x):
 # second pixel.  dx collects the residual gradient, the projection's and conv1's data gradients inside the kernels
 # (`accumulate`).
 class _BlockPlan:
-    __slots__ = ("conv1", "bn1", "cot", "conv3", "bn3", "ds_conv", "ds_bn", "ds_stride", "avd", "params", "static_ok")
+    __slots__ = ("conv1", "bn1", "cot", "conv3", "bn3", "ds_conv", "ds_bn", "ds_stride", "avd", "avd_post", "ds_pool2", "params",
+                 "static_ok")
 
     def __init__(self, blk):
         from .cotnet import CotLayer, CoXtLayer
@@ -838,19 +839,30 @@ class _BlockPlan:
         ds = blk.downsample
         self.ds_conv = self.ds_bn = None
         self.ds_stride = 1
+        from .layers import BlurPool2d
         avd = blk.avd
-        self.avd = avd is not None
-        # (cotnet_hybrid.CoTBottleneck pools AFTER the layer when avd_first is False, SE-CoTNetD-152's BlurPool: not this node)
-        avd_ok = avd is None or (isinstance(avd, nn.AvgPool2d) and avd.kernel_size == 3 and avd.stride == 2
-                                 and avd.padding == 1 and not avd.ceil_mode and avd.count_include_pad
-                                 and avd.divisor_override is None and getattr(blk, "avd_first", True))
+        # cotnet_hybrid.CoTBottleneck pools AFTER the layer when avd_first is False (models/cotnet_hybrid.py:196-199): SE-CoTNetD-152's
+        # BlurPool2d(filt_size 3, stride 2) behind conv2 -- `avd_post`; cotnet.Bottleneck pools in front of it (3 x 3 / 2 average) -- `avd`
+        post = (avd is not None and not getattr(blk, "avd_first", True) and isinstance(avd, BlurPool2d) and avd.filt_size == 3
+                and avd.stride == 2)
+        self.avd_post = post
+        self.avd = avd is not None and not post
+        avd_ok = avd is None or post or (isinstance(avd, nn.AvgPool2d) and avd.kernel_size == 3 and avd.stride == 2
+                                         and avd.padding == 1 and not avd.ceil_mode and avd.count_include_pad
+                                         and avd.divisor_override is None and getattr(blk, "avd_first", True))
         ds_ok = ds is None and avd is None
-        if isinstance(ds, nn.Sequential) and (len(ds) == 2 or (len(ds) == 3 and isinstance(ds[0], nn.Identity))):
+        self.ds_pool2 = False
+        if isinstance(ds, nn.Sequential) and (len(ds) == 2 or (len(ds) == 3 and isinstance(ds[0], (nn.Identity, nn.AvgPool2d)))):
             self.ds_conv, self.ds_bn = ds[-2], ds[-1]  # models/resnet.py:364-394: [pool,] conv, norm
             c = ds[-2]
-            self.ds_stride = 2 if avd is not None else 1
+            pool = ds[0] if len(ds) == 3 and isinstance(ds[0], nn.AvgPool2d) else None
+            # `avg_down` shortcut of a stride-2 block (models/resnet.py:380-394): AvgPool2d(2, 2) in front of a stride-1 projection
+            self.ds_pool2 = (pool is not None and pool.kernel_size == 2 and pool.stride == 2 and pool.padding == 0
+                             and pool.divisor_override is None)  # (ceil_mode / count_include_pad: no effect on even planes, checked at run time)
+            self.ds_stride = 2 if (avd is not None and pool is None) else 1
             ds_ok = (isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.padding == (0, 0) and c.groups == 1
-                     and c.stride == (self.ds_stride, self.ds_stride) and c.bias is None and _bn_static_ok(ds[-1]))
+                     and c.stride == (self.ds_stride, self.ds_stride) and c.bias is None and _bn_static_ok(ds[-1])
+                     and (pool is None or (self.ds_pool2 and avd is not None)))
         self.static_ok = (
             ds_ok and avd_ok and isinstance(blk.conv2, (CotLayer, CoXtLayer)) and blk.drop_block is None
             and (blk.drop_path is None or hasattr(blk.drop_path, "drop_prob")) and getattr(blk, "se", None) is None
@@ -892,7 +904,7 @@ class _BottleneckNode(Function):
         bp = _block_plan(blk)
         N, Cin, H, W = x.shape
         Cw, Cout = bp.conv1.out_channels, bp.conv3.out_channels
-        Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if bp.avd else (H, W)  # 3x3/2 pooling, padding 1
+        Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if (bp.avd or bp.avd_post) else (H, W)  # 3x3/2 pooling, padding 1 / BlurPool
         HW, HWo = H * W, Ho * Wo
         dev, st = x.device, _stream()
         _, nws_w, _ = _block_sizes(L, N, Cin, Cw, Cout, HW)
@@ -909,9 +921,16 @@ class _BottleneckNode(Function):
         else:
             p1 = a1
         cot_out, saved, geom = _cot_forward(L, bp.cot, p1)
+        if bp.avd_post:  # anti-aliased down-sampling behind the layer (cotnet_hybrid.py:196-199; blur_pool.py:53-58)
+            cot_full = cot_out
+            cot_out = new(Cw, Ho, Wo)
+            _ck(L.cot_blurpool3x3s2_forward(_p(cot_full), _p(cot_out), N * Cw, H, W, BF16, st), "cot_blurpool3x3s2_forward")
         c3, y = new(Cout, Ho, Wo), new(Cout, Ho, Wo)
         if bp.ds_conv is not None:  # projection shortcut: bn(conv1x1(x)), on every second pixel in a stride-2 block
-            if bp.ds_stride == 2 and H % 2 == 0 and W % 2 == 0:  # every second pixel: one pass, 16-byte accesses (pool3x3.hip)
+            if bp.ds_pool2:  # `avg_down`: 2 x 2 average pooling, then the stride-1 projection
+                xs = torch.empty((N, Cin, H // 2, W // 2), dtype=x.dtype, device=dev)
+                _ck(L.cot_avgpool2x2s2_forward(_p(x), _p(xs), N * Cin, H, W, BF16, st), "cot_avgpool2x2s2_forward")
+            elif bp.ds_stride == 2 and H % 2 == 0 and W % 2 == 0:  # every second pixel: one pass, 16-byte accesses (pool3x3.hip)
                 xs = torch.empty((N, Cin, H // 2, W // 2), dtype=x.dtype, device=dev)
                 _ck(L.cot_subsample2_forward(_p(x), _p(xs), N * Cin, H, W, BF16, st), "cot_subsample2_forward")
             else:
@@ -963,14 +982,20 @@ class _BottleneckNode(Function):
                                         BF16, st), "cot_conv1x1_backward_data")
         g_w3 = grad_sink.out_like(bp.conv3.weight)
         side.run(lambda st_, a_=(_p(g_c3), _p(cot_out), None, Cw, _p(g_w3), None, _p(side.ws), N, Cw, Cout, HWo, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, cot_out)
-        g_p1, g_cot = _cot_backward(L, bp.cot, saved, ctx.geom, g_cot_out, side)
+        if bp.avd_post:  # (cot_out at the output resolution was the pooled tensor: its gradient goes back through the blur)
+            g_full = torch.empty((N, Cw, H, W), dtype=x.dtype, device=dev)
+            _ck(L.cot_blurpool3x3s2_backward(_p(g_cot_out), _p(g_full), N * Cw, H, W, BF16, st), "cot_blurpool3x3s2_backward")
+            g_layer_out = g_full
+        else:
+            g_layer_out = g_cot_out
+        g_p1, g_cot = _cot_backward(L, bp.cot, saved, ctx.geom, g_layer_out, side)
         if bp.avd:
             g_a1 = torch.empty_like(a1)
             _ck(L.cot_avgpool3x3s2_backward(_p(g_p1), _p(g_a1), N * Cw, H, W, BF16, st), "cot_avgpool3x3s2_backward")
             g_c1 = torch.empty_like(c1)
         else:
             g_a1 = g_p1
-            g_c1 = g_cot_out  # (reuse: consumed by the layer's backward)
+            g_c1 = g_layer_out  # (reuse: consumed by the layer's backward)
         d_bn1_w, d_bn1_b = _bn_bwd(L, g_a1, c1, None, g_c1, bp.bn1, s_1, N, Cw, HW, 1, nws_w)
         g_ds = ()
         if ctx.has_ds:
@@ -978,7 +1003,13 @@ class _BottleneckNode(Function):
             # (g_c3 is still being read by conv3's weight gradient on the side stream: no reuse of its buffer here)
             g_d0 = torch.empty_like(g_c3) if side.on else g_c3
             d_ds_w, d_ds_b = _bn_bwd(L, g_res, d0, None, g_d0, bp.ds_bn, s_d, N, Cout, HWo, 0, nws_o)
-            if bp.ds_stride == 2:  # the projection saw every second pixel: its data gradient lands there, zeros elsewhere
+            if bp.ds_pool2:  # the projection saw 2 x 2 averages: its data gradient is spread over the four pixels of each window
+                g_xs = torch.empty_like(xs)
+                _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(g_xs), None, Cin, 0, _p(ws), N, Cin,
+                                                Cout, HWo, BF16, st), "cot_conv1x1_backward_data")
+                gx = torch.empty_like(x)
+                _ck(L.cot_avgpool2x2s2_backward(_p(g_xs), _p(gx), N * Cin, H, W, BF16, st), "cot_avgpool2x2s2_backward")
+            elif bp.ds_stride == 2:  # the projection saw every second pixel: its data gradient lands there, zeros elsewhere
                 g_xs = torch.empty_like(xs)
                 _ck(L.cot_conv1x1_backward_data(_p(g_d0), _p(bp.ds_conv.weight), _p(g_xs), None, Cin, 0, _p(ws), N, Cin,
                                                 Cout, HWo, BF16, st), "cot_conv1x1_backward_data")
@@ -1013,7 +1044,8 @@ def block_eligible(blk, x):
     bp = _block_plan(blk)
     if not (bp.static_ok and x.shape[1] == bp.conv1.in_channels and bp.conv1.weight.dtype == torch.bfloat16
             and bp.conv3.weight.dtype == torch.bfloat16 and bp.bn1.weight.dtype == torch.float32 and bp.bn1.training
-            and (bp.ds_conv is not None or (bp.conv1.in_channels == bp.conv3.out_channels and not bp.avd))):
+            and (bp.ds_conv is not None or (bp.conv1.in_channels == bp.conv3.out_channels and not bp.avd))
+            and not (bp.ds_pool2 and (x.shape[2] % 2 or x.shape[3] % 2))):  # (cot_avgpool2x2s2_*: even planes)
         return False
     pl = _plan(bp.cot)
     return (pl.ke0.weight.dtype == torch.bfloat16 and pl.em3.weight.dtype == torch.bfloat16

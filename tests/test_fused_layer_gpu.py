@@ -125,6 +125,29 @@ def test_single_node_split_attn_block_against_fp32_truth(inpl, planes, hw):
     assert node.startswith("_SplitAttnBlockNode")
 
 
+@pytest.mark.parametrize("kind,inpl,planes,hw", [("split_attn", 128, 64, 160), ("split_attn", 256, 128, 80), ("cot", 512, 256, 40),
+                                                 ("cot", 1024, 512, 20)])
+def test_se_cotnetd_stage_opening_blocks_as_single_nodes_against_fp32_truth(kind, inpl, planes, hw):
+    """SE-CoTNetD-152's four stage-opening blocks at their real widths / maps (320 x 320 input): BlurPool2d behind conv2 (avd_first False,
+    models/cotnet_hybrid.py:196-199) and the `avg_down` projection shortcut (models/resnet.py:380-394) inside the single-node paths"""
+    from cotnet_amd.cotnet_hybrid import CoTBottleneck
+    from cotnet_amd.layers import BlurPool2d, get_act_layer
+    from cotnet_amd.resnet import downsample_avg
+    torch.manual_seed(hw + planes)
+    blk = CoTBottleneck(0, inpl, planes, stride=2, downsample=downsample_avg(inpl, planes * 4, 1, stride=2), aa_layer=BlurPool2d, radix=1,
+                        avd=True, avd_first=False, conv_dim={64, 128}, c4_dim=256, c4_idx={0, 2}, act_layer=get_act_layer("swish")).to(DEV).train()
+    assert type(blk.conv2).__name__ == ("SplitAttnConv2d" if kind == "split_attn" else "CoTLayer")
+    with torch.no_grad():
+        blk.bn3.weight.fill_(0.8)
+    blk = to_mixed_bf16(blk)
+    N = 4
+    x = torch.randn(N, inpl, hw, hw, device=DEV).bfloat16()
+    g = torch.randn(N, planes * 4, hw // 2, hw // 2, device=DEV).bfloat16()
+    truth.check_against_truth(blk, x, g, cand=truth.SINGLE_NODE)
+    *_, node = truth.run(blk, x, g, want_module=True, **truth.SINGLE_NODE)
+    assert node.startswith("_SplitAttnBlockNode" if kind == "split_attn" else "_BottleneckNode"), node
+
+
 class _FixedDropPath(torch.nn.Module):
     """stochastic depth with a GIVEN per-sample scale (0 or 1 / keep): what models/layers/drop.py:140-168 computes, minus the draw"""
 

@@ -1837,6 +1837,82 @@ def test_fused_split_attn_block_node_on_emulated_kernels(act, monkeypatch):
         cache.clear()
 
 
+@pytest.mark.parametrize("kind", ["split_attn", "cot"])
+def test_se_cotnetd_stage_opening_blocks_as_single_nodes(kind, monkeypatch):
+    """SE-CoTNetD-152's stage-opening blocks (models/cotnet_hybrid.py:172-202 with avd = BlurPool2d behind conv2, avd_first False, and the
+    `avg_down` projection shortcut AvgPool2d(2, 2) -> 1x1 -> BatchNorm, models/resnet.py:380-394) as ONE autograd node -- the SplitAttn
+    kind (layer1[0], layer2[0]) and the CoT kind (layer3[0], layer4[0]) -- against the same block node per op, emulated kernels"""
+    import copy
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, group_norm9 as g9, pool3x3 as p3, radix_tail, se_gate
+    from cotnet_amd.cotnet_hybrid import CoTBottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    from cotnet_amd.layers import BlurPool2d, get_act_layer
+    from cotnet_amd.resnet import downsample_avg
+    torch.manual_seed(14)
+    N, H, W = 4, 8, 8
+    inpl, planes = 128, 64
+    conv_dim = {64} if kind == "split_attn" else set()
+    node = CoTBottleneck(0, inpl, planes, stride=2, downsample=downsample_avg(inpl, planes * 4, 1, stride=2), aa_layer=BlurPool2d,
+                         radix=1, avd=True, avd_first=False, conv_dim=conv_dim, c4_dim=-1, c4_idx=set(),
+                         act_layer=get_act_layer("swish")).train()
+    assert type(node.conv2).__name__ == ("SplitAttnConv2d" if kind == "split_attn" else "CoTLayer") and isinstance(node.avd, BlurPool2d)
+    with torch.no_grad():
+        for p in node.parameters():
+            if p.ndim == 1:
+                p.add_(0.3 * torch.randn_like(p))
+        node.bn3.weight.fill_(0.8)
+    node = to_mixed_bf16(node)
+    perop = copy.deepcopy(node)
+    x = torch.randn(N, inpl, H, W).bfloat16()
+    g = torch.randn(N, planes * 4, H // 2, W // 2).bfloat16()
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail, se_gate, g9, p3):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    for mod in (c1, c3, g9, p3):
+        monkeypatch.setattr(mod, "MODE", "hip")
+    import cotnet_amd.aggregation_zeropad as az
+    monkeypatch.setattr(az, "aggregation_zeropad",
+                        lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
+    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, clf._SASIZES, c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
+    for cache in caches:
+        cache.clear()
+    clf.reset_node_counts()
+    monkeypatch.setattr(clf, "ENABLED", False)
+    xr = x.clone().requires_grad_(True)
+    yr = perop(xr)
+    yr.backward(g)
+    monkeypatch.setattr(clf, "ENABLED", True)
+    xf = x.clone().requires_grad_(True)
+    assert (clf.sa_block_eligible if kind == "split_attn" else clf.block_eligible)(node, xf)
+    yf = node(xf)
+    assert yf.grad_fn.name().startswith("_SplitAttnBlockNode" if kind == "split_attn" else "_BottleneckNode"), yf.grad_fn.name()
+    assert yf.shape == yr.shape == (N, planes * 4, H // 2, W // 2)
+    yf.backward(g)
+
+    def relmax(a, b):
+        return ((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-6)).item()
+
+    def rel(a, b):
+        return ((a.float() - b.float()).abs().mean() / (b.float().abs().mean() + 1e-6)).item()
+
+    assert relmax(yf, yr.detach()) < 2e-2
+    assert rel(xf.grad, xr.grad) < 8e-2
+    pr = dict(perop.named_parameters())
+    top = max(q.grad.float().abs().max() for q in pr.values())
+    for n_, p in node.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == p.dtype, n_
+        if pr[n_].grad.float().abs().max() > 1e-3 * top and not n_.endswith("fc1.bias") and "se.0.bias" not in n_:
+            assert rel(p.grad, pr[n_].grad) < 0.15, (n_, rel(p.grad, pr[n_].grad))
+    br, bf = dict(perop.named_buffers()), dict(node.named_buffers())
+    for n_ in br:
+        assert torch.allclose(bf[n_].float(), br[n_].float(), atol=1e-3, rtol=1e-3), n_
+    # an odd plane keeps the module path (cot_avgpool2x2s2_* / the blur's output size need even H, W)
+    xo = torch.randn(N, inpl, 7, 7).bfloat16()
+    assert not (clf.sa_block_eligible if kind == "split_attn" else clf.block_eligible)(node, xo)
+    for cache in caches:
+        cache.clear()
+
+
 def test_whole_cotnet50_forward_backward_with_every_opt_in_on_emulated_kernels(monkeypatch):
     """cotnet50 (tiny input) trained one step's worth -- forward, loss, backward into the flat gradient buckets -- twice on
     the host-emulated kernels: node-per-op with the default switches, and with every opt-in on (hand-written 1x1 / 3x3
