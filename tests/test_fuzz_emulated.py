@@ -732,7 +732,7 @@ def test_random_shapes_round6_kernels(seed):
     rng = random.Random(seed)
     torch.manual_seed(seed)
     failures = []
-    for _ in range(30):
+    for _ in range(10):  # (the oracle's loop nest on 2 x 11 x 12 planes is the slow part: 1-2 s per case)
         ok, desc = rng.choice([case_mix, case_mix, case_stem3x3])(rng)
         if not ok:
             failures.append(desc)
