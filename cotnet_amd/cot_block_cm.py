@@ -228,14 +228,24 @@ class _BottleneckCMNode(Function):
         # aggregation, bn + swish (NCHW)                                                                            (ref :88-90)
         geom = _lib.AggGeom(2 * N, C // 2, H, W, 1, C // 16, 3, 3, 1, 1, 1, 1, 1, 1) if GX else \
             _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
-        a, y = nchw(C), nchw(C)
+        bn_tail = clf.BN_TAIL  # BatchNorm + SiLU folded into the radix tail (cot_radix_*_bn): y = silu(bn(a)) is never written
+        a, y = nchw(C), (None if bn_tail else nchw(C))
+        bnl = pl.bn
         _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
         s_y = stat(C, nws_c)
-        _bn_fwd(L, a, y, pl.bn, s_y, 2 * C, N, C, HW, 2)
+        if bn_tail:
+            _ck(L.cot_bn_stats_partial(_p(a), _p(s_y[2 * C:]), N, C, HW, BF16, st), "cot_bn_stats_partial")
+        else:
+            _bn_fwd(L, a, y, bnl, s_y, 2 * C, N, C, HW, 2)
         # radix-2 split attention: y NCHW, k channel-major, the mix written channel-major for conv3                (ref :92-104)
         row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
         gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
-        _ck(L.cot_radix_gap_t_lay(_p(y), _p(k), _p(gapT), N, C, HW, 2, BF16, st), "cot_radix_gap_t_lay")
+        if bn_tail:
+            _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]), _p(bnl.running_mean),
+                                     _p(bnl.running_var), _p(bnl.num_batches_tracked), _p(s_y[2 * C:]), N, C, HW, float(bnl.eps),
+                                     float(bnl.momentum), 2, BF16, st), "cot_radix_gap_t_bn")
+        else:
+            _ck(L.cot_radix_gap_t_lay(_p(y), _p(k), _p(gapT), N, C, HW, 2, BF16, st), "cot_radix_gap_t_lay")
         _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st), "cot_conv1x1_forward")
         s_a = stat(A, nws_a)
         _bn_fwd(L, hpre, h, pl.sebn, s_a, 2 * A, 1, A, N, 1)
@@ -243,7 +253,11 @@ class _BottleneckCMNode(Function):
             "cot_conv1x1_forward")
         attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
         cot_out = cmj(C)
-        _ck(L.cot_radix_mix_logits_lay(_p(y), _p(k), _p(logitsT), _p(cot_out), _p(attn), N, C, HW, 2 | 4, BF16, st), "cot_radix_mix_logits_lay")
+        if bn_tail:
+            _ck(L.cot_radix_mix_logits_bn(_p(a), _p(k), _p(logitsT), _p(cot_out), _p(attn), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]),
+                                          N, C, HW, 2 | 4, BF16, st), "cot_radix_mix_logits_bn")
+        else:
+            _ck(L.cot_radix_mix_logits_lay(_p(y), _p(k), _p(logitsT), _p(cot_out), _p(attn), N, C, HW, 2 | 4, BF16, st), "cot_radix_mix_logits_lay")
         # conv3 -> bn3 + residual + relu.  The residual: the block's input (identity) or bn(conv1x1(every second pixel of it))
         c3 = cmj(Cout)
         _ck(L.cot_conv1x1_forward(_p(cot_out), None, C, _p(bp.conv3.weight), None, _p(c3), 1, C, Cout, M, BF16, st), "cot_conv1x1_forward")
@@ -326,8 +340,14 @@ class _BottleneckCMNode(Function):
         # radix mix -> pair-softmax backward -> se branch -> gap
         row = lambda c: torch.empty((c, N), dtype=a1.dtype, device=dev)  # noqa: E731
         glogT, gh, ggapT = row(2 * C), row(A), row(C)
-        _ck(L.cot_radix_mix_backward_reduce_lay(_p(g_out), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, 1 | 4, BF16, st),
-            "cot_radix_mix_backward_reduce_lay")
+        bnl = pl.bn
+        if y is None:  # (the forward folded bn + swish into the tail: so does the backward)
+            tsum = torch.empty(N * C * 4, dtype=torch.float32, device=dev)
+            _ck(L.cot_radix_mix_backward_reduce_bn(_p(g_out), _p(a), _p(k), _p(attn), _p(glogT), _p(tsum), _p(bnl.weight), _p(bnl.bias),
+                                                   _p(s_y), _p(s_y[C:]), N, C, HW, 1 | 4, BF16, st), "cot_radix_mix_backward_reduce_bn")
+        else:
+            _ck(L.cot_radix_mix_backward_reduce_lay(_p(g_out), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, 1 | 4, BF16, st),
+                "cot_radix_mix_backward_reduce_lay")
         _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st), "cot_conv1x1_backward_data")
         g_w3, g_b3 = grad_sink.out_like(se3.weight), grad_sink.out_like(se3.bias)
         side.run(lambda st_, a_=(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(side.ws), 1, A, 2 * C, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), glogT, h)
@@ -336,12 +356,18 @@ class _BottleneckCMNode(Function):
         _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st), "cot_conv1x1_backward_data")
         g_w0, g_b0 = grad_sink.out_like(se0.weight), grad_sink.out_like(se0.bias)
         side.run(lambda st_, a_=(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(side.ws), 1, C, A, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ghpre, gapT)
-        gy, gk = nchw(C), cmj(C)
-        _ck(L.cot_radix_mix_backward_apply_lay(_p(g_out), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, 1 | 4, BF16, st),
-            "cot_radix_mix_backward_apply_lay")
         # bn + swish, aggregation (NCHW)
-        ga = nchw(C)
-        d_bn_w, d_bn_b = _bn_bwd(L, gy, a, None, ga, pl.bn, s_y, N, C, HW, 2, nws_c)
+        ga, gk = nchw(C), cmj(C)
+        if y is None:
+            d_bn_w, d_bn_b = grad_sink.out_like(bnl.weight), grad_sink.out_like(bnl.bias)
+            _ck(L.cot_radix_mix_backward_apply_bn(_p(g_out), _p(a), _p(attn), _p(ggapT), _p(tsum), _p(ga), _p(gk), _p(bnl.weight),
+                                                  _p(bnl.bias), _p(s_y), _p(s_y[C:]), _p(d_bn_w), _p(d_bn_b), N, C, HW, 1 | 4, BF16, st),
+                "cot_radix_mix_backward_apply_bn")
+        else:
+            gy = nchw(C)
+            _ck(L.cot_radix_mix_backward_apply_lay(_p(g_out), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, 1 | 4, BF16, st),
+                "cot_radix_mix_backward_apply_lay")
+            d_bn_w, d_bn_b = _bn_bwd(L, gy, a, None, ga, bnl, s_y, N, C, HW, 2, nws_c)
         gv, gw = nchw(C), nchw(Ce)
         _ck(L.cot_agg_backward(_p(ga), _p(v), _p(w), _p(gv), _p(gw), ctypes.byref(ctx.geom), BF16, _lib.COT_NCHW, st), "cot_agg_backward")
         # values branch: bn (NCHW gradient in, channel-major out), 1x1 -> first contribution to the channel-major dx

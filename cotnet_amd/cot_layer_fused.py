@@ -213,6 +213,12 @@ def _gn_fused_ok(L, Ch, HW, W):
     return v
 
 
+# BatchNorm + SiLU of the aggregation's output folded into the radix tail (round 6; VERDICT r5 J1 / next #2b; models/cotnet.py:89-104):
+# a statistics pass over `a`, then the pooling and the mix kernels normalise + activate as they load (cot_radix_*_bn) -- y = silu(bn(a))
+# is never written; backward: two launches (reduce, apply) instead of four, the BatchNorm's channel sums out of the reduce kernel's
+# plane sums.  COT_BN_TAIL=0 = the separate cot_bn_act_* kernels as before.
+BN_TAIL = os.environ.get("COT_BN_TAIL", "1") != "0"
+
 _SIZES = _lib.register_cache({})  # (N, C, H, W, A) -> (workspace bytes, bn workspace floats for C, C/2 and the se branch's A channels)
 _MASKS = {}
 
@@ -622,20 +628,30 @@ def _cot_forward(L, layer, x):
     # (CoXtLayer folds its two groups into the batch: [N, C] -> [2N, C/2], weights [2N, 1, C/16, 9]: views of the same memory)
     geom = _lib.AggGeom(2 * N, C // 2, H, W, 1, C // 16, 3, 3, 1, 1, 1, 1, 1, 1) if GX else \
         _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
-    a, y = new(C), new(C)
+    a, y = new(C), (None if BN_TAIL else new(C))
     if fused_gn:
         _ck(L.cot_agg_gn9_forward(_p(v), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(gn.bias), gn.num_groups, _p(a),
                                   ctypes.byref(geom), BF16, st), "cot_agg_gn9_forward")
     else:
         _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
     s_y = stat(C, nws_c)
-    _bn_fwd(L, a, y, pl.bn, s_y, 2 * C, N, C, HW, 2)
+    bnl = pl.bn
+    if BN_TAIL:
+        y = None
+        _ck(L.cot_bn_stats_partial(_p(a), _p(s_y[2 * C:]), N, C, HW, BF16, st), "cot_bn_stats_partial")
+    else:
+        _bn_fwd(L, a, y, bnl, s_y, 2 * C, N, C, HW, 2)
     # radix-2 split attention                                                                    (ref :92-104)
     # descriptors are kept channel-major ([C][N]) so that the se branch runs on the 1x1-convolution / BatchNorm
     # kernels with the batch as the pixel axis
     row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
     gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
-    _ck(L.cot_radix_gap_t(_p(y), _p(k), _p(gapT), N, C, HW, BF16, st), "cot_radix_gap_t")
+    if BN_TAIL:
+        _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]), _p(bnl.running_mean),
+                                 _p(bnl.running_var), _p(bnl.num_batches_tracked), _p(s_y[2 * C:]), N, C, HW, float(bnl.eps),
+                                 float(bnl.momentum), 0, BF16, st), "cot_radix_gap_t_bn")
+    else:
+        _ck(L.cot_radix_gap_t(_p(y), _p(k), _p(gapT), N, C, HW, BF16, st), "cot_radix_gap_t")
     _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st),
         "cot_conv1x1_forward")
     s_a = stat(A, nws_a)
@@ -644,8 +660,12 @@ def _cot_forward(L, layer, x):
                               st), "cot_conv1x1_forward")
     attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
     out = new(C)
-    _ck(L.cot_radix_mix_logits(_p(y), _p(k), _p(logitsT), _p(out), _p(attn), N, C, HW, BF16, st),
-        "cot_radix_mix_logits")
+    if BN_TAIL:
+        _ck(L.cot_radix_mix_logits_bn(_p(a), _p(k), _p(logitsT), _p(out), _p(attn), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]),
+                                      N, C, HW, 0, BF16, st), "cot_radix_mix_logits_bn")
+    else:
+        _ck(L.cot_radix_mix_logits(_p(y), _p(k), _p(logitsT), _p(out), _p(attn), N, C, HW, BF16, st),
+            "cot_radix_mix_logits")
 
     return out, (x, k_pre, k, e0, e1, e3, w, gn_mean, gn_rstd, v_pre, v, a, y, attn, s_k, s_e, s_v, s_y, gapT, hpre, h,
                  s_a, qk), geom
@@ -679,8 +699,14 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     # radix mix -> pair-softmax backward -> se branch (two 1x1 convolutions over the batch axis) -> gap
     row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
     glogT, gh, ggapT = row(2 * C), row(A), row(C)
-    _ck(L.cot_radix_mix_backward_reduce(_p(gout), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, BF16, st),
-        "cot_radix_mix_backward_reduce")
+    bnl = pl.bn
+    if y is None:  # (the forward folded bn + swish into the tail: so does the backward)
+        tsum = torch.empty(N * C * 4, dtype=torch.float32, device=dev)
+        _ck(L.cot_radix_mix_backward_reduce_bn(_p(gout), _p(a), _p(k), _p(attn), _p(glogT), _p(tsum), _p(bnl.weight), _p(bnl.bias),
+                                               _p(s_y), _p(s_y[C:]), N, C, HW, 0, BF16, st), "cot_radix_mix_backward_reduce_bn")
+    else:
+        _ck(L.cot_radix_mix_backward_reduce(_p(gout), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, BF16, st),
+            "cot_radix_mix_backward_reduce")
     _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st),
         "cot_conv1x1_backward_data")
     g_w3, g_b3 = grad_sink.out_like(se3.weight), grad_sink.out_like(se3.bias)
@@ -691,12 +717,18 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
         "cot_conv1x1_backward_data")
     g_w0, g_b0 = grad_sink.out_like(se0.weight), grad_sink.out_like(se0.bias)
     side.run(lambda st_, a_=(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(side.ws), 1, C, A, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ghpre, gapT)
-    gy, gk = torch.empty_like(y), torch.empty_like(k)
-    _ck(L.cot_radix_mix_backward_apply(_p(gout), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, BF16, st),
-        "cot_radix_mix_backward_apply")
     # bn + swish, aggregation
-    ga = torch.empty_like(a)
-    d_bn_w, d_bn_b = _bn_bwd(L, gy, a, None, ga, pl.bn, s_y, N, C, HW, 2, nws_c)
+    ga, gk = torch.empty_like(a), torch.empty_like(k)
+    if y is None:
+        d_bn_w, d_bn_b = grad_sink.out_like(bnl.weight), grad_sink.out_like(bnl.bias)
+        _ck(L.cot_radix_mix_backward_apply_bn(_p(gout), _p(a), _p(attn), _p(ggapT), _p(tsum), _p(ga), _p(gk), _p(bnl.weight), _p(bnl.bias),
+                                              _p(s_y), _p(s_y[C:]), _p(d_bn_w), _p(d_bn_b), N, C, HW, 0, BF16, st),
+            "cot_radix_mix_backward_apply_bn")
+    else:
+        gy = torch.empty_like(y)
+        _ck(L.cot_radix_mix_backward_apply(_p(gout), _p(attn), _p(ggapT), _p(gy), _p(gk), N, C, HW, BF16, st),
+            "cot_radix_mix_backward_apply")
+        d_bn_w, d_bn_b = _bn_bwd(L, gy, a, None, ga, bnl, s_y, N, C, HW, 2, nws_c)
     gv, gw = torch.empty_like(v), torch.empty_like(e3)
     if w is None:  # (the forward normalised the logits inside the aggregation: so does the backward; gw = d / d normalised weights)
         gn_ = pl.gn

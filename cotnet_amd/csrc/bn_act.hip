@@ -1022,6 +1022,33 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
 }
 
 
+// ---- the statistics pass alone (round 6): chunk statistics [C][split][4] = (count, mean, M2, 0) of every channel into `ws`
+// (bn_workspace_floats(N, C) floats; split = bn_stats_split(N, C)).  For consumers that normalise while they load -- the radix tail's
+// cot_radix_*_bn kernels (radix_tail.hip) -- instead of reading a normalised tensor somebody wrote for them.
+int bn_stats_split(int N, int C) {
+    int split, nper;
+    pick_split(N, C, &split, &nper);
+    return split;
+}
+template <typename T>
+int bn_stats_only(const void* x, float* ws, int N, int C, int HW, hipStream_t s) {
+    int split, nper;
+    pick_split(N, C, &split, &nper);
+    int v = pick_vec(sizeof(T), HW);
+    if (v == 1 && HW % 7 == 0 && sizeof(T) == 2) v = 7;  // 7 x 7 planes: 7 elements per lane and access (Vec<T, 7>)
+    if (sizeof(T) > 2 && v == 8) v = 4;
+#define BN_SO(V_) COT_LAUNCH((bn_stats_partial<T, V_>), dim3(C, split), dim3(256), 48 * sizeof(float), s, (const T*)x, ws, N, C, HW, nper)
+    if (v == 8) BN_SO((sizeof(T) <= 2 ? 8 : 4));
+    else if (v == 7) BN_SO(7);
+    else if (v == 4) BN_SO(4);
+    else if (v == 2) BN_SO(2);
+    else BN_SO(1);
+#undef BN_SO
+    return check_launch("bn_stats_partial");
+}
+template int bn_stats_only<float>(const void*, float*, int, int, int, hipStream_t);
+template int bn_stats_only<bf16_t>(const void*, float*, int, int, int, hipStream_t);
+
 // ---- statistics from the PRODUCER's epilogue (round 5): the 1x1 convolution that writes a BatchNorm's
 // input also writes, per (image, 128-pixel tile, channel), the sum and the sum of squares of the bf16 values it stores
 // (conv_lds_common.h tile_epilogue, BIG tiles: planes of more than 256 pixels).  This kernel turns them into the channel's batch

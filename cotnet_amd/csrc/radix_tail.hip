@@ -226,6 +226,231 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_apply_kernel(const T* __res
     }
 }
 
+// ---- BatchNorm + SiLU of the aggregation's output folded into the tail (round 6; VERDICT r5 J1 / next #2b; models/cotnet.py:88-104:
+// x = local_conv(x, w); x = bn(x); x = act(x); then the radix tail).  The normalised, activated tensor y = silu(bn(a)) has exactly two
+// readers, both in this file, and both read it plane by plane with the channel wave-uniform: they take the RAW aggregation output `a`
+// and the BatchNorm's statistics and form y as they load -- y is never written, the BatchNorm's apply pass (1 read + 1 write) and the
+// tail's two reads of y become two reads of a.  Backward: what BatchNorm needs per channel, sum g_z and sum g_z * xhat with
+// g_z = (g*a0 + add) * silu'(z), splits into four plane sums that do not depend on `add` (the gradient of the pooled descriptor, known
+// only after the se branch's backward): t0 = sum g*s', t1 = sum s', t2 = sum g*s'*xhat, t3 = sum s'*xhat.  The reduce kernel -- which
+// reads g and a anyway -- emits them; the apply kernel's prologue combines them over the batch (fixed order: deterministic) and writes
+// the gradient w.r.t. a directly.  4 launches and 11 tensor passes (mix apply, BatchNorm reduce, BatchNorm apply, + the reduce) become 2
+// launches and 7 passes.
+//   radix_gap_t_bn        gapT[c][n] = mean_hw(silu(bn(a)) + k); with `part` given its prologue also FINALIZES the statistics (merges the
+//                         [C][split][4] chunk statistics of bn_stats_partial exactly as bn_apply_fwd_fold does; plane n = 0 of a channel
+//                         writes mean / rstd / running statistics)
+//   radix_mix_logits_bn   out = silu(bn(a))*a0 + k*a1
+//   radix_mix_bwd_reduce_bn  glogitsT as radix_mix_bwd_reduce + tsum[n][c][0..3]
+//   radix_mix_bwd_apply_bn   ga = gamma*rstd*(g_z - dbeta/M - xhat*dgamma/M), gk = g*a1 + add; dgamma / dbeta written by plane n = 0
+// z = a*sc + sh with sc = gamma*rstd, sh = beta - mean*sc, y rounded to the storage type: bit-identical to bn_apply_fwd{,_fold}.
+struct BnTail {
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* rstd;
+};
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+
+template <typename T, int V, int SEG = 64>
+__global__ __launch_bounds__(256) void radix_gap_t_bn_kernel(const T* __restrict__ a, const T* __restrict__ k, T* __restrict__ gapT,
+                                                            BnTail bn, const float* __restrict__ part, int split, float eps,
+                                                            float momentum, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                            long long* __restrict__ nbt, int N, int C, int HW, int lay) {
+    const int lane = threadIdx.x & (SEG - 1);
+    int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
+    const bool live = plane < (int64_t)N * C;
+    if (SEG == 64 && !live) return;
+    if (!live) plane = (int64_t)N * C - 1;
+    const int n = (int)(plane / C), c = (int)(plane % C);
+    float m, r;
+    if (part) {  // Chan merge of the channel's chunk statistics, in bn_apply_fwd_fold's order
+        float cnt = 0.f, M2 = 0.f;
+        m = 0.f;
+        for (int q = 0; q < split; ++q) {
+            const float* p = part + ((int64_t)c * split + q) * 4;
+            const float nb = p[0];
+            if (nb <= 0.f) continue;
+            const float delta = p[1] - m, nn = cnt + nb;
+            m += delta * nb / nn;
+            M2 += p[2] + delta * delta * cnt * nb / nn;
+            cnt = nn;
+        }
+        const float var = cnt > 0 ? M2 / cnt : 0.f;
+        r = 1.0f / sqrtf(var + eps);
+        if (n == 0 && lane == 0 && live) {
+            mean_out[c] = m;
+            rstd_out[c] = r;
+            if (running_mean) {
+                const float unbiased = cnt > 1 ? M2 / (cnt - 1.f) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            }
+            if (c == 0 && nbt) *nbt += 1;
+        }
+    } else {
+        m = bn.mean[c];
+        r = bn.rstd[c];
+    }
+    const float sc = bn.gamma[c] * r, sh = bn.beta[c] - m * sc;
+    const T* ap = a + tail_base(lay & 1, n, c, N, C, HW);
+    const T* kp = k + tail_base(lay & 2, n, c, N, C, HW);
+    float acc = 0.f;
+    for (int i = lane * V; i < HW; i += SEG * V) {
+        const Vec<T, V> av = ldv<T, V>(ap + i), b = ldv<T, V>(kp + i);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc += (float)(T)silu_f((float)av.v[j] * sc + sh) + (float)b.v[j];
+    }
+    acc = seg_sum_f<SEG>(acc);
+    if (lane == 0 && live) gapT[(int64_t)c * N + n] = (T)(acc / (float)HW);
+}
+
+template <typename T, int V, int SEG = 64>
+__global__ __launch_bounds__(256) void radix_mix_logits_bn_kernel(const T* __restrict__ a, const T* __restrict__ k,
+                                                                 const T* __restrict__ logitsT, T* __restrict__ out,
+                                                                 T* __restrict__ attn, BnTail bn, int N, int C, int HW, int lay) {
+    const int lane = threadIdx.x & (SEG - 1);
+    const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
+    if (plane >= (int64_t)N * C) return;  // (no shuffles below)
+    const int n = (int)(plane / C), c = (int)(plane % C);
+    const float l0 = (float)logitsT[(int64_t)(2 * c) * N + n], l1 = (float)logitsT[(int64_t)(2 * c + 1) * N + n];
+    const float a0 = 1.f / (1.f + __expf(l1 - l0)), a1 = 1.f - a0;
+    if (lane == 0) {
+        attn[plane * 2] = (T)a0;
+        attn[plane * 2 + 1] = (T)a1;
+    }
+    const float sc = bn.gamma[c] * bn.rstd[c], sh = bn.beta[c] - bn.mean[c] * sc;
+    const T* ap = a + tail_base(lay & 1, n, c, N, C, HW);
+    const T* kp = k + tail_base(lay & 2, n, c, N, C, HW);
+    T* op = out + tail_base(lay & 4, n, c, N, C, HW);
+    for (int i = lane * V; i < HW; i += SEG * V) {
+        const Vec<T, V> av = ldv<T, V>(ap + i), b = ldv<T, V>(kp + i);
+        Vec<T, V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.v[j] = (T)((float)(T)silu_f((float)av.v[j] * sc + sh) * a0 + (float)b.v[j] * a1);
+        stv<T, V>(op + i, o);
+    }
+}
+
+template <typename T, int V, int SEG = 64>
+__global__ __launch_bounds__(256) void radix_mix_bwd_reduce_bn_kernel(const T* __restrict__ g, const T* __restrict__ a,
+                                                                     const T* __restrict__ k, const T* __restrict__ attn,
+                                                                     T* __restrict__ glogitsT, float* __restrict__ tsum, BnTail bn,
+                                                                     int N, int C, int HW, int lay) {
+    const int lane = threadIdx.x & (SEG - 1);
+    int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
+    const bool live = plane < (int64_t)N * C;
+    if (SEG == 64 && !live) return;
+    if (!live) plane = (int64_t)N * C - 1;
+    const int n = (int)(plane / C), c = (int)(plane % C);
+    const float m = bn.mean[c], r = bn.rstd[c];
+    const float sc = bn.gamma[c] * r, sh = bn.beta[c] - m * sc;
+    const T* gp = g + tail_base(lay & 1, n, c, N, C, HW);
+    const T* ap = a + tail_base(lay & 2, n, c, N, C, HW);
+    const T* kp = k + tail_base(lay & 4, n, c, N, C, HW);
+    float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int i = lane * V; i < HW; i += SEG * V) {
+        const Vec<T, V> gv = ldv<T, V>(gp + i), av = ldv<T, V>(ap + i), b = ldv<T, V>(kp + i);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gg = (float)gv.v[j], x = (float)av.v[j];
+            const float z = x * sc + sh, den = 1.f + __expf(-z), sg = 1.f / den;
+            const float y = (float)(T)(z / den);       // the forward's y, as it was formed and rounded there (silu_f)
+            const float sp = sg * (1.f + z * (1.f - sg));  // silu'(z)
+            const float xh = (x - m) * r;
+            s0 += gg * y;
+            s1 += gg * (float)b.v[j];
+            t0 += gg * sp;
+            t1 += sp;
+            t2 += gg * sp * xh;
+            t3 += sp * xh;
+        }
+    }
+    s0 = seg_sum_f<SEG>(s0);
+    s1 = seg_sum_f<SEG>(s1);
+    t0 = seg_sum_f<SEG>(t0);
+    t1 = seg_sum_f<SEG>(t1);
+    t2 = seg_sum_f<SEG>(t2);
+    t3 = seg_sum_f<SEG>(t3);
+    if (lane == 0 && live) {
+        const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
+        const float gl = a0 * a1 * (s0 - s1);
+        glogitsT[(int64_t)(2 * c) * N + n] = (T)gl;
+        glogitsT[(int64_t)(2 * c + 1) * N + n] = (T)(-gl);
+        float* tp = tsum + plane * 4;
+        tp[0] = t0;
+        tp[1] = t1;
+        tp[2] = t2;
+        tp[3] = t3;
+    }
+}
+
+// all-lanes sum over a segment of SEG lanes (xor butterfly; SEG = 64: the whole wave)
+template <int SEG> __device__ __forceinline__ float seg_allsum_f(float v) {
+#pragma unroll
+    for (int o = SEG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T, int V, int SEG = 64>
+__global__ __launch_bounds__(256) void radix_mix_bwd_apply_bn_kernel(const T* __restrict__ g, const T* __restrict__ a,
+                                                                    const T* __restrict__ attn, const T* __restrict__ ggapT,
+                                                                    const float* __restrict__ tsum, T* __restrict__ ga,
+                                                                    T* __restrict__ gk, BnTail bn, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, int N, int C, int HW, int lay) {
+    const int lane = threadIdx.x & (SEG - 1);
+    int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
+    const bool live = plane < (int64_t)N * C;
+    if (SEG == 64 && !live) return;
+    if (!live) plane = (int64_t)N * C - 1;
+    const int n = (int)(plane / C), c = (int)(plane % C);
+    const float inv_hw = 1.f / (float)HW;
+    // the channel's BatchNorm sums over the batch: sum_n (a0*t0 + add*t1), sum_n (a0*t2 + add*t3); every plane of a channel forms the
+    // same two numbers in the same order
+    float sb = 0.f, sgm = 0.f;
+    for (int q = lane; q < N; q += SEG) {
+        const float* tp = tsum + ((int64_t)q * C + c) * 4;
+        const float qa0 = (float)attn[((int64_t)q * C + c) * 2], qadd = (float)ggapT[(int64_t)c * N + q] * inv_hw;
+        sb += qa0 * tp[0] + qadd * tp[1];
+        sgm += qa0 * tp[2] + qadd * tp[3];
+    }
+    sb = seg_allsum_f<SEG>(sb);
+    sgm = seg_allsum_f<SEG>(sgm);
+    if (n == 0 && lane == 0 && live) {
+        dbeta[c] = sb;
+        dgamma[c] = sgm;
+    }
+    const float inv_m = 1.f / ((float)N * (float)HW);
+    const float m = bn.mean[c], r = bn.rstd[c], gam = bn.gamma[c];
+    const float sc = gam * r, sh = bn.beta[c] - m * sc;
+    const float k1 = sb * inv_m, k2 = sgm * inv_m;
+    const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
+    const float add = (float)ggapT[(int64_t)c * N + n] * inv_hw;
+    const T* gp = g + tail_base(lay & 1, n, c, N, C, HW);
+    const T* ap = a + tail_base(lay & 2, n, c, N, C, HW);
+    T* gap_ = ga + tail_base(lay & 2, n, c, N, C, HW);
+    T* gkp = gk + tail_base(lay & 4, n, c, N, C, HW);
+    for (int i = lane * V; i < HW; i += SEG * V) {
+        const Vec<T, V> gv = ldv<T, V>(gp + i), av = ldv<T, V>(ap + i);
+        Vec<T, V> oa, ok;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gg = (float)gv.v[j], x = (float)av.v[j];
+            const float z = x * sc + sh, sg = 1.f / (1.f + __expf(-z));
+            const float sp = sg * (1.f + z * (1.f - sg));
+            const float xh = (x - m) * r;
+            const float gz = (gg * a0 + add) * sp;
+            oa.v[j] = (T)(sc * (gz - k1 - xh * k2));
+            ok.v[j] = (T)(gg * a1 + add);
+        }
+        if (live) {
+            stv<T, V>(gap_ + i, oa);
+            stv<T, V>(gkp + i, ok);
+        }
+    }
+}
+
 // ---- SE-style sigmoid gate of SplitAttnConv2d(radix = 1) (reference models/layers/split_attn.py:62-88 as
 // SE-CoTNetD uses it, models/cotnet_hybrid.py:143-146): out = x * sigmoid(logit[n][c]) with logit = fc2(relu(bn1(fc1(
 // mean_hw(x))))).  Three HBM-bound kernels around the tiny MLP, one wave per (image, channel) plane:
@@ -380,6 +605,46 @@ int radix_mix_bwd_apply(const void* g, const void* attn, const void* ggapT, void
     return check_launch("radix_mix_bwd_apply");
 }
 
+// ---- BatchNorm + SiLU folded into the tail (kernels above)
+template <typename T>
+int radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, float* mean, float* rstd,
+                   float* rmean, float* rvar, long long* nbt, const float* part, int split, float eps, float mom, int N, int C, int HW,
+                   int lay, hipStream_t s) {
+    const int64_t planes = (int64_t)N * C;
+    const BnTail bn{gamma, beta, mean, rstd};
+    TAIL_DISPATCH7(radix_gap_t_bn_kernel, (const T*)a, (const T*)k, (T*)gapT, bn, part, split, eps, mom, mean, rstd, rmean, rvar, nbt, N,
+                   C, HW, lay);
+    return check_launch("radix_gap_t_bn");
+}
+template <typename T>
+int radix_mix_logits_bn(const void* a, const void* k, const void* logitsT, void* out, void* attn, const float* gamma, const float* beta,
+                        const float* mean, const float* rstd, int N, int C, int HW, int lay, hipStream_t s) {
+    const int64_t planes = (int64_t)N * C;
+    const BnTail bn{gamma, beta, mean, rstd};
+    TAIL_DISPATCH7(radix_mix_logits_bn_kernel, (const T*)a, (const T*)k, (const T*)logitsT, (T*)out, (T*)attn, bn, N, C, HW, lay);
+    return check_launch("radix_mix_logits_bn");
+}
+template <typename T>
+int radix_mix_bwd_reduce_bn(const void* g, const void* a, const void* k, const void* attn, void* glogitsT, float* tsum,
+                            const float* gamma, const float* beta, const float* mean, const float* rstd, int N, int C, int HW, int lay,
+                            hipStream_t s) {
+    const int64_t planes = (int64_t)N * C;
+    const BnTail bn{gamma, beta, mean, rstd};
+    TAIL_DISPATCH7(radix_mix_bwd_reduce_bn_kernel, (const T*)g, (const T*)a, (const T*)k, (const T*)attn, (T*)glogitsT, tsum, bn, N, C,
+                   HW, lay);
+    return check_launch("radix_mix_bwd_reduce_bn");
+}
+template <typename T>
+int radix_mix_bwd_apply_bn(const void* g, const void* a, const void* attn, const void* ggapT, const float* tsum, void* ga, void* gk,
+                           const float* gamma, const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                           int N, int C, int HW, int lay, hipStream_t s) {
+    const int64_t planes = (int64_t)N * C;
+    const BnTail bn{gamma, beta, mean, rstd};
+    TAIL_DISPATCH7(radix_mix_bwd_apply_bn_kernel, (const T*)g, (const T*)a, (const T*)attn, (const T*)ggapT, tsum, (T*)ga, (T*)gk, bn,
+                   dgamma, dbeta, N, C, HW, lay);
+    return check_launch("radix_mix_bwd_apply_bn");
+}
+
 #define INST(T)                                                                                                    \
     template int radix_gap<T>(const void*, const void*, void*, int64_t, int, hipStream_t);                         \
     template int radix_mix<T>(const void*, const void*, const void*, void*, int64_t, int, hipStream_t);            \
@@ -394,7 +659,16 @@ int radix_mix_bwd_apply(const void* g, const void* attn, const void* ggapT, void
     template int radix_mix_bwd_reduce<T>(const void*, const void*, const void*, const void*, void*, int, int, int, \
                                          int, hipStream_t);                                                        \
     template int radix_mix_bwd_apply<T>(const void*, const void*, const void*, void*, void*, int, int, int, int,   \
-                                        hipStream_t);
+                                        hipStream_t);                                                              \
+    template int radix_gap_t_bn<T>(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*,    \
+                                   long long*, const float*, int, float, float, int, int, int, int, hipStream_t);  \
+    template int radix_mix_logits_bn<T>(const void*, const void*, const void*, void*, void*, const float*, const float*,           \
+                                        const float*, const float*, int, int, int, int, hipStream_t);              \
+    template int radix_mix_bwd_reduce_bn<T>(const void*, const void*, const void*, const void*, void*, float*, const float*,       \
+                                            const float*, const float*, const float*, int, int, int, int, hipStream_t); \
+    template int radix_mix_bwd_apply_bn<T>(const void*, const void*, const void*, const void*, const float*, void*, void*,         \
+                                           const float*, const float*, const float*, const float*, float*, float*, int, int, int,  \
+                                           int, hipStream_t);
 INST(float)
 INST(bf16_t)
 

@@ -1,0 +1,34 @@
+"""BatchNorm + SiLU of the aggregation's output folded into the radix tail (cot_bn_stats_partial + cot_radix_*_bn; reference
+models/cotnet.py:89-104) on the MI355X, through the C ABI: forward against the unfused kernels (bit for bit where those ran the
+streaming BatchNorm), both directions against torch autograd of the reference formula; CoTNet-50's four stage shapes at the recipe
+batch and small / ragged ones, NCHW and the deep stages' channel-major k / output."""
+import pytest
+import torch
+
+from cotnet_amd import _lib
+from tests.bn_tail_cases import bn_tail_case
+
+pytestmark = pytest.mark.gpu
+
+STEP = [(80, 64, 56, 56), (80, 128, 28, 28), (80, 256, 14, 14), (80, 512, 7, 7)]
+SMALL = [(3, 8, 8, 8), (5, 12, 7, 7), (2, 4, 3, 5), (9, 3, 7, 7), (4, 16, 14, 14), (2, 8, 24, 24), (33, 5, 7, 7)]
+
+
+def _lib_on_device():
+    L = _lib.lib()
+    L._test_device = "cuda"
+    return L
+
+
+@pytest.mark.parametrize("lay_k", [0, 1])
+@pytest.mark.parametrize("shape", STEP + SMALL)
+def test_bn_tail_bf16(shape, lay_k):
+    bn_tail_case(_lib_on_device(), *shape, torch.bfloat16, lay_k)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("lay_k", [0, 1])
+@pytest.mark.parametrize("shape", SMALL + [(8, 64, 56, 56)])
+def test_bn_tail_fp32(shape, lay_k):
+    bn_tail_case(_lib_on_device(), *shape, torch.float32, lay_k)
+    torch.cuda.synchronize()

@@ -12,6 +12,7 @@ import torch
 from cotnet_amd import _lib
 from oracle import cref, unfold_oracle
 from tests.emul import build_emul
+from tests.bn_tail_cases import bn_tail_case
 
 try:
     _EMUL = ctypes.CDLL(build_emul.build())
@@ -1641,6 +1642,18 @@ def test_radix_tail_channel_major_kernels(N, C, H, W, dtype, pack7, request):
     add = (ggapT.float().t() / HW)[:, :, None, None]
     assert torch.allclose(gy.float(), yf.grad + add, atol=3 * tol, rtol=3 * tol)
     assert torch.allclose(gk.float(), kf.grad + add, atol=3 * tol, rtol=3 * tol)
+
+
+@pytest.mark.parametrize("lay_k", [0, 1])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(3, 8, 8, 8), (4, 16, 14, 14), (5, 12, 7, 7), (2, 4, 3, 5), (3, 11, 7, 7), (9, 3, 7, 7), (2, 8, 24, 24)])
+def test_radix_tail_bn_fused_kernels(N, C, H, W, dtype, lay_k):
+    """BatchNorm + SiLU folded into the radix tail (cot_radix_*_bn): forward bit-identical to the unfused kernels, backward against autograd"""
+    _EMUL.cot_set_tuning(12, 1)  # the unfused composition on the folded streaming kernels (the library's default form)
+    same = bn_tail_case(_EMUL, N, C, H, W, dtype, lay_k)
+    # True: the bit-for-bit branch of the forward comparison ran (7 x 7 bf16 planes: the statistics pass reads 7 elements per lane where
+    # the unfused streaming kernel reads one -- another summation order)
+    assert same or (dtype == torch.bfloat16 and (H * W) % 7 == 0 and (H * W) % 2 == 1)
 
 
 @pytest.mark.parametrize("pack", [1, 0])
