@@ -139,8 +139,8 @@ SYMBOLS = {
     "cot_radix_mix_logits_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_reduce_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_apply_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
-    "cot_bn_stats_partial": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "cot_radix_gap_t_bn": (_I, [_P] * 11 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
+    "cot_bn_batch_stats": (_I, [_P] * 7 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _P]),
+    "cot_radix_gap_t_bn": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_logits_bn": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_reduce_bn": (_I, [_P] * 10 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_apply_bn": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P]),

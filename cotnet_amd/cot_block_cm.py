@@ -234,16 +234,15 @@ class _BottleneckCMNode(Function):
         _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
         s_y = stat(C, nws_c)
         if bn_tail:
-            _ck(L.cot_bn_stats_partial(_p(a), _p(s_y[2 * C:]), N, C, HW, BF16, st), "cot_bn_stats_partial")
+            clf._bn_batch_stats(L, a, bnl, s_y, N, C, HW)
         else:
             _bn_fwd(L, a, y, bnl, s_y, 2 * C, N, C, HW, 2)
         # radix-2 split attention: y NCHW, k channel-major, the mix written channel-major for conv3                (ref :92-104)
         row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
         gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
         if bn_tail:
-            _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]), _p(bnl.running_mean),
-                                     _p(bnl.running_var), _p(bnl.num_batches_tracked), _p(s_y[2 * C:]), N, C, HW, float(bnl.eps),
-                                     float(bnl.momentum), 2, BF16, st), "cot_radix_gap_t_bn")
+            _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]), N, C, HW, 2, BF16, st),
+                "cot_radix_gap_t_bn")
         else:
             _ck(L.cot_radix_gap_t_lay(_p(y), _p(k), _p(gapT), N, C, HW, 2, BF16, st), "cot_radix_gap_t_lay")
         _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st), "cot_conv1x1_forward")

@@ -219,6 +219,13 @@ def _gn_fused_ok(L, Ch, HW, W):
 # plane sums.  COT_BN_TAIL=0 = the separate cot_bn_act_* kernels as before.
 BN_TAIL = os.environ.get("COT_BN_TAIL", "1") != "0"
 
+
+def _bn_batch_stats(L, x, bn, stats, N, C, HW):
+    """mean = stats[:C], rstd = stats[C:2C] (+ running statistics) of x [N, C, HW] in one launch; stats[2C:] is the workspace"""
+    _ck(L.cot_bn_batch_stats(_p(x), _p(stats), _p(stats[C:]), _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked),
+                             _p(stats[2 * C:]), N, C, HW, float(bn.eps), float(bn.momentum), BF16, _stream()),
+        "cot_bn_batch_stats")
+
 _SIZES = _lib.register_cache({})  # (N, C, H, W, A) -> (workspace bytes, bn workspace floats for C, C/2 and the se branch's A channels)
 _MASKS = {}
 
@@ -638,7 +645,7 @@ def _cot_forward(L, layer, x):
     bnl = pl.bn
     if BN_TAIL:
         y = None
-        _ck(L.cot_bn_stats_partial(_p(a), _p(s_y[2 * C:]), N, C, HW, BF16, st), "cot_bn_stats_partial")
+        _bn_batch_stats(L, a, bnl, s_y, N, C, HW)
     else:
         _bn_fwd(L, a, y, bnl, s_y, 2 * C, N, C, HW, 2)
     # radix-2 split attention                                                                    (ref :92-104)
@@ -647,9 +654,8 @@ def _cot_forward(L, layer, x):
     row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
     gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
     if BN_TAIL:
-        _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]), _p(bnl.running_mean),
-                                 _p(bnl.running_var), _p(bnl.num_batches_tracked), _p(s_y[2 * C:]), N, C, HW, float(bnl.eps),
-                                 float(bnl.momentum), 0, BF16, st), "cot_radix_gap_t_bn")
+        _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]), N, C, HW, 0, BF16, st),
+            "cot_radix_gap_t_bn")
     else:
         _ck(L.cot_radix_gap_t(_p(y), _p(k), _p(gapT), N, C, HW, BF16, st), "cot_radix_gap_t")
     _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st),

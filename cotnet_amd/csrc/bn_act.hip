@@ -176,7 +176,7 @@ template <typename T, int V> __device__ __forceinline__ uint8_t sign_bits(const 
 
 template <int ACT> __device__ __forceinline__ float act_fwd(float z) {
     if (ACT == ACT_RELU || ACT == ACT_RELU_Y) return z > 0.f ? z : 0.f;
-    if (ACT == ACT_SILU) return z / (1.f + __expf(-z));
+    if (ACT == ACT_SILU) return silu_fwd(z);
     return z;
 }
 
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd(const T* __restrict__ x, con
 template <int ACT> __device__ __forceinline__ float act_bwd(float dy, float z_or_y) {
     if (ACT == ACT_RELU || ACT == ACT_RELU_Y) return z_or_y > 0.f ? dy : 0.f;
     if (ACT == ACT_SILU) {
-        const float sg = 1.f / (1.f + __expf(-z_or_y));
+        const float sg = COT_RCP(1.f + __expf(-z_or_y));
         return dy * sg * (1.f + z_or_y * (1.f - sg));
     }
     return dy;
@@ -1022,16 +1022,17 @@ int bn_act_backward(const void* dy, const void* x, const void* y, void* dx, void
 }
 
 
-// ---- the statistics pass alone (round 6): chunk statistics [C][split][4] = (count, mean, M2, 0) of every channel into `ws`
-// (bn_workspace_floats(N, C) floats; split = bn_stats_split(N, C)).  For consumers that normalise while they load -- the radix tail's
-// cot_radix_*_bn kernels (radix_tail.hip) -- instead of reading a normalised tensor somebody wrote for them.
-int bn_stats_split(int N, int C) {
-    int split, nper;
-    pick_split(N, C, &split, &nper);
-    return split;
-}
+// ---- the statistics of a BatchNorm alone (round 6): mean / rstd / running statistics of x [N, C, HW] -- bn_stats_partial, then
+// bn_stats_finalize (the same chunk statistics and the same merge as the folded apply kernel's prologue: bit-identical mean / rstd).
+// For consumers that normalise while they load -- the radix tail's cot_radix_*_bn kernels (radix_tail.hip) -- instead of reading a
+// normalised tensor somebody wrote for them.  ws: bn_workspace_floats(N, C) floats.
+// (Tried and dropped: ONE launch, the channel's last chunk to finish -- an atomic ticket per channel -- doing the merge.  The
+// __threadfence() pair around the ticket is a device-scope release / acquire, which on this eight-XCD part writes back and invalidates
+// the workgroup's L2: 33.7 us against 8.0 us for the plain pass at 64 ch x 56 x 56, B = 80 -- profiles/r06_bn_tail_kernels.log.  A
+// dependent 256-thread launch costs ~3 us.)
 template <typename T>
-int bn_stats_only(const void* x, float* ws, int N, int C, int HW, hipStream_t s) {
+int bn_batch_stats(const void* x, float* mean, float* rstd, float* rmean, float* rvar, long long* nbt, float* ws, int N, int C, int HW,
+                   float eps, float mom, hipStream_t s) {
     int split, nper;
     pick_split(N, C, &split, &nper);
     int v = pick_vec(sizeof(T), HW);
@@ -1044,10 +1045,11 @@ int bn_stats_only(const void* x, float* ws, int N, int C, int HW, hipStream_t s)
     else if (v == 2) BN_SO(2);
     else BN_SO(1);
 #undef BN_SO
-    return check_launch("bn_stats_partial");
+    COT_LAUNCH(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, C, split, eps, mom, mean, rstd, rmean, rvar, nbt);
+    return check_launch("bn_batch_stats");
 }
-template int bn_stats_only<float>(const void*, float*, int, int, int, hipStream_t);
-template int bn_stats_only<bf16_t>(const void*, float*, int, int, int, hipStream_t);
+template int bn_batch_stats<float>(const void*, float*, float*, float*, float*, long long*, float*, int, int, int, float, float, hipStream_t);
+template int bn_batch_stats<bf16_t>(const void*, float*, float*, float*, float*, long long*, float*, int, int, int, float, float, hipStream_t);
 
 // ---- statistics from the PRODUCER's epilogue (round 5): the 1x1 convolution that writes a BatchNorm's
 // input also writes, per (image, 128-pixel tile, channel), the sum and the sum of squares of the bf16 values it stores

@@ -44,6 +44,14 @@ template <typename T, int V> __device__ __forceinline__ void stv(T* p, const Vec
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #endif
 
+// 1 / x by v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division sequence: the sigmoid inside SiLU and its derivative sit in
+// HBM-bound element loops that the division made VALU-bound (radix_gap_t_bn 56 x 56: 24 us for a 12 us read, profiles/r06_bn_tail_kernels.log).
+// ONE definition for every kernel that forms silu(z), so that a tensor activated by one kernel and re-formed by another agrees bit for bit.
+#ifndef COT_RCP  // (tests/emul pre-defines it for its host build)
+#define COT_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
+__device__ __forceinline__ float silu_fwd(float z) { return z * COT_RCP(1.f + __expf(-z)); }
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

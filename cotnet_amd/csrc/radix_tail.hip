@@ -104,6 +104,10 @@ __device__ __forceinline__ int64_t tail_base(int cm, int n, int c, int N, int C,
 // SEG < 64 (round 5): SEG lanes per plane, 64 / SEG planes per wave -- 7 x 7 planes as 7 lanes x 7 elements (V = 7, SEG = 8) instead of
 // 49 lanes x one 2-byte element and a wave per plane (40960 waves for 80 x 512 planes).  Sums: xor butterfly over the segment (every lane
 // ends with the total).  No early return in the kernels that shuffle: lanes of planes past the end follow along and store nothing.
+// y*a0 + k*a1 with the contraction spelled out (one rounding of k*a1, one of the sum): the radix mix and its BatchNorm-folded twin
+// must agree bit for bit, and left to the compiler the two kernels contracted differently (263 of 16 M outputs one bf16 ulp apart)
+__device__ __forceinline__ float mix2(float y, float a0, float k, float a1) { return __builtin_fmaf(y, a0, k * a1); }
+
 template <int SEG> __device__ __forceinline__ float seg_sum_f(float v) {
     if (SEG == 64) return wave_sum_f(v);
 #pragma unroll
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void radix_mix_logits_kernel(const T* __restri
         const Vec<T, V> a = ldv<T, V>(yp + i), b = ldv<T, V>(kp + i);
         Vec<T, V> o;
 #pragma unroll
-        for (int j = 0; j < V; ++j) o.v[j] = (T)((float)a.v[j] * a0 + (float)b.v[j] * a1);
+        for (int j = 0; j < V; ++j) o.v[j] = (T)mix2((float)a.v[j], a0, (float)b.v[j], a1);
         stv<T, V>(op + i, o);
     }
 }
@@ -236,9 +240,7 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_apply_kernel(const T* __res
 // reads g and a anyway -- emits them; the apply kernel's prologue combines them over the batch (fixed order: deterministic) and writes
 // the gradient w.r.t. a directly.  4 launches and 11 tensor passes (mix apply, BatchNorm reduce, BatchNorm apply, + the reduce) become 2
 // launches and 7 passes.
-//   radix_gap_t_bn        gapT[c][n] = mean_hw(silu(bn(a)) + k); with `part` given its prologue also FINALIZES the statistics (merges the
-//                         [C][split][4] chunk statistics of bn_stats_partial exactly as bn_apply_fwd_fold does; plane n = 0 of a channel
-//                         writes mean / rstd / running statistics)
+//   radix_gap_t_bn        gapT[c][n] = mean_hw(silu(bn(a)) + k)   (mean / rstd: bn_batch_stats, bn_act.hip)
 //   radix_mix_logits_bn   out = silu(bn(a))*a0 + k*a1
 //   radix_mix_bwd_reduce_bn  glogitsT as radix_mix_bwd_reduce + tsum[n][c][0..3]
 //   radix_mix_bwd_apply_bn   ga = gamma*rstd*(g_z - dbeta/M - xhat*dgamma/M), gk = g*a1 + add; dgamma / dbeta written by plane n = 0
@@ -250,57 +252,59 @@ struct BnTail {
     const float* rstd;
 };
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+// all-lanes sum over a segment of SEG lanes (xor butterfly; SEG = 64: the whole wave)
+template <int SEG> __device__ __forceinline__ float seg_allsum_f(float v) {
+#pragma unroll
+    for (int o = SEG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Loads run two vectors ahead of the arithmetic (exp + rcp per element: ~80 instructions per 8 elements -- with one vector in flight per
+// lane and tensor the kernels added their VALU time to their memory time: gap_t_bn 24.4 us against gap_t's 11.2 at 56 x 56,
+// profiles/r06_bn_tail_kernels.log), and the first two are issued before the per-plane scalars are fetched.
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> ldv_if(const T* p, bool ok) {
+    Vec<T, V> v;
+    if (ok) v = ldv<T, V>(p);
+    else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v.v[j] = (T)0.f;
+    }
+    return v;
+}
+template <typename T, int V, int STEP> struct Ahead2 {  // vectors i, i + STEP, i + 2 STEP of one plane tensor
+    const T* p;
+    int HW;
+    Vec<T, V> v0, v1;
+    __device__ __forceinline__ Ahead2(const T* p_, int i, int HW_) : p(p_), HW(HW_) {
+        v0 = ldv_if<T, V>(p + i, i < HW);
+        v1 = ldv_if<T, V>(p + i + STEP, i + STEP < HW);
+    }
+    __device__ __forceinline__ Vec<T, V> next(int i) {  // -> vector i; vector i + 2 STEP goes in flight
+        const Vec<T, V> cur = v0;
+        v0 = v1;
+        v1 = ldv_if<T, V>(p + i + 2 * STEP, i + 2 * STEP < HW);
+        return cur;
+    }
+};
 
 template <typename T, int V, int SEG = 64>
 __global__ __launch_bounds__(256) void radix_gap_t_bn_kernel(const T* __restrict__ a, const T* __restrict__ k, T* __restrict__ gapT,
-                                                            BnTail bn, const float* __restrict__ part, int split, float eps,
-                                                            float momentum, float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                            long long* __restrict__ nbt, int N, int C, int HW, int lay) {
+                                                            BnTail bn, int N, int C, int HW, int lay) {
+    constexpr int STEP = SEG * V;
     const int lane = threadIdx.x & (SEG - 1);
     int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
     const bool live = plane < (int64_t)N * C;
     if (SEG == 64 && !live) return;
     if (!live) plane = (int64_t)N * C - 1;
     const int n = (int)(plane / C), c = (int)(plane % C);
-    float m, r;
-    if (part) {  // Chan merge of the channel's chunk statistics, in bn_apply_fwd_fold's order
-        float cnt = 0.f, M2 = 0.f;
-        m = 0.f;
-        for (int q = 0; q < split; ++q) {
-            const float* p = part + ((int64_t)c * split + q) * 4;
-            const float nb = p[0];
-            if (nb <= 0.f) continue;
-            const float delta = p[1] - m, nn = cnt + nb;
-            m += delta * nb / nn;
-            M2 += p[2] + delta * delta * cnt * nb / nn;
-            cnt = nn;
-        }
-        const float var = cnt > 0 ? M2 / cnt : 0.f;
-        r = 1.0f / sqrtf(var + eps);
-        if (n == 0 && lane == 0 && live) {
-            mean_out[c] = m;
-            rstd_out[c] = r;
-            if (running_mean) {
-                const float unbiased = cnt > 1 ? M2 / (cnt - 1.f) : var;
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-            }
-            if (c == 0 && nbt) *nbt += 1;
-        }
-    } else {
-        m = bn.mean[c];
-        r = bn.rstd[c];
-    }
-    const float sc = bn.gamma[c] * r, sh = bn.beta[c] - m * sc;
-    const T* ap = a + tail_base(lay & 1, n, c, N, C, HW);
-    const T* kp = k + tail_base(lay & 2, n, c, N, C, HW);
+    const int i0 = lane * V;
+    Ahead2<T, V, STEP> av(a + tail_base(lay & 1, n, c, N, C, HW), i0, HW), kv(k + tail_base(lay & 2, n, c, N, C, HW), i0, HW);
+    const float sc = bn.gamma[c] * bn.rstd[c], sh = bn.beta[c] - bn.mean[c] * sc;
     float acc = 0.f;
-    for (int i = lane * V; i < HW; i += SEG * V) {
-        const Vec<T, V> av = ldv<T, V>(ap + i), b = ldv<T, V>(kp + i);
+    for (int i = i0; i < HW; i += STEP) {
+        const Vec<T, V> x = av.next(i), b = kv.next(i);
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc += (float)(T)silu_f((float)av.v[j] * sc + sh) + (float)b.v[j];
+        for (int j = 0; j < V; ++j) acc += (float)(T)silu_fwd((float)x.v[j] * sc + sh) + (float)b.v[j];
     }
     acc = seg_sum_f<SEG>(acc);
     if (lane == 0 && live) gapT[(int64_t)c * N + n] = (T)(acc / (float)HW);
@@ -310,10 +314,13 @@ template <typename T, int V, int SEG = 64>
 __global__ __launch_bounds__(256) void radix_mix_logits_bn_kernel(const T* __restrict__ a, const T* __restrict__ k,
                                                                  const T* __restrict__ logitsT, T* __restrict__ out,
                                                                  T* __restrict__ attn, BnTail bn, int N, int C, int HW, int lay) {
+    constexpr int STEP = SEG * V;
     const int lane = threadIdx.x & (SEG - 1);
     const int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
     if (plane >= (int64_t)N * C) return;  // (no shuffles below)
     const int n = (int)(plane / C), c = (int)(plane % C);
+    const int i0 = lane * V;
+    Ahead2<T, V, STEP> av(a + tail_base(lay & 1, n, c, N, C, HW), i0, HW), kv(k + tail_base(lay & 2, n, c, N, C, HW), i0, HW);
     const float l0 = (float)logitsT[(int64_t)(2 * c) * N + n], l1 = (float)logitsT[(int64_t)(2 * c + 1) * N + n];
     const float a0 = 1.f / (1.f + __expf(l1 - l0)), a1 = 1.f - a0;
     if (lane == 0) {
@@ -321,49 +328,52 @@ __global__ __launch_bounds__(256) void radix_mix_logits_bn_kernel(const T* __res
         attn[plane * 2 + 1] = (T)a1;
     }
     const float sc = bn.gamma[c] * bn.rstd[c], sh = bn.beta[c] - bn.mean[c] * sc;
-    const T* ap = a + tail_base(lay & 1, n, c, N, C, HW);
-    const T* kp = k + tail_base(lay & 2, n, c, N, C, HW);
     T* op = out + tail_base(lay & 4, n, c, N, C, HW);
-    for (int i = lane * V; i < HW; i += SEG * V) {
-        const Vec<T, V> av = ldv<T, V>(ap + i), b = ldv<T, V>(kp + i);
+    for (int i = i0; i < HW; i += STEP) {
+        const Vec<T, V> x = av.next(i), b = kv.next(i);
         Vec<T, V> o;
 #pragma unroll
-        for (int j = 0; j < V; ++j) o.v[j] = (T)((float)(T)silu_f((float)av.v[j] * sc + sh) * a0 + (float)b.v[j] * a1);
+        for (int j = 0; j < V; ++j) o.v[j] = (T)mix2((float)(T)silu_fwd((float)x.v[j] * sc + sh), a0, (float)b.v[j], a1);
         stv<T, V>(op + i, o);
     }
 }
 
+// tsum: [C][N][4] = (a0*t0, t1, a0*t2, t3) -- a channel's N records are one contiguous run (the apply kernel's prologue reads all of
+// them in every plane of the channel: stored [N][C] and with a0 fetched from attn that was 128 scattered sectors per wave, 105 MB of L2
+// traffic at 14 x 14 against 32 MB of tensors)
 template <typename T, int V, int SEG = 64>
 __global__ __launch_bounds__(256) void radix_mix_bwd_reduce_bn_kernel(const T* __restrict__ g, const T* __restrict__ a,
                                                                      const T* __restrict__ k, const T* __restrict__ attn,
                                                                      T* __restrict__ glogitsT, float* __restrict__ tsum, BnTail bn,
                                                                      int N, int C, int HW, int lay) {
+    constexpr int STEP = SEG * V;
     const int lane = threadIdx.x & (SEG - 1);
     int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
     const bool live = plane < (int64_t)N * C;
     if (SEG == 64 && !live) return;
     if (!live) plane = (int64_t)N * C - 1;
     const int n = (int)(plane / C), c = (int)(plane % C);
+    const int i0 = lane * V;
+    Ahead2<T, V, STEP> gv(g + tail_base(lay & 1, n, c, N, C, HW), i0, HW), av(a + tail_base(lay & 2, n, c, N, C, HW), i0, HW),
+        kv(k + tail_base(lay & 4, n, c, N, C, HW), i0, HW);
     const float m = bn.mean[c], r = bn.rstd[c];
     const float sc = bn.gamma[c] * r, sh = bn.beta[c] - m * sc;
-    const T* gp = g + tail_base(lay & 1, n, c, N, C, HW);
-    const T* ap = a + tail_base(lay & 2, n, c, N, C, HW);
-    const T* kp = k + tail_base(lay & 4, n, c, N, C, HW);
     float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    for (int i = lane * V; i < HW; i += SEG * V) {
-        const Vec<T, V> gv = ldv<T, V>(gp + i), av = ldv<T, V>(ap + i), b = ldv<T, V>(kp + i);
+    for (int i = i0; i < HW; i += STEP) {
+        const Vec<T, V> gq = gv.next(i), xq = av.next(i), b = kv.next(i);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const float gg = (float)gv.v[j], x = (float)av.v[j];
-            const float z = x * sc + sh, den = 1.f + __expf(-z), sg = 1.f / den;
-            const float y = (float)(T)(z / den);       // the forward's y, as it was formed and rounded there (silu_f)
+            const float gg = (float)gq.v[j], x = (float)xq.v[j];
+            const float z = x * sc + sh, sg = COT_RCP(1.f + __expf(-z));
+            const float y = (float)(T)(z * sg);            // the forward's y, as it was formed and rounded there (silu_fwd)
             const float sp = sg * (1.f + z * (1.f - sg));  // silu'(z)
             const float xh = (x - m) * r;
+            const float gs = gg * sp;
             s0 += gg * y;
             s1 += gg * (float)b.v[j];
-            t0 += gg * sp;
+            t0 += gs;
             t1 += sp;
-            t2 += gg * sp * xh;
+            t2 += gs * xh;
             t3 += sp * xh;
         }
     }
@@ -378,19 +388,13 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_reduce_bn_kernel(const T* _
         const float gl = a0 * a1 * (s0 - s1);
         glogitsT[(int64_t)(2 * c) * N + n] = (T)gl;
         glogitsT[(int64_t)(2 * c + 1) * N + n] = (T)(-gl);
-        float* tp = tsum + plane * 4;
-        tp[0] = t0;
-        tp[1] = t1;
-        tp[2] = t2;
-        tp[3] = t3;
+        Vec<float, 4> tv;
+        tv.v[0] = a0 * t0;
+        tv.v[1] = t1;
+        tv.v[2] = a0 * t2;
+        tv.v[3] = t3;
+        stv<float, 4>(tsum + ((int64_t)c * N + n) * 4, tv);
     }
-}
-
-// all-lanes sum over a segment of SEG lanes (xor butterfly; SEG = 64: the whole wave)
-template <int SEG> __device__ __forceinline__ float seg_allsum_f(float v) {
-#pragma unroll
-    for (int o = SEG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
 }
 
 template <typename T, int V, int SEG = 64>
@@ -399,21 +403,26 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_apply_bn_kernel(const T* __
                                                                     const float* __restrict__ tsum, T* __restrict__ ga,
                                                                     T* __restrict__ gk, BnTail bn, float* __restrict__ dgamma,
                                                                     float* __restrict__ dbeta, int N, int C, int HW, int lay) {
+    constexpr int STEP = SEG * V;
     const int lane = threadIdx.x & (SEG - 1);
     int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
     const bool live = plane < (int64_t)N * C;
     if (SEG == 64 && !live) return;
     if (!live) plane = (int64_t)N * C - 1;
     const int n = (int)(plane / C), c = (int)(plane % C);
-    const float inv_hw = 1.f / (float)HW;
+    const int i0 = lane * V;
+    Ahead2<T, V, STEP> gv(g + tail_base(lay & 1, n, c, N, C, HW), i0, HW), av(a + tail_base(lay & 2, n, c, N, C, HW), i0, HW);
+    T* gap_ = ga + tail_base(lay & 2, n, c, N, C, HW);
+    T* gkp = gk + tail_base(lay & 4, n, c, N, C, HW);
+    const float inv_hw = COT_RCP((float)HW);  // (1 ulp: the pooled descriptor's gradient per pixel)
     // the channel's BatchNorm sums over the batch: sum_n (a0*t0 + add*t1), sum_n (a0*t2 + add*t3); every plane of a channel forms the
     // same two numbers in the same order
     float sb = 0.f, sgm = 0.f;
     for (int q = lane; q < N; q += SEG) {
-        const float* tp = tsum + ((int64_t)q * C + c) * 4;
-        const float qa0 = (float)attn[((int64_t)q * C + c) * 2], qadd = (float)ggapT[(int64_t)c * N + q] * inv_hw;
-        sb += qa0 * tp[0] + qadd * tp[1];
-        sgm += qa0 * tp[2] + qadd * tp[3];
+        const Vec<float, 4> t = ldv<float, 4>(tsum + ((int64_t)c * N + q) * 4);
+        const float qadd = (float)ggapT[(int64_t)c * N + q] * inv_hw;
+        sb += t.v[0] + qadd * t.v[1];
+        sgm += t.v[2] + qadd * t.v[3];
     }
     sb = seg_allsum_f<SEG>(sb);
     sgm = seg_allsum_f<SEG>(sgm);
@@ -421,23 +430,19 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_apply_bn_kernel(const T* __
         dbeta[c] = sb;
         dgamma[c] = sgm;
     }
-    const float inv_m = 1.f / ((float)N * (float)HW);
+    const float inv_m = COT_RCP((float)N * (float)HW);
     const float m = bn.mean[c], r = bn.rstd[c], gam = bn.gamma[c];
     const float sc = gam * r, sh = bn.beta[c] - m * sc;
     const float k1 = sb * inv_m, k2 = sgm * inv_m;
     const float a0 = (float)attn[plane * 2], a1 = (float)attn[plane * 2 + 1];
     const float add = (float)ggapT[(int64_t)c * N + n] * inv_hw;
-    const T* gp = g + tail_base(lay & 1, n, c, N, C, HW);
-    const T* ap = a + tail_base(lay & 2, n, c, N, C, HW);
-    T* gap_ = ga + tail_base(lay & 2, n, c, N, C, HW);
-    T* gkp = gk + tail_base(lay & 4, n, c, N, C, HW);
-    for (int i = lane * V; i < HW; i += SEG * V) {
-        const Vec<T, V> gv = ldv<T, V>(gp + i), av = ldv<T, V>(ap + i);
+    for (int i = i0; i < HW; i += STEP) {
+        const Vec<T, V> gq = gv.next(i), xq = av.next(i);
         Vec<T, V> oa, ok;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const float gg = (float)gv.v[j], x = (float)av.v[j];
-            const float z = x * sc + sh, sg = 1.f / (1.f + __expf(-z));
+            const float gg = (float)gq.v[j], x = (float)xq.v[j];
+            const float z = x * sc + sh, sg = COT_RCP(1.f + __expf(-z));
             const float sp = sg * (1.f + z * (1.f - sg));
             const float xh = (x - m) * r;
             const float gz = (gg * a0 + add) * sp;
@@ -607,13 +612,11 @@ int radix_mix_bwd_apply(const void* g, const void* attn, const void* ggapT, void
 
 // ---- BatchNorm + SiLU folded into the tail (kernels above)
 template <typename T>
-int radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, float* mean, float* rstd,
-                   float* rmean, float* rvar, long long* nbt, const float* part, int split, float eps, float mom, int N, int C, int HW,
-                   int lay, hipStream_t s) {
+int radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                   int N, int C, int HW, int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
     const BnTail bn{gamma, beta, mean, rstd};
-    TAIL_DISPATCH7(radix_gap_t_bn_kernel, (const T*)a, (const T*)k, (T*)gapT, bn, part, split, eps, mom, mean, rstd, rmean, rvar, nbt, N,
-                   C, HW, lay);
+    TAIL_DISPATCH7(radix_gap_t_bn_kernel, (const T*)a, (const T*)k, (T*)gapT, bn, N, C, HW, lay);
     return check_launch("radix_gap_t_bn");
 }
 template <typename T>
@@ -660,8 +663,8 @@ int radix_mix_bwd_apply_bn(const void* g, const void* a, const void* attn, const
                                          int, hipStream_t);                                                        \
     template int radix_mix_bwd_apply<T>(const void*, const void*, const void*, void*, void*, int, int, int, int,   \
                                         hipStream_t);                                                              \
-    template int radix_gap_t_bn<T>(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*,    \
-                                   long long*, const float*, int, float, float, int, int, int, int, hipStream_t);  \
+    template int radix_gap_t_bn<T>(const void*, const void*, void*, const float*, const float*, const float*, const float*, int,   \
+                                   int, int, int, hipStream_t);                                                    \
     template int radix_mix_logits_bn<T>(const void*, const void*, const void*, void*, void*, const float*, const float*,           \
                                         const float*, const float*, int, int, int, int, hipStream_t);              \
     template int radix_mix_bwd_reduce_bn<T>(const void*, const void*, const void*, const void*, void*, float*, const float*,       \

@@ -527,21 +527,21 @@ int cot_radix_mix_backward_apply_lay(const void* gout, const void* attn, const v
  * pooled descriptor and the radix mix; both take `a` and the BatchNorm's statistics and form y as they load (rounded to the storage
  * type, bit-identical to cot_bn_act_forward's output), so y is never written.  `lay` as for the cot_radix_*_lay calls (a in y's place;
  * backward_apply_bn: 1 gout, 2 a and ga, 4 gk).  COT_F32 / COT_BF16.
- *   cot_bn_stats_partial             chunk statistics of x [N, C, HW] into `workspace` (cot_bn_act_workspace(N, C) floats): the
- *                                    statistics pass of cot_bn_act_forward alone
- *   cot_radix_gap_t_bn               gapT[c][n] = mean_hw(silu(bn(a)) + k).  workspace != NULL: the kernel's prologue finalizes the
- *                                    statistics (save_mean / save_rstd / running statistics / num_batches_tracked are WRITTEN, as by
- *                                    cot_bn_act_forward); NULL: save_mean / save_rstd are read
+ *   cot_bn_batch_stats               the statistics of cot_bn_act_forward alone: save_mean / save_rstd [C], running statistics and
+ *                                    num_batches_tracked updated as there (bit-identical to its streaming kernels' values).
+ *                                    workspace: cot_bn_act_workspace(N, C) floats
+ *   cot_radix_gap_t_bn               gapT[c][n] = mean_hw(silu(bn(a)) + k)
  *   cot_radix_mix_logits_bn          cot_radix_mix_logits on silu(bn(a))
- *   cot_radix_mix_backward_reduce_bn cot_radix_mix_backward_reduce + tsum[n][c][0..3] (fp32, N*C*4 floats) = sum_hw of g*s', s',
- *                                    g*s'*xhat, s'*xhat with s' = silu'(z), xhat = (a - mean)*rstd: the four plane sums the BatchNorm's
- *                                    backward needs and that do not depend on the pooled descriptor's gradient
+ *   cot_radix_mix_backward_reduce_bn cot_radix_mix_backward_reduce + tsum[c][n][0..3] (fp32, N*C*4 floats, 16-byte aligned) = a0 * sum_hw
+ *                                    g*s', sum_hw s', a0 * sum_hw g*s'*xhat, sum_hw s'*xhat with s' = silu'(z), xhat = (a - mean)*rstd: the
+ *                                    plane sums the BatchNorm's backward needs and that do not depend on the pooled descriptor's gradient
  *   cot_radix_mix_backward_apply_bn  ga = d loss / d a (through the mix, the pooling, SiLU and the BatchNorm), gk = g*a1 + ggapT/HW;
  *                                    dgamma / dbeta [C] fp32 written (sums over the batch in a fixed order: deterministic) */
-int cot_bn_stats_partial(const void* x, float* workspace, int N, int C, int HW, int dtype, void* stream);
-int cot_radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, float* save_mean,
-                       float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* workspace,
-                       int N, int C, int HW, float eps, float momentum, int lay, int dtype, void* stream);
+int cot_bn_batch_stats(const void* x, float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, float* workspace, int N, int C, int HW, float eps, float momentum, int dtype,
+                       void* stream);
+int cot_radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, const float* save_mean,
+                       const float* save_rstd, int N, int C, int HW, int lay, int dtype, void* stream);
 int cot_radix_mix_logits_bn(const void* a, const void* k, const void* logitsT, void* out, void* attn, const float* gamma,
                             const float* beta, const float* save_mean, const float* save_rstd, int N, int C, int HW, int lay, int dtype,
                             void* stream);

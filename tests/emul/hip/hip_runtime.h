@@ -361,6 +361,7 @@ inline void __builtin_amdgcn_s_waitcnt(int) {}
 #define COT_WAIT_LOADS() ((void)0)
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only ever applied to wave-uniform values
 inline float __expf(float x) { return std::exp(x); }
+#define COT_RCP(x) (1.0f / (x))
 using std::min;
 using std::max;
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }

@@ -1,4 +1,4 @@
-"""BatchNorm + SiLU of the aggregation's output folded into the radix tail (cot_bn_stats_partial + cot_radix_*_bn; reference
+"""BatchNorm + SiLU of the aggregation's output folded into the radix tail (cot_bn_batch_stats + cot_radix_*_bn; reference
 models/cotnet.py:89-104) on the MI355X, through the C ABI: forward against the unfused kernels (bit for bit where those ran the
 streaming BatchNorm), both directions against torch autograd of the reference formula; CoTNet-50's four stage shapes at the recipe
 batch and small / ragged ones, NCHW and the deep stages' channel-major k / output."""
