@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("COT_LIB_PATH") or os.path.join(_HERE, "lib", "libcotn
 
 COT_F32, COT_F64, COT_BF16, COT_F16 = 0, 1, 2, 3
 COT_NCHW, COT_NHWC = 0, 1
+COT_ERR_UNSUPPORTED = -2  # (cot_status, include/cotnet_amd.h)
 
 _lib = None
 _SHAPE_CACHES = []  # dicts of shape -> workspace size held by the Python wrappers (see register_cache)
@@ -139,6 +140,9 @@ SYMBOLS = {
     "cot_radix_mix_logits_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_reduce_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_apply_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
+    "cot_agg_rowstats_floats": (ctypes.c_int64, [_I, _I, _I]),
+    "cot_agg_forward_rowstats": (_I, [_P] * 8 + [_I, _G, _I, _P]),
+    "cot_bn_rowstats_finalize": (_I, [_P] * 6 + [_I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
     "cot_bn_batch_stats": (_I, [_P] * 7 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _P]),
     "cot_radix_gap_t_bn": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_logits_bn": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P]),

@@ -231,11 +231,11 @@ class _BottleneckCMNode(Function):
         bn_tail = clf.BN_TAIL  # BatchNorm + SiLU folded into the radix tail (cot_radix_*_bn): y = silu(bn(a)) is never written
         a, y = nchw(C), (None if bn_tail else nchw(C))
         bnl = pl.bn
-        _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
         s_y = stat(C, nws_c)
-        if bn_tail:
-            clf._bn_batch_stats(L, a, bnl, s_y, N, C, HW)
+        if bn_tail:  # (aggregation + the statistics of bn out of its epilogue; bn + swish themselves happen inside the tail's kernels)
+            clf._agg_fwd_stats(L, v, w, a, None, None, None, geom, bnl, s_y, N, C, H, W)
         else:
+            _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
             _bn_fwd(L, a, y, bnl, s_y, 2 * C, N, C, HW, 2)
         # radix-2 split attention: y NCHW, k channel-major, the mix written channel-major for conv3                (ref :92-104)
         row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731

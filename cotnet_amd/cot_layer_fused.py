@@ -220,6 +220,39 @@ def _gn_fused_ok(L, Ch, HW, W):
 BN_TAIL = os.environ.get("COT_BN_TAIL", "1") != "0"
 
 
+# ... and its statistics out of the aggregation's own epilogue (cot_agg_forward_rowstats + cot_bn_rowstats_finalize) where the LDS
+# forward kernel serves the geometry: no statistics pass over `a` at all.  COT_AGG_ROWSTATS=0 = cot_bn_batch_stats (a read of a).
+AGG_ROWSTATS = os.environ.get("COT_AGG_ROWSTATS", "1") != "0"
+_ROWSTATS_OK = _lib.register_cache({})
+
+
+def _agg_fwd_stats(L, v, w_or_logits, a, gn, gn_mean, gn_rstd, geom, bn, stats, N, C, H, W):
+    """a = aggregation(v, w) and bn's batch statistics of a into stats[:C] / stats[C:2C] (+ running statistics).  gn given: w_or_logits
+    holds the raw logits and the GroupNorm is applied in the aggregation's prologue (cot_agg_gn9_forward's contract)."""
+    st = _stream()
+    key = (geom.N, geom.C, H, W, geom.wC, gn is not None)
+    if AGG_ROWSTATS and _ROWSTATS_OK.get(key, True):
+        rows = torch.empty(int(L.cot_agg_rowstats_floats(N, C, H)), dtype=torch.float32, device=a.device)
+        rc = L.cot_agg_forward_rowstats(_p(v), _p(w_or_logits), _p(a), _p(rows), _p(gn_mean) if gn is not None else None,
+                                        _p(gn_rstd) if gn is not None else None, _p(gn.weight) if gn is not None else None,
+                                        _p(gn.bias) if gn is not None else None, gn.num_groups if gn is not None else 0,
+                                        ctypes.byref(geom), BF16, st)
+        if rc == 0:
+            _ck(L.cot_bn_rowstats_finalize(_p(rows), _p(stats), _p(stats[C:]), _p(bn.running_mean), _p(bn.running_var),
+                                           _p(bn.num_batches_tracked), N, C, H, W, float(bn.eps), float(bn.momentum), st),
+                "cot_bn_rowstats_finalize")
+            return
+        if rc != _lib.COT_ERR_UNSUPPORTED:
+            _ck(rc, "cot_agg_forward_rowstats")
+        _ROWSTATS_OK[key] = False  # (geometry off the LDS forward kernel: the plain forward + a statistics pass, from now on without asking)
+    if gn is not None:
+        _ck(L.cot_agg_gn9_forward(_p(v), _p(w_or_logits), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(gn.bias), gn.num_groups, _p(a),
+                                  ctypes.byref(geom), BF16, st), "cot_agg_gn9_forward")
+    else:
+        _ck(L.cot_agg_forward(_p(v), _p(w_or_logits), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
+    _bn_batch_stats(L, a, bn, stats, N, C, H * W)
+
+
 def _bn_batch_stats(L, x, bn, stats, N, C, HW):
     """mean = stats[:C], rstd = stats[C:2C] (+ running statistics) of x [N, C, HW] in one launch; stats[2C:] is the workspace"""
     _ck(L.cot_bn_batch_stats(_p(x), _p(stats), _p(stats[C:]), _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked),
@@ -636,17 +669,16 @@ def _cot_forward(L, layer, x):
     geom = _lib.AggGeom(2 * N, C // 2, H, W, 1, C // 16, 3, 3, 1, 1, 1, 1, 1, 1) if GX else \
         _lib.AggGeom(N, C, H, W, 1, C // 8, 3, 3, 1, 1, 1, 1, 1, 1)
     a, y = new(C), (None if BN_TAIL else new(C))
-    if fused_gn:
-        _ck(L.cot_agg_gn9_forward(_p(v), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(gn.bias), gn.num_groups, _p(a),
-                                  ctypes.byref(geom), BF16, st), "cot_agg_gn9_forward")
-    else:
-        _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
     s_y = stat(C, nws_c)
     bnl = pl.bn
-    if BN_TAIL:
-        y = None
-        _bn_batch_stats(L, a, bnl, s_y, N, C, HW)
+    if BN_TAIL:  # (aggregation + the statistics of bn; bn + swish themselves happen inside the tail's kernels)
+        _agg_fwd_stats(L, v, e3 if fused_gn else w, a, gn if fused_gn else None, gn_mean, gn_rstd, geom, bnl, s_y, N, C, H, W)
     else:
+        if fused_gn:
+            _ck(L.cot_agg_gn9_forward(_p(v), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(gn.bias), gn.num_groups, _p(a),
+                                      ctypes.byref(geom), BF16, st), "cot_agg_gn9_forward")
+        else:
+            _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
         _bn_fwd(L, a, y, bnl, s_y, 2 * C, N, C, HW, 2)
     # radix-2 split attention                                                                    (ref :92-104)
     # descriptors are kept channel-major ([C][N]) so that the se branch runs on the 1x1-convolution / BatchNorm

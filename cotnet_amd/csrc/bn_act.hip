@@ -1091,6 +1091,44 @@ int bn_tile_stats(const float* part, int N, int C, int HW, float eps, float mom,
     COT_LAUNCH(bn_tile_stats_finalize, dim3(C), dim3(64), 0, s, part, N, C, ceil_div(HW, 128), HW, eps, mom, mean, rstd, rmean, rvar, nbt);
     return check_launch("bn_tile_stats_finalize");
 }
+// ---- statistics from the AGGREGATION's epilogue (round 6): agg_fwd_nchw_k3_lds<ST = 1> writes per output row (n, c, h) the sum and the
+// sum of squares of what it stores; one workgroup per channel adds the channel's N*H rows -- per-thread fp64 partials in a fixed
+// interleaving, then a fixed-order workgroup sum: deterministic -- and finishes exactly as bn_tile_stats_finalize does.
+__global__ __launch_bounds__(256) void bn_rowstats_finalize(const float* __restrict__ rows, int N, int C, int H, int W, float eps,
+                                                           float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           long long* __restrict__ num_batches_tracked) {
+    __shared__ double red[32];
+    const int c = blockIdx.x, t = threadIdx.x;
+    if (c == 0 && t == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    double s1 = 0.0, s2 = 0.0;
+    const int NR = N * H;  // rows of this channel: image n, row h at ((n*C + c)*H + h)*2
+    for (int e = t; e < NR; e += 256) {
+        const int n = e / H, h = e - n * H;
+        const Vec<float, 2> v = ldv<float, 2>(rows + (((int64_t)n * C + c) * H + h) * 2);
+        s1 += (double)v.v[0];
+        s2 += (double)v.v[1];
+    }
+    double acc[2] = {s1, s2};
+    block_allsum_d<2>(acc, red);
+    if (t == 0) {
+        const double cnt = (double)N * H * W, m = acc[0] / cnt;
+        double var = acc[1] / cnt - m * m;  // (fp64 on sums of bf16-exact squares: no visible cancellation at these counts)
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+int bn_rowstats(const float* rows, int N, int C, int H, int W, float eps, float mom, float* mean, float* rstd, float* rmean, float* rvar,
+                long long* nbt, hipStream_t s) {
+    COT_LAUNCH(bn_rowstats_finalize, dim3(C), dim3(256), 0, s, rows, N, C, H, W, eps, mom, mean, rstd, rmean, rvar, nbt);
+    return check_launch("bn_rowstats_finalize");
+}
 // y = act(gamma * (x - mean_c) * rstd_c + beta [+ residual]) from GIVEN batch statistics (bf16; the flat apply kernel)
 int bn_apply_forward(const void* x, const void* res, void* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
                      int N, int C, int HW, int act, hipStream_t s) {

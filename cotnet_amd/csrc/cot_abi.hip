@@ -259,6 +259,9 @@ int radix_mix_bwd_reduce_bn(const void*, const void*, const void*, const void*, 
 template <typename T>
 int radix_mix_bwd_apply_bn(const void*, const void*, const void*, const void*, const float*, void*, void*, const float*, const float*,
                            const float*, const float*, float*, float*, int, int, int, int, hipStream_t);
+int agg_forward_rowstats_nchw(const bf16_t*, const bf16_t*, bf16_t*, float*, const float*, const float*, const bf16_t*, const bf16_t*, int,
+                              const cot_agg_geom&, hipStream_t);
+int bn_rowstats(const float*, int, int, int, int, float, float, float*, float*, float*, float*, long long*, hipStream_t);
 template <typename T>
 int bn_batch_stats(const void*, float*, float*, float*, float*, long long*, float*, int, int, int, float, float, hipStream_t);
 int input_normalize(const void*, void*, const float*, const float*, int64_t, int, int, int, hipStream_t);  // input_norm.hip
@@ -662,6 +665,37 @@ int cot_agg_gn9_forward(const void* x, const void* logits, const float* mean, co
     else g_kernel = last_kernel_nchw();
     if (p) prof::annotate(*g, dtype, COT_NCHW, 0, 0);  // (same algorithmic bytes as the plain aggregation: x, logits read, out written)
     return rc;
+}
+// ---- aggregation forward that also emits the following BatchNorm's row statistics (agg_fwd_nchw_k3_lds<ST = 1>), and their finalize
+int64_t cot_agg_rowstats_floats(int N, int C, int H) { return (N > 0 && C > 0 && H > 0) ? (int64_t)N * C * H * 2 : 0; }
+int cot_agg_forward_rowstats(const void* x, const void* w, void* out, float* rowstats, const float* gn_mean, const float* gn_rstd,
+                             const void* gn_gamma, const void* gn_beta, int groups_per_image, const cot_agg_geom* g, int dtype,
+                             void* stream) {
+    int Ho, Wo, rc = validate(g, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !w || !out || !rowstats) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (gn_mean && (!gn_rstd || !gn_gamma || !gn_beta || groups_per_image <= 0))
+        return set_error(COT_ERR_INVALID_ARG, "GroupNorm prologue: rstd / gamma / beta / groups_per_image missing");
+    if ((rc = check_align16({x, w, out, rowstats}))) return rc;
+    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_agg_forward_rowstats: COT_BF16 only");
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    rc = agg_forward_rowstats_nchw((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out, rowstats, gn_mean, gn_rstd, (const bf16_t*)gn_gamma,
+                                   (const bf16_t*)gn_beta, groups_per_image, *g, (hipStream_t)stream);
+    if (rc == COT_ERR_UNSUPPORTED)
+        return set_error(rc, "cot_agg_forward_rowstats: geometry not covered (3x3, stride 1, pad 1, one head, C / wC <= 8, the LDS kernel's planes)");
+    g_kernel = last_kernel_nchw();
+    if (p) prof::annotate(*g, dtype, COT_NCHW, 0, 0);
+    return rc;
+}
+int cot_bn_rowstats_finalize(const float* rowstats, float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, int N, int C, int H, int W, float eps, float momentum, void* stream) {
+    if (!rowstats || !save_mean || !save_rstd) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "bad N/C/H/W");
+    if ((running_mean == NULL) != (running_var == NULL))
+        return set_error(COT_ERR_INVALID_ARG, "running_mean and running_var must be given together");
+    return bn_rowstats(rowstats, N, C, H, W, eps, momentum, save_mean, save_rstd, running_mean, running_var, (long long*)num_batches_tracked,
+                       (hipStream_t)stream);
 }
 int cot_agg_gn9_backward(const void* gout, const void* x, const void* logits, const float* mean, const float* rstd, const void* gamma,
                          const void* beta, int groups_per_image, void* gx, void* gw, const cot_agg_geom* g, int dtype, void* stream) {

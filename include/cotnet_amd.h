@@ -537,6 +537,18 @@ int cot_radix_mix_backward_apply_lay(const void* gout, const void* attn, const v
  *                                    plane sums the BatchNorm's backward needs and that do not depend on the pooled descriptor's gradient
  *   cot_radix_mix_backward_apply_bn  ga = d loss / d a (through the mix, the pooling, SiLU and the BatchNorm), gk = g*a1 + ggapT/HW;
  *                                    dgamma / dbeta [C] fp32 written (sums over the batch in a fixed order: deterministic) */
+/* The statistics pass disappears where the aggregation that writes `a` emits them (models/cotnet.py:88-89: x = self.local_conv(x, w);
+ * x = self.bn(x)): cot_agg_forward_rowstats = cot_agg_forward (gn_mean == NULL: w holds the weights) or cot_agg_gn9_forward (gn_mean
+ * given: w holds the raw logits) that ALSO writes, per output row (n, c, h), the sum and the sum of squares of the values it stores to
+ * rowstats[((n*C + c)*H + h)*2 + {0, 1}] (cot_agg_rowstats_floats(N, C, H) floats, 16-byte aligned); cot_bn_rowstats_finalize turns them
+ * into save_mean / save_rstd / the running statistics (fp64 sums in a fixed order: deterministic).  COT_BF16, the 3x3 / stride 1 / pad 1
+ * one-head geometry with at most 8 channels per weight channel; COT_ERR_UNSUPPORTED otherwise (then: cot_agg_forward + cot_bn_batch_stats). */
+int64_t cot_agg_rowstats_floats(int N, int C, int H);
+int cot_agg_forward_rowstats(const void* x, const void* w, void* out, float* rowstats, const float* gn_mean, const float* gn_rstd,
+                             const void* gn_gamma, const void* gn_beta, int groups_per_image, const cot_agg_geom* g, int dtype,
+                             void* stream);
+int cot_bn_rowstats_finalize(const float* rowstats, float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, int N, int C, int H, int W, float eps, float momentum, void* stream);
 int cot_bn_batch_stats(const void* x, float* save_mean, float* save_rstd, float* running_mean, float* running_var,
                        int64_t* num_batches_tracked, float* workspace, int N, int C, int HW, float eps, float momentum, int dtype,
                        void* stream);

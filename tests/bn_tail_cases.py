@@ -101,3 +101,43 @@ def bn_tail_case(L, N, C, H, W, dtype, lay_k, seed=21):
     assert (dgam.cpu() - gam_r.grad).abs().max() <= btol * scale(gam_r.grad)
     assert (dbet.cpu() - bet_r.grad).abs().max() <= btol * scale(bet_r.grad)
     return same_stats
+
+
+def rowstats_case(L, N, C, H, W, gn, seed=5):
+    """cot_agg_forward_rowstats (the aggregation forward that also emits the following BatchNorm's per-row sums) + cot_bn_rowstats_finalize
+    against the plain entry points: the output bit for bit, the row sums against torch on the stored values, mean / rstd / running
+    statistics against torch's batch statistics.  gn: GroupNorm-9 prologue (w = raw logits) as in cot_agg_gn9_forward."""
+    torch.manual_seed(seed)
+    dev = getattr(L, "_test_device", "cpu")
+    wC, HW = C // 8, H * W
+    dt = _lib.COT_BF16
+    x = torch.randn(N, C, H, W).bfloat16().to(dev)
+    w = (0.4 * torch.randn(N, 1, wC, 9, H, W) + 0.1).bfloat16().to(dev)
+    geom = _lib.AggGeom(N, C, H, W, 1, wC, 3, 3, 1, 1, 1, 1, 1, 1)
+    out0, out = torch.empty_like(x), torch.full_like(x, float("nan"))
+    rows = torch.full((int(L.cot_agg_rowstats_floats(N, C, H)),), float("nan"), dtype=torch.float32, device=dev)
+    if gn:
+        G = wC  # one GroupNorm group per weight channel: 9 taps each
+        gm, gr = torch.randn(N * G).to(dev) * 0.1, (1 + 0.2 * torch.rand(N * G)).to(dev)
+        gam, bet = (1 + 0.3 * torch.randn(9 * G)).bfloat16().to(dev), (0.2 * torch.randn(9 * G)).bfloat16().to(dev)
+        assert L.cot_agg_gn9_forward(P(x), P(w), P(gm), P(gr), P(gam), P(bet), G, P(out0), ctypes.byref(geom), dt, None) == 0, L.cot_last_error()
+        rc = L.cot_agg_forward_rowstats(P(x), P(w), P(out), P(rows), P(gm), P(gr), P(gam), P(bet), G, ctypes.byref(geom), dt, None)
+    else:
+        assert L.cot_agg_forward(P(x), P(w), P(out0), ctypes.byref(geom), dt, _lib.COT_NCHW, None) == 0, L.cot_last_error()
+        rc = L.cot_agg_forward_rowstats(P(x), P(w), P(out), P(rows), None, None, None, None, 0, ctypes.byref(geom), dt, None)
+    assert rc == 0, L.cot_last_error()
+    assert L.cot_last_kernel().decode().endswith("rowstats>")
+    assert torch.equal(out, out0)
+    of = out.float().cpu()
+    r = rows.cpu().view(N, C, H, 2)
+    assert torch.allclose(r[..., 0], of.sum(3), atol=1e-4, rtol=1e-5) and torch.allclose(r[..., 1], (of * of).sum(3), atol=1e-4, rtol=1e-5)
+    f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    mean, rstd = f32(C), f32(C)
+    rm, rv, nbt = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    assert L.cot_bn_rowstats_finalize(P(rows), P(mean), P(rstd), P(rm), P(rv), P(nbt), N, C, H, W, 1e-5, 0.1, None) == 0, L.cot_last_error()
+    var = of.var((0, 2, 3), unbiased=False)
+    assert torch.allclose(mean.cpu(), of.mean((0, 2, 3)), atol=2e-6, rtol=1e-5)
+    assert torch.allclose(rstd.cpu(), 1 / torch.sqrt(var + 1e-5), atol=1e-5, rtol=1e-5)
+    cnt = N * HW
+    assert int(nbt) == 1 and torch.allclose(rm.cpu(), 0.1 * of.mean((0, 2, 3)), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(rv.cpu(), 0.9 + 0.1 * var * cnt / max(cnt - 1, 1), atol=1e-5, rtol=1e-5)

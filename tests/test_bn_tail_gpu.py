@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from cotnet_amd import _lib
-from tests.bn_tail_cases import bn_tail_case
+from tests.bn_tail_cases import bn_tail_case, rowstats_case
 
 pytestmark = pytest.mark.gpu
 
@@ -31,4 +31,14 @@ def test_bn_tail_bf16(shape, lay_k):
 @pytest.mark.parametrize("shape", SMALL + [(8, 64, 56, 56)])
 def test_bn_tail_fp32(shape, lay_k):
     bn_tail_case(_lib_on_device(), *shape, torch.float32, lay_k)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("gn", [0, 1])
+@pytest.mark.parametrize("shape", STEP + [(2, 64, 8, 8), (3, 64, 7, 7), (1, 128, 5, 8), (3, 192, 7, 7), (5, 64, 20, 20)])
+def test_agg_forward_rowstats(shape, gn):
+    """cot_agg_forward_rowstats + cot_bn_rowstats_finalize: output bit-identical to the plain forward, row sums and statistics against torch"""
+    if gn and shape[3] % 2:
+        pytest.skip("the GroupNorm prologue takes even rows (cot_agg_gn9_forward)")
+    rowstats_case(_lib_on_device(), *shape, gn)
     torch.cuda.synchronize()

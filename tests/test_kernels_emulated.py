@@ -12,7 +12,7 @@ import torch
 from cotnet_amd import _lib
 from oracle import cref, unfold_oracle
 from tests.emul import build_emul
-from tests.bn_tail_cases import bn_tail_case
+from tests.bn_tail_cases import bn_tail_case, rowstats_case
 
 try:
     _EMUL = ctypes.CDLL(build_emul.build())
@@ -1576,6 +1576,8 @@ def test_fused_cot_layer_node_on_emulated_kernels(cls, C, H, monkeypatch):
     launched = []
     orig_gn9 = _EMUL.cot_agg_gn9_forward
     monkeypatch.setattr(_EMUL, "cot_agg_gn9_forward", lambda *a: (launched.append(1), orig_gn9(*a))[1], raising=False)
+    orig_rs = _EMUL.cot_agg_forward_rowstats  # (the same prologue behind the forward that also emits bn's statistics: gn_mean given)
+    monkeypatch.setattr(_EMUL, "cot_agg_forward_rowstats", lambda *a: (launched.append(1) if a[4] else None, orig_rs(*a))[1], raising=False)
 
     monkeypatch.setattr(clf, "ENABLED", True)
     xf = x.clone().requires_grad_(True)
@@ -1654,6 +1656,15 @@ def test_radix_tail_bn_fused_kernels(N, C, H, W, dtype, lay_k):
     # True: the bit-for-bit branch of the forward comparison ran (7 x 7 bf16 planes: the statistics pass reads 7 elements per lane where
     # the unfused streaming kernel reads one -- another summation order)
     assert same or (dtype == torch.bfloat16 and (H * W) % 7 == 0 and (H * W) % 2 == 1)
+
+
+@pytest.mark.parametrize("gn", [0, 1])
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 8), (3, 64, 7, 7), (2, 128, 14, 14), (1, 64, 28, 28), (2, 64, 56, 56), (1, 128, 5, 8), (3, 192, 7, 7)])
+def test_agg_forward_rowstats(N, C, H, W, gn):
+    """the aggregation forward with the following BatchNorm's statistics out of its epilogue (agg_fwd_nchw_k3_lds<ST = 1>) and their finalize"""
+    if gn and W % 2:
+        pytest.skip("the GroupNorm prologue takes even rows (cot_agg_gn9_forward)")
+    rowstats_case(_EMUL, N, C, H, W, gn)
 
 
 @pytest.mark.parametrize("pack", [1, 0])
