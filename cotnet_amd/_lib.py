@@ -144,7 +144,8 @@ SYMBOLS = {
     "cot_agg_forward_rowstats": (_I, [_P] * 8 + [_I, _G, _I, _P]),
     "cot_bn_rowstats_finalize": (_I, [_P] * 6 + [_I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
     "cot_bn_batch_stats": (_I, [_P] * 7 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _P]),
-    "cot_radix_gap_t_bn": (_I, [_P] * 7 + [_I, _I, _I, _I, _I, _P]),
+    "cot_bn_stats_sums": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "cot_radix_gap_t_bn": (_I, [_P] * 11 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "cot_radix_mix_logits_bn": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_reduce_bn": (_I, [_P] * 10 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_apply_bn": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P]),

@@ -233,7 +233,7 @@ class _BottleneckCMNode(Function):
         bnl = pl.bn
         s_y = stat(C, nws_c)
         if bn_tail:  # (aggregation + the statistics of bn out of its epilogue; bn + swish themselves happen inside the tail's kernels)
-            clf._agg_fwd_stats(L, v, w, a, None, None, None, geom, bnl, s_y, N, C, H, W)
+            y_final = clf._agg_fwd_stats(L, v, w, a, None, None, None, geom, bnl, s_y, N, C, H, W)
         else:
             _ck(L.cot_agg_forward(_p(v), _p(w), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
             _bn_fwd(L, a, y, bnl, s_y, 2 * C, N, C, HW, 2)
@@ -241,8 +241,7 @@ class _BottleneckCMNode(Function):
         row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
         gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
         if bn_tail:
-            _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]), N, C, HW, 2, BF16, st),
-                "cot_radix_gap_t_bn")
+            clf._tail_gap(L, a, k, gapT, bnl, s_y, y_final, N, C, HW, 2)
         else:
             _ck(L.cot_radix_gap_t_lay(_p(y), _p(k), _p(gapT), N, C, HW, 2, BF16, st), "cot_radix_gap_t_lay")
         _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st), "cot_conv1x1_forward")

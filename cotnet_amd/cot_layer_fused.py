@@ -220,15 +220,19 @@ def _gn_fused_ok(L, Ch, HW, W):
 BN_TAIL = os.environ.get("COT_BN_TAIL", "1") != "0"
 
 
-# ... and its statistics out of the aggregation's own epilogue (cot_agg_forward_rowstats + cot_bn_rowstats_finalize) where the LDS
-# forward kernel serves the geometry: no statistics pass over `a` at all.  COT_AGG_ROWSTATS=0 = cot_bn_batch_stats (a read of a).
-AGG_ROWSTATS = os.environ.get("COT_AGG_ROWSTATS", "1") != "0"
+# ... and, opt-in (COT_AGG_ROWSTATS=1), its statistics out of the aggregation's own epilogue (cot_agg_forward_rowstats +
+# cot_bn_rowstats_finalize) where the LDS forward kernel serves the geometry: no statistics pass over `a` at all.  Built, parity-green and
+# measured: the epilogue costs the aggregation +5.7 / +3.0 / +1.7 / -0.8 us at 56 / 28 / 14 / 7 pixels and its finalize 6.4-7.4 us, against
+# 10.3-14.9 us for cot_bn_batch_stats -- 37.1 -> 35.3, 26.6 -> 26.1, 20.5 -> 18.3, 20.7 -> 15.4 us per layer, and the step does not move
+# (13.56 vs 13.56 ms, alternating; profiles/r06_rowstats_kernels.log, r06_rowstats_ab.log): default off.
+AGG_ROWSTATS = os.environ.get("COT_AGG_ROWSTATS", "0") == "1"
 _ROWSTATS_OK = _lib.register_cache({})
 
 
 def _agg_fwd_stats(L, v, w_or_logits, a, gn, gn_mean, gn_rstd, geom, bn, stats, N, C, H, W):
-    """a = aggregation(v, w) and bn's batch statistics of a into stats[:C] / stats[C:2C] (+ running statistics).  gn given: w_or_logits
-    holds the raw logits and the GroupNorm is applied in the aggregation's prologue (cot_agg_gn9_forward's contract)."""
+    """a = aggregation(v, w) and what bn's batch statistics of a are made of.  -> True: mean / rstd are in stats[:C] / stats[C:2C] and
+    the running statistics updated; False: stats[2C:] holds chunk sums that the pooling kernel's prologue finalizes (_tail_gap).  gn
+    given: w_or_logits holds the raw logits and the GroupNorm is applied in the aggregation's prologue (cot_agg_gn9_forward's contract)."""
     st = _stream()
     key = (geom.N, geom.C, H, W, geom.wC, gn is not None)
     if AGG_ROWSTATS and _ROWSTATS_OK.get(key, True):
@@ -241,7 +245,7 @@ def _agg_fwd_stats(L, v, w_or_logits, a, gn, gn_mean, gn_rstd, geom, bn, stats, 
             _ck(L.cot_bn_rowstats_finalize(_p(rows), _p(stats), _p(stats[C:]), _p(bn.running_mean), _p(bn.running_var),
                                            _p(bn.num_batches_tracked), N, C, H, W, float(bn.eps), float(bn.momentum), st),
                 "cot_bn_rowstats_finalize")
-            return
+            return True
         if rc != _lib.COT_ERR_UNSUPPORTED:
             _ck(rc, "cot_agg_forward_rowstats")
         _ROWSTATS_OK[key] = False  # (geometry off the LDS forward kernel: the plain forward + a statistics pass, from now on without asking)
@@ -250,14 +254,15 @@ def _agg_fwd_stats(L, v, w_or_logits, a, gn, gn_mean, gn_rstd, geom, bn, stats, 
                                   ctypes.byref(geom), BF16, st), "cot_agg_gn9_forward")
     else:
         _ck(L.cot_agg_forward(_p(v), _p(w_or_logits), _p(a), ctypes.byref(geom), BF16, _lib.COT_NCHW, st), "cot_agg_forward")
-    _bn_batch_stats(L, a, bn, stats, N, C, H * W)
+    _ck(L.cot_bn_stats_sums(_p(a), _p(stats[2 * C:]), N, C, H * W, BF16, st), "cot_bn_stats_sums")
+    return False
 
 
-def _bn_batch_stats(L, x, bn, stats, N, C, HW):
-    """mean = stats[:C], rstd = stats[C:2C] (+ running statistics) of x [N, C, HW] in one launch; stats[2C:] is the workspace"""
-    _ck(L.cot_bn_batch_stats(_p(x), _p(stats), _p(stats[C:]), _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked),
-                             _p(stats[2 * C:]), N, C, HW, float(bn.eps), float(bn.momentum), BF16, _stream()),
-        "cot_bn_batch_stats")
+def _tail_gap(L, a, k, gapT, bn, stats, final, N, C, HW, lay):
+    """gapT = mean_hw(silu(bn(a)) + k); final False: stats[2C:] holds cot_bn_stats_sums' chunk sums and this launch finalizes them"""
+    _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]), _p(bn.running_mean),
+                             _p(bn.running_var), _p(bn.num_batches_tracked), None if final else _p(stats[2 * C:]), N, C, HW, float(bn.eps),
+                             float(bn.momentum), lay, BF16, _stream()), "cot_radix_gap_t_bn")
 
 _SIZES = _lib.register_cache({})  # (N, C, H, W, A) -> (workspace bytes, bn workspace floats for C, C/2 and the se branch's A channels)
 _MASKS = {}
@@ -672,7 +677,7 @@ def _cot_forward(L, layer, x):
     s_y = stat(C, nws_c)
     bnl = pl.bn
     if BN_TAIL:  # (aggregation + the statistics of bn; bn + swish themselves happen inside the tail's kernels)
-        _agg_fwd_stats(L, v, e3 if fused_gn else w, a, gn if fused_gn else None, gn_mean, gn_rstd, geom, bnl, s_y, N, C, H, W)
+        y_final = _agg_fwd_stats(L, v, e3 if fused_gn else w, a, gn if fused_gn else None, gn_mean, gn_rstd, geom, bnl, s_y, N, C, H, W)
     else:
         if fused_gn:
             _ck(L.cot_agg_gn9_forward(_p(v), _p(e3), _p(gn_mean), _p(gn_rstd), _p(gn.weight), _p(gn.bias), gn.num_groups, _p(a),
@@ -686,8 +691,7 @@ def _cot_forward(L, layer, x):
     row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
     gapT, hpre, h, logitsT = row(C), row(A), row(A), row(2 * C)
     if BN_TAIL:
-        _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bnl.weight), _p(bnl.bias), _p(s_y), _p(s_y[C:]), N, C, HW, 0, BF16, st),
-            "cot_radix_gap_t_bn")
+        _tail_gap(L, a, k, gapT, bnl, s_y, y_final, N, C, HW, 0)
     else:
         _ck(L.cot_radix_gap_t(_p(y), _p(k), _p(gapT), N, C, HW, BF16, st), "cot_radix_gap_t")
     _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st),

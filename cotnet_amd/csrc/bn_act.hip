@@ -135,6 +135,47 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
     }
 }
 
+// Chunk SUMS about a shift common to the channel's chunks (round 6): part[c][s] = (sum (x - shift), sum (x - shift)^2, count, shift),
+// shift = the channel's first element.  Merging such chunks is three additions each -- cheap enough to live in the prologue of a consumer
+// that has one wave per (image, channel) plane (radix_gap_t_bn: bn_stats_partial's Chan merge, two divisions per chunk, cost those
+// waves more instructions than their plane at 14 x 14) -- so the statistics need no finalize launch.  One sample as the shift keeps
+// sum (x - shift)^2 / n - (sum (x - shift) / n)^2 at a few times the variance: no cancellation to speak of in fp32.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_stats_sums(const T* __restrict__ x, float* __restrict__ part, int N, int C, int HW, int nper) {
+    extern __shared__ __attribute__((aligned(16))) char cot_smem[];
+    float* smem = reinterpret_cast<float*>(cot_smem);
+    const int c = blockIdx.x, s = blockIdx.y, split = gridDim.y;
+    const int n0 = s * nper, n1 = min(N, n0 + nper);
+    const int vpp = HW / V;
+    const float shift = (float)x[(int64_t)c * HW];
+    float acc[2] = {0.f, 0.f};
+    const int cnt = n1 - n0;
+    auto accumulate = [&](const Vec<T, V>& xv) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float d = (float)xv.v[k] - shift;
+            acc[0] += d;
+            acc[1] += d * d;
+        }
+    };
+    PlaneWalk a(threadIdx.x, 2 * blockDim.x, vpp), b(threadIdx.x + blockDim.x, 2 * blockDim.x, vpp);
+    for (; b.n < cnt; a.next(), b.next()) {
+        const Vec<T, V> xa = ldv<T, V>(x + ((int64_t)(n0 + a.n) * C + c) * HW + (int64_t)a.v * V);
+        const Vec<T, V> xb = ldv<T, V>(x + ((int64_t)(n0 + b.n) * C + c) * HW + (int64_t)b.v * V);
+        accumulate(xa);
+        accumulate(xb);
+    }
+    if (a.n < cnt) accumulate(ldv<T, V>(x + ((int64_t)(n0 + a.n) * C + c) * HW + (int64_t)a.v * V));
+    block_sum<2>(acc, smem);
+    if (threadIdx.x == 0) {
+        float* p = part + ((int64_t)c * split + s) * 4;
+        p[0] = acc[0];
+        p[1] = acc[1];
+        p[2] = (float)((int64_t)(n1 > n0 ? n1 - n0 : 0) * HW);
+        p[3] = shift;
+    }
+}
+
 // one thread per channel: merge the SPLIT chunks (Chan), produce mean / rstd, update running statistics
 __global__ void bn_stats_finalize(const float* __restrict__ part, int C, int split, float eps, float momentum,
                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
@@ -1050,6 +1091,30 @@ int bn_batch_stats(const void* x, float* mean, float* rstd, float* rmean, float*
 }
 template int bn_batch_stats<float>(const void*, float*, float*, float*, float*, long long*, float*, int, int, int, float, float, hipStream_t);
 template int bn_batch_stats<bf16_t>(const void*, float*, float*, float*, float*, long long*, float*, int, int, int, float, float, hipStream_t);
+
+int bn_stats_split(int N, int C) {
+    int split, nper;
+    pick_split(N, C, &split, &nper);
+    return split;
+}
+template <typename T>
+int bn_stats_sums_launch(const void* x, float* ws, int N, int C, int HW, hipStream_t s) {
+    int split, nper;
+    pick_split(N, C, &split, &nper);
+    int v = pick_vec(sizeof(T), HW);
+    if (v == 1 && HW % 7 == 0 && sizeof(T) == 2) v = 7;
+    if (sizeof(T) > 2 && v == 8) v = 4;
+#define BN_SS(V_) COT_LAUNCH((bn_stats_sums<T, V_>), dim3(C, split), dim3(256), 48 * sizeof(float), s, (const T*)x, ws, N, C, HW, nper)
+    if (v == 8) BN_SS((sizeof(T) <= 2 ? 8 : 4));
+    else if (v == 7) BN_SS(7);
+    else if (v == 4) BN_SS(4);
+    else if (v == 2) BN_SS(2);
+    else BN_SS(1);
+#undef BN_SS
+    return check_launch("bn_stats_sums");
+}
+template int bn_stats_sums_launch<float>(const void*, float*, int, int, int, hipStream_t);
+template int bn_stats_sums_launch<bf16_t>(const void*, float*, int, int, int, hipStream_t);
 
 // ---- statistics from the PRODUCER's epilogue (round 5): the 1x1 convolution that writes a BatchNorm's
 // input also writes, per (image, 128-pixel tile, channel), the sum and the sum of squares of the bf16 values it stores

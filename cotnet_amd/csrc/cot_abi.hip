@@ -249,7 +249,10 @@ int radix_mix_bwd_reduce(const void*, const void*, const void*, const void*, voi
 template <typename T>
 int radix_mix_bwd_apply(const void*, const void*, const void*, void*, void*, int, int, int, int, hipStream_t);
 template <typename T>
-int radix_gap_t_bn(const void*, const void*, void*, const float*, const float*, const float*, const float*, int, int, int, int, hipStream_t);
+int radix_gap_t_bn(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*, long long*, const float*,
+                   int, float, float, int, int, int, int, hipStream_t);
+int bn_stats_split(int N, int C);
+template <typename T> int bn_stats_sums_launch(const void*, float*, int, int, int, hipStream_t);
 template <typename T>
 int radix_mix_logits_bn(const void*, const void*, const void*, void*, void*, const float*, const float*, const float*, const float*, int,
                         int, int, int, hipStream_t);
@@ -1180,14 +1183,31 @@ static int tail_bn_check(int N, int C, int HW, int dtype, const char* what) {
     if (N <= 0 || C <= 0) return set_error(COT_ERR_INVALID_ARG, "%s: non-positive N=%d C=%d", what, N, C);
     return COT_OK;
 }
-int cot_radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, const float* save_mean,
-                       const float* save_rstd, int N, int C, int HW, int lay, int dtype, void* stream) {
+int cot_bn_stats_sums(const void* x, float* workspace, int N, int C, int HW, int dtype, void* stream) {
+    if (!x || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (N <= 0 || C <= 0 || HW <= 0) return set_error(COT_ERR_INVALID_ARG, "bad N/C/HW");
+    int rc = check_align16({x, workspace});
+    if (rc) return rc;
+    if (dtype == COT_F32) return bn_stats_sums_launch<float>(x, workspace, N, C, HW, (hipStream_t)stream);
+    if (dtype == COT_BF16) return bn_stats_sums_launch<bf16_t>(x, workspace, N, C, HW, (hipStream_t)stream);
+    return set_error(COT_ERR_UNSUPPORTED, "cot_bn_stats_sums: dtype %d (float32 / bfloat16 only)", dtype);
+}
+int cot_radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, float* save_mean,
+                       float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* workspace,
+                       int N, int C, int HW, float eps, float momentum, int lay, int dtype, void* stream) {
     int rc = tail_bn_check(N, C, HW, dtype, "cot_radix_gap_t_bn");
     if (rc) return rc;
     if (!a || !k || !gapT || !gamma || !beta || !save_mean || !save_rstd) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
-    if ((rc = check_align16({a, k}))) return rc;
-    return dtype == COT_F32 ? radix_gap_t_bn<float>(a, k, gapT, gamma, beta, save_mean, save_rstd, N, C, HW, lay, (hipStream_t)stream)
-                            : radix_gap_t_bn<bf16_t>(a, k, gapT, gamma, beta, save_mean, save_rstd, N, C, HW, lay, (hipStream_t)stream);
+    if ((running_mean == NULL) != (running_var == NULL))
+        return set_error(COT_ERR_INVALID_ARG, "running_mean and running_var must be given together");
+    if ((rc = check_align16({a, k, workspace}))) return rc;
+    const int split = workspace ? bn_stats_split(N, C) : 0;
+    return dtype == COT_F32 ? radix_gap_t_bn<float>(a, k, gapT, gamma, beta, save_mean, save_rstd, running_mean, running_var,
+                                                    (long long*)num_batches_tracked, workspace, split, eps, momentum, N, C, HW, lay,
+                                                    (hipStream_t)stream)
+                            : radix_gap_t_bn<bf16_t>(a, k, gapT, gamma, beta, save_mean, save_rstd, running_mean, running_var,
+                                                     (long long*)num_batches_tracked, workspace, split, eps, momentum, N, C, HW, lay,
+                                                     (hipStream_t)stream);
 }
 int cot_radix_mix_logits_bn(const void* a, const void* k, const void* logitsT, void* out, void* attn, const float* gamma,
                             const float* beta, const float* save_mean, const float* save_rstd, int N, int C, int HW, int lay, int dtype,

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void radix_mix_bwd_apply_kernel(const T* __res
 // reads g and a anyway -- emits them; the apply kernel's prologue combines them over the batch (fixed order: deterministic) and writes
 // the gradient w.r.t. a directly.  4 launches and 11 tensor passes (mix apply, BatchNorm reduce, BatchNorm apply, + the reduce) become 2
 // launches and 7 passes.
-//   radix_gap_t_bn        gapT[c][n] = mean_hw(silu(bn(a)) + k)   (mean / rstd: bn_batch_stats, bn_act.hip)
+//   radix_gap_t_bn        gapT[c][n] = mean_hw(silu(bn(a)) + k); given bn_stats_sums' chunk sums its prologue also finalizes the statistics
 //   radix_mix_logits_bn   out = silu(bn(a))*a0 + k*a1
 //   radix_mix_bwd_reduce_bn  glogitsT as radix_mix_bwd_reduce + tsum[n][c][0..3]
 //   radix_mix_bwd_apply_bn   ga = gamma*rstd*(g_z - dbeta/M - xhat*dgamma/M), gk = g*a1 + add; dgamma / dbeta written by plane n = 0
@@ -287,9 +287,23 @@ template <typename T, int V, int STEP> struct Ahead2 {  // vectors i, i + STEP, 
     }
 };
 
+// part != NULL: the prologue FINALIZES the statistics -- it adds the channel's chunk sums (bn_stats_sums, bn_act.hip: three additions per
+// chunk), and the wave of plane n = 0 writes mean / rstd / the running statistics for everybody behind this launch.  NULL: bn.mean /
+// bn.rstd are read.
+struct BnFin {
+    const float* part;  // [C][split][4] = (sum (x - shift), sum (x - shift)^2, count, shift)
+    int split;
+    float eps, momentum;
+    float* mean;
+    float* rstd;
+    float* running_mean;
+    float* running_var;
+    long long* nbt;
+};
+
 template <typename T, int V, int SEG = 64>
 __global__ __launch_bounds__(256) void radix_gap_t_bn_kernel(const T* __restrict__ a, const T* __restrict__ k, T* __restrict__ gapT,
-                                                            BnTail bn, int N, int C, int HW, int lay) {
+                                                            BnTail bn, BnFin fin, int N, int C, int HW, int lay) {
     constexpr int STEP = SEG * V;
     const int lane = threadIdx.x & (SEG - 1);
     int64_t plane = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SEG;
@@ -299,7 +313,36 @@ __global__ __launch_bounds__(256) void radix_gap_t_bn_kernel(const T* __restrict
     const int n = (int)(plane / C), c = (int)(plane % C);
     const int i0 = lane * V;
     Ahead2<T, V, STEP> av(a + tail_base(lay & 1, n, c, N, C, HW), i0, HW), kv(k + tail_base(lay & 2, n, c, N, C, HW), i0, HW);
-    const float sc = bn.gamma[c] * bn.rstd[c], sh = bn.beta[c] - bn.mean[c] * sc;
+    float m, r;
+    if (fin.part) {
+        float s1 = 0.f, s2 = 0.f, cnt = 0.f;
+        const float* p = fin.part + (int64_t)c * fin.split * 4;
+        for (int q = 0; q < fin.split; ++q) {
+            const Vec<float, 4> t = ldv<float, 4>(p + q * 4);
+            s1 += t.v[0];
+            s2 += t.v[1];
+            cnt += t.v[2];
+        }
+        const float inv = 1.f / cnt, d = s1 * inv;
+        float var = s2 * inv - d * d;
+        var = var > 0.f ? var : 0.f;
+        m = p[3] + d;
+        r = 1.0f / sqrtf(var + fin.eps);
+        if (n == 0 && lane == 0 && live) {
+            fin.mean[c] = m;
+            fin.rstd[c] = r;
+            if (fin.running_mean) {
+                const float unbiased = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
+                fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * m;
+                fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * unbiased;
+            }
+            if (c == 0 && fin.nbt) *fin.nbt += 1;
+        }
+    } else {
+        m = bn.mean[c];
+        r = bn.rstd[c];
+    }
+    const float sc = bn.gamma[c] * r, sh = bn.beta[c] - m * sc;
     float acc = 0.f;
     for (int i = i0; i < HW; i += STEP) {
         const Vec<T, V> x = av.next(i), b = kv.next(i);
@@ -612,11 +655,13 @@ int radix_mix_bwd_apply(const void* g, const void* attn, const void* ggapT, void
 
 // ---- BatchNorm + SiLU folded into the tail (kernels above)
 template <typename T>
-int radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                   int N, int C, int HW, int lay, hipStream_t s) {
+int radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, float* mean, float* rstd,
+                   float* rmean, float* rvar, long long* nbt, const float* part, int split, float eps, float mom, int N, int C, int HW,
+                   int lay, hipStream_t s) {
     const int64_t planes = (int64_t)N * C;
     const BnTail bn{gamma, beta, mean, rstd};
-    TAIL_DISPATCH7(radix_gap_t_bn_kernel, (const T*)a, (const T*)k, (T*)gapT, bn, N, C, HW, lay);
+    const BnFin fin{part, split, eps, mom, mean, rstd, rmean, rvar, nbt};
+    TAIL_DISPATCH7(radix_gap_t_bn_kernel, (const T*)a, (const T*)k, (T*)gapT, bn, fin, N, C, HW, lay);
     return check_launch("radix_gap_t_bn");
 }
 template <typename T>
@@ -663,8 +708,8 @@ int radix_mix_bwd_apply_bn(const void* g, const void* a, const void* attn, const
                                          int, hipStream_t);                                                        \
     template int radix_mix_bwd_apply<T>(const void*, const void*, const void*, void*, void*, int, int, int, int,   \
                                         hipStream_t);                                                              \
-    template int radix_gap_t_bn<T>(const void*, const void*, void*, const float*, const float*, const float*, const float*, int,   \
-                                   int, int, int, hipStream_t);                                                    \
+    template int radix_gap_t_bn<T>(const void*, const void*, void*, const float*, const float*, float*, float*, float*, float*,    \
+                                   long long*, const float*, int, float, float, int, int, int, int, hipStream_t);  \
     template int radix_mix_logits_bn<T>(const void*, const void*, const void*, void*, void*, const float*, const float*,           \
                                         const float*, const float*, int, int, int, int, hipStream_t);              \
     template int radix_mix_bwd_reduce_bn<T>(const void*, const void*, const void*, const void*, void*, float*, const float*,       \

@@ -530,7 +530,12 @@ int cot_radix_mix_backward_apply_lay(const void* gout, const void* attn, const v
  *   cot_bn_batch_stats               the statistics of cot_bn_act_forward alone: save_mean / save_rstd [C], running statistics and
  *                                    num_batches_tracked updated as there (bit-identical to its streaming kernels' values).
  *                                    workspace: cot_bn_act_workspace(N, C) floats
- *   cot_radix_gap_t_bn               gapT[c][n] = mean_hw(silu(bn(a)) + k)
+ *   cot_bn_stats_sums                chunk sums of x about a per-channel shift into `workspace` (cot_bn_act_workspace(N, C) floats, 16-byte
+ *                                    aligned): what cot_radix_gap_t_bn's prologue finalizes -- statistics without a finalize launch
+ *   cot_radix_gap_t_bn               gapT[c][n] = mean_hw(silu(bn(a)) + k).  workspace != NULL (cot_bn_stats_sums' output): the prologue
+ *                                    finalizes the statistics and save_mean / save_rstd / the running statistics / num_batches_tracked
+ *                                    are WRITTEN as by cot_bn_act_forward; NULL: save_mean / save_rstd are read (cot_bn_batch_stats,
+ *                                    cot_bn_rowstats_finalize)
  *   cot_radix_mix_logits_bn          cot_radix_mix_logits on silu(bn(a))
  *   cot_radix_mix_backward_reduce_bn cot_radix_mix_backward_reduce + tsum[c][n][0..3] (fp32, N*C*4 floats, 16-byte aligned) = a0 * sum_hw
  *                                    g*s', sum_hw s', a0 * sum_hw g*s'*xhat, sum_hw s'*xhat with s' = silu'(z), xhat = (a - mean)*rstd: the
@@ -552,8 +557,10 @@ int cot_bn_rowstats_finalize(const float* rowstats, float* save_mean, float* sav
 int cot_bn_batch_stats(const void* x, float* save_mean, float* save_rstd, float* running_mean, float* running_var,
                        int64_t* num_batches_tracked, float* workspace, int N, int C, int HW, float eps, float momentum, int dtype,
                        void* stream);
-int cot_radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, const float* save_mean,
-                       const float* save_rstd, int N, int C, int HW, int lay, int dtype, void* stream);
+int cot_bn_stats_sums(const void* x, float* workspace, int N, int C, int HW, int dtype, void* stream);
+int cot_radix_gap_t_bn(const void* a, const void* k, void* gapT, const float* gamma, const float* beta, float* save_mean,
+                       float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* workspace,
+                       int N, int C, int HW, float eps, float momentum, int lay, int dtype, void* stream);
 int cot_radix_mix_logits_bn(const void* a, const void* k, const void* logitsT, void* out, void* attn, const float* gamma,
                             const float* beta, const float* save_mean, const float* save_rstd, int N, int C, int HW, int lay, int dtype,
                             void* stream);

@@ -61,7 +61,9 @@ def main():
             "bwd_apply": lambda d: L.cot_radix_mix_backward_apply(P(d["g"]), P(d["attn"]), P(d["ggap"]), P(d["gy"]), P(d["gk"]), N, C, HW, BF, None),
             "bn_bwd(silu)": lambda d: L.cot_bn_act_backward(P(d["gy"]), P(d["a"]), None, P(d["ga"]), None, P(d["gamma"]), P(d["beta"]), *st(d), P(d["dg"]), P(d["db"]), P(d["ws"]), N, C, HW, 2, BF, None),
             "batch_stats": lambda d: L.cot_bn_batch_stats(P(d["a"]), *st(d), P(d["rm"]), P(d["rv"]), P(d["nbt"]), P(d["st"][2 * C:]), N, C, HW, 1e-5, 0.1, BF, None),
-            "gap_t_bn": lambda d: L.cot_radix_gap_t_bn(P(d["a"]), P(d["k"]), P(d["gap"]), P(d["gamma"]), P(d["beta"]), *st(d), N, C, HW, 0, BF, None),
+            "gap_t_bn": lambda d: L.cot_radix_gap_t_bn(P(d["a"]), P(d["k"]), P(d["gap"]), P(d["gamma"]), P(d["beta"]), *st(d), None, None, None, None, N, C, HW, 1e-5, 0.1, 0, BF, None),
+            "stats_sums": lambda d: L.cot_bn_stats_sums(P(d["a"]), P(d["st"][2 * C:]), N, C, HW, BF, None),
+            "gap_t_bn(fin)": lambda d: L.cot_radix_gap_t_bn(P(d["a"]), P(d["k"]), P(d["gap"]), P(d["gamma"]), P(d["beta"]), *st(d), P(d["rm"]), P(d["rv"]), P(d["nbt"]), P(d["st"][2 * C:]), N, C, HW, 1e-5, 0.1, 0, BF, None),
             "mix_logits_bn": lambda d: L.cot_radix_mix_logits_bn(P(d["a"]), P(d["k"]), P(d["logits"]), P(d["out"]), P(d["attn"]), P(d["gamma"]), P(d["beta"]), *st(d), N, C, HW, 0, BF, None),
             "bwd_reduce_bn": lambda d: L.cot_radix_mix_backward_reduce_bn(P(d["g"]), P(d["a"]), P(d["k"]), P(d["attn"]), P(d["glog"]), P(d["tsum"]), P(d["gamma"]), P(d["beta"]), *st(d), N, C, HW, 0, BF, None),
             "bwd_apply_bn": lambda d: L.cot_radix_mix_backward_apply_bn(P(d["g"]), P(d["a"]), P(d["attn"]), P(d["ggap"]), P(d["tsum"]), P(d["ga"]), P(d["gk"]), P(d["gamma"]), P(d["beta"]), *st(d), P(d["dg"]), P(d["db"]), N, C, HW, 0, BF, None),
@@ -74,7 +76,7 @@ def main():
                     raise RuntimeError(nm + ": " + L.cot_last_error().decode())
             t[nm] = timeit(chk, sets)
         sep = t["bn_fwd(silu)"] + t["gap_t"] + t["mix_logits"], t["bwd_reduce"] + t["bwd_apply"] + t["bn_bwd(silu)"]
-        fus = t["batch_stats"] + t["gap_t_bn"] + t["mix_logits_bn"], t["bwd_reduce_bn"] + t["bwd_apply_bn"]
+        fus = t["stats_sums"] + t["gap_t_bn(fin)"] + t["mix_logits_bn"], t["bwd_reduce_bn"] + t["bwd_apply_bn"]
         print(f"N{N} C{C} {H}x{W}: " + "  ".join(f"{k} {v:.1f}" for k, v in t.items()))
         print(f"    forward separate {sep[0]:.1f} us -> folded {fus[0]:.1f};  backward separate {sep[1]:.1f} -> folded {fus[1]:.1f}")
         if diff:

@@ -11,7 +11,7 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def bn_tail_case(L, N, C, H, W, dtype, lay_k, seed=21):
+def bn_tail_case(L, N, C, H, W, dtype, lay_k, sums=False, seed=21):
     """cot_bn_batch_stats + cot_radix_*_bn (BatchNorm + SiLU folded into the radix tail, models/cotnet.py:89-104) through library `L`
     on CPU tensors: forward against the unfused composition (cot_bn_act_forward, then cot_radix_gap_t / _mix_logits) -- bit for bit when
     the unfused call ran the streaming kernels, whose statistics the fused prologue repeats -- and both directions against torch autograd
@@ -44,13 +44,18 @@ def bn_tail_case(L, N, C, H, W, dtype, lay_k, seed=21):
     out0, attn0 = torch.empty_like(a), torch.empty(N, C, 2, dtype=dtype, device=dev)
     assert L.cot_radix_mix_logits_lay(P(y), P(kb), P(logitsT), P(out0), P(attn0), N, C, HW, 6 if lay_k else 0, dt, None) == 0
 
-    # fused: the statistics alone, y formed on load
+    # fused: the statistics alone (either route), y formed on load
     mean, rstd, ws = f32(C), f32(C), f32(max(nws, 1))
     rm, rv, nbt = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
-    assert L.cot_bn_batch_stats(P(a), P(mean), P(rstd), P(rm), P(rv), P(nbt), P(ws), N, C, HW, eps, mom, dt, None) == 0, L.cot_last_error()
     gap = torch.empty(C, N, dtype=dtype, device=dev)
-    assert L.cot_radix_gap_t_bn(P(a), P(kb), P(gap), P(gamma), P(beta), P(mean), P(rstd), N, C, HW, 2 if lay_k else 0, dt,
-                                None) == 0, L.cot_last_error()
+    if sums:  # chunk sums, finalized in the pooling kernel's prologue (the nodes' route)
+        assert L.cot_bn_stats_sums(P(a), P(ws), N, C, HW, dt, None) == 0, L.cot_last_error()
+        assert L.cot_radix_gap_t_bn(P(a), P(kb), P(gap), P(gamma), P(beta), P(mean), P(rstd), P(rm), P(rv), P(nbt), P(ws), N, C, HW, eps,
+                                    mom, 2 if lay_k else 0, dt, None) == 0, L.cot_last_error()
+    else:     # statistics finalized by their own launches, read by the pooling kernel
+        assert L.cot_bn_batch_stats(P(a), P(mean), P(rstd), P(rm), P(rv), P(nbt), P(ws), N, C, HW, eps, mom, dt, None) == 0, L.cot_last_error()
+        assert L.cot_radix_gap_t_bn(P(a), P(kb), P(gap), P(gamma), P(beta), P(mean), P(rstd), None, None, None, None, N, C, HW, eps, mom,
+                                    2 if lay_k else 0, dt, None) == 0, L.cot_last_error()
     out, attn = torch.empty_like(a), torch.empty(N, C, 2, dtype=dtype, device=dev)
     assert L.cot_radix_mix_logits_bn(P(a), P(kb), P(logitsT), P(out), P(attn), P(gamma), P(beta), P(mean), P(rstd), N, C, HW,
                                      6 if lay_k else 0, dt, None) == 0, L.cot_last_error()

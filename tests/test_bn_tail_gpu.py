@@ -20,17 +20,19 @@ def _lib_on_device():
     return L
 
 
+@pytest.mark.parametrize("sums", [0, 1])
 @pytest.mark.parametrize("lay_k", [0, 1])
 @pytest.mark.parametrize("shape", STEP + SMALL)
-def test_bn_tail_bf16(shape, lay_k):
-    bn_tail_case(_lib_on_device(), *shape, torch.bfloat16, lay_k)
+def test_bn_tail_bf16(shape, lay_k, sums):
+    bn_tail_case(_lib_on_device(), *shape, torch.bfloat16, lay_k, bool(sums))
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("sums", [0, 1])
 @pytest.mark.parametrize("lay_k", [0, 1])
 @pytest.mark.parametrize("shape", SMALL + [(8, 64, 56, 56)])
-def test_bn_tail_fp32(shape, lay_k):
-    bn_tail_case(_lib_on_device(), *shape, torch.float32, lay_k)
+def test_bn_tail_fp32(shape, lay_k, sums):
+    bn_tail_case(_lib_on_device(), *shape, torch.float32, lay_k, bool(sums))
     torch.cuda.synchronize()
 
 
