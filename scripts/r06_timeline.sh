@@ -5,4 +5,4 @@ export TMPDIR=/tmp
 rm -rf /tmp/prof/out; mkdir -p /tmp/prof && cd /tmp/prof && COT_ROCTX=1 timeout 400 rocprofv3 --kernel-trace --marker-trace --output-format csv \
     -d /tmp/prof/out -o trace -- python $GRAFT_REPO_ROOT/bench.py --kernels new --steps 5 --warmup 4 --no-cpu-baseline --no-kernel-timing --no-secondary --no-pmc "$@" > /tmp/prof/log 2>&1
 cd $GRAFT_REPO_ROOT
-python scripts/trace_timeline.py /tmp/prof/out --steps 5 | tee gpurun_out/r06_timeline.log
+python scripts/trace_timeline.py /tmp/prof/out --steps 5 --gaps 120 | tee gpurun_out/r06_timeline.log

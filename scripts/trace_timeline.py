@@ -15,6 +15,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("path")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--gaps", type=int, default=0, help="list the N largest idle gaps with their neighbours")
+    ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     files = [a.path] if os.path.isfile(a.path) else glob.glob(os.path.join(a.path, "**", "*kernel_trace.csv"), recursive=True)
     ev = []
@@ -55,6 +57,24 @@ def main():
     print(f"  union busy {union:.3f} ms ({union / a.steps:.3f} per step); idle {wall - union:.3f} ms in {len(gaps)} gaps: "
           f"{sum(1 for g in gaps if g < 2)} under 2 us, {sum(1 for g in gaps if 2 <= g < 10)} of 2-10 us, {sum(1 for g in gaps if g >= 10)} over 10 us "
           f"(largest {max(gaps) if gaps else 0:.1f} us)")
+    # the largest idle gaps of the union: which kernel ended last before the gap, which started after it (fork / join points, graph launch)
+    if a.gaps:
+        ends = sorted(ev, key=lambda x: x[1])
+        import bisect
+        end_ts = [x[1] for x in ends]
+        big = sorted(((merged[i + 1][0] - merged[i][1], merged[i][1], merged[i + 1][0]) for i in range(len(merged) - 1)), reverse=True)[:a.gaps]
+        starts = {x[0]: x for x in ev}
+        short = lambda n: n.split("(")[0].replace("void cot::", "").replace("cot::", "")[:46]  # noqa: E731
+        hist = {}
+        for g, te, ts in sorted(big, key=lambda x: x[1]):
+            before = ends[bisect.bisect_right(end_ts, te) - 1]
+            after = starts[ts]
+            hist[(short(before[3]), short(after[3]))] = hist.get((short(before[3]), short(after[3])), 0) + g / 1e3
+            if a.verbose:
+                print(f"    gap {g / 1e3:6.1f} us at +{(te - t0) / 1e6:8.3f} ms: after {short(before[3])} [q{before[2]}] -> before {short(after[3])} [q{after[2]}]")
+        print(f"  the {len(big)} largest gaps by (kernel before, kernel after), us summed:")
+        for k, v in sorted(hist.items(), key=lambda kv: -kv[1])[:25]:
+            print(f"    {v:8.1f}  {k[0]} -> {k[1]}")
     # per-queue gaps on the busiest queue: dependent-launch boundaries
     q0 = max(queues.items(), key=lambda kv: len(kv[1]))[1]
     q0.sort()
