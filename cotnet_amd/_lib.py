@@ -140,9 +140,6 @@ SYMBOLS = {
     "cot_radix_mix_logits_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_reduce_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
     "cot_radix_mix_backward_apply_lay": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P]),
-    "cot_se_fc_bn_covers": (_I, [_I, _I, _I, _I]),
-    "cot_se_fc_bn_forward": (_I, [_P] * 12 + [_I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _P]),
-    "cot_se_fc_bn_backward": (_I, [_P] * 9 + [_I, _I, _I, _I, _P]),
     "cot_agg_rowstats_floats": (ctypes.c_int64, [_I, _I, _I]),
     "cot_agg_forward_rowstats": (_I, [_P] * 8 + [_I, _G, _I, _P]),
     "cot_bn_rowstats_finalize": (_I, [_P] * 6 + [_I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),

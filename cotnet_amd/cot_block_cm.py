@@ -244,8 +244,9 @@ class _BottleneckCMNode(Function):
             clf._tail_gap(L, a, k, gapT, bnl, s_y, y_final, N, C, HW, 2)
         else:
             _ck(L.cot_radix_gap_t_lay(_p(y), _p(k), _p(gapT), N, C, HW, 2, BF16, st), "cot_radix_gap_t_lay")
+        _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st), "cot_conv1x1_forward")
         s_a = stat(A, nws_a)
-        clf._se_fc1_bn(L, pl, gapT, hpre, h, s_a, nws_a, N, C, A)
+        _bn_fwd(L, hpre, h, pl.sebn, s_a, 2 * A, 1, A, N, 1)
         _ck(L.cot_conv1x1_forward(_p(h), None, A, _p(pl.se3.weight), _p(pl.se3.bias), _p(logitsT), 1, A, 2 * C, N, BF16, st),
             "cot_conv1x1_forward")
         attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
@@ -336,7 +337,7 @@ class _BottleneckCMNode(Function):
         side.run(lambda st_, a_=(_p(g_c3), _p(cot_out), None, C, _p(g_w3c), None, _p(side.ws), 1, C, Cout, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c3, cot_out)
         # radix mix -> pair-softmax backward -> se branch -> gap
         row = lambda c: torch.empty((c, N), dtype=a1.dtype, device=dev)  # noqa: E731
-        glogT, ggapT = row(2 * C), row(C)
+        glogT, gh, ggapT = row(2 * C), row(A), row(C)
         bnl = pl.bn
         if y is None:  # (the forward folded bn + swish into the tail: so does the backward)
             tsum = torch.empty(N * C * 4, dtype=torch.float32, device=dev)
@@ -345,10 +346,11 @@ class _BottleneckCMNode(Function):
         else:
             _ck(L.cot_radix_mix_backward_reduce_lay(_p(g_out), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, 1 | 4, BF16, st),
                 "cot_radix_mix_backward_reduce_lay")
+        _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st), "cot_conv1x1_backward_data")
         g_w3, g_b3 = grad_sink.out_like(se3.weight), grad_sink.out_like(se3.bias)
         side.run(lambda st_, a_=(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(side.ws), 1, A, 2 * C, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), glogT, h)
         ghpre = row(A)
-        d_sa_w, d_sa_b = clf._se_fc2_dgrad_bn(L, pl, glogT, hpre, ghpre, s_a, nws_a, ws, N, C, A)
+        d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, None, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
         _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st), "cot_conv1x1_backward_data")
         g_w0, g_b0 = grad_sink.out_like(se0.weight), grad_sink.out_like(se0.bias)
         side.run(lambda st_, a_=(_p(ghpre), _p(gapT), None, C, _p(g_w0), _p(g_b0), _p(side.ws), 1, C, A, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ghpre, gapT)

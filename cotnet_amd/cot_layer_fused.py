@@ -258,48 +258,6 @@ def _agg_fwd_stats(L, v, w_or_logits, a, gn, gn_mean, gn_rstd, geom, bn, stats, 
     return False
 
 
-# the se branch's fc1 -> BatchNorm -> ReLU, and fc2's data gradient -> that BatchNorm's backward, as one launch each (cot_se_fc_bn_*:
-# two of the six dependent tiny launches per block off the step's critical path; bit-identical to the separate calls).  COT_SE_FUSED=0 opts out.
-SE_FUSED = os.environ.get("COT_SE_FUSED", "1") != "0"
-_SE_OK = _lib.register_cache({})
-
-
-def _se_covers(L, C, A, N):
-    k = (C, A, N)
-    v = _SE_OK.get(k)
-    if v is None:
-        v = _SE_OK[k] = bool(L.cot_se_fc_bn_covers(C, A, N, BF16))
-    return v
-
-
-def _se_fc1_bn(L, pl, gapT, hpre, h, s_a, nws_a, N, C, A):
-    """hpre = se[0](gapT); h = relu(se[1](hpre)) -- descriptors channel-major [.][N] (models/cotnet.py:71-77, :98-99)"""
-    st = _stream()
-    bn = pl.sebn
-    if SE_FUSED and _se_covers(L, C, A, N):
-        _ck(L.cot_se_fc_bn_forward(_p(gapT), _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), _p(h), _p(bn.weight), _p(bn.bias), _p(s_a), _p(s_a[A:]),
-                                   _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), C, A, N, float(bn.eps),
-                                   float(bn.momentum), BF16, st), "cot_se_fc_bn_forward")
-        return
-    _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st), "cot_conv1x1_forward")
-    _bn_fwd(L, hpre, h, bn, s_a, 2 * A, 1, A, N, 1)
-
-
-def _se_fc2_dgrad_bn(L, pl, glogT, hpre, ghpre, s_a, nws_a, ws, N, C, A):
-    """ghpre = d loss / d hpre from glogT through se[3]'s data gradient and se[1] + ReLU's backward -> (dgamma, dbeta) of se[1]"""
-    st = _stream()
-    bn = pl.sebn
-    if SE_FUSED and _se_covers(L, C, A, N):
-        dg, db = grad_sink.out_like(bn.weight), grad_sink.out_like(bn.bias)
-        _ck(L.cot_se_fc_bn_backward(_p(glogT), _p(pl.se3.weight), _p(hpre), _p(ghpre), _p(bn.weight), _p(bn.bias), _p(s_a[A:]), _p(dg), _p(db),
-                                    A, 2 * C, N, BF16, st), "cot_se_fc_bn_backward")
-        return dg, db
-    gh = torch.empty_like(ghpre)
-    _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(pl.se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st),
-        "cot_conv1x1_backward_data")
-    return _bn_bwd(L, gh, hpre, None, ghpre, bn, s_a, 1, A, N, 1, nws_a)
-
-
 def _tail_gap(L, a, k, gapT, bn, stats, final, N, C, HW, lay):
     """gapT = mean_hw(silu(bn(a)) + k); final False: stats[2C:] holds cot_bn_stats_sums' chunk sums and this launch finalizes them"""
     _ck(L.cot_radix_gap_t_bn(_p(a), _p(k), _p(gapT), _p(bn.weight), _p(bn.bias), _p(stats), _p(stats[C:]), _p(bn.running_mean),
@@ -736,8 +694,10 @@ def _cot_forward(L, layer, x):
         _tail_gap(L, a, k, gapT, bnl, s_y, y_final, N, C, HW, 0)
     else:
         _ck(L.cot_radix_gap_t(_p(y), _p(k), _p(gapT), N, C, HW, BF16, st), "cot_radix_gap_t")
+    _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(pl.se0.weight), _p(pl.se0.bias), _p(hpre), 1, C, A, N, BF16, st),
+        "cot_conv1x1_forward")
     s_a = stat(A, nws_a)
-    _se_fc1_bn(L, pl, gapT, hpre, h, s_a, nws_a, N, C, A)
+    _bn_fwd(L, hpre, h, pl.sebn, s_a, 2 * A, 1, A, N, 1)
     _ck(L.cot_conv1x1_forward(_p(h), None, A, _p(pl.se3.weight), _p(pl.se3.bias), _p(logitsT), 1, A, 2 * C, N, BF16,
                               st), "cot_conv1x1_forward")
     attn = torch.empty((N, C, 2), dtype=x.dtype, device=dev)
@@ -780,7 +740,7 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
 
     # radix mix -> pair-softmax backward -> se branch (two 1x1 convolutions over the batch axis) -> gap
     row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
-    glogT, ggapT = row(2 * C), row(C)
+    glogT, gh, ggapT = row(2 * C), row(A), row(C)
     bnl = pl.bn
     if y is None:  # (the forward folded bn + swish into the tail: so does the backward)
         tsum = torch.empty(N * C * 4, dtype=torch.float32, device=dev)
@@ -789,10 +749,12 @@ def _cot_backward(L, layer, saved, geom, gout, side=None):
     else:
         _ck(L.cot_radix_mix_backward_reduce(_p(gout), _p(y), _p(k), _p(attn), _p(glogT), N, C, HW, BF16, st),
             "cot_radix_mix_backward_reduce")
+    _ck(L.cot_conv1x1_backward_data(_p(glogT), _p(se3.weight), _p(gh), None, A, 0, _p(ws), 1, A, 2 * C, N, BF16, st),
+        "cot_conv1x1_backward_data")
     g_w3, g_b3 = grad_sink.out_like(se3.weight), grad_sink.out_like(se3.bias)
     side.run(lambda st_, a_=(_p(glogT), _p(h), None, A, _p(g_w3), _p(g_b3), _p(side.ws), 1, A, 2 * C, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), glogT, h)
     ghpre = row(A)
-    d_sa_w, d_sa_b = _se_fc2_dgrad_bn(L, pl, glogT, hpre, ghpre, s_a, nws_a, ws, N, C, A)
+    d_sa_w, d_sa_b = _bn_bwd(L, gh, hpre, None, ghpre, sebn, s_a, 1, A, N, 1, nws_a)
     _ck(L.cot_conv1x1_backward_data(_p(ghpre), _p(se0.weight), _p(ggapT), None, C, 0, _p(ws), 1, C, A, N, BF16, st),
         "cot_conv1x1_backward_data")
     g_w0, g_b0 = grad_sink.out_like(se0.weight), grad_sink.out_like(se0.bias)

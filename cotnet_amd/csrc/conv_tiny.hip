@@ -156,136 +156,6 @@ __global__ __launch_bounds__(256) void tiny_wgrad(const bf16_t* __restrict__ gy,
     }
 }
 
-// ---- the se branch's first half as ONE launch each way (round 6): fc1 -> BatchNorm over the batch -> ReLU (models/cotnet.py:71-77: se[0],
-// se[1], se[2]) and, backward, fc2's data gradient -> that BatchNorm's backward.  The five tiny launches between the pooled descriptor and
-// the radix mix are each a dependent launch on the step's critical path -- 4.2-5.3 us for ~1 us of work -- and the BatchNorm (statistics
-// over the N "pixels" = the batch) is the one with a cross-tile dependency: a workgroup that owns 16 channels for ALL N pixels (one wave
-// per 16-pixel tile, N <= 128) has every sample of its channels and needs nobody else.  The convolution part is tiny_fwd / tiny_dgrad with
-// the reduction kept inside a wave; the BatchNorm part repeats bn_small_fwd / bn_small_bwd (bn_act.hip: fp64, lane l takes samples
-// l, l + 64, same butterfly) on the tile's bf16-rounded values, so both halves give the separate kernels' bits.
-__device__ __forceinline__ double wave_allsum_dd(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// hpre[m][n] = bf16(sum_k w[m][k] x[k][n] + b[m]);  h = relu(bn(hpre)) over n;  one workgroup per 16 channels m, wave v = pixels 16v..
-__global__ __launch_bounds__(512) void tiny_fwd_bn(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
-                                                  bf16_t* __restrict__ hpre, bf16_t* __restrict__ h, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
-                                                  float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt, int K,
-                                                  int M, int N, float eps, float mom) {
-    __shared__ float tile[16][128];
-    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * 16, n0 = wv * 16;
-    const int mr = min(m0 + i, M - 1), nc = min(n0 + i, N - 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        const int kb = k0 + 8 * g;
-        const bf16x8_t a = vec8(w + (int64_t)mr * K + min(kb, K - 8), kb < K);
-        const bf16x8_t b = gather8(x + (int64_t)min(kb, K - 8) * N + nc, N, kb < K ? 8 : 0);
-        acc = COT_MFMA_16X16X32_BF16(a, b, acc);
-    }
-    const int n = n0 + i;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ml = 4 * g + r, m = m0 + ml;
-        const bf16_t v = (bf16_t)(acc[r] + ((bias && m < M) ? (float)bias[m] : 0.f));
-        if (n < N) {
-            tile[ml][n] = (float)v;
-            if (m < M) hpre[(int64_t)m * N + n] = v;
-        }
-    }
-    __syncthreads();
-    for (int ml = wv; ml < 16; ml += nw) {  // a wave per channel, as bn_small_fwd
-        const int m = m0 + ml;
-        if (m >= M) break;
-        double sm = 0.0;
-        for (int e = lane; e < N; e += 64) sm += (double)tile[ml][e];
-        const double mu = wave_allsum_dd(sm) / N;
-        double m2 = 0.0;
-        for (int e = lane; e < N; e += 64) {
-            const double d = (double)tile[ml][e] - mu;
-            m2 += d * d;
-        }
-        m2 = wave_allsum_dd(m2);
-        const double var = m2 / N, r = 1.0 / sqrt(var + (double)eps);
-        if (lane == 0) {
-            mean[m] = (float)mu;
-            rstd[m] = (float)r;
-            if (rmean) {
-                const double unbiased = N > 1 ? m2 / (N - 1) : var;
-                rmean[m] = (float)((1.0 - mom) * rmean[m] + mom * mu);
-                rvar[m] = (float)((1.0 - mom) * rvar[m] + mom * unbiased);
-            }
-        }
-        const double ga = gamma[m], be = beta[m];
-        for (int e = lane; e < N; e += 64) {
-            double z = ((double)tile[ml][e] - mu) * r * ga + be;
-            z = z > 0.0 ? z : 0.0;
-            h[(int64_t)m * N + e] = (bf16_t)(float)z;
-        }
-    }
-}
-
-// gh[k][n] = bf16(sum_m w[m][k] gy[m][n]) (fc2's data gradient, not stored); ghpre = the BatchNorm + ReLU backward of gh over n, with the
-// statistics recomputed from hpre in fp64 as bn_small_bwd does.  One workgroup per 16 channels k, wave v = pixels 16v..
-__global__ __launch_bounds__(512) void tiny_dgrad_bn(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ w,
-                                                    const bf16_t* __restrict__ hpre, bf16_t* __restrict__ ghpre,
-                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                    int K, int M, int N) {
-    __shared__ float tile[16][128];
-    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * 16, n0 = wv * 16;
-    const int kr = min(k0 + i, K - 1), nc = min(n0 + i, N - 1);
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int mb = 0; mb < M; mb += 32) {
-        const int m = mb + 8 * g, cnt = M - m;
-        const int ms = min(m, M - 1);
-        const bf16x8_t a = gather8(w + (int64_t)ms * K + kr, K, cnt);
-        const bf16x8_t b = gather8(gy + (int64_t)ms * N + nc, N, cnt);
-        acc = COT_MFMA_16X16X32_BF16(a, b, acc);
-    }
-    const int n = n0 + i;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (n < N) tile[4 * g + r][n] = (float)(bf16_t)acc[r];
-    __syncthreads();
-    for (int kl = wv; kl < 16; kl += nw) {
-        const int k = k0 + kl;
-        if (k >= K) break;
-        const bf16_t* xp = hpre + (int64_t)k * N;
-        double sm = 0.0;
-        for (int e = lane; e < N; e += 64) sm += (double)(float)xp[e];
-        const double mu = wave_allsum_dd(sm) / N, r = (double)rstd[k], ga = gamma[k], be = beta[k];
-        double sg = 0.0, sgx = 0.0;
-        for (int e = lane; e < N; e += 64) {
-            const double xh = ((double)(float)xp[e] - mu) * r, z = xh * ga + be;
-            const double gg = z > 0.0 ? (double)tile[kl][e] : 0.0;
-            sg += gg;
-            sgx += gg * xh;
-        }
-        sg = wave_allsum_dd(sg);
-        sgx = wave_allsum_dd(sgx);
-        if (lane == 0) {
-            dbeta[k] = (float)sg;
-            dgamma[k] = (float)sgx;
-        }
-        const double k1 = sg / N, k2 = sgx / N;
-        for (int e = lane; e < N; e += 64) {
-            const double xh = ((double)(float)xp[e] - mu) * r, z = xh * ga + be;
-            const double gg = z > 0.0 ? (double)tile[kl][e] : 0.0;
-            ghpre[(int64_t)k * N + e] = (bf16_t)(float)(ga * r * (gg - k1 - xh * k2));
-        }
-    }
-}
-
 }  // namespace tiny
 
 // one image, few pixels, one tensor each side, bf16 (checked by the caller), reduction lengths on 8-element chunks
@@ -313,24 +183,6 @@ int conv_tiny_backward_weight(const void* gy, const void* x, void* gw, void* gb,
     COT_LAUNCH(tiny::tiny_wgrad, dim3(ceil_div(total, 4)), dim3(256), 0, stream, (const bf16_t*)gy, (const bf16_t*)x,
                (bf16_t*)gw, (bf16_t*)gb, Ci, Co, HW, ktiles, total);
     return check_launch("tiny_wgrad");
-}
-
-// the fused se halves: bf16, one image whose N <= 128 pixels are the batch, reduction lengths on 8-element chunks
-bool conv_tiny_bn_covers(int Ci, int Co, int HW) { return g_conv_tiny && HW >= 1 && HW <= 128 && Ci % 8 == 0 && Ci >= 8 && Co >= 1; }
-
-int conv_tiny_forward_bn(const void* x, const void* w, const void* bias, void* hpre, void* h, const float* gamma, const float* beta,
-                         float* mean, float* rstd, float* rmean, float* rvar, long long* nbt, int Ci, int Co, int HW, float eps, float mom,
-                         hipStream_t stream) {
-    COT_LAUNCH(tiny::tiny_fwd_bn, dim3(ceil_div(Co, 16)), dim3(64 * ceil_div(HW, 16)), 0, stream, (const bf16_t*)x, (const bf16_t*)w,
-               (const bf16_t*)bias, (bf16_t*)hpre, (bf16_t*)h, gamma, beta, mean, rstd, rmean, rvar, nbt, Ci, Co, HW, eps, mom);
-    return check_launch("tiny_fwd_bn");
-}
-
-int conv_tiny_backward_data_bn(const void* gy, const void* w, const void* hpre, void* ghpre, const float* gamma, const float* beta,
-                               const float* rstd, float* dgamma, float* dbeta, int Ci, int Co, int HW, hipStream_t stream) {
-    COT_LAUNCH(tiny::tiny_dgrad_bn, dim3(ceil_div(Ci, 16)), dim3(64 * ceil_div(HW, 16)), 0, stream, (const bf16_t*)gy, (const bf16_t*)w,
-               (const bf16_t*)hpre, (bf16_t*)ghpre, gamma, beta, rstd, dgamma, dbeta, Ci, Co, HW);
-    return check_launch("tiny_dgrad_bn");
 }
 
 }  // namespace cot

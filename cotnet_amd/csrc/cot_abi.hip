@@ -226,11 +226,6 @@ bool conv_tiny_covers(int N, int Ci, int Co, int HW);
 int conv_tiny_forward(const void*, const void*, const void*, void*, int, int, int, hipStream_t);
 int conv_tiny_backward_data(const void*, const void*, void*, int, int, int, int, hipStream_t);
 int conv_tiny_backward_weight(const void*, const void*, void*, void*, int, int, int, hipStream_t);
-bool conv_tiny_bn_covers(int Ci, int Co, int HW);
-int conv_tiny_forward_bn(const void*, const void*, const void*, void*, void*, const float*, const float*, float*, float*, float*, float*,
-                         long long*, int, int, int, float, float, hipStream_t);
-int conv_tiny_backward_data_bn(const void*, const void*, const void*, void*, const float*, const float*, const float*, float*, float*, int,
-                               int, int, hipStream_t);
 // implemented in conv_gen.hip (general grouped 1x1 / 3x3 convolutions, fp32 or bf16, any channel counts)
 int convg_forward(const void*, const void*, const void*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
 int convg_backward_data(const void*, const void*, void*, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -1162,31 +1157,6 @@ int cot_radix_mix_backward_apply_lay(const void* gout, const void* attn, const v
     if ((rc = check_align16({gout, gy, gk}))) return rc;
     return dtype == COT_F32 ? radix_mix_bwd_apply<float>(gout, attn, ggapT, gy, gk, N, C, HW, lay, (hipStream_t)stream)
                             : radix_mix_bwd_apply<bf16_t>(gout, attn, ggapT, gy, gk, N, C, HW, lay, (hipStream_t)stream);
-}
-
-// ---- the se branch's first half in one launch each way (conv_tiny.hip; models/cotnet.py:71-77, :98-99)
-int cot_se_fc_bn_covers(int C, int A, int N, int dtype) { return (dtype == COT_BF16 && C > 0 && A > 0 && conv_tiny_bn_covers(C, A, N)) ? 1 : 0; }
-int cot_se_fc_bn_forward(const void* gapT, const void* weight, const void* bias, void* hpre, void* h, const float* gamma, const float* beta,
-                         float* save_mean, float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int C,
-                         int A, int N, float eps, float momentum, int dtype, void* stream) {
-    if (!gapT || !weight || !hpre || !h || !gamma || !beta || !save_mean || !save_rstd)
-        return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
-    if ((running_mean == NULL) != (running_var == NULL))
-        return set_error(COT_ERR_INVALID_ARG, "running_mean and running_var must be given together");
-    if (!cot_se_fc_bn_covers(C, A, N, dtype))
-        return set_error(COT_ERR_UNSUPPORTED, "cot_se_fc_bn_forward: COT_BF16, C %% 8 == 0, N <= 128 (C=%d A=%d N=%d)", C, A, N);
-    int rc = check_align16({gapT, weight});
-    if (rc) return rc;
-    return conv_tiny_forward_bn(gapT, weight, bias, hpre, h, gamma, beta, save_mean, save_rstd, running_mean, running_var,
-                                (long long*)num_batches_tracked, C, A, N, eps, momentum, (hipStream_t)stream);
-}
-int cot_se_fc_bn_backward(const void* glogitsT, const void* weight2, const void* hpre, void* ghpre, const float* gamma, const float* beta,
-                          const float* save_rstd, float* dgamma, float* dbeta, int A, int C2, int N, int dtype, void* stream) {
-    if (!glogitsT || !weight2 || !hpre || !ghpre || !gamma || !beta || !save_rstd || !dgamma || !dbeta)
-        return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
-    if (!(dtype == COT_BF16 && A > 0 && C2 > 0 && conv_tiny_bn_covers(8, C2, N)))
-        return set_error(COT_ERR_UNSUPPORTED, "cot_se_fc_bn_backward: COT_BF16, N <= 128 (A=%d 2C=%d N=%d)", A, C2, N);
-    return conv_tiny_backward_data_bn(glogitsT, weight2, hpre, ghpre, gamma, beta, save_rstd, dgamma, dbeta, A, C2, N, (hipStream_t)stream);
 }
 
 // ---- BatchNorm + SiLU of the aggregation's output folded into the radix tail (radix_tail.hip; models/cotnet.py:88-104)

@@ -522,20 +522,6 @@ int cot_radix_mix_backward_reduce_lay(const void* gout, const void* y, const voi
                                       int C, int HW, int lay, int dtype, void* stream);
 int cot_radix_mix_backward_apply_lay(const void* gout, const void* attn, const void* ggapT, void* gy, void* gk, int N, int C,
                                      int HW, int lay, int dtype, void* stream);
-/* ---- the se branch's first half as one launch each way (round 6; models/cotnet.py:71-77 `self.se = Sequential(Conv2d(dim, attn_chs, 1),
- * BatchNorm2d, ReLU, Conv2d(attn_chs, radix*dim, 1))`, applied to the pooled descriptor :98-99).  Descriptors are channel-major: gapT [C][N],
- * hpre / h [A][N], glogitsT [2C][N]; N = the batch (<= 128), COT_BF16.  cot_se_fc_bn_covers == 0: use cot_conv1x1_forward +
- * cot_bn_act_forward (and cot_conv1x1_backward_data + cot_bn_act_backward), whose values these calls reproduce bit for bit.
- *   cot_se_fc_bn_forward   hpre = weight [A][C] . gapT + bias;  h = relu(bn(hpre)) with the batch statistics over N (fp64, as
- *                          cot_bn_act_forward's small-batch path); save_mean / save_rstd / running statistics / num_batches_tracked written
- *   cot_se_fc_bn_backward  gh = weight2^T [A][2C] . glogitsT (fc2's data gradient, not stored);  ghpre = BatchNorm + ReLU backward of gh
- *                          (statistics recomputed from hpre in fp64);  dgamma / dbeta [A] fp32 written */
-int cot_se_fc_bn_covers(int C, int A, int N, int dtype);
-int cot_se_fc_bn_forward(const void* gapT, const void* weight, const void* bias, void* hpre, void* h, const float* gamma, const float* beta,
-                         float* save_mean, float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int C,
-                         int A, int N, float eps, float momentum, int dtype, void* stream);
-int cot_se_fc_bn_backward(const void* glogitsT, const void* weight2, const void* hpre, void* ghpre, const float* gamma, const float* beta,
-                          const float* save_rstd, float* dgamma, float* dbeta, int A, int C2, int N, int dtype, void* stream);
 /* ---- BatchNorm + SiLU of the aggregation's output folded into the radix tail (round 6; replaces `x = self.bn(x); x = self.act(x)` +
  * the tail, models/cotnet.py:89-104, as ONE read of the raw aggregation output per consumer).  y = silu(bn(a)) has two readers, the
  * pooled descriptor and the radix mix; both take `a` and the BatchNorm's statistics and form y as they load (rounded to the storage

@@ -146,57 +146,3 @@ def rowstats_case(L, N, C, H, W, gn, seed=5):
     cnt = N * HW
     assert int(nbt) == 1 and torch.allclose(rm.cpu(), 0.1 * of.mean((0, 2, 3)), atol=1e-6, rtol=1e-5)
     assert torch.allclose(rv.cpu(), 0.9 + 0.1 * var * cnt / max(cnt - 1, 1), atol=1e-5, rtol=1e-5)
-
-
-def se_fc_bn_case(L, C, A, N, seed=3):
-    """cot_se_fc_bn_forward / _backward (the se branch's fc1 -> BatchNorm -> ReLU and fc2-dgrad -> BatchNorm backward as one launch each)
-    against the separate calls they replace, bit for bit (cot_conv1x1_forward + cot_bn_act_forward's small-batch path,
-    cot_conv1x1_backward_data + cot_bn_act_backward), and against torch autograd in fp32 on the same operands."""
-    torch.manual_seed(seed)
-    dev = getattr(L, "_test_device", "cpu")
-    dt = _lib.COT_BF16
-    bf = lambda t: t.bfloat16().to(dev)  # noqa: E731
-    f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-    gapT, w0, b0 = bf(torch.randn(C, N)), bf(torch.randn(A, C) / C ** 0.5), bf(0.1 * torch.randn(A))
-    w3, glog = bf(torch.randn(2 * C, A) / A ** 0.5), bf(torch.randn(2 * C, N))
-    gamma, beta = (1 + 0.3 * torch.randn(A)).to(dev), (0.2 * torch.randn(A)).to(dev)
-    assert L.cot_se_fc_bn_covers(C, A, N, dt) == 1
-    ws = torch.empty(max(int(L.cot_conv1x1_workspace(1, max(C, A), 2 * C, N, 1)), 16), dtype=torch.uint8, device=dev)
-    nws = max(int(L.cot_bn_act_workspace(1, A)), 1)
-
-    def state():
-        return torch.zeros(A, device=dev), torch.ones(A, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
-    # separate
-    hpre0, h0 = torch.empty(A, N, dtype=torch.bfloat16, device=dev), torch.empty(A, N, dtype=torch.bfloat16, device=dev)
-    m0, r0, (rm0, rv0, nbt0) = f32(A), f32(A), state()
-    assert L.cot_conv1x1_forward(P(gapT), None, C, P(w0), P(b0), P(hpre0), 1, C, A, N, dt, None) == 0, L.cot_last_error()
-    assert L.cot_bn_act_forward(P(hpre0), None, P(h0), P(gamma), P(beta), P(m0), P(r0), P(rm0), P(rv0), P(nbt0), P(f32(nws)), 1, A, N,
-                                1e-5, 0.1, 1, dt, None) == 0, L.cot_last_error()
-    gh0, ghpre0, dg0, db0 = torch.empty_like(h0), torch.empty_like(h0), f32(A), f32(A)
-    assert L.cot_conv1x1_backward_data(P(glog), P(w3), P(gh0), None, A, 0, P(ws), 1, A, 2 * C, N, dt, None) == 0, L.cot_last_error()
-    assert L.cot_bn_act_backward(P(gh0), P(hpre0), None, P(ghpre0), None, P(gamma), P(beta), P(m0), P(r0), P(dg0), P(db0), P(f32(nws)), 1, A,
-                                 N, 1, dt, None) == 0, L.cot_last_error()
-    # fused
-    hpre, h = torch.full_like(hpre0, float("nan")), torch.full_like(h0, float("nan"))
-    m, r, (rm, rv, nbt) = f32(A), f32(A), state()
-    assert L.cot_se_fc_bn_forward(P(gapT), P(w0), P(b0), P(hpre), P(h), P(gamma), P(beta), P(m), P(r), P(rm), P(rv), P(nbt), C, A, N, 1e-5,
-                                  0.1, dt, None) == 0, L.cot_last_error()
-    ghpre, dg, db = torch.full_like(h0, float("nan")), f32(A), f32(A)
-    assert L.cot_se_fc_bn_backward(P(glog), P(w3), P(hpre), P(ghpre), P(gamma), P(beta), P(r), P(dg), P(db), A, 2 * C, N, dt,
-                                   None) == 0, L.cot_last_error()
-    for nm, x, y in (("hpre", hpre, hpre0), ("h", h, h0), ("mean", m, m0), ("rstd", r, r0), ("running_mean", rm, rm0), ("running_var", rv, rv0),
-                     ("ghpre", ghpre, ghpre0), ("dgamma", dg, dg0), ("dbeta", db, db0)):
-        assert torch.equal(x, y), (nm, (x.float() - y.float()).abs().max().item())
-    assert int(nbt) == 1 == int(nbt0)
-    # the reference formula in fp32
-    g_r, w0_r = gapT.float().cpu().requires_grad_(True), w0.float().cpu()
-    hp = w0_r @ g_r + b0.float().cpu()[:, None]                       # [A][N]
-    hb = hp.detach().bfloat16().float().requires_grad_(True)           # (the BatchNorm sees the stored bf16 values)
-    ga_r, be_r = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
-    hh = torch.relu(torch.nn.functional.batch_norm(hb.t()[None].transpose(1, 2), None, None, ga_r, be_r, True, 0.0, 1e-5))[0]  # [A][N]
-    assert torch.allclose(h.float().cpu(), hh.detach(), atol=2e-2, rtol=2e-2)
-    gh_r = (w3.float().cpu().t() @ glog.float().cpu()).bfloat16().float()
-    hh.backward(gh_r)
-    sc = lambda t: float(t.abs().max()) + 1e-6  # noqa: E731
-    assert (ghpre.float().cpu() - hb.grad).abs().max() <= 2e-2 * sc(hb.grad)
-    assert (dg.cpu() - ga_r.grad).abs().max() <= 2e-3 * sc(ga_r.grad) and (db.cpu() - be_r.grad).abs().max() <= 2e-3 * sc(be_r.grad)

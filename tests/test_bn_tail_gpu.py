@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from cotnet_amd import _lib
-from tests.bn_tail_cases import bn_tail_case, rowstats_case, se_fc_bn_case
+from tests.bn_tail_cases import bn_tail_case, rowstats_case
 
 pytestmark = pytest.mark.gpu
 
@@ -43,12 +43,4 @@ def test_agg_forward_rowstats(shape, gn):
     if gn and shape[3] % 2:
         pytest.skip("the GroupNorm prologue takes even rows (cot_agg_gn9_forward)")
     rowstats_case(_lib_on_device(), *shape, gn)
-    torch.cuda.synchronize()
-
-
-@pytest.mark.parametrize("C,A,N", [(64, 32, 80), (128, 64, 80), (256, 128, 80), (512, 256, 80), (64, 32, 5), (72, 40, 17), (64, 24, 128), (32, 8, 33),
-                                   (512, 256, 64), (1024, 512, 64)])
-def test_se_fc_bn(C, A, N):
-    """cot_se_fc_bn_forward / _backward: bit-identical to cot_conv1x1_* + cot_bn_act_* on the se branch's shapes (CoTNet-50 B = 80, B = 64 widths)"""
-    se_fc_bn_case(_lib_on_device(), C, A, N)
     torch.cuda.synchronize()

@@ -12,7 +12,7 @@ import torch
 from cotnet_amd import _lib
 from oracle import cref, unfold_oracle
 from tests.emul import build_emul
-from tests.bn_tail_cases import bn_tail_case, rowstats_case, se_fc_bn_case
+from tests.bn_tail_cases import bn_tail_case, rowstats_case
 
 try:
     _EMUL = ctypes.CDLL(build_emul.build())
@@ -1657,13 +1657,6 @@ def test_radix_tail_bn_fused_kernels(N, C, H, W, dtype, lay_k, sums):
     # True: the bit-for-bit branch of the forward comparison ran (7 x 7 bf16 planes: the statistics pass reads 7 elements per lane where
     # the unfused streaming kernel reads one -- another summation order)
     assert same or sums or (dtype == torch.bfloat16 and (H * W) % 7 == 0 and (H * W) % 2 == 1)  # (sums: another formula for the variance)
-
-
-@pytest.mark.parametrize("C,A,N", [(64, 32, 80), (128, 64, 80), (64, 32, 5), (72, 40, 17), (256, 128, 16), (64, 24, 128), (32, 8, 33)])
-def test_se_fc_bn_fused_kernels(C, A, N):
-    """the se branch's fc1 -> BatchNorm -> ReLU and fc2-dgrad -> BatchNorm-backward launches: bit-identical to the separate kernels"""
-    _EMUL.cot_set_tuning(18, 256)  # (the separate BatchNorm on its small-batch fp64 path, as in the product)
-    se_fc_bn_case(_EMUL, C, A, N)
 
 
 @pytest.mark.parametrize("gn", [0, 1])
