@@ -22,6 +22,7 @@
 #include "conv_lds_common.h"
 
 namespace cot {
+extern int g_conv_ablate;  // (conv_lds2.hip; cot_set_tuning key 24)
 
 extern int g_conv_lds_tune[3];
 extern int g_conv_lds2_tune;
@@ -315,6 +316,7 @@ struct C3LdsArgs {
     int TR;            // BIG: image rows per tile
     int SL;            // BIG: staged elements per channel ((TR+2)*W + 8, rounded up to 8)
     int xcd_remap;
+    int ablate;        // DIAGNOSTIC (cot_set_tuning key 24 bit 1; results become wrong): the K loop skips its LDS operand gathers
 };
 
 // K16: KK == 16 (two taps per K step, 5 steps); else KK % 32 == 0 (9 steps per 32-channel chunk).  XP = X copies per thread
@@ -472,10 +474,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
             const int idx = min(max(abase[cb] + shift, 0), xelems - 7 * SLc - 1);  // masked positions: any staged element
             const uint16_t* p = xb + idx;
             u16x2_t q4[4];
+            if (a.ablate & 2) {
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh) {
-                q4[hh][0] = p[(2 * hh) * SLc];
-                q4[hh][1] = p[(2 * hh + 1) * SLc];
+                for (int hh = 0; hh < 4; ++hh) q4[hh][0] = q4[hh][1] = (uint16_t)(0x3c00 + lane);
+            } else {
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh) {
+                    q4[hh][0] = p[(2 * hh) * SLc];
+                    q4[hh][1] = p[(2 * hh + 1) * SLc];
+                }
             }
             // (a padded chunk's channels past the group's end belong to the next group: cleared by selection like the padded taps --
             // their weights are zeros, but 0 * Inf / NaN must not reach the sum; KX % 8 == 0, so a lane's 8 channels go together)
@@ -513,6 +520,7 @@ static int launch_c3n(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) {
     if (otile > lds) lds = otile;
     C3LdsArgs b = a;
     b.xcd_remap = (blocks % 8 == 0) ? 1 : 0;
+    b.ablate = g_conv_ablate;
     static std::atomic<uint32_t> raised{0};
     if (lds > 64 * 1024 &&
         !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv3x3g_lds_fwd<CB, MB, FLAT, K16, XP, WAVES, NSW>)))
@@ -696,11 +704,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
 #pragma unroll
                     for (int cb = 0; cb < CB; ++cb) {
                         uint32_t q[4];
+                        if (a.ablate & 2) {
 #pragma unroll
-                        for (int hh = 0; hh < 4; ++hh) {
-                            const uint32_t lo = *reinterpret_cast<const uint16_t*>(xr + aoff[cb][2 * hh] + 2 * dx);
-                            const uint32_t hi = *reinterpret_cast<const uint16_t*>(xr + aoff[cb][2 * hh + 1] + 2 * dx);
-                            q[hh] = lo | (hi << 16);
+                            for (int hh = 0; hh < 4; ++hh) q[hh] = 0x3c003c00u + lane;
+                        } else {
+#pragma unroll
+                            for (int hh = 0; hh < 4; ++hh) {
+                                const uint32_t lo = *reinterpret_cast<const uint16_t*>(xr + aoff[cb][2 * hh] + 2 * dx);
+                                const uint32_t hi = *reinterpret_cast<const uint16_t*>(xr + aoff[cb][2 * hh + 1] + 2 * dx);
+                                q[hh] = lo | (hi << 16);
+                            }
                         }
                         const uint32_t msk = (uint32_t)(((int32_t)(am[cb] << (31 - tap))) >> 31);  // all ones / zero
 #pragma unroll
@@ -727,11 +740,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
                     uint32_t q[4];
+                    if (a.ablate & 2) {
 #pragma unroll
-                    for (int hh = 0; hh < 4; ++hh) {
-                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(xb + aoff[cb][2 * hh] + sh);
-                        const uint32_t hi = *reinterpret_cast<const uint16_t*>(xb + aoff[cb][2 * hh + 1] + sh);
-                        q[hh] = lo | (hi << 16);
+                        for (int hh = 0; hh < 4; ++hh) q[hh] = 0x3c003c00u + lane;
+                    } else {
+#pragma unroll
+                        for (int hh = 0; hh < 4; ++hh) {
+                            const uint32_t lo = *reinterpret_cast<const uint16_t*>(xb + aoff[cb][2 * hh] + sh);
+                            const uint32_t hi = *reinterpret_cast<const uint16_t*>(xb + aoff[cb][2 * hh + 1] + sh);
+                            q[hh] = lo | (hi << 16);
+                        }
                     }
                     const uint32_t msk = (uint32_t)(((int32_t)(am[cb] << (31 - 2 * tp))) >> 31);
 #pragma unroll
@@ -784,6 +802,7 @@ static int launch_c3res(const C3LdsArgs& a, int64_t blocks, hipStream_t stream) 
     if (otile > lds) lds = otile;
     if (lds > 160 * 1024) return -1;
     b.xcd_remap = (blocks % 8 == 0) ? 1 : 0;
+    b.ablate = g_conv_ablate;
     static std::atomic<uint32_t> raised{0};
     if (lds > 64 * 1024 &&
         !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv3x3g_lds_res<CB, MB, FLAT, K16, XP, WAVES>)))
@@ -1283,6 +1302,7 @@ static int launch_c1(const C1LdsArgs& a, int tiles, hipStream_t stream) {
     const int64_t blocks = (int64_t)tiles * a.mblocks;
     C1LdsArgs b = a;
     b.xcd_remap = (blocks % 8 == 0) ? 1 : 0;
+    b.ablate = g_conv_ablate;
     static std::atomic<uint32_t> raised{0};  // more than the default dynamic-LDS window: opt in once per device and instantiation
     if (lds > 64 * 1024 &&
         !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv1x1_lds_fwd<CB, MB, FLAT, NS, WAVES, TRD, WT>)))
