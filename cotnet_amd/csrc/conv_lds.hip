@@ -253,6 +253,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
     e.y1 = a.y1; e.y2 = a.y2; e.bias = a.bias; e.m1 = a.m1; e.M = M; e.HW = HW; e.N = a.N; e.ni = a.ni;
     e.ys1 = a.ys1; e.ys2 = a.ys2; e.stats = nullptr; e.ptiles = 0;
     e.n0 = n0; e.p0 = p0; e.m0 = m0; e.mv = min(BM, M - m0); e.ncols = ncols; e.accumulate = a.accumulate;
+    e.ablate = 0;
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
@@ -506,6 +507,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
     e.y1 = a.y; e.y2 = nullptr; e.bias = nullptr; e.m1 = G * MM; e.M = G * MM; e.HW = HW; e.N = a.N; e.ni = a.ni;
     e.ys1 = (int64_t)G * MM * HW; e.ys2 = 0; e.stats = nullptr; e.ptiles = 0;
     e.n0 = n0; e.p0 = r0 * W; e.m0 = grp * MM; e.mv = MM; e.ncols = ncols; e.accumulate = a.accumulate;
+    e.ablate = 0;
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
@@ -774,6 +776,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
     e.y1 = a.y; e.y2 = nullptr; e.bias = nullptr; e.m1 = G * MM; e.M = G * MM; e.HW = HW; e.N = a.N; e.ni = a.ni;
     e.ys1 = (int64_t)G * MM * HW; e.ys2 = 0; e.stats = nullptr; e.ptiles = 0;
     e.n0 = n0; e.p0 = r0 * W; e.m0 = grp * MM; e.mv = MM; e.ncols = ncols; e.accumulate = a.accumulate;
+    e.ablate = 0;
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 

@@ -135,6 +135,8 @@ struct EpiArgs {
     int64_t ys1, ys2;    // elements from one image to the next in y1 / y2 (dense: m1 * HW, (M - m1) * HW; larger when the slab is
                          // a channel range of a wider tensor: one group of a grouped convolution)
     float* stats;        // NULL, or [N][ptiles][M][2]: per (image, pixel tile, channel) the sum and the sum of squares of the
+    int ablate;          // DIAGNOSTIC (cot_set_tuning key 24): bit 5 (32) = no epilogue at all (nothing stored); bit 6 (64) = BIG tiles without a bias /
+                         // second slab / accumulate / statistics: the accumulators stored directly (8 bytes per lane), no LDS round trip
     int ptiles;          // tile's outputs AS STORED (rounded to bf16) -- the statistics of the consumer's normalisation come out
                          // of the producing GEMM's epilogue (GroupNorm of the attention logits, cot_conv1x1_forward_gn9;
                          // SURVEY 7.6).  BIG tiles only.
@@ -146,6 +148,23 @@ __device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], cons
     extern __shared__ __attribute__((aligned(16))) char cot_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const int HW = a.HW, M = a.M, m0 = a.m0, n0 = a.n0, p0 = a.p0, ncols = a.ncols, mv = a.mv;
+    if (a.ablate & 32) return;
+    if (!FLAT && (a.ablate & 64) && !a.bias && !a.y2 && !a.accumulate && !a.stats) {
+#pragma unroll
+        for (int mbk = 0; mbk < MB; ++mbk) {
+            const int ml = mbk * 16 + i16;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const int col = (wave * CB + cb) * 16 + 4 * g;
+                bf16_t o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[cb][mbk][r];
+                if (ml < mv && col < ncols)
+                    __builtin_memcpy(__builtin_assume_aligned(a.y1 + (int64_t)n0 * a.ys1 + (int64_t)(m0 + ml) * HW + p0 + col, 8), o, 8);
+            }
+        }
+        return;
+    }
     COT_LDS_BARRIER();  // every wave is done with the last stage: the stage memory is free
     bf16_t* const ot = reinterpret_cast<bf16_t*>(cot_smem);
     constexpr int OS = BPX + 8;                      // BIG: padded row stride of the tile image (bank spread)
