@@ -231,9 +231,9 @@ def run_downsample(ds, x):
         for m in ds:
             if isinstance(m, torch.nn.Conv2d):
                 if (MODE == "hip" and m.kernel_size == (1, 1) and m.stride == (2, 2) and m.padding == (0, 0)
-                        and m.groups == 1 and x.dim() == 4 and x.dtype == torch.bfloat16
-                        and m.weight.dtype == torch.bfloat16 and (x.is_cuda or not _DEVICE_ONLY)
-                        and m.in_channels % 8 == 0 and m.out_channels % 8 == 0):
+                        and m.groups == 1 and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32)
+                        and m.weight.dtype == x.dtype and (x.is_cuda or not _DEVICE_ONLY)
+                        and m.in_channels % 8 == 0 and m.out_channels % 8 == 0):  # (fp32: the general kernels, conv_gen.hip)
                     x = _Conv1x1Hip.apply(x[:, :, ::2, ::2].contiguous(), None, m.weight, m.bias)
                 else:
                     x = conv1x1(m, x)

@@ -222,6 +222,8 @@ int gn9f_backward(const void*, const void*, const float*, const float*, const vo
                   int, hipStream_t);
 // implemented in conv_tiny.hip (one image of <= 256 pixels: the se branch's convolutions over the batch axis)
 extern int g_conv_tiny;
+int stem7x7_f32_forward(const void*, const void*, void*, int, int, int, hipStream_t);                       // stem7x7_f32.hip
+int stem7x7_f32_backward_weight(const void*, const void*, void*, float*, int, int, int, int, hipStream_t);
 bool conv_tiny_covers(int N, int Ci, int Co, int HW);
 int conv_tiny_forward(const void*, const void*, const void*, void*, int, int, int, hipStream_t);
 int conv_tiny_backward_data(const void*, const void*, void*, int, int, int, int, hipStream_t);
@@ -1258,9 +1260,13 @@ int64_t cot_stem7x7s2_workspace(int N, int H, int W) {
 int cot_stem7x7s2_forward(const void* x, const void* weight, void* y, int N, int H, int W, int dtype, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d H=%d W=%d", N, H, W);
     if (!x || !weight || !y) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
-    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_stem7x7s2_*: only COT_BF16 (dtype %d given)", dtype);
+    if (dtype != COT_BF16 && dtype != COT_F32) return set_error(COT_ERR_UNSUPPORTED, "cot_stem7x7s2_*: COT_BF16 or COT_F32 (dtype %d given)", dtype);
     int rc = check_align16({x, weight, y});
     if (rc) return rc;
+    if (dtype == COT_F32) {  // the reference's own precision: plain fp32 kernels (stem7x7_f32.hip), the bf16 kernels' geometry
+        if (stem7x7_splits(N, H, W) <= 0) return set_error(COT_ERR_UNSUPPORTED, "cot_stem7x7s2_forward: a %dx%d input is not covered", H, W);
+        return stem7x7_f32_forward(x, weight, y, N, H, W, (hipStream_t)stream);
+    }
     rc = stem7x7_forward(x, weight, y, N, H, W, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_stem7x7s2_forward: output width of a %dx%d input is not a multiple of 8", H, W);
     return rc;
@@ -1270,9 +1276,16 @@ int cot_stem7x7s2_backward_weight(const void* gy, const void* x, void* gweight, 
                                   int dtype, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0) return set_error(COT_ERR_INVALID_ARG, "non-positive dimension N=%d H=%d W=%d", N, H, W);
     if (!gy || !x || !gweight || !workspace) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
-    if (dtype != COT_BF16) return set_error(COT_ERR_UNSUPPORTED, "cot_stem7x7s2_*: only COT_BF16 (dtype %d given)", dtype);
+    if (dtype != COT_BF16 && dtype != COT_F32) return set_error(COT_ERR_UNSUPPORTED, "cot_stem7x7s2_*: COT_BF16 or COT_F32 (dtype %d given)", dtype);
     int rc = check_align16({gy, x, gweight, workspace});
     if (rc) return rc;
+    if (dtype == COT_F32) {
+        const int S = stem7x7_splits(N, H, W);  // (the workspace is sized for S slices of 64 x 147 floats: cot_stem7x7s2_workspace)
+        if (S <= 0) return set_error(COT_ERR_UNSUPPORTED, "cot_stem7x7s2_backward_weight: %dx%d input not covered", H, W);
+        rc = stem7x7_f32_backward_weight(gy, x, gweight, (float*)workspace, S, N, H, W, (hipStream_t)stream);
+        if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_stem7x7s2_backward_weight: the fp32 kernel's LDS window was refused");
+        return rc;
+    }
     rc = stem7x7_wgrad(gy, x, gweight, (float*)workspace, N, H, W, (hipStream_t)stream);
     if (rc == COT_ERR_UNSUPPORTED) set_error(rc, "cot_stem7x7s2_backward_weight: %dx%d input not covered", H, W);
     return rc;

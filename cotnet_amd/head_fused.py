@@ -43,7 +43,8 @@ class _Head(Function):
         O = weight.shape[0]
         st = _stream()
         gapT = torch.empty((C, N), dtype=x.dtype, device=x.device)
-        _ck(L.cot_radix_gap_t(_p(x), None, _p(gapT), N, C, H * W, BF16, st), "cot_radix_gap_t")
+        dt = _lib.dtype_code(x.dtype)
+        _ck(L.cot_radix_gap_t(_p(x), None, _p(gapT), N, C, H * W, dt, st), "cot_radix_gap_t")
         ctx.mask = None
         if drop_p > 0.0:  # F.dropout on the pooled descriptor (reference recipe: drop 0.25): C x N elements, two tiny launches
             # 0/1 keep mask, the 1/(1-p) scale applied in fp32 and the product rounded once -- as F.dropout does (a bf16 mask
@@ -51,7 +52,7 @@ class _Head(Function):
             ctx.mask, ctx.scale = torch.rand((C, N), dtype=torch.float32, device=x.device) >= drop_p, 1.0 / (1.0 - drop_p)
             gapT = (gapT.float() * ctx.mask * ctx.scale).to(x.dtype)
         logT = torch.empty((O, N), dtype=x.dtype, device=x.device)
-        _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(weight), _p(bias), _p(logT), 1, C, O, N, BF16, st),
+        _ck(L.cot_conv1x1_forward(_p(gapT), None, C, _p(weight), _p(bias), _p(logT), 1, C, O, N, dt, st),
             "cot_conv1x1_forward")
         ctx.save_for_backward(gapT, weight)
         ctx.shape, ctx.has_bias = x.shape, bias is not None
@@ -65,17 +66,18 @@ class _Head(Function):
         O = weight.shape[0]
         st = _stream()
         gT = g.t().contiguous()
-        key = (N, C, O)
+        dt = _lib.dtype_code(gapT.dtype)
+        key = (N, C, O, dt)
         nb = _WS.get(key)
-        if nb is None:
-            nb = _WS[key] = int(L.cot_conv1x1_workspace(1, C, O, N, 1))
+        if nb is None:  # (fp32 runs on the general kernels, whose weight gradient has its own workspace)
+            nb = _WS[key] = int(L.cot_convg_workspace(1, C, O, 1, N, 1, 1)) if dt == _lib.COT_F32 else int(L.cot_conv1x1_workspace(1, C, O, N, 1))
         ws = torch.empty(nb, dtype=torch.uint8, device=g.device)
         ggapT = torch.empty_like(gapT)
-        _ck(L.cot_conv1x1_backward_data(_p(gT), _p(weight), _p(ggapT), None, C, 0, _p(ws), 1, C, O, N, BF16, st),
+        _ck(L.cot_conv1x1_backward_data(_p(gT), _p(weight), _p(ggapT), None, C, 0, _p(ws), 1, C, O, N, dt, st),
             "cot_conv1x1_backward_data")
         gw = grad_sink.out_like(weight)
         gb = torch.empty(O, dtype=weight.dtype, device=g.device) if ctx.has_bias else None
-        _ck(L.cot_conv1x1_backward_weight(_p(gT), _p(gapT), None, C, _p(gw), _p(gb), _p(ws), 1, C, O, N, BF16, st),
+        _ck(L.cot_conv1x1_backward_weight(_p(gT), _p(gapT), None, C, _p(gw), _p(gb), _p(ws), 1, C, O, N, dt, st),
             "cot_conv1x1_backward_weight")
         gf = ggapT.t().float()
         if ctx.mask is not None:
@@ -87,7 +89,8 @@ class _Head(Function):
 def eligible(pool, fc, x):
     return (MODE == "hip" and isinstance(fc, nn.Linear) and getattr(pool, "pool_type", None) == "avg"
             and getattr(pool, "flatten", False) and (x.is_cuda or not _DEVICE_ONLY) and x.dim() == 4
-            and x.dtype == torch.bfloat16 and x.is_contiguous() and fc.weight.dtype == torch.bfloat16
+            and x.dtype in (torch.bfloat16, torch.float32) and x.is_contiguous() and fc.weight.dtype == x.dtype
+            and (fc.bias is None or fc.bias.dtype == x.dtype)
             and fc.weight.is_contiguous() and fc.in_features == x.shape[1] and fc.in_features % 8 == 0
             and fc.out_features % 8 == 0 and x.data_ptr() % 16 == 0)
 

@@ -21,6 +21,8 @@ SHAPES = [("s3 conv1 1024->256", 1024, 256, 15680), ("s3 embed0 512->128", 512, 
 ABL = [0, 1, 31, 32, 63, 64]
 if len(sys.argv) > 1:
     ABL = [int(v) for v in sys.argv[1].split(',')]
+for kv in (sys.argv[2].split(',') if len(sys.argv) > 2 else []):  # further tuning keys: KEY=VALUE,...
+    assert L.cot_set_tuning(int(kv.split('=')[0]), int(kv.split('=')[1])) == 0
 
 
 def timeit(fn, n=20):

@@ -2284,6 +2284,90 @@ def test_stem_convolution_kernels(N, H, W):
     assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(y), N, 30, 30, dt, None) == -2
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (1, 16, 64), (3, 32, 16), (1, 64, 48), (2, 8, 16), (5, 48, 32)])
+def test_stem_convolution_fp32_kernels(N, H, W):
+    """csrc/stem7x7_f32.hip: the stem at the reference's own precision (fp32 operands and sums) against torch, forward and weight
+    gradient; same entry points, dtype COT_F32; the weight gradient twice (deterministic)"""
+    torch.manual_seed(23)
+    dt = _lib.dtype_code(torch.float32)
+    x, w = torch.randn(N, 3, H, W), torch.randn(64, 3, 7, 7) / 12
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = torch.randn(N, 64, Ho, Wo)
+    wf = w.clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(x, wf, None, 2, 3)
+    yr.backward(gy)
+    y = torch.full((N, 64, Ho, Wo), float("nan"))
+    assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(y), N, H, W, dt, None) == 0, _EMUL.cot_last_error()
+    assert torch.allclose(y, yr.detach(), atol=1e-5, rtol=1e-5), (y - yr).abs().max()
+    ws = torch.empty(_EMUL.cot_stem7x7s2_workspace(N, H, W), dtype=torch.uint8)
+    gws = []
+    for _ in range(2):
+        gw = torch.full_like(w, float("nan"))
+        assert _EMUL.cot_stem7x7s2_backward_weight(P(gy), P(x), P(gw), P(ws), N, H, W, dt, None) == 0, _EMUL.cot_last_error()
+        gws.append(gw)
+    assert torch.equal(gws[0], gws[1])
+    assert (gws[0] - wf.grad).abs().max() <= 1e-5 * wf.grad.abs().max() + 1e-5
+    assert _EMUL.cot_stem7x7s2_forward(P(x), P(w), P(y), N, 30, 30, dt, None) == -2   # the bf16 kernels' geometry (output width % 8)
+
+
+def test_fp32_step_pieces_on_emulated_kernels(monkeypatch):
+    """what kept the fp32 step on torch modules (VERDICT r5 missing #4): the stem, a stride-2 projection shortcut and the classifier head in
+    fp32 through the library -- the wrappers take them, no fallback is counted, values follow torch"""
+    from cotnet_amd import conv1x1 as c1, fused_bn, head_fused as hf, stem7x7 as s7
+    from cotnet_amd.layers import create_classifier
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (c1, hf, s7, fused_bn):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(c1, "MODE", "hip")
+    monkeypatch.setattr(hf, "MODE", "hip")
+    monkeypatch.setattr(s7, "MODE", "hip")
+    for cache in (c1._WS, hf._WS, s7._WS, fused_bn._WS):
+        cache.clear()
+    torch.manual_seed(41)
+    _lib.FALLBACKS.clear()
+    # stem
+    conv = torch.nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+    x = torch.randn(2, 3, 32, 32)
+    assert s7.eligible(conv, x)
+    y = s7.stem_conv(conv, x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    gw = conv.weight.grad.clone()
+    conv.weight.grad = None
+    yr = conv(x)
+    yr.backward(g)
+    assert torch.allclose(y, yr, atol=1e-5, rtol=1e-5) and torch.allclose(gw, conv.weight.grad, atol=1e-4, rtol=1e-4)
+    # stride-2 projection shortcut (models/resnet.py:364-378)
+    ds = torch.nn.Sequential(torch.nn.Conv2d(16, 32, 1, stride=2, bias=False), torch.nn.BatchNorm2d(32)).train()
+    import copy
+    ref = copy.deepcopy(ds)
+    xd = torch.randn(3, 16, 8, 8, requires_grad=True)
+    yd = c1.run_downsample(ds, xd)
+    gd = torch.randn_like(yd)
+    yd.backward(gd)
+    xr = xd.detach().clone().requires_grad_(True)
+    ydr = ref(xr)
+    ydr.backward(gd)
+    assert torch.allclose(yd, ydr, atol=1e-4, rtol=1e-4) and torch.allclose(xd.grad, xr.grad, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(ds[0].weight.grad, ref[0].weight.grad, atol=1e-4, rtol=1e-3)
+    # head
+    pool, fc = create_classifier(64, 24, pool_type="avg")
+    xh = torch.randn(5, 64, 7, 7, requires_grad=True)
+    assert hf.eligible(pool, fc, xh)
+    yh = hf.head(pool, fc, xh)
+    gh = torch.randn(5, 24)
+    yh.backward(gh)
+    xhr = xh.detach().clone().requires_grad_(True)
+    wr, br = fc.weight.detach().clone().requires_grad_(True), fc.bias.detach().clone().requires_grad_(True)
+    yhr = torch.nn.functional.linear(xhr.mean((2, 3)), wr, br)
+    yhr.backward(gh)
+    assert torch.allclose(yh, yhr.detach(), atol=1e-5, rtol=1e-4) and torch.allclose(xh.grad, xhr.grad, atol=1e-6, rtol=1e-4)
+    assert torch.allclose(fc.weight.grad, wr.grad, atol=1e-5, rtol=1e-4) and torch.allclose(fc.bias.grad, br.grad, atol=1e-5, rtol=1e-4)
+    assert not _lib.FALLBACKS, dict(_lib.FALLBACKS)
+    for cache in (c1._WS, hf._WS, s7._WS, fused_bn._WS):
+        cache.clear()
+
+
 @pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 64), (1, 16, 64, 32), (3, 32, 16, 64), (1, 64, 48, 32), (2, 8, 16, 64)])
 def test_deep_stem_first_convolution_kernels(N, H, W, Co):
     """csrc/stem3x3.hip (3x3 / stride 2 / padding 1, 3 -> 32 / 64: models/cotnet_hybrid.py:359) forward and weight gradient against torch
