@@ -365,8 +365,9 @@ int cot_agg_gn9_forward(const void* x, const void* logits, const float* mean, co
 int cot_agg_gn9_backward(const void* gout, const void* x, const void* logits, const float* mean, const float* rstd, const void* gamma,
                          const void* beta, int groups_per_image, void* gx, void* gw, const cot_agg_geom* g, int dtype, void* stream);
 
-/* ---- the backbone's first convolution: 7x7, stride 2, padding 3, 3 -> 64 channels, NCHW, COT_BF16 (reference:
- * models/resnet.py:539-555, conv1 of the default stem), forward and weight gradient (the network input takes no gradient).
+/* ---- the backbone's first convolution: 7x7, stride 2, padding 3, 3 -> 64 channels, NCHW, COT_BF16 (MFMA implicit GEMM) or COT_F32
+ * (plain fp32 kernels: the reference's own precision) (reference: models/resnet.py:539-555, conv1 of the default stem), forward and
+ * weight gradient (the network input takes no gradient).
  * weight [64][3][7][7] as torch stores it; x [N][3][H][W]; y / gy [N][64][Ho][Wo], Ho = (H - 1)/2 + 1.  Covered when Wo is a
  * multiple of 8 and Ho*Wo of 32 (224, 256, 288, 320 inputs); otherwise COT_ERR_UNSUPPORTED / workspace 0 (caller keeps
  * nn.Conv2d).  backward_weight is deterministic; workspace: cot_stem7x7s2_workspace(...) bytes. */
