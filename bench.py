@@ -807,6 +807,14 @@ def main():
         # remember the stream they were created under, and a node created under the default stream makes the engine synchronise
         # with it during capture, which aborts the process)
         torch.cuda.synchronize()
+        # With a process group the RCCL watchdog THREAD polls the events of the collectives it has seen (hipEventQuery); under the
+        # default global capture mode such a call from another thread while this one captures is an error that the watchdog rethrows
+        # -- the process dies (2 of 12 runs through the world-of-one communicator, profiles/r06_capture_flake.log; with 8 ranks most
+        # launches would lose one).  So: thread-local capture mode (other threads' calls are none of the capture's business), and the
+        # watchdog gets a moment to retire the settling steps' finished collectives before the capture starts.
+        CAPTURE_MODE = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        if CAPTURE_MODE == "thread_local":
+            time.sleep(0.3)
         graph = torch.cuda.CUDAGraph()
         captured, full = True, False
 
@@ -823,7 +831,7 @@ def main():
             # they do eagerly) and the flat SGD kernels: one replay per step on every rank, nothing issued by the host afterwards
             try:
                 barrier()
-                with torch.cuda.graph(graph, stream=gstream):
+                with torch.cuda.graph(graph, stream=gstream, capture_error_mode=CAPTURE_MODE):
                     graph_loss = eager_step()
                     if os.environ.get("COT_BENCH_FAIL_CAPTURE") == "full":
                         raise RuntimeError("COT_BENCH_FAIL_CAPTURE=full is set (test of the fallback)")
@@ -846,12 +854,12 @@ def main():
                 # bucket, no host synchronisation) -- the reference's order: backward, all-reduce, optimizer (train.py:264-293)
                 opt.reducer.defer_comm = True
                 barrier()
-                with torch.cuda.graph(graph, stream=gstream):
+                with torch.cuda.graph(graph, stream=gstream, capture_error_mode=CAPTURE_MODE):
                     graph_loss = step_compute_only()
                     if os.environ.get("COT_BENCH_FAIL_CAPTURE") in ("1", "all"):
                         raise RuntimeError("COT_BENCH_FAIL_CAPTURE is set (test of the fallback)")
             else:
-                with torch.cuda.graph(graph, stream=gstream):
+                with torch.cuda.graph(graph, stream=gstream, capture_error_mode=CAPTURE_MODE):
                     graph_loss = eager_step()
                     if os.environ.get("COT_BENCH_FAIL_CAPTURE") in ("1", "all"):
                         raise RuntimeError("COT_BENCH_FAIL_CAPTURE is set (test of the fallback)")
