@@ -89,8 +89,9 @@ def _sa_sizes(L, N, Cin, Cw, A, G, H, W, Cout=None, HWo=None):
     if v is None:
         HW = H * W
         ws = max(int(L.cot_conv1x1_workspace(N, Cin, Cw, HW, 0)), int(L.cot_conv1x1_workspace(N, Cw, Cout, HWo, 0)),
-                 int(L.cot_conv1x1_workspace(N, Cin, Cout, HWo, 0)), int(L.cot_conv3x3g_workspace(N, Cw, Cw, G, H, W)))
-        v = _SASIZES[k] = (ws, int(L.cot_bn_act_workspace(N, Cw)), int(L.cot_bn_act_workspace(N, Cout)), int(L.cot_bn_act_workspace(N, A)))
+                 int(L.cot_conv1x1_workspace(N, Cin, Cout, HWo, 0)), int(L.cot_conv3x3g_workspace(N, Cw, Cw, G, H, W)),
+                 int(L.cot_conv1x1_workspace(1, Cw, A, N, 1)), int(L.cot_conv1x1_workspace(1, A, Cw, N, 1)))  # (the gate's fc layers)
+        v = _SASIZES[k] = (ws, int(L.cot_bn_act_workspace(N, Cw)), int(L.cot_bn_act_workspace(N, Cout)), int(L.cot_bn_act_workspace(1, A)))
     return v
 
 
@@ -120,13 +121,17 @@ class _SplitAttnBlockNode(Function):
         s_0 = stat(Cw, nws_w)
         _bn_fwd(L, c2, b2, sp.bn0, s_0, 2 * Cw, N, Cw, HW, sp.act0)
         # the gate: pooled descriptor [N, Cw] -> fc1 -> BatchNorm over the batch + act -> fc2 -> x * sigmoid(logits)
-        gap = torch.empty((N, Cw), dtype=x.dtype, device=dev)
-        _ck(L.cot_se_gap(_p(b2), _p(gap), N * Cw, HW, BF16, st), "cot_se_gap")
-        hpre = torch.addmm(sp.fc1.bias, gap, sp.fc1.weight.view(A, Cw).t())
-        h = torch.empty_like(hpre)
+        # (round 6: descriptors channel-major [.][N], as in the CoT layer's se branch -- the two fc layers are 1x1 convolutions over ONE
+        # image whose N pixels are the batch, on the library's kernels; rounds 4-5 ran them as torch.addmm / matmul, i.e. vendor GEMMs:
+        # 174 launches + their bias-gradient reductions per SE-CoTNetD-152 step)
+        row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
+        gap, hpre, h, logitsT = row(Cw), row(A), row(A), row(Cw)
+        _ck(L.cot_radix_gap_t(_p(b2), None, _p(gap), N, Cw, HW, BF16, st), "cot_radix_gap_t")
+        _ck(L.cot_conv1x1_forward(_p(gap), None, Cw, _p(sp.fc1.weight), _p(sp.fc1.bias), _p(hpre), 1, Cw, A, N, BF16, st), "cot_conv1x1_forward")
         s_s = stat(A, nws_a)
-        _bn_fwd(L, hpre, h, sp.sbn, s_s, 2 * A, N, A, 1, sp.act1)  # ([N, A, 1, 1]: N samples per channel)
-        logits = torch.addmm(sp.fc2.bias, h, sp.fc2.weight.view(Cw, A).t())
+        _bn_fwd(L, hpre, h, sp.sbn, s_s, 2 * A, 1, A, N, sp.act1)  # (one image, N pixels: the statistics run over the batch)
+        _ck(L.cot_conv1x1_forward(_p(h), None, A, _p(sp.fc2.weight), _p(sp.fc2.bias), _p(logitsT), 1, A, Cw, N, BF16, st), "cot_conv1x1_forward")
+        logits = logitsT.t().contiguous()  # [N][Cw]: the gate kernels index it by plane n * Cw + c
         out2 = new(Cw)
         _ck(L.cot_se_gate(_p(b2), _p(logits), _p(out2), N * Cw, HW, BF16, st), "cot_se_gate")
         if sp.avd_post:  # anti-aliased down-sampling behind conv2 (cotnet_hybrid.py:196-199; blur_pool.py:53-58)
@@ -195,18 +200,17 @@ class _SplitAttnBlockNode(Function):
         # gate: dx of x * sigmoid(l) and dl in one pass; then the two fc layers (GEMMs on [N, .] descriptors) and their BatchNorm
         g_b2, g_log = torch.empty_like(b2), torch.empty_like(logits)
         _ck(L.cot_se_gate_backward(_p(g_out2), _p(b2), _p(logits), _p(g_b2), _p(g_log), N * Cw, HW, BF16, st), "cot_se_gate_backward")
-        W2, W1 = sp.fc2.weight.view(Cw, A), sp.fc1.weight.view(A, Cw)
-        g_h = torch.matmul(g_log, W2)
+        row = lambda c: torch.empty((c, N), dtype=x.dtype, device=dev)  # noqa: E731
+        g_logT = g_log.t().contiguous()  # [Cw][N]
+        g_h, g_hpre, g_gapT = row(A), row(A), row(Cw)
+        _ck(L.cot_conv1x1_backward_data(_p(g_logT), _p(sp.fc2.weight), _p(g_h), None, A, 0, _p(ws), 1, A, Cw, N, BF16, st), "cot_conv1x1_backward_data")
         g_fc2_w, g_fc2_b = grad_sink.out_like(sp.fc2.weight), grad_sink.out_like(sp.fc2.bias)
-        torch.matmul(g_log.t(), h, out=g_fc2_w.view(Cw, A))
-        g_fc2_b.copy_(g_log.float().sum(0))
-        g_hpre = torch.empty_like(hpre)
-        d_sbn_w, d_sbn_b = _bn_bwd(L, g_h, hpre, None, g_hpre, sp.sbn, s_s, N, A, 1, sp.act1, nws_a)
-        g_gap = torch.matmul(g_hpre, W1)
+        side.run(lambda st_, a_=(_p(g_logT), _p(h), None, A, _p(g_fc2_w), _p(g_fc2_b), _p(side.ws), 1, A, Cw, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_logT, h)
+        d_sbn_w, d_sbn_b = _bn_bwd(L, g_h, hpre, None, g_hpre, sp.sbn, s_s, 1, A, N, sp.act1, nws_a)
+        _ck(L.cot_conv1x1_backward_data(_p(g_hpre), _p(sp.fc1.weight), _p(g_gapT), None, Cw, 0, _p(ws), 1, Cw, A, N, BF16, st), "cot_conv1x1_backward_data")
         g_fc1_w, g_fc1_b = grad_sink.out_like(sp.fc1.weight), grad_sink.out_like(sp.fc1.bias)
-        torch.matmul(g_hpre.t(), gap, out=g_fc1_w.view(A, Cw))
-        g_fc1_b.copy_(g_hpre.float().sum(0))
-        g_b2.add_((g_gap.float() / HW).to(g_b2.dtype).view(N, Cw, 1, 1))  # d mean_hw: the same value for every pixel of a plane
+        side.run(lambda st_, a_=(_p(g_hpre), _p(gap), None, Cw, _p(g_fc1_w), _p(g_fc1_b), _p(side.ws), 1, Cw, A, N, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_hpre, gap)
+        g_b2.add_((g_gapT.t().float() / HW).to(g_b2.dtype).reshape(N, Cw, 1, 1))  # d mean_hw: the same value for every pixel of a plane
         g_c2 = g_out2  # (reuse: consumed by the gate's backward)
         d_bn0_w, d_bn0_b = _bn_bwd(L, g_b2, c2, None, g_c2, sp.bn0, s_0, N, Cw, HW, sp.act0, nws_w)
         g_wc = grad_sink.out_like(sp.conv.weight)
