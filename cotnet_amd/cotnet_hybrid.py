@@ -8,13 +8,13 @@ ResNet skeleton without max-pool whose four stages all stride by 2 (:251-256,:43
 """
 import math
 
-import torch.nn.functional as F
 from torch import nn
 
 from . import cot_layer_fused
 from .conv1x1 import conv1x1, run_downsample
 from .cotnet import CotLayer, _cfg
 from .fused_bn import fused_bn_act
+from .head_fused import head
 from .layers import BlurPool2d, SplitAttnConv2d, create_classifier, get_act_layer
 from .registry import build_model_with_cfg, register_model
 from .resnet import init_weights, make_blocks, make_stem, stem_forward
@@ -162,10 +162,9 @@ class CoTHybridNet(nn.Module):
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
     def forward(self, x):
-        x = self.global_pool(self.forward_features(x))
-        if self.drop_rate:
-            x = F.dropout(x, p=float(self.drop_rate), training=self.training)
-        return self.fc(x)
+        x = self.forward_features(x)
+        # fc(dropout(global_pool(x))) (models/cotnet_hybrid.py:439-445), on the library's kernels when eligible (head_fused.py)
+        return head(self.global_pool, self.fc, x, float(self.drop_rate) if (self.drop_rate and self.training) else 0.0)
 
 
 def _create_se_cotnetd(variant, pretrained=False, **kwargs):
