@@ -94,7 +94,10 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object of the default line (BASELINE configs 4 / 5 and the reference's fp32 precision "
                          "measured by short child runs of this script on the same GPU)")
-    ap.add_argument("--bucket-mb", type=float, default=10.0, help="flat gradient bucket size (MiB): the all-reduce granularity")
+    ap.add_argument("--bucket-mb", type=float, default=25.0,
+                    help="flat gradient bucket size (MiB): the all-reduce granularity.  25 since round 6: the default N > 1 form issues the "
+                         "all-reduces behind the replayed backward (nothing to overlap with), where fewer, larger messages cost less -- one GPU, "
+                         "world-of-one RCCL: 14.23 ms at 10 MiB, 13.92-14.09 at 25 (profiles/r06_bucket_sweep.log)")
     ap.add_argument("--conv1x1", default=None, choices=["module", "hip", "matmul"],
                     help="1x1-convolution implementation (cotnet_amd/conv1x1.py); default: COT_CONV1X1 or the module")
     ap.add_argument("--ema", type=float, default=None, metavar="DECAY",
