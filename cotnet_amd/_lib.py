@@ -103,6 +103,8 @@ SYMBOLS = {
     "cot_conv1x1_forward": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cot_conv1x1_backward_data": (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "cot_conv1x1_backward_weight": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cot_conv1x1_backward_data_relu_res_covers": (_I, [_I] * 5),
+    "cot_conv1x1_backward_data_relu_res": (_I, [_P] * 5 + [_I] * 5 + [_P]),
     "cot_conv3x3g_masks_bytes": (ctypes.c_int64, [_I, _I]),
     "cot_conv3x3g_masks": (_I, [_P, _I, _I, _P]),
     "cot_conv3x3g_workspace": (ctypes.c_int64, [_I] * 6),

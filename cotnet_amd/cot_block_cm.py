@@ -324,7 +324,9 @@ class _BottleneckCMNode(Function):
             gb = gout.contiguous()
         # bn3 + residual + relu
         g_c3 = cmj(Cout)
-        g_res = cmj(Cout) if res_cm else nchw(Cout)
+        # identity shortcut, everything channel-major, a sign mask: the residual's gradient is folded into conv1's data gradient below
+        fold = has_mask and in_cm and not opening and clf._res_fold_ok(L, 1, Cin, C, M)
+        g_res = None if fold else (cmj(Cout) if res_cm else nchw(Cout))
         if has_mask:
             d_bn3_w, d_bn3_b = _bn_bwd(L, gb, c3, None, g_c3, bp.bn3, s_3, 1, Cout, M, 1, nws_o1, dres=g_res, mask=m3)
         else:
@@ -444,7 +446,12 @@ class _BottleneckCMNode(Function):
             gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
             if in_cm:
                 side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), 1, Cin, C, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
-                _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), 1, Cin, C, M, BF16, st), "cot_conv1x1_backward_data")
+                if fold:
+                    gx = cmj(Cin)
+                    _ck(L.cot_conv1x1_backward_data_relu_res(_p(g_c1), _p(bp.conv1.weight), _p(gx), _p(gb), _p(m3), 1, Cin, C, M, BF16, st),
+                        "cot_conv1x1_backward_data_relu_res")
+                else:
+                    _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), 1, Cin, C, M, BF16, st), "cot_conv1x1_backward_data")
             else:
                 side.run(lambda st_, a_=(_p(g_c1), _p(xb), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, C, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, xb)
                 _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, C, HW, BF16, st), "cot_conv1x1_backward_data")

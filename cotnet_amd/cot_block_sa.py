@@ -185,7 +185,8 @@ class _SplitAttnBlockNode(Function):
         masks = _masks(L, H, W, dev)
         side = _Side(dev, ws_bytes, ws, sp.params)
         gout = gout.contiguous()
-        g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
+        fold = sp.ds_conv is None and m3 is not None and not sp.avd_post and clf._res_fold_ok(L, N, Cin, Cw, HW)
+        g_c3, g_res = torch.empty_like(c3), (None if fold else torch.empty_like(c3))  # (fold: the residual's gradient goes into conv1's data gradient)
         d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, sp.bn3, s_3, N, Cout, HWo, 1, nws_o, dres=g_res, ps=ps, mask=m3)
         g_out2p = torch.empty_like(out2p)
         _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(sp.conv3.weight), _p(g_out2p), None, Cw, 0, _p(ws), N, Cw, Cout, HWo, BF16, st),
@@ -238,8 +239,13 @@ class _SplitAttnBlockNode(Function):
             gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
         g_w1 = grad_sink.out_like(sp.conv1.weight)
         side.run(lambda st_, a_=(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, Cw, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, x)
-        _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(sp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16, st),
-            "cot_conv1x1_backward_data")
+        if fold:
+            gx = torch.empty_like(x)
+            _ck(L.cot_conv1x1_backward_data_relu_res(_p(g_c1), _p(sp.conv1.weight), _p(gx), _p(gout), _p(m3), N, Cin, Cw, HW, BF16, st),
+                "cot_conv1x1_backward_data_relu_res")
+        else:
+            _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(sp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16, st),
+                "cot_conv1x1_backward_data")
         side.join()
         return (None, gx, g_w1, d_bn1_w, d_bn1_b, g_wc, d_bn0_w, d_bn0_b, g_fc1_w, g_fc1_b, d_sbn_w, d_sbn_b, g_fc2_w, g_fc2_b, g_w3,
                 d_bn3_w, d_bn3_b) + g_ds

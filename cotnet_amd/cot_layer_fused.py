@@ -471,6 +471,22 @@ def _guard_elems(t):
 
 
 RELU_MASK = os.environ.get("COT_BN_RELU_MASK", "1") != "0"  # bn3 + residual + ReLU: backward reads a 1-bit sign mask, not y
+# identity-shortcut blocks: the residual's gradient gout * [block output > 0] is not written by bn3's backward and read back by conv1's
+# data gradient (`accumulate`) but formed in that data gradient's epilogue from gout and the sign mask (cot_conv1x1_backward_data_relu_res).
+# COT_RES_FOLD=0 opts out.
+RES_FOLD = os.environ.get("COT_RES_FOLD", "1") != "0"
+_RES_FOLD_OK = _lib.register_cache({})
+
+
+def _res_fold_ok(L, N, Ci, Co, HW):
+    if not RES_FOLD:
+        return False
+    k = (N, Ci, Co, HW)
+    v = _RES_FOLD_OK.get(k)
+    if v is None:
+        v = _RES_FOLD_OK[k] = bool(L.cot_conv1x1_backward_data_relu_res_covers(N, Ci, Co, HW, BF16))
+    return v
+
 _MASK_BYTES = _lib.register_cache({})
 
 
@@ -1047,9 +1063,11 @@ class _BottleneckNode(Function):
                      bp.params)
         gout = gout.contiguous()
         # bn3 + residual + relu: dx of the normalisation and the residual's gradient in one pass
-        g_c3, g_res = torch.empty_like(c3), torch.empty_like(c3)
         ps = extra[-1] if ctx.has_ps else None
         m3 = extra[-2 if ctx.has_ps else -1] if ctx.has_mask else None
+        # identity shortcut with a sign mask: the residual's gradient is folded into conv1's data gradient below, never written
+        fold = (not ctx.has_ds) and m3 is not None and not bp.avd and _res_fold_ok(L, N, Cin, Cw, HW)
+        g_c3, g_res = torch.empty_like(c3), (None if fold else torch.empty_like(c3))
         d_bn3_w, d_bn3_b = _bn_bwd(L, gout, c3, y, g_c3, bp.bn3, s_3, N, Cout, HWo, 1, nws_o, dres=g_res, ps=ps, mask=m3)
         g_cot_out = torch.empty_like(cot_out)
         _ck(L.cot_conv1x1_backward_data(_p(g_c3), _p(bp.conv3.weight), _p(g_cot_out), None, Cw, 0, _p(ws), N, Cw, Cout, HWo,
@@ -1104,8 +1122,13 @@ class _BottleneckNode(Function):
             gx = g_res  # identity shortcut: the residual's gradient is the first contribution to dx
         g_w1 = grad_sink.out_like(bp.conv1.weight)  # (issued before its data gradient: the two overlap)
         side.run(lambda st_, a_=(_p(g_c1), _p(x), None, Cin, _p(g_w1), None, _p(side.ws), N, Cin, Cw, HW, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), g_c1, x)
-        _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16,
-                                        st), "cot_conv1x1_backward_data")
+        if fold:
+            gx = torch.empty_like(x)
+            _ck(L.cot_conv1x1_backward_data_relu_res(_p(g_c1), _p(bp.conv1.weight), _p(gx), _p(gout), _p(m3), N, Cin, Cw, HW, BF16, st),
+                "cot_conv1x1_backward_data_relu_res")
+        else:
+            _ck(L.cot_conv1x1_backward_data(_p(g_c1), _p(bp.conv1.weight), _p(gx), None, Cin, 1, _p(ws), N, Cin, Cw, HW, BF16,
+                                            st), "cot_conv1x1_backward_data")
         side.join()
         return (None, gx, g_w1, d_bn1_w, d_bn1_b) + g_cot + (g_w3, d_bn3_w, d_bn3_b) + g_ds
 

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd(const C1LdsArgs
     e.y1 = a.y1; e.y2 = a.y2; e.bias = a.bias; e.m1 = a.m1; e.M = M; e.HW = HW; e.N = a.N; e.ni = a.ni;
     e.ys1 = a.ys1; e.ys2 = a.ys2; e.stats = nullptr; e.ptiles = 0;
     e.n0 = n0; e.p0 = p0; e.m0 = m0; e.mv = min(BM, M - m0); e.ncols = ncols; e.accumulate = a.accumulate;
-    e.ablate = 0;
+    e.ablate = 0; e.acc_src = nullptr; e.acc_mask = nullptr;
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_fwd(const C3LdsArg
     e.y1 = a.y; e.y2 = nullptr; e.bias = nullptr; e.m1 = G * MM; e.M = G * MM; e.HW = HW; e.N = a.N; e.ni = a.ni;
     e.ys1 = (int64_t)G * MM * HW; e.ys2 = 0; e.stats = nullptr; e.ptiles = 0;
     e.n0 = n0; e.p0 = r0 * W; e.m0 = grp * MM; e.mv = MM; e.ncols = ncols; e.accumulate = a.accumulate;
-    e.ablate = 0;
+    e.ablate = 0; e.acc_src = nullptr; e.acc_mask = nullptr;
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3g_lds_res(const C3LdsArg
     e.y1 = a.y; e.y2 = nullptr; e.bias = nullptr; e.m1 = G * MM; e.M = G * MM; e.HW = HW; e.N = a.N; e.ni = a.ni;
     e.ys1 = (int64_t)G * MM * HW; e.ys2 = 0; e.stats = nullptr; e.ptiles = 0;
     e.n0 = n0; e.p0 = r0 * W; e.m0 = grp * MM; e.mv = MM; e.ncols = ncols; e.accumulate = a.accumulate;
-    e.ablate = 0;
+    e.ablate = 0; e.acc_src = nullptr; e.acc_mask = nullptr;
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
@@ -1326,8 +1326,10 @@ bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW) {
 // stats: NULL or [N][ceil(HW/128)][M][2] floats -- per (image, 128-pixel tile, channel) sum and sum of squares of the stored
 // outputs, written by the epilogue (planes of more than 256 pixels only)
 int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int wpacked, const void* bias, void* y1, void* y2,
-                     int m1, int N, int K, int M, int HW, int accumulate, hipStream_t stream, int64_t xs, int64_t ys, float* stats) {
+                     int m1, int N, int K, int M, int HW, int accumulate, hipStream_t stream, int64_t xs, int64_t ys, float* stats,
+                     const void* acc_src, const void* acc_mask) {
     if (!conv1x1_lds_covers(K, k1, x2 != nullptr, HW)) return -1;
+    if (acc_src && (y2 || xs || ys || stats || (accumulate & 1) || HW % 8 != 0 || !acc_mask)) return -1;
     if ((xs || ys) && (x2 || y2)) return -1;
     if (stats && (y2 || accumulate || HW <= 256 || HW % 8 != 0)) return -1;
     if (y2 && m1 % 8 != 0) return -1;  // (16-byte pieces of the output must not straddle the two output slabs)
@@ -1339,12 +1341,13 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int 
     a.xs1 = xs ? xs : (int64_t)a.k1 * HW; a.xs2 = (int64_t)(K - a.k1) * HW;
     a.ys1 = ys ? ys : (int64_t)a.m1 * HW; a.ys2 = (int64_t)(M - a.m1) * HW;
     a.ni = 1; a.xcd_remap = 0; a.xswz = 0; a.wpacked = wpacked; a.ablate = 0; a.stats = stats;
+    a.acc_src = (const bf16_t*)acc_src; a.acc_mask = (const uint8_t*)acc_mask;
     const int u16 = (g_conv_lds_tune[2] >> 1) & 1;  // tuning key 17 bit 1: 2-byte gathers everywhere (A/B; default: transposing reads)
     const bool wt = wpacked == 2;
     if (wt && (M % 8 != 0 || M < 8)) return -1;
-    if (!(g_conv_lds2_tune & 1) || xs || ys || stats) {  // third generation (conv_lds2.hip) unless tuning key 23 bit 0 asks for this one (A/B)
+    if (!(g_conv_lds2_tune & 1) || xs || ys || stats || acc_src) {  // third generation (conv_lds2.hip) unless tuning key 23 bit 0 asks for this one (A/B)
         const int rc2 = conv1x1_lds_gemm2(a, stream);
-        if (rc2 != -1 || xs || ys || stats) return rc2;  // (strided slabs / epilogue statistics: third generation only)
+        if (rc2 != -1 || xs || ys || stats || acc_src) return rc2;  // (strided slabs / epilogue statistics / masked residual: third generation only)
     }
 #define COT_C1W(CB_, MB_, FLAT_, NS_, WV_, TR_)                                                             \
     return wt ? launch_c1<CB_, MB_, FLAT_, NS_, WV_, TR_, 1>(a, tiles, stream)                             \

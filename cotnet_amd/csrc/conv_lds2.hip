@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
     e.y1 = a.y1; e.y2 = a.y2; e.bias = a.bias; e.m1 = a.m1; e.M = M; e.HW = HW; e.N = a.N; e.ni = a.ni;
     e.ys1 = a.ys1; e.ys2 = a.ys2; e.stats = a.stats; e.ptiles = a.ptiles;
     e.n0 = n0; e.p0 = p0; e.m0 = m0; e.mv = min(BM, M - m0); e.ncols = ncols; e.accumulate = a.accumulate;
-    e.ablate = a.ablate;
+    e.ablate = a.ablate; e.acc_src = a.acc_src; e.acc_mask = a.acc_mask;
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 

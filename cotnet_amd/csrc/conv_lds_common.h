@@ -135,6 +135,10 @@ struct EpiArgs {
     int64_t ys1, ys2;    // elements from one image to the next in y1 / y2 (dense: m1 * HW, (M - m1) * HW; larger when the slab is
                          // a channel range of a wider tensor: one group of a grouped convolution)
     float* stats;        // NULL, or [N][ptiles][M][2]: per (image, pixel tile, channel) the sum and the sum of squares of the
+    const bf16_t* acc_src;       // NULL, or a tensor laid out as y1 whose elements -- where the sign-mask bit is set -- are ADDED to the result
+    const uint8_t* acc_mask;     // (acc_mask[e >> 3] bit e & 7 for element e of y1): the residual's gradient gout * [block output > 0] of a
+                                 // Bottleneck (models/cotnet.py:259-262) folded into conv1's data gradient -- bn3's backward then need not
+                                 // write it (cot_conv1x1_backward_data_relu_res).  One output slab, planes of a multiple of 8 pixels.
     int ablate;          // DIAGNOSTIC (cot_set_tuning key 24): bit 5 (32) = no epilogue at all (nothing stored); bit 6 (64) = BIG tiles without a bias /
                          // second slab / accumulate / statistics: the accumulators stored directly (8 bytes per lane), no LDS round trip
     int ptiles;          // tile's outputs AS STORED (rounded to bf16) -- the statistics of the consumer's normalisation come out
@@ -254,6 +258,11 @@ __device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], cons
                 const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(dst);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
+            } else if (a.acc_src) {  // (one slab: ioff is the element's offset in y1 and in acc_src alike; a multiple of 8)
+                const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(a.acc_src + ioff);
+                const unsigned mb = a.acc_mask[ioff >> 3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (((mb >> e) & 1u) ? (float)pv.v[e] : 0.f));
             }
             stv<bf16_t, 8>(dst, v);
         }
@@ -274,6 +283,11 @@ __device__ __forceinline__ void tile_epilogue(const f32x4_t (&acc)[CB][MB], cons
                     const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(blk + e0);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (float)pv.v[e]);
+                } else if (a.acc_src) {  // (H*W % 8 == 0 with a mask: boff + e0 is a multiple of 8)
+                    const Vec<bf16_t, 8> pv = ldv<bf16_t, 8>(a.acc_src + boff + e0);
+                    const unsigned mb = a.acc_mask[(boff + e0) >> 3];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.v[e] = (bf16_t)((float)v.v[e] + (((mb >> e) & 1u) ? (float)pv.v[e] : 0.f));
                 }
                 stv<bf16_t, 8>(blk + e0, v);
             } else {  // the block's last, partial piece (mv * HW % 8 != 0: only when mv is not a multiple of 8)
@@ -294,6 +308,8 @@ struct C1LdsArgs {
     int64_t xs1, xs2;  // elements from one image to the next in x1 / x2 (dense: k1 * HW, (K - k1) * HW), and in
     int64_t ys1, ys2;  // y1 / y2 (dense: m1 * HW, (M - m1) * HW): a slab may be a channel range of a wider tensor
     float* stats;      // NULL or the epilogue statistics workspace (EpiArgs::stats; BIG tiles only)
+    const bf16_t* acc_src;      // EpiArgs::acc_src / acc_mask (third generation only)
+    const uint8_t* acc_mask;
     int accumulate;    // bit 0: y1 += result, bit 1: y2 += result
     int wpacked;
     int mblocks;       // output-channel blocks of BM

@@ -181,7 +181,8 @@ static int g_conv3x3_merge = 1;  // tuning key 37: merged-groups 3x3 weight grad
 static inline bool g_conv_lds_tune_wgrad_off() { return (g_conv_lds_tune[2] >> 2) & 1; }  // tuning key 17 bit 2 (A/B)
 bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW);
 int conv1x1_lds_gemm(const void*, const void*, int, const void*, int, const void*, void*, void*, int, int, int, int, int, int,
-                     hipStream_t, int64_t xs = 0, int64_t ys = 0, float* stats = nullptr);
+                     hipStream_t, int64_t xs = 0, int64_t ys = 0, float* stats = nullptr, const void* acc_src = nullptr,
+                     const void* acc_mask = nullptr);
 int gn9_stats_finalize(const float*, float*, float*, int, int, int, float, hipStream_t);
 int agg_gn9_forward_nchw(const bf16_t*, const bf16_t*, const float*, const float*, const bf16_t*, const bf16_t*, int, bf16_t*,
                          const cot_agg_geom&, hipStream_t);
@@ -749,6 +750,34 @@ static int cot_conv1x1_backward_data_impl(const void* gy, const void* weight, vo
     return conv1x1_gemm(gy, nullptr, Co, weight, nullptr, gx1, gx2, c1, N, Co, Ci, HW, accumulate & 3, 1,
                         (hipStream_t)stream);
 }
+// ---- conv1's data gradient of an identity-shortcut Bottleneck with the residual's gradient folded in (models/cotnet.py:228-264: out =
+// relu(bn3(...) + x)): gx = W^T gy + gout * [block output > 0], the second term from the block's upstream gradient and bn3's sign mask
+// (cot_bn_act_forward_mask) -- bn3's backward (cot_bn_act_backward_mask with dresidual = NULL) then does not write the residual's gradient
+// and this call does not read it back: one write and most of one read of a [N, Cin, HW] tensor per block less.
+int cot_conv1x1_backward_data_relu_res_covers(int N, int Ci, int Co, int HW, int dtype) {
+    if (dtype != COT_BF16 || N <= 0 || Ci <= 0 || Co <= 0 || HW <= 0 || HW % 8 != 0 || Ci % 8 != 0 || Co % 8 != 0) return 0;
+    if (conv_tiny_covers(N, Ci, Co, HW) || !conv1x1_lds_covers(Co, Co, false, HW)) return 0;
+    const int64_t slab = (int64_t)std::max(Ci, Co) * HW * 2;  // (conv1x1_lds_gemm2's 32-bit lane offsets)
+    if ((HW <= 256 ? slab * (256 / HW + 1) : slab) >= ((int64_t)1 << 31) || (int64_t)Ci * Co * 2 >= ((int64_t)1 << 31)) return 0;
+    if (cot_bn_relu_mask_bytes(N, Ci, HW, COT_BF16) <= 0) return 0;
+    return 1;
+}
+int cot_conv1x1_backward_data_relu_res(const void* gy, const void* weight, void* gx, const void* gout, const void* relu_mask, int N, int Ci,
+                                       int Co, int HW, int dtype, void* stream) {
+    if (!gy || !weight || !gx || !gout || !relu_mask) return set_error(COT_ERR_INVALID_ARG, "NULL device pointer");
+    if (!cot_conv1x1_backward_data_relu_res_covers(N, Ci, Co, HW, dtype))
+        return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_backward_data_relu_res: N=%d %d->%d HW=%d is off the LDS kernels (_covers)", N, Ci, Co, HW);
+    int rc = check_align16({gy, weight, gx, gout});
+    if (rc) return rc;
+    const bool p = prof::enabled();
+    if (p) prof::mark();
+    rc = conv1x1_lds_gemm(gy, nullptr, Co, weight, 2, nullptr, gx, nullptr, Ci, N, Co, Ci, HW, 0, (hipStream_t)stream, 0, 0, nullptr, gout,
+                          relu_mask);
+    if (rc == -1) return set_error(COT_ERR_UNSUPPORTED, "cot_conv1x1_backward_data_relu_res: the kernel refused N=%d %d->%d HW=%d", N, Ci, Co, HW);
+    if (p) prof::annotate_op(11, N, Ci, Co, HW, 1, dtype, 0);
+    return rc;
+}
+
 int cot_conv1x1_backward_data(const void* gy, const void* weight, void* gx1, void* gx2, int c1, int accumulate,
                               void* workspace, int N, int Ci, int Co, int HW, int dtype, void* stream) {
     const bool p = prof::enabled();

@@ -365,6 +365,16 @@ int cot_agg_gn9_forward(const void* x, const void* logits, const float* mean, co
 int cot_agg_gn9_backward(const void* gout, const void* x, const void* logits, const float* mean, const float* rstd, const void* gamma,
                          const void* beta, int groups_per_image, void* gx, void* gw, const cot_agg_geom* g, int dtype, void* stream);
 
+/* ---- conv1's data gradient of an identity-shortcut Bottleneck with the residual's gradient folded in (models/cotnet.py:228-264: the
+ * block returns relu(bn3(...) + x), so d loss / d x = conv1's data gradient + gout * [block output > 0]):
+ *   gx = weight^T [Ci][Co] . gy  +  gout * relu_mask      gy [N, Co, HW], gx / gout [N, Ci, HW], relu_mask = bn3's sign mask
+ * (cot_bn_act_forward_mask: one bit per element of the [N, Ci, HW] block output).  bn3's backward is then called with dresidual = NULL.
+ * COT_BF16, HW % 8 == 0, the LDS kernels' geometries: cot_conv1x1_backward_data_relu_res_covers(...) == 1, else COT_ERR_UNSUPPORTED
+ * (keep cot_bn_act_backward_mask's dresidual + cot_conv1x1_backward_data(accumulate = 1)). */
+int cot_conv1x1_backward_data_relu_res_covers(int N, int Ci, int Co, int HW, int dtype);
+int cot_conv1x1_backward_data_relu_res(const void* gy, const void* weight, void* gx, const void* gout, const void* relu_mask, int N, int Ci,
+                                       int Co, int HW, int dtype, void* stream);
+
 /* ---- the backbone's first convolution: 7x7, stride 2, padding 3, 3 -> 64 channels, NCHW, COT_BF16 (MFMA implicit GEMM) or COT_F32
  * (plain fp32 kernels: the reference's own precision) (reference: models/resnet.py:539-555, conv1 of the default stem), forward and
  * weight gradient (the network input takes no gradient).

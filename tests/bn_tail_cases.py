@@ -146,3 +146,26 @@ def rowstats_case(L, N, C, H, W, gn, seed=5):
     cnt = N * HW
     assert int(nbt) == 1 and torch.allclose(rm.cpu(), 0.1 * of.mean((0, 2, 3)), atol=1e-6, rtol=1e-5)
     assert torch.allclose(rv.cpu(), 0.9 + 0.1 * var * cnt / max(cnt - 1, 1), atol=1e-5, rtol=1e-5)
+
+
+def relu_res_case(L, N, Ci, Co, HW, seed=7):
+    """cot_conv1x1_backward_data_relu_res (conv1's data gradient + the residual's gradient gout * [y > 0] from bn3's sign mask) against
+    the two-step form it replaces -- the masked gradient materialised, then cot_conv1x1_backward_data(accumulate = 1): bit for bit."""
+    torch.manual_seed(seed)
+    dev = getattr(L, "_test_device", "cpu")
+    dt = _lib.COT_BF16
+    assert L.cot_conv1x1_backward_data_relu_res_covers(N, Ci, Co, HW, dt) == 1
+    gy = torch.randn(N, Co, HW).bfloat16().to(dev)
+    w = (torch.randn(Co, Ci) / Co ** 0.5).bfloat16().to(dev)
+    gout, y = torch.randn(N, Ci, HW).bfloat16().to(dev), torch.randn(N, Ci, HW).to(dev)
+    bits = (y.reshape(-1, 8) > 0).to(torch.int32)
+    mask = (bits * (2 ** torch.arange(8, device=dev, dtype=torch.int32))).sum(1).to(torch.uint8).contiguous()
+    assert mask.numel() == int(L.cot_bn_relu_mask_bytes(N, Ci, HW, dt))
+    gx0 = (gout.float() * (y > 0)).bfloat16().contiguous()
+    ws = torch.empty(max(int(L.cot_conv1x1_workspace(N, Ci, Co, HW, 0)), 16), dtype=torch.uint8, device=dev)
+    assert L.cot_conv1x1_backward_data(P(gy), P(w), P(gx0), None, Ci, 1, P(ws), N, Ci, Co, HW, dt, None) == 0, L.cot_last_error()
+    gx = torch.full_like(gout, float("nan"))
+    assert L.cot_conv1x1_backward_data_relu_res(P(gy), P(w), P(gx), P(gout), P(mask), N, Ci, Co, HW, dt, None) == 0, L.cot_last_error()
+    assert torch.equal(gx, gx0), (gx.float() - gx0.float()).abs().max().item()
+    ref = torch.einsum("oc,nop->ncp", w.float().cpu(), gy.float().cpu()) + gout.float().cpu() * (y.cpu() > 0)
+    assert (gx.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()

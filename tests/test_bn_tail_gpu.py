@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from cotnet_amd import _lib
-from tests.bn_tail_cases import bn_tail_case, rowstats_case
+from tests.bn_tail_cases import bn_tail_case, relu_res_case, rowstats_case
 
 pytestmark = pytest.mark.gpu
 
@@ -43,4 +43,13 @@ def test_agg_forward_rowstats(shape, gn):
     if gn and shape[3] % 2:
         pytest.skip("the GroupNorm prologue takes even rows (cot_agg_gn9_forward)")
     rowstats_case(_lib_on_device(), *shape, gn)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("N,Ci,Co,HW", [(80, 256, 64, 3136), (80, 512, 128, 784), (1, 1024, 256, 15680), (1, 2048, 512, 3920), (80, 1024, 256, 196),
+                                        (2, 64, 32, 784), (3, 128, 64, 64), (5, 64, 32, 16), (1, 96, 64, 392)])
+def test_conv1x1_data_gradient_with_the_masked_residual(N, Ci, Co, HW):
+    """cot_conv1x1_backward_data_relu_res on CoTNet-50's conv1 shapes at B = 80 (NCHW and channel-major) and small ones: bit-identical to
+    the residual gradient materialised + cot_conv1x1_backward_data(accumulate = 1)"""
+    relu_res_case(_lib_on_device(), N, Ci, Co, HW)
     torch.cuda.synchronize()

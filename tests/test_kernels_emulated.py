@@ -12,7 +12,7 @@ import torch
 from cotnet_amd import _lib
 from oracle import cref, unfold_oracle
 from tests.emul import build_emul
-from tests.bn_tail_cases import bn_tail_case, rowstats_case
+from tests.bn_tail_cases import bn_tail_case, relu_res_case, rowstats_case
 
 try:
     _EMUL = ctypes.CDLL(build_emul.build())
@@ -1657,6 +1657,13 @@ def test_radix_tail_bn_fused_kernels(N, C, H, W, dtype, lay_k, sums):
     # True: the bit-for-bit branch of the forward comparison ran (7 x 7 bf16 planes: the statistics pass reads 7 elements per lane where
     # the unfused streaming kernel reads one -- another summation order)
     assert same or sums or (dtype == torch.bfloat16 and (H * W) % 7 == 0 and (H * W) % 2 == 1)  # (sums: another formula for the variance)
+
+
+@pytest.mark.parametrize("N,Ci,Co,HW", [(2, 64, 32, 784), (3, 128, 64, 64), (1, 64, 64, 1568), (2, 256, 64, 3136), (5, 64, 32, 16), (1, 96, 64, 392)])
+def test_conv1x1_data_gradient_with_the_masked_residual(N, Ci, Co, HW):
+    """conv1's data gradient with the residual's gradient (gout under bn3's sign mask) added in the epilogue: 128-pixel tiles, whole-image
+    tiles and the channel-major one-image form, bit-identical to materialise + accumulate"""
+    relu_res_case(_EMUL, N, Ci, Co, HW)
 
 
 @pytest.mark.parametrize("gn", [0, 1])
