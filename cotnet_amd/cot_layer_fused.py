@@ -472,9 +472,10 @@ def _guard_elems(t):
 
 RELU_MASK = os.environ.get("COT_BN_RELU_MASK", "1") != "0"  # bn3 + residual + ReLU: backward reads a 1-bit sign mask, not y
 # identity-shortcut blocks: the residual's gradient gout * [block output > 0] is not written by bn3's backward and read back by conv1's
-# data gradient (`accumulate`) but formed in that data gradient's epilogue from gout and the sign mask (cot_conv1x1_backward_data_relu_res).
-# COT_RES_FOLD=0 opts out.
-RES_FOLD = os.environ.get("COT_RES_FOLD", "1") != "0"
+# data gradient (`accumulate`) but formed in that data gradient's epilogue from gout and the sign mask (cot_conv1x1_backward_data_relu_res):
+# one tensor write and most of one read per block less, one backward buffer less.  Opt-in (COT_RES_FOLD=1): bit-identical results, and the
+# step does not move (13.556 vs 13.552 ms, alternating; profiles/r06_res_fold_ab.log) -- bn3's backward is not where these blocks wait.
+RES_FOLD = os.environ.get("COT_RES_FOLD", "0") == "1"
 _RES_FOLD_OK = _lib.register_cache({})
 
 

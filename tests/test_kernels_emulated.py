@@ -1869,6 +1869,52 @@ def test_fused_split_attn_block_node_on_emulated_kernels(act, monkeypatch):
         cache.clear()
 
 
+def test_residual_gradient_folded_into_conv1_data_gradient(monkeypatch):
+    """COT_RES_FOLD: an identity-shortcut Bottleneck node with the residual's gradient formed in conv1's data-gradient epilogue (bn3's
+    backward writes no dresidual) against the same node with the gradient materialised -- bit for bit, NCHW node at a mask geometry"""
+    import copy
+    from cotnet_amd import cot_layer_fused as clf, conv1x1 as c1, conv3x3g as c3, fused_bn, radix_tail
+    from cotnet_amd.cotnet import Bottleneck
+    from cotnet_amd.flat_sgd import to_mixed_bf16
+    torch.manual_seed(17)
+    blk = Bottleneck(256, 64).train()
+    with torch.no_grad():
+        blk.bn3.weight.fill_(0.8)
+    blk = to_mixed_bf16(blk)
+    x = torch.randn(2, 256, 8, 8).bfloat16()
+    g = torch.randn(2, 256, 8, 8).bfloat16()
+    monkeypatch.setattr(_lib, "lib", lambda: _EMUL)
+    for mod in (clf, c1, c3, fused_bn, radix_tail):
+        monkeypatch.setattr(mod, "_DEVICE_ONLY", False)
+    monkeypatch.setattr(c1, "MODE", "hip")
+    monkeypatch.setattr(c3, "MODE", "hip")
+    import cotnet_amd.aggregation_zeropad as az
+    monkeypatch.setattr(az, "aggregation_zeropad", lambda i, w, kernel_size=3, stride=1, padding=0, dilation=1: _EmulAggregation.apply(i, w))
+    caches = (clf._SIZES, clf._MASKS, clf._BSIZES, clf._RES_FOLD_OK, c1._WS, c3._WS, c3._MASKS, fused_bn._WS)
+    res = []
+    for fold in (False, True):
+        for cache in caches:
+            cache.clear()
+        monkeypatch.setattr(clf, "RES_FOLD", fold)
+        m = copy.deepcopy(blk)
+        xi = x.clone().requires_grad_(True)
+        assert clf.block_eligible(m, xi)
+        calls = []
+        orig = _EMUL.cot_conv1x1_backward_data_relu_res
+        monkeypatch.setattr(_EMUL, "cot_conv1x1_backward_data_relu_res", lambda *a: (calls.append(1), orig(*a))[1], raising=False)
+        y = m(xi)
+        assert y.grad_fn.name().startswith("_BottleneckNode")
+        y.backward(g)
+        monkeypatch.setattr(_EMUL, "cot_conv1x1_backward_data_relu_res", orig, raising=False)
+        assert bool(calls) == fold
+        res.append((y.detach().clone(), xi.grad.clone(), {n_: p.grad.clone() for n_, p in m.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for n_ in res[0][2]:
+        assert torch.equal(res[0][2][n_], res[1][2][n_]), n_
+    for cache in caches:
+        cache.clear()
+
+
 @pytest.mark.parametrize("kind", ["split_attn", "cot"])
 def test_se_cotnetd_stage_opening_blocks_as_single_nodes(kind, monkeypatch):
     """SE-CoTNetD-152's stage-opening blocks (models/cotnet_hybrid.py:172-202 with avd = BlurPool2d behind conv2, avd_first False, and the
