@@ -47,7 +47,7 @@ def test_agg_forward_rowstats(shape, gn):
 
 
 @pytest.mark.parametrize("N,Ci,Co,HW", [(80, 256, 64, 3136), (80, 512, 128, 784), (1, 1024, 256, 15680), (1, 2048, 512, 3920),
-                                        (2, 64, 32, 784), (3, 128, 64, 64), (5, 64, 32, 16), (1, 96, 64, 392)])
+                                        (2, 64, 32, 784), (5, 128, 64, 64), (20, 64, 32, 16), (1, 96, 64, 392)])  # (N * HW > 256: the sign mask's geometries)
 def test_conv1x1_data_gradient_with_the_masked_residual(N, Ci, Co, HW):
     """cot_conv1x1_backward_data_relu_res on CoTNet-50's conv1 shapes at B = 80 (NCHW and channel-major) and small ones: bit-identical to
     the residual gradient materialised + cot_conv1x1_backward_data(accumulate = 1)"""
