@@ -8,7 +8,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from cotnet_amd import _lib  # noqa: E402
 
 L = _lib.lib()

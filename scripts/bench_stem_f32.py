@@ -1,5 +1,5 @@
 import ctypes, sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from cotnet_amd import _lib
 L = _lib.lib(); P = lambda t: ctypes.c_void_p(t.data_ptr())
 dev = "cuda"; N, H = 80, 224
