@@ -53,6 +53,8 @@ def main():
         # automatic dispatch (key 0 = 0): bf16 fused backward on the packed dot-product kernel (agg_dot2.hip); keys 30 / 32 / 33 =
         # channel groups per LDS phase, waves per workgroup, SAFE operand masking; "lds" = the same dispatch with it off
         "lds": [(29, 0)], "dot2": [],
+        # automatic dispatch with the forward's pixels per lane / waves per workgroup changed (round 6 re-check of the small planes)
+        "fP2": [(1, 2)], "fP8": [(1, 8)], "nw8": [(5, 8)], "fP2_nw8": [(1, 2), (5, 8)], "fP1": [(1, 1)],
     }
     for jp in (2, 4, 8):
         for nw in (2, 4, 7):
