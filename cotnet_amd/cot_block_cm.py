@@ -92,6 +92,13 @@ def _cm_sizes(L, N, Cin, C, A, G, H, W, grouped=False, Cout=None):
     return v
 
 
+def _gx_slabs_ok(L, C, Ch, M):
+    """CoXtLayer.embed[0] as two two-slab 1x1 convolutions (one per group) on channel-major operands.  _cm_geometry_ok's C % 64 == 0 makes
+    every slab (C/2 rows of x or k, Ch/2 = C/4 output rows) 16-byte aligned with a reduction count the 1x1 kernels take; CoTNeXt's widths
+    (C = 384 / 768 at 14x14 / 7x7) land on the LDS kernels, narrower ones on the first-generation kernel"""
+    return clf.GX_SLABS and C % 64 == 0 and Ch * 2 == C
+
+
 def _cm_geometry_ok(L, N, Cin, C, H, W, grouped=False):
     k = (N, Cin, C, H, W, grouped)
     v = _CM_OK.get(k)
@@ -199,7 +206,17 @@ class _BottleneckCMNode(Function):
         # attention logits from [x | k]: two 1x1 convolutions on channel rows, GroupNorm writes the aggregation's weights NCHW (ref :81-85)
         e0, e1, e3 = cmj(Ch), cmj(Ch), cmj(Ce)
         qk = None
-        if GX:
+        if GX and _gx_slabs_ok(L, C, Ch, M):
+            # CoXtLayer's embed[0] reads the row-INTERLEAVED [x0, k0, x1, k1, ...] in two groups (ref :153-154): group g sees the rows
+            # g*C/2 .. of x and of k.  Channel-major, each of those is one contiguous slab, so a group is the two-slab 1x1 kernel on [x_g | k_g]
+            # with the group's weight columns de-interleaved to match -- a copy of the (small) weight per step instead of a copy of the
+            # activations (torch.stack: 2 C*M elements written and read) and, backward, two strided adds of C*M elements each
+            qk = pl.em0.weight.view(Ch, C // 2, 2).permute(0, 2, 1).reshape(Ch, C)  # [Ch][x-part C/2 | k-part C/2], a copy (kept for the backward)
+            Hc, Mg = C // 2, Ch // 2
+            for g_ in range(2):
+                _ck(L.cot_conv1x1_forward(_p(a1c[g_ * Hc:]), _p(k[g_ * Hc:]), Hc, _p(qk[g_ * Mg:]), None, _p(e0[g_ * Mg:]), 1, C, Mg, M, BF16, st),
+                    "cot_conv1x1_forward")
+        elif GX:
             qk = torch.stack([a1c, k], dim=1).view(2 * C, N, H, W)  # rows x0, k0, x1, k1, ... (ref :153-154)
             _ck(L.cot_conv1x1g_forward(_p(qk), _p(pl.em0.weight), None, _p(e0), 1, 2 * C, Ch, 2, M, BF16, st), "cot_conv1x1g_forward")
         else:
@@ -399,7 +416,22 @@ class _BottleneckCMNode(Function):
         ge0 = cmj(Ch)
         d_em_w, d_em_b = _bn_bwd(L, ge1, e0, None, ge0, em1, s_e, 1, Ch, M, 1, nws_h1)
         g_we0 = grad_sink.out_like(em0.weight)
-        if GX:  # gradient of the row-interleaved [x0, k0, x1, k1, ...]: de-interleaved into dx / dk (two strided adds)
+        if GX and qk.dim() == 2:  # (the forward took the two-slab form: qk holds the de-interleaved weight)
+            Hc, Mg = C // 2, Ch // 2
+            gwp = torch.empty_like(qk)  # gradient w.r.t. the de-interleaved weight, re-interleaved into the parameter's slot below
+            for g_ in range(2):
+                _ck(L.cot_conv1x1_backward_data(_p(ge0[g_ * Mg:]), _p(qk[g_ * Mg:]), _p(gxc[g_ * Hc:]), _p(gk[g_ * Hc:]), Hc, 3, _p(ws), 1, C, Mg, M,
+                                                BF16, st), "cot_conv1x1_backward_data")
+                side.run(lambda st_, a_=(_p(ge0[g_ * Mg:]), _p(a1c[g_ * Hc:]), _p(k[g_ * Hc:]), Hc, _p(gwp[g_ * Mg:]), None, _p(side.ws), 1, C, Mg, M, BF16): _ck(L.cot_conv1x1_backward_weight(*a_, st_), "cot_conv1x1_backward_weight"), ge0, a1c, k, gwp)
+
+            def _interleave(st_, dst=g_we0, src=gwp, side_=side):  # [Ch][2][C/2] -> [Ch][C/2][2], behind the two launches above on their stream
+                if side_.on:
+                    with torch.cuda.stream(side_.stream):
+                        dst.view(Ch, C // 2, 2).copy_(src.view(Ch, 2, C // 2).permute(0, 2, 1))
+                else:
+                    dst.view(Ch, C // 2, 2).copy_(src.view(Ch, 2, C // 2).permute(0, 2, 1))
+            side.run(_interleave, gwp)
+        elif GX:  # gradient of the row-interleaved [x0, k0, x1, k1, ...]: de-interleaved into dx / dk (two strided adds)
             gqk = torch.empty_like(qk)
             _ck(L.cot_conv1x1g_backward_data(_p(ge0), _p(em0.weight), _p(gqk), 0, 1, 2 * C, Ch, 2, M, BF16, st), "cot_conv1x1g_backward_data")
             gq5 = gqk.view(C, 2, N, H, W)

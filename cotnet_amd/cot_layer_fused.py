@@ -1160,6 +1160,7 @@ def block_forward(blk, x):
 # the wrappers, bench.py and the tests have always used.  The channel-major switches are attributes of THIS module (tests rebind them).
 CM_LAYOUT = os.environ.get("COT_CM_LAYOUT", "1") != "0"
 CM_OPENING = os.environ.get("COT_CM_OPENING", "1") != "0"  # the stage's stride-2 opening block on the channel-major node too (A/B switch)
+GX_SLABS = os.environ.get("COT_GX_SLABS", "1") != "0"  # CoXtLayer.embed[0] in channel-major blocks: two-slab kernels per group instead of torch.stack (cot_block_cm.py)
 from .cot_block_sa import (_SABlockPlan, _SA_PLANS, _SASIZES, _sa_plan, _sa_sizes, _SplitAttnBlockNode, sa_block_eligible,  # noqa: E402,F401
                            sa_block_forward)
 from .cot_block_cm import (_CM_OK, _CM_SIZES, _BottleneckCMNode, _bn_bwd_lay, _bn_fwd_lay, _cm_buf, _cm_geometry_ok, _cm_sizes,  # noqa: E402,F401
