@@ -11,7 +11,7 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def bn_tail_case(L, N, C, H, W, dtype, lay_k, sums=False, seed=21):
+def bn_tail_case(L, N, C, H, W, dtype, lay_k, sums=False, seed=21, report=None):
     """cot_bn_batch_stats + cot_radix_*_bn (BatchNorm + SiLU folded into the radix tail, models/cotnet.py:89-104) through library `L`
     on CPU tensors: forward against the unfused composition (cot_bn_act_forward, then cot_radix_gap_t / _mix_logits) -- bit for bit when
     the unfused call ran the streaming kernels, whose statistics the fused prologue repeats -- and both directions against torch autograd
@@ -64,7 +64,9 @@ def bn_tail_case(L, N, C, H, W, dtype, lay_k, sums=False, seed=21):
     assert torch.allclose(rstd.cpu(), 1 / torch.sqrt(af.var((0, 2, 3), unbiased=False) + eps), atol=1e-4, rtol=1e-4)
     assert int(nbt) == 1 and torch.allclose(rm.cpu(), rm0.cpu(), atol=1e-6) and torch.allclose(rv.cpu(), rv0.cpu(), atol=1e-5, rtol=1e-5)
     same_stats = torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
-    if same_stats:  # (the unfused call took the streaming kernels: the same chunk statistics, merged in the same order)
+    if same_stats and lp:  # (the unfused call took the streaming kernels: the same chunk statistics, merged in the same order.  bf16 storage:
+        # y is rounded to bf16 on both routes, which absorbs the last-place differences of the two kernels' fp32 expressions; fp32 storage
+        # keeps them -- found by the fuzz on populations whose statistics happened to agree to the bit)
         assert torch.equal(gap, gap0) and torch.equal(out, out0) and torch.equal(attn, attn0)
     else:
         tol = 3e-2 if lp else 1e-4
@@ -74,6 +76,7 @@ def bn_tail_case(L, N, C, H, W, dtype, lay_k, sums=False, seed=21):
     a_r, k_r = af.clone().requires_grad_(True), k.float().cpu().requires_grad_(True)
     gam_r, bet_r = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
     z = torch.nn.functional.batch_norm(a_r, None, None, gam_r, bet_r, True, 0.0, eps)
+    z.retain_grad()
     y_r = torch.nn.functional.silu(z)
     gap_r = (y_r + k_r).mean((2, 3))                                          # [N, C]
     lg = logitsT.float().cpu().t().reshape(N, C, 2).requires_grad_(True)
@@ -103,8 +106,15 @@ def bn_tail_case(L, N, C, H, W, dtype, lay_k, sums=False, seed=21):
     btol = 4e-2 if lp else 1e-3
     assert (gk_n.float().cpu() - k_r.grad).abs().max() <= btol * scale(k_r.grad)
     assert (ga.float().cpu() - a_r.grad).abs().max() <= btol * scale(a_r.grad), (ga.float().cpu() - a_r.grad).abs().max() / scale(a_r.grad)
-    assert (dgam.cpu() - gam_r.grad).abs().max() <= btol * scale(gam_r.grad)
-    assert (dbet.cpu() - bet_r.grad).abs().max() <= btol * scale(bet_r.grad)
+    # dgamma / dbeta are sums of N * HW signed terms dz (* z_hat): a sum that cancels to almost nothing (one channel, small populations) still
+    # carries the rounding of its terms -- the yardstick is the sum's natural size rms(dz) * sqrt(count) next to the largest gradient
+    noise = float(z.grad.pow(2).mean().sqrt()) * (N * HW) ** 0.5
+    if report is not None:
+        report.append(((dgam.cpu() - gam_r.grad).abs().max().item(), (dbet.cpu() - bet_r.grad).abs().max().item(), scale(gam_r.grad),
+                       scale(bet_r.grad), noise))
+        return same_stats
+    assert (dgam.cpu() - gam_r.grad).abs().max() <= btol * (scale(gam_r.grad) + noise)
+    assert (dbet.cpu() - bet_r.grad).abs().max() <= btol * (scale(bet_r.grad) + noise)
     return same_stats
 
 
