@@ -26,6 +26,7 @@ extern int g_conv_ablate;  // (conv_lds2.hip; cot_set_tuning key 24)
 
 extern int g_conv_lds_tune[3];
 extern int g_conv_lds2_tune;
+extern int g_conv_k_tail;  // (conv_lds2.hip; cot_set_tuning key 54)
 int conv1x1_lds_gemm2(const C1LdsArgs& a0, hipStream_t stream);  // conv_lds2.hip
 
 // dst[c][r] = src[r][c]   (R x C row-major -> C x R row-major), 32x32 tiles through LDS.
@@ -1316,7 +1317,9 @@ static int launch_c1(const C1LdsArgs& a, int tiles, hipStream_t stream) {
 
 bool conv1x1_lds_covers(int K, int k1, bool two_slabs, int HW) {
     if (!g_conv_lds_tune[0]) return false;
-    if (K % 32 != 0 || K < 32 || (two_slabs && k1 % 32 != 0)) return false;
+    // (a reduction depth off the 32-row K step: the third-generation kernel's KT instantiations -- one slab, multiples of 8)
+    const bool ktail = K % 32 != 0 && K % 8 == 0 && K >= 8 && !two_slabs && g_conv_k_tail && !(g_conv_lds2_tune & 1);
+    if (!ktail && (K % 32 != 0 || K < 32 || (two_slabs && k1 % 32 != 0))) return false;
     return (HW % 8 == 0 && HW >= 256) || HW <= 256;
 }
 
@@ -1345,9 +1348,11 @@ int conv1x1_lds_gemm(const void* x1, const void* x2, int k1, const void* w, int 
     const int u16 = (g_conv_lds_tune[2] >> 1) & 1;  // tuning key 17 bit 1: 2-byte gathers everywhere (A/B; default: transposing reads)
     const bool wt = wpacked == 2;
     if (wt && (M % 8 != 0 || M < 8)) return -1;
-    if (!(g_conv_lds2_tune & 1) || xs || ys || stats || acc_src) {  // third generation (conv_lds2.hip) unless tuning key 23 bit 0 asks for this one (A/B)
+    const bool ktail = K % 32 != 0;
+    if (ktail && wpacked == 1) return -1;
+    if (!(g_conv_lds2_tune & 1) || xs || ys || stats || acc_src || ktail) {  // third generation (conv_lds2.hip) unless tuning key 23 bit 0 asks for this one (A/B)
         const int rc2 = conv1x1_lds_gemm2(a, stream);
-        if (rc2 != -1 || xs || ys || stats || acc_src) return rc2;  // (strided slabs / epilogue statistics / masked residual: third generation only)
+        if (rc2 != -1 || xs || ys || stats || acc_src || ktail) return rc2;  // (strided slabs / epilogue statistics / masked residual / K tail: third generation only)
     }
 #define COT_C1W(CB_, MB_, FLAT_, NS_, WV_, TR_)                                                             \
     return wt ? launch_c1<CB_, MB_, FLAT_, NS_, WV_, TR_, 1>(a, tiles, stream)                             \

@@ -34,6 +34,7 @@ int g_conv_big_fill = 200;  // cot_set_tuning key 46: BIG tiles -- output-channe
 int g_conv_big_xswz = 7;  // cot_set_tuning key 48: bit 0 = BIG tiles: bank-conflict-free (XOR-permuted) X stage (0: rows stored as they lie in memory); bit 1 = W tile: the permutation that is conflict-free under the hardware's ds_read_b128 lane groups (0: rounds 2-4's); bit 2 = the transposed W tile's (data gradient), see wt_perm
 int g_conv_flat_ns3 = 1;  // cot_set_tuning key 43: FLAT 128-row tiles take three stages instead of six when the launch exceeds one workgroup per CU
 int g_conv_ablate = 0;  // cot_set_tuning key 24 (diagnostic: see C1LdsArgs::ablate)
+int g_conv_k_tail = 1;  // cot_set_tuning key 54: reduction depths that are multiples of 8 but not of 32 on these kernels (KT instantiations); 0 = the first-generation / general kernels as before round 6
 
 // Chunk permutation of the TRANSPOSED weight tile (WT kernels: k rows of CPR 16-byte channel chunks): position p of k row `row`
 // holds chunk p ^ wt_perm(row).  A half-wave's transposing read touches the eight rows 8g + q (g = 0, 1 or 2, 3; q = 0..3), 32
@@ -49,7 +50,12 @@ template <int CPR> __device__ __forceinline__ int wt_perm(int row, int fixed) {
 }
 
 // template parameters as conv1x1_lds_fwd (conv_lds.hip); PF = fragment prefetch (register double buffer)
-template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD, int WT, int PF>
+// KT = 1: the reduction depth K is a multiple of 8 but not of 32 (CoXtLayer's grouped 1x1s: 48 / 24 / 216 / 432 channels per group,
+// models/cotnet.py:118-135).  The last K step then has kt = K % 32 valid rows: its copies take their X rows / W rows (WT) or W k-chunks from
+// INSIDE the operands (row min(r, kt - 1), chunk 0 -- nothing past a tensor's end is touched, whatever lies behind it) and the lanes
+// holding k >= kt (lane group g with 8 g >= kt) clear their A fragment, so those products are exact zeros.  One input slab, weights in
+// place.  KT = 0 instantiations carry none of this.
+template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD, int WT, int PF, int KT = 0>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArgs a) {
     constexpr int NT = 64 * WAVES;
     constexpr int BPX = 16 * WAVES * CB, BM = 16 * MB, BK = 32;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
         ncols = min(BPX, HW - p0);
     }
     const int m0 = mb * BM;
-    const int KB = K - a.k1;  // channels of the second input slab (0: one slab)
+    const int kt = KT ? (K & (BK - 1)) : 0;  // valid k rows of the last step (KT: never 0 -- the host picks the instantiation)
 
     // ---- staging.  Per-lane byte offsets of this thread's copies relative to the step's scalar base (image n0, channel k0 of
     // the slab the step reads): resolved once.  Every wave issues exactly G copies per stage (lanes past a stage's data copy
@@ -95,7 +101,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             const int img = q / cpi, c = q - img * cpi;
             const int nrel = min(n0 + img, a.N - 1) - n0;  // images past the batch: in-bounds bytes, never stored
             xvA[ps] = (unsigned)((int64_t)nrel * a.xs1 + c * 8) * 2u;
-            xvB[ps] = (unsigned)((int64_t)nrel * a.xs2 + c * 8) * 2u;
+            if (KT) {  // (one slab: the second slab's offsets serve the last K step -- chunks past its kt rows re-read chunks inside them)
+                const int vc = kt * HW / 8;  // (kt % 8 == 0: whole chunks)
+                xvB[ps] = (unsigned)((int64_t)nrel * a.xs1 + (c < vc ? c : c % vc) * 8) * 2u;
+            } else {
+                xvB[ps] = (unsigned)((int64_t)nrel * a.xs2 + c * 8) * 2u;
+            }
         } else {
             constexpr int cpr = BPX / 8;  // chunks per row
             const int row = q / cpr, pos = q - row * cpr;
@@ -107,12 +118,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             const int c = ((a.xswz & 1) && TRD) ? pos ^ (2 * ((row & 3) | (((row >> 3) & 1) << 2))) : pos;
             int pc = p0 + c * 8;
             if (pc + 8 > HW) pc = 0;  // partial last tile: columns never stored; any in-bounds bytes will do
-            xvA[ps] = xvB[ps] = (unsigned)(row * HW + pc) * 2u;
+            xvA[ps] = (unsigned)(row * HW + pc) * 2u;
+            xvB[ps] = KT ? (unsigned)(min(row, kt - 1) * HW + pc) * 2u : xvA[ps];
         }
     }
     const bf16_t* const xbaseA = a.x1 + (int64_t)n0 * a.xs1;
     const bf16_t* const xbaseB = a.x2 ? a.x2 + (int64_t)n0 * a.xs2 : a.x1;
-    unsigned wv[WPASS];
+    unsigned wv[WPASS], wvT[KT ? WPASS : 1];  // wvT: the last K step's (KT)
 #pragma unroll
     for (int ps = 0; ps < WPASS; ++ps) {
         const int q = min(ps * NT + tid, BM * 4 - 1);
@@ -123,6 +135,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             int mcol = m0 + c * 8;
             if (mcol + 8 > M) mcol = M - 8;  // channels past M (M % 8 == 0): in-bounds bytes, never stored
             wv[ps] = (unsigned)(row * M + mcol) * 2u;
+            if (KT) wvT[ps] = (unsigned)(min(row, kt - 1) * M + mcol) * 2u;
         } else {
             const int row = q >> 2, pos = q & 3;
             // XOR permutation: position `pos` of a row holds its k-chunk c.  (-(row >> 2)) & 3 is the form under which the four lane
@@ -132,24 +145,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             const int c = pos ^ ((a.xswz & 2) ? (-(row >> 2)) & 3 : (row >> 2) & 3);
             const int m = min(m0 + row, M - 1);    // rows past M: a copy of row M-1, never stored
             wv[ps] = (unsigned)(a.wpacked ? m * 32 + c * 8 : m * K + c * 8) * 2u;
+            if (KT) wvT[ps] = (unsigned)(m * K + (8 * c < kt ? c : 0) * 8) * 2u;
         }
     }
     const int64_t wstep = WT ? (int64_t)M * 32 : (a.wpacked ? (int64_t)M * 32 : 32);  // elements from one K step's W tile to the next
-    const int nk = K / BK;
+    const int nk = KT ? (K + BK - 1) / BK : K / BK;
     const unsigned lds_w = COT_LDS_ADDR(wsm) + (unsigned)(wave * 64 * 16);
     const unsigned lds_x = COT_LDS_ADDR(xsm) + (unsigned)(wave * 64 * 16);
     // stage `s` (K step s) into ring slot `buf`; both wave-uniform
     auto stage = [&](int s, int buf) __attribute__((always_inline)) {
         const int k0 = s * BK;
         const bool first = k0 < a.k1;  // the K step's rows come from one slab (k1 % 32 == 0 is checked on the host)
+        const bool tl = KT && s == nk - 1;
         const bf16_t* xb = first ? xbaseA + (int64_t)k0 * HW : xbaseB + (int64_t)(k0 - a.k1) * HW;
         const unsigned xd = lds_x + (unsigned)(buf * XST * 2);
 #pragma unroll
-        for (int ps = 0; ps < XP; ++ps) COT_GLDS16S(xb, first ? xvA[ps] : xvB[ps], xd + (unsigned)(ps * NT * 16));
+        for (int ps = 0; ps < XP; ++ps) COT_GLDS16S(xb, (first && !tl) ? xvA[ps] : xvB[ps], xd + (unsigned)(ps * NT * 16));
         const bf16_t* wb = a.w + s * wstep;
         const unsigned wd = lds_w + (unsigned)(buf * WST * 2);
 #pragma unroll
-        for (int ps = 0; ps < WPASS; ++ps) COT_GLDS16S(wb, wv[ps], wd + (unsigned)(ps * NT * 16));
+        for (int ps = 0; ps < WPASS; ++ps) COT_GLDS16S(wb, (KT && tl) ? wvT[KT ? ps : 0] : wv[ps], wd + (unsigned)(ps * NT * 16));
     };
 
     // ---- per-lane LDS offsets of the A (= X^T) gathers: column -> element offset of (k = 0, column) inside a stage
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
         for (int mbk = 0; mbk < MB; ++mbk) acc[cb][mbk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     typedef __attribute__((ext_vector_type(2))) uint16_t u16x2_t;
-    auto read_frags = [&](int buf, bf16x8_t (&af)[CB], bf16x8_t (&bfr)[MB]) __attribute__((always_inline)) {
+    auto read_frags = [&](int buf, bf16x8_t (&af)[CB], bf16x8_t (&bfr)[MB], bool tl) __attribute__((always_inline)) {
         const uint16_t* xb = reinterpret_cast<const uint16_t*>(xsm + buf * XST);
         const bf16_t* wb = wsm + buf * WST;
 #pragma unroll
@@ -211,6 +226,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
                 }
                 __builtin_memcpy(&af[cb], q4, 16);
             }
+            if (KT && tl && 8 * g >= kt) __builtin_memset(&af[cb], 0, 16);  // (this lane's eight k of the last step lie past K)
         }
 #pragma unroll
         for (int mbk = 0; mbk < MB; ++mbk) {
@@ -250,8 +266,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
         WaitBehind<G, NS - 1>::go(min(NS - 1, nk - 1));
         COT_LDS_BARRIER();
         bf16x8_t a0[CB], b0[MB], a1[CB], b1[MB];
-        read_frags(0, a0, b0);
-        if (abl & 2) read_frags(0, a1, b1);
+        read_frags(0, a0, b0, KT && nk == 1);
+        if (abl & 2) read_frags(0, a1, b1, false);
         int slot = 0;  // ring slot of step ks
         // STEADY: ks + NS < nk is known (full wait count, the re-fill always happens): the loop body carries no conditions
         auto step = [&](auto steady, int ks, const bf16x8_t (&ac)[CB], const bf16x8_t (&bc)[MB], bf16x8_t (&an)[CB],
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
                 if (!(abl & 8)) COT_LDS_BARRIER();
                 if ((STEADY || ks + NS < nk) && !(abl & 1)) stage(ks + NS, slot);
                 slot = slot + 1 == NS ? 0 : slot + 1;
-                if (!(abl & 2)) read_frags(slot, an, bn);
+                if (!(abl & 2)) read_frags(slot, an, bn, KT && ks + 2 == nk);
                 COT_SCHED_FENCE();  // the reads are in flight BEFORE the multiplies start (they hide the LDS round trip)
             }
             multiply(ac, bc);
@@ -291,7 +307,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
             if (ks + NS - 1 < nk && !(abl & 1)) stage(ks + NS - 1, fill);
             fill = fill + 1 == NS ? 0 : fill + 1;
             bf16x8_t af[CB], bfr[MB];
-            read_frags((abl & 2) ? 0 : slot, af, bfr);
+            read_frags((abl & 2) ? 0 : slot, af, bfr, KT && ks + 1 == nk);
             slot = slot + 1 == NS ? 0 : slot + 1;
             multiply(af, bfr);
         }
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_lds_fwd2(const C1LdsArg
     tile_epilogue<CB, MB, FLAT, WAVES>(acc, e);
 }
 
-template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD, int WT, int PF>
+template <int CB, int MB, int FLAT, int NS, int WAVES, int TRD, int WT, int PF, int KT>
 static int launch_c1v2(const C1LdsArgs& a, int tiles, hipStream_t stream) {
     constexpr int NT = 64 * WAVES, BPX = 16 * WAVES * CB, BM = 16 * MB;
     constexpr int XST = ((32 * BPX / 8 + NT - 1) / NT) * NT * 8, WST = ((BM * 4 + NT - 1) / NT) * NT * 8;
@@ -317,9 +333,9 @@ static int launch_c1v2(const C1LdsArgs& a, int tiles, hipStream_t stream) {
     b.xcd_remap = (blocks % 8 == 0) ? 1 : 0;
     static std::atomic<uint32_t> raised{0};
     if (lds > 64 * 1024 &&
-        !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv1x1_lds_fwd2<CB, MB, FLAT, NS, WAVES, TRD, WT, PF>)))
+        !raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&conv1x1_lds_fwd2<CB, MB, FLAT, NS, WAVES, TRD, WT, PF, KT>)))
         return -1;  // (the caller falls back to a kernel that needs no large LDS window)
-    COT_LAUNCH((conv1x1_lds_fwd2<CB, MB, FLAT, NS, WAVES, TRD, WT, PF>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
+    COT_LAUNCH((conv1x1_lds_fwd2<CB, MB, FLAT, NS, WAVES, TRD, WT, PF, KT>), dim3((unsigned)blocks), dim3(NT), lds, stream, b);
     return check_launch("conv1x1_lds_fwd2");
 }
 
@@ -333,10 +349,14 @@ int conv1x1_lds_gemm2(const C1LdsArgs& a0, hipStream_t stream) {
     const int64_t slab = std::max(a.xs1, a.xs2) * 2;  // bytes from one image to the next
     if ((HW <= 256 ? slab * (256 / HW + 1) : slab) >= ((int64_t)1 << 31) || (int64_t)M * a.K * 2 >= ((int64_t)1 << 31)) return -1;
     const bool wt = a.wpacked == 2;
+    const bool ktl = a.K % 32 != 0;  // K tail (KT instantiations): one slab, weights read in place
+    if (ktl && (a.K % 8 != 0 || a.x2 || a.wpacked == 1 || a.k1 != a.K)) return -1;
     const bool pf_flat = !((g_conv_lds2_tune >> 1) & 1), pf_big = (g_conv_lds2_tune >> 2) & 1;
 #define COT_C2W(CB_, MB_, FLAT_, NS_, TR_, PF_)                                                            \
-    return wt ? launch_c1v2<CB_, MB_, FLAT_, NS_, 8, TR_, 1, PF_>(a, tiles, stream)                        \
-              : launch_c1v2<CB_, MB_, FLAT_, NS_, 8, TR_, 0, PF_>(a, tiles, stream)
+    return ktl ? (wt ? launch_c1v2<CB_, MB_, FLAT_, NS_, 8, TR_, 1, PF_, 1>(a, tiles, stream)              \
+                     : launch_c1v2<CB_, MB_, FLAT_, NS_, 8, TR_, 0, PF_, 1>(a, tiles, stream))             \
+               : (wt ? launch_c1v2<CB_, MB_, FLAT_, NS_, 8, TR_, 1, PF_, 0>(a, tiles, stream)              \
+                     : launch_c1v2<CB_, MB_, FLAT_, NS_, 8, TR_, 0, PF_, 0>(a, tiles, stream))
 #define COT_C2(CB_, MB_, FLAT_, NS_)                                                                       \
     do {                                                                                                   \
         if (pf) {                                                                                          \

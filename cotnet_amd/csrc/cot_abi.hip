@@ -174,6 +174,7 @@ extern int g_conv_big_xswz;
 extern int g_gn9_pack;
 extern int g_radix_pack7;
 extern int g_conv_lds2_tune;
+extern int g_conv_k_tail;
 extern int g_conv_ablate;
 unsigned long long* g_debug_stamps = nullptr;  // DIAGNOSTIC: see cot_debug_stamps
 static int g_grouped_tuned = 1;  // tuning key 36: grouped 1x1 convolutions group by group on the tuned kernels
@@ -513,6 +514,10 @@ int cot_set_tuning(int key, int value) {
     }
     if (key == 36) {
         g_grouped_tuned = value ? 1 : 0;
+        return COT_OK;
+    }
+    if (key == 54) {
+        g_conv_k_tail = value ? 1 : 0;
         return COT_OK;
     }
     if (key >= 29 && key <= 34) {
@@ -1441,7 +1446,7 @@ int64_t cot_convg_workspace(int N, int Cin, int Cout, int groups, int H, int W, 
 // aligned; the general kernels of conv_gen.hip (64 x 64 tiles, 2-byte staging loads) keep the rest.  Tuning key 36 = 0: general
 // kernels everywhere (A/B).
 static inline bool grouped_on_tuned(int Kg, int Mg, int HW, int groups, int dtype) {
-    return g_grouped_tuned && dtype == COT_BF16 && groups > 1 && groups <= 8 && Kg % 32 == 0 && Mg % 8 == 0 &&
+    return g_grouped_tuned && dtype == COT_BF16 && groups > 1 && groups <= 8 && Kg % 8 == 0 && Mg % 8 == 0 &&  // (Kg % 32 != 0: the kernels' K tail)
            conv1x1_lds_covers(Kg, Kg, false, HW);
 }
 

@@ -182,6 +182,8 @@ const char* cot_last_kernel(void);
  *   key 51: aggregation_zeropad_mix: 1 = the one-lane-per-element kernels for every call (A/B; default 0 = LDS-tiled kernels where
  *           the geometry is stride 1, padding 1 / 2);  key 52: lanes a tiled workgroup aims for (default 256);  key 53: pixels per lane
  *           (0 = the planner's choice per direction, else 1 / 2 / 4)
+ *   key 54: 1x1 convolutions whose reduction depth is a multiple of 8 but not of 32 (CoXtLayer's groups of 24 / 48 / 216 / 432 channels)
+ *           on the LDS-pipelined kernels with a partial last K step (1 default), 0 = first-generation / general kernels
  *   key 39: LDS-staged 3x3 forward / data gradient: 1 (default) = the chunk-resident form (all nine taps' weights of a 32-channel
  *           chunk in LDS, one barrier per chunk) for groups of >= 24 channels, 2 = also for 16-channel groups, 0 = the per-step
  *           ring everywhere

@@ -205,3 +205,49 @@ def test_one_image_convolutions_of_the_se_branch(Ci, Co, NB, monkeypatch):
             assert _close(conv.weight.grad, gwr, 1e-2) and _close(conv.bias.grad, gbr, 1e-2)
     finally:
         _lib.check(_lib.lib().cot_set_tuning(22, 1), "cot_set_tuning")
+
+
+@pytest.mark.parametrize("N,Ci,Co,H", [(64, 48, 48, 56), (64, 96, 24, 56), (64, 96, 48, 28), (64, 96, 216, 14), (64, 192, 432, 7),
+                                       (80, 32, 72, 56), (80, 64, 144, 28), (3, 24, 56, 28), (5, 40, 72, 20), (7, 56, 120, 7), (2, 8, 16, 16)])
+def test_partial_last_k_step_on_the_lds_kernels(N, Ci, Co, H):
+    """reduction depths on the 8-channel grid but off the 32-row K step -- one group of CoXtLayer's grouped 1x1s at the benchmark batch
+    (models/cotnet.py:118-135: 48 -> 48, 96 -> 24 | 48, 96 -> 216, 192 -> 432 per group), CotLayer.embed[3]'s data gradient (72 / 144) and small
+    ragged ones: conv_lds2.hip's KT instantiations through the C ABI, operands inside NaN margins, against torch in fp32 on the rounded
+    operands and against the first-generation kernel (tuning key 54 = 0)"""
+    import ctypes
+
+    from cotnet_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(Ci + Co)
+    HW, dt = H * H, _lib.COT_BF16
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+
+    def margined(t, m):
+        flat = torch.full((t.numel() + 2 * m,), float("nan"), dtype=t.dtype, device=DEV)
+        v = flat[m:m + t.numel()].view(t.shape)
+        v.copy_(t)
+        return v
+    x, gy = margined(torch.randn(N, Ci, H, H, device=DEV).bfloat16(), 8), margined(torch.randn(N, Co, H, H, device=DEV).bfloat16(), 16)
+    w = margined((torch.randn(Co, Ci, device=DEV) * Ci ** -0.5).bfloat16(), 8)
+    ws = torch.empty(max(int(L.cot_conv1x1_workspace(N, Ci, Co, HW, 0)), 256), dtype=torch.uint8, device=DEV)
+    yr = torch.einsum("oc,nchw->nohw", w.float(), x.float())
+    gr = torch.einsum("oc,nohw->nchw", w.float(), gy.float())
+    init = torch.randn(N, Ci, H, H, device=DEV).bfloat16()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    try:
+        for k54 in (1, 0):
+            assert L.cot_set_tuning(54, k54) == 0
+            y, gx, ga = torch.full_like(gy, float("nan")), torch.full_like(x, float("nan")), init.clone()
+            assert L.cot_conv1x1_forward(P(x), None, Ci, P(w), None, P(y), N, Ci, Co, HW, dt, st) == 0, L.cot_last_error()
+            assert L.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, HW, dt, st) == 0, L.cot_last_error()
+            assert L.cot_conv1x1_backward_data(P(gy), P(w), P(ga), None, Ci, 1, P(ws), N, Ci, Co, HW, dt, st) == 0, L.cot_last_error()
+            torch.cuda.synchronize()
+            outs[k54] = (y, gx, ga)
+    finally:
+        L.cot_set_tuning(54, 1)
+    assert L.cot_conv1x1_lds_covers(Ci, Ci, 0, HW) == 1 and L.cot_conv1x1_lds_covers(Co, Co, 0, HW) == 1
+    y, gx, ga = outs[1]
+    assert _close(y, yr, 2e-2) and _close(gx, gr, 2e-2) and _close(ga, gr + init.float(), 3e-2)
+    for a, b, ref in zip(outs[1], outs[0], (yr, gr, gr)):
+        assert (a.float() - b.float()).abs().max() <= 2e-2 * ref.abs().max()

@@ -61,6 +61,24 @@ def _randn(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, device=DEV, generator=g) * scale).bfloat16()
 
 
+def _gamma_beta(C, seed):
+    """affine parameters from a generator of their own: the cases must not depend on which tests drew from the global generator before them
+    (round 6: a subset run in another order put one bncm case's dbeta 0.7 % off -- ReLU decisions of near-zero pre-activations, see below)"""
+    g = torch.Generator(device=DEV).manual_seed(7919 + seed)
+    return (torch.rand(C, device=DEV, generator=g) + 0.5).float(), (torch.randn(C, device=DEV, generator=g) * 0.2).float()
+
+
+def _param_grads_under_the_kernels_mask(x, dsum, y, eps=1e-5):
+    """dgamma / dbeta of relu(bn(x)) in fp32 with the ReLU decisions the KERNEL took (the sign of its stored output): the fp32 reference
+    decides a pre-activation below the inputs' bf16 resolution differently now and then, and each such element moves a channel's sum by
+    |dy| -- per-element that is masked out of the dx comparison, in a sum it cannot be"""
+    xf = x.float()
+    mu = xf.mean((0, 2, 3), keepdim=True)
+    xhat = (xf - mu) * torch.rsqrt(xf.var((0, 2, 3), unbiased=False, keepdim=True) + eps)
+    dz = dsum * (y.float() > 0)
+    return (dz * xhat).sum((0, 2, 3)), dz.sum((0, 2, 3))
+
+
 class _Pinned:
     """issue(fn) runs `fn()` (one C-ABI call) twice: dry (launch log compared with the table's entry) and for real"""
 
@@ -227,8 +245,7 @@ def _bn(key, shp, what):
     seed = C + HW
     x = _randn(N, C, HW, 1, seed=seed) * 1.5 + 0.25
     x = x.bfloat16()
-    gamma = (torch.rand(C, device=DEV) + 0.5).float()
-    beta = (torch.randn(C, device=DEV) * 0.2).float()
+    gamma, beta = _gamma_beta(C, seed)
     mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     nbt = torch.zeros((), dtype=torch.int64, device=DEV)
@@ -266,8 +283,9 @@ def _bn(key, shp, what):
     tol = 1e-2 * (xr.grad.abs() + xr.grad.abs().mean())
     assert (d[clear] <= tol[clear]).all(), d[clear].max().item()
     assert (~clear).float().mean().item() < 0.02
-    _rel(dg, gr.grad, 5e-3 if N * HW > 1000 else 2e-2)
-    _rel(db, br.grad, 5e-3 if N * HW > 1000 else 2e-2)
+    dg_r, db_r = _param_grads_under_the_kernels_mask(x, dy.float(), y)
+    _rel(dg, dg_r, 5e-3 if N * HW > 1000 else 2e-2)
+    _rel(db, db_r, 5e-3 if N * HW > 1000 else 2e-2)
 
 
 def _gn(key, shp, what):
@@ -275,8 +293,7 @@ def _gn(key, shp, what):
     L, pin = _lib.lib(), _Pinned(key)
     seed = C + HW
     x = _randn(N, C, HW, 1, seed=seed)
-    gamma = (torch.rand(C, device=DEV) + 0.5).bfloat16()
-    beta = (torch.randn(C, device=DEV) * 0.2).bfloat16()
+    gamma, beta = (t.bfloat16() for t in _gamma_beta(C, C + HW))
     mean, rstd = torch.empty(N * G, device=DEV), torch.empty(N * G, device=DEV)
     y = torch.full((N, C, HW, 1), float("nan"), device=DEV).bfloat16()
     st = _st()
@@ -362,8 +379,7 @@ def _bn_lay(key, shp, what):
     L, pin = _lib.lib(), _Pinned(key)
     seed = C + HW
     x = (_randn(N, C, HW, 1, seed=seed).float() * 1.5 + 0.25).bfloat16()
-    gamma = (torch.rand(C, device=DEV) + 0.5).float()
-    beta = (torch.randn(C, device=DEV) * 0.2).float()
+    gamma, beta = _gamma_beta(C, seed)
     mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     nbt = torch.zeros((), dtype=torch.int64, device=DEV)
@@ -402,8 +418,9 @@ def _bn_lay(key, shp, what):
     tol = 1e-2 * (xr.grad.abs() + xr.grad.abs().mean())
     assert (d[clear] <= tol[clear]).all(), d[clear].max().item()
     assert (~clear).float().mean().item() < 0.02
-    _rel(dg, gr.grad, 5e-3)
-    _rel(db, br.grad, 5e-3)
+    dg_r, db_r = _param_grads_under_the_kernels_mask(x, dsum, y)
+    _rel(dg, dg_r, 5e-3)
+    _rel(db, db_r, 5e-3)
 
 
 def _run_entry(key):

@@ -223,7 +223,7 @@ def test_no_benchmark_layer_falls_off_the_tuned_kernels():
             if key.startswith("cotnet50") and key.endswith(" bwd") and "x7x7x" not in key:
                 assert all("k3_dot2" in n for n in names), (key, launches)
     # CoTNeXt's grouped 1x1 convolutions (groups = 2): group by group on the tuned kernels wherever the depth of a group's
-    # reduction is on the 32-channel grid (forward: Ci / 2, data gradient: Co / 2) resp. its slabs are 16-byte aligned (weight
+    # reduction is on the 8-channel grid (forward: Ci / 2, data gradient: Co / 2) resp. its slabs are 16-byte aligned (weight
     # gradient) -- one launch (+ reduce) per group --, else the general kernels
     grouped = [k for k in table if k.startswith("cotnext") and " conv1x1 " in k and k.split()[2].split("x")[3] == "2"]
     assert grouped
@@ -233,7 +233,10 @@ def test_no_benchmark_layer_falls_off_the_tuned_kernels():
         names = [ln.split("[")[0] for ln in table[k]]
         depth = (Ci if k.endswith(" fwd") else Co) // g
         if k.endswith(" fwd") or k.endswith(" dgrad"):
-            want_tuned = depth % 32 == 0 and (Co // g if k.endswith(" fwd") else Ci // g) % 8 == 0
+            # (round 6: a depth off the 32-row K step but on the 8-channel grid -- 24 / 48 / 216 / 432 per group -- takes the kernels' KT form)
+            want_tuned = depth % 8 == 0 and (Co // g if k.endswith(" fwd") else Ci // g) % 8 == 0
+            if want_tuned and depth % 32:
+                assert all("KT=1" in ln for ln in table[k]), (k, table[k])
             assert (names == ["conv1x1_lds_fwd2"] * g) if want_tuned else all("convg_" in n for n in names), (k, table[k])
             n_tuned += want_tuned
         elif k.endswith(" wgrad"):

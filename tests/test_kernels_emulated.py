@@ -1086,6 +1086,62 @@ def test_input_normalize_matches_the_reference_loader_arithmetic(shape):
     assert _EMUL.cot_input_normalize(P(x), P(y), P(mean), P(std), planes, C, HW, 1, None) != 0  # fp64 output: unsupported
 
 
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("N,Ci,Co,H,W", [
+    (2, 48, 48, 28, 28),    # CoXtLayer(96).conv1x1: 48 channels per group -- BIG tiles, K = 32 + 16 both ways
+    (2, 24, 56, 28, 28),    # K = 24: the only K step is the partial one; data gradient K = 56 = 32 + 24
+    (3, 216, 96, 14, 14),   # CoXtLayer(384).embed[3]'s data gradient depth: 6 full steps + 24 (FLAT, six-stage ring, prefetch)
+    (2, 96, 216, 14, 14),
+    (5, 48, 24, 7, 7),      # FLAT 7 x 7 (2-byte gathers), five images per workgroup
+    (4, 432, 192, 7, 7),    # CoXtLayer(768).embed[3]'s data gradient depth: 13 steps + 16
+    (1, 40, 72, 20, 20),    # BIG with a partial last pixel tile, K = 40 / 72 (CotLayer(64).embed[3]'s data gradient: 72)
+    (2, 8, 16, 16, 16), (2, 16, 8, 4, 4), (3, 56, 120, 5, 9), (6, 24, 48, 3, 3),
+])
+def test_conv1x1_lds_kernels_partial_last_k_step(N, Ci, Co, H, W, dma):
+    """conv_lds2.hip's KT instantiations (reduction depth a multiple of 8, not of 32): forward and data gradient (with and without
+    accumulate) inside NaN margins -- the last step's clamped copies must not pull anything from outside the operands into the sums --,
+    against torch on the same rounded operands and against the first-generation kernel (tuning key 54 = 0); the launch log names the kernel"""
+    torch.manual_seed(13)
+    HW, dt = H * W, _lib.dtype_code(torch.bfloat16)
+
+    def margined(t, m):
+        flat = torch.full((t.numel() + 2 * m,), float("nan"), dtype=t.dtype)
+        v = flat[m:m + t.numel()].view(t.shape)
+        v.copy_(t)
+        return v
+    x, gy = margined(torch.randn(N, Ci, H, W).bfloat16(), 8), margined(torch.randn(N, Co, H, W).bfloat16(), 16)
+    w = margined((torch.randn(Co, Ci) * Ci ** -0.5).bfloat16(), 8)
+    ws = torch.empty(max(_EMUL.cot_conv1x1_workspace(N, Ci, Co, HW, 0), 256), dtype=torch.uint8)
+    yr = torch.einsum("oc,nchw->nohw", w.float(), x.float())
+    gr = torch.einsum("oc,nohw->nchw", w.float(), gy.float())
+    init = torch.randn(N, Ci, H, W).bfloat16()
+    outs = {}
+    _EMUL.emul_set_dma_mode(dma)
+    try:
+        for k54 in (1, 0):
+            assert _EMUL.cot_set_tuning(54, k54) == 0
+            y, gx, ga = torch.full_like(gy, float("nan")), torch.full_like(x, float("nan")), init.clone()
+            assert _EMUL.cot_conv1x1_forward(P(x), None, Ci, P(w), None, P(y), N, Ci, Co, HW, dt, None) == 0, _EMUL.cot_last_error()
+            assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, HW, dt, None) == 0, _EMUL.cot_last_error()
+            assert _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(ga), None, Ci, 1, P(ws), N, Ci, Co, HW, dt, None) == 0, _EMUL.cot_last_error()
+            outs[k54] = (y.clone(), gx.clone(), ga.clone())
+        assert _EMUL.cot_set_tuning(54, 1) == 0 and _EMUL.cot_set_tuning(26, 1) == 0
+        _EMUL.cot_conv1x1_forward(P(x), None, Ci, P(w), None, P(y), N, Ci, Co, HW, dt, None)
+        _EMUL.cot_conv1x1_backward_data(P(gy), P(w), P(gx), None, Ci, 0, P(ws), N, Ci, Co, HW, dt, None)
+        buf = ctypes.create_string_buffer(1 << 14)
+        _EMUL.cot_launch_log(buf, 1 << 14)
+        log = buf.value.decode()
+    finally:
+        _EMUL.cot_set_tuning(26, 0), _EMUL.cot_set_tuning(54, 1), _EMUL.emul_set_dma_mode(0)
+    assert log.count("conv1x1_lds_fwd2") == 2 and log.count("KT = 1") == (Ci % 32 != 0) + (Co % 32 != 0), log
+    y, gx, ga = outs[1]
+    assert torch.allclose(y.float(), yr, atol=2e-2, rtol=2e-2), (y.float() - yr).abs().max()
+    assert torch.allclose(gx.float(), gr, atol=3e-2, rtol=2e-2), (gx.float() - gr).abs().max()
+    assert torch.allclose(ga.float(), gr + init.float(), atol=5e-2, rtol=2e-2)
+    for a, b, ref in zip(outs[1], outs[0], (yr, gr, gr)):  # the two kernels: same products, another order
+        assert (a.float() - b.float()).abs().max() <= 2e-2 * ref.abs().max()
+
+
 def test_conv1x1_lds_kernel_is_the_one_that_runs():
     torch.manual_seed(8)
     x = torch.randn(1, 64, 16, 16).bfloat16()
@@ -1093,7 +1149,10 @@ def test_conv1x1_lds_kernel_is_the_one_that_runs():
     y = torch.zeros(1, 32, 16, 16).bfloat16()
     dt = _lib.dtype_code(torch.bfloat16)
     assert _EMUL.cot_set_tuning(15, 1) == 0
-    assert _EMUL.cot_conv1x1_lds_covers(64, 64, 0, 256) == 1 and _EMUL.cot_conv1x1_lds_covers(40, 40, 0, 256) == 0
+    assert _EMUL.cot_conv1x1_lds_covers(64, 64, 0, 256) == 1 and _EMUL.cot_conv1x1_lds_covers(36, 36, 0, 256) == 0
+    # (a depth on the 8-channel grid but off the 32-row K step: the KT instantiations, one slab only; tuning key 54 = 0: as before round 6)
+    assert _EMUL.cot_conv1x1_lds_covers(40, 40, 0, 256) == 1 and _EMUL.cot_conv1x1_lds_covers(72, 40, 1, 256) == 0
+    assert _EMUL.cot_set_tuning(54, 0) == 0 and _EMUL.cot_conv1x1_lds_covers(40, 40, 0, 256) == 0 and _EMUL.cot_set_tuning(54, 1) == 0
     assert _EMUL.cot_conv1x1_forward(P(x), None, 64, P(w), None, P(y), 1, 64, 32, 256, dt, None) == 0
     ref = torch.einsum("oc,nchw->nohw", w.float(), x.float())
     assert (y.float() - ref).abs().max() < 0.01 * ref.abs().max()  # (one bf16 rounding of outputs up to ~30)
@@ -2643,7 +2702,7 @@ def _tol(dtype):
     (1, 96, 96, 2, 9, 9, False),     # conv1x1[0]: 48 -> 48 per group
     (3, 20, 136, 1, 3, 3, False),    # 20 reduction channels (two steps, the second mostly zeros), three output tiles
     (1, 6, 2, 2, 1, 5, True),        # 3 -> 1 per group, one-row image
-    # bf16 with a group depth on the 32-channel grid: group by group on the TUNED kernels with the full tensors' image strides
+    # bf16 with a group depth on the 8-channel grid: group by group on the TUNED kernels with the full tensors' image strides
     # (round 4; fp32 stays on the general kernels) -- CoXtLayer at dim 384: embed[0] 384 -> 96, embed[3] 96 -> 216 (+ bias),
     # conv1x1[0] 192 -> 192 per group; small-plane (several images per workgroup) and 128-pixel-tile forms, ragged last tile
     (3, 768, 192, 2, 7, 7, False),
@@ -2672,7 +2731,7 @@ def test_general_grouped_conv1x1_kernels(N, Ci, Co, G, H, W, bias, dtype):
     rc = _EMUL.cot_conv1x1g_forward(P(x), P(w), P(b) if bias else None, P(y), N, Ci, Co, G, HW, dt, None)
     assert rc == 0, _EMUL.cot_last_error()
     assert torch.allclose(y.double(), yr.detach(), atol=atol * 4, rtol=rtol), (y.double() - yr).abs().max()
-    tuned = dtype == torch.bfloat16 and G > 1 and (Ci // G) % 32 == 0 and (Co // G) % 8 == 0
+    tuned = dtype == torch.bfloat16 and G > 1 and (Ci // G) % 8 == 0 and (Co // G) % 8 == 0  # (depth % 32 != 0: the kernels' KT form, round 6)
     buf = ctypes.create_string_buffer(1 << 14)
     _EMUL.cot_launch_log(buf, len(buf))
     assert _EMUL.cot_set_tuning(26, 1) == 0  # dry run: which kernels would this call launch?
