@@ -274,7 +274,8 @@ def _sizes(L, N, C, H, W, A, G, grouped=False):
     if v is None:
         HW = H * W
         if grouped:  # CoXtLayer: the three 1x1 convolutions of the layer are grouped (groups = 2): general kernels' workspace
-            ws = max(int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_convg_workspace(N, 2 * C, C // 2, 2, H, W, 1)),
+            ws = max(int(L.cot_conv3x3g_workspace(N, C, C, G, H, W)), int(L.cot_conv3x3g_workspace(N, C, C, _conv3x3_ws_groups(C, G), H, W)),
+                     int(L.cot_convg_workspace(N, 2 * C, C // 2, 2, H, W, 1)),
                      int(L.cot_convg_workspace(N, C // 2, 9 * C // 8, 2, H, W, 1)), int(L.cot_convg_workspace(N, C, C, 2, H, W, 1)),
                      int(L.cot_conv1x1_workspace(1, C, A, N, 1)), int(L.cot_conv1x1_workspace(1, A, 2 * C, N, 1)))
         else:
@@ -391,7 +392,42 @@ def after_optimizer_step(device):
         _PACK_EVENT[device.index] = ev
 
 
+# ---- groups of 12 channels (CoXtLayer(96).key_embed: 96 channels in 8 groups, models/cotnet.py:113-117): the LDS-pipelined 3x3 kernels take
+# groups from 16 channels on, the general kernel (conv_gen.hip) runs this layer at 169 us per launch at 56 x 56, B = 64.  Two neighbouring
+# groups ARE one group of 24 channels with a block-diagonal weight (the off-diagonal blocks zero), which the LDS kernels take: a copy of the
+# 12 x 12 x 9 blocks onto the diagonal of a persistent zero-filled [C, 24, 3, 3] buffer per step (one small launch) instead.  The weight
+# gradient keeps the module's grouping (its kernel merges neighbours itself).  COT_MERGE12=0 opts out.
+MERGE12 = os.environ.get("COT_MERGE12", "1") != "0"
+_MERGED = weakref.WeakKeyDictionary()  # nn.Conv2d -> [key, merged weight]
+
+
+def _merge12(C, G):
+    return MERGE12 and G % 2 == 0 and C == 12 * G
+
+
+def _merged_weight(conv, C, G, refresh):
+    w = conv.weight
+    ent = _MERGED.get(conv)
+    if ent is None or ent[1].device != w.device or ent[1].dtype != w.dtype:
+        ent = _MERGED[conv] = [None, torch.zeros((C, 24, 3, 3), dtype=w.dtype, device=w.device)]
+    key = (w.data_ptr(), w._version, PARAM_EPOCH[0])
+    if refresh or ent[0] != key:  # (forward: always -- a replayed graph moves the weights behind every counter; backward: the forward's copy)
+        G2 = G // 2
+        ent[1].view(G2, 2, 12, 2, 12, 9).diagonal(dim1=1, dim2=3).copy_(w.detach().view(G2, 2, 12, 12, 9).permute(0, 2, 3, 4, 1))
+        ent[0] = key
+    return ent[1]
+
+
+def _conv3x3_ws_groups(C, G):
+    """the group count the 3x3 forward / data gradient are launched with (workspace sizing)"""
+    return G // 2 if _merge12(C, G) else G
+
+
 def _conv3x3_fwd(L, conv, x, y, masks, ws, N, C, G, H, W):
+    if _merge12(C, G):
+        wm = _merged_weight(conv, C, G, True)
+        _ck(L.cot_conv3x3g_forward(_p(x), _p(wm), _p(y), _p(masks), _p(ws), N, C, C, G // 2, H, W, BF16, _stream()), "cot_conv3x3g_forward")
+        return
     pk = _pack_for(L, conv, 0, N, C, G, H, W)
     if pk is not None:
         _ck(L.cot_conv3x3g_forward_packed(_p(x), _p(pk), _p(y), N, C, C, G, H, W, BF16, _stream()), "cot_conv3x3g_forward_packed")
@@ -400,6 +436,11 @@ def _conv3x3_fwd(L, conv, x, y, masks, ws, N, C, G, H, W):
 
 
 def _conv3x3_dgrad(L, conv, gy, gx, accumulate, masks, ws, N, C, G, H, W):
+    if _merge12(C, G):
+        wm = _merged_weight(conv, C, G, False)
+        _ck(L.cot_conv3x3g_backward_data(_p(gy), _p(wm), _p(gx), accumulate, _p(masks), _p(ws), N, C, C, G // 2, H, W, BF16, _stream()),
+            "cot_conv3x3g_backward_data")
+        return
     pk = _pack_for(L, conv, 1, N, C, G, H, W)
     if pk is not None:
         _ck(L.cot_conv3x3g_backward_data_packed(_p(gy), _p(pk), _p(gx), accumulate, N, C, C, G, H, W, BF16, _stream()),

@@ -218,15 +218,25 @@ def _conv3x3(key, shp, what):
     masks = torch.empty(int(L.cot_conv3x3g_masks_bytes(H, W)), dtype=torch.uint8, device=DEV)
     st = _st()
     assert L.cot_conv3x3g_masks(P(masks), H, W, st) == 0
-    ws = torch.empty(max(int(L.cot_conv3x3g_workspace(N, Ci, Co, G, H, W)), 256), dtype=torch.uint8, device=DEV)
+    # groups of 12 channels: what the nodes launch is pairs of groups as ONE group of 24 with a block-diagonal weight (cot_layer_fused.
+    # _merged_weight, made by the product's own helper here) -- compared with torch on the module's grouping
+    from cotnet_amd import cot_layer_fused as clf
+    Gl, wl = G, w
+    if Ci == Co and clf._merge12(Ci, G) and what in ("fwd", "dgrad"):
+        conv = torch.nn.Conv2d(Ci, Co, 3, 1, 1, groups=G, bias=False).to(DEV).bfloat16()
+        with torch.no_grad():
+            conv.weight.copy_(w)
+        Gl, wl = G // 2, clf._merged_weight(conv, Ci, G, True)
+    ws = torch.empty(max(int(L.cot_conv3x3g_workspace(N, Ci, Co, G, H, W)), int(L.cot_conv3x3g_workspace(N, Ci, Co, Gl, H, W)), 256),
+                     dtype=torch.uint8, device=DEV)
     ws.fill_(0xFF)
     if what == "fwd":
         y = torch.full((N, Co, H, W), float("nan"), device=DEV).bfloat16()
-        pin.issue(lambda: L.cot_conv3x3g_forward(P(x), P(w), P(y), P(masks), P(ws), N, Ci, Co, G, H, W, BF, st))
+        pin.issue(lambda: L.cot_conv3x3g_forward(P(x), P(wl), P(y), P(masks), P(ws), N, Ci, Co, Gl, H, W, BF, st))
         _close(y, F.conv2d(x.float(), w.float(), None, 1, 1, 1, G))
     elif what == "dgrad":
         gx = torch.full((N, Ci, H, W), float("nan"), device=DEV).bfloat16()
-        pin.issue(lambda: L.cot_conv3x3g_backward_data(P(gy), P(w), P(gx), 0, P(masks), P(ws), N, Ci, Co, G, H, W, BF, st))
+        pin.issue(lambda: L.cot_conv3x3g_backward_data(P(gy), P(wl), P(gx), 0, P(masks), P(ws), N, Ci, Co, Gl, H, W, BF, st))
         _close(gx, F.conv_transpose2d(gy.float(), w.float(), None, 1, 1, 0, G))
     else:
         gw = torch.full((Co, Ci // G, 3, 3), float("nan"), device=DEV).bfloat16()

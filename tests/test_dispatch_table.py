@@ -132,8 +132,12 @@ def build_table():
                     if s != 1 or bias:
                         table[tag] = ["module (MIOpen): strided / biased 3x3 convolutions are outside the library"]
                         continue
-                    rec(tag + " fwd", L.cot_conv3x3g_forward(PTR, PTR, PTR, PTR, PTR, N, Ci, Co, g, H, W, BF, None))
-                    rec(tag + " dgrad", L.cot_conv3x3g_backward_data(PTR, PTR, PTR, 0, PTR, PTR, N, Ci, Co, g, H, W, BF, None))
+                    # (groups of 12 channels -- CoXtLayer(96).key_embed: the nodes launch pairs of groups as one group of 24 with a
+                    # block-diagonal weight, cot_layer_fused._conv3x3_fwd / _dgrad)
+                    from cotnet_amd import cot_layer_fused as clf
+                    gl = clf._conv3x3_ws_groups(Ci, g) if Ci == Co else g
+                    rec(tag + " fwd", L.cot_conv3x3g_forward(PTR, PTR, PTR, PTR, PTR, N, Ci, Co, gl, H, W, BF, None))
+                    rec(tag + " dgrad", L.cot_conv3x3g_backward_data(PTR, PTR, PTR, 0, PTR, PTR, N, Ci, Co, gl, H, W, BF, None))
                     rec(tag + " wgrad", L.cot_conv3x3g_backward_weight(PTR, PTR, PTR, PTR, PTR, N, Ci, Co, g, H, W, BF, None))
                     # (the single-node Bottleneck allocates the CoT layer's input with margins: cot_layer_fused._new_guarded)
                     rec(tag + " wgrad(guarded)", L.cot_conv3x3g_backward_weight_guarded(PTR, PTR, PTR, PTR, PTR, N, Ci, Co, g, H, W, BF,
