@@ -16,9 +16,11 @@ def main():
     ap.add_argument("--count", type=int, default=100)
     ap.add_argument("--first", type=int, default=7000)
     ap.add_argument("--seconds", type=float, default=0, help="stop starting new seeds after this many seconds (0: no limit)")
+    ap.add_argument("--scale", type=int, default=1, help="plane sizes of the convolution cases times this (tests.test_fuzz_emulated.SCALE)")
     a = ap.parse_args()
     t0, total, bad, kinds = time.time(), 0, [], {}
     with device_fuzz() as tfe:
+        tfe.SCALE = a.scale
         for seed in range(a.first, a.first + a.seeds):
             if a.seconds and time.time() - t0 > a.seconds:
                 break
@@ -32,6 +34,7 @@ def main():
             for f in failures:
                 bad.append((seed, f))
                 print("FAIL", seed, f, flush=True)
+        tfe.SCALE = 1
     print(f"{total} cases over {seed - a.first + 1} seeds in {time.time() - t0:.0f} s: {len(bad)} failures")
     print("cases per kind:", dict(sorted(kinds.items())))
     return 1 if bad else 0

@@ -17,6 +17,7 @@ BF = 2  # COT_BF16
 # tests/test_fuzz_gpu.py runs these cases on the device, where the compiler contracts a * b + c into one rounding: results that are the
 # host model's bits here (same operations in the same order as the C oracle / as torch) are there within a few ulps of them
 ON_DEVICE = False
+SCALE = 1  # (scripts/fuzz_gpu.py --scale: larger planes on the device -- the 128-pixel-tile forms of the convolution kernels, H * W > 256)
 
 
 def P(t):
@@ -30,7 +31,7 @@ def close(a, b, tol=2e-2):
 
 def case_conv1x1(rng):
     N, Ci, Co = rng.randint(1, 3), 8 * rng.randint(1, 12), 8 * rng.randint(1, 12)
-    H, W = rng.randint(1, 13), rng.randint(1, 13)
+    H, W = rng.randint(1, 13 * SCALE), rng.randint(1, 13 * SCALE)
     split = rng.random() < 0.3 and Ci > 8
     bias = rng.random() < 0.5
     c1 = 8 * rng.randint(1, Ci // 8 - 1) if split else Ci
@@ -68,7 +69,7 @@ def case_conv1x1(rng):
 
 def case_conv3x3(rng):
     G, Kc = rng.choice([1, 2, 4, 8]), 8 * rng.randint(1, 4)
-    C, N, H, W = G * Kc, rng.randint(1, 2), rng.randint(1, 12), rng.randint(1, 12)
+    C, N, H, W = G * Kc, rng.randint(1, 2), rng.randint(1, 12 * SCALE), rng.randint(1, 12 * SCALE)
     E.cot_set_tuning(11, rng.choice([2048, -2]))
     x = torch.randn(N, C, H, W).bfloat16()
     w = (torch.randn(C, Kc, 3, 3) / (9 * Kc) ** 0.5).bfloat16()
@@ -195,7 +196,7 @@ def case_conv3x3_lds(rng):
     while G * Kc > 512:
         G //= 2
     C, N = G * Kc, rng.randint(1, 3)
-    H, W = rng.randint(3, 30), rng.randint(3, 30)
+    H, W = rng.randint(3, 30 * min(SCALE, 2)), rng.randint(3, 30 * min(SCALE, 2))
     keys = {39: rng.choice([0, 1, 1, 2]), 42: rng.choice([0, 1, 2]), 44: rng.choice([0, 1, 2]), 45: rng.choice([0, 1, 2])}
     dma = rng.choice([0, 1])
     x = _nan_margined(torch.randn(N, C, H, W).bfloat16(), W + 1 + rng.randint(0, 9))
@@ -502,7 +503,7 @@ def case_conv_general(rng):
     dt = tke._lib.dtype_code(dtype)
     atol, rtol = tke._tol(dtype)
     G = rng.choice([1, 2, 3, 4, 8])
-    N, H, W = rng.randint(1, 3), rng.randint(1, 11), rng.randint(1, 11)
+    N, H, W = rng.randint(1, 3), rng.randint(1, 11 * SCALE), rng.randint(1, 11 * SCALE)
     step = 1 if dtype == torch.float32 else 4
     if rng.random() < 0.5:   # grouped 1x1
         Ci, Co = G * step * rng.randint(1, 12), G * step * rng.randint(1, 12)
